@@ -1,0 +1,186 @@
+"""ctypes wrapper of oracle/libsvo_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg;
+never from the product package rpg_svo_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsvo_oracle.so")
+MAX_LEVELS = 8
+HALFSAMPLE_SCALAR, HALFSAMPLE_SSE2, HALFSAMPLE_AUTO = 0, 1, 2
+
+
+class Pyramid(C.Structure):
+    _fields_ = [("n_levels", C.c_int), ("w", C.c_int * MAX_LEVELS), ("h", C.c_int * MAX_LEVELS),
+                ("data", C.c_void_p * MAX_LEVELS)]
+
+
+class Pinhole(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("width", C.c_int), ("height", C.c_int)]
+
+
+class SiaOptions(C.Structure):
+    _fields_ = [("max_level", C.c_int), ("min_level", C.c_int), ("n_iter", C.c_int), ("eps", C.c_double)]
+
+
+class SiaResult(C.Structure):
+    _fields_ = [("n_tracked", C.c_int), ("stop", C.c_int), ("iters", C.c_int * MAX_LEVELS),
+                ("chi2", C.c_double), ("H", C.c_double * 36), ("T_cur_from_ref", C.c_double * 12)]
+
+
+_lib = None
+
+
+def build(force: bool = False) -> None:
+    args = ["make", "-C", HERE] + (["-B"] if force else [])
+    subprocess.run(args, check=True, stdout=subprocess.DEVNULL)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.orc_sparse_img_align_run.restype = C.c_int
+        _lib.orc_sparse_img_align_batch.restype = C.c_int
+        _lib.orc_ldlt_solve_n.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# ---- SE(3) -----------------------------------------------------------------
+def se3_exp(xi):
+    out = np.zeros(12)
+    lib().orc_se3_exp(_p(_f64(xi)), _p(out))
+    return out
+
+
+def se3_log(T):
+    out = np.zeros(6)
+    lib().orc_se3_log(_p(_f64(T)), _p(out))
+    return out
+
+
+def se3_mul(A, B):
+    out = np.zeros(12)
+    lib().orc_se3_mul(_p(_f64(A)), _p(_f64(B)), _p(out))
+    return out
+
+
+def se3_inv(A):
+    out = np.zeros(12)
+    lib().orc_se3_inv(_p(_f64(A)), _p(out))
+    return out
+
+
+def ldlt_solve(H, b):
+    H = _f64(H)
+    b = _f64(b)
+    x = np.zeros(b.shape[0])
+    lib().orc_ldlt_solve_n(C.c_int(b.shape[0]), _p(H), _p(b), _p(x))
+    return x
+
+
+# ---- pyramid ---------------------------------------------------------------
+def half_sample(img: np.ndarray, mode: int = HALFSAMPLE_AUTO) -> np.ndarray:
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.zeros((h // 2, w // 2), dtype=np.uint8)
+    lib().orc_half_sample(_p(img), C.c_int(w), C.c_int(h), C.c_int(w), _p(out), C.c_int(w // 2), C.c_int(mode))
+    return out
+
+
+def create_img_pyramid(img: np.ndarray, n_levels: int, mode: int = HALFSAMPLE_AUTO) -> list[np.ndarray]:
+    """frame_utils::createImgPyramid (svo/src/frame.cpp:156-165)."""
+    pyr = [np.ascontiguousarray(img, dtype=np.uint8)]
+    for _ in range(1, n_levels):
+        pyr.append(half_sample(pyr[-1], mode))
+    return pyr
+
+
+def make_pyramid_struct(levels: list[np.ndarray]) -> Pyramid:
+    p = Pyramid()
+    p.n_levels = len(levels)
+    for i, l in enumerate(levels):
+        assert l.dtype == np.uint8 and l.flags["C_CONTIGUOUS"]
+        p.w[i] = l.shape[1]
+        p.h[i] = l.shape[0]
+        p.data[i] = l.ctypes.data
+    p._keep = levels
+    return p
+
+
+def make_cam(cam) -> Pinhole:
+    return Pinhole(cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height)
+
+
+# ---- SparseImgAlign --------------------------------------------------------
+def sparse_img_align_run(ref_pyr, cur_pyr, cam, T_ref_w, T_cur_w, px, f, has_point, pos,
+                         max_level, min_level, n_iter=30, eps=1e-6):
+    """One SparseImgAlign::run.  Returns (T_cur_w_new [12], result dict)."""
+    rp = make_pyramid_struct(ref_pyr)
+    cp = make_pyramid_struct(cur_pyr)
+    pc = make_cam(cam)
+    px, f, pos = _f64(px), _f64(f), _f64(pos)
+    n = px.shape[0]
+    hp = np.ascontiguousarray(has_point, dtype=np.uint8)
+    Tr = _f64(T_ref_w).copy()
+    Tc = _f64(T_cur_w).copy()
+    opt = SiaOptions(max_level, min_level, n_iter, eps)
+    res = SiaResult()
+    vis = np.zeros(max(n, 1), dtype=np.uint8)
+    lib().orc_sparse_img_align_run(C.byref(rp), C.byref(cp), C.byref(pc), _p(Tr), _p(Tc), C.c_int(n),
+                                   _p(px), _p(f), _p(hp), _p(pos), C.byref(opt), C.byref(res), _p(vis))
+    return Tc, _res_dict(res, vis[:n])
+
+
+def _res_dict(res: SiaResult, vis=None) -> dict:
+    d = dict(n_tracked=res.n_tracked, stop=res.stop, iters=np.array(res.iters[:]), chi2=res.chi2,
+             H=np.array(res.H[:]).reshape(6, 6), T_cur_from_ref=np.array(res.T_cur_from_ref[:]))
+    if vis is not None:
+        d["visible"] = vis.copy()
+    return d
+
+
+def sparse_img_align_batch(pyrs, ref_slot, cur_slot, cam, T_ref_w, T_cur_w, n, px, f, has_point, pos,
+                           max_level, min_level, n_iter=30, eps=1e-6, n_threads=1):
+    """pyrs: list of pyramids (list of level arrays).  Arrays are [B, n_stride, .].
+    Returns (T_cur_w_new [B,12], list of result dicts)."""
+    B = len(ref_slot)
+    arr = (Pyramid * len(pyrs))()
+    keep = []
+    for i, lv in enumerate(pyrs):
+        s = make_pyramid_struct(lv)
+        keep.append(s)
+        arr[i] = s
+    pc = make_cam(cam)
+    px, f, pos = _f64(px), _f64(f), _f64(pos)
+    n_stride = px.shape[1]
+    hp = np.ascontiguousarray(has_point, dtype=np.uint8)
+    Tr = _f64(T_ref_w).copy()
+    Tc = _f64(T_cur_w).copy()
+    rs = np.ascontiguousarray(ref_slot, dtype=np.int32)
+    cs = np.ascontiguousarray(cur_slot, dtype=np.int32)
+    nn = np.ascontiguousarray(n, dtype=np.int32)
+    opt = SiaOptions(max_level, min_level, n_iter, eps)
+    res = (SiaResult * B)()
+    lib().orc_sparse_img_align_batch(C.c_int(B), arr, _p(rs), _p(cs), C.byref(pc), _p(Tr), _p(Tc), _p(nn),
+                                     C.c_int(n_stride), _p(px), _p(f), _p(hp), _p(pos), C.byref(opt), res,
+                                     C.c_int(n_threads))
+    return Tc, [_res_dict(r) for r in res]

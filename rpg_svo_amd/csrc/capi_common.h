@@ -1,0 +1,37 @@
+// capi_common.h -- host-side helpers shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "svo_hip.h"
+
+namespace svo_capi {
+
+// last raw HIP error seen by any entry point (per host thread: the library may
+// be driven from the tracking and the mapping thread concurrently)
+extern thread_local int g_last_hip_error;
+
+inline int hip_fail(hipError_t e) {
+  g_last_hip_error = static_cast<int>(e);
+  return SVO_HIP_EHIP;
+}
+
+#define SVO_HIP_TRY(expr)                                   \
+  do {                                                      \
+    hipError_t _e = (expr);                                 \
+    if (_e != hipSuccess) return ::svo_capi::hip_fail(_e);  \
+  } while (0)
+
+inline int check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e);
+  return SVO_HIP_OK;
+}
+
+inline bool layout_ok(const svo_hip_pyr_layout* L) {
+  if (!L || L->n_levels < 1 || L->n_levels > SVO_HIP_MAX_LEVELS) return false;
+  for (int i = 0; i < L->n_levels; ++i)
+    if (L->w[i] < 1 || L->h[i] < 1 || L->pitch[i] < L->w[i] || (L->pitch[i] & 63)) return false;
+  return L->slot_bytes > 0;
+}
+
+}  // namespace svo_capi

@@ -1,0 +1,146 @@
+// capi_util.hip -- error strings, raw device helpers and the pyramid-store
+// layout of the C ABI (include/svo_hip.h).  No kernels here.
+#include <cstring>
+
+#include "capi_common.h"
+
+namespace svo_capi {
+thread_local int g_last_hip_error = 0;
+}
+
+using namespace svo_capi;
+
+extern "C" {
+
+const char* svo_hip_strerror(int code) {
+  switch (code) {
+    case SVO_HIP_OK: return "ok";
+    case SVO_HIP_EINVAL: return "invalid argument";
+    case SVO_HIP_ERANGE: return "size beyond a documented limit";
+    case SVO_HIP_EHIP: return "HIP runtime call failed (see svo_hip_last_hip_error)";
+    case SVO_HIP_ENODEV: return "no usable HIP device";
+    case SVO_HIP_ENOMEM: return "out of memory";
+    default: return "unknown svo_hip error";
+  }
+}
+
+int svo_hip_last_hip_error(void) { return g_last_hip_error; }
+
+const char* svo_hip_version(void) { return "svo_hip 0.1 (gfx950)"; }
+
+int svo_hip_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    g_last_hip_error = static_cast<int>(e);
+    return SVO_HIP_ENODEV;
+  }
+  return n;
+}
+
+int svo_hip_set_device(int device) {
+  SVO_HIP_TRY(hipSetDevice(device));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_malloc(void** d_ptr, size_t bytes) {
+  if (!d_ptr) return SVO_HIP_EINVAL;
+  hipError_t e = hipMalloc(d_ptr, bytes);
+  if (e == hipErrorOutOfMemory) {
+    g_last_hip_error = static_cast<int>(e);
+    return SVO_HIP_ENOMEM;
+  }
+  SVO_HIP_TRY(e);
+  return SVO_HIP_OK;
+}
+
+int svo_hip_free(void* d_ptr) {
+  SVO_HIP_TRY(hipFree(d_ptr));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_memcpy_h2d(void* d_dst, const void* src, size_t bytes, void* stream) {
+  SVO_HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_memcpy_d2h(void* dst, const void* d_src, size_t bytes, void* stream) {
+  SVO_HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_memset(void* d_dst, int value, size_t bytes, void* stream) {
+  SVO_HIP_TRY(hipMemsetAsync(d_dst, value, bytes, static_cast<hipStream_t>(stream)));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_stream_create(void** stream_out) {
+  if (!stream_out) return SVO_HIP_EINVAL;
+  hipStream_t s;
+  SVO_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream_out = s;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_stream_destroy(void* stream) {
+  SVO_HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_stream_sync(void* stream) {
+  SVO_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_event_create(void** event_out) {
+  if (!event_out) return SVO_HIP_EINVAL;
+  hipEvent_t e;
+  SVO_HIP_TRY(hipEventCreate(&e));
+  *event_out = e;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_event_destroy(void* event) {
+  SVO_HIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_event_record(void* event, void* stream) {
+  SVO_HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_event_elapsed_ms(void* start, void* stop, float* ms_out) {
+  if (!ms_out) return SVO_HIP_EINVAL;
+  SVO_HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(stop)));
+  SVO_HIP_TRY(hipEventElapsedTime(ms_out, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_pyr_layout_init(int width, int height, int n_levels, svo_hip_pyr_layout* out) {
+  if (!out || width < 1 || height < 1 || n_levels < 1 || n_levels > SVO_HIP_MAX_LEVELS) return SVO_HIP_EINVAL;
+  std::memset(out, 0, sizeof(*out));
+  out->n_levels = n_levels;
+  int w = width, h = height;
+  int64_t off = 0;
+  for (int i = 0; i < n_levels; ++i) {
+    if (w < 1 || h < 1) return SVO_HIP_EINVAL;  // pyramid deeper than the image allows
+    out->w[i] = w;
+    out->h[i] = h;
+    out->pitch[i] = (w + 63) & ~63;
+    out->offset[i] = off;
+    off += static_cast<int64_t>(out->pitch[i]) * h;
+    off = (off + 255) & ~static_cast<int64_t>(255);
+    w /= 2;  // cv::Mat(rows/2, cols/2), svo/src/frame.cpp:162
+    h /= 2;
+  }
+  out->slot_bytes = (off + 4095) & ~static_cast<int64_t>(4095);
+  return SVO_HIP_OK;
+}
+
+int64_t svo_hip_pyr_store_bytes(const svo_hip_pyr_layout* layout, int n_slots) {
+  if (!layout_ok(layout) || n_slots < 0) return SVO_HIP_EINVAL;
+  return layout->slot_bytes * n_slots + SVO_HIP_STORE_TAIL_PAD;
+}
+
+}  // extern "C"

@@ -1,0 +1,183 @@
+// device_math.h -- small f64 SO(3)/SE(3) + 6x6 LDLT helpers shared by the gfx950
+// kernels.  Formulas follow what the reference's dependencies compute (Sophus
+// SE3::exp / operator*, Eigen quaternion <-> matrix), written for registers:
+// everything is fully unrolled, no dynamically indexed local arrays.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace svo_dev {
+
+// Eigen QuaternionBase::toRotationMatrix; q = (w, x, y, z)
+__device__ __forceinline__ void quat_to_R(const double q[4], double R[9]) {
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+  R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+
+// Eigen Quaternion(Matrix3).  Branchy but only run once per problem.
+__device__ __forceinline__ void quat_from_R(const double R[9], double q[4]) {
+  double t = R[0] + R[4] + R[8];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0);
+    q[0] = 0.5 * t;
+    t = 0.5 / t;
+    q[1] = (R[7] - R[5]) * t;
+    q[2] = (R[2] - R[6]) * t;
+    q[3] = (R[3] - R[1]) * t;
+  } else if (R[0] >= R[4] && R[0] >= R[8]) {  // i=0, j=1, k=2
+    t = sqrt(R[0] - R[4] - R[8] + 1.0);
+    q[1] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[7] - R[5]) * t;
+    q[2] = (R[3] + R[1]) * t;
+    q[3] = (R[6] + R[2]) * t;
+  } else if (R[4] > R[0] && R[4] >= R[8]) {  // i=1, j=2, k=0
+    t = sqrt(R[4] - R[8] - R[0] + 1.0);
+    q[2] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[2] - R[6]) * t;
+    q[3] = (R[7] + R[5]) * t;
+    q[1] = (R[1] + R[3]) * t;
+  } else {  // i=2, j=0, k=1
+    t = sqrt(R[8] - R[0] - R[4] + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[3] - R[1]) * t;
+    q[1] = (R[2] + R[6]) * t;
+    q[2] = (R[5] + R[7]) * t;
+  }
+}
+
+__device__ __forceinline__ void quat_mul(const double a[4], const double b[4], double o[4]) {
+  o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  o[2] = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3];
+  o[3] = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1];
+}
+
+__device__ __forceinline__ void quat_normalize(double q[4]) {
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double inv = 1.0 / n;
+  q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+}
+
+// Eigen _transformVector
+__device__ __forceinline__ void quat_rot(const double q[4], const double v[3], double o[3]) {
+  double ux = q[2] * v[2] - q[3] * v[1];
+  double uy = q[3] * v[0] - q[1] * v[2];
+  double uz = q[1] * v[1] - q[2] * v[0];
+  ux += ux; uy += uy; uz += uz;
+  const double cx = q[2] * uz - q[3] * uy;
+  const double cy = q[3] * ux - q[1] * uz;
+  const double cz = q[1] * uy - q[2] * ux;
+  o[0] = v[0] + q[0] * ux + cx;
+  o[1] = v[1] + q[0] * uy + cy;
+  o[2] = v[2] + q[0] * uz + cz;
+}
+
+// Sophus SE3::exp (SO3::expAndTheta + V matrix); xi = [upsilon, omega].
+__device__ __forceinline__ void se3_exp(const double xi[6], double q[4], double t[3]) {
+  const double ox = xi[3], oy = xi[4], oz = xi[5];
+  const double theta_sq = ox * ox + oy * oy + oz * oz;
+  const double theta = sqrt(theta_sq);
+  const double half_theta = 0.5 * theta;
+  double imag_factor, c1, c2;
+  double s_h, c_h;
+  sincos(half_theta, &s_h, &c_h);
+  if (theta < 1e-10) {
+    const double theta_po4 = theta_sq * theta_sq;
+    imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * theta_po4;
+  } else {
+    imag_factor = s_h / theta;
+  }
+  q[0] = c_h;
+  q[1] = imag_factor * ox;
+  q[2] = imag_factor * oy;
+  q[3] = imag_factor * oz;
+  // V = I + c1*Omega + c2*Omega^2 ; V*u = u + c1*(w x u) + c2*(w x (w x u))
+  const double ux = xi[0], uy = xi[1], uz = xi[2];
+  if (theta < 1e-10) {
+    // V = so3.matrix()  (Sophus: "that is an accurate expansion")
+    quat_rot(q, xi, t);
+  } else {
+    double s_t, c_t;
+    sincos(theta, &s_t, &c_t);
+    c1 = (1.0 - c_t) / theta_sq;
+    c2 = (theta - s_t) / (theta_sq * theta);
+    const double wx = oy * uz - oz * uy;
+    const double wy = oz * ux - ox * uz;
+    const double wz = ox * uy - oy * ux;
+    const double wwx = oy * wz - oz * wy;
+    const double wwy = oz * wx - ox * wz;
+    const double wwz = ox * wy - oy * wx;
+    t[0] = ux + c1 * wx + c2 * wwx;
+    t[1] = uy + c1 * wy + c2 * wwy;
+    t[2] = uz + c1 * wz + c2 * wwz;
+  }
+}
+
+// index into the packed upper triangle of a symmetric 6x6 (row-major, i<=j)
+__host__ __device__ constexpr int sym6(int i, int j) {
+  return (i <= j) ? (i * 6 - (i * (i - 1)) / 2 + (j - i)) : (j * 6 - (j * (j - 1)) / 2 + (i - j));
+}
+// index of L(i,j), i>j, in a packed strictly-lower 6x6 (15 entries)
+__host__ __device__ constexpr int low6(int i, int j) { return (i * (i - 1)) / 2 + j; }
+
+// LDL^T of a symmetric 6x6 given as packed upper triangle H[21]; no pivoting
+// (the systems here are SPD normal equations).  A pivot with |d| <= DBL_MIN is
+// treated like Eigen's LDLT::solve treats it: its D^-1 entry becomes 0.
+// LD[0..14] = L strictly lower, LD[15..20] = 1/d.
+__device__ __forceinline__ void ldlt6_factor(const double H[21], double LD[21]) {
+  double d[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double dj = H[sym6(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) dj -= LD[low6(j, k)] * LD[low6(j, k)] * d[k];
+    d[j] = dj;
+    const bool ok = fabs(dj) > 2.2250738585072014e-308;
+    const double inv = ok ? 1.0 / dj : 0.0;
+    LD[15 + j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double v = H[sym6(j, i)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= LD[low6(i, k)] * LD[low6(j, k)] * d[k];
+      LD[low6(i, j)] = ok ? v * inv : v;
+    }
+  }
+}
+
+__device__ __forceinline__ void ldlt6_solve(const double LD[21], const double b[6], double x[6]) {
+  double y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double v = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= LD[low6(i, k)] * y[k];
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) y[i] *= LD[15 + i];
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double v = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) v -= LD[low6(k, i)] * x[k];
+    x[i] = v;
+  }
+}
+
+// full-wave (64 lanes) sum; every lane receives the total
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+}  // namespace svo_dev

@@ -1,0 +1,199 @@
+"""Synthetic textured-plane sequences for parity tests and the benchmark.
+
+Stands in for the reference's `sin2_tex2_h1_v8_d` dataset (svo/test/README.md,
+test_utils.h:30-41), which is not available offline: a textured plane z = 0
+seen by a downward-looking pinhole camera at ~2 m (the reference's test
+trajectory also sits at z = 2.0, svo/test/test_matcher.cpp:52-53), rendered by
+exact ray/plane intersection + bilinear texture lookup, with analytic depth.
+Everything is seeded and deterministic.  torch is used so the same code runs on
+CPU (tests) and on the GPU (bench data generation, untimed).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+
+@dataclass
+class Camera:
+    width: int
+    height: int
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+
+    @staticmethod
+    def vga() -> "Camera":
+        return Camera(640, 480, 400.0, 400.0, 320.0, 240.0)
+
+
+TEX_SIZE = 1024        # texels
+TEX_EXTENT = 8.0       # metres covered by the texture (centred on the origin)
+
+
+def make_texture(size: int = TEX_SIZE, seed: int = 12345) -> torch.Tensor:
+    """Band-limited noise texture in [16, 240], float32 [size, size] (CPU)."""
+    g = torch.Generator().manual_seed(seed)
+    tex = torch.zeros(size, size, dtype=torch.float64)
+    for sigma, amp in ((1.5, 0.35), (4.0, 0.6), (12.0, 1.0), (32.0, 0.8)):
+        noise = torch.rand(size, size, generator=g, dtype=torch.float64) - 0.5
+        k = int(4 * sigma) | 1
+        xs = torch.arange(k, dtype=torch.float64) - k // 2
+        ker = torch.exp(-0.5 * (xs / sigma) ** 2)
+        ker /= ker.sum()
+        n4 = noise[None, None]
+        n4 = torch.nn.functional.conv2d(torch.nn.functional.pad(n4, (k // 2, k // 2, 0, 0), mode="circular"), ker.view(1, 1, 1, k))
+        n4 = torch.nn.functional.conv2d(torch.nn.functional.pad(n4, (0, 0, k // 2, k // 2), mode="circular"), ker.view(1, 1, k, 1))
+        n4 = n4[0, 0]
+        tex += amp * n4 / n4.std()
+    tex = (tex - tex.mean()) / tex.std()
+    tex = 128.0 + 45.0 * tex
+    return tex.clamp(16.0, 240.0).to(torch.float32)
+
+
+def make_trajectory(n_frames: int, seed: int = 12345, height: float = 2.0,
+                    max_step: float = 0.012, max_rot_deg: float = 0.25) -> np.ndarray:
+    """T_f_w for n_frames, float64 [n,12].  Smooth random walk: <= max_step*height
+    metres and <= max_rot_deg degrees per frame."""
+    rng = np.random.default_rng(seed)
+    from . import se3
+    R0 = np.diag([1.0, -1.0, -1.0])  # camera looks down: z_cam = -z_world
+    T = np.zeros((n_frames, 12))
+    c = np.array([0.0, 0.0, height])
+    rv = np.zeros(3)
+    vel = rng.normal(size=3)
+    ang = rng.normal(size=3)
+    for i in range(n_frames):
+        Rs = se3.split(se3.exp(np.concatenate([np.zeros(3), rv])))[0]
+        R = Rs @ R0
+        T[i] = se3.join(R, -R @ c)
+        vel = 0.85 * vel + 0.5 * rng.normal(size=3)
+        ang = 0.85 * ang + 0.5 * rng.normal(size=3)
+        step = vel / max(np.linalg.norm(vel), 1e-9) * max_step * height * rng.uniform(0.3, 1.0)
+        step[2] *= 0.3
+        c = c + step
+        c[:2] = np.clip(c[:2], -1.0, 1.0)
+        c[2] = np.clip(c[2], 0.85 * height, 1.15 * height)
+        drv = ang / max(np.linalg.norm(ang), 1e-9) * math.radians(max_rot_deg) * rng.uniform(0.3, 1.0)
+        rv = np.clip(rv + drv, -0.12, 0.12)
+    return T
+
+
+def _plane_points(T_f_w: torch.Tensor, cam: Camera, u: torch.Tensor, v: torch.Tensor):
+    """World points on z=0 seen at pixels (u,v) of frames T_f_w [n,12]; u,v broadcast
+    against the leading n.  Returns (X [...,3], cam centre [n,3])."""
+    R = T_f_w[:, :9].reshape(-1, 3, 3)
+    t = T_f_w[:, 9:]
+    c = -(R.transpose(1, 2) @ t[..., None])[..., 0]          # camera centre in world
+    dx = (u - cam.cx) / cam.fx
+    dy = (v - cam.cy) / cam.fy
+    d_c = torch.stack([dx, dy, torch.ones_like(dx)], dim=-1)  # [..., 3]
+    shape = [R.shape[0]] + [1] * (d_c.dim() - 2)
+    Rt = R.transpose(1, 2).reshape(shape + [3, 3])
+    d_w = (Rt @ d_c[..., None])[..., 0]
+    cc = c.reshape(shape + [3])
+    s = -cc[..., 2] / d_w[..., 2]
+    X = cc + s[..., None] * d_w
+    return X, c
+
+
+def render(tex: torch.Tensor, T_f_w, cam: Camera, device="cpu", chunk: int = 16) -> torch.Tensor:
+    """uint8 [n, h, w] images of the textured plane."""
+    T = torch.as_tensor(np.asarray(T_f_w), dtype=torch.float64, device=device)
+    tex = tex.to(device=device, dtype=torch.float32)
+    S = tex.shape[0]
+    n = T.shape[0]
+    out = torch.empty(n, cam.height, cam.width, dtype=torch.uint8, device=device)
+    vv, uu = torch.meshgrid(torch.arange(cam.height, dtype=torch.float64, device=device),
+                            torch.arange(cam.width, dtype=torch.float64, device=device), indexing="ij")
+    for i0 in range(0, n, chunk):
+        Tc = T[i0:i0 + chunk]
+        X, _ = _plane_points(Tc, cam, uu[None], vv[None])
+        # texture coordinates (texel units), bilinear
+        tu = (X[..., 0] / TEX_EXTENT + 0.5) * (S - 1)
+        tv = (X[..., 1] / TEX_EXTENT + 0.5) * (S - 1)
+        tu = tu.clamp(0, S - 1.001)
+        tv = tv.clamp(0, S - 1.001)
+        iu = tu.floor().long()
+        iv = tv.floor().long()
+        fu = (tu - iu).float()
+        fv = (tv - iv).float()
+        a = tex[iv, iu]
+        b = tex[iv, iu + 1]
+        c = tex[iv + 1, iu]
+        d = tex[iv + 1, iu + 1]
+        img = (a * (1 - fu) + b * fu) * (1 - fv) + (c * (1 - fu) + d * fu) * fv
+        out[i0:i0 + chunk] = img.round().clamp(0, 255).to(torch.uint8)
+    return out
+
+
+def select_features(images: torch.Tensor, n_feat: int, margin: int = 28, cell: int = 32) -> torch.Tensor:
+    """Per image: strongest-gradient pixel of each cell x cell grid cell, then the
+    n_feat best cells (FAST/Shi-Tomasi grid stand-in, svo/src/feature_detection.cpp
+    :66-114).  Returns float64 [n, n_feat, 2] level-0 pixel coordinates (u, v)."""
+    n, h, w = images.shape
+    img = images.float()
+    gx = torch.zeros_like(img)
+    gy = torch.zeros_like(img)
+    gx[:, :, 1:-1] = img[:, :, 2:] - img[:, :, :-2]
+    gy[:, 1:-1, :] = img[:, 2:, :] - img[:, :-2, :]
+    score = gx * gx + gy * gy
+    # smooth the score a little so a single noisy pixel does not win
+    score = torch.nn.functional.avg_pool2d(score[:, None], 3, 1, 1)[:, 0]
+    score[:, :margin, :] = -1
+    score[:, h - margin:, :] = -1
+    score[:, :, :margin] = -1
+    score[:, :, w - margin:] = -1
+    hc, wc = h // cell, w // cell
+    s = score[:, :hc * cell, :wc * cell].reshape(n, hc, cell, wc, cell).permute(0, 1, 3, 2, 4).reshape(n, hc * wc, cell * cell)
+    best, idx = s.max(dim=-1)
+    cy = torch.arange(hc, device=images.device).repeat_interleave(wc)
+    cx = torch.arange(wc, device=images.device).repeat(hc)
+    v = cy[None] * cell + idx // cell
+    u = cx[None] * cell + idx % cell
+    if hc * wc < n_feat:
+        raise ValueError(f"grid {hc}x{wc} has fewer cells than n_feat={n_feat}")
+    top = best.topk(n_feat, dim=-1).indices
+    top, _ = top.sort(dim=-1)
+    u = torch.gather(u, 1, top)
+    v = torch.gather(v, 1, top)
+    return torch.stack([u, v], dim=-1).to(torch.float64)
+
+
+def features_3d(T_f_w, cam: Camera, px: torch.Tensor):
+    """Unit bearings f [n,N,3] and world points pos [n,N,3] (plane hit) for px [n,N,2]."""
+    T = torch.as_tensor(np.asarray(T_f_w), dtype=torch.float64, device=px.device)
+    X, _ = _plane_points(T, cam, px[..., 0], px[..., 1])
+    dx = (px[..., 0] - cam.cx) / cam.fx
+    dy = (px[..., 1] - cam.cy) / cam.fy
+    f = torch.stack([dx, dy, torch.ones_like(dx)], dim=-1)
+    f = f / f.norm(dim=-1, keepdim=True)  # vk::PinholeCamera::cam2world -> normalized()
+    return f, X
+
+
+@dataclass
+class Sequence:
+    cam: Camera
+    T_f_w: np.ndarray            # [n,12] ground truth
+    images: torch.Tensor         # uint8 [n,h,w]
+    px: torch.Tensor             # [n,N,2] features detected in each frame
+    f: torch.Tensor              # [n,N,3]
+    pos: torch.Tensor            # [n,N,3]
+
+
+def make_sequence(n_frames: int, n_feat: int, cam: Camera | None = None, seed: int = 12345,
+                  device="cpu", margin: int = 28, cell: int = 32, subpixel: bool = True, **traj_kw) -> Sequence:
+    cam = cam or Camera.vga()
+    tex = make_texture(seed=seed)
+    T = make_trajectory(n_frames, seed=seed, **traj_kw)
+    images = render(tex, T, cam, device=device)
+    px = select_features(images, n_feat, margin=margin, cell=cell)
+    if subpixel:  # refined features are not integer pixels (matcher output is sub-pixel)
+        g = torch.Generator().manual_seed(seed + 1)
+        px = px + (torch.rand(px.shape, generator=g, dtype=torch.float64) - 0.5).to(px.device)
+    f, pos = features_3d(T, cam, px)
+    return Sequence(cam, T, images, px, f, pos)

@@ -1,0 +1,69 @@
+"""Shared builders for parity tests: a batch of (ref, cur) alignment problems in
+both representations (host arrays for the oracle, device tensors for the HIP path)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from rpg_svo_amd import se3, synth
+from rpg_svo_amd.sparse_img_align import marshal_problem
+
+
+class Batch:
+    pass
+
+
+def make_batch(seq: synth.Sequence, pairs, n_levels: int, n_valid=None, prior="ref", has_point=None,
+               prior_noise=None, seed=0):
+    """pairs: list of (ref_idx, cur_idx).  prior: 'ref' = pose of the reference frame
+    (the pipeline's constant-position prior, frame_handler_mono.cpp:132) or 'gt'."""
+    b = Batch()
+    B = len(pairs)
+    N = seq.px.shape[1]
+    b.B, b.N, b.n_levels = B, N, n_levels
+    b.cam = seq.cam
+    b.ref_slot = np.array([p[0] for p in pairs], dtype=np.int32)
+    b.cur_slot = np.array([p[1] for p in pairs], dtype=np.int32)
+    b.images = seq.images.cpu().numpy()
+    b.T_ref_w = seq.T_f_w[b.ref_slot].copy()
+    b.T_gt_w = seq.T_f_w[b.cur_slot].copy()
+    b.T_cur_w = b.T_ref_w.copy() if prior == "ref" else b.T_gt_w.copy()
+    if prior_noise is not None:
+        rng = np.random.default_rng(seed)
+        b.T_cur_w = se3.mul(se3.exp(rng.normal(size=(B, 6)) * prior_noise), b.T_cur_w)
+    b.px = seq.px[b.ref_slot].cpu().numpy().copy()
+    b.f = seq.f[b.ref_slot].cpu().numpy().copy()
+    b.pos = seq.pos[b.ref_slot].cpu().numpy().copy()
+    b.n = np.full(B, N, dtype=np.int32) if n_valid is None else np.asarray(n_valid, dtype=np.int32)
+    b.has_point = np.ones((B, N), dtype=np.uint8) if has_point is None else np.asarray(has_point, dtype=np.uint8)
+    return b
+
+
+def run_oracle(oracle, b: Batch, max_level, min_level, n_iter=30, halfsample=None, n_threads=4):
+    mode = oracle.HALFSAMPLE_AUTO if halfsample is None else halfsample
+    pyrs = [oracle.create_img_pyramid(im, b.n_levels, mode) for im in b.images]
+    T, res = oracle.sparse_img_align_batch(pyrs, b.ref_slot, b.cur_slot, b.cam, b.T_ref_w, b.T_cur_w, b.n,
+                                           b.px, b.f, b.has_point, b.pos, max_level, min_level, n_iter,
+                                           n_threads=n_threads)
+    return T, res, pyrs
+
+
+def run_hip(b: Batch, max_level, min_level, n_iter=30, device="cuda:0", halfsample=None):
+    from rpg_svo_amd import capi
+    from rpg_svo_amd.pyramid import PyramidStore
+    from rpg_svo_amd.sparse_img_align import SparseImgAlign
+    mode = capi.HALFSAMPLE_AUTO if halfsample is None else halfsample
+    store = PyramidStore(b.cam.width, b.cam.height, b.n_levels, len(b.images), device=device, halfsample=mode)
+    store.load_images(torch.from_numpy(b.images).to(device))
+    T_cr, xyz = marshal_problem(b.T_ref_w, b.T_cur_w, b.f, b.pos)
+    dev = torch.device(device)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+    sia = SparseImgAlign(max_level, min_level, n_iter)
+    out = sia.run(store, b.cam, t(b.ref_slot, torch.int32), t(b.cur_slot, torch.int32), t(b.n, torch.int32),
+                  t(b.px, torch.float64), t(xyz, torch.float64), t(T_cr, torch.float64),
+                  valid=t(b.has_point, torch.uint8))
+    torch.cuda.synchronize()
+    T_cr_out = out.T_cur_from_ref.cpu().numpy()
+    # cur_frame_->T_f_w_ = T_cur_from_ref * ref_frame_->T_f_w_ (sparse_img_align.cpp:70)
+    T_cur_w = se3.mul(T_cr_out, b.T_ref_w)
+    return T_cur_w, out, store

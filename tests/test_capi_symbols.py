@@ -1,0 +1,55 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/svo_hip.h
+declares (no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "svo_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(svo_hip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(hip_lib):
+    names = declared_functions()
+    assert len(names) >= 20
+    raw = ctypes.CDLL(os.path.join(ROOT, "rpg_svo_amd", "lib", "libsvo_hip.so"))
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in svo_hip.h but not exported"
+
+
+def test_binding_covers_header(hip_lib):
+    from rpg_svo_amd import capi
+    assert sorted(capi.PROTOTYPES) == declared_functions()
+
+
+def test_layout_is_host_only(hip_lib):
+    from rpg_svo_amd import capi
+    L = capi.pyr_layout(640, 480, 4)
+    assert list(L.w[:4]) == [640, 320, 160, 80] and list(L.h[:4]) == [480, 240, 120, 60]
+    assert all(p % 64 == 0 for p in L.pitch[:4])
+    assert L.slot_bytes % 4096 == 0 and L.slot_bytes >= 408000
+    L5 = capi.pyr_layout(752, 480, 5)
+    assert list(L5.w[:5]) == [752, 376, 188, 94, 47] and list(L5.h[:5]) == [480, 240, 120, 60, 30]
+    assert capi.pyr_store_bytes(L, 3) == 3 * L.slot_bytes + capi.STORE_TAIL_PAD
+
+
+def test_error_strings(hip_lib):
+    assert hip_lib.svo_hip_strerror(0) == b"ok"
+    assert b"invalid" in hip_lib.svo_hip_strerror(-1)
+    from rpg_svo_amd import capi
+    bad = capi.PyrLayout()
+    assert hip_lib.svo_hip_pyr_layout_init(640, 480, 99, ctypes.byref(bad)) == -1
+
+
+def test_product_never_imports_oracle():
+    """The shipped package must not reference the checker."""
+    pkg = os.path.join(ROOT, "rpg_svo_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "pyoracle" not in txt and "svo_oracle" not in txt and "orc_" not in txt, f
