@@ -1,0 +1,312 @@
+#!/usr/bin/env python
+"""bench.py -- frames/s of sparse image alignment (+ the Gauss-Newton pose
+refinement it contains) on synthetic VGA pyramid batches.
+
+A "step" is one pass of the hot path (svo_hip_sparse_align, K1) over one batch
+of B independent (reference frame, current frame) problems per GPU, with the
+image pyramids and feature arrays already resident in HBM.  Workload at N=1 is
+BASELINE.json configs[1]: 640x480 mono, 4 pyramid levels (3 -> 0), 200 reference
+patches, SparseImgAlign only.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see the keys below).  The oracle (oracle/, CPU
+restatement) is used here only for the `cpu_baseline` leg and a parity read-out;
+it is never the thing measured as `value`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from rpg_svo_amd import capi, se3, synth  # noqa: E402
+from rpg_svo_amd.pyramid import PyramidStore  # noqa: E402
+from rpg_svo_amd.sparse_img_align import SparseImgAlign, marshal_problem  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (width, height, f, n_levels, max_level, min_level, n_patches, margin, cell)
+    "vga4_n200_sparse_align": (640, 480, 400.0, 4, 3, 0, 200, 28, 32),
+    "svo_default_752_l4to2_n120": (752, 480, 315.5, 5, 4, 2, 120, 56, 40),
+    "xga5_n1000_sparse_align": (1280, 960, 800.0, 5, 4, 0, 1000, 56, 32),
+}
+
+
+def algorithmic_bytes(n_patches: np.ndarray, n_tracked: np.ndarray, iters: np.ndarray, max_level: int, min_level: int) -> float:
+    """per frame  sum_l N_l*(49 + 25*I_l) + per-patch geometry + pose/H I/O.
+    N_l is taken as the tracked-patch count; geometry is 41 B/patch here (px 2xf64,
+    xyz_ref 3xf64, valid u8) and the fixed I/O is 540 B (poses in/out 2x96, H 288,
+    counters 60)."""
+    lv = slice(min_level, max_level + 1)
+    per_level = n_tracked[:, None] * (49.0 + 25.0 * iters[:, lv])
+    return float(per_level.sum() + 41.0 * n_patches.sum() + 540.0 * len(n_patches))
+
+
+def horn_ate(P: np.ndarray, Q: np.ndarray) -> float:
+    """ATE RMSE after Horn alignment (svo_analysis/.../evaluate_ate.py:47-80)."""
+    Pc, Qc = P - P.mean(0), Q - Q.mean(0)
+    W = Pc.T @ Qc
+    U, _, Vt = np.linalg.svd(W.T)
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[2, 2] = -1
+    R = U @ S @ Vt
+    t = Q.mean(0) - R @ P.mean(0)
+    err = (R @ P.T).T + t - Q
+    return float(np.sqrt((err ** 2).sum(1).mean()))
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="frames per step per GPU")
+    ap.add_argument("--workload", default="vga4_n200_sparse_align", choices=sorted(WORKLOADS))
+    ap.add_argument("--noise", type=float, default=0.0, help="image noise sigma (gray levels)")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="frames timed on the host for cpu_baseline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    lib = capi.load()
+
+    width, height, focal, n_levels, max_level, min_level, n_patches, margin, cell = WORKLOADS[args.workload]
+    cam = synth.Camera(width, height, focal, focal, width / 2.0, height / 2.0)
+    B = args.batch
+
+    # ---- synthetic replay sequence: B+1 frames, problem b = (frame b -> frame b+1) ----
+    t_gen = time.time()
+    tex = synth.make_texture(seed=12345)
+    T_gt = synth.make_trajectory(B + 1, seed=12345 + rank)
+    images = synth.render(tex, T_gt, cam, device=dev, chunk=32)
+    if args.noise > 0:
+        g = torch.Generator(device=dev).manual_seed(99 + rank)
+        images = (images.float() + args.noise * torch.randn(images.shape, generator=g, device=dev)).round().clamp(0, 255).to(torch.uint8)
+    px_all = synth.select_features(images[:B], n_patches, margin=margin, cell=cell)
+    g = torch.Generator().manual_seed(777 + rank)
+    px_all = px_all + (torch.rand(px_all.shape, generator=g, dtype=torch.float64) - 0.5).to(dev)
+    f_all, pos_all = synth.features_3d(T_gt[:B], cam, px_all)
+    store = PyramidStore(width, height, n_levels, B + 1, device=dev)
+    store.load_images(images)  # level 0 copy + K0 pyramid build (untimed here)
+    T_ref_w = T_gt[:B]
+    T_prior_w = T_ref_w.copy()  # constant-position prior, frame_handler_mono.cpp:132
+    T_cr, xyz_ref = marshal_problem(T_ref_w, T_prior_w, f_all.cpu().numpy(), pos_all.cpu().numpy())
+    tdev = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+    ref_slot = torch.arange(0, B, dtype=torch.int32, device=dev)
+    cur_slot = torch.arange(1, B + 1, dtype=torch.int32, device=dev)
+    n_t = torch.full((B,), n_patches, dtype=torch.int32, device=dev)
+    px_t = px_all.contiguous()
+    xyz_t = tdev(xyz_ref, torch.float64)
+    T_in = tdev(T_cr, torch.float64)
+    sia = SparseImgAlign(max_level, min_level, 30)
+    out = sia.alloc_result(B, dev)
+    gathered = torch.empty(world * B, 12, dtype=torch.float64, device=dev) if world > 1 else None
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ev = []
+    for _ in range(2 * args.steps):
+        e = C_void()
+        capi.check(lib.svo_hip_event_create(e.ref()))
+        ev.append(e.value)
+
+    def step(i: int | None) -> None:
+        if i is not None:
+            lib.svo_hip_event_record(ev[2 * i], stream)
+        sia.run(store, cam, ref_slot, cur_slot, n_t, px_t, xyz_t, T_in, out=out)
+        if i is not None:
+            lib.svo_hip_event_record(ev[2 * i + 1], stream)
+        if world > 1:  # RCCL gather of the SE(3) results (the only exchange step)
+            dist.all_gather_into_tensor(gathered, out.T_cur_from_ref)
+
+    for _ in range(args.warmup):
+        step(None)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-launch kernel duration from HIP events on the launch stream
+    kms = []
+    for i in range(args.steps):
+        ms = C_float()
+        capi.check(lib.svo_hip_event_elapsed_ms(ev[2 * i], ev[2 * i + 1], ms.ref()))
+        kms.append(ms.value)
+    kernel_ms = float(np.mean(kms)) if kms else float("nan")
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    n_tracked = out.n_tracked.cpu().numpy().astype(np.float64)
+    iters = out.iters.cpu().numpy().astype(np.float64)
+    alg_bytes = algorithmic_bytes(np.full(B, n_patches, dtype=np.float64), n_tracked, iters, max_level, min_level)
+    achieved_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = f"{args.workload}:B{B}"
+            if key in tj:
+                traffic = tj[key]
+        except Exception:
+            traffic = None
+
+    T_est_w = se3.mul(out.T_cur_from_ref.cpu().numpy(), T_ref_w)
+    gt_err = se3.log_norm(T_est_w, T_gt[1:B + 1])
+
+    result = {
+        "metric": "frames/sec sparse-align+pose-refine (VGA, 4 pyr lvls); ATE vs CPU ref",
+        "value": world * B * args.steps / elapsed,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32 pixels / f64 pose+normal equations",
+        "data": "synthetic",
+        "config": {
+            "workload": args.workload, "image": f"{width}x{height}", "pyr_levels": n_levels,
+            "schedule": f"levels {max_level}->{min_level}", "patches_per_frame": n_patches,
+            "frames_per_step_per_gpu": B, "n_iter_cap": 30, "image_noise_sigma": args.noise,
+            "parallelism": f"frames sharded 1 rank/GPU x{world}" + (", RCCL all_gather of poses" if world > 1 else ""),
+            "mean_gn_iterations_per_frame": float(iters.sum(1).mean()),
+            "mean_tracked_patches": float(n_tracked.mean()),
+            "median_pose_error_vs_gt": float(np.median(gt_err)),
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "sia_kernel (svo_hip_sparse_align)",
+            "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel_ms_avg": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic_bytes_per_frame": alg_bytes / B,
+        },
+        "setup_s": t_gen,
+    }
+
+    if not args.no_cpu_baseline and world == 1:
+        result["cpu_baseline"] = cpu_baseline(args, cam, images, T_gt, px_all, f_all, pos_all, T_ref_w, T_prior_w,
+                                              n_levels, max_level, min_level, n_patches, T_est_w, result,
+                                              out.iters.cpu().numpy())
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, cam, images, T_gt, px_all, f_all, pos_all, T_ref_w, T_prior_w, n_levels, max_level,
+                 min_level, n_patches, T_est_w, result, iters_gpu) -> dict:
+    """Times the oracle (CPU restatement of the reference path; the reference itself
+    cannot be built: Eigen/OpenCV/Sophus/vikit are absent) on a bounded sample of
+    the same problems, on this box's host cores."""
+    from oracle import pyoracle
+    S = min(args.cpu_sample, px_all.shape[0])
+    imgs = images[:S + 1].cpu().numpy()
+    pyrs = [pyoracle.create_img_pyramid(im, n_levels, pyoracle.HALFSAMPLE_AUTO) for im in imgs]
+    rs = np.arange(S, dtype=np.int32)
+    cs = rs + 1
+    nn = np.full(S, n_patches, dtype=np.int32)
+    px = px_all[:S].cpu().numpy()
+    f = f_all[:S].cpu().numpy()
+    pos = pos_all[:S].cpu().numpy()
+    hp = np.ones((S, n_patches), dtype=np.uint8)
+    cores = os.cpu_count() or 1
+    s1 = min(S, 512)
+    t0 = time.perf_counter()
+    pyoracle.sparse_img_align_batch(pyrs, rs[:s1], cs[:s1], cam, T_ref_w[:s1], T_prior_w[:s1], nn[:s1], px[:s1],
+                                    f[:s1], hp[:s1], pos[:s1], max_level, min_level, 30, n_threads=1)
+    t1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    T_cpu, res = pyoracle.sparse_img_align_batch(pyrs, rs, cs, cam, T_ref_w[:S], T_prior_w[:S], nn, px, f, hp, pos,
+                                                 max_level, min_level, 30, n_threads=cores)
+    tn = time.perf_counter() - t0
+    d = se3.log_norm(T_est_w[:S], T_cpu)
+    pos_gpu = se3.inv(T_est_w[:S])[:, 9:]
+    pos_cpu = se3.inv(T_cpu)[:, 9:]
+    result["parity"] = {
+        "frames_compared": int(S), "se3_lognorm_max": float(d.max()), "se3_lognorm_median": float(np.median(d)),
+        "ate_rmse_vs_cpu_m": horn_ate(pos_gpu, pos_cpu),
+        "same_iteration_counts_frac": float(np.mean([np.array_equal(r["iters"], it) for r, it in zip(res, iters_gpu[:S])])),
+    }
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {"value": S / tn, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{S} of the benchmark's own frame pairs, oracle/libsvo_oracle.so (gcc -O3), {cores} pthreads",
+            "value_1core": s1 / t1, "sample_1core": f"{s1} frame pairs, 1 thread", "cpu_model": model}
+
+
+class C_void:
+    def __init__(self):
+        import ctypes
+        self._v = ctypes.c_void_p()
+
+    def ref(self):
+        import ctypes
+        return ctypes.byref(self._v)
+
+    @property
+    def value(self):
+        return self._v.value
+
+
+class C_float:
+    def __init__(self):
+        import ctypes
+        self._v = ctypes.c_float()
+
+    def ref(self):
+        import ctypes
+        return ctypes.byref(self._v)
+
+    @property
+    def value(self):
+        return self._v.value
+
+
+if __name__ == "__main__":
+    main()
