@@ -25,14 +25,16 @@ def _newer(target: str, sources: list[str]) -> bool:
     return all(os.path.getmtime(s) <= t for s in sources)
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> str:
+def build_hip(force: bool = False, verbose: bool = False, defines: list[str] | None = None) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
     if not force and _newer(LIB, deps):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *srcs, "-o", LIB]
+           # SLP packing (v_pk_*_f32) costs register pairs + moves in the pixel loops
+           "-fno-slp-vectorize",
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *[f"-D{d}" for d in (defines or [])], *srcs, "-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -80,6 +80,48 @@ __device__ __forceinline__ void quat_rot(const double q[4], const double v[3], d
   o[2] = v[2] + q[0] * uz + cz;
 }
 
+// Taylor coefficients of sin (x^3..x^17, sign included, highest first) and cos
+// (x^2..x^16).  Kept in constant memory and read through a laundered pointer so the
+// compiler loads them into SGPRs at the point of use instead of hoisting sixteen f64
+// literals into VGPRs for the lifetime of the calling kernel.
+__constant__ double kSinCoef[8] = {-1.0 / 355687428096000.0, 1.0 / 1307674368000.0, -1.0 / 6227020800.0,
+                                   1.0 / 39916800.0,         -1.0 / 362880.0,       1.0 / 5040.0,
+                                   -1.0 / 120.0,             1.0 / 6.0};
+__constant__ double kCosCoef[8] = {1.0 / 20922789888000.0, -1.0 / 87178291200.0, 1.0 / 479001600.0,
+                                   -1.0 / 3628800.0,       1.0 / 40320.0,        -1.0 / 720.0,
+                                   1.0 / 24.0,             -0.5};
+
+// sin/cos for the angles a Gauss-Newton step produces.  |x| <= 0.5 (always, in
+// practice): Taylor/Horner in x^2, truncation < 2e-20 relative.  Larger arguments
+// are halved until they fit and rebuilt with the double-angle identities (no
+// libm-style argument-reduction tables).
+__device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
+  int k = 0;
+  while (fabs(x) > 0.5 && k < 64) {
+    x *= 0.5;
+    ++k;
+  }
+  const double* cs = kSinCoef;
+  const double* cc = kCosCoef;
+  asm volatile("" : "+s"(cs), "+s"(cc));
+  const double z = x * x;
+  double ps = cs[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) ps = ps * z + cs[i];
+  double sv = x - x * z * ps;
+  double pc = cc[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) pc = pc * z + cc[i];
+  double cv = 1.0 + z * pc;
+  for (; k > 0; --k) {
+    const double s2 = 2.0 * sv * cv;
+    cv = 1.0 - 2.0 * sv * sv;
+    sv = s2;
+  }
+  *s = sv;
+  *c = cv;
+}
+
 // Sophus SE3::exp (SO3::expAndTheta + V matrix); xi = [upsilon, omega].
 __device__ __forceinline__ void se3_exp(const double xi[6], double q[4], double t[3]) {
   const double ox = xi[3], oy = xi[4], oz = xi[5];
@@ -88,7 +130,7 @@ __device__ __forceinline__ void se3_exp(const double xi[6], double q[4], double 
   const double half_theta = 0.5 * theta;
   double imag_factor, c1, c2;
   double s_h, c_h;
-  sincos(half_theta, &s_h, &c_h);
+  sincos_small(half_theta, &s_h, &c_h);
   if (theta < 1e-10) {
     const double theta_po4 = theta_sq * theta_sq;
     imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * theta_po4;
@@ -105,9 +147,9 @@ __device__ __forceinline__ void se3_exp(const double xi[6], double q[4], double 
     // V = so3.matrix()  (Sophus: "that is an accurate expansion")
     quat_rot(q, xi, t);
   } else {
-    double s_t, c_t;
-    sincos(theta, &s_t, &c_t);
-    c1 = (1.0 - c_t) / theta_sq;
+    // sin(theta) = 2 s c, 1 - cos(theta) = 2 s^2 with s,c of theta/2
+    const double s_t = 2.0 * s_h * c_h;
+    c1 = (2.0 * s_h * s_h) / theta_sq;
     c2 = (theta - s_t) / (theta_sq * theta);
     const double wx = oy * uz - oz * uy;
     const double wy = oz * ux - ox * uz;

@@ -26,11 +26,15 @@
 //     cached factors, applies the stop / rollback rules and writes the new
 //     pose (quaternion + t, as Sophus stores it) to LDS for everyone.
 //
-// Numerics: pixel math in f32 (like the reference), projection, Jacobian rows,
-// H, Jres and the pose in f64 (like the reference); sums are tree- instead of
-// sequentially reduced, so results agree to rounding, not bit-for-bit.
+// Numerics: pixel math in f32 (like the reference); projection, the solve and the
+// pose in f64 (like the reference).  The per-patch Jacobian rows and the per-lane
+// Jres / H partials are f32 (the reference keeps them in f64): a 1e-7 relative
+// perturbation of J moves the Gauss-Newton fixed point by ~1e-11, far below the
+// stated parity tolerance.  Sums are tree- instead of sequentially reduced, so
+// results agree to rounding, not bit-for-bit.
 #include "capi_common.h"
 #include "device_math.h"
+#include "wave_reduce.h"
 
 using namespace svo_capi;
 using namespace svo_dev;
@@ -89,25 +93,177 @@ __device__ __forceinline__ void load_row7(const uint8_t* __restrict__ row, int x
   out[6] = (float)((hi >> 16) & 0xffu);
 }
 
+#ifndef MINW
+#define MINW 4  // waves per SIMD asked of the register allocator (4 x 256-lane workgroups per CU)
+#endif
+
+#ifndef SIA_STEP_INLINE
+#define SIA_STEP_INLINE __forceinline__
+#endif
+
+constexpr int MAX_WAVES = SVO_HIP_MAX_PATCHES / 64;
+
+// Workgroup state.  File-scope LDS so that the serial Gauss-Newton step can live in
+// a non-inlined function: inlined, its f64 polynomial constants and address
+// arithmetic get hoisted out of the loops and push the hot per-lane patch tile into
+// scratch.
+struct SiaLds {
+  double q[4], t[3];          // model: T_cur_from_ref as Sophus stores it (unit quaternion + t)
+  double R[9];                // rotation matrix of q (what the lanes project with)
+  double oq[4], ot[3];        // old_model (rollback)
+  double H[21];               // H_ of the last evaluated iteration (packed upper triangle)
+  double Hinv[36];            // its inverse, row-major
+  double A[36];               // Gauss-Jordan scratch
+  double tot[8];              // workgroup totals: Jres[6], chi2, n_meas
+  double chi2;                // vk::NLLSSolver::chi2_
+  float part[MAX_WAVES][8];   // per-wave partials of tot
+  float Hpart[MAX_WAVES][24]; // per-wave partials of H (21 used)
+  long long lo[SVO_HIP_MAX_LEVELS];  // pyramid geometry per level (copied from the kernel
+  int lw[SVO_HIP_MAX_LEVELS];        // arguments so the level loop can index it dynamically)
+  int lh[SVO_HIP_MAX_LEVELS];
+  int lp[SVO_HIP_MAX_LEVELS];
+  int done;                   // level finished
+  int stop;                   // vk::NLLSSolver::stop_
+  int n_meas;                 // n_meas_ of the last evaluated iteration
+};
+__shared__ SiaLds g_s;
+
+__device__ __forceinline__ int sym6_rt(int i, int j) {
+  const int a = i < j ? i : j, b = i < j ? j : i;
+  return a * 6 - (a * (a - 1)) / 2 + (b - a);
+}
+
+// solve() / update() and the stop / rollback rules of
+// vk::NLLSSolver::optimizeGaussNewton (sparse_img_align.cpp:245-258), executed by
+// wave 0 after the workgroup reduction.  Same-wave LDS traffic only: DS
+// instructions of one wave execute in order; the wavefront-scope fences stop the
+// compiler from moving accesses across the exchange points.
+__device__ SIA_STEP_INLINE void sia_gauss_newton_step(int lane, int nw, int changed, int iter, double eps) {
+  // opaque lane: keeps this block's address arithmetic from being hoisted out of the
+  // caller's loops when the function is inlined
+  asm volatile("" : "+v"(lane));
+  if (changed) {
+    // H = sum of the per-wave partials (lanes 0..20), then H^-1 by Gauss-Jordan on a
+    // 6x6 tile held one element per lane (36 lanes), LDS as the row/column exchange.
+    // Runs once per level (or when the set of patches inside the image changes).
+    if (lane < 21) {
+      double v = 0.0;
+      for (int w = 0; w < nw; ++w) v += (double)g_s.Hpart[w][lane];
+      g_s.H[lane] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int gi = lane / 6, gj = lane - 6 * gi;
+    if (lane < 36) {
+      g_s.A[lane] = g_s.H[sym6_rt(gi, gj)];
+      g_s.Hinv[lane] = (gi == gj) ? 1.0 : 0.0;
+    }
+    for (int k = 0; k < 6; ++k) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (lane < 36) {
+        const double p = g_s.A[k * 6 + k];
+        const double aik = g_s.A[gi * 6 + k];
+        const double akj = g_s.A[k * 6 + gj];
+        const double bkj = g_s.Hinv[k * 6 + gj];
+        const double aij = g_s.A[lane];
+        const double bij = g_s.Hinv[lane];
+        // a zero pivot contributes nothing, like the D^-1 step of Eigen's LDLT::solve
+        const double ip = (fabs(p) > 2.2250738585072014e-308) ? 1.0 / p : 0.0;
+        const double na = (gi == k) ? akj * ip : aij - aik * (akj * ip);
+        const double nb = (gi == k) ? bkj * ip : bij - aik * (bkj * ip);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        g_s.A[lane] = na;
+        g_s.Hinv[lane] = nb;
+      }
+    }
+  }
+  // Jres, chi2, n_meas: lanes 0..7 sum their column over the waves
+  if (lane < 8) {
+    double v = 0.0;
+    for (int w = 0; w < nw; ++w) v += (double)g_s.part[w][lane];
+    g_s.tot[lane] = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  double tot[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) tot[k] = g_s.tot[k];
+  // x_ = H_.ldlt().solve(Jres_)  (:247), here x = H^-1 Jres (all lanes redundantly)
+  double x[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v += g_s.Hinv[i * 6 + j] * tot[j];
+    x[i] = v;
+  }
+  const int n_meas = (int)tot[7];
+  // return chi2/n_meas_  (float / size_t -> float), :242
+  const double new_chi2 = (double)((float)tot[6] / (float)n_meas);
+  int stop = g_s.stop;
+  if (isnan(x[0])) stop = 1;  // solve(), :248-249
+  const double chi2_prev = g_s.chi2;
+  int done = 0;
+  double q[4], t[3], oq[4], ot[3], R[9];
+  double chi2_out = chi2_prev;
+  if ((iter > 0 && new_chi2 > chi2_prev) || stop) {
+    // rollback: model = old_model
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = oq[k] = g_s.oq[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = ot[k] = g_s.ot[k];
+    done = 1;
+  } else {
+    // update(): T_new = T_old * SE3::exp(-x_)  (:253-258)
+    double mx[6], eq[4], et[3], rt[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) mx[k] = -x[k];
+    se3_exp(mx, eq, et);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) oq[k] = g_s.q[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ot[k] = g_s.t[k];
+    quat_rot(oq, et, rt);
+    quat_mul(oq, eq, q);
+    quat_normalize(q);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = ot[k] + rt[k];
+    chi2_out = new_chi2;
+    double nm = 0.0;  // vk::norm_max(x_) <= eps_
+#pragma unroll
+    for (int k = 0; k < 6; ++k) nm = fmax(nm, fabs(x[k]));
+    if (nm <= eps) done = 1;
+  }
+  quat_to_R(q, R);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      g_s.q[k] = q[k];
+      g_s.oq[k] = oq[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      g_s.t[k] = t[k];
+      g_s.ot[k] = ot[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g_s.R[k] = R[k];
+    g_s.chi2 = chi2_out;
+    g_s.stop = stop;
+    g_s.n_meas = n_meas;
+    g_s.done = done;
+  }
+}
+
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK) sia_kernel(const SiaArgs a) {
+__global__ void __launch_bounds__(BLOCK, MINW) sia_kernel(const SiaArgs a) {
   constexpr int NW = BLOCK / 64;
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
 
-  __shared__ double s_q[4], s_t[3];      // model: T_cur_from_ref as Sophus stores it
-  __shared__ double s_R[9];              // rotation matrix of s_q (for the lanes)
-  __shared__ double s_oq[4], s_ot[3];    // old_model (rollback)
-  __shared__ double s_part[NW][8];       // per-wave partials: Jres[6], chi2, n_meas
-  __shared__ double s_Hpart[NW][21];     // per-wave partials of H (packed upper)
-  __shared__ double s_H[21];             // H_ of the last evaluated iteration
-  __shared__ double s_LD[21];            // its LDL' factors
-  __shared__ int s_done;                 // level finished flag
-
   const int n = a.n[b];
-  const svo_hip_sia_params& P = a.P;
+  const svo_hip_sia_params P = a.P;
 
   if (n <= 0) {  // sparse_img_align.cpp:47-51: nothing to track, pose untouched
     if (tid == 0) {
@@ -123,140 +279,145 @@ __global__ void __launch_bounds__(BLOCK) sia_kernel(const SiaArgs a) {
     return;
   }
 
-  // ---- per-lane geometry (Feature::px, f*depth) --------------------------
+  // ---- per-lane geometry (Feature::px is re-read per level, f*depth kept) --
   const size_t fo = (size_t)b * a.n_stride + tid;
   const bool has = (tid < n) && (a.valid ? a.valid[fo] != 0 : true);
-  double pxx = 0, pxy = 0, X = 0, Y = 0, Z = 1;
+  double X = 0, Y = 0, Z = 1;
   if (has) {
-    pxx = a.px[2 * fo];
-    pxy = a.px[2 * fo + 1];
     X = a.xyz[3 * fo];
     Y = a.xyz[3 * fo + 1];
     Z = a.xyz[3 * fo + 2];
   }
+  // normalised coordinates of xyz_ref: all of Frame::jacobian_xyz2uv (frame.h:116-138)
+  // is a function of (x/z, y/z, 1/z)
+  const float zi = (float)(1.0 / Z);
+  const float xn = (float)(X / Z);
+  const float yn = (float)(Y / Z);
   const uint8_t* ref_base = a.store + (int64_t)a.ref_slot[b] * a.L.slot_bytes;
   const uint8_t* cur_base = a.store + (int64_t)a.cur_slot[b] * a.L.slot_bytes;
 
   if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < SVO_HIP_MAX_LEVELS; ++k) {
+      g_s.lw[k] = a.L.w[k];
+      g_s.lh[k] = a.L.h[k];
+      g_s.lp[k] = a.L.pitch[k];
+      g_s.lo[k] = a.L.offset[k];
+    }
     double R[9], q[4];
     for (int k = 0; k < 9; ++k) R[k] = a.T_in[12 * b + k];
     quat_from_R(R, q);
     quat_to_R(q, R);
-    for (int k = 0; k < 4; ++k) s_q[k] = s_oq[k] = q[k];
-    for (int k = 0; k < 3; ++k) s_t[k] = s_ot[k] = a.T_in[12 * b + 9 + k];
-    for (int k = 0; k < 9; ++k) s_R[k] = R[k];
-    for (int k = 0; k < 21; ++k) s_H[k] = 0.0;
+    for (int k = 0; k < 4; ++k) g_s.q[k] = g_s.oq[k] = q[k];
+    for (int k = 0; k < 3; ++k) g_s.t[k] = g_s.ot[k] = a.T_in[12 * b + 9 + k];
+    for (int k = 0; k < 9; ++k) g_s.R[k] = R[k];
+    for (int k = 0; k < 21; ++k) g_s.H[k] = 0.0;
+    // vk::NLLSSolver::reset()
+    g_s.chi2 = 1e10;
+    g_s.stop = 0;
+    g_s.n_meas = 0;
+    g_s.done = 0;
     if (a.iters)
       for (int k = 0; k < SVO_HIP_MAX_LEVELS; ++k) a.iters[SVO_HIP_MAX_LEVELS * b + k] = 0;
   }
 
-  // NLLSSolver state after reset(); authoritative copy lives in wave 0 (uniform)
-  double chi2_prev = 1e10;
-  int stop = 0;
-  int n_meas_last = 0;
-
-  float refv[16], dxv[16], dyv[16];  // ref_patch_cache_ row + gradients of this lane's patch
-#pragma unroll
-  for (int k = 0; k < 16; ++k) refv[k] = dxv[k] = dyv[k] = 0.f;
-  double ja[6], jb[6];
-  double Sxx = 0, Sxy = 0, Syy = 0;
-  bool vis = false;  // visible_fts_[i]; never cleared between levels (:57)
+  // Interpolated reference image around this lane's patch, staged in LDS: the
+  // bilinear sample at window pixel (r,c) of the 6x6 neighbourhood (corners unused
+  // -> 32 floats = 8 float4 per lane, laid out [8][BLOCK] so a wave reads 1 KiB
+  // contiguous per ds_read_b128).  ref_patch_cache_(y,x) = Bt[y+1][x+1]; the gradients
+  // dx,dy (:133-136) are central differences of Bt, rebuilt in flight.
+  //   q0 = r0 c1..4 | q1 = r1 c0..3 | q2 = r1 c4,5 r2 c0,1 | q3 = r2 c2..5
+  //   q4 = r3 c0..3 | q5 = r3 c4,5 r4 c0,1 | q6 = r4 c2..5 | q7 = r5 c1..4
+  __shared__ float4 s_bt[8][BLOCK];
+  float Sxx = 0.f, Sxy = 0.f, Syy = 0.f;
+  float gmask = 0.f;  // 0 while this lane's Jacobian columns are zero at this level
+  bool vis = false;   // visible_fts_[i]; never cleared between levels (:57)
 
   __syncthreads();
 
   for (int level = P.max_level; level >= P.min_level; --level) {
-    const int cols = a.L.w[level], rows = a.L.h[level], pitch = a.L.pitch[level];
-    const uint8_t* ref_img = ref_base + a.L.offset[level];
-    const uint8_t* cur_img = cur_base + a.L.offset[level];
+    const int cols = g_s.lw[level], rows = g_s.lh[level], pitch = g_s.lp[level];
+    const uint8_t* ref_img = ref_base + g_s.lo[level];
+    const uint8_t* cur_img = cur_base + g_s.lo[level];
     const float scale = 1.0f / (float)(1 << level);
+    // focal_length / 2^level (:139-140), folded into the per-patch sums
+    const float fl = (float)(fabs(P.fx) / (double)(1 << level));
 
     // ---- precomputeReferencePatches (:84-145) ----------------------------
     {
+      double pxx = 0, pxy = 0;
+      if (has) {
+        pxx = a.px[2 * fo];
+        pxy = a.px[2 * fo + 1];
+      }
       const float u_ref = (float)(pxx * (double)scale);
       const float v_ref = (float)(pxy * (double)scale);
       const int u_i = (int)floorf(u_ref);
       const int v_i = (int)floorf(v_ref);
       const bool inb = has && !(u_i - 3 < 0 || v_i - 3 < 0 || u_i + 3 >= cols || v_i + 3 >= rows);
-      // jacobian_cache_.setZero() (:64): features skipped below keep J = 0
-#pragma unroll
-      for (int k = 0; k < 6; ++k) ja[k] = jb[k] = 0.0;
-      Sxx = Sxy = Syy = 0.0;
+      Sxx = Sxy = Syy = 0.f;
       if (inb) {
         vis = true;
-        // Frame::jacobian_xyz2uv(xyz_ref) scaled by focal_length / 2^level (:139-140)
-        const double fl = fabs(P.fx) / (double)(1 << level);
-        const double z_inv = 1.0 / Z;
-        const double z_inv_2 = z_inv * z_inv;
-        const double j02 = X * z_inv_2, j12 = Y * z_inv_2;
-        ja[0] = -z_inv * fl;
-        ja[1] = 0.0;
-        ja[2] = j02 * fl;
-        ja[3] = (Y * j02) * fl;
-        ja[4] = -(1.0 + X * j02) * fl;
-        ja[5] = (Y * z_inv) * fl;
-        jb[0] = 0.0;
-        jb[1] = -z_inv * fl;
-        jb[2] = j12 * fl;
-        jb[3] = (1.0 + Y * j12) * fl;
-        jb[4] = -(Y * j02) * fl;
-        jb[5] = -(X * z_inv) * fl;
-
+        gmask = 1.f;
         const float su = u_ref - (float)u_i, sv = v_ref - (float)v_i;
         const float wtl = (float)((1.0 - su) * (1.0 - sv));
         const float wtr = (float)(su * (1.0 - sv));
         const float wbl = (float)((1.0 - su) * sv);
         const float wbr = (float)((double)su * (double)sv);
-
-        float W[7][7];
+        float Bt[6][6];
+        float Wp[7], Wc[7];
+        load_row7(ref_img + (int64_t)(v_i - 3) * pitch, u_i - 3, Wp);
 #pragma unroll
-        for (int r = 0; r < 7; ++r) load_row7(ref_img + (int64_t)(v_i - 3 + r) * pitch, u_i - 3, W[r]);
-        // bilinear image B(r,c) = interpolated reference at window pixel (r,c), r,c in 0..5
-        // patch pixel (y,x) sits at window (y+1, x+1); gradients are central
-        // differences of the interpolated image (:133-136)
-        float Bi[6][6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
+        for (int r = 0; r < 6; ++r) {
+          load_row7(ref_img + (int64_t)(v_i - 2 + r) * pitch, u_i - 3, Wc);
 #pragma unroll
           for (int c = 0; c < 6; ++c) {
-            const bool need = ((r >= 1 && r <= 4) && (c <= 5)) || ((c >= 1 && c <= 4) && (r <= 5));
-            Bi[r][c] = need ? (wtl * W[r][c] + wtr * W[r][c + 1] + wbl * W[r + 1][c] + wbr * W[r + 1][c + 1]) : 0.f;
+            const bool need = ((r >= 1 && r <= 4)) || ((c >= 1 && c <= 4));
+            if (need) Bt[r][c] = wtl * Wp[c] + wtr * Wp[c + 1] + wbl * Wc[c] + wbr * Wc[c + 1];
           }
+#pragma unroll
+          for (int c = 0; c < 7; ++c) Wp[c] = Wc[c];
+        }
 #pragma unroll
         for (int y = 0; y < 4; ++y)
 #pragma unroll
           for (int x = 0; x < 4; ++x) {
-            const int k = y * 4 + x;
-            refv[k] = Bi[y + 1][x + 1];
-            dxv[k] = 0.5f * (Bi[y + 1][x + 2] - Bi[y + 1][x]);
-            dyv[k] = 0.5f * (Bi[y + 2][x + 1] - Bi[y][x + 1]);
+            const float dx = 0.5f * (Bt[y + 1][x + 2] - Bt[y + 1][x]);
+            const float dy = 0.5f * (Bt[y + 2][x + 1] - Bt[y][x + 1]);
+            Sxx += dx * dx;
+            Sxy += dx * dy;
+            Syy += dy * dy;
           }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          Sxx += (double)dxv[k] * (double)dxv[k];
-          Sxy += (double)dxv[k] * (double)dyv[k];
-          Syy += (double)dyv[k] * (double)dyv[k];
-        }
+        s_bt[0][tid] = make_float4(Bt[0][1], Bt[0][2], Bt[0][3], Bt[0][4]);
+        s_bt[1][tid] = make_float4(Bt[1][0], Bt[1][1], Bt[1][2], Bt[1][3]);
+        s_bt[2][tid] = make_float4(Bt[1][4], Bt[1][5], Bt[2][0], Bt[2][1]);
+        s_bt[3][tid] = make_float4(Bt[2][2], Bt[2][3], Bt[2][4], Bt[2][5]);
+        s_bt[4][tid] = make_float4(Bt[3][0], Bt[3][1], Bt[3][2], Bt[3][3]);
+        s_bt[5][tid] = make_float4(Bt[3][4], Bt[3][5], Bt[4][0], Bt[4][1]);
+        s_bt[6][tid] = make_float4(Bt[4][2], Bt[4][3], Bt[4][4], Bt[4][5]);
+        s_bt[7][tid] = make_float4(Bt[5][1], Bt[5][2], Bt[5][3], Bt[5][4]);
       } else {
-        // J column stays zero; a stale ref_patch_cache_ row (if any) is kept
-#pragma unroll
-        for (int k = 0; k < 16; ++k) dxv[k] = dyv[k] = 0.f;
+        // jacobian_cache_.setZero() (:64): the J columns of a feature skipped here
+        // stay zero; a stale ref_patch_cache_ row (if any) is kept
+        gmask = 0.f;
       }
     }
 
     // ---- vk::NLLSSolver::optimizeGaussNewton ------------------------------
-    int inH = -1;  // membership of this lane in the sum that s_H currently holds
+    int inH = -1;  // membership of this lane in the sum that g_s.H currently holds
     int evals = 0;
     for (int iter = 0; iter < P.n_iter; ++iter) {
       // -- computeResiduals (:147-243): this lane's patch -------------------
       bool m = false;
       float gx = 0.f, gy = 0.f, c2 = 0.f;
       if (vis) {
-        const double xc = s_R[0] * X + s_R[1] * Y + s_R[2] * Z + s_t[0];
-        const double yc = s_R[3] * X + s_R[4] * Y + s_R[5] * Z + s_t[1];
-        const double zc = s_R[6] * X + s_R[7] * Y + s_R[8] * Z + s_t[2];
-        // vk::PinholeCamera::world2cam(project2d(xyz))
-        const double pu = P.fx * (xc / zc) + P.cx;
-        const double pv = P.fy * (yc / zc) + P.cy;
+        const double xc = g_s.R[0] * X + g_s.R[1] * Y + g_s.R[2] * Z + g_s.t[0];
+        const double yc = g_s.R[3] * X + g_s.R[4] * Y + g_s.R[5] * Z + g_s.t[1];
+        const double zc = g_s.R[6] * X + g_s.R[7] * Y + g_s.R[8] * Z + g_s.t[2];
+        // vk::PinholeCamera::world2cam(project2d(xyz)), one reciprocal
+        const double izc = 1.0 / zc;
+        const double pu = P.fx * (xc * izc) + P.cx;
+        const double pv = P.fy * (yc * izc) + P.cy;
         const float u_cur = (float)pu * scale;
         const float v_cur = (float)pv * scale;
         const float fu = floorf(u_cur), fv = floorf(v_cur);
@@ -272,161 +433,91 @@ __global__ void __launch_bounds__(BLOCK) sia_kernel(const SiaArgs a) {
           float W[5][5];
 #pragma unroll
           for (int r = 0; r < 5; ++r) load_row5(cur_img + (int64_t)(v_i - 2 + r) * pitch, u_i - 2, W[r]);
+          float Bt[6][6];
+          {
+            const float4 q0 = s_bt[0][tid], q1 = s_bt[1][tid], q2 = s_bt[2][tid], q3 = s_bt[3][tid];
+            const float4 q4 = s_bt[4][tid], q5 = s_bt[5][tid], q6 = s_bt[6][tid], q7 = s_bt[7][tid];
+            Bt[0][0] = Bt[0][5] = Bt[5][0] = Bt[5][5] = 0.f;
+            Bt[0][1] = q0.x; Bt[0][2] = q0.y; Bt[0][3] = q0.z; Bt[0][4] = q0.w;
+            Bt[1][0] = q1.x; Bt[1][1] = q1.y; Bt[1][2] = q1.z; Bt[1][3] = q1.w;
+            Bt[1][4] = q2.x; Bt[1][5] = q2.y; Bt[2][0] = q2.z; Bt[2][1] = q2.w;
+            Bt[2][2] = q3.x; Bt[2][3] = q3.y; Bt[2][4] = q3.z; Bt[2][5] = q3.w;
+            Bt[3][0] = q4.x; Bt[3][1] = q4.y; Bt[3][2] = q4.z; Bt[3][3] = q4.w;
+            Bt[3][4] = q5.x; Bt[3][5] = q5.y; Bt[4][0] = q5.z; Bt[4][1] = q5.w;
+            Bt[4][2] = q6.x; Bt[4][3] = q6.y; Bt[4][4] = q6.z; Bt[4][5] = q6.w;
+            Bt[5][1] = q7.x; Bt[5][2] = q7.y; Bt[5][3] = q7.z; Bt[5][4] = q7.w;
+          }
 #pragma unroll
           for (int y = 0; y < 4; ++y)
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-              const int k = y * 4 + x;
               const float I = wtl * W[y][x] + wtr * W[y][x + 1] + wbl * W[y + 1][x] + wbr * W[y + 1][x + 1];
-              const float res = I - refv[k];
+              const float res = I - Bt[y + 1][x + 1];
               c2 += res * res;
-              gx += res * dxv[k];
-              gy += res * dyv[k];
+              gx += res * (Bt[y + 1][x + 2] - Bt[y + 1][x]);
+              gy += res * (Bt[y + 2][x + 1] - Bt[y][x + 1]);
             }
         }
       }
       // -- workgroup reduction of Jres, chi2, n_meas ------------------------
-      double part[8];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) part[k] = m ? -((double)gx * ja[k] + (double)gy * jb[k]) : 0.0;
-      part[6] = (double)c2;
-      part[7] = m ? 16.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) part[k] = wave_sum(part[k]);
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s_part[wave][k] = part[k];
+      // Jres -= J res with J = dx*a + dy*b, a = fl*jac.row(0), b = fl*jac.row(1)
+      {
+        // dx, dy carry a factor 0.5 (central difference)
+        const float gsc = 0.5f * fl * gmask;
+        const float gxf = m ? gx * gsc : 0.f, gyf = m ? gy * gsc : 0.f;
+        float part[8];
+        part[0] = zi * gxf;
+        part[1] = zi * gyf;
+        part[2] = -zi * (xn * gxf + yn * gyf);
+        part[3] = -(xn * yn * gxf + (1.f + yn * yn) * gyf);
+        part[4] = (1.f + xn * xn) * gxf + xn * yn * gyf;
+        part[5] = xn * gyf - yn * gxf;
+        part[6] = c2;
+        part[7] = m ? 16.f : 0.f;
+        const float tot = wave_reduce8(part, lane);
+        if ((lane & 7) == 0) g_s.part[wave][lane >> 3] = tot;
       }
       const int changed = __syncthreads_or((int)m != inH);
       if (changed) {
-        // the set of patches inside the current image changed: rebuild H
-        double hp[21];
+        // the set of patches inside the current image changed: rebuild H.
+        // H += J J' summed over the patch = Sxx aa' + Sxy (ab'+ba') + Syy bb'
+        const float ja[6] = {-zi * fl, 0.f, xn * zi * fl, xn * yn * fl, -(1.f + xn * xn) * fl, yn * fl};
+        const float jb[6] = {0.f, -zi * fl, yn * zi * fl, (1.f + yn * yn) * fl, -xn * yn * fl, -xn * fl};
+        float hp[24];
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
           for (int j = i; j < 6; ++j) {
-            const double v = Sxx * (ja[i] * ja[j]) + Sxy * (ja[i] * jb[j] + jb[i] * ja[j]) + Syy * (jb[i] * jb[j]);
-            hp[sym6(i, j)] = m ? v : 0.0;
+            const float v = Sxx * (ja[i] * ja[j]) + Sxy * (ja[i] * jb[j] + jb[i] * ja[j]) + Syy * (jb[i] * jb[j]);
+            hp[sym6(i, j)] = m ? v : 0.f;
           }
+        hp[21] = hp[22] = hp[23] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 21; ++k) hp[k] = wave_sum(hp[k]);
-        if (lane == 0) {
-#pragma unroll
-          for (int k = 0; k < 21; ++k) s_Hpart[wave][k] = hp[k];
+        for (int g = 0; g < 3; ++g) {
+          const float tot = wave_reduce8(hp + 8 * g, lane);
+          if ((lane & 7) == 0) g_s.Hpart[wave][8 * g + (lane >> 3)] = tot;
         }
         inH = (int)m;
         __syncthreads();
       }
       ++evals;
-
-      // -- solve / update / stop rules: wave 0, all lanes redundantly -------
-      if (wave == 0) {
-        double tot[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          double v = s_part[0][k];
-#pragma unroll
-          for (int w = 1; w < NW; ++w) v += s_part[w][k];
-          tot[k] = v;
-        }
-        double LD[21];
-        if (changed) {
-          double H[21];
-#pragma unroll
-          for (int k = 0; k < 21; ++k) {
-            double v = s_Hpart[0][k];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) v += s_Hpart[w][k];
-            H[k] = v;
-          }
-          ldlt6_factor(H, LD);
-          if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 21; ++k) {
-              s_H[k] = H[k];
-              s_LD[k] = LD[k];
-            }
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 21; ++k) LD[k] = s_LD[k];
-        }
-        double x[6];
-        ldlt6_solve(LD, tot, x);
-        const int n_meas = (int)tot[7];
-        n_meas_last = n_meas;
-        // return chi2/n_meas_  (float / size_t -> float), :242
-        const double new_chi2 = (double)((float)tot[6] / (float)n_meas);
-        if (isnan(x[0])) stop = 1;  // solve(), :248-249
-        int done = 0;
-        if ((iter > 0 && new_chi2 > chi2_prev) || stop) {
-          // rollback: model = old_model
-          if (lane == 0) {
-            double q[4] = {s_oq[0], s_oq[1], s_oq[2], s_oq[3]};
-            double R[9];
-            quat_to_R(q, R);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s_q[k] = q[k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) s_t[k] = s_ot[k];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) s_R[k] = R[k];
-          }
-          done = 1;
-        } else {
-          // update(): T_new = T_old * SE3::exp(-x_)  (:253-258)
-          double mx[6], eq[4], et[3];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) mx[k] = -x[k];
-          se3_exp(mx, eq, et);
-          double q[4] = {s_q[0], s_q[1], s_q[2], s_q[3]};
-          double t[3] = {s_t[0], s_t[1], s_t[2]};
-          double rt[3], nq[4], R[9];
-          quat_rot(q, et, rt);
-          quat_mul(q, eq, nq);
-          quat_normalize(nq);
-          quat_to_R(nq, R);
-          if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              s_oq[k] = q[k];
-              s_q[k] = nq[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              s_ot[k] = t[k];
-              s_t[k] = t[k] + rt[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 9; ++k) s_R[k] = R[k];
-          }
-          chi2_prev = new_chi2;
-          double nm = 0.0;  // vk::norm_max(x_) <= eps_
-#pragma unroll
-          for (int k = 0; k < 6; ++k) nm = fmax(nm, fabs(x[k]));
-          if (nm <= P.eps) done = 1;
-        }
-        if (lane == 0) s_done = done;
-      }
+      if (wave == 0) sia_gauss_newton_step(lane, NW, changed, iter, P.eps);
       __syncthreads();
-      if (s_done) break;
+      if (g_s.done) break;
     }
     if (tid == 0 && a.iters) a.iters[SVO_HIP_MAX_LEVELS * b + level] = evals;
-    __syncthreads();  // s_done / model are re-used by the next level
+    __syncthreads();  // done / model are re-used by the next level
   }
 
   if (tid == 0) {
-    double q[4] = {s_q[0], s_q[1], s_q[2], s_q[3]};
-    double R[9];
-    quat_to_R(q, R);
-    for (int k = 0; k < 9; ++k) a.T_out[12 * b + k] = R[k];
-    for (int k = 0; k < 3; ++k) a.T_out[12 * b + 9 + k] = s_t[k];
+    for (int k = 0; k < 9; ++k) a.T_out[12 * b + k] = g_s.R[k];
+    for (int k = 0; k < 3; ++k) a.T_out[12 * b + 9 + k] = g_s.t[k];
     if (a.H_out)
       for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) a.H_out[36 * b + i * 6 + j] = s_H[sym6(i, j)];
-    a.n_tracked[b] = n_meas_last / 16;
-    if (a.chi2) a.chi2[b] = chi2_prev;
-    if (a.status) a.status[b] = stop ? SVO_HIP_SIA_STOP : 0;
+        for (int j = 0; j < 6; ++j) a.H_out[36 * b + i * 6 + j] = g_s.H[sym6_rt(i, j)];
+    a.n_tracked[b] = g_s.n_meas / 16;
+    if (a.chi2) a.chi2[b] = g_s.chi2;
+    if (a.status) a.status[b] = g_s.stop ? SVO_HIP_SIA_STOP : 0;
   }
 }
 
