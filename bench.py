@@ -77,6 +77,7 @@ def main() -> None:
     ap.add_argument("--noise", type=float, default=0.0, help="image noise sigma (gray levels)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="frames timed on the host for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--n-iter", type=int, default=30, help="Gauss-Newton iteration cap per level (30 in the pipeline)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,7 +125,7 @@ def main() -> None:
     px_t = px_all.contiguous()
     xyz_t = tdev(xyz_ref, torch.float64)
     T_in = tdev(T_cr, torch.float64)
-    sia = SparseImgAlign(max_level, min_level, 30)
+    sia = SparseImgAlign(max_level, min_level, args.n_iter)
     out = sia.alloc_result(B, dev)
     gathered = torch.empty(world * B, 12, dtype=torch.float64, device=dev) if world > 1 else None
     torch.cuda.synchronize()
@@ -212,7 +213,7 @@ def main() -> None:
         "config": {
             "workload": args.workload, "image": f"{width}x{height}", "pyr_levels": n_levels,
             "schedule": f"levels {max_level}->{min_level}", "patches_per_frame": n_patches,
-            "frames_per_step_per_gpu": B, "n_iter_cap": 30, "image_noise_sigma": args.noise,
+            "frames_per_step_per_gpu": B, "n_iter_cap": args.n_iter, "image_noise_sigma": args.noise,
             "parallelism": f"frames sharded 1 rank/GPU x{world}" + (", RCCL all_gather of poses" if world > 1 else ""),
             "mean_gn_iterations_per_frame": float(iters.sum(1).mean()),
             "mean_tracked_patches": float(n_tracked.mean()),
@@ -257,11 +258,11 @@ def cpu_baseline(args, cam, images, T_gt, px_all, f_all, pos_all, T_ref_w, T_pri
     s1 = min(S, 512)
     t0 = time.perf_counter()
     pyoracle.sparse_img_align_batch(pyrs, rs[:s1], cs[:s1], cam, T_ref_w[:s1], T_prior_w[:s1], nn[:s1], px[:s1],
-                                    f[:s1], hp[:s1], pos[:s1], max_level, min_level, 30, n_threads=1)
+                                    f[:s1], hp[:s1], pos[:s1], max_level, min_level, args.n_iter, n_threads=1)
     t1 = time.perf_counter() - t0
     t0 = time.perf_counter()
     T_cpu, res = pyoracle.sparse_img_align_batch(pyrs, rs, cs, cam, T_ref_w[:S], T_prior_w[:S], nn, px, f, hp, pos,
-                                                 max_level, min_level, 30, n_threads=cores)
+                                                 max_level, min_level, args.n_iter, n_threads=cores)
     tn = time.perf_counter() - t0
     d = se3.log_norm(T_est_w[:S], T_cpu)
     pos_gpu = se3.inv(T_est_w[:S])[:, 9:]

@@ -15,7 +15,7 @@ MAX_PATCHES = 1024
 HALFSAMPLE_SCALAR, HALFSAMPLE_SSE2, HALFSAMPLE_AUTO = 0, 1, 2
 SIA_STOP = 1
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsvo_hip.so")
+_LIB_PATH = os.environ.get("SVO_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsvo_hip.so")
 
 
 class SvoHipError(RuntimeError):

@@ -163,6 +163,87 @@ __device__ __forceinline__ void se3_exp(const double xi[6], double q[4], double 
   }
 }
 
+// SE3::exp for a Gauss-Newton increment, in f32 and without sqrt/divisions: the four
+// scalar functions of theta that Sophus::SE3::exp evaluates,
+//   sin(th/2)/th, cos(th/2), (1-cos th)/th^2, (th-sin th)/th^3,
+// are entire in th^2; nine-term Horner forms are exact to f32 rounding for th <= 2 rad
+// and stay finite beyond (steps of that size only occur once an alignment has
+// diverged).  The increment is tiny against the f64 pose it is composed with, so
+// f32 here perturbs an iterate by <= 1e-7 of the step, which Gauss-Newton absorbs.
+__device__ __forceinline__ void se3_exp_f32(const float xi[6], float q[4], float t[3]) {
+  const float ox = xi[3], oy = xi[4], oz = xi[5];
+  const float z = ox * ox + oy * oy + oz * oz;  // theta^2
+  const float y = 0.25f * z;                    // (theta/2)^2
+  // sinc(th/2) = sum (-1)^k y^k/(2k+1)!,  cos(th/2) = sum (-1)^k y^k/(2k)!
+  float a = 1.f / 355687428096000.f;
+  a = a * -y + 1.f / 1307674368000.f;
+  a = a * -y + 1.f / 6227020800.f;
+  a = a * -y + 1.f / 39916800.f;
+  a = a * -y + 1.f / 362880.f;
+  a = a * -y + 1.f / 5040.f;
+  a = a * -y + 1.f / 120.f;
+  a = a * -y + 1.f / 6.f;
+  a = a * -y + 1.f;
+  float w = 1.f / 20922789888000.f;
+  w = w * -y + 1.f / 87178291200.f;
+  w = w * -y + 1.f / 479001600.f;
+  w = w * -y + 1.f / 3628800.f;
+  w = w * -y + 1.f / 40320.f;
+  w = w * -y + 1.f / 720.f;
+  w = w * -y + 1.f / 24.f;
+  w = w * -y + 0.5f;
+  w = w * -y + 1.f;
+  // (1-cos th)/th^2 = sum (-1)^k z^k/(2k+2)!,  (th-sin th)/th^3 = sum (-1)^k z^k/(2k+3)!
+  float c1 = 1.f / 6402373705728000.f;
+  c1 = c1 * -z + 1.f / 20922789888000.f;
+  c1 = c1 * -z + 1.f / 87178291200.f;
+  c1 = c1 * -z + 1.f / 479001600.f;
+  c1 = c1 * -z + 1.f / 3628800.f;
+  c1 = c1 * -z + 1.f / 40320.f;
+  c1 = c1 * -z + 1.f / 720.f;
+  c1 = c1 * -z + 1.f / 24.f;
+  c1 = c1 * -z + 0.5f;
+  float c2 = 1.f / 121645100408832000.f;
+  c2 = c2 * -z + 1.f / 355687428096000.f;
+  c2 = c2 * -z + 1.f / 1307674368000.f;
+  c2 = c2 * -z + 1.f / 6227020800.f;
+  c2 = c2 * -z + 1.f / 39916800.f;
+  c2 = c2 * -z + 1.f / 362880.f;
+  c2 = c2 * -z + 1.f / 5040.f;
+  c2 = c2 * -z + 1.f / 120.f;
+  c2 = c2 * -z + 1.f / 6.f;
+  const float imag = 0.5f * a;
+  q[0] = w;
+  q[1] = imag * ox;
+  q[2] = imag * oy;
+  q[3] = imag * oz;
+  const float ux = xi[0], uy = xi[1], uz = xi[2];
+  const float wx = oy * uz - oz * uy, wy = oz * ux - ox * uz, wz = ox * uy - oy * ux;
+  const float wwx = oy * wz - oz * wy, wwy = oz * wx - ox * wz, wwz = ox * wy - oy * wx;
+  t[0] = ux + c1 * wx + c2 * wwx;
+  t[1] = uy + c1 * wy + c2 * wwy;
+  t[2] = uz + c1 * wz + c2 * wwz;
+}
+
+// q <- q / |q| for a quaternion that is already close to unit length or not:
+// v_rsq_f64 seed + two Newton steps (no f64 sqrt / division sequences).
+__device__ __forceinline__ void quat_normalize_fast(double q[4]) {
+  const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  double r = __builtin_amdgcn_rsq(n2);
+  r = r * (1.5 - 0.5 * n2 * r * r);
+  r = r * (1.5 - 0.5 * n2 * r * r);
+  q[0] *= r; q[1] *= r; q[2] *= r; q[3] *= r;
+}
+
+// broadcast lane `src` (compile-time constant) of a double to the whole wave (SGPRs)
+template <int SRC>
+__device__ __forceinline__ double readlane_f64(double v) {
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, SRC);
+  const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), SRC);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
 // index into the packed upper triangle of a symmetric 6x6 (row-major, i<=j)
 __host__ __device__ constexpr int sym6(int i, int j) {
   return (i <= j) ? (i * 6 - (i * (i - 1)) / 2 + (j - i)) : (j * 6 - (j * (j - 1)) / 2 + (i - j));

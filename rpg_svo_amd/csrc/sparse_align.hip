@@ -97,34 +97,28 @@ __device__ __forceinline__ void load_row7(const uint8_t* __restrict__ row, int x
 #define MINW 4  // waves per SIMD asked of the register allocator (4 x 256-lane workgroups per CU)
 #endif
 
-#ifndef SIA_STEP_INLINE
-#define SIA_STEP_INLINE __forceinline__
-#endif
-
 constexpr int MAX_WAVES = SVO_HIP_MAX_PATCHES / 64;
 
-// Workgroup state.  File-scope LDS so that the serial Gauss-Newton step can live in
-// a non-inlined function: inlined, its f64 polynomial constants and address
-// arithmetic get hoisted out of the loops and push the hot per-lane patch tile into
-// scratch.
+// Gauss-Newton state of one wave.  Every wave of the workgroup runs the (cheap)
+// solve/update step redundantly on the same workgroup totals, so all copies stay
+// bit-identical and no wave ever waits for another one's result.
+struct WaveModel {
+  double q[4], t[3];    // model: T_cur_from_ref as Sophus stores it (unit quaternion + t)
+  double oq[4], ot[3];  // old_model (rollback)
+};
+
+// Workgroup state (file-scope LDS).
 struct SiaLds {
-  double q[4], t[3];          // model: T_cur_from_ref as Sophus stores it (unit quaternion + t)
-  double R[9];                // rotation matrix of q (what the lanes project with)
-  double oq[4], ot[3];        // old_model (rollback)
-  double H[21];               // H_ of the last evaluated iteration (packed upper triangle)
-  double Hinv[36];            // its inverse, row-major
-  double A[36];               // Gauss-Jordan scratch
-  double tot[8];              // workgroup totals: Jres[6], chi2, n_meas
-  double chi2;                // vk::NLLSSolver::chi2_
-  float part[MAX_WAVES][8];   // per-wave partials of tot
-  float Hpart[MAX_WAVES][24]; // per-wave partials of H (21 used)
+  WaveModel wm[MAX_WAVES];
+  double H[21];                  // H_ of the last evaluated iteration (packed upper triangle)
+  double Hinv[36];               // its inverse, row-major
+  double A[36];                  // Gauss-Jordan scratch
+  float part[2][MAX_WAVES][8];   // per-wave partials of Jres[6], chi2, n_meas (double-buffered)
+  float Hpart[MAX_WAVES][24];    // per-wave partials of H (21 used)
   long long lo[SVO_HIP_MAX_LEVELS];  // pyramid geometry per level (copied from the kernel
   int lw[SVO_HIP_MAX_LEVELS];        // arguments so the level loop can index it dynamically)
   int lh[SVO_HIP_MAX_LEVELS];
   int lp[SVO_HIP_MAX_LEVELS];
-  int done;                   // level finished
-  int stop;                   // vk::NLLSSolver::stop_
-  int n_meas;                 // n_meas_ of the last evaluated iteration
 };
 __shared__ SiaLds g_s;
 
@@ -133,124 +127,41 @@ __device__ __forceinline__ int sym6_rt(int i, int j) {
   return a * 6 - (a * (a - 1)) / 2 + (b - a);
 }
 
-// solve() / update() and the stop / rollback rules of
-// vk::NLLSSolver::optimizeGaussNewton (sparse_img_align.cpp:245-258), executed by
-// wave 0 after the workgroup reduction.  Same-wave LDS traffic only: DS
-// instructions of one wave execute in order; the wavefront-scope fences stop the
-// compiler from moving accesses across the exchange points.
-__device__ SIA_STEP_INLINE void sia_gauss_newton_step(int lane, int nw, int changed, int iter, double eps) {
-  // opaque lane: keeps this block's address arithmetic from being hoisted out of the
-  // caller's loops when the function is inlined
-  asm volatile("" : "+v"(lane));
-  if (changed) {
-    // H = sum of the per-wave partials (lanes 0..20), then H^-1 by Gauss-Jordan on a
-    // 6x6 tile held one element per lane (36 lanes), LDS as the row/column exchange.
-    // Runs once per level (or when the set of patches inside the image changes).
-    if (lane < 21) {
-      double v = 0.0;
-      for (int w = 0; w < nw; ++w) v += (double)g_s.Hpart[w][lane];
-      g_s.H[lane] = v;
-    }
+// H = sum of the per-wave partials, then H^-1 by Gauss-Jordan on a 6x6 tile held one
+// element per lane (36 lanes), LDS as the row/column exchange.  Wave 0 only; runs
+// once per level (or when the set of patches inside the current image changes).
+// Same-wave LDS traffic: DS instructions of one wave execute in order; the
+// wavefront-scope fences stop the compiler from moving accesses across the exchanges.
+__device__ __forceinline__ void sia_rebuild_hinv(int lane, int nw) {
+  asm volatile("" : "+v"(lane));  // keep this cold block's address math out of the caller's loops
+  if (lane < 21) {
+    double v = 0.0;
+    for (int w = 0; w < nw; ++w) v += (double)g_s.Hpart[w][lane];
+    g_s.H[lane] = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int gi = lane / 6, gj = lane - 6 * gi;
+  if (lane < 36) {
+    g_s.A[lane] = g_s.H[sym6_rt(gi, gj)];
+    g_s.Hinv[lane] = (gi == gj) ? 1.0 : 0.0;
+  }
+  for (int k = 0; k < 6; ++k) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const int gi = lane / 6, gj = lane - 6 * gi;
     if (lane < 36) {
-      g_s.A[lane] = g_s.H[sym6_rt(gi, gj)];
-      g_s.Hinv[lane] = (gi == gj) ? 1.0 : 0.0;
-    }
-    for (int k = 0; k < 6; ++k) {
+      const double p = g_s.A[k * 6 + k];
+      const double aik = g_s.A[gi * 6 + k];
+      const double akj = g_s.A[k * 6 + gj];
+      const double bkj = g_s.Hinv[k * 6 + gj];
+      const double aij = g_s.A[lane];
+      const double bij = g_s.Hinv[lane];
+      // a zero pivot contributes nothing, like the D^-1 step of Eigen's LDLT::solve
+      const double ip = (fabs(p) > 2.2250738585072014e-308) ? 1.0 / p : 0.0;
+      const double na = (gi == k) ? akj * ip : aij - aik * (akj * ip);
+      const double nb = (gi == k) ? bkj * ip : bij - aik * (bkj * ip);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      if (lane < 36) {
-        const double p = g_s.A[k * 6 + k];
-        const double aik = g_s.A[gi * 6 + k];
-        const double akj = g_s.A[k * 6 + gj];
-        const double bkj = g_s.Hinv[k * 6 + gj];
-        const double aij = g_s.A[lane];
-        const double bij = g_s.Hinv[lane];
-        // a zero pivot contributes nothing, like the D^-1 step of Eigen's LDLT::solve
-        const double ip = (fabs(p) > 2.2250738585072014e-308) ? 1.0 / p : 0.0;
-        const double na = (gi == k) ? akj * ip : aij - aik * (akj * ip);
-        const double nb = (gi == k) ? bkj * ip : bij - aik * (bkj * ip);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        g_s.A[lane] = na;
-        g_s.Hinv[lane] = nb;
-      }
+      g_s.A[lane] = na;
+      g_s.Hinv[lane] = nb;
     }
-  }
-  // Jres, chi2, n_meas: lanes 0..7 sum their column over the waves
-  if (lane < 8) {
-    double v = 0.0;
-    for (int w = 0; w < nw; ++w) v += (double)g_s.part[w][lane];
-    g_s.tot[lane] = v;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  double tot[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) tot[k] = g_s.tot[k];
-  // x_ = H_.ldlt().solve(Jres_)  (:247), here x = H^-1 Jres (all lanes redundantly)
-  double x[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    double v = 0.0;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) v += g_s.Hinv[i * 6 + j] * tot[j];
-    x[i] = v;
-  }
-  const int n_meas = (int)tot[7];
-  // return chi2/n_meas_  (float / size_t -> float), :242
-  const double new_chi2 = (double)((float)tot[6] / (float)n_meas);
-  int stop = g_s.stop;
-  if (isnan(x[0])) stop = 1;  // solve(), :248-249
-  const double chi2_prev = g_s.chi2;
-  int done = 0;
-  double q[4], t[3], oq[4], ot[3], R[9];
-  double chi2_out = chi2_prev;
-  if ((iter > 0 && new_chi2 > chi2_prev) || stop) {
-    // rollback: model = old_model
-#pragma unroll
-    for (int k = 0; k < 4; ++k) q[k] = oq[k] = g_s.oq[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) t[k] = ot[k] = g_s.ot[k];
-    done = 1;
-  } else {
-    // update(): T_new = T_old * SE3::exp(-x_)  (:253-258)
-    double mx[6], eq[4], et[3], rt[3];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) mx[k] = -x[k];
-    se3_exp(mx, eq, et);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) oq[k] = g_s.q[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) ot[k] = g_s.t[k];
-    quat_rot(oq, et, rt);
-    quat_mul(oq, eq, q);
-    quat_normalize(q);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) t[k] = ot[k] + rt[k];
-    chi2_out = new_chi2;
-    double nm = 0.0;  // vk::norm_max(x_) <= eps_
-#pragma unroll
-    for (int k = 0; k < 6; ++k) nm = fmax(nm, fabs(x[k]));
-    if (nm <= eps) done = 1;
-  }
-  quat_to_R(q, R);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      g_s.q[k] = q[k];
-      g_s.oq[k] = oq[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      g_s.t[k] = t[k];
-      g_s.ot[k] = ot[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) g_s.R[k] = R[k];
-    g_s.chi2 = chi2_out;
-    g_s.stop = stop;
-    g_s.n_meas = n_meas;
-    g_s.done = done;
   }
 }
 
@@ -261,6 +172,15 @@ __global__ void __launch_bounds__(BLOCK, MINW) sia_kernel(const SiaArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+
+  // Interpolated reference image around this lane's patch, staged in LDS: the
+  // bilinear sample at window pixel (r,c) of the 6x6 neighbourhood (corners unused
+  // -> 32 floats = 8 float4 per lane, laid out [8][BLOCK] so a wave reads 1 KiB
+  // contiguous per ds_read_b128).  ref_patch_cache_(y,x) = Bt[y+1][x+1]; the gradients
+  // dx,dy (:133-136) are central differences of Bt, rebuilt in flight.
+  //   q0 = r0 c1..4 | q1 = r1 c0..3 | q2 = r1 c4,5 r2 c0,1 | q3 = r2 c2..5
+  //   q4 = r3 c0..3 | q5 = r3 c4,5 r4 c0,1 | q6 = r4 c2..5 | q7 = r5 c1..4
+  __shared__ float4 s_bt[8][BLOCK];
 
   const int n = a.n[b];
   const svo_hip_sia_params P = a.P;
@@ -304,31 +224,30 @@ __global__ void __launch_bounds__(BLOCK, MINW) sia_kernel(const SiaArgs a) {
       g_s.lp[k] = a.L.pitch[k];
       g_s.lo[k] = a.L.offset[k];
     }
-    double R[9], q[4];
-    for (int k = 0; k < 9; ++k) R[k] = a.T_in[12 * b + k];
-    quat_from_R(R, q);
-    quat_to_R(q, R);
-    for (int k = 0; k < 4; ++k) g_s.q[k] = g_s.oq[k] = q[k];
-    for (int k = 0; k < 3; ++k) g_s.t[k] = g_s.ot[k] = a.T_in[12 * b + 9 + k];
-    for (int k = 0; k < 9; ++k) g_s.R[k] = R[k];
     for (int k = 0; k < 21; ++k) g_s.H[k] = 0.0;
-    // vk::NLLSSolver::reset()
-    g_s.chi2 = 1e10;
-    g_s.stop = 0;
-    g_s.n_meas = 0;
-    g_s.done = 0;
     if (a.iters)
       for (int k = 0; k < SVO_HIP_MAX_LEVELS; ++k) a.iters[SVO_HIP_MAX_LEVELS * b + k] = 0;
   }
+  // model of this wave: every lane computes the same values, lane 0 stores them
+  double R[9], tr[3];
+  {
+    double q[4];
+    for (int k = 0; k < 9; ++k) R[k] = a.T_in[12 * b + k];
+    for (int k = 0; k < 3; ++k) tr[k] = a.T_in[12 * b + 9 + k];
+    quat_from_R(R, q);
+    quat_to_R(q, R);
+    if (lane == 0) {
+      WaveModel& wm = g_s.wm[wave];
+      for (int k = 0; k < 4; ++k) wm.q[k] = wm.oq[k] = q[k];
+      for (int k = 0; k < 3; ++k) wm.t[k] = wm.ot[k] = tr[k];
+    }
+  }
+  // vk::NLLSSolver::reset(): wave-uniform solver state
+  double chi2_prev = 1e10;
+  int stop = 0;
+  int n_meas_last = 0;
+  int buf = 0;  // which half of g_s.part this iteration writes
 
-  // Interpolated reference image around this lane's patch, staged in LDS: the
-  // bilinear sample at window pixel (r,c) of the 6x6 neighbourhood (corners unused
-  // -> 32 floats = 8 float4 per lane, laid out [8][BLOCK] so a wave reads 1 KiB
-  // contiguous per ds_read_b128).  ref_patch_cache_(y,x) = Bt[y+1][x+1]; the gradients
-  // dx,dy (:133-136) are central differences of Bt, rebuilt in flight.
-  //   q0 = r0 c1..4 | q1 = r1 c0..3 | q2 = r1 c4,5 r2 c0,1 | q3 = r2 c2..5
-  //   q4 = r3 c0..3 | q5 = r3 c4,5 r4 c0,1 | q6 = r4 c2..5 | q7 = r5 c1..4
-  __shared__ float4 s_bt[8][BLOCK];
   float Sxx = 0.f, Sxy = 0.f, Syy = 0.f;
   float gmask = 0.f;  // 0 while this lane's Jacobian columns are zero at this level
   bool vis = false;   // visible_fts_[i]; never cleared between levels (:57)
@@ -411,9 +330,9 @@ __global__ void __launch_bounds__(BLOCK, MINW) sia_kernel(const SiaArgs a) {
       bool m = false;
       float gx = 0.f, gy = 0.f, c2 = 0.f;
       if (vis) {
-        const double xc = g_s.R[0] * X + g_s.R[1] * Y + g_s.R[2] * Z + g_s.t[0];
-        const double yc = g_s.R[3] * X + g_s.R[4] * Y + g_s.R[5] * Z + g_s.t[1];
-        const double zc = g_s.R[6] * X + g_s.R[7] * Y + g_s.R[8] * Z + g_s.t[2];
+        const double xc = R[0] * X + R[1] * Y + R[2] * Z + tr[0];
+        const double yc = R[3] * X + R[4] * Y + R[5] * Z + tr[1];
+        const double zc = R[6] * X + R[7] * Y + R[8] * Z + tr[2];
         // vk::PinholeCamera::world2cam(project2d(xyz)), one reciprocal
         const double izc = 1.0 / zc;
         const double pu = P.fx * (xc * izc) + P.cx;
@@ -432,7 +351,12 @@ __global__ void __launch_bounds__(BLOCK, MINW) sia_kernel(const SiaArgs a) {
           const float wbr = (float)((double)su * (double)sv);
           float W[5][5];
 #pragma unroll
+#ifdef SIA_DBG_NOLOAD
+          for (int r = 0; r < 5; ++r)
+            for (int c = 0; c < 5; ++c) W[r][c] = su * (float)(r * 5 + c);
+#else
           for (int r = 0; r < 5; ++r) load_row5(cur_img + (int64_t)(v_i - 2 + r) * pitch, u_i - 2, W[r]);
+#endif
           float Bt[6][6];
           {
             const float4 q0 = s_bt[0][tid], q1 = s_bt[1][tid], q2 = s_bt[2][tid], q3 = s_bt[3][tid];
@@ -475,8 +399,9 @@ __global__ void __launch_bounds__(BLOCK, MINW) sia_kernel(const SiaArgs a) {
         part[6] = c2;
         part[7] = m ? 16.f : 0.f;
         const float tot = wave_reduce8(part, lane);
-        if ((lane & 7) == 0) g_s.part[wave][lane >> 3] = tot;
+        if ((lane & 7) == 0) g_s.part[buf][wave][lane >> 3] = tot;
       }
+      // the one workgroup barrier of an iteration
       const int changed = __syncthreads_or((int)m != inH);
       if (changed) {
         // the set of patches inside the current image changed: rebuild H.
@@ -499,25 +424,102 @@ __global__ void __launch_bounds__(BLOCK, MINW) sia_kernel(const SiaArgs a) {
         }
         inH = (int)m;
         __syncthreads();
+        if (wave == 0) sia_rebuild_hinv(lane, NW);
+        __syncthreads();
       }
       ++evals;
-      if (wave == 0) sia_gauss_newton_step(lane, NW, changed, iter, P.eps);
-      __syncthreads();
-      if (g_s.done) break;
+
+      // -- solve() / update() and the stop / rollback rules of
+      //    vk::NLLSSolver::optimizeGaussNewton (:245-258): every wave, redundantly --
+      int done = 0;
+#ifndef SIA_DBG_NOSOLVE
+      {
+        // totals over the waves: lane k (<8) owns column k
+        double colsum = 0.0;
+        {
+          const int k = lane & 7;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) colsum += (double)g_s.part[buf][w][k];
+        }
+        const double b0 = readlane_f64<0>(colsum), b1 = readlane_f64<1>(colsum), b2 = readlane_f64<2>(colsum);
+        const double b3 = readlane_f64<3>(colsum), b4 = readlane_f64<4>(colsum), b5 = readlane_f64<5>(colsum);
+        const float chi2_sum = (float)readlane_f64<6>(colsum);
+        const int n_meas = (int)readlane_f64<7>(colsum);
+        // x_ = H_.ldlt().solve(Jres_) (:247), here x = H^-1 Jres: lane i (<6) owns row i
+        double xi;
+        {
+          const double* row = &g_s.Hinv[6 * (lane < 6 ? lane : 0)];
+          xi = row[0] * b0 + row[1] * b1 + row[2] * b2 + row[3] * b3 + row[4] * b4 + row[5] * b5;
+        }
+        const double x0 = readlane_f64<0>(xi), x1 = readlane_f64<1>(xi), x2 = readlane_f64<2>(xi);
+        const double x3 = readlane_f64<3>(xi), x4 = readlane_f64<4>(xi), x5 = readlane_f64<5>(xi);
+        n_meas_last = n_meas;
+        // return chi2/n_meas_  (float / size_t -> float), :242
+        const double new_chi2 = (double)(chi2_sum / (float)n_meas);
+        if (isnan(x0)) stop = 1;  // solve(), :248-249
+        WaveModel& wm = g_s.wm[wave];
+        double q[4];
+        if ((iter > 0 && new_chi2 > chi2_prev) || stop) {
+          // rollback: model = old_model
+#pragma unroll
+          for (int k = 0; k < 4; ++k) q[k] = wm.oq[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) tr[k] = wm.ot[k];
+          done = 1;
+        } else {
+          // update(): T_new = T_old * SE3::exp(-x_)  (:253-258)
+          const float mx[6] = {-(float)x0, -(float)x1, -(float)x2, -(float)x3, -(float)x4, -(float)x5};
+          float eqf[4], etf[3];
+          se3_exp_f32(mx, eqf, etf);
+          const double eq[4] = {eqf[0], eqf[1], eqf[2], eqf[3]};
+          const double et[3] = {etf[0], etf[1], etf[2]};
+          double oq[4], ot[3], rt[3];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) oq[k] = wm.q[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) ot[k] = wm.t[k];
+          quat_rot(oq, et, rt);
+          quat_mul(oq, eq, q);
+          quat_normalize_fast(q);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) tr[k] = ot[k] + rt[k];
+          if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wm.oq[k] = oq[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wm.ot[k] = ot[k];
+          }
+          chi2_prev = new_chi2;
+          // vk::norm_max(x_) <= eps_
+          const double nm = fmax(fmax(fmax(fabs(x0), fabs(x1)), fmax(fabs(x2), fabs(x3))), fmax(fabs(x4), fabs(x5)));
+          if (nm <= P.eps) done = 1;
+        }
+        quat_to_R(q, R);
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) wm.q[k] = q[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) wm.t[k] = tr[k];
+        }
+      }
+#endif
+      buf ^= 1;
+#ifndef SIA_DBG_FIXED_ITERS
+      if (done) break;
+#endif
     }
     if (tid == 0 && a.iters) a.iters[SVO_HIP_MAX_LEVELS * b + level] = evals;
-    __syncthreads();  // done / model are re-used by the next level
   }
 
   if (tid == 0) {
-    for (int k = 0; k < 9; ++k) a.T_out[12 * b + k] = g_s.R[k];
-    for (int k = 0; k < 3; ++k) a.T_out[12 * b + 9 + k] = g_s.t[k];
+    for (int k = 0; k < 9; ++k) a.T_out[12 * b + k] = R[k];
+    for (int k = 0; k < 3; ++k) a.T_out[12 * b + 9 + k] = tr[k];
     if (a.H_out)
       for (int i = 0; i < 6; ++i)
         for (int j = 0; j < 6; ++j) a.H_out[36 * b + i * 6 + j] = g_s.H[sym6_rt(i, j)];
-    a.n_tracked[b] = g_s.n_meas / 16;
-    if (a.chi2) a.chi2[b] = g_s.chi2;
-    if (a.status) a.status[b] = g_s.stop ? SVO_HIP_SIA_STOP : 0;
+    a.n_tracked[b] = n_meas_last / 16;
+    if (a.chi2) a.chi2[b] = chi2_prev;
+    if (a.status) a.status[b] = stop ? SVO_HIP_SIA_STOP : 0;
   }
 }
 

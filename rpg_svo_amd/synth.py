@@ -135,6 +135,9 @@ def select_features(images: torch.Tensor, n_feat: int, margin: int = 28, cell: i
     """Per image: strongest-gradient pixel of each cell x cell grid cell, then the
     n_feat best cells (FAST/Shi-Tomasi grid stand-in, svo/src/feature_detection.cpp
     :66-114).  Returns float64 [n, n_feat, 2] level-0 pixel coordinates (u, v)."""
+    if images.shape[0] > 256:  # bound peak memory for large replay batches
+        return torch.cat([select_features(images[i:i + 256], n_feat, margin, cell)
+                          for i in range(0, images.shape[0], 256)], dim=0)
     n, h, w = images.shape
     img = images.float()
     gx = torch.zeros_like(img)
