@@ -19,38 +19,32 @@ __device__ __forceinline__ void quat_to_R(const double q[4], double R[9]) {
   R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
 }
 
-// Eigen Quaternion(Matrix3).  Branchy but only run once per problem.
+// Eigen Quaternion(Matrix3).  The four cases of Eigen's algorithm (trace > 0, or the
+// largest diagonal element i with j=(i+1)%3, k=(j+1)%3) are evaluated with selects so
+// the result stays in registers (an array indexed by i would live in scratch).
 __device__ __forceinline__ void quat_from_R(const double R[9], double q[4]) {
-  double t = R[0] + R[4] + R[8];
-  if (t > 0.0) {
-    t = sqrt(t + 1.0);
-    q[0] = 0.5 * t;
-    t = 0.5 / t;
-    q[1] = (R[7] - R[5]) * t;
-    q[2] = (R[2] - R[6]) * t;
-    q[3] = (R[3] - R[1]) * t;
-  } else if (R[0] >= R[4] && R[0] >= R[8]) {  // i=0, j=1, k=2
-    t = sqrt(R[0] - R[4] - R[8] + 1.0);
-    q[1] = 0.5 * t;
-    t = 0.5 / t;
-    q[0] = (R[7] - R[5]) * t;
-    q[2] = (R[3] + R[1]) * t;
-    q[3] = (R[6] + R[2]) * t;
-  } else if (R[4] > R[0] && R[4] >= R[8]) {  // i=1, j=2, k=0
-    t = sqrt(R[4] - R[8] - R[0] + 1.0);
-    q[2] = 0.5 * t;
-    t = 0.5 / t;
-    q[0] = (R[2] - R[6]) * t;
-    q[3] = (R[7] + R[5]) * t;
-    q[1] = (R[1] + R[3]) * t;
-  } else {  // i=2, j=0, k=1
-    t = sqrt(R[8] - R[0] - R[4] + 1.0);
-    q[3] = 0.5 * t;
-    t = 0.5 / t;
-    q[0] = (R[3] - R[1]) * t;
-    q[1] = (R[2] + R[6]) * t;
-    q[2] = (R[5] + R[7]) * t;
-  }
+  const double tr = R[0] + R[4] + R[8];
+  // Eigen: i = 0; if (m11 > m00) i = 1; if (m22 > m_ii) i = 2;
+  const bool i1 = R[4] > R[0];
+  const double mii = i1 ? R[4] : R[0];
+  const bool i2 = R[8] > mii;
+  const int i = i2 ? 2 : (i1 ? 1 : 0);
+  // s = the quantity under the square root in each case
+  const double s_tr = tr + 1.0;
+  const double s_0 = R[0] - R[4] - R[8] + 1.0;
+  const double s_1 = R[4] - R[8] - R[0] + 1.0;
+  const double s_2 = R[8] - R[0] - R[4] + 1.0;
+  const bool pos = tr > 0.0;
+  const double sq = sqrt(pos ? s_tr : (i == 0 ? s_0 : (i == 1 ? s_1 : s_2)));
+  const double big = 0.5 * sq;   // the component computed from the square root
+  const double f = 0.5 / sq;
+  // antisymmetric / symmetric off-diagonal combinations
+  const double a21 = R[7] - R[5], a02 = R[2] - R[6], a10 = R[3] - R[1];
+  const double s10 = R[3] + R[1], s20 = R[6] + R[2], s21 = R[7] + R[5];
+  q[0] = pos ? big : (i == 0 ? a21 * f : (i == 1 ? a02 * f : a10 * f));
+  q[1] = pos ? a21 * f : (i == 0 ? big : (i == 1 ? s10 * f : s20 * f));
+  q[2] = pos ? a02 * f : (i == 0 ? s10 * f : (i == 1 ? big : s21 * f));
+  q[3] = pos ? a10 * f : (i == 0 ? s20 * f : (i == 1 ? s21 * f : big));
 }
 
 __device__ __forceinline__ void quat_mul(const double a[4], const double b[4], double o[4]) {

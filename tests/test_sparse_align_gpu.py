@@ -161,6 +161,24 @@ def test_zero_motion_fixed_point(oracle, gpu_device, seq_vga):
     assert se3.log_norm(T_h, T_o).max() < 1e-7
 
 
+def test_prior_rotation_roundtrip_all_quaternion_branches(gpu_device, seq_vga):
+    """n_iter = 0: the kernel only converts the prior R -> unit quaternion -> R (as
+    Sophus::SE3(R,t) would).  Random large rotations exercise all four branches of
+    Eigen's Quaternion(Matrix3)."""
+    rng = np.random.default_rng(21)
+    B = 16
+    b = make_batch(seq_vga, [(0, 1)] * B, 4)
+    axes = rng.normal(size=(B, 3))
+    axes /= np.linalg.norm(axes, axis=1, keepdims=True)
+    ang = rng.uniform(2.0, 3.1, size=B)
+    ang[:4] = rng.uniform(0.0, 0.5, size=4)
+    xi = np.concatenate([rng.normal(size=(B, 3)), axes * ang[:, None]], axis=1)
+    b.T_cur_w = se3.mul(se3.exp(xi), b.T_ref_w)
+    T_h, out, _ = run_hip(b, 3, 0, n_iter=0)
+    assert np.abs(T_h - b.T_cur_w).max() < 1e-13
+    assert np.all(out.n_tracked.cpu().numpy() == 0)
+
+
 def test_bad_arguments(hip_lib, gpu_device):
     import ctypes as C
     from rpg_svo_amd import capi
