@@ -278,4 +278,74 @@ static inline int orc_ldlt_solve(int n, const double* A, const double* b, double
   return 1;
 }
 
+/* ---- Eigen small inverses (Eigen/src/LU/Inverse.h) -------------------------
+ * 2x2: invdet = 1/det; adjugate * invdet.
+ * 3x3: cofactors of column 0, det = sum(cofactors_col0 .* col(0)), invdet,
+ *      result(i,j) = cofactor(j,i) * invdet.
+ * Matrices are row-major here: m[r*n+c].                                      */
+#define ORC_DEFINE_SMALL_INV(SUF, T)                                              \
+  static inline T orc_det2##SUF(const T m[4]) { return m[0] * m[3] - m[2] * m[1]; } \
+  static inline void orc_inv2##SUF(const T m[4], T r[4]) {                        \
+    const T invdet = (T)1 / orc_det2##SUF(m);                                     \
+    r[0] = m[3] * invdet;                                                         \
+    r[2] = -m[2] * invdet;                                                        \
+    r[1] = -m[1] * invdet;                                                        \
+    r[3] = m[0] * invdet;                                                         \
+  }                                                                               \
+  static inline T orc_cof3##SUF(const T m[9], int i, int j) {                     \
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3; \
+    return m[i1 * 3 + j1] * m[i2 * 3 + j2] - m[i1 * 3 + j2] * m[i2 * 3 + j1];     \
+  }                                                                               \
+  static inline void orc_inv3##SUF(const T m[9], T r[9]) {                        \
+    const T c0 = orc_cof3##SUF(m, 0, 0), c1 = orc_cof3##SUF(m, 1, 0), c2 = orc_cof3##SUF(m, 2, 0); \
+    const T det = (c0 * m[0] + c1 * m[3]) + c2 * m[6];                            \
+    const T invdet = (T)1 / det;                                                  \
+    r[0] = c0 * invdet; r[1] = c1 * invdet; r[2] = c2 * invdet;                   \
+    r[3] = orc_cof3##SUF(m, 0, 1) * invdet;                                       \
+    r[4] = orc_cof3##SUF(m, 1, 1) * invdet;                                       \
+    r[5] = orc_cof3##SUF(m, 2, 1) * invdet;                                       \
+    r[6] = orc_cof3##SUF(m, 0, 2) * invdet;                                       \
+    r[7] = orc_cof3##SUF(m, 1, 2) * invdet;                                       \
+    r[8] = orc_cof3##SUF(m, 2, 2) * invdet;                                       \
+  }
+ORC_DEFINE_SMALL_INV(f, float)
+ORC_DEFINE_SMALL_INV(d, double)
+
+/* General inverse by partial-pivot LU (Eigen PartialPivLU for n > 4), n <= 12.
+ * Only used for Frame::Cov_ (pose_optimizer.cpp:126); compared with a tolerance. */
+static inline int orc_inv_lu(int n, const double* A, double* out) {
+  double lu[144];
+  int perm[12];
+  if (n > 12) return 0;
+  for (int i = 0; i < n * n; ++i) lu[i] = A[i];
+  for (int i = 0; i < n; ++i) perm[i] = i;
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    double best = fabs(lu[k * n + k]);
+    for (int i = k + 1; i < n; ++i)
+      if (fabs(lu[i * n + k]) > best) { best = fabs(lu[i * n + k]); piv = i; }
+    if (piv != k) {
+      for (int c = 0; c < n; ++c) { double t = lu[k * n + c]; lu[k * n + c] = lu[piv * n + c]; lu[piv * n + c] = t; }
+      int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+    }
+    for (int i = k + 1; i < n; ++i) {
+      lu[i * n + k] /= lu[k * n + k];
+      for (int c = k + 1; c < n; ++c) lu[i * n + c] -= lu[i * n + k] * lu[k * n + c];
+    }
+  }
+  for (int col = 0; col < n; ++col) {
+    double y[12];
+    for (int i = 0; i < n; ++i) {
+      y[i] = (perm[i] == col) ? 1.0 : 0.0;
+      for (int c = 0; c < i; ++c) y[i] -= lu[i * n + c] * y[c];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      for (int c = i + 1; c < n; ++c) y[i] -= lu[i * n + c] * y[c];
+      y[i] /= lu[i * n + i];
+    }
+    for (int i = 0; i < n; ++i) out[i * n + col] = y[i];
+  }
+  return 1;
+}
+
 #endif /* ORC_MATH_H_ */

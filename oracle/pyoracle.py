@@ -44,6 +44,13 @@ def build(force: bool = False) -> None:
     subprocess.run(args, check=True, stdout=subprocess.DEVNULL)
 
 
+def build_ref(force: bool = False) -> bool:
+    """oracle/_ref/libsvo_ref.so: the reference's own translation units compiled in place
+    (only where the reference checkout exists; see oracle/Makefile)."""
+    from . import pytrack
+    return pytrack.build_ref(force)
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:

@@ -6,6 +6,7 @@
  */
 #include "svo_oracle.h"
 #include "orc_math.h"
+#include "orc_vikit.h"
 
 #include <stdlib.h>
 #include <stdio.h>
@@ -49,27 +50,7 @@ int orc_ldlt_solve_n(int n, const double* H, const double* b, double* x) {
 /* ------------------------------------------------------------------------ */
 void orc_half_sample(const uint8_t* in, int in_w, int in_h, int in_stride,
                      uint8_t* out, int out_stride, int mode) {
-  const int out_w = in_w / 2;
-  const int out_h = in_h / 2;
-  if (mode == ORC_HALFSAMPLE_AUTO)
-    mode = (in_w % 16 == 0) ? ORC_HALFSAMPLE_SSE2 : ORC_HALFSAMPLE_SCALAR;
-  for (int y = 0; y < out_h; ++y) {
-    const uint8_t* top = in + (size_t)(2 * y) * in_stride;
-    const uint8_t* bottom = top + in_stride;
-    uint8_t* p = out + (size_t)y * out_stride;
-    if (mode == ORC_HALFSAMPLE_SCALAR) {
-      /* static_cast<uint8_t>((uint16_t(top[0]) + top[1] + bottom[0] + bottom[1]) / 4) */
-      for (int j = 0; j < out_w; ++j)
-        p[j] = (uint8_t)(((uint16_t)top[2 * j] + top[2 * j + 1] + bottom[2 * j] + bottom[2 * j + 1]) / 4);
-    } else {
-      /* halfSampleSSE2: here = avg_epu8(here,next) ; avg_epu16(even, odd)     */
-      for (int j = 0; j < out_w; ++j) {
-        unsigned a = ((unsigned)top[2 * j] + bottom[2 * j] + 1u) >> 1;
-        unsigned b = ((unsigned)top[2 * j + 1] + bottom[2 * j + 1] + 1u) >> 1;
-        p[j] = (uint8_t)((a + b + 1u) >> 1);
-      }
-    }
-  }
+  orc_half_sample_impl(in, in_w, in_h, in_stride, out, out_stride, mode); /* orc_vikit.h */
 }
 
 void orc_create_img_pyramid(const uint8_t* lvl0, int w, int h, int n_levels, int mode,

@@ -123,6 +123,154 @@ int orc_sparse_img_align_batch(int B, const orc_pyramid* pyrs, const int* ref_sl
                                const orc_sia_options* opt, orc_sia_result* res /*[B]*/,
                                int n_threads);
 
+/* ======================================================================== */
+/* Rows a8-a13 of SURVEY.md section 8: matcher / feature alignment / pose    */
+/* optimizer / depth filter / structure optimisation.                        */
+/* The same declarations, with the prefix ref_ instead of orc_, are exported */
+/* by oracle/_ref/libsvo_ref.so (oracle/ref_driver.cpp), where they run the   */
+/* reference's own translation units.                                        */
+/* ======================================================================== */
+
+/* ---- feature_alignment (svo/src/feature_alignment.cpp:30-277, float paths) */
+/* px: in = estimate, out = refined (always written, :145/:275); returns converged */
+int orc_align2d(const uint8_t* cur_img, int w, int h, int stride,
+                const uint8_t* ref_patch_with_border /*[100]*/, const uint8_t* ref_patch /*[64]*/,
+                int n_iter, double px[2]);
+int orc_align1d(const uint8_t* cur_img, int w, int h, int stride, const float dir[2],
+                const uint8_t* ref_patch_with_border, const uint8_t* ref_patch, int n_iter,
+                double px[2], double* h_inv);
+
+/* ---- warp:: (svo/src/matcher.cpp:33-105); A is 2x2 row-major ------------- */
+void orc_get_warp_matrix_affine(const orc_pinhole* cam_ref, const orc_pinhole* cam_cur,
+                                const double px_ref[2], const double f_ref[3], double depth_ref,
+                                const double T_cur_ref[12], int level_ref, double A_cur_ref[4]);
+int orc_get_best_search_level(const double A_cur_ref[4], int max_level);
+/* returns 0 when A^-1 is NaN (patch left untouched, matcher.cpp:83-87), else 1 */
+int orc_warp_affine(const double A_cur_ref[4], const uint8_t* img_ref, int w, int h, int stride,
+                    const double px_ref[2], int level_ref, int search_level, int halfpatch_size,
+                    uint8_t* patch);
+
+/* ---- scene description shared by the matcher / depth-filter entry points -- */
+typedef struct {
+  orc_pyramid pyr;   /* Frame::img_pyr_ */
+  double T_f_w[12];  /* Frame::T_f_w_   */
+} orc_frame;
+
+#define ORC_FTR_CORNER 0
+#define ORC_FTR_EDGELET 1
+typedef struct {     /* svo::Feature (svo/include/svo/feature.h:26-71) */
+  int frame;         /* index into the frames array (Feature::frame) */
+  int level;
+  int type;
+  int pad_;
+  double px[2];
+  double f[3];
+  double grad[2];
+} orc_feature;
+
+typedef struct {     /* Matcher::Options (svo/include/svo/matcher.h:76-93) + Config::nPyrLevels */
+  int align_1d;
+  int align_max_iter;
+  double max_epi_length_optim;
+  int max_epi_search_steps;
+  int subpix_refinement;
+  int epi_search_edgelet_filtering;
+  double epi_search_edgelet_max_angle;
+  int n_pyr_levels;  /* Config::nPyrLevels(): search level is capped at n_pyr_levels-1 */
+  int pad_;
+} orc_matcher_options;
+void orc_matcher_options_default(orc_matcher_options* o);
+
+typedef struct {     /* public scratch of svo::Matcher after a call (matcher.h:94-104) */
+  int success;
+  int ref_obs;       /* index of the observation Point::getCloseViewObs chose (-1: none) */
+  int search_level;
+  int reject;
+  double A_cur_ref[4];
+  double px_cur[2];
+  double h_inv;
+  double epi_length;
+  double depth;      /* findEpipolarMatchDirect only */
+  uint8_t patch[64];
+  uint8_t patch_with_border[100];
+} orc_match_result;
+
+/* Matcher::findMatchDirect (matcher.cpp:135-177) with Point::getCloseViewObs (point.cpp:97-117).
+ * obs[] is Point::obs_ in list order.  px_cur in/out.  Returns success. */
+int orc_find_match_direct(const orc_frame* frames, const orc_pinhole* cam, int cur_frame,
+                          const double pt_pos[3], int n_obs, const orc_feature* obs,
+                          const orc_matcher_options* opt, double px_cur[2], orc_match_result* res);
+
+/* Matcher::findEpipolarMatchDirect (matcher.cpp:179-321). Returns success; depth in res->depth. */
+int orc_find_epipolar_match_direct(const orc_frame* frames, const orc_pinhole* cam, int ref_frame,
+                                   int cur_frame, const orc_feature* ref_ftr, double d_estimate,
+                                   double d_min, double d_max, const orc_matcher_options* opt,
+                                   orc_match_result* res);
+
+/* ---- pose_optimizer::optimizeGaussNewton (svo/src/pose_optimizer.cpp:28-161) */
+typedef struct {
+  double T_f_w[12];        /* optimised pose                         */
+  double Cov[36];          /* Frame::Cov_ (:126)                     */
+  double estimated_scale;  /* out-params of the reference signature  */
+  double error_init;
+  double error_final;
+  int num_obs;
+  int n_iter_done;         /* iterations that updated the model (not in the reference API) */
+  int ran;                 /* 0 when errors.empty() (:57-58): nothing else is written      */
+} orc_pose_opt_result;
+/* features in Frame::fts_ order; has_point[i]=0 <=> Feature::point==NULL.  On return
+ * has_point[i] is cleared for observations pruned at :139-144. */
+int orc_pose_optimize(double reproj_thresh, int n_iter, const orc_pinhole* cam,
+                      const double T_f_w[12], int n, const double* f /*[n][3]*/,
+                      const int* level /*[n]*/, uint8_t* has_point /*[n] in/out*/,
+                      const double* pos /*[n][3]*/, orc_pose_opt_result* res);
+
+/* ---- Point::optimize (svo/src/point.cpp:119-177) -------------------------- */
+/* obs in Point::obs_ order: T_f_w [n_obs][12], f [n_obs][3]; pos in/out */
+void orc_point_optimize(int n_iter, int n_obs, const double* T_f_w, const double* f, double pos[3]);
+
+/* ---- DepthFilter (svo/src/depth_filter.cpp) ------------------------------- */
+typedef struct {     /* svo::Seed (depth_filter.h:35-51) + its Feature */
+  orc_feature ftr;
+  int batch_id;
+  float a, b, mu, z_range, sigma2;
+} orc_seed;
+void orc_seed_init(orc_seed* s, float depth_mean, float depth_min); /* Seed ctor, :37-46 */
+void orc_update_seed(float x, float tau2, orc_seed* seed);          /* updateSeed, :309-332 */
+double orc_compute_tau(const double T_ref_cur[12], const double f[3], double z,
+                       double px_error_angle);                     /* computeTau, :334-350 */
+
+#define ORC_SEED_ERASED_OLD 1   /* batch too old (:216-219), erased                    */
+#define ORC_SEED_BEHIND 2       /* behind the camera (:225-228), untouched             */
+#define ORC_SEED_NOT_IN_FRAME 3 /* does not project into the image (:229-232)          */
+#define ORC_SEED_NO_MATCH 4     /* findEpipolarMatchDirect failed: b++ (:238-245)      */
+#define ORC_SEED_UPDATED 5      /* updateSeed ran, seed kept                           */
+#define ORC_SEED_CONVERGED 6    /* updateSeed ran, seed converged -> Point, erased     */
+#define ORC_SEED_NAN 7          /* updateSeed ran, z_inv_min is NaN, erased (:283-287) */
+typedef struct {
+  int status;
+  int search_level;
+  double z;            /* triangulated depth            */
+  double tau;
+  double px_cur[2];    /* Matcher::px_cur_              */
+  double xyz_world[3]; /* new Point::pos_ if converged  */
+} orc_seed_update_info;
+typedef struct {     /* DepthFilter::Options (depth_filter.h:70-86), the fields updateSeeds reads */
+  int max_n_kfs;
+  int batch_counter; /* Seed::batch_counter */
+  double seed_convergence_sigma2_thresh;
+} orc_depth_filter_options;
+/* DepthFilter::updateSeeds(frame) (:197-291) over seeds[] in list order; seeds updated in
+ * place, info[i] says what happened to seed i.  Returns the number of updates. */
+int orc_update_seeds(const orc_frame* frames, const orc_pinhole* cam, int cur_frame, int n_seeds,
+                     orc_seed* seeds, orc_seed_update_info* info,
+                     const orc_depth_filter_options* dopt, const orc_matcher_options* mopt);
+
+/* ---- Reprojector (svo/src/reprojector.cpp) -------------------------------- */
+/* reprojectPoint (:206-217): returns cell index k or -1; px_out = frame.w2c(pos) */
+int orc_reproject_point(const orc_pinhole* cam, const double T_f_w[12], const double pos[3],
+                        int cell_size, int grid_n_cols, double px_out[2]);
+
 #ifdef __cplusplus
 }
 #endif

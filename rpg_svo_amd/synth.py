@@ -200,3 +200,92 @@ def make_sequence(n_frames: int, n_feat: int, cam: Camera | None = None, seed: i
         px = px + (torch.rand(px.shape, generator=g, dtype=torch.float64) - 0.5).to(px.device)
     f, pos = features_3d(T, cam, px)
     return Sequence(cam, T, images, px, f, pos)
+
+
+# ------------------------------------------------------------------------------------------
+# Scenes for the steps after sparse alignment (reprojection matching, pose refinement,
+# depth filter): K keyframes + one current frame looking at the same plane, map points
+# observed from several keyframes, seeds with an uncertain inverse depth.
+# ------------------------------------------------------------------------------------------
+@dataclass
+class TrackScene:
+    cam: Camera
+    T_f_w: np.ndarray            # [K+1,12]; index K is the current frame (ground truth)
+    images: torch.Tensor         # uint8 [K+1,h,w]
+    cur: int                     # index of the current frame
+    T_cur_prior: np.ndarray      # [12] perturbed pose of the current frame (sparse-align output stand-in)
+    pt_pos: np.ndarray           # [P,3] map points (slightly off the true surface)
+    obs: list                    # per point: list of (frame, px[2], f[3], level, type, grad[2]), newest first
+    px_true: np.ndarray          # [P,2] exact projection of the true surface point in the current frame
+    px_init: np.ndarray          # [P,2] projection of pt_pos with T_cur_prior (the matcher's start)
+
+
+def _proj(T, cam: Camera, X):
+    R = T[:9].reshape(3, 3)
+    p = X @ R.T + T[9:]
+    return np.stack([cam.fx * p[:, 0] / p[:, 2] + cam.cx, cam.fy * p[:, 1] / p[:, 2] + cam.cy], axis=-1), p[:, 2]
+
+
+def _bearing(cam: Camera, px):
+    f = np.stack([(px[:, 0] - cam.cx) / cam.fx, (px[:, 1] - cam.cy) / cam.fy, np.ones(len(px))], axis=-1)
+    return f / np.linalg.norm(f, axis=-1, keepdims=True)
+
+
+def make_track_scene(n_kf: int = 4, n_feat: int = 100, cam: Camera | None = None, seed: int = 777, kf_gap: int = 6,
+                     depth_noise: float = 0.01, prior_noise: float = 2e-3, edgelet_frac: float = 0.25,
+                     device="cpu") -> TrackScene:
+    from . import se3
+    cam = cam or Camera.vga()
+    rng = np.random.default_rng(seed)
+    tex = make_texture(seed=12345)
+    T_all = make_trajectory(n_kf * kf_gap + 1, seed=seed, max_step=0.02, max_rot_deg=0.5)
+    idx = list(range(0, n_kf * kf_gap, kf_gap)) + [n_kf * kf_gap]
+    T = T_all[idx]
+    images = render(tex, T, cam, device=device)
+    K = n_kf
+    px_kf = select_features(images[:K], n_feat, margin=40, cell=32).cpu().numpy()
+    px_kf = px_kf + rng.uniform(-0.5, 0.5, size=px_kf.shape)
+    imgs = images.cpu().numpy().astype(np.float32)
+    pts, obs_all, px_true = [], [], []
+    for k in range(K):
+        f_k, X_k = features_3d(T[k:k + 1], cam, torch.as_tensor(px_kf[k:k + 1]))
+        f_k, X_k = f_k[0].numpy(), X_k[0].numpy()
+        c_k = -T[k, :9].reshape(3, 3).T @ T[k, 9:]
+        for i in range(n_feat):
+            X = X_k[i]
+            # the map point is the surface point moved along the viewing ray (depth error)
+            ray = X - c_k
+            Xn = c_k + ray * (1.0 + depth_noise * rng.normal())
+            u, v = px_kf[k, i]
+            iu, iv = int(round(u)), int(round(v))
+            gx = imgs[k, iv, iu + 1] - imgs[k, iv, iu - 1]
+            gy = imgs[k, iv + 1, iu] - imgs[k, iv - 1, iu]
+            gn = math.hypot(gx, gy)
+            is_edge = rng.uniform() < edgelet_frac and gn > 1e-3
+            grad = (gx / gn, gy / gn) if is_edge else (1.0, 0.0)
+            o = [(k, px_kf[k, i].copy(), f_k[i].copy(), 0, 1 if is_edge else 0, grad)]
+            for k2 in range(K):
+                if k2 == k:
+                    continue
+                p2, z2 = _proj(T[k2], cam, X[None])
+                if z2[0] > 0 and 12 <= p2[0, 0] < cam.width - 12 and 12 <= p2[0, 1] < cam.height - 12:
+                    g2 = (1.0, 0.0)
+                    if is_edge:  # an edgelet stays an edgelet in every keyframe that observes it
+                        ju, jv = int(round(p2[0, 0])), int(round(p2[0, 1]))
+                        hx = imgs[k2, jv, ju + 1] - imgs[k2, jv, ju - 1]
+                        hy = imgs[k2, jv + 1, ju] - imgs[k2, jv - 1, ju]
+                        hn = math.hypot(hx, hy)
+                        g2 = (hx / hn, hy / hn) if hn > 1e-3 else grad
+                    o.append((k2, p2[0].copy(), _bearing(cam, p2)[0], 0, 1 if is_edge else 0, g2))
+            pc, zc = _proj(T[K], cam, X[None])
+            if zc[0] <= 0:
+                continue
+            order = rng.permutation(len(o))
+            pts.append(Xn)
+            obs_all.append([o[j] for j in order])
+            px_true.append(pc[0])
+    pt_pos = np.array(pts)
+    px_true = np.array(px_true)
+    T_prior = se3.mul(se3.exp(rng.normal(size=6) * prior_noise), T[K])
+    px_init, _ = _proj(T_prior, cam, pt_pos)
+    return TrackScene(cam, T, images, K, T_prior, pt_pos, obs_all, px_true, px_init)
