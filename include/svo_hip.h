@@ -142,6 +142,172 @@ int svo_hip_sparse_align(const svo_hip_pyr_layout* layout, const uint8_t* d_stor
                          int32_t* d_n_tracked, int32_t* d_iters, double* d_chi2,
                          int32_t* d_status, void* stream);
 
+/* ======================================================================== */
+/* Rows a8-a13: the steps FrameHandlerMono::processFrame runs after sparse   */
+/* alignment (svo/src/frame_handler_mono.cpp:145-235) and the depth-filter    */
+/* update of the mapping thread.  All arrays are device pointers.            */
+/* ======================================================================== */
+
+typedef struct svo_hip_camera { /* vk::PinholeCamera without distortion */
+  double fx, fy, cx, cy;
+  int32_t width, height;
+} svo_hip_camera;
+
+#define SVO_HIP_FTR_CORNER 0  /* svo::Feature::FeatureType (feature.h:30-33) */
+#define SVO_HIP_FTR_EDGELET 1
+
+/* A batch refers to frames through a FRAME TABLE (device mirror of the svo::Frame objects
+ * involved): d_frame_slot[F] = pyramid-store slot, d_frame_T[F][12] = Frame::T_f_w_. */
+typedef struct svo_hip_frames {
+  int32_t n_frames;
+  int32_t reserved;
+  const int32_t* d_slot;
+  const double* d_T_f_w;
+} svo_hip_frames;
+
+/* A set of svo::Feature records, SoA (feature.h:26-71). */
+typedef struct svo_hip_features {
+  const int32_t* d_frame; /* [n] index into the frame table (Feature::frame) */
+  const int32_t* d_level; /* [n] Feature::level                             */
+  const uint8_t* d_type;  /* [n] SVO_HIP_FTR_*; NULL = all corners          */
+  const double* d_px;     /* [n][2] Feature::px                             */
+  const double* d_f;      /* [n][3] Feature::f                              */
+  const double* d_grad;   /* [n][2] Feature::grad; may be NULL when d_type is NULL */
+} svo_hip_features;
+
+/*
+ * K3: batched feature_alignment::align2D / align1D (svo/src/feature_alignment.cpp:30-277,
+ * the float paths an x86 build runs).  One lane per trial, pixels visited in the
+ * reference's order, no contraction: results are bit-identical to the reference's.
+ *   d_slot/d_level [M]   image = level d_level[t] of pyramid slot d_slot[t]
+ *   d_patch_with_border [M][100]  Matcher::patch_with_border_ (10x10 u8, row-major); the
+ *                        8x8 ref_patch is its interior (Matcher::createPatchFromPatchWithBorder)
+ *   d_dir [M][2] f32     align1D direction; used where d_use_1d[t] != 0 (both may be NULL)
+ *   d_px [M][2]          in: estimate, out: refined position, in pixels OF THAT LEVEL
+ *   d_ok [M]             1 = converged (the functions' bool result)
+ *   d_h_inv [M]          align1D's h_inv (may be NULL)
+ */
+int svo_hip_align_batch(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int M,
+                        const int32_t* d_slot, const int32_t* d_level,
+                        const uint8_t* d_patch_with_border, const float* d_dir,
+                        const uint8_t* d_use_1d, int n_iter, double* d_px, int32_t* d_ok,
+                        double* d_h_inv, void* stream);
+
+/* bytes of scratch the matcher / depth-filter entry points need for M trials */
+size_t svo_hip_match_workspace_bytes(int M);
+
+/*
+ * K2+K3: batched Matcher::findMatchDirect (svo/src/matcher.cpp:135-177) including
+ * Point::getCloseViewObs (svo/src/point.cpp:97-117), warp::getWarpMatrixAffine /
+ * getBestSearchLevel / warpAffine (matcher.cpp:33-105) and the feature alignment.
+ * Candidate m is a map point seen from frame d_cur_frame[m]:
+ *   d_pt_pos [M][3]      Point::pos_
+ *   d_obs_ptr [M+1]      CSR offsets into `obs`: Point::obs_ of candidate m, in list order
+ *   d_px_cur [M][2]      in: Candidate::px (projection, level-0 pixels); out: refined px
+ *   d_ok [M]             findMatchDirect's result
+ *   d_ref_obs [M]        index (into obs) of the observation chosen as ref_ftr_ (-1: none)
+ *   d_search_level [M]   Matcher::search_level_
+ *   d_A_cur_ref [M][4]   Matcher::A_cur_ref_, row-major 2x2 (may be NULL)
+ *   d_patch_out [M][100] Matcher::patch_with_border_ (may be NULL)
+ *   n_pyr_levels         Config::nPyrLevels(): search level <= n_pyr_levels-1
+ *   align_max_iter       Matcher::Options::align_max_iter (10)
+ */
+int svo_hip_find_match_direct(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
+                              const svo_hip_camera* cam, const svo_hip_frames* frames, int M,
+                              const int32_t* d_cur_frame, const double* d_pt_pos,
+                              const int32_t* d_obs_ptr, const svo_hip_features* obs,
+                              int n_pyr_levels, int align_max_iter, double* d_px_cur,
+                              int32_t* d_ok, int32_t* d_ref_obs, int32_t* d_search_level,
+                              double* d_A_cur_ref, uint8_t* d_patch_out, void* d_workspace,
+                              size_t workspace_bytes, void* stream);
+
+/* Reprojector::reprojectPoint (svo/src/reprojector.cpp:206-217): d_cell[m] = grid cell of the
+ * projection of point m into frame d_cur_frame[m] (or -1 when outside the 8 px border),
+ * d_px[m] = the projection. */
+int svo_hip_reproject_points(const svo_hip_camera* cam, const svo_hip_frames* frames, int M,
+                             const int32_t* d_cur_frame, const double* d_pt_pos, int cell_size,
+                             int grid_n_cols, int32_t* d_cell, double* d_px, void* stream);
+
+/*
+ * K4: batched pose_optimizer::optimizeGaussNewton (svo/src/pose_optimizer.cpp:28-161), one
+ * workgroup per frame.  Observations of frame b are rows [b*n_stride, b*n_stride+d_n[b]):
+ *   d_f [B][n_stride][3]   Feature::f
+ *   d_level [B][n_stride]  Feature::level
+ *   d_pos [B][n_stride][3] Feature::point->pos_
+ *   d_has_point [B][n_stride] in: 0 where Feature::point == NULL; out: also 0 where the
+ *                          observation was pruned (:139-144)
+ *   d_T_f_w [B][12]        in/out Frame::T_f_w_
+ *   d_Cov [B][36]          Frame::Cov_ (may be NULL)
+ *   d_stats [B][4]         estimated_scale, error_init, error_final, (double)num_obs
+ *   d_ran [B]              0 where no observation had a point (:57-58: nothing is touched)
+ */
+int svo_hip_pose_optimize(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride,
+                          const double* d_f, const int32_t* d_level, const double* d_pos,
+                          uint8_t* d_has_point, double reproj_thresh, int n_iter,
+                          double* d_T_f_w, double* d_Cov, double* d_stats, int32_t* d_ran,
+                          void* stream);
+
+/*
+ * K6: batched Point::optimize (svo/src/point.cpp:119-177).  Point p has observations
+ * [d_obs_ptr[p], d_obs_ptr[p+1]) in (d_obs_frame -> frame table, d_obs_f); d_pos in/out.
+ */
+int svo_hip_point_optimize(const svo_hip_frames* frames, int P, const int32_t* d_obs_ptr,
+                           const int32_t* d_obs_frame, const double* d_obs_f, int n_iter,
+                           double* d_pos, void* stream);
+
+/* ---- K5: depth filter ---------------------------------------------------- */
+/* svo::Seed state, SoA (depth_filter.h:35-51): a, b, mu, z_range, sigma2 */
+typedef struct svo_hip_seeds {
+  float* d_a;
+  float* d_b;
+  float* d_mu;
+  float* d_z_range;
+  float* d_sigma2;
+  const int32_t* d_batch_id;
+} svo_hip_seeds;
+
+#define SVO_HIP_SEED_ERASED_OLD 1   /* too old (depth_filter.cpp:216-219): erase           */
+#define SVO_HIP_SEED_BEHIND 2       /* behind the camera (:225-228): untouched             */
+#define SVO_HIP_SEED_NOT_IN_FRAME 3 /* projects outside the image (:229-232): untouched    */
+#define SVO_HIP_SEED_NO_MATCH 4     /* findEpipolarMatchDirect failed: b++ (:238-245)      */
+#define SVO_HIP_SEED_UPDATED 5      /* updateSeed ran, seed kept                           */
+#define SVO_HIP_SEED_CONVERGED 6    /* updateSeed ran and converged -> new Point, erase    */
+#define SVO_HIP_SEED_NAN 7          /* updateSeed ran, z_inv_min NaN: erase (:283-287)     */
+
+typedef struct svo_hip_depth_filter_options {
+  int32_t max_n_kfs;     /* DepthFilter::Options::max_n_kfs (3)                  */
+  int32_t batch_counter; /* Seed::batch_counter                                  */
+  double seed_convergence_sigma2_thresh; /* 200                                  */
+  /* Matcher::Options (matcher.h:76-93) */
+  int32_t align_1d;
+  int32_t align_max_iter;
+  int32_t max_epi_search_steps;
+  int32_t subpix_refinement;
+  int32_t epi_search_edgelet_filtering;
+  int32_t n_pyr_levels;
+  double epi_search_edgelet_max_angle;
+} svo_hip_depth_filter_options;
+
+/*
+ * Batched DepthFilter::updateSeeds (svo/src/depth_filter.cpp:197-291) with
+ * Matcher::findEpipolarMatchDirect (matcher.cpp:179-321), computeTau and updateSeed.
+ * Seed s belongs to feature s of `ftr` and is updated with frame d_cur_frame[s].
+ *   d_status [S]        SVO_HIP_SEED_*  (the list surgery -- erase / new Point -- stays on the host)
+ *   d_xyz_world [S][3]  position of the new Point where status == CONVERGED
+ *   d_px_cur [S][2]     Matcher::px_cur_ of successful matches (may be NULL)
+ * static DepthFilter::updateSeed / computeTau are also exported on their own.
+ */
+int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
+                         const svo_hip_camera* cam, const svo_hip_frames* frames, int S,
+                         const int32_t* d_cur_frame, const svo_hip_features* ftr,
+                         const svo_hip_seeds* seeds, const svo_hip_depth_filter_options* opt,
+                         int32_t* d_status, double* d_xyz_world, double* d_px_cur,
+                         void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* DepthFilter::updateSeed(x, tau2, seed) for S independent (x, tau2) measurements */
+int svo_hip_update_seed_batch(int S, const float* d_x, const float* d_tau2,
+                              const svo_hip_seeds* seeds, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

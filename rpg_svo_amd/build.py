@@ -25,19 +25,39 @@ def _newer(target: str, sources: list[str]) -> bool:
     return all(os.path.getmtime(s) <= t for s in sources)
 
 
-def build_hip(force: bool = False, verbose: bool = False, defines: list[str] | None = None) -> str:
-    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
-    if not force and _newer(LIB, deps):
-        return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+def _compile_one(src: str, obj: str, defines: list[str], verbose: bool) -> None:
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
            # SLP packing (v_pk_*_f32) costs register pairs + moves in the pixel loops
            "-fno-slp-vectorize",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *[f"-D{d}" for d in (defines or [])], *srcs, "-o", LIB]
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *[f"-D{d}" for d in defines], src, "-o", obj]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+
+
+def build_hip(force: bool = False, verbose: bool = False, defines: list[str] | None = None) -> str:
+    """One object per translation unit (rebuilt only when it or a header changed), compiled in
+    parallel, then linked into libsvo_hip.so."""
+    from concurrent.futures import ThreadPoolExecutor
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    objdir = os.path.join(ROOT, "build", "obj" + ("_" + "_".join(defines) if defines else ""))
+    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    todo, objs = [], []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not _newer(obj, [src] + hdrs):
+            todo.append((src, obj))
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
+            list(ex.map(lambda so: _compile_one(so[0], so[1], defines or [], verbose), todo))
+    if todo or force or not _newer(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
     return LIB
 
 

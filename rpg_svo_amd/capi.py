@@ -41,7 +41,42 @@ class SiaParams(C.Structure):
     ]
 
 
+class Camera(C.Structure):
+    """svo_hip_camera: vk::PinholeCamera without distortion."""
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class Frames(C.Structure):
+    """svo_hip_frames: frame table (device pointers)."""
+    _fields_ = [("n_frames", C.c_int32), ("reserved", C.c_int32), ("d_slot", C.c_void_p), ("d_T_f_w", C.c_void_p)]
+
+
+class Features(C.Structure):
+    """svo_hip_features: SoA svo::Feature records (device pointers)."""
+    _fields_ = [("d_frame", C.c_void_p), ("d_level", C.c_void_p), ("d_type", C.c_void_p), ("d_px", C.c_void_p),
+                ("d_f", C.c_void_p), ("d_grad", C.c_void_p)]
+
+
+class Seeds(C.Structure):
+    """svo_hip_seeds: SoA svo::Seed state (device pointers)."""
+    _fields_ = [("d_a", C.c_void_p), ("d_b", C.c_void_p), ("d_mu", C.c_void_p), ("d_z_range", C.c_void_p),
+                ("d_sigma2", C.c_void_p), ("d_batch_id", C.c_void_p)]
+
+
+class DepthFilterOptions(C.Structure):
+    _fields_ = [("max_n_kfs", C.c_int32), ("batch_counter", C.c_int32),
+                ("seed_convergence_sigma2_thresh", C.c_double), ("align_1d", C.c_int32),
+                ("align_max_iter", C.c_int32), ("max_epi_search_steps", C.c_int32),
+                ("subpix_refinement", C.c_int32), ("epi_search_edgelet_filtering", C.c_int32),
+                ("n_pyr_levels", C.c_int32), ("epi_search_edgelet_max_angle", C.c_double)]
+
+
+FTR_CORNER, FTR_EDGELET = 0, 1
+SEED_ERASED_OLD, SEED_BEHIND, SEED_NOT_IN_FRAME, SEED_NO_MATCH, SEED_UPDATED, SEED_CONVERGED, SEED_NAN = range(1, 8)
+
 _vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
+_LP = C.POINTER(PyrLayout)
 
 # name -> (restype, argtypes); the list every test checks against include/svo_hip.h
 PROTOTYPES = {
@@ -70,6 +105,17 @@ PROTOTYPES = {
     "svo_hip_pyramid_download_level": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _vp]),
     "svo_hip_sparse_align": (_i, [C.POINTER(PyrLayout), _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp,
                                   C.POINTER(SiaParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "svo_hip_align_batch": (_i, [_LP, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "svo_hip_match_workspace_bytes": (C.c_size_t, [_i]),
+    "svo_hip_find_match_direct": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, _vp, _vp,
+                                       C.POINTER(Features), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "svo_hip_reproject_points": (_i, [C.POINTER(Camera), C.POINTER(Frames), _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "svo_hip_pose_optimize": (_i, [C.POINTER(Camera), _i, _vp, _i, _vp, _vp, _vp, _vp, C.c_double, _i, _vp, _vp, _vp,
+                                   _vp, _vp]),
+    "svo_hip_point_optimize": (_i, [C.POINTER(Frames), _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "svo_hip_update_seeds": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, C.POINTER(Features),
+                                  C.POINTER(Seeds), C.POINTER(DepthFilterOptions), _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "svo_hip_update_seed_batch": (_i, [_i, _vp, _vp, C.POINTER(Seeds), _vp]),
 }
 
 _lib = None
@@ -113,3 +159,7 @@ def pyr_layout(width: int, height: int, n_levels: int) -> PyrLayout:
 
 def pyr_store_bytes(L: PyrLayout, n_slots: int) -> int:
     return check(load().svo_hip_pyr_store_bytes(C.byref(L), n_slots), "svo_hip_pyr_store_bytes")
+
+
+def camera(cam) -> Camera:
+    return Camera(cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height)

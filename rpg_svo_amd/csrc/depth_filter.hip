@@ -1,0 +1,613 @@
+// depth_filter.hip -- K5: batched DepthFilter::updateSeeds for gfx950.
+//
+// Replaces, per seed (svo/src/depth_filter.cpp:197-291):
+//   age / visibility tests, inverse-depth interval (:216-235)            seed_prepare_kernel
+//   Matcher::findEpipolarMatchDirect (svo/src/matcher.cpp:179-321):        (lane per seed, f64)
+//     epipolar segment, affine warp matrix, edgelet filter, search level
+//     warp::warpAffine 10x10                                              warp_kernel (matcher.hip)
+//     ZMSSD scan along the epipolar line (:248-291)                       epi_scan_kernel
+//                                                                           (one WAVE per seed)
+//     sub-pixel refinement align2D / align1D (:295-315)                   K3 (feature_align.hip)
+//     depthFromTriangulation (:109-122)                                  \ seed_finish_kernel
+//   DepthFilter::computeTau (:334-350), updateSeed (:309-332),           | (lane per seed)
+//   convergence test (:261-262, :283-287)                                /
+//
+// The epipolar scan is the only part with real per-seed parallelism (up to 1000 candidate
+// positions x 64 pixels of integer ZMSSD): the 64 lanes of a wave take the steps round-robin,
+// score them with v_dot4_u32_u8, and a lexicographic (score, step) wave-min reproduces the
+// reference's "first strictly smaller score wins".  Every lane replays the cheap sequential
+// part of the loop (uv += step in f64, the last_checked_pxi rule), so the positions visited
+// are the reference's to the bit.
+//
+// List surgery (erasing seeds, creating svo::Point objects, the converged callback) stays on
+// the host: the kernel reports a status per seed and the new point's position.
+#pragma clang fp contract(off)
+#include "track_kernels.h"
+#include "track_math.h"
+#include "matcher_device.h"
+
+using namespace svo_capi;
+using namespace svo_dev;
+using namespace svo_track;
+
+namespace {
+
+constexpr int ZMSSD_THRESHOLD = 2000 * 64;  // vk::patch_score::ZMSSD<4>::threshold()
+constexpr double SVO_PI = 3.14159265;       // svo/include/svo/global.h:78
+
+enum : int { MODE_NONE = 0, MODE_SHORT = 1, MODE_SCAN = 2 };
+
+struct SeedWs {
+  uint8_t* warp_active;   // [S]
+  uint8_t* align_active;  // [S]
+  uint8_t* use_1d;        // [S]
+  int32_t* status;        // [S] preliminary status (0 = still running)
+  int32_t* mode;          // [S]
+  int32_t* ref_slot;
+  int32_t* ref_level;
+  int32_t* cur_slot;
+  int32_t* search_level;
+  int32_t* n_steps;
+  float* A_ref_cur;   // [S][4]
+  float* px_ref_pyr;  // [S][2]
+  float* dir;         // [S][2]
+  float* z_inv_min;   // [S]
+  double* B;          // [S][2] epipolar start (unit plane)
+  double* step;       // [S][2]
+  double* px_scaled;  // [S][2] align start, level coordinates
+  double* px_cur;     // [S][2] Matcher::px_cur_
+  double* uv_best;    // [S][2]
+  uint8_t* pwb;       // [S][100]
+  int32_t* align_ok;  // [S]
+};
+
+struct SeedArgs {
+  svo_hip_pyr_layout L;
+  const uint8_t* store;
+  Cam cam;
+  int S;
+  const int32_t* frame_slot;
+  const double* frame_T;
+  const int32_t* cur_frame;
+  svo_hip_features ftr;
+  svo_hip_seeds seeds;
+  svo_hip_depth_filter_options opt;
+  int32_t* status_out;
+  double* xyz_world;
+  double* px_cur_out;
+  SeedWs ws;
+};
+
+__global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= a.S) return;
+  const SeedWs& w = a.ws;
+  w.warp_active[s] = 0;
+  w.align_active[s] = 0;
+  w.use_1d[s] = a.opt.align_1d ? 1 : 0;
+  w.mode[s] = MODE_NONE;
+  w.status[s] = 0;
+  w.search_level[s] = 0;
+  w.ref_slot[s] = 0;
+  w.ref_level[s] = 0;
+  w.n_steps[s] = 0;
+  w.align_ok[s] = 0;
+  w.dir[2 * s] = 1.f;
+  w.dir[2 * s + 1] = 0.f;
+  w.px_scaled[2 * s] = w.px_scaled[2 * s + 1] = 0.0;
+  w.px_cur[2 * s] = w.px_cur[2 * s + 1] = 0.0;
+  const int cf = a.cur_frame[s];
+  w.cur_slot[s] = a.frame_slot[cf];
+  // check if seed is not already too old (:216-219)
+  if ((a.opt.batch_counter - a.seeds.d_batch_id[s]) > a.opt.max_n_kfs) {
+    w.status[s] = SVO_HIP_SEED_ERASED_OLD;
+    return;
+  }
+  const int rfi = a.ftr.d_frame[s];
+  Se3 Tr, Tc;
+  se3_from_Rt(a.frame_T + 12 * rfi, Tr);
+  se3_from_Rt(a.frame_T + 12 * cf, Tc);
+  const float mu = a.seeds.d_mu[s], sigma2 = a.seeds.d_sigma2[s];
+  const double f[3] = {a.ftr.d_f[3 * s], a.ftr.d_f[3 * s + 1], a.ftr.d_f[3 * s + 2]};
+  // visibility (:221-232)
+  {
+    const Se3 T_ref_cur = se3_compose(Tr, se3_inverse(Tc));
+    const Se3 T_cur_ref0 = se3_inverse(T_ref_cur);
+    const double k = 1.0 / (double)mu;
+    const double pr[3] = {k * f[0], k * f[1], k * f[2]};
+    double xyz_f[3];
+    se3_apply(T_cur_ref0, pr, xyz_f);
+    if (xyz_f[2] < 0.0) {
+      w.status[s] = SVO_HIP_SEED_BEHIND;
+      return;
+    }
+    double pxp[2];
+    world2cam(a.cam, xyz_f, pxp);
+    if (!is_in_frame(a.cam, cast_int(pxp[0]), cast_int(pxp[1]), 0)) {
+      w.status[s] = SVO_HIP_SEED_NOT_IN_FRAME;
+      return;
+    }
+  }
+  // inverse depth interval (:234-236)
+  const float sq = sqrtf(sigma2);
+  const float z_inv_min = mu + sq;
+  const float zlo = mu - sq;
+  const float z_inv_max = (zlo < 0.00000001f) ? 0.00000001f : zlo;
+  w.z_inv_min[s] = z_inv_min;
+  const double d_estimate = 1.0 / (double)mu, d_min = 1.0 / (double)z_inv_min, d_max = 1.0 / (double)z_inv_max;
+
+  // ---- Matcher::findEpipolarMatchDirect, matcher.cpp:188-246 -------------------------
+  const Se3 T_cur_ref = se3_compose(Tc, se3_inverse(Tr));
+  double p[3], q[3], A[2], B[2];
+  p[0] = f[0] * d_min; p[1] = f[1] * d_min; p[2] = f[2] * d_min;
+  se3_apply(T_cur_ref, p, q);
+  project2d(q, A);
+  p[0] = f[0] * d_max; p[1] = f[1] * d_max; p[2] = f[2] * d_max;
+  se3_apply(T_cur_ref, p, q);
+  project2d(q, B);
+  const double epi_dir[2] = {A[0] - B[0], A[1] - B[1]};
+  const int rlevel = a.ftr.d_level[s];
+  const double rpx[2] = {a.ftr.d_px[2 * s], a.ftr.d_px[2 * s + 1]};
+  double Am[4];
+  warp_matrix_affine(a.cam, rpx, f, d_estimate, T_cur_ref, rlevel, Am);
+  if (a.ftr.d_type && a.ftr.d_type[s] == SVO_HIP_FTR_EDGELET && a.opt.epi_search_edgelet_filtering) {
+    const double gx = a.ftr.d_grad[2 * s], gy = a.ftr.d_grad[2 * s + 1];
+    double g[2] = {Am[0] * gx + Am[1] * gy, Am[2] * gx + Am[3] * gy};
+    const double gn = norm2(g);
+    g[0] /= gn;
+    g[1] /= gn;
+    double e[2] = {epi_dir[0], epi_dir[1]};
+    const double en = norm2(e);
+    e[0] /= en;
+    e[1] /= en;
+    const double cosangle = fabs(g[0] * e[0] + g[1] * e[1]);
+    if (cosangle < a.opt.epi_search_edgelet_max_angle) {
+      w.status[s] = SVO_HIP_SEED_NO_MATCH;  // reject_ = true
+      return;
+    }
+  }
+  const int sl = best_search_level(Am, a.opt.n_pyr_levels - 1);
+  w.search_level[s] = sl;
+  double px_A[2], px_B[2];
+  world2cam_uv(a.cam, A, px_A);
+  world2cam_uv(a.cam, B, px_B);
+  const double dAB[2] = {px_A[0] - px_B[0], px_A[1] - px_B[1]};
+  const double epi_length = norm2(dAB) / (double)(1 << sl);
+  // warp set-up (matcher.cpp:221-224)
+  double Ainv[4];
+  inv2<double>(Am, Ainv);
+  w.A_ref_cur[4 * s] = (float)Ainv[0];
+  w.A_ref_cur[4 * s + 1] = (float)Ainv[1];
+  w.A_ref_cur[4 * s + 2] = (float)Ainv[2];
+  w.A_ref_cur[4 * s + 3] = (float)Ainv[3];
+  w.px_ref_pyr[2 * s] = (float)rpx[0] / (float)(1 << rlevel);
+  w.px_ref_pyr[2 * s + 1] = (float)rpx[1] / (float)(1 << rlevel);
+  w.ref_slot[s] = a.frame_slot[rfi];
+  w.ref_level[s] = rlevel;
+  w.warp_active[s] = 1;
+  {  // (px_A-px_B).cast<float>().normalized()
+    float d0 = (float)dAB[0], d1 = (float)dAB[1];
+    const float n = sqrtf(d0 * d0 + d1 * d1);
+    w.dir[2 * s] = d0 / n;
+    w.dir[2 * s + 1] = d1 / n;
+  }
+  if (epi_length < 2.0) {
+    const double pc[2] = {(px_A[0] + px_B[0]) / 2.0, (px_A[1] + px_B[1]) / 2.0};
+    w.px_cur[2 * s] = pc[0];
+    w.px_cur[2 * s + 1] = pc[1];
+    w.px_scaled[2 * s] = pc[0] / (double)(1 << sl);
+    w.px_scaled[2 * s + 1] = pc[1] / (double)(1 << sl);
+    w.mode[s] = MODE_SHORT;
+    w.align_active[s] = 1;
+    return;
+  }
+  const unsigned long long n_steps = (unsigned long long)(epi_length / 0.7);
+  if (n_steps > (unsigned long long)a.opt.max_epi_search_steps) {
+    w.status[s] = SVO_HIP_SEED_NO_MATCH;  // "skip epipolar search"
+    w.warp_active[s] = 0;
+    return;
+  }
+  w.n_steps[s] = (int)n_steps;
+  w.step[2 * s] = epi_dir[0] / (double)n_steps;
+  w.step[2 * s + 1] = epi_dir[1] / (double)n_steps;
+  w.B[2 * s] = B[0];
+  w.B[2 * s + 1] = B[1];
+  w.mode[s] = MODE_SCAN;
+}
+
+// bytes [x0, x0+7] of a row as two dwords
+__device__ __forceinline__ void load_row8(const uint8_t* __restrict__ row, int x0, uint32_t& lo, uint32_t& hi) {
+  const int xa = x0 & ~3;
+  const uint32_t sel = (uint32_t)(x0 & 3);
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(row + xa);
+  const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+  lo = __builtin_amdgcn_alignbyte(d1, d0, sel);
+  hi = __builtin_amdgcn_alignbyte(d2, d1, sel);
+}
+
+constexpr int SCAN_BLOCK = 256;
+
+// ZMSSD scan, matcher.cpp:248-291.  One wave per seed.
+__global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) {
+  const int s = blockIdx.x * (SCAN_BLOCK / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (s >= a.S) return;
+  const SeedWs& w = a.ws;
+  if (w.mode[s] != MODE_SCAN) return;
+  const int sl = w.search_level[s];
+  const uint8_t* img = a.store + (int64_t)w.cur_slot[s] * a.L.slot_bytes + a.L.offset[sl];
+  const int pitch = a.L.pitch[sl];
+  // reference patch: interior of patch_with_border (createPatchFromPatchWithBorder), 8 rows of 8
+  uint32_t ra[16];
+  {
+    const uint8_t* pw = w.pwb + (size_t)s * 100;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      const uint8_t* r = pw + (y + 1) * 10 + 1;
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        lo |= (uint32_t)r[k] << (8 * k);
+        hi |= (uint32_t)r[4 + k] << (8 * k);
+      }
+      ra[2 * y] = lo;
+      ra[2 * y + 1] = hi;
+    }
+  }
+  uint32_t sumA_u = 0, sumAA_u = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    sumA_u = __builtin_amdgcn_udot4(ra[k], 0x01010101u, sumA_u, false);
+    sumAA_u = __builtin_amdgcn_udot4(ra[k], ra[k], sumAA_u, false);
+  }
+  const int sumA = (int)sumA_u, sumAA = (int)sumAA_u;
+  const double step0 = w.step[2 * s], step1 = w.step[2 * s + 1];
+  double uv0 = w.B[2 * s] - step0, uv1 = w.B[2 * s + 1] - step1;
+  int last_x = 0, last_y = 0;
+  const int n_total = w.n_steps[s] + 1;
+  int best = ZMSSD_THRESHOLD;
+  int best_i = 0x7fffffff;
+  double best_uv0 = 0, best_uv1 = 0;
+  const double lvl = (double)(1 << sl);
+  for (int i = 0; i < n_total; ++i, uv0 += step0, uv1 += step1) {
+    const double px0 = a.cam.fx * uv0 + a.cam.cx;
+    const double px1 = a.cam.fy * uv1 + a.cam.cy;
+    const int pxi0 = cast_int(px0 / lvl + 0.5);
+    const int pxi1 = cast_int(px1 / lvl + 0.5);
+    if (pxi0 == last_x && pxi1 == last_y) continue;
+    last_x = pxi0;
+    last_y = pxi1;
+    if ((i & 63) != lane) continue;
+    if (!is_in_frame_level(a.cam, pxi0, pxi1, 8, sl)) continue;
+    const uint8_t* cp = img + (int64_t)(pxi1 - 4) * pitch;
+    uint32_t sumB = 0, sumBB = 0, sumAB = 0;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      uint32_t lo, hi;
+      load_row8(cp + (int64_t)y * pitch, pxi0 - 4, lo, hi);
+      sumB = __builtin_amdgcn_udot4(lo, 0x01010101u, sumB, false);
+      sumB = __builtin_amdgcn_udot4(hi, 0x01010101u, sumB, false);
+      sumBB = __builtin_amdgcn_udot4(lo, lo, sumBB, false);
+      sumBB = __builtin_amdgcn_udot4(hi, hi, sumBB, false);
+      sumAB = __builtin_amdgcn_udot4(lo, ra[2 * y], sumAB, false);
+      sumAB = __builtin_amdgcn_udot4(hi, ra[2 * y + 1], sumAB, false);
+    }
+    const int sB = (int)sumB, sBB = (int)sumBB, sAB = (int)sumAB;
+    const int zmssd = sumAA - 2 * sAB + sBB - (sumA * sumA - 2 * sumA * sB + sB * sB) / 64;
+    if (zmssd < best) {
+      best = zmssd;
+      best_i = i;
+      best_uv0 = uv0;
+      best_uv1 = uv1;
+    }
+  }
+  // first strictly smaller score along the line == lexicographic minimum of (score, step)
+  unsigned long long key = ((unsigned long long)(unsigned)best << 32) | (unsigned)best_i;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(key, off, 64);
+    key = o < key ? o : key;
+  }
+  const int win_score = (int)(key >> 32);
+  const int win_i = (int)(key & 0xffffffffu);
+  if (win_score < ZMSSD_THRESHOLD && win_i == best_i && best < ZMSSD_THRESHOLD) {
+    // exactly one lane owns step win_i
+    w.uv_best[2 * s] = best_uv0;
+    w.uv_best[2 * s + 1] = best_uv1;
+    const double pc0 = a.cam.fx * best_uv0 + a.cam.cx, pc1 = a.cam.fy * best_uv1 + a.cam.cy;
+    w.px_cur[2 * s] = pc0;
+    w.px_cur[2 * s + 1] = pc1;
+    w.px_scaled[2 * s] = pc0 / lvl;
+    w.px_scaled[2 * s + 1] = pc1 / lvl;
+    w.align_active[s] = a.opt.subpix_refinement ? 1 : 0;
+    w.align_ok[s] = a.opt.subpix_refinement ? 0 : 2;  // 2: accepted without refinement
+  }
+  if (lane == 0 && !(win_score < ZMSSD_THRESHOLD)) w.status[s] = SVO_HIP_SEED_NO_MATCH;
+}
+
+// depthFromTriangulation, matcher.cpp:109-122
+__device__ __forceinline__ bool depth_from_triangulation(const Se3& T_search_ref, const double f_ref[3],
+                                                         const double f_cur[3], double* depth) {
+  double R[9];
+  quat_to_R(T_search_ref.q, R);
+  double A[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    A[i][0] = R[i * 3] * f_ref[0] + R[i * 3 + 1] * f_ref[1] + R[i * 3 + 2] * f_ref[2];
+    A[i][1] = f_cur[i];
+  }
+  double AtA[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) AtA[i * 2 + j] = A[0][i] * A[0][j] + A[1][i] * A[1][j] + A[2][i] * A[2][j];
+  if (det2<double>(AtA) < 0.000001) return false;
+  double inv[4];
+  inv2<double>(AtA, inv);
+  const double i0 = -inv[0], i1 = -inv[1];
+  double m[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) m[k] = i0 * A[k][0] + i1 * A[k][1];
+  const double d0 = m[0] * T_search_ref.t[0] + m[1] * T_search_ref.t[1] + m[2] * T_search_ref.t[2];
+  *depth = fabs(d0);
+  return true;
+}
+
+// boost::math::pdf(normal_distribution<float>(mean, sd), x)
+__device__ __forceinline__ float normal_pdff(float x, float mean, float sd) {
+  float exponent = x - mean;
+  exponent *= -exponent;
+  exponent /= 2 * sd * sd;
+  float result = expf(exponent);
+  result /= sd * sqrtf(2 * 3.14159265358979323846f);
+  return result;
+}
+
+// DepthFilter::updateSeed, depth_filter.cpp:309-332 (all float, mixed with double literals
+// exactly as written in the reference)
+__device__ __forceinline__ void update_seed(const float x, const float tau2, float& a_, float& b_, float& mu_,
+                                            const float z_range, float& sigma2_) {
+  const float norm_scale = sqrtf(sigma2_ + tau2);
+  if (isnan(norm_scale)) return;
+  const float s2 = (float)(1. / (1. / (double)sigma2_ + 1. / (double)tau2));
+  const float m = s2 * (mu_ / sigma2_ + x / tau2);
+  float C1 = a_ / (a_ + b_) * normal_pdff(x, mu_, norm_scale);
+  float C2 = (float)((double)(b_ / (a_ + b_)) * 1. / (double)z_range);
+  const float normalization_constant = C1 + C2;
+  C1 /= normalization_constant;
+  C2 /= normalization_constant;
+  const float f = (float)((double)C1 * ((double)a_ + 1.) / ((double)(a_ + b_) + 1.) +
+                          (double)(C2 * a_) / ((double)(a_ + b_) + 1.));
+  const float e = (float)((double)C1 * ((double)a_ + 1.) * ((double)a_ + 2.) /
+                              (((double)(a_ + b_) + 1.) * ((double)(a_ + b_) + 2.)) +
+                          (double)(C2 * a_ * (a_ + 1.0f) / ((a_ + b_ + 1.0f) * (a_ + b_ + 2.0f))));
+  const float mu_new = C1 * m + C2 * mu_;
+  sigma2_ = C1 * (s2 + m * m) + C2 * (sigma2_ + mu_ * mu_) - mu_new * mu_new;
+  mu_ = mu_new;
+  a_ = (e - f) / (f - e / f);
+  b_ = a_ * (1.0f - f) / f;
+}
+
+// DepthFilter::computeTau, depth_filter.cpp:334-350
+__device__ __forceinline__ double compute_tau(const Se3& T_ref_cur, const double f[3], const double z,
+                                              const double px_error_angle) {
+  const double t[3] = {T_ref_cur.t[0], T_ref_cur.t[1], T_ref_cur.t[2]};
+  const double av[3] = {f[0] * z - t[0], f[1] * z - t[1], f[2] * z - t[2]};
+  const double t_norm = norm3(t);
+  const double a_norm = norm3(av);
+  const double alpha = acos(dot3(f, t) / t_norm);
+  const double mt[3] = {-t[0], -t[1], -t[2]};
+  const double beta = acos(dot3(av, mt) / (t_norm * a_norm));
+  const double beta_plus = beta + px_error_angle;
+  const double gamma_plus = SVO_PI - alpha - beta_plus;
+  const double z_plus = t_norm * sin(beta_plus) / sin(gamma_plus);
+  return (z_plus - z);
+}
+
+__global__ void __launch_bounds__(64) seed_finish_kernel(const SeedArgs a) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= a.S) return;
+  const SeedWs& w = a.ws;
+  int status = w.status[s];
+  if (a.px_cur_out) {
+    a.px_cur_out[2 * s] = w.px_cur[2 * s];
+    a.px_cur_out[2 * s + 1] = w.px_cur[2 * s + 1];
+  }
+  if (status == SVO_HIP_SEED_ERASED_OLD || status == SVO_HIP_SEED_BEHIND || status == SVO_HIP_SEED_NOT_IN_FRAME) {
+    a.status_out[s] = status;
+    return;
+  }
+  const int cf = a.cur_frame[s];
+  const int rfi = a.ftr.d_frame[s];
+  Se3 Tr, Tc;
+  se3_from_Rt(a.frame_T + 12 * rfi, Tr);
+  se3_from_Rt(a.frame_T + 12 * cf, Tc);
+  const double f[3] = {a.ftr.d_f[3 * s], a.ftr.d_f[3 * s + 1], a.ftr.d_f[3 * s + 2]};
+  bool matched = false;
+  double z = 0;
+  if (status == 0) {
+    const int aok = w.align_ok[s];
+    const Se3 T_cur_ref = se3_compose(Tc, se3_inverse(Tr));
+    if (w.align_active[s] && aok == 1) {
+      // px_cur_ = px_scaled*(1<<search_level_) was written by the alignment kernel
+      double fc[3];
+      cam2world(a.cam, w.px_cur[2 * s], w.px_cur[2 * s + 1], fc);
+      matched = depth_from_triangulation(T_cur_ref, f, fc, &z);
+    } else if (aok == 2) {
+      // subpix_refinement == false: vk::unproject2d(uv_best).normalized()
+      double fc[3] = {w.uv_best[2 * s], w.uv_best[2 * s + 1], 1.0};
+      normalize3(fc);
+      matched = depth_from_triangulation(T_cur_ref, f, fc, &z);
+    }
+  }
+  float sa = a.seeds.d_a[s], sb = a.seeds.d_b[s], smu = a.seeds.d_mu[s], ssig = a.seeds.d_sigma2[s];
+  const float zr = a.seeds.d_z_range[s];
+  if (!matched) {
+    a.seeds.d_b[s] = sb + 1.0f;  // it->b++ (:240)
+    a.status_out[s] = SVO_HIP_SEED_NO_MATCH;
+    return;
+  }
+  const double focal_length = fabs(a.cam.fx);
+  const double px_noise = 1.0;
+  const double px_error_angle = atan(px_noise / (2.0 * focal_length)) * 2.0;
+  const Se3 T_ref_cur = se3_compose(Tr, se3_inverse(Tc));
+  const double tau = compute_tau(T_ref_cur, f, z, px_error_angle);
+  const double zmt = (0.0000001 < z - tau) ? z - tau : 0.0000001;
+  const double tau_inverse = 0.5 * (1.0 / zmt - 1.0 / (z + tau));
+  update_seed((float)(1. / z), (float)(tau_inverse * tau_inverse), sa, sb, smu, zr, ssig);
+  a.seeds.d_a[s] = sa;
+  a.seeds.d_b[s] = sb;
+  a.seeds.d_mu[s] = smu;
+  a.seeds.d_sigma2[s] = ssig;
+  if ((double)sqrtf(ssig) < (double)zr / a.opt.seed_convergence_sigma2_thresh) {
+    const Se3 Tr_inv = se3_inverse(Tr);
+    const double kk = 1.0 / (double)smu;
+    const double pw[3] = {f[0] * kk, f[1] * kk, f[2] * kk};
+    double xw[3];
+    se3_apply(Tr_inv, pw, xw);
+    if (a.xyz_world) {
+      a.xyz_world[3 * s] = xw[0];
+      a.xyz_world[3 * s + 1] = xw[1];
+      a.xyz_world[3 * s + 2] = xw[2];
+    }
+    status = SVO_HIP_SEED_CONVERGED;
+  } else if (isnan(w.z_inv_min[s])) {
+    status = SVO_HIP_SEED_NAN;
+  } else {
+    status = SVO_HIP_SEED_UPDATED;
+  }
+  a.status_out[s] = status;
+}
+
+struct SeedOnlyArgs {
+  int S;
+  const float* x;
+  const float* tau2;
+  svo_hip_seeds seeds;
+};
+__global__ void __launch_bounds__(256) update_seed_kernel(const SeedOnlyArgs a) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= a.S) return;
+  float sa = a.seeds.d_a[s], sb = a.seeds.d_b[s], smu = a.seeds.d_mu[s], ssig = a.seeds.d_sigma2[s];
+  update_seed(a.x[s], a.tau2[s], sa, sb, smu, a.seeds.d_z_range[s], ssig);
+  a.seeds.d_a[s] = sa;
+  a.seeds.d_b[s] = sb;
+  a.seeds.d_mu[s] = smu;
+  a.seeds.d_sigma2[s] = ssig;
+}
+
+}  // namespace
+
+extern "C" int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
+                                    const svo_hip_camera* cam, const svo_hip_frames* frames, int S,
+                                    const int32_t* d_cur_frame, const svo_hip_features* ftr,
+                                    const svo_hip_seeds* seeds, const svo_hip_depth_filter_options* opt,
+                                    int32_t* d_status, double* d_xyz_world, double* d_px_cur, void* d_workspace,
+                                    size_t workspace_bytes, void* stream) {
+  if (!layout_ok(layout) || !d_store || !cam || !frames || !ftr || !seeds || !opt || S < 0) return SVO_HIP_EINVAL;
+  if (S == 0) return SVO_HIP_OK;
+  if (!d_cur_frame || !d_status || !frames->d_slot || !frames->d_T_f_w || !ftr->d_frame || !ftr->d_level ||
+      !ftr->d_px || !ftr->d_f || !seeds->d_a || !seeds->d_b || !seeds->d_mu || !seeds->d_z_range ||
+      !seeds->d_sigma2 || !seeds->d_batch_id)
+    return SVO_HIP_EINVAL;
+  if (ftr->d_type && !ftr->d_grad) return SVO_HIP_EINVAL;
+  if (opt->n_pyr_levels < 1 || opt->n_pyr_levels > layout->n_levels || opt->align_max_iter < 0 ||
+      opt->max_epi_search_steps < 0)
+    return SVO_HIP_EINVAL;
+  if (!d_workspace || workspace_bytes < svo_hip_match_workspace_bytes(S)) return SVO_HIP_ERANGE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Carver c(d_workspace, workspace_bytes);
+  const size_t n = (size_t)S;
+  SeedArgs a;
+  a.L = *layout;
+  a.store = d_store;
+  a.cam.fx = cam->fx; a.cam.fy = cam->fy; a.cam.cx = cam->cx; a.cam.cy = cam->cy;
+  a.cam.width = cam->width; a.cam.height = cam->height;
+  a.S = S;
+  a.frame_slot = frames->d_slot;
+  a.frame_T = frames->d_T_f_w;
+  a.cur_frame = d_cur_frame;
+  a.ftr = *ftr;
+  a.seeds = *seeds;
+  a.opt = *opt;
+  a.status_out = d_status;
+  a.xyz_world = d_xyz_world;
+  a.px_cur_out = d_px_cur;
+  SeedWs& w = a.ws;
+  w.pwb = c.take<uint8_t>(n * 100);
+  w.warp_active = c.take<uint8_t>(n);
+  w.align_active = c.take<uint8_t>(n);
+  w.use_1d = c.take<uint8_t>(n);
+  w.status = c.take<int32_t>(n);
+  w.mode = c.take<int32_t>(n);
+  w.ref_slot = c.take<int32_t>(n);
+  w.ref_level = c.take<int32_t>(n);
+  w.cur_slot = c.take<int32_t>(n);
+  w.search_level = c.take<int32_t>(n);
+  w.n_steps = c.take<int32_t>(n);
+  w.align_ok = c.take<int32_t>(n);
+  w.A_ref_cur = c.take<float>(4 * n);
+  w.px_ref_pyr = c.take<float>(2 * n);
+  w.dir = c.take<float>(2 * n);
+  w.z_inv_min = c.take<float>(n);
+  w.B = c.take<double>(2 * n);
+  w.step = c.take<double>(2 * n);
+  w.px_scaled = c.take<double>(2 * n);
+  w.px_cur = c.take<double>(2 * n);
+  w.uv_best = c.take<double>(2 * n);
+  if (!c.ok) return SVO_HIP_ERANGE;
+  hipLaunchKernelGGL(seed_prepare_kernel, dim3((S + 63) / 64), dim3(64), 0, st, a);
+  int rc = check_launch();
+  if (rc) return rc;
+  WarpArgs wa;
+  wa.L = *layout;
+  wa.store = d_store;
+  wa.M = S;
+  wa.active = w.warp_active;
+  wa.ref_slot = w.ref_slot;
+  wa.ref_level = w.ref_level;
+  wa.search_level = w.search_level;
+  wa.A_ref_cur = w.A_ref_cur;
+  wa.px_ref_pyr = w.px_ref_pyr;
+  wa.pwb = w.pwb;
+  rc = launch_warp(wa, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(epi_scan_kernel, dim3((S + (SCAN_BLOCK / 64) - 1) / (SCAN_BLOCK / 64)), dim3(SCAN_BLOCK), 0, st, a);
+  rc = check_launch();
+  if (rc) return rc;
+  AlignArgs al;
+  al.L = *layout;
+  al.store = d_store;
+  al.M = S;
+  al.slot = w.cur_slot;
+  al.level = w.search_level;
+  al.pwb = w.pwb;
+  al.dir = w.dir;
+  al.use_1d = w.use_1d;
+  al.active = w.align_active;
+  al.n_iter = opt->align_max_iter;
+  al.px_in = w.px_scaled;
+  al.px_out = w.px_cur;
+  al.scale_out = 1;
+  al.ok = w.align_ok;
+  al.h_inv = nullptr;
+  rc = launch_align(al, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(seed_finish_kernel, dim3((S + 63) / 64), dim3(64), 0, st, a);
+  return check_launch();
+}
+
+extern "C" int svo_hip_update_seed_batch(int S, const float* d_x, const float* d_tau2, const svo_hip_seeds* seeds,
+                                         void* stream) {
+  if (S < 0 || !seeds) return SVO_HIP_EINVAL;
+  if (S == 0) return SVO_HIP_OK;
+  if (!d_x || !d_tau2 || !seeds->d_a || !seeds->d_b || !seeds->d_mu || !seeds->d_z_range || !seeds->d_sigma2)
+    return SVO_HIP_EINVAL;
+  SeedOnlyArgs a;
+  a.S = S;
+  a.x = d_x;
+  a.tau2 = d_tau2;
+  a.seeds = *seeds;
+  hipLaunchKernelGGL(update_seed_kernel, dim3((S + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch();
+}

@@ -1,0 +1,353 @@
+// matcher.hip -- K2: batched Matcher::findMatchDirect front end for gfx950, plus
+// Reprojector::reprojectPoint.
+//
+// Replaces, per candidate map point (svo/src/matcher.cpp:135-177):
+//   Point::getCloseViewObs            (svo/src/point.cpp:97-117)     \  match_prepare_kernel
+//   isInFrame test on the ref feature (matcher.cpp:143-145)          |  one lane per candidate,
+//   warp::getWarpMatrixAffine         (matcher.cpp:33-55)            |  f64 geometry
+//   warp::getBestSearchLevel          (matcher.cpp:57-70)            /
+//   warp::warpAffine 10x10            (matcher.cpp:72-105)              warp_kernel, 25 lanes per
+//                                                                       candidate x 4 samples
+//   feature_alignment::align2D/1D     (feature_alignment.cpp)           K3 (feature_align.hip)
+//
+// The map (Point -> list of observing Features -> Frames) reaches the device as a CSR
+// structure over SoA feature records and a frame table; no pointer graph on the GPU.
+// Everything a later stage needs travels through a caller-provided workspace, so the whole
+// chain is three launches on one stream with no host synchronisation.
+#pragma clang fp contract(off)
+#include "track_kernels.h"
+#include "track_math.h"
+#include "matcher_device.h"
+
+using namespace svo_capi;
+using namespace svo_dev;
+using namespace svo_track;
+
+
+namespace {
+
+struct PrepArgs {
+  Cam cam;
+  int M;
+  int n_pyr_levels;
+  const int32_t* frame_slot;
+  const double* frame_T;
+  const int32_t* cur_frame;
+  const double* pt_pos;
+  const int32_t* obs_ptr;
+  svo_hip_features obs;
+  const double* px_cur;  // [M][2] level-0 estimate
+  // outputs for the caller
+  int32_t* ref_obs;
+  int32_t* search_level;
+  double* A_cur_ref;  // may be NULL
+  // workspace
+  uint8_t* active;
+  int32_t* ref_slot;
+  int32_t* ref_level;
+  int32_t* cur_slot;
+  float* A_ref_cur;
+  float* px_ref_pyr;
+  float* dir;
+  uint8_t* use_1d;
+  double* px_scaled;
+};
+
+__global__ void __launch_bounds__(64) match_prepare_kernel(const PrepArgs a) {
+  const int m = blockIdx.x * 64 + threadIdx.x;
+  if (m >= a.M) return;
+  a.active[m] = 0;
+  a.ref_obs[m] = -1;
+  a.search_level[m] = 0;
+  a.ref_slot[m] = 0;
+  a.ref_level[m] = 0;
+  a.use_1d[m] = 0;
+  a.dir[2 * m] = 1.f;
+  a.dir[2 * m + 1] = 0.f;
+  const int cf = a.cur_frame[m];
+  a.cur_slot[m] = a.frame_slot[cf];
+  a.px_scaled[2 * m] = a.px_cur[2 * m];
+  a.px_scaled[2 * m + 1] = a.px_cur[2 * m + 1];
+  if (a.A_cur_ref) {
+    a.A_cur_ref[4 * m] = a.A_cur_ref[4 * m + 1] = a.A_cur_ref[4 * m + 2] = a.A_cur_ref[4 * m + 3] = 0.0;
+  }
+  const int o0 = a.obs_ptr[m], o1 = a.obs_ptr[m + 1];
+  if (o1 <= o0) return;
+  Se3 Tc;
+  se3_from_Rt(a.frame_T + 12 * cf, Tc);
+  double cur_pos[3];
+  frame_pos(Tc, cur_pos);
+  const double pt[3] = {a.pt_pos[3 * m], a.pt_pos[3 * m + 1], a.pt_pos[3 * m + 2]};
+  // Point::getCloseViewObs (point.cpp:97-117)
+  double obs_dir[3] = {cur_pos[0] - pt[0], cur_pos[1] - pt[1], cur_pos[2] - pt[2]};
+  normalize3(obs_dir);
+  int best = o0;
+  double min_cos_angle = 0;
+  for (int o = o0; o < o1; ++o) {
+    Se3 Tf;
+    se3_from_Rt(a.frame_T + 12 * a.obs.d_frame[o], Tf);
+    double fp[3];
+    frame_pos(Tf, fp);
+    double dir[3] = {fp[0] - pt[0], fp[1] - pt[1], fp[2] - pt[2]};
+    normalize3(dir);
+    const double cos_angle = dot3(obs_dir, dir);
+    if (cos_angle > min_cos_angle) {
+      min_cos_angle = cos_angle;
+      best = o;
+    }
+  }
+  a.ref_obs[m] = best;
+  if (min_cos_angle < 0.5) return;
+  const int rfi = a.obs.d_frame[best];
+  const int rlevel = a.obs.d_level[best];
+  const double rpx[2] = {a.obs.d_px[2 * best], a.obs.d_px[2 * best + 1]};
+  // isInFrame(px.cast<int>()/(1<<level), halfpatch_size_+2, level)  (matcher.cpp:143-145)
+  if (!is_in_frame_level(a.cam, cast_int(rpx[0]) / (1 << rlevel), cast_int(rpx[1]) / (1 << rlevel), 4 + 2, rlevel))
+    return;
+  Se3 Tr;
+  se3_from_Rt(a.frame_T + 12 * rfi, Tr);
+  double ref_pos[3];
+  frame_pos(Tr, ref_pos);
+  const double d[3] = {ref_pos[0] - pt[0], ref_pos[1] - pt[1], ref_pos[2] - pt[2]};
+  const Se3 T_cur_ref = se3_compose(Tc, se3_inverse(Tr));
+  const double rf[3] = {a.obs.d_f[3 * best], a.obs.d_f[3 * best + 1], a.obs.d_f[3 * best + 2]};
+  double A[4];
+  warp_matrix_affine(a.cam, rpx, rf, norm3(d), T_cur_ref, rlevel, A);
+  const int sl = best_search_level(A, a.n_pyr_levels - 1);
+  a.search_level[m] = sl;
+  if (a.A_cur_ref) {
+    a.A_cur_ref[4 * m] = A[0]; a.A_cur_ref[4 * m + 1] = A[1]; a.A_cur_ref[4 * m + 2] = A[2]; a.A_cur_ref[4 * m + 3] = A[3];
+  }
+  double Ainv[4];
+  inv2<double>(A, Ainv);
+  a.A_ref_cur[4 * m] = (float)Ainv[0];
+  a.A_ref_cur[4 * m + 1] = (float)Ainv[1];
+  a.A_ref_cur[4 * m + 2] = (float)Ainv[2];
+  a.A_ref_cur[4 * m + 3] = (float)Ainv[3];
+  a.px_ref_pyr[2 * m] = (float)rpx[0] / (float)(1 << rlevel);
+  a.px_ref_pyr[2 * m + 1] = (float)rpx[1] / (float)(1 << rlevel);
+  a.ref_slot[m] = a.frame_slot[rfi];
+  a.ref_level[m] = rlevel;
+  a.px_scaled[2 * m] = a.px_cur[2 * m] / (double)(1 << sl);
+  a.px_scaled[2 * m + 1] = a.px_cur[2 * m + 1] / (double)(1 << sl);
+  const bool edgelet = a.obs.d_type && a.obs.d_type[best] == SVO_HIP_FTR_EDGELET;
+  if (edgelet) {
+    const double gx = a.obs.d_grad[2 * best], gy = a.obs.d_grad[2 * best + 1];
+    double dir_cur[2] = {A[0] * gx + A[1] * gy, A[2] * gx + A[3] * gy};
+    const double n = norm2(dir_cur);
+    dir_cur[0] /= n;
+    dir_cur[1] /= n;
+    a.dir[2 * m] = (float)dir_cur[0];
+    a.dir[2 * m + 1] = (float)dir_cur[1];
+    a.use_1d[m] = 1;
+  }
+  a.active[m] = 1;
+}
+
+// vk::interpolateMat_8u (rpg_vikit vision.h)
+__device__ __forceinline__ float interpolate_8u(const uint8_t* __restrict__ img, int pitch, float u, float v) {
+  const int x = (int)floorf(u);
+  const int y = (int)floorf(v);
+  const float subpix_x = u - (float)x;
+  const float subpix_y = v - (float)y;
+  const float w00 = (1.0f - subpix_x) * (1.0f - subpix_y);
+  const float w01 = (1.0f - subpix_x) * subpix_y;
+  const float w10 = subpix_x * (1.0f - subpix_y);
+  const float w11 = 1.0f - w00 - w01 - w10;
+  const uint8_t* ptr = img + (int64_t)y * pitch + x;
+  return w00 * (float)ptr[0] + w01 * (float)ptr[pitch] + w10 * (float)ptr[1] + w11 * (float)ptr[pitch + 1];
+}
+
+// warp::warpAffine (matcher.cpp:72-105), halfpatch_size = 5.  32 lanes per trial, lanes
+// 0..24 produce 4 consecutive output bytes each and store one dword.
+__global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int m = gid >> 5;
+  const int k = gid & 31;
+  if (m >= a.M || k >= 25) return;
+  uint32_t packed = 0;
+  const float A0 = a.A_ref_cur[4 * m], A1 = a.A_ref_cur[4 * m + 1], A2 = a.A_ref_cur[4 * m + 2], A3 = a.A_ref_cur[4 * m + 3];
+  // "Affine warp is NaN": the reference leaves the previous patch in place; here: zeros
+  if (a.active[m] && !isnan(A0)) {
+    const int level = a.ref_level[m];
+    const uint8_t* img = a.store + (int64_t)a.ref_slot[m] * a.L.slot_bytes + a.L.offset[level];
+    const int cols = a.L.w[level], rows = a.L.h[level], pitch = a.L.pitch[level];
+    const float pyr0 = a.px_ref_pyr[2 * m], pyr1 = a.px_ref_pyr[2 * m + 1];
+    const float sc = (float)(1 << a.search_level[m]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = 4 * k + j;
+      const int y = i / 10, x = i - 10 * y;
+      float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
+      pp0 *= sc;
+      pp1 *= sc;
+      const float px0 = (A0 * pp0 + A1 * pp1) + pyr0;
+      const float px1 = (A2 * pp0 + A3 * pp1) + pyr1;
+      uint32_t val = 0;
+      if (!(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1)))
+        val = (uint32_t)(uint8_t)interpolate_8u(img, pitch, px0, px1);
+      packed |= val << (8 * j);
+    }
+  }
+  reinterpret_cast<uint32_t*>(a.pwb + (size_t)m * 100)[k] = packed;
+}
+
+struct ReprojArgs {
+  Cam cam;
+  int M;
+  const double* frame_T;
+  const int32_t* cur_frame;
+  const double* pt_pos;
+  int cell_size, grid_n_cols;
+  int32_t* cell;
+  double* px;
+};
+__global__ void __launch_bounds__(256) reproject_kernel(const ReprojArgs a) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= a.M) return;
+  Se3 T;
+  se3_from_Rt(a.frame_T + 12 * a.cur_frame[m], T);
+  const double pos[3] = {a.pt_pos[3 * m], a.pt_pos[3 * m + 1], a.pt_pos[3 * m + 2]};
+  double p[3], px[2];
+  se3_apply(T, pos, p);
+  world2cam(a.cam, p, px);
+  int k = -1;
+  if (is_in_frame(a.cam, cast_int(px[0]), cast_int(px[1]), 8))
+    k = cast_int(px[1] / a.cell_size) * a.grid_n_cols + cast_int(px[0] / a.cell_size);
+  a.cell[m] = k;
+  if (a.px) {
+    a.px[2 * m] = px[0];
+    a.px[2 * m + 1] = px[1];
+  }
+}
+
+inline Cam make_cam(const svo_hip_camera* c) {
+  Cam k;
+  k.fx = c->fx; k.fy = c->fy; k.cx = c->cx; k.cy = c->cy; k.width = c->width; k.height = c->height;
+  return k;
+}
+
+}  // namespace
+
+namespace svo_track {
+int launch_warp(const WarpArgs& a, hipStream_t s) {
+  if (a.M <= 0) return SVO_HIP_OK;
+  const long long lanes = (long long)a.M * 32;
+  hipLaunchKernelGGL(warp_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, a);
+  return check_launch();
+}
+}  // namespace svo_track
+
+extern "C" size_t svo_hip_match_workspace_bytes(int M) {
+  if (M < 0) return 0;
+  const size_t m = (size_t)M;
+  // generous: every per-trial scratch array of the matcher and of the depth filter
+  size_t b = 0;
+  b += Carver::round(m * 100);                 // patches
+  b += 6 * Carver::round(m * sizeof(int32_t)); // slots, levels, flags
+  b += 3 * Carver::round(m);                   // u8 flags
+  b += Carver::round(m * 4 * sizeof(float)) + 2 * Carver::round(m * 2 * sizeof(float));
+  b += 8 * Carver::round(m * 2 * sizeof(double));  // px arrays, epipolar geometry
+  b += 4 * Carver::round(m * sizeof(double));
+  b += Carver::round(m * 12 * sizeof(double));     // T_cur_ref (quaternion + t padded)
+  return b + 4096;
+}
+
+extern "C" int svo_hip_find_match_direct(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
+                                         const svo_hip_camera* cam, const svo_hip_frames* frames, int M,
+                                         const int32_t* d_cur_frame, const double* d_pt_pos,
+                                         const int32_t* d_obs_ptr, const svo_hip_features* obs, int n_pyr_levels,
+                                         int align_max_iter, double* d_px_cur, int32_t* d_ok, int32_t* d_ref_obs,
+                                         int32_t* d_search_level, double* d_A_cur_ref, uint8_t* d_patch_out,
+                                         void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (!layout_ok(layout) || !d_store || !cam || !frames || !obs || M < 0) return SVO_HIP_EINVAL;
+  if (M == 0) return SVO_HIP_OK;
+  if (!d_cur_frame || !d_pt_pos || !d_obs_ptr || !d_px_cur || !d_ok || !d_ref_obs || !d_search_level ||
+      !frames->d_slot || !frames->d_T_f_w || !obs->d_frame || !obs->d_level || !obs->d_px || !obs->d_f)
+    return SVO_HIP_EINVAL;
+  if (obs->d_type && !obs->d_grad) return SVO_HIP_EINVAL;
+  if (n_pyr_levels < 1 || n_pyr_levels > layout->n_levels || align_max_iter < 0) return SVO_HIP_EINVAL;
+  if (!d_workspace || workspace_bytes < svo_hip_match_workspace_bytes(M)) return SVO_HIP_ERANGE;
+  if (d_patch_out && (reinterpret_cast<uintptr_t>(d_patch_out) & 3)) return SVO_HIP_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Carver ws(d_workspace, workspace_bytes);
+  const size_t m = (size_t)M;
+  PrepArgs p;
+  p.cam = make_cam(cam);
+  p.M = M;
+  p.n_pyr_levels = n_pyr_levels;
+  p.frame_slot = frames->d_slot;
+  p.frame_T = frames->d_T_f_w;
+  p.cur_frame = d_cur_frame;
+  p.pt_pos = d_pt_pos;
+  p.obs_ptr = d_obs_ptr;
+  p.obs = *obs;
+  p.px_cur = d_px_cur;
+  p.ref_obs = d_ref_obs;
+  p.search_level = d_search_level;
+  p.A_cur_ref = d_A_cur_ref;
+  uint8_t* pwb = d_patch_out ? d_patch_out : ws.take<uint8_t>(m * 100);
+  p.active = ws.take<uint8_t>(m);
+  p.ref_slot = ws.take<int32_t>(m);
+  p.ref_level = ws.take<int32_t>(m);
+  p.cur_slot = ws.take<int32_t>(m);
+  p.A_ref_cur = ws.take<float>(4 * m);
+  p.px_ref_pyr = ws.take<float>(2 * m);
+  p.dir = ws.take<float>(2 * m);
+  p.use_1d = ws.take<uint8_t>(m);
+  p.px_scaled = ws.take<double>(2 * m);
+  if (!ws.ok || !pwb) return SVO_HIP_ERANGE;
+  hipLaunchKernelGGL(match_prepare_kernel, dim3((M + 63) / 64), dim3(64), 0, s, p);
+  int rc = check_launch();
+  if (rc) return rc;
+  WarpArgs w;
+  w.L = *layout;
+  w.store = d_store;
+  w.M = M;
+  w.active = p.active;
+  w.ref_slot = p.ref_slot;
+  w.ref_level = p.ref_level;
+  w.search_level = d_search_level;
+  w.A_ref_cur = p.A_ref_cur;
+  w.px_ref_pyr = p.px_ref_pyr;
+  w.pwb = pwb;
+  rc = launch_warp(w, s);
+  if (rc) return rc;
+  AlignArgs al;
+  al.L = *layout;
+  al.store = d_store;
+  al.M = M;
+  al.slot = p.cur_slot;
+  al.level = d_search_level;
+  al.pwb = pwb;
+  al.dir = p.dir;
+  al.use_1d = p.use_1d;
+  al.active = p.active;
+  al.n_iter = align_max_iter;
+  al.px_in = p.px_scaled;
+  al.px_out = d_px_cur;
+  al.scale_out = 1;
+  al.ok = d_ok;
+  al.h_inv = nullptr;
+  return launch_align(al, s);
+}
+
+extern "C" int svo_hip_reproject_points(const svo_hip_camera* cam, const svo_hip_frames* frames, int M,
+                                        const int32_t* d_cur_frame, const double* d_pt_pos, int cell_size,
+                                        int grid_n_cols, int32_t* d_cell, double* d_px, void* stream) {
+  if (!cam || !frames || M < 0 || cell_size < 1 || grid_n_cols < 1) return SVO_HIP_EINVAL;
+  if (M == 0) return SVO_HIP_OK;
+  if (!d_cur_frame || !d_pt_pos || !d_cell || !frames->d_T_f_w) return SVO_HIP_EINVAL;
+  ReprojArgs a;
+  a.cam = make_cam(cam);
+  a.M = M;
+  a.frame_T = frames->d_T_f_w;
+  a.cur_frame = d_cur_frame;
+  a.pt_pos = d_pt_pos;
+  a.cell_size = cell_size;
+  a.grid_n_cols = grid_n_cols;
+  a.cell = d_cell;
+  a.px = d_px;
+  hipLaunchKernelGGL(reproject_kernel, dim3((M + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch();
+}

@@ -1,0 +1,325 @@
+// pose_optimizer.hip -- K4: batched pose_optimizer::optimizeGaussNewton for gfx950.
+//
+// Replaces svo::pose_optimizer::optimizeGaussNewton (svo/src/pose_optimizer.cpp:28-161):
+// robust (Tukey / MAD) Gauss-Newton refinement of Frame::T_f_w_ over the reprojection
+// errors of the frame's matched features, the covariance (:126), the outlier pruning
+// (:129-145) and the reported medians (:147-152).
+//
+// Mapping: one workgroup per frame, one lane per observation.  An iteration needs 28 f64
+// sums (21 unique entries of A, 6 of b, chi2).  Lanes drop their contributions into an LDS
+// tile [28][BLOCK]; 28 lanes then add their row in observation order, chunk after chunk --
+// the same order the reference's `for(fts_)` loop adds them in, so the normal equations are
+// reproduced to the bit wherever the per-observation arithmetic is (no reassociation).
+// Lane 0 runs the 6x6 pivoted LDLT (Eigen's algorithm), the rollback / convergence rules
+// and SE3::exp(dT)*T; medians are found by exact rank counting in LDS (nth_element's value).
+#pragma clang fp contract(off)
+#include "track_kernels.h"
+#include "track_math.h"
+
+using namespace svo_capi;
+using namespace svo_dev;
+
+namespace {
+
+constexpr int PO_BLOCK = 128;
+constexpr int PO_MAXN = 1024;
+constexpr double SVO_EPS = 0.0000000001;  // svo/include/svo/global.h:77
+
+struct PoseArgs {
+  Cam cam;
+  const int32_t* n;
+  int n_stride;
+  const double* f;
+  const int32_t* level;
+  const double* pos;
+  uint8_t* has_point;
+  double reproj_thresh;
+  int n_iter;
+  double* T;
+  double* Cov;
+  double* stats;
+  int32_t* ran;
+};
+
+struct PoseLds {
+  double tile[28][PO_BLOCK];
+  double vals[PO_MAXN];  // chi2_vec_init, later chi2_vec_final (0 where no point)
+  float err[PO_MAXN];
+  double acc[28];
+  Se3 T, T_old;
+  double scale;
+  double median_d;
+  double chi2;
+  float median_f;
+  int n_err;
+  int flag;  // 0 continue, 1 stop
+};
+
+// tukey: vk::robust_cost::TukeyWeightFunction::value
+__device__ __forceinline__ float tukey_weight(float x) {
+  const float b_square = 4.6851f * 4.6851f;
+  const float x_square = x * x;
+  if (x_square <= b_square) {
+    const float tmp = 1.0f - x_square / b_square;
+    return tmp * tmp;
+  }
+  return 0.0f;
+}
+
+// value with rank k among the entries of v[0..n) flagged in `hp` (ties broken by index):
+// what nth_element(begin, begin+k, end) leaves at position k.
+template <typename T>
+__device__ __forceinline__ void rank_select(const T* v, const uint8_t* hp, size_t hp_base, int n, int k, T* out) {
+  for (int i = threadIdx.x; i < n; i += PO_BLOCK) {
+    if (!hp[hp_base + i]) continue;
+    const T mine = v[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      if (!hp[hp_base + j]) continue;
+      const T o = v[j];
+      rank += (o < mine || (o == mine && j < i)) ? 1 : 0;
+    }
+    if (rank == k) *out = mine;
+  }
+}
+
+__global__ void __launch_bounds__(PO_BLOCK) pose_opt_kernel(const PoseArgs a) {
+  __shared__ PoseLds s;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int n = a.n[b];
+  const size_t base = (size_t)b * a.n_stride;
+  const double focal = fabs(a.cam.fx);
+
+  if (tid == 0) {
+    se3_from_Rt(a.T + 12 * b, s.T);
+    s.T_old = s.T;
+    s.n_err = 0;
+    s.flag = 0;
+    s.chi2 = 0.0;
+  }
+  __syncthreads();
+  // ---- error scale (:45-60) ---------------------------------------------------------
+  {
+    const Se3 T = s.T;
+    int cnt = 0;
+    for (int i = tid; i < n; i += PO_BLOCK) {
+      s.err[i] = 0.f;
+      if (!a.has_point[base + i]) continue;
+      const double p[3] = {a.pos[3 * (base + i)], a.pos[3 * (base + i) + 1], a.pos[3 * (base + i) + 2]};
+      const double fb[3] = {a.f[3 * (base + i)], a.f[3 * (base + i) + 1], a.f[3 * (base + i) + 2]};
+      double pf[3], u0[2], u1[2];
+      se3_apply(T, p, pf);
+      project2d(fb, u0);
+      project2d(pf, u1);
+      double e[2] = {u0[0] - u1[0], u0[1] - u1[1]};
+      const double k = 1.0 / (double)(1 << a.level[base + i]);
+      e[0] *= k;
+      e[1] *= k;
+      s.err[i] = (float)norm2(e);
+      ++cnt;
+    }
+    if (cnt) atomicAdd(&s.n_err, cnt);
+  }
+  __syncthreads();
+  const int n_err = s.n_err;
+  if (n_err == 0) {  // errors.empty(): return before touching anything (:57-58)
+    if (tid == 0) a.ran[b] = 0;
+    return;
+  }
+  rank_select<float>(s.err, a.has_point, base, n, n_err / 2, &s.median_f);
+  __syncthreads();
+  const double estimated_scale = (double)(1.48f * s.median_f);  // MADScaleEstimator::compute
+  if (tid == 0) s.scale = estimated_scale;
+
+  if (tid < 28) s.acc[tid] = 0.0;
+  // ---- Gauss-Newton (:66-121) -------------------------------------------------------
+  for (int iter = 0; iter < a.n_iter; ++iter) {
+    if (tid == 0 && iter == 5) s.scale = 0.85 / focal;
+    if (tid < 28) s.acc[tid] = 0.0;
+    __syncthreads();
+    const Se3 T = s.T;
+    const double scale = s.scale;
+    for (int c0 = 0; c0 < n; c0 += PO_BLOCK) {
+      const int i = c0 + tid;
+      double A21[21], bb[6], c2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 21; ++k) A21[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) bb[k] = 0.0;
+      bool live = false;
+      if (i < n && a.has_point[base + i]) {
+        live = true;
+        const double p[3] = {a.pos[3 * (base + i)], a.pos[3 * (base + i) + 1], a.pos[3 * (base + i) + 2]};
+        const double fb[3] = {a.f[3 * (base + i)], a.f[3 * (base + i) + 1], a.f[3 * (base + i) + 2]};
+        double J[12], xyz_f[3], u0[2], u1[2];
+        se3_apply(T, p, xyz_f);
+        frame_jacobian_xyz2uv(xyz_f, J);
+        project2d(fb, u0);
+        project2d(xyz_f, u1);
+        double e[2] = {u0[0] - u1[0], u0[1] - u1[1]};
+        const double sqrt_inv_cov = 1.0 / (double)(1 << a.level[base + i]);
+        e[0] *= sqrt_inv_cov;
+        e[1] *= sqrt_inv_cov;
+        const double e2 = e[0] * e[0] + e[1] * e[1];
+        if (iter == 0) s.vals[i] = e2;  // chi2_vec_init
+#pragma unroll
+        for (int k = 0; k < 12; ++k) J[k] *= sqrt_inv_cov;
+        const double weight = (double)tukey_weight((float)(norm2(e) / scale));
+        int q = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = r; c < 6; ++c) A21[q++] = (J[r] * J[c] + J[6 + r] * J[6 + c]) * weight;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) bb[r] = (J[r] * e[0] + J[6 + r] * e[1]) * weight;
+        c2 = e2 * weight;
+      } else if (iter == 0 && i < n) {
+        s.vals[i] = 0.0;
+      }
+      (void)live;
+#pragma unroll
+      for (int k = 0; k < 21; ++k) s.tile[k][tid] = A21[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s.tile[21 + k][tid] = bb[k];
+      s.tile[27][tid] = c2;
+      __syncthreads();
+      if (tid < 28) {
+        // A += ..., b -= ..., new_chi2 += ...   in observation order
+        const int m = (n - c0) < PO_BLOCK ? (n - c0) : PO_BLOCK;
+        double acc = s.acc[tid];
+        const bool neg = (tid >= 21 && tid < 27);
+        for (int j = 0; j < m; ++j) {
+          if (!a.has_point[base + c0 + j]) continue;  // `continue` in the reference: no +0.0 either
+          const double v = s.tile[tid][j];
+          acc = neg ? acc - v : acc + v;
+        }
+        s.acc[tid] = acc;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      double A[36], bv[6], dT[6];
+      int q = 0;
+      for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) {
+          A[r * 6 + c] = s.acc[q];
+          A[c * 6 + r] = s.acc[q];
+          ++q;
+        }
+      for (int r = 0; r < 6; ++r) bv[r] = s.acc[21 + r];
+      const double new_chi2 = s.acc[27];
+      ldlt_solve_pivoted<6>(A, bv, dT);
+      if ((iter > 0 && new_chi2 > s.chi2) || isnan(dT[0])) {
+        s.T = s.T_old;  // roll-back
+        s.flag = 1;
+      } else {
+        const Se3 ex = se3_exp_full(dT);
+        const Se3 T_new = se3_compose(ex, s.T);
+        s.T_old = s.T;
+        s.T = T_new;
+        s.chi2 = new_chi2;
+        double nm = -1;
+        for (int k = 0; k < 6; ++k)
+          if (fabs(dT[k]) > nm) nm = fabs(dT[k]);
+        if (nm <= SVO_EPS) s.flag = 1;
+      }
+    }
+    __syncthreads();
+    if (s.flag) break;
+  }
+  __syncthreads();
+  // ---- covariance (:124-126) --------------------------------------------------------
+  if (tid == 0) {
+    double A[36], Af[36], C[36];
+    int q = 0;
+    for (int r = 0; r < 6; ++r)
+      for (int c = r; c < 6; ++c) {
+        A[r * 6 + c] = s.acc[q];
+        A[c * 6 + r] = s.acc[q];
+        ++q;
+      }
+    const double f2 = focal * focal;  // std::pow(f, 2)
+    for (int k = 0; k < 36; ++k) Af[k] = A[k] * f2;
+    inv_lu<6>(Af, C);
+    if (a.Cov)
+      for (int k = 0; k < 36; ++k) a.Cov[36 * b + k] = 1.0 * C[k];
+    se3_to_Rt(s.T, a.T + 12 * b);
+  }
+  // chi2_vec_init median before vals is overwritten
+  rank_select<double>(s.vals, a.has_point, base, n, n_err / 2, &s.median_d);
+  __syncthreads();
+  const double med_init = s.median_d;
+  __syncthreads();
+  // ---- prune outliers (:128-145) ----------------------------------------------------
+  const double reproj_thresh_scaled = a.reproj_thresh / focal;
+  {
+    const Se3 T = s.T;
+    if (tid == 0) s.n_err = 0;
+    __syncthreads();
+    int deleted = 0;
+    for (int i = tid; i < n; i += PO_BLOCK) {
+      s.err[i] = 0.f;
+      if (!a.has_point[base + i]) continue;
+      const double p[3] = {a.pos[3 * (base + i)], a.pos[3 * (base + i) + 1], a.pos[3 * (base + i) + 2]};
+      const double fb[3] = {a.f[3 * (base + i)], a.f[3 * (base + i) + 1], a.f[3 * (base + i) + 2]};
+      double pf[3], u0[2], u1[2];
+      se3_apply(T, p, pf);
+      project2d(fb, u0);
+      project2d(pf, u1);
+      double e[2] = {u0[0] - u1[0], u0[1] - u1[1]};
+      const double k = 1.0 / (double)(1 << a.level[base + i]);
+      e[0] *= k;
+      e[1] *= k;
+      s.vals[i] = e[0] * e[0] + e[1] * e[1];  // chi2_vec_final
+      s.err[i] = 1.f;                         // member of chi2_vec_final
+      if (norm2(e) > reproj_thresh_scaled) {
+        s.err[i] = 2.f;  // pruned after the median is taken
+        ++deleted;
+      }
+    }
+    if (deleted) atomicAdd(&s.n_err, deleted);
+  }
+  __syncthreads();
+  rank_select<double>(s.vals, a.has_point, base, n, n_err / 2, &s.median_d);
+  __syncthreads();
+  const int n_deleted = s.n_err;
+  for (int i = tid; i < n; i += PO_BLOCK)
+    if (s.err[i] == 2.f) a.has_point[base + i] = 0;  // (*it)->point = NULL
+  if (tid == 0) {
+    a.stats[4 * b + 0] = estimated_scale * focal;
+    a.stats[4 * b + 1] = sqrt(med_init) * focal;
+    a.stats[4 * b + 2] = sqrt(s.median_d) * focal;
+    a.stats[4 * b + 3] = (double)(n_err - n_deleted);
+    a.ran[b] = 1;
+  }
+}
+
+}  // namespace
+
+extern "C" int svo_hip_pose_optimize(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride,
+                                     const double* d_f, const int32_t* d_level, const double* d_pos,
+                                     uint8_t* d_has_point, double reproj_thresh, int n_iter, double* d_T_f_w,
+                                     double* d_Cov, double* d_stats, int32_t* d_ran, void* stream) {
+  if (!cam || B < 0 || n_stride < 1 || n_iter < 0) return SVO_HIP_EINVAL;
+  if (n_stride > PO_MAXN) return SVO_HIP_ERANGE;
+  if (B == 0) return SVO_HIP_OK;
+  if (!d_n || !d_f || !d_level || !d_pos || !d_has_point || !d_T_f_w || !d_stats || !d_ran) return SVO_HIP_EINVAL;
+  PoseArgs a;
+  a.cam.fx = cam->fx; a.cam.fy = cam->fy; a.cam.cx = cam->cx; a.cam.cy = cam->cy;
+  a.cam.width = cam->width; a.cam.height = cam->height;
+  a.n = d_n;
+  a.n_stride = n_stride;
+  a.f = d_f;
+  a.level = d_level;
+  a.pos = d_pos;
+  a.has_point = d_has_point;
+  a.reproj_thresh = reproj_thresh;
+  a.n_iter = n_iter;
+  a.T = d_T_f_w;
+  a.Cov = d_Cov;
+  a.stats = d_stats;
+  a.ran = d_ran;
+  hipLaunchKernelGGL(pose_opt_kernel, dim3(B), dim3(PO_BLOCK), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch();
+}

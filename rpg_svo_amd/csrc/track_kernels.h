@@ -1,0 +1,60 @@
+// track_kernels.h -- internal launchers shared by the matcher / depth-filter entry points.
+#pragma once
+#include "capi_common.h"
+
+namespace svo_track {
+
+// K3 (feature_align.hip): one lane per trial
+struct AlignArgs {
+  svo_hip_pyr_layout L;
+  const uint8_t* store;
+  int M;
+  const int32_t* slot;     // [M] pyramid slot of the image searched
+  const int32_t* level;    // [M] its level
+  const uint8_t* pwb;      // [M][100]
+  const float* dir;        // [M][2] or NULL
+  const uint8_t* use_1d;   // [M] or NULL
+  const uint8_t* active;   // [M] or NULL: trials with 0 are skipped (ok = 0, px untouched)
+  int n_iter;
+  const double* px_in;     // [M][2] level coordinates
+  double* px_out;          // [M][2]
+  int scale_out;           // 1: px_out = px * (1 << level)  (Matcher: px_cur = px_scaled*(1<<search_level_))
+  int32_t* ok;             // [M]
+  double* h_inv;           // [M] or NULL
+};
+int launch_align(const AlignArgs& a, hipStream_t s);
+
+// K2b (matcher.hip): warp::warpAffine for M trials, 10x10 output, 32 lanes per trial
+struct WarpArgs {
+  svo_hip_pyr_layout L;
+  const uint8_t* store;
+  int M;
+  const uint8_t* active;      // [M]: 0 -> patch zeroed
+  const int32_t* ref_slot;    // [M]
+  const int32_t* ref_level;   // [M]
+  const int32_t* search_level;  // [M]
+  const float* A_ref_cur;     // [M][4] row-major (A_cur_ref^-1 cast to float)
+  const float* px_ref_pyr;    // [M][2] px_ref.cast<float>() / (1 << level_ref)
+  uint8_t* pwb;               // [M][100]
+};
+int launch_warp(const WarpArgs& a, hipStream_t s);
+
+// carve 256-byte aligned arrays out of a caller-provided workspace
+struct Carver {
+  uint8_t* p;
+  size_t left;
+  bool ok = true;
+  Carver(void* base, size_t bytes) : p(static_cast<uint8_t*>(base)), left(bytes) {}
+  template <typename T>
+  T* take(size_t n) {
+    const size_t need = (n * sizeof(T) + 255) & ~size_t(255);
+    if (need > left) { ok = false; return nullptr; }
+    T* r = reinterpret_cast<T*>(p);
+    p += need;
+    left -= need;
+    return r;
+  }
+  static size_t round(size_t n_bytes) { return (n_bytes + 255) & ~size_t(255); }
+};
+
+}  // namespace svo_track

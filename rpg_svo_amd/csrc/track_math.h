@@ -1,0 +1,297 @@
+// track_math.h -- device math for the kernels that follow sparse alignment (matcher,
+// feature alignment, pose optimizer, depth filter, point optimizer).
+//
+// The translation units that include this header are compiled with floating-point
+// contraction OFF (#pragma clang fp contract(off) before the includes): the feature
+// alignment and the affine warp are float pipelines whose results the reference truncates
+// to u8 / compares against thresholds, so every mul/add rounds separately, exactly like the
+// x86 build of the reference.  f64 geometry uses IEEE division and sqrt.
+//
+// Conventions: SE(3) as Sophus stores it (unit quaternion w,x,y,z + translation); poses
+// cross the C ABI as 12 doubles [R row-major | t].
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_math.h"
+
+namespace svo_dev {
+
+struct Se3 {
+  double q[4];
+  double t[3];
+};
+
+struct Cam {  // vk::PinholeCamera, zero distortion
+  double fx, fy, cx, cy;
+  int width, height;
+};
+
+__device__ __forceinline__ double norm3(const double v[3]) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+__device__ __forceinline__ double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void normalize3(double v[3]) {
+  const double n = norm3(v);
+  v[0] /= n; v[1] /= n; v[2] /= n;
+}
+__device__ __forceinline__ double norm2(const double v[2]) { return sqrt(v[0] * v[0] + v[1] * v[1]); }
+
+__device__ __forceinline__ void se3_from_Rt(const double* __restrict__ T, Se3& s) {
+  double R[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[k] = T[k];
+  quat_from_R(R, s.q);
+  s.t[0] = T[9]; s.t[1] = T[10]; s.t[2] = T[11];
+}
+__device__ __forceinline__ void se3_to_Rt(const Se3& s, double* __restrict__ T) {
+  double R[9];
+  quat_to_R(s.q, R);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) T[k] = R[k];
+  T[9] = s.t[0]; T[10] = s.t[1]; T[11] = s.t[2];
+}
+// Sophus SE3::operator*: t += so3*other.t ; so3 *= other.so3, renormalised
+__device__ __forceinline__ Se3 se3_compose(const Se3& a, const Se3& b) {
+  Se3 r;
+  double rt[3];
+  quat_rot(a.q, b.t, rt);
+  r.t[0] = a.t[0] + rt[0]; r.t[1] = a.t[1] + rt[1]; r.t[2] = a.t[2] + rt[2];
+  quat_mul(a.q, b.q, r.q);
+  const double n = sqrt(r.q[0] * r.q[0] + r.q[1] * r.q[1] + r.q[2] * r.q[2] + r.q[3] * r.q[3]);
+  r.q[0] /= n; r.q[1] /= n; r.q[2] /= n; r.q[3] /= n;
+  return r;
+}
+__device__ __forceinline__ Se3 se3_inverse(const Se3& a) {
+  Se3 r;
+  r.q[0] = a.q[0]; r.q[1] = -a.q[1]; r.q[2] = -a.q[2]; r.q[3] = -a.q[3];
+  const double nt[3] = {a.t[0] * -1., a.t[1] * -1., a.t[2] * -1.};
+  quat_rot(r.q, nt, r.t);
+  return r;
+}
+__device__ __forceinline__ void se3_apply(const Se3& a, const double v[3], double o[3]) {
+  quat_rot(a.q, v, o);
+  o[0] += a.t[0]; o[1] += a.t[1]; o[2] += a.t[2];
+}
+// Frame::pos() = T_f_w_.inverse().translation()
+__device__ __forceinline__ void frame_pos(const Se3& T_f_w, double p[3]) {
+  const Se3 inv = se3_inverse(T_f_w);
+  p[0] = inv.t[0]; p[1] = inv.t[1]; p[2] = inv.t[2];
+}
+
+// ---- vk::PinholeCamera -------------------------------------------------------------
+__device__ __forceinline__ void cam2world(const Cam& c, double u, double v, double f[3]) {
+  f[0] = (u - c.cx) / c.fx;
+  f[1] = (v - c.cy) / c.fy;
+  f[2] = 1.0;
+  normalize3(f);
+}
+__device__ __forceinline__ void world2cam_uv(const Cam& c, const double uv[2], double px[2]) {
+  px[0] = c.fx * uv[0] + c.cx;
+  px[1] = c.fy * uv[1] + c.cy;
+}
+__device__ __forceinline__ void project2d(const double v[3], double uv[2]) {
+  uv[0] = v[0] / v[2];
+  uv[1] = v[1] / v[2];
+}
+__device__ __forceinline__ void world2cam(const Cam& c, const double xyz[3], double px[2]) {
+  double uv[2];
+  project2d(xyz, uv);
+  world2cam_uv(c, uv, px);
+}
+__device__ __forceinline__ bool is_in_frame(const Cam& c, int x, int y, int boundary) {
+  return x >= boundary && x < c.width - boundary && y >= boundary && y < c.height - boundary;
+}
+__device__ __forceinline__ bool is_in_frame_level(const Cam& c, int x, int y, int boundary, int level) {
+  return x >= boundary && x < c.width / (1 << level) - boundary && y >= boundary &&
+         y < c.height / (1 << level) - boundary;
+}
+// double -> int like a C cast on x86 (cvttsd2si): out-of-range / NaN give INT_MIN
+__device__ __forceinline__ int cast_int(double v) {
+  if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
+  return (int)v;
+}
+
+// ---- Eigen small inverses (Eigen/src/LU/Inverse.h), row-major ------------------------
+template <typename T>
+__device__ __forceinline__ T det2(const T m[4]) { return m[0] * m[3] - m[2] * m[1]; }
+template <typename T>
+__device__ __forceinline__ void inv2(const T m[4], T r[4]) {
+  const T invdet = (T)1 / det2(m);
+  r[0] = m[3] * invdet;
+  r[2] = -m[2] * invdet;
+  r[1] = -m[1] * invdet;
+  r[3] = m[0] * invdet;
+}
+#define SVO_COF3(m, i1, i2, j1, j2) ((m)[(i1)*3 + (j1)] * (m)[(i2)*3 + (j2)] - (m)[(i1)*3 + (j2)] * (m)[(i2)*3 + (j1)])
+__device__ __forceinline__ void inv3f(const float m[9], float r[9]) {
+  // cofactor(i,j): rows (i+1)%3,(i+2)%3 ; cols (j+1)%3,(j+2)%3
+  const float c00 = SVO_COF3(m, 1, 2, 1, 2), c10 = SVO_COF3(m, 2, 0, 1, 2), c20 = SVO_COF3(m, 0, 1, 1, 2);
+  const float det = (c00 * m[0] + c10 * m[3]) + c20 * m[6];
+  const float invdet = 1.0f / det;
+  r[0] = c00 * invdet; r[1] = c10 * invdet; r[2] = c20 * invdet;
+  r[3] = SVO_COF3(m, 1, 2, 2, 0) * invdet;
+  r[4] = SVO_COF3(m, 2, 0, 2, 0) * invdet;
+  r[5] = SVO_COF3(m, 0, 1, 2, 0) * invdet;
+  r[6] = SVO_COF3(m, 1, 2, 0, 1) * invdet;
+  r[7] = SVO_COF3(m, 2, 0, 0, 1) * invdet;
+  r[8] = SVO_COF3(m, 0, 1, 0, 1) * invdet;
+}
+
+// ---- Eigen::LDLT<Lower> with diagonal pivoting + solve, n <= 6, local arrays ---------
+// (runs in one lane per problem; the arrays live in scratch/LDS, which is fine for a
+// 6x6 solve executed a handful of times per problem)
+template <int N>
+__device__ inline void ldlt_solve_pivoted(const double* A, const double* b, double* x) {
+  double m[N * N];
+  int tr[N];
+  double temp[N];
+  for (int i = 0; i < N * N; ++i) m[i] = A[i];
+#define M_(r, c) m[(r)*N + (c)]
+  bool all_zero = false;
+  for (int k = 0; k < N && !all_zero; ++k) {
+    int big = k;
+    double best = fabs(M_(k, k));
+    for (int i = k + 1; i < N; ++i)
+      if (fabs(M_(i, i)) > best) { best = fabs(M_(i, i)); big = i; }
+    tr[k] = big;
+    if (k != big) {
+      const int s = N - big - 1;
+      for (int c = 0; c < k; ++c) { double t = M_(k, c); M_(k, c) = M_(big, c); M_(big, c) = t; }
+      for (int r = 0; r < s; ++r) { double t = M_(big + 1 + r, k); M_(big + 1 + r, k) = M_(big + 1 + r, big); M_(big + 1 + r, big) = t; }
+      { double t = M_(k, k); M_(k, k) = M_(big, big); M_(big, big) = t; }
+      for (int i = k + 1; i < big; ++i) { double t = M_(i, k); M_(i, k) = M_(big, i); M_(big, i) = t; }
+    }
+    const int rs = N - k - 1;
+    if (k > 0) {
+      for (int c = 0; c < k; ++c) temp[c] = M_(c, c) * M_(k, c);
+      double acc = 0;
+      for (int c = 0; c < k; ++c) acc += M_(k, c) * temp[c];
+      M_(k, k) -= acc;
+      for (int r = 0; r < rs; ++r) {
+        double a2 = 0;
+        for (int c = 0; c < k; ++c) a2 += M_(k + 1 + r, c) * temp[c];
+        M_(k + 1 + r, k) -= a2;
+      }
+    }
+    const double akk = M_(k, k);
+    const bool pivot_is_valid = fabs(akk) > 0.0;
+    if (k == 0 && !pivot_is_valid) {
+      for (int j = 0; j < N; ++j) tr[j] = j;
+      all_zero = true;
+      break;
+    }
+    if (rs > 0 && pivot_is_valid)
+      for (int r = 0; r < rs; ++r) M_(k + 1 + r, k) /= akk;
+  }
+  for (int i = 0; i < N; ++i) x[i] = b[i];
+  for (int k = 0; k < N; ++k)
+    if (tr[k] != k) { double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+  for (int i = 0; i < N; ++i)
+    for (int c = 0; c < i; ++c) x[i] -= M_(i, c) * x[c];
+  for (int i = 0; i < N; ++i) {
+    if (fabs(M_(i, i)) > 2.2250738585072014e-308) x[i] /= M_(i, i);
+    else x[i] = 0;
+  }
+  for (int i = N - 1; i >= 0; --i)
+    for (int c = i + 1; c < N; ++c) x[i] -= M_(c, i) * x[c];
+  for (int k = N - 1; k >= 0; --k)
+    if (tr[k] != k) { double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+#undef M_
+}
+
+// general inverse by partial-pivot LU (Eigen PartialPivLU path for n > 4); Frame::Cov_
+template <int N>
+__device__ inline void inv_lu(const double* A, double* out) {
+  double lu[N * N];
+  int perm[N];
+  for (int i = 0; i < N * N; ++i) lu[i] = A[i];
+  for (int i = 0; i < N; ++i) perm[i] = i;
+  for (int k = 0; k < N; ++k) {
+    int piv = k;
+    double best = fabs(lu[k * N + k]);
+    for (int i = k + 1; i < N; ++i)
+      if (fabs(lu[i * N + k]) > best) { best = fabs(lu[i * N + k]); piv = i; }
+    if (piv != k) {
+      for (int c = 0; c < N; ++c) { double t = lu[k * N + c]; lu[k * N + c] = lu[piv * N + c]; lu[piv * N + c] = t; }
+      int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+    }
+    for (int i = k + 1; i < N; ++i) {
+      lu[i * N + k] /= lu[k * N + k];
+      for (int c = k + 1; c < N; ++c) lu[i * N + c] -= lu[i * N + k] * lu[k * N + c];
+    }
+  }
+  for (int col = 0; col < N; ++col) {
+    double y[N];
+    for (int i = 0; i < N; ++i) {
+      y[i] = (perm[i] == col) ? 1.0 : 0.0;
+      for (int c = 0; c < i; ++c) y[i] -= lu[i * N + c] * y[c];
+    }
+    for (int i = N - 1; i >= 0; --i) {
+      for (int c = i + 1; c < N; ++c) y[i] -= lu[i * N + c] * y[c];
+      y[i] /= lu[i * N + i];
+    }
+    for (int i = 0; i < N; ++i) out[i * N + col] = y[i];
+  }
+}
+
+// Sophus SE3::exp with libm-grade sin/cos (pose optimizer: increments are applied once per
+// iteration by one lane, accuracy matters more than speed here)
+__device__ inline Se3 se3_exp_full(const double xi[6]) {
+  Se3 r;
+  const double* ups = xi;
+  const double* om = xi + 3;
+  const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+  const double half_theta = 0.5 * theta;
+  double imag_factor;
+  const double real_factor = cos(half_theta);
+  if (theta < 1e-10) {
+    const double theta_sq = theta * theta;
+    const double theta_po4 = theta_sq * theta_sq;
+    imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * theta_po4;
+  } else {
+    imag_factor = sin(half_theta) / theta;
+  }
+  r.q[0] = real_factor;
+  r.q[1] = imag_factor * om[0];
+  r.q[2] = imag_factor * om[1];
+  r.q[3] = imag_factor * om[2];
+  const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+  double V[9];
+  if (theta < 1e-10) {
+    quat_to_R(r.q, V);
+  } else {
+    double O2[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double s = 0;
+        for (int k = 0; k < 3; ++k) s += O[i * 3 + k] * O[k * 3 + j];
+        O2[i * 3 + j] = s;
+      }
+    const double theta_sq = theta * theta;
+    const double c1 = (1 - cos(theta)) / (theta_sq);
+    const double c2 = (theta - sin(theta)) / (theta_sq * theta);
+    for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * O[i] + c2 * O2[i];
+  }
+  for (int i = 0; i < 3; ++i) r.t[i] = V[i * 3] * ups[0] + V[i * 3 + 1] * ups[1] + V[i * 3 + 2] * ups[2];
+  return r;
+}
+
+// Frame::jacobian_xyz2uv (svo/include/svo/frame.h:116-138), 2x6 row-major
+__device__ __forceinline__ void frame_jacobian_xyz2uv(const double xyz[3], double J[12]) {
+  const double x = xyz[0];
+  const double y = xyz[1];
+  const double z_inv = 1. / xyz[2];
+  const double z_inv_2 = z_inv * z_inv;
+  J[0] = -z_inv;
+  J[1] = 0.0;
+  J[2] = x * z_inv_2;
+  J[3] = y * J[2];
+  J[4] = -(1.0 + x * J[2]);
+  J[5] = y * z_inv;
+  J[6] = 0.0;
+  J[7] = -z_inv;
+  J[8] = y * z_inv_2;
+  J[9] = 1.0 + y * J[8];
+  J[10] = -J[3];
+  J[11] = -x * z_inv;
+}
+
+}  // namespace svo_dev

@@ -67,3 +67,34 @@ def run_hip(b: Batch, max_level, min_level, n_iter=30, device="cuda:0", halfsamp
     # cur_frame_->T_f_w_ = T_cur_from_ref * ref_frame_->T_f_w_ (sparse_img_align.cpp:70)
     T_cur_w = se3.mul(T_cr_out, b.T_ref_w)
     return T_cur_w, out, store
+
+
+# ---- scenes for the steps after sparse alignment ---------------------------------------
+def scene_store(scene, n_levels=5, device="cuda:0", T_override=None):
+    """PyramidStore + FrameTable of a synth.TrackScene (slot i = frame i)."""
+    from rpg_svo_amd.pyramid import PyramidStore
+    from rpg_svo_amd.tracking import FrameTable
+    dev = torch.device(device)
+    n = scene.images.shape[0]
+    store = PyramidStore(scene.cam.width, scene.cam.height, n_levels, n, device=device)
+    store.load_images(scene.images.to(dev))
+    T = scene.T_f_w if T_override is None else T_override
+    frames = FrameTable(torch.arange(n, dtype=torch.int32, device=dev),
+                        torch.as_tensor(np.ascontiguousarray(T), dtype=torch.float64, device=dev))
+    return store, frames
+
+
+def obs_csr(obs_lists, device="cuda:0"):
+    """Point::obs_ lists [(frame, px, f, level, type, grad)] -> (obs_ptr, FeatureSet)."""
+    from rpg_svo_amd.tracking import FeatureSet
+    dev = torch.device(device)
+    ptr = np.zeros(len(obs_lists) + 1, dtype=np.int32)
+    flat = []
+    for i, o in enumerate(obs_lists):
+        ptr[i + 1] = ptr[i] + len(o)
+        flat.extend(o)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+    fs = FeatureSet(frame=t([o[0] for o in flat], torch.int32), level=t([o[3] for o in flat], torch.int32),
+                    px=t([o[1] for o in flat], torch.float64), f=t([o[2] for o in flat], torch.float64),
+                    type=t([o[4] for o in flat], torch.uint8), grad=t([o[5] for o in flat], torch.float64))
+    return t(ptr, torch.int32), fs
