@@ -228,6 +228,18 @@ int svo_hip_reproject_points(const svo_hip_camera* cam, const svo_hip_frames* fr
                              const int32_t* d_cur_frame, const double* d_pt_pos, int cell_size,
                              int grid_n_cols, int32_t* d_cell, double* d_px, void* stream);
 
+/* Frame glue that the reference does inline on the host, kept on the device so a tracked
+ * frame never leaves HBM between kernels:
+ *  - svo_hip_compose_poses: d_out[i] = d_A[i] * d_B[i] (Sophus SE3 product), e.g.
+ *    cur_frame_->T_f_w_ = T_cur_from_ref * ref_frame_->T_f_w_ (sparse_img_align.cpp:70);
+ *    d_out rows may be scattered through d_out_index (NULL = identity).
+ *  - svo_hip_cam2world: d_f[i] = cam->cam2world(d_px[i]), the unit bearing a new Feature is
+ *    constructed with (feature.h:44-52, reprojector.cpp:182). */
+int svo_hip_compose_poses(int n, const double* d_A, const double* d_B, double* d_out,
+                          const int32_t* d_out_index, void* stream);
+int svo_hip_cam2world(const svo_hip_camera* cam, int n, const double* d_px, double* d_f,
+                      void* stream);
+
 /*
  * K4: batched pose_optimizer::optimizeGaussNewton (svo/src/pose_optimizer.cpp:28-161), one
  * workgroup per frame.  Observations of frame b are rows [b*n_stride, b*n_stride+d_n[b]):

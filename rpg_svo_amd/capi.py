@@ -110,6 +110,8 @@ PROTOTYPES = {
     "svo_hip_find_match_direct": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, _vp, _vp,
                                        C.POINTER(Features), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "svo_hip_reproject_points": (_i, [C.POINTER(Camera), C.POINTER(Frames), _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "svo_hip_compose_poses": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "svo_hip_cam2world": (_i, [C.POINTER(Camera), _i, _vp, _vp, _vp]),
     "svo_hip_pose_optimize": (_i, [C.POINTER(Camera), _i, _vp, _i, _vp, _vp, _vp, _vp, C.c_double, _i, _vp, _vp, _vp,
                                    _vp, _vp]),
     "svo_hip_point_optimize": (_i, [C.POINTER(Frames), _i, _vp, _vp, _vp, _i, _vp, _vp]),

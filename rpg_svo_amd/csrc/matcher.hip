@@ -155,7 +155,13 @@ __device__ __forceinline__ float interpolate_8u(const uint8_t* __restrict__ img,
   const float w10 = subpix_x * (1.0f - subpix_y);
   const float w11 = 1.0f - w00 - w01 - w10;
   const uint8_t* ptr = img + (int64_t)y * pitch + x;
-  return w00 * (float)ptr[0] + w01 * (float)ptr[pitch] + w10 * (float)ptr[1] + w11 * (float)ptr[pitch + 1];
+  // two unaligned 16-bit loads (gfx950 global memory takes any alignment) instead of four bytes
+  uint16_t top, bot;
+  __builtin_memcpy(&top, ptr, 2);
+  __builtin_memcpy(&bot, ptr + pitch, 2);
+  const float p00 = (float)(top & 0xffu), p10 = (float)(top >> 8);
+  const float p01 = (float)(bot & 0xffu), p11 = (float)(bot >> 8);
+  return w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
 }
 
 // warp::warpAffine (matcher.cpp:72-105), halfpatch_size = 5.  32 lanes per trial, lanes
@@ -219,6 +225,36 @@ __global__ void __launch_bounds__(256) reproject_kernel(const ReprojArgs a) {
     a.px[2 * m] = px[0];
     a.px[2 * m + 1] = px[1];
   }
+}
+
+struct GlueArgs {
+  Cam cam;
+  int n;
+  const double* A;
+  const double* B;
+  double* out;
+  const int32_t* out_index;
+  const double* px;
+  double* f;
+};
+__global__ void __launch_bounds__(256) compose_kernel(const GlueArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  Se3 x, y;
+  se3_from_Rt(a.A + 12 * i, x);
+  se3_from_Rt(a.B + 12 * i, y);
+  const Se3 r = se3_compose(x, y);
+  const int o = a.out_index ? a.out_index[i] : i;
+  se3_to_Rt(r, a.out + 12 * o);
+}
+__global__ void __launch_bounds__(256) cam2world_kernel(const GlueArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  double f[3];
+  cam2world(a.cam, a.px[2 * i], a.px[2 * i + 1], f);
+  a.f[3 * i] = f[0];
+  a.f[3 * i + 1] = f[1];
+  a.f[3 * i + 2] = f[2];
 }
 
 inline Cam make_cam(const svo_hip_camera* c) {
@@ -349,5 +385,33 @@ extern "C" int svo_hip_reproject_points(const svo_hip_camera* cam, const svo_hip
   a.cell = d_cell;
   a.px = d_px;
   hipLaunchKernelGGL(reproject_kernel, dim3((M + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch();
+}
+
+extern "C" int svo_hip_compose_poses(int n, const double* d_A, const double* d_B, double* d_out,
+                                     const int32_t* d_out_index, void* stream) {
+  if (n < 0) return SVO_HIP_EINVAL;
+  if (n == 0) return SVO_HIP_OK;
+  if (!d_A || !d_B || !d_out) return SVO_HIP_EINVAL;
+  GlueArgs a{};
+  a.n = n;
+  a.A = d_A;
+  a.B = d_B;
+  a.out = d_out;
+  a.out_index = d_out_index;
+  hipLaunchKernelGGL(compose_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch();
+}
+
+extern "C" int svo_hip_cam2world(const svo_hip_camera* cam, int n, const double* d_px, double* d_f, void* stream) {
+  if (!cam || n < 0) return SVO_HIP_EINVAL;
+  if (n == 0) return SVO_HIP_OK;
+  if (!d_px || !d_f) return SVO_HIP_EINVAL;
+  GlueArgs a{};
+  a.cam = make_cam(cam);
+  a.n = n;
+  a.px = d_px;
+  a.f = d_f;
+  hipLaunchKernelGGL(cam2world_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return check_launch();
 }

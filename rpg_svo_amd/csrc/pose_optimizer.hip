@@ -21,7 +21,7 @@ using namespace svo_dev;
 
 namespace {
 
-constexpr int PO_BLOCK = 128;
+constexpr int PO_BLOCK = 64;  // one wave per frame: the serial parts dominate, occupancy comes from many small workgroups
 constexpr int PO_MAXN = 1024;
 constexpr double SVO_EPS = 0.0000000001;  // svo/include/svo/global.h:77
 
@@ -43,8 +43,7 @@ struct PoseArgs {
 
 struct PoseLds {
   double tile[28][PO_BLOCK];
-  double vals[PO_MAXN];  // chi2_vec_init, later chi2_vec_final (0 where no point)
-  float err[PO_MAXN];
+  unsigned long long live[PO_BLOCK / 64];  // which lanes of the current chunk contributed
   double acc[28];
   Se3 T, T_old;
   double scale;
@@ -69,13 +68,14 @@ __device__ __forceinline__ float tukey_weight(float x) {
 // value with rank k among the entries of v[0..n) flagged in `hp` (ties broken by index):
 // what nth_element(begin, begin+k, end) leaves at position k.
 template <typename T>
-__device__ __forceinline__ void rank_select(const T* v, const uint8_t* hp, size_t hp_base, int n, int k, T* out) {
+__device__ __forceinline__ void rank_select(const T* v, int n, int k, T* out) {
+  // entries that do not take part hold +inf: they are never "smaller" and never selected
   for (int i = threadIdx.x; i < n; i += PO_BLOCK) {
-    if (!hp[hp_base + i]) continue;
     const T mine = v[i];
+    if (!(mine < (T)INFINITY)) continue;
     int rank = 0;
+#pragma unroll 8
     for (int j = 0; j < n; ++j) {
-      if (!hp[hp_base + j]) continue;
       const T o = v[j];
       rank += (o < mine || (o == mine && j < i)) ? 1 : 0;
     }
@@ -83,8 +83,24 @@ __device__ __forceinline__ void rank_select(const T* v, const uint8_t* hp, size_
   }
 }
 
+// per-observation arrays, sized by n_stride at launch (dynamic LDS):
+//   vals f64 [ns]: chi2_vec_init, later chi2_vec_final (+inf where there is no point)
+//   err  f32 [ns]: |e| for the MAD scale, later the pruning marks
+//   hp   u8  [ns]: has_point of this frame (global loads inside the serial sums would dominate)
+struct PoseDyn {
+  double* vals;
+  float* err;
+  uint8_t* hp;
+};
+
 __global__ void __launch_bounds__(PO_BLOCK) pose_opt_kernel(const PoseArgs a) {
   __shared__ PoseLds s;
+  extern __shared__ double po_dyn[];
+  const int ns8 = (a.n_stride + 7) & ~7;
+  PoseDyn d;
+  d.vals = po_dyn;
+  d.err = reinterpret_cast<float*>(po_dyn + ns8);
+  d.hp = reinterpret_cast<uint8_t*>(d.err + ns8);
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   const int n = a.n[b];
@@ -98,14 +114,15 @@ __global__ void __launch_bounds__(PO_BLOCK) pose_opt_kernel(const PoseArgs a) {
     s.flag = 0;
     s.chi2 = 0.0;
   }
+  for (int i = tid; i < n; i += PO_BLOCK) d.hp[i] = a.has_point[base + i];
   __syncthreads();
   // ---- error scale (:45-60) ---------------------------------------------------------
   {
     const Se3 T = s.T;
     int cnt = 0;
     for (int i = tid; i < n; i += PO_BLOCK) {
-      s.err[i] = 0.f;
-      if (!a.has_point[base + i]) continue;
+      d.err[i] = INFINITY;
+      if (!d.hp[i]) continue;
       const double p[3] = {a.pos[3 * (base + i)], a.pos[3 * (base + i) + 1], a.pos[3 * (base + i) + 2]};
       const double fb[3] = {a.f[3 * (base + i)], a.f[3 * (base + i) + 1], a.f[3 * (base + i) + 2]};
       double pf[3], u0[2], u1[2];
@@ -116,7 +133,7 @@ __global__ void __launch_bounds__(PO_BLOCK) pose_opt_kernel(const PoseArgs a) {
       const double k = 1.0 / (double)(1 << a.level[base + i]);
       e[0] *= k;
       e[1] *= k;
-      s.err[i] = (float)norm2(e);
+      d.err[i] = (float)norm2(e);
       ++cnt;
     }
     if (cnt) atomicAdd(&s.n_err, cnt);
@@ -127,7 +144,7 @@ __global__ void __launch_bounds__(PO_BLOCK) pose_opt_kernel(const PoseArgs a) {
     if (tid == 0) a.ran[b] = 0;
     return;
   }
-  rank_select<float>(s.err, a.has_point, base, n, n_err / 2, &s.median_f);
+  rank_select<float>(d.err, n, n_err / 2, &s.median_f);
   __syncthreads();
   const double estimated_scale = (double)(1.48f * s.median_f);  // MADScaleEstimator::compute
   if (tid == 0) s.scale = estimated_scale;
@@ -148,7 +165,7 @@ __global__ void __launch_bounds__(PO_BLOCK) pose_opt_kernel(const PoseArgs a) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) bb[k] = 0.0;
       bool live = false;
-      if (i < n && a.has_point[base + i]) {
+      if (i < n && d.hp[i]) {
         live = true;
         const double p[3] = {a.pos[3 * (base + i)], a.pos[3 * (base + i) + 1], a.pos[3 * (base + i) + 2]};
         const double fb[3] = {a.f[3 * (base + i)], a.f[3 * (base + i) + 1], a.f[3 * (base + i) + 2]};
@@ -162,7 +179,7 @@ __global__ void __launch_bounds__(PO_BLOCK) pose_opt_kernel(const PoseArgs a) {
         e[0] *= sqrt_inv_cov;
         e[1] *= sqrt_inv_cov;
         const double e2 = e[0] * e[0] + e[1] * e[1];
-        if (iter == 0) s.vals[i] = e2;  // chi2_vec_init
+        if (iter == 0) d.vals[i] = e2;  // chi2_vec_init
 #pragma unroll
         for (int k = 0; k < 12; ++k) J[k] *= sqrt_inv_cov;
         const double weight = (double)tukey_weight((float)(norm2(e) / scale));
@@ -175,9 +192,12 @@ __global__ void __launch_bounds__(PO_BLOCK) pose_opt_kernel(const PoseArgs a) {
         for (int r = 0; r < 6; ++r) bb[r] = (J[r] * e[0] + J[6 + r] * e[1]) * weight;
         c2 = e2 * weight;
       } else if (iter == 0 && i < n) {
-        s.vals[i] = 0.0;
+        d.vals[i] = INFINITY;
       }
-      (void)live;
+      {
+        const unsigned long long mk = __ballot(live);
+        if ((tid & 63) == 0) s.live[tid >> 6] = mk;
+      }
 #pragma unroll
       for (int k = 0; k < 21; ++k) s.tile[k][tid] = A21[k];
 #pragma unroll
@@ -185,14 +205,24 @@ __global__ void __launch_bounds__(PO_BLOCK) pose_opt_kernel(const PoseArgs a) {
       s.tile[27][tid] = c2;
       __syncthreads();
       if (tid < 28) {
-        // A += ..., b -= ..., new_chi2 += ...   in observation order
+        // A += ..., b -= ..., new_chi2 += ...   in observation order.  Observations without a
+        // point are skipped (`continue` in the reference), here by a select so that the LDS
+        // reads of eight elements are in flight together instead of one per branch.
         const int m = (n - c0) < PO_BLOCK ? (n - c0) : PO_BLOCK;
         double acc = s.acc[tid];
         const bool neg = (tid >= 21 && tid < 27);
-        for (int j = 0; j < m; ++j) {
-          if (!a.has_point[base + c0 + j]) continue;  // `continue` in the reference: no +0.0 either
-          const double v = s.tile[tid][j];
-          acc = neg ? acc - v : acc + v;
+        const double* row = s.tile[tid];
+        for (int j0 = 0; j0 < m; j0 += 8) {
+          const unsigned long long mk = s.live[j0 >> 6] >> (j0 & 63);
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = row[(j0 + u) < PO_BLOCK ? (j0 + u) : 0];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const bool on = ((mk >> u) & 1ull) != 0 && (j0 + u) < m;
+            const double nv = neg ? acc - v[u] : acc + v[u];
+            acc = on ? nv : acc;
+          }
         }
         s.acc[tid] = acc;
       }
@@ -241,13 +271,13 @@ __global__ void __launch_bounds__(PO_BLOCK) pose_opt_kernel(const PoseArgs a) {
       }
     const double f2 = focal * focal;  // std::pow(f, 2)
     for (int k = 0; k < 36; ++k) Af[k] = A[k] * f2;
-    inv_lu<6>(Af, C);
+    inv_sym<6>(Af, C);
     if (a.Cov)
       for (int k = 0; k < 36; ++k) a.Cov[36 * b + k] = 1.0 * C[k];
     se3_to_Rt(s.T, a.T + 12 * b);
   }
   // chi2_vec_init median before vals is overwritten
-  rank_select<double>(s.vals, a.has_point, base, n, n_err / 2, &s.median_d);
+  rank_select<double>(d.vals, n, n_err / 2, &s.median_d);
   __syncthreads();
   const double med_init = s.median_d;
   __syncthreads();
@@ -259,8 +289,9 @@ __global__ void __launch_bounds__(PO_BLOCK) pose_opt_kernel(const PoseArgs a) {
     __syncthreads();
     int deleted = 0;
     for (int i = tid; i < n; i += PO_BLOCK) {
-      s.err[i] = 0.f;
-      if (!a.has_point[base + i]) continue;
+      d.err[i] = 0.f;
+      d.vals[i] = INFINITY;
+      if (!d.hp[i]) continue;
       const double p[3] = {a.pos[3 * (base + i)], a.pos[3 * (base + i) + 1], a.pos[3 * (base + i) + 2]};
       const double fb[3] = {a.f[3 * (base + i)], a.f[3 * (base + i) + 1], a.f[3 * (base + i) + 2]};
       double pf[3], u0[2], u1[2];
@@ -271,21 +302,21 @@ __global__ void __launch_bounds__(PO_BLOCK) pose_opt_kernel(const PoseArgs a) {
       const double k = 1.0 / (double)(1 << a.level[base + i]);
       e[0] *= k;
       e[1] *= k;
-      s.vals[i] = e[0] * e[0] + e[1] * e[1];  // chi2_vec_final
-      s.err[i] = 1.f;                         // member of chi2_vec_final
+      d.vals[i] = e[0] * e[0] + e[1] * e[1];  // chi2_vec_final
+      d.err[i] = 1.f;                         // member of chi2_vec_final
       if (norm2(e) > reproj_thresh_scaled) {
-        s.err[i] = 2.f;  // pruned after the median is taken
+        d.err[i] = 2.f;  // pruned after the median is taken
         ++deleted;
       }
     }
     if (deleted) atomicAdd(&s.n_err, deleted);
   }
   __syncthreads();
-  rank_select<double>(s.vals, a.has_point, base, n, n_err / 2, &s.median_d);
+  rank_select<double>(d.vals, n, n_err / 2, &s.median_d);
   __syncthreads();
   const int n_deleted = s.n_err;
   for (int i = tid; i < n; i += PO_BLOCK)
-    if (s.err[i] == 2.f) a.has_point[base + i] = 0;  // (*it)->point = NULL
+    if (d.err[i] == 2.f) a.has_point[base + i] = 0;  // (*it)->point = NULL
   if (tid == 0) {
     a.stats[4 * b + 0] = estimated_scale * focal;
     a.stats[4 * b + 1] = sqrt(med_init) * focal;
@@ -320,6 +351,8 @@ extern "C" int svo_hip_pose_optimize(const svo_hip_camera* cam, int B, const int
   a.Cov = d_Cov;
   a.stats = d_stats;
   a.ran = d_ran;
-  hipLaunchKernelGGL(pose_opt_kernel, dim3(B), dim3(PO_BLOCK), 0, static_cast<hipStream_t>(stream), a);
+  const int ns8 = (n_stride + 7) & ~7;
+  const size_t dyn = (size_t)ns8 * (sizeof(double) + sizeof(float) + 1);
+  hipLaunchKernelGGL(pose_opt_kernel, dim3(B), dim3(PO_BLOCK), dyn, static_cast<hipStream_t>(stream), a);
   return check_launch();
 }

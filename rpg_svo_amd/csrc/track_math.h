@@ -135,100 +135,128 @@ __device__ __forceinline__ void inv3f(const float m[9], float r[9]) {
   r[8] = SVO_COF3(m, 0, 1, 0, 1) * invdet;
 }
 
-// ---- Eigen::LDLT<Lower> with diagonal pivoting + solve, n <= 6, local arrays ---------
-// (runs in one lane per problem; the arrays live in scratch/LDS, which is fine for a
-// 6x6 solve executed a handful of times per problem)
+// ---- Eigen::LDLT<Lower> with diagonal pivoting, register resident -------------------
+// Eigen's unblocked LDLT (Eigen/src/Cholesky/LDLT.h) is left-looking: step k picks the largest
+// remaining |diagonal|, swaps it to position k symmetrically, then forms column k of L from the
+// columns before it; the trailing block is never updated, so it stays symmetric and a full
+// row+column swap is the same permutation Eigen applies to the stored lower triangle.
+// Everything is unrolled over compile-time indices (pivot positions become predicated
+// swaps), so the N x N matrix lives in VGPRs: a dynamically indexed local array would sit in
+// scratch memory and turn the few hundred dependent accesses of a solve into ~100 us.
 template <int N>
-__device__ inline void ldlt_solve_pivoted(const double* A, const double* b, double* x) {
-  double m[N * N];
+struct LdltReg {
+  double m[N * N];  // row-major; lower triangle + diagonal meaningful after factor()
   int tr[N];
-  double temp[N];
-  for (int i = 0; i < N * N; ++i) m[i] = A[i];
-#define M_(r, c) m[(r)*N + (c)]
-  bool all_zero = false;
-  for (int k = 0; k < N && !all_zero; ++k) {
-    int big = k;
-    double best = fabs(M_(k, k));
-    for (int i = k + 1; i < N; ++i)
-      if (fabs(M_(i, i)) > best) { best = fabs(M_(i, i)); big = i; }
-    tr[k] = big;
-    if (k != big) {
-      const int s = N - big - 1;
-      for (int c = 0; c < k; ++c) { double t = M_(k, c); M_(k, c) = M_(big, c); M_(big, c) = t; }
-      for (int r = 0; r < s; ++r) { double t = M_(big + 1 + r, k); M_(big + 1 + r, k) = M_(big + 1 + r, big); M_(big + 1 + r, big) = t; }
-      { double t = M_(k, k); M_(k, k) = M_(big, big); M_(big, big) = t; }
-      for (int i = k + 1; i < big; ++i) { double t = M_(i, k); M_(i, k) = M_(big, i); M_(big, i) = t; }
-    }
-    const int rs = N - k - 1;
-    if (k > 0) {
-      for (int c = 0; c < k; ++c) temp[c] = M_(c, c) * M_(k, c);
-      double acc = 0;
-      for (int c = 0; c < k; ++c) acc += M_(k, c) * temp[c];
-      M_(k, k) -= acc;
-      for (int r = 0; r < rs; ++r) {
-        double a2 = 0;
-        for (int c = 0; c < k; ++c) a2 += M_(k + 1 + r, c) * temp[c];
-        M_(k + 1 + r, k) -= a2;
+  bool all_zero;
+
+  __device__ __forceinline__ static void cswap(bool c, double& a, double& b) {
+    const double ta = a, tb = b;
+    a = c ? tb : ta;
+    b = c ? ta : tb;
+  }
+
+  __device__ __forceinline__ void factor(const double* A) {
+#pragma unroll
+    for (int i = 0; i < N * N; ++i) m[i] = A[i];
+    all_zero = false;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      // pivot: largest |diagonal| in the trailing block, first maximum wins
+      int big = k;
+      double best = fabs(m[k * N + k]);
+#pragma unroll
+      for (int i = k + 1; i < N; ++i) {
+        const double v = fabs(m[i * N + i]);
+        const bool gt = v > best;
+        best = gt ? v : best;
+        big = gt ? i : big;
       }
+      tr[k] = all_zero ? k : big;
+#pragma unroll
+      for (int b = k + 1; b < N; ++b) {
+        const bool c = (!all_zero) && (big == b);
+#pragma unroll
+        for (int j = 0; j < N; ++j) cswap(c, m[k * N + j], m[b * N + j]);  // rows
+#pragma unroll
+        for (int i = 0; i < N; ++i) cswap(c, m[i * N + k], m[i * N + b]);  // columns
+      }
+      double temp[N];
+      double acc = 0;
+#pragma unroll
+      for (int c = 0; c < k; ++c) {
+        temp[c] = m[c * N + c] * m[k * N + c];
+        acc += m[k * N + c] * temp[c];
+      }
+      const double akk_new = (k > 0) ? m[k * N + k] - acc : m[k * N + k];
+      if (!all_zero) m[k * N + k] = akk_new;
+#pragma unroll
+      for (int r = k + 1; r < N; ++r) {
+        double a2 = 0;
+#pragma unroll
+        for (int c = 0; c < k; ++c) a2 += m[r * N + c] * temp[c];
+        if (k > 0 && !all_zero) m[r * N + k] -= a2;
+      }
+      const double akk = m[k * N + k];
+      const bool pivot_is_valid = fabs(akk) > 0.0;
+      if (k == 0 && !pivot_is_valid) all_zero = true;  // Eigen: identity transpositions, stop
+#pragma unroll
+      for (int r = k + 1; r < N; ++r)
+        if (pivot_is_valid && !all_zero) m[r * N + k] /= akk;
     }
-    const double akk = M_(k, k);
-    const bool pivot_is_valid = fabs(akk) > 0.0;
-    if (k == 0 && !pivot_is_valid) {
-      for (int j = 0; j < N; ++j) tr[j] = j;
-      all_zero = true;
-      break;
+  }
+
+  // LDLT::solve: P, L^-1, D^-1 (tolerance = DBL_MIN, Eigen >= 3.2.2), L^-T, P^T
+  __device__ __forceinline__ void solve(const double* b, double* x) const {
+    double y[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = b[i];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+      for (int j = k + 1; j < N; ++j) cswap(tr[k] == j, y[k], y[j]);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int c = 0; c < i; ++c) y[i] -= m[i * N + c] * y[c];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const double d = m[i * N + i];
+      y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] / d : 0.0;
     }
-    if (rs > 0 && pivot_is_valid)
-      for (int r = 0; r < rs; ++r) M_(k + 1 + r, k) /= akk;
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i)
+#pragma unroll
+      for (int c = i + 1; c < N; ++c) y[i] -= m[c * N + i] * y[c];
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k)
+#pragma unroll
+      for (int j = k + 1; j < N; ++j) cswap(tr[k] == j, y[k], y[j]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = y[i];
   }
-  for (int i = 0; i < N; ++i) x[i] = b[i];
-  for (int k = 0; k < N; ++k)
-    if (tr[k] != k) { double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
-  for (int i = 0; i < N; ++i)
-    for (int c = 0; c < i; ++c) x[i] -= M_(i, c) * x[c];
-  for (int i = 0; i < N; ++i) {
-    if (fabs(M_(i, i)) > 2.2250738585072014e-308) x[i] /= M_(i, i);
-    else x[i] = 0;
-  }
-  for (int i = N - 1; i >= 0; --i)
-    for (int c = i + 1; c < N; ++c) x[i] -= M_(c, i) * x[c];
-  for (int k = N - 1; k >= 0; --k)
-    if (tr[k] != k) { double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
-#undef M_
+};
+
+template <int N>
+__device__ __forceinline__ void ldlt_solve_pivoted(const double* A, const double* b, double* x) {
+  LdltReg<N> f;
+  f.factor(A);
+  f.solve(b, x);
 }
 
-// general inverse by partial-pivot LU (Eigen PartialPivLU path for n > 4); Frame::Cov_
+// inverse of a symmetric matrix through its pivoted LDLT: column j = solve(e_j).  (Eigen
+// computes Frame::Cov_ with PartialPivLU, pose_optimizer.cpp:126; the two agree to rounding.)
 template <int N>
-__device__ inline void inv_lu(const double* A, double* out) {
-  double lu[N * N];
-  int perm[N];
-  for (int i = 0; i < N * N; ++i) lu[i] = A[i];
-  for (int i = 0; i < N; ++i) perm[i] = i;
-  for (int k = 0; k < N; ++k) {
-    int piv = k;
-    double best = fabs(lu[k * N + k]);
-    for (int i = k + 1; i < N; ++i)
-      if (fabs(lu[i * N + k]) > best) { best = fabs(lu[i * N + k]); piv = i; }
-    if (piv != k) {
-      for (int c = 0; c < N; ++c) { double t = lu[k * N + c]; lu[k * N + c] = lu[piv * N + c]; lu[piv * N + c] = t; }
-      int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
-    }
-    for (int i = k + 1; i < N; ++i) {
-      lu[i * N + k] /= lu[k * N + k];
-      for (int c = k + 1; c < N; ++c) lu[i * N + c] -= lu[i * N + k] * lu[k * N + c];
-    }
-  }
-  for (int col = 0; col < N; ++col) {
-    double y[N];
-    for (int i = 0; i < N; ++i) {
-      y[i] = (perm[i] == col) ? 1.0 : 0.0;
-      for (int c = 0; c < i; ++c) y[i] -= lu[i * N + c] * y[c];
-    }
-    for (int i = N - 1; i >= 0; --i) {
-      for (int c = i + 1; c < N; ++c) y[i] -= lu[i * N + c] * y[c];
-      y[i] /= lu[i * N + i];
-    }
-    for (int i = 0; i < N; ++i) out[i * N + col] = y[i];
+__device__ __forceinline__ void inv_sym(const double* A, double* out) {
+  LdltReg<N> f;
+  f.factor(A);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double e[N], x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = (i == j) ? 1.0 : 0.0;
+    f.solve(e, x);
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i * N + j] = x[i];
   }
 }
 

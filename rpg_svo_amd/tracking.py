@@ -141,6 +141,30 @@ def reproject_points(cam, frames: FrameTable, cur_frame, pt_pos, cell_size: int,
     return cell, px
 
 
+def compose_poses(A, B, out=None, out_index=None):
+    """out[idx[i]] = A[i] * B[i] (SE3 product), e.g. T_f_w(cur) = T_cur_from_ref * T_f_w(ref)."""
+    lib = capi.load()
+    n = A.shape[0]
+    if out is None:
+        out = torch.empty_like(A)
+    capi.check(lib.svo_hip_compose_poses(n, _chk(A, torch.float64).data_ptr(), _chk(B, torch.float64).data_ptr(),
+                                         _chk(out, torch.float64).data_ptr(), _ptr(out_index), _stream_ptr(A.device)),
+               "svo_hip_compose_poses")
+    return out
+
+
+def cam2world(cam, px, out=None):
+    """Unit bearings of pixels px [n,2] (vk::PinholeCamera::cam2world)."""
+    lib = capi.load()
+    n = px.shape[0]
+    if out is None:
+        out = torch.empty(n, 3, dtype=torch.float64, device=px.device)
+    c = capi.camera(cam)
+    capi.check(lib.svo_hip_cam2world(C.byref(c), n, _chk(px, torch.float64).data_ptr(), out.data_ptr(),
+                                     _stream_ptr(px.device)), "svo_hip_cam2world")
+    return out
+
+
 # ---- pose_optimizer ---------------------------------------------------------------------
 @dataclass
 class PoseOptResult:
