@@ -57,8 +57,12 @@ int svo_hip_device_count(void);
 int svo_hip_set_device(int device);
 int svo_hip_malloc(void** d_ptr, size_t bytes);
 int svo_hip_free(void* d_ptr);
+/* page-locked host memory (staging buffers of the host classes: async copies need it) */
+int svo_hip_host_alloc(void** ptr, size_t bytes);
+int svo_hip_host_free(void* ptr);
 int svo_hip_memcpy_h2d(void* d_dst, const void* src, size_t bytes, void* stream);
 int svo_hip_memcpy_d2h(void* dst, const void* d_src, size_t bytes, void* stream);
+int svo_hip_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream);
 int svo_hip_memset(void* d_dst, int value, size_t bytes, void* stream);
 int svo_hip_stream_create(void** stream_out);
 int svo_hip_stream_destroy(void* stream);
@@ -319,6 +323,11 @@ int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint8_t* d_stor
 /* DepthFilter::updateSeed(x, tau2, seed) for S independent (x, tau2) measurements */
 int svo_hip_update_seed_batch(int S, const float* d_x, const float* d_tau2,
                               const svo_hip_seeds* seeds, void* stream);
+
+/* static DepthFilter::computeTau(T_ref_cur, f, z, px_error_angle) (depth_filter.cpp:334-350) for S
+ * independent measurements: d_t_ref_cur [S][3] = T_ref_cur.translation(), d_f [S][3], d_z [S]. */
+int svo_hip_compute_tau_batch(int S, const double* d_t_ref_cur, const double* d_f, const double* d_z,
+                              double px_error_angle, double* d_tau, void* stream);
 
 #ifdef __cplusplus
 }

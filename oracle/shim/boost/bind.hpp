@@ -23,10 +23,22 @@ template <typename M, typename C, int N1, int N2>
 less_bound<bound_member<M, C, N1>, bound_member<M, C, N2>> operator<(const bound_member<M, C, N1>& l, const bound_member<M, C, N2>& r) {
   return less_bound<bound_member<M, C, N1>, bound_member<M, C, N2>>{l, r};
 }
+template <typename L, typename R> struct greater_bound {
+  L l; R r;
+  template <typename A, typename B> bool operator()(const A& a, const B& b) const { return l(a, b) > r(a, b); }
+};
+template <typename M, typename C, int N1, int N2>
+greater_bound<bound_member<M, C, N1>, bound_member<M, C, N2>> operator>(const bound_member<M, C, N1>& l, const bound_member<M, C, N2>& r) {
+  return greater_bound<bound_member<M, C, N1>, bound_member<M, C, N2>>{l, r};
+}
 template <typename M, typename C> bound_member<M, C, 1> bind(M C::*pm, const arg1&) { return bound_member<M, C, 1>{pm}; }
 template <typename M, typename C> bound_member<M, C, 2> bind(M C::*pm, const arg2&) { return bound_member<M, C, 2>{pm}; }
 // free / static functions of two arguments
 template <typename R, typename A, typename B> std::function<R(A, B)> bind(R (*f)(A, B), const arg1&, const arg2&) { return std::function<R(A, B)>(f); }
+// member function of two arguments on an object pointer (frame_handler_mono.cpp:47-48)
+template <typename R, typename C, typename A, typename B> std::function<R(A, B)> bind(R (C::*f)(A, B), C* obj, const arg1&, const arg2&) {
+  return [f, obj](A a, B b) -> R { return (obj->*f)(a, b); };
+}
 }  // namespace boost
 static const boost::arg1 _1 = boost::arg1();
 static const boost::arg2 _2 = boost::arg2();

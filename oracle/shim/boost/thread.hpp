@@ -3,6 +3,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <boost/bind.hpp>
 namespace boost {
 using std::mutex;
 using std::unique_lock;

@@ -17,6 +17,7 @@
 
 namespace cv {
 struct Scalar { double v; Scalar(double a = 0) : v(a) {} };
+struct Point2f { float x, y; Point2f(float a = 0, float b = 0) : x(a), y(b) {} };  // initialization.h members only
 struct Size { int width, height; Size(int w = 0, int h = 0) : width(w), height(h) {} };
 
 class Mat {

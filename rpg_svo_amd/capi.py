@@ -87,8 +87,11 @@ PROTOTYPES = {
     "svo_hip_set_device": (_i, [_i]),
     "svo_hip_malloc": (_i, [C.POINTER(_vp), C.c_size_t]),
     "svo_hip_free": (_i, [_vp]),
+    "svo_hip_host_alloc": (_i, [C.POINTER(_vp), C.c_size_t]),
+    "svo_hip_host_free": (_i, [_vp]),
     "svo_hip_memcpy_h2d": (_i, [_vp, _vp, C.c_size_t, _vp]),
     "svo_hip_memcpy_d2h": (_i, [_vp, _vp, C.c_size_t, _vp]),
+    "svo_hip_memcpy_d2d": (_i, [_vp, _vp, C.c_size_t, _vp]),
     "svo_hip_memset": (_i, [_vp, _i, C.c_size_t, _vp]),
     "svo_hip_stream_create": (_i, [C.POINTER(_vp)]),
     "svo_hip_stream_destroy": (_i, [_vp]),
@@ -118,6 +121,7 @@ PROTOTYPES = {
     "svo_hip_update_seeds": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, C.POINTER(Features),
                                   C.POINTER(Seeds), C.POINTER(DepthFilterOptions), _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "svo_hip_update_seed_batch": (_i, [_i, _vp, _vp, C.POINTER(Seeds), _vp]),
+    "svo_hip_compute_tau_batch": (_i, [_i, _vp, _vp, _vp, C.c_double, _vp, _vp]),
 }
 
 _lib = None

@@ -59,6 +59,22 @@ int svo_hip_free(void* d_ptr) {
   return SVO_HIP_OK;
 }
 
+int svo_hip_host_alloc(void** ptr, size_t bytes) {
+  if (!ptr) return SVO_HIP_EINVAL;
+  hipError_t e = hipHostMalloc(ptr, bytes, hipHostMallocDefault);
+  if (e == hipErrorOutOfMemory) {
+    g_last_hip_error = static_cast<int>(e);
+    return SVO_HIP_ENOMEM;
+  }
+  SVO_HIP_TRY(e);
+  return SVO_HIP_OK;
+}
+
+int svo_hip_host_free(void* ptr) {
+  SVO_HIP_TRY(hipHostFree(ptr));
+  return SVO_HIP_OK;
+}
+
 int svo_hip_memcpy_h2d(void* d_dst, const void* src, size_t bytes, void* stream) {
   SVO_HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
   return SVO_HIP_OK;
@@ -66,6 +82,11 @@ int svo_hip_memcpy_h2d(void* d_dst, const void* src, size_t bytes, void* stream)
 
 int svo_hip_memcpy_d2h(void* dst, const void* d_src, size_t bytes, void* stream) {
   SVO_HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream) {
+  SVO_HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
   return SVO_HIP_OK;
 }
 

@@ -496,7 +496,36 @@ __global__ void __launch_bounds__(256) update_seed_kernel(const SeedOnlyArgs a) 
   a.seeds.d_sigma2[s] = ssig;
 }
 
+struct TauArgs {
+  int S;
+  const double* t_ref_cur;
+  const double* f;
+  const double* z;
+  double px_error_angle;
+  double* tau;
+};
+__global__ void __launch_bounds__(256) compute_tau_kernel(const TauArgs a) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= a.S) return;
+  Se3 T;
+  T.q[0] = 1.0; T.q[1] = T.q[2] = T.q[3] = 0.0;  // only the translation enters computeTau
+  for (int k = 0; k < 3; ++k) T.t[k] = a.t_ref_cur[3 * s + k];
+  const double f[3] = {a.f[3 * s], a.f[3 * s + 1], a.f[3 * s + 2]};
+  a.tau[s] = compute_tau(T, f, a.z[s], a.px_error_angle);
+}
+
 }  // namespace
+
+extern "C" int svo_hip_compute_tau_batch(int S, const double* d_t_ref_cur, const double* d_f, const double* d_z,
+                                         double px_error_angle, double* d_tau, void* stream) {
+  if (S < 0) return SVO_HIP_EINVAL;
+  if (S == 0) return SVO_HIP_OK;
+  if (!d_t_ref_cur || !d_f || !d_z || !d_tau) return SVO_HIP_EINVAL;
+  TauArgs a;
+  a.S = S; a.t_ref_cur = d_t_ref_cur; a.f = d_f; a.z = d_z; a.px_error_angle = px_error_angle; a.tau = d_tau;
+  hipLaunchKernelGGL(compute_tau_kernel, dim3((S + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch();
+}
 
 extern "C" int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
                                     const svo_hip_camera* cam, const svo_hip_frames* frames, int S,

@@ -1,0 +1,292 @@
+// Drop-in body for svo/src/depth_filter.cpp: the classes svo::Seed / svo::DepthFilter of
+// svo/include/svo/depth_filter.h.  The seed list, the keyframe queue and the mapping thread
+// stay on the host as the reference has them; DepthFilter::updateSeeds (depth_filter.cpp
+// :197-291) -- visibility test, Matcher::findEpipolarMatchDirect (epipolar ZMSSD scan +
+// sub-pixel alignment, matcher.cpp:179-321), triangulation, computeTau and the Bayesian
+// updateSeed -- runs for ALL seeds in one batched call of svo_hip_update_seeds (K5) on the
+// mapping lane's stream.  The list surgery the reference interleaves with the arithmetic
+// (erase old / NaN seeds, create the Point of a converged seed and hand it to the callback,
+// mark the detector grid) is replayed on the host from the per-seed status, in list order.
+#include <svo/depth_filter.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include <svo/config.h>
+#include <svo/feature.h>
+#include <svo/feature_detection.h>
+#include <svo/frame.h>
+#include <svo/matcher.h>
+#include <svo/point.h>
+
+#include "marshal.h"
+
+namespace svo {
+
+int Seed::batch_counter = 0;
+int Seed::seed_counter = 0;
+
+// depth_filter.cpp:37-46: Beta(10,10), inverse depth ~ N(1/mean, (range/6)^2)
+Seed::Seed(Feature* ftr, float depth_mean, float depth_min)
+    : batch_id(batch_counter), id(seed_counter++), ftr(ftr), a(10), b(10), mu(1.0 / depth_mean), z_range(1.0 / depth_min),
+      sigma2(z_range * z_range / 36) {}
+
+DepthFilter::DepthFilter(feature_detection::DetectorPtr feature_detector, callback_t seed_converged_cb)
+    : feature_detector_(feature_detector), seed_converged_cb_(seed_converged_cb), seeds_updating_halt_(false), thread_(NULL),
+      new_keyframe_set_(false), new_keyframe_min_depth_(0.0), new_keyframe_mean_depth_(0.0) {}
+
+DepthFilter::~DepthFilter() {
+  stopThread();
+  SVO_INFO_STREAM("DepthFilter destructed.");
+}
+
+// ---- mapping thread (host control, unchanged in behaviour) ---------------------------------
+void DepthFilter::startThread() { thread_ = new boost::thread(&DepthFilter::updateSeedsLoop, this); }
+
+void DepthFilter::stopThread() {
+  SVO_INFO_STREAM("DepthFilter stop thread invoked.");
+  if (thread_ == NULL) return;
+  SVO_INFO_STREAM("DepthFilter interrupt and join thread... ");
+  seeds_updating_halt_ = true;
+  thread_->interrupt();
+  thread_->join();
+  thread_ = NULL;
+}
+
+void DepthFilter::addFrame(FramePtr frame) {
+  if (thread_ == NULL) {  // synchronous use
+    updateSeeds(frame);
+    return;
+  }
+  {
+    lock_t lock(frame_queue_mut_);
+    if (frame_queue_.size() > 2) frame_queue_.pop();  // keep at most three frames pending
+    frame_queue_.push(frame);
+  }
+  seeds_updating_halt_ = false;
+  frame_queue_cond_.notify_one();
+}
+
+void DepthFilter::addKeyframe(FramePtr frame, double depth_mean, double depth_min) {
+  new_keyframe_min_depth_ = depth_min;
+  new_keyframe_mean_depth_ = depth_mean;
+  if (thread_ == NULL) {
+    initializeSeeds(frame);
+    return;
+  }
+  new_keyframe_ = frame;
+  new_keyframe_set_ = true;
+  seeds_updating_halt_ = true;
+  frame_queue_cond_.notify_one();
+}
+
+void DepthFilter::initializeSeeds(FramePtr frame) {
+  // corner detection stays on the host (keyframes only)
+  Features new_features;
+  feature_detector_->setExistingFeatures(frame->fts_);
+  feature_detector_->detect(frame.get(), frame->img_pyr_, Config::triangMinCornerScore(), new_features);
+
+  seeds_updating_halt_ = true;
+  lock_t lock(seeds_mut_);  // waits for a running update to finish
+  ++Seed::batch_counter;
+  for (Features::iterator it = new_features.begin(); it != new_features.end(); ++it)
+    seeds_.push_back(Seed(*it, new_keyframe_mean_depth_, new_keyframe_min_depth_));
+  if (options_.verbose) SVO_INFO_STREAM("DepthFilter: Initialized " << new_features.size() << " new seeds");
+  seeds_updating_halt_ = false;
+}
+
+void DepthFilter::removeKeyframe(FramePtr frame) {
+  seeds_updating_halt_ = true;
+  lock_t lock(seeds_mut_);
+  const Frame* gone = frame.get();
+  seeds_.remove_if([gone](const Seed& s) { return s.ftr->frame == gone; });
+  seeds_updating_halt_ = false;
+}
+
+void DepthFilter::reset() {
+  seeds_updating_halt_ = true;
+  {
+    lock_t lock(seeds_mut_);
+    seeds_.clear();
+  }
+  clearFrameQueue();
+  seeds_updating_halt_ = false;
+  if (options_.verbose) SVO_INFO_STREAM("DepthFilter: RESET.");
+}
+
+void DepthFilter::clearFrameQueue() {
+  while (!frame_queue_.empty()) frame_queue_.pop();
+}
+
+void DepthFilter::updateSeedsLoop() {
+  while (!boost::this_thread::interruption_requested()) {
+    FramePtr frame;
+    {
+      lock_t lock(frame_queue_mut_);
+      while (frame_queue_.empty() && !new_keyframe_set_) frame_queue_cond_.wait(lock);
+      if (new_keyframe_set_) {  // a keyframe supersedes everything queued before it
+        new_keyframe_set_ = false;
+        seeds_updating_halt_ = false;
+        clearFrameQueue();
+        frame = new_keyframe_;
+      } else {
+        frame = frame_queue_.front();
+        frame_queue_.pop();
+      }
+    }
+    updateSeeds(frame);
+    if (frame->isKeyframe()) initializeSeeds(frame);
+  }
+}
+
+void DepthFilter::getSeedsCopy(const FramePtr& frame, std::list<Seed>& seeds) {
+  lock_t lock(seeds_mut_);
+  for (std::list<Seed>::iterator it = seeds_.begin(); it != seeds_.end(); ++it)
+    if (it->ftr->frame == frame.get()) seeds.push_back(*it);
+}
+
+// ---- the update, on the device ---------------------------------------------------------------
+void DepthFilter::updateSeeds(FramePtr frame) {
+  lock_t lock(seeds_mut_);
+  if (seeds_updating_halt_) return;  // the halt flag is honoured between launches
+  const size_t S = seeds_.size();
+  if (S == 0) return;
+
+  using namespace hip_dropin;
+  ensureDevice(*frame);
+  svo_hip::Device& dev = svo_hip::Device::instance();
+  const int L = svo_hip::Device::LANE_MAPPING;
+  svo_hip::Lane& lane = dev.lane(L);
+  std::lock_guard<std::mutex> guard(lane.mut);
+  dev.beginCall(L);
+  svo_hip::Arena& a = lane.arena;
+  a.reset();
+  a.reserve(((size_t)1 << 16) + S * 256 + 4096 * 32);
+  FrameTable frames(dev, L);
+  const int i_cur = frames.indexOf(frame.get());
+
+  int32_t *d_cur, *d_batch; float *d_a, *d_b, *d_mu, *d_zr, *d_s2;
+  int32_t* cur = a.alloc<int32_t>(S, &d_cur);
+  int32_t* batch = a.alloc<int32_t>(S, &d_batch);
+  float* sa = a.alloc<float>(S, &d_a);
+  float* sb = a.alloc<float>(S, &d_b);
+  float* smu = a.alloc<float>(S, &d_mu);
+  float* szr = a.alloc<float>(S, &d_zr);
+  float* ss2 = a.alloc<float>(S, &d_s2);
+  FeatureColumns ftr;
+  ftr.alloc(a, S);
+  size_t s = 0;
+  for (std::list<Seed>::iterator it = seeds_.begin(); it != seeds_.end(); ++it, ++s) {
+    cur[s] = i_cur;
+    batch[s] = it->batch_id;
+    sa[s] = it->a; sb[s] = it->b; smu[s] = it->mu; szr[s] = it->z_range; ss2[s] = it->sigma2;
+    ftr.set(s, frames.indexOf(it->ftr->frame), it->ftr);
+  }
+  svo_hip_frames ft;
+  frames.emit(a, &ft);
+  a.endInputs();
+  int32_t* d_status; double *d_xyz, *d_px;
+  int32_t* status = a.alloc<int32_t>(S, &d_status);
+  double* xyz = a.alloc<double>(3 * S, &d_xyz);
+  double* px_cur = a.alloc<double>(2 * S, &d_px);
+
+  svo_hip_seeds seeds;
+  seeds.d_a = d_a; seeds.d_b = d_b; seeds.d_mu = d_mu; seeds.d_z_range = d_zr; seeds.d_sigma2 = d_s2; seeds.d_batch_id = d_batch;
+  svo_hip_depth_filter_options opt;
+  opt.max_n_kfs = options_.max_n_kfs;
+  opt.batch_counter = Seed::batch_counter;
+  opt.seed_convergence_sigma2_thresh = options_.seed_convergence_sigma2_thresh;
+  opt.align_1d = matcher_.options_.align_1d;
+  opt.align_max_iter = matcher_.options_.align_max_iter;
+  opt.max_epi_search_steps = (int32_t)matcher_.options_.max_epi_search_steps;
+  opt.subpix_refinement = matcher_.options_.subpix_refinement;
+  opt.epi_search_edgelet_filtering = matcher_.options_.epi_search_edgelet_filtering;
+  opt.n_pyr_levels = Config::nPyrLevels();
+  opt.epi_search_edgelet_max_angle = matcher_.options_.epi_search_edgelet_max_angle;
+  const svo_hip_camera cam = cameraOf(frame->cam_);
+  void* ws = dev.workspace(lane, (int)S);
+
+  a.upload(lane.stream);
+  svo_hip::check(svo_hip_update_seeds(&dev.layout(), dev.store(), &cam, &ft, (int)S, d_cur, &ftr.dev, &seeds, &opt, d_status, d_xyz,
+                                      d_px, ws, lane.workspace_bytes, lane.stream),
+                 "svo_hip_update_seeds");
+  a.download(lane.stream);
+  a.fetch(sa, S, lane.stream);   // seed state is updated in place
+  a.fetch(sb, S, lane.stream);
+  a.fetch(smu, S, lane.stream);
+  a.fetch(ss2, S, lane.stream);
+  svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+
+  // ---- replay of the list surgery, in list order (:216-219, :238-245, :255-290) ---------------
+  const bool is_kf = frame->isKeyframe();
+  s = 0;
+  for (std::list<Seed>::iterator it = seeds_.begin(); it != seeds_.end(); ++s) {
+    const int st = status[s];
+    if (st == SVO_HIP_SEED_BEHIND || st == SVO_HIP_SEED_NOT_IN_FRAME) { ++it; continue; }
+    if (st == SVO_HIP_SEED_ERASED_OLD) { it = seeds_.erase(it); continue; }
+    it->a = sa[s]; it->b = sb[s]; it->mu = smu[s]; it->sigma2 = ss2[s];
+    if (st == SVO_HIP_SEED_NO_MATCH) { ++it; continue; }  // b was incremented on the device
+    if (is_kf)  // the detector must not start new seeds next to a matched one
+      feature_detector_->setGridOccpuancy(Vector2d(px_cur[2 * s], px_cur[2 * s + 1]));
+    if (st == SVO_HIP_SEED_CONVERGED) {
+      Point* point = new Point(Vector3d(xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]), it->ftr);
+      it->ftr->point = point;
+      seed_converged_cb_(point, it->sigma2);  // into the map's candidate list
+      it = seeds_.erase(it);
+    } else if (st == SVO_HIP_SEED_NAN) {
+      SVO_WARN_STREAM("z_min is NaN");
+      it = seeds_.erase(it);
+    } else {
+      ++it;
+    }
+  }
+}
+
+// ---- the two static helpers, also on the device (single measurement) --------------------------
+void DepthFilter::updateSeed(const float x, const float tau2, Seed* seed) {
+  svo_hip::Device& dev = svo_hip::Device::instance();
+  if (!dev.configured()) throw svo_hip::Error("DepthFilter::updateSeed: device context not configured yet");
+  const int L = svo_hip::Device::LANE_MAPPING;
+  svo_hip::Lane& lane = dev.lane(L);
+  std::lock_guard<std::mutex> guard(lane.mut);
+  svo_hip::Arena& a = lane.arena;
+  a.reset();
+  float* d[7];
+  float* h[7];
+  for (int i = 0; i < 7; ++i) h[i] = a.alloc<float>(1, &d[i]);
+  *h[0] = x; *h[1] = tau2; *h[2] = seed->a; *h[3] = seed->b; *h[4] = seed->mu; *h[5] = seed->z_range; *h[6] = seed->sigma2;
+  a.endInputs();
+  svo_hip_seeds sd;
+  sd.d_a = d[2]; sd.d_b = d[3]; sd.d_mu = d[4]; sd.d_z_range = d[5]; sd.d_sigma2 = d[6]; sd.d_batch_id = NULL;
+  a.upload(lane.stream);
+  svo_hip::check(svo_hip_update_seed_batch(1, d[0], d[1], &sd, lane.stream), "svo_hip_update_seed_batch");
+  for (int i = 2; i < 7; ++i) a.fetch(h[i], 1, lane.stream);
+  svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+  seed->a = *h[2]; seed->b = *h[3]; seed->mu = *h[4]; seed->sigma2 = *h[6];
+}
+
+double DepthFilter::computeTau(const SE3& T_ref_cur, const Vector3d& f, const double z, const double px_error_angle) {
+  svo_hip::Device& dev = svo_hip::Device::instance();
+  if (!dev.configured()) throw svo_hip::Error("DepthFilter::computeTau: device context not configured yet");
+  const int L = svo_hip::Device::LANE_MAPPING;
+  svo_hip::Lane& lane = dev.lane(L);
+  std::lock_guard<std::mutex> guard(lane.mut);
+  svo_hip::Arena& a = lane.arena;
+  a.reset();
+  double *d_t, *d_f, *d_z, *d_tau;
+  double* ht = a.alloc<double>(3, &d_t);
+  double* hf = a.alloc<double>(3, &d_f);
+  double* hz = a.alloc<double>(1, &d_z);
+  const Vector3d t(T_ref_cur.translation());
+  for (int k = 0; k < 3; ++k) { ht[k] = t[k]; hf[k] = f[k]; }
+  *hz = z;
+  a.endInputs();
+  double* tau = a.alloc<double>(1, &d_tau);
+  a.upload(lane.stream);
+  svo_hip::check(svo_hip_compute_tau_batch(1, d_t, d_f, d_z, px_error_angle, d_tau, lane.stream), "svo_hip_compute_tau_batch");
+  a.download(lane.stream);
+  svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+  return *tau;
+}
+
+}  // namespace svo

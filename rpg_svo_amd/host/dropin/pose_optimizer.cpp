@@ -1,0 +1,90 @@
+// Drop-in body for svo/src/pose_optimizer.cpp: svo::pose_optimizer::optimizeGaussNewton
+// (svo/include/svo/pose_optimizer.h:37-45) on the MI355X through svo_hip_pose_optimize (K4).
+// Same signature, same side effects on the frame: T_f_w_, Cov_, and Feature::point reset to
+// NULL for observations pruned at reproj_thresh (pose_optimizer.cpp:129-145).
+#include <svo/pose_optimizer.h>
+
+#include <svo/feature.h>
+#include <svo/frame.h>
+#include <svo/point.h>
+
+#include "marshal.h"
+
+namespace svo {
+namespace pose_optimizer {
+
+void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const bool verbose, FramePtr& frame,
+                         double& estimated_scale, double& error_init, double& error_final, size_t& num_obs) {
+  using namespace hip_dropin;
+  const size_t n = frame->fts_.size();
+  if (n == 0) return;
+  ensureDevice(*frame);
+  svo_hip::Device& dev = svo_hip::Device::instance();
+  const int L = svo_hip::Device::LANE_TRACKING;
+  svo_hip::Lane& lane = dev.lane(L);
+  std::lock_guard<std::mutex> guard(lane.mut);
+  dev.beginCall(L);
+  svo_hip::Arena& a = lane.arena;
+  a.reset();
+
+  // ---- observations, in the order of Frame::fts_ (the order the reference accumulates in) --
+  int32_t *d_n, *d_level; double *d_f, *d_pos, *d_T; uint8_t* d_has;
+  int32_t* hn = a.alloc<int32_t>(1, &d_n);
+  int32_t* level = a.alloc<int32_t>(n, &d_level);
+  double* f = a.alloc<double>(3 * n, &d_f);
+  double* pos = a.alloc<double>(3 * n, &d_pos);
+  double* T = a.alloc<double>(12, &d_T);
+  // has_point and the pose are read AND written by the kernel: they sit at the end of the
+  // input block and are copied back explicitly below
+  uint8_t* has = a.alloc<uint8_t>(n, &d_has);
+  *hn = (int32_t)n;
+  size_t i = 0;
+  for (Features::const_iterator it = frame->fts_.begin(); it != frame->fts_.end(); ++it, ++i) {
+    const Feature* ftr = *it;
+    level[i] = ftr->level;
+    for (int k = 0; k < 3; ++k) f[3 * i + k] = ftr->f[k];
+    has[i] = ftr->point != NULL;
+    for (int k = 0; k < 3; ++k) pos[3 * i + k] = ftr->point ? ftr->point->pos_[k] : 0.0;
+  }
+  poseToRt(frame->T_f_w_, T);
+  a.endInputs();
+  double *d_Cov, *d_stats, *d_Tout; int32_t* d_ran; uint8_t* d_has_out;
+  double* Cov = a.alloc<double>(36, &d_Cov);
+  double* stats = a.alloc<double>(4, &d_stats);
+  int32_t* ran = a.alloc<int32_t>(1, &d_ran);
+  double* Tout = a.alloc<double>(12, &d_Tout);
+  uint8_t* has_out = a.alloc<uint8_t>(n, &d_has_out);
+
+  const svo_hip_camera cam = cameraOf(frame->cam_);
+  a.upload(lane.stream);
+  // in/out arrays live in the output block so that one D2H brings everything back
+  svo_hip::check(svo_hip_memcpy_d2d(d_Tout, d_T, 12 * sizeof(double), lane.stream), "svo_hip_memcpy_d2d");
+  svo_hip::check(svo_hip_memcpy_d2d(d_has_out, d_has, n, lane.stream), "svo_hip_memcpy_d2d");
+  svo_hip::check(svo_hip_pose_optimize(&cam, 1, d_n, (int)n, d_f, d_level, d_pos, d_has_out, reproj_thresh, (int)n_iter, d_Tout,
+                                       d_Cov, d_stats, d_ran, lane.stream),
+                 "svo_hip_pose_optimize");
+  a.download(lane.stream);
+  svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+
+  if (!*ran) return;  // no observation carried a point: the reference returns untouched (:57-58)
+  frame->T_f_w_ = poseFromRt(Tout);
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) frame->Cov_(r, c) = Cov[r * 6 + c];
+  size_t n_deleted_refs = 0;
+  i = 0;
+  for (Features::iterator it = frame->fts_.begin(); it != frame->fts_.end(); ++it, ++i)
+    if ((*it)->point != NULL && !has_out[i]) {
+      (*it)->point = NULL;  // the point holds no reference to this feature yet (:139-141)
+      ++n_deleted_refs;
+    }
+  estimated_scale = stats[0];
+  error_init = stats[1];
+  error_final = stats[2];
+  num_obs = (size_t)stats[3];
+  if (verbose)
+    std::cout << "n deleted obs = " << n_deleted_refs << "\t scale = " << estimated_scale << "\t error init = " << error_init
+              << "\t error end = " << error_final << std::endl;
+}
+
+}  // namespace pose_optimizer
+}  // namespace svo

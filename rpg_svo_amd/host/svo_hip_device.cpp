@@ -1,0 +1,172 @@
+// svo_hip_device.cpp -- see svo_hip_device.h.
+#include "svo_hip_device.h"
+
+#include <cstring>
+
+namespace svo_hip {
+
+void check(int code, const char* what) {
+  if (code >= 0) return;
+  throw Error(std::string(what) + ": " + svo_hip_strerror(code) + " (hip error " +
+              std::to_string(svo_hip_last_hip_error()) + ")");
+}
+
+// ---- Arena ---------------------------------------------------------------------------
+void Arena::release() {
+  if (h_) svo_hip_host_free(h_);
+  if (d_) svo_hip_free(d_);
+  h_ = d_ = NULL;
+  cap_ = used_ = in_end_ = 0;
+}
+
+void Arena::reserve(size_t bytes) {
+  if (bytes <= cap_) return;
+  if (used_ != 0) throw Error("svo_hip::Arena::reserve on a non-empty arena");
+  release();
+  size_t cap = (size_t)1 << 20;
+  while (cap < bytes) cap <<= 1;
+  void* h = NULL;
+  void* d = NULL;
+  check(svo_hip_host_alloc(&h, cap), "svo_hip_host_alloc");
+  check(svo_hip_malloc(&d, cap), "svo_hip_malloc");
+  h_ = static_cast<uint8_t*>(h);
+  d_ = static_cast<uint8_t*>(d);
+  cap_ = cap;
+}
+
+void Arena::grow(size_t need) {
+  // blocks already handed out would dangle: callers size the arena with reserve() first
+  throw Error("svo_hip::Arena overflow (" + std::to_string(need) + " > " + std::to_string(cap_) +
+              " bytes): reserve() an upper bound before filling");
+}
+
+void Arena::upload(void* stream) {
+  if (in_end_) check(svo_hip_memcpy_h2d(d_, h_, in_end_, stream), "arena upload");
+}
+
+void Arena::download(void* stream) {
+  if (used_ > in_end_) check(svo_hip_memcpy_d2h(h_ + in_end_, d_ + in_end_, used_ - in_end_, stream), "arena download");
+}
+
+void Arena::fetchBytes(uint8_t* host_block, size_t bytes, void* stream) {
+  if (host_block < h_ || host_block + bytes > h_ + used_) throw Error("svo_hip::Arena::fetch: not an arena block");
+  check(svo_hip_memcpy_d2h(host_block, d_ + (host_block - h_), bytes, stream), "arena fetch");
+}
+
+// ---- Device --------------------------------------------------------------------------
+Device::Device() : d_store_(NULL), n_slots_(0), clock_(0) {
+  std::memset(&layout_, 0, sizeof(layout_));
+  for (int l = 0; l < N_LANES; ++l) epoch_[l] = 1;
+}
+Device::~Device() { shutdown(); }
+
+Device& Device::instance() {
+  static Device dev;
+  return dev;
+}
+
+void Device::shutdown() {
+  for (int i = 0; i < N_LANES; ++i) {
+    Lane& l = lanes_[i];
+    if (l.stream) { svo_hip_stream_sync(l.stream); svo_hip_stream_destroy(l.stream); l.stream = NULL; }
+    l.arena.release();
+    if (l.d_workspace) { svo_hip_free(l.d_workspace); l.d_workspace = NULL; l.workspace_bytes = 0; }
+  }
+  if (d_store_) { svo_hip_free(d_store_); d_store_ = NULL; }
+  frames_.clear();
+  free_slots_.clear();
+  n_slots_ = 0;
+}
+
+void Device::configure(int width, int height, int n_levels, int n_slots, int device) {
+  std::lock_guard<std::mutex> g(frames_mut_);
+  shutdown();
+  if (svo_hip_device_count() <= 0) throw Error("svo_hip: no HIP device visible (there is no CPU fallback)");
+  check(svo_hip_set_device(device), "svo_hip_set_device");
+  check(svo_hip_pyr_layout_init(width, height, n_levels, &layout_), "svo_hip_pyr_layout_init");
+  const int64_t bytes = svo_hip_pyr_store_bytes(&layout_, n_slots);
+  if (bytes < 0) check((int)bytes, "svo_hip_pyr_store_bytes");
+  void* p = NULL;
+  check(svo_hip_malloc(&p, (size_t)bytes), "svo_hip_malloc(store)");
+  d_store_ = static_cast<uint8_t*>(p);
+  check(svo_hip_memset(d_store_, 0, (size_t)bytes, NULL), "svo_hip_memset(store)");
+  check(svo_hip_stream_sync(NULL), "svo_hip_stream_sync");
+  n_slots_ = n_slots;
+  for (int s = n_slots - 1; s >= 0; --s) free_slots_.push_back(s);
+  for (int i = 0; i < N_LANES; ++i) {
+    check(svo_hip_stream_create(&lanes_[i].stream), "svo_hip_stream_create");
+    lanes_[i].arena.reserve((size_t)4 << 20);
+  }
+}
+
+void Device::ensureConfigured(int width, int height, int n_levels) {
+  if (d_store_ && layout_.w[0] == width && layout_.h[0] == height && layout_.n_levels >= n_levels) return;
+  configure(width, height, n_levels);
+}
+
+void Device::beginCall(int which_lane) {
+  std::lock_guard<std::mutex> g(frames_mut_);
+  ++epoch_[which_lane];
+  ++stats.calls;
+}
+
+int Device::slotOf(int frame_id, const uint8_t* level0, int stride, int which_lane) {
+  std::lock_guard<std::mutex> g(frames_mut_);
+  Lane& lane = lanes_[which_lane];
+  std::map<int, Entry>::iterator it = frames_.find(frame_id);
+  if (it != frames_.end()) {
+    it->second.last_use = ++clock_;
+    it->second.epoch[which_lane] = epoch_[which_lane];
+    return it->second.slot;
+  }
+  if (free_slots_.empty()) {  // evict the least recently used frame no running call has touched
+    std::map<int, Entry>::iterator victim = frames_.end();
+    for (std::map<int, Entry>::iterator e = frames_.begin(); e != frames_.end(); ++e) {
+      bool pinned = false;
+      for (int l = 0; l < N_LANES; ++l) pinned = pinned || e->second.epoch[l] == epoch_[l];
+      if (!pinned && (victim == frames_.end() || e->second.last_use < victim->second.last_use)) victim = e;
+    }
+    if (victim == frames_.end())
+      throw Error("svo_hip::Device: one call needs more than " + std::to_string(n_slots_) +
+                  " frames resident; configure() a larger pool");
+    free_slots_.push_back(victim->second.slot);
+    frames_.erase(victim);
+    ++stats.evictions;
+  }
+  const int slot = free_slots_.back();
+  free_slots_.pop_back();
+  check(svo_hip_pyramid_upload_level0(&layout_, d_store_, slot, level0, stride, lane.stream), "svo_hip_pyramid_upload_level0");
+  check(svo_hip_pyramid_build(&layout_, d_store_, slot, 1, SVO_HIP_HALFSAMPLE_AUTO, lane.stream), "svo_hip_pyramid_build");
+  // the other lane may consume this slot next: complete the upload before publishing it
+  check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync(upload)");
+  Entry en;
+  en.slot = slot;
+  en.last_use = ++clock_;
+  for (int l = 0; l < N_LANES; ++l) en.epoch[l] = 0;
+  en.epoch[which_lane] = epoch_[which_lane];
+  frames_[frame_id] = en;
+  ++stats.uploads;
+  return slot;
+}
+
+void Device::forget(int frame_id) {
+  std::lock_guard<std::mutex> g(frames_mut_);
+  std::map<int, Entry>::iterator it = frames_.find(frame_id);
+  if (it == frames_.end()) return;
+  free_slots_.push_back(it->second.slot);
+  frames_.erase(it);
+}
+
+void* Device::workspace(Lane& lane, int n_trials) {
+  const size_t need = svo_hip_match_workspace_bytes(n_trials);
+  if (need > lane.workspace_bytes) {
+    if (lane.d_workspace) { check(svo_hip_stream_sync(lane.stream), "sync"); svo_hip_free(lane.d_workspace); }
+    size_t cap = (size_t)1 << 20;
+    while (cap < need) cap <<= 1;
+    check(svo_hip_malloc(&lane.d_workspace, cap), "svo_hip_malloc(workspace)");
+    lane.workspace_bytes = cap;
+  }
+  return lane.d_workspace;
+}
+
+}  // namespace svo_hip

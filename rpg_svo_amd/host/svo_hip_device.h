@@ -1,0 +1,129 @@
+// svo_hip_device.h -- host-side device context shared by the C++ drop-in bodies
+// (rpg_svo_amd/host/dropin/*.cpp).  Plain C++11 over the C ABI of include/svo_hip.h: no HIP
+// headers, no Eigen, no reference headers, so it compiles with the g++ that builds libsvo.
+//
+// What it owns (one per process, see Device::instance()):
+//   * the pyramid store in HBM, one slot per live svo::Frame, keyed by Frame::id_; a frame is
+//     uploaded (level 0 H2D + K0 half-sampling on the device, replacing the host pyramid of
+//     frame_utils::createImgPyramid, svo/src/frame.cpp:156-165, for every device consumer)
+//     the first time a kernel needs it; the pool is an LRU cache (a frame that was evicted
+//     while its host object still lives is simply uploaded again on its next use);
+//   * two "lanes" (tracking thread, mapping thread -- depth_filter.cpp:64-67), each with its
+//     own HIP stream, a pinned host arena and its device mirror, so one call is: fill the
+//     arena -> ONE H2D copy -> kernels -> ONE D2H copy -> stream sync.
+#ifndef SVO_HIP_DEVICE_H_
+#define SVO_HIP_DEVICE_H_
+
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <svo_hip.h>
+
+namespace svo_hip {
+
+struct Error : std::runtime_error {
+  explicit Error(const std::string& what) : std::runtime_error(what) {}
+};
+void check(int code, const char* what);  // throws Error on a negative svo_hip status
+
+// Bump allocator over a pinned host buffer and its same-sized device mirror.  Input blocks
+// are carved from the front, output blocks after them; both sides share offsets.
+class Arena {
+ public:
+  Arena() : h_(NULL), d_(NULL), cap_(0), used_(0), in_end_(0) {}
+  void reserve(size_t bytes);
+  void reset() { used_ = 0; in_end_ = 0; }
+  // n elements of T, 256-byte aligned; *dev receives the device address of the same block
+  template <typename T> T* alloc(size_t n, T** dev) {
+    size_t off = (used_ + 255) & ~(size_t)255;
+    size_t end = off + n * sizeof(T);
+    if (end > cap_) grow(end);
+    used_ = end;
+    *dev = reinterpret_cast<T*>(d_ + off);
+    return reinterpret_cast<T*>(h_ + off);
+  }
+  void endInputs() { in_end_ = used_; }          // everything allocated so far is kernel input
+  void upload(void* stream);                      // H2D of [0, in_end)
+  void download(void* stream);                    // D2H of [in_end, used)
+  // D2H of one block handed out by alloc() (for arrays a kernel updates in place)
+  template <typename T> void fetch(T* host_block, size_t n, void* stream) {
+    fetchBytes(reinterpret_cast<uint8_t*>(host_block), n * sizeof(T), stream);
+  }
+  void release();
+  size_t used() const { return used_; }
+
+ private:
+  void grow(size_t need);
+  void fetchBytes(uint8_t* host_block, size_t bytes, void* stream);
+  uint8_t* h_;
+  uint8_t* d_;
+  size_t cap_, used_, in_end_;
+};
+
+struct Lane {
+  void* stream;
+  Arena arena;
+  void* d_workspace;      // matcher / depth-filter scratch (svo_hip_match_workspace_bytes)
+  size_t workspace_bytes;
+  std::mutex mut;
+  Lane() : stream(NULL), d_workspace(NULL), workspace_bytes(0) {}
+};
+
+class Device {
+ public:
+  enum { LANE_TRACKING = 0, LANE_MAPPING = 1, N_LANES = 2 };
+
+  // Process-wide context, created on first use with the image geometry of the first frame
+  // that reaches it (all frames of one svo::FrameHandlerMono share a camera).
+  static Device& instance();
+
+  // (Re)create the store: width/height of level 0, pyramid levels, slots.  Called lazily by
+  // ensureConfigured(); call it explicitly to size the slot pool (default 64 frames).
+  void configure(int width, int height, int n_levels, int n_slots = 64, int device = 0);
+  void ensureConfigured(int width, int height, int n_levels);
+  bool configured() const { return d_store_ != NULL; }
+  void shutdown();
+
+  const svo_hip_pyr_layout& layout() const { return layout_; }
+  const uint8_t* store() const { return d_store_; }
+  int nLevels() const { return layout_.n_levels; }
+
+  // Every entry point brackets its work with beginCall(): slots touched since then are
+  // pinned (never evicted) until the lane's next beginCall().
+  void beginCall(int which_lane);
+  // Slot of frame `id`; on a miss the level-0 image (8-bit, `stride` bytes per row) is
+  // uploaded and the pyramid built on the lane's stream, evicting the least recently used
+  // unpinned frame when the pool is full.
+  int slotOf(int frame_id, const uint8_t* level0, int stride, int which_lane);
+  void forget(int frame_id);
+
+  Lane& lane(int which) { return lanes_[which]; }
+  void* workspace(Lane& lane, int n_trials);  // grows the lane's matcher scratch on demand
+
+  // statistics for the latency read-outs
+  struct Stats { uint64_t uploads, evictions, calls; Stats() : uploads(0), evictions(0), calls(0) {} };
+  Stats stats;
+
+ private:
+  Device();
+  ~Device();
+  Device(const Device&);
+  struct Entry { int slot; uint64_t last_use; uint64_t epoch[N_LANES]; };
+  svo_hip_pyr_layout layout_;
+  uint8_t* d_store_;
+  int n_slots_;
+  std::vector<int> free_slots_;
+  std::map<int, Entry> frames_;
+  std::mutex frames_mut_;
+  uint64_t clock_;
+  uint64_t epoch_[N_LANES];
+  Lane lanes_[N_LANES];
+};
+
+}  // namespace svo_hip
+#endif  // SVO_HIP_DEVICE_H_

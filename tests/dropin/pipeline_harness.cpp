@@ -1,0 +1,198 @@
+// tests/dropin/pipeline_harness.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// C entry points around the REFERENCE'S OWN svo::FrameHandlerMono (compiled from the
+// sources where they lie under /root/reference/svo/src against the dependency shims in
+// oracle/shim/), the way svo_ros/src/benchmark_node.cpp:178-256 drives it: first frame
+// set at a known pose with FAST features lifted to 3-D through a depth map, every later
+// image through addImage().  tests/dropin/Makefile links this file twice:
+//
+//   _build/libsvo_pipeline_ref.so  all reference translation units          (CPU reference)
+//   _build/libsvo_pipeline_hip.so  the reference's control plane (frame handlers, map,
+//                                  frame, point, detector, config, matcher) + the drop-in
+//                                  bodies of rpg_svo_amd/host/dropin/*.cpp, which replace
+//                                  sparse_img_align.cpp, reprojector.cpp, pose_optimizer.cpp
+//                                  and depth_filter.cpp and call libsvo_hip.so
+//
+// so the two trajectories can be compared frame by frame (tests/test_dropin_pipeline_gpu.py,
+// bench.py --pipeline dropin).  No arithmetic of the path lives here.
+#include <cstdlib>
+#include <cstring>
+
+#include <svo/config.h>
+#include <svo/depth_filter.h>
+#include <svo/feature.h>
+#include <svo/feature_detection.h>
+#include <svo/frame.h>
+#include <svo/frame_handler_mono.h>
+#include <svo/map.h>
+#include <svo/point.h>
+#include <vikit/pinhole_camera.h>
+#include <vikit/vision.h>
+
+namespace vk {
+int g_halfsample_mode = 2;  // x86 dispatch of vk::halfSample (see oracle/shim/vikit/vision.h)
+}
+
+// The two-view bootstrap (svo/src/initialization.cpp: OpenCV KLT + vikit homography) is
+// out of scope and never entered: the harness starts from setFirstFrame().
+namespace svo {
+namespace initialization {
+InitResult KltHomographyInit::addFirstFrame(FramePtr) { return FAILURE; }
+InitResult KltHomographyInit::addSecondFrame(FramePtr) { return FAILURE; }
+void KltHomographyInit::reset() {}
+}  // namespace initialization
+}  // namespace svo
+
+using namespace svo;
+
+extern "C" {
+
+typedef struct pipe_config {
+  int32_t n_pyr_levels, klt_max_level, klt_min_level, grid_size, max_fts, max_n_kfs;
+  int32_t quality_min_fts, quality_max_drop_fts, structureoptim_max_pts, structureoptim_num_iter;
+  int32_t poseoptim_num_iter, shuffle_seed;
+  double kfselect_mindist, poseoptim_thresh, triang_min_corner_score;
+} pipe_config;
+
+typedef struct pipe_result {
+  double T_f_w[12];
+  int32_t stage, quality, n_obs, is_keyframe, frame_id, n_kfs, n_candidates, n_seeds;
+  // the columns FrameHandlerBase writes to its trace file (frame_handler_base.cpp:46-74)
+  double img_align_n_tracked, repr_n_mps, repr_n_new_references, sfba_thresh, sfba_error_init, sfba_error_final,
+      sfba_n_edges_final, dropout;
+  double t_pyramid_creation, t_sparse_img_align, t_reproject, t_pose_optimizer, t_point_optimizer, t_tot_time;
+} pipe_result;
+
+struct Pipe {
+  vk::PinholeCamera* cam;
+  FrameHandlerMono* vo;
+};
+
+void pipe_config_default(pipe_config* c) {
+  c->n_pyr_levels = 3; c->klt_max_level = 4; c->klt_min_level = 2; c->grid_size = 30; c->max_fts = 120;
+  c->max_n_kfs = 10; c->quality_min_fts = 50; c->quality_max_drop_fts = 40; c->structureoptim_max_pts = 20;
+  c->structureoptim_num_iter = 5; c->poseoptim_num_iter = 10; c->shuffle_seed = 1;
+  c->kfselect_mindist = 0.12; c->poseoptim_thresh = 2.0; c->triang_min_corner_score = 20.0;
+}
+
+void* pipe_create(int width, int height, double fx, double fy, double cx, double cy, const pipe_config* c) {
+  Config::nPyrLevels() = c->n_pyr_levels;
+  Config::kltMaxLevel() = c->klt_max_level;
+  Config::kltMinLevel() = c->klt_min_level;
+  Config::gridSize() = c->grid_size;
+  Config::maxFts() = c->max_fts;
+  Config::maxNKfs() = c->max_n_kfs;
+  Config::qualityMinFts() = c->quality_min_fts;
+  Config::qualityMaxFtsDrop() = c->quality_max_drop_fts;
+  Config::structureOptimMaxPts() = c->structureoptim_max_pts;
+  Config::structureOptimNumIter() = c->structureoptim_num_iter;
+  Config::poseOptimNumIter() = c->poseoptim_num_iter;
+  Config::poseOptimThresh() = c->poseoptim_thresh;
+  Config::kfSelectMinDist() = c->kfselect_mindist;
+  Config::triangMinCornerScore() = c->triang_min_corner_score;
+  Pipe* p = new Pipe;
+  p->cam = new vk::PinholeCamera(width, height, fx, fy, cx, cy);
+  std::srand((unsigned)c->shuffle_seed);  // Reprojector::initializeGrid's random_shuffle (reprojector.cpp:54)
+  p->vo = new FrameHandlerMono(p->cam);
+  p->vo->start();
+  // run the mapper synchronously inside addFrame()/addKeyframe() (depth_filter.cpp:82-107):
+  // deterministic interleaving of tracking and mapping for both libraries
+  p->vo->depthFilter()->stopThread();
+  return p;
+}
+
+void pipe_destroy(void* h) {
+  Pipe* p = (Pipe*)h;
+  delete p->vo;
+  delete p->cam;
+  delete p;
+}
+
+static void fill_result(Pipe* p, pipe_result* r) {
+  std::memset(r, 0, sizeof(*r));
+  FramePtr f = p->vo->lastFrame();
+  if (f) {
+    Matrix3d R = f->T_f_w_.rotation_matrix();
+    Vector3d t = f->T_f_w_.translation();
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r->T_f_w[i * 3 + j] = R(i, j);
+    for (int i = 0; i < 3; ++i) r->T_f_w[9 + i] = t[i];
+    r->is_keyframe = f->isKeyframe();
+    r->frame_id = f->id_;
+  }
+  r->stage = (int)p->vo->stage();
+  r->quality = (int)p->vo->trackingQuality();
+  r->n_obs = (int)p->vo->lastNumObservations();
+  r->n_kfs = (int)p->vo->map().size();
+  r->n_candidates = (int)p->vo->map().point_candidates_.candidates_.size();
+  r->n_seeds = (int)p->vo->depthFilter()->getSeeds().size();
+#ifdef SVO_TRACE
+  vk::PerformanceMonitor* m = g_permon;
+  r->img_align_n_tracked = m->get("img_align_n_tracked");
+  r->repr_n_mps = m->get("repr_n_mps");
+  r->repr_n_new_references = m->get("repr_n_new_references");
+  r->sfba_thresh = m->get("sfba_thresh");
+  r->sfba_error_init = m->get("sfba_error_init");
+  r->sfba_error_final = m->get("sfba_error_final");
+  r->sfba_n_edges_final = m->get("sfba_n_edges_final");
+  r->dropout = m->get("dropout");
+  r->t_pyramid_creation = m->get("pyramid_creation");
+  r->t_sparse_img_align = m->get("sparse_img_align");
+  r->t_reproject = m->get("reproject");
+  r->t_pose_optimizer = m->get("pose_optimizer");
+  r->t_point_optimizer = m->get("point_optimizer");
+  r->t_tot_time = m->get("tot_time");
+#endif
+}
+
+// benchmark_node.cpp:216-235: reference frame at a known pose, FAST corners of every pyramid
+// level lifted through the (level-0) depth map `depth` [height][width] (z-depth along the
+// optical axis is NOT what the reference uses: it scales the unit bearing, i.e. range).
+int pipe_set_first_frame(void* h, const uint8_t* img, double timestamp, const double T_f_w[12], const float* range_map,
+                         pipe_result* out) {
+  Pipe* p = (Pipe*)h;
+  const int w = p->cam->width(), hh = p->cam->height();
+  cv::Mat m(hh, w, CV_8UC1);
+  std::memcpy(m.data, img, (size_t)w * hh);
+  FramePtr frame_ref(new Frame(p->cam, m, timestamp));
+  Matrix3d R;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R(i, j) = T_f_w[i * 3 + j];
+  frame_ref->T_f_w_ = SE3(R, Vector3d(T_f_w[9], T_f_w[10], T_f_w[11]));
+  feature_detection::FastDetector detector(w, hh, Config::gridSize(), Config::nPyrLevels());
+  detector.detect(frame_ref.get(), frame_ref->img_pyr_, Config::triangMinCornerScore(), frame_ref->fts_);
+  for (Features::iterator it = frame_ref->fts_.begin(); it != frame_ref->fts_.end(); ++it) {
+    Feature* ftr = *it;
+    Vector3d pt_pos_cur = ftr->f * (double)range_map[(size_t)((int)ftr->px[1]) * w + (int)ftr->px[0]];
+    Vector3d pt_pos_world = frame_ref->T_f_w_.inverse() * pt_pos_cur;
+    Point* point = new Point(pt_pos_world, ftr);
+    ftr->point = point;
+  }
+  const int n = (int)frame_ref->nObs();
+  p->vo->setFirstFrame(frame_ref);
+  if (out) fill_result(p, out);
+  return n;
+}
+
+int pipe_add_image(void* h, const uint8_t* img, double timestamp, pipe_result* out) {
+  Pipe* p = (Pipe*)h;
+  const int w = p->cam->width(), hh = p->cam->height();
+  cv::Mat m(hh, w, CV_8UC1, (void*)img);
+  p->vo->addImage(m, timestamp);  // addImage clones (frame_handler_mono.cpp:69)
+  fill_result(p, out);
+  return (int)p->vo->stage();
+}
+
+// features of the last frame (px, level, has point), for inspection
+int pipe_last_features(void* h, int max_n, double* px, int32_t* level, double* pos) {
+  Pipe* p = (Pipe*)h;
+  FramePtr f = p->vo->lastFrame();
+  int n = 0;
+  if (!f) return 0;
+  for (Features::iterator it = f->fts_.begin(); it != f->fts_.end() && n < max_n; ++it, ++n) {
+    px[2 * n] = (*it)->px[0]; px[2 * n + 1] = (*it)->px[1];
+    level[n] = (*it)->level;
+    for (int k = 0; k < 3; ++k) pos[3 * n + k] = (*it)->point ? (*it)->point->pos_[k] : 0.0;
+  }
+  return n;
+}
+
+}  // extern "C"

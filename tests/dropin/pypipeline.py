@@ -1,0 +1,122 @@
+"""TEST INFRASTRUCTURE: ctypes driver of tests/dropin/_build/libsvo_pipeline_{ref,hip}.so (the
+reference's svo::FrameHandlerMono, either all-CPU or with the drop-in HIP bodies)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BUILD = os.path.join(HERE, "_build")
+REF_SRC = "/root/reference/svo/src"
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_pyr_levels", "klt_max_level", "klt_min_level", "grid_size", "max_fts",
+                                         "max_n_kfs", "quality_min_fts", "quality_max_drop_fts",
+                                         "structureoptim_max_pts", "structureoptim_num_iter", "poseoptim_num_iter",
+                                         "shuffle_seed")] + \
+               [(n, C.c_double) for n in ("kfselect_mindist", "poseoptim_thresh", "triang_min_corner_score")]
+
+
+class Result(C.Structure):
+    _fields_ = [("T_f_w", C.c_double * 12)] + \
+               [(n, C.c_int32) for n in ("stage", "quality", "n_obs", "is_keyframe", "frame_id", "n_kfs",
+                                         "n_candidates", "n_seeds")] + \
+               [(n, C.c_double) for n in ("img_align_n_tracked", "repr_n_mps", "repr_n_new_references", "sfba_thresh",
+                                          "sfba_error_init", "sfba_error_final", "sfba_n_edges_final", "dropout",
+                                          "t_pyramid_creation", "t_sparse_img_align", "t_reproject",
+                                          "t_pose_optimizer", "t_point_optimizer", "t_tot_time")]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "T_f_w"}
+        d["T_f_w"] = np.array(self.T_f_w[:])
+        return d
+
+
+STAGE_DEFAULT_FRAME = 3
+
+
+def lib_path(flavour: str) -> str:
+    return os.path.join(BUILD, f"libsvo_pipeline_{flavour}.so")
+
+
+def available(flavour: str) -> bool:
+    return os.path.exists(lib_path(flavour))
+
+
+def build(flavour: str = "all") -> bool:
+    """Needs the reference checkout (this container only); the GPU box uses the prebuilt files."""
+    if not os.path.isdir(REF_SRC):
+        return False
+    subprocess.run(["make", "-s", "-C", HERE, "-j8", flavour], check=True)
+    return True
+
+
+class Pipeline:
+    def __init__(self, flavour: str, cam, **cfg):
+        self.lib = C.CDLL(lib_path(flavour))
+        self.lib.pipe_create.restype = C.c_void_p
+        self.lib.pipe_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(Config)]
+        self.lib.pipe_destroy.argtypes = [C.c_void_p]
+        self.lib.pipe_set_first_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.POINTER(Result)]
+        self.lib.pipe_add_image.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.POINTER(Result)]
+        self.lib.pipe_last_features.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        c = Config()
+        self.lib.pipe_config_default(C.byref(c))
+        for k, v in cfg.items():
+            setattr(c, k, v)
+        self.cfg = c
+        self.cam = cam
+        self.h = self.lib.pipe_create(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, C.byref(c))
+
+    def close(self):
+        if self.h:
+            self.lib.pipe_destroy(self.h)
+            self.h = None
+
+    def set_first_frame(self, img, ts, T_f_w, range_map):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        T = np.ascontiguousarray(T_f_w, dtype=np.float64)
+        rm = np.ascontiguousarray(range_map, dtype=np.float32)
+        r = Result()
+        n = self.lib.pipe_set_first_frame(self.h, img.ctypes.data, ts, T.ctypes.data, rm.ctypes.data, C.byref(r))
+        return n, r.as_dict()
+
+    def add_image(self, img, ts):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        r = Result()
+        self.lib.pipe_add_image(self.h, img.ctypes.data, ts, C.byref(r))
+        return r.as_dict()
+
+    def last_features(self, max_n=2048):
+        px = np.zeros((max_n, 2)); lvl = np.zeros(max_n, dtype=np.int32); pos = np.zeros((max_n, 3))
+        n = self.lib.pipe_last_features(self.h, max_n, px.ctypes.data, lvl.ctypes.data, pos.ctypes.data)
+        return px[:n], lvl[:n], pos[:n]
+
+
+def range_map(cam, T_f_w):
+    """Distance from the camera centre to the plane z = 0 along each pixel's viewing ray."""
+    R = np.asarray(T_f_w[:9]).reshape(3, 3)
+    c = -R.T @ np.asarray(T_f_w[9:])
+    u, v = np.meshgrid(np.arange(cam.width, dtype=np.float64), np.arange(cam.height, dtype=np.float64))
+    d = np.stack([(u - cam.cx) / cam.fx, (v - cam.cy) / cam.fy, np.ones_like(u)], -1)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    dw = d @ R  # R^T d
+    return (-c[2] / dw[..., 2]).astype(np.float32)
+
+
+def run_sequence(flavour, cam, images, T_gt, **cfg):
+    """Feed a whole sequence; returns the per-frame result dicts (frame 0 = first frame)."""
+    p = Pipeline(flavour, cam, **cfg)
+    try:
+        n0, r0 = p.set_first_frame(images[0], 0.0, T_gt[0], range_map(cam, T_gt[0]))
+        r0["n_first_features"] = n0
+        out = [r0]
+        for i in range(1, len(images)):
+            out.append(p.add_image(images[i], float(i)))
+        return out
+    finally:
+        p.close()
