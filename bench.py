@@ -75,7 +75,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=8192, help="frames per step per GPU")
     ap.add_argument("--workload", default="vga4_n200_sparse_align", choices=sorted(WORKLOADS))
     ap.add_argument("--noise", type=float, default=0.0, help="image noise sigma (gray levels)")
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="frames timed on the host for cpu_baseline")
+    ap.add_argument("--cpu-sample", type=int, default=8192, help="frames timed on the host for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n-iter", type=int, default=30, help="Gauss-Newton iteration cap per level (30 in the pipeline)")
     ap.add_argument("--pipeline", default="align", choices=["align", "full"],
@@ -246,9 +246,49 @@ def main() -> None:
         result["cpu_baseline"] = cpu_baseline(args, cam, images, T_gt, px_all, f_all, pos_all, T_ref_w, T_prior_w,
                                               n_levels, max_level, min_level, n_patches, T_est_w, result,
                                               out.iters.cpu().numpy())
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            result["dropin_sequence"] = dropin_sequence()
+        except Exception as e:  # the demonstration libraries are optional (built from the reference checkout)
+            result["dropin_sequence"] = {"skipped": str(e)}
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def dropin_sequence(n_frames: int = 120) -> dict:
+    """Single-stream, image-in -> pose-out: the reference's own svo::FrameHandlerMono on a
+    752x480 synthetic sequence, once with all-reference translation units on the host CPU and
+    once with the drop-in HIP bodies (tests/dropin, rpg_svo_amd/host/dropin).  Reports the
+    trajectory agreement (the metric's "ATE vs CPU ref") and the per-frame latency of both."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "dropin"))
+    import pypipeline as pp
+    if not (pp.available("ref") and pp.available("hip")):
+        raise RuntimeError("tests/dropin/_build/*.so not built")
+    cam = synth.Camera(752, 480, 315.5, 315.5, 376.0, 240.0)
+    T = synth.make_trajectory(n_frames, seed=5, max_step=0.02, max_rot_deg=0.3)
+    imgs = synth.render(synth.make_texture(seed=12345), T, cam).numpy()
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    saved = os.dup(2)
+    os.dup2(devnull, 2)  # the reference logs every frame to stderr
+    try:
+        ref = pp.run_sequence("ref", cam, imgs, T)
+        pp.run_sequence("hip", cam, imgs[:10], T[:10])  # warm-up: context creation, first launches
+        hip = pp.run_sequence("hip", cam, imgs, T)
+    finally:
+        os.dup2(saved, 2)
+        os.close(devnull)
+    Tr = np.stack([r["T_f_w"] for r in ref])
+    Th = np.stack([r["T_f_w"] for r in hip])
+    d = se3.log_norm(Th, Tr)
+    med = lambda rs, k: float(np.median([r[k] for r in rs[1:]]) * 1e3)
+    stages = ("tot_time", "sparse_img_align", "reproject", "pose_optimizer")
+    return {"frames": n_frames, "image": "752x480", "se3_lognorm_max": float(d.max()), "se3_lognorm_median": float(np.median(d)),
+            "ate_rmse_vs_cpu_m": horn_ate(se3.inv(Th)[:, 9:], se3.inv(Tr)[:, 9:]),
+            "keyframes": int(sum(r["is_keyframe"] for r in hip)),
+            "same_keyframe_frames": [r["is_keyframe"] for r in ref] == [r["is_keyframe"] for r in hip],
+            "median_ms_per_frame_cpu_reference": {k: med(ref, "t_" + k) for k in stages},
+            "median_ms_per_frame_hip_dropin": {k: med(hip, "t_" + k) for k in stages}}
 
 
 def cpu_baseline(args, cam, images, T_gt, px_all, f_all, pos_all, T_ref_w, T_prior_w, n_levels, max_level,
@@ -268,15 +308,21 @@ def cpu_baseline(args, cam, images, T_gt, px_all, f_all, pos_all, T_ref_w, T_pri
     pos = pos_all[:S].cpu().numpy()
     hp = np.ones((S, n_patches), dtype=np.uint8)
     cores = os.cpu_count() or 1
-    s1 = min(S, 512)
-    t0 = time.perf_counter()
-    pyoracle.sparse_img_align_batch(pyrs, rs[:s1], cs[:s1], cam, T_ref_w[:s1], T_prior_w[:s1], nn[:s1], px[:s1],
-                                    f[:s1], hp[:s1], pos[:s1], max_level, min_level, args.n_iter, n_threads=1)
-    t1 = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    T_cpu, res = pyoracle.sparse_img_align_batch(pyrs, rs, cs, cam, T_ref_w[:S], T_prior_w[:S], nn, px, f, hp, pos,
-                                                 max_level, min_level, args.n_iter, n_threads=cores)
-    tn = time.perf_counter() - t0
+    s1 = min(S, 2048)
+    # kind "reference": the reference's own SparseImgAlign translation unit (oracle/_ref, built
+    # from /root/reference/svo/src in the build container, travels prebuilt); otherwise the C port
+    which = "ref" if pyoracle.ref_available() else "orc"
+
+    def timed(k, threads):
+        tm = {}
+        t0 = time.perf_counter()
+        T, r = pyoracle.sparse_img_align_batch(pyrs, rs[:k], cs[:k], cam, T_ref_w[:k], T_prior_w[:k], nn[:k], px[:k],
+                                               f[:k], hp[:k], pos[:k], max_level, min_level, args.n_iter,
+                                               n_threads=threads, which=which, timing=tm)
+        return T, r, tm.get("run_seconds", time.perf_counter() - t0)
+
+    _, _, t1 = timed(s1, 1)
+    T_cpu, res, tn = timed(S, cores)
     d = se3.log_norm(T_est_w[:S], T_cpu)
     pos_gpu = se3.inv(T_est_w[:S])[:, 9:]
     pos_cpu = se3.inv(T_cpu)[:, 9:]
@@ -289,8 +335,10 @@ def cpu_baseline(args, cam, images, T_gt, px_all, f_all, pos_all, T_ref_w, T_pri
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
-    return {"value": S / tn, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{S} of the benchmark's own frame pairs, oracle/libsvo_oracle.so (gcc -O3), {cores} pthreads",
+    impl = ("the reference's own sparse_img_align.cpp (oracle/_ref/libsvo_ref.so, g++ -O3 against dependency shims), "
+            "run() calls only") if which == "ref" else "oracle/libsvo_oracle.so (C port, gcc -O3)"
+    return {"value": S / tn, "unit": "frames/s", "cores": cores, "kind": "reference" if which == "ref" else "port",
+            "sample": f"{S} of the benchmark's own frame pairs, {impl}, {cores} threads",
             "value_1core": s1 / t1, "sample_1core": f"{s1} frame pairs, 1 thread", "cpu_model": model}
 
 

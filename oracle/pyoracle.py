@@ -63,6 +63,25 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_ref_lib = None
+
+
+def ref_available() -> bool:
+    from . import pytrack
+    return pytrack.ref_available()
+
+
+def ref_lib() -> C.CDLL:
+    """oracle/_ref/libsvo_ref.so (prebuilt; built here only where the reference checkout exists)."""
+    global _ref_lib
+    if _ref_lib is None:
+        from . import pytrack
+        if not pytrack.ref_available():
+            build_ref()
+        _ref_lib = C.CDLL(pytrack.REF_LIB_PATH)
+    return _ref_lib
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -166,7 +185,7 @@ def _res_dict(res: SiaResult, vis=None) -> dict:
 
 
 def sparse_img_align_batch(pyrs, ref_slot, cur_slot, cam, T_ref_w, T_cur_w, n, px, f, has_point, pos,
-                           max_level, min_level, n_iter=30, eps=1e-6, n_threads=1):
+                           max_level, min_level, n_iter=30, eps=1e-6, n_threads=1, which="orc", timing=None):
     """pyrs: list of pyramids (list of level arrays).  Arrays are [B, n_stride, .].
     Returns (T_cur_w_new [B,12], list of result dicts)."""
     B = len(ref_slot)
@@ -187,6 +206,14 @@ def sparse_img_align_batch(pyrs, ref_slot, cur_slot, cam, T_ref_w, T_cur_w, n, p
     nn = np.ascontiguousarray(n, dtype=np.int32)
     opt = SiaOptions(max_level, min_level, n_iter, eps)
     res = (SiaResult * B)()
+    if which == "ref":  # the reference's own SparseImgAlign (oracle/_ref/libsvo_ref.so)
+        secs = C.c_double(0)
+        ref_lib().ref_sparse_img_align_batch(C.c_int(B), arr, _p(rs), _p(cs), C.byref(pc), _p(Tr), _p(Tc), _p(nn),
+                                             C.c_int(n_stride), _p(px), _p(f), _p(hp), _p(pos), C.byref(opt), res,
+                                             C.c_int(n_threads), C.byref(secs))
+        if timing is not None:
+            timing["run_seconds"] = secs.value
+        return Tc, [_res_dict(r) for r in res]
     lib().orc_sparse_img_align_batch(C.c_int(B), arr, _p(rs), _p(cs), C.byref(pc), _p(Tr), _p(Tc), _p(nn),
                                      C.c_int(n_stride), _p(px), _p(f), _p(hp), _p(pos), C.byref(opt), res,
                                      C.c_int(n_threads))

@@ -9,8 +9,11 @@
 //
 // Output: oracle/_ref/libsvo_ref.so (git-ignored; travels with gpurun).  Used by
 // tests/test_oracle_vs_ref.py to pin the C restatement, never by the product.
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <map>
+#include <thread>
 #include <vector>
 
 #include <svo/config.h>
@@ -188,6 +191,65 @@ int ref_sparse_img_align_run(const orc_pyramid* ref_pyr, const orc_pyramid* cur_
   cur.reset();
   delete c;
   return (int)tracked;
+}
+
+// Batch driver for bench.py's cpu_baseline (kind "reference"): the reference's own
+// SparseImgAlign::run over B problems on n_threads host threads.  All Frame / Feature / Point
+// objects are built first; *seconds_out is the wall time of the run() calls alone.
+int ref_sparse_img_align_batch(int B, const orc_pyramid* pyrs, const int* ref_slot, const int* cur_slot,
+                               const orc_pinhole* cam, const double* T_ref_w, double* T_cur_w, const int* n, int n_stride,
+                               const double* px, const double* f, const uint8_t* has_point, const double* pos,
+                               const orc_sia_options* opt, orc_sia_result* res, int n_threads, double* seconds_out) {
+  vk::PinholeCamera* c = make_cam(cam);
+  std::vector<FramePtr> refs(B), curs(B);
+  std::vector<Point*> points;
+  for (int b = 0; b < B; ++b) {
+    refs[b] = make_frame(c, &pyrs[ref_slot[b]], T_ref_w + 12 * b);
+    curs[b] = make_frame(c, &pyrs[cur_slot[b]], T_cur_w + 12 * b);
+    for (int i = 0; i < n[b]; ++i) {
+      const size_t k = (size_t)b * n_stride + i;
+      Feature* ftr = new Feature(refs[b].get(), Vector2d(px[2 * k], px[2 * k + 1]), Vector3d(f[3 * k], f[3 * k + 1], f[3 * k + 2]), 0);
+      if (has_point[k]) {
+        Point* p = new Point(Vector3d(pos[3 * k], pos[3 * k + 1], pos[3 * k + 2]));
+        points.push_back(p);
+        ftr->point = p;
+      }
+      refs[b]->addFeature(ftr);
+    }
+  }
+  if (n_threads < 1) n_threads = 1;
+  std::atomic<int> next(0);
+  auto worker = [&]() {
+    for (;;) {
+      const int b = next.fetch_add(1);
+      if (b >= B) break;
+      std::memset(&res[b], 0, sizeof(res[b]));
+      SiaProbe sia(opt->max_level, opt->min_level, opt->n_iter, opt->eps);
+      const size_t tracked = sia.run(refs[b], curs[b]);
+      res[b].n_tracked = (int)tracked;
+      res[b].stop = sia.stop_;
+      res[b].chi2 = sia.chi2();
+      for (int l = 0; l < ORC_MAX_LEVELS; ++l) res[b].iters[l] = sia.evals[l];
+    }
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  if (n_threads == 1) {
+    worker();
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+  }
+  if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (int b = 0; b < B; ++b) {
+    se3_to_Rt(curs[b]->T_f_w_, T_cur_w + 12 * b);
+    se3_to_Rt(curs[b]->T_f_w_ * refs[b]->T_f_w_.inverse(), res[b].T_cur_from_ref);
+  }
+  for (Point* p : points) delete p;
+  refs.clear();
+  curs.clear();
+  delete c;
+  return 0;
 }
 
 int ref_align2d(const uint8_t* cur_img, int w, int h, int stride, const uint8_t* ref_patch_with_border,
