@@ -246,6 +246,8 @@ def main() -> None:
         result["cpu_baseline"] = cpu_baseline(args, cam, images, T_gt, px_all, f_all, pos_all, T_ref_w, T_prior_w,
                                               n_levels, max_level, min_level, n_patches, T_est_w, result,
                                               out.iters.cpu().numpy())
+    if world == 1:
+        result["k0_pyramid"] = pyramid_roofline(lib, store, images, stream)
     if not args.no_cpu_baseline and world == 1:
         try:
             result["dropin_sequence"] = dropin_sequence()
@@ -254,6 +256,47 @@ def main() -> None:
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pyramid_roofline(lib, store, images, stream, reps: int = 5) -> dict:
+    """K0, the one HBM-streaming kernel of the path: image pyramids of the whole
+    replay batch rebuilt from the packed images in a single fused pass.  Algorithmic bytes per
+    frame = w*h read + every level written once."""
+    n = images.shape[0]
+    per_frame = images.shape[1] * images.shape[2] + store.bytes_per_pyramid()
+
+    def timed(fn):
+        ms = []
+        for _ in range(reps + 1):
+            e0, e1 = C_void(), C_void()
+            capi.check(lib.svo_hip_event_create(e0.ref()))
+            capi.check(lib.svo_hip_event_create(e1.ref()))
+            lib.svo_hip_event_record(e0.value, stream)
+            fn()
+            lib.svo_hip_event_record(e1.value, stream)
+            m = C_float()
+            capi.check(lib.svo_hip_event_elapsed_ms(e0.value, e1.value, m.ref()))
+            ms.append(m.value)
+            lib.svo_hip_event_destroy(e0.value)
+            lib.svo_hip_event_destroy(e1.value)
+        return float(np.mean(ms[1:]))
+
+    tiles = {}
+    for tw in (128, 256):
+        lib.svo_hip_pyramid_set_tile(tw)
+        tiles[str(tw)] = timed(lambda: store.load_images(images, 0))
+    lib.svo_hip_pyramid_set_tile(0)
+    fused = timed(lambda: store.load_images(images, 0))
+
+    def per_level():
+        store.load_images(images, 0, build=False)
+        store.build_per_level(0, n)
+    unfused = timed(per_level)
+    gbs = n * per_frame / (fused * 1e-3) / 1e9
+    return {"kernel": "pyramid_fused_kernel (svo_hip_pyramid_build_from_images)", "frames": int(n),
+            "ms": fused, "frames_per_s": n / (fused * 1e-3), "algorithmic_bytes_per_frame": int(per_frame),
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "ms_level0_copy_plus_one_launch_per_level": unfused, "ms_by_tile_width": tiles}
 
 
 def dropin_sequence(n_frames: int = 120) -> dict:
@@ -323,6 +366,15 @@ def cpu_baseline(args, cam, images, T_gt, px_all, f_all, pos_all, T_ref_w, T_pri
 
     _, _, t1 = timed(s1, 1)
     T_cpu, res, tn = timed(S, cores)
+    best_threads, best_rate = cores, S / tn
+    sweep = {str(cores): S / tn}
+    for th in (cores // 2, cores // 4):  # SMT siblings / allocator contention: fewer threads can be faster
+        if th >= 1:
+            k = max(1, S // 2)
+            _, _, tt = timed(k, th)
+            sweep[str(th)] = k / tt
+            if k / tt > best_rate:
+                best_threads, best_rate = th, k / tt
     d = se3.log_norm(T_est_w[:S], T_cpu)
     pos_gpu = se3.inv(T_est_w[:S])[:, 9:]
     pos_cpu = se3.inv(T_cpu)[:, 9:]
@@ -337,8 +389,9 @@ def cpu_baseline(args, cam, images, T_gt, px_all, f_all, pos_all, T_ref_w, T_pri
         model = "unknown"
     impl = ("the reference's own sparse_img_align.cpp (oracle/_ref/libsvo_ref.so, g++ -O3 against dependency shims), "
             "run() calls only") if which == "ref" else "oracle/libsvo_oracle.so (C port, gcc -O3)"
-    return {"value": S / tn, "unit": "frames/s", "cores": cores, "kind": "reference" if which == "ref" else "port",
-            "sample": f"{S} of the benchmark's own frame pairs, {impl}, {cores} threads",
+    return {"value": best_rate, "unit": "frames/s", "cores": best_threads, "kind": "reference" if which == "ref" else "port",
+            "sample": f"{S} of the benchmark's own frame pairs, {impl}; best of the thread counts tried",
+            "frames_per_s_by_threads": sweep, "host_logical_cpus": cores,
             "value_1core": s1 / t1, "sample_1core": f"{s1} frame pairs, 1 thread", "cpu_model": model}
 
 

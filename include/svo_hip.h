@@ -102,6 +102,18 @@ int svo_hip_pyramid_upload_level0(const svo_hip_pyr_layout* layout, uint8_t* d_s
  * (svo/src/frame.cpp:156-165).  Bit-exact with the selected flavour. */
 int svo_hip_pyramid_build(const svo_hip_pyr_layout* layout, uint8_t* d_store, int first_slot,
                           int n_slots, int halfsample_mode, void* stream);
+/* N1: level 0 filled from packed device images AND every further level built in
+ * the same single pass over the pixels (one read of the source, 1.33 B written per pixel). */
+int svo_hip_pyramid_build_from_images(const svo_hip_pyr_layout* layout, uint8_t* d_store, int first_slot,
+                                      int n_slots, const uint8_t* d_images, int64_t image_stride,
+                                      int row_stride, int halfsample_mode, void* stream);
+/* Tuning knob: level-0 tile of the fused builder, 128 (x64 rows) or 256 (x32 rows); 0 = choose
+ * by image width (the default).  Results do not depend on it. */
+int svo_hip_pyramid_set_tile(int tile_width);
+/* The one-launch-per-level builder svo_hip_pyramid_build used before the fused kernel; same
+ * results, kept for A/B timing. */
+int svo_hip_pyramid_build_per_level(const svo_hip_pyr_layout* layout, uint8_t* d_store, int first_slot,
+                                    int n_slots, int halfsample_mode, void* stream);
 /* Download one level of one slot into a tightly packed host buffer (tests). */
 int svo_hip_pyramid_download_level(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
                                    int slot, int level, uint8_t* out, void* stream);

@@ -105,6 +105,9 @@ PROTOTYPES = {
     "svo_hip_pyramid_load_level0": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _i64, _i, _vp]),
     "svo_hip_pyramid_upload_level0": (_i, [C.POINTER(PyrLayout), _vp, _i, _vp, _i, _vp]),
     "svo_hip_pyramid_build": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _i, _vp]),
+    "svo_hip_pyramid_build_from_images": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _i64, _i, _i, _vp]),
+    "svo_hip_pyramid_set_tile": (_i, [_i]),
+    "svo_hip_pyramid_build_per_level": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _i, _vp]),
     "svo_hip_pyramid_download_level": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _vp]),
     "svo_hip_sparse_align": (_i, [C.POINTER(PyrLayout), _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp,
                                   C.POINTER(SiaParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -52,6 +52,128 @@ __global__ void __launch_bounds__(256) half_sample_kernel(uint8_t* __restrict__ 
   *reinterpret_cast<uint32_t*>(slot + out_off + (int64_t)y * out_pitch + x4 * 4) = half4(t, b, sse2 != 0);
 }
 
+// ---- fused builder ---------------------------------------------------------
+// One pass over level 0 builds EVERY level: a workgroup owns a 128x64 tile of level 0
+// (256 lanes, each 16 pixels x 2 rows = two dwordx4 loads), forms its 64x32 tile of level 1
+// in registers, parks it in LDS, and 128 / 32 / 8 lanes then reduce 32x16, 16x8 and 8x4 tiles
+// of levels 2..4 from LDS.  HBM traffic per level-0 pixel: 1 B read + 0.33 B written (plus
+// 1 B written when level 0 itself is being filled from packed images), instead of the
+// 1 + 0.25 + 2*(0.25 + 0.0625 + ...) of one launch per level.
+constexpr int FUSED_MAX_LEVELS = 5;
+
+struct FusedArgs {
+  uint8_t* store;
+  int64_t slot_bytes;
+  int first_slot;
+  int n_levels;                       // levels built here (<= FUSED_MAX_LEVELS)
+  int w[FUSED_MAX_LEVELS], h[FUSED_MAX_LEVELS], pitch[FUSED_MAX_LEVELS];
+  int64_t off[FUSED_MAX_LEVELS];
+  int sse2[FUSED_MAX_LEVELS];         // flavour of the transition INTO level l
+  const uint8_t* images;              // packed source images, or nullptr: level 0 is in the store
+  int64_t image_stride;
+  int row_stride;
+};
+
+__device__ __forceinline__ void store4(uint8_t* dst, uint32_t v, int x0, int w) {
+  if (x0 + 4 <= w) {
+    *reinterpret_cast<uint32_t*>(dst) = v;
+  } else {
+    for (int k = 0; k < w - x0; ++k) dst[k] = (uint8_t)(v >> (8 * k));
+  }
+}
+
+__device__ __forceinline__ uint4 load16(const uint8_t* src, int x0, int w, bool aligned) {
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (x0 + 16 <= w && aligned) {
+    v = *reinterpret_cast<const uint4*>(src);
+  } else if (x0 < w) {
+    uint32_t t[4] = {0, 0, 0, 0};
+    const int n = min(16, w - x0);
+    for (int k = 0; k < n; ++k) t[k >> 2] |= (uint32_t)src[k] << (8 * (k & 3));
+    v = make_uint4(t[0], t[1], t[2], t[3]);
+  }
+  return v;
+}
+
+// TW x TH level-0 pixels per workgroup, TW*TH = 8192 (256 lanes x 32 px): 128x64 or 256x32
+template <int TW>
+__global__ void __launch_bounds__(256) pyramid_fused_kernel(const FusedArgs a) {
+  constexpr int TH = 8192 / TW;
+  constexpr int WX = TW / 16;            // lanes across the tile
+  constexpr int W1 = TW / 2, W2 = TW / 4, W3 = TW / 8;
+  __shared__ uint8_t l1[(TH / 2) * W1];
+  __shared__ uint8_t l2[(TH / 4) * W2];
+  __shared__ uint8_t l3[(TH / 8) * W3];
+  const int tid = threadIdx.x;
+  const int tx = tid % WX, ty = tid / WX;
+  uint8_t* slot = a.store + (int64_t)(a.first_slot + blockIdx.z) * a.slot_bytes;
+  const int x0 = blockIdx.x * TW + tx * 16;
+  const int y0 = blockIdx.y * TH + ty * 2;
+  uint4 top = make_uint4(0, 0, 0, 0), bot = top;
+  if (a.images) {  // fill level 0 on the way
+    const uint8_t* img = a.images + (int64_t)blockIdx.z * a.image_stride;
+    const bool al = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)a.row_stride) & 15) == 0;
+    if (y0 < a.h[0]) top = load16(img + (int64_t)y0 * a.row_stride + x0, x0, a.w[0], al);
+    if (y0 + 1 < a.h[0]) bot = load16(img + (int64_t)(y0 + 1) * a.row_stride + x0, x0, a.w[0], al);
+    // rows of the store are 64-byte aligned and padded: whole 16-byte stores are in bounds
+    if (x0 < a.w[0]) {
+      if (y0 < a.h[0]) *reinterpret_cast<uint4*>(slot + (int64_t)y0 * a.pitch[0] + x0) = top;
+      if (y0 + 1 < a.h[0]) *reinterpret_cast<uint4*>(slot + (int64_t)(y0 + 1) * a.pitch[0] + x0) = bot;
+    }
+  } else if (x0 < a.w[0]) {
+    if (y0 < a.h[0]) top = *reinterpret_cast<const uint4*>(slot + (int64_t)y0 * a.pitch[0] + x0);
+    if (y0 + 1 < a.h[0]) bot = *reinterpret_cast<const uint4*>(slot + (int64_t)(y0 + 1) * a.pitch[0] + x0);
+  }
+  if (a.n_levels < 2) return;
+  {  // level 1: 8 px per lane
+    const uint32_t lo = half4(make_uint2(top.x, top.y), make_uint2(bot.x, bot.y), a.sse2[1] != 0);
+    const uint32_t hi = half4(make_uint2(top.z, top.w), make_uint2(bot.z, bot.w), a.sse2[1] != 0);
+    *reinterpret_cast<uint2*>(&l1[ty * W1 + tx * 8]) = make_uint2(lo, hi);
+    const int ox = blockIdx.x * W1 + tx * 8, oy = blockIdx.y * (TH / 2) + ty;
+    if (oy < a.h[1] && ox < a.w[1]) {
+      uint8_t* dst = slot + a.off[1] + (int64_t)oy * a.pitch[1] + ox;
+      if (ox + 8 <= a.w[1]) {
+        *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+      } else {
+        store4(dst, lo, ox, a.w[1]);
+        if (ox + 4 < a.w[1]) store4(dst + 4, hi, ox + 4, a.w[1]);
+      }
+    }
+  }
+  if (a.n_levels < 3) return;
+  __syncthreads();
+  if (tid < 128) {  // level 2: W2 x TH/4 px, 4 px per lane
+    const int r = tid / WX, c = tid % WX;
+    const uint2 t = *reinterpret_cast<const uint2*>(&l1[(2 * r) * W1 + c * 8]);
+    const uint2 b = *reinterpret_cast<const uint2*>(&l1[(2 * r + 1) * W1 + c * 8]);
+    const uint32_t v = half4(t, b, a.sse2[2] != 0);
+    *reinterpret_cast<uint32_t*>(&l2[r * W2 + c * 4]) = v;
+    const int ox = blockIdx.x * W2 + c * 4, oy = blockIdx.y * (TH / 4) + r;
+    if (oy < a.h[2] && ox < a.w[2]) store4(slot + a.off[2] + (int64_t)oy * a.pitch[2] + ox, v, ox, a.w[2]);
+  }
+  if (a.n_levels < 4) return;
+  __syncthreads();
+  if (tid < 32) {  // level 3
+    const int r = tid / (WX / 2), c = tid % (WX / 2);
+    const uint2 t = *reinterpret_cast<const uint2*>(&l2[(2 * r) * W2 + c * 8]);
+    const uint2 b = *reinterpret_cast<const uint2*>(&l2[(2 * r + 1) * W2 + c * 8]);
+    const uint32_t v = half4(t, b, a.sse2[3] != 0);
+    *reinterpret_cast<uint32_t*>(&l3[r * W3 + c * 4]) = v;
+    const int ox = blockIdx.x * W3 + c * 4, oy = blockIdx.y * (TH / 8) + r;
+    if (oy < a.h[3] && ox < a.w[3]) store4(slot + a.off[3] + (int64_t)oy * a.pitch[3] + ox, v, ox, a.w[3]);
+  }
+  if (a.n_levels < 5) return;
+  __syncthreads();
+  if (tid < 8) {  // level 4
+    const int r = tid / (WX / 4), c = tid % (WX / 4);
+    const uint2 t = *reinterpret_cast<const uint2*>(&l3[(2 * r) * W3 + c * 8]);
+    const uint2 b = *reinterpret_cast<const uint2*>(&l3[(2 * r + 1) * W3 + c * 8]);
+    const uint32_t v = half4(t, b, a.sse2[4] != 0);
+    const int ox = blockIdx.x * (TW / 16) + c * 4, oy = blockIdx.y * (TH / 16) + r;
+    if (oy < a.h[4] && ox < a.w[4]) store4(slot + a.off[4] + (int64_t)oy * a.pitch[4] + ox, v, ox, a.w[4]);
+  }
+}
+
 // packed images -> level 0 of the slots; 4 bytes per lane
 __global__ void __launch_bounds__(256) load_level0_kernel(uint8_t* __restrict__ store, int64_t slot_bytes,
                                                          int first_slot, int pitch, int w, int h,
@@ -102,8 +224,90 @@ int svo_hip_pyramid_upload_level0(const svo_hip_pyr_layout* L, uint8_t* d_store,
   return SVO_HIP_OK;
 }
 
+static int g_forced_tile = 0;
+
+int svo_hip_pyramid_set_tile(int tile_width) {
+  if (tile_width != 0 && tile_width != 128 && tile_width != 256) return SVO_HIP_EINVAL;
+  g_forced_tile = tile_width;
+  return SVO_HIP_OK;
+}
+
+static int build_impl(const svo_hip_pyr_layout* L, uint8_t* d_store, int first_slot, int n_slots, const uint8_t* d_images,
+                      int64_t image_stride, int row_stride, int halfsample_mode, hipStream_t s) {
+  auto flavour = [&](int lvl) {
+    if (halfsample_mode == SVO_HIP_HALFSAMPLE_AUTO) return (L->w[lvl - 1] % 16) == 0 ? 1 : 0;
+    return halfsample_mode == SVO_HIP_HALFSAMPLE_SSE2 ? 1 : 0;
+  };
+  FusedArgs a;
+  a.store = d_store;
+  a.slot_bytes = L->slot_bytes;
+  a.n_levels = min(L->n_levels, FUSED_MAX_LEVELS);
+  for (int l = 0; l < FUSED_MAX_LEVELS; ++l) {
+    const bool on = l < a.n_levels;
+    a.w[l] = on ? L->w[l] : 0; a.h[l] = on ? L->h[l] : 0; a.pitch[l] = on ? L->pitch[l] : 0; a.off[l] = on ? L->offset[l] : 0;
+    a.sse2[l] = (on && l > 0) ? flavour(l) : 0;
+  }
+  a.image_stride = image_stride;
+  a.row_stride = row_stride;
+  int done = 0;
+  while (done < n_slots) {
+    const int chunk = min(n_slots - done, 32768);
+    a.first_slot = first_slot + done;
+    a.images = d_images ? d_images + (int64_t)done * image_stride : nullptr;
+    // wide tiles (256 B contiguous per row per wave) when the width fills them, else 128x64
+    const int forced = g_forced_tile;
+    const int tw = forced ? forced : ((L->w[0] % 256 == 0 || L->w[0] >= 1024) ? 256 : 128);
+    if (tw == 256) {
+      const dim3 grid((L->w[0] + 255) / 256, (L->h[0] + 31) / 32, chunk);
+      hipLaunchKernelGGL(pyramid_fused_kernel<256>, grid, dim3(256), 0, s, a);
+    } else {
+      const dim3 grid((L->w[0] + 127) / 128, (L->h[0] + 63) / 64, chunk);
+      hipLaunchKernelGGL(pyramid_fused_kernel<128>, grid, dim3(256), 0, s, a);
+    }
+    int rc = check_launch();
+    if (rc) return rc;
+    done += chunk;
+  }
+  // levels beyond the fused ones (pyramids deeper than 5 levels): one launch per level
+  const dim3 block(64, 4, 1);
+  for (int lvl = FUSED_MAX_LEVELS; lvl < L->n_levels; ++lvl) {
+    const int sse2 = flavour(lvl);
+    const int out_w = L->w[lvl], out_h = L->h[lvl];
+    done = 0;
+    while (done < n_slots) {
+      const int chunk = min(n_slots - done, 32768);
+      const dim3 grid(((out_w + 3) / 4 + 63) / 64, (out_h + 3) / 4, chunk);
+      hipLaunchKernelGGL(half_sample_kernel, grid, block, 0, s, d_store, L->slot_bytes, first_slot + done,
+                         L->offset[lvl - 1], L->pitch[lvl - 1], L->offset[lvl], L->pitch[lvl], out_w, out_h, sse2);
+      int rc = check_launch();
+      if (rc) return rc;
+      done += chunk;
+    }
+  }
+  return SVO_HIP_OK;
+}
+
 int svo_hip_pyramid_build(const svo_hip_pyr_layout* L, uint8_t* d_store, int first_slot, int n_slots,
                           int halfsample_mode, void* stream) {
+  if (!layout_ok(L) || !d_store || first_slot < 0 || n_slots < 0) return SVO_HIP_EINVAL;
+  if (halfsample_mode < SVO_HIP_HALFSAMPLE_SCALAR || halfsample_mode > SVO_HIP_HALFSAMPLE_AUTO)
+    return SVO_HIP_EINVAL;
+  return build_impl(L, d_store, first_slot, n_slots, nullptr, 0, 0, halfsample_mode, static_cast<hipStream_t>(stream));
+}
+
+int svo_hip_pyramid_build_from_images(const svo_hip_pyr_layout* L, uint8_t* d_store, int first_slot, int n_slots,
+                                      const uint8_t* d_images, int64_t image_stride, int row_stride,
+                                      int halfsample_mode, void* stream) {
+  if (!layout_ok(L) || !d_store || !d_images || first_slot < 0 || n_slots < 0 || row_stride < L->w[0]) return SVO_HIP_EINVAL;
+  if (halfsample_mode < SVO_HIP_HALFSAMPLE_SCALAR || halfsample_mode > SVO_HIP_HALFSAMPLE_AUTO)
+    return SVO_HIP_EINVAL;
+  return build_impl(L, d_store, first_slot, n_slots, d_images, image_stride, row_stride, halfsample_mode,
+                    static_cast<hipStream_t>(stream));
+}
+
+// the level-by-level builder the fused kernel replaced; kept for A/B timing (bench.py --pyramid-ab)
+int svo_hip_pyramid_build_per_level(const svo_hip_pyr_layout* L, uint8_t* d_store, int first_slot, int n_slots,
+                                    int halfsample_mode, void* stream) {
   if (!layout_ok(L) || !d_store || first_slot < 0 || n_slots < 0) return SVO_HIP_EINVAL;
   if (halfsample_mode < SVO_HIP_HALFSAMPLE_SCALAR || halfsample_mode > SVO_HIP_HALFSAMPLE_AUTO)
     return SVO_HIP_EINVAL;

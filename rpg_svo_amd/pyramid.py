@@ -39,11 +39,18 @@ class PyramidStore:
     def n_levels(self) -> int:
         return self.layout.n_levels
 
-    def load_images(self, images: torch.Tensor, first_slot: int = 0, build: bool = True) -> None:
-        """images: uint8 [n,h,w] on the device (contiguous)."""
+    def load_images(self, images: torch.Tensor, first_slot: int = 0, build: bool = True, fused: bool = True) -> None:
+        """images: uint8 [n,h,w] on the device (contiguous).  fused (default): level 0 and all
+        further levels in one pass (svo_hip_pyramid_build_from_images)."""
         assert images.dtype == torch.uint8 and images.is_cuda and images.is_contiguous()
         n, h, w = images.shape
         assert h == self.layout.h[0] and w == self.layout.w[0] and first_slot + n <= self.n_slots
+        if build and fused:
+            capi.check(self.lib.svo_hip_pyramid_build_from_images(C.byref(self.layout), self.ptr, first_slot, n,
+                                                                  images.data_ptr(), h * w, w, self.halfsample,
+                                                                  _stream_ptr(self.device)),
+                       "svo_hip_pyramid_build_from_images")
+            return
         capi.check(self.lib.svo_hip_pyramid_load_level0(C.byref(self.layout), self.ptr, first_slot, n,
                                                         images.data_ptr(), h * w, w, _stream_ptr(self.device)),
                    "svo_hip_pyramid_load_level0")
@@ -65,6 +72,13 @@ class PyramidStore:
         n = self.n_slots - first_slot if n_slots is None else n_slots
         capi.check(self.lib.svo_hip_pyramid_build(C.byref(self.layout), self.ptr, first_slot, n, self.halfsample,
                                                   _stream_ptr(self.device)), "svo_hip_pyramid_build")
+
+    def build_per_level(self, first_slot: int = 0, n_slots: int | None = None) -> None:
+        """The pre-fusion builder (one launch per level); A/B timing and tests only."""
+        n = self.n_slots - first_slot if n_slots is None else n_slots
+        capi.check(self.lib.svo_hip_pyramid_build_per_level(C.byref(self.layout), self.ptr, first_slot, n,
+                                                            self.halfsample, _stream_ptr(self.device)),
+                   "svo_hip_pyramid_build_per_level")
 
     def level(self, slot: int, level: int) -> np.ndarray:
         out = np.zeros((self.layout.h[level], self.layout.w[level]), dtype=np.uint8)

@@ -1,25 +1,61 @@
-"""K0 parity: GPU pyramid vs oracle vk::halfSample restatement, bit-exact."""
+"""K0 parity: GPU pyramid vs oracle vk::halfSample restatement, bit-exact -- through the fused
+single-pass builder (from packed images and from a level 0 already in the store) and the
+one-launch-per-level builder it replaced."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
+SHAPES = [(640, 480, 4), (752, 480, 5), (1280, 960, 5), (70, 50, 3), (67, 35, 2), (131, 197, 4), (640, 480, 6),
+          (752, 480, 1), (16, 16, 2)]
 
-@pytest.mark.parametrize("w,h,levels", [(640, 480, 4), (752, 480, 5), (1280, 960, 5), (70, 50, 3), (67, 35, 2)])
-@pytest.mark.parametrize("mode", [0, 1, 2])
-def test_pyramid_bit_exact(oracle, gpu_device, w, h, levels, mode):
-    from rpg_svo_amd.pyramid import PyramidStore
-    rng = np.random.default_rng(w * 7 + h + mode)
-    imgs = rng.integers(0, 256, size=(3, h, w), dtype=np.uint8)
-    store = PyramidStore(w, h, levels, 4, device=gpu_device, halfsample=mode)
-    store.load_images(torch.from_numpy(imgs).to(gpu_device), first_slot=1)
-    for i in range(3):
+
+def _check(store, oracle, imgs, levels, mode, first):
+    for i in range(len(imgs)):
         ref = oracle.create_img_pyramid(imgs[i], levels, mode)
         for l in range(levels):
-            got = store.level(1 + i, l)
+            got = store.level(first + i, l)
             assert got.shape == ref[l].shape
             assert np.array_equal(got, ref[l]), f"slot {i} level {l} differs"
+
+
+@pytest.mark.parametrize("w,h,levels", SHAPES)
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("tile", [128, 256])
+def test_pyramid_bit_exact(oracle, gpu_device, hip_lib, w, h, levels, mode, tile):
+    from rpg_svo_amd.pyramid import PyramidStore
+    assert hip_lib.svo_hip_pyramid_set_tile(tile) == 0
+    rng = np.random.default_rng(w * 7 + h + mode)
+    imgs = rng.integers(0, 256, size=(3, h, w), dtype=np.uint8)
+    dimgs = torch.from_numpy(imgs).to(gpu_device)
+    # (a) fused, level 0 filled from the packed images in the same pass
+    store = PyramidStore(w, h, levels, 4, device=gpu_device, halfsample=mode)
+    store.load_images(dimgs, first_slot=1)
+    _check(store, oracle, imgs, levels, mode, 1)
+    # (b) level 0 copied first, fused build from the store
+    store2 = PyramidStore(w, h, levels, 4, device=gpu_device, halfsample=mode)
+    store2.load_images(dimgs, first_slot=0, fused=False)
+    _check(store2, oracle, imgs, levels, mode, 0)
+    # (c) the per-level builder
+    store3 = PyramidStore(w, h, levels, 4, device=gpu_device, halfsample=mode)
+    store3.load_images(dimgs, first_slot=0, build=False)
+    store3.build_per_level(0, 3)
+    _check(store3, oracle, imgs, levels, mode, 0)
+    # padding bytes of the store stay out of the way: slot 3 / slot 0 of (a) untouched
+    assert int(store.buf[: store.layout.slot_bytes].sum().item()) == 0
+    hip_lib.svo_hip_pyramid_set_tile(0)
+
+
+def test_unaligned_source_rows(oracle, gpu_device):
+    """Packed source whose rows are not 16-byte aligned (width 67): the fused loader takes the
+    byte path and still fills level 0 and the levels above it exactly."""
+    from rpg_svo_amd.pyramid import PyramidStore
+    rng = np.random.default_rng(9)
+    imgs = rng.integers(0, 256, size=(5, 45, 67), dtype=np.uint8)
+    store = PyramidStore(67, 45, 3, 5, device=gpu_device)
+    store.load_images(torch.from_numpy(imgs).to(gpu_device))
+    _check(store, oracle, imgs, 3, oracle.HALFSAMPLE_AUTO, 0)
 
 
 def test_upload_path_matches_load_path(oracle, gpu_device):
