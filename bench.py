@@ -282,7 +282,7 @@ def pyramid_roofline(lib, store, images, stream, reps: int = 5) -> dict:
         return float(np.mean(ms[1:]))
 
     tiles = {}
-    for tw in (128, 256):
+    for tw in (128, 256, 257, 512):
         lib.svo_hip_pyramid_set_tile(tw)
         tiles[str(tw)] = timed(lambda: store.load_images(images, 0))
     lib.svo_hip_pyramid_set_tile(0)

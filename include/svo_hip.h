@@ -6,7 +6,8 @@
  * called by svo::FrameHandlerMono::processFrame (svo/src/frame_handler_mono.cpp
  * :129-235).  Each entry point below replaces the arithmetic behind one of
  * those methods; the API-compatible host classes that marshal into these calls
- * live in rpg_svo_amd/host/ (C++) and the rpg_svo_amd Python modules (mirror).
+ * live in rpg_svo_amd/host/ (C++: svo_hip_device + dropin/*.cpp, bodies for the
+ * reference's own classes) and the rpg_svo_amd Python modules (batched mirror).
  *
  * Conventions
  *  - every function returns 0 on success or a negative SVO_HIP_E* code;
@@ -107,8 +108,8 @@ int svo_hip_pyramid_build(const svo_hip_pyr_layout* layout, uint8_t* d_store, in
 int svo_hip_pyramid_build_from_images(const svo_hip_pyr_layout* layout, uint8_t* d_store, int first_slot,
                                       int n_slots, const uint8_t* d_images, int64_t image_stride,
                                       int row_stride, int halfsample_mode, void* stream);
-/* Tuning knob: level-0 tile of the fused builder, 128 (x64 rows) or 256 (x32 rows); 0 = choose
- * by image width (the default).  Results do not depend on it. */
+/* Tuning knob: level-0 tile of the fused builder: 128 (128x64), 256 (256x32) or 512 (256x64, two
+ * row blocks per lane); 0 = choose by image size (the default).  Results do not depend on it. */
 int svo_hip_pyramid_set_tile(int tile_width);
 /* The one-launch-per-level builder svo_hip_pyramid_build used before the fused kernel; same
  * results, kept for A/B timing. */

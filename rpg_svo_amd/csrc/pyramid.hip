@@ -95,41 +95,76 @@ __device__ __forceinline__ uint4 load16(const uint8_t* src, int x0, int w, bool 
   return v;
 }
 
-// TW x TH level-0 pixels per workgroup, TW*TH = 8192 (256 lanes x 32 px): 128x64 or 256x32
-template <int TW>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ntload16(const uint8_t* p) {
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void ntstore16(uint8_t* p, uint4 v) {
+  u32x4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
+}
+
+// Level-0 tile per workgroup: TW x THT pixels, THT = NS * 8192 / TW; each of the 256 lanes owns
+// NS blocks of 16 px x 2 rows (all 2*NS dwordx4 loads are issued before anything is consumed,
+// so a lane keeps 32*NS bytes in flight).  <128,1> = 128x64, <256,1> = 256x32, <256,2> = 256x64.
+template <int TW, int NS, bool NT = false>
 __global__ void __launch_bounds__(256) pyramid_fused_kernel(const FusedArgs a) {
-  constexpr int TH = 8192 / TW;
+  constexpr int TH = 8192 / TW;          // rows covered by one sub-tile
+  constexpr int THT = NS * TH;
   constexpr int WX = TW / 16;            // lanes across the tile
   constexpr int W1 = TW / 2, W2 = TW / 4, W3 = TW / 8;
-  __shared__ uint8_t l1[(TH / 2) * W1];
-  __shared__ uint8_t l2[(TH / 4) * W2];
-  __shared__ uint8_t l3[(TH / 8) * W3];
+  constexpr int N2 = (THT / 4) * (W2 / 4), N3 = (THT / 8) * (W3 / 4), N4 = (THT / 16) * (TW / 64);
+  static_assert(N2 <= 256, "tile too large");
+  __shared__ uint8_t l1[(THT / 2) * W1];
+  __shared__ uint8_t l2[(THT / 4) * W2];
+  __shared__ uint8_t l3[(THT / 8) * W3];
   const int tid = threadIdx.x;
   const int tx = tid % WX, ty = tid / WX;
   uint8_t* slot = a.store + (int64_t)(a.first_slot + blockIdx.z) * a.slot_bytes;
   const int x0 = blockIdx.x * TW + tx * 16;
-  const int y0 = blockIdx.y * TH + ty * 2;
-  uint4 top = make_uint4(0, 0, 0, 0), bot = top;
-  if (a.images) {  // fill level 0 on the way
-    const uint8_t* img = a.images + (int64_t)blockIdx.z * a.image_stride;
-    const bool al = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)a.row_stride) & 15) == 0;
-    if (y0 < a.h[0]) top = load16(img + (int64_t)y0 * a.row_stride + x0, x0, a.w[0], al);
-    if (y0 + 1 < a.h[0]) bot = load16(img + (int64_t)(y0 + 1) * a.row_stride + x0, x0, a.w[0], al);
-    // rows of the store are 64-byte aligned and padded: whole 16-byte stores are in bounds
-    if (x0 < a.w[0]) {
-      if (y0 < a.h[0]) *reinterpret_cast<uint4*>(slot + (int64_t)y0 * a.pitch[0] + x0) = top;
-      if (y0 + 1 < a.h[0]) *reinterpret_cast<uint4*>(slot + (int64_t)(y0 + 1) * a.pitch[0] + x0) = bot;
+  uint4 top[NS], bot[NS];
+  const uint8_t* img = a.images ? a.images + (int64_t)blockIdx.z * a.image_stride : nullptr;
+  const bool al = img && ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)a.row_stride) & 15) == 0;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int y0 = blockIdx.y * THT + s * TH + ty * 2;
+    top[s] = make_uint4(0, 0, 0, 0);
+    bot[s] = top[s];
+    if (img) {
+      if (NT && al && x0 + 16 <= a.w[0]) {  // streaming source: read once, never again
+        if (y0 < a.h[0]) top[s] = ntload16(img + (int64_t)y0 * a.row_stride + x0);
+        if (y0 + 1 < a.h[0]) bot[s] = ntload16(img + (int64_t)(y0 + 1) * a.row_stride + x0);
+      } else {
+        if (y0 < a.h[0]) top[s] = load16(img + (int64_t)y0 * a.row_stride + x0, x0, a.w[0], al);
+        if (y0 + 1 < a.h[0]) bot[s] = load16(img + (int64_t)(y0 + 1) * a.row_stride + x0, x0, a.w[0], al);
+      }
+    } else if (x0 < a.w[0]) {
+      if (y0 < a.h[0]) top[s] = *reinterpret_cast<const uint4*>(slot + (int64_t)y0 * a.pitch[0] + x0);
+      if (y0 + 1 < a.h[0]) bot[s] = *reinterpret_cast<const uint4*>(slot + (int64_t)(y0 + 1) * a.pitch[0] + x0);
     }
-  } else if (x0 < a.w[0]) {
-    if (y0 < a.h[0]) top = *reinterpret_cast<const uint4*>(slot + (int64_t)y0 * a.pitch[0] + x0);
-    if (y0 + 1 < a.h[0]) bot = *reinterpret_cast<const uint4*>(slot + (int64_t)(y0 + 1) * a.pitch[0] + x0);
+  }
+  if (img && x0 < a.w[0]) {  // fill level 0 on the way; rows of the store are padded to 64 B
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int y0 = blockIdx.y * THT + s * TH + ty * 2;
+      if (NT) {
+        if (y0 < a.h[0]) ntstore16(slot + (int64_t)y0 * a.pitch[0] + x0, top[s]);
+        if (y0 + 1 < a.h[0]) ntstore16(slot + (int64_t)(y0 + 1) * a.pitch[0] + x0, bot[s]);
+      } else {
+        if (y0 < a.h[0]) *reinterpret_cast<uint4*>(slot + (int64_t)y0 * a.pitch[0] + x0) = top[s];
+        if (y0 + 1 < a.h[0]) *reinterpret_cast<uint4*>(slot + (int64_t)(y0 + 1) * a.pitch[0] + x0) = bot[s];
+      }
+    }
   }
   if (a.n_levels < 2) return;
-  {  // level 1: 8 px per lane
-    const uint32_t lo = half4(make_uint2(top.x, top.y), make_uint2(bot.x, bot.y), a.sse2[1] != 0);
-    const uint32_t hi = half4(make_uint2(top.z, top.w), make_uint2(bot.z, bot.w), a.sse2[1] != 0);
-    *reinterpret_cast<uint2*>(&l1[ty * W1 + tx * 8]) = make_uint2(lo, hi);
-    const int ox = blockIdx.x * W1 + tx * 8, oy = blockIdx.y * (TH / 2) + ty;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {  // level 1: 8 px per lane and sub-tile
+    const uint32_t lo = half4(make_uint2(top[s].x, top[s].y), make_uint2(bot[s].x, bot[s].y), a.sse2[1] != 0);
+    const uint32_t hi = half4(make_uint2(top[s].z, top[s].w), make_uint2(bot[s].z, bot[s].w), a.sse2[1] != 0);
+    const int r1 = s * (TH / 2) + ty;
+    *reinterpret_cast<uint2*>(&l1[r1 * W1 + tx * 8]) = make_uint2(lo, hi);
+    const int ox = blockIdx.x * W1 + tx * 8, oy = blockIdx.y * (THT / 2) + r1;
     if (oy < a.h[1] && ox < a.w[1]) {
       uint8_t* dst = slot + a.off[1] + (int64_t)oy * a.pitch[1] + ox;
       if (ox + 8 <= a.w[1]) {
@@ -142,34 +177,34 @@ __global__ void __launch_bounds__(256) pyramid_fused_kernel(const FusedArgs a) {
   }
   if (a.n_levels < 3) return;
   __syncthreads();
-  if (tid < 128) {  // level 2: W2 x TH/4 px, 4 px per lane
-    const int r = tid / WX, c = tid % WX;
+  if (tid < N2) {  // level 2: 4 px per lane
+    const int r = tid / (W2 / 4), c = tid % (W2 / 4);
     const uint2 t = *reinterpret_cast<const uint2*>(&l1[(2 * r) * W1 + c * 8]);
     const uint2 b = *reinterpret_cast<const uint2*>(&l1[(2 * r + 1) * W1 + c * 8]);
     const uint32_t v = half4(t, b, a.sse2[2] != 0);
     *reinterpret_cast<uint32_t*>(&l2[r * W2 + c * 4]) = v;
-    const int ox = blockIdx.x * W2 + c * 4, oy = blockIdx.y * (TH / 4) + r;
+    const int ox = blockIdx.x * W2 + c * 4, oy = blockIdx.y * (THT / 4) + r;
     if (oy < a.h[2] && ox < a.w[2]) store4(slot + a.off[2] + (int64_t)oy * a.pitch[2] + ox, v, ox, a.w[2]);
   }
   if (a.n_levels < 4) return;
   __syncthreads();
-  if (tid < 32) {  // level 3
-    const int r = tid / (WX / 2), c = tid % (WX / 2);
+  if (tid < N3) {  // level 3
+    const int r = tid / (W3 / 4), c = tid % (W3 / 4);
     const uint2 t = *reinterpret_cast<const uint2*>(&l2[(2 * r) * W2 + c * 8]);
     const uint2 b = *reinterpret_cast<const uint2*>(&l2[(2 * r + 1) * W2 + c * 8]);
     const uint32_t v = half4(t, b, a.sse2[3] != 0);
     *reinterpret_cast<uint32_t*>(&l3[r * W3 + c * 4]) = v;
-    const int ox = blockIdx.x * W3 + c * 4, oy = blockIdx.y * (TH / 8) + r;
+    const int ox = blockIdx.x * W3 + c * 4, oy = blockIdx.y * (THT / 8) + r;
     if (oy < a.h[3] && ox < a.w[3]) store4(slot + a.off[3] + (int64_t)oy * a.pitch[3] + ox, v, ox, a.w[3]);
   }
   if (a.n_levels < 5) return;
   __syncthreads();
-  if (tid < 8) {  // level 4
-    const int r = tid / (WX / 4), c = tid % (WX / 4);
+  if (tid < N4) {  // level 4
+    const int r = tid / (TW / 64), c = tid % (TW / 64);
     const uint2 t = *reinterpret_cast<const uint2*>(&l3[(2 * r) * W3 + c * 8]);
     const uint2 b = *reinterpret_cast<const uint2*>(&l3[(2 * r + 1) * W3 + c * 8]);
     const uint32_t v = half4(t, b, a.sse2[4] != 0);
-    const int ox = blockIdx.x * (TW / 16) + c * 4, oy = blockIdx.y * (TH / 16) + r;
+    const int ox = blockIdx.x * (TW / 16) + c * 4, oy = blockIdx.y * (THT / 16) + r;
     if (oy < a.h[4] && ox < a.w[4]) store4(slot + a.off[4] + (int64_t)oy * a.pitch[4] + ox, v, ox, a.w[4]);
   }
 }
@@ -227,7 +262,7 @@ int svo_hip_pyramid_upload_level0(const svo_hip_pyr_layout* L, uint8_t* d_store,
 static int g_forced_tile = 0;
 
 int svo_hip_pyramid_set_tile(int tile_width) {
-  if (tile_width != 0 && tile_width != 128 && tile_width != 256) return SVO_HIP_EINVAL;
+  if (tile_width != 0 && tile_width != 128 && tile_width != 256 && tile_width != 257 && tile_width != 512) return SVO_HIP_EINVAL;
   g_forced_tile = tile_width;
   return SVO_HIP_OK;
 }
@@ -254,15 +289,21 @@ static int build_impl(const svo_hip_pyr_layout* L, uint8_t* d_store, int first_s
     const int chunk = min(n_slots - done, 32768);
     a.first_slot = first_slot + done;
     a.images = d_images ? d_images + (int64_t)done * image_stride : nullptr;
-    // wide tiles (256 B contiguous per row per wave) when the width fills them, else 128x64
+    // tile selection: 0 = by image size; 128 -> 128x64, 256 -> 256x32, 512 -> 256x64 (two blocks per lane)
     const int forced = g_forced_tile;
-    const int tw = forced ? forced : ((L->w[0] % 256 == 0 || L->w[0] >= 1024) ? 256 : 128);
-    if (tw == 256) {
+    const int tw = forced ? forced : (L->w[0] >= 256 ? 256 : 128);
+    if (tw == 512) {
+      const dim3 grid((L->w[0] + 255) / 256, (L->h[0] + 63) / 64, chunk);
+      hipLaunchKernelGGL((pyramid_fused_kernel<256, 2>), grid, dim3(256), 0, s, a);
+    } else if (tw == 257) {  // experimental: non-temporal source loads / level-0 stores
       const dim3 grid((L->w[0] + 255) / 256, (L->h[0] + 31) / 32, chunk);
-      hipLaunchKernelGGL(pyramid_fused_kernel<256>, grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((pyramid_fused_kernel<256, 1, true>), grid, dim3(256), 0, s, a);
+    } else if (tw == 256) {
+      const dim3 grid((L->w[0] + 255) / 256, (L->h[0] + 31) / 32, chunk);
+      hipLaunchKernelGGL((pyramid_fused_kernel<256, 1>), grid, dim3(256), 0, s, a);
     } else {
       const dim3 grid((L->w[0] + 127) / 128, (L->h[0] + 63) / 64, chunk);
-      hipLaunchKernelGGL(pyramid_fused_kernel<128>, grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((pyramid_fused_kernel<128, 1>), grid, dim3(256), 0, s, a);
     }
     int rc = check_launch();
     if (rc) return rc;

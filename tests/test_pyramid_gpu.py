@@ -22,7 +22,7 @@ def _check(store, oracle, imgs, levels, mode, first):
 
 @pytest.mark.parametrize("w,h,levels", SHAPES)
 @pytest.mark.parametrize("mode", [0, 1, 2])
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [128, 256, 257, 512])
 def test_pyramid_bit_exact(oracle, gpu_device, hip_lib, w, h, levels, mode, tile):
     from rpg_svo_amd.pyramid import PyramidStore
     assert hip_lib.svo_hip_pyramid_set_tile(tile) == 0
