@@ -6,7 +6,7 @@
  * called by svo::FrameHandlerMono::processFrame (svo/src/frame_handler_mono.cpp
  * :129-235).  Each entry point below replaces the arithmetic behind one of
  * those methods; the API-compatible host classes that marshal into these calls
- * live in rpg_svo_amd/host/ (C++: svo_hip_device + dropin/*.cpp, bodies for the
+ * live in rpg_svo_amd/host/ (C++: svo_hip_device + the dropin/ sources, bodies for the
  * reference's own classes) and the rpg_svo_amd Python modules (batched mirror).
  *
  * Conventions
@@ -108,8 +108,9 @@ int svo_hip_pyramid_build(const svo_hip_pyr_layout* layout, uint8_t* d_store, in
 int svo_hip_pyramid_build_from_images(const svo_hip_pyr_layout* layout, uint8_t* d_store, int first_slot,
                                       int n_slots, const uint8_t* d_images, int64_t image_stride,
                                       int row_stride, int halfsample_mode, void* stream);
-/* Tuning knob: level-0 tile of the fused builder: 128 (128x64), 256 (256x32) or 512 (256x64, two
- * row blocks per lane); 0 = choose by image size (the default).  Results do not depend on it. */
+/* Tuning knob: level-0 tile of the fused builder: 128 (128x64), 256 (256x32), 257 (256x32 with
+ * non-temporal level-0 traffic) or 512 (256x64, two row blocks per lane); 0 = choose by image
+ * size (the default: 257 for widths >= 256).  Results do not depend on it. */
 int svo_hip_pyramid_set_tile(int tile_width);
 /* The one-launch-per-level builder svo_hip_pyramid_build used before the fused kernel; same
  * results, kept for A/B timing. */
@@ -336,6 +337,26 @@ int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint8_t* d_stor
 /* DepthFilter::updateSeed(x, tau2, seed) for S independent (x, tau2) measurements */
 int svo_hip_update_seed_batch(int S, const float* d_x, const float* d_tau2,
                               const svo_hip_seeds* seeds, void* stream);
+
+/* ---- K7: seed initialisation --------------------------------------------- */
+/*
+ * Batched feature_detection::FastDetector::detect (svo/src/feature_detection.cpp:66-114) on the
+ * pyramids of n_frames store slots: FAST-10 (threshold fast_threshold = 20 in the reference),
+ * FAST score, 3x3 non-max, Shi-Tomasi score, best corner per grid cell over levels
+ * 0..n_levels-1 (Config::nPyrLevels()).
+ *   d_occupancy [n_frames][cells]  AbstractDetector::grid_occupancy_ (setExistingFeatures /
+ *                                  setGridOccpuancy); NULL = all free
+ *   detection_threshold            Config::triangMinCornerScore()
+ *   d_corner_xy [n_frames][cells][2]  Corner::x, y (level-0 pixels); -1 where the cell stays empty
+ *   d_corner_level / d_corner_score   Corner::level / score (score == threshold where empty)
+ * A Feature is created for every cell with score > detection_threshold, in cell order (:107-110).
+ */
+size_t svo_hip_fast_workspace_bytes(const svo_hip_pyr_layout* layout, int n_frames, int n_cells);
+int svo_hip_fast_detect(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int n_frames,
+                        const int32_t* d_slot, int n_levels, int fast_threshold, int cell_size,
+                        int grid_n_cols, int grid_n_rows, const uint8_t* d_occupancy,
+                        double detection_threshold, int32_t* d_corner_xy, int32_t* d_corner_level,
+                        float* d_corner_score, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* static DepthFilter::computeTau(T_ref_cur, f, z, px_error_angle) (depth_filter.cpp:334-350) for S
  * independent measurements: d_t_ref_cur [S][3] = T_ref_cur.translation(), d_f [S][3], d_z [S]. */

@@ -106,7 +106,9 @@ static inline float orc_shi_tomasi_score(const uint8_t* data, int cols, int rows
   dXX = dXX / (2.0 * box_area);
   dYY = dYY / (2.0 * box_area);
   dXY = dXY / (2.0 * box_area);
-  return 0.5 * (dXX + dYY - sqrt((dXX + dYY) * (dXX + dYY) - 4 * (dXX * dYY - dXY * dXY)));
+  /* vikit is C++: sqrt(float) resolves to the float overload; written out so that C and C++
+   * translation units agree */
+  return 0.5 * (dXX + dYY - sqrtf((dXX + dYY) * (dXX + dYY) - 4 * (dXX * dYY - dXY * dXY)));
 }
 
 #endif /* ORC_FAST_H_ */

@@ -282,6 +282,36 @@ class Track:
         return int(k), px
 
 
+def fast_detect_grid(pyr_levels, n_levels, cell_size, cols, rows, occupancy=None, fast_threshold=20,
+                     detection_threshold=20.0):
+    """C restatement of FastDetector::detect: (xy [cells,2], level [cells], score [cells], n_features)."""
+    lib = pyoracle.lib()
+    ps = make_pyramid_struct(pyr_levels)
+    n_cells = cols * rows
+    xy = np.zeros((n_cells, 2), dtype=np.int32)
+    lvl = np.zeros(n_cells, dtype=np.int32)
+    sc = np.zeros(n_cells, dtype=np.float32)
+    occ = None if occupancy is None else np.ascontiguousarray(occupancy, dtype=np.uint8)
+    n = lib.orc_fast_detect_grid(C.byref(ps), C.c_int(n_levels), C.c_int(fast_threshold), C.c_int(cell_size), C.c_int(cols),
+                                 C.c_int(rows), _p(occ) if occ is not None else None, C.c_double(detection_threshold),
+                                 _p(xy), _p(lvl), _p(sc))
+    return xy, lvl, sc, n
+
+
+def ref_fast_detect(pyr_levels, cam, n_levels, cell_size, occupancy=None, detection_threshold=20.0, max_out=4096):
+    """The reference's own FastDetector::detect (oracle/_ref): (px [n,2], level [n]) in emission order."""
+    lib = C.CDLL(REF_LIB_PATH)
+    ps = make_pyramid_struct(pyr_levels)
+    pc = make_cam(cam)
+    px = np.zeros((max_out, 2))
+    lvl = np.zeros(max_out, dtype=np.int32)
+    occ = None if occupancy is None else np.ascontiguousarray(occupancy, dtype=np.uint8)
+    n = lib.ref_fast_detect(C.byref(ps), C.byref(pc), C.c_int(n_levels), C.c_int(cell_size),
+                            _p(occ) if occ is not None else None, C.c_double(detection_threshold), C.c_int(max_out),
+                            _p(px), _p(lvl))
+    return px[:n], lvl[:n]
+
+
 def _match_dict(r: MatchResult) -> dict:
     return dict(success=r.success, ref_obs=r.ref_obs, search_level=r.search_level, reject=r.reject,
                 A_cur_ref=np.array(r.A_cur_ref[:]).reshape(2, 2), px_cur=np.array(r.px_cur[:]), h_inv=r.h_inv,

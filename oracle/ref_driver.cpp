@@ -561,6 +561,34 @@ int ref_update_seeds(const orc_frame* frames, const orc_pinhole* cam, int cur_fr
   return n_updates;
 }
 
+// The reference's own FastDetector::detect (feature_detection.cpp:66-114) on the shimmed FAST
+// library: features in the order the detector emits them (cell order).  Returns their count.
+int ref_fast_detect(const orc_pyramid* pyr, const orc_pinhole* cam, int n_levels, int cell_size, const uint8_t* occupancy,
+                    double detection_threshold, int max_out, double* px_out, int32_t* level_out) {
+  vk::PinholeCamera* c = make_cam(cam);
+  const double T0[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+  FramePtr frame = make_frame(c, pyr, T0);
+  feature_detection::FastDetector det(cam->width, cam->height, cell_size, n_levels);
+  const int cols = (cam->width + cell_size - 1) / cell_size, rows = (cam->height + cell_size - 1) / cell_size;
+  if (occupancy)
+    for (int k = 0; k < cols * rows; ++k)
+      if (occupancy[k]) det.setGridOccpuancy(Vector2d((k % cols) * cell_size + 0.5, (k / cols) * cell_size + 0.5));
+  Features fts;
+  det.detect(frame.get(), frame->img_pyr_, detection_threshold, fts);
+  int n = 0;
+  for (Features::iterator it = fts.begin(); it != fts.end(); ++it) {
+    if (n < max_out) {
+      px_out[2 * n] = (*it)->px[0]; px_out[2 * n + 1] = (*it)->px[1];
+      level_out[n] = (*it)->level;
+    }
+    ++n;
+    delete *it;
+  }
+  frame.reset();
+  delete c;
+  return n;
+}
+
 int ref_reproject_point(const orc_pinhole* cam, const double T_f_w[12], const double pos[3], int cell_size,
                         int grid_n_cols, double px_out[2]) {
   // Reprojector::reprojectPoint is private; its three statements are frame->w2c(),

