@@ -52,6 +52,7 @@ typedef struct pipe_config {
   int32_t n_pyr_levels, klt_max_level, klt_min_level, grid_size, max_fts, max_n_kfs;
   int32_t quality_min_fts, quality_max_drop_fts, structureoptim_max_pts, structureoptim_num_iter;
   int32_t poseoptim_num_iter, shuffle_seed;
+  int32_t mapper_thread, reserved;  // 1: keep DepthFilter's own thread running (asynchronous mapping)
   double kfselect_mindist, poseoptim_thresh, triang_min_corner_score;
 } pipe_config;
 
@@ -72,7 +73,7 @@ struct Pipe {
 void pipe_config_default(pipe_config* c) {
   c->n_pyr_levels = 3; c->klt_max_level = 4; c->klt_min_level = 2; c->grid_size = 30; c->max_fts = 120;
   c->max_n_kfs = 10; c->quality_min_fts = 50; c->quality_max_drop_fts = 40; c->structureoptim_max_pts = 20;
-  c->structureoptim_num_iter = 5; c->poseoptim_num_iter = 10; c->shuffle_seed = 1;
+  c->structureoptim_num_iter = 5; c->poseoptim_num_iter = 10; c->shuffle_seed = 1; c->mapper_thread = 0; c->reserved = 0;
   c->kfselect_mindist = 0.12; c->poseoptim_thresh = 2.0; c->triang_min_corner_score = 20.0;
 }
 
@@ -98,7 +99,7 @@ void* pipe_create(int width, int height, double fx, double fy, double cx, double
   p->vo->start();
   // run the mapper synchronously inside addFrame()/addKeyframe() (depth_filter.cpp:82-107):
   // deterministic interleaving of tracking and mapping for both libraries
-  p->vo->depthFilter()->stopThread();
+  if (!c->mapper_thread) p->vo->depthFilter()->stopThread();
   return p;
 }
 

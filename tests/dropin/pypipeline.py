@@ -17,7 +17,7 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_pyr_levels", "klt_max_level", "klt_min_level", "grid_size", "max_fts",
                                          "max_n_kfs", "quality_min_fts", "quality_max_drop_fts",
                                          "structureoptim_max_pts", "structureoptim_num_iter", "poseoptim_num_iter",
-                                         "shuffle_seed")] + \
+                                         "shuffle_seed", "mapper_thread", "reserved")] + \
                [(n, C.c_double) for n in ("kfselect_mindist", "poseoptim_thresh", "triang_min_corner_score")]
 
 

@@ -111,3 +111,18 @@ def test_dropin_second_sequence_with_noise(pipeline_libs, gpu_device):
     print(f"noisy sequence: SE3 log-norm max {d.max():.3e} median {np.median(d):.3e}")
     assert d.max() <= SE3_LOGNORM_TOL
     assert [r["is_keyframe"] for r in ref] == [r["is_keyframe"] for r in hip]
+
+
+@pytest.mark.gpu
+def test_dropin_with_asynchronous_mapper_thread(pipeline_libs, gpu_device):
+    """DepthFilter's own thread left running (the reference's normal mode): tracking lane and
+    mapping lane of svo_hip::Device work concurrently.  Interleaving is timing dependent -- as in
+    the reference -- so the check is against ground truth, not frame-by-frame equality."""
+    cam, imgs, T = _sequence(120)
+    for _ in range(2):
+        hip = pp.run_sequence("hip", cam, imgs, T, mapper_thread=1)
+        est = np.stack([r["T_f_w"] for r in hip])
+        assert all(r["stage"] == pp.STAGE_DEFAULT_FRAME for r in hip)
+        assert se3.log_norm(est, T).max() < 5e-3
+        assert sum(r["is_keyframe"] for r in hip) >= 3
+        assert max(r["n_candidates"] for r in hip) > 50
