@@ -93,8 +93,38 @@ __device__ __forceinline__ void load_row7(const uint8_t* __restrict__ row, int x
   out[6] = (float)((hi >> 16) & 0xffu);
 }
 
+// ---- window cache (template parameter WC) --------------------------------------------------------------
+// The 5x5 window of the current image moves by a fraction of a pixel per Gauss-Newton iteration,
+// yet re-fetching it every iteration misses L2 (128 resident problems per XCD x ~64 KB of touched
+// sectors) and puts an HBM round trip on the critical path of every iteration.  With the cache a
+// lane fetches 7 rows x 3 aligned dwords around the patch (49+ bytes, once) and later iterations
+// cut their 5x5 window out of those 21 registers as long as the integer position stays within
+// +-1 row and the 12 cached columns; only then is nothing loaded at all.
+__device__ __forceinline__ void load_row12(const uint8_t* __restrict__ row, int xa, uint32_t d[3]) {
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(row + xa);
+  d[0] = p[0]; d[1] = p[1]; d[2] = p[2];
+}
+// bytes [bo, bo+4] (bo in 0..7) of three consecutive dwords as floats
+__device__ __forceinline__ void cut_row5(uint32_t a, uint32_t b, uint32_t c, int bo, float out[5]) {
+  const bool up = bo >= 4;
+  const uint32_t d0 = up ? b : a, d1 = up ? c : b;
+  const uint32_t sel = (uint32_t)(bo & 3);
+  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sel);
+  const uint32_t hi = d1 >> (8 * sel);
+  out[0] = (float)(lo & 0xffu);
+  out[1] = (float)((lo >> 8) & 0xffu);
+  out[2] = (float)((lo >> 16) & 0xffu);
+  out[3] = (float)(lo >> 24);
+  out[4] = (float)(hi & 0xffu);
+}
+
+// Waves per SIMD asked of the register allocator.  Without the window cache the kernel fits 128
+// VGPRs (4 waves/SIMD); asking for 4 outright makes the allocator spill 3 dwords to scratch
+// (-9 % measured), asking for 3 yields the same 128 registers without spills.  With the window
+// cache (+21 registers) it settles at 168 VGPRs = 3 waves/SIMD, still faster for 256/512-lane
+// workgroups; a 1024-lane workgroup needs 4 waves per SIMD just to be resident.
 #ifndef MINW
-#define MINW 4  // waves per SIMD asked of the register allocator (4 x 256-lane workgroups per CU)
+#define MINW(BLOCK) ((BLOCK) >= 1024 ? 4 : 3)
 #endif
 
 constexpr int MAX_WAVES = SVO_HIP_MAX_PATCHES / 64;
@@ -165,8 +195,8 @@ __device__ __forceinline__ void sia_rebuild_hinv(int lane, int nw) {
   }
 }
 
-template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK, MINW) sia_kernel(const SiaArgs a) {
+template <int BLOCK, bool WC>
+__global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a) {
   constexpr int NW = BLOCK / 64;
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -325,6 +355,12 @@ __global__ void __launch_bounds__(BLOCK, MINW) sia_kernel(const SiaArgs a) {
     // ---- vk::NLLSSolver::optimizeGaussNewton ------------------------------
     int inH = -1;  // membership of this lane in the sum that g_s.H currently holds
     int evals = 0;
+    uint32_t wc[WC ? 7 : 1][3];
+    int wc_u0 = 0, wc_v0 = -100000;  // cached columns [wc_u0, wc_u0+11], rows [wc_v0, wc_v0+6]
+    if (WC) {
+#pragma unroll
+      for (int r = 0; r < (WC ? 7 : 1); ++r) wc[r][0] = wc[r][1] = wc[r][2] = 0u;
+    }
     for (int iter = 0; iter < P.n_iter; ++iter) {
       // -- computeResiduals (:147-243): this lane's patch -------------------
       bool m = false;
@@ -350,12 +386,35 @@ __global__ void __launch_bounds__(BLOCK, MINW) sia_kernel(const SiaArgs a) {
           const float wbl = (float)((1.0 - su) * sv);
           const float wbr = (float)((double)su * (double)sv);
           float W[5][5];
-#pragma unroll
 #ifdef SIA_DBG_NOLOAD
+#pragma unroll
           for (int r = 0; r < 5; ++r)
             for (int c = 0; c < 5; ++c) W[r][c] = su * (float)(r * 5 + c);
 #else
-          for (int r = 0; r < 5; ++r) load_row5(cur_img + (int64_t)(v_i - 2 + r) * pitch, u_i - 2, W[r]);
+          if (WC) {
+            int r0 = (v_i - 2) - wc_v0;  // first cached row needed
+            int bo = (u_i - 2) - wc_u0;  // first cached byte needed
+            if (!(r0 >= 0 && r0 <= 2 && bo >= 0 && bo <= 7)) {
+              wc_v0 = v_i - 3;
+              wc_u0 = (u_i - 3) & ~3;
+              const uint8_t* base = cur_img + (int64_t)wc_v0 * pitch;
+#pragma unroll
+              for (int r = 0; r < (WC ? 7 : 1); ++r) load_row12(base + (int64_t)r * pitch, wc_u0, wc[r]);
+              r0 = 1;
+              bo = (u_i - 2) - wc_u0;
+            }
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+              constexpr int S = WC ? 1 : 0;  // keeps the indices in range when the cache is compiled out
+              const uint32_t d0 = r0 == 0 ? wc[r * S][0] : (r0 == 1 ? wc[(r + 1) * S][0] : wc[(r + 2) * S][0]);
+              const uint32_t d1 = r0 == 0 ? wc[r * S][1] : (r0 == 1 ? wc[(r + 1) * S][1] : wc[(r + 2) * S][1]);
+              const uint32_t d2 = r0 == 0 ? wc[r * S][2] : (r0 == 1 ? wc[(r + 1) * S][2] : wc[(r + 2) * S][2]);
+              cut_row5(d0, d1, d2, bo, W[r]);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) load_row5(cur_img + (int64_t)(v_i - 2 + r) * pitch, u_i - 2, W[r]);
+          }
 #endif
           float Bt[6][6];
           {
@@ -525,7 +584,9 @@ __global__ void __launch_bounds__(BLOCK, MINW) sia_kernel(const SiaArgs a) {
 
 template <int BLOCK>
 int launch(const SiaArgs& args, int B, hipStream_t s) {
-  hipLaunchKernelGGL(sia_kernel<BLOCK>, dim3(B), dim3(BLOCK), 0, s, args);
+  // window cache where the workgroup is large enough for the extra registers to pay (see MINW)
+  constexpr bool WC = (BLOCK == 256);  // 512 lanes: 168 VGPRs would leave one workgroup per CU
+  hipLaunchKernelGGL((sia_kernel<BLOCK, WC>), dim3(B), dim3(BLOCK), 0, s, args);
   return check_launch();
 }
 
