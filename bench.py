@@ -293,9 +293,16 @@ def pyramid_roofline(lib, store, images, stream, reps: int = 5) -> dict:
         store.build_per_level(0, n)
     unfused = timed(per_level)
     gbs = n * per_frame / (fused * 1e-3) / 1e9
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        traffic = tj.get(f"k0_pyramid:vga4:B{n}") if (images.shape[1], images.shape[2]) == (480, 640) else None
+    except Exception:
+        pass
     return {"kernel": "pyramid_fused_kernel (svo_hip_pyramid_build_from_images)", "frames": int(n),
             "ms": fused, "frames_per_s": n / (fused * 1e-3), "algorithmic_bytes_per_frame": int(per_frame),
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": traffic, "algorithmic_bytes_per_launch": int(n * per_frame),
             "ms_level0_copy_plus_one_launch_per_level": unfused, "ms_by_tile_width": tiles}
 
 

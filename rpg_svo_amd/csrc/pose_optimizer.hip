@@ -21,6 +21,10 @@ using namespace svo_dev;
 
 namespace {
 
+#ifndef PO_MINW
+#define PO_MINW 4
+#endif
+constexpr int PO_HALF = 32;
 constexpr int PO_BLOCK = 64;  // one wave per frame: the serial parts dominate, occupancy comes from many small workgroups
 constexpr int PO_MAXN = 1024;
 constexpr double SVO_EPS = 0.0000000001;  // svo/include/svo/global.h:77
@@ -42,7 +46,7 @@ struct PoseArgs {
 };
 
 struct PoseLds {
-  double tile[28][PO_BLOCK];
+  double tile[28][PO_HALF];  // half a chunk at a time: 7 KB instead of 14 KB per frame doubles the frames per CU
   unsigned long long live[PO_BLOCK / 64];  // which lanes of the current chunk contributed
   double acc[28];
   Se3 T, T_old;
@@ -93,7 +97,7 @@ struct PoseDyn {
   uint8_t* hp;
 };
 
-__global__ void __launch_bounds__(PO_BLOCK) pose_opt_kernel(const PoseArgs a) {
+__global__ void __launch_bounds__(PO_BLOCK, PO_MINW) pose_opt_kernel(const PoseArgs a) {
   __shared__ PoseLds s;
   extern __shared__ double po_dyn[];
   const int ns8 = (a.n_stride + 7) & ~7;
@@ -198,35 +202,43 @@ __global__ void __launch_bounds__(PO_BLOCK) pose_opt_kernel(const PoseArgs a) {
         const unsigned long long mk = __ballot(live);
         if ((tid & 63) == 0) s.live[tid >> 6] = mk;
       }
+      __syncthreads();  // s.live visible
+      for (int half = 0; half < 2; ++half) {
+        if ((tid >> 5) == half) {
+          const int t = tid & 31;
 #pragma unroll
-      for (int k = 0; k < 21; ++k) s.tile[k][tid] = A21[k];
+          for (int k = 0; k < 21; ++k) s.tile[k][t] = A21[k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) s.tile[21 + k][tid] = bb[k];
-      s.tile[27][tid] = c2;
-      __syncthreads();
-      if (tid < 28) {
-        // A += ..., b -= ..., new_chi2 += ...   in observation order.  Observations without a
-        // point are skipped (`continue` in the reference), here by a select so that the LDS
-        // reads of eight elements are in flight together instead of one per branch.
-        const int m = (n - c0) < PO_BLOCK ? (n - c0) : PO_BLOCK;
-        double acc = s.acc[tid];
-        const bool neg = (tid >= 21 && tid < 27);
-        const double* row = s.tile[tid];
-        for (int j0 = 0; j0 < m; j0 += 8) {
-          const unsigned long long mk = s.live[j0 >> 6] >> (j0 & 63);
-          double v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = row[(j0 + u) < PO_BLOCK ? (j0 + u) : 0];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const bool on = ((mk >> u) & 1ull) != 0 && (j0 + u) < m;
-            const double nv = neg ? acc - v[u] : acc + v[u];
-            acc = on ? nv : acc;
-          }
+          for (int k = 0; k < 6; ++k) s.tile[21 + k][t] = bb[k];
+          s.tile[27][t] = c2;
         }
-        s.acc[tid] = acc;
+        __syncthreads();
+        if (tid < 28) {
+          // A += ..., b -= ..., new_chi2 += ...   in observation order.  Observations without a
+          // point are skipped (`continue` in the reference), here by a select so that the LDS
+          // reads of eight elements are in flight together instead of one per branch.
+          int m = n - c0 - PO_HALF * half;
+          m = m < 0 ? 0 : (m > PO_HALF ? PO_HALF : m);
+          double acc = s.acc[tid];
+          const bool neg = (tid >= 21 && tid < 27);
+          const double* row = s.tile[tid];
+          const unsigned long long lv = s.live[0] >> (PO_HALF * half);
+          for (int j0 = 0; j0 < m; j0 += 8) {
+            const unsigned long long mk = lv >> j0;
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = row[(j0 + u) < PO_HALF ? (j0 + u) : 0];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const bool on = ((mk >> u) & 1ull) != 0 && (j0 + u) < m;
+              const double nv = neg ? acc - v[u] : acc + v[u];
+              acc = on ? nv : acc;
+            }
+          }
+          s.acc[tid] = acc;
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
     if (tid == 0) {
       double A[36], bv[6], dT[6];
