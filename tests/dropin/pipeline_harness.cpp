@@ -29,6 +29,9 @@
 #include <svo/point.h>
 #include <vikit/pinhole_camera.h>
 #include <vikit/vision.h>
+#ifdef SVO_PIPELINE_HIP
+#include "svo_hip_device.h"
+#endif
 
 namespace vk {
 int g_halfsample_mode = 2;  // x86 dispatch of vk::halfSample (see oracle/shim/vikit/vision.h)
@@ -52,7 +55,8 @@ typedef struct pipe_config {
   int32_t n_pyr_levels, klt_max_level, klt_min_level, grid_size, max_fts, max_n_kfs;
   int32_t quality_min_fts, quality_max_drop_fts, structureoptim_max_pts, structureoptim_num_iter;
   int32_t poseoptim_num_iter, shuffle_seed;
-  int32_t mapper_thread, reserved;  // 1: keep DepthFilter's own thread running (asynchronous mapping)
+  int32_t mapper_thread;  // 1: keep DepthFilter's own thread running (asynchronous mapping)
+  int32_t pool_slots;     // >0 (hip flavour): size of the device pyramid pool, to exercise LRU eviction
   double kfselect_mindist, poseoptim_thresh, triang_min_corner_score;
 } pipe_config;
 
@@ -73,7 +77,7 @@ struct Pipe {
 void pipe_config_default(pipe_config* c) {
   c->n_pyr_levels = 3; c->klt_max_level = 4; c->klt_min_level = 2; c->grid_size = 30; c->max_fts = 120;
   c->max_n_kfs = 10; c->quality_min_fts = 50; c->quality_max_drop_fts = 40; c->structureoptim_max_pts = 20;
-  c->structureoptim_num_iter = 5; c->poseoptim_num_iter = 10; c->shuffle_seed = 1; c->mapper_thread = 0; c->reserved = 0;
+  c->structureoptim_num_iter = 5; c->poseoptim_num_iter = 10; c->shuffle_seed = 1; c->mapper_thread = 0; c->pool_slots = 0;
   c->kfselect_mindist = 0.12; c->poseoptim_thresh = 2.0; c->triang_min_corner_score = 20.0;
 }
 
@@ -94,6 +98,12 @@ void* pipe_create(int width, int height, double fx, double fy, double cx, double
   Config::triangMinCornerScore() = c->triang_min_corner_score;
   Pipe* p = new Pipe;
   p->cam = new vk::PinholeCamera(width, height, fx, fy, cx, cy);
+#ifdef SVO_PIPELINE_HIP
+  if (c->pool_slots > 0) {
+    int levels = c->n_pyr_levels > c->klt_max_level + 1 ? c->n_pyr_levels : c->klt_max_level + 1;  // frame.cpp:58
+    svo_hip::Device::instance().configure(width, height, levels, c->pool_slots);
+  }
+#endif
   std::srand((unsigned)c->shuffle_seed);  // Reprojector::initializeGrid's random_shuffle (reprojector.cpp:54)
   p->vo = new FrameHandlerMono(p->cam);
   p->vo->start();
@@ -181,6 +191,15 @@ int pipe_add_image(void* h, const uint8_t* img, double timestamp, pipe_result* o
   p->vo->addImage(m, timestamp);  // addImage clones (frame_handler_mono.cpp:69)
   fill_result(p, out);
   return (int)p->vo->stage();
+}
+
+// pyramid-cache statistics of the device context (hip flavour; zeros otherwise)
+void pipe_device_stats(uint64_t out[3]) {
+  out[0] = out[1] = out[2] = 0;
+#ifdef SVO_PIPELINE_HIP
+  svo_hip::Device& d = svo_hip::Device::instance();
+  out[0] = d.stats.uploads; out[1] = d.stats.evictions; out[2] = d.stats.calls;
+#endif
 }
 
 // features of the last frame (px, level, has point), for inspection

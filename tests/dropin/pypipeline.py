@@ -17,7 +17,7 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_pyr_levels", "klt_max_level", "klt_min_level", "grid_size", "max_fts",
                                          "max_n_kfs", "quality_min_fts", "quality_max_drop_fts",
                                          "structureoptim_max_pts", "structureoptim_num_iter", "poseoptim_num_iter",
-                                         "shuffle_seed", "mapper_thread", "reserved")] + \
+                                         "shuffle_seed", "mapper_thread", "pool_slots")] + \
                [(n, C.c_double) for n in ("kfselect_mindist", "poseoptim_thresh", "triang_min_corner_score")]
 
 
@@ -91,6 +91,12 @@ class Pipeline:
         self.lib.pipe_add_image(self.h, img.ctypes.data, ts, C.byref(r))
         return r.as_dict()
 
+    def device_stats(self):
+        """(pyramid uploads, evictions, device calls) of the process-wide svo_hip::Device."""
+        out = (C.c_uint64 * 3)()
+        self.lib.pipe_device_stats(out)
+        return tuple(int(x) for x in out)
+
     def last_features(self, max_n=2048):
         px = np.zeros((max_n, 2)); lvl = np.zeros(max_n, dtype=np.int32); pos = np.zeros((max_n, 3))
         n = self.lib.pipe_last_features(self.h, max_n, px.ctypes.data, lvl.ctypes.data, pos.ctypes.data)
@@ -108,15 +114,19 @@ def range_map(cam, T_f_w):
     return (-c[2] / dw[..., 2]).astype(np.float32)
 
 
-def run_sequence(flavour, cam, images, T_gt, **cfg):
+def run_sequence(flavour, cam, images, T_gt, stats_out=None, **cfg):
     """Feed a whole sequence; returns the per-frame result dicts (frame 0 = first frame)."""
     p = Pipeline(flavour, cam, **cfg)
     try:
+        s0 = p.device_stats()
         n0, r0 = p.set_first_frame(images[0], 0.0, T_gt[0], range_map(cam, T_gt[0]))
         r0["n_first_features"] = n0
         out = [r0]
         for i in range(1, len(images)):
             out.append(p.add_image(images[i], float(i)))
+        if stats_out is not None:
+            s1 = p.device_stats()
+            stats_out.update(uploads=s1[0] - s0[0], evictions=s1[1] - s0[1], calls=s1[2] - s0[2])
         return out
     finally:
         p.close()

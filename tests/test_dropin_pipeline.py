@@ -126,3 +126,19 @@ def test_dropin_with_asynchronous_mapper_thread(pipeline_libs, gpu_device):
         assert se3.log_norm(est, T).max() < 5e-3
         assert sum(r["is_keyframe"] for r in hip) >= 3
         assert max(r["n_candidates"] for r in hip) > 50
+
+
+@pytest.mark.gpu
+def test_dropin_small_pyramid_pool_evicts_and_reuploads(pipeline_libs, gpu_device):
+    """A device pool of 7 pyramid slots for a run that keeps up to 5 keyframes + 2 working frames
+    alive: live frames get evicted (LRU) and uploaded again on their next use; the trajectory
+    must not notice."""
+    cam, imgs, T = _sequence(120)
+    big, small = {}, {}
+    ref = pp.run_sequence("hip", cam, imgs, T, stats_out=big, pool_slots=256)
+    hip = pp.run_sequence("hip", cam, imgs, T, stats_out=small, pool_slots=7)
+    assert big["evictions"] == 0 and big["uploads"] == len(imgs)
+    assert small["evictions"] > 100 and small["uploads"] >= big["uploads"]
+    a = np.stack([r["T_f_w"] for r in ref])
+    b = np.stack([r["T_f_w"] for r in hip])
+    assert np.array_equal(a, b)  # same kernels on the same bytes: identical, not just close
