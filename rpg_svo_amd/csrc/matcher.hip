@@ -144,42 +144,42 @@ __global__ void __launch_bounds__(64) match_prepare_kernel(const PrepArgs a) {
   a.active[m] = 1;
 }
 
-// vk::interpolateMat_8u (rpg_vikit vision.h)
-__device__ __forceinline__ float interpolate_8u(const uint8_t* __restrict__ img, int pitch, float u, float v) {
-  const int x = (int)floorf(u);
-  const int y = (int)floorf(v);
-  const float subpix_x = u - (float)x;
-  const float subpix_y = v - (float)y;
-  const float w00 = (1.0f - subpix_x) * (1.0f - subpix_y);
-  const float w01 = (1.0f - subpix_x) * subpix_y;
-  const float w10 = subpix_x * (1.0f - subpix_y);
-  const float w11 = 1.0f - w00 - w01 - w10;
-  const uint8_t* ptr = img + (int64_t)y * pitch + x;
-  // two unaligned 16-bit loads (gfx950 global memory takes any alignment) instead of four bytes
-  uint16_t top, bot;
-  __builtin_memcpy(&top, ptr, 2);
-  __builtin_memcpy(&bot, ptr + pitch, 2);
-  const float p00 = (float)(top & 0xffu), p10 = (float)(top >> 8);
-  const float p01 = (float)(bot & 0xffu), p11 = (float)(bot >> 8);
-  return w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
-}
-
 // warp::warpAffine (matcher.cpp:72-105), halfpatch_size = 5.  32 lanes per trial, lanes
-// 0..24 produce 4 consecutive output bytes each and store one dword.
+// 0..24 produce 4 consecutive output bytes each and store one dword.  Two dependent memory
+// rounds only: (1) the trial's parameters, all independent loads, with the pyramid geometry
+// of its level looked up in an LDS copy of the layout; (2) the 8 two-byte gathers of the
+// lane's four bilinear samples, issued together before any is consumed.
 __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
+  __shared__ long long s_off[SVO_HIP_MAX_LEVELS];
+  __shared__ int s_w[SVO_HIP_MAX_LEVELS], s_h[SVO_HIP_MAX_LEVELS], s_p[SVO_HIP_MAX_LEVELS];
+  if (threadIdx.x < SVO_HIP_MAX_LEVELS) {
+    s_off[threadIdx.x] = a.L.offset[threadIdx.x];
+    s_w[threadIdx.x] = a.L.w[threadIdx.x];
+    s_h[threadIdx.x] = a.L.h[threadIdx.x];
+    s_p[threadIdx.x] = a.L.pitch[threadIdx.x];
+  }
+  __syncthreads();
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int m = gid >> 5;
   const int k = gid & 31;
   if (m >= a.M || k >= 25) return;
+  // round 1: parameters of the trial
+  const float4 A = *reinterpret_cast<const float4*>(a.A_ref_cur + 4 * (size_t)m);
+  const float2 pyr = *reinterpret_cast<const float2*>(a.px_ref_pyr + 2 * (size_t)m);
+  const int act = a.active[m];
+  const int level = a.ref_level[m] & (SVO_HIP_MAX_LEVELS - 1);
+  const int slot = a.ref_slot[m];
+  const int slev = a.search_level[m];
   uint32_t packed = 0;
-  const float A0 = a.A_ref_cur[4 * m], A1 = a.A_ref_cur[4 * m + 1], A2 = a.A_ref_cur[4 * m + 2], A3 = a.A_ref_cur[4 * m + 3];
   // "Affine warp is NaN": the reference leaves the previous patch in place; here: zeros
-  if (a.active[m] && !isnan(A0)) {
-    const int level = a.ref_level[m];
-    const uint8_t* img = a.store + (int64_t)a.ref_slot[m] * a.L.slot_bytes + a.L.offset[level];
-    const int cols = a.L.w[level], rows = a.L.h[level], pitch = a.L.pitch[level];
-    const float pyr0 = a.px_ref_pyr[2 * m], pyr1 = a.px_ref_pyr[2 * m + 1];
-    const float sc = (float)(1 << a.search_level[m]);
+  if (act && !isnan(A.x)) {
+    const uint8_t* img = a.store + (int64_t)slot * a.L.slot_bytes + s_off[level];
+    const int cols = s_w[level], rows = s_h[level], pitch = s_p[level];
+    const float sc = (float)(1 << slev);
+    // round 2: addresses and weights of the four samples, then all eight loads
+    float w00[4], w01[4], w10[4], w11[4];
+    bool in[4];
+    uint16_t top[4], bot[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int i = 4 * k + j;
@@ -187,12 +187,28 @@ __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
       float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
       pp0 *= sc;
       pp1 *= sc;
-      const float px0 = (A0 * pp0 + A1 * pp1) + pyr0;
-      const float px1 = (A2 * pp0 + A3 * pp1) + pyr1;
-      uint32_t val = 0;
-      if (!(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1)))
-        val = (uint32_t)(uint8_t)interpolate_8u(img, pitch, px0, px1);
-      packed |= val << (8 * j);
+      const float px0 = (A.x * pp0 + A.y * pp1) + pyr.x;
+      const float px1 = (A.z * pp0 + A.w * pp1) + pyr.y;
+      in[j] = !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
+      // vk::interpolateMat_8u; samples outside the image read pixel (0,0) and are discarded
+      const float u = in[j] ? px0 : 0.f, v = in[j] ? px1 : 0.f;
+      const int xi = (int)floorf(u), yi = (int)floorf(v);
+      const float sx = u - (float)xi, sy = v - (float)yi;
+      w00[j] = (1.0f - sx) * (1.0f - sy);
+      w01[j] = (1.0f - sx) * sy;
+      w10[j] = sx * (1.0f - sy);
+      w11[j] = 1.0f - w00[j] - w01[j] - w10[j];
+      const uint8_t* ptr = img + (int64_t)yi * pitch + xi;
+      // two unaligned 16-bit loads (gfx950 global memory takes any alignment) instead of four bytes
+      __builtin_memcpy(&top[j], ptr, 2);
+      __builtin_memcpy(&bot[j], ptr + pitch, 2);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float p00 = (float)(top[j] & 0xffu), p10 = (float)(top[j] >> 8);
+      const float p01 = (float)(bot[j] & 0xffu), p11 = (float)(bot[j] >> 8);
+      const float val = w00[j] * p00 + w01[j] * p01 + w10[j] * p10 + w11[j] * p11;
+      packed |= (in[j] ? (uint32_t)(uint8_t)val : 0u) << (8 * j);
     }
   }
   reinterpret_cast<uint32_t*>(a.pwb + (size_t)m * 100)[k] = packed;
