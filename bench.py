@@ -78,6 +78,9 @@ def main() -> None:
     ap.add_argument("--cpu-sample", type=int, default=8192, help="frames timed on the host for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n-iter", type=int, default=30, help="Gauss-Newton iteration cap per level (30 in the pipeline)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step (all kernel launches of the pipeline) in a HIP graph and replay it: "
+                         "small batches -- e.g. one frame per camera of a rig -- are launch-bound")
     ap.add_argument("--pipeline", default="align", choices=["align", "full"],
                     help="align: SparseImgAlign only (BASELINE configs[1], the default); full: configs[2] -- "
                          "sparse align + reprojection matching (align2D) + pose refinement + depth-filter update")
@@ -142,20 +145,46 @@ def main() -> None:
         capi.check(lib.svo_hip_event_create(e.ref()))
         ev.append(e.value)
 
-    def step(i: int | None) -> None:
+    graph = None
+
+    def step_compute(i: int | None) -> None:
+        st = torch.cuda.current_stream(dev).cuda_stream
         if i is not None:
-            lib.svo_hip_event_record(ev[2 * i], stream)
+            lib.svo_hip_event_record(ev[2 * i], st)
         sia.run(store, cam, ref_slot, cur_slot, n_t, px_t, xyz_t, T_in, out=out)
         if i is not None:
-            lib.svo_hip_event_record(ev[2 * i + 1], stream)
+            lib.svo_hip_event_record(ev[2 * i + 1], st)
         if full is not None:
-            full.step(out.T_cur_from_ref, lib, stream, timed=i is not None)
+            full.step(out.T_cur_from_ref, lib, st, timed=i is not None)
+
+    def step(i: int | None) -> None:
+        if graph is not None:
+            if i is not None:
+                lib.svo_hip_event_record(ev[2 * i], stream)
+            graph.replay()
+            if i is not None:
+                lib.svo_hip_event_record(ev[2 * i + 1], stream)
+        else:
+            step_compute(i)
         if world > 1:  # RCCL gather of the SE(3) results (the only exchange step)
             dist.all_gather_into_tensor(gathered, out.T_cur_from_ref)
 
     for _ in range(args.warmup):
         step(None)
     torch.cuda.synchronize()
+    if args.graph:
+        # torch's graph object is the capture front end (private allocator pool for the tensors the
+        # host mirrors create); what gets captured are the launches libsvo_hip.so enqueues on the
+        # capture stream.  C++ hosts use svo_hip_graph_begin_capture / end_capture / launch.
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            step_compute(None)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        with torch.cuda.graph(graph):
+            step_compute(None)
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -221,6 +250,7 @@ def main() -> None:
             "schedule": f"levels {max_level}->{min_level}", "patches_per_frame": n_patches,
             "frames_per_step_per_gpu": B, "n_iter_cap": args.n_iter, "image_noise_sigma": args.noise,
             "parallelism": f"frames sharded 1 rank/GPU x{world}" + (", RCCL all_gather of poses" if world > 1 else ""),
+            "hip_graph": bool(args.graph),
             "mean_gn_iterations_per_frame": float(iters.sum(1).mean()),
             "mean_tracked_patches": float(n_tracked.mean()),
             "median_pose_error_vs_gt": float(np.median(gt_err)),
@@ -239,8 +269,8 @@ def main() -> None:
         T_ref_est = d.pop("_T_refined")
         d["median_pose_error_vs_gt_after_refine"] = float(np.median(se3.log_norm(T_ref_est, T_gt[1:B + 1])))
         result["config"].update(d)
-        result["stages_ms"] = full.stage_ms(lib)
-        result["stages_ms"]["sparse_align"] = kernel_ms
+        result["stages_ms"] = full.stage_ms(lib) if not args.graph else {}
+        result["stages_ms"]["sparse_align" if not args.graph else "whole_graph"] = kernel_ms
 
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(args, cam, images, T_gt, px_all, f_all, pos_all, T_ref_w, T_prior_w,

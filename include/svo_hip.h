@@ -74,6 +74,15 @@ int svo_hip_event_destroy(void* event);
 int svo_hip_event_record(void* event, void* stream);
 int svo_hip_event_elapsed_ms(void* start, void* stop, float* ms_out); /* syncs on stop */
 
+/* HIP graphs: every entry point below only enqueues kernels / memsets on `stream`, so a fixed
+ * chain of calls (same pointers, same sizes: e.g. one tracked frame of every camera of a rig) can
+ * be captured once and replayed with a single launch per step -- for small batches the chain is
+ * launch-bound.  begin_capture .. <entry-point calls on `stream`> .. end_capture, then launch. */
+int svo_hip_graph_begin_capture(void* stream);
+int svo_hip_graph_end_capture(void* stream, void** graph_exec_out);
+int svo_hip_graph_launch(void* graph_exec, void* stream);
+int svo_hip_graph_destroy(void* graph_exec);
+
 /* ---- pyramid store ------------------------------------------------------ */
 typedef struct svo_hip_pyr_layout {
   int32_t n_levels;

@@ -100,6 +100,10 @@ PROTOTYPES = {
     "svo_hip_event_destroy": (_i, [_vp]),
     "svo_hip_event_record": (_i, [_vp, _vp]),
     "svo_hip_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
+    "svo_hip_graph_begin_capture": (_i, [_vp]),
+    "svo_hip_graph_end_capture": (_i, [_vp, C.POINTER(_vp)]),
+    "svo_hip_graph_launch": (_i, [_vp, _vp]),
+    "svo_hip_graph_destroy": (_i, [_vp]),
     "svo_hip_pyr_layout_init": (_i, [_i, _i, _i, C.POINTER(PyrLayout)]),
     "svo_hip_pyr_store_bytes": (_i64, [C.POINTER(PyrLayout), _i]),
     "svo_hip_pyramid_load_level0": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _i64, _i, _vp]),

@@ -138,6 +138,34 @@ int svo_hip_event_elapsed_ms(void* start, void* stop, float* ms_out) {
   return SVO_HIP_OK;
 }
 
+// ---- HIP graphs: capture a fixed chain of entry-point calls once, replay it per step ----------
+int svo_hip_graph_begin_capture(void* stream) {
+  SVO_HIP_TRY(hipStreamBeginCapture(static_cast<hipStream_t>(stream), hipStreamCaptureModeThreadLocal));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_graph_end_capture(void* stream, void** graph_exec_out) {
+  if (!graph_exec_out) return SVO_HIP_EINVAL;
+  hipGraph_t g = nullptr;
+  SVO_HIP_TRY(hipStreamEndCapture(static_cast<hipStream_t>(stream), &g));
+  hipGraphExec_t e = nullptr;
+  hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  SVO_HIP_TRY(rc);
+  *graph_exec_out = e;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_graph_launch(void* graph_exec, void* stream) {
+  SVO_HIP_TRY(hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), static_cast<hipStream_t>(stream)));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_graph_destroy(void* graph_exec) {
+  SVO_HIP_TRY(hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec)));
+  return SVO_HIP_OK;
+}
+
 int svo_hip_pyr_layout_init(int width, int height, int n_levels, svo_hip_pyr_layout* out) {
   if (!out || width < 1 || height < 1 || n_levels < 1 || n_levels > SVO_HIP_MAX_LEVELS) return SVO_HIP_EINVAL;
   std::memset(out, 0, sizeof(*out));
