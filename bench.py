@@ -261,6 +261,9 @@ def main() -> None:
             "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
             "kernel_ms_avg": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
             "algorithmic_bytes_per_frame": alg_bytes / B,
+            # iterations/s and per-iteration time of the batch
+            "gn_iterations_per_s": float(iters.sum()) / (kernel_ms * 1e-3),
+            "us_per_gn_iteration_of_the_batch": kernel_ms * 1e3 / max(float(iters.sum(1).mean()), 1e-9),
         },
         "setup_s": t_gen,
     }

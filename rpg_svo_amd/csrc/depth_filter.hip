@@ -244,12 +244,10 @@ __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) 
 #pragma unroll
     for (int y = 0; y < 8; ++y) {
       const uint8_t* r = pw + (y + 1) * 10 + 1;
-      uint32_t lo = 0, hi = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        lo |= (uint32_t)r[k] << (8 * k);
-        hi |= (uint32_t)r[4 + k] << (8 * k);
-      }
+      // one unaligned 8-byte load per row (gfx950 global memory takes any alignment)
+      uint32_t lo, hi;
+      __builtin_memcpy(&lo, r, 4);
+      __builtin_memcpy(&hi, r + 4, 4);
       ra[2 * y] = lo;
       ra[2 * y + 1] = hi;
     }
@@ -269,11 +267,14 @@ __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) 
   int best_i = 0x7fffffff;
   double best_uv0 = 0, best_uv1 = 0;
   const double lvl = (double)(1 << sl);
+  // every lane replays this loop for all steps: keep it lean.  Dividing by 2^level is exact,
+  // so multiplying by 2^-level gives the same bits without two f64 division sequences per step
+  const double inv_lvl = 1.0 / lvl;
   for (int i = 0; i < n_total; ++i, uv0 += step0, uv1 += step1) {
     const double px0 = a.cam.fx * uv0 + a.cam.cx;
     const double px1 = a.cam.fy * uv1 + a.cam.cy;
-    const int pxi0 = cast_int(px0 / lvl + 0.5);
-    const int pxi1 = cast_int(px1 / lvl + 0.5);
+    const int pxi0 = cast_int(px0 * inv_lvl + 0.5);
+    const int pxi1 = cast_int(px1 * inv_lvl + 0.5);
     if (pxi0 == last_x && pxi1 == last_y) continue;
     last_x = pxi0;
     last_y = pxi1;
