@@ -133,7 +133,18 @@ def main() -> None:
     T_in = tdev(T_cr, torch.float64)
     sia = SparseImgAlign(max_level, min_level, args.n_iter)
     out = sia.alloc_result(B, dev)
-    gathered = torch.empty(world * B, 12, dtype=torch.float64, device=dev) if world > 1 else None
+    # N>1: the only exchange is the gather of the [B,12] poses.  It is double-buffered and issued
+    # asynchronously (RCCL's own stream) so that it overlaps the next step's kernels; the timed
+    # region ends only after the last gather has completed.  SVO_BENCH_SYNC_GATHER=1: blocking gather.
+    gather = None
+    outs = [out]
+    if world > 1:
+        from rpg_svo_amd.dist import OverlappedPoseGather
+        gather = OverlappedPoseGather(B, 12, torch.float64, dev)
+        if os.environ.get("SVO_BENCH_SYNC_GATHER") != "1":
+            outs = [sia.alloc_result(B, dev) for _ in range(gather.depth)]
+        for k, o in enumerate(outs):
+            o.T_cur_from_ref = gather._local[k]
     full = FullTrack(args, cam, store, T_gt, px_all, f_all, pos_all, n_patches, n_levels, dev, rank) if args.pipeline == "full" else None
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
@@ -147,15 +158,21 @@ def main() -> None:
 
     graph = None
 
+    counter = [0]
+
     def step_compute(i: int | None) -> None:
         st = torch.cuda.current_stream(dev).cuda_stream
+        k = counter[0] % len(outs)
+        o = outs[k]
+        if gather is not None:
+            gather.local(counter[0] if len(outs) > 1 else 0)  # waits for the gather that last read this buffer
         if i is not None:
             lib.svo_hip_event_record(ev[2 * i], st)
-        sia.run(store, cam, ref_slot, cur_slot, n_t, px_t, xyz_t, T_in, out=out)
+        sia.run(store, cam, ref_slot, cur_slot, n_t, px_t, xyz_t, T_in, out=o)
         if i is not None:
             lib.svo_hip_event_record(ev[2 * i + 1], st)
         if full is not None:
-            full.step(out.T_cur_from_ref, lib, st, timed=i is not None)
+            full.step(o.T_cur_from_ref, lib, st, timed=i is not None)
 
     def step(i: int | None) -> None:
         if graph is not None:
@@ -166,12 +183,21 @@ def main() -> None:
                 lib.svo_hip_event_record(ev[2 * i + 1], stream)
         else:
             step_compute(i)
-        if world > 1:  # RCCL gather of the SE(3) results (the only exchange step)
-            dist.all_gather_into_tensor(gathered, out.T_cur_from_ref)
+        if gather is not None:  # RCCL gather of the SE(3) results (the only exchange step)
+            if len(outs) > 1:
+                gather.submit(counter[0])
+            else:
+                gather.submit(0)
+                gather.result(0)
+        counter[0] += 1
 
     for _ in range(args.warmup):
         step(None)
+    if gather is not None:
+        gather.drain()
     torch.cuda.synchronize()
+    if args.graph and world > 1:
+        raise SystemExit("--graph replays fixed buffers; combine it with the overlapped gather only at --gpus 1")
     if args.graph:
         # torch's graph object is the capture front end (private allocator pool for the tensors the
         # host mirrors create); what gets captured are the launches libsvo_hip.so enqueues on the
@@ -191,6 +217,8 @@ def main() -> None:
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    if gather is not None:
+        gather.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -214,6 +242,7 @@ def main() -> None:
             dist.destroy_process_group()
         return
 
+    out = outs[(counter[0] - 1) % len(outs)]  # the result block of the last step
     n_tracked = out.n_tracked.cpu().numpy().astype(np.float64)
     iters = out.iters.cpu().numpy().astype(np.float64)
     alg_bytes = algorithmic_bytes(np.full(B, n_patches, dtype=np.float64), n_tracked, iters, max_level, min_level)
@@ -249,7 +278,7 @@ def main() -> None:
             "workload": args.workload if full is None else args.workload.replace("sparse_align", "full_track"), "image": f"{width}x{height}", "pyr_levels": n_levels,
             "schedule": f"levels {max_level}->{min_level}", "patches_per_frame": n_patches,
             "frames_per_step_per_gpu": B, "n_iter_cap": args.n_iter, "image_noise_sigma": args.noise,
-            "parallelism": f"frames sharded 1 rank/GPU x{world}" + (", RCCL all_gather of poses" if world > 1 else ""),
+            "parallelism": f"frames sharded 1 rank/GPU x{world}" + (", RCCL all_gather of poses, double-buffered and overlapped with the next step" if world > 1 else ""),
             "hip_graph": bool(args.graph),
             "mean_gn_iterations_per_frame": float(iters.sum(1).mean()),
             "mean_tracked_patches": float(n_tracked.mean()),

@@ -59,3 +59,34 @@ def test_two_rank_gather_matches_single_process(tmp_path, oracle):
     T, _, _ = run_oracle(oracle, b, 2, 0, n_threads=1)
     assert got.shape == (n_total, 12)
     assert np.array_equal(got, T)
+
+
+def _overlap_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rpg_svo_amd.dist import OverlappedPoseGather
+    g = OverlappedPoseGather(3, width=12, device="cpu")
+    got = []
+    for i in range(5):  # more steps than buffers: every buffer is reused after its gather
+        T = g.local(i)
+        T.copy_(torch.full((3, 12), float(100 * i + rank), dtype=torch.float64))
+        g.submit(i)
+        if i >= 1:
+            got.append(g.result(i - 1).clone())  # consume one step behind, as the bench does
+    got.append(g.result(4).clone())
+    g.drain()
+    if rank == 1:
+        np.save(os.path.join(tmp, "overlap.npy"), torch.stack(got).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_overlapped_pose_gather_two_ranks(tmp_path):
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_overlap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "overlap.npy"))
+    assert got.shape == (5, 6, 12)
+    for i in range(5):
+        assert (got[i, :3] == 100 * i).all() and (got[i, 3:] == 100 * i + 1).all()
