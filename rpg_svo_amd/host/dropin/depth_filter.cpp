@@ -153,8 +153,7 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   if (S == 0) return;
 
   using namespace hip_dropin;
-  ensureDevice(*frame);
-  svo_hip::Device& dev = svo_hip::Device::instance();
+  svo_hip::Device& dev = ensureDevice(*frame);
   const int L = svo_hip::Device::LANE_MAPPING;
   svo_hip::Lane& lane = dev.lane(L);
   std::lock_guard<std::mutex> guard(lane.mut);

@@ -37,8 +37,7 @@ FastDetector::FastDetector(const int img_width, const int img_height, const int 
 void FastDetector::detect(Frame* frame, const ImgPyr& img_pyr, const double detection_threshold, Features& fts) {
   using namespace hip_dropin;
   (void)img_pyr;  // the device pyramid of `frame` (built by K0 from its level 0) is the one searched
-  ensureDevice(*frame);
-  svo_hip::Device& dev = svo_hip::Device::instance();
+  svo_hip::Device& dev = ensureDevice(*frame);
   const int L = svo_hip::Device::LANE_MAPPING;  // seeds are initialised by the mapping thread
   svo_hip::Lane& lane = dev.lane(L);
   std::lock_guard<std::mutex> guard(lane.mut);

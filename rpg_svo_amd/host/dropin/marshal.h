@@ -117,8 +117,9 @@ struct FeatureColumns {
   }
 };
 
-inline void ensureDevice(const Frame& f) {
-  svo_hip::Device::instance().ensureConfigured(f.img_pyr_[0].cols, f.img_pyr_[0].rows, (int)f.img_pyr_.size());
+// the device context for frames of this geometry (created and sized on first use)
+inline svo_hip::Device& ensureDevice(const Frame& f) {
+  return svo_hip::Device::forGeometry(f.img_pyr_[0].cols, f.img_pyr_[0].rows, (int)f.img_pyr_.size());
 }
 
 }  // namespace hip_dropin

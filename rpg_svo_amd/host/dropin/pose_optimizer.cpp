@@ -18,8 +18,7 @@ void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const 
   using namespace hip_dropin;
   const size_t n = frame->fts_.size();
   if (n == 0) return;
-  ensureDevice(*frame);
-  svo_hip::Device& dev = svo_hip::Device::instance();
+  svo_hip::Device& dev = ensureDevice(*frame);
   const int L = svo_hip::Device::LANE_TRACKING;
   svo_hip::Lane& lane = dev.lane(L);
   std::lock_guard<std::mutex> guard(lane.mut);

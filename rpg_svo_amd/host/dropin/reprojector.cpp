@@ -128,8 +128,7 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
         }
     const size_t M = trials.size();
     if (M > 0) {
-      ensureDevice(*frame);
-      svo_hip::Device& dev = svo_hip::Device::instance();
+      svo_hip::Device& dev = ensureDevice(*frame);
       const int L = svo_hip::Device::LANE_TRACKING;
       svo_hip::Lane& lane = dev.lane(L);
       std::lock_guard<std::mutex> guard(lane.mut);

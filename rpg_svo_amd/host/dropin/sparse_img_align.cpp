@@ -34,8 +34,7 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   cur_frame_ = cur_frame;
 
   using namespace hip_dropin;
-  ensureDevice(*ref_frame);
-  svo_hip::Device& dev = svo_hip::Device::instance();
+  svo_hip::Device& dev = ensureDevice(*ref_frame);
   const int L = svo_hip::Device::LANE_TRACKING;
   svo_hip::Lane& lane = dev.lane(L);
   std::lock_guard<std::mutex> guard(lane.mut);

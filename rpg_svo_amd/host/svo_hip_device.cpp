@@ -60,9 +60,36 @@ Device::Device() : d_store_(NULL), n_slots_(0), clock_(0) {
 }
 Device::~Device() { shutdown(); }
 
+namespace {
+std::mutex g_registry_mut;
+std::vector<Device*> g_registry;  // contexts live until process exit
+Device* g_last = NULL;
+}  // namespace
+
+Device& Device::forGeometry(int width, int height, int n_levels) {
+  std::lock_guard<std::mutex> g(g_registry_mut);
+  for (size_t i = 0; i < g_registry.size(); ++i) {
+    Device* d = g_registry[i];
+    if (!d->configured() || (d->layout_.w[0] == width && d->layout_.h[0] == height && d->layout_.n_levels >= n_levels)) {
+      if (!d->configured()) d->configure(width, height, n_levels);
+      g_last = d;
+      return *d;
+    }
+  }
+  Device* d = new Device();
+  g_registry.push_back(d);
+  d->configure(width, height, n_levels);
+  g_last = d;
+  return *d;
+}
+
 Device& Device::instance() {
-  static Device dev;
-  return dev;
+  std::lock_guard<std::mutex> g(g_registry_mut);
+  if (g_last == NULL) {
+    g_last = new Device();
+    g_registry.push_back(g_last);
+  }
+  return *g_last;
 }
 
 void Device::shutdown() {

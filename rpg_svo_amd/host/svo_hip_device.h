@@ -78,8 +78,11 @@ class Device {
  public:
   enum { LANE_TRACKING = 0, LANE_MAPPING = 1, N_LANES = 2 };
 
-  // Process-wide context, created on first use with the image geometry of the first frame
-  // that reaches it (all frames of one svo::FrameHandlerMono share a camera).
+  // Context for frames of one image geometry (width x height x pyramid levels), created on
+  // first use; all frames of one svo::FrameHandlerMono share a camera, several handlers with
+  // different cameras (a heterogeneous rig) get one context each.
+  static Device& forGeometry(int width, int height, int n_levels);
+  // The context used last (the one and only in a single-camera process).
   static Device& instance();
 
   // (Re)create the store: width/height of level 0, pyramid levels, slots.  Called lazily by

@@ -116,6 +116,11 @@ void* pipe_create(int width, int height, double fx, double fy, double cx, double
 void pipe_destroy(void* h) {
   Pipe* p = (Pipe*)h;
   delete p->vo;
+#ifdef SVO_TRACE
+  // ~FrameHandlerBase deletes the process-global trace monitor (frame_handler_base.cpp:82-84);
+  // with two handlers alive the second destructor would delete it again
+  g_permon = NULL;
+#endif
   delete p->cam;
   delete p;
 }

@@ -142,3 +142,26 @@ def test_dropin_small_pyramid_pool_evicts_and_reuploads(pipeline_libs, gpu_devic
     a = np.stack([r["T_f_w"] for r in ref])
     b = np.stack([r["T_f_w"] for r in hip])
     assert np.array_equal(a, b)  # same kernels on the same bytes: identical, not just close
+
+
+@pytest.mark.gpu
+def test_two_cameras_of_different_geometry_in_one_process(pipeline_libs, gpu_device):
+    """A heterogeneous rig: two FrameHandlerMono instances (752x480 and 640x480) fed alternately.
+    Each image geometry gets its own device context (pyramid store layout); both must track."""
+    cam_a, imgs_a, T_a = _sequence(40)
+    cam_b = synth.Camera(640, 480, 400.0, 400.0, 320.0, 240.0)
+    T_b = synth.make_trajectory(40, seed=9, max_step=0.02, max_rot_deg=0.3)
+    imgs_b = synth.render(synth.make_texture(seed=12345), T_b, cam_b).numpy()
+    pa, pb = pp.Pipeline("hip", cam_a), pp.Pipeline("hip", cam_b)
+    try:
+        pa.set_first_frame(imgs_a[0], 0.0, T_a[0], pp.range_map(cam_a, T_a[0]))
+        pb.set_first_frame(imgs_b[0], 0.0, T_b[0], pp.range_map(cam_b, T_b[0]))
+        for i in range(1, 40):
+            ra = pa.add_image(imgs_a[i], float(i))
+            rb = pb.add_image(imgs_b[i], float(i))
+            assert ra["stage"] == pp.STAGE_DEFAULT_FRAME and rb["stage"] == pp.STAGE_DEFAULT_FRAME
+            assert se3.log_norm(ra["T_f_w"][None], T_a[i][None])[0] < 5e-3
+            assert se3.log_norm(rb["T_f_w"][None], T_b[i][None])[0] < 5e-3
+    finally:
+        pa.close()
+        pb.close()
