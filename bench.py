@@ -585,8 +585,6 @@ class FullTrack:
     def describe(self):
         m, po, st = self.last["match"], self.last["pose"], self.last["seed_status"].cpu().numpy()
         T_est = po.T_f_w.cpu().numpy()
-        T_true = self.frame_T.new_tensor(0).cpu()  # placeholder to keep torch import local
-        del T_true
         return {"match_trials_per_frame": self.N, "matches_per_frame": float(m.ok.float().sum().item() / self.B),
                 "pose_refine_obs_after_pruning": float(po.stats[:, 3].mean().item()),
                 "seeds_per_frame": self.N,
