@@ -22,9 +22,9 @@
 //     workgroup; the 21 unique entries of H and its LDL' factors are rebuilt
 //     only when the set of patches inside the current image changes.
 //   serial point (solve/update, :245-258 + vk::NLLSSolver::optimizeGaussNewton)
-//     wave 0 sums the per-wave partials from LDS, back-substitutes through the
-//     cached factors, applies the stop / rollback rules and writes the new
-//     pose (quaternion + t, as Sophus stores it) to LDS for everyone.
+//     one wave of the workgroup (rotating with the workgroup id) sums the per-wave
+//     partials from LDS, multiplies by the cached H^-1, applies the stop / rollback
+//     rules and publishes the new pose through LDS; the others wait at a barrier.
 //
 // Numerics: pixel math in f32 (like the reference); projection, the solve and the
 // pose in f64 (like the reference).  The per-patch Jacobian rows and the per-lane
@@ -129,9 +129,7 @@ __device__ __forceinline__ void cut_row5(uint32_t a, uint32_t b, uint32_t c, int
 
 constexpr int MAX_WAVES = SVO_HIP_MAX_PATCHES / 64;
 
-// Gauss-Newton state of one wave.  Every wave of the workgroup runs the (cheap)
-// solve/update step redundantly on the same workgroup totals, so all copies stay
-// bit-identical and no wave ever waits for another one's result.
+// Gauss-Newton state kept by the solver wave of a workgroup (quaternion form, as Sophus stores it).
 struct WaveModel {
   double q[4], t[3];    // model: T_cur_from_ref as Sophus stores it (unit quaternion + t)
   double oq[4], ot[3];  // old_model (rollback)
@@ -140,6 +138,9 @@ struct WaveModel {
 // Workgroup state (file-scope LDS).
 struct SiaLds {
   WaveModel wm[MAX_WAVES];
+  double Rt[12];                 // pose published by the solver wave of the iteration
+  int sw_done, sw_stop, sw_nmeas;
+  double sw_chi2;
   double H[21];                  // H_ of the last evaluated iteration (packed upper triangle)
   double Hinv[36];               // its inverse, row-major
   double A[36];                  // Gauss-Jordan scratch
@@ -489,8 +490,15 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
       ++evals;
 
       // -- solve() / update() and the stop / rollback rules of
-      //    vk::NLLSSolver::optimizeGaussNewton (:245-258): every wave, redundantly --
+      //    vk::NLLSSolver::optimizeGaussNewton (:245-258) --
       int done = 0;
+      // ONE wave per workgroup runs the serial step (it is ~300 VALU instructions against ~250 for
+      // a wave's pixel work, so running it in all waves redundantly spent more than half of the
+      // issue slots on it); which wave rotates with the workgroup id so that the solver waves of the
+      // workgroups sharing a CU do not pile up on one SIMD.  The others take the second barrier
+      // and pick the new pose up from LDS.
+      const int sw = (NW > 1) ? (int)(blockIdx.x % NW) : 0;
+      if (wave == sw)
 #ifndef SIA_DBG_NOSOLVE
       {
         // totals over the waves: lane k (<8) owns column k
@@ -560,8 +568,29 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
 #pragma unroll
           for (int k = 0; k < 3; ++k) wm.t[k] = tr[k];
         }
+        if (NW > 1 && lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) g_s.Rt[k] = R[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) g_s.Rt[9 + k] = tr[k];
+          g_s.sw_done = done;
+          g_s.sw_stop = stop;
+          g_s.sw_nmeas = n_meas_last;
+          g_s.sw_chi2 = chi2_prev;
+        }
       }
 #endif
+      if (NW > 1) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = g_s.Rt[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tr[k] = g_s.Rt[9 + k];
+        done = g_s.sw_done;
+        stop = g_s.sw_stop;
+        n_meas_last = g_s.sw_nmeas;
+        chi2_prev = g_s.sw_chi2;
+      }
       buf ^= 1;
 #ifndef SIA_DBG_FIXED_ITERS
       if (done) break;
