@@ -150,7 +150,7 @@ int svo_hip_graph_end_capture(void* stream, void** graph_exec_out) {
   SVO_HIP_TRY(hipStreamEndCapture(static_cast<hipStream_t>(stream), &g));
   hipGraphExec_t e = nullptr;
   hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
-  hipGraphDestroy(g);
+  (void)hipGraphDestroy(g);
   SVO_HIP_TRY(rc);
   *graph_exec_out = e;
   return SVO_HIP_OK;
