@@ -167,13 +167,13 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   int32_t *d_cur, *d_batch; float *d_a, *d_b, *d_mu, *d_zr, *d_s2;
   int32_t* cur = a.alloc<int32_t>(S, &d_cur);
   int32_t* batch = a.alloc<int32_t>(S, &d_batch);
-  float* sa = a.alloc<float>(S, &d_a);
-  float* sb = a.alloc<float>(S, &d_b);
-  float* smu = a.alloc<float>(S, &d_mu);
   float* szr = a.alloc<float>(S, &d_zr);
-  float* ss2 = a.alloc<float>(S, &d_s2);
   FeatureColumns ftr;
   ftr.alloc(a, S);
+  // the seed state is updated in place by the kernel: it lives in the output block, is filled
+  // below and travels both ways (uploadAll / download)
+  std::vector<float> st(4 * S);
+  float *sa = &st[0], *sb = &st[S], *smu = &st[2 * S], *ss2 = &st[3 * S];
   size_t s = 0;
   for (std::list<Seed>::iterator it = seeds_.begin(); it != seeds_.end(); ++it, ++s) {
     cur[s] = i_cur;
@@ -184,6 +184,13 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   svo_hip_frames ft;
   frames.emit(a, &ft);
   a.endInputs();
+  {
+    float* h;
+    h = a.alloc<float>(S, &d_a);  std::copy(sa, sa + S, h);  sa = h;
+    h = a.alloc<float>(S, &d_b);  std::copy(sb, sb + S, h);  sb = h;
+    h = a.alloc<float>(S, &d_mu); std::copy(smu, smu + S, h); smu = h;
+    h = a.alloc<float>(S, &d_s2); std::copy(ss2, ss2 + S, h); ss2 = h;
+  }
   int32_t* d_status; double *d_xyz, *d_px;
   int32_t* status = a.alloc<int32_t>(S, &d_status);
   double* xyz = a.alloc<double>(3 * S, &d_xyz);
@@ -205,15 +212,11 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   const svo_hip_camera cam = cameraOf(frame->cam_);
   void* ws = dev.workspace(lane, (int)S);
 
-  a.upload(lane.stream);
+  a.uploadAll(lane.stream);
   svo_hip::check(svo_hip_update_seeds(&dev.layout(), dev.store(), &cam, &ft, (int)S, d_cur, &ftr.dev, &seeds, &opt, d_status, d_xyz,
                                       d_px, ws, lane.workspace_bytes, lane.stream),
                  "svo_hip_update_seeds");
   a.download(lane.stream);
-  a.fetch(sa, S, lane.stream);   // seed state is updated in place
-  a.fetch(sb, S, lane.stream);
-  a.fetch(smu, S, lane.stream);
-  a.fetch(ss2, S, lane.stream);
   svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
 
   // ---- replay of the list surgery, in list order (:216-219, :238-245, :255-290) ---------------

@@ -27,38 +27,33 @@ void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const 
   a.reset();
 
   // ---- observations, in the order of Frame::fts_ (the order the reference accumulates in) --
-  int32_t *d_n, *d_level; double *d_f, *d_pos, *d_T; uint8_t* d_has;
+  int32_t *d_n, *d_level; double *d_f, *d_pos, *d_Tout; uint8_t* d_has_out;
   int32_t* hn = a.alloc<int32_t>(1, &d_n);
   int32_t* level = a.alloc<int32_t>(n, &d_level);
   double* f = a.alloc<double>(3 * n, &d_f);
   double* pos = a.alloc<double>(3 * n, &d_pos);
-  double* T = a.alloc<double>(12, &d_T);
-  // has_point and the pose are read AND written by the kernel: they sit at the end of the
-  // input block and are copied back explicitly below
-  uint8_t* has = a.alloc<uint8_t>(n, &d_has);
+  a.endInputs();
+  // has_point and the pose are read AND written by the kernel: they live in the output block,
+  // are filled here and travel both ways (uploadAll / download), so the call is two copies
+  double* Tout = a.alloc<double>(12, &d_Tout);
+  uint8_t* has_out = a.alloc<uint8_t>(n, &d_has_out);
   *hn = (int32_t)n;
   size_t i = 0;
   for (Features::const_iterator it = frame->fts_.begin(); it != frame->fts_.end(); ++it, ++i) {
     const Feature* ftr = *it;
     level[i] = ftr->level;
     for (int k = 0; k < 3; ++k) f[3 * i + k] = ftr->f[k];
-    has[i] = ftr->point != NULL;
+    has_out[i] = ftr->point != NULL;
     for (int k = 0; k < 3; ++k) pos[3 * i + k] = ftr->point ? ftr->point->pos_[k] : 0.0;
   }
-  poseToRt(frame->T_f_w_, T);
-  a.endInputs();
-  double *d_Cov, *d_stats, *d_Tout; int32_t* d_ran; uint8_t* d_has_out;
+  poseToRt(frame->T_f_w_, Tout);
+  double *d_Cov, *d_stats; int32_t* d_ran;
   double* Cov = a.alloc<double>(36, &d_Cov);
   double* stats = a.alloc<double>(4, &d_stats);
   int32_t* ran = a.alloc<int32_t>(1, &d_ran);
-  double* Tout = a.alloc<double>(12, &d_Tout);
-  uint8_t* has_out = a.alloc<uint8_t>(n, &d_has_out);
 
   const svo_hip_camera cam = cameraOf(frame->cam_);
-  a.upload(lane.stream);
-  // in/out arrays live in the output block so that one D2H brings everything back
-  svo_hip::check(svo_hip_memcpy_d2d(d_Tout, d_T, 12 * sizeof(double), lane.stream), "svo_hip_memcpy_d2d");
-  svo_hip::check(svo_hip_memcpy_d2d(d_has_out, d_has, n, lane.stream), "svo_hip_memcpy_d2d");
+  a.uploadAll(lane.stream);
   svo_hip::check(svo_hip_pose_optimize(&cam, 1, d_n, (int)n, d_f, d_level, d_pos, d_has_out, reproj_thresh, (int)n_iter, d_Tout,
                                        d_Cov, d_stats, d_ran, lane.stream),
                  "svo_hip_pose_optimize");

@@ -139,11 +139,11 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
       FrameTable frames(dev, L);
       const int i_cur = frames.indexOf(frame.get());
 
-      int32_t *d_cur, *d_ptr; double *d_pos, *d_px_in;
+      int32_t *d_cur, *d_ptr; double* d_pos;
       int32_t* cur = a.alloc<int32_t>(M, &d_cur);
       double* pos = a.alloc<double>(3 * M, &d_pos);
       int32_t* ptr = a.alloc<int32_t>(M + 1, &d_ptr);
-      double* px_in = a.alloc<double>(2 * M, &d_px_in);
+      std::vector<double> px_in(2 * M);  // goes into the in/out block below
       FeatureColumns obs;
       obs.alloc(a, n_obs);
       std::vector<Feature*> obs_ftr(n_obs);
@@ -165,7 +165,8 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
       a.endInputs();
 
       double *d_px, *d_A; int32_t *d_ok, *d_ref, *d_lvl;
-      double* px = a.alloc<double>(2 * M, &d_px);
+      double* px = a.alloc<double>(2 * M, &d_px);  // in: projection, out: refined pixel (uploadAll + download)
+      std::copy(px_in.begin(), px_in.end(), px);
       int32_t* ok = a.alloc<int32_t>(M, &d_ok);
       int32_t* ref = a.alloc<int32_t>(M, &d_ref);
       int32_t* lvl = a.alloc<int32_t>(M, &d_lvl);
@@ -173,8 +174,7 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
 
       const svo_hip_camera cam = cameraOf(frame->cam_);
       void* ws = dev.workspace(lane, (int)M);
-      a.upload(lane.stream);
-      svo_hip::check(svo_hip_memcpy_d2d(d_px, d_px_in, 2 * M * sizeof(double), lane.stream), "svo_hip_memcpy_d2d");
+      a.uploadAll(lane.stream);
       svo_hip::check(svo_hip_find_match_direct(&dev.layout(), dev.store(), &cam, &ft, (int)M, d_cur, d_pos, d_ptr, &obs.dev,
                                                Config::nPyrLevels(), matcher_.options_.align_max_iter, d_px, d_ok, d_ref, d_lvl,
                                                d_A, NULL, ws, lane.workspace_bytes, lane.stream),

@@ -44,6 +44,10 @@ void Arena::upload(void* stream) {
   if (in_end_) check(svo_hip_memcpy_h2d(d_, h_, in_end_, stream), "arena upload");
 }
 
+void Arena::uploadAll(void* stream) {
+  if (used_) check(svo_hip_memcpy_h2d(d_, h_, used_, stream), "arena upload");
+}
+
 void Arena::download(void* stream) {
   if (used_ > in_end_) check(svo_hip_memcpy_d2h(h_ + in_end_, d_ + in_end_, used_ - in_end_, stream), "arena download");
 }

@@ -49,6 +49,8 @@ class Arena {
   }
   void endInputs() { in_end_ = used_; }          // everything allocated so far is kernel input
   void upload(void* stream);                      // H2D of [0, in_end)
+  void uploadAll(void* stream);                   // H2D of [0, used): also blocks a kernel updates in place,
+                                                  // allocated after endInputs() and pre-filled by the host
   void download(void* stream);                    // D2H of [in_end, used)
   // D2H of one block handed out by alloc() (for arrays a kernel updates in place)
   template <typename T> void fetch(T* host_block, size_t n, void* stream) {
