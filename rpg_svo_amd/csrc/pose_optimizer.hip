@@ -49,6 +49,8 @@ struct PoseLds {
   double tile[28][PO_HALF];  // half a chunk at a time: 7 KB instead of 14 KB per frame doubles the frames per CU
   unsigned long long live[PO_BLOCK / 64];  // which lanes of the current chunk contributed
   double acc[28];
+  double dT[6];
+  double new_chi2;
   Se3 T, T_old;
   double scale;
   double median_d;
@@ -252,11 +254,28 @@ __global__ void __launch_bounds__(PO_BLOCK, PO_MINW) pose_opt_kernel(const PoseA
       for (int r = 0; r < 6; ++r) bv[r] = s.acc[21 + r];
       const double new_chi2 = s.acc[27];
       ldlt_solve_pivoted<6>(A, bv, dT);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s.dT[k] = dT[k];
+      s.new_chi2 = new_chi2;
+    }
+    __syncthreads();
+    // sin/cos of theta/2 (lane 0) and theta (lane 1) in one evaluation
+    double sn, cs;
+    {
+      const double dTl[6] = {s.dT[0], s.dT[1], s.dT[2], s.dT[3], s.dT[4], s.dT[5]};
+      const double theta = se3_exp_theta(dTl);
+      sincos((tid & 1) ? theta : 0.5 * theta, &sn, &cs);
+    }
+    const double sin_half = readlane_f64<0>(sn), cos_half = readlane_f64<0>(cs);
+    const double sin_theta = readlane_f64<1>(sn), cos_theta = readlane_f64<1>(cs);
+    if (tid == 0) {
+      const double dT[6] = {s.dT[0], s.dT[1], s.dT[2], s.dT[3], s.dT[4], s.dT[5]};
+      const double new_chi2 = s.new_chi2;
       if ((iter > 0 && new_chi2 > s.chi2) || isnan(dT[0])) {
         s.T = s.T_old;  // roll-back
         s.flag = 1;
       } else {
-        const Se3 ex = se3_exp_full(dT);
+        const Se3 ex = se3_exp_full(dT, sin_half, cos_half, sin_theta, cos_theta);
         const Se3 T_new = se3_compose(ex, s.T);
         s.T_old = s.T;
         s.T = T_new;

@@ -262,20 +262,27 @@ __device__ __forceinline__ void inv_sym(const double* A, double* out) {
 
 // Sophus SE3::exp with libm-grade sin/cos (pose optimizer: increments are applied once per
 // iteration by one lane, accuracy matters more than speed here)
-__device__ inline Se3 se3_exp_full(const double xi[6]) {
+// theta of an increment (the argument of the trigonometric functions below)
+__device__ __forceinline__ double se3_exp_theta(const double xi[6]) {
+  return sqrt(xi[3] * xi[3] + xi[4] * xi[4] + xi[5] * xi[5]);
+}
+
+// The four trigonometric values (sin/cos of theta/2 and of theta) are passed in: the caller
+// evaluates them with ONE sincos over two lanes instead of four serial libm calls in one lane.
+__device__ inline Se3 se3_exp_full(const double xi[6], double sin_half, double cos_half, double sin_theta,
+                                   double cos_theta) {
   Se3 r;
   const double* ups = xi;
   const double* om = xi + 3;
-  const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
-  const double half_theta = 0.5 * theta;
+  const double theta = se3_exp_theta(xi);
   double imag_factor;
-  const double real_factor = cos(half_theta);
+  const double real_factor = cos_half;
   if (theta < 1e-10) {
     const double theta_sq = theta * theta;
     const double theta_po4 = theta_sq * theta_sq;
     imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * theta_po4;
   } else {
-    imag_factor = sin(half_theta) / theta;
+    imag_factor = sin_half / theta;
   }
   r.q[0] = real_factor;
   r.q[1] = imag_factor * om[0];
@@ -294,8 +301,8 @@ __device__ inline Se3 se3_exp_full(const double xi[6]) {
         O2[i * 3 + j] = s;
       }
     const double theta_sq = theta * theta;
-    const double c1 = (1 - cos(theta)) / (theta_sq);
-    const double c2 = (theta - sin(theta)) / (theta_sq * theta);
+    const double c1 = (1 - cos_theta) / (theta_sq);
+    const double c2 = (theta - sin_theta) / (theta_sq * theta);
     for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * O[i] + c2 * O2[i];
   }
   for (int i = 0; i < 3; ++i) r.t[i] = V[i * 3] * ups[0] + V[i * 3 + 1] * ups[1] + V[i * 3 + 2] * ups[2];
