@@ -230,12 +230,16 @@ __global__ void __launch_bounds__(PO_BLOCK, PO_MINW) pose_opt_kernel(const PoseA
             double v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = row[(j0 + u) < PO_HALF ? (j0 + u) : 0];
+            // only the additions form the dependent chain: sign and skip are folded into the
+            // addend (a - b == a + (-b); adding +0.0 to a sum that is never -0.0 changes nothing)
+            double addend[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
               const bool on = ((mk >> u) & 1ull) != 0 && (j0 + u) < m;
-              const double nv = neg ? acc - v[u] : acc + v[u];
-              acc = on ? nv : acc;
+              addend[u] = on ? (neg ? -v[u] : v[u]) : 0.0;
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += addend[u];
           }
           s.acc[tid] = acc;
         }
@@ -291,22 +295,35 @@ __global__ void __launch_bounds__(PO_BLOCK, PO_MINW) pose_opt_kernel(const PoseA
   }
   __syncthreads();
   // ---- covariance (:124-126) --------------------------------------------------------
-  if (tid == 0) {
-    double A[36], Af[36], C[36];
-    int q = 0;
-    for (int r = 0; r < 6; ++r)
-      for (int c = r; c < 6; ++c) {
-        A[r * 6 + c] = s.acc[q];
-        A[c * 6 + r] = s.acc[q];
-        ++q;
-      }
-    const double f2 = focal * focal;  // std::pow(f, 2)
-    for (int k = 0; k < 36; ++k) Af[k] = A[k] * f2;
-    inv_sym<6>(Af, C);
-    if (a.Cov)
-      for (int k = 0; k < 36; ++k) a.Cov[36 * b + k] = 1.0 * C[k];
-    se3_to_Rt(s.T, a.T + 12 * b);
+  // (A f^2)^-1 column by column through the pivoted LDLT: lane j solves for e_j, so the six
+  // solves run side by side (every lane factors the same matrix: same instructions, same bits)
+  if (a.Cov) {
+    double Af[36];
+    {
+      const double f2 = focal * focal;  // std::pow(f, 2)
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) {
+          const double v = s.acc[q] * f2;
+          Af[r * 6 + c] = v;
+          Af[c * 6 + r] = v;
+          ++q;
+        }
+    }
+    LdltReg<6> fac;
+    fac.factor(Af);
+    double e[6], x[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) e[i] = (i == tid) ? 1.0 : 0.0;
+    fac.solve(e, x);
+    if (tid < 6) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) a.Cov[36 * b + i * 6 + tid] = 1.0 * x[i];
+    }
   }
+  if (tid == 0) se3_to_Rt(s.T, a.T + 12 * b);
   // chi2_vec_init median before vals is overwritten
   rank_select<double>(d.vals, n, n_err / 2, &s.median_d);
   __syncthreads();

@@ -5,7 +5,7 @@ from rpg_svo_amd import synth, tracking, capi
 dev=torch.device('cuda:0')
 lib=capi.load()
 cam=synth.Camera(752,480,315.5,315.5,376.0,240.0)
-rng=np.random.default_rng(0)
+rng=np.random.default_rng(0); torch.manual_seed(0)
 N=120
 T=synth.make_trajectory(2, seed=1)
 px=np.stack([rng.uniform(60,690,N), rng.uniform(60,420,N)],-1)[None]
