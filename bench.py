@@ -72,7 +72,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8192, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=16384, help="frames per step per GPU")
     ap.add_argument("--workload", default="vga4_n200_sparse_align", choices=sorted(WORKLOADS))
     ap.add_argument("--noise", type=float, default=0.0, help="image noise sigma (gray levels)")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="frames timed on the host for cpu_baseline")
