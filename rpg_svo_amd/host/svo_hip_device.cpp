@@ -58,10 +58,7 @@ void Arena::fetchBytes(uint8_t* host_block, size_t bytes, void* stream) {
 }
 
 // ---- Device --------------------------------------------------------------------------
-Device::Device() : d_store_(NULL), n_slots_(0), clock_(0) {
-  std::memset(&layout_, 0, sizeof(layout_));
-  for (int l = 0; l < N_LANES; ++l) epoch_[l] = 1;
-}
+Device::Device() : d_store_(NULL), n_slots_(0), clock_(0) { std::memset(&layout_, 0, sizeof(layout_)); }
 Device::~Device() { shutdown(); }
 
 namespace {
@@ -96,12 +93,35 @@ Device& Device::instance() {
   return *g_last;
 }
 
+Lane* Device::makeLane() {
+  Lane* l = new Lane();
+  check(svo_hip_stream_create(&l->stream), "svo_hip_stream_create");
+  l->arena.reserve((size_t)4 << 20);
+  return l;
+}
+
+Lane& Device::lane(int which) {
+  std::lock_guard<std::mutex> g(lanes_mut_);
+  const std::pair<std::thread::id, int> key(std::this_thread::get_id(), which);
+  std::map<std::pair<std::thread::id, int>, Lane*>::iterator it = lanes_.find(key);
+  if (it != lanes_.end()) return *it->second;
+  if (!d_store_) throw Error("svo_hip::Device::lane before configure()");
+  Lane* l = makeLane();
+  lanes_[key] = l;
+  return *l;
+}
+
 void Device::shutdown() {
-  for (int i = 0; i < N_LANES; ++i) {
-    Lane& l = lanes_[i];
-    if (l.stream) { svo_hip_stream_sync(l.stream); svo_hip_stream_destroy(l.stream); l.stream = NULL; }
-    l.arena.release();
-    if (l.d_workspace) { svo_hip_free(l.d_workspace); l.d_workspace = NULL; l.workspace_bytes = 0; }
+  {
+    std::lock_guard<std::mutex> g(lanes_mut_);
+    for (std::map<std::pair<std::thread::id, int>, Lane*>::iterator it = lanes_.begin(); it != lanes_.end(); ++it) {
+      Lane& l = *it->second;
+      if (l.stream) { svo_hip_stream_sync(l.stream); svo_hip_stream_destroy(l.stream); l.stream = NULL; }
+      l.arena.release();
+      if (l.d_workspace) { svo_hip_free(l.d_workspace); l.d_workspace = NULL; l.workspace_bytes = 0; }
+      delete it->second;
+    }
+    lanes_.clear();
   }
   if (d_store_) { svo_hip_free(d_store_); d_store_ = NULL; }
   frames_.clear();
@@ -124,10 +144,6 @@ void Device::configure(int width, int height, int n_levels, int n_slots, int dev
   check(svo_hip_stream_sync(NULL), "svo_hip_stream_sync");
   n_slots_ = n_slots;
   for (int s = n_slots - 1; s >= 0; --s) free_slots_.push_back(s);
-  for (int i = 0; i < N_LANES; ++i) {
-    check(svo_hip_stream_create(&lanes_[i].stream), "svo_hip_stream_create");
-    lanes_[i].arena.reserve((size_t)4 << 20);
-  }
 }
 
 void Device::ensureConfigured(int width, int height, int n_levels) {
@@ -135,30 +151,32 @@ void Device::ensureConfigured(int width, int height, int n_levels) {
   configure(width, height, n_levels);
 }
 
-void Device::beginCall(int which_lane) {
+void Device::beginCall(Lane& lane) {
   std::lock_guard<std::mutex> g(frames_mut_);
-  ++epoch_[which_lane];
+  for (size_t i = 0; i < lane.touched.size(); ++i) {  // the previous call of this lane is over: unpin
+    std::map<int, Entry>::iterator it = frames_.find(lane.touched[i]);
+    if (it != frames_.end() && it->second.pins > 0) --it->second.pins;
+  }
+  lane.touched.clear();
   ++stats.calls;
 }
 
-int Device::slotOf(int frame_id, const uint8_t* level0, int stride, int which_lane) {
+int Device::slotOf(int frame_id, const uint8_t* level0, int stride, Lane& lane) {
   std::lock_guard<std::mutex> g(frames_mut_);
-  Lane& lane = lanes_[which_lane];
+  bool mine = false;
+  for (size_t i = 0; i < lane.touched.size(); ++i) mine = mine || lane.touched[i] == frame_id;
   std::map<int, Entry>::iterator it = frames_.find(frame_id);
   if (it != frames_.end()) {
     it->second.last_use = ++clock_;
-    it->second.epoch[which_lane] = epoch_[which_lane];
+    if (!mine) { ++it->second.pins; lane.touched.push_back(frame_id); }
     return it->second.slot;
   }
   if (free_slots_.empty()) {  // evict the least recently used frame no running call has touched
     std::map<int, Entry>::iterator victim = frames_.end();
-    for (std::map<int, Entry>::iterator e = frames_.begin(); e != frames_.end(); ++e) {
-      bool pinned = false;
-      for (int l = 0; l < N_LANES; ++l) pinned = pinned || e->second.epoch[l] == epoch_[l];
-      if (!pinned && (victim == frames_.end() || e->second.last_use < victim->second.last_use)) victim = e;
-    }
+    for (std::map<int, Entry>::iterator e = frames_.begin(); e != frames_.end(); ++e)
+      if (e->second.pins == 0 && (victim == frames_.end() || e->second.last_use < victim->second.last_use)) victim = e;
     if (victim == frames_.end())
-      throw Error("svo_hip::Device: one call needs more than " + std::to_string(n_slots_) +
+      throw Error("svo_hip::Device: the running calls need more than " + std::to_string(n_slots_) +
                   " frames resident; configure() a larger pool");
     free_slots_.push_back(victim->second.slot);
     frames_.erase(victim);
@@ -168,13 +186,13 @@ int Device::slotOf(int frame_id, const uint8_t* level0, int stride, int which_la
   free_slots_.pop_back();
   check(svo_hip_pyramid_upload_level0(&layout_, d_store_, slot, level0, stride, lane.stream), "svo_hip_pyramid_upload_level0");
   check(svo_hip_pyramid_build(&layout_, d_store_, slot, 1, SVO_HIP_HALFSAMPLE_AUTO, lane.stream), "svo_hip_pyramid_build");
-  // the other lane may consume this slot next: complete the upload before publishing it
+  // another lane may consume this slot next: complete the upload before publishing it
   check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync(upload)");
   Entry en;
   en.slot = slot;
   en.last_use = ++clock_;
-  for (int l = 0; l < N_LANES; ++l) en.epoch[l] = 0;
-  en.epoch[which_lane] = epoch_[which_lane];
+  en.pins = 1;
+  lane.touched.push_back(frame_id);
   frames_[frame_id] = en;
   ++stats.uploads;
   return slot;

@@ -8,9 +8,11 @@
 //     frame_utils::createImgPyramid, svo/src/frame.cpp:156-165, for every device consumer)
 //     the first time a kernel needs it; the pool is an LRU cache (a frame that was evicted
 //     while its host object still lives is simply uploaded again on its next use);
-//   * two "lanes" (tracking thread, mapping thread -- depth_filter.cpp:64-67), each with its
-//     own HIP stream, a pinned host arena and its device mirror, so one call is: fill the
-//     arena -> ONE H2D copy -> kernels -> ONE D2H copy -> stream sync.
+//   * "lanes": per host thread and role (tracking / mapping -- depth_filter.cpp:64-67) a HIP
+//     stream, a pinned host arena and its device mirror, so one call is: fill the arena ->
+//     ONE H2D copy -> kernels -> ONE D2H copy -> stream sync.  Several FrameHandlers driven
+//     from several threads (a camera rig on one GPU) therefore run concurrently on separate
+//     streams; only the pyramid cache is shared.
 #ifndef SVO_HIP_DEVICE_H_
 #define SVO_HIP_DEVICE_H_
 
@@ -20,6 +22,8 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include <svo_hip.h>
@@ -73,6 +77,7 @@ struct Lane {
   void* d_workspace;      // matcher / depth-filter scratch (svo_hip_match_workspace_bytes)
   size_t workspace_bytes;
   std::mutex mut;
+  std::vector<int> touched;  // frames pinned by the lane's current call
   Lane() : stream(NULL), d_workspace(NULL), workspace_bytes(0) {}
 };
 
@@ -100,14 +105,17 @@ class Device {
 
   // Every entry point brackets its work with beginCall(): slots touched since then are
   // pinned (never evicted) until the lane's next beginCall().
-  void beginCall(int which_lane);
+  void beginCall(int which_lane) { beginCall(lane(which_lane)); }
+  void beginCall(Lane& lane);
   // Slot of frame `id`; on a miss the level-0 image (8-bit, `stride` bytes per row) is
   // uploaded and the pyramid built on the lane's stream, evicting the least recently used
   // unpinned frame when the pool is full.
-  int slotOf(int frame_id, const uint8_t* level0, int stride, int which_lane);
+  int slotOf(int frame_id, const uint8_t* level0, int stride, int which_lane) { return slotOf(frame_id, level0, stride, lane(which_lane)); }
+  int slotOf(int frame_id, const uint8_t* level0, int stride, Lane& lane);
   void forget(int frame_id);
 
-  Lane& lane(int which) { return lanes_[which]; }
+  // The calling thread's lane of the given role (created on first use).
+  Lane& lane(int which);
   void* workspace(Lane& lane, int n_trials);  // grows the lane's matcher scratch on demand
 
   // statistics for the latency read-outs
@@ -118,7 +126,7 @@ class Device {
   Device();
   ~Device();
   Device(const Device&);
-  struct Entry { int slot; uint64_t last_use; uint64_t epoch[N_LANES]; };
+  struct Entry { int slot; uint64_t last_use; int pins; };
   svo_hip_pyr_layout layout_;
   uint8_t* d_store_;
   int n_slots_;
@@ -126,8 +134,9 @@ class Device {
   std::map<int, Entry> frames_;
   std::mutex frames_mut_;
   uint64_t clock_;
-  uint64_t epoch_[N_LANES];
-  Lane lanes_[N_LANES];
+  std::mutex lanes_mut_;
+  std::map<std::pair<std::thread::id, int>, Lane*> lanes_;
+  Lane* makeLane();
 };
 
 }  // namespace svo_hip

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "svo_hip_device.h"
@@ -120,6 +121,52 @@ int main() {
   dev.workspace(lane, 200000);
   CHECK(lane.workspace_bytes >= svo_hip_match_workspace_bytes(200000));
   std::puts("ok workspace");
+  // ---- several host threads (a rig of cameras on one GPU): each gets its own lane / stream ------------
+  dev.configure(W, H, LEVELS, /*n_slots=*/16);
+  {
+    const int NT = 6, ROUNDS = 40;
+    std::vector<int> bad(NT, 0);
+    std::vector<Lane*> lanes(NT, (Lane*)NULL);
+    std::vector<std::thread> th;
+    for (int t = 0; t < NT; ++t)
+      th.push_back(std::thread([&, t]() {
+        try {
+          Lane& l = dev.lane(Device::LANE_TRACKING);
+          lanes[t] = &l;
+          std::vector<uint8_t> mine = image(W, H, 100 + t);
+          for (int r = 0; r < ROUNDS; ++r) {
+            dev.beginCall(l);
+            const int a0 = dev.slotOf(1000 + t, mine.data(), W, l);          // this thread's own frame
+            const int a1 = dev.slotOf(2000 + (r + t) % 5, img[(r + t) % 5].data(), W, l);  // shared keyframes
+            if (a0 == a1) bad[t] = 1;
+            Arena& ar = l.arena;
+            ar.reset();
+            double* d_x; double* d_y;
+            double* x = ar.alloc<double>(512, &d_x);
+            for (int i = 0; i < 512; ++i) x[i] = t * 1000.0 + r + i;
+            ar.endInputs();
+            double* y = ar.alloc<double>(512, &d_y);
+            ar.upload(l.stream);
+            check(svo_hip_memcpy_d2d(d_y, d_x, 512 * sizeof(double), l.stream), "d2d");
+            ar.download(l.stream);
+            check(svo_hip_stream_sync(l.stream), "sync");
+            for (int i = 0; i < 512; ++i) if (y[i] != t * 1000.0 + r + i) bad[t] = 2;
+            std::vector<uint8_t> back0((size_t)W * H);
+            check(svo_hip_pyramid_download_level(&dev.layout(), dev.store(), a0, 0, back0.data(), l.stream), "download");
+            if (back0 != mine) bad[t] = 3;
+          }
+        } catch (const Error& e) {
+          std::fprintf(stderr, "thread %d: %s\n", t, e.what());
+          bad[t] = 4;
+        }
+      }));
+    for (size_t t = 0; t < th.size(); ++t) th[t].join();
+    for (int t = 0; t < NT; ++t) {
+      CHECK(bad[t] == 0);
+      for (int u = 0; u < t; ++u) CHECK(lanes[t] != lanes[u] && lanes[t]->stream != lanes[u]->stream);
+    }
+  }
+  std::puts("ok concurrent lanes");
   std::puts("ALL OK");
   return 0;
 }
