@@ -169,6 +169,15 @@ int svo_hip_sparse_align(const svo_hip_pyr_layout* layout, const uint8_t* d_stor
                          int32_t* d_n_tracked, int32_t* d_iters, double* d_chi2,
                          int32_t* d_status, void* stream);
 
+/* The 6x6 solve x = H^-1 b of a batch of problems through hipSOLVER (batched Cholesky: potrf +
+ * potrs), e.g. on the H_out of svo_hip_sparse_align.  NOT used by the kernels (they solve in
+ * registers/LDS inside the persistent loop); exported as an independent cross-check of those
+ * solvers and for hosts that want covariances after the fact.  d_info [B]: potrf status per
+ * problem (0 = positive definite), may be NULL. */
+size_t svo_hip_solve6_hipsolver_workspace_bytes(int B);
+int svo_hip_solve6_hipsolver(int B, const double* d_H, const double* d_b, double* d_x, int32_t* d_info,
+                             void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* ======================================================================== */
 /* Rows a8-a13: the steps FrameHandlerMono::processFrame runs after sparse   */
 /* alignment (svo/src/frame_handler_mono.cpp:145-235) and the depth-filter    */

@@ -54,7 +54,7 @@ def build_hip(force: bool = False, verbose: bool = False, defines: list[str] | N
         with ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
             list(ex.map(lambda so: _compile_one(so[0], so[1], defines or [], verbose), todo))
     if todo or force or not _newer(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lhipsolver", "-o", LIB]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
