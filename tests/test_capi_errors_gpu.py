@@ -1,0 +1,52 @@
+"""Error behaviour of the C ABI: bad arguments are rejected with SVO_HIP_EINVAL / ERANGE before any
+launch, never with a crash (the host wrappers turn the codes into exceptions)."""
+import ctypes as C
+
+import pytest
+import torch
+
+from rpg_svo_amd import capi
+
+pytestmark = pytest.mark.gpu
+EINVAL, ERANGE = -1, -2
+
+
+def test_bad_arguments_are_rejected(hip_lib, gpu_device):
+    lib = hip_lib
+    L = capi.pyr_layout(640, 480, 4)
+    buf = torch.zeros(capi.pyr_store_bytes(L, 2), dtype=torch.uint8, device=gpu_device)
+    p = buf.data_ptr()
+    bad = capi.PyrLayout()
+    # pyramid
+    assert lib.svo_hip_pyramid_build(C.byref(bad), p, 0, 1, 2, None) == EINVAL
+    assert lib.svo_hip_pyramid_build(C.byref(L), None, 0, 1, 2, None) == EINVAL
+    assert lib.svo_hip_pyramid_build(C.byref(L), p, 0, 1, 7, None) == EINVAL           # unknown half-sample flavour
+    assert lib.svo_hip_pyramid_build_from_images(C.byref(L), p, 0, 1, p, 640 * 480, 600, 2, None) == EINVAL   # stride < width
+    assert lib.svo_hip_pyramid_set_tile(300) == EINVAL and lib.svo_hip_pyramid_set_tile(0) == 0
+    # feature alignment / matcher / depth filter
+    assert lib.svo_hip_align_batch(C.byref(L), p, -1, None, None, None, None, None, 10, None, None, None, None) == EINVAL
+    assert lib.svo_hip_align_batch(C.byref(L), p, 0, None, None, None, None, None, 10, None, None, None, None) == 0  # empty batch
+    cam = capi.Camera(400, 400, 320, 240, 640, 480)
+    fr = capi.Frames(0, 0, None, None)
+    ft = capi.Features(None, None, None, None, None, None)
+    assert lib.svo_hip_find_match_direct(C.byref(L), p, C.byref(cam), C.byref(fr), 4, None, None, None, C.byref(ft), 3, 10,
+                                         None, None, None, None, None, None, None, 0, None) < 0
+    sd = capi.Seeds(None, None, None, None, None, None)
+    opt = capi.DepthFilterOptions(3, 0, 200.0, 0, 10, 1000, 1, 1, 3, 0.7)
+    assert lib.svo_hip_update_seeds(C.byref(L), p, C.byref(cam), C.byref(fr), 4, None, C.byref(ft), C.byref(sd), C.byref(opt),
+                                    None, None, None, None, 0, None) < 0
+    assert lib.svo_hip_update_seed_batch(3, None, None, C.byref(sd), None) == EINVAL
+    assert lib.svo_hip_compute_tau_batch(3, None, None, None, 0.001, None, None) == EINVAL
+    # pose / point optimizers
+    assert lib.svo_hip_pose_optimize(None, 1, None, 10, None, None, None, None, 2.0, 10, None, None, None, None, None) == EINVAL
+    assert lib.svo_hip_pose_optimize(C.byref(cam), 1, p, 1 << 20, p, p, p, p, 2.0, 10, p, None, p, p, None) == ERANGE
+    assert lib.svo_hip_point_optimize(None, 1, None, None, None, 5, None, None) < 0
+    # detector
+    assert lib.svo_hip_fast_detect(C.byref(L), p, 1, p, 9, 20, 30, 22, 16, None, 20.0, p, p, p, p, 1 << 30, None) == EINVAL   # levels > layout
+    assert lib.svo_hip_fast_detect(C.byref(L), p, 1, p, 3, 20, 30, 22, 16, None, 20.0, p, p, p, p, 16, None) == ERANGE      # workspace too small
+    # hipSOLVER cross-check, graphs
+    assert lib.svo_hip_solve6_hipsolver(2, p, p, p, None, p, 8, None) == ERANGE
+    assert lib.svo_hip_graph_end_capture(None, None) == EINVAL
+    assert b"invalid" in lib.svo_hip_strerror(EINVAL) and b"limit" in lib.svo_hip_strerror(ERANGE)
+    torch.cuda.synchronize()  # nothing above may have poisoned the context
+    assert int(buf.sum().item()) == 0

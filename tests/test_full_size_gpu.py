@@ -92,3 +92,44 @@ def test_config4_rig_752_default_schedule_parity(oracle, gpu_device):
     Th, out, _ = run_hip(b, 4, 2)
     d = se3.log_norm(Th, To)
     assert d.max() <= 1e-4 and np.median(d) <= 1e-5
+
+
+def test_store_beyond_4gib_addresses_correctly(gpu_device, big_vga):
+    """A pyramid store of 11 000 VGA slots (4.55 GB): slots above the 4 GiB mark must behave exactly
+    like slots 0/1 (64-bit slot offsets in every kernel that touches the store)."""
+    from rpg_svo_amd.pyramid import PyramidStore
+    from rpg_svo_amd.sparse_img_align import SparseImgAlign, marshal_problem
+    from rpg_svo_amd import tracking
+    n_slots = 11000
+    store = PyramidStore(640, 480, 4, n_slots, device=gpu_device)
+    assert store.buf.numel() > (1 << 32)
+    imgs = big_vga.images[:2].to(gpu_device)
+    store.load_images(imgs, first_slot=0)
+    store.load_images(imgs, first_slot=n_slots - 2)
+    for l in range(4):
+        assert np.array_equal(store.level(0, l), store.level(n_slots - 2, l))
+        assert np.array_equal(store.level(1, l), store.level(n_slots - 1, l))
+    b = make_batch(big_vga, [(0, 1)], 4)
+    T_cr, xyz = marshal_problem(b.T_ref_w, b.T_cur_w, b.f, b.pos)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=gpu_device)
+    sia = SparseImgAlign(3, 0, 30)
+    outs = []
+    for ref, cur in ((0, 1), (n_slots - 2, n_slots - 1)):
+        o = sia.run(store, b.cam, t([ref], torch.int32), t([cur], torch.int32), t(b.n, torch.int32), t(b.px, torch.float64),
+                    t(xyz, torch.float64), t(T_cr, torch.float64))
+        outs.append((o.T_cur_from_ref.cpu().numpy(), o.iters.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    # the detector and the matcher front end read the store too
+    from rpg_svo_amd.feature_detection import FastDetector
+    det = FastDetector(640, 480, 30, 3)
+    a = det.detect(store, t([0, n_slots - 2], torch.int32), 20.0)
+    assert torch.equal(a[0][0], a[0][1]) and torch.equal(a[2][0], a[2][1])
+    pwb = torch.randint(0, 256, (64, 100), dtype=torch.uint8, device=gpu_device)
+    px0 = torch.rand(64, 2, dtype=torch.float64, device=gpu_device) * 200 + 100
+    res = []
+    for s in (1, n_slots - 1):
+        px = px0.clone()
+        ok, _ = tracking.align_batch(store, torch.full((64,), s, dtype=torch.int32, device=gpu_device),
+                                     torch.zeros(64, dtype=torch.int32, device=gpu_device), pwb, px, 10)
+        res.append((px.cpu().numpy(), ok.cpu().numpy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
