@@ -34,3 +34,27 @@ def test_device_arena_and_pyramid_cache(hip_lib, gpu_device):
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stderr
     assert "ALL OK" in r.stdout
+
+
+EXAMPLE = os.path.join(ROOT, "build", "sparse_align_batch")
+
+
+def _build_example():
+    os.makedirs(os.path.dirname(EXAMPLE), exist_ok=True)
+    lib = os.path.join(ROOT, "rpg_svo_amd", "lib")
+    subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "sparse_align_batch.cpp"), "-L", lib, "-lsvo_hip", f"-Wl,-rpath,{lib}",
+                    "-o", EXAMPLE], check=True)
+
+
+def test_cxx_example_builds(hip_lib):
+    _build_example()
+
+
+@pytest.mark.gpu
+def test_cxx_example_recovers_the_motion(hip_lib, gpu_device):
+    """The C ABI driven from plain C++ end to end: upload, K0, K1 on 1024 problems, poses back."""
+    _build_example()
+    r = subprocess.run([EXAMPLE, "1024"], capture_output=True, text=True, timeout=120)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "OK" in r.stdout
