@@ -34,4 +34,13 @@ inline bool layout_ok(const svo_hip_pyr_layout* L) {
   return L->slot_bytes > 0;
 }
 
+// XCD-aware workgroup order.  Workgroup ids are dealt round-robin to the 8 XCDs of an MI355X, each
+// with its own L2.  Work items that are neighbours in memory (the trials of one frame, the
+// problems that share a frame) are neighbours in the batch, so every XCD is handed a CONTIGUOUS
+// eighth of the grid instead of every eighth workgroup.  Identity when the grid is not a multiple of 8.
+__device__ __forceinline__ unsigned xcd_contiguous_block() {
+  const unsigned nb = gridDim.x, bid = blockIdx.x;
+  return (nb % 8u == 0u) ? (bid % 8u) * (nb / 8u) + bid / 8u : bid;
+}
+
 }  // namespace svo_capi

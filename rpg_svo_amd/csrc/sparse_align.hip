@@ -199,12 +199,9 @@ __device__ __forceinline__ void sia_rebuild_hinv(int lane, int nw) {
 template <int BLOCK, bool WC>
 __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a) {
   constexpr int NW = BLOCK / 64;
-  // XCD-aware problem order.  Workgroup ids are dealt round-robin to the 8 XCDs (each with its own
-  // L2); in a replay batch consecutive problems share a frame (frame b+1 is the current image of
-  // problem b and the reference image of problem b+1), so each XCD is given a CONTIGUOUS range of
-  // problems instead of every eighth one.
-  const int nb = (int)gridDim.x;
-  const int b = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  // XCD-aware problem order (capi_common.h): in a replay batch consecutive problems share a frame
+  // (frame b+1 is the current image of problem b and the reference image of problem b+1)
+  const int b = (int)xcd_contiguous_block();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
