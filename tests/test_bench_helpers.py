@@ -1,0 +1,46 @@
+"""bench.py's bookkeeping (CPU only): the algorithmic-byte formula of SURVEY 8(d) and the ATE helper."""
+import importlib.util
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+
+
+def test_algorithmic_bytes_formula():
+    # SURVEY 8(d) worked example: VGA-4, N = 200 all visible, 4 levels, 10 iterations per level:
+    # 4*200*49 (7x7 reference windows) + 4*200*10*25 (5x5 current windows) + geometry + fixed I/O
+    B = 3
+    n = np.full(B, 200.0)
+    iters = np.zeros((B, 8))
+    iters[:, :4] = 10
+    got = bench.algorithmic_bytes(n, n, iters, 3, 0)
+    per_frame = 4 * 200 * 49 + 4 * 200 * 10 * 25 + 41 * 200 + 540
+    assert got == B * per_frame
+    # only the levels of the schedule count; untracked patches fetch no windows
+    iters2 = np.zeros((1, 8)); iters2[0, 2:5] = [3, 2, 4]
+    got = bench.algorithmic_bytes(np.array([120.0]), np.array([100.0]), iters2, 4, 2)
+    assert got == 100 * ((49 + 25 * 3) + (49 + 25 * 2) + (49 + 25 * 4)) + 41 * 120 + 540
+
+
+def test_horn_ate_invariance():
+    rng = np.random.default_rng(0)
+    P = rng.normal(size=(50, 3))
+    th = 0.7
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    Q = P @ R.T + np.array([3.0, -1.0, 2.0])
+    assert bench.horn_ate(P, Q) < 1e-12
+    assert abs(bench.horn_ate(P, Q + np.array([0.0, 0.0, 0.0])) - 0.0) < 1e-12
+    Qn = Q.copy(); Qn[0] += 0.5   # one outlier of 0.5*sqrt(3) m among 50 poses: rmse ~ 0.87/sqrt(50) = 0.12
+    assert 0.08 < bench.horn_ate(P, Qn) < 0.16
+
+
+def test_workloads_match_baseline_configs():
+    w = bench.WORKLOADS
+    assert w["vga4_n200_sparse_align"][:7] == (640, 480, 400.0, 4, 3, 0, 200)          # configs[1]
+    assert w["xga5_n1000_sparse_align"][:7] == (1280, 960, 800.0, 5, 4, 0, 1000)       # configs[3]
+    assert w["svo_default_752_l4to2_n120"][:7] == (752, 480, 315.5, 5, 4, 2, 120)      # configs[0]/[4] geometry
+    assert bench.HBM_PEAK_GBS == 8000.0
