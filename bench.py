@@ -67,6 +67,29 @@ def horn_ate(P: np.ndarray, Q: np.ndarray) -> float:
     return float(np.sqrt((err ** 2).sum(1).mean()))
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def spawn_command(n_gpus: int, argv: list[str], port: int) -> list[str]:
+    """The launch line of the contract (one rank per GPU of one node, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def spawn_ranks(n_gpus: int) -> int:
+    """`python bench.py --gpus N` from a plain shell: re-launch under torch.distributed.run."""
+    import subprocess
+    cmd = spawn_command(n_gpus, sys.argv[1:], free_port())
+    if os.environ.get("SVO_BENCH_DRY_SPAWN") == "1":
+        print(json.dumps({"spawn": cmd}))
+        return 0
+    return subprocess.call(cmd)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,20 +109,26 @@ def main() -> None:
                          "sparse align + reprojection matching (align2D) + pose refinement + depth-filter update")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))  # plain `python bench.py --gpus N`: one rank per GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible); "
+                         "one process per GPU is the only supported mapping")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # SVO_BENCH_FORCE_DIST=1 runs the RCCL code path (process group, overlapped gather) even with a
+    # single rank: the 1-GPU box can then exercise it (tests/test_bench_dist_gpu.py)
+    use_dist = world > 1 or os.environ.get("SVO_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     lib = capi.load()
 
@@ -138,7 +167,7 @@ def main() -> None:
     # region ends only after the last gather has completed.  SVO_BENCH_SYNC_GATHER=1: blocking gather.
     gather = None
     outs = [out]
-    if world > 1:
+    if use_dist:
         from rpg_svo_amd.dist import OverlappedPoseGather
         gather = OverlappedPoseGather(B, 12, torch.float64, dev)
         if os.environ.get("SVO_BENCH_SYNC_GATHER") != "1":
@@ -196,7 +225,7 @@ def main() -> None:
     if gather is not None:
         gather.drain()
     torch.cuda.synchronize()
-    if args.graph and world > 1:
+    if args.graph and use_dist:
         raise SystemExit("--graph replays fixed buffers; combine it with the overlapped gather only at --gpus 1")
     if args.graph:
         # torch's graph object is the capture front end (private allocator pool for the tensors the
@@ -211,7 +240,7 @@ def main() -> None:
         with torch.cuda.graph(graph):
             step_compute(None)
         torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -220,14 +249,32 @@ def main() -> None:
     if gather is not None:
         gather.drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    gather_stats = None
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # the exchange step on its own (untimed region): blocking all-gathers of one pose block
+        reps = 20
+        for _ in range(3):
+            gather.submit(0)
+            gather.result(0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        for _ in range(reps):
+            gather.submit(0)
+            gather.result(0)
+        torch.cuda.synchronize()
+        tg = torch.tensor([(time.perf_counter() - tg) / reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        gather_stats = {"collective": "all_gather_into_tensor (RCCL)", "bytes_per_rank_per_step": int(B * 12 * 8),
+                        "bytes_gathered_per_step": int(world * B * 12 * 8), "ms_blocking_avg": float(tg.item()) * 1e3,
+                        "overlapped_in_timed_region": len(outs) > 1}
 
     # per-launch kernel duration from HIP events on the launch stream
     kms = []
@@ -238,8 +285,7 @@ def main() -> None:
     kernel_ms = float(np.mean(kms)) if kms else float("nan")
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     out = outs[(counter[0] - 1) % len(outs)]  # the result block of the last step
@@ -315,8 +361,10 @@ def main() -> None:
             result["dropin_sequence"] = dropin_sequence()
         except Exception as e:  # the demonstration libraries are optional (built from the reference checkout)
             result["dropin_sequence"] = {"skipped": str(e)}
+    if gather_stats is not None:
+        result["gather"] = gather_stats
     print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -117,10 +117,13 @@ int svo_hip_pyramid_build(const svo_hip_pyr_layout* layout, uint8_t* d_store, in
 int svo_hip_pyramid_build_from_images(const svo_hip_pyr_layout* layout, uint8_t* d_store, int first_slot,
                                       int n_slots, const uint8_t* d_images, int64_t image_stride,
                                       int row_stride, int halfsample_mode, void* stream);
-/* Tuning knob: level-0 tile of the fused builder: 128 (128x64), 256 (256x32), 257 (256x32 with
- * non-temporal level-0 traffic) or 512 (256x64, two row blocks per lane); 0 = choose by image
- * size (the default: 257 for widths >= 256).  Results do not depend on it. */
-int svo_hip_pyramid_set_tile(int tile_width);
+/* The two builders above with the level-0 tile of the fused kernel chosen by the caller instead of
+ * by image size: 128 (128x64), 256 (256x32), 257 (256x32 with non-temporal level-0 traffic), 512
+ * (256x64, two row blocks per lane), 0 = automatic (257 for widths >= 256).  d_images may be NULL
+ * (level 0 already in the store).  Results do not depend on the tile; there is no global state. */
+int svo_hip_pyramid_build_tiled(const svo_hip_pyr_layout* layout, uint8_t* d_store, int first_slot, int n_slots,
+                                const uint8_t* d_images, int64_t image_stride, int row_stride,
+                                int halfsample_mode, int tile_width, void* stream);
 /* The one-launch-per-level builder svo_hip_pyramid_build used before the fused kernel; same
  * results, kept for A/B timing. */
 int svo_hip_pyramid_build_per_level(const svo_hip_pyr_layout* layout, uint8_t* d_store, int first_slot,
@@ -229,6 +232,15 @@ int svo_hip_align_batch(const svo_hip_pyr_layout* layout, const uint8_t* d_store
                         const uint8_t* d_use_1d, int n_iter, double* d_px, int32_t* d_ok,
                         double* d_h_inv, void* stream);
 
+/* Same, plus d_evaluations [M]: residual evaluations (9x9 windows read) per trial.  Instrumented
+ * variant for roofline accounting (bytes per trial = 100 + 81 * evaluations); results are
+ * identical to svo_hip_align_batch. */
+int svo_hip_align_batch_counted(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int M,
+                                const int32_t* d_slot, const int32_t* d_level,
+                                const uint8_t* d_patch_with_border, const float* d_dir,
+                                const uint8_t* d_use_1d, int n_iter, double* d_px, int32_t* d_ok,
+                                double* d_h_inv, int32_t* d_evaluations, void* stream);
+
 /* bytes of scratch the matcher / depth-filter entry points need for M trials */
 size_t svo_hip_match_workspace_bytes(int M);
 
@@ -277,8 +289,15 @@ int svo_hip_cam2world(const svo_hip_camera* cam, int n, const double* d_px, doub
                       void* stream);
 
 /*
- * K4: batched pose_optimizer::optimizeGaussNewton (svo/src/pose_optimizer.cpp:28-161), one
- * workgroup per frame.  Observations of frame b are rows [b*n_stride, b*n_stride+d_n[b]):
+ * K4: batched pose_optimizer::optimizeGaussNewton (svo/src/pose_optimizer.cpp:28-161).
+ * Observations of frame b are rows [b*n_stride, b*n_stride+d_n[b]); d_n[b] <= n_stride is the
+ * caller's contract (the kernels clamp it, they never read past a frame's row).
+ *   svo_hip_pose_optimize          one wave per frame, f64 sums reduced by a wave butterfly:
+ *                                  pose within 1e-9 (SE(3) log norm) of the reference, pruning
+ *                                  decisions and medians exact.  n_stride > 256 runs the
+ *                                  ordered kernel.
+ *   svo_hip_pose_optimize_ordered  one workgroup per frame, sums in the reference's observation
+ *                                  order (normal equations reproduced to the bit): the checker.
  *   d_f [B][n_stride][3]   Feature::f
  *   d_level [B][n_stride]  Feature::level
  *   d_pos [B][n_stride][3] Feature::point->pos_
@@ -294,6 +313,11 @@ int svo_hip_pose_optimize(const svo_hip_camera* cam, int B, const int32_t* d_n, 
                           uint8_t* d_has_point, double reproj_thresh, int n_iter,
                           double* d_T_f_w, double* d_Cov, double* d_stats, int32_t* d_ran,
                           void* stream);
+int svo_hip_pose_optimize_ordered(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride,
+                                  const double* d_f, const int32_t* d_level, const double* d_pos,
+                                  uint8_t* d_has_point, double reproj_thresh, int n_iter,
+                                  double* d_T_f_w, double* d_Cov, double* d_stats, int32_t* d_ran,
+                                  void* stream);
 
 /*
  * K6: batched Point::optimize (svo/src/point.cpp:119-177).  Point p has observations
@@ -351,6 +375,11 @@ int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint8_t* d_stor
                          const svo_hip_seeds* seeds, const svo_hip_depth_filter_options* opt,
                          int32_t* d_status, double* d_xyz_world, double* d_px_cur,
                          void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Device pointer to n_steps [S] of the last svo_hip_update_seeds call that used this workspace: the
+ * number of epipolar-line positions scanned per seed (matcher.cpp:248, 0 where no scan ran).  For
+ * roofline accounting (64 B scanned per step). */
+const int32_t* svo_hip_update_seeds_scan_steps(const void* d_workspace);
 
 /* DepthFilter::updateSeed(x, tau2, seed) for S independent (x, tau2) measurements */
 int svo_hip_update_seed_batch(int S, const float* d_x, const float* d_tau2,

@@ -10,6 +10,7 @@
 // Output: oracle/_ref/libsvo_ref.so (git-ignored; travels with gpurun).  Used by
 // tests/test_oracle_vs_ref.py to pin the C restatement, never by the product.
 #include <atomic>
+#include <malloc.h>
 #include <chrono>
 #include <cstring>
 #include <map>
@@ -218,6 +219,13 @@ int ref_sparse_img_align_batch(int B, const orc_pyramid* pyrs, const int* ref_sl
     }
   }
   if (n_threads < 1) n_threads = 1;
+  // SparseImgAlign::run allocates its caches per call (jacobian_cache_ is 150 KB at 200 patches:
+  // above glibc's mmap threshold, i.e. an mmap + page faults + munmap per frame, all serialised
+  // on the process' mm lock).  Serve them from the per-thread malloc arenas instead, so that the
+  // many-thread baseline measures the reference's arithmetic and not the kernel's VM lock.
+  mallopt(M_MMAP_THRESHOLD, 64 << 20);
+  mallopt(M_TRIM_THRESHOLD, 512 << 20);
+  mallopt(M_ARENA_MAX, 1024);
   std::atomic<int> next(0);
   auto worker = [&]() {
     for (;;) {

@@ -110,7 +110,7 @@ PROTOTYPES = {
     "svo_hip_pyramid_upload_level0": (_i, [C.POINTER(PyrLayout), _vp, _i, _vp, _i, _vp]),
     "svo_hip_pyramid_build": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _i, _vp]),
     "svo_hip_pyramid_build_from_images": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _i64, _i, _i, _vp]),
-    "svo_hip_pyramid_set_tile": (_i, [_i]),
+    "svo_hip_pyramid_build_tiled": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _i64, _i, _i, _i, _vp]),
     "svo_hip_pyramid_build_per_level": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _i, _vp]),
     "svo_hip_pyramid_download_level": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _vp]),
     "svo_hip_sparse_align": (_i, [C.POINTER(PyrLayout), _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp,
@@ -118,6 +118,8 @@ PROTOTYPES = {
     "svo_hip_solve6_hipsolver_workspace_bytes": (C.c_size_t, [_i]),
     "svo_hip_solve6_hipsolver": (_i, [_i, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "svo_hip_align_batch": (_i, [_LP, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "svo_hip_align_batch_counted": (_i, [_LP, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "svo_hip_update_seeds_scan_steps": (_vp, [_vp]),
     "svo_hip_match_workspace_bytes": (C.c_size_t, [_i]),
     "svo_hip_find_match_direct": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, _vp, _vp,
                                        C.POINTER(Features), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
@@ -126,6 +128,8 @@ PROTOTYPES = {
     "svo_hip_cam2world": (_i, [C.POINTER(Camera), _i, _vp, _vp, _vp]),
     "svo_hip_pose_optimize": (_i, [C.POINTER(Camera), _i, _vp, _i, _vp, _vp, _vp, _vp, C.c_double, _i, _vp, _vp, _vp,
                                    _vp, _vp]),
+    "svo_hip_pose_optimize_ordered": (_i, [C.POINTER(Camera), _i, _vp, _i, _vp, _vp, _vp, _vp, C.c_double, _i, _vp, _vp,
+                                           _vp, _vp, _vp]),
     "svo_hip_point_optimize": (_i, [C.POINTER(Frames), _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "svo_hip_update_seeds": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, C.POINTER(Features),
                                   C.POINTER(Seeds), C.POINTER(DepthFilterOptions), _vp, _vp, _vp, _vp, C.c_size_t, _vp]),

@@ -58,7 +58,8 @@ struct SeedWs {
   double* px_cur;     // [S][2] Matcher::px_cur_
   double* uv_best;    // [S][2]
   uint8_t* pwb;       // [S][100]
-  int32_t* align_ok;  // [S]
+  int32_t* align_ok;  // [S] written by the alignment kernel only
+  uint8_t* accepted_raw;  // [S] 1: scan match accepted without sub-pixel refinement (subpix_refinement == false)
 };
 
 struct SeedArgs {
@@ -92,6 +93,7 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   w.ref_level[s] = 0;
   w.n_steps[s] = 0;
   w.align_ok[s] = 0;
+  w.accepted_raw[s] = 0;
   w.dir[2 * s] = 1.f;
   w.dir[2 * s + 1] = 0.f;
   w.px_scaled[2 * s] = w.px_scaled[2 * s + 1] = 0.0;
@@ -320,8 +322,10 @@ __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) 
     w.px_cur[2 * s + 1] = pc1;
     w.px_scaled[2 * s] = pc0 / lvl;
     w.px_scaled[2 * s + 1] = pc1 / lvl;
+    // matcher.cpp:293-318: refine with align1D/2D, or triangulate straight from uv_best.  The
+    // second case is flagged in its own array: the alignment kernel clears ok[] of inactive trials.
     w.align_active[s] = a.opt.subpix_refinement ? 1 : 0;
-    w.align_ok[s] = a.opt.subpix_refinement ? 0 : 2;  // 2: accepted without refinement
+    w.accepted_raw[s] = a.opt.subpix_refinement ? 0 : 1;
   }
   if (lane == 0 && !(win_score < ZMSSD_THRESHOLD)) w.status[s] = SVO_HIP_SEED_NO_MATCH;
 }
@@ -434,7 +438,7 @@ __global__ void __launch_bounds__(64) seed_finish_kernel(const SeedArgs a) {
       double fc[3];
       cam2world(a.cam, w.px_cur[2 * s], w.px_cur[2 * s + 1], fc);
       matched = depth_from_triangulation(T_cur_ref, f, fc, &z);
-    } else if (aok == 2) {
+    } else if (w.accepted_raw[s]) {
       // subpix_refinement == false: vk::unproject2d(uv_best).normalized()
       double fc[3] = {w.uv_best[2 * s], w.uv_best[2 * s + 1], 1.0};
       normalize3(fc);
@@ -564,6 +568,7 @@ extern "C" int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint
   a.xyz_world = d_xyz_world;
   a.px_cur_out = d_px_cur;
   SeedWs& w = a.ws;
+  w.n_steps = c.take<int32_t>(n);  // first array of the workspace: svo_hip_update_seeds_scan_steps
   w.pwb = c.take<uint8_t>(n * 100);
   w.warp_active = c.take<uint8_t>(n);
   w.align_active = c.take<uint8_t>(n);
@@ -574,8 +579,8 @@ extern "C" int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint
   w.ref_level = c.take<int32_t>(n);
   w.cur_slot = c.take<int32_t>(n);
   w.search_level = c.take<int32_t>(n);
-  w.n_steps = c.take<int32_t>(n);
   w.align_ok = c.take<int32_t>(n);
+  w.accepted_raw = c.take<uint8_t>(n);
   w.A_ref_cur = c.take<float>(4 * n);
   w.px_ref_pyr = c.take<float>(2 * n);
   w.dir = c.take<float>(2 * n);
@@ -625,6 +630,10 @@ extern "C" int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint
   if (rc) return rc;
   hipLaunchKernelGGL(seed_finish_kernel, dim3((S + 63) / 64), dim3(64), 0, st, a);
   return check_launch();
+}
+
+extern "C" const int32_t* svo_hip_update_seeds_scan_steps(const void* d_workspace) {
+  return static_cast<const int32_t*>(d_workspace);
 }
 
 extern "C" int svo_hip_update_seed_batch(int S, const float* d_x, const float* d_tau2, const svo_hip_seeds* seeds,

@@ -54,9 +54,11 @@ __device__ __forceinline__ int floor_int(float x) {
 
 // align2D, feature_alignment.cpp:149-277.  Returns converged; (u,v) in/out.
 __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, int cols, int rows, int pitch,
-                                             const uint32_t g[25], int n_iter, float& u, float& v, bool& wrote) {
+                                             const uint32_t g[25], int n_iter, float& u, float& v, bool& wrote,
+                                             int& n_eval) {
   bool converged = false;
   wrote = true;
+  n_eval = 0;  // residual evaluations (9x9 windows read); dead code unless the caller stores it
   // H = sum J J', J = (dx, dy, 1); dx,dy are multiples of 0.5 -> every partial sum is exact
   float H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -85,6 +87,7 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
       wrote = false;
       return false;
     }
+    ++n_eval;
     const float subpix_x = u - (float)u_r;
     const float subpix_y = v - (float)v_r;
     const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
@@ -127,9 +130,10 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
 // align1D, feature_alignment.cpp:30-147
 __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, int cols, int rows, int pitch,
                                              const uint32_t g[25], float dir0, float dir1, int n_iter, float& u,
-                                             float& v, double& h_inv, bool& wrote) {
+                                             float& v, double& h_inv, bool& wrote, int& n_eval) {
   bool converged = false;
   wrote = true;
+  n_eval = 0;
   float H[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int y = 0; y < 8; ++y)
@@ -159,6 +163,7 @@ __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, in
       wrote = false;
       return false;
     }
+    ++n_eval;
     const float subpix_x = u - (float)u_r;
     const float subpix_y = v - (float)v_r;
     const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
@@ -206,11 +211,13 @@ __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, in
 
 constexpr int ALIGN_BLOCK = 64;
 
+template <bool COUNT>
 __global__ void __launch_bounds__(ALIGN_BLOCK) align_kernel(const AlignArgs a) {
   const int t = blockIdx.x * ALIGN_BLOCK + threadIdx.x;
   if (t >= a.M) return;
   if (a.active && !a.active[t]) {
     a.ok[t] = 0;  // px_out is left as it is (findMatchDirect returns before touching px_cur)
+    if (COUNT) a.iters[t] = 0;
     return;
   }
   const int level = a.level[t];
@@ -226,14 +233,16 @@ __global__ void __launch_bounds__(ALIGN_BLOCK) align_kernel(const AlignArgs a) {
   float v = (float)a.px_in[2 * t + 1];
   bool wrote = true;
   bool ok;
+  int n_eval = 0;
   const bool one_d = a.use_1d && a.use_1d[t];
   if (one_d) {
     double h_inv = 0;
-    ok = align1d_lane(img, cols, rows, pitch, g, a.dir[2 * t], a.dir[2 * t + 1], a.n_iter, u, v, h_inv, wrote);
+    ok = align1d_lane(img, cols, rows, pitch, g, a.dir[2 * t], a.dir[2 * t + 1], a.n_iter, u, v, h_inv, wrote, n_eval);
     if (a.h_inv) a.h_inv[t] = h_inv;
   } else {
-    ok = align2d_lane(img, cols, rows, pitch, g, a.n_iter, u, v, wrote);
+    ok = align2d_lane(img, cols, rows, pitch, g, a.n_iter, u, v, wrote, n_eval);
   }
+  if (COUNT) a.iters[t] = n_eval;
   a.ok[t] = ok ? 1 : 0;
   double ou = wrote ? (double)u : a.px_in[2 * t];
   double ov = wrote ? (double)v : a.px_in[2 * t + 1];
@@ -250,15 +259,17 @@ __global__ void __launch_bounds__(ALIGN_BLOCK) align_kernel(const AlignArgs a) {
 namespace svo_track {
 int launch_align(const AlignArgs& a, hipStream_t s) {
   if (a.M <= 0) return SVO_HIP_OK;
-  hipLaunchKernelGGL(align_kernel, dim3((a.M + ALIGN_BLOCK - 1) / ALIGN_BLOCK), dim3(ALIGN_BLOCK), 0, s, a);
+  const dim3 grid((a.M + ALIGN_BLOCK - 1) / ALIGN_BLOCK), blk(ALIGN_BLOCK);
+  if (a.iters) hipLaunchKernelGGL(align_kernel<true>, grid, blk, 0, s, a);  // instrumented: also counts evaluations
+  else hipLaunchKernelGGL(align_kernel<false>, grid, blk, 0, s, a);
   return check_launch();
 }
 }  // namespace svo_track
 
-extern "C" int svo_hip_align_batch(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int M,
-                                   const int32_t* d_slot, const int32_t* d_level,
-                                   const uint8_t* d_patch_with_border, const float* d_dir, const uint8_t* d_use_1d,
-                                   int n_iter, double* d_px, int32_t* d_ok, double* d_h_inv, void* stream) {
+static int align_batch(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int M, const int32_t* d_slot,
+                       const int32_t* d_level, const uint8_t* d_patch_with_border, const float* d_dir,
+                       const uint8_t* d_use_1d, int n_iter, double* d_px, int32_t* d_ok, double* d_h_inv,
+                       int32_t* d_iters, void* stream) {
   if (!layout_ok(layout) || !d_store || M < 0 || n_iter < 0) return SVO_HIP_EINVAL;
   if (M == 0) return SVO_HIP_OK;
   if (!d_slot || !d_level || !d_patch_with_border || !d_px || !d_ok) return SVO_HIP_EINVAL;
@@ -280,5 +291,24 @@ extern "C" int svo_hip_align_batch(const svo_hip_pyr_layout* layout, const uint8
   a.scale_out = 0;
   a.ok = d_ok;
   a.h_inv = d_h_inv;
+  a.iters = d_iters;
   return launch_align(a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int svo_hip_align_batch(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int M,
+                                   const int32_t* d_slot, const int32_t* d_level,
+                                   const uint8_t* d_patch_with_border, const float* d_dir, const uint8_t* d_use_1d,
+                                   int n_iter, double* d_px, int32_t* d_ok, double* d_h_inv, void* stream) {
+  return align_batch(layout, d_store, M, d_slot, d_level, d_patch_with_border, d_dir, d_use_1d, n_iter, d_px, d_ok, d_h_inv,
+                     nullptr, stream);
+}
+
+extern "C" int svo_hip_align_batch_counted(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int M,
+                                           const int32_t* d_slot, const int32_t* d_level,
+                                           const uint8_t* d_patch_with_border, const float* d_dir,
+                                           const uint8_t* d_use_1d, int n_iter, double* d_px, int32_t* d_ok,
+                                           double* d_h_inv, int32_t* d_evaluations, void* stream) {
+  if (!d_evaluations) return SVO_HIP_EINVAL;
+  return align_batch(layout, d_store, M, d_slot, d_level, d_patch_with_border, d_dir, d_use_1d, n_iter, d_px, d_ok, d_h_inv,
+                     d_evaluations, stream);
 }

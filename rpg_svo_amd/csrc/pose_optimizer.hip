@@ -43,6 +43,7 @@ struct PoseArgs {
   double* Cov;
   double* stats;
   int32_t* ran;
+  int only_flagged;  // 1: work only on frames the wave kernel handed over (ran[b] == 2)
 };
 
 struct PoseLds {
@@ -109,7 +110,9 @@ __global__ void __launch_bounds__(PO_BLOCK, PO_MINW) pose_opt_kernel(const PoseA
   d.hp = reinterpret_cast<uint8_t*>(d.err + ns8);
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
-  const int n = a.n[b];
+  if (a.only_flagged && a.ran[b] != 2) return;
+  int n = a.n[b];
+  n = n < 0 ? 0 : (n > a.n_stride ? a.n_stride : n);  // contract: n <= n_stride; never index past the row
   const size_t base = (size_t)b * a.n_stride;
   const double focal = fabs(a.cam.fx);
 
@@ -367,7 +370,7 @@ __global__ void __launch_bounds__(PO_BLOCK, PO_MINW) pose_opt_kernel(const PoseA
     if (d.err[i] == 2.f) a.has_point[base + i] = 0;  // (*it)->point = NULL
   if (tid == 0) {
     a.stats[4 * b + 0] = estimated_scale * focal;
-    a.stats[4 * b + 1] = sqrt(med_init) * focal;
+    a.stats[4 * b + 1] = a.n_iter > 0 ? sqrt(med_init) * focal : 0.0;  // chi2_vec_init empty without an iteration
     a.stats[4 * b + 2] = sqrt(s.median_d) * focal;
     a.stats[4 * b + 3] = (double)(n_err - n_deleted);
     a.ran[b] = 1;
@@ -376,14 +379,20 @@ __global__ void __launch_bounds__(PO_BLOCK, PO_MINW) pose_opt_kernel(const PoseA
 
 }  // namespace
 
-extern "C" int svo_hip_pose_optimize(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride,
-                                     const double* d_f, const int32_t* d_level, const double* d_pos,
-                                     uint8_t* d_has_point, double reproj_thresh, int n_iter, double* d_T_f_w,
-                                     double* d_Cov, double* d_stats, int32_t* d_ran, void* stream) {
+static int pose_args_check(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride, const double* d_f,
+                           const int32_t* d_level, const double* d_pos, uint8_t* d_has_point, int n_iter,
+                           double* d_T_f_w, double* d_stats, int32_t* d_ran) {
   if (!cam || B < 0 || n_stride < 1 || n_iter < 0) return SVO_HIP_EINVAL;
   if (n_stride > PO_MAXN) return SVO_HIP_ERANGE;
-  if (B == 0) return SVO_HIP_OK;
+  if (B == 0) return 1;
   if (!d_n || !d_f || !d_level || !d_pos || !d_has_point || !d_T_f_w || !d_stats || !d_ran) return SVO_HIP_EINVAL;
+  return SVO_HIP_OK;
+}
+
+static int launch_ordered(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride, const double* d_f,
+                          const int32_t* d_level, const double* d_pos, uint8_t* d_has_point, double reproj_thresh,
+                          int n_iter, double* d_T_f_w, double* d_Cov, double* d_stats, int32_t* d_ran, int only_flagged,
+                          void* stream) {
   PoseArgs a;
   a.cam.fx = cam->fx; a.cam.fy = cam->fy; a.cam.cx = cam->cx; a.cam.cy = cam->cy;
   a.cam.width = cam->width; a.cam.height = cam->height;
@@ -399,8 +408,51 @@ extern "C" int svo_hip_pose_optimize(const svo_hip_camera* cam, int B, const int
   a.Cov = d_Cov;
   a.stats = d_stats;
   a.ran = d_ran;
+  a.only_flagged = only_flagged;
   const int ns8 = (n_stride + 7) & ~7;
   const size_t dyn = (size_t)ns8 * (sizeof(double) + sizeof(float) + 1);
   hipLaunchKernelGGL(pose_opt_kernel, dim3(B), dim3(PO_BLOCK), dyn, static_cast<hipStream_t>(stream), a);
   return check_launch();
+}
+
+extern "C" int svo_hip_pose_optimize(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride,
+                                     const double* d_f, const int32_t* d_level, const double* d_pos,
+                                     uint8_t* d_has_point, double reproj_thresh, int n_iter, double* d_T_f_w,
+                                     double* d_Cov, double* d_stats, int32_t* d_ran, void* stream) {
+  const int rc = pose_args_check(cam, B, d_n, n_stride, d_f, d_level, d_pos, d_has_point, n_iter, d_T_f_w, d_stats, d_ran);
+  if (rc != SVO_HIP_OK) return rc > 0 ? SVO_HIP_OK : rc;
+  if (n_stride > svo_track::POSE_WAVE_MAX_STRIDE)  // more than 4 observations per lane: ordered kernel
+    return launch_ordered(cam, B, d_n, n_stride, d_f, d_level, d_pos, d_has_point, reproj_thresh, n_iter, d_T_f_w, d_Cov,
+                          d_stats, d_ran, 0, stream);
+  svo_track::PoseWaveArgs w;
+  w.cam = *cam;
+  w.B = B;
+  w.n = d_n;
+  w.n_stride = n_stride;
+  w.f = d_f;
+  w.level = d_level;
+  w.pos = d_pos;
+  w.has_point = d_has_point;
+  w.reproj_thresh = reproj_thresh;
+  w.n_iter = n_iter;
+  w.T = d_T_f_w;
+  w.Cov = d_Cov;
+  w.stats = d_stats;
+  w.ran = d_ran;
+  const int r2 = svo_track::launch_pose_wave(w, static_cast<hipStream_t>(stream));
+  if (r2 != SVO_HIP_OK) return r2;
+  // frames whose normal equations are (nearly) singular were left untouched and flagged ran = 2:
+  // the ordered kernel takes exactly those (its other workgroups exit at once)
+  return launch_ordered(cam, B, d_n, n_stride, d_f, d_level, d_pos, d_has_point, reproj_thresh, n_iter, d_T_f_w, d_Cov,
+                        d_stats, d_ran, 1, stream);
+}
+
+extern "C" int svo_hip_pose_optimize_ordered(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride,
+                                             const double* d_f, const int32_t* d_level, const double* d_pos,
+                                             uint8_t* d_has_point, double reproj_thresh, int n_iter, double* d_T_f_w,
+                                             double* d_Cov, double* d_stats, int32_t* d_ran, void* stream) {
+  const int rc = pose_args_check(cam, B, d_n, n_stride, d_f, d_level, d_pos, d_has_point, n_iter, d_T_f_w, d_stats, d_ran);
+  if (rc != SVO_HIP_OK) return rc > 0 ? SVO_HIP_OK : rc;
+  return launch_ordered(cam, B, d_n, n_stride, d_f, d_level, d_pos, d_has_point, reproj_thresh, n_iter, d_T_f_w, d_Cov,
+                        d_stats, d_ran, 0, stream);
 }

@@ -259,16 +259,12 @@ int svo_hip_pyramid_upload_level0(const svo_hip_pyr_layout* L, uint8_t* d_store,
   return SVO_HIP_OK;
 }
 
-static int g_forced_tile = 0;
-
-int svo_hip_pyramid_set_tile(int tile_width) {
-  if (tile_width != 0 && tile_width != 128 && tile_width != 256 && tile_width != 257 && tile_width != 512) return SVO_HIP_EINVAL;
-  g_forced_tile = tile_width;
-  return SVO_HIP_OK;
+static bool tile_ok(int tile_width) {
+  return tile_width == 0 || tile_width == 128 || tile_width == 256 || tile_width == 257 || tile_width == 512;
 }
 
 static int build_impl(const svo_hip_pyr_layout* L, uint8_t* d_store, int first_slot, int n_slots, const uint8_t* d_images,
-                      int64_t image_stride, int row_stride, int halfsample_mode, hipStream_t s) {
+                      int64_t image_stride, int row_stride, int halfsample_mode, int tile_width, hipStream_t s) {
   auto flavour = [&](int lvl) {
     if (halfsample_mode == SVO_HIP_HALFSAMPLE_AUTO) return (L->w[lvl - 1] % 16) == 0 ? 1 : 0;
     return halfsample_mode == SVO_HIP_HALFSAMPLE_SSE2 ? 1 : 0;
@@ -290,8 +286,7 @@ static int build_impl(const svo_hip_pyr_layout* L, uint8_t* d_store, int first_s
     a.first_slot = first_slot + done;
     a.images = d_images ? d_images + (int64_t)done * image_stride : nullptr;
     // tile selection: 0 = by image size; 128 -> 128x64, 256 -> 256x32, 512 -> 256x64 (two blocks per lane)
-    const int forced = g_forced_tile;
-    const int tw = forced ? forced : (L->w[0] >= 256 ? 257 : 128);  // 257: 256x32 tile, non-temporal level 0
+    const int tw = tile_width ? tile_width : (L->w[0] >= 256 ? 257 : 128);  // 257: 256x32 tile, non-temporal level 0
     if (tw == 512) {
       const dim3 grid((L->w[0] + 255) / 256, (L->h[0] + 63) / 64, chunk);
       hipLaunchKernelGGL((pyramid_fused_kernel<256, 2>), grid, dim3(256), 0, s, a);
@@ -333,7 +328,7 @@ int svo_hip_pyramid_build(const svo_hip_pyr_layout* L, uint8_t* d_store, int fir
   if (!layout_ok(L) || !d_store || first_slot < 0 || n_slots < 0) return SVO_HIP_EINVAL;
   if (halfsample_mode < SVO_HIP_HALFSAMPLE_SCALAR || halfsample_mode > SVO_HIP_HALFSAMPLE_AUTO)
     return SVO_HIP_EINVAL;
-  return build_impl(L, d_store, first_slot, n_slots, nullptr, 0, 0, halfsample_mode, static_cast<hipStream_t>(stream));
+  return build_impl(L, d_store, first_slot, n_slots, nullptr, 0, 0, halfsample_mode, 0, static_cast<hipStream_t>(stream));
 }
 
 int svo_hip_pyramid_build_from_images(const svo_hip_pyr_layout* L, uint8_t* d_store, int first_slot, int n_slots,
@@ -342,7 +337,18 @@ int svo_hip_pyramid_build_from_images(const svo_hip_pyr_layout* L, uint8_t* d_st
   if (!layout_ok(L) || !d_store || !d_images || first_slot < 0 || n_slots < 0 || row_stride < L->w[0]) return SVO_HIP_EINVAL;
   if (halfsample_mode < SVO_HIP_HALFSAMPLE_SCALAR || halfsample_mode > SVO_HIP_HALFSAMPLE_AUTO)
     return SVO_HIP_EINVAL;
-  return build_impl(L, d_store, first_slot, n_slots, d_images, image_stride, row_stride, halfsample_mode,
+  return build_impl(L, d_store, first_slot, n_slots, d_images, image_stride, row_stride, halfsample_mode, 0,
+                    static_cast<hipStream_t>(stream));
+}
+
+int svo_hip_pyramid_build_tiled(const svo_hip_pyr_layout* L, uint8_t* d_store, int first_slot, int n_slots,
+                                const uint8_t* d_images, int64_t image_stride, int row_stride, int halfsample_mode,
+                                int tile_width, void* stream) {
+  if (!layout_ok(L) || !d_store || first_slot < 0 || n_slots < 0 || !tile_ok(tile_width)) return SVO_HIP_EINVAL;
+  if (d_images && row_stride < L->w[0]) return SVO_HIP_EINVAL;
+  if (halfsample_mode < SVO_HIP_HALFSAMPLE_SCALAR || halfsample_mode > SVO_HIP_HALFSAMPLE_AUTO)
+    return SVO_HIP_EINVAL;
+  return build_impl(L, d_store, first_slot, n_slots, d_images, image_stride, row_stride, halfsample_mode, tile_width,
                     static_cast<hipStream_t>(stream));
 }
 

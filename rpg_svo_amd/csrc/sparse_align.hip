@@ -215,7 +215,8 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
   //   q4 = r3 c0..3 | q5 = r3 c4,5 r4 c0,1 | q6 = r4 c2..5 | q7 = r5 c1..4
   __shared__ float4 s_bt[8][BLOCK];
 
-  const int n = a.n[b];
+  int n = a.n[b];
+  n = n > a.n_stride ? a.n_stride : n;  // contract: n <= n_stride (svo_hip.h); never read the next problem's rows
   const svo_hip_sia_params P = a.P;
 
   if (n <= 0) {  // sparse_img_align.cpp:47-51: nothing to track, pose untouched
@@ -281,6 +282,8 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
   int n_meas_last = 0;
   int buf = 0;  // which half of g_s.part this iteration writes
 
+  // which wave runs the serial solve/update step (see below)
+  const int sw = (NW > 1) ? (int)(blockIdx.x % NW) : 0;
   float Sxx = 0.f, Sxy = 0.f, Syy = 0.f;
   float gmask = 0.f;  // 0 while this lane's Jacobian columns are zero at this level
   bool vis = false;   // visible_fts_[i]; never cleared between levels (:57)
@@ -356,6 +359,15 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
     }
 
     // ---- vk::NLLSSolver::optimizeGaussNewton ------------------------------
+    // old_model = model at the start of every optimize() call: a stop at the first evaluation of
+    // this level (NaN solve, stop_ carried over) keeps the pose the previous level ended with
+    if (wave == sw && lane == 0) {
+      WaveModel& wm0 = g_s.wm[wave];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wm0.oq[k] = wm0.q[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wm0.ot[k] = wm0.t[k];
+    }
     int inH = -1;  // membership of this lane in the sum that g_s.H currently holds
     int evals = 0;
     uint32_t wc[WC ? 7 : 1][3];
@@ -499,7 +511,6 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
       // issue slots on it); which wave rotates with the workgroup id so that the solver waves of the
       // workgroups sharing a CU do not pile up on one SIMD.  The others take the second barrier
       // and pick the new pose up from LDS.
-      const int sw = (NW > 1) ? (int)(blockIdx.x % NW) : 0;
       if (wave == sw)
 #ifndef SIA_DBG_NOSOLVE
       {

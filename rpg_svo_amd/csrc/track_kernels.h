@@ -21,6 +21,7 @@ struct AlignArgs {
   int scale_out;           // 1: px_out = px * (1 << level)  (Matcher: px_cur = px_scaled*(1<<search_level_))
   int32_t* ok;             // [M]
   double* h_inv;           // [M] or NULL
+  int32_t* iters = nullptr;  // [M] or NULL: residual evaluations per trial (instrumented kernel variant)
 };
 int launch_align(const AlignArgs& a, hipStream_t s);
 
@@ -38,6 +39,26 @@ struct WarpArgs {
   uint8_t* pwb;               // [M][100]
 };
 int launch_warp(const WarpArgs& a, hipStream_t s);
+
+// K4 (pose_optimizer_wave.hip): one wave per frame, n_stride <= 256
+struct PoseWaveArgs {
+  svo_hip_camera cam;
+  int B;
+  const int32_t* n;
+  int n_stride;
+  const double* f;
+  const int32_t* level;
+  const double* pos;
+  uint8_t* has_point;
+  double reproj_thresh;
+  int n_iter;
+  double* T;
+  double* Cov;
+  double* stats;
+  int32_t* ran;
+};
+constexpr int POSE_WAVE_MAX_STRIDE = 256;
+int launch_pose_wave(const PoseWaveArgs& a, hipStream_t s);
 
 // carve 256-byte aligned arrays out of a caller-provided workspace
 struct Carver {

@@ -39,23 +39,25 @@ class PyramidStore:
     def n_levels(self) -> int:
         return self.layout.n_levels
 
-    def load_images(self, images: torch.Tensor, first_slot: int = 0, build: bool = True, fused: bool = True) -> None:
+    def load_images(self, images: torch.Tensor, first_slot: int = 0, build: bool = True, fused: bool = True,
+                    tile: int = 0) -> None:
         """images: uint8 [n,h,w] on the device (contiguous).  fused (default): level 0 and all
-        further levels in one pass (svo_hip_pyramid_build_from_images)."""
+        further levels in one pass (svo_hip_pyramid_build_from_images).  tile: level-0 tile of the
+        fused kernel (svo_hip_pyramid_build_tiled; 0 = chosen by image size)."""
         assert images.dtype == torch.uint8 and images.is_cuda and images.is_contiguous()
         n, h, w = images.shape
         assert h == self.layout.h[0] and w == self.layout.w[0] and first_slot + n <= self.n_slots
         if build and fused:
-            capi.check(self.lib.svo_hip_pyramid_build_from_images(C.byref(self.layout), self.ptr, first_slot, n,
-                                                                  images.data_ptr(), h * w, w, self.halfsample,
-                                                                  _stream_ptr(self.device)),
-                       "svo_hip_pyramid_build_from_images")
+            capi.check(self.lib.svo_hip_pyramid_build_tiled(C.byref(self.layout), self.ptr, first_slot, n,
+                                                            images.data_ptr(), h * w, w, self.halfsample, tile,
+                                                            _stream_ptr(self.device)),
+                       "svo_hip_pyramid_build_tiled")
             return
         capi.check(self.lib.svo_hip_pyramid_load_level0(C.byref(self.layout), self.ptr, first_slot, n,
                                                         images.data_ptr(), h * w, w, _stream_ptr(self.device)),
                    "svo_hip_pyramid_load_level0")
         if build:
-            self.build(first_slot, n)
+            self.build(first_slot, n, tile)
 
     def upload(self, slot: int, image: np.ndarray, build: bool = True) -> None:
         """image: uint8 [h,w] host array (a new camera frame)."""
@@ -68,10 +70,11 @@ class PyramidStore:
         if build:
             self.build(slot, 1)
 
-    def build(self, first_slot: int = 0, n_slots: int | None = None) -> None:
+    def build(self, first_slot: int = 0, n_slots: int | None = None, tile: int = 0) -> None:
         n = self.n_slots - first_slot if n_slots is None else n_slots
-        capi.check(self.lib.svo_hip_pyramid_build(C.byref(self.layout), self.ptr, first_slot, n, self.halfsample,
-                                                  _stream_ptr(self.device)), "svo_hip_pyramid_build")
+        capi.check(self.lib.svo_hip_pyramid_build_tiled(C.byref(self.layout), self.ptr, first_slot, n, None, 0, 0,
+                                                        self.halfsample, tile, _stream_ptr(self.device)),
+                   "svo_hip_pyramid_build_tiled")
 
     def build_per_level(self, first_slot: int = 0, n_slots: int | None = None) -> None:
         """The pre-fusion builder (one launch per level); A/B timing and tests only."""

@@ -22,7 +22,7 @@ def test_bad_arguments_are_rejected(hip_lib, gpu_device):
     assert lib.svo_hip_pyramid_build(C.byref(L), None, 0, 1, 2, None) == EINVAL
     assert lib.svo_hip_pyramid_build(C.byref(L), p, 0, 1, 7, None) == EINVAL           # unknown half-sample flavour
     assert lib.svo_hip_pyramid_build_from_images(C.byref(L), p, 0, 1, p, 640 * 480, 600, 2, None) == EINVAL   # stride < width
-    assert lib.svo_hip_pyramid_set_tile(300) == EINVAL and lib.svo_hip_pyramid_set_tile(0) == 0
+    assert lib.svo_hip_pyramid_build_tiled(C.byref(L), p, 0, 1, None, 0, 0, 2, 300, None) == EINVAL        # unknown tile
     # feature alignment / matcher / depth filter
     assert lib.svo_hip_align_batch(C.byref(L), p, -1, None, None, None, None, None, 10, None, None, None, None) == EINVAL
     assert lib.svo_hip_align_batch(C.byref(L), p, 0, None, None, None, None, None, 10, None, None, None, None) == 0  # empty batch

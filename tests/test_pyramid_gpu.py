@@ -25,17 +25,16 @@ def _check(store, oracle, imgs, levels, mode, first):
 @pytest.mark.parametrize("tile", [128, 256, 257, 512])
 def test_pyramid_bit_exact(oracle, gpu_device, hip_lib, w, h, levels, mode, tile):
     from rpg_svo_amd.pyramid import PyramidStore
-    assert hip_lib.svo_hip_pyramid_set_tile(tile) == 0
     rng = np.random.default_rng(w * 7 + h + mode)
     imgs = rng.integers(0, 256, size=(3, h, w), dtype=np.uint8)
     dimgs = torch.from_numpy(imgs).to(gpu_device)
     # (a) fused, level 0 filled from the packed images in the same pass
     store = PyramidStore(w, h, levels, 4, device=gpu_device, halfsample=mode)
-    store.load_images(dimgs, first_slot=1)
+    store.load_images(dimgs, first_slot=1, tile=tile)
     _check(store, oracle, imgs, levels, mode, 1)
     # (b) level 0 copied first, fused build from the store
     store2 = PyramidStore(w, h, levels, 4, device=gpu_device, halfsample=mode)
-    store2.load_images(dimgs, first_slot=0, fused=False)
+    store2.load_images(dimgs, first_slot=0, fused=False, tile=tile)
     _check(store2, oracle, imgs, levels, mode, 0)
     # (c) the per-level builder
     store3 = PyramidStore(w, h, levels, 4, device=gpu_device, halfsample=mode)
@@ -44,7 +43,6 @@ def test_pyramid_bit_exact(oracle, gpu_device, hip_lib, w, h, levels, mode, tile
     _check(store3, oracle, imgs, levels, mode, 0)
     # padding bytes of the store stay out of the way: slot 3 / slot 0 of (a) untouched
     assert int(store.buf[: store.layout.slot_bytes].sum().item()) == 0
-    hip_lib.svo_hip_pyramid_set_tile(0)
 
 
 def test_unaligned_source_rows(oracle, gpu_device):
