@@ -1,25 +1,38 @@
 #!/usr/bin/env python
 """bench.py -- frames/s of sparse image alignment (+ the Gauss-Newton pose
-refinement it contains) on synthetic VGA pyramid batches.
+refinement it contains) on synthetic VGA pyramid batches, plus the read-outs the
+scope table asks for next to it.
 
 A "step" is one pass of the hot path (svo_hip_sparse_align, K1) over one batch
 of B independent (reference frame, current frame) problems per GPU, with the
 image pyramids and feature arrays already resident in HBM.  Workload at N=1 is
 BASELINE.json configs[1]: 640x480 mono, 4 pyramid levels (3 -> 0), 200 reference
-patches, SparseImgAlign only.
+patches, SparseImgAlign only.  `value` is that and nothing else.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1: spawns one rank per GPU itself)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (see the keys below).  The oracle (oracle/, CPU
-restatement) is used here only for the `cpu_baseline` leg and a parity read-out;
-it is never the thing measured as `value`.
+Prints ONE JSON line on rank 0.  Extra keys of that line (N = 1 only, each leg is
+independent and never changes `value`):
+  roofline / parity / cpu_baseline   the headline kernel (K1)
+  align_plus_refine                  K1 + pose_optimizer (K4) timed together
+  full_track                         BASELINE configs[2]: K1 + findMatchDirect + K4 + updateSeeds,
+                                     per-stage times and rooflines, parity against the CPU chain
+  noise_sigma2                       the headline workload with image noise (benchmark_node.cpp:166-176)
+  config3_xga5_b64                   BASELINE configs[3]: 1280x960, 5 levels, 1000 patches, 64 frames
+  rig_replay                         BASELINE configs[4] shape: one camera stream per rank, a pose gather
+                                     per frame (also reported for N > 1)
+  k0_pyramid / dropin_sequence       pyramid builder roofline; the reference pipeline with HIP bodies
+The oracle (oracle/, CPU restatement + the reference's own translation units) is used here only
+for the `cpu_baseline` and `parity` legs; it is never the thing measured.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,6 +47,8 @@ from rpg_svo_amd.pyramid import PyramidStore  # noqa: E402
 from rpg_svo_amd.sparse_img_align import SparseImgAlign, marshal_problem  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+N_SIMD = 1024          # 256 CUs x 4 SIMD-32
+CLOCK_GHZ = 2.4
 
 WORKLOADS = {
     # name: (width, height, f, n_levels, max_level, min_level, n_patches, margin, cell)
@@ -41,6 +56,8 @@ WORKLOADS = {
     "svo_default_752_l4to2_n120": (752, 480, 315.5, 5, 4, 2, 120, 56, 40),
     "xga5_n1000_sparse_align": (1280, 960, 800.0, 5, 4, 0, 1000, 56, 32),
 }
+EXTRA_KEYS = {"refine": "align_plus_refine", "full": "full_track", "noise": "noise_sigma2", "config3": "config3_xga5_b64",
+              "k0": "k0_pyramid", "dropin": "dropin_sequence"}
 
 
 def algorithmic_bytes(n_patches: np.ndarray, n_tracked: np.ndarray, iters: np.ndarray, max_level: int, min_level: int) -> float:
@@ -67,6 +84,15 @@ def horn_ate(P: np.ndarray, Q: np.ndarray) -> float:
     return float(np.sqrt((err ** 2).sum(1).mean()))
 
 
+def roofline(kernel: str, alg_bytes: float, ms: float, **extra) -> dict:
+    gbs = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else float("nan")
+    d = {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": gbs / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes_per_launch": alg_bytes}
+    d.update(extra)
+    return d
+
+
+# ---- launch plumbing -----------------------------------------------------------------------------
 def free_port() -> int:
     import socket
     with socket.socket() as so:
@@ -82,12 +108,98 @@ def spawn_command(n_gpus: int, argv: list[str], port: int) -> list[str]:
 
 def spawn_ranks(n_gpus: int) -> int:
     """`python bench.py --gpus N` from a plain shell: re-launch under torch.distributed.run."""
-    import subprocess
     cmd = spawn_command(n_gpus, sys.argv[1:], free_port())
     if os.environ.get("SVO_BENCH_DRY_SPAWN") == "1":
         print(json.dumps({"spawn": cmd}))
         return 0
     return subprocess.call(cmd)
+
+
+class Events:
+    """HIP-event timing on torch's current stream through the C ABI (the stream the kernels of
+    libsvo_hip.so are enqueued on)."""
+
+    def __init__(self, lib, dev):
+        self.lib, self.dev = lib, dev
+
+    def stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def mark(self):
+        e = C.c_void_p()
+        capi.check(self.lib.svo_hip_event_create(C.byref(e)))
+        self.lib.svo_hip_event_record(e, self.stream())
+        return e
+
+    def ms(self, e0, e1) -> float:
+        m = C.c_float()
+        capi.check(self.lib.svo_hip_event_elapsed_ms(e0, e1, C.byref(m)))
+        return m.value
+
+    def time(self, fn, reps: int, warmup: int = 1) -> float:
+        """mean milliseconds of fn() over `reps` back-to-back runs"""
+        for _ in range(warmup):
+            fn()
+        marks = []
+        for _ in range(reps):
+            e0 = self.mark()
+            fn()
+            marks.append((e0, self.mark()))
+        out = float(np.mean([self.ms(a, b) for a, b in marks]))
+        for a, b in marks:
+            self.lib.svo_hip_event_destroy(a)
+            self.lib.svo_hip_event_destroy(b)
+        return out
+
+
+class Workload:
+    """Synthetic replay sequence of B+1 frames on one GPU: problem b = (frame b -> frame b+1)."""
+
+    def __init__(self, name: str, B: int, dev, rank: int = 0, noise: float = 0.0, images: torch.Tensor | None = None,
+                 T_gt: np.ndarray | None = None):
+        (self.width, self.height, self.focal, self.n_levels, self.max_level, self.min_level, self.n_patches,
+         margin, cell) = WORKLOADS[name]
+        self.name, self.B, self.dev, self.noise = name, B, dev, noise
+        w, h, f = self.width, self.height, self.focal
+        self.cam = synth.Camera(w, h, f, f, w / 2.0, h / 2.0)
+        self.T_gt = synth.make_trajectory(B + 1, seed=12345 + rank) if T_gt is None else T_gt
+        if images is None:
+            images = synth.render(synth.make_texture(seed=12345), self.T_gt, self.cam, device=dev, chunk=32 if w <= 800 else 8)
+        self.clean_images = images
+        if noise > 0:  # svo_ros/src/benchmark_node.cpp:166-176: N(0, sigma) on every pixel, saturated
+            g = torch.Generator(device=dev).manual_seed(99 + rank)
+            out = torch.empty_like(images)
+            for i0 in range(0, images.shape[0], 1024):
+                blk = images[i0:i0 + 1024].float()
+                out[i0:i0 + 1024] = (blk + noise * torch.randn(blk.shape, generator=g, device=dev)).round().clamp(0, 255).to(torch.uint8)
+            images = out
+        self.images = images
+        self.px_all = synth.select_features(self.clean_images[:B], self.n_patches, margin=margin, cell=cell)
+        g = torch.Generator().manual_seed(777 + rank)
+        self.px_all = (self.px_all + (torch.rand(self.px_all.shape, generator=g, dtype=torch.float64) - 0.5).to(dev)).contiguous()
+        self.f_all, self.pos_all = synth.features_3d(self.T_gt[:B], self.cam, self.px_all)
+        self.store = PyramidStore(w, h, self.n_levels, B + 1, device=dev)
+        self.store.load_images(self.images)  # level 0 copy + K0 pyramid build (untimed here)
+        self.T_ref_w = self.T_gt[:B]
+        self.T_prior_w = self.T_ref_w.copy()  # constant-position prior, frame_handler_mono.cpp:132
+        T_cr, xyz_ref = marshal_problem(self.T_ref_w, self.T_prior_w, self.f_all.cpu().numpy(), self.pos_all.cpu().numpy())
+        tdev = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+        self.ref_slot = torch.arange(0, B, dtype=torch.int32, device=dev)
+        self.cur_slot = torch.arange(1, B + 1, dtype=torch.int32, device=dev)
+        self.n_t = torch.full((B,), self.n_patches, dtype=torch.int32, device=dev)
+        self.xyz_t = tdev(xyz_ref, torch.float64)
+        self.T_in = tdev(T_cr, torch.float64)
+
+    def run_align(self, sia, out=None):
+        return sia.run(self.store, self.cam, self.ref_slot, self.cur_slot, self.n_t, self.px_all, self.xyz_t, self.T_in, out=out)
+
+    def align_stats(self, out) -> dict:
+        n_tracked = out.n_tracked.cpu().numpy().astype(np.float64)
+        iters = out.iters.cpu().numpy().astype(np.float64)
+        alg = algorithmic_bytes(np.full(self.B, self.n_patches, dtype=np.float64), n_tracked, iters, self.max_level, self.min_level)
+        T_est_w = se3.mul(out.T_cur_from_ref.cpu().numpy(), self.T_ref_w)
+        return {"alg_bytes": alg, "iters": iters, "n_tracked": n_tracked, "T_est_w": T_est_w,
+                "gt_err": se3.log_norm(T_est_w, self.T_gt[1:self.B + 1])}
 
 
 def main() -> None:
@@ -97,7 +209,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16384, help="frames per step per GPU")
     ap.add_argument("--workload", default="vga4_n200_sparse_align", choices=sorted(WORKLOADS))
-    ap.add_argument("--noise", type=float, default=0.0, help="image noise sigma (gray levels)")
+    ap.add_argument("--noise", type=float, default=0.0, help="image noise sigma (gray levels) of the headline workload")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="frames timed on the host for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n-iter", type=int, default=30, help="Gauss-Newton iteration cap per level (30 in the pipeline)")
@@ -105,8 +217,13 @@ def main() -> None:
                     help="capture one step (all kernel launches of the pipeline) in a HIP graph and replay it: "
                          "small batches -- e.g. one frame per camera of a rig -- are launch-bound")
     ap.add_argument("--pipeline", default="align", choices=["align", "full"],
-                    help="align: SparseImgAlign only (BASELINE configs[1], the default); full: configs[2] -- "
-                         "sparse align + reprojection matching (align2D) + pose refinement + depth-filter update")
+                    help="what the TIMED step runs.  align: SparseImgAlign only (BASELINE configs[1], the default and the "
+                         "headline); full: configs[2] -- the whole track is the step (the default run reports it as the "
+                         "extra key full_track instead)")
+    ap.add_argument("--extras", default="all",
+                    help="comma list of the extra legs to run at N=1 (all, none, or any of: refine, full, noise, config3, rig, "
+                         "k0, dropin, pmc)")
+    ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -131,36 +248,23 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", str(free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     lib = capi.load()
+    ev = Events(lib, dev)
+    if args.extras == "all":
+        extras = {"refine", "full", "noise", "config3", "rig", "k0", "dropin", "pmc"}
+    elif args.extras == "none":
+        extras = set()
+    else:
+        extras = set(args.extras.split(","))
+    if args.no_cpu_baseline:
+        extras.discard("dropin")
+    if args.pmc_child or world > 1:
+        extras = set()
 
-    width, height, focal, n_levels, max_level, min_level, n_patches, margin, cell = WORKLOADS[args.workload]
-    cam = synth.Camera(width, height, focal, focal, width / 2.0, height / 2.0)
     B = args.batch
-
-    # ---- synthetic replay sequence: B+1 frames, problem b = (frame b -> frame b+1) ----
     t_gen = time.time()
-    tex = synth.make_texture(seed=12345)
-    T_gt = synth.make_trajectory(B + 1, seed=12345 + rank)
-    images = synth.render(tex, T_gt, cam, device=dev, chunk=32)
-    if args.noise > 0:
-        g = torch.Generator(device=dev).manual_seed(99 + rank)
-        images = (images.float() + args.noise * torch.randn(images.shape, generator=g, device=dev)).round().clamp(0, 255).to(torch.uint8)
-    px_all = synth.select_features(images[:B], n_patches, margin=margin, cell=cell)
-    g = torch.Generator().manual_seed(777 + rank)
-    px_all = px_all + (torch.rand(px_all.shape, generator=g, dtype=torch.float64) - 0.5).to(dev)
-    f_all, pos_all = synth.features_3d(T_gt[:B], cam, px_all)
-    store = PyramidStore(width, height, n_levels, B + 1, device=dev)
-    store.load_images(images)  # level 0 copy + K0 pyramid build (untimed here)
-    T_ref_w = T_gt[:B]
-    T_prior_w = T_ref_w.copy()  # constant-position prior, frame_handler_mono.cpp:132
-    T_cr, xyz_ref = marshal_problem(T_ref_w, T_prior_w, f_all.cpu().numpy(), pos_all.cpu().numpy())
-    tdev = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
-    ref_slot = torch.arange(0, B, dtype=torch.int32, device=dev)
-    cur_slot = torch.arange(1, B + 1, dtype=torch.int32, device=dev)
-    n_t = torch.full((B,), n_patches, dtype=torch.int32, device=dev)
-    px_t = px_all.contiguous()
-    xyz_t = tdev(xyz_ref, torch.float64)
-    T_in = tdev(T_cr, torch.float64)
-    sia = SparseImgAlign(max_level, min_level, args.n_iter)
+    W = Workload(args.workload, B, dev, rank, noise=args.noise)
+    store = W.store
+    sia = SparseImgAlign(W.max_level, W.min_level, args.n_iter)
     out = sia.alloc_result(B, dev)
     # N>1: the only exchange is the gather of the [B,12] poses.  It is double-buffered and issued
     # asynchronously (RCCL's own stream) so that it overlaps the next step's kernels; the timed
@@ -174,44 +278,34 @@ def main() -> None:
             outs = [sia.alloc_result(B, dev) for _ in range(gather.depth)]
         for k, o in enumerate(outs):
             o.T_cur_from_ref = gather._local[k]
-    full = FullTrack(args, cam, store, T_gt, px_all, f_all, pos_all, n_patches, n_levels, dev, rank) if args.pipeline == "full" else None
+    full = FullTrack(W, dev, rank) if args.pipeline == "full" else None
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
 
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    ev = []
-    for _ in range(2 * args.steps):
-        e = C_void()
-        capi.check(lib.svo_hip_event_create(e.ref()))
-        ev.append(e.value)
-
+    marks = []
     graph = None
-
     counter = [0]
 
-    def step_compute(i: int | None) -> None:
-        st = torch.cuda.current_stream(dev).cuda_stream
+    def step_compute(timed: bool) -> None:
         k = counter[0] % len(outs)
         o = outs[k]
         if gather is not None:
             gather.local(counter[0] if len(outs) > 1 else 0)  # waits for the gather that last read this buffer
-        if i is not None:
-            lib.svo_hip_event_record(ev[2 * i], st)
-        sia.run(store, cam, ref_slot, cur_slot, n_t, px_t, xyz_t, T_in, out=o)
-        if i is not None:
-            lib.svo_hip_event_record(ev[2 * i + 1], st)
+        e0 = ev.mark() if timed else None
+        W.run_align(sia, out=o)
+        if timed:
+            marks.append((e0, ev.mark()))
         if full is not None:
-            full.step(o.T_cur_from_ref, lib, st, timed=i is not None)
+            full.step(o.T_cur_from_ref, ev if timed else None)
 
-    def step(i: int | None) -> None:
+    def step(timed: bool) -> None:
         if graph is not None:
-            if i is not None:
-                lib.svo_hip_event_record(ev[2 * i], stream)
+            e0 = ev.mark() if timed else None
             graph.replay()
-            if i is not None:
-                lib.svo_hip_event_record(ev[2 * i + 1], stream)
+            if timed:
+                marks.append((e0, ev.mark()))
         else:
-            step_compute(i)
+            step_compute(timed)
         if gather is not None:  # RCCL gather of the SE(3) results (the only exchange step)
             if len(outs) > 1:
                 gather.submit(counter[0])
@@ -221,7 +315,7 @@ def main() -> None:
         counter[0] += 1
 
     for _ in range(args.warmup):
-        step(None)
+        step(False)
     if gather is not None:
         gather.drain()
     torch.cuda.synchronize()
@@ -235,17 +329,18 @@ def main() -> None:
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            step_compute(None)
+            step_compute(False)
         torch.cuda.current_stream(dev).wait_stream(side)
         with torch.cuda.graph(graph):
-            step_compute(None)
+            step_compute(False)
         torch.cuda.synchronize()
+    # ---- the timed region: exactly K steps between barrier + synchronize on both sides ----
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(True)
     if gather is not None:
         gather.drain()
     torch.cuda.synchronize()
@@ -258,54 +353,25 @@ def main() -> None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        # the exchange step on its own (untimed region): blocking all-gathers of one pose block
-        reps = 20
-        for _ in range(3):
-            gather.submit(0)
-            gather.result(0)
-        torch.cuda.synchronize()
-        dist.barrier()
-        tg = time.perf_counter()
-        for _ in range(reps):
-            gather.submit(0)
-            gather.result(0)
-        torch.cuda.synchronize()
-        tg = torch.tensor([(time.perf_counter() - tg) / reps], dtype=torch.float64, device=dev)
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        gather_stats = {"collective": "all_gather_into_tensor (RCCL)", "bytes_per_rank_per_step": int(B * 12 * 8),
-                        "bytes_gathered_per_step": int(world * B * 12 * 8), "ms_blocking_avg": float(tg.item()) * 1e3,
-                        "overlapped_in_timed_region": len(outs) > 1}
+        gather_stats = time_gather(gather, dist, dev, world, B, len(outs) > 1)
 
     # per-launch kernel duration from HIP events on the launch stream
-    kms = []
-    for i in range(args.steps):
-        ms = C_float()
-        capi.check(lib.svo_hip_event_elapsed_ms(ev[2 * i], ev[2 * i + 1], ms.ref()))
-        kms.append(ms.value)
-    kernel_ms = float(np.mean(kms)) if kms else float("nan")
+    kernel_ms = float(np.mean([ev.ms(a, b) for a, b in marks])) if marks else float("nan")
+
+    rig = None
+    if ("rig" in extras or use_dist) and not args.pmc_child:
+        try:
+            rig = rig_replay(ev, dev, dist if use_dist else None, world, rank)
+        except Exception as e:  # never lose the headline line to an extra leg
+            rig = {"skipped": repr(e)}
 
     if rank != 0:
         dist.destroy_process_group()
         return
 
     out = outs[(counter[0] - 1) % len(outs)]  # the result block of the last step
-    n_tracked = out.n_tracked.cpu().numpy().astype(np.float64)
-    iters = out.iters.cpu().numpy().astype(np.float64)
-    alg_bytes = algorithmic_bytes(np.full(B, n_patches, dtype=np.float64), n_tracked, iters, max_level, min_level)
-    achieved_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            key = f"{args.workload}:B{B}"
-            if key in tj:
-                traffic = tj[key]
-        except Exception:
-            traffic = None
-
-    T_est_w = se3.mul(out.T_cur_from_ref.cpu().numpy(), T_ref_w)
-    gt_err = se3.log_norm(T_est_w, T_gt[1:B + 1])
+    st = W.align_stats(out)
+    iters, n_tracked, alg_bytes = st["iters"], st["n_tracked"], st["alg_bytes"]
 
     result = {
         "metric": "frames/sec sparse-align+pose-refine (VGA, 4 pyr lvls); ATE vs CPU ref",
@@ -321,98 +387,314 @@ def main() -> None:
         "dtype": "f32 pixels / f64 pose+normal equations",
         "data": "synthetic",
         "config": {
-            "workload": args.workload if full is None else args.workload.replace("sparse_align", "full_track"), "image": f"{width}x{height}", "pyr_levels": n_levels,
-            "schedule": f"levels {max_level}->{min_level}", "patches_per_frame": n_patches,
+            "workload": args.workload if full is None else args.workload.replace("sparse_align", "full_track"),
+            "image": f"{W.width}x{W.height}", "pyr_levels": W.n_levels,
+            "schedule": f"levels {W.max_level}->{W.min_level}", "patches_per_frame": W.n_patches,
             "frames_per_step_per_gpu": B, "n_iter_cap": args.n_iter, "image_noise_sigma": args.noise,
-            "parallelism": f"frames sharded 1 rank/GPU x{world}" + (", RCCL all_gather of poses, double-buffered and overlapped with the next step" if world > 1 else ""),
+            "timed_region": "svo_hip_sparse_align (SparseImgAlign::run incl. its Gauss-Newton pose solve) over the batch"
+                            + (" + the rest of the track" if full is not None else "")
+                            + (" + RCCL all_gather of the poses" if use_dist else ""),
+            "parallelism": f"frames sharded 1 rank/GPU x{world}" + (", RCCL all_gather of poses, double-buffered and overlapped with the next step" if use_dist else ""),
             "hip_graph": bool(args.graph),
             "mean_gn_iterations_per_frame": float(iters.sum(1).mean()),
             "mean_tracked_patches": float(n_tracked.mean()),
-            "median_pose_error_vs_gt": float(np.median(gt_err)),
+            "median_pose_error_vs_gt": float(np.median(st["gt_err"])),
         },
-        "roofline": {
-            "bound": "hbm", "kernel": "sia_kernel (svo_hip_sparse_align)",
-            "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel_ms_avg": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
-            "algorithmic_bytes_per_frame": alg_bytes / B,
-            # iterations/s and per-iteration time of the batch
-            "gn_iterations_per_s": float(iters.sum()) / (kernel_ms * 1e-3),
-            "us_per_gn_iteration_of_the_batch": kernel_ms * 1e3 / max(float(iters.sum(1).mean()), 1e-9),
-        },
+        "roofline": roofline("sia_kernel (svo_hip_sparse_align)", alg_bytes, kernel_ms, traffic=None, kernel_ms_avg=kernel_ms,
+                             algorithmic_bytes_per_frame=alg_bytes / B,
+                             # iterations/s and per-iteration time of the batch
+                             gn_iterations_per_s=float(iters.sum()) / (kernel_ms * 1e-3),
+                             us_per_gn_iteration_of_the_batch=kernel_ms * 1e3 / max(float(iters.sum(1).mean()), 1e-9)),
         "setup_s": t_gen,
     }
+    if args.pmc_child:  # child of the PMC leg: nothing else is needed from this process
+        print(json.dumps(result))
+        return
     if full is not None:
         d = full.describe()
-        T_ref_est = d.pop("_T_refined")
-        d["median_pose_error_vs_gt_after_refine"] = float(np.median(se3.log_norm(T_ref_est, T_gt[1:B + 1])))
+        d.pop("_T_refined")
         result["config"].update(d)
-        result["stages_ms"] = full.stage_ms(lib) if not args.graph else {}
+        result["stages_ms"] = full.stage_ms(ev) if not args.graph else {}
         result["stages_ms"]["sparse_align" if not args.graph else "whole_graph"] = kernel_ms
-
-    if not args.no_cpu_baseline and world == 1:
-        result["cpu_baseline"] = cpu_baseline(args, cam, images, T_gt, px_all, f_all, pos_all, T_ref_w, T_prior_w,
-                                              n_levels, max_level, min_level, n_patches, T_est_w, result,
-                                              out.iters.cpu().numpy())
-    if world == 1:
-        result["k0_pyramid"] = pyramid_roofline(lib, store, images, stream)
-    if not args.no_cpu_baseline and world == 1:
-        try:
-            result["dropin_sequence"] = dropin_sequence()
-        except Exception as e:  # the demonstration libraries are optional (built from the reference checkout)
-            result["dropin_sequence"] = {"skipped": str(e)}
     if gather_stats is not None:
         result["gather"] = gather_stats
+    if rig is not None:
+        result["rig_replay"] = rig
+
+    def leg(name, fn):
+        if name not in extras:
+            return
+        t = time.time()
+        try:
+            r = fn()
+        except Exception as e:  # an extra leg must never cost the headline line
+            r = {"skipped": repr(e)}
+        if isinstance(r, dict):
+            r["leg_seconds"] = time.time() - t
+        result[EXTRA_KEYS[name]] = r
+
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            result["cpu_baseline"] = cpu_baseline(args, W, st["T_est_w"], result, out.iters.cpu().numpy())
+        except Exception as e:
+            result["cpu_baseline"] = {"skipped": repr(e)}
+    leg("refine", lambda: align_plus_refine(W, sia, ev, dev, args.steps))
+    leg("full", lambda: full_track_leg(W, sia, ev, dev, rank, lib, not args.no_cpu_baseline))
+    leg("k0", lambda: pyramid_roofline(ev, store, W.images))
+    if args.noise == 0:
+        leg("noise", lambda: noise_leg(W, sia, ev, dev, rank, args.steps))
+    leg("config3", lambda: config3_leg(ev, dev, rank, args.n_iter))
+    if "pmc" in extras:
+        t = time.time()
+        try:
+            pm = pmc_leg(args, kernel_ms)
+        except Exception as e:
+            pm = {"skipped": repr(e)}
+        pm["leg_seconds"] = time.time() - t
+        if "traffic_bytes_per_launch" in pm:
+            result["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
+            result["roofline"]["traffic_over_algorithmic"] = pm["traffic_bytes_per_launch"] / alg_bytes
+        if "roofline_valu" in pm:
+            result["roofline_valu"] = pm.pop("roofline_valu")
+        result["pmc"] = pm
+    leg("dropin", dropin_sequence)
     print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
 
 
-def pyramid_roofline(lib, store, images, stream, reps: int = 5) -> dict:
+def time_gather(gather, dist, dev, world, B, overlapped) -> dict:
+    """the exchange step on its own (outside the timed region): blocking all-gathers of one pose block"""
+    reps = 20
+    for _ in range(3):
+        gather.submit(0)
+        gather.result(0)
+    torch.cuda.synchronize()
+    dist.barrier()
+    tg = time.perf_counter()
+    for _ in range(reps):
+        gather.submit(0)
+        gather.result(0)
+    torch.cuda.synchronize()
+    tg = torch.tensor([(time.perf_counter() - tg) / reps], dtype=torch.float64, device=dev)
+    dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+    return {"collective": "all_gather_into_tensor (RCCL)", "bytes_per_rank_per_step": int(B * 12 * 8),
+            "bytes_gathered_per_step": int(world * B * 12 * 8), "ms_blocking_avg": float(tg.item()) * 1e3,
+            "overlapped_in_timed_region": overlapped}
+
+
+# ---- extra legs ------------------------------------------------------------------------------------
+def rig_replay(ev, dev, dist, world, rank, n_frames: int = 200) -> dict:
+    """BASELINE configs[4] shape: every rank is one camera of a rig (752x480, the reference's default
+    schedule: 5 levels, 4 -> 2, 120 patches) tracking ITS OWN stream frame by frame -- frame k+1 needs
+    frame k's pose (frame_handler_mono.cpp:85,132), so the per-camera batch is 1 -- with one all-gather
+    of the SE(3) results per frame set.  Latency-bound by construction; reported as rig frames/s
+    (all cameras) and the per-frame split."""
+    W = Workload("svo_default_752_l4to2_n120", n_frames, dev, rank + 100)
+    sia = SparseImgAlign(W.max_level, W.min_level, 30)
+    out = sia.alloc_result(1, dev)
+    allT = torch.zeros(max(world, 1), 12, dtype=torch.float64, device=dev)
+    views = [(W.ref_slot[i:i + 1], W.cur_slot[i:i + 1], W.n_t[i:i + 1], W.px_all[i:i + 1], W.xyz_t[i:i + 1], W.T_in[i:i + 1])
+             for i in range(n_frames)]
+
+    def frame(i, do_gather=True):
+        r, c, n, px, xyz, T = views[i]
+        sia.run(W.store, W.cam, r, c, n, px, xyz, T, out=out)
+        if dist is not None and do_gather:
+            dist.all_gather_into_tensor(allT, out.T_cur_from_ref)
+        # the host consumes the pose before the next frame is handed in (live tracking)
+        torch.cuda.current_stream(dev).synchronize()
+
+    for i in range(10):
+        frame(i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_frames):
+        frame(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for i in range(n_frames):
+        frame(i, do_gather=False)
+    torch.cuda.synchronize()
+    dt_nogather = time.perf_counter() - t1
+    if dist is not None:
+        tt = torch.tensor([dt, dt_nogather], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, dt_nogather = float(tt[0].item()), float(tt[1].item())
+    return {"workload": "svo_default_752_l4to2_n120, one camera stream per rank, batch 1 per camera, pose gather per frame set",
+            "cameras": world, "frames_per_camera": n_frames, "rig_frames_per_s": world * n_frames / dt,
+            "us_per_frame_set": dt / n_frames * 1e6, "us_per_frame_set_without_gather": dt_nogather / n_frames * 1e6,
+            "gather_bytes_per_frame_set": int(world * 96) if dist is not None else 0}
+
+
+def refine_inputs(W: Workload, dev, rank: int, px_sigma: float = 0.3):
+    """Synthetic matches for pose refinement: the reference frame's points observed in the current
+    frame at their true projection + px_sigma pixels (what findMatchDirect would deliver)."""
+    B, N, cam = W.B, W.n_patches, W.cam
+    T = torch.as_tensor(W.T_gt[1:B + 1], dtype=torch.float64, device=dev)
+    p = (T[:, :9].reshape(B, 1, 3, 3) @ W.pos_all[..., None])[..., 0] + T[:, None, 9:]
+    g = torch.Generator().manual_seed(31 + rank)
+    px = torch.stack([cam.fx * p[..., 0] / p[..., 2] + cam.cx, cam.fy * p[..., 1] / p[..., 2] + cam.cy], -1)
+    px = px + px_sigma * torch.randn(px.shape, generator=g, dtype=torch.float64).to(dev)
+    d = torch.stack([(px[..., 0] - cam.cx) / cam.fx, (px[..., 1] - cam.cy) / cam.fy, torch.ones_like(px[..., 0])], -1)
+    f_cur = (d / d.norm(dim=-1, keepdim=True)).contiguous()
+    level = torch.zeros(B, N, dtype=torch.int32, device=dev)
+    has = torch.ones(B, N, dtype=torch.uint8, device=dev)
+    return f_cur, level, has
+
+
+def align_plus_refine(W: Workload, sia, ev: Events, dev, steps: int) -> dict:
+    """The metric's "+pose-refine" read literally: SparseImgAlign followed by
+    pose_optimizer::optimizeGaussNewton (K1 -> compose -> K4) on the headline batch."""
+    from rpg_svo_amd import tracking as tr
+    B, N = W.B, W.n_patches
+    f_cur, level, has = refine_inputs(W, dev, 0)
+    T_ref = torch.as_tensor(W.T_ref_w, dtype=torch.float64, device=dev)
+    T_cur = torch.empty(B, 12, dtype=torch.float64, device=dev)
+    out = sia.alloc_result(B, dev)
+    po = tr.PoseOptResult(torch.empty(B, 12, dtype=torch.float64, device=dev), torch.zeros(B, 36, dtype=torch.float64, device=dev),
+                          torch.zeros(B, 4, dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.int32, device=dev),
+                          torch.empty(B, N, dtype=torch.uint8, device=dev))
+
+    def refine():
+        tr.compose_poses(out.T_cur_from_ref, T_ref, out=T_cur)
+        tr.optimize_gauss_newton(W.cam, W.n_t, f_cur, level, W.pos_all, has, T_cur, 2.0, 10, out=po)
+
+    def both():
+        W.run_align(sia, out=out)
+        refine()
+
+    ms_both = ev.time(both, steps, warmup=2)
+    ms_refine = ev.time(refine, steps, warmup=1)
+    torch.cuda.synchronize()
+    err = se3.log_norm(po.T_f_w.cpu().numpy(), W.T_gt[1:B + 1])
+    k4_bytes = float(B) * (N * 52 + 416)
+    return {"frames_per_s": B / ms_both * 1e3, "ms_per_step": ms_both, "ms_pose_optimize": ms_refine,
+            "frames_per_step": B, "matches": f"{N} synthetic matches per frame at the true projection + 0.3 px",
+            "median_pose_error_vs_gt_after_refine": float(np.median(err)),
+            "mean_obs_after_pruning": float(po.stats[:, 3].mean().item()),
+            "roofline_pose_optimize": roofline("pose_opt_wave_kernel (svo_hip_pose_optimize)", k4_bytes, ms_refine,
+                                               algorithmic_bytes_per_frame=N * 52 + 416)}
+
+
+def noise_leg(W: Workload, sia, ev: Events, dev, rank: int, steps: int) -> dict:
+    """The headline workload with N(0, 2) image noise (svo_ros/src/benchmark_node.cpp:166-176): more
+    Gauss-Newton evaluations per frame, same kernel."""
+    Wn = Workload(W.name, W.B, dev, rank, noise=2.0, images=W.clean_images, T_gt=W.T_gt)
+    out = sia.alloc_result(W.B, dev)
+    ms = ev.time(lambda: Wn.run_align(sia, out=out), max(steps // 2, 3), warmup=2)
+    torch.cuda.synchronize()
+    st = Wn.align_stats(out)
+    r = {"image_noise_sigma": 2.0, "frames_per_s": W.B / ms * 1e3, "ms_per_step": ms,
+         "mean_gn_iterations_per_frame": float(st["iters"].sum(1).mean()), "mean_tracked_patches": float(st["n_tracked"].mean()),
+         "median_pose_error_vs_gt": float(np.median(st["gt_err"])),
+         "roofline": roofline("sia_kernel", st["alg_bytes"], ms, gn_iterations_per_s=float(st["iters"].sum()) / (ms * 1e-3))}
+    del Wn
+    torch.cuda.empty_cache()
+    return r
+
+
+def config3_leg(ev: Events, dev, rank: int, n_iter: int) -> dict:
+    """BASELINE configs[3]: 1280x960, 5 levels (4 -> 0), 1000 patches, 64 frames at once."""
+    W = Workload("xga5_n1000_sparse_align", 64, dev, rank + 7)
+    sia = SparseImgAlign(W.max_level, W.min_level, n_iter)
+    out = sia.alloc_result(W.B, dev)
+    ms = ev.time(lambda: W.run_align(sia, out=out), 20, warmup=3)
+    torch.cuda.synchronize()
+    st = W.align_stats(out)
+    return {"workload": "xga5_n1000_sparse_align", "frames_per_step": 64, "frames_per_s": 64 / ms * 1e3, "ms_per_step": ms,
+            "mean_gn_iterations_per_frame": float(st["iters"].sum(1).mean()), "mean_tracked_patches": float(st["n_tracked"].mean()),
+            "median_pose_error_vs_gt": float(np.median(st["gt_err"])),
+            "roofline": roofline("sia_kernel", st["alg_bytes"], ms)}
+
+
+def pmc_leg(args, kernel_ms: float) -> dict:
+    """HBM traffic and VALU issue of the headline kernel, measured on THIS box by re-running this
+    command (headline leg only, 3 steps) under rocprofv3 --pmc, one counter group per pass as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit one
+    pass; no trace domain is combined with --pmc)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return {"skipped": "rocprofv3 not on PATH"}
+    base = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--batch", str(args.batch),
+            "--workload", args.workload, "--noise", str(args.noise), "--n-iter", str(args.n_iter), "--no-cpu-baseline",
+            "--extras", "none", "--pmc-child", "1"]
+    passes = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
+              "sq": ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+                     "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"]}
+    status, raw = {}, {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("SVO_BENCH_FORCE_DIST", None)
+    for name, ctrs in passes.items():
+        d = tempfile.mkdtemp(prefix=f"svo_pmc_{name}_", dir="/tmp")
+        cmd = [exe, "--pmc", *ctrs, "--kernel-include-regex", "sia_kernel", "--output-format", "csv", "-d", d, "-o", name, "--", *base]
+        try:
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+        except subprocess.TimeoutExpired:
+            status[name] = "timeout"
+            continue
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            status[name] = f"rc={p.returncode}: {p.stderr[-200:]}"
+            continue
+        acc: dict[str, list[float]] = {}
+        with open(files[0]) as fh:
+            for row in csv.DictReader(fh):
+                if "sia_kernel" not in row.get("Kernel_Name", ""):
+                    continue
+                acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        for k, v in acc.items():
+            raw[k] = float(np.mean(v))  # per launch
+        status[name] = "ok"
+        shutil.rmtree(d, ignore_errors=True)
+    out: dict = {"passes": status, "counters_per_launch": raw,
+                 "how": "child runs of this command (3 steps) under rocprofv3 --pmc, one counter group per pass, averaged per "
+                        "sia_kernel launch; FETCH_SIZE / WRITE_SIZE are KiB of 64-byte fabric requests (the guide's x2 "
+                        "correction applies to wide streaming reads; this kernel gathers 4-byte words, so no factor is applied)"}
+    if "FETCH_SIZE" in raw and "WRITE_SIZE" in raw:
+        out["traffic_bytes_per_launch"] = (raw["FETCH_SIZE"] + raw["WRITE_SIZE"]) * 1024.0
+        out["fetch_bytes_per_launch"] = raw["FETCH_SIZE"] * 1024.0
+        out["write_bytes_per_launch"] = raw["WRITE_SIZE"] * 1024.0
+    if "SQ_INSTS_VALU" in raw:
+        # a wave64 VALU instruction occupies its SIMD-32 for >= 2 cycles (f64: 4); counted as 2, so this
+        # is a LOWER bound of the issue utilisation
+        cycles_avail = N_SIMD * kernel_ms * 1e-3 * CLOCK_GHZ * 1e9
+        busy = raw["SQ_INSTS_VALU"] * 2.0
+        wc = raw.get("SQ_WAVE_CYCLES")
+        out["roofline_valu"] = {"bound": "valu-issue", "kernel": "sia_kernel", "achieved": busy / cycles_avail, "peak": 1.0,
+                                "unit": "fraction of SIMD issue cycles (SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel time x 2.4 GHz))",
+                                "frac": busy / cycles_avail, "valu_instructions_per_launch": raw["SQ_INSTS_VALU"],
+                                "kernel_ms": kernel_ms,
+                                "wave_cycles_issuing_frac": raw.get("SQ_ACTIVE_INST_ANY", float("nan")) / wc if wc else None,
+                                "wave_cycles_waiting_frac": raw.get("SQ_WAIT_ANY", float("nan")) / wc if wc else None}
+    return out
+
+
+def pyramid_roofline(ev: Events, store, images, reps: int = 5) -> dict:
     """K0, the one HBM-streaming kernel of the path: image pyramids of the whole
     replay batch rebuilt from the packed images in a single fused pass.  Algorithmic bytes per
     frame = w*h read + every level written once."""
     n = images.shape[0]
     per_frame = images.shape[1] * images.shape[2] + store.bytes_per_pyramid()
-
-    def timed(fn):
-        ms = []
-        for _ in range(reps + 1):
-            e0, e1 = C_void(), C_void()
-            capi.check(lib.svo_hip_event_create(e0.ref()))
-            capi.check(lib.svo_hip_event_create(e1.ref()))
-            lib.svo_hip_event_record(e0.value, stream)
-            fn()
-            lib.svo_hip_event_record(e1.value, stream)
-            m = C_float()
-            capi.check(lib.svo_hip_event_elapsed_ms(e0.value, e1.value, m.ref()))
-            ms.append(m.value)
-            lib.svo_hip_event_destroy(e0.value)
-            lib.svo_hip_event_destroy(e1.value)
-        return float(np.mean(ms[1:]))
-
-    tiles = {}
-    for tw in (128, 256, 257, 512):
-        lib.svo_hip_pyramid_set_tile(tw)
-        tiles[str(tw)] = timed(lambda: store.load_images(images, 0))
-    lib.svo_hip_pyramid_set_tile(0)
-    fused = timed(lambda: store.load_images(images, 0))
+    tiles = {str(tw): ev.time(lambda: store.load_images(images, 0, tile=tw), reps) for tw in (128, 256, 257, 512)}
+    fused = ev.time(lambda: store.load_images(images, 0), reps)
 
     def per_level():
         store.load_images(images, 0, build=False)
         store.build_per_level(0, n)
-    unfused = timed(per_level)
+    unfused = ev.time(per_level, reps)
     gbs = n * per_frame / (fused * 1e-3) / 1e9
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        traffic = tj.get(f"k0_pyramid:vga4:B{n}") if (images.shape[1], images.shape[2]) == (480, 640) else None
-    except Exception:
-        pass
     return {"kernel": "pyramid_fused_kernel (svo_hip_pyramid_build_from_images)", "frames": int(n),
             "ms": fused, "frames_per_s": n / (fused * 1e-3), "algorithmic_bytes_per_frame": int(per_frame),
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "traffic": traffic, "algorithmic_bytes_per_launch": int(n * per_frame),
+            "traffic": None, "algorithmic_bytes_per_launch": int(n * per_frame),
             "ms_level0_copy_plus_one_launch_per_level": unfused, "ms_by_tile_width": tiles}
 
 
@@ -451,22 +733,21 @@ def dropin_sequence(n_frames: int = 120) -> dict:
             "median_ms_per_frame_hip_dropin": {k: med(hip, "t_" + k) for k in stages}}
 
 
-def cpu_baseline(args, cam, images, T_gt, px_all, f_all, pos_all, T_ref_w, T_prior_w, n_levels, max_level,
-                 min_level, n_patches, T_est_w, result, iters_gpu) -> dict:
-    """Times the oracle (CPU restatement of the reference path; the reference itself
-    cannot be built: Eigen/OpenCV/Sophus/vikit are absent) on a bounded sample of
-    the same problems, on this box's host cores."""
+def cpu_baseline(args, W: Workload, T_est_w, result, iters_gpu) -> dict:
+    """Times the reference's own SparseImgAlign translation unit (oracle/_ref, kind "reference";
+    the C port where that library is absent) on a bounded sample of the same problems, on this
+    box's host cores, and fills result["parity"] from the same run."""
     from oracle import pyoracle
-    S = min(args.cpu_sample, px_all.shape[0])
-    imgs = images[:S + 1].cpu().numpy()
-    pyrs = [pyoracle.create_img_pyramid(im, n_levels, pyoracle.HALFSAMPLE_AUTO) for im in imgs]
+    S = min(args.cpu_sample, W.B)
+    imgs = W.images[:S + 1].cpu().numpy()
+    pyrs = [pyoracle.create_img_pyramid(im, W.n_levels, pyoracle.HALFSAMPLE_AUTO) for im in imgs]
     rs = np.arange(S, dtype=np.int32)
     cs = rs + 1
-    nn = np.full(S, n_patches, dtype=np.int32)
-    px = px_all[:S].cpu().numpy()
-    f = f_all[:S].cpu().numpy()
-    pos = pos_all[:S].cpu().numpy()
-    hp = np.ones((S, n_patches), dtype=np.uint8)
+    nn = np.full(S, W.n_patches, dtype=np.int32)
+    px = W.px_all[:S].cpu().numpy()
+    f = W.f_all[:S].cpu().numpy()
+    pos = W.pos_all[:S].cpu().numpy()
+    hp = np.ones((S, W.n_patches), dtype=np.uint8)
     cores = os.cpu_count() or 1
     s1 = min(S, 2048)
     # kind "reference": the reference's own SparseImgAlign translation unit (oracle/_ref, built
@@ -476,8 +757,8 @@ def cpu_baseline(args, cam, images, T_gt, px_all, f_all, pos_all, T_ref_w, T_pri
     def timed(k, threads):
         tm = {}
         t0 = time.perf_counter()
-        T, r = pyoracle.sparse_img_align_batch(pyrs, rs[:k], cs[:k], cam, T_ref_w[:k], T_prior_w[:k], nn[:k], px[:k],
-                                               f[:k], hp[:k], pos[:k], max_level, min_level, args.n_iter,
+        T, r = pyoracle.sparse_img_align_batch(pyrs, rs[:k], cs[:k], W.cam, W.T_ref_w[:k], W.T_prior_w[:k], nn[:k], px[:k],
+                                               f[:k], hp[:k], pos[:k], W.max_level, W.min_level, args.n_iter,
                                                n_threads=threads, which=which, timing=tm)
         return T, r, tm.get("run_seconds", time.perf_counter() - t0)
 
@@ -485,7 +766,7 @@ def cpu_baseline(args, cam, images, T_gt, px_all, f_all, pos_all, T_ref_w, T_pri
     T_cpu, res, tn = timed(S, cores)
     best_threads, best_rate = cores, S / tn
     sweep = {str(cores): S / tn}
-    for th in (cores // 2, cores // 4):  # SMT siblings / allocator contention: fewer threads can be faster
+    for th in (cores // 2, cores // 4):  # SMT siblings / memory bandwidth: fewer threads can be faster
         if th >= 1:
             k = max(1, S // 2)
             _, _, tt = timed(k, th)
@@ -499,6 +780,7 @@ def cpu_baseline(args, cam, images, T_gt, px_all, f_all, pos_all, T_ref_w, T_pri
         "frames_compared": int(S), "se3_lognorm_max": float(d.max()), "se3_lognorm_median": float(np.median(d)),
         "ate_rmse_vs_cpu_m": horn_ate(pos_gpu, pos_cpu),
         "same_iteration_counts_frac": float(np.mean([np.array_equal(r["iters"], it) for r, it in zip(res, iters_gpu[:S])])),
+        "against": "reference" if which == "ref" else "port",
     }
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
@@ -520,14 +802,17 @@ class FullTrack:
 
     STAGES = ("compose_pose", "reproject", "find_match_direct", "cam2world", "pose_optimize", "update_seeds")
 
-    def __init__(self, args, cam, store, T_gt, px_all, f_all, pos_all, n_patches, n_levels, dev, rank):
+    def __init__(self, W: Workload, dev, rank):
         from rpg_svo_amd import tracking
         self.tr = tracking
+        self.W = W
+        cam, store = W.cam, W.store
         self.cam, self.store, self.dev = cam, store, dev
-        B, N = px_all.shape[0], n_patches
+        B, N = W.B, W.n_patches
         self.B, self.N = B, N
+        px_all, f_all, pos_all = W.px_all, W.f_all, W.pos_all
         g = torch.Generator().manual_seed(4242 + rank)
-        T = torch.as_tensor(T_gt, dtype=torch.float64, device=dev)
+        T = torch.as_tensor(W.T_gt, dtype=torch.float64, device=dev)
         # frame table: rows 0..B = replay frames with their (ground truth) keyframe poses,
         # rows B+1+b = frame b+1 as the frame being tracked (pose = sparse-align output)
         slot = torch.cat([torch.arange(0, B + 1, dtype=torch.int32, device=dev),
@@ -547,6 +832,7 @@ class FullTrack:
         # observations: the feature in frame b, and (where it projects inside) in frame b-2
         b_idx = torch.arange(B, device=dev)
         older = (b_idx - 2).clamp(min=0)
+        self.older = older
         R2 = T[older, :9].reshape(B, 3, 3)
         p2 = (R2[:, None] @ pos_all[..., None])[..., 0] + T[older, None, 9:]
         px2 = torch.stack([cam.fx * p2[..., 0] / p2[..., 2] + cam.cx, cam.fy * p2[..., 1] / p2[..., 2] + cam.cy], -1)
@@ -572,7 +858,7 @@ class FullTrack:
         self.obs_ptr = ptr
         self.obs = tracking.FeatureSet(frame=o_frame, level=torch.zeros(n_total, dtype=torch.int32, device=dev),
                                        px=o_px, f=o_f)
-        self.matcher = tracking.Matcher(align_max_iter=10, n_pyr_levels=n_levels)
+        self.matcher = tracking.Matcher(align_max_iter=10, n_pyr_levels=W.n_levels)
         self.n = torch.full((B,), N, dtype=torch.int32, device=dev)
         # seeds: one per reference feature, inverse depth known to 10 %, range from 0.6 x depth
         depth = ray.norm(dim=-1).reshape(M)
@@ -585,49 +871,55 @@ class FullTrack:
         self.seed_ftr = tracking.FeatureSet(frame=b_idx.repeat_interleave(N).to(torch.int32).contiguous(),
                                             level=torch.zeros(M, dtype=torch.int32, device=dev),
                                             px=px_all.reshape(M, 2).contiguous(), f=f_all.reshape(M, 3).contiguous())
-        self.df = tracking.DepthFilter(n_pyr_levels=n_levels)
+        self.df = tracking.DepthFilter(n_pyr_levels=W.n_levels)
         self.f_new = torch.empty(M, 3, dtype=torch.float64, device=dev)
+        # result blocks reused by every step (no allocation / memset inside the timed stages)
+        self.cell_px = (torch.zeros(M, dtype=torch.int32, device=dev), torch.zeros(M, 2, dtype=torch.float64, device=dev))
+        self.match = self.matcher.alloc_result(M, dev)
+        self.okb = torch.zeros(B, N, dtype=torch.uint8, device=dev)
+        self.po = tracking.PoseOptResult(torch.empty(B, 12, dtype=torch.float64, device=dev),
+                                         torch.zeros(B, 36, dtype=torch.float64, device=dev),
+                                         torch.zeros(B, 4, dtype=torch.float64, device=dev),
+                                         torch.zeros(B, dtype=torch.int32, device=dev),
+                                         torch.empty(B, N, dtype=torch.uint8, device=dev))
+        self.seed_out = (torch.zeros(M, dtype=torch.int32, device=dev), torch.zeros(M, 3, dtype=torch.float64, device=dev),
+                         torch.zeros(M, 2, dtype=torch.float64, device=dev))
         self.events = []
         self.last = {}
 
-    def _mark(self, lib, stream, timed):
-        if timed:
-            e = C_void()
-            capi.check(lib.svo_hip_event_create(e.ref()))
-            lib.svo_hip_event_record(e.value, stream)
-            self.events.append(e.value)
-
-    def step(self, T_cur_from_ref, lib, stream, timed):
+    def step(self, T_cur_from_ref, ev: Events | None):
         tr = self.tr
-        self._mark(lib, stream, timed)
-        tr.compose_poses(T_cur_from_ref, self.T_ref, out=self.frame_T, out_index=self.cur_rows)
-        self._mark(lib, stream, timed)
-        cell, px = tr.reproject_points(self.cam, self.frames, self.cur_frame, self.pt_pos, 30, (self.cam.width + 29) // 30)
-        self._mark(lib, stream, timed)
-        m = self.matcher.find_match_direct(self.store, self.cam, self.frames, self.cur_frame, self.pt_pos, self.obs_ptr,
-                                           self.obs, px)
-        self._mark(lib, stream, timed)
-        tr.cam2world(self.cam, m.px_cur, out=self.f_new)
-        self._mark(lib, stream, timed)
         B, N = self.B, self.N
+        mk = (lambda: self.events.append(ev.mark())) if ev is not None else (lambda: None)
+        mk()
+        tr.compose_poses(T_cur_from_ref, self.T_ref, out=self.frame_T, out_index=self.cur_rows)
+        mk()
+        cell, px = tr.reproject_points(self.cam, self.frames, self.cur_frame, self.pt_pos, 30, (self.cam.width + 29) // 30,
+                                       out=self.cell_px)
+        mk()
+        m = self.matcher.find_match_direct(self.store, self.cam, self.frames, self.cur_frame, self.pt_pos, self.obs_ptr,
+                                           self.obs, px, out=self.match)
+        mk()
+        tr.cam2world(self.cam, m.px_cur, out=self.f_new)
+        mk()
+        torch.gt(m.ok.view(B, N), 0, out=self.okb.view(torch.bool))
         po = tr.optimize_gauss_newton(self.cam, self.n, self.f_new.view(B, N, 3), m.search_level.view(B, N),
-                                      self.pt_pos.view(B, N, 3), (m.ok > 0).to(torch.uint8).view(B, N),
-                                      self.frame_T[B + 1:], 2.0, 10)
-        self._mark(lib, stream, timed)
+                                      self.pt_pos.view(B, N, 3), self.okb, self.frame_T[B + 1:], 2.0, 10, out=self.po)
+        self.frame_T[B + 1:].copy_(po.T_f_w)  # the mapper sees the refined pose (frame_handler_mono.cpp:190,221)
+        mk()
         for k, v in self.seed0.items():
             getattr(self.seeds, k).copy_(v)
-        status, _, _ = self.df.update_seeds(self.store, self.cam, self.frames, self.cur_frame, self.seed_ftr, self.seeds, 0)
-        self._mark(lib, stream, timed)
-        self.last = dict(match=m, pose=po, seed_status=status)
+        status, _, _ = self.df.update_seeds(self.store, self.cam, self.frames, self.cur_frame, self.seed_ftr, self.seeds, 0,
+                                            out=self.seed_out)
+        mk()
+        self.last = dict(match=m, pose=po, seed_status=status, px_proj=px)
 
-    def stage_ms(self, lib):
+    def stage_ms(self, ev: Events):
         k = len(self.STAGES) + 1
         acc = {s: [] for s in self.STAGES}
         for i in range(0, len(self.events) - k + 1, k):
             for j, sname in enumerate(self.STAGES):
-                ms = C_float()
-                capi.check(lib.svo_hip_event_elapsed_ms(self.events[i + j], self.events[i + j + 1], ms.ref()))
-                acc[sname].append(ms.value)
+                acc[sname].append(ev.ms(self.events[i + j], self.events[i + j + 1]))
         return {s: float(np.mean(v)) for s, v in acc.items() if v}
 
     def describe(self):
@@ -640,33 +932,162 @@ class FullTrack:
                 "pipeline": "sparse_align -> reproject -> findMatchDirect -> pose_optimize -> updateSeeds",
                 "_T_refined": T_est}
 
+    def stage_rooflines(self, lib, stages: dict) -> dict:
+        """Per stage: algorithmic bytes of one step (SURVEY 8d byte formulas) / measured stage time.
+          findMatchDirect (K2+K3): per trial 121 B template footprint + 100 B warped patch + 48 B geometry
+                                   + 81 B per alignment evaluation (9x9 window)
+          pose refine (K4):        M*52 + 416 B per frame
+          depth update (K5):       36 B seed state + 64 B per scanned epipolar position + the template"""
+        dev, M, B, N = self.dev, self.M, self.B, self.N
+        m = self.last["match"]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        # alignment evaluations per trial: K3 alone (instrumented variant) on the patches / start positions of the step
+        lvl = m.search_level
+        scale = (1 << lvl.long()).double()[:, None]
+        px0 = (self.last["px_proj"] / scale).contiguous()
+        slot = self.frames.slot[self.cur_frame.long()].contiguous()
+        ok = torch.zeros(M, dtype=torch.int32, device=dev)
+        evals = torch.zeros(M, dtype=torch.int32, device=dev)
+        capi.check(lib.svo_hip_align_batch_counted(C.byref(self.store.layout), self.store.ptr, M, slot.data_ptr(), lvl.data_ptr(),
+                                                   m.patch_with_border.data_ptr(), None, None, 10, px0.data_ptr(), ok.data_ptr(),
+                                                   None, evals.data_ptr(), stream), "svo_hip_align_batch_counted")
+        tried = m.ref_obs >= 0
+        n_eval = float(evals[tried].sum().item())
+        n_tried = float(tried.sum().item())
+        fm_bytes = n_tried * (121 + 100 + 48) + 81.0 * n_eval
+        steps_ptr = lib.svo_hip_update_seeds_scan_steps(self.df.last_workspace.data_ptr())
+        scan = torch.empty(M, dtype=torch.int32, device=dev)
+        capi.check(lib.svo_hip_memcpy_d2d(scan.data_ptr(), steps_ptr, M * 4, stream), "svo_hip_memcpy_d2d")
+        torch.cuda.synchronize()
+        n_scan = float(scan.sum().item())
+        seed_bytes = M * 36.0 + 64.0 * n_scan + M * (121.0 + 100.0)
+        return {
+            "find_match_direct": roofline("match_prepare + warp_kernel + align_kernel", fm_bytes, stages["find_match_direct"],
+                                          trials=n_tried, alignment_evaluations_per_trial=n_eval / max(n_tried, 1)),
+            "pose_optimize": roofline("pose_opt_wave_kernel", B * (N * 52.0 + 416.0), stages["pose_optimize"]),
+            "update_seeds": roofline("seed_prepare + warp_kernel + epi_scan + align_kernel + seed_finish", seed_bytes,
+                                     stages["update_seeds"], scanned_positions_per_seed=n_scan / M),
+        }
 
-class C_void:
-    def __init__(self):
-        import ctypes
-        self._v = ctypes.c_void_p()
 
-    def ref(self):
-        import ctypes
-        return ctypes.byref(self._v)
+def full_track_leg(W: Workload, sia, ev: Events, dev, rank, lib, with_parity: bool, steps: int = 5) -> dict:
+    """BASELINE configs[2] on the headline frames: the whole track as one step."""
+    full = FullTrack(W, dev, rank)
+    out = sia.alloc_result(W.B, dev)
+    marks = []
 
-    @property
-    def value(self):
-        return self._v.value
+    def step(timed):
+        e0 = ev.mark() if timed else None
+        W.run_align(sia, out=out)
+        e1 = ev.mark() if timed else None
+        full.step(out.T_cur_from_ref, ev if timed else None)
+        if timed:
+            marks.append((e0, e1, ev.mark()))
+
+    step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    stages = full.stage_ms(ev)
+    stages["sparse_align"] = float(np.mean([ev.ms(a, b) for a, b, _ in marks]))
+    step_ms = float(np.mean([ev.ms(a, c) for a, _, c in marks]))
+    d = full.describe()
+    T_ref_est = d.pop("_T_refined")
+    res = {"workload": "vga4_n200_full_track", "frames_per_step": W.B, "frames_per_s": W.B / step_ms * 1e3, "ms_per_step": step_ms,
+           "ms_per_step_host_wall": wall, "stages_ms": stages,
+           "median_pose_error_vs_gt_after_refine": float(np.median(se3.log_norm(T_ref_est, W.T_gt[1:W.B + 1])))}
+    res.update(d)
+    st = W.align_stats(out)
+    rl = full.stage_rooflines(lib, stages)
+    rl["sparse_align"] = roofline("sia_kernel", st["alg_bytes"], stages["sparse_align"])
+    res["rooflines"] = rl
+    if with_parity:
+        try:
+            res["parity"] = full_track_parity(W, full, out, T_ref_est)
+        except Exception as e:
+            res["parity"] = {"skipped": repr(e)}
+    del full
+    torch.cuda.empty_cache()
+    return res
 
 
-class C_float:
-    def __init__(self):
-        import ctypes
-        self._v = ctypes.c_float()
-
-    def ref(self):
-        import ctypes
-        return ctypes.byref(self._v)
-
-    @property
-    def value(self):
-        return self._v.value
+def full_track_parity(W: Workload, full: FullTrack, out, T_refined_gpu, n_sample: int = 48) -> dict:
+    """The same chain on the host for a sample of frames -- the reference's own translation units
+    where oracle/_ref is present (SparseImgAlign::run -> Matcher::findMatchDirect per point ->
+    pose_optimizer::optimizeGaussNewton -> DepthFilter::updateSeeds) -- compared stage by stage."""
+    from oracle import pytrack
+    which = "ref" if pytrack.ref_available() else "orc"
+    trk = pytrack.Track(which)
+    B, N, cam = W.B, W.n_patches, W.cam
+    idx = np.unique(np.linspace(2, B - 1, n_sample).astype(int))
+    m = full.last["match"]
+    ok_g = m.ok.view(B, N).cpu().numpy()
+    px_g = m.px_cur.view(B, N, 2).cpu().numpy()
+    st_g = full.last["seed_status"].view(B, N).cpu().numpy()
+    mu_g = full.seeds.mu.view(B, N).cpu().numpy()
+    T_k1_g = se3.mul(out.T_cur_from_ref.cpu().numpy(), W.T_ref_w)
+    pt_pos = full.pt_pos.view(B, N, 3).cpu().numpy()
+    px_all, f_all, pos_all = W.px_all.cpu().numpy(), W.f_all.cpu().numpy(), W.pos_all.cpu().numpy()
+    optr = full.obs_ptr.cpu().numpy()
+    o_px, o_f = full.obs.px.cpu().numpy(), full.obs.f.cpu().numpy()
+    seed0 = {k: v.view(B, N).cpu().numpy() for k, v in full.seed0.items()}
+    older = full.older.cpu().numpy()
+    opt = pytrack.matcher_options(n_pyr_levels=W.n_levels)
+    d_k1, d_final, same_ok, same_px, same_status, mu_rel = [], [], [], [], [], []
+    t0 = time.time()
+    for b in idx:
+        imgs = [W.images[i].cpu().numpy() for i in (b, older[b], b + 1)]
+        pyrs = [trk.create_img_pyramid(im, W.n_levels) for im in imgs]
+        hp = np.ones(N, dtype=np.uint8)
+        T_cur, _ = trk.sparse_img_align_run(pyrs[0], pyrs[2], cam, W.T_ref_w[b], W.T_prior_w[b], px_all[b], f_all[b], hp,
+                                            pos_all[b], W.max_level, W.min_level)
+        d_k1.append(se3.log_norm(T_k1_g[b][None], T_cur[None])[0])
+        frames = pytrack.make_frames(pyrs, np.stack([W.T_gt[b], W.T_gt[older[b]], T_cur]))
+        ok_c = np.zeros(N, dtype=np.int32)
+        px_c = np.zeros((N, 2))
+        lvl_c = np.zeros(N, dtype=np.int32)
+        for i in range(N):
+            k0, k1 = optr[b * N + i], optr[b * N + i + 1]
+            obs = [pytrack.make_feature(0, o_px[k0], o_f[k0])]
+            if k1 - k0 == 2:
+                obs.append(pytrack.make_feature(1, o_px[k0 + 1], o_f[k0 + 1]))
+            _, px_init = trk.reproject_point(cam, T_cur, pt_pos[b, i], 30, (cam.width + 29) // 30)
+            ok, px, r = trk.find_match_direct(frames, cam, 2, pt_pos[b, i], obs, px_init, opt)
+            ok_c[i], px_c[i], lvl_c[i] = ok, px, r["search_level"]
+        same_ok.append(np.mean((ok_c > 0) == (ok_g[b] > 0)))
+        both = (ok_c > 0) & (ok_g[b] > 0)
+        same_px.append(np.mean(np.abs(px_c[both] - px_g[b][both]).max(1) < 1e-6) if both.any() else 1.0)
+        dd = np.stack([(px_c[:, 0] - cam.cx) / cam.fx, (px_c[:, 1] - cam.cy) / cam.fy, np.ones(N)], -1)
+        f_new = dd / np.linalg.norm(dd, axis=1, keepdims=True)
+        po = trk.pose_optimize(cam, T_cur, f_new, lvl_c, (ok_c > 0).astype(np.uint8), pt_pos[b], 2.0, 10)
+        d_final.append(se3.log_norm(T_refined_gpu[b][None], po["T_f_w"][None])[0])
+        frames2 = pytrack.make_frames(pyrs, np.stack([W.T_gt[b], W.T_gt[older[b]], po["T_f_w"]]))
+        seeds = []
+        for i in range(N):
+            s = pytrack.Seed()
+            s.ftr = pytrack.make_feature(0, px_all[b, i], f_all[b, i])
+            s.batch_id, s.a, s.b, s.mu = 0, float(seed0["a"][b, i]), float(seed0["b"][b, i]), float(seed0["mu"][b, i])
+            s.z_range, s.sigma2 = float(seed0["z_range"][b, i]), float(seed0["sigma2"][b, i])
+            seeds.append(s)
+        _, so, io = trk.update_seeds(frames2, cam, 2, seeds, batch_counter=0, opt=opt)
+        stc = np.array([x.status for x in io])
+        same_status.append(np.mean(stc == st_g[b]))
+        upd = (stc == st_g[b]) & np.isin(stc, (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED))
+        if upd.any():
+            muc = np.array([x.mu for x in so])
+            mu_rel.append(np.max(np.abs(muc[upd] - mu_g[b][upd]) / np.abs(muc[upd])))
+    return {"frames_compared": int(len(idx)), "against": "reference" if which == "ref" else "port",
+            "sparse_align_se3_lognorm_max": float(np.max(d_k1)), "sparse_align_se3_lognorm_median": float(np.median(d_k1)),
+            "find_match_direct_same_verdict_frac": float(np.mean(same_ok)),
+            "find_match_direct_same_pixel_frac_of_common_matches": float(np.mean(same_px)),
+            "refined_pose_se3_lognorm_max": float(np.max(d_final)), "refined_pose_se3_lognorm_median": float(np.median(d_final)),
+            "seed_status_same_frac": float(np.mean(same_status)),
+            "seed_mu_max_rel_diff": float(np.max(mu_rel)) if mu_rel else None,
+            "seconds": time.time() - t0,
+            "note": "each stage is fed by the previous stage of ITS OWN chain: differences accumulate along the chain"}
 
 
 if __name__ == "__main__":

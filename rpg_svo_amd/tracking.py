@@ -108,15 +108,21 @@ class Matcher:
         self.lib = capi.load()
         self._ws = _Workspace()
 
+    def alloc_result(self, M: int, device) -> MatchResult:
+        return MatchResult(torch.zeros(M, dtype=torch.int32, device=device), torch.zeros(M, 2, dtype=torch.float64, device=device),
+                           torch.zeros(M, dtype=torch.int32, device=device), torch.zeros(M, dtype=torch.int32, device=device),
+                           torch.zeros(M, 4, dtype=torch.float64, device=device),
+                           torch.zeros(M, 100, dtype=torch.uint8, device=device))
+
     def find_match_direct(self, store: PyramidStore, cam, frames: FrameTable, cur_frame, pt_pos, obs_ptr,
-                          obs: FeatureSet, px_cur) -> MatchResult:
+                          obs: FeatureSet, px_cur, out: MatchResult | None = None) -> MatchResult:
+        """out: a result block from alloc_result() to reuse (every field is overwritten by the
+        kernels; px_cur is copied into out.px_cur first)."""
         M = pt_pos.shape[0]
         dev = store.device
         _chk(cur_frame, torch.int32); _chk(pt_pos, torch.float64); _chk(obs_ptr, torch.int32); _chk(px_cur, torch.float64)
-        res = MatchResult(torch.zeros(M, dtype=torch.int32, device=dev), px_cur.clone(),
-                          torch.zeros(M, dtype=torch.int32, device=dev), torch.zeros(M, dtype=torch.int32, device=dev),
-                          torch.zeros(M, 4, dtype=torch.float64, device=dev),
-                          torch.zeros(M, 100, dtype=torch.uint8, device=dev))
+        res = out if out is not None else self.alloc_result(M, dev)
+        res.px_cur.copy_(px_cur)
         ws = self._ws.get(self.lib, M, dev)
         c, fr, ob = capi.camera(cam), frames.struct(), obs.struct()
         capi.check(self.lib.svo_hip_find_match_direct(
@@ -127,13 +133,17 @@ class Matcher:
         return res
 
 
-def reproject_points(cam, frames: FrameTable, cur_frame, pt_pos, cell_size: int, grid_n_cols: int):
-    """Reprojector::reprojectPoint for M points: (cell [M] i32 (-1 = not in frame), px [M,2])."""
+def reproject_points(cam, frames: FrameTable, cur_frame, pt_pos, cell_size: int, grid_n_cols: int, out=None):
+    """Reprojector::reprojectPoint for M points: (cell [M] i32 (-1 = not in frame), px [M,2]).
+    out: (cell, px) tensors to reuse."""
     lib = capi.load()
     M = pt_pos.shape[0]
     dev = pt_pos.device
-    cell = torch.zeros(M, dtype=torch.int32, device=dev)
-    px = torch.zeros(M, 2, dtype=torch.float64, device=dev)
+    if out is not None:
+        cell, px = out
+    else:
+        cell = torch.zeros(M, dtype=torch.int32, device=dev)
+        px = torch.zeros(M, 2, dtype=torch.float64, device=dev)
     c, fr = capi.camera(cam), frames.struct()
     capi.check(lib.svo_hip_reproject_points(C.byref(c), C.byref(fr), M, _chk(cur_frame, torch.int32).data_ptr(),
                                             _chk(pt_pos, torch.float64).data_ptr(), cell_size, grid_n_cols,
@@ -176,7 +186,7 @@ class PoseOptResult:
 
 
 def optimize_gauss_newton(cam, n, f, level, pos, has_point, T_f_w, reproj_thresh: float = 2.0, n_iter: int = 10,
-                          ordered: bool = False) -> PoseOptResult:
+                          ordered: bool = False, out: PoseOptResult | None = None) -> PoseOptResult:
     """pose_optimizer::optimizeGaussNewton for B frames (reproj_thresh = Config::poseOptimThresh(),
     n_iter = Config::poseOptimNumIter(), frame_handler_mono.cpp:163-165).  ordered=True runs the
     kernel that adds the normal equations in the reference's observation order (the checker)."""
@@ -185,9 +195,14 @@ def optimize_gauss_newton(cam, n, f, level, pos, has_point, T_f_w, reproj_thresh
     dev = f.device
     _chk(n, torch.int32); _chk(f, torch.float64); _chk(level, torch.int32); _chk(pos, torch.float64)
     _chk(has_point, torch.uint8); _chk(T_f_w, torch.float64)
-    res = PoseOptResult(T_f_w.clone(), torch.zeros(B, 36, dtype=torch.float64, device=dev),
-                        torch.zeros(B, 4, dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.int32, device=dev),
-                        has_point.clone())
+    if out is not None:  # reuse a result block: pose and flags are in/out for the kernel
+        res = out
+        res.T_f_w.copy_(T_f_w)
+        res.has_point.copy_(has_point)
+    else:
+        res = PoseOptResult(T_f_w.clone(), torch.zeros(B, 36, dtype=torch.float64, device=dev),
+                            torch.zeros(B, 4, dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.int32, device=dev),
+                            has_point.clone())
     c = capi.camera(cam)
     fn = lib.svo_hip_pose_optimize_ordered if ordered else lib.svo_hip_pose_optimize
     capi.check(fn(C.byref(c), B, n.data_ptr(), ns, f.data_ptr(), level.data_ptr(), pos.data_ptr(),
@@ -242,15 +257,19 @@ class DepthFilter:
         self._ws = _Workspace()
 
     def update_seeds(self, store: PyramidStore, cam, frames: FrameTable, cur_frame, ftr: FeatureSet, seeds: SeedSet,
-                     batch_counter: int):
-        """Returns (status [S] i32 capi.SEED_*, xyz_world [S,3], px_cur [S,2])."""
+                     batch_counter: int, out=None):
+        """Returns (status [S] i32 capi.SEED_*, xyz_world [S,3], px_cur [S,2]); out: those three to reuse."""
         S = seeds.mu.shape[0]
         dev = store.device
         self.opt.batch_counter = batch_counter
-        status = torch.zeros(S, dtype=torch.int32, device=dev)
-        xyz = torch.zeros(S, 3, dtype=torch.float64, device=dev)
-        px = torch.zeros(S, 2, dtype=torch.float64, device=dev)
+        if out is not None:
+            status, xyz, px = out
+        else:
+            status = torch.zeros(S, dtype=torch.int32, device=dev)
+            xyz = torch.zeros(S, 3, dtype=torch.float64, device=dev)
+            px = torch.zeros(S, 2, dtype=torch.float64, device=dev)
         ws = self._ws.get(self.lib, S, dev)
+        self.last_workspace = ws
         c, fr, ft, sd = capi.camera(cam), frames.struct(), ftr.struct(), seeds.struct()
         capi.check(self.lib.svo_hip_update_seeds(C.byref(store.layout), store.ptr, C.byref(c), C.byref(fr), S,
                                                  _chk(cur_frame, torch.int32).data_ptr(), C.byref(ft), C.byref(sd),
