@@ -238,6 +238,9 @@ int ref_sparse_img_align_batch(int B, const orc_pyramid* pyrs, const int* ref_sl
       res[b].stop = sia.stop_;
       res[b].chi2 = sia.chi2();
       for (int l = 0; l < ORC_MAX_LEVELS; ++l) res[b].iters[l] = sia.evals[l];
+      if (n[b] > 0)
+        for (int i = 0; i < 6; ++i)
+          for (int j = 0; j < 6; ++j) res[b].H[i * 6 + j] = sia.H()(i, j);
     }
   };
   const auto t0 = std::chrono::steady_clock::now();

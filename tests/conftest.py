@@ -36,3 +36,16 @@ def gpu_device(hip_lib):
     if not torch.cuda.is_available():
         pytest.fail("gpu-marked test started without a visible HIP device")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module", params=["orc", "ref"])
+def checker(request, oracle):
+    """Which CPU checker a GPU parity test compares against: "orc" = oracle/libsvo_oracle.so (the C
+    restatement, always present), "ref" = oracle/_ref/libsvo_ref.so (the reference's own translation
+    units; built where the reference checkout exists and shipped to the GPU box prebuilt).  The
+    "ref" leg closes the chain HIP <-> reference on the GPU box itself."""
+    if request.param == "ref":
+        from oracle import pytrack
+        if not pytrack.ref_available():
+            pytest.skip("oracle/_ref/libsvo_ref.so not built (needs the reference checkout at build time)")
+    return request.param

@@ -39,12 +39,13 @@ def make_batch(seq: synth.Sequence, pairs, n_levels: int, n_valid=None, prior="r
     return b
 
 
-def run_oracle(oracle, b: Batch, max_level, min_level, n_iter=30, halfsample=None, n_threads=4):
+def run_oracle(oracle, b: Batch, max_level, min_level, n_iter=30, halfsample=None, n_threads=4, which="orc"):
+    """which: "orc" = the C restatement, "ref" = the reference's own SparseImgAlign (oracle/_ref)."""
     mode = oracle.HALFSAMPLE_AUTO if halfsample is None else halfsample
     pyrs = [oracle.create_img_pyramid(im, b.n_levels, mode) for im in b.images]
     T, res = oracle.sparse_img_align_batch(pyrs, b.ref_slot, b.cur_slot, b.cam, b.T_ref_w, b.T_cur_w, b.n,
                                            b.px, b.f, b.has_point, b.pos, max_level, min_level, n_iter,
-                                           n_threads=n_threads)
+                                           n_threads=n_threads, which=which)
     return T, res, pyrs
 
 

@@ -60,6 +60,12 @@ def test_fast_detect_bit_exact(oracle, gpu_device, w, h, f, levels, cell):
         assert n > 50
         assert np.array_equal(sc[i].view(np.uint32), esc.view(np.uint32)), f"image {i}: scores differ"
         assert np.array_equal(xy[i], exy) and np.array_equal(lvl[i], elvl)
+        if pytrack.ref_available():
+            # the reference's own FastDetector::detect (oracle/_ref) on the same pyramid: the features it
+            # creates are the device's cells with score > threshold, in cell order
+            px_ref, lvl_ref = pytrack.ref_fast_detect(pyr, cam, levels, cell, occ[i], 20.0)
+            sel = sc[i] > 20.0
+            assert np.array_equal(xy[i][sel].astype(np.float64), px_ref) and np.array_equal(lvl[i][sel], lvl_ref)
 
 
 @pytest.mark.gpu

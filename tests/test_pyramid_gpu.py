@@ -12,8 +12,13 @@ SHAPES = [(640, 480, 4), (752, 480, 5), (1280, 960, 5), (70, 50, 3), (67, 35, 2)
 
 
 def _check(store, oracle, imgs, levels, mode, first):
+    from oracle import pytrack
+    trk_ref = pytrack.Track("ref") if pytrack.ref_available() else None
     for i in range(len(imgs)):
         ref = oracle.create_img_pyramid(imgs[i], levels, mode)
+        if trk_ref is not None:  # frame_utils::createImgPyramid of the reference itself (oracle/_ref)
+            rr = trk_ref.create_img_pyramid(imgs[i], levels, mode)
+            assert all(np.array_equal(a, b) for a, b in zip(ref, rr))
         for l in range(levels):
             got = store.level(first + i, l)
             assert got.shape == ref[l].shape

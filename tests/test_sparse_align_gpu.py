@@ -28,8 +28,8 @@ def seq_vga():
     return synth.make_sequence(17, 200)
 
 
-def compare(oracle, b, max_level, min_level, n_iter=30, tol=TOL):
-    T_o, res_o, _ = run_oracle(oracle, b, max_level, min_level, n_iter)
+def compare(oracle, b, max_level, min_level, n_iter=30, tol=TOL, which="orc"):
+    T_o, res_o, _ = run_oracle(oracle, b, max_level, min_level, n_iter, which=which)
     T_h, out, _ = run_hip(b, max_level, min_level, n_iter)
     d = se3.log_norm(T_h, T_o)
     ntr_o = np.array([r["n_tracked"] for r in res_o])
@@ -45,11 +45,11 @@ def compare(oracle, b, max_level, min_level, n_iter=30, tol=TOL):
     return d, same_iters, T_o, T_h, res_o, out
 
 
-def test_config2_vga_4levels(oracle, gpu_device, seq_vga):
+def test_config2_vga_4levels(oracle, gpu_device, seq_vga, checker):
     """BASELINE config[1]: 640x480, 4 levels (3->0), ~200 patches."""
     pairs = [(i, i + 1) for i in range(16)]
     b = make_batch(seq_vga, pairs, 4)
-    d, same, T_o, T_h, res_o, out = compare(oracle, b, 3, 0)
+    d, same, T_o, T_h, res_o, out = compare(oracle, b, 3, 0, which=checker)
     assert np.median(d) <= TOL_MEDIAN
     assert same.mean() >= 0.75, f"only {same.mean():.2f} of problems ran identical iteration counts"
     # both must actually have solved the problem (pose error vs ground truth ~1e-4)
@@ -63,16 +63,16 @@ def test_config2_vga_4levels(oracle, gpu_device, seq_vga):
     assert np.allclose(out.chi2.cpu().numpy()[same], chi_o, rtol=1e-4)
 
 
-def test_reference_default_schedule(oracle, gpu_device):
+def test_reference_default_schedule(oracle, gpu_device, checker):
     """Pipeline default: 5-level pyramid, levels 4->2 (config.cpp:36-37), 752x480."""
     cam = synth.Camera(752, 480, 315.5, 315.5, 376.0, 240.0)
     seq = synth.make_sequence(5, 120, cam=cam, seed=7, margin=56, cell=40)
     b = make_batch(seq, [(i, i + 1) for i in range(4)], 5)
-    d, same, *_ = compare(oracle, b, 4, 2)
+    d, same, *_ = compare(oracle, b, 4, 2, which=checker)
     assert np.median(d) <= 1e-5
 
 
-def test_ragged_and_missing_points(oracle, gpu_device, seq_vga):
+def test_ragged_and_missing_points(oracle, gpu_device, seq_vga, checker):
     rng = np.random.default_rng(11)
     pairs = [(0, 1), (3, 4), (5, 6), (8, 9), (9, 10), (12, 11), (13, 14)]
     n_valid = [200, 12, 64, 65, 137, 0, 1]
@@ -80,7 +80,7 @@ def test_ragged_and_missing_points(oracle, gpu_device, seq_vga):
     hp[0] = 1
     hp[6] = 1
     b = make_batch(seq_vga, pairs, 4, n_valid=n_valid, has_point=hp)
-    T_o, res_o, _ = run_oracle(oracle, b, 3, 0)
+    T_o, res_o, _ = run_oracle(oracle, b, 3, 0, which=checker)
     T_h, out, _ = run_hip(b, 3, 0)
     d = se3.log_norm(T_h, T_o)
     ntr = out.n_tracked.cpu().numpy()
@@ -96,7 +96,7 @@ def test_ragged_and_missing_points(oracle, gpu_device, seq_vga):
     assert np.all(np.isfinite(T_h[6])) and ntr[6] <= 1
 
 
-def test_border_features_and_visibility(oracle, gpu_device):
+def test_border_features_and_visibility(oracle, gpu_device, checker):
     """Features close to the image border are invisible at coarse levels and join at
     finer ones (visible_fts_ is never reset, sparse_img_align.cpp:57)."""
     seq = synth.make_sequence(5, 200, seed=3)
@@ -117,38 +117,38 @@ def test_border_features_and_visibility(oracle, gpu_device):
     seq.f, seq.pos = synth.features_3d(seq.T_f_w, seq.cam, seq.px)
     b = make_batch(seq, [(0, 1), (1, 2), (2, 3), (3, 4), (4, 3)], 4)
     # full schedule: every feature is >= 3 px inside at level 0, so all join eventually
-    compare(oracle, b, 3, 0)
+    compare(oracle, b, 3, 0, which=checker)
     # stop at level 2 (12 px border at level 0): some features never become visible
-    d, same, T_o, T_h, res_o, out = compare(oracle, b, 3, 2)
+    d, same, T_o, T_h, res_o, out = compare(oracle, b, 3, 2, which=checker)
     ntr = out.n_tracked.cpu().numpy()
     assert np.all(ntr < 200) and np.all(ntr > 100), ntr
     assert all(r["visible"].sum() == t for r, t in zip(res_o, ntr)) if "visible" in res_o[0] else True
 
 
-def test_all_patches_outside(oracle, gpu_device, seq_vga):
+def test_all_patches_outside(oracle, gpu_device, seq_vga, checker):
     """Prior so wrong that nothing projects into the image: H = 0, x = 0, pose kept."""
     b = make_batch(seq_vga, [(0, 1), (2, 3)], 4)
     b.T_cur_w = se3.mul(se3.exp(np.array([[50.0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0.0, 0]])), b.T_cur_w)
-    T_o, res_o, _ = run_oracle(oracle, b, 3, 0)
+    T_o, res_o, _ = run_oracle(oracle, b, 3, 0, which=checker)
     T_h, out, _ = run_hip(b, 3, 0)
     assert res_o[0]["n_tracked"] == 0 and out.n_tracked.cpu().numpy()[0] == 0
     assert se3.log_norm(T_h[:1], T_o[:1]).max() < 1e-12
     assert se3.log_norm(T_h[1:], T_o[1:]).max() <= TOL
 
 
-def test_iteration_caps(oracle, gpu_device, seq_vga):
+def test_iteration_caps(oracle, gpu_device, seq_vga, checker):
     for n_iter in (0, 1, 2):
         b = make_batch(seq_vga, [(0, 1), (4, 5)], 4)
-        T_o, res_o, _ = run_oracle(oracle, b, 3, 0, n_iter=n_iter)
+        T_o, res_o, _ = run_oracle(oracle, b, 3, 0, n_iter=n_iter, which=checker)
         T_h, out, _ = run_hip(b, 3, 0, n_iter=n_iter)
         assert se3.log_norm(T_h, T_o).max() <= 1e-6
         assert np.array_equal(out.iters.cpu().numpy(), np.array([r["iters"] for r in res_o]))
         assert np.array_equal(out.n_tracked.cpu().numpy(), np.array([r["n_tracked"] for r in res_o]))
 
 
-def test_large_prior_error_and_noise(oracle, gpu_device, seq_vga):
+def test_large_prior_error_and_noise(oracle, gpu_device, seq_vga, checker):
     b = make_batch(seq_vga, [(i, i + 1) for i in range(8)], 4, prior_noise=4e-3, seed=5)
-    d, same, *_ = compare(oracle, b, 3, 0, tol=1e-3)
+    d, same, *_ = compare(oracle, b, 3, 0, tol=1e-3, which=checker)
     assert np.median(d) <= 1e-5
 
 

@@ -19,8 +19,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def orc(oracle):
-    return pytrack.Track("orc")
+def orc(oracle, checker):
+    """The CPU side of every comparison in this file: the C restatement and, where
+    oracle/_ref/libsvo_ref.so is present, the reference's own translation units."""
+    return pytrack.Track(checker)
 
 
 @pytest.fixture(scope="module")
