@@ -133,13 +133,23 @@ int svo_hip_pyramid_download_level(const svo_hip_pyr_layout* layout, const uint8
                                    int slot, int level, uint8_t* out, void* stream);
 
 /* ---- K1: sparse image alignment ----------------------------------------- */
+/* camera models: the vk::AbstractCamera implementations rpg_vikit ships and SVO's launch files use
+ * (svo_ros/param/camera_pinhole.yaml, camera_atan.yaml) */
+#define SVO_HIP_CAM_PINHOLE 0        /* vk::PinholeCamera, all distortion coefficients zero            */
+#define SVO_HIP_CAM_PINHOLE_RADTAN 1 /* vk::PinholeCamera, d = {d0, d1, d2, d3, d4} = k1 k2 p1 p2 k3    */
+#define SVO_HIP_CAM_ATAN 2           /* vk::ATANCamera; d = {s, 1/s, 2 tan(s/2), 1/(2 tan(s/2)), 0} and
+                                        fx, fy, cx, cy hold the constructor's fx_, fy_, cx_, cy_
+                                        (width*fx, height*fy, cx*width - 0.5, cy*height - 0.5): fill
+                                        the struct with svo_hip_camera_atan()                         */
+
 typedef struct svo_hip_sia_params {
-  double fx, fy, cx, cy; /* vk::PinholeCamera without distortion            */
-  int32_t max_level;     /* SparseImgAlign ctor, sparse_img_align.cpp:29-41 */
+  double fx, fy, cx, cy; /* camera intrinsics (see svo_hip_camera)                  */
+  int32_t max_level;     /* SparseImgAlign ctor, sparse_img_align.cpp:29-41         */
   int32_t min_level;
-  int32_t n_iter;        /* 30 in the pipeline, frame_handler_mono.cpp:136  */
-  int32_t reserved;
-  double eps;            /* 1e-6, sparse_img_align.cpp:40                   */
+  int32_t n_iter;        /* 30 in the pipeline, frame_handler_mono.cpp:136          */
+  int32_t cam_model;     /* SVO_HIP_CAM_*: world2cam of sparse_img_align.cpp:183    */
+  double eps;            /* 1e-6, sparse_img_align.cpp:40                           */
+  double d[5];           /* distortion parameters of cam_model (see svo_hip_camera) */
 } svo_hip_sia_params;
 
 /* status bits written per problem */
@@ -187,10 +197,23 @@ int svo_hip_solve6_hipsolver(int B, const double* d_H, const double* d_b, double
 /* update of the mapping thread.  All arrays are device pointers.            */
 /* ======================================================================== */
 
-typedef struct svo_hip_camera { /* vk::PinholeCamera without distortion */
+typedef struct svo_hip_camera { /* a vk::AbstractCamera: world2cam / cam2world / errorMultiplier2 = |fx| */
   double fx, fy, cx, cy;
   int32_t width, height;
+  int32_t model; /* SVO_HIP_CAM_* */
+  int32_t reserved;
+  double d[5];   /* distortion parameters of the model (zeros for SVO_HIP_CAM_PINHOLE) */
 } svo_hip_camera;
+
+/* Host-only constructors mirroring the vikit ones (no GPU needed).
+ *  svo_hip_camera_pinhole: vk::PinholeCamera(width, height, fx, fy, cx, cy, d0..d4); the model is
+ *      SVO_HIP_CAM_PINHOLE when |d0| <= 1e-7 (vikit's `distortion_` test), else ..._RADTAN.
+ *  svo_hip_camera_atan:    vk::ATANCamera(width, height, fx, fy, cx, cy, s) with the NORMALISED
+ *      parameters of camera_atan.yaml. */
+int svo_hip_camera_pinhole(int width, int height, double fx, double fy, double cx, double cy, double d0, double d1,
+                           double d2, double d3, double d4, svo_hip_camera* out);
+int svo_hip_camera_atan(int width, int height, double fx, double fy, double cx, double cy, double s,
+                        svo_hip_camera* out);
 
 #define SVO_HIP_FTR_CORNER 0  /* svo::Feature::FeatureType (feature.h:30-33) */
 #define SVO_HIP_FTR_EDGELET 1

@@ -23,8 +23,9 @@ class Pyramid(C.Structure):
 
 
 class Pinhole(C.Structure):
+    """orc_pinhole (orc_camera.h): intrinsics + model tag + distortion parameters."""
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
-                ("width", C.c_int), ("height", C.c_int)]
+                ("width", C.c_int), ("height", C.c_int), ("model", C.c_int), ("pad_", C.c_int), ("d", C.c_double * 5)]
 
 
 class SiaOptions(C.Structure):
@@ -153,7 +154,8 @@ def make_pyramid_struct(levels: list[np.ndarray]) -> Pyramid:
 
 
 def make_cam(cam) -> Pinhole:
-    return Pinhole(cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height)
+    d = tuple(getattr(cam, "d", (0.0,) * 5))
+    return Pinhole(cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height, int(getattr(cam, "model", 0)), 0, (C.c_double * 5)(*d))
 
 
 # ---- SparseImgAlign --------------------------------------------------------

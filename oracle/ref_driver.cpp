@@ -27,6 +27,7 @@
 #include <svo/point.h>
 #include <svo/pose_optimizer.h>
 #include <svo/sparse_img_align.h>
+#include <vikit/atan_camera.h>
 #include <vikit/pinhole_camera.h>
 #include <vikit/vision.h>
 
@@ -54,8 +55,10 @@ void se3_to_Rt(const SE3& S, double T[12]) {
   T[9] = t[0]; T[10] = t[1]; T[11] = t[2];
 }
 
-vk::PinholeCamera* make_cam(const orc_pinhole* c) {
-  return new vk::PinholeCamera(c->width, c->height, c->fx, c->fy, c->cx, c->cy);
+// the reference-side camera object for a camera description (orc_camera.h)
+vk::AbstractCamera* make_cam(const orc_pinhole* c) {
+  if (c->model == ORC_CAM_ATAN) return new vk::ATANCamera(*c);
+  return new vk::PinholeCamera(c->width, c->height, c->fx, c->fy, c->cx, c->cy, c->d[0], c->d[1], c->d[2], c->d[3], c->d[4]);
 }
 
 // A reference Frame built from level 0 (the reference builds its own pyramid through
@@ -157,7 +160,7 @@ int ref_sparse_img_align_run(const orc_pyramid* ref_pyr, const orc_pyramid* cur_
                              const uint8_t* has_point, const double* pos, const orc_sia_options* opt,
                              orc_sia_result* res, uint8_t* visible_out) {
   std::memset(res, 0, sizeof(*res));
-  vk::PinholeCamera* c = make_cam(cam);
+  vk::AbstractCamera* c = make_cam(cam);
   FramePtr ref = make_frame(c, ref_pyr, T_ref_w);
   FramePtr cur = make_frame(c, cur_pyr, T_cur_w);
   std::vector<Point*> points;
@@ -201,7 +204,7 @@ int ref_sparse_img_align_batch(int B, const orc_pyramid* pyrs, const int* ref_sl
                                const orc_pinhole* cam, const double* T_ref_w, double* T_cur_w, const int* n, int n_stride,
                                const double* px, const double* f, const uint8_t* has_point, const double* pos,
                                const orc_sia_options* opt, orc_sia_result* res, int n_threads, double* seconds_out) {
-  vk::PinholeCamera* c = make_cam(cam);
+  vk::AbstractCamera* c = make_cam(cam);
   std::vector<FramePtr> refs(B), curs(B);
   std::vector<Point*> points;
   for (int b = 0; b < B; ++b) {
@@ -293,8 +296,8 @@ int ref_align1d(const uint8_t* cur_img, int w, int h, int stride, const float di
 void ref_get_warp_matrix_affine(const orc_pinhole* cam_ref, const orc_pinhole* cam_cur, const double px_ref[2],
                                 const double f_ref[3], double depth_ref, const double T_cur_ref[12], int level_ref,
                                 double A_cur_ref[4]) {
-  vk::PinholeCamera* cr = make_cam(cam_ref);
-  vk::PinholeCamera* cc = make_cam(cam_cur);
+  vk::AbstractCamera* cr = make_cam(cam_ref);
+  vk::AbstractCamera* cc = make_cam(cam_cur);
   Matrix2d A;
   warp::getWarpMatrixAffine(*cr, *cc, Vector2d(px_ref[0], px_ref[1]), Vector3d(f_ref[0], f_ref[1], f_ref[2]),
                             depth_ref, se3_from_Rt(T_cur_ref), level_ref, A);
@@ -327,7 +330,7 @@ int ref_find_match_direct(const orc_frame* frames, const orc_pinhole* cam, int c
   res->success = 0;
   res->ref_obs = -1;
   if (n_obs <= 0) return 0;
-  vk::PinholeCamera* c = make_cam(cam);
+  vk::AbstractCamera* c = make_cam(cam);
   std::map<int, FramePtr> fr;
   auto get = [&](int idx) {
     auto it = fr.find(idx);
@@ -377,7 +380,7 @@ int ref_find_match_direct(const orc_frame* frames, const orc_pinhole* cam, int c
 int ref_find_epipolar_match_direct(const orc_frame* frames, const orc_pinhole* cam, int ref_frame, int cur_frame,
                                    const orc_feature* ref_ftr, double d_estimate, double d_min, double d_max,
                                    const orc_matcher_options* opt, orc_match_result* res) {
-  vk::PinholeCamera* c = make_cam(cam);
+  vk::AbstractCamera* c = make_cam(cam);
   FramePtr ref = make_frame(c, &frames[ref_frame].pyr, frames[ref_frame].T_f_w);
   FramePtr cur = make_frame(c, &frames[cur_frame].pyr, frames[cur_frame].T_f_w);
   Feature* ftr = make_feature(ref.get(), ref_ftr);
@@ -406,7 +409,7 @@ int ref_pose_optimize(double reproj_thresh, int n_iter, const orc_pinhole* cam, 
                       orc_pose_opt_result* res) {
   std::memset(res, 0, sizeof(*res));
   std::memcpy(res->T_f_w, T_f_w, sizeof(double) * 12);
-  vk::PinholeCamera* c = make_cam(cam);
+  vk::AbstractCamera* c = make_cam(cam);
   Config::nPyrLevels() = 1;
   Config::kltMaxLevel() = 0;
   cv::Mat img0(cam->height, cam->width, CV_8UC1, cv::Scalar(0));
@@ -450,7 +453,7 @@ int ref_pose_optimize(double reproj_thresh, int n_iter, const orc_pinhole* cam, 
 
 void ref_point_optimize(int n_iter, int n_obs, const double* T_f_w, const double* f, double pos[3]) {
   orc_pinhole pc = {100, 100, 50, 50, 100, 100};
-  vk::PinholeCamera* c = make_cam(&pc);
+  vk::AbstractCamera* c = make_cam(&pc);
   Config::nPyrLevels() = 1;
   Config::kltMaxLevel() = 0;
   std::vector<FramePtr> frames;
@@ -491,7 +494,7 @@ double ref_compute_tau(const double T_ref_cur[12], const double f[3], double z, 
 int ref_update_seeds(const orc_frame* frames, const orc_pinhole* cam, int cur_frame, int n_seeds, orc_seed* seeds,
                      orc_seed_update_info* info, const orc_depth_filter_options* dopt,
                      const orc_matcher_options* mopt) {
-  vk::PinholeCamera* c = make_cam(cam);
+  vk::AbstractCamera* c = make_cam(cam);
   std::map<int, FramePtr> fr;
   auto get = [&](int idx) {
     auto it = fr.find(idx);
@@ -576,7 +579,7 @@ int ref_update_seeds(const orc_frame* frames, const orc_pinhole* cam, int cur_fr
 // library: features in the order the detector emits them (cell order).  Returns their count.
 int ref_fast_detect(const orc_pyramid* pyr, const orc_pinhole* cam, int n_levels, int cell_size, const uint8_t* occupancy,
                     double detection_threshold, int max_out, double* px_out, int32_t* level_out) {
-  vk::PinholeCamera* c = make_cam(cam);
+  vk::AbstractCamera* c = make_cam(cam);
   const double T0[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
   FramePtr frame = make_frame(c, pyr, T0);
   feature_detection::FastDetector det(cam->width, cam->height, cell_size, n_levels);
@@ -605,7 +608,7 @@ int ref_reproject_point(const orc_pinhole* cam, const double T_f_w[12], const do
   // Reprojector::reprojectPoint is private; its three statements are frame->w2c(),
   // isInFrame(px.cast<int>(), 8) and the cell index (reprojector.cpp:208-213) -- executed
   // here through the reference's Frame and camera objects.
-  vk::PinholeCamera* c = make_cam(cam);
+  vk::AbstractCamera* c = make_cam(cam);
   Config::nPyrLevels() = 1;
   Config::kltMaxLevel() = 0;
   cv::Mat img0(cam->height, cam->width, CV_8UC1, cv::Scalar(0));

@@ -197,11 +197,12 @@ static double compute_residuals(sia_t* s, const orc_se3* T_cur_from_ref, int lin
     const double xyz_ref[3] = {s->f[3 * i] * depth, s->f[3 * i + 1] * depth, s->f[3 * i + 2] * depth};
     double xyz_cur[3];
     orc_se3_apply(T_cur_from_ref, xyz_ref, xyz_cur);
-    /* vk::PinholeCamera::world2cam (no distortion): px = f * (x/z) + c */
-    const double uvx = xyz_cur[0] / xyz_cur[2];
-    const double uvy = xyz_cur[1] / xyz_cur[2];
-    const double pxd = s->cam->fx * uvx + s->cam->cx;
-    const double pyd = s->cam->fy * uvy + s->cam->cy;
+    /* cur_frame_->cam_->world2cam(xyz_cur) = world2cam(project2d(xyz_cur)) */
+    const double uvn[2] = {xyz_cur[0] / xyz_cur[2], xyz_cur[1] / xyz_cur[2]};
+    double pxy[2];
+    orc_cam_world2cam_uv(s->cam, uvn, pxy);
+    const double pxd = pxy[0];
+    const double pyd = pxy[1];
     const float u_cur = (float)pxd * scale;
     const float v_cur = (float)pyd * scale;
     const int u_cur_i = floorf(u_cur);

@@ -76,10 +76,7 @@ typedef struct {
   const uint8_t* data[ORC_MAX_LEVELS]; /* stride == w, like a continuous cv::Mat */
 } orc_pyramid;
 
-typedef struct {
-  double fx, fy, cx, cy;
-  int width, height;
-} orc_pinhole;
+#include "orc_camera.h" /* orc_pinhole: intrinsics + model tag + distortion parameters */
 
 typedef struct {
   int max_level;

@@ -25,17 +25,9 @@ static inline double dot3(const double a[3], const double b[3]) { return a[0] * 
 static inline void normalize3(double v[3]) { double n = norm3(v); v[0] /= n; v[1] /= n; v[2] /= n; }
 static inline double norm2(const double v[2]) { return sqrt(v[0] * v[0] + v[1] * v[1]); }
 
-/* ---- vk::PinholeCamera without distortion (rpg_vikit pinhole_camera.cpp) -------- */
-static inline void cam2world(const orc_pinhole* c, double u, double v, double f[3]) {
-  f[0] = (u - c->cx) / c->fx;
-  f[1] = (v - c->cy) / c->fy;
-  f[2] = 1.0;
-  normalize3(f);
-}
-static inline void world2cam_uv(const orc_pinhole* c, const double uv[2], double px[2]) {
-  px[0] = c->fx * uv[0] + c->cx;
-  px[1] = c->fy * uv[1] + c->cy;
-}
+/* ---- vk::AbstractCamera (orc_camera.h: pinhole, pinhole + radial-tangential, ATAN) ---- */
+static inline void cam2world(const orc_pinhole* c, double u, double v, double f[3]) { orc_cam_cam2world(c, u, v, f); }
+static inline void world2cam_uv(const orc_pinhole* c, const double uv[2], double px[2]) { orc_cam_world2cam_uv(c, uv, px); }
 static inline void project2d(const double v[3], double uv[2]) { uv[0] = v[0] / v[2]; uv[1] = v[1] / v[2]; }
 static inline void world2cam(const orc_pinhole* c, const double xyz[3], double px[2]) {
   double uv[2];

@@ -37,14 +37,15 @@ class SiaParams(C.Structure):
     _fields_ = [
         ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
         ("max_level", C.c_int32), ("min_level", C.c_int32), ("n_iter", C.c_int32),
-        ("reserved", C.c_int32), ("eps", C.c_double),
+        ("cam_model", C.c_int32), ("eps", C.c_double), ("d", C.c_double * 5),
     ]
 
 
 class Camera(C.Structure):
-    """svo_hip_camera: vk::PinholeCamera without distortion."""
+    """svo_hip_camera: a vk::AbstractCamera (pinhole, pinhole + radial-tangential, ATAN)."""
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
-                ("width", C.c_int32), ("height", C.c_int32)]
+                ("width", C.c_int32), ("height", C.c_int32), ("model", C.c_int32), ("reserved", C.c_int32),
+                ("d", C.c_double * 5)]
 
 
 class Frames(C.Structure):
@@ -104,6 +105,8 @@ PROTOTYPES = {
     "svo_hip_graph_end_capture": (_i, [_vp, C.POINTER(_vp)]),
     "svo_hip_graph_launch": (_i, [_vp, _vp]),
     "svo_hip_graph_destroy": (_i, [_vp]),
+    "svo_hip_camera_pinhole": (_i, [_i, _i] + [C.c_double] * 9 + [C.POINTER(Camera)]),
+    "svo_hip_camera_atan": (_i, [_i, _i] + [C.c_double] * 5 + [C.POINTER(Camera)]),
     "svo_hip_pyr_layout_init": (_i, [_i, _i, _i, C.POINTER(PyrLayout)]),
     "svo_hip_pyr_store_bytes": (_i64, [C.POINTER(PyrLayout), _i]),
     "svo_hip_pyramid_load_level0": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _i64, _i, _vp]),
@@ -183,4 +186,8 @@ def pyr_store_bytes(L: PyrLayout, n_slots: int) -> int:
 
 
 def camera(cam) -> Camera:
-    return Camera(cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height)
+    """svo_hip_camera of a camera description with fx, fy, cx, cy, width, height and (optionally)
+    model / d as svo_hip_camera defines them (rpg_svo_amd.synth.Camera)."""
+    d = tuple(getattr(cam, "d", (0.0,) * 5))
+    return Camera(cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height, int(getattr(cam, "model", 0)), 0,
+                  (C.c_double * 5)(*d))

@@ -2,6 +2,8 @@
 // layout of the C ABI (include/svo_hip.h).  No kernels here.
 #include <cstring>
 
+#include <cmath>
+
 #include "capi_common.h"
 
 namespace svo_capi {
@@ -163,6 +165,43 @@ int svo_hip_graph_launch(void* graph_exec, void* stream) {
 
 int svo_hip_graph_destroy(void* graph_exec) {
   SVO_HIP_TRY(hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec)));
+  return SVO_HIP_OK;
+}
+
+// vk::PinholeCamera::PinholeCamera (vikit pinhole_camera.cpp): distortion_ = fabs(d0) > 0.0000001
+int svo_hip_camera_pinhole(int width, int height, double fx, double fy, double cx, double cy, double d0, double d1,
+                           double d2, double d3, double d4, svo_hip_camera* out) {
+  if (!out || width < 1 || height < 1) return SVO_HIP_EINVAL;
+  out->fx = fx; out->fy = fy; out->cx = cx; out->cy = cy;
+  out->width = width; out->height = height;
+  out->reserved = 0;
+  const bool distortion = fabs(d0) > 0.0000001;
+  out->model = distortion ? SVO_HIP_CAM_PINHOLE_RADTAN : SVO_HIP_CAM_PINHOLE;
+  const double d[5] = {d0, d1, d2, d3, d4};
+  for (int i = 0; i < 5; ++i) out->d[i] = distortion ? d[i] : 0.0;
+  return SVO_HIP_OK;
+}
+
+// vk::ATANCamera::ATANCamera (vikit atan_camera.cpp): fx_ = width*fx, cx_ = cx*width - 0.5, ...;
+// s != 0: tans_ = 2 tan(s/2), tans_inv_ = 1/tans_, s_inv_ = 1/s
+int svo_hip_camera_atan(int width, int height, double fx, double fy, double cx, double cy, double s,
+                        svo_hip_camera* out) {
+  if (!out || width < 1 || height < 1) return SVO_HIP_EINVAL;
+  out->fx = (double)width * fx;
+  out->fy = (double)height * fy;
+  out->cx = cx * (double)width - 0.5;
+  out->cy = cy * (double)height - 0.5;
+  out->width = width; out->height = height;
+  out->model = SVO_HIP_CAM_ATAN;
+  out->reserved = 0;
+  for (int i = 0; i < 5; ++i) out->d[i] = 0.0;
+  if (s != 0.0) {
+    const double tans = 2.0 * tan(s / 2.0);
+    out->d[0] = s;
+    out->d[1] = 1.0 / s;
+    out->d[2] = tans;
+    out->d[3] = 1.0 / tans;
+  }
   return SVO_HIP_OK;
 }
 

@@ -273,8 +273,12 @@ __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) 
   // so multiplying by 2^-level gives the same bits without two f64 division sequences per step
   const double inv_lvl = 1.0 / lvl;
   for (int i = 0; i < n_total; ++i, uv0 += step0, uv1 += step1) {
-    const double px0 = a.cam.fx * uv0 + a.cam.cx;
-    const double px1 = a.cam.fy * uv1 + a.cam.cy;
+    double pxs[2];
+    {
+      const double uvs[2] = {uv0, uv1};
+      world2cam_uv(a.cam, uvs, pxs);  // cur_frame.cam_->world2cam(uv), matcher.cpp:269
+    }
+    const double px0 = pxs[0], px1 = pxs[1];
     const int pxi0 = cast_int(px0 * inv_lvl + 0.5);
     const int pxi1 = cast_int(px1 * inv_lvl + 0.5);
     if (pxi0 == last_x && pxi1 == last_y) continue;
@@ -317,7 +321,12 @@ __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) 
     // exactly one lane owns step win_i
     w.uv_best[2 * s] = best_uv0;
     w.uv_best[2 * s + 1] = best_uv1;
-    const double pc0 = a.cam.fx * best_uv0 + a.cam.cx, pc1 = a.cam.fy * best_uv1 + a.cam.cy;
+    double pcs[2];
+    {
+      const double uvb[2] = {best_uv0, best_uv1};
+      world2cam_uv(a.cam, uvb, pcs);  // px_cur_ = cur_frame.cam_->world2cam(uv_best), matcher.cpp:297,316
+    }
+    const double pc0 = pcs[0], pc1 = pcs[1];
     w.px_cur[2 * s] = pc0;
     w.px_cur[2 * s + 1] = pc1;
     w.px_scaled[2 * s] = pc0 / lvl;
@@ -538,7 +547,7 @@ extern "C" int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint
                                     const svo_hip_seeds* seeds, const svo_hip_depth_filter_options* opt,
                                     int32_t* d_status, double* d_xyz_world, double* d_px_cur, void* d_workspace,
                                     size_t workspace_bytes, void* stream) {
-  if (!layout_ok(layout) || !d_store || !cam || !frames || !ftr || !seeds || !opt || S < 0) return SVO_HIP_EINVAL;
+  if (!layout_ok(layout) || !d_store || !cam || !cam_model_ok(cam) || !frames || !ftr || !seeds || !opt || S < 0) return SVO_HIP_EINVAL;
   if (S == 0) return SVO_HIP_OK;
   if (!d_cur_frame || !d_status || !frames->d_slot || !frames->d_T_f_w || !ftr->d_frame || !ftr->d_level ||
       !ftr->d_px || !ftr->d_f || !seeds->d_a || !seeds->d_b || !seeds->d_mu || !seeds->d_z_range ||
@@ -555,8 +564,7 @@ extern "C" int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint
   SeedArgs a;
   a.L = *layout;
   a.store = d_store;
-  a.cam.fx = cam->fx; a.cam.fy = cam->fy; a.cam.cx = cam->cx; a.cam.cy = cam->cy;
-  a.cam.width = cam->width; a.cam.height = cam->height;
+  a.cam = make_cam(cam);
   a.S = S;
   a.frame_slot = frames->d_slot;
   a.frame_T = frames->d_T_f_w;

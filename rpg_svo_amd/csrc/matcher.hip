@@ -273,12 +273,6 @@ __global__ void __launch_bounds__(256) cam2world_kernel(const GlueArgs a) {
   a.f[3 * i + 2] = f[2];
 }
 
-inline Cam make_cam(const svo_hip_camera* c) {
-  Cam k;
-  k.fx = c->fx; k.fy = c->fy; k.cx = c->cx; k.cy = c->cy; k.width = c->width; k.height = c->height;
-  return k;
-}
-
 }  // namespace
 
 namespace svo_track {
@@ -312,7 +306,7 @@ extern "C" int svo_hip_find_match_direct(const svo_hip_pyr_layout* layout, const
                                          int align_max_iter, double* d_px_cur, int32_t* d_ok, int32_t* d_ref_obs,
                                          int32_t* d_search_level, double* d_A_cur_ref, uint8_t* d_patch_out,
                                          void* d_workspace, size_t workspace_bytes, void* stream) {
-  if (!layout_ok(layout) || !d_store || !cam || !frames || !obs || M < 0) return SVO_HIP_EINVAL;
+  if (!layout_ok(layout) || !d_store || !cam || !cam_model_ok(cam) || !frames || !obs || M < 0) return SVO_HIP_EINVAL;
   if (M == 0) return SVO_HIP_OK;
   if (!d_cur_frame || !d_pt_pos || !d_obs_ptr || !d_px_cur || !d_ok || !d_ref_obs || !d_search_level ||
       !frames->d_slot || !frames->d_T_f_w || !obs->d_frame || !obs->d_level || !obs->d_px || !obs->d_f)
@@ -387,7 +381,7 @@ extern "C" int svo_hip_find_match_direct(const svo_hip_pyr_layout* layout, const
 extern "C" int svo_hip_reproject_points(const svo_hip_camera* cam, const svo_hip_frames* frames, int M,
                                         const int32_t* d_cur_frame, const double* d_pt_pos, int cell_size,
                                         int grid_n_cols, int32_t* d_cell, double* d_px, void* stream) {
-  if (!cam || !frames || M < 0 || cell_size < 1 || grid_n_cols < 1) return SVO_HIP_EINVAL;
+  if (!cam || !cam_model_ok(cam) || !frames || M < 0 || cell_size < 1 || grid_n_cols < 1) return SVO_HIP_EINVAL;
   if (M == 0) return SVO_HIP_OK;
   if (!d_cur_frame || !d_pt_pos || !d_cell || !frames->d_T_f_w) return SVO_HIP_EINVAL;
   ReprojArgs a;
@@ -420,7 +414,7 @@ extern "C" int svo_hip_compose_poses(int n, const double* d_A, const double* d_B
 }
 
 extern "C" int svo_hip_cam2world(const svo_hip_camera* cam, int n, const double* d_px, double* d_f, void* stream) {
-  if (!cam || n < 0) return SVO_HIP_EINVAL;
+  if (!cam || !cam_model_ok(cam) || n < 0) return SVO_HIP_EINVAL;
   if (n == 0) return SVO_HIP_OK;
   if (!d_px || !d_f) return SVO_HIP_EINVAL;
   GlueArgs a{};

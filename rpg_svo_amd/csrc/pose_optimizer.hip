@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(PO_BLOCK, PO_MINW) pose_opt_kernel(const PoseA
 static int pose_args_check(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride, const double* d_f,
                            const int32_t* d_level, const double* d_pos, uint8_t* d_has_point, int n_iter,
                            double* d_T_f_w, double* d_stats, int32_t* d_ran) {
-  if (!cam || B < 0 || n_stride < 1 || n_iter < 0) return SVO_HIP_EINVAL;
+  if (!cam || !cam_model_ok(cam) || B < 0 || n_stride < 1 || n_iter < 0) return SVO_HIP_EINVAL;
   if (n_stride > PO_MAXN) return SVO_HIP_ERANGE;
   if (B == 0) return 1;
   if (!d_n || !d_f || !d_level || !d_pos || !d_has_point || !d_T_f_w || !d_stats || !d_ran) return SVO_HIP_EINVAL;
@@ -394,8 +394,7 @@ static int launch_ordered(const svo_hip_camera* cam, int B, const int32_t* d_n, 
                           int n_iter, double* d_T_f_w, double* d_Cov, double* d_stats, int32_t* d_ran, int only_flagged,
                           void* stream) {
   PoseArgs a;
-  a.cam.fx = cam->fx; a.cam.fy = cam->fy; a.cam.cx = cam->cx; a.cam.cy = cam->cy;
-  a.cam.width = cam->width; a.cam.height = cam->height;
+  a.cam = make_cam(cam);
   a.n = d_n;
   a.n_stride = n_stride;
   a.f = d_f;

@@ -34,6 +34,7 @@
 // results agree to rounding, not bit-for-bit.
 #include "capi_common.h"
 #include "device_math.h"
+#include "track_math.h"
 #include "wave_reduce.h"
 
 using namespace svo_capi;
@@ -196,7 +197,9 @@ __device__ __forceinline__ void sia_rebuild_hinv(int lane, int nw) {
   }
 }
 
-template <int BLOCK, bool WC>
+// DIST: the camera is a distorted model (radial-tangential pinhole or ATAN); the undistorted pinhole
+// keeps its own instantiation so that its inner loop carries no model dispatch.
+template <int BLOCK, bool WC, bool DIST>
 __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a) {
   constexpr int NW = BLOCK / 64;
   // XCD-aware problem order (capi_common.h): in a replay batch consecutive problems share a frame
@@ -384,10 +387,25 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
         const double xc = R[0] * X + R[1] * Y + R[2] * Z + tr[0];
         const double yc = R[3] * X + R[4] * Y + R[5] * Z + tr[1];
         const double zc = R[6] * X + R[7] * Y + R[8] * Z + tr[2];
-        // vk::PinholeCamera::world2cam(project2d(xyz)), one reciprocal
+        // cam_->world2cam(project2d(xyz)) (:183), one reciprocal
         const double izc = 1.0 / zc;
-        const double pu = P.fx * (xc * izc) + P.cx;
-        const double pv = P.fy * (yc * izc) + P.cy;
+        double pu, pv;
+        if (DIST) {
+          Cam cm;
+          cm.fx = P.fx; cm.fy = P.fy; cm.cx = P.cx; cm.cy = P.cy;
+          cm.width = 0; cm.height = 0;
+          cm.model = P.cam_model;
+#pragma unroll
+          for (int k = 0; k < 5; ++k) cm.d[k] = P.d[k];
+          const double uvn[2] = {xc * izc, yc * izc};
+          double pxd[2];
+          world2cam_uv(cm, uvn, pxd);
+          pu = pxd[0];
+          pv = pxd[1];
+        } else {
+          pu = P.fx * (xc * izc) + P.cx;
+          pv = P.fy * (yc * izc) + P.cy;
+        }
         const float u_cur = (float)pu * scale;
         const float v_cur = (float)pv * scale;
         const float fu = floorf(u_cur), fv = floorf(v_cur);
@@ -628,7 +646,10 @@ template <int BLOCK>
 int launch(const SiaArgs& args, int B, hipStream_t s) {
   // window cache where the workgroup is large enough for the extra registers to pay (see MINW)
   constexpr bool WC = (BLOCK == 256);  // 512 lanes: 168 VGPRs would leave one workgroup per CU
-  hipLaunchKernelGGL((sia_kernel<BLOCK, WC>), dim3(B), dim3(BLOCK), 0, s, args);
+  if (args.P.cam_model == SVO_HIP_CAM_PINHOLE)
+    hipLaunchKernelGGL((sia_kernel<BLOCK, WC, false>), dim3(B), dim3(BLOCK), 0, s, args);
+  else
+    hipLaunchKernelGGL((sia_kernel<BLOCK, false, true>), dim3(B), dim3(BLOCK), 0, s, args);  // atan / radtan code: no room for the window cache
   return check_launch();
 }
 
@@ -649,6 +670,9 @@ extern "C" int svo_hip_sparse_align(const svo_hip_pyr_layout* layout, const uint
   if (n_stride > SVO_HIP_MAX_PATCHES) return SVO_HIP_ERANGE;
   if (params->min_level < 0 || params->max_level < params->min_level || params->max_level >= layout->n_levels ||
       params->n_iter < 0)
+    return SVO_HIP_EINVAL;
+  if (params->cam_model != SVO_HIP_CAM_PINHOLE && params->cam_model != SVO_HIP_CAM_PINHOLE_RADTAN &&
+      params->cam_model != SVO_HIP_CAM_ATAN)
     return SVO_HIP_EINVAL;
   SiaArgs args;
   args.L = *layout;

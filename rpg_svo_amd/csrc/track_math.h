@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_math.h"
+#include "svo_hip.h"
 
 namespace svo_dev {
 
@@ -21,9 +22,15 @@ struct Se3 {
   double t[3];
 };
 
-struct Cam {  // vk::PinholeCamera, zero distortion
+// vk::AbstractCamera implementations of rpg_vikit, by model tag (include/svo_hip.h):
+//   SVO_HIP_CAM_PINHOLE         vk::PinholeCamera, distortion_ == false
+//   SVO_HIP_CAM_PINHOLE_RADTAN  vk::PinholeCamera with radial-tangential distortion d[0..4] = k1 k2 p1 p2 k3
+//   SVO_HIP_CAM_ATAN            vk::ATANCamera (PTAM's FOV model): d = {s, 1/s, 2 tan(s/2), 1/(2 tan(s/2))}
+struct Cam {
   double fx, fy, cx, cy;
   int width, height;
+  int model;
+  double d[5];
 };
 
 __device__ __forceinline__ double norm3(const double v[3]) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
@@ -76,16 +83,67 @@ __device__ __forceinline__ void frame_pos(const Se3& T_f_w, double p[3]) {
   p[0] = inv.t[0]; p[1] = inv.t[1]; p[2] = inv.t[2];
 }
 
-// ---- vk::PinholeCamera -------------------------------------------------------------
-__device__ __forceinline__ void cam2world(const Cam& c, double u, double v, double f[3]) {
-  f[0] = (u - c.cx) / c.fx;
-  f[1] = (v - c.cy) / c.fy;
-  f[2] = 1.0;
-  normalize3(f);
+// ---- vk::PinholeCamera / vk::ATANCamera ---------------------------------------------
+// cam2world of the distorted pinhole goes through cv::undistortPoints on CV_32FC2 points with a
+// float camera matrix / distortion vector (vikit pinhole_camera.cpp): pixel, intrinsics and
+// coefficients are rounded to float first, five fixed-point iterations run in double, the result is
+// rounded to float again.
+__device__ inline void cam2world(const Cam& c, double u, double v, double f[3]) {
+  if (c.model == SVO_HIP_CAM_PINHOLE) {
+    f[0] = (u - c.cx) / c.fx;
+    f[1] = (v - c.cy) / c.fy;
+    f[2] = 1.0;
+  } else if (c.model == SVO_HIP_CAM_PINHOLE_RADTAN) {
+    const double fx = (double)(float)c.fx, fy = (double)(float)c.fy, cx = (double)(float)c.cx, cy = (double)(float)c.cy;
+    const double k0 = (double)(float)c.d[0], k1 = (double)(float)c.d[1], k2 = (double)(float)c.d[2];
+    const double k3 = (double)(float)c.d[3], k4 = (double)(float)c.d[4];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    double x = (double)(float)u, y = (double)(float)v;
+    const double x0 = x = (x - cx) * ifx;
+    const double y0 = y = (y - cy) * ify;
+    for (int j = 0; j < 5; ++j) {
+      const double r2 = x * x + y * y;
+      const double icdist = 1. / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
+      const double deltaX = 2 * k2 * x * y + k3 * (r2 + 2 * x * x);
+      const double deltaY = k2 * (r2 + 2 * y * y) + 2 * k3 * x * y;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    f[0] = (double)(float)x;
+    f[1] = (double)(float)y;
+    f[2] = 1.0;
+  } else {
+    const double fx_inv = 1.0 / c.fx, fy_inv = 1.0 / c.fy;
+    const double dc[2] = {(u - c.cx) * fx_inv, (v - c.cy) * fy_inv};
+    const double dist_r = sqrt(dc[0] * dc[0] + dc[1] * dc[1]);
+    const double r = (c.d[0] == 0.0) ? dist_r : tan(dist_r * c.d[0]) * c.d[3];  // invrtrans
+    const double d_factor = (dist_r > 0.01) ? r / dist_r : 1.0;
+    f[0] = d_factor * dc[0];
+    f[1] = d_factor * dc[1];
+    f[2] = 1.0;
+  }
+  const double n = sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+  f[0] /= n; f[1] /= n; f[2] /= n;
 }
-__device__ __forceinline__ void world2cam_uv(const Cam& c, const double uv[2], double px[2]) {
-  px[0] = c.fx * uv[0] + c.cx;
-  px[1] = c.fy * uv[1] + c.cy;
+__device__ inline void world2cam_uv(const Cam& c, const double uv[2], double px[2]) {
+  if (c.model == SVO_HIP_CAM_PINHOLE) {
+    px[0] = c.fx * uv[0] + c.cx;
+    px[1] = c.fy * uv[1] + c.cy;
+  } else if (c.model == SVO_HIP_CAM_PINHOLE_RADTAN) {
+    const double x = uv[0], y = uv[1];
+    const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+    const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+    const double cdist = 1 + c.d[0] * r2 + c.d[1] * r4 + c.d[4] * r6;
+    const double xd = x * cdist + c.d[2] * a1 + c.d[3] * a2;
+    const double yd = y * cdist + c.d[2] * a3 + c.d[3] * a1;
+    px[0] = xd * c.fx + c.cx;
+    px[1] = yd * c.fy + c.cy;
+  } else {
+    const double r = sqrt(uv[0] * uv[0] + uv[1] * uv[1]);
+    const double factor = (r < 0.001 || c.d[0] == 0.0) ? 1.0 : (c.d[1] * atan(r * c.d[2]) / r);  // rtrans_factor
+    px[0] = c.cx + c.fx * (factor * uv[0]);
+    px[1] = c.cy + c.fy * (factor * uv[1]);
+  }
 }
 __device__ __forceinline__ void project2d(const double v[3], double uv[2]) {
   uv[0] = v[0] / v[2];
@@ -95,6 +153,17 @@ __device__ __forceinline__ void world2cam(const Cam& c, const double xyz[3], dou
   double uv[2];
   project2d(xyz, uv);
   world2cam_uv(c, uv, px);
+}
+inline Cam make_cam(const svo_hip_camera* c) {
+  Cam k;
+  k.fx = c->fx; k.fy = c->fy; k.cx = c->cx; k.cy = c->cy;
+  k.width = c->width; k.height = c->height;
+  k.model = c->model;
+  for (int i = 0; i < 5; ++i) k.d[i] = c->d[i];
+  return k;
+}
+inline bool cam_model_ok(const svo_hip_camera* c) {
+  return c->model == SVO_HIP_CAM_PINHOLE || c->model == SVO_HIP_CAM_PINHOLE_RADTAN || c->model == SVO_HIP_CAM_ATAN;
 }
 __device__ __forceinline__ bool is_in_frame(const Cam& c, int x, int y, int boundary) {
   return x >= boundary && x < c.width - boundary && y >= boundary && y < c.height - boundary;

@@ -85,7 +85,9 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   const svo_hip_camera cam = cameraOf(ref_frame->cam_);
   svo_hip_sia_params P;
   P.fx = cam.fx; P.fy = cam.fy; P.cx = cam.cx; P.cy = cam.cy;
-  P.max_level = max_level_; P.min_level = min_level_; P.n_iter = (int32_t)n_iter_; P.reserved = 0; P.eps = eps_;
+  P.max_level = max_level_; P.min_level = min_level_; P.n_iter = (int32_t)n_iter_; P.eps = eps_;
+  P.cam_model = cam.model;
+  for (int k = 0; k < 5; ++k) P.d[k] = cam.d[k];
 
   a.upload(lane.stream);
   svo_hip::check(svo_hip_sparse_align(&dev.layout(), dev.store(), 1, d_slots, d_slots + 1, d_slots + 2, (int)n, d_px, d_xyz,

@@ -54,7 +54,9 @@ class SparseImgAlign:
         self.lib = capi.load()
 
     def params(self, cam) -> capi.SiaParams:
-        return capi.SiaParams(cam.fx, cam.fy, cam.cx, cam.cy, self.max_level, self.min_level, self.n_iter, 0, self.eps)
+        d = tuple(getattr(cam, "d", (0.0,) * 5))
+        return capi.SiaParams(cam.fx, cam.fy, cam.cx, cam.cy, self.max_level, self.min_level, self.n_iter,
+                              int(getattr(cam, "model", 0)), self.eps, (C.c_double * 5)(*d))
 
     def alloc_result(self, B: int, device) -> SparseAlignResult:
         return SparseAlignResult(

@@ -17,18 +17,92 @@ import numpy as np
 import torch
 
 
+CAM_PINHOLE, CAM_PINHOLE_RADTAN, CAM_ATAN = 0, 1, 2   # include/svo_hip.h SVO_HIP_CAM_*
+
+
 @dataclass
 class Camera:
+    """A vk::AbstractCamera: intrinsics + model tag + distortion parameters as svo_hip_camera holds
+    them (radtan: d0..d4 = k1 k2 p1 p2 k3; ATAN: s, 1/s, 2 tan(s/2), 1/(2 tan(s/2)))."""
     width: int
     height: int
     fx: float
     fy: float
     cx: float
     cy: float
+    model: int = CAM_PINHOLE
+    d: tuple = (0.0, 0.0, 0.0, 0.0, 0.0)
+    ctor: tuple = ()   # ATAN: the normalised constructor arguments (fx, fy, cx, cy, s)
 
     @staticmethod
     def vga() -> "Camera":
         return Camera(640, 480, 400.0, 400.0, 320.0, 240.0)
+
+    @staticmethod
+    def radtan(width, height, fx, fy, cx, cy, d0, d1=0.0, d2=0.0, d3=0.0, d4=0.0) -> "Camera":
+        """vk::PinholeCamera(width, height, fx, fy, cx, cy, d0..d4), e.g. svo_ros/param/camera_pinhole.yaml."""
+        if abs(d0) <= 0.0000001:  # vikit: distortion_ = fabs(d0) > 0.0000001
+            return Camera(width, height, fx, fy, cx, cy)
+        return Camera(width, height, fx, fy, cx, cy, CAM_PINHOLE_RADTAN, (d0, d1, d2, d3, d4))
+
+    @staticmethod
+    def atan(width, height, fx, fy, cx, cy, s) -> "Camera":
+        """vk::ATANCamera with the normalised parameters of svo_ros/param/camera_atan.yaml."""
+        d = (0.0,) * 5
+        if s != 0.0:
+            tans = 2.0 * math.tan(s / 2.0)
+            d = (s, 1.0 / s, tans, 1.0 / tans, 0.0)
+        return Camera(width, height, width * fx, height * fy, cx * width - 0.5, cy * height - 0.5, CAM_ATAN, d,
+                      (fx, fy, cx, cy, s))
+
+
+def _lib(x):
+    return torch if isinstance(x, torch.Tensor) else np
+
+
+def cam_distort(cam: Camera, x, y):
+    """Normalised image-plane point (x, y) = project2d(xyz) -> pixel: vk::*Camera::world2cam(uv)."""
+    if cam.model == CAM_PINHOLE_RADTAN:
+        d = cam.d
+        r2 = x * x + y * y
+        r4 = r2 * r2
+        r6 = r4 * r2
+        a1, a2, a3 = 2 * x * y, r2 + 2 * x * x, r2 + 2 * y * y
+        cdist = 1 + d[0] * r2 + d[1] * r4 + d[4] * r6
+        xd = x * cdist + d[2] * a1 + d[3] * a2
+        yd = y * cdist + d[2] * a3 + d[3] * a1
+        return xd * cam.fx + cam.cx, yd * cam.fy + cam.cy
+    if cam.model == CAM_ATAN and cam.d[0] != 0.0:
+        L = _lib(x)
+        r = L.sqrt(x * x + y * y)
+        rs = L.where(r < 0.001, L.ones_like(r), r)
+        factor = L.where(r < 0.001, L.ones_like(r), cam.d[1] * L.arctan(rs * cam.d[2]) / rs)
+        return cam.cx + cam.fx * (factor * x), cam.cy + cam.fy * (factor * y)
+    return cam.fx * x + cam.cx, cam.fy * y + cam.cy
+
+
+def cam_undistort(cam: Camera, u, v):
+    """Pixel -> normalised image-plane point (the un-normalised cam2world), accurate inverse of
+    cam_distort (the radial-tangential model is inverted by fixed-point iteration in double)."""
+    x0, y0 = (u - cam.cx) / cam.fx, (v - cam.cy) / cam.fy
+    if cam.model == CAM_PINHOLE_RADTAN:
+        d = cam.d
+        x, y = x0, y0
+        for _ in range(30):
+            r2 = x * x + y * y
+            icdist = 1.0 / (1 + ((d[4] * r2 + d[1]) * r2 + d[0]) * r2)
+            dx = 2 * d[2] * x * y + d[3] * (r2 + 2 * x * x)
+            dy = d[2] * (r2 + 2 * y * y) + 2 * d[3] * x * y
+            x, y = (x0 - dx) * icdist, (y0 - dy) * icdist
+        return x, y
+    if cam.model == CAM_ATAN and cam.d[0] != 0.0:
+        L = _lib(x0)
+        dist_r = L.sqrt(x0 * x0 + y0 * y0)
+        r = L.tan(dist_r * cam.d[0]) * cam.d[3]
+        safe = L.where(dist_r > 0.01, dist_r, L.ones_like(dist_r))
+        k = L.where(dist_r > 0.01, r / safe, L.ones_like(dist_r))
+        return k * x0, k * y0
+    return x0, y0
 
 
 TEX_SIZE = 1024        # texels
@@ -89,8 +163,7 @@ def _plane_points(T_f_w: torch.Tensor, cam: Camera, u: torch.Tensor, v: torch.Te
     R = T_f_w[:, :9].reshape(-1, 3, 3)
     t = T_f_w[:, 9:]
     c = -(R.transpose(1, 2) @ t[..., None])[..., 0]          # camera centre in world
-    dx = (u - cam.cx) / cam.fx
-    dy = (v - cam.cy) / cam.fy
+    dx, dy = cam_undistort(cam, u, v)
     d_c = torch.stack([dx, dy, torch.ones_like(dx)], dim=-1)  # [..., 3]
     shape = [R.shape[0]] + [1] * (d_c.dim() - 2)
     Rt = R.transpose(1, 2).reshape(shape + [3, 3])
@@ -171,10 +244,9 @@ def features_3d(T_f_w, cam: Camera, px: torch.Tensor):
     """Unit bearings f [n,N,3] and world points pos [n,N,3] (plane hit) for px [n,N,2]."""
     T = torch.as_tensor(np.asarray(T_f_w), dtype=torch.float64, device=px.device)
     X, _ = _plane_points(T, cam, px[..., 0], px[..., 1])
-    dx = (px[..., 0] - cam.cx) / cam.fx
-    dy = (px[..., 1] - cam.cy) / cam.fy
+    dx, dy = cam_undistort(cam, px[..., 0], px[..., 1])
     f = torch.stack([dx, dy, torch.ones_like(dx)], dim=-1)
-    f = f / f.norm(dim=-1, keepdim=True)  # vk::PinholeCamera::cam2world -> normalized()
+    f = f / f.norm(dim=-1, keepdim=True)  # cam2world -> normalized()
     return f, X
 
 
@@ -223,11 +295,13 @@ class TrackScene:
 def _proj(T, cam: Camera, X):
     R = T[:9].reshape(3, 3)
     p = X @ R.T + T[9:]
-    return np.stack([cam.fx * p[:, 0] / p[:, 2] + cam.cx, cam.fy * p[:, 1] / p[:, 2] + cam.cy], axis=-1), p[:, 2]
+    u, v = cam_distort(cam, p[:, 0] / p[:, 2], p[:, 1] / p[:, 2])
+    return np.stack([u, v], axis=-1), p[:, 2]
 
 
 def _bearing(cam: Camera, px):
-    f = np.stack([(px[:, 0] - cam.cx) / cam.fx, (px[:, 1] - cam.cy) / cam.fy, np.ones(len(px))], axis=-1)
+    x, y = cam_undistort(cam, px[:, 0], px[:, 1])
+    f = np.stack([x, y, np.ones(len(px))], axis=-1)
     return f / np.linalg.norm(f, axis=-1, keepdims=True)
 
 

@@ -27,6 +27,7 @@
 #include <svo/frame_handler_mono.h>
 #include <svo/map.h>
 #include <svo/point.h>
+#include <vikit/atan_camera.h>
 #include <vikit/pinhole_camera.h>
 #include <vikit/vision.h>
 #ifdef SVO_PIPELINE_HIP
@@ -70,7 +71,7 @@ typedef struct pipe_result {
 } pipe_result;
 
 struct Pipe {
-  vk::PinholeCamera* cam;
+  vk::AbstractCamera* cam;
   FrameHandlerMono* vo;
 };
 
@@ -81,7 +82,16 @@ void pipe_config_default(pipe_config* c) {
   c->kfselect_mindist = 0.12; c->poseoptim_thresh = 2.0; c->triang_min_corner_score = 20.0;
 }
 
+// cam_model 0 / 1: vk::PinholeCamera(width, height, p[0..3] = fx fy cx cy, p[4..8] = d0..d4);
+// cam_model 2: vk::ATANCamera(width, height, p[0..3] = NORMALISED fx fy cx cy, p[4] = s)
+void* pipe_create_cam(int width, int height, int cam_model, const double* p9, const pipe_config* c);
+
 void* pipe_create(int width, int height, double fx, double fy, double cx, double cy, const pipe_config* c) {
+  const double p9[9] = {fx, fy, cx, cy, 0, 0, 0, 0, 0};
+  return pipe_create_cam(width, height, 0, p9, c);
+}
+
+void* pipe_create_cam(int width, int height, int cam_model, const double* p9, const pipe_config* c) {
   Config::nPyrLevels() = c->n_pyr_levels;
   Config::kltMaxLevel() = c->klt_max_level;
   Config::kltMinLevel() = c->klt_min_level;
@@ -97,7 +107,10 @@ void* pipe_create(int width, int height, double fx, double fy, double cx, double
   Config::kfSelectMinDist() = c->kfselect_mindist;
   Config::triangMinCornerScore() = c->triang_min_corner_score;
   Pipe* p = new Pipe;
-  p->cam = new vk::PinholeCamera(width, height, fx, fy, cx, cy);
+  if (cam_model == 2)
+    p->cam = new vk::ATANCamera(width, height, p9[0], p9[1], p9[2], p9[3], p9[4]);
+  else
+    p->cam = new vk::PinholeCamera(width, height, p9[0], p9[1], p9[2], p9[3], p9[4], p9[5], p9[6], p9[7], p9[8]);
 #ifdef SVO_PIPELINE_HIP
   if (c->pool_slots > 0) {
     int levels = c->n_pyr_levels > c->klt_max_level + 1 ? c->n_pyr_levels : c->klt_max_level + 1;  // frame.cpp:58

@@ -70,7 +70,14 @@ class Pipeline:
             setattr(c, k, v)
         self.cfg = c
         self.cam = cam
-        self.h = self.lib.pipe_create(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, C.byref(c))
+        self.lib.pipe_create_cam.restype = C.c_void_p
+        self.lib.pipe_create_cam.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(Config)]
+        model = int(getattr(cam, "model", 0))
+        if model == 2:   # vk::ATANCamera takes the normalised parameters of camera_atan.yaml
+            p9 = list(cam.ctor) + [0.0] * 4
+        else:            # vk::PinholeCamera(width, height, fx, fy, cx, cy, d0..d4)
+            p9 = [cam.fx, cam.fy, cam.cx, cam.cy] + list(getattr(cam, "d", (0.0,) * 5))
+        self.h = self.lib.pipe_create_cam(cam.width, cam.height, model, (C.c_double * 9)(*p9), C.byref(c))
 
     def close(self):
         if self.h:
@@ -108,7 +115,9 @@ def range_map(cam, T_f_w):
     R = np.asarray(T_f_w[:9]).reshape(3, 3)
     c = -R.T @ np.asarray(T_f_w[9:])
     u, v = np.meshgrid(np.arange(cam.width, dtype=np.float64), np.arange(cam.height, dtype=np.float64))
-    d = np.stack([(u - cam.cx) / cam.fx, (v - cam.cy) / cam.fy, np.ones_like(u)], -1)
+    from rpg_svo_amd import synth
+    x, y = synth.cam_undistort(cam, u, v)
+    d = np.stack([x, y, np.ones_like(u)], -1)
     d /= np.linalg.norm(d, axis=-1, keepdims=True)
     dw = d @ R  # R^T d
     return (-c[2] / dw[..., 2]).astype(np.float32)

@@ -99,3 +99,18 @@ def obs_csr(obs_lists, device="cuda:0"):
                     px=t([o[1] for o in flat], torch.float64), f=t([o[2] for o in flat], torch.float64),
                     type=t([o[4] for o in flat], torch.uint8), grad=t([o[5] for o in flat], torch.float64))
     return t(ptr, torch.int32), fs
+
+
+# ---- the camera models of the reference's launch files -------------------------------------
+def camera_models():
+    """name -> synth.Camera: the undistorted VGA pinhole of the benchmark, and the two cameras the
+    reference ships (svo_ros/param/camera_pinhole.yaml: radial-tangential, camera_atan.yaml: ATAN)."""
+    return {
+        "pinhole": synth.Camera.vga(),
+        "radtan": synth.Camera.radtan(752, 480, 414.536145, 414.284429, 348.804988, 240.076451,
+                                      -0.283076, 0.066674, 0.000896, 0.000778),
+        "atan": synth.Camera.atan(752, 480, 0.509326, 0.796651, 0.45905, 0.510056, 0.9320),
+    }
+
+
+CAMERA_KINDS = ("pinhole", "radtan", "atan")

@@ -30,8 +30,8 @@ SE3_LOGNORM_TOL_NOISY = 3e-4
 ATE_TOL_M = 1e-5         # Horn-aligned RMSE over the sequence, scene depth 2 m
 
 
-def _sequence(n_frames, seed=5):
-    cam = synth.Camera(752, 480, 315.5, 315.5, 376.0, 240.0)  # svo/test/test_pipeline.cpp:46-47 intrinsics
+def _sequence(n_frames, seed=5, cam=None):
+    cam = cam or synth.Camera(752, 480, 315.5, 315.5, 376.0, 240.0)  # svo/test/test_pipeline.cpp:46-47 intrinsics
     tex = synth.make_texture(seed=12345)
     T = synth.make_trajectory(n_frames, seed=seed, max_step=0.02, max_rot_deg=0.3)
     return cam, synth.render(tex, T, cam).numpy(), T
@@ -115,6 +115,28 @@ def test_dropin_second_sequence_with_noise(pipeline_libs, gpu_device):
     print(f"noisy sequence: SE3 log-norm max {d.max():.3e} median {np.median(d):.3e}")
     assert d.max() <= SE3_LOGNORM_TOL_NOISY and np.median(d) <= 1e-6
     assert [r["is_keyframe"] for r in ref] == [r["is_keyframe"] for r in hip]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["atan", "radtan"])
+def test_dropin_sequence_with_the_reference_launch_file_cameras(pipeline_libs, gpu_device, kind):
+    """The cameras SVO's own launch files configure (svo_ros/param/camera_atan.yaml: vk::ATANCamera,
+    camera_pinhole.yaml: vk::PinholeCamera with radial-tangential distortion).  The drop-in recovers
+    the model and its parameters through vk::AbstractCamera::world2cam (marshal.h) and runs every
+    kernel with it; same comparison as the pinhole sequence."""
+    from helpers import camera_models
+    cam, imgs, T = _sequence(80, seed=7, cam=camera_models()[kind])
+    ref = pp.run_sequence("ref", cam, imgs, T)
+    hip = pp.run_sequence("hip", cam, imgs, T)
+    Tr = np.stack([r["T_f_w"] for r in ref])
+    Th = np.stack([r["T_f_w"] for r in hip])
+    d = se3.log_norm(Th, Tr)
+    print(f"{kind} camera: SE3 log-norm max {d.max():.3e} median {np.median(d):.3e}; keyframes {sum(r['is_keyframe'] for r in ref)}")
+    assert all(r["stage"] == pp.STAGE_DEFAULT_FRAME for r in hip)
+    assert d.max() <= SE3_LOGNORM_TOL and np.median(d) <= 1e-6
+    assert [r["is_keyframe"] for r in ref] == [r["is_keyframe"] for r in hip]
+    err = se3.log_norm(Th, T)   # and the trajectory is actually tracked
+    assert err.max() < 0.05
 
 
 @pytest.mark.gpu

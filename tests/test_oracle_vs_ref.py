@@ -25,14 +25,23 @@ def libs():
     return pytrack.Track("orc"), pytrack.Track("ref")
 
 
-@pytest.fixture(scope="module")
-def seq():
-    return synth.make_sequence(6, 80)
+from helpers import CAMERA_KINDS, camera_models
+
+
+@pytest.fixture(scope="module", params=CAMERA_KINDS)
+def cam(request):
+    """every reference-owned computation is pinned under the three vikit camera models"""
+    return camera_models()[request.param]
 
 
 @pytest.fixture(scope="module")
-def scene():
-    return synth.make_track_scene(n_kf=3, n_feat=60)
+def seq(cam):
+    return synth.make_sequence(6, 80, cam=cam, margin=40)
+
+
+@pytest.fixture(scope="module")
+def scene(cam):
+    return synth.make_track_scene(n_kf=3, n_feat=60, cam=cam)
 
 
 @pytest.fixture(scope="module")
@@ -239,7 +248,7 @@ def test_pose_optimize(libs, scene):
         for k in ("T_f_w", "Cov", "estimated_scale", "error_init", "error_final", "num_obs", "ran", "has_point"):
             assert same(a[k], b[k]), (trial, k)
         if trial == 0:
-            assert se3.log_norm(a["T_f_w"][None], scene.T_f_w[scene.cur][None])[0] < 2e-3
+            assert se3.log_norm(a["T_f_w"][None], scene.T_f_w[scene.cur][None])[0] < 6e-3   # scene sanity (noisy observations), not parity
             assert a["num_obs"] < hp.sum()
     # no observation with a point: nothing happens
     a = orc.pose_optimize(scene.cam, T0, f[:5], level[:5], np.zeros(5, np.uint8), pos[:5])

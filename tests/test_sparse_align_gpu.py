@@ -15,7 +15,7 @@ import torch
 
 from rpg_svo_amd import se3, synth
 
-from helpers import make_batch, run_hip, run_oracle
+from helpers import camera_models, make_batch, run_hip, run_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -191,3 +191,17 @@ def test_bad_arguments(hip_lib, gpu_device):
     P.max_level = 3
     rc = hip_lib.svo_hip_sparse_align(C.byref(L), p, 1, p, p, p, 2000, p, p, None, C.byref(P), p, p, None, p, None, None, None, None)
     assert rc == -2  # ERANGE: more than SVO_HIP_MAX_PATCHES per frame
+
+
+@pytest.mark.parametrize("kind", ["radtan", "atan"])
+def test_distorted_camera_models(oracle, gpu_device, checker, kind):
+    """world2cam of sparse_img_align.cpp:183 through the distorted vikit models (the cameras of the
+    reference's launch files): default schedule 4 -> 2 and the full 3 -> 0."""
+    cam = camera_models()[kind]
+    seq = synth.make_sequence(6, 120, cam=cam, seed=9, margin=56, cell=40)
+    b = make_batch(seq, [(i, i + 1) for i in range(5)], 5)
+    d, same, T_o, T_h, *_ = compare(oracle, b, 4, 2, which=checker)
+    assert np.median(d) <= 1e-5
+    d, same, T_o, T_h, *_ = compare(oracle, b, 3, 0, which=checker)
+    assert np.median(d) <= TOL_MEDIAN
+    assert se3.log_norm(T_h, b.T_gt_w).max() < 1e-3   # both solved the problem

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import obs_csr, scene_store
+from helpers import CAMERA_KINDS, camera_models, obs_csr, scene_store
 from oracle import pytrack
 from rpg_svo_amd import capi, se3, synth, tracking
 
@@ -25,9 +25,11 @@ def orc(oracle, checker):
     return pytrack.Track(checker)
 
 
-@pytest.fixture(scope="module")
-def scene():
-    return synth.make_track_scene(n_kf=4, n_feat=100)
+@pytest.fixture(scope="module", params=CAMERA_KINDS)
+def scene(request):
+    """the same scene seen through each vikit camera model (undistorted pinhole, the reference's
+    camera_pinhole.yaml with radial-tangential distortion, its camera_atan.yaml)"""
+    return synth.make_track_scene(n_kf=4, n_feat=100, cam=camera_models()[request.param])
 
 
 @pytest.fixture(scope="module")
