@@ -372,7 +372,10 @@ __device__ __forceinline__ float normal_pdff(float x, float mean, float sd) {
   float exponent = x - mean;
   exponent *= -exponent;
   exponent /= 2 * sd * sd;
-  float result = expf(exponent);
+  // host libm's expf is correctly rounded in all but ~0.3 % of its arguments; the f64 exp rounded to
+  // float is too (ocml's expf is not): the seed state then matches the reference's bit for bit except
+  // for those rare arguments, instead of differing in the last bit every few updates
+  float result = (float)exp((double)exponent);
   result /= sd * sqrtf(2 * 3.14159265358979323846f);
   return result;
 }

@@ -128,6 +128,31 @@ __device__ __forceinline__ void cut_row5(uint32_t a, uint32_t b, uint32_t c, int
 #define MINW(BLOCK) ((BLOCK) >= 1024 ? 4 : 3)
 #endif
 
+// SIA_SGPR_POSE: the pose published by the solver wave is wave-uniform; reading it back through
+// v_readfirstlane keeps its 24 dwords in SGPRs instead of VGPRs
+__device__ __forceinline__ double sia_uni(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+#ifdef SIA_SGPR_POSE
+#define SIA_UNI(x) sia_uni(x)
+#else
+#define SIA_UNI(x) (x)
+#endif
+
+// SIA_PROFILE: per-phase shader-clock totals of wave 0 of every workgroup, written over H_out[b][0..7]
+// (pixel work, reduce, barrier 1, H rebuild, solve + barrier 2, per-level precompute, total, #iterations).
+// Instrumentation build only (scripts/k1_phase_profile.py); costs ~10 % itself.
+#ifdef SIA_PROFILE
+#define SIA_T() ((long long)__builtin_readcyclecounter())
+#define SIA_ACC(k, t0, t1) prof[k] += (t1) - (t0)
+#else
+#define SIA_T() 0ll
+#define SIA_ACC(k, t0, t1)
+#endif
+
 constexpr int MAX_WAVES = SVO_HIP_MAX_PATCHES / 64;
 
 // Gauss-Newton state kept by the solver wave of a workgroup (quaternion form, as Sophus stores it).
@@ -199,6 +224,39 @@ __device__ __forceinline__ void sia_rebuild_hinv(int lane, int nw) {
 
 // DIST: the camera is a distorted model (radial-tangential pinhole or ATAN); the undistorted pinhole
 // keeps its own instantiation so that its inner loop carries no model dispatch.
+// The same through a register LDL^T, run by the SOLVER wave itself: H = sum of the per-wave partials
+// (lane k < 21 owns entry k, v_readlane broadcasts them), one unpivoted factorisation executed
+// redundantly by every lane (zero pivot -> 0, as above), then lane j < 6 solves for unit vector j, i.e.
+// row j of the symmetric inverse.  Only the solver wave reads Hinv, so the workgroup needs no second
+// barrier after a rebuild, and the chain is ~200 dependent f64 operations instead of six LDS exchange
+// rounds (measured 4.0k -> see DESIGN section 6 for the phase profile).
+__device__ __forceinline__ void sia_rebuild_hinv_ldlt(int lane, int nw) {
+  asm volatile("" : "+v"(lane));
+  double v = 0.0;
+  if (lane < 21) {
+    for (int w = 0; w < nw; ++w) v += (double)g_s.Hpart[w][lane];
+    g_s.H[lane] = v;
+  }
+  double H[21];
+  H[0] = readlane_f64<0>(v); H[1] = readlane_f64<1>(v); H[2] = readlane_f64<2>(v); H[3] = readlane_f64<3>(v);
+  H[4] = readlane_f64<4>(v); H[5] = readlane_f64<5>(v); H[6] = readlane_f64<6>(v); H[7] = readlane_f64<7>(v);
+  H[8] = readlane_f64<8>(v); H[9] = readlane_f64<9>(v); H[10] = readlane_f64<10>(v); H[11] = readlane_f64<11>(v);
+  H[12] = readlane_f64<12>(v); H[13] = readlane_f64<13>(v); H[14] = readlane_f64<14>(v); H[15] = readlane_f64<15>(v);
+  H[16] = readlane_f64<16>(v); H[17] = readlane_f64<17>(v); H[18] = readlane_f64<18>(v); H[19] = readlane_f64<19>(v);
+  H[20] = readlane_f64<20>(v);
+  double LD[21];
+  ldlt6_factor(H, LD);
+  double e[6], x[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) e[i] = (i == lane) ? 1.0 : 0.0;
+  ldlt6_solve(LD, e, x);
+  if (lane < 6) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g_s.Hinv[6 * lane + i] = x[i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 template <int BLOCK, bool WC, bool DIST>
 __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a) {
   constexpr int NW = BLOCK / 64;
@@ -293,7 +351,12 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
 
   __syncthreads();
 
+#ifdef SIA_PROFILE
+  long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long t_begin = SIA_T();
+#endif
   for (int level = P.max_level; level >= P.min_level; --level) {
+    const long long tl0 = SIA_T();
     const int cols = g_s.lw[level], rows = g_s.lh[level], pitch = g_s.lp[level];
     const uint8_t* ref_img = ref_base + g_s.lo[level];
     const uint8_t* cur_img = cur_base + g_s.lo[level];
@@ -379,7 +442,9 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
 #pragma unroll
       for (int r = 0; r < (WC ? 7 : 1); ++r) wc[r][0] = wc[r][1] = wc[r][2] = 0u;
     }
+    SIA_ACC(5, tl0, SIA_T());
     for (int iter = 0; iter < P.n_iter; ++iter) {
+      const long long tp0 = SIA_T();
       // -- computeResiduals (:147-243): this lane's patch -------------------
       bool m = false;
       float gx = 0.f, gy = 0.f, c2 = 0.f;
@@ -387,8 +452,15 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
         const double xc = R[0] * X + R[1] * Y + R[2] * Z + tr[0];
         const double yc = R[3] * X + R[4] * Y + R[5] * Z + tr[1];
         const double zc = R[6] * X + R[7] * Y + R[8] * Z + tr[2];
-        // cam_->world2cam(project2d(xyz)) (:183), one reciprocal
+        // cam_->world2cam(project2d(xyz)) (:183), one reciprocal (v_rcp_f64 + two Newton steps: the
+        // IEEE division sequence is twice as long and sits on the critical path of every iteration)
+#ifdef SIA_IEEE_DIV
         const double izc = 1.0 / zc;
+#else
+        double izc = __builtin_amdgcn_rcp(zc);
+        izc = fma(fma(-zc, izc, 1.0), izc, izc);
+        izc = fma(fma(-zc, izc, 1.0), izc, izc);
+#endif
         double pu, pv;
         if (DIST) {
           Cam cm;
@@ -490,11 +562,17 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
         part[5] = xn * gyf - yn * gxf;
         part[6] = c2;
         part[7] = m ? 16.f : 0.f;
+        const long long tp1 = SIA_T();
+        SIA_ACC(0, tp0, tp1);
         const float tot = wave_reduce8(part, lane);
         if ((lane & 7) == 0) g_s.part[buf][wave][lane >> 3] = tot;
+        SIA_ACC(1, tp1, SIA_T());
       }
       // the one workgroup barrier of an iteration
+      const long long tb0 = SIA_T();
       const int changed = __syncthreads_or((int)m != inH);
+      const long long tb1 = SIA_T();
+      SIA_ACC(2, tb0, tb1);
       if (changed) {
         // the set of patches inside the current image changed: rebuild H.
         // H += J J' summed over the patch = Sxx aa' + Sxy (ab'+ba') + Syy bb'
@@ -516,10 +594,19 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
         }
         inH = (int)m;
         __syncthreads();
+#ifdef SIA_GAUSS_JORDAN
         if (wave == 0) sia_rebuild_hinv(lane, NW);
         __syncthreads();
+#else
+        if (wave == sw) sia_rebuild_hinv_ldlt(lane, NW);  // its only reader: no barrier needed
+#endif
       }
       ++evals;
+      const long long ts0 = SIA_T();
+      SIA_ACC(3, tb1, ts0);
+#ifdef SIA_PROFILE
+      prof[7] += 1;
+#endif
 
       // -- solve() / update() and the stop / rollback rules of
       //    vk::NLLSSolver::optimizeGaussNewton (:245-258) --
@@ -532,6 +619,11 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
       if (wave == sw)
 #ifndef SIA_DBG_NOSOLVE
       {
+#ifndef SIA_NO_PRIO
+        // the three other waves of the workgroup wait for this one: let it win the issue arbitration
+        // against the pixel waves of the other workgroups on its SIMD
+        __builtin_amdgcn_s_setprio(3);
+#endif
         // totals over the waves: lane k (<8) owns column k
         double colsum = 0.0;
         {
@@ -609,20 +701,24 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
           g_s.sw_nmeas = n_meas_last;
           g_s.sw_chi2 = chi2_prev;
         }
+#ifndef SIA_NO_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
       }
 #endif
       if (NW > 1) {
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 9; ++k) R[k] = g_s.Rt[k];
+        for (int k = 0; k < 9; ++k) R[k] = SIA_UNI(g_s.Rt[k]);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) tr[k] = g_s.Rt[9 + k];
+        for (int k = 0; k < 3; ++k) tr[k] = SIA_UNI(g_s.Rt[9 + k]);
         done = g_s.sw_done;
         stop = g_s.sw_stop;
         n_meas_last = g_s.sw_nmeas;
         chi2_prev = g_s.sw_chi2;
       }
       buf ^= 1;
+      SIA_ACC(4, ts0, SIA_T());
 #ifndef SIA_DBG_FIXED_ITERS
       if (done) break;
 #endif
@@ -636,6 +732,11 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
     if (a.H_out)
       for (int i = 0; i < 6; ++i)
         for (int j = 0; j < 6; ++j) a.H_out[36 * b + i * 6 + j] = g_s.H[sym6_rt(i, j)];
+#ifdef SIA_PROFILE
+    prof[6] = SIA_T() - t_begin;
+    if (a.H_out)
+      for (int k = 0; k < 8; ++k) a.H_out[36 * b + k] = (double)prof[k];
+#endif
     a.n_tracked[b] = n_meas_last / 16;
     if (a.chi2) a.chi2[b] = chi2_prev;
     if (a.status) a.status[b] = stop ? SVO_HIP_SIA_STOP : 0;

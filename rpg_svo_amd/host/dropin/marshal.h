@@ -43,9 +43,10 @@ inline SE3 poseFromRt(const double in[12]) {
 //   2. vk::ATANCamera: radially symmetric about the principal point; the focal lengths follow from a
 //      probe inside the model's r < 0.001 linear zone, s from one radius by bisection
 //      (factor(r) = atan(r * 2 tan(s/2)) / (s r) is monotone in s);
-//   3. vk::PinholeCamera with radial-tangential distortion: px - c is LINEAR in
-//      (f, f k1, f k2, f k3, f p1, f p2) for known uv -- solved from eight probes per axis.
-// Every candidate is verified on independent probes to 1e-9 px; a camera none of them reproduces
+//   3. vk::PinholeCamera with radial-tangential distortion: on either axis the odd part of the
+//      projection is a cubic in r^2 with coefficients (f, f k1, f k2, f k3), the even part is the
+//      tangential term -- four radii per axis.
+// Every candidate is verified on independent probes to 1e-8 px; a camera none of them reproduces
 // throws.  Recovered parameters agree with the constructor's to ~1e-13 relative; callers that want
 // them bit-exact register the block they constructed the camera from (registerCamera).
 inline std::map<const vk::AbstractCamera*, svo_hip_camera>& cameraRegistry() {
@@ -78,34 +79,8 @@ inline bool reproduces(const vk::AbstractCamera* cam, const svo_hip_camera& c) {
     double px[2];
     modelWorld2cam(c, probes[i][0], probes[i][1], px);
     const Vector2d q = cam->world2cam(Vector2d(probes[i][0], probes[i][1]));
-    if (!(std::fabs(px[0] - q[0]) <= 1e-9 && std::fabs(px[1] - q[1]) <= 1e-9)) return false;
+    if (!(std::fabs(px[0] - q[0]) <= 1e-8 && std::fabs(px[1] - q[1]) <= 1e-8)) return false;
   }
-  return true;
-}
-// least squares of an 8 x 6 system by normal equations + Gaussian elimination with pivoting
-inline bool solve6(const double A[8][6], const double b[8], double x[6]) {
-  double N[6][7];
-  for (int i = 0; i < 6; ++i) {
-    for (int j = 0; j < 6; ++j) {
-      N[i][j] = 0;
-      for (int k = 0; k < 8; ++k) N[i][j] += A[k][i] * A[k][j];
-    }
-    N[i][6] = 0;
-    for (int k = 0; k < 8; ++k) N[i][6] += A[k][i] * b[k];
-  }
-  for (int c = 0; c < 6; ++c) {
-    int p = c;
-    for (int r = c + 1; r < 6; ++r)
-      if (std::fabs(N[r][c]) > std::fabs(N[p][c])) p = r;
-    if (std::fabs(N[p][c]) < 1e-300) return false;
-    for (int j = 0; j < 7; ++j) std::swap(N[c][j], N[p][j]);
-    for (int r = 0; r < 6; ++r) {
-      if (r == c) continue;
-      const double k = N[r][c] / N[c][c];
-      for (int j = c; j < 7; ++j) N[r][j] -= k * N[c][j];
-    }
-  }
-  for (int i = 0; i < 6; ++i) x[i] = N[i][6] / N[i][i];
   return true;
 }
 }  // namespace detail
@@ -148,32 +123,54 @@ inline svo_hip_camera cameraOf(const vk::AbstractCamera* cam) {
     a.d[0] = s; a.d[1] = 1.0 / s; a.d[2] = tans; a.d[3] = 1.0 / tans; a.d[4] = 0.0;
     if (detail::reproduces(cam, a)) return reg[cam] = a;
   }
-  // (3) pinhole + radial-tangential: linear in (f, f k1, f k2, f k3, f p1, f p2) per axis
+  // (3) pinhole + radial-tangential.  On the x axis (y = 0) the model reads
+  //        u(x) - cx = fx (x + k1 x^3 + k2 x^5 + k3 x^7) + fx p2 3 x^2,     v(x) - cy = fy p1 x^2
+  //     so the odd part in x isolates (fx, fx k1, fx k2, fx k3) -- a 4 x 4 Vandermonde system in x^2
+  //     from four radii -- and the even part p2; the y axis gives fy and p1 the same way.
   {
-    static const double P[8][2] = {{0.3, 0.1}, {-0.2, 0.35}, {0.5, -0.3}, {-0.45, -0.25}, {0.15, 0.55}, {0.6, 0.2}, {-0.6, 0.05}, {0.1, -0.5}};
-    double Ax[8][6], Ay[8][6], bx[8], by[8];
-    for (int k = 0; k < 8; ++k) {
-      const double x = P[k][0], y = P[k][1];
-      const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
-      const Vector2d q = cam->world2cam(Vector2d(x, y));
-      // x-axis: f x + (f k1) x r2 + (f k2) x r4 + (f k3) x r6 + (f p1) 2xy + (f p2)(r2 + 2x^2)
-      Ax[k][0] = x; Ax[k][1] = x * r2; Ax[k][2] = x * r4; Ax[k][3] = x * r6; Ax[k][4] = 2 * x * y; Ax[k][5] = r2 + 2 * x * x;
-      // y-axis: f y + (f k1) y r2 + (f k2) y r4 + (f k3) y r6 + (f p1)(r2 + 2y^2) + (f p2) 2xy
-      Ay[k][0] = y; Ay[k][1] = y * r2; Ay[k][2] = y * r4; Ay[k][3] = y * r6; Ay[k][4] = r2 + 2 * y * y; Ay[k][5] = 2 * x * y;
-      bx[k] = q[0] - o[0];
-      by[k] = q[1] - o[1];
+    static const double X[4] = {0.2, 0.4, 0.6, 0.8};
+    long double ax[4], ay[4];
+    for (int axis = 0; axis < 2; ++axis) {
+      long double M[4][5];
+      for (int k = 0; k < 4; ++k) {
+        const double x = X[k];
+        const Vector2d qp = cam->world2cam(axis == 0 ? Vector2d(x, 0.0) : Vector2d(0.0, x));
+        const Vector2d qm = cam->world2cam(axis == 0 ? Vector2d(-x, 0.0) : Vector2d(0.0, -x));
+        const long double odd = ((long double)qp[axis] - (long double)qm[axis]) / 2 / x;  // f (1 + k1 t + k2 t^2 + k3 t^3)
+        const long double t = (long double)x * x;
+        M[k][0] = 1; M[k][1] = t; M[k][2] = t * t; M[k][3] = t * t * t; M[k][4] = odd;
+      }
+      for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r)
+          if (fabsl(M[r][col]) > fabsl(M[piv][col])) piv = r;
+        for (int j = 0; j < 5; ++j) std::swap(M[col][j], M[piv][j]);
+        for (int r = 0; r < 4; ++r) {
+          if (r == col) continue;
+          const long double k = M[r][col] / M[col][col];
+          for (int j = col; j < 5; ++j) M[r][j] -= k * M[col][j];
+        }
+      }
+      for (int i = 0; i < 4; ++i) (axis == 0 ? ax : ay)[i] = M[i][4] / M[i][i];
     }
-    double sx[6], sy[6];
-    if (detail::solve6(Ax, bx, sx) && detail::solve6(Ay, by, sy) && sx[0] != 0.0 && sy[0] != 0.0) {
+    if (ax[0] != 0 && ay[0] != 0) {
       svo_hip_camera r = c;
       r.model = SVO_HIP_CAM_PINHOLE_RADTAN;
-      r.fx = sx[0]; r.fy = sy[0];
-      // the coefficients are shared by both axes: average the two estimates
-      r.d[0] = 0.5 * (sx[1] / sx[0] + sy[1] / sy[0]);
-      r.d[1] = 0.5 * (sx[2] / sx[0] + sy[2] / sy[0]);
-      r.d[4] = 0.5 * (sx[3] / sx[0] + sy[3] / sy[0]);
-      r.d[2] = 0.5 * (sx[4] / sx[0] + sy[4] / sy[0]);
-      r.d[3] = 0.5 * (sx[5] / sx[0] + sy[5] / sy[0]);
+      r.fx = (double)ax[0]; r.fy = (double)ay[0];
+      r.d[0] = (double)((ax[1] / ax[0] + ay[1] / ay[0]) / 2);
+      r.d[1] = (double)((ax[2] / ax[0] + ay[2] / ay[0]) / 2);
+      r.d[4] = (double)((ax[3] / ax[0] + ay[3] / ay[0]) / 2);
+      const double x = 0.8;
+      const Vector2d qxp = cam->world2cam(Vector2d(x, 0.0)), qxm = cam->world2cam(Vector2d(-x, 0.0));
+      const Vector2d qyp = cam->world2cam(Vector2d(0.0, x)), qym = cam->world2cam(Vector2d(0.0, -x));
+      // p1 (d2): v on the x axis, and the even part of v on the y axis (fy p1 3 y^2)
+      const double p1a = ((qxp[1] + qxm[1]) / 2 - o[1]) / (r.fy * x * x);
+      const double p1b = ((qyp[1] + qym[1]) / 2 - o[1]) / (3.0 * r.fy * x * x);
+      // p2 (d3): the even part of u on the x axis (fx p2 3 x^2), and u on the y axis
+      const double p2a = ((qxp[0] + qxm[0]) / 2 - o[0]) / (3.0 * r.fx * x * x);
+      const double p2b = ((qyp[0] + qym[0]) / 2 - o[0]) / (r.fx * x * x);
+      r.d[2] = 0.5 * (p1a + p1b);
+      r.d[3] = 0.5 * (p2a + p2b);
       if (detail::reproduces(cam, r)) return reg[cam] = r;
     }
   }

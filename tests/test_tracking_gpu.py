@@ -234,6 +234,10 @@ def test_update_seeds(gpu_device, orc, scene, pyrs, align_1d, subpix):
                                       fs, ss, batch_counter=5)
     torch.cuda.synchronize()
     status, xyz, px = status.cpu().numpy(), xyz.cpu().numpy(), px.cpu().numpy()
+    if orc.which == "ref":
+        # the reference's updateSeeds leaves no trace of "behind the camera" / "outside the image"
+        # (depth_filter.cpp:225-232: plain `continue`): its driver reports 0 for both
+        status = np.where(np.isin(status, (pytrack.SEED_BEHIND, pytrack.SEED_NOT_IN_FRAME)), 0, status)
     a, b, mu, s2 = (t.cpu().numpy() for t in (ss.a, ss.b, ss.mu, ss.sigma2))
     hist = {}
     for i in range(S):
@@ -257,12 +261,13 @@ def test_update_seeds(gpu_device, orc, scene, pyrs, align_1d, subpix):
             assert np.isclose(mu[i], so[i].mu, rtol=2e-6, atol=0), (i, mu[i], so[i].mu)
             assert abs(float(s2[i]) - so[i].sigma2) <= 1e-4 * abs(so[i].sigma2) + 1e-6 * so[i].mu ** 2, (i, s2[i], so[i].sigma2)
             assert np.allclose([a[i], b[i]], [so[i].a, so[i].b], rtol=5e-3, atol=1e-5), (i, a[i], so[i].a, b[i], so[i].b)
-        if st in (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED):
+        if st in (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED) and orc.which == "orc":
+            # (the reference's DepthFilter does not expose Matcher::px_cur_ per seed: C port only)
             assert np.abs(px[i] - np.array(io[i].px_cur[:])).max() < 1e-9      # float alignment, identical start
         if st == pytrack.SEED_CONVERGED:
             assert np.abs(xyz[i] - np.array(io[i].xyz_world[:])).max() < 1e-5
     assert hist.get(pytrack.SEED_UPDATED, 0) > 50 and hist.get(pytrack.SEED_CONVERGED, 0) > 2
-    assert hist.get(pytrack.SEED_ERASED_OLD, 0) > 5 and hist.get(pytrack.SEED_BEHIND, 0) > 2
+    assert hist.get(pytrack.SEED_ERASED_OLD, 0) > 5 and hist.get(pytrack.SEED_BEHIND if orc.which == "orc" else 0, 0) > 2
 
 
 def test_update_seed_batch(gpu_device, orc):
