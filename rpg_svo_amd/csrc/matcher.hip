@@ -144,14 +144,21 @@ __global__ void __launch_bounds__(64) match_prepare_kernel(const PrepArgs a) {
   a.active[m] = 1;
 }
 
-// warp::warpAffine (matcher.cpp:72-105), halfpatch_size = 5.  32 lanes per trial, lanes
-// 0..24 produce 4 consecutive output bytes each and store one dword.  Two dependent memory
-// rounds only: (1) the trial's parameters, all independent loads, with the pyramid geometry
-// of its level looked up in an LDS copy of the layout; (2) the 8 two-byte gathers of the
-// lane's four bilinear samples, issued together before any is consumed.
+// warp::warpAffine (matcher.cpp:72-105), halfpatch_size = 5.  A wave owns SIX trials: lane = (trial,
+// output column), 10 lanes per trial, and walks down the 10 output rows.  One load instruction then
+// touches ONE source row per trial (1-2 cache lines for the usual near-upright warp) instead of the
+// ten rows a 25-lanes-x-4-samples mapping spreads over: the kernel is bound by the number of distinct
+// lines the vector L1 looks up per instruction (80 line look-ups per trial before, ~30 now).  The
+// 100 output bytes of a trial are assembled in LDS and the wave stores its 600 contiguous bytes as
+// coalesced dwords.  Arithmetic per sample is unchanged (bit-identical patches).
+constexpr int WARP_TPW = 6;  // trials per wave
+#ifndef WARP_WGS_PER_CU
+#define WARP_WGS_PER_CU 16
+#endif
 __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
   __shared__ long long s_off[SVO_HIP_MAX_LEVELS];
   __shared__ int s_w[SVO_HIP_MAX_LEVELS], s_h[SVO_HIP_MAX_LEVELS], s_p[SVO_HIP_MAX_LEVELS];
+  __shared__ uint32_t s_patch[4][WARP_TPW * 25 + 2];
   if (threadIdx.x < SVO_HIP_MAX_LEVELS) {
     s_off[threadIdx.x] = a.L.offset[threadIdx.x];
     s_w[threadIdx.x] = a.L.w[threadIdx.x];
@@ -159,59 +166,80 @@ __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
     s_p[threadIdx.x] = a.L.pitch[threadIdx.x];
   }
   __syncthreads();
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  const int m = gid >> 5;
-  const int k = gid & 31;
-  if (m >= a.M || k >= 25) return;
-  // round 1: parameters of the trial
-  const float4 A = *reinterpret_cast<const float4*>(a.A_ref_cur + 4 * (size_t)m);
-  const float2 pyr = *reinterpret_cast<const float2*>(a.px_ref_pyr + 2 * (size_t)m);
-  const int act = a.active[m];
-  const int level = a.ref_level[m] & (SVO_HIP_MAX_LEVELS - 1);
-  const int slot = a.ref_slot[m];
-  const int slev = a.search_level[m];
-  uint32_t packed = 0;
-  // "Affine warp is NaN": the reference leaves the previous patch in place; here: zeros
-  if (act && !isnan(A.x)) {
-    const uint8_t* img = a.store + (int64_t)slot * a.L.slot_bytes + s_off[level];
-    const int cols = s_w[level], rows = s_h[level], pitch = s_p[level];
-    const float sc = (float)(1 << slev);
-    // round 2: addresses and weights of the four samples, then all eight loads
-    float w00[4], w01[4], w10[4], w11[4];
-    bool in[4];
-    uint16_t top[4], bot[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = lane / 10, x = lane - 10 * t;
+  uint8_t* const my_patch = reinterpret_cast<uint8_t*>(s_patch[wave]);
+  const long long n_wave_groups = ((long long)a.M + WARP_TPW - 1) / WARP_TPW;
+  for (long long gw = (long long)blockIdx.x * 4 + wave; gw < n_wave_groups; gw += (long long)gridDim.x * 4) {
+    const long long m0 = gw * WARP_TPW;
+    const long long m = m0 + t;
+    const bool lane_on = lane < 10 * WARP_TPW && m < a.M;
+    uint8_t out[10];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = 4 * k + j;
-      const int y = i / 10, x = i - 10 * y;
-      float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
-      pp0 *= sc;
-      pp1 *= sc;
-      const float px0 = (A.x * pp0 + A.y * pp1) + pyr.x;
-      const float px1 = (A.z * pp0 + A.w * pp1) + pyr.y;
-      in[j] = !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
-      // vk::interpolateMat_8u; samples outside the image read pixel (0,0) and are discarded
-      const float u = in[j] ? px0 : 0.f, v = in[j] ? px1 : 0.f;
-      const int xi = (int)floorf(u), yi = (int)floorf(v);
-      const float sx = u - (float)xi, sy = v - (float)yi;
-      w00[j] = (1.0f - sx) * (1.0f - sy);
-      w01[j] = (1.0f - sx) * sy;
-      w10[j] = sx * (1.0f - sy);
-      w11[j] = 1.0f - w00[j] - w01[j] - w10[j];
-      const uint8_t* ptr = img + (int64_t)yi * pitch + xi;
-      // two unaligned 16-bit loads (gfx950 global memory takes any alignment) instead of four bytes
-      __builtin_memcpy(&top[j], ptr, 2);
-      __builtin_memcpy(&bot[j], ptr + pitch, 2);
-    }
+    for (int y = 0; y < 10; ++y) out[y] = 0;
+    if (lane_on) {
+      // round 1: parameters of the trial (the 10 lanes of a trial read the same words)
+      const float4 A = *reinterpret_cast<const float4*>(a.A_ref_cur + 4 * (size_t)m);
+      const float2 pyr = *reinterpret_cast<const float2*>(a.px_ref_pyr + 2 * (size_t)m);
+      const int act = a.active[m];
+      const int level = a.ref_level[m] & (SVO_HIP_MAX_LEVELS - 1);
+      const int slot = a.ref_slot[m];
+      const int slev = a.search_level[m];
+      // "Affine warp is NaN": the reference leaves the previous patch in place; here: zeros
+      if (act && !isnan(A.x)) {
+        const uint8_t* img = a.store + (int64_t)slot * a.L.slot_bytes + s_off[level];
+        const int cols = s_w[level], rows = s_h[level], pitch = s_p[level];
+        const float sc = (float)(1 << slev);
+        // round 2: addresses and weights of the ten samples of this column, then all twenty loads
+        float w00[10], w01[10], w10[10], w11[10];
+        bool in[10];
+        uint16_t top[10], bot[10];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float p00 = (float)(top[j] & 0xffu), p10 = (float)(top[j] >> 8);
-      const float p01 = (float)(bot[j] & 0xffu), p11 = (float)(bot[j] >> 8);
-      const float val = w00[j] * p00 + w01[j] * p01 + w10[j] * p10 + w11[j] * p11;
-      packed |= (in[j] ? (uint32_t)(uint8_t)val : 0u) << (8 * j);
+        for (int y = 0; y < 10; ++y) {
+          float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
+          pp0 *= sc;
+          pp1 *= sc;
+          const float px0 = (A.x * pp0 + A.y * pp1) + pyr.x;
+          const float px1 = (A.z * pp0 + A.w * pp1) + pyr.y;
+          in[y] = !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
+          // vk::interpolateMat_8u; samples outside the image read pixel (0,0) and are discarded
+          const float u = in[y] ? px0 : 0.f, v = in[y] ? px1 : 0.f;
+          const int xi = (int)floorf(u), yi = (int)floorf(v);
+          const float sx = u - (float)xi, sy = v - (float)yi;
+          w00[y] = (1.0f - sx) * (1.0f - sy);
+          w01[y] = (1.0f - sx) * sy;
+          w10[y] = sx * (1.0f - sy);
+          w11[y] = 1.0f - w00[y] - w01[y] - w10[y];
+          const uint8_t* ptr = img + (int64_t)yi * pitch + xi;
+          // two unaligned 16-bit loads (gfx950 global memory takes any alignment) instead of four bytes
+          __builtin_memcpy(&top[y], ptr, 2);
+          __builtin_memcpy(&bot[y], ptr + pitch, 2);
+        }
+#pragma unroll
+        for (int y = 0; y < 10; ++y) {
+          const float p00 = (float)(top[y] & 0xffu), p10 = (float)(top[y] >> 8);
+          const float p01 = (float)(bot[y] & 0xffu), p11 = (float)(bot[y] >> 8);
+          const float val = w00[y] * p00 + w01[y] * p01 + w10[y] * p10 + w11[y] * p11;
+          out[y] = in[y] ? (uint8_t)val : (uint8_t)0;
+        }
+      }
+#pragma unroll
+      for (int y = 0; y < 10; ++y) my_patch[t * 100 + y * 10 + x] = out[y];
     }
+    // same-wave LDS hand-over: DS operations of one wave execute in order
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const long long left = (long long)a.M - m0;
+    const int n_dw = 25 * (int)(left < WARP_TPW ? left : WARP_TPW);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(a.pwb + (size_t)m0 * 100);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int idx = lane + 64 * k;
+      if (idx < n_dw) dst[idx] = s_patch[wave][idx];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
-  reinterpret_cast<uint32_t*>(a.pwb + (size_t)m * 100)[k] = packed;
 }
 
 struct ReprojArgs {
@@ -278,8 +306,10 @@ __global__ void __launch_bounds__(256) cam2world_kernel(const GlueArgs a) {
 namespace svo_track {
 int launch_warp(const WarpArgs& a, hipStream_t s) {
   if (a.M <= 0) return SVO_HIP_OK;
-  const long long lanes = (long long)a.M * 32;
-  hipLaunchKernelGGL(warp_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, a);
+  // 4 waves x WARP_TPW trials per workgroup pass; at most WARP_WGS_PER_CU workgroups per CU walk over them
+  const long long n_groups = ((long long)a.M + 4 * WARP_TPW - 1) / (4 * WARP_TPW);
+  const long long cap = 256ll * WARP_WGS_PER_CU;
+  hipLaunchKernelGGL(warp_kernel, dim3((unsigned)(n_groups < cap ? n_groups : cap)), dim3(256), 0, s, a);
   return check_launch();
 }
 }  // namespace svo_track
