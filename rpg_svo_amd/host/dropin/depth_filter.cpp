@@ -1,6 +1,8 @@
-// Drop-in body for svo/src/depth_filter.cpp: the classes svo::Seed / svo::DepthFilter of
-// svo/include/svo/depth_filter.h.  The seed list, the keyframe queue and the mapping thread
-// stay on the host as the reference has them; DepthFilter::updateSeeds (depth_filter.cpp
+// Drop-in for THREE members of svo::DepthFilter (svo/include/svo/depth_filter.h): updateSeeds,
+// updateSeed and computeTau.  Everything else of svo/src/depth_filter.cpp -- svo::Seed, the seed list,
+// the keyframe queue, the mapping thread -- stays in the reference's own file: build that file minus
+// these three definitions (scripts/strip_members.py) next to this one.
+// DepthFilter::updateSeeds (depth_filter.cpp
 // :197-291) -- visibility test, Matcher::findEpipolarMatchDirect (epipolar ZMSSD scan +
 // sub-pixel alignment, matcher.cpp:179-321), triangulation, computeTau and the Bayesian
 // updateSeed -- runs for ALL seeds in one batched call of svo_hip_update_seeds (K5) on the
@@ -22,128 +24,6 @@
 #include "marshal.h"
 
 namespace svo {
-
-int Seed::batch_counter = 0;
-int Seed::seed_counter = 0;
-
-// depth_filter.cpp:37-46: Beta(10,10), inverse depth ~ N(1/mean, (range/6)^2)
-Seed::Seed(Feature* ftr, float depth_mean, float depth_min)
-    : batch_id(batch_counter), id(seed_counter++), ftr(ftr), a(10), b(10), mu(1.0 / depth_mean), z_range(1.0 / depth_min),
-      sigma2(z_range * z_range / 36) {}
-
-DepthFilter::DepthFilter(feature_detection::DetectorPtr feature_detector, callback_t seed_converged_cb)
-    : feature_detector_(feature_detector), seed_converged_cb_(seed_converged_cb), seeds_updating_halt_(false), thread_(NULL),
-      new_keyframe_set_(false), new_keyframe_min_depth_(0.0), new_keyframe_mean_depth_(0.0) {}
-
-DepthFilter::~DepthFilter() {
-  stopThread();
-  SVO_INFO_STREAM("DepthFilter destructed.");
-}
-
-// ---- mapping thread (host control, unchanged in behaviour) ---------------------------------
-void DepthFilter::startThread() { thread_ = new boost::thread(&DepthFilter::updateSeedsLoop, this); }
-
-void DepthFilter::stopThread() {
-  SVO_INFO_STREAM("DepthFilter stop thread invoked.");
-  if (thread_ == NULL) return;
-  SVO_INFO_STREAM("DepthFilter interrupt and join thread... ");
-  seeds_updating_halt_ = true;
-  thread_->interrupt();
-  thread_->join();
-  thread_ = NULL;
-}
-
-void DepthFilter::addFrame(FramePtr frame) {
-  if (thread_ == NULL) {  // synchronous use
-    updateSeeds(frame);
-    return;
-  }
-  {
-    lock_t lock(frame_queue_mut_);
-    if (frame_queue_.size() > 2) frame_queue_.pop();  // keep at most three frames pending
-    frame_queue_.push(frame);
-  }
-  seeds_updating_halt_ = false;
-  frame_queue_cond_.notify_one();
-}
-
-void DepthFilter::addKeyframe(FramePtr frame, double depth_mean, double depth_min) {
-  new_keyframe_min_depth_ = depth_min;
-  new_keyframe_mean_depth_ = depth_mean;
-  if (thread_ == NULL) {
-    initializeSeeds(frame);
-    return;
-  }
-  new_keyframe_ = frame;
-  new_keyframe_set_ = true;
-  seeds_updating_halt_ = true;
-  frame_queue_cond_.notify_one();
-}
-
-void DepthFilter::initializeSeeds(FramePtr frame) {
-  // corner detection stays on the host (keyframes only)
-  Features new_features;
-  feature_detector_->setExistingFeatures(frame->fts_);
-  feature_detector_->detect(frame.get(), frame->img_pyr_, Config::triangMinCornerScore(), new_features);
-
-  seeds_updating_halt_ = true;
-  lock_t lock(seeds_mut_);  // waits for a running update to finish
-  ++Seed::batch_counter;
-  for (Features::iterator it = new_features.begin(); it != new_features.end(); ++it)
-    seeds_.push_back(Seed(*it, new_keyframe_mean_depth_, new_keyframe_min_depth_));
-  if (options_.verbose) SVO_INFO_STREAM("DepthFilter: Initialized " << new_features.size() << " new seeds");
-  seeds_updating_halt_ = false;
-}
-
-void DepthFilter::removeKeyframe(FramePtr frame) {
-  seeds_updating_halt_ = true;
-  lock_t lock(seeds_mut_);
-  const Frame* gone = frame.get();
-  seeds_.remove_if([gone](const Seed& s) { return s.ftr->frame == gone; });
-  seeds_updating_halt_ = false;
-}
-
-void DepthFilter::reset() {
-  seeds_updating_halt_ = true;
-  {
-    lock_t lock(seeds_mut_);
-    seeds_.clear();
-  }
-  clearFrameQueue();
-  seeds_updating_halt_ = false;
-  if (options_.verbose) SVO_INFO_STREAM("DepthFilter: RESET.");
-}
-
-void DepthFilter::clearFrameQueue() {
-  while (!frame_queue_.empty()) frame_queue_.pop();
-}
-
-void DepthFilter::updateSeedsLoop() {
-  while (!boost::this_thread::interruption_requested()) {
-    FramePtr frame;
-    {
-      lock_t lock(frame_queue_mut_);
-      while (frame_queue_.empty() && !new_keyframe_set_) frame_queue_cond_.wait(lock);
-      if (new_keyframe_set_) {  // a keyframe supersedes everything queued before it
-        new_keyframe_set_ = false;
-        seeds_updating_halt_ = false;
-        clearFrameQueue();
-        frame = new_keyframe_;
-      } else {
-        frame = frame_queue_.front();
-        frame_queue_.pop();
-      }
-    }
-    updateSeeds(frame);
-    if (frame->isKeyframe()) initializeSeeds(frame);
-  }
-}
-
-void DepthFilter::getSeedsCopy(const FramePtr& frame, std::list<Seed>& seeds) {
-  lock_t lock(seeds_mut_);
-  for (std::list<Seed>::iterator it = seeds_.begin(); it != seeds_.end(); ++it)
-    if (it->ftr->frame == frame.get()) seeds.push_back(*it);
-}
 
 // ---- the update, on the device ---------------------------------------------------------------
 void DepthFilter::updateSeeds(FramePtr frame) {

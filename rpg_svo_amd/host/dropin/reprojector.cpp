@@ -1,5 +1,8 @@
-// Drop-in body for svo/src/reprojector.cpp: the class svo::Reprojector of
-// svo/include/svo/reprojector.h.  The map bookkeeping stays on the host exactly as the
+// Drop-in for svo::Reprojector::reprojectMap (svo/include/svo/reprojector.h); reprojectCell, which only
+// it called, goes away.  Constructor, grid set-up, resetGrid, reprojectPoint and the candidate comparator
+// stay in the reference's own svo/src/reprojector.cpp: build that file minus reprojectMap / reprojectCell
+// (scripts/strip_members.py) next to this one.
+// The map bookkeeping stays on the host exactly as the
 // reference has it (which keyframes overlap, which cell a point falls in, one match per
 // cell in the shuffled cell order, the n_failed/n_succeeded counters and point deletion,
 // reprojector.cpp:64-204); what moves to the MI355X is the expensive part, the
@@ -23,42 +26,6 @@
 #include "marshal.h"
 
 namespace svo {
-
-Reprojector::Reprojector(vk::AbstractCamera* cam, Map& map) : map_(map) { initializeGrid(cam); }
-
-Reprojector::~Reprojector() {
-  for (size_t i = 0; i < grid_.cells.size(); ++i) delete grid_.cells[i];
-}
-
-void Reprojector::initializeGrid(vk::AbstractCamera* cam) {
-  grid_.cell_size = Config::gridSize();
-  grid_.grid_n_cols = (cam->width() + grid_.cell_size - 1) / grid_.cell_size;
-  grid_.grid_n_rows = (cam->height() + grid_.cell_size - 1) / grid_.cell_size;
-  const size_t n_cells = (size_t)grid_.grid_n_cols * grid_.grid_n_rows;
-  grid_.cells.assign(n_cells, NULL);
-  grid_.cell_order.resize(n_cells);
-  for (size_t i = 0; i < n_cells; ++i) {
-    grid_.cells[i] = new Cell;
-    grid_.cell_order[i] = (int)i;
-  }
-  // visiting order of the cells: fixed at construction, like the reference (:54)
-  std::random_shuffle(grid_.cell_order.begin(), grid_.cell_order.end());
-}
-
-void Reprojector::resetGrid() {
-  n_matches_ = 0;
-  n_trials_ = 0;
-  for (size_t i = 0; i < grid_.cells.size(); ++i) grid_.cells[i]->clear();
-}
-
-bool Reprojector::reprojectPoint(FramePtr frame, Point* point) {
-  Vector2d px(frame->w2c(point->pos_));
-  if (!frame->cam_->isInFrame(px.cast<int>(), 8))  // 8 px: the matcher's patch
-    return false;
-  const int k = static_cast<int>(px[1] / grid_.cell_size) * grid_.grid_n_cols + static_cast<int>(px[0] / grid_.cell_size);
-  grid_.cells.at(k)->push_back(Candidate(point, px));
-  return true;
-}
 
 namespace {
 struct Outcome {  // what one findMatchDirect trial left in the Matcher
@@ -118,15 +85,28 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
   std::map<Point*, Outcome> outcome;
   if (options_.find_match_direct) {
     using namespace hip_dropin;
+    // The reference observation of a trial (Point::getCloseViewObs, matcher.cpp:137) is chosen HERE,
+    // by the reference's own host code: a trial then ships exactly one svo::Feature, and only the
+    // keyframes that actually serve as reference need their pyramid on the device (a point seen from
+    // 40 keyframes no longer pins 40 pool slots for one 10x10 template).
     std::vector<Candidate*> trials;
-    size_t n_obs = 0;
+    std::vector<Feature*> trial_ref;
+    const Vector3d cur_pos(frame->pos());
     for (size_t k = 0; k < grid_.cells.size(); ++k)
-      for (Cell::iterator c = grid_.cells[k]->begin(); c != grid_.cells[k]->end(); ++c)
-        if (c->pt->type_ != Point::TYPE_DELETED) {
-          trials.push_back(&*c);
-          n_obs += c->pt->obs_.size();
+      for (Cell::iterator c = grid_.cells[k]->begin(); c != grid_.cells[k]->end(); ++c) {
+        if (c->pt->type_ == Point::TYPE_DELETED) continue;
+        Feature* ref_ftr = NULL;
+        if (!c->pt->getCloseViewObs(cur_pos, ref_ftr)) {  // findMatchDirect returns false at once (:137-138)
+          Outcome r;
+          r.ok = false; r.px = c->px; r.search_level = 0; r.ref_ftr = NULL;
+          outcome[c->pt] = r;
+          continue;
         }
+        trials.push_back(&*c);
+        trial_ref.push_back(ref_ftr);
+      }
     const size_t M = trials.size();
+    const size_t n_obs = M;
     if (M > 0) {
       svo_hip::Device& dev = ensureDevice(*frame);
       const int L = svo_hip::Device::LANE_TRACKING;
@@ -154,10 +134,9 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
         for (int k = 0; k < 3; ++k) pos[3 * m + k] = pt->pos_[k];
         px_in[2 * m] = trials[m]->px[0]; px_in[2 * m + 1] = trials[m]->px[1];
         ptr[m] = (int32_t)o;
-        for (std::list<Feature*>::const_iterator f = pt->obs_.begin(); f != pt->obs_.end(); ++f, ++o) {
-          obs.set(o, frames.indexOf((*f)->frame), *f);
-          obs_ftr[o] = *f;
-        }
+        obs.set(o, frames.indexOf(trial_ref[m]->frame), trial_ref[m]);
+        obs_ftr[o] = trial_ref[m];
+        ++o;
       }
       ptr[M] = (int32_t)o;
       svo_hip_frames ft;

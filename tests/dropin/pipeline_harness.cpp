@@ -34,19 +34,6 @@
 #include "svo_hip_device.h"
 #endif
 
-namespace vk {
-int g_halfsample_mode = 2;  // x86 dispatch of vk::halfSample (see oracle/shim/vikit/vision.h)
-}
-
-// The two-view bootstrap (svo/src/initialization.cpp: OpenCV KLT + vikit homography) is
-// out of scope and never entered: the harness starts from setFirstFrame().
-namespace svo {
-namespace initialization {
-InitResult KltHomographyInit::addFirstFrame(FramePtr) { return FAILURE; }
-InitResult KltHomographyInit::addSecondFrame(FramePtr) { return FAILURE; }
-void KltHomographyInit::reset() {}
-}  // namespace initialization
-}  // namespace svo
 
 using namespace svo;
 
