@@ -1,0 +1,113 @@
+// pose_exchange.cpp -- see pose_exchange.h.  RCCL (rccl.h) is the only dependency besides sockets.
+#include "pose_exchange.h"
+
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <thread>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+namespace svo_hip {
+
+namespace {
+void sendAll(int fd, const void* p, size_t n) {
+  const char* c = static_cast<const char*>(p);
+  while (n) {
+    const ssize_t k = ::send(fd, c, n, 0);
+    if (k <= 0) throw std::runtime_error("pose exchange bootstrap: send failed");
+    c += k; n -= (size_t)k;
+  }
+}
+void recvAll(int fd, void* p, size_t n) {
+  char* c = static_cast<char*>(p);
+  while (n) {
+    const ssize_t k = ::recv(fd, c, n, 0);
+    if (k <= 0) throw std::runtime_error("pose exchange bootstrap: recv failed");
+    c += k; n -= (size_t)k;
+  }
+}
+int envInt(const char* name, int fallback) {
+  const char* v = std::getenv(name);
+  return v && *v ? std::atoi(v) : fallback;
+}
+}  // namespace
+
+void tcpBroadcast(int rank, int world, const std::string& addr, int port, void* blob, size_t bytes, int timeout_s) {
+  if (world <= 1) return;
+  sockaddr_in sa;
+  std::memset(&sa, 0, sizeof(sa));
+  sa.sin_family = AF_INET;
+  sa.sin_port = htons((uint16_t)port);
+  if (::inet_pton(AF_INET, addr.c_str(), &sa.sin_addr) != 1) throw std::runtime_error("pose exchange bootstrap: MASTER_ADDR must be an IPv4 address");
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(timeout_s);
+  if (rank == 0) {
+    const int ls = ::socket(AF_INET, SOCK_STREAM, 0);
+    int one = 1;
+    ::setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    sockaddr_in any = sa;
+    any.sin_addr.s_addr = htonl(INADDR_ANY);
+    if (::bind(ls, reinterpret_cast<sockaddr*>(&any), sizeof(any)) != 0 || ::listen(ls, world) != 0) {
+      ::close(ls);
+      throw std::runtime_error("pose exchange bootstrap: cannot listen on the rig port");
+    }
+    timeval tv = {timeout_s, 0};
+    ::setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+    for (int k = 1; k < world; ++k) {
+      const int fd = ::accept(ls, NULL, NULL);
+      if (fd < 0) { ::close(ls); throw std::runtime_error("pose exchange bootstrap: a rank did not connect in time"); }
+      sendAll(fd, blob, bytes);
+      ::close(fd);
+    }
+    ::close(ls);
+  } else {
+    for (;;) {
+      const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
+      if (::connect(fd, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) == 0) {
+        recvAll(fd, blob, bytes);
+        ::close(fd);
+        return;
+      }
+      ::close(fd);
+      if (std::chrono::steady_clock::now() > deadline) throw std::runtime_error("pose exchange bootstrap: rank 0 is not reachable");
+      std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    }
+  }
+}
+
+PoseExchange* PoseExchange::fromEnvironment() {
+  const int rank = envInt("RANK", 0), world = envInt("WORLD_SIZE", 1);
+  const char* addr = std::getenv("MASTER_ADDR");
+  const int port = envInt("SVO_RIG_PORT", envInt("MASTER_PORT", 29600) + 17);
+  return new PoseExchange(rank, world, addr && *addr ? addr : "127.0.0.1", port);
+}
+
+PoseExchange::PoseExchange(int rank, int world, const std::string& addr, int port) : rank_(rank), world_(world), comm_(NULL) {
+  if (rank < 0 || world < 1 || rank >= world) throw std::runtime_error("pose exchange: bad rank / world size");
+  ncclUniqueId id;
+  std::memset(&id, 0, sizeof(id));
+  if (rank == 0 && ncclGetUniqueId(&id) != ncclSuccess) throw std::runtime_error("pose exchange: ncclGetUniqueId failed");
+  tcpBroadcast(rank, world, addr, port, &id, sizeof(id));
+  ncclComm_t comm;
+  if (ncclCommInitRank(&comm, world, id, rank) != ncclSuccess) throw std::runtime_error("pose exchange: ncclCommInitRank failed");
+  comm_ = comm;
+}
+
+PoseExchange::~PoseExchange() {
+  if (comm_) ncclCommDestroy(static_cast<ncclComm_t>(comm_));
+}
+
+void PoseExchange::allGather(const double* d_local, double* d_all, int n, void* stream) {
+  if (ncclAllGather(d_local, d_all, (size_t)n, ncclDouble, static_cast<ncclComm_t>(comm_), static_cast<hipStream_t>(stream)) != ncclSuccess)
+    throw std::runtime_error("pose exchange: ncclAllGather failed");
+}
+
+}  // namespace svo_hip
