@@ -107,6 +107,10 @@ int svo_hip_pyramid_load_level0(const svo_hip_pyr_layout* layout, uint8_t* d_sto
 /* Same from host memory (pinned or pageable): H2D copy straight into level 0. */
 int svo_hip_pyramid_upload_level0(const svo_hip_pyr_layout* layout, uint8_t* d_store, int slot,
                                   const uint8_t* image, int row_stride, void* stream);
+/* One pyramid level of one slot from host memory (an image that is not level 0 of a frame, e.g. the
+ * cv::Mat a direct caller hands to feature_alignment::align2D). */
+int svo_hip_pyramid_upload_level(const svo_hip_pyr_layout* layout, uint8_t* d_store, int slot, int level,
+                                 const uint8_t* image, int row_stride, void* stream);
 /* K0: build levels 1..n_levels-1 of slots [first_slot, first_slot+n_slots) from
  * their level 0.  Replaces frame_utils::createImgPyramid -> vk::halfSample
  * (svo/src/frame.cpp:156-165).  Bit-exact with the selected flavour. */
@@ -398,6 +402,24 @@ int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint8_t* d_stor
                          const svo_hip_seeds* seeds, const svo_hip_depth_filter_options* opt,
                          int32_t* d_status, double* d_xyz_world, double* d_px_cur,
                          void* d_workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Batched Matcher::findEpipolarMatchDirect (svo/src/matcher.cpp:179-321; matcher.h:113-123) on its own:
+ * query s searches along the epipolar segment of feature s of `ftr` (a feature of frame ftr->d_frame[s])
+ * in frame d_cur_frame[s], for depths d_d_min[s] .. d_d_max[s] around d_d_estimate[s].
+ *   d_ok [S]            the function's result
+ *   d_depth [S]         `depth` (triangulated, 0 where no match)
+ *   d_px_cur [S][2]     Matcher::px_cur_ (may be NULL)
+ *   d_search_level [S]  Matcher::search_level_ (may be NULL)
+ * Matcher::Options are taken from `opt` (the DepthFilter fields of the struct are ignored).
+ */
+int svo_hip_find_epipolar_match_direct(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
+                                       const svo_hip_camera* cam, const svo_hip_frames* frames, int S,
+                                       const int32_t* d_cur_frame, const svo_hip_features* ftr,
+                                       const double* d_d_estimate, const double* d_d_min, const double* d_d_max,
+                                       const svo_hip_depth_filter_options* opt, int32_t* d_ok, double* d_depth,
+                                       double* d_px_cur, int32_t* d_search_level, void* d_workspace,
+                                       size_t workspace_bytes, void* stream);
 
 /* Device pointer to n_steps [S] of the last svo_hip_update_seeds call that used this workspace: the
  * number of epipolar-line positions scanned per seed (matcher.cpp:248, 0 where no scan ran).  For

@@ -111,6 +111,7 @@ PROTOTYPES = {
     "svo_hip_pyr_store_bytes": (_i64, [C.POINTER(PyrLayout), _i]),
     "svo_hip_pyramid_load_level0": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _i64, _i, _vp]),
     "svo_hip_pyramid_upload_level0": (_i, [C.POINTER(PyrLayout), _vp, _i, _vp, _i, _vp]),
+    "svo_hip_pyramid_upload_level": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _i, _vp]),
     "svo_hip_pyramid_build": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _i, _vp]),
     "svo_hip_pyramid_build_from_images": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _i64, _i, _i, _vp]),
     "svo_hip_pyramid_build_tiled": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _i64, _i, _i, _i, _vp]),
@@ -136,6 +137,8 @@ PROTOTYPES = {
     "svo_hip_point_optimize": (_i, [C.POINTER(Frames), _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "svo_hip_update_seeds": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, C.POINTER(Features),
                                   C.POINTER(Seeds), C.POINTER(DepthFilterOptions), _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "svo_hip_find_epipolar_match_direct": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, C.POINTER(Features),
+                                                _vp, _vp, _vp, C.POINTER(DepthFilterOptions), _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "svo_hip_update_seed_batch": (_i, [_i, _vp, _vp, C.POINTER(Seeds), _vp]),
     "svo_hip_fast_workspace_bytes": (C.c_size_t, [_LP, _i, _i]),
     "svo_hip_fast_detect": (_i, [_LP, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, C.c_double, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),

@@ -76,6 +76,15 @@ struct SeedArgs {
   int32_t* status_out;
   double* xyz_world;
   double* px_cur_out;
+  // Matcher::findEpipolarMatchDirect on its own (svo_hip_find_epipolar_match_direct): the depth interval
+  // is given, nothing of DepthFilter::updateSeeds runs around it
+  int match_only;
+  const double* d_est;
+  const double* d_min;
+  const double* d_max;
+  double* depth_out;
+  int32_t* ok_out;
+  int32_t* search_level_out;
   SeedWs ws;
 };
 
@@ -101,7 +110,7 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   const int cf = a.cur_frame[s];
   w.cur_slot[s] = a.frame_slot[cf];
   // check if seed is not already too old (:216-219)
-  if ((a.opt.batch_counter - a.seeds.d_batch_id[s]) > a.opt.max_n_kfs) {
+  if (!a.match_only && (a.opt.batch_counter - a.seeds.d_batch_id[s]) > a.opt.max_n_kfs) {
     w.status[s] = SVO_HIP_SEED_ERASED_OLD;
     return;
   }
@@ -109,10 +118,10 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   Se3 Tr, Tc;
   se3_from_Rt(a.frame_T + 12 * rfi, Tr);
   se3_from_Rt(a.frame_T + 12 * cf, Tc);
-  const float mu = a.seeds.d_mu[s], sigma2 = a.seeds.d_sigma2[s];
+  const float mu = a.match_only ? 1.f : a.seeds.d_mu[s], sigma2 = a.match_only ? 0.f : a.seeds.d_sigma2[s];
   const double f[3] = {a.ftr.d_f[3 * s], a.ftr.d_f[3 * s + 1], a.ftr.d_f[3 * s + 2]};
   // visibility (:221-232)
-  {
+  if (!a.match_only) {
     const Se3 T_ref_cur = se3_compose(Tr, se3_inverse(Tc));
     const Se3 T_cur_ref0 = se3_inverse(T_ref_cur);
     const double k = 1.0 / (double)mu;
@@ -136,7 +145,9 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   const float zlo = mu - sq;
   const float z_inv_max = (zlo < 0.00000001f) ? 0.00000001f : zlo;
   w.z_inv_min[s] = z_inv_min;
-  const double d_estimate = 1.0 / (double)mu, d_min = 1.0 / (double)z_inv_min, d_max = 1.0 / (double)z_inv_max;
+  const double d_estimate = a.match_only ? a.d_est[s] : 1.0 / (double)mu;
+  const double d_min = a.match_only ? a.d_min[s] : 1.0 / (double)z_inv_min;
+  const double d_max = a.match_only ? a.d_max[s] : 1.0 / (double)z_inv_max;
 
   // ---- Matcher::findEpipolarMatchDirect, matcher.cpp:188-246 -------------------------
   const Se3 T_cur_ref = se3_compose(Tc, se3_inverse(Tr));
@@ -457,6 +468,12 @@ __global__ void __launch_bounds__(64) seed_finish_kernel(const SeedArgs a) {
       matched = depth_from_triangulation(T_cur_ref, f, fc, &z);
     }
   }
+  if (a.match_only) {  // findEpipolarMatchDirect's own outputs: the verdict, depth, px_cur_, search_level_
+    a.ok_out[s] = matched ? 1 : 0;
+    a.depth_out[s] = matched ? z : 0.0;
+    if (a.search_level_out) a.search_level_out[s] = w.search_level[s];
+    return;
+  }
   float sa = a.seeds.d_a[s], sb = a.seeds.d_b[s], smu = a.seeds.d_mu[s], ssig = a.seeds.d_sigma2[s];
   const float zr = a.seeds.d_z_range[s];
   if (!matched) {
@@ -544,6 +561,50 @@ extern "C" int svo_hip_compute_tau_batch(int S, const double* d_t_ref_cur, const
   return check_launch();
 }
 
+static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_store, SeedArgs& a, int S, void* d_workspace,
+                          size_t workspace_bytes, hipStream_t st);
+
+extern "C" int svo_hip_find_epipolar_match_direct(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
+                                                  const svo_hip_camera* cam, const svo_hip_frames* frames, int S,
+                                                  const int32_t* d_cur_frame, const svo_hip_features* ftr,
+                                                  const double* d_d_estimate, const double* d_d_min, const double* d_d_max,
+                                                  const svo_hip_depth_filter_options* opt, int32_t* d_ok, double* d_depth,
+                                                  double* d_px_cur, int32_t* d_search_level, void* d_workspace,
+                                                  size_t workspace_bytes, void* stream) {
+  if (!layout_ok(layout) || !d_store || !cam || !cam_model_ok(cam) || !frames || !ftr || !opt || S < 0) return SVO_HIP_EINVAL;
+  if (S == 0) return SVO_HIP_OK;
+  if (!d_cur_frame || !d_ok || !d_depth || !d_d_estimate || !d_d_min || !d_d_max || !frames->d_slot || !frames->d_T_f_w ||
+      !ftr->d_frame || !ftr->d_level || !ftr->d_px || !ftr->d_f)
+    return SVO_HIP_EINVAL;
+  if (ftr->d_type && !ftr->d_grad) return SVO_HIP_EINVAL;
+  if (opt->n_pyr_levels < 1 || opt->n_pyr_levels > layout->n_levels || opt->align_max_iter < 0 || opt->max_epi_search_steps < 0)
+    return SVO_HIP_EINVAL;
+  if (!d_workspace || workspace_bytes < svo_hip_match_workspace_bytes(S)) return SVO_HIP_ERANGE;
+  SeedArgs a;
+  a.L = *layout;
+  a.store = d_store;
+  a.cam = make_cam(cam);
+  a.S = S;
+  a.frame_slot = frames->d_slot;
+  a.frame_T = frames->d_T_f_w;
+  a.cur_frame = d_cur_frame;
+  a.ftr = *ftr;
+  a.seeds.d_a = a.seeds.d_b = a.seeds.d_mu = a.seeds.d_z_range = a.seeds.d_sigma2 = nullptr;
+  a.seeds.d_batch_id = nullptr;
+  a.opt = *opt;
+  a.status_out = nullptr;
+  a.xyz_world = nullptr;
+  a.px_cur_out = d_px_cur;
+  a.match_only = 1;
+  a.d_est = d_d_estimate;
+  a.d_min = d_d_min;
+  a.d_max = d_d_max;
+  a.depth_out = d_depth;
+  a.ok_out = d_ok;
+  a.search_level_out = d_search_level;
+  return run_seed_chain(layout, d_store, a, S, d_workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
                                     const svo_hip_camera* cam, const svo_hip_frames* frames, int S,
                                     const int32_t* d_cur_frame, const svo_hip_features* ftr,
@@ -561,9 +622,6 @@ extern "C" int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint
       opt->max_epi_search_steps < 0)
     return SVO_HIP_EINVAL;
   if (!d_workspace || workspace_bytes < svo_hip_match_workspace_bytes(S)) return SVO_HIP_ERANGE;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  Carver c(d_workspace, workspace_bytes);
-  const size_t n = (size_t)S;
   SeedArgs a;
   a.L = *layout;
   a.store = d_store;
@@ -578,6 +636,19 @@ extern "C" int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint
   a.status_out = d_status;
   a.xyz_world = d_xyz_world;
   a.px_cur_out = d_px_cur;
+  a.match_only = 0;
+  a.d_est = a.d_min = a.d_max = nullptr;
+  a.depth_out = nullptr;
+  a.ok_out = nullptr;
+  a.search_level_out = nullptr;
+  return run_seed_chain(layout, d_store, a, S, d_workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+// seed_prepare -> warp -> epipolar scan -> sub-pixel alignment -> seed_finish on one stream
+static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_store, SeedArgs& a, int S, void* d_workspace,
+                          size_t workspace_bytes, hipStream_t st) {
+  Carver c(d_workspace, workspace_bytes);
+  const size_t n = (size_t)S;
   SeedWs& w = a.ws;
   w.n_steps = c.take<int32_t>(n);  // first array of the workspace: svo_hip_update_seeds_scan_steps
   w.pwb = c.take<uint8_t>(n * 100);
@@ -631,7 +702,7 @@ extern "C" int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint
   al.dir = w.dir;
   al.use_1d = w.use_1d;
   al.active = w.align_active;
-  al.n_iter = opt->align_max_iter;
+  al.n_iter = a.opt.align_max_iter;
   al.px_in = w.px_scaled;
   al.px_out = w.px_cur;
   al.scale_out = 1;

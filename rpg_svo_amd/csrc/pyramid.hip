@@ -259,6 +259,15 @@ int svo_hip_pyramid_upload_level0(const svo_hip_pyr_layout* L, uint8_t* d_store,
   return SVO_HIP_OK;
 }
 
+int svo_hip_pyramid_upload_level(const svo_hip_pyr_layout* L, uint8_t* d_store, int slot, int level, const uint8_t* image,
+                                 int row_stride, void* stream) {
+  if (!layout_ok(L) || !d_store || !image || slot < 0 || level < 0 || level >= L->n_levels || row_stride < L->w[level])
+    return SVO_HIP_EINVAL;
+  SVO_HIP_TRY(hipMemcpy2DAsync(d_store + (int64_t)slot * L->slot_bytes + L->offset[level], L->pitch[level], image, row_stride,
+                               L->w[level], L->h[level], hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+  return SVO_HIP_OK;
+}
+
 static bool tile_ok(int tile_width) {
   return tile_width == 0 || tile_width == 128 || tile_width == 256 || tile_width == 257 || tile_width == 512;
 }

@@ -198,6 +198,31 @@ int Device::slotOf(int frame_id, const uint8_t* level0, int stride, Lane& lane) 
   return slot;
 }
 
+int Device::scratchSlotOf(const uint8_t* image, int w, int h, int stride, int* level_out, Lane& lane) {
+  int level = -1;
+  for (int l = 0; l < layout_.n_levels; ++l)
+    if (layout_.w[l] == w && layout_.h[l] == h) { level = l; break; }
+  if (level < 0)
+    throw Error("svo_hip::Device: a " + std::to_string(w) + "x" + std::to_string(h) + " image matches no pyramid level of the device context");
+  // scratch frames live under negative ids, one per level: a blank level-0 upload allocates the slot
+  const int id = -1 - level;
+  int slot;
+  {
+    std::lock_guard<std::mutex> g(frames_mut_);
+    std::map<int, Entry>::iterator it = frames_.find(id);
+    slot = it == frames_.end() ? -1 : it->second.slot;
+  }
+  if (slot < 0) {
+    std::vector<uint8_t> blank((size_t)layout_.w[0] * layout_.h[0], 0);
+    slot = slotOf(id, &blank[0], layout_.w[0], lane);
+  } else {
+    slot = slotOf(id, NULL, 0, lane);  // hit: pins it for this call
+  }
+  check(svo_hip_pyramid_upload_level(&layout_, d_store_, slot, level, image, stride, lane.stream), "svo_hip_pyramid_upload_level");
+  *level_out = level;
+  return slot;
+}
+
 void Device::forget(int frame_id) {
   std::lock_guard<std::mutex> g(frames_mut_);
   std::map<int, Entry>::iterator it = frames_.find(frame_id);

@@ -113,6 +113,10 @@ class Device {
   int slotOf(int frame_id, const uint8_t* level0, int stride, int which_lane) { return slotOf(frame_id, level0, stride, lane(which_lane)); }
   int slotOf(int frame_id, const uint8_t* level0, int stride, Lane& lane);
   void forget(int frame_id);
+  // A stand-alone image (not level 0 of a svo::Frame) as level *level_out of a scratch slot: the level
+  // of the layout whose size is w x h.  Uploaded on every call (the caller's buffer may have changed);
+  // the slot is pinned like a frame until the lane's next beginCall().  Throws when no level matches.
+  int scratchSlotOf(const uint8_t* image, int w, int h, int stride, int* level_out, Lane& lane);
 
   // The calling thread's lane of the given role (created on first use).
   Lane& lane(int which);

@@ -133,6 +133,31 @@ class Matcher:
         return res
 
 
+def find_epipolar_match_direct(store: PyramidStore, cam, frames: FrameTable, cur_frame, ftr: FeatureSet, d_estimate, d_min,
+                               d_max, n_pyr_levels: int = 3, align_1d: bool = False, align_max_iter: int = 10,
+                               max_epi_search_steps: int = 1000, subpix_refinement: bool = True,
+                               epi_search_edgelet_filtering: bool = True, epi_search_edgelet_max_angle: float = 0.7):
+    """Batched Matcher::findEpipolarMatchDirect (matcher.h:113-123) for S queries.  Returns
+    (ok [S] i32, depth [S] f64, px_cur [S,2], search_level [S] i32)."""
+    lib = capi.load()
+    S = ftr.px.shape[0]
+    dev = store.device
+    opt = capi.DepthFilterOptions(0, 0, 0.0, int(align_1d), align_max_iter, max_epi_search_steps, int(subpix_refinement),
+                                  int(epi_search_edgelet_filtering), n_pyr_levels, epi_search_edgelet_max_angle)
+    ok = torch.zeros(S, dtype=torch.int32, device=dev)
+    depth = torch.zeros(S, dtype=torch.float64, device=dev)
+    px = torch.zeros(S, 2, dtype=torch.float64, device=dev)
+    lvl = torch.zeros(S, dtype=torch.int32, device=dev)
+    ws = torch.empty(lib.svo_hip_match_workspace_bytes(S), dtype=torch.uint8, device=dev)
+    c, fr, ft = capi.camera(cam), frames.struct(), ftr.struct()
+    capi.check(lib.svo_hip_find_epipolar_match_direct(
+        C.byref(store.layout), store.ptr, C.byref(c), C.byref(fr), S, _chk(cur_frame, torch.int32).data_ptr(), C.byref(ft),
+        _chk(d_estimate, torch.float64).data_ptr(), _chk(d_min, torch.float64).data_ptr(), _chk(d_max, torch.float64).data_ptr(),
+        C.byref(opt), ok.data_ptr(), depth.data_ptr(), px.data_ptr(), lvl.data_ptr(), ws.data_ptr(), ws.numel(),
+        _stream_ptr(dev)), "svo_hip_find_epipolar_match_direct")
+    return ok, depth, px, lvl
+
+
 def reproject_points(cam, frames: FrameTable, cur_frame, pt_pos, cell_size: int, grid_n_cols: int, out=None):
     """Reprojector::reprojectPoint for M points: (cell [M] i32 (-1 = not in frame), px [M,2]).
     out: (cell, px) tensors to reuse."""

@@ -148,6 +148,30 @@ def test_dropin_sequence_with_the_reference_launch_file_cameras(pipeline_libs, g
 
 
 @pytest.mark.gpu
+def test_standalone_matcher_and_feature_alignment_seams(pipeline_libs, gpu_device):
+    """Flavour "hipm": Reprojector, DepthFilter and FastDetector are the reference's own files and call
+    svo::Matcher, which is the drop-in here (findMatchDirect / findEpipolarMatchDirect = one device trial
+    per call, rpg_svo_amd/host/dropin/matcher.cpp) together with feature_alignment::align1D/align2D
+    (dropin/feature_alignment.cpp): the seams of matcher.h:106-123 and feature_alignment.h:29-44 used the
+    way a direct caller uses them."""
+    if not pp.available("hipm"):
+        pytest.skip("tests/dropin/_build/libsvo_pipeline_hipm.so not built")
+    cam, imgs, T = _sequence(45, seed=5)
+    ref = pp.run_sequence("ref", cam, imgs, T)
+    hip = pp.run_sequence("hipm", cam, imgs, T)
+    Tr = np.stack([r["T_f_w"] for r in ref])
+    Th = np.stack([r["T_f_w"] for r in hip])
+    d = se3.log_norm(Th, Tr)
+    print(f"stand-alone seams: SE3 log-norm max {d.max():.3e} median {np.median(d):.3e}")
+    assert all(r["stage"] == pp.STAGE_DEFAULT_FRAME for r in hip)
+    assert d.max() <= SE3_LOGNORM_TOL and np.median(d) <= 1e-6
+    assert [r["is_keyframe"] for r in ref] == [r["is_keyframe"] for r in hip]
+    for k in ("repr_n_mps", "repr_n_new_references", "sfba_n_edges_final", "img_align_n_tracked"):
+        assert np.mean([a[k] == b[k] for a, b in zip(ref, hip)]) >= 0.95, k
+    assert np.mean([abs(a["n_seeds"] - b["n_seeds"]) <= 2 for a, b in zip(ref, hip)]) >= 0.95
+
+
+@pytest.mark.gpu
 def test_dropin_with_asynchronous_mapper_thread(pipeline_libs, gpu_device):
     """DepthFilter's own thread left running (the reference's normal mode): tracking lane and
     mapping lane of svo_hip::Device work concurrently.  Interleaving is timing dependent -- as in

@@ -191,6 +191,43 @@ def test_point_optimize(gpu_device, orc, scene):
         assert np.abs(o - out[i]).max() < 1e-11, i
 
 
+def test_find_epipolar_match_direct(gpu_device, orc, scene, pyrs):
+    """Matcher::findEpipolarMatchDirect on its own (the seam matcher.h:113-123 offers besides the depth
+    filter): verdict and search level identical, px_cur_ to 1e-9, depth to 1e-9 relative."""
+    store, frames = scene_store(scene)
+    oframes = pytrack.make_frames(pyrs, scene.T_f_w)
+    rng = np.random.default_rng(11)
+    feats, de, dmin, dmax = [], [], [], []
+    for i in range(0, len(scene.obs), 2):
+        o = [x for x in scene.obs[i] if x[0] != scene.cur][0]
+        c_ref = -scene.T_f_w[o[0], :9].reshape(3, 3).T @ scene.T_f_w[o[0], 9:]
+        d_true = np.linalg.norm(scene.pt_pos[i] - c_ref)
+        spread = [0.4, 0.1, 0.0005][(i // 2) % 3]
+        d_est = d_true * (1 + rng.normal() * spread * 0.3)
+        feats.append(o); de.append(d_est); dmin.append(d_est * (1 - spread)); dmax.append(d_est * (1 + spread))
+    S = len(feats)
+    fs = tracking.FeatureSet(frame=dev([o[0] for o in feats], torch.int32), level=dev([o[3] for o in feats], torch.int32),
+                             px=dev([o[1] for o in feats], torch.float64), f=dev([o[2] for o in feats], torch.float64),
+                             type=dev([o[4] for o in feats], torch.uint8), grad=dev([o[5] for o in feats], torch.float64))
+    for align_1d in (0, 1):
+        ok, depth, px, lvl = tracking.find_epipolar_match_direct(
+            store, scene.cam, frames, torch.full((S,), scene.cur, dtype=torch.int32, device="cuda:0"), fs,
+            dev(de, torch.float64), dev(dmin, torch.float64), dev(dmax, torch.float64), n_pyr_levels=5, align_1d=bool(align_1d))
+        torch.cuda.synchronize()
+        ok, depth, px, lvl = ok.cpu().numpy(), depth.cpu().numpy(), px.cpu().numpy(), lvl.cpu().numpy()
+        opt = pytrack.matcher_options(n_pyr_levels=5, align_1d=align_1d)
+        n_ok = 0
+        for k in range(S):
+            ok_o, r = orc.find_epipolar_match_direct(oframes, scene.cam, feats[k][0], scene.cur, pytrack.make_feature(*feats[k]),
+                                                     de[k], dmin[k], dmax[k], opt)
+            assert bool(ok[k]) == ok_o, (k, ok[k], ok_o)
+            if ok_o:
+                n_ok += 1
+                assert lvl[k] == r["search_level"]
+                assert np.abs(px[k] - r["px_cur"]).max() < 1e-9 and abs(depth[k] - r["depth"]) < 1e-9 * abs(r["depth"])
+        assert n_ok > S // 3
+
+
 def _make_seeds(scene, orc, rng):
     seeds, feats = [], []
     for i in range(len(scene.obs)):
