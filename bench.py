@@ -758,7 +758,8 @@ def dropin_sequence(n_frames: int = 120) -> dict:
     try:
         ref = pp.run_sequence("ref", cam, imgs, T)
         pp.run_sequence("hip", cam, imgs[:10], T[:10])  # warm-up: context creation, first launches
-        hip = pp.run_sequence("hip", cam, imgs, T)
+        host = {}
+        hip = pp.run_sequence("hip", cam, imgs, T, stats_out=host)
     finally:
         os.dup2(saved, 2)
         os.close(devnull)
@@ -772,7 +773,12 @@ def dropin_sequence(n_frames: int = 120) -> dict:
             "keyframes": int(sum(r["is_keyframe"] for r in hip)),
             "same_keyframe_frames": [r["is_keyframe"] for r in ref] == [r["is_keyframe"] for r in hip],
             "median_ms_per_frame_cpu_reference": {k: med(ref, "t_" + k) for k in stages},
-            "median_ms_per_frame_hip_dropin": {k: med(hip, "t_" + k) for k in stages}}
+            "median_ms_per_frame_hip_dropin": {k: med(hip, "t_" + k) for k in stages},
+            # N2 evidence: per drop-in call, the host walking the reference's pointer graph into the pinned
+            # arena and back (marshal/unmarshal) against the device round trip (H2D + kernels + D2H + sync)
+            "host_vs_device_us_per_call": {k: {q: round(v, 2) if isinstance(v, float) else v for q, v in st.items()}
+                                           for k, st in host.get("stages", {}).items()},
+            "pyramid_uploads": host.get("uploads"), "pyramid_upload_us_per_frame": host.get("pyramid_upload_us_total", 0.0) / n_frames}
 
 
 def cpu_baseline(args, W: Workload, T_est_w, result, iters_gpu) -> dict:

@@ -38,6 +38,7 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   svo_hip::Lane& lane = dev.lane(L);
   std::lock_guard<std::mutex> guard(lane.mut);
   dev.beginCall(L);
+  svo_hip::StageTimer stage_timer(dev, svo_hip::Device::STAGE_DEPTH_FILTER);
   svo_hip::Arena& a = lane.arena;
   a.reset();
   a.reserve(((size_t)1 << 16) + S * 256 + 4096 * 32);
@@ -92,12 +93,14 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   const svo_hip_camera cam = cameraOf(frame->cam_);
   void* ws = dev.workspace(lane, (int)S);
 
+  stage_timer.device(a.used());
   a.uploadAll(lane.stream);
   svo_hip::check(svo_hip_update_seeds(&dev.layout(), dev.store(), &cam, &ft, (int)S, d_cur, &ftr.dev, &seeds, &opt, d_status, d_xyz,
                                       d_px, ws, lane.workspace_bytes, lane.stream),
                  "svo_hip_update_seeds");
   a.download(lane.stream);
   svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+  stage_timer.unmarshal();
 
   // ---- replay of the list surgery, in list order (:216-219, :238-245, :255-290) ---------------
   const bool is_kf = frame->isKeyframe();

@@ -23,6 +23,7 @@ void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const 
   svo_hip::Lane& lane = dev.lane(L);
   std::lock_guard<std::mutex> guard(lane.mut);
   dev.beginCall(L);
+  svo_hip::StageTimer stage_timer(dev, svo_hip::Device::STAGE_POSE_OPT);
   svo_hip::Arena& a = lane.arena;
   a.reset();
 
@@ -53,12 +54,14 @@ void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const 
   int32_t* ran = a.alloc<int32_t>(1, &d_ran);
 
   const svo_hip_camera cam = cameraOf(frame->cam_);
+  stage_timer.device(a.used());
   a.uploadAll(lane.stream);
   svo_hip::check(svo_hip_pose_optimize(&cam, 1, d_n, (int)n, d_f, d_level, d_pos, d_has_out, reproj_thresh, (int)n_iter, d_Tout,
                                        d_Cov, d_stats, d_ran, lane.stream),
                  "svo_hip_pose_optimize");
   a.download(lane.stream);
   svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+  stage_timer.unmarshal();
 
   if (!*ran) return;  // no observation carried a point: the reference returns untouched (:57-58)
   frame->T_f_w_ = poseFromRt(Tout);

@@ -113,6 +113,7 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
       svo_hip::Lane& lane = dev.lane(L);
       std::lock_guard<std::mutex> guard(lane.mut);
       dev.beginCall(L);
+      svo_hip::StageTimer stage_timer(dev, svo_hip::Device::STAGE_REPROJECT);
       svo_hip::Arena& a = lane.arena;
       a.reset();
       a.reserve(((size_t)1 << 16) + M * 512 + n_obs * 128 + 4096 * 32);
@@ -153,6 +154,7 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
 
       const svo_hip_camera cam = cameraOf(frame->cam_);
       void* ws = dev.workspace(lane, (int)M);
+      stage_timer.device(a.used());
       a.uploadAll(lane.stream);
       svo_hip::check(svo_hip_find_match_direct(&dev.layout(), dev.store(), &cam, &ft, (int)M, d_cur, d_pos, d_ptr, &obs.dev,
                                                Config::nPyrLevels(), matcher_.options_.align_max_iter, d_px, d_ok, d_ref, d_lvl,
@@ -160,6 +162,7 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
                      "svo_hip_find_match_direct");
       a.download(lane.stream);
       svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+      stage_timer.unmarshal();
 
       for (size_t m = 0; m < M; ++m) {
         Outcome r;

@@ -39,6 +39,7 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   svo_hip::Lane& lane = dev.lane(L);
   std::lock_guard<std::mutex> guard(lane.mut);
   dev.beginCall(L);
+  svo_hip::StageTimer stage_timer(dev, svo_hip::Device::STAGE_SPARSE_ALIGN);
 
   const size_t n = ref_frame->fts_.size();
   if (n > SVO_HIP_MAX_PATCHES) throw svo_hip::Error("SparseImgAlign: more than SVO_HIP_MAX_PATCHES features");
@@ -89,12 +90,14 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   P.cam_model = cam.model;
   for (int k = 0; k < 5; ++k) P.d[k] = cam.d[k];
 
+  stage_timer.device(a.used());
   a.upload(lane.stream);
   svo_hip::check(svo_hip_sparse_align(&dev.layout(), dev.store(), 1, d_slots, d_slots + 1, d_slots + 2, (int)n, d_px, d_xyz,
                                       d_valid, &P, d_Tin, d_Tout, d_H, d_ntracked, d_iters, d_chi2, d_status, lane.stream),
                  "svo_hip_sparse_align");
   a.download(lane.stream);
   svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+  stage_timer.unmarshal();
 
   cur_frame->T_f_w_ = poseFromRt(Tout) * ref_frame->T_f_w_;  // :70
   for (int r = 0; r < 6; ++r)

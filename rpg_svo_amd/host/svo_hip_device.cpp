@@ -1,6 +1,8 @@
 // svo_hip_device.cpp -- see svo_hip_device.h.
 #include "svo_hip_device.h"
 
+#include <chrono>
+
 #include <cstring>
 
 namespace svo_hip {
@@ -184,6 +186,7 @@ int Device::slotOf(int frame_id, const uint8_t* level0, int stride, Lane& lane) 
   }
   const int slot = free_slots_.back();
   free_slots_.pop_back();
+  const double t_up = StageTimer::now();
   check(svo_hip_pyramid_upload_level0(&layout_, d_store_, slot, level0, stride, lane.stream), "svo_hip_pyramid_upload_level0");
   check(svo_hip_pyramid_build(&layout_, d_store_, slot, 1, SVO_HIP_HALFSAMPLE_AUTO, lane.stream), "svo_hip_pyramid_build");
   // another lane may consume this slot next: complete the upload before publishing it
@@ -195,7 +198,12 @@ int Device::slotOf(int frame_id, const uint8_t* level0, int stride, Lane& lane) 
   lane.touched.push_back(frame_id);
   frames_[frame_id] = en;
   ++stats.uploads;
+  stats.pyr_upload_us += StageTimer::now() - t_up;
   return slot;
+}
+
+double StageTimer::now() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 int Device::scratchSlotOf(const uint8_t* image, int w, int h, int stride, int* level_out, Lane& lane) {

@@ -122,8 +122,20 @@ class Device {
   Lane& lane(int which);
   void* workspace(Lane& lane, int n_trials);  // grows the lane's matcher scratch on demand
 
-  // statistics for the latency read-outs
-  struct Stats { uint64_t uploads, evictions, calls; Stats() : uploads(0), evictions(0), calls(0) {} };
+  // statistics for the latency read-outs.  Per stage (STAGE_*) the host time of a drop-in call is split
+  // into: marshal (walking the reference's pointer graph into the pinned arena), device (H2D copy +
+  // kernels + D2H copy + stream sync, as seen from the host) and unmarshal (writing results back into
+  // Frame / Feature / Point / Seed objects); pyramid uploads (new frames: H2D + K0) are kept apart.
+  enum { STAGE_SPARSE_ALIGN = 0, STAGE_REPROJECT = 1, STAGE_POSE_OPT = 2, STAGE_DEPTH_FILTER = 3, N_STAGES = 4 };
+  struct Stats {
+    uint64_t uploads, evictions, calls;
+    double pyr_upload_us;
+    double marshal_us[N_STAGES], device_us[N_STAGES], unmarshal_us[N_STAGES], payload_bytes[N_STAGES];
+    uint64_t n[N_STAGES];
+    Stats() : uploads(0), evictions(0), calls(0), pyr_upload_us(0) {
+      for (int i = 0; i < N_STAGES; ++i) { marshal_us[i] = device_us[i] = unmarshal_us[i] = payload_bytes[i] = 0; n[i] = 0; }
+    }
+  };
   Stats stats;
 
  private:
@@ -141,6 +153,32 @@ class Device {
   std::mutex lanes_mut_;
   std::map<std::pair<std::thread::id, int>, Lane*> lanes_;
   Lane* makeLane();
+};
+
+// Splits one drop-in call on the host clock (see Device::Stats).  marshal until device(), device until
+// unmarshal(), unmarshal until destruction; time spent uploading pyramids inside the marshal phase is
+// taken out of it.
+class StageTimer {
+ public:
+  StageTimer(Device& dev, int stage) : dev_(dev), stage_(stage), phase_(0), up0_(dev.stats.pyr_upload_us) { t_[0] = now(); }
+  void device(size_t payload_bytes) { t_[1] = now(); phase_ = 1; up1_ = dev_.stats.pyr_upload_us; bytes_ = (double)payload_bytes; }
+  void unmarshal() { t_[2] = now(); phase_ = 2; }
+  ~StageTimer() {
+    if (phase_ < 2) return;  // the call left early (nothing to do): not a sample
+    const double t3 = now();
+    Device::Stats& s = dev_.stats;
+    s.marshal_us[stage_] += (t_[1] - t_[0]) - (up1_ - up0_);
+    s.device_us[stage_] += t_[2] - t_[1];
+    s.unmarshal_us[stage_] += t3 - t_[2];
+    s.payload_bytes[stage_] += bytes_;
+    ++s.n[stage_];
+  }
+  static double now();  // microseconds, steady clock
+
+ private:
+  Device& dev_;
+  int stage_, phase_;
+  double t_[3], up0_, up1_, bytes_;
 };
 
 }  // namespace svo_hip

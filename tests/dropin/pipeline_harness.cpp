@@ -207,6 +207,20 @@ void pipe_device_stats(uint64_t out[3]) {
 #endif
 }
 
+// per stage (sparse_align, reproject, pose_opt, depth_filter): calls, marshal us, device round-trip us,
+// unmarshal us, payload bytes -- 5 doubles each; out[20] = pyramid upload us (svo_hip::Device::Stats)
+void pipe_stage_times(double out[21]) {
+  for (int i = 0; i < 21; ++i) out[i] = 0;
+#ifdef SVO_PIPELINE_HIP
+  const svo_hip::Device::Stats& s = svo_hip::Device::instance().stats;
+  for (int k = 0; k < svo_hip::Device::N_STAGES; ++k) {
+    out[5 * k] = (double)s.n[k]; out[5 * k + 1] = s.marshal_us[k]; out[5 * k + 2] = s.device_us[k];
+    out[5 * k + 3] = s.unmarshal_us[k]; out[5 * k + 4] = s.payload_bytes[k];
+  }
+  out[20] = s.pyr_upload_us;
+#endif
+}
+
 // features of the last frame (px, level, has point), for inspection
 int pipe_last_features(void* h, int max_n, double* px, int32_t* level, double* pos) {
   Pipe* p = (Pipe*)h;

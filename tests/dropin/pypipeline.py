@@ -104,6 +104,16 @@ class Pipeline:
         self.lib.pipe_device_stats(out)
         return tuple(int(x) for x in out)
 
+    STAGES = ("sparse_align", "reproject", "pose_opt", "depth_filter")
+
+    def stage_times(self):
+        """Host-clock split of the drop-in calls so far (svo_hip::Device::Stats): per stage
+        calls / marshal / device round trip / unmarshal microseconds and arena payload bytes."""
+        out = (C.c_double * 21)()
+        self.lib.pipe_stage_times(out)
+        v = np.array(out[:], dtype=np.float64)
+        return v
+
     def last_features(self, max_n=2048):
         px = np.zeros((max_n, 2)); lvl = np.zeros(max_n, dtype=np.int32); pos = np.zeros((max_n, 3))
         n = self.lib.pipe_last_features(self.h, max_n, px.ctypes.data, lvl.ctypes.data, pos.ctypes.data)
@@ -128,6 +138,7 @@ def run_sequence(flavour, cam, images, T_gt, stats_out=None, **cfg):
     p = Pipeline(flavour, cam, **cfg)
     try:
         s0 = p.device_stats()
+        t0 = p.stage_times()
         n0, r0 = p.set_first_frame(images[0], 0.0, T_gt[0], range_map(cam, T_gt[0]))
         r0["n_first_features"] = n0
         out = [r0]
@@ -136,6 +147,14 @@ def run_sequence(flavour, cam, images, T_gt, stats_out=None, **cfg):
         if stats_out is not None:
             s1 = p.device_stats()
             stats_out.update(uploads=s1[0] - s0[0], evictions=s1[1] - s0[1], calls=s1[2] - s0[2])
+            dt = p.stage_times() - t0
+            stages = {}
+            for k, name in enumerate(Pipeline.STAGES):
+                n = dt[5 * k]
+                if n > 0:
+                    stages[name] = dict(calls=int(n), marshal_us=dt[5 * k + 1] / n, device_us=dt[5 * k + 2] / n,
+                                        unmarshal_us=dt[5 * k + 3] / n, payload_bytes=dt[5 * k + 4] / n)
+            stats_out.update(stages=stages, pyramid_upload_us_total=float(dt[20]))
         return out
     finally:
         p.close()
