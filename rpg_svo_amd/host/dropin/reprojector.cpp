@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <stdexcept>
+#include <unordered_map>
 
 #include <svo/config.h>
 #include <svo/feature.h>
@@ -82,8 +83,11 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
 
   // ---- 3. device: one findMatchDirect trial per binned candidate -----------------------------
   SVO_START_TIMER("feature_align");
-  std::map<Point*, Outcome> outcome;
+  std::unordered_map<Point*, Outcome> outcome;
   if (options_.find_match_direct) {
+    size_t n_binned = 0;
+    for (size_t k = 0; k < grid_.cells.size(); ++k) n_binned += grid_.cells[k]->size();
+    outcome.reserve(2 * n_binned);
     using namespace hip_dropin;
     // The reference observation of a trial (Point::getCloseViewObs, matcher.cpp:137) is chosen HERE,
     // by the reference's own host code: a trial then ships exactly one svo::Feature, and only the
@@ -189,7 +193,7 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
       if (pt->type_ == Point::TYPE_DELETED) { it = cell.erase(it); continue; }
       Outcome r;
       if (options_.find_match_direct) {
-        std::map<Point*, Outcome>::iterator f = outcome.find(pt);
+        std::unordered_map<Point*, Outcome>::iterator f = outcome.find(pt);
         if (f == outcome.end()) throw std::logic_error("Reprojector: candidate without a device trial");
         r = f->second;
       } else {  // accept the projection as it is

@@ -2,6 +2,7 @@
 #include "svo_hip_device.h"
 
 #include <chrono>
+#include <cstdlib>
 
 #include <cstring>
 
@@ -42,20 +43,29 @@ void Arena::grow(size_t need) {
               " bytes): reserve() an upper bound before filling");
 }
 
+void Arena::setMode(Mode m) {
+  if (used_ != 0) throw Error("svo_hip::Arena::setMode on a non-empty arena");
+  mode_ = m;
+}
+
 void Arena::upload(void* stream) {
+  if (mode_ == MAPPED) return;
   if (in_end_) check(svo_hip_memcpy_h2d(d_, h_, in_end_, stream), "arena upload");
 }
 
 void Arena::uploadAll(void* stream) {
+  if (mode_ == MAPPED) return;
   if (used_) check(svo_hip_memcpy_h2d(d_, h_, used_, stream), "arena upload");
 }
 
 void Arena::download(void* stream) {
+  if (mode_ == MAPPED) return;
   if (used_ > in_end_) check(svo_hip_memcpy_d2h(h_ + in_end_, d_ + in_end_, used_ - in_end_, stream), "arena download");
 }
 
 void Arena::fetchBytes(uint8_t* host_block, size_t bytes, void* stream) {
   if (host_block < h_ || host_block + bytes > h_ + used_) throw Error("svo_hip::Arena::fetch: not an arena block");
+  if (mode_ == MAPPED) return;
   check(svo_hip_memcpy_d2h(host_block, d_ + (host_block - h_), bytes, stream), "arena fetch");
 }
 
@@ -99,6 +109,10 @@ Lane* Device::makeLane() {
   Lane* l = new Lane();
   check(svo_hip_stream_create(&l->stream), "svo_hip_stream_create");
   l->arena.reserve((size_t)4 << 20);
+  // SVO_HIP_ARENA=mapped|mirrored selects how a call's arguments reach the device (Arena)
+  const char* mode = std::getenv("SVO_HIP_ARENA");
+  if (mode && std::string(mode) == "mapped") l->arena.setMode(Arena::MAPPED);
+  else if (mode && std::string(mode) != "mirrored") throw Error("SVO_HIP_ARENA must be 'mapped' or 'mirrored'");
   return l;
 }
 

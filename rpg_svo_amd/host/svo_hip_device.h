@@ -37,9 +37,16 @@ void check(int code, const char* what);  // throws Error on a negative svo_hip s
 
 // Bump allocator over a pinned host buffer and its same-sized device mirror.  Input blocks
 // are carved from the front, output blocks after them; both sides share offsets.
+// In MAPPED mode there is no mirror: the kernels read and write the pinned (coherent,
+// device-mapped) host buffer over the host link directly, so a call is kernels + one stream sync
+// with no copy commands at all -- the shorter round trip for the few-KB payloads of a single
+// camera (DESIGN.md "single-stream latency"); upload()/download() are then no-ops.
 class Arena {
  public:
-  Arena() : h_(NULL), d_(NULL), cap_(0), used_(0), in_end_(0) {}
+  enum Mode { MIRRORED = 0, MAPPED = 1 };
+  Arena() : h_(NULL), d_(NULL), cap_(0), used_(0), in_end_(0), mode_(MIRRORED) {}
+  void setMode(Mode m);  // before the first alloc of a call
+  Mode mode() const { return mode_; }
   void reserve(size_t bytes);
   void reset() { used_ = 0; in_end_ = 0; }
   // n elements of T, 256-byte aligned; *dev receives the device address of the same block
@@ -48,7 +55,7 @@ class Arena {
     size_t end = off + n * sizeof(T);
     if (end > cap_) grow(end);
     used_ = end;
-    *dev = reinterpret_cast<T*>(d_ + off);
+    *dev = reinterpret_cast<T*>((mode_ == MAPPED ? h_ : d_) + off);
     return reinterpret_cast<T*>(h_ + off);
   }
   void endInputs() { in_end_ = used_; }          // everything allocated so far is kernel input
@@ -69,6 +76,7 @@ class Arena {
   uint8_t* h_;
   uint8_t* d_;
   size_t cap_, used_, in_end_;
+  Mode mode_;
 };
 
 struct Lane {
