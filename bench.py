@@ -159,6 +159,8 @@ class Workload:
                  T_gt: np.ndarray | None = None):
         (self.width, self.height, self.focal, self.n_levels, self.max_level, self.min_level, self.n_patches,
          margin, cell) = WORKLOADS[name]
+        if os.environ.get("SVO_BENCH_PATCHES"):  # kernel experiments only (scripts/): NOT the configuration the metric names
+            self.n_patches = int(os.environ["SVO_BENCH_PATCHES"])
         self.name, self.B, self.dev, self.noise = name, B, dev, noise
         w, h, f = self.width, self.height, self.focal
         self.cam = synth.Camera(w, h, f, f, w / 2.0, h / 2.0)
@@ -223,6 +225,8 @@ def main() -> None:
     ap.add_argument("--extras", default="all",
                     help="comma list of the extra legs to run at N=1 (all, none, or any of: refine, full, noise, config3, rig, "
                          "k0, dropin, pmc)")
+    ap.add_argument("--k1-kernel", default="auto", choices=["auto", "workgroup"],
+                    help="auto: svo_hip_sparse_align (one wave per frame up to 256 patches); workgroup: the workgroup-per-frame kernel")
     ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -265,6 +269,7 @@ def main() -> None:
     W = Workload(args.workload, B, dev, rank, noise=args.noise)
     store = W.store
     sia = SparseImgAlign(W.max_level, W.min_level, args.n_iter)
+    sia.kernel = args.k1_kernel
     out = sia.alloc_result(B, dev)
     # N>1: the only exchange is the gather of the [B,12] poses.  It is double-buffered and issued
     # asynchronously (RCCL's own stream) so that it overlaps the next step's kernels; the timed
@@ -395,12 +400,12 @@ def main() -> None:
                             + (" + the rest of the track" if full is not None else "")
                             + (" + RCCL all_gather of the poses" if use_dist else ""),
             "parallelism": f"frames sharded 1 rank/GPU x{world}" + (", RCCL all_gather of poses, double-buffered and overlapped with the next step" if use_dist else ""),
-            "hip_graph": bool(args.graph),
+            "hip_graph": bool(args.graph), "k1_kernel": args.k1_kernel,
             "mean_gn_iterations_per_frame": float(iters.sum(1).mean()),
             "mean_tracked_patches": float(n_tracked.mean()),
             "median_pose_error_vs_gt": float(np.median(st["gt_err"])),
         },
-        "roofline": roofline("sia_kernel (svo_hip_sparse_align)", alg_bytes, kernel_ms, traffic=None, kernel_ms_avg=kernel_ms,
+        "roofline": roofline(("sia_wave_kernel" if args.k1_kernel == "auto" and W.n_patches <= 256 else "sia_kernel") + " (svo_hip_sparse_align)", alg_bytes, kernel_ms, traffic=None, kernel_ms_avg=kernel_ms,
                              algorithmic_bytes_per_frame=alg_bytes / B,
                              # iterations/s and per-iteration time of the batch
                              gn_iterations_per_s=float(iters.sum()) / (kernel_ms * 1e-3),
@@ -664,7 +669,7 @@ def pmc_leg(args, kernel_ms: float) -> dict:
         return {"skipped": "rocprofv3 not on PATH"}
     base = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--batch", str(args.batch),
             "--workload", args.workload, "--noise", str(args.noise), "--n-iter", str(args.n_iter), "--no-cpu-baseline",
-            "--extras", "none", "--pmc-child", "1"]
+            "--extras", "none", "--pmc-child", "1", "--k1-kernel", args.k1_kernel]
     passes = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
               "sq": ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
                      "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"]}
@@ -673,7 +678,7 @@ def pmc_leg(args, kernel_ms: float) -> dict:
     env.pop("SVO_BENCH_FORCE_DIST", None)
     for name, ctrs in passes.items():
         d = tempfile.mkdtemp(prefix=f"svo_pmc_{name}_", dir="/tmp")
-        cmd = [exe, "--pmc", *ctrs, "--kernel-include-regex", "sia_kernel", "--output-format", "csv", "-d", d, "-o", name, "--", *base]
+        cmd = [exe, "--pmc", *ctrs, "--kernel-include-regex", "sia_(wave_)?kernel", "--output-format", "csv", "-d", d, "-o", name, "--", *base]
         try:
             p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
         except subprocess.TimeoutExpired:
@@ -686,7 +691,7 @@ def pmc_leg(args, kernel_ms: float) -> dict:
         acc: dict[str, list[float]] = {}
         with open(files[0]) as fh:
             for row in csv.DictReader(fh):
-                if "sia_kernel" not in row.get("Kernel_Name", ""):
+                if "sia_kernel" not in row.get("Kernel_Name", "") and "sia_wave_kernel" not in row.get("Kernel_Name", ""):
                     continue
                 acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
         for k, v in acc.items():

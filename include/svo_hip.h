@@ -161,8 +161,11 @@ typedef struct svo_hip_sia_params {
 
 /*
  * Batched SparseImgAlign::run (svo/src/sparse_img_align.cpp:43-75) for B
- * independent (reference frame, current frame) problems; one workgroup per
- * problem, one lane per 4x4 patch.
+ * independent (reference frame, current frame) problems.  One workgroup per
+ * problem, one lane per 4x4 patch (sparse_align.hip); batches of >= 1024 problems
+ * with n_stride <= 192 run one WAVE per problem, a lane carrying up to three
+ * patches (sparse_align_wave.hip).  Same arithmetic per patch; the order of the
+ * (tolerance-mode, f32) sums differs between the two.
  *
  *   d_ref_slot/d_cur_slot [B]   pyramid-store slots of the two frames
  *   d_n [B]                     features of problem b (<= n_stride <= SVO_HIP_MAX_PATCHES)
@@ -185,6 +188,16 @@ int svo_hip_sparse_align(const svo_hip_pyr_layout* layout, const uint8_t* d_stor
                          const double* d_T_in, double* d_T_out, double* d_H_out,
                          int32_t* d_n_tracked, int32_t* d_iters, double* d_chi2,
                          int32_t* d_status, void* stream);
+
+/* The workgroup-per-problem kernel whatever B and n_stride, exported so tests and the bench can put both
+ * kernels on the same problems.  Arguments as svo_hip_sparse_align. */
+int svo_hip_sparse_align_workgroup(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int B,
+                                   const int32_t* d_ref_slot, const int32_t* d_cur_slot, const int32_t* d_n,
+                                   int n_stride, const double* d_px, const double* d_xyz_ref,
+                                   const uint8_t* d_valid, const svo_hip_sia_params* params,
+                                   const double* d_T_in, double* d_T_out, double* d_H_out,
+                                   int32_t* d_n_tracked, int32_t* d_iters, double* d_chi2,
+                                   int32_t* d_status, void* stream);
 
 /* The 6x6 solve x = H^-1 b of a batch of problems through hipSOLVER (batched Cholesky: potrf +
  * potrs), e.g. on the H_out of svo_hip_sparse_align.  NOT used by the kernels (they solve in

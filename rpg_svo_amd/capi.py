@@ -119,6 +119,8 @@ PROTOTYPES = {
     "svo_hip_pyramid_download_level": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _vp]),
     "svo_hip_sparse_align": (_i, [C.POINTER(PyrLayout), _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp,
                                   C.POINTER(SiaParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "svo_hip_sparse_align_workgroup": (_i, [C.POINTER(PyrLayout), _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp,
+                                            C.POINTER(SiaParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "svo_hip_solve6_hipsolver_workspace_bytes": (C.c_size_t, [_i]),
     "svo_hip_solve6_hipsolver": (_i, [_i, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "svo_hip_align_batch": (_i, [_LP, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -32,114 +32,21 @@
 // perturbation of J moves the Gauss-Newton fixed point by ~1e-11, far below the
 // stated parity tolerance.  Sums are tree- instead of sequentially reduced, so
 // results agree to rounding, not bit-for-bit.
-#include "capi_common.h"
-#include "device_math.h"
-#include "track_math.h"
-#include "wave_reduce.h"
+#include "sia_common.h"
 
 using namespace svo_capi;
 using namespace svo_dev;
+using namespace svo_sia;
 
 namespace {
 
-struct SiaArgs {
-  svo_hip_pyr_layout L;
-  const uint8_t* store;
-  const int32_t* ref_slot;
-  const int32_t* cur_slot;
-  const int32_t* n;
-  int n_stride;
-  const double* px;
-  const double* xyz;
-  const uint8_t* valid;
-  svo_hip_sia_params P;
-  const double* T_in;
-  double* T_out;
-  double* H_out;
-  int32_t* n_tracked;
-  int32_t* iters;
-  double* chi2;
-  int32_t* status;
-};
-
-// bytes [x0, x0+4] of a row (x0 = first column, any alignment) as floats
-__device__ __forceinline__ void load_row5(const uint8_t* __restrict__ row, int x0, float out[5]) {
-  const int xa = x0 & ~3;
-  const uint32_t sel = (uint32_t)(x0 & 3);
-  const uint32_t* p = reinterpret_cast<const uint32_t*>(row + xa);
-  const uint32_t d0 = p[0], d1 = p[1];
-  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sel);  // bytes x0..x0+3
-  const uint32_t hi = d1 >> (8 * sel);                          // byte x0+4 in bits 0..7
-  out[0] = (float)(lo & 0xffu);
-  out[1] = (float)((lo >> 8) & 0xffu);
-  out[2] = (float)((lo >> 16) & 0xffu);
-  out[3] = (float)(lo >> 24);
-  out[4] = (float)(hi & 0xffu);
-}
-
-// bytes [x0, x0+6] of a row as floats
-__device__ __forceinline__ void load_row7(const uint8_t* __restrict__ row, int x0, float out[7]) {
-  const int xa = x0 & ~3;
-  const uint32_t sel = (uint32_t)(x0 & 3);
-  const uint32_t* p = reinterpret_cast<const uint32_t*>(row + xa);
-  const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sel);  // bytes 0..3
-  const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sel);  // bytes 4..7
-  out[0] = (float)(lo & 0xffu);
-  out[1] = (float)((lo >> 8) & 0xffu);
-  out[2] = (float)((lo >> 16) & 0xffu);
-  out[3] = (float)(lo >> 24);
-  out[4] = (float)(hi & 0xffu);
-  out[5] = (float)((hi >> 8) & 0xffu);
-  out[6] = (float)((hi >> 16) & 0xffu);
-}
-
-// ---- window cache (template parameter WC) --------------------------------------------------------------
-// The 5x5 window of the current image moves by a fraction of a pixel per Gauss-Newton iteration,
-// yet re-fetching it every iteration misses L2 (128 resident problems per XCD x ~64 KB of touched
-// sectors) and puts an HBM round trip on the critical path of every iteration.  With the cache a
-// lane fetches 7 rows x 3 aligned dwords around the patch (49+ bytes, once) and later iterations
-// cut their 5x5 window out of those 21 registers as long as the integer position stays within
-// +-1 row and the 12 cached columns; only then is nothing loaded at all.
-__device__ __forceinline__ void load_row12(const uint8_t* __restrict__ row, int xa, uint32_t d[3]) {
-  const uint32_t* p = reinterpret_cast<const uint32_t*>(row + xa);
-  d[0] = p[0]; d[1] = p[1]; d[2] = p[2];
-}
-// bytes [bo, bo+4] (bo in 0..7) of three consecutive dwords as floats
-__device__ __forceinline__ void cut_row5(uint32_t a, uint32_t b, uint32_t c, int bo, float out[5]) {
-  const bool up = bo >= 4;
-  const uint32_t d0 = up ? b : a, d1 = up ? c : b;
-  const uint32_t sel = (uint32_t)(bo & 3);
-  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sel);
-  const uint32_t hi = d1 >> (8 * sel);
-  out[0] = (float)(lo & 0xffu);
-  out[1] = (float)((lo >> 8) & 0xffu);
-  out[2] = (float)((lo >> 16) & 0xffu);
-  out[3] = (float)(lo >> 24);
-  out[4] = (float)(hi & 0xffu);
-}
-
-// Waves per SIMD asked of the register allocator.  Without the window cache the kernel fits 128
-// VGPRs (4 waves/SIMD); asking for 4 outright makes the allocator spill 3 dwords to scratch
-// (-9 % measured), asking for 3 yields the same 128 registers without spills.  With the window
-// cache (+21 registers) it settles at 168 VGPRs = 3 waves/SIMD, still faster for 256/512-lane
-// workgroups; a 1024-lane workgroup needs 4 waves per SIMD just to be resident.
+// Waves per SIMD asked of the register allocator.  With the Jacobian products kept inside the iteration
+// loop (see the opaque copies in the H rebuild) and the Gauss-Jordan rebuild the 256-lane instantiation
+// fits 128 VGPRs = 4 waves per SIMD WITH the window cache, i.e. four frames per CU instead of three
+// (1.40 against 1.50 ms on the headline batch); one 8-byte value is spilled once per level.  64/128-lane
+// workgroups are not limited by registers.
 #ifndef MINW
-#define MINW(BLOCK) ((BLOCK) >= 1024 ? 4 : 3)
-#endif
-
-// SIA_SGPR_POSE: the pose published by the solver wave is wave-uniform; reading it back through
-// v_readfirstlane keeps its 24 dwords in SGPRs instead of VGPRs
-__device__ __forceinline__ double sia_uni(double v) {
-  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-#ifdef SIA_SGPR_POSE
-#define SIA_UNI(x) sia_uni(x)
-#else
-#define SIA_UNI(x) (x)
+#define MINW(BLOCK) ((BLOCK) >= 256 ? 4 : 3)
 #endif
 
 // SIA_PROFILE: per-phase shader-clock totals of wave 0 of every workgroup, written over H_out[b][0..7]
@@ -171,6 +78,7 @@ struct SiaLds {
   double Hinv[36];               // its inverse, row-major
   double A[36];                  // Gauss-Jordan scratch
   float part[2][MAX_WAVES][8];   // per-wave partials of Jres[6], chi2, n_meas (double-buffered)
+  int chg[2][MAX_WAVES];         // per wave: some patch entered or left the current image (same buffering)
   float Hpart[MAX_WAVES][24];    // per-wave partials of H (21 used)
   long long lo[SVO_HIP_MAX_LEVELS];  // pyramid geometry per level (copied from the kernel
   int lw[SVO_HIP_MAX_LEVELS];        // arguments so the level loop can index it dynamically)
@@ -179,10 +87,6 @@ struct SiaLds {
 };
 __shared__ SiaLds g_s;
 
-__device__ __forceinline__ int sym6_rt(int i, int j) {
-  const int a = i < j ? i : j, b = i < j ? j : i;
-  return a * 6 - (a * (a - 1)) / 2 + (b - a);
-}
 
 // H = sum of the per-wave partials, then H^-1 by Gauss-Jordan on a 6x6 tile held one
 // element per lane (36 lanes), LDS as the row/column exchange.  Wave 0 only; runs
@@ -381,10 +285,13 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
         vis = true;
         gmask = 1.f;
         const float su = u_ref - (float)u_i, sv = v_ref - (float)v_i;
-        const float wtl = (float)((1.0 - su) * (1.0 - sv));
-        const float wtr = (float)(su * (1.0 - sv));
-        const float wbl = (float)((1.0 - su) * sv);
-        const float wbr = (float)((double)su * (double)sv);
+        // The reference forms these products in double and rounds to float (:118-121).  u >= 3 here, so su
+        // and sv are multiples of 2^-22: 1-su and 1-sv are exact in f32, and the f32 product of two f32
+        // values is the correctly rounded exact product, like the rounded double product -- bit-identical.
+        const float wtl = (1.f - su) * (1.f - sv);
+        const float wtr = su * (1.f - sv);
+        const float wbl = (1.f - su) * sv;
+        const float wbr = su * sv;
         float Bt[6][6];
         float Wp[7], Wc[7];
         load_row7(ref_img + (int64_t)(v_i - 3) * pitch, u_i - 3, Wp);
@@ -486,10 +393,11 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
           m = true;
           const int u_i = (int)fu, v_i = (int)fv;
           const float su = u_cur - fu, sv = v_cur - fv;
-          const float wtl = (float)((1.0 - su) * (1.0 - sv));
-          const float wtr = (float)(su * (1.0 - sv));
-          const float wbl = (float)((1.0 - su) * sv);
-          const float wbr = (float)((double)su * (double)sv);
+          const float wtl = (1.f - su) * (1.f - sv);  // == the reference's rounded double products (:200-203), see above
+          const float wtr = su * (1.f - sv);
+          const float wbl = (1.f - su) * sv;
+          const float wbr = su * sv;
+          {
           float W[5][5];
 #ifdef SIA_DBG_NOLOAD
 #pragma unroll
@@ -508,13 +416,15 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
               r0 = 1;
               bo = (u_i - 2) - wc_u0;
             }
+            const uint64_t k0 = __builtin_amdgcn_ballot_w64(r0 == 0), k1 = __builtin_amdgcn_ballot_w64(r0 == 1);
+            const uint64_t kup = __builtin_amdgcn_ballot_w64(bo >= 4);
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
               constexpr int S = WC ? 1 : 0;  // keeps the indices in range when the cache is compiled out
-              const uint32_t d0 = r0 == 0 ? wc[r * S][0] : (r0 == 1 ? wc[(r + 1) * S][0] : wc[(r + 2) * S][0]);
-              const uint32_t d1 = r0 == 0 ? wc[r * S][1] : (r0 == 1 ? wc[(r + 1) * S][1] : wc[(r + 2) * S][1]);
-              const uint32_t d2 = r0 == 0 ? wc[r * S][2] : (r0 == 1 ? wc[(r + 1) * S][2] : wc[(r + 2) * S][2]);
-              cut_row5(d0, d1, d2, bo, W[r]);
+              const uint32_t d0 = sel_e64(k0, wc[r * S][0], sel_e64(k1, wc[(r + 1) * S][0], wc[(r + 2) * S][0]));
+              const uint32_t d1 = sel_e64(k0, wc[r * S][1], sel_e64(k1, wc[(r + 1) * S][1], wc[(r + 2) * S][1]));
+              const uint32_t d2 = sel_e64(k0, wc[r * S][2], sel_e64(k1, wc[(r + 1) * S][2], wc[(r + 2) * S][2]));
+              cut_row5(d0, d1, d2, bo, kup, W[r]);
             }
           } else {
 #pragma unroll
@@ -545,6 +455,7 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
               gx += res * (Bt[y + 1][x + 2] - Bt[y + 1][x]);
               gy += res * (Bt[y + 2][x + 1] - Bt[y][x + 1]);
             }
+          }
         }
       }
       // -- workgroup reduction of Jres, chi2, n_meas ------------------------
@@ -554,30 +465,47 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
         const float gsc = 0.5f * fl * gmask;
         const float gxf = m ? gx * gsc : 0.f, gyf = m ? gy * gsc : 0.f;
         float part[8];
-        part[0] = zi * gxf;
-        part[1] = zi * gyf;
-        part[2] = -zi * (xn * gxf + yn * gyf);
-        part[3] = -(xn * yn * gxf + (1.f + yn * yn) * gyf);
-        part[4] = (1.f + xn * xn) * gxf + xn * yn * gyf;
-        part[5] = xn * gyf - yn * gxf;
+        float zi_ = zi, xn_ = xn, yn_ = yn;  // opaque, as in the H rebuild below: keeps xn*yn, 1+xn^2, ... inside the loop
+#ifndef SIA_ALLOW_HOIST
+        asm volatile("" : "+v"(zi_), "+v"(xn_), "+v"(yn_));
+#endif
+        part[0] = zi_ * gxf;
+        part[1] = zi_ * gyf;
+        part[2] = -zi_ * (xn_ * gxf + yn_ * gyf);
+        part[3] = -(xn_ * yn_ * gxf + (1.f + yn_ * yn_) * gyf);
+        part[4] = (1.f + xn_ * xn_) * gxf + xn_ * yn_ * gyf;
+        part[5] = xn_ * gyf - yn_ * gxf;
         part[6] = c2;
         part[7] = m ? 16.f : 0.f;
         const long long tp1 = SIA_T();
         SIA_ACC(0, tp0, tp1);
         const float tot = wave_reduce8(part, lane);
         if ((lane & 7) == 0) g_s.part[buf][wave][lane >> 3] = tot;
+        // "did the set of patches inside the current image change" travels with the partials: one barrier,
+        // where __syncthreads_or costs three and an LDS atomic
+        const int mine = __builtin_amdgcn_ballot_w64((int)m != inH) != 0ull;
+        if (lane == 0) g_s.chg[buf][wave] = mine;
         SIA_ACC(1, tp1, SIA_T());
       }
       // the one workgroup barrier of an iteration
       const long long tb0 = SIA_T();
-      const int changed = __syncthreads_or((int)m != inH);
+      __syncthreads();
+      int changed = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) changed |= g_s.chg[buf][w];
       const long long tb1 = SIA_T();
       SIA_ACC(2, tb0, tb1);
       if (changed) {
         // the set of patches inside the current image changed: rebuild H.
         // H += J J' summed over the patch = Sxx aa' + Sxy (ab'+ba') + Syy bb'
-        const float ja[6] = {-zi * fl, 0.f, xn * zi * fl, xn * yn * fl, -(1.f + xn * xn) * fl, yn * fl};
-        const float jb[6] = {0.f, -zi * fl, yn * zi * fl, (1.f + yn * yn) * fl, -xn * yn * fl, -xn * fl};
+        // (opaque copies: otherwise the ~60 products below, all invariant in the iteration loop, are hoisted
+        // out of it and stay live across it -- 35 VGPRs, the difference between 3 and 4 waves per SIMD)
+        float zi_ = zi, xn_ = xn, yn_ = yn;
+#ifndef SIA_ALLOW_HOIST
+        asm volatile("" : "+v"(zi_), "+v"(xn_), "+v"(yn_));
+#endif
+        const float ja[6] = {-zi_ * fl, 0.f, xn_ * zi_ * fl, xn_ * yn_ * fl, -(1.f + xn_ * xn_) * fl, yn_ * fl};
+        const float jb[6] = {0.f, -zi_ * fl, yn_ * zi_ * fl, (1.f + yn_ * yn_) * fl, -xn_ * yn_ * fl, -xn_ * fl};
         float hp[24];
 #pragma unroll
         for (int i = 0; i < 6; ++i)
@@ -594,7 +522,7 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
         }
         inH = (int)m;
         __syncthreads();
-#ifdef SIA_GAUSS_JORDAN
+#ifndef SIA_LDLT_REBUILD
         if (wave == 0) sia_rebuild_hinv(lane, NW);
         __syncthreads();
 #else
@@ -756,13 +684,13 @@ int launch(const SiaArgs& args, int B, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int svo_hip_sparse_align(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int B,
-                                    const int32_t* d_ref_slot, const int32_t* d_cur_slot, const int32_t* d_n,
-                                    int n_stride, const double* d_px, const double* d_xyz_ref,
-                                    const uint8_t* d_valid, const svo_hip_sia_params* params,
-                                    const double* d_T_in, double* d_T_out, double* d_H_out,
-                                    int32_t* d_n_tracked, int32_t* d_iters, double* d_chi2, int32_t* d_status,
-                                    void* stream) {
+namespace {
+
+// validates the arguments of the two entry points and fills the kernels' argument block
+int sia_prepare(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int B, const int32_t* d_ref_slot,
+                const int32_t* d_cur_slot, const int32_t* d_n, int n_stride, const double* d_px, const double* d_xyz_ref,
+                const uint8_t* d_valid, const svo_hip_sia_params* params, const double* d_T_in, double* d_T_out,
+                double* d_H_out, int32_t* d_n_tracked, int32_t* d_iters, double* d_chi2, int32_t* d_status, SiaArgs* out) {
   if (!layout_ok(layout) || !d_store || !params || B < 0) return SVO_HIP_EINVAL;
   if (B == 0) return SVO_HIP_OK;
   if (!d_ref_slot || !d_cur_slot || !d_n || !d_px || !d_xyz_ref || !d_T_in || !d_T_out || !d_n_tracked)
@@ -775,7 +703,7 @@ extern "C" int svo_hip_sparse_align(const svo_hip_pyr_layout* layout, const uint
   if (params->cam_model != SVO_HIP_CAM_PINHOLE && params->cam_model != SVO_HIP_CAM_PINHOLE_RADTAN &&
       params->cam_model != SVO_HIP_CAM_ATAN)
     return SVO_HIP_EINVAL;
-  SiaArgs args;
+  SiaArgs& args = *out;
   args.L = *layout;
   args.store = d_store;
   args.ref_slot = d_ref_slot;
@@ -793,10 +721,48 @@ extern "C" int svo_hip_sparse_align(const svo_hip_pyr_layout* layout, const uint
   args.iters = d_iters;
   args.chi2 = d_chi2;
   args.status = d_status;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (n_stride <= 64) return launch<64>(args, B, s);
-  if (n_stride <= 128) return launch<128>(args, B, s);
-  if (n_stride <= 256) return launch<256>(args, B, s);
-  if (n_stride <= 512) return launch<512>(args, B, s);
+  return 1;  // launch
+}
+
+int launch_workgroup(const SiaArgs& args, int B, hipStream_t s) {
+  if (args.n_stride <= 64) return launch<64>(args, B, s);
+  if (args.n_stride <= 128) return launch<128>(args, B, s);
+  if (args.n_stride <= 256) return launch<256>(args, B, s);
+  if (args.n_stride <= 512) return launch<512>(args, B, s);
   return launch<1024>(args, B, s);
+}
+
+}  // namespace
+
+extern "C" int svo_hip_sparse_align(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int B,
+                                    const int32_t* d_ref_slot, const int32_t* d_cur_slot, const int32_t* d_n,
+                                    int n_stride, const double* d_px, const double* d_xyz_ref,
+                                    const uint8_t* d_valid, const svo_hip_sia_params* params,
+                                    const double* d_T_in, double* d_T_out, double* d_H_out,
+                                    int32_t* d_n_tracked, int32_t* d_iters, double* d_chi2, int32_t* d_status,
+                                    void* stream) {
+  SiaArgs args;
+  const int rc = sia_prepare(layout, d_store, B, d_ref_slot, d_cur_slot, d_n, n_stride, d_px, d_xyz_ref, d_valid, params,
+                             d_T_in, d_T_out, d_H_out, d_n_tracked, d_iters, d_chi2, d_status, &args);
+  if (rc <= 0) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // large batches of frames with up to 192 patches: one wave per frame (sparse_align_wave.hip); else one workgroup
+  if (sia_wave_applies(args, B)) return launch_sia_wave(args, B, s);
+  return launch_workgroup(args, B, s);
+}
+
+// The workgroup-per-frame kernel for any patch count: the path svo_hip_sparse_align takes above 256 patches
+// per frame, exposed so that tests and the bench can run both kernels on the same problems.
+extern "C" int svo_hip_sparse_align_workgroup(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int B,
+                                              const int32_t* d_ref_slot, const int32_t* d_cur_slot, const int32_t* d_n,
+                                              int n_stride, const double* d_px, const double* d_xyz_ref,
+                                              const uint8_t* d_valid, const svo_hip_sia_params* params,
+                                              const double* d_T_in, double* d_T_out, double* d_H_out,
+                                              int32_t* d_n_tracked, int32_t* d_iters, double* d_chi2,
+                                              int32_t* d_status, void* stream) {
+  SiaArgs args;
+  const int rc = sia_prepare(layout, d_store, B, d_ref_slot, d_cur_slot, d_n, n_stride, d_px, d_xyz_ref, d_valid, params,
+                             d_T_in, d_T_out, d_H_out, d_n_tracked, d_iters, d_chi2, d_status, &args);
+  if (rc <= 0) return rc;
+  return launch_workgroup(args, B, static_cast<hipStream_t>(stream));
 }

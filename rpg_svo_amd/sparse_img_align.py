@@ -52,6 +52,9 @@ class SparseImgAlign:
         self.eps = 0.000001  # sparse_img_align.cpp:40
         self.verbose = verbose
         self.lib = capi.load()
+        # "auto": svo_hip_sparse_align picks the kernel (one wave per frame up to 256 patches, one workgroup
+        # per frame beyond); "workgroup": the workgroup-per-frame kernel for any patch count
+        self.kernel = "auto"
 
     def params(self, cam) -> capi.SiaParams:
         d = tuple(getattr(cam, "d", (0.0,) * 5))
@@ -79,7 +82,10 @@ class SparseImgAlign:
         if out is None:
             out = self.alloc_result(B, dev)
         P = self.params(cam)
-        capi.check(self.lib.svo_hip_sparse_align(
+        if self.kernel not in ("auto", "workgroup"):
+            raise ValueError("SparseImgAlign.kernel must be 'auto' or 'workgroup'")
+        entry = self.lib.svo_hip_sparse_align if self.kernel == "auto" else self.lib.svo_hip_sparse_align_workgroup
+        capi.check(entry(
             C.byref(store.layout), store.ptr, B, ref_slot.data_ptr(), cur_slot.data_ptr(), n.data_ptr(), ns,
             px.data_ptr(), xyz_ref.data_ptr(), valid.data_ptr() if valid is not None else None, C.byref(P),
             T_cur_from_ref.data_ptr(), out.T_cur_from_ref.data_ptr(), out.H.data_ptr(), out.n_tracked.data_ptr(),

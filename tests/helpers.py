@@ -49,7 +49,18 @@ def run_oracle(oracle, b: Batch, max_level, min_level, n_iter=30, halfsample=Non
     return T, res, pyrs
 
 
-def run_hip(b: Batch, max_level, min_level, n_iter=30, device="cuda:0", halfsample=None):
+def tile_batch(b: Batch, times: int) -> Batch:
+    """The same problems `times` over (large-batch paths: svo_hip_sparse_align switches kernel with B)."""
+    import copy
+    t = copy.copy(b)
+    t.B = b.B * times
+    for k in ("ref_slot", "cur_slot", "T_ref_w", "T_gt_w", "T_cur_w", "px", "f", "pos", "n", "has_point"):
+        a = getattr(b, k)
+        setattr(t, k, np.concatenate([a] * times, axis=0))
+    return t
+
+
+def run_hip(b: Batch, max_level, min_level, n_iter=30, device="cuda:0", halfsample=None, kernel="auto"):
     from rpg_svo_amd import capi
     from rpg_svo_amd.pyramid import PyramidStore
     from rpg_svo_amd.sparse_img_align import SparseImgAlign
@@ -60,6 +71,7 @@ def run_hip(b: Batch, max_level, min_level, n_iter=30, device="cuda:0", halfsamp
     dev = torch.device(device)
     t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
     sia = SparseImgAlign(max_level, min_level, n_iter)
+    sia.kernel = kernel
     out = sia.run(store, b.cam, t(b.ref_slot, torch.int32), t(b.cur_slot, torch.int32), t(b.n, torch.int32),
                   t(b.px, torch.float64), t(xyz, torch.float64), t(T_cr, torch.float64),
                   valid=t(b.has_point, torch.uint8))

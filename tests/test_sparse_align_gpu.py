@@ -15,7 +15,7 @@ import torch
 
 from rpg_svo_amd import se3, synth
 
-from helpers import camera_models, make_batch, run_hip, run_oracle
+from helpers import camera_models, make_batch, run_hip, run_oracle, tile_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -205,3 +205,40 @@ def test_distorted_camera_models(oracle, gpu_device, checker, kind):
     d, same, T_o, T_h, *_ = compare(oracle, b, 3, 0, which=checker)
     assert np.median(d) <= TOL_MEDIAN
     assert se3.log_norm(T_h, b.T_gt_w).max() < 1e-3   # both solved the problem
+
+
+@pytest.mark.parametrize("n_patches", [60, 120, 190])
+def test_wave_per_frame_kernel(oracle, gpu_device, checker, n_patches):
+    """Batches of >= 1024 problems with <= 192 patches run one wave per frame (sparse_align_wave.hip; 1, 2 and
+    3 patches per lane here): same tolerances against the checker as the workgroup kernel, and the two kernels
+    agree with each other on the same problems."""
+    seq = synth.make_sequence(33, n_patches, seed=23)
+    pairs = [(i, i + 1) for i in range(32)]
+    b = make_batch(seq, pairs, 4)
+    # ragged counts and missing points in a few problems
+    b.n[3] = n_patches - 7
+    b.n[9] = 1
+    b.has_point[5, ::3] = 0
+    T_o, res_o, _ = run_oracle(oracle, b, 3, 0, 30, which=checker)
+    big = tile_batch(b, 32)  # B = 1024
+    T_w, out_w, _ = run_hip(big, 3, 0, 30, kernel="auto")
+    T_g, out_g, _ = run_hip(big, 3, 0, 30, kernel="workgroup")
+    assert np.all(np.isfinite(T_w))
+    # every copy of a problem gives the same result (no cross-talk between the waves sharing a CU)
+    assert np.array_equal(T_w.reshape(32, 32, 12), np.broadcast_to(T_w[:32], (32, 32, 12)))
+    d = se3.log_norm(T_w[:32], T_o)
+    assert d.max() <= TOL, f"max SE3 log-norm {d.max():.3e} (argmax {d.argmax()})"
+    assert np.median(d) <= TOL_MEDIAN
+    it_o = np.array([r["iters"] for r in res_o])
+    it_w = out_w.iters.cpu().numpy()[:32]
+    same = np.all(it_o == it_w, axis=1)
+    assert same.mean() >= 0.75
+    ntr_o = np.array([r["n_tracked"] for r in res_o])
+    assert np.array_equal(out_w.n_tracked.cpu().numpy()[:32][same], ntr_o[same])
+    assert np.array_equal(out_w.status.cpu().numpy()[:32], np.array([r["stop"] for r in res_o]))
+    # the two kernels: identical per-patch arithmetic, different summation order
+    dk = se3.log_norm(T_w[:32], T_g[:32])
+    assert dk.max() <= TOL and np.median(dk) <= TOL_MEDIAN
+    Hw = out_w.H.cpu().numpy().reshape(-1, 36)[:32][same]
+    Ho = np.stack([r["H"] for r in res_o]).reshape(-1, 36)[same]
+    assert np.allclose(Hw, Ho, rtol=2e-5, atol=1e-3 * np.abs(Ho).max())
