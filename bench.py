@@ -156,9 +156,11 @@ class Workload:
     """Synthetic replay sequence of B+1 frames on one GPU: problem b = (frame b -> frame b+1)."""
 
     def __init__(self, name: str, B: int, dev, rank: int = 0, noise: float = 0.0, images: torch.Tensor | None = None,
-                 T_gt: np.ndarray | None = None):
+                 T_gt: np.ndarray | None = None, n_patches: int | None = None):
         (self.width, self.height, self.focal, self.n_levels, self.max_level, self.min_level, self.n_patches,
          margin, cell) = WORKLOADS[name]
+        if n_patches is not None:  # side measurements only (config3_leg's latency floor), never the headline
+            self.n_patches = n_patches
         if os.environ.get("SVO_BENCH_PATCHES"):  # kernel experiments only (scripts/): NOT the configuration the metric names
             self.n_patches = int(os.environ["SVO_BENCH_PATCHES"])
         self.name, self.B, self.dev, self.noise = name, B, dev, noise
@@ -609,17 +611,30 @@ def noise_leg(W: Workload, sia, ev: Events, dev, rank: int, steps: int) -> dict:
 
 
 def config3_leg(ev: Events, dev, rank: int, n_iter: int) -> dict:
-    """BASELINE configs[3]: 1280x960, 5 levels (4 -> 0), 1000 patches, 64 frames at once."""
-    W = Workload("xga5_n1000_sparse_align", 64, dev, rank + 7)
-    sia = SparseImgAlign(W.max_level, W.min_level, n_iter)
-    out = sia.alloc_result(W.B, dev)
-    ms = ev.time(lambda: W.run_align(sia, out=out), 20, warmup=3)
-    torch.cuda.synchronize()
-    st = W.align_stats(out)
+    """BASELINE configs[3]: 1280x960, 5 levels (4 -> 0), 1000 patches, 64 frames at once -- plus the two
+    numbers that say what bounds it: the same frames at a batch that fills the GPU, and the latency floor of
+    a 4-way split of a frame over workgroups (a 250-patch frame alone on a CU)."""
+    def run(B, n_patches=None, reps=20):
+        W = Workload("xga5_n1000_sparse_align", B, dev, rank + 7, n_patches=n_patches)
+        sia = SparseImgAlign(W.max_level, W.min_level, n_iter)
+        out = sia.alloc_result(W.B, dev)
+        ms = ev.time(lambda: W.run_align(sia, out=out), reps, warmup=3)
+        torch.cuda.synchronize()
+        return ms, W.align_stats(out)
+    ms, st = run(64)
+    ms_big, st_big = run(1024, reps=10)
+    ms_q, st_q = run(64, n_patches=250)
     return {"workload": "xga5_n1000_sparse_align", "frames_per_step": 64, "frames_per_s": 64 / ms * 1e3, "ms_per_step": ms,
             "mean_gn_iterations_per_frame": float(st["iters"].sum(1).mean()), "mean_tracked_patches": float(st["n_tracked"].mean()),
             "median_pose_error_vs_gt": float(np.median(st["gt_err"])),
-            "roofline": roofline("sia_kernel", st["alg_bytes"], ms)}
+            "roofline": roofline("sia_kernel", st["alg_bytes"], ms),
+            # 64 frames occupy 64 of 256 CUs: the step time is the latency of ONE frame's alignment
+            "frames_per_s_at_batch_1024": 1024 / ms_big * 1e3, "ms_per_step_at_batch_1024": ms_big,
+            "roofline_at_batch_1024": roofline("sia_kernel", st_big["alg_bytes"], ms_big),
+            # VERDICT r01 item 8 proposed splitting a frame over 4 workgroups with a global exchange of the sums:
+            # a quarter of the patches per workgroup is this measurement, BEFORE any exchange cost
+            "split4_latency_floor": {"patches_per_workgroup": 250, "ms_per_step": ms_q, "frames_per_s_upper_bound": 64 / ms_q * 1e3,
+                                     "mean_gn_iterations_per_frame": float(st_q["iters"].sum(1).mean())}}
 
 
 def line_floor_bytes(W: Workload, n_sample: int = 64) -> float:

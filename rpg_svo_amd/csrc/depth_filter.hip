@@ -274,49 +274,75 @@ __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) 
   const int sumA = (int)sumA_u, sumAA = (int)sumAA_u;
   const double step0 = w.step[2 * s], step1 = w.step[2 * s + 1];
   double uv0 = w.B[2 * s] - step0, uv1 = w.B[2 * s + 1] - step1;
-  int last_x = 0, last_y = 0;
   const int n_total = w.n_steps[s] + 1;
   int best = ZMSSD_THRESHOLD;
   int best_i = 0x7fffffff;
   double best_uv0 = 0, best_uv1 = 0;
   const double lvl = (double)(1 << sl);
-  // every lane replays this loop for all steps: keep it lean.  Dividing by 2^level is exact,
-  // so multiplying by 2^-level gives the same bits without two f64 division sequences per step
+  // Dividing by 2^level is exact, so multiplying by 2^-level gives the same bits without f64 division sequences.
   const double inv_lvl = 1.0 / lvl;
-  for (int i = 0; i < n_total; ++i, uv0 += step0, uv1 += step1) {
-    double pxs[2];
-    {
-      const double uvs[2] = {uv0, uv1};
-      world2cam_uv(a.cam, uvs, pxs);  // cur_frame.cam_->world2cam(uv), matcher.cpp:269
+  // The reference walks the line sequentially (matcher.cpp:268: uv += step, in f64) and skips a step whose
+  // integer pixel equals the previous step's.  Lane l takes the steps l, l+64, ...: it replays only the CHAIN of
+  // additions up to its step (two v_add_f64 per step, so the positions carry the reference's rounding), keeps the
+  // position of the step before, and does the expensive part -- camera model, rounding, the 8x8 ZMSSD -- for its
+  // own steps only, all 64 lanes at once.  "Same pixel as the last step looked at" is "same pixel as step i-1":
+  // last_x/last_y are overwritten by every step that differs from them, so they always hold step i-1's pixel.
+  double pv0 = 0, pv1 = 0;  // position of step i-1
+  {
+    const int lead = lane < n_total ? lane : n_total;
+    for (int j = 0; j < lead; ++j) {
+      pv0 = uv0; pv1 = uv1;
+      uv0 += step0; uv1 += step1;
     }
-    const double px0 = pxs[0], px1 = pxs[1];
-    const int pxi0 = cast_int(px0 * inv_lvl + 0.5);
-    const int pxi1 = cast_int(px1 * inv_lvl + 0.5);
-    if (pxi0 == last_x && pxi1 == last_y) continue;
-    last_x = pxi0;
-    last_y = pxi1;
-    if ((i & 63) != lane) continue;
-    if (!is_in_frame_level(a.cam, pxi0, pxi1, 8, sl)) continue;
-    const uint8_t* cp = img + (int64_t)(pxi1 - 4) * pitch;
-    uint32_t sumB = 0, sumBB = 0, sumAB = 0;
+  }
+  for (int base = 0; base < n_total; base += 64) {
+    const int i = base + lane;
+    if (i < n_total) {
+      double pxs[2];
+      {
+        const double uvs[2] = {uv0, uv1};
+        world2cam_uv(a.cam, uvs, pxs);  // cur_frame.cam_->world2cam(uv), matcher.cpp:269
+      }
+      const int pxi0 = cast_int(pxs[0] * inv_lvl + 0.5);
+      const int pxi1 = cast_int(pxs[1] * inv_lvl + 0.5);
+      int prv0 = 0, prv1 = 0;  // last_x, last_y before the first step
+      if (i > 0) {
+        double pps[2];
+        const double pvs[2] = {pv0, pv1};
+        world2cam_uv(a.cam, pvs, pps);
+        prv0 = cast_int(pps[0] * inv_lvl + 0.5);
+        prv1 = cast_int(pps[1] * inv_lvl + 0.5);
+      }
+      if (!(pxi0 == prv0 && pxi1 == prv1) && is_in_frame_level(a.cam, pxi0, pxi1, 8, sl)) {
+        const uint8_t* cp = img + (int64_t)(pxi1 - 4) * pitch;
+        uint32_t sumB = 0, sumBB = 0, sumAB = 0;
 #pragma unroll
-    for (int y = 0; y < 8; ++y) {
-      uint32_t lo, hi;
-      load_row8(cp + (int64_t)y * pitch, pxi0 - 4, lo, hi);
-      sumB = __builtin_amdgcn_udot4(lo, 0x01010101u, sumB, false);
-      sumB = __builtin_amdgcn_udot4(hi, 0x01010101u, sumB, false);
-      sumBB = __builtin_amdgcn_udot4(lo, lo, sumBB, false);
-      sumBB = __builtin_amdgcn_udot4(hi, hi, sumBB, false);
-      sumAB = __builtin_amdgcn_udot4(lo, ra[2 * y], sumAB, false);
-      sumAB = __builtin_amdgcn_udot4(hi, ra[2 * y + 1], sumAB, false);
+        for (int y = 0; y < 8; ++y) {
+          uint32_t lo, hi;
+          load_row8(cp + (int64_t)y * pitch, pxi0 - 4, lo, hi);
+          sumB = __builtin_amdgcn_udot4(lo, 0x01010101u, sumB, false);
+          sumB = __builtin_amdgcn_udot4(hi, 0x01010101u, sumB, false);
+          sumBB = __builtin_amdgcn_udot4(lo, lo, sumBB, false);
+          sumBB = __builtin_amdgcn_udot4(hi, hi, sumBB, false);
+          sumAB = __builtin_amdgcn_udot4(lo, ra[2 * y], sumAB, false);
+          sumAB = __builtin_amdgcn_udot4(hi, ra[2 * y + 1], sumAB, false);
+        }
+        const int sB = (int)sumB, sBB = (int)sumBB, sAB = (int)sumAB;
+        const int zmssd = sumAA - 2 * sAB + sBB - (sumA * sumA - 2 * sumA * sB + sB * sB) / 64;
+        if (zmssd < best) {  // the lane's steps come in increasing order: keeps its first minimum
+          best = zmssd;
+          best_i = i;
+          best_uv0 = uv0;
+          best_uv1 = uv1;
+        }
+      }
     }
-    const int sB = (int)sumB, sBB = (int)sumBB, sAB = (int)sumAB;
-    const int zmssd = sumAA - 2 * sAB + sBB - (sumA * sumA - 2 * sumA * sB + sB * sB) / 64;
-    if (zmssd < best) {
-      best = zmssd;
-      best_i = i;
-      best_uv0 = uv0;
-      best_uv1 = uv1;
+    if (base + 64 < n_total) {  // on to this lane's next step: 64 more additions
+      for (int j = 0; j < 63; ++j) {
+        uv0 += step0; uv1 += step1;
+      }
+      pv0 = uv0; pv1 = uv1;
+      uv0 += step0; uv1 += step1;
     }
   }
   // first strictly smaller score along the line == lexicographic minimum of (score, step)

@@ -25,6 +25,20 @@ namespace {
 // byte i (compile-time) of the 100-byte template held in 25 dwords
 #define PWB(i) ((int)((g[(i) >> 2] >> (8 * ((i)&3))) & 0xffu))
 
+// ALIGN_REMAT_TEMPLATE keeps the byte extractions and the template gradients derived from g[] inside the
+// iteration that uses them (the compiler otherwise hoists them out of the loop as 192 floats: 255 VGPRs, 2 waves
+// per SIMD).  Measured: 165 VGPRs / 3 waves per SIMD but +50 % instructions per iteration -- no faster (0.82 ms
+// either way on 3.3 M trials), so the hoisted form stays the default.  Emits no instruction.
+#ifdef ALIGN_REMAT_TEMPLATE
+#define ALIGN_OPAQUE_TEMPLATE(g)                                                                                   \
+  asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]), "+v"(g[7]),  \
+               "+v"(g[8]), "+v"(g[9]), "+v"(g[10]), "+v"(g[11]), "+v"(g[12]));                                        \
+  asm volatile("" : "+v"(g[13]), "+v"(g[14]), "+v"(g[15]), "+v"(g[16]), "+v"(g[17]), "+v"(g[18]), "+v"(g[19]),       \
+               "+v"(g[20]), "+v"(g[21]), "+v"(g[22]), "+v"(g[23]), "+v"(g[24]))
+#else
+#define ALIGN_OPAQUE_TEMPLATE(g)
+#endif
+
 // bytes [x0, x0+8] of an image row as floats (3 aligned dwords)
 __device__ __forceinline__ void load_row9(const uint8_t* __restrict__ row, int x0, float out[9]) {
   const int xa = x0 & ~3;
@@ -54,7 +68,7 @@ __device__ __forceinline__ int floor_int(float x) {
 
 // align2D, feature_alignment.cpp:149-277.  Returns converged; (u,v) in/out.
 __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, int cols, int rows, int pitch,
-                                             const uint32_t g[25], int n_iter, float& u, float& v, bool& wrote,
+                                             uint32_t g[25], int n_iter, float& u, float& v, bool& wrote,
                                              int& n_eval) {
   bool converged = false;
   wrote = true;
@@ -80,6 +94,7 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
   float mean_diff = 0;
   const float min_update_squared = (float)(0.03 * 0.03);
   for (int iter = 0; iter < n_iter; ++iter) {
+    ALIGN_OPAQUE_TEMPLATE(g);
     const int u_r = floor_int(u);
     const int v_r = floor_int(v);
     if (u_r < 4 || v_r < 4 || u_r >= cols - 4 || v_r >= rows - 4) break;
@@ -129,7 +144,7 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
 
 // align1D, feature_alignment.cpp:30-147
 __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, int cols, int rows, int pitch,
-                                             const uint32_t g[25], float dir0, float dir1, int n_iter, float& u,
+                                             uint32_t g[25], float dir0, float dir1, int n_iter, float& u,
                                              float& v, double& h_inv, bool& wrote, int& n_eval) {
   bool converged = false;
   wrote = true;
@@ -156,6 +171,7 @@ __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, in
   float chi2 = 0;
   float up0 = 0, up1 = 0;
   for (int iter = 0; iter < n_iter; ++iter) {
+    ALIGN_OPAQUE_TEMPLATE(g);
     const int u_r = floor_int(u);
     const int v_r = floor_int(v);
     if (u_r < 4 || v_r < 4 || u_r >= cols - 4 || v_r >= rows - 4) break;

@@ -213,7 +213,11 @@ __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
           const uint8_t* ptr = img + (int64_t)yi * pitch + xi;
           // two unaligned 16-bit loads (gfx950 global memory takes any alignment) instead of four bytes
           __builtin_memcpy(&top[y], ptr, 2);
+#ifdef WARP_DBG_HALF_LOADS  // timing experiment only (wrong pixels): how much of the kernel is the gathers?
+          bot[y] = top[y];
+#else
           __builtin_memcpy(&bot[y], ptr + pitch, 2);
+#endif
         }
 #pragma unroll
         for (int y = 0; y < 10; ++y) {

@@ -671,10 +671,15 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
   }
 }
 
+// smallest workgroup that carries the window cache
+#ifndef SIA_WC_MIN_BLOCK
+#define SIA_WC_MIN_BLOCK 256
+#endif
+
 template <int BLOCK>
 int launch(const SiaArgs& args, int B, hipStream_t s) {
   // window cache where the workgroup is large enough for the extra registers to pay (see MINW)
-  constexpr bool WC = (BLOCK == 256);  // 512 lanes: 168 VGPRs would leave one workgroup per CU
+  constexpr bool WC = (BLOCK >= SIA_WC_MIN_BLOCK);
   if (args.P.cam_model == SVO_HIP_CAM_PINHOLE)
     hipLaunchKernelGGL((sia_kernel<BLOCK, WC, false>), dim3(B), dim3(BLOCK), 0, s, args);
   else

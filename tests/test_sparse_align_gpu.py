@@ -217,7 +217,8 @@ def test_wave_per_frame_kernel(oracle, gpu_device, checker, n_patches):
     b = make_batch(seq, pairs, 4)
     # ragged counts and missing points in a few problems
     b.n[3] = n_patches - 7
-    b.n[9] = 1
+    b.n[9] = 8  # (fewer than three patches leave H singular: the kernels' unpivoted solve and Eigen's pivoted LDLT
+                # then disagree arbitrarily; the pipeline never aligns such a frame -- Config::qualityMinFts = 50)
     b.has_point[5, ::3] = 0
     T_o, res_o, _ = run_oracle(oracle, b, 3, 0, 30, which=checker)
     big = tile_batch(b, 32)  # B = 1024
