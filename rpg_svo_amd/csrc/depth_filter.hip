@@ -239,11 +239,20 @@ __device__ __forceinline__ void load_row8(const uint8_t* __restrict__ row, int x
 }
 
 constexpr int SCAN_BLOCK = 256;
+// Lanes per seed in the epipolar scan.  A line has a few tens of steps: with a whole wave per seed most
+// lanes had no step of their own, and every lane still replays the chain of additions.  8 lanes per seed
+// share the chain replay between eight seeds of a wave and keep the lanes busy (update_seeds on 3.3 M seeds:
+// 3.24 ms at 64 lanes per seed, 2.74 at 32, 2.47 at 16, 2.33 at 8).
+#ifndef SCAN_LANES
+#define SCAN_LANES 8
+#endif
+constexpr int SCAN_G = SCAN_LANES;
+static_assert(SCAN_G == 4 || SCAN_G == 8 || SCAN_G == 16 || SCAN_G == 32 || SCAN_G == 64, "SCAN_LANES");
 
 // ZMSSD scan, matcher.cpp:248-291.  One wave per seed.
 __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) {
-  const int s = blockIdx.x * (SCAN_BLOCK / 64) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * (SCAN_BLOCK / SCAN_G) + (threadIdx.x / SCAN_G);
+  const int lane = threadIdx.x & (SCAN_G - 1);  // lane within the seed's group
   if (s >= a.S) return;
   const SeedWs& w = a.ws;
   if (w.mode[s] != MODE_SCAN) return;
@@ -282,10 +291,10 @@ __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) 
   // Dividing by 2^level is exact, so multiplying by 2^-level gives the same bits without f64 division sequences.
   const double inv_lvl = 1.0 / lvl;
   // The reference walks the line sequentially (matcher.cpp:268: uv += step, in f64) and skips a step whose
-  // integer pixel equals the previous step's.  Lane l takes the steps l, l+64, ...: it replays only the CHAIN of
+  // integer pixel equals the previous step's.  Lane l of the seed's group takes the steps l, l+SCAN_G, ...: it replays only the CHAIN of
   // additions up to its step (two v_add_f64 per step, so the positions carry the reference's rounding), keeps the
   // position of the step before, and does the expensive part -- camera model, rounding, the 8x8 ZMSSD -- for its
-  // own steps only, all 64 lanes at once.  "Same pixel as the last step looked at" is "same pixel as step i-1":
+  // own steps only, all lanes of the group at once.  "Same pixel as the last step looked at" is "same pixel as step i-1":
   // last_x/last_y are overwritten by every step that differs from them, so they always hold step i-1's pixel.
   double pv0 = 0, pv1 = 0;  // position of step i-1
   {
@@ -295,7 +304,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) 
       uv0 += step0; uv1 += step1;
     }
   }
-  for (int base = 0; base < n_total; base += 64) {
+  for (int base = 0; base < n_total; base += SCAN_G) {
     const int i = base + lane;
     if (i < n_total) {
       double pxs[2];
@@ -337,8 +346,8 @@ __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) 
         }
       }
     }
-    if (base + 64 < n_total) {  // on to this lane's next step: 64 more additions
-      for (int j = 0; j < 63; ++j) {
+    if (base + SCAN_G < n_total) {  // on to this lane's next step: SCAN_G more additions
+      for (int j = 0; j < SCAN_G - 1; ++j) {
         uv0 += step0; uv1 += step1;
       }
       pv0 = uv0; pv1 = uv1;
@@ -348,7 +357,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) 
   // first strictly smaller score along the line == lexicographic minimum of (score, step)
   unsigned long long key = ((unsigned long long)(unsigned)best << 32) | (unsigned)best_i;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
+  for (int off = SCAN_G / 2; off > 0; off >>= 1) {  // within the seed's lane group
     const unsigned long long o = __shfl_xor(key, off, 64);
     key = o < key ? o : key;
   }
@@ -715,7 +724,7 @@ static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_sto
   wa.pwb = w.pwb;
   rc = launch_warp(wa, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(epi_scan_kernel, dim3((S + (SCAN_BLOCK / 64) - 1) / (SCAN_BLOCK / 64)), dim3(SCAN_BLOCK), 0, st, a);
+  hipLaunchKernelGGL(epi_scan_kernel, dim3((S + (SCAN_BLOCK / SCAN_G) - 1) / (SCAN_BLOCK / SCAN_G)), dim3(SCAN_BLOCK), 0, st, a);
   rc = check_launch();
   if (rc) return rc;
   AlignArgs al;
