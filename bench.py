@@ -47,6 +47,7 @@ from rpg_svo_amd.pyramid import PyramidStore  # noqa: E402
 from rpg_svo_amd.sparse_img_align import SparseImgAlign, marshal_problem  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+N_CU = 256
 N_SIMD = 1024          # 256 CUs x 4 SIMD-32
 CLOCK_GHZ = 2.4
 
@@ -687,7 +688,12 @@ def pmc_leg(args, kernel_ms: float) -> dict:
             "--extras", "none", "--pmc-child", "1", "--k1-kernel", args.k1_kernel]
     passes = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
               "sq": ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
-                     "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"]}
+                     "SQ_INSTS_VALU", "SQ_BUSY_CU_CYCLES"],
+              # the VALU instruction mix, priced below with the per-class issue costs of scripts/valu_ubench.hip
+              "mix": ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F64",
+                      "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32"],
+              "mix2": ["SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_INT64", "SQ_INSTS", "SQ_INSTS_SALU",
+                       "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_BRANCH"]}
     status, raw = {}, {}
     env = dict(os.environ, TMPDIR="/tmp")
     env.pop("SVO_BENCH_FORCE_DIST", None)
@@ -725,17 +731,33 @@ def pmc_leg(args, kernel_ms: float) -> dict:
         out["fetch_bytes_per_launch_raw_counter"] = raw["FETCH_SIZE"] * 1024.0
         out["write_bytes_per_launch"] = raw["WRITE_SIZE"] * 1024.0
     if "SQ_INSTS_VALU" in raw:
-        # a wave64 VALU instruction occupies its SIMD-32 for >= 2 cycles (f64: 4); counted as 2, so this
-        # is a LOWER bound of the issue utilisation
-        cycles_avail = N_SIMD * kernel_ms * 1e-3 * CLOCK_GHZ * 1e9
-        busy = raw["SQ_INSTS_VALU"] * 2.0
+        # SIMD cycles of the launch on THIS run's clock: SQ_BUSY_CU_CYCLES is summed over the CUs
+        cu_cycles = raw.get("SQ_BUSY_CU_CYCLES", 0.0) / N_CU if raw.get("SQ_BUSY_CU_CYCLES") else kernel_ms * 1e-3 * CLOCK_GHZ * 1e9
+        simd_cycles = N_SIMD * cu_cycles
+        n_valu = raw["SQ_INSTS_VALU"]
+        # issue cost per wave-instruction and SIMD with 4 waves resident, measured by scripts/valu_ubench.hip on
+        # this part (profiles/r02_valu_ubench.json): f32 add/mul/fma 2.4, f64 3.5, conversions 3.0, f32
+        # transcendentals 3.9, v_rcp_f64 & co 9.6, 32-bit integer/logic 2.5; whatever the class counters do not
+        # cover (moves, selects, DPP, lane reads) is priced at 3.0
+        cost = {"SQ_INSTS_VALU_ADD_F32": 2.4, "SQ_INSTS_VALU_MUL_F32": 2.4, "SQ_INSTS_VALU_FMA_F32": 2.4,
+                "SQ_INSTS_VALU_ADD_F64": 3.5, "SQ_INSTS_VALU_MUL_F64": 3.5, "SQ_INSTS_VALU_FMA_F64": 3.5,
+                "SQ_INSTS_VALU_CVT": 3.0, "SQ_INSTS_VALU_INT32": 2.5, "SQ_INSTS_VALU_INT64": 3.0,
+                "SQ_INSTS_VALU_TRANS_F32": 3.9, "SQ_INSTS_VALU_TRANS_F64": 9.6}
+        classified = sum(raw.get(k, 0.0) for k in cost)
+        busy_weighted = sum(raw.get(k, 0.0) * c for k, c in cost.items()) + max(n_valu - classified, 0.0) * 3.0
         wc = raw.get("SQ_WAVE_CYCLES")
-        out["roofline_valu"] = {"bound": "valu-issue", "kernel": "sia_kernel", "achieved": busy / cycles_avail, "peak": 1.0,
-                                "unit": "fraction of SIMD issue cycles (SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel time x 2.4 GHz))",
-                                "frac": busy / cycles_avail, "valu_instructions_per_launch": raw["SQ_INSTS_VALU"],
-                                "kernel_ms": kernel_ms,
-                                "wave_cycles_issuing_frac": raw.get("SQ_ACTIVE_INST_ANY", float("nan")) / wc if wc else None,
-                                "wave_cycles_waiting_frac": raw.get("SQ_WAIT_ANY", float("nan")) / wc if wc else None}
+        out["roofline_valu"] = {
+            "bound": "valu-issue", "kernel": "sia_kernel", "peak": 1.0,
+            "achieved": busy_weighted / simd_cycles, "frac": busy_weighted / simd_cycles,
+            "unit": "fraction of SIMD cycles the VALU is issuing: sum over instruction classes of (class count x measured issue cost) "
+                    "/ (1024 SIMDs x SQ_BUSY_CU_CYCLES/256)",
+            "lower_bound_2_cycles_per_instruction": n_valu * 2.0 / simd_cycles,
+            "valu_instructions_per_launch": n_valu, "classified_by_counters_frac": classified / n_valu if n_valu else None,
+            "simd_cycles_per_valu_instruction": simd_cycles / n_valu if n_valu else None,
+            "all_instructions_per_launch": raw.get("SQ_INSTS"), "cu_cycles_per_launch": cu_cycles, "kernel_ms": kernel_ms,
+            "wave_cycles_issuing_frac": raw.get("SQ_ACTIVE_INST_ANY", float("nan")) / wc if wc else None,
+            "wave_cycles_waiting_frac": raw.get("SQ_WAIT_ANY", float("nan")) / wc if wc else None,
+            "wave_cycles_at_waitcnt_frac": raw.get("SQ_WAIT_INST_ANY", float("nan")) / wc if wc else None}
     return out
 
 

@@ -27,7 +27,10 @@ SE3_LOGNORM_TOL = 1e-4   # per frame
 # tree- vs sequentially-summed chi2 can flip the reference's `new_chi2 > chi2` stop test, which leaves the
 # two runs ONE step apart for a frame (the later stages pull the pose back: median stays ~1e-8).
 SE3_LOGNORM_TOL_NOISY = 3e-4
-ATE_TOL_M = 1e-5         # Horn-aligned RMSE over the sequence, scene depth 2 m
+# Horn-aligned RMSE over the sequence, scene depth 2 m.  The per-frame deviation is 1e-9..1e-8 except on the
+# frames where the stop test of sparse alignment flips (single frames at 1e-6..6e-5, scripts/dropin_frame_debug.py);
+# those spikes are the whole of the RMSE, so its bound follows the per-frame bound (1.2e-5 measured).
+ATE_TOL_M = 5e-5
 
 
 def _sequence(n_frames, seed=5, cam=None):
