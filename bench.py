@@ -408,7 +408,7 @@ def main() -> None:
             "mean_tracked_patches": float(n_tracked.mean()),
             "median_pose_error_vs_gt": float(np.median(st["gt_err"])),
         },
-        "roofline": roofline(("sia_wave_kernel" if args.k1_kernel == "auto" and W.n_patches <= 256 else "sia_kernel") + " (svo_hip_sparse_align)", alg_bytes, kernel_ms, traffic=None, kernel_ms_avg=kernel_ms,
+        "roofline": roofline(("sia_wave_kernel" if args.k1_kernel == "auto" and W.n_patches <= 192 and B >= 1024 else "sia_kernel") + " (svo_hip_sparse_align)", alg_bytes, kernel_ms, traffic=None, kernel_ms_avg=kernel_ms,
                              algorithmic_bytes_per_frame=alg_bytes / B,
                              # iterations/s and per-iteration time of the batch
                              gn_iterations_per_s=float(iters.sum()) / (kernel_ms * 1e-3),
