@@ -257,7 +257,8 @@ typedef struct svo_hip_features {
 /*
  * K3: batched feature_alignment::align2D / align1D (svo/src/feature_alignment.cpp:30-277,
  * the float paths an x86 build runs).  One lane per trial, pixels visited in the
- * reference's order, no contraction: results are bit-identical to the reference's.
+ * reference's order, no contraction: refined pixel and verdict carry the reference's bits
+ * (checked against the reference's own translation unit, tests/test_tracking_gpu.py).
  *   d_slot/d_level [M]   image = level d_level[t] of pyramid slot d_slot[t]
  *   d_patch_with_border [M][100]  Matcher::patch_with_border_ (10x10 u8, row-major); the
  *                        8x8 ref_patch is its interior (Matcher::createPatchFromPatchWithBorder)
@@ -337,7 +338,9 @@ int svo_hip_cam2world(const svo_hip_camera* cam, int n, const double* d_px, doub
  *                                  decisions and medians exact.  n_stride > 256 runs the
  *                                  ordered kernel.
  *   svo_hip_pose_optimize_ordered  one workgroup per frame, sums in the reference's observation
- *                                  order (normal equations reproduced to the bit): the checker.
+ *                                  order (same normal equations as the reference, pose <= 1e-12;
+ *                                  Cov_ to 1e-6 relative: pivoted LDLT here, Matrix6d::inverse()
+ *                                  there): the checker.
  *   d_f [B][n_stride][3]   Feature::f
  *   d_level [B][n_stride]  Feature::level
  *   d_pos [B][n_stride][3] Feature::point->pos_
@@ -358,6 +361,16 @@ int svo_hip_pose_optimize_ordered(const svo_hip_camera* cam, int B, const int32_
                                   uint8_t* d_has_point, double reproj_thresh, int n_iter,
                                   double* d_T_f_w, double* d_Cov, double* d_stats, int32_t* d_ran,
                                   void* stream);
+
+/* svo_hip_pose_optimize without its second launch: frames the wave kernel cannot take (normal equations
+ * singular to working precision, n_iter == 0) are left UNTOUCHED and reported with d_ran[b] == 2; the caller
+ * finishes them with svo_hip_pose_optimize_ordered after looking at d_ran.  For single-stream hosts that
+ * synchronise after the call anyway (the drop-in): the fix-up launch of svo_hip_pose_optimize is 5 us of an
+ * otherwise 20 us call and almost never has work. */
+int svo_hip_pose_optimize_deferred(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride,
+                                   const double* d_f, const int32_t* d_level, const double* d_pos,
+                                   uint8_t* d_has_point, double reproj_thresh, int n_iter, double* d_T_f_w,
+                                   double* d_Cov, double* d_stats, int32_t* d_ran, void* stream);
 
 /*
  * K6: batched Point::optimize (svo/src/point.cpp:119-177).  Point p has observations

@@ -136,6 +136,8 @@ PROTOTYPES = {
                                    _vp, _vp]),
     "svo_hip_pose_optimize_ordered": (_i, [C.POINTER(Camera), _i, _vp, _i, _vp, _vp, _vp, _vp, C.c_double, _i, _vp, _vp,
                                            _vp, _vp, _vp]),
+    "svo_hip_pose_optimize_deferred": (_i, [C.POINTER(Camera), _i, _vp, _i, _vp, _vp, _vp, _vp, C.c_double, _i, _vp, _vp,
+                                           _vp, _vp, _vp]),
     "svo_hip_point_optimize": (_i, [C.POINTER(Frames), _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "svo_hip_update_seeds": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, C.POINTER(Features),
                                   C.POINTER(Seeds), C.POINTER(DepthFilterOptions), _vp, _vp, _vp, _vp, C.c_size_t, _vp]),

@@ -6,18 +6,19 @@
 //     epipolar segment, affine warp matrix, edgelet filter, search level
 //     warp::warpAffine 10x10                                              warp_kernel (matcher.hip)
 //     ZMSSD scan along the epipolar line (:248-291)                       epi_scan_kernel
-//                                                                           (one WAVE per seed)
+//                                                                           (8 lanes per seed)
 //     sub-pixel refinement align2D / align1D (:295-315)                   K3 (feature_align.hip)
 //     depthFromTriangulation (:109-122)                                  \ seed_finish_kernel
 //   DepthFilter::computeTau (:334-350), updateSeed (:309-332),           | (lane per seed)
 //   convergence test (:261-262, :283-287)                                /
 //
 // The epipolar scan is the only part with real per-seed parallelism (up to 1000 candidate
-// positions x 64 pixels of integer ZMSSD): the 64 lanes of a wave take the steps round-robin,
-// score them with v_dot4_u32_u8, and a lexicographic (score, step) wave-min reproduces the
-// reference's "first strictly smaller score wins".  Every lane replays the cheap sequential
-// part of the loop (uv += step in f64, the last_checked_pxi rule), so the positions visited
-// are the reference's to the bit.
+// positions x 64 pixels of integer ZMSSD): SCAN_LANES (8) lanes share a seed and take its steps
+// round-robin, score them with v_dot4_u32_u8, and a lexicographic (score, step) minimum over the
+// group reproduces the reference's "first strictly smaller score wins".  A lane replays only the
+// chain of f64 additions (uv += step) up to its own step and keeps the position of the step before
+// (the last_checked_pxi rule compares with step i-1), so the positions visited are the
+// reference's, rounding included; see epi_scan_kernel.
 //
 // List surgery (erasing seeds, creating svo::Point objects, the converged callback) stays on
 // the host: the kernel reports a status per seed and the new point's position.
@@ -249,7 +250,7 @@ constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_G = SCAN_LANES;
 static_assert(SCAN_G == 4 || SCAN_G == 8 || SCAN_G == 16 || SCAN_G == 32 || SCAN_G == 64, "SCAN_LANES");
 
-// ZMSSD scan, matcher.cpp:248-291.  One wave per seed.
+// ZMSSD scan, matcher.cpp:248-291.  SCAN_LANES lanes per seed.
 __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) {
   const int s = blockIdx.x * (SCAN_BLOCK / SCAN_G) + (threadIdx.x / SCAN_G);
   const int lane = threadIdx.x & (SCAN_G - 1);  // lane within the seed's group

@@ -414,10 +414,11 @@ static int launch_ordered(const svo_hip_camera* cam, int B, const int32_t* d_n, 
   return check_launch();
 }
 
-extern "C" int svo_hip_pose_optimize(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride,
-                                     const double* d_f, const int32_t* d_level, const double* d_pos,
-                                     uint8_t* d_has_point, double reproj_thresh, int n_iter, double* d_T_f_w,
-                                     double* d_Cov, double* d_stats, int32_t* d_ran, void* stream) {
+// finish: also run the ordered kernel on the frames the wave kernel flags (ran = 2)
+static int pose_optimize_impl(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride, const double* d_f,
+                              const int32_t* d_level, const double* d_pos, uint8_t* d_has_point, double reproj_thresh,
+                              int n_iter, double* d_T_f_w, double* d_Cov, double* d_stats, int32_t* d_ran, bool finish,
+                              void* stream) {
   const int rc = pose_args_check(cam, B, d_n, n_stride, d_f, d_level, d_pos, d_has_point, n_iter, d_T_f_w, d_stats, d_ran);
   if (rc != SVO_HIP_OK) return rc > 0 ? SVO_HIP_OK : rc;
   if (n_stride > svo_track::POSE_WAVE_MAX_STRIDE)  // more than 4 observations per lane: ordered kernel
@@ -439,11 +440,27 @@ extern "C" int svo_hip_pose_optimize(const svo_hip_camera* cam, int B, const int
   w.stats = d_stats;
   w.ran = d_ran;
   const int r2 = svo_track::launch_pose_wave(w, static_cast<hipStream_t>(stream));
-  if (r2 != SVO_HIP_OK) return r2;
+  if (r2 != SVO_HIP_OK || !finish) return r2;
   // frames whose normal equations are (nearly) singular were left untouched and flagged ran = 2:
   // the ordered kernel takes exactly those (its other workgroups exit at once)
   return launch_ordered(cam, B, d_n, n_stride, d_f, d_level, d_pos, d_has_point, reproj_thresh, n_iter, d_T_f_w, d_Cov,
                         d_stats, d_ran, 1, stream);
+}
+
+extern "C" int svo_hip_pose_optimize(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride,
+                                     const double* d_f, const int32_t* d_level, const double* d_pos,
+                                     uint8_t* d_has_point, double reproj_thresh, int n_iter, double* d_T_f_w,
+                                     double* d_Cov, double* d_stats, int32_t* d_ran, void* stream) {
+  return pose_optimize_impl(cam, B, d_n, n_stride, d_f, d_level, d_pos, d_has_point, reproj_thresh, n_iter, d_T_f_w, d_Cov,
+                            d_stats, d_ran, true, stream);
+}
+
+extern "C" int svo_hip_pose_optimize_deferred(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride,
+                                              const double* d_f, const int32_t* d_level, const double* d_pos,
+                                              uint8_t* d_has_point, double reproj_thresh, int n_iter, double* d_T_f_w,
+                                              double* d_Cov, double* d_stats, int32_t* d_ran, void* stream) {
+  return pose_optimize_impl(cam, B, d_n, n_stride, d_f, d_level, d_pos, d_has_point, reproj_thresh, n_iter, d_T_f_w, d_Cov,
+                            d_stats, d_ran, false, stream);
 }
 
 extern "C" int svo_hip_pose_optimize_ordered(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride,

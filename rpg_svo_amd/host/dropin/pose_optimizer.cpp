@@ -56,11 +56,20 @@ void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const 
   const svo_hip_camera cam = cameraOf(frame->cam_);
   stage_timer.device(a.used());
   a.uploadAll(lane.stream);
-  svo_hip::check(svo_hip_pose_optimize(&cam, 1, d_n, (int)n, d_f, d_level, d_pos, d_has_out, reproj_thresh, (int)n_iter, d_Tout,
-                                       d_Cov, d_stats, d_ran, lane.stream),
-                 "svo_hip_pose_optimize");
+  // the wave kernel alone; a frame it hands over (ran == 2: singular normal equations, n_iter == 0) is rare
+  // and found out after the sync this call needs anyway, so the single-stream path pays for one launch
+  svo_hip::check(svo_hip_pose_optimize_deferred(&cam, 1, d_n, (int)n, d_f, d_level, d_pos, d_has_out, reproj_thresh,
+                                                (int)n_iter, d_Tout, d_Cov, d_stats, d_ran, lane.stream),
+                 "svo_hip_pose_optimize_deferred");
   a.download(lane.stream);
   svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+  if (*ran == 2) {  // untouched by the wave kernel: the ordered kernel on the same blocks
+    svo_hip::check(svo_hip_pose_optimize_ordered(&cam, 1, d_n, (int)n, d_f, d_level, d_pos, d_has_out, reproj_thresh,
+                                                 (int)n_iter, d_Tout, d_Cov, d_stats, d_ran, lane.stream),
+                   "svo_hip_pose_optimize_ordered");
+    a.download(lane.stream);
+    svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+  }
   stage_timer.unmarshal();
 
   if (!*ran) return;  // no observation carried a point: the reference returns untouched (:57-58)

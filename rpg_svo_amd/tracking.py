@@ -211,7 +211,7 @@ class PoseOptResult:
 
 
 def optimize_gauss_newton(cam, n, f, level, pos, has_point, T_f_w, reproj_thresh: float = 2.0, n_iter: int = 10,
-                          ordered: bool = False, out: PoseOptResult | None = None) -> PoseOptResult:
+                          ordered: bool = False, out: PoseOptResult | None = None, deferred: bool = False) -> PoseOptResult:
     """pose_optimizer::optimizeGaussNewton for B frames (reproj_thresh = Config::poseOptimThresh(),
     n_iter = Config::poseOptimNumIter(), frame_handler_mono.cpp:163-165).  ordered=True runs the
     kernel that adds the normal equations in the reference's observation order (the checker)."""
@@ -229,7 +229,8 @@ def optimize_gauss_newton(cam, n, f, level, pos, has_point, T_f_w, reproj_thresh
                             torch.zeros(B, 4, dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.int32, device=dev),
                             has_point.clone())
     c = capi.camera(cam)
-    fn = lib.svo_hip_pose_optimize_ordered if ordered else lib.svo_hip_pose_optimize
+    # deferred: svo_hip_pose_optimize_deferred -- frames the wave kernel hands over come back untouched with ran == 2
+    fn = lib.svo_hip_pose_optimize_ordered if ordered else (lib.svo_hip_pose_optimize_deferred if deferred else lib.svo_hip_pose_optimize)
     capi.check(fn(C.byref(c), B, n.data_ptr(), ns, f.data_ptr(), level.data_ptr(), pos.data_ptr(),
                   res.has_point.data_ptr(), reproj_thresh, n_iter, res.T_f_w.data_ptr(),
                   res.Cov.data_ptr(), res.stats.data_ptr(), res.ran.data_ptr(), _stream_ptr(dev)),

@@ -129,6 +129,43 @@ def test_reproject_points(gpu_device, orc, scene):
     assert (cell >= 0).sum() > P // 2
 
 
+def test_pose_optimize_deferred(gpu_device, scene):
+    """svo_hip_pose_optimize_deferred = svo_hip_pose_optimize without the fix-up launch: same results on the frames
+    the wave kernel takes; the others come back untouched with ran == 2 and are finished by
+    svo_hip_pose_optimize_ordered.  n_iter = 0 is a documented hand-over (the kernel only reports the initial error
+    there), so it exercises that path for every frame."""
+    rng = np.random.default_rng(4)
+    P = min(len(scene.pt_pos), 200)  # <= 256 observations per frame: the wave kernel's range
+    B = 6
+    pt_pos = scene.pt_pos[:P]
+    f = synth._bearing(scene.cam, scene.px_true[:P] + rng.normal(size=(P, 2)) * 0.3)
+    level = rng.integers(0, 3, size=P).astype(np.int32)
+    n = np.array([P, 150, 2, 64, 1, 40], dtype=np.int32)
+    hp = np.ones((B, P), dtype=np.uint8)
+    T0 = np.stack([se3.mul(se3.exp(rng.normal(size=6) * 5e-3), scene.T_f_w[scene.cur]) for _ in range(B)])
+
+    def run(n_iter, **kw):
+        r = tracking.optimize_gauss_newton(scene.cam, dev(n, torch.int32), dev(np.tile(f, (B, 1, 1)), torch.float64),
+                                           dev(np.tile(level, (B, 1)), torch.int32), dev(np.tile(pt_pos, (B, 1, 1)), torch.float64),
+                                           dev(hp, torch.uint8), dev(T0, torch.float64), 2.0, n_iter, **kw)
+        torch.cuda.synchronize()
+        return r.T_f_w.cpu().numpy(), r.ran.cpu().numpy(), r.has_point.cpu().numpy(), r.stats.cpu().numpy()
+
+    Tf, ran_f, hp_f, st_f = run(10)
+    Tp, ran_p, hp_p, st_p = run(10, deferred=True)
+    assert not (ran_f == 2).any()
+    taken = ran_p != 2
+    assert taken.any()
+    assert np.array_equal(Tf[taken], Tp[taken]) and np.array_equal(ran_f[taken], ran_p[taken]) and np.array_equal(hp_f[taken], hp_p[taken])
+    assert np.array_equal(Tp[~taken], T0[~taken]) and np.array_equal(hp_p[~taken], hp[~taken])          # untouched
+    # n_iter = 0: everything is handed over; the caller's second step gives what the one-call entry gives
+    T0f, ran0f, hp0f, st0f = run(0)
+    T0p, ran0p, hp0p, _ = run(0, deferred=True)
+    assert (ran0p == 2).all() and np.array_equal(T0p, T0) and np.array_equal(hp0p, hp)
+    T0o, ran0o, hp0o, st0o = run(0, ordered=True)
+    assert np.array_equal(T0o, T0f) and np.array_equal(ran0o, ran0f) and np.array_equal(hp0o, hp0f) and np.array_equal(st0o, st0f)
+
+
 @pytest.mark.parametrize("ordered", [True, False])
 def test_pose_optimize(gpu_device, orc, scene, ordered):
     """ordered=True: the checker kernel (normal equations summed in the reference's order).
