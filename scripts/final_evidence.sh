@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round evidence, run on the GPU box: default bench line, rocprofv3 kernel-trace stats of the headline and of the
+# full-track step, single-stream drop-in kernel stats, the VALU issue microbenchmark.  Summaries land in
+# gpurun_out/<tag>/ and are copied from there into profiles/ (prefix <tag>_).
+# usage: scripts/final_evidence.sh <tag>
+set -u
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/$TAG; rm -rf "$O"; mkdir -p "$O"
+cd /tmp && export TMPDIR=/tmp
+stats() {  # <dir> <out.csv>: our kernels' rows of the kernel_stats table
+  python - "$1" "$2" <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f)) if 'at::native' not in r['Name'] and 'Cijk' not in r['Name'] and 'rocprim' not in r['Name'] and 'rocclr' not in r['Name']]
+rows.sort(key=lambda r: -float(r['TotalDurationNs']))
+w = csv.writer(open(sys.argv[2], 'w'))
+w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'MinNs', 'MaxNs'])
+for r in rows: w.writerow([r['Name'], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r.get('MinNs', ''), r.get('MaxNs', '')])
+PY
+}
+echo "== default bench"; (time python $R/bench.py) > $O/bench_default.json 2> $O/bench_default.err
+echo "== headline under kernel trace"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_align -o trace -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --extras none > $O/align_bench_under_trace.json 2> $O/trace_align.err
+stats $O/trace_align $O/align_kernel_stats.csv
+echo "== full track under kernel trace"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_full -o trace -- python $R/bench.py --pipeline full --steps 5 --warmup 2 --no-cpu-baseline --extras none > $O/full_bench_under_trace.json 2> $O/trace_full.err
+stats $O/trace_full $O/full_kernel_stats.csv
+echo "== drop-in sequence under kernel trace"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_dropin -o trace -- python -c "import sys; sys.path.insert(0, '$R'); import bench, json; print(json.dumps(bench.dropin_sequence(120)))" > $O/dropin_under_trace.json 2> $O/trace_dropin.err
+stats $O/trace_dropin $O/dropin_kernel_stats.csv
+echo "== valu microbenchmark"; [ -x $R/build/valu_ubench ] && $R/build/valu_ubench > $O/valu_ubench.json
+find $O -name "*.csv" -size +300k -delete; find $O -name "*.db" -delete
+ls -la $O
