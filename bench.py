@@ -671,6 +671,40 @@ def line_floor_bytes(W: Workload, n_sample: int = 64) -> float:
     return total / len(idx)
 
 
+# Issue cost per wave-instruction and SIMD with 4 waves resident, measured by scripts/valu_ubench.hip on this part
+# (profiles/r02_valu_ubench.json): f32 add/mul/fma 2.4, f64 3.5, conversions 3.0, f32 transcendentals 3.9,
+# v_rcp_f64 & co 9.6, 32-bit integer/logic 2.5; whatever the class counters do not cover (moves, selects, DPP,
+# lane reads) is priced at 3.0.
+VALU_CLASS_COST = {"SQ_INSTS_VALU_ADD_F32": 2.4, "SQ_INSTS_VALU_MUL_F32": 2.4, "SQ_INSTS_VALU_FMA_F32": 2.4,
+                   "SQ_INSTS_VALU_ADD_F64": 3.5, "SQ_INSTS_VALU_MUL_F64": 3.5, "SQ_INSTS_VALU_FMA_F64": 3.5,
+                   "SQ_INSTS_VALU_CVT": 3.0, "SQ_INSTS_VALU_INT32": 2.5, "SQ_INSTS_VALU_INT64": 3.0,
+                   "SQ_INSTS_VALU_TRANS_F32": 3.9, "SQ_INSTS_VALU_TRANS_F64": 9.6}
+VALU_OTHER_COST = 3.0
+
+
+def valu_roofline(raw: dict, kernel_ms: float) -> dict:
+    """VALU issue utilisation of one K1 launch from the SQ counters (per-launch averages in `raw`): the instruction
+    classes priced with their measured issue cost over the SIMD cycles of the launch.  The cycles come from
+    SQ_BUSY_CU_CYCLES (summed over the CUs, i.e. this run's clock) when present, else from the kernel time at the
+    nominal clock."""
+    cu_cycles = raw["SQ_BUSY_CU_CYCLES"] / N_CU if raw.get("SQ_BUSY_CU_CYCLES") else kernel_ms * 1e-3 * CLOCK_GHZ * 1e9
+    simd_cycles = N_SIMD * cu_cycles
+    n_valu = raw["SQ_INSTS_VALU"]
+    classified = sum(raw.get(k, 0.0) for k in VALU_CLASS_COST)
+    busy = sum(raw.get(k, 0.0) * c for k, c in VALU_CLASS_COST.items()) + max(n_valu - classified, 0.0) * VALU_OTHER_COST
+    wc = raw.get("SQ_WAVE_CYCLES")
+    frac_of_wave = lambda k: (raw[k] / wc) if (wc and k in raw) else None
+    return {"bound": "valu-issue", "kernel": "sia_kernel", "peak": 1.0, "achieved": busy / simd_cycles, "frac": busy / simd_cycles,
+            "unit": "fraction of SIMD cycles the VALU is issuing: sum over instruction classes of (class count x measured issue cost) "
+                    "/ (1024 SIMDs x SQ_BUSY_CU_CYCLES/256)",
+            "lower_bound_2_cycles_per_instruction": n_valu * 2.0 / simd_cycles,
+            "valu_instructions_per_launch": n_valu, "classified_by_counters_frac": classified / n_valu if n_valu else None,
+            "simd_cycles_per_valu_instruction": simd_cycles / n_valu if n_valu else None,
+            "all_instructions_per_launch": raw.get("SQ_INSTS"), "cu_cycles_per_launch": cu_cycles, "kernel_ms": kernel_ms,
+            "wave_cycles_issuing_frac": frac_of_wave("SQ_ACTIVE_INST_ANY"), "wave_cycles_waiting_frac": frac_of_wave("SQ_WAIT_ANY"),
+            "wave_cycles_at_waitcnt_frac": frac_of_wave("SQ_WAIT_INST_ANY")}
+
+
 def pmc_leg(args, kernel_ms: float) -> dict:
     """HBM traffic and VALU issue of the headline kernel, measured on THIS box by re-running this
     command (headline leg only, 3 steps) under rocprofv3 --pmc, one counter group per pass as
@@ -731,33 +765,7 @@ def pmc_leg(args, kernel_ms: float) -> dict:
         out["fetch_bytes_per_launch_raw_counter"] = raw["FETCH_SIZE"] * 1024.0
         out["write_bytes_per_launch"] = raw["WRITE_SIZE"] * 1024.0
     if "SQ_INSTS_VALU" in raw:
-        # SIMD cycles of the launch on THIS run's clock: SQ_BUSY_CU_CYCLES is summed over the CUs
-        cu_cycles = raw.get("SQ_BUSY_CU_CYCLES", 0.0) / N_CU if raw.get("SQ_BUSY_CU_CYCLES") else kernel_ms * 1e-3 * CLOCK_GHZ * 1e9
-        simd_cycles = N_SIMD * cu_cycles
-        n_valu = raw["SQ_INSTS_VALU"]
-        # issue cost per wave-instruction and SIMD with 4 waves resident, measured by scripts/valu_ubench.hip on
-        # this part (profiles/r02_valu_ubench.json): f32 add/mul/fma 2.4, f64 3.5, conversions 3.0, f32
-        # transcendentals 3.9, v_rcp_f64 & co 9.6, 32-bit integer/logic 2.5; whatever the class counters do not
-        # cover (moves, selects, DPP, lane reads) is priced at 3.0
-        cost = {"SQ_INSTS_VALU_ADD_F32": 2.4, "SQ_INSTS_VALU_MUL_F32": 2.4, "SQ_INSTS_VALU_FMA_F32": 2.4,
-                "SQ_INSTS_VALU_ADD_F64": 3.5, "SQ_INSTS_VALU_MUL_F64": 3.5, "SQ_INSTS_VALU_FMA_F64": 3.5,
-                "SQ_INSTS_VALU_CVT": 3.0, "SQ_INSTS_VALU_INT32": 2.5, "SQ_INSTS_VALU_INT64": 3.0,
-                "SQ_INSTS_VALU_TRANS_F32": 3.9, "SQ_INSTS_VALU_TRANS_F64": 9.6}
-        classified = sum(raw.get(k, 0.0) for k in cost)
-        busy_weighted = sum(raw.get(k, 0.0) * c for k, c in cost.items()) + max(n_valu - classified, 0.0) * 3.0
-        wc = raw.get("SQ_WAVE_CYCLES")
-        out["roofline_valu"] = {
-            "bound": "valu-issue", "kernel": "sia_kernel", "peak": 1.0,
-            "achieved": busy_weighted / simd_cycles, "frac": busy_weighted / simd_cycles,
-            "unit": "fraction of SIMD cycles the VALU is issuing: sum over instruction classes of (class count x measured issue cost) "
-                    "/ (1024 SIMDs x SQ_BUSY_CU_CYCLES/256)",
-            "lower_bound_2_cycles_per_instruction": n_valu * 2.0 / simd_cycles,
-            "valu_instructions_per_launch": n_valu, "classified_by_counters_frac": classified / n_valu if n_valu else None,
-            "simd_cycles_per_valu_instruction": simd_cycles / n_valu if n_valu else None,
-            "all_instructions_per_launch": raw.get("SQ_INSTS"), "cu_cycles_per_launch": cu_cycles, "kernel_ms": kernel_ms,
-            "wave_cycles_issuing_frac": raw.get("SQ_ACTIVE_INST_ANY", float("nan")) / wc if wc else None,
-            "wave_cycles_waiting_frac": raw.get("SQ_WAIT_ANY", float("nan")) / wc if wc else None,
-            "wave_cycles_at_waitcnt_frac": raw.get("SQ_WAIT_INST_ANY", float("nan")) / wc if wc else None}
+        out["roofline_valu"] = valu_roofline(raw, kernel_ms)
     return out
 
 
@@ -1044,6 +1052,10 @@ class FullTrack:
         tried = m.ref_obs >= 0
         n_eval = float(evals[tried].sum().item())
         n_tried = float(tried.sum().item())
+        # a wave of K3 runs as long as its slowest trial: mean over the 64-trial groups of the group maximum
+        ev64 = evals[: (M // 64) * 64].view(-1, 64)
+        eval_hist = torch.bincount(evals[tried].long(), minlength=12)[:12].tolist()
+        wave_max_mean = float(ev64.max(dim=1).values.float().mean().item())
         fm_bytes = n_tried * (121 + 100 + 48) + 81.0 * n_eval
         steps_ptr = lib.svo_hip_update_seeds_scan_steps(self.df.last_workspace.data_ptr())
         scan = torch.empty(M, dtype=torch.int32, device=dev)
@@ -1053,7 +1065,9 @@ class FullTrack:
         seed_bytes = M * 36.0 + 64.0 * n_scan + M * (121.0 + 100.0)
         return {
             "find_match_direct": roofline("match_prepare + warp_kernel + align_kernel", fm_bytes, stages["find_match_direct"],
-                                          trials=n_tried, alignment_evaluations_per_trial=n_eval / max(n_tried, 1)),
+                                          trials=n_tried, alignment_evaluations_per_trial=n_eval / max(n_tried, 1),
+                                          alignment_evaluations_histogram=eval_hist,
+                                          alignment_evaluations_per_wave_of_64_trials=wave_max_mean),
             "pose_optimize": roofline("pose_opt_wave_kernel", B * (N * 52.0 + 416.0), stages["pose_optimize"]),
             "update_seeds": roofline("seed_prepare + warp_kernel + epi_scan + align_kernel + seed_finish", seed_bytes,
                                      stages["update_seeds"], scanned_positions_per_seed=n_scan / M),

@@ -44,3 +44,21 @@ def test_workloads_match_baseline_configs():
     assert w["xga5_n1000_sparse_align"][:7] == (1280, 960, 800.0, 5, 4, 0, 1000)       # configs[3]
     assert w["svo_default_752_l4to2_n120"][:7] == (752, 480, 315.5, 5, 4, 2, 120)      # configs[0]/[4] geometry
     assert bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_valu_roofline_pricing():
+    """roofline_valu: class counters x measured issue cost over the SIMD cycles of the launch."""
+    n_cu, n_simd = bench.N_CU, bench.N_SIMD
+    raw = {"SQ_INSTS_VALU": 1000.0 * n_simd, "SQ_BUSY_CU_CYCLES": 10000.0 * n_cu,        # 1000 VALU per SIMD in 10000 cycles
+           "SQ_INSTS_VALU_FMA_F32": 400.0 * n_simd, "SQ_INSTS_VALU_FMA_F64": 100.0 * n_simd, "SQ_INSTS_VALU_TRANS_F64": 10.0 * n_simd,
+           "SQ_WAVE_CYCLES": 100.0, "SQ_WAIT_ANY": 50.0}
+    r = bench.valu_roofline(raw, kernel_ms=1.0)
+    busy = 400 * 2.4 + 100 * 3.5 + 10 * 9.6 + (1000 - 510) * 3.0
+    assert abs(r["frac"] - busy / 10000.0) < 1e-12 and r["achieved"] == r["frac"]
+    assert abs(r["lower_bound_2_cycles_per_instruction"] - 0.2) < 1e-12
+    assert abs(r["classified_by_counters_frac"] - 0.51) < 1e-12
+    assert r["wave_cycles_waiting_frac"] == 0.5 and r["wave_cycles_issuing_frac"] is None
+    # without the busy counter the nominal clock stands in
+    raw.pop("SQ_BUSY_CU_CYCLES")
+    r2 = bench.valu_roofline(raw, kernel_ms=1.0)
+    assert abs(r2["cu_cycles_per_launch"] - 1e-3 * bench.CLOCK_GHZ * 1e9) < 1e-6
