@@ -243,3 +243,19 @@ def test_wave_per_frame_kernel(oracle, gpu_device, checker, n_patches):
     Hw = out_w.H.cpu().numpy().reshape(-1, 36)[:32][same]
     Ho = np.stack([r["H"] for r in res_o]).reshape(-1, 36)[same]
     assert np.allclose(Hw, Ho, rtol=2e-5, atol=1e-3 * np.abs(Ho).max())
+
+
+@pytest.mark.parametrize("kind", ["radtan", "atan"])
+def test_wave_per_frame_kernel_distorted_cameras(oracle, gpu_device, checker, kind):
+    """The wave-per-frame kernel under the distorted camera models (its DIST instantiations)."""
+    cam = camera_models()[kind]
+    seq = synth.make_sequence(6, 120, cam=cam, seed=9, margin=56, cell=40)
+    b = make_batch(seq, [(i, i + 1) for i in range(5)], 5)
+    T_o, res_o, _ = run_oracle(oracle, b, 3, 0, 30, which=checker)
+    big = tile_batch(b, 205)  # B = 1025 >= 1024, 120 patches: two per lane
+    T_w, out_w, _ = run_hip(big, 3, 0, 30, kernel="auto")
+    T_g, out_g, _ = run_hip(big, 3, 0, 30, kernel="workgroup")
+    d = se3.log_norm(T_w[:5], T_o)
+    assert d.max() <= TOL and np.median(d) <= TOL_MEDIAN
+    assert np.array_equal(T_w.reshape(205, 5, 12), np.broadcast_to(T_w[:5], (205, 5, 12)))
+    assert se3.log_norm(T_w[:5], T_g[:5]).max() <= TOL
