@@ -64,6 +64,19 @@ __device__ __forceinline__ void load_row7(const uint8_t* __restrict__ row, int x
   out[6] = (float)((hi >> 16) & 0xffu);
 }
 
+// bytes [sel, sel+6] (sel in 0..3) of three consecutive dwords as floats: load_row7 on registers
+__device__ __forceinline__ void cut_row7(const uint32_t d[3], uint32_t sel, float out[7]) {
+  const uint32_t lo = __builtin_amdgcn_alignbyte(d[1], d[0], sel);  // bytes 0..3
+  const uint32_t hi = __builtin_amdgcn_alignbyte(d[2], d[1], sel);  // bytes 4..7
+  out[0] = (float)(lo & 0xffu);
+  out[1] = (float)((lo >> 8) & 0xffu);
+  out[2] = (float)((lo >> 16) & 0xffu);
+  out[3] = (float)(lo >> 24);
+  out[4] = (float)(hi & 0xffu);
+  out[5] = (float)((hi >> 8) & 0xffu);
+  out[6] = (float)((hi >> 16) & 0xffu);
+}
+
 // ---- window cache (template parameter WC) --------------------------------------------------------------
 // The 5x5 window of the current image moves by a fraction of a pixel per Gauss-Newton iteration,
 // yet re-fetching it every iteration misses L2 (128 resident problems per XCD x ~64 KB of touched

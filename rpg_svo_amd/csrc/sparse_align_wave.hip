@@ -164,6 +164,136 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
     const float fl = (float)(fabs(P.fx) / (double)(1 << level));
 
     // ---- precomputeReferencePatches (:84-145) --------------------------------------------------------
+    // Stage A, all of the lane's patches: positions, then EVERY global load of the level in one go -- the
+    // 7 x 3 dwords of the reference window and, with the pose the level starts from, the 7 x 3 dwords of the
+    // current image that iteration 0 will cut its 5x5 window from (the window cache is filled here, so that
+    // iteration finds it valid).  A single wave has nobody to hide a round trip behind: taken patch by patch
+    // these are 2 x PPL dependent round trips per level, taken together one.  Lanes without a usable patch load
+    // from a clamped position and throw the bytes away (keeps the block free of branches).
+#ifndef SIAW_SERIAL_LOADS
+    uint32_t rw[PPL][7][3];
+    int sel_ref[PPL];
+    bool inb_k[PPL];
+    float su_k[PPL], sv_k[PPL];
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      Patch& p = pt[k];
+      const int slot = lane + 64 * k;
+      const size_t fo = (size_t)b * a.n_stride + slot;
+      double pxx = 0, pxy = 0;
+      if (p.has) {
+        pxx = a.px[2 * fo];
+        pxy = a.px[2 * fo + 1];
+      }
+      const float u_ref = (float)(pxx * (double)scale);
+      const float v_ref = (float)(pxy * (double)scale);
+      const int u_i = (int)floorf(u_ref);
+      const int v_i = (int)floorf(v_ref);
+      const bool inb = p.has && !(u_i - 3 < 0 || v_i - 3 < 0 || u_i + 3 >= cols || v_i + 3 >= rows);
+      inb_k[k] = inb;
+      su_k[k] = u_ref - (float)u_i;
+      sv_k[k] = v_ref - (float)v_i;
+      const int cu = inb ? u_i : 3, cv = inb ? v_i : 3;
+      sel_ref[k] = (cu - 3) & 3;
+      const uint8_t* base = ref_img + (int64_t)(cv - 3) * pitch;
+#pragma unroll
+      for (int r = 0; r < 7; ++r) load_row12(base + (int64_t)r * pitch, (cu - 3) & ~3, rw[k][r]);
+    }
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      Patch& p = pt[k];
+      p.wc_v0 = -100000;  // the cache holds rows of the previous level
+      const bool will_see = p.vis || inb_k[k];
+      const double xc = R[0] * p.X + R[1] * p.Y + R[2] * p.Z + tr[0];
+      const double yc = R[3] * p.X + R[4] * p.Y + R[5] * p.Z + tr[1];
+      const double zc = R[6] * p.X + R[7] * p.Y + R[8] * p.Z + tr[2];
+      double izc = __builtin_amdgcn_rcp(zc);
+      izc = fma(fma(-zc, izc, 1.0), izc, izc);
+      izc = fma(fma(-zc, izc, 1.0), izc, izc);
+      double pu, pv;
+      if (DIST) {
+        Cam cm;
+        cm.fx = P.fx; cm.fy = P.fy; cm.cx = P.cx; cm.cy = P.cy;
+        cm.width = 0; cm.height = 0;
+        cm.model = P.cam_model;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) cm.d[j] = P.d[j];
+        const double uvn[2] = {xc * izc, yc * izc};
+        double pxd[2];
+        world2cam_uv(cm, uvn, pxd);
+        pu = pxd[0];
+        pv = pxd[1];
+      } else {
+        pu = P.fx * (xc * izc) + P.cx;
+        pv = P.fy * (yc * izc) + P.cy;
+      }
+      const float fu = floorf((float)pu * scale), fv = floorf((float)pv * scale);
+      const bool okc = will_see && fu - 3.f >= 0.f && fv - 3.f >= 0.f && fu + 3.f < (float)cols && fv + 3.f < (float)rows;
+      const int cu = okc ? (int)fu : 3, cv = okc ? (int)fv : 3;
+      const int v0 = cv - 3, u0 = (cu - 3) & ~3;
+      const uint8_t* base = cur_img + (int64_t)v0 * pitch;
+#pragma unroll
+      for (int r = 0; r < 7; ++r) load_row12(base + (int64_t)r * pitch, u0, p.wc[r]);
+      p.wc_u0 = u0;
+      p.wc_v0 = okc ? v0 : -100000;
+    }
+    // Stage B: the interpolated reference tiles
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      Patch& p = pt[k];
+      p.Sxx = p.Sxy = p.Syy = 0.f;
+      p.inH = -1;
+      if (inb_k[k]) {
+        p.vis = true;
+        p.gmask = 1.f;
+        const float su = su_k[k], sv = sv_k[k];
+        // == the reference's rounded double products (:118-121): u >= 3, so su, sv are multiples of 2^-22,
+        // 1-su and 1-sv are exact in f32 and an f32 product is the correctly rounded exact product
+        const float wtl = (1.f - su) * (1.f - sv);
+        const float wtr = su * (1.f - sv);
+        const float wbl = (1.f - su) * sv;
+        const float wbr = su * sv;
+        float Bt[6][6];
+        float Wp[7], Wc[7];
+        cut_row7(rw[k][0], (uint32_t)sel_ref[k], Wp);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          cut_row7(rw[k][r + 1], (uint32_t)sel_ref[k], Wc);
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            const bool need = ((r >= 1 && r <= 4)) || ((c >= 1 && c <= 4));
+            if (need) Bt[r][c] = wtl * Wp[c] + wtr * Wp[c + 1] + wbl * Wc[c] + wbr * Wc[c + 1];
+          }
+#pragma unroll
+          for (int c = 0; c < 7; ++c) Wp[c] = Wc[c];
+        }
+        float Sxx = 0.f, Sxy = 0.f, Syy = 0.f;
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const float dx = 0.5f * (Bt[y + 1][x + 2] - Bt[y + 1][x]);
+            const float dy = 0.5f * (Bt[y + 2][x + 1] - Bt[y][x + 1]);
+            Sxx += dx * dx;
+            Sxy += dx * dy;
+            Syy += dy * dy;
+          }
+        p.Sxx = Sxx; p.Sxy = Sxy; p.Syy = Syy;
+        SIA_BT(k, 0) = make_float4(Bt[0][1], Bt[0][2], Bt[0][3], Bt[0][4]);
+        SIA_BT(k, 1) = make_float4(Bt[1][0], Bt[1][1], Bt[1][2], Bt[1][3]);
+        SIA_BT(k, 2) = make_float4(Bt[1][4], Bt[1][5], Bt[2][0], Bt[2][1]);
+        SIA_BT(k, 3) = make_float4(Bt[2][2], Bt[2][3], Bt[2][4], Bt[2][5]);
+        SIA_BT(k, 4) = make_float4(Bt[3][0], Bt[3][1], Bt[3][2], Bt[3][3]);
+        SIA_BT(k, 5) = make_float4(Bt[3][4], Bt[3][5], Bt[4][0], Bt[4][1]);
+        SIA_BT(k, 6) = make_float4(Bt[4][2], Bt[4][3], Bt[4][4], Bt[4][5]);
+        SIA_BT(k, 7) = make_float4(Bt[5][1], Bt[5][2], Bt[5][3], Bt[5][4]);
+      } else {
+        // jacobian_cache_.setZero() (:64): the J columns of a feature skipped here stay zero; a stale
+        // ref_patch_cache_ row (if any) is kept
+        p.gmask = 0.f;
+      }
+    }
+#else
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
       Patch& p = pt[k];
@@ -232,6 +362,8 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
         p.gmask = 0.f;
       }
     }
+
+#endif
 
     // ---- vk::NLLSSolver::optimizeGaussNewton ------------------------------------------------------------
     // old_model = model at the start of every optimize() call
@@ -539,7 +671,10 @@ namespace svo_sia {
 // waves turns the saved barriers and the idle solver-wave partners into throughput.  Measured on the 640x480
 // batch of 16384 frames: 1.29 against 1.36 ms at 192 patches per frame (3 per lane); at 200 (4 per lane, the
 // fourth pass for 8 patches) the workgroup kernel wins, 1.41 against 1.62 ms.
-bool sia_wave_applies(const SiaArgs& args, int B) { return args.n_stride <= 192 && B >= 1024; }
+#ifndef SIAW_MAX_PATCHES
+#define SIAW_MAX_PATCHES 192
+#endif
+bool sia_wave_applies(const SiaArgs& args, int B) { return args.n_stride <= SIAW_MAX_PATCHES && B >= 1024; }
 
 int launch_sia_wave(const SiaArgs& args, int B, hipStream_t s) {
   return args.P.cam_model == SVO_HIP_CAM_PINHOLE ? launch_dist<false>(args, B, s) : launch_dist<true>(args, B, s);
