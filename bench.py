@@ -101,6 +101,16 @@ def free_port() -> int:
         return so.getsockname()[1]
 
 
+def flush_c_stdio() -> None:
+    """fflush(NULL): libraries below us (librccl, the reference's logging in the drop-in leg) write through C stdio."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def spawn_command(n_gpus: int, argv: list[str], port: int) -> list[str]:
     """The launch line of the contract (one rank per GPU of one node, rendezvous on 127.0.0.1)."""
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
@@ -254,6 +264,10 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # librccl announces itself through C stdio, which is block-buffered on a pipe and would otherwise come out
+        # at process exit, AFTER the JSON line: create the communicator now and push the banner out now
+        dist.barrier()
+        flush_c_stdio()
     lib = capi.load()
     ev = Events(lib, dev)
     if args.extras == "all":
@@ -375,6 +389,7 @@ def main() -> None:
 
     if rank != 0:
         dist.destroy_process_group()
+        flush_c_stdio()
         return
 
     out = outs[(counter[0] - 1) % len(outs)]  # the result block of the last step
@@ -472,9 +487,10 @@ def main() -> None:
             result["roofline_valu"] = pm.pop("roofline_valu")
         result["pmc"] = pm
     leg("dropin", dropin_sequence)
-    print(json.dumps(result))
     if use_dist:
-        dist.destroy_process_group()
+        dist.destroy_process_group()  # (the other ranks have left already)
+    flush_c_stdio()
+    print(json.dumps(result), flush=True)  # rank 0, and the last thing on stdout
 
 
 def time_gather(gather, dist, dev, world, B, overlapped) -> dict:

@@ -268,6 +268,33 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
     // focal_length / 2^level (:139-140), folded into the per-patch sums
     const float fl = (float)(fabs(P.fx) / (double)(1 << level));
 
+    uint32_t wc[WC ? 7 : 1][3];
+    int wc_u0 = 0, wc_v0 = -100000;  // cached columns [wc_u0, wc_u0+11], rows [wc_v0, wc_v0+6]
+    if (WC) {
+#pragma unroll
+      for (int r = 0; r < (WC ? 7 : 1); ++r) wc[r][0] = wc[r][1] = wc[r][2] = 0u;
+    }
+#ifdef SIA_PREFETCH_CUR
+    // fill the window cache for iteration 0 with the pose the level starts from, ahead of the reference-patch
+    // work: the round trip of the current image overlaps the one of the reference image and the tile arithmetic
+    if (WC && !DIST) {
+      const double xc = R[0] * X + R[1] * Y + R[2] * Z + tr[0];
+      const double yc = R[3] * X + R[4] * Y + R[5] * Z + tr[1];
+      const double zc = R[6] * X + R[7] * Y + R[8] * Z + tr[2];
+      double izc = __builtin_amdgcn_rcp(zc);
+      izc = fma(fma(-zc, izc, 1.0), izc, izc);
+      izc = fma(fma(-zc, izc, 1.0), izc, izc);
+      const double pu = P.fx * (xc * izc) + P.cx, pv = P.fy * (yc * izc) + P.cy;
+      const float fu = floorf((float)pu * scale), fv = floorf((float)pv * scale);
+      const bool okc = has && fu - 3.f >= 0.f && fv - 3.f >= 0.f && fu + 3.f < (float)cols && fv + 3.f < (float)rows;
+      const int cu = okc ? (int)fu : 3, cv = okc ? (int)fv : 3;
+      wc_u0 = (cu - 3) & ~3;
+      const uint8_t* base = cur_img + (int64_t)(cv - 3) * pitch;
+#pragma unroll
+      for (int r = 0; r < (WC ? 7 : 1); ++r) load_row12(base + (int64_t)r * pitch, wc_u0, wc[r]);
+      wc_v0 = okc ? cv - 3 : -100000;
+    }
+#endif
     // ---- precomputeReferencePatches (:84-145) ----------------------------
     {
       double pxx = 0, pxy = 0;
@@ -343,12 +370,6 @@ __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a
     }
     int inH = -1;  // membership of this lane in the sum that g_s.H currently holds
     int evals = 0;
-    uint32_t wc[WC ? 7 : 1][3];
-    int wc_u0 = 0, wc_v0 = -100000;  // cached columns [wc_u0, wc_u0+11], rows [wc_v0, wc_v0+6]
-    if (WC) {
-#pragma unroll
-      for (int r = 0; r < (WC ? 7 : 1); ++r) wc[r][0] = wc[r][1] = wc[r][2] = 0u;
-    }
     SIA_ACC(5, tl0, SIA_T());
     for (int iter = 0; iter < P.n_iter; ++iter) {
       const long long tp0 = SIA_T();
