@@ -126,14 +126,12 @@ __device__ __forceinline__ void sia_rebuild_hinv(int lane, int nw) {
   }
 }
 
-// DIST: the camera is a distorted model (radial-tangential pinhole or ATAN); the undistorted pinhole
-// keeps its own instantiation so that its inner loop carries no model dispatch.
-// The same through a register LDL^T, run by the SOLVER wave itself: H = sum of the per-wave partials
-// (lane k < 21 owns entry k, v_readlane broadcasts them), one unpivoted factorisation executed
-// redundantly by every lane (zero pivot -> 0, as above), then lane j < 6 solves for unit vector j, i.e.
-// row j of the symmetric inverse.  Only the solver wave reads Hinv, so the workgroup needs no second
-// barrier after a rebuild, and the chain is ~200 dependent f64 operations instead of six LDS exchange
-// rounds (measured 4.0k -> see DESIGN section 6 for the phase profile).
+// SIA_LDLT_REBUILD (off by default): the same through a register LDL^T, run by the SOLVER wave itself: H = sum
+// of the per-wave partials (lane k < 21 owns entry k, v_readlane broadcasts them), one unpivoted factorisation
+// executed redundantly by every lane (zero pivot -> 0, as above), then lane j < 6 solves for unit vector j,
+// i.e. row j of the symmetric inverse.  Saves the barrier after a rebuild, but keeps ~84 f64 registers live
+// in a block that runs once per level: with it the 256-lane kernel does not fit 128 VGPRs without spilling in
+// the loop (4 spilled dwords against 2 cold ones; 1.42 against 1.40 ms), so the LDS Gauss-Jordan is the default.
 __device__ __forceinline__ void sia_rebuild_hinv_ldlt(int lane, int nw) {
   asm volatile("" : "+v"(lane));
   double v = 0.0;
@@ -161,6 +159,8 @@ __device__ __forceinline__ void sia_rebuild_hinv_ldlt(int lane, int nw) {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// DIST: the camera is a distorted model (radial-tangential pinhole or ATAN); the undistorted pinhole
+// keeps its own instantiation so that its inner loop carries no model dispatch.
 template <int BLOCK, bool WC, bool DIST>
 __global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a) {
   constexpr int NW = BLOCK / 64;
