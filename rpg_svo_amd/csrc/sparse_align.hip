@@ -44,7 +44,8 @@ namespace {
 // loop (see the opaque copies in the H rebuild) and the Gauss-Jordan rebuild the 256-lane instantiation
 // fits 128 VGPRs = 4 waves per SIMD WITH the window cache, i.e. four frames per CU instead of three
 // (1.40 against 1.50 ms on the headline batch); one 8-byte value is spilled once per level.  64/128-lane
-// workgroups are not limited by registers.
+// workgroups are not limited by registers.  The distorted-camera instantiations (no window cache, the model's
+// world2cam in the loop) stay at 3 waves per SIMD where the workgroup size allows: at 4 they spill 22 dwords.
 #ifndef MINW
 #define MINW(BLOCK) ((BLOCK) >= 256 ? 4 : 3)
 #endif
@@ -162,7 +163,7 @@ __device__ __forceinline__ void sia_rebuild_hinv_ldlt(int lane, int nw) {
 // DIST: the camera is a distorted model (radial-tangential pinhole or ATAN); the undistorted pinhole
 // keeps its own instantiation so that its inner loop carries no model dispatch.
 template <int BLOCK, bool WC, bool DIST>
-__global__ void __launch_bounds__(BLOCK, MINW(BLOCK)) sia_kernel(const SiaArgs a) {
+__global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK)) sia_kernel(const SiaArgs a) {
   constexpr int NW = BLOCK / 64;
   // XCD-aware problem order (capi_common.h): in a replay batch consecutive problems share a frame
   // (frame b+1 is the current image of problem b and the reference image of problem b+1)
