@@ -163,8 +163,8 @@ typedef struct svo_hip_sia_params {
  * Batched SparseImgAlign::run (svo/src/sparse_img_align.cpp:43-75) for B
  * independent (reference frame, current frame) problems.  One workgroup per
  * problem, one lane per 4x4 patch (sparse_align.hip); batches of >= 1024 problems
- * with n_stride <= 192 run one WAVE per problem, a lane carrying up to three
- * patches (sparse_align_wave.hip).  Same arithmetic per patch; the order of the
+ * with n_stride <= 192 (<= 64 under a distorted camera model) run one WAVE per
+ * problem, a lane carrying up to three patches (sparse_align_wave.hip).  Same arithmetic per patch; the order of the
  * (tolerance-mode, f32) sums differs between the two.
  *
  *   d_ref_slot/d_cur_slot [B]   pyramid-store slots of the two frames

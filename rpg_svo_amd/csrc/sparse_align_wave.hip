@@ -674,7 +674,12 @@ namespace svo_sia {
 #ifndef SIAW_MAX_PATCHES
 #define SIAW_MAX_PATCHES 192
 #endif
-bool sia_wave_applies(const SiaArgs& args, int B) { return args.n_stride <= SIAW_MAX_PATCHES && B >= 1024; }
+// Distorted cameras: the model's world2cam in the loop costs registers (26 / 89 spilled dwords at 2 / 3 patches
+// per lane), so they take this kernel only with one patch per lane.
+bool sia_wave_applies(const SiaArgs& args, int B) {
+  const int max_patches = args.P.cam_model == SVO_HIP_CAM_PINHOLE ? SIAW_MAX_PATCHES : 64;
+  return args.n_stride <= max_patches && B >= 1024;
+}
 
 int launch_sia_wave(const SiaArgs& args, int B, hipStream_t s) {
   return args.P.cam_model == SVO_HIP_CAM_PINHOLE ? launch_dist<false>(args, B, s) : launch_dist<true>(args, B, s);
