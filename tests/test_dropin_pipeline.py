@@ -226,3 +226,27 @@ def test_two_cameras_of_different_geometry_in_one_process(pipeline_libs, gpu_dev
     finally:
         pa.close()
         pb.close()
+
+
+@pytest.mark.gpu
+def test_dropin_mapped_arena_follows_the_mirrored_one(pipeline_libs, gpu_device, tmp_path):
+    """SVO_HIP_ARENA=mapped (kernels read and write the pinned host arena, no copy commands) against the default
+    mirrored arena: same kernels on the same bytes.  The mode is fixed when a lane is created, hence one process each."""
+    import subprocess
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {HERE!r}); sys.path.insert(0, {os.path.join(HERE, 'dropin')!r})\n"
+        "import pypipeline as pp\n"
+        "import test_dropin_pipeline as t\n"
+        "cam, imgs, T = t._sequence(40)\n"
+        "hip = pp.run_sequence('hip', cam, imgs, T)\n"
+        "np.save(sys.argv[1], np.stack([r['T_f_w'] for r in hip]))\n")
+    out = {}
+    for mode in ("mirrored", "mapped"):
+        path = str(tmp_path / f"traj_{mode}.npy")
+        p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, SVO_HIP_ARENA=mode), capture_output=True,
+                           text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out[mode] = np.load(path)
+    d = se3.log_norm(out["mapped"], out["mirrored"])
+    assert d.max() <= SE3_LOGNORM_TOL, d.max()
