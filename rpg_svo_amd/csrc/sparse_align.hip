@@ -133,7 +133,7 @@ __device__ __forceinline__ void sia_rebuild_hinv(int lane, int nw) {
 // i.e. row j of the symmetric inverse.  Saves the barrier after a rebuild, but keeps ~84 f64 registers live
 // in a block that runs once per level: with it the 256-lane kernel does not fit 128 VGPRs without spilling in
 // the loop (4 spilled dwords against 2 cold ones; 1.42 against 1.40 ms), so the LDS Gauss-Jordan is the default.
-__device__ __forceinline__ void sia_rebuild_hinv_ldlt(int lane, int nw) {
+[[maybe_unused]] __device__ __forceinline__ void sia_rebuild_hinv_ldlt(int lane, int nw) {
   asm volatile("" : "+v"(lane));
   double v = 0.0;
   if (lane < 21) {
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
   const long long t_begin = SIA_T();
 #endif
   for (int level = P.max_level; level >= P.min_level; --level) {
-    const long long tl0 = SIA_T();
+    [[maybe_unused]] const long long tl0 = SIA_T();
     const int cols = g_s.lw[level], rows = g_s.lh[level], pitch = g_s.lp[level];
     const uint8_t* ref_img = ref_base + g_s.lo[level];
     const uint8_t* cur_img = cur_base + g_s.lo[level];
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
     int evals = 0;
     SIA_ACC(5, tl0, SIA_T());
     for (int iter = 0; iter < P.n_iter; ++iter) {
-      const long long tp0 = SIA_T();
+      [[maybe_unused]] const long long tp0 = SIA_T();
       // -- computeResiduals (:147-243): this lane's patch -------------------
       bool m = false;
       float gx = 0.f, gy = 0.f, c2 = 0.f;
@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
         part[5] = xn_ * gyf - yn_ * gxf;
         part[6] = c2;
         part[7] = m ? 16.f : 0.f;
-        const long long tp1 = SIA_T();
+        [[maybe_unused]] const long long tp1 = SIA_T();
         SIA_ACC(0, tp0, tp1);
         const float tot = wave_reduce8(part, lane);
         if ((lane & 7) == 0) g_s.part[buf][wave][lane >> 3] = tot;
@@ -510,12 +510,12 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
         SIA_ACC(1, tp1, SIA_T());
       }
       // the one workgroup barrier of an iteration
-      const long long tb0 = SIA_T();
+      [[maybe_unused]] const long long tb0 = SIA_T();
       __syncthreads();
       int changed = 0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) changed |= g_s.chg[buf][w];
-      const long long tb1 = SIA_T();
+      [[maybe_unused]] const long long tb1 = SIA_T();
       SIA_ACC(2, tb0, tb1);
       if (changed) {
         // the set of patches inside the current image changed: rebuild H.
@@ -552,7 +552,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
 #endif
       }
       ++evals;
-      const long long ts0 = SIA_T();
+      [[maybe_unused]] const long long ts0 = SIA_T();
       SIA_ACC(3, tb1, ts0);
 #ifdef SIA_PROFILE
       prof[7] += 1;

@@ -382,7 +382,6 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
         Patch& p = pt[k];
-        const int slot = lane + 64 * k;
         bool m = false;
         float gx = 0.f, gy = 0.f, c2 = 0.f;
         if (p.vis) {
