@@ -48,6 +48,7 @@ from rpg_svo_amd.sparse_img_align import SparseImgAlign, marshal_problem  # noqa
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 N_CU = 256
+PMC_PASS_TIMEOUT_S = 90  # per rocprofv3 --pmc child run of the pmc leg
 N_SIMD = 1024          # 256 CUs x 4 SIMD-32
 CLOCK_GHZ = 2.4
 
@@ -752,17 +753,25 @@ def pmc_leg(args, kernel_ms: float) -> dict:
     status, raw = {}, {}
     env = dict(os.environ, TMPDIR="/tmp")
     env.pop("SVO_BENCH_FORCE_DIST", None)
+    # a pass takes ~16 s; a profiler that hangs or fails must not hold the headline line back: one strike and the
+    # remaining passes are skipped (worst case PMC_PASS_TIMEOUT_S on top of the run)
+    broken = False
     for name, ctrs in passes.items():
+        if broken:
+            status[name] = "skipped (an earlier pass failed)"
+            continue
         d = tempfile.mkdtemp(prefix=f"svo_pmc_{name}_", dir="/tmp")
         cmd = [exe, "--pmc", *ctrs, "--kernel-include-regex", "sia_(wave_)?kernel", "--output-format", "csv", "-d", d, "-o", name, "--", *base]
         try:
-            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=PMC_PASS_TIMEOUT_S)
         except subprocess.TimeoutExpired:
             status[name] = "timeout"
+            broken = True
             continue
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if p.returncode != 0 or not files:
             status[name] = f"rc={p.returncode}: {p.stderr[-200:]}"
+            broken = True
             continue
         acc: dict[str, list[float]] = {}
         with open(files[0]) as fh:
