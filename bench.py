@@ -664,8 +664,9 @@ def line_floor_bytes(W: Workload, n_sample: int = 64) -> float:
     """What the gathers of K1 cost at cache-line granularity, per frame: the DISTINCT 128-byte lines of a
     pyramid touched by the 7-row x 12-byte windows the kernel fetches -- as reference frame (its own
     features) and as current frame (the previous frame's features, projected) -- on every level of the
-    schedule.  The algorithmic byte count (49 + 25 I bytes per patch and level) cannot be reached with
-    byte gathers from a row-major image: a 7-row window touches 7..14 lines of 128 bytes."""
+    schedule, in the store's own layout (capi.pyr_px_offset: 16 x 8 pixel tiles of one line each; a 7 x 12
+    window touches 2.6 tiles on average where a row-major level costs it 7..14 lines).  The algorithmic byte
+    count (49 + 25 I bytes per patch and level) is below that floor because a line is fetched whole."""
     lay = W.store.layout
     cam = W.cam
     B = W.B
@@ -686,9 +687,8 @@ def line_floor_bytes(W: Workload, n_sample: int = 64) -> float:
                 u, v = u[ok], v[ok]
                 c0 = (u - 3) & ~3
                 for r in range(-3, 4):
-                    base = lay.offset[l] + (v + r) * lay.pitch[l]
-                    for cb in (c0, c0 + 11):
-                        lines.update(((base + cb) // 128).tolist())
+                    for cb in (c0, c0 + 4, c0 + 8):  # the three aligned dwords of a window row
+                        lines.update((capi.pyr_px_offset(lay, l, cb, v + r) // 128).tolist())
         total += 128.0 * len(lines)
     return total / len(idx)
 

@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
       ref[(size_t)v * W + u] = (uint8_t)std::lround(texture(u, v));
       cur[(size_t)v * W + u] = (uint8_t)std::lround(texture(u - sx, v - sy));  // content moved by (+sx, +sy)
     }
-  // pyramid store with two slots; K0 builds the levels on the device
+  // pyramid store with two slots; K0 fills them on the device
   svo_hip_pyr_layout L;
   CK(svo_hip_pyr_layout_init(W, H, LEVELS, &L));
   void* d_store = NULL;
@@ -50,9 +50,9 @@ int main(int argc, char** argv) {
   CK(svo_hip_memset(d_store, 0, (size_t)svo_hip_pyr_store_bytes(&L, 2), NULL));
   void* stream = NULL;
   CK(svo_hip_stream_create(&stream));
-  CK(svo_hip_pyramid_upload_level0(&L, (uint8_t*)d_store, 0, ref.data(), W, stream));
-  CK(svo_hip_pyramid_upload_level0(&L, (uint8_t*)d_store, 1, cur.data(), W, stream));
-  CK(svo_hip_pyramid_build(&L, (uint8_t*)d_store, 0, 2, SVO_HIP_HALFSAMPLE_AUTO, stream));
+  // image -> packed device scratch (NULL: a stream-ordered temporary) -> one kernel: tiled level 0 + levels 1..
+  CK(svo_hip_pyramid_upload_build(&L, (uint8_t*)d_store, 0, ref.data(), W, SVO_HIP_HALFSAMPLE_AUTO, NULL, stream));
+  CK(svo_hip_pyramid_upload_build(&L, (uint8_t*)d_store, 1, cur.data(), W, SVO_HIP_HALFSAMPLE_AUTO, NULL, stream));
 
   // N features on a grid of the reference frame, all at depth Z: xyz_ref = f * range
   std::vector<double> px((size_t)B * N * 2), xyz((size_t)B * N * 3), Tin((size_t)B * 12, 0.0);

@@ -17,9 +17,11 @@
  *    *_async style work is enqueued on it and NOT synchronised.
  *  - poses are 12 doubles: R row-major [9] followed by t [3]  (T = [R|t]).
  *  - image pyramids live in a "pyramid store": n_slots equally sized slots,
- *    one slot per frame, levels at fixed byte offsets with 64-byte-aligned
- *    row pitch (svo_hip_pyr_layout).  The store needs SVO_HIP_STORE_TAIL_PAD
- *    readable bytes after the last slot.
+ *    one slot per frame, levels at fixed byte offsets (svo_hip_pyr_layout), each
+ *    level cut into tiles of 16 bytes x 8 rows = one 128-byte line (the readers
+ *    gather small 2-D windows).  The store is filled and read through the entry
+ *    points below only; it needs SVO_HIP_STORE_TAIL_PAD readable bytes after the
+ *    last slot.
  */
 #ifndef SVO_HIP_H_
 #define SVO_HIP_H_
@@ -88,10 +90,19 @@ typedef struct svo_hip_pyr_layout {
   int32_t n_levels;
   int32_t w[SVO_HIP_MAX_LEVELS];
   int32_t h[SVO_HIP_MAX_LEVELS];
-  int32_t pitch[SVO_HIP_MAX_LEVELS];  /* bytes per row, multiple of 64          */
-  int64_t offset[SVO_HIP_MAX_LEVELS]; /* byte offset of the level inside a slot */
-  int64_t slot_bytes;                 /* distance between consecutive slots     */
+  int32_t pitch[SVO_HIP_MAX_LEVELS];  /* bytes per image row: w rounded up to 16 */
+  int32_t tile;                       /* SVO_HIP_PYR_*: how (x, y) maps to bytes  */
+  int64_t offset[SVO_HIP_MAX_LEVELS]; /* byte offset of the level inside a slot   */
+  int64_t slot_bytes;                 /* distance between consecutive slots       */
 } svo_hip_pyr_layout;
+
+/* svo_hip_pyr_layout::tile.  TILED (what svo_hip_pyr_layout_init produces): byte offset of pixel (x, y) inside
+ * its level = (y / 8) * 8 * pitch + (x / 16) * 128 + (y % 8) * 16 + x % 16, i.e. 16 x 8 pixel tiles of one
+ * 128-byte line each, the tiles of an 8-row band consecutive; a level occupies pitch * roundup8(h) bytes.
+ * ROWMAJOR (y * pitch + x) exists only in -DSVO_PYR_ROWMAJOR builds of the library (A/B timing); every entry
+ * point rejects a layout of the other kind with SVO_HIP_EINVAL. */
+#define SVO_HIP_PYR_ROWMAJOR 0
+#define SVO_HIP_PYR_TILED 1
 
 /* Level sizes follow frame_utils::createImgPyramid (svo/src/frame.cpp:156-165):
  * level i is (rows/2, cols/2) of level i-1.  Host-only, no GPU needed. */
@@ -104,13 +115,20 @@ int64_t svo_hip_pyr_store_bytes(const svo_hip_pyr_layout* layout, int n_slots);
 int svo_hip_pyramid_load_level0(const svo_hip_pyr_layout* layout, uint8_t* d_store, int first_slot,
                                 int n_slots, const uint8_t* d_images, int64_t image_stride,
                                 int row_stride, void* stream);
-/* Same from host memory (pinned or pageable): H2D copy straight into level 0. */
+/* Same from host memory (pinned or pageable).  The store is tiled, so the image is copied H2D into packed device
+ * scratch and re-tiled from there by a kernel: d_staging = w[level]*h[level] bytes of device memory owned by the
+ * caller that nothing else touches until `stream` has passed this call (one buffer per stream, reused call after
+ * call), or NULL: a stream-ordered temporary (hipMallocAsync / hipFreeAsync) per call. */
 int svo_hip_pyramid_upload_level0(const svo_hip_pyr_layout* layout, uint8_t* d_store, int slot,
-                                  const uint8_t* image, int row_stride, void* stream);
+                                  const uint8_t* image, int row_stride, void* d_staging, void* stream);
 /* One pyramid level of one slot from host memory (an image that is not level 0 of a frame, e.g. the
  * cv::Mat a direct caller hands to feature_alignment::align2D). */
 int svo_hip_pyramid_upload_level(const svo_hip_pyr_layout* layout, uint8_t* d_store, int slot, int level,
-                                 const uint8_t* image, int row_stride, void* stream);
+                                 const uint8_t* image, int row_stride, void* d_staging, void* stream);
+/* A new camera frame in one go (Frame::initFrame, svo/src/frame.cpp:48-59: the image and its pyramid): H2D copy
+ * into the scratch, then ONE kernel that writes level 0 and every further level of the slot. */
+int svo_hip_pyramid_upload_build(const svo_hip_pyr_layout* layout, uint8_t* d_store, int slot, const uint8_t* image,
+                                 int row_stride, int halfsample_mode, void* d_staging, void* stream);
 /* K0: build levels 1..n_levels-1 of slots [first_slot, first_slot+n_slots) from
  * their level 0.  Replaces frame_utils::createImgPyramid -> vk::halfSample
  * (svo/src/frame.cpp:156-165).  Bit-exact with the selected flavour. */

@@ -28,6 +28,7 @@ class PyrLayout(C.Structure):
         ("w", C.c_int32 * MAX_LEVELS),
         ("h", C.c_int32 * MAX_LEVELS),
         ("pitch", C.c_int32 * MAX_LEVELS),
+        ("tile", C.c_int32),  # SVO_HIP_PYR_*: 1 = 16 x 8 tiles (one 128-byte line each), 0 = row-major (A/B builds)
         ("offset", C.c_int64 * MAX_LEVELS),
         ("slot_bytes", C.c_int64),
     ]
@@ -110,8 +111,9 @@ PROTOTYPES = {
     "svo_hip_pyr_layout_init": (_i, [_i, _i, _i, C.POINTER(PyrLayout)]),
     "svo_hip_pyr_store_bytes": (_i64, [C.POINTER(PyrLayout), _i]),
     "svo_hip_pyramid_load_level0": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _i64, _i, _vp]),
-    "svo_hip_pyramid_upload_level0": (_i, [C.POINTER(PyrLayout), _vp, _i, _vp, _i, _vp]),
-    "svo_hip_pyramid_upload_level": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _i, _vp]),
+    "svo_hip_pyramid_upload_level0": (_i, [C.POINTER(PyrLayout), _vp, _i, _vp, _i, _vp, _vp]),
+    "svo_hip_pyramid_upload_level": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _i, _vp, _vp]),
+    "svo_hip_pyramid_upload_build": (_i, [C.POINTER(PyrLayout), _vp, _i, _vp, _i, _i, _vp, _vp]),
     "svo_hip_pyramid_build": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _i, _vp]),
     "svo_hip_pyramid_build_from_images": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _i64, _i, _i, _vp]),
     "svo_hip_pyramid_build_tiled": (_i, [C.POINTER(PyrLayout), _vp, _i, _i, _vp, _i64, _i, _i, _i, _vp]),
@@ -186,6 +188,19 @@ def pyr_layout(width: int, height: int, n_levels: int) -> PyrLayout:
     L = PyrLayout()
     check(load().svo_hip_pyr_layout_init(width, height, n_levels, C.byref(L)), "svo_hip_pyr_layout_init")
     return L
+
+
+PYR_ROWMAJOR, PYR_TILED = 0, 1
+
+
+def pyr_px_offset(L: PyrLayout, level: int, x, y):
+    """Byte offset inside a slot of pixel (x, y) of `level` (ints or integer numpy arrays): the host mirror of
+    csrc/pyr_addr.h for accounting (bench.py's cache-line floor) and tests.  The store itself is only ever
+    filled and read through the library."""
+    p = int(L.pitch[level])
+    if L.tile == PYR_TILED:  # 16 x 8 pixel tiles of 128 bytes, the tiles of an 8-row band consecutive
+        return L.offset[level] + (y >> 3) * (8 * p) + ((y & 7) << 4) + ((x >> 4) << 7) + (x & 15)
+    return L.offset[level] + y * p + x
 
 
 def pyr_store_bytes(L: PyrLayout, n_slots: int) -> int:

@@ -229,14 +229,13 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   w.mode[s] = MODE_SCAN;
 }
 
-// bytes [x0, x0+7] of a row as two dwords
-__device__ __forceinline__ void load_row8(const uint8_t* __restrict__ row, int x0, uint32_t& lo, uint32_t& hi) {
-  const int xa = x0 & ~3;
-  const uint32_t sel = (uint32_t)(x0 & 3);
-  const uint32_t* p = reinterpret_cast<const uint32_t*>(row + xa);
-  const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-  lo = __builtin_amdgcn_alignbyte(d1, d0, sel);
-  hi = __builtin_amdgcn_alignbyte(d2, d1, sel);
+// bytes [x0, x0+7] of the row at byte offset ro (svo_pyr::row_off) as two dwords; c = cols3(x0 & ~3), sel = x0 & 3
+__device__ __forceinline__ void load_row8(const uint8_t* __restrict__ img, uint32_t ro, const svo_pyr::Cols3& c,
+                                          uint32_t sel, uint32_t& lo, uint32_t& hi) {
+  uint32_t d[3];
+  svo_pyr::load3(img, ro, c, d);
+  lo = __builtin_amdgcn_alignbyte(d[1], d[0], sel);
+  hi = __builtin_amdgcn_alignbyte(d[2], d[1], sel);
 }
 
 constexpr int SCAN_BLOCK = 256;
@@ -324,12 +323,13 @@ __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) 
         prv1 = cast_int(pps[1] * inv_lvl + 0.5);
       }
       if (!(pxi0 == prv0 && pxi1 == prv1) && is_in_frame_level(a.cam, pxi0, pxi1, 8, sl)) {
-        const uint8_t* cp = img + (int64_t)(pxi1 - 4) * pitch;
+        const svo_pyr::Cols3 wc3 = svo_pyr::cols3((pxi0 - 4) & ~3);
+        const uint32_t wsel = (uint32_t)((pxi0 - 4) & 3);
         uint32_t sumB = 0, sumBB = 0, sumAB = 0;
 #pragma unroll
         for (int y = 0; y < 8; ++y) {
           uint32_t lo, hi;
-          load_row8(cp + (int64_t)y * pitch, pxi0 - 4, lo, hi);
+          load_row8(img, svo_pyr::row_off(pxi1 - 4 + y, pitch), wc3, wsel, lo, hi);
           sumB = __builtin_amdgcn_udot4(lo, 0x01010101u, sumB, false);
           sumB = __builtin_amdgcn_udot4(hi, 0x01010101u, sumB, false);
           sumBB = __builtin_amdgcn_udot4(lo, lo, sumBB, false);

@@ -10,7 +10,8 @@
 // restatement the reference's own feature_detection.cpp is run on in oracle/_ref.
 //
 //   fast_score_kernel   one lane per pixel and level: ring test at b = 20, bisection score
-//                       -> score map (u8, 0 = no corner), laid out like the pyramid store
+//                       -> score map (u8, 0 = no corner), laid out like the pyramid store (pyr_addr.h);
+//                       a workgroup covers 16 x 16 pixels = two 16 x 8 tiles of the store
 //   fast_select_kernel  one lane per pixel: 3x3 non-max on the score map; survivors compute
 //                       Shi-Tomasi and race for their cell with a 64-bit atomicMax on
 //                       (score bits | ~(level, y, x)), which reproduces "strictly greater
@@ -59,20 +60,25 @@ __device__ __forceinline__ bool is_corner(const int ring[16], int p, int b) {
 __global__ void __launch_bounds__(256) fast_score_kernel(const FastArgs a) {
   const int f = blockIdx.z / a.n_levels, l = blockIdx.z % a.n_levels;
   const int w = a.L.w[l], h = a.L.h[l], pitch = a.L.pitch[l];
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (x >= w || y >= h) return;
   uint8_t* smap = a.score + (int64_t)f * a.L.slot_bytes + a.L.offset[l];
   uint8_t s = 0;
   if (x >= 3 && y >= 3 && x < w - 3 && y < h - 3) {
     const uint8_t* img = a.store + (int64_t)a.slot[f] * a.L.slot_bytes + a.L.offset[l];
-    const uint8_t* c = img + (int64_t)y * pitch + x;
     // Bresenham circle r = 3, clockwise from 12 o'clock
     const int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     const int dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+    uint32_t ro[7], co[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      ro[k] = svo_pyr::row_off(y + k - 3, pitch);
+      co[k] = svo_pyr::col_off(x + k - 3);
+    }
     int ring[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) ring[k] = c[dy[k] * pitch + dx[k]];
-    const int p = *c;
+    for (int k = 0; k < 16; ++k) ring[k] = img[ro[dy[k] + 3] + co[dx[k] + 3]];
+    const int p = img[ro[3] + co[3]];
     if (is_corner(ring, p, a.threshold)) {
       int bmin = a.threshold, bmax = 255, t = (bmax + bmin) / 2;  // fast_corner_score_10
       for (;;) {
@@ -83,20 +89,23 @@ __global__ void __launch_bounds__(256) fast_score_kernel(const FastArgs a) {
       s = (uint8_t)bmin;
     }
   }
-  smap[(int64_t)y * pitch + x] = s;
+  smap[svo_pyr::px_off(x, y, pitch)] = s;
 }
 
 // vk::shiTomasiScore: float sums in the CPU's order
-__device__ __forceinline__ float shi_tomasi(const uint8_t* data, int cols, int rows, int stride, int u, int v) {
+__device__ __forceinline__ float shi_tomasi(const uint8_t* data, int cols, int rows, int pitch, int u, int v) {
   float dXX = 0.0f, dYY = 0.0f, dXY = 0.0f;
   const int x_min = u - 4, x_max = u + 4, y_min = v - 4, y_max = v + 4;
   if (x_min < 1 || x_max >= cols - 1 || y_min < 1 || y_max >= rows - 1) return 0.0f;
+  uint32_t co[10];  // columns x_min-1 .. x_min+8
+#pragma unroll
+  for (int k = 0; k < 10; ++k) co[k] = svo_pyr::col_off(x_min - 1 + k);
   for (int y = y_min; y < y_max; ++y) {
-    const uint8_t* row = data + (int64_t)stride * y + x_min;
+    const uint32_t rm = svo_pyr::row_off(y - 1, pitch), r0 = svo_pyr::row_off(y, pitch), rp = svo_pyr::row_off(y + 1, pitch);
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
-      const float dx = (float)((int)row[x + 1] - (int)row[x - 1]);
-      const float dy = (float)((int)row[x + stride] - (int)row[x - stride]);
+      const float dx = (float)((int)data[r0 + co[x + 2]] - (int)data[r0 + co[x]]);
+      const float dy = (float)((int)data[rp + co[x + 1]] - (int)data[rm + co[x + 1]]);
       dXX += dx * dx;
       dYY += dy * dy;
       dXY += dx * dy;
@@ -112,15 +121,16 @@ __device__ __forceinline__ float shi_tomasi(const uint8_t* data, int cols, int r
 __global__ void __launch_bounds__(256) fast_select_kernel(const FastArgs a) {
   const int f = blockIdx.z / a.n_levels, l = blockIdx.z % a.n_levels;
   const int w = a.L.w[l], h = a.L.h[l], pitch = a.L.pitch[l];
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (x < 3 || y < 3 || x >= w - 3 || y >= h - 3) return;
   const uint8_t* smap = a.score + (int64_t)f * a.L.slot_bytes + a.L.offset[l];
-  const uint8_t* sp = smap + (int64_t)y * pitch + x;
-  const int s = *sp;
+  const uint32_t r0 = svo_pyr::row_off(y, pitch), rm = svo_pyr::row_off(y - 1, pitch), rp = svo_pyr::row_off(y + 1, pitch);
+  const uint32_t c0 = svo_pyr::col_off(x), cm = svo_pyr::col_off(x - 1), cp = svo_pyr::col_off(x + 1);
+  const int s = smap[r0 + c0];
   if (s == 0) return;
   // fast_nonmax_3x3: suppressed by any neighbouring corner with score >= own
-  if (sp[-1] >= s || sp[1] >= s || sp[-pitch - 1] >= s || sp[-pitch] >= s || sp[-pitch + 1] >= s ||
-      sp[pitch - 1] >= s || sp[pitch] >= s || sp[pitch + 1] >= s)
+  if (smap[r0 + cm] >= s || smap[r0 + cp] >= s || smap[rm + cm] >= s || smap[rm + c0] >= s || smap[rm + cp] >= s ||
+      smap[rp + cm] >= s || smap[rp + c0] >= s || smap[rp + cp] >= s)
     return;
   const int scale = 1 << l;
   const int k = ((y * scale) / a.cell_size) * a.grid_n_cols + (x * scale) / a.cell_size;
@@ -188,7 +198,7 @@ int svo_hip_fast_detect(const svo_hip_pyr_layout* L, const uint8_t* d_store, int
   a.detection_threshold = (float)detection_threshold;
   a.out_xy = d_corner_xy; a.out_level = d_corner_level; a.out_score = d_corner_score;
   SVO_HIP_TRY(hipMemsetAsync(a.keys, 0, (size_t)n_frames * n_cells * 8, s));
-  const dim3 block(64, 4, 1);
+  const dim3 block(256, 1, 1);
   int done = 0;
   while (done < n_frames) {  // grid.z limit
     const int chunk = min(n_frames - done, 65535 / n_levels);
@@ -198,7 +208,7 @@ int svo_hip_fast_detect(const svo_hip_pyr_layout* L, const uint8_t* d_store, int
     c.keys = a.keys + (size_t)done * n_cells;
     c.slot = a.slot + done;
     c.occupancy = a.occupancy ? a.occupancy + (size_t)done * n_cells : nullptr;
-    const dim3 grid((L->w[0] + 63) / 64, (L->h[0] + 3) / 4, chunk * n_levels);
+    const dim3 grid((L->w[0] + 15) / 16, (L->h[0] + 15) / 16, chunk * n_levels);
     hipLaunchKernelGGL(fast_score_kernel, grid, block, 0, s, c);
     int rc = check_launch();
     if (rc) return rc;

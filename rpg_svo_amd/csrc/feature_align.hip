@@ -39,12 +39,13 @@ namespace {
 #define ALIGN_OPAQUE_TEMPLATE(g)
 #endif
 
-// bytes [x0, x0+8] of an image row as floats (3 aligned dwords)
-__device__ __forceinline__ void load_row9(const uint8_t* __restrict__ row, int x0, float out[9]) {
-  const int xa = x0 & ~3;
-  const uint32_t sel = (uint32_t)(x0 & 3);
-  const uint32_t* p = reinterpret_cast<const uint32_t*>(row + xa);
-  const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+// bytes [x0, x0+8] of the image row at byte offset ro (svo_pyr::row_off) as floats: 3 aligned dwords,
+// c = cols3(x0 & ~3), sel = x0 & 3
+__device__ __forceinline__ void load_row9(const uint8_t* __restrict__ img, uint32_t ro, const svo_pyr::Cols3& c,
+                                          uint32_t sel, float out[9]) {
+  uint32_t d[3];
+  svo_pyr::load3(img, ro, c, d);
+  const uint32_t d0 = d[0], d1 = d[1], d2 = d[2];
   const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sel);
   const uint32_t mid = __builtin_amdgcn_alignbyte(d2, d1, sel);
   const uint32_t hi = d2 >> (8 * sel);
@@ -122,12 +123,13 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
     const float wBL = (float)((1.0 - subpix_x) * subpix_y);
     const float wBR = subpix_x * subpix_y;
     float Jres0 = 0, Jres1 = 0, Jres2 = 0;
-    const uint8_t* rp = img + (int64_t)(v_r - 4) * pitch;
+    const svo_pyr::Cols3 wc3 = svo_pyr::cols3((u_r - 4) & ~3);
+    const uint32_t wsel = (uint32_t)((u_r - 4) & 3);
     float P0[9], P1[9];
-    load_row9(rp, u_r - 4, P0);
+    load_row9(img, svo_pyr::row_off(v_r - 4, pitch), wc3, wsel, P0);
 #pragma unroll
     for (int y = 0; y < 8; ++y) {
-      load_row9(rp + (int64_t)(y + 1) * pitch, u_r - 4, P1);
+      load_row9(img, svo_pyr::row_off(v_r - 3 + y, pitch), wc3, wsel, P1);
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
         const int c = (y + 1) * 10 + x + 1;
@@ -199,12 +201,13 @@ __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, in
     const float wBL = (float)((1.0 - subpix_x) * subpix_y);
     const float wBR = subpix_x * subpix_y;
     float new_chi2 = 0, Jres0 = 0, Jres1 = 0;
-    const uint8_t* rp = img + (int64_t)(v_r - 4) * pitch;
+    const svo_pyr::Cols3 wc3 = svo_pyr::cols3((u_r - 4) & ~3);
+    const uint32_t wsel = (uint32_t)((u_r - 4) & 3);
     float P0[9], P1[9];
-    load_row9(rp, u_r - 4, P0);
+    load_row9(img, svo_pyr::row_off(v_r - 4, pitch), wc3, wsel, P0);
 #pragma unroll
     for (int y = 0; y < 8; ++y) {
-      load_row9(rp + (int64_t)(y + 1) * pitch, u_r - 4, P1);
+      load_row9(img, svo_pyr::row_off(v_r - 3 + y, pitch), wc3, wsel, P1);
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
         const int c = (y + 1) * 10 + x + 1;

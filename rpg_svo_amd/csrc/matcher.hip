@@ -194,6 +194,10 @@ __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
         float w00[10], w01[10], w10[10], w11[10];
         bool in[10];
         uint16_t top[10], bot[10];
+#if SVO_PYR_TILE
+        uint32_t fix_t[10], fix_b[10];  // where the right-hand pixels live when (xi, xi+1) straddle two tiles
+        bool cross[10];
+#endif
 #pragma unroll
         for (int y = 0; y < 10; ++y) {
           float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
@@ -210,15 +214,33 @@ __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
           w01[y] = (1.0f - sx) * sy;
           w10[y] = sx * (1.0f - sy);
           w11[y] = 1.0f - w00[y] - w01[y] - w10[y];
-          const uint8_t* ptr = img + (int64_t)yi * pitch + xi;
+          const uint32_t rt = svo_pyr::row_off(yi, pitch), rb = svo_pyr::row_off(yi + 1, pitch);
+          const uint32_t cl = svo_pyr::col_off(xi);
           // two unaligned 16-bit loads (gfx950 global memory takes any alignment) instead of four bytes
-          __builtin_memcpy(&top[y], ptr, 2);
+          __builtin_memcpy(&top[y], img + (rt + cl), 2);
 #ifdef WARP_DBG_HALF_LOADS  // timing experiment only (wrong pixels): how much of the kernel is the gathers?
           bot[y] = top[y];
 #else
-          __builtin_memcpy(&bot[y], ptr + pitch, 2);
+          __builtin_memcpy(&bot[y], img + (rb + cl), 2);
+#endif
+#if SVO_PYR_TILE
+          cross[y] = (xi & 15) == 15;  // one column in sixteen: pixel xi+1 is the first byte of the next tile
+          const uint32_t cr = svo_pyr::col_off(xi + 1);
+          fix_t[y] = rt + cr;
+          fix_b[y] = rb + cr;
 #endif
         }
+#if SVO_PYR_TILE
+#pragma unroll
+        for (int y = 0; y < 10; ++y) {
+          if (__builtin_amdgcn_ballot_w64(cross[y]) != 0ull) {
+            if (cross[y]) {
+              top[y] = (uint16_t)((top[y] & 0xffu) | ((uint32_t)img[fix_t[y]] << 8));
+              bot[y] = (uint16_t)((bot[y] & 0xffu) | ((uint32_t)img[fix_b[y]] << 8));
+            }
+          }
+        }
+#endif
 #pragma unroll
         for (int y = 0; y < 10; ++y) {
           const float p00 = (float)(top[y] & 0xffu), p10 = (float)(top[y] >> 8);

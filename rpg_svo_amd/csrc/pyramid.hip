@@ -5,12 +5,14 @@
 // vision.cpp).  Integer work, bit-exact with the CPU routine for either of its
 // two flavours (scalar truncating mean / SSE2 avg-of-avg).
 //
-// HBM-bound streaming kernel: per output dword one lane reads 2 x 8 contiguous
-// bytes (rows are 64-byte aligned in the store, so wave loads are fully
-// coalesced 512-byte segments) and writes 4 bytes.
+// HBM-bound streaming kernel.  The store is TILED (pyr_addr.h: 16 bytes x 8 rows = one 128-byte line per
+// tile, because every reader gathers small 2-D windows); K0 is the only writer, so the tiling costs nothing but
+// address arithmetic here: a lane's 16-byte (level 0), 8-byte (level 1) or 4-byte (levels 2+) piece never
+// crosses a tile row, and the 64 lanes of a wave together still fill whole 128-byte lines.
 #include "capi_common.h"
 
 using namespace svo_capi;
+using svo_pyr::px_off;
 
 namespace {
 
@@ -46,10 +48,9 @@ __global__ void __launch_bounds__(256) half_sample_kernel(uint8_t* __restrict__ 
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x4 * 4 >= out_w || y >= out_h) return;
   uint8_t* slot = store + (int64_t)(first_slot + blockIdx.z) * slot_bytes;
-  const uint8_t* top = slot + in_off + (int64_t)(2 * y) * in_pitch + x4 * 8;
-  const uint2 t = *reinterpret_cast<const uint2*>(top);
-  const uint2 b = *reinterpret_cast<const uint2*>(top + in_pitch);
-  *reinterpret_cast<uint32_t*>(slot + out_off + (int64_t)y * out_pitch + x4 * 4) = half4(t, b, sse2 != 0);
+  const uint2 t = *reinterpret_cast<const uint2*>(slot + in_off + px_off(x4 * 8, 2 * y, in_pitch));
+  const uint2 b = *reinterpret_cast<const uint2*>(slot + in_off + px_off(x4 * 8, 2 * y + 1, in_pitch));
+  *reinterpret_cast<uint32_t*>(slot + out_off + px_off(x4 * 4, y, out_pitch)) = half4(t, b, sse2 != 0);
 }
 
 // ---- fused builder ---------------------------------------------------------
@@ -140,20 +141,20 @@ __global__ void __launch_bounds__(256) pyramid_fused_kernel(const FusedArgs a) {
         if (y0 + 1 < a.h[0]) bot[s] = load16(img + (int64_t)(y0 + 1) * a.row_stride + x0, x0, a.w[0], al);
       }
     } else if (x0 < a.w[0]) {
-      if (y0 < a.h[0]) top[s] = *reinterpret_cast<const uint4*>(slot + (int64_t)y0 * a.pitch[0] + x0);
-      if (y0 + 1 < a.h[0]) bot[s] = *reinterpret_cast<const uint4*>(slot + (int64_t)(y0 + 1) * a.pitch[0] + x0);
+      if (y0 < a.h[0]) top[s] = *reinterpret_cast<const uint4*>(slot + px_off(x0, y0, a.pitch[0]));
+      if (y0 + 1 < a.h[0]) bot[s] = *reinterpret_cast<const uint4*>(slot + px_off(x0, y0 + 1, a.pitch[0]));
     }
   }
-  if (img && x0 < a.w[0]) {  // fill level 0 on the way; rows of the store are padded to 64 B
+  if (img && x0 < a.w[0]) {  // fill level 0 on the way; x0 is a multiple of 16: one tile row per store
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int y0 = blockIdx.y * THT + s * TH + ty * 2;
       if (NT) {
-        if (y0 < a.h[0]) ntstore16(slot + (int64_t)y0 * a.pitch[0] + x0, top[s]);
-        if (y0 + 1 < a.h[0]) ntstore16(slot + (int64_t)(y0 + 1) * a.pitch[0] + x0, bot[s]);
+        if (y0 < a.h[0]) ntstore16(slot + px_off(x0, y0, a.pitch[0]), top[s]);
+        if (y0 + 1 < a.h[0]) ntstore16(slot + px_off(x0, y0 + 1, a.pitch[0]), bot[s]);
       } else {
-        if (y0 < a.h[0]) *reinterpret_cast<uint4*>(slot + (int64_t)y0 * a.pitch[0] + x0) = top[s];
-        if (y0 + 1 < a.h[0]) *reinterpret_cast<uint4*>(slot + (int64_t)(y0 + 1) * a.pitch[0] + x0) = bot[s];
+        if (y0 < a.h[0]) *reinterpret_cast<uint4*>(slot + px_off(x0, y0, a.pitch[0])) = top[s];
+        if (y0 + 1 < a.h[0]) *reinterpret_cast<uint4*>(slot + px_off(x0, y0 + 1, a.pitch[0])) = bot[s];
       }
     }
   }
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(256) pyramid_fused_kernel(const FusedArgs a) {
     *reinterpret_cast<uint2*>(&l1[r1 * W1 + tx * 8]) = make_uint2(lo, hi);
     const int ox = blockIdx.x * W1 + tx * 8, oy = blockIdx.y * (THT / 2) + r1;
     if (oy < a.h[1] && ox < a.w[1]) {
-      uint8_t* dst = slot + a.off[1] + (int64_t)oy * a.pitch[1] + ox;
+      uint8_t* dst = slot + a.off[1] + px_off(ox, oy, a.pitch[1]);
       if (ox + 8 <= a.w[1]) {
         *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
       } else {
@@ -184,7 +185,7 @@ __global__ void __launch_bounds__(256) pyramid_fused_kernel(const FusedArgs a) {
     const uint32_t v = half4(t, b, a.sse2[2] != 0);
     *reinterpret_cast<uint32_t*>(&l2[r * W2 + c * 4]) = v;
     const int ox = blockIdx.x * W2 + c * 4, oy = blockIdx.y * (THT / 4) + r;
-    if (oy < a.h[2] && ox < a.w[2]) store4(slot + a.off[2] + (int64_t)oy * a.pitch[2] + ox, v, ox, a.w[2]);
+    if (oy < a.h[2] && ox < a.w[2]) store4(slot + a.off[2] + px_off(ox, oy, a.pitch[2]), v, ox, a.w[2]);
   }
   if (a.n_levels < 4) return;
   __syncthreads();
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(256) pyramid_fused_kernel(const FusedArgs a) {
     const uint32_t v = half4(t, b, a.sse2[3] != 0);
     *reinterpret_cast<uint32_t*>(&l3[r * W3 + c * 4]) = v;
     const int ox = blockIdx.x * W3 + c * 4, oy = blockIdx.y * (THT / 8) + r;
-    if (oy < a.h[3] && ox < a.w[3]) store4(slot + a.off[3] + (int64_t)oy * a.pitch[3] + ox, v, ox, a.w[3]);
+    if (oy < a.h[3] && ox < a.w[3]) store4(slot + a.off[3] + px_off(ox, oy, a.pitch[3]), v, ox, a.w[3]);
   }
   if (a.n_levels < 5) return;
   __syncthreads();
@@ -205,20 +206,20 @@ __global__ void __launch_bounds__(256) pyramid_fused_kernel(const FusedArgs a) {
     const uint2 b = *reinterpret_cast<const uint2*>(&l3[(2 * r + 1) * W3 + c * 8]);
     const uint32_t v = half4(t, b, a.sse2[4] != 0);
     const int ox = blockIdx.x * (TW / 16) + c * 4, oy = blockIdx.y * (THT / 16) + r;
-    if (oy < a.h[4] && ox < a.w[4]) store4(slot + a.off[4] + (int64_t)oy * a.pitch[4] + ox, v, ox, a.w[4]);
+    if (oy < a.h[4] && ox < a.w[4]) store4(slot + a.off[4] + px_off(ox, oy, a.pitch[4]), v, ox, a.w[4]);
   }
 }
 
-// packed images -> level 0 of the slots; 4 bytes per lane
-__global__ void __launch_bounds__(256) load_level0_kernel(uint8_t* __restrict__ store, int64_t slot_bytes,
-                                                         int first_slot, int pitch, int w, int h,
-                                                         const uint8_t* __restrict__ images,
-                                                         int64_t image_stride, int row_stride) {
+// packed images -> one level of the slots; 4 bytes per lane
+__global__ void __launch_bounds__(256) load_level_kernel(uint8_t* __restrict__ store, int64_t slot_bytes,
+                                                        int first_slot, int64_t level_off, int pitch, int w, int h,
+                                                        const uint8_t* __restrict__ images,
+                                                        int64_t image_stride, int row_stride) {
   const int x4 = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x4 * 4 >= w || y >= h) return;
   const uint8_t* src = images + (int64_t)blockIdx.z * image_stride + (int64_t)y * row_stride + x4 * 4;
-  uint8_t* dst = store + (int64_t)(first_slot + blockIdx.z) * slot_bytes + (int64_t)y * pitch + x4 * 4;
+  uint8_t* dst = store + (int64_t)(first_slot + blockIdx.z) * slot_bytes + level_off + px_off(x4 * 4, y, pitch);
   const int nb = min(4, w - x4 * 4);
   if (nb == 4 && ((reinterpret_cast<uintptr_t>(src) & 3) == 0)) {
     *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
@@ -226,6 +227,38 @@ __global__ void __launch_bounds__(256) load_level0_kernel(uint8_t* __restrict__ 
     for (int k = 0; k < nb; ++k) dst[k] = src[k];
   }
 }
+
+// one level of one slot -> packed rows (w bytes each); one byte per lane (tests / debugging only)
+__global__ void __launch_bounds__(256) unload_level_kernel(const uint8_t* __restrict__ level, int pitch, int w, int h,
+                                                          uint8_t* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  out[(int64_t)y * w + x] = level[px_off(x, y, pitch)];
+}
+
+// Device scratch of the upload entry points: the caller's d_staging, or (d_staging == NULL) a stream-ordered
+// temporary that is released again behind the work that reads it.
+struct Staging {
+  uint8_t* p = nullptr;
+  bool owned = false;
+  hipStream_t s;
+  explicit Staging(hipStream_t stream) : s(stream) {}
+  int get(void* d_staging, size_t bytes) {
+    if (d_staging) {
+      p = static_cast<uint8_t*>(d_staging);
+      return SVO_HIP_OK;
+    }
+    void* t = nullptr;
+    SVO_HIP_TRY(hipMallocAsync(&t, bytes, s));
+    p = static_cast<uint8_t*>(t);
+    owned = true;
+    return SVO_HIP_OK;
+  }
+  ~Staging() {
+    if (owned && p) (void)hipFreeAsync(p, s);
+  }
+};
 
 }  // namespace
 
@@ -241,7 +274,7 @@ int svo_hip_pyramid_load_level0(const svo_hip_pyr_layout* L, uint8_t* d_store, i
   while (done < n_slots) {
     const int chunk = min(n_slots - done, 32768);
     const dim3 grid((L->w[0] / 4 + 1 + 63) / 64, (L->h[0] + 3) / 4, chunk);
-    hipLaunchKernelGGL(load_level0_kernel, grid, block, 0, s, d_store, L->slot_bytes, first_slot + done,
+    hipLaunchKernelGGL(load_level_kernel, grid, block, 0, s, d_store, L->slot_bytes, first_slot + done, (int64_t)0,
                        L->pitch[0], L->w[0], L->h[0], d_images + (int64_t)done * image_stride, image_stride,
                        row_stride);
     int rc = check_launch();
@@ -251,21 +284,31 @@ int svo_hip_pyramid_load_level0(const svo_hip_pyr_layout* L, uint8_t* d_store, i
   return SVO_HIP_OK;
 }
 
+// host image -> packed device scratch -> one (tiled) level of one slot
+static int upload_one_level(const svo_hip_pyr_layout* L, uint8_t* d_store, int slot, int level, const uint8_t* image,
+                            int row_stride, void* d_staging, hipStream_t s) {
+  const int w = L->w[level], h = L->h[level];
+  Staging st(s);
+  int rc = st.get(d_staging, (size_t)w * h);
+  if (rc) return rc;
+  SVO_HIP_TRY(hipMemcpy2DAsync(st.p, w, image, row_stride, w, h, hipMemcpyHostToDevice, s));
+  const dim3 block(64, 4, 1), grid((w / 4 + 1 + 63) / 64, (h + 3) / 4, 1);
+  hipLaunchKernelGGL(load_level_kernel, grid, block, 0, s, d_store, L->slot_bytes, slot, L->offset[level], L->pitch[level],
+                     w, h, st.p, (int64_t)0, w);
+  return check_launch();
+}
+
 int svo_hip_pyramid_upload_level0(const svo_hip_pyr_layout* L, uint8_t* d_store, int slot, const uint8_t* image,
-                                  int row_stride, void* stream) {
+                                  int row_stride, void* d_staging, void* stream) {
   if (!layout_ok(L) || !d_store || !image || slot < 0 || row_stride < L->w[0]) return SVO_HIP_EINVAL;
-  SVO_HIP_TRY(hipMemcpy2DAsync(d_store + (int64_t)slot * L->slot_bytes, L->pitch[0], image, row_stride, L->w[0],
-                               L->h[0], hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
-  return SVO_HIP_OK;
+  return upload_one_level(L, d_store, slot, 0, image, row_stride, d_staging, static_cast<hipStream_t>(stream));
 }
 
 int svo_hip_pyramid_upload_level(const svo_hip_pyr_layout* L, uint8_t* d_store, int slot, int level, const uint8_t* image,
-                                 int row_stride, void* stream) {
+                                 int row_stride, void* d_staging, void* stream) {
   if (!layout_ok(L) || !d_store || !image || slot < 0 || level < 0 || level >= L->n_levels || row_stride < L->w[level])
     return SVO_HIP_EINVAL;
-  SVO_HIP_TRY(hipMemcpy2DAsync(d_store + (int64_t)slot * L->slot_bytes + L->offset[level], L->pitch[level], image, row_stride,
-                               L->w[level], L->h[level], hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
-  return SVO_HIP_OK;
+  return upload_one_level(L, d_store, slot, level, image, row_stride, d_staging, static_cast<hipStream_t>(stream));
 }
 
 static bool tile_ok(int tile_width) {
@@ -387,14 +430,40 @@ int svo_hip_pyramid_build_per_level(const svo_hip_pyr_layout* L, uint8_t* d_stor
   return SVO_HIP_OK;
 }
 
+// A new camera frame in one go: H2D copy of the image into packed scratch, then ONE kernel that writes level 0
+// and every further level of the slot (Frame::initFrame -> createImgPyramid, svo/src/frame.cpp:48-59,156-165).
+int svo_hip_pyramid_upload_build(const svo_hip_pyr_layout* L, uint8_t* d_store, int slot, const uint8_t* image,
+                                 int row_stride, int halfsample_mode, void* d_staging, void* stream) {
+  if (!layout_ok(L) || !d_store || !image || slot < 0 || row_stride < L->w[0]) return SVO_HIP_EINVAL;
+  if (halfsample_mode < SVO_HIP_HALFSAMPLE_SCALAR || halfsample_mode > SVO_HIP_HALFSAMPLE_AUTO)
+    return SVO_HIP_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int w = L->w[0], h = L->h[0];
+  Staging st(s);
+  int rc = st.get(d_staging, (size_t)w * h);
+  if (rc) return rc;
+  SVO_HIP_TRY(hipMemcpy2DAsync(st.p, w, image, row_stride, w, h, hipMemcpyHostToDevice, s));
+  return build_impl(L, d_store, slot, 1, st.p, (int64_t)w * h, w, halfsample_mode, 0, s);
+}
+
 int svo_hip_pyramid_download_level(const svo_hip_pyr_layout* L, const uint8_t* d_store, int slot, int level,
                                    uint8_t* out, void* stream) {
   if (!layout_ok(L) || !d_store || !out || slot < 0 || level < 0 || level >= L->n_levels) return SVO_HIP_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  SVO_HIP_TRY(hipMemcpy2DAsync(out, L->w[level], d_store + (int64_t)slot * L->slot_bytes + L->offset[level],
-                               L->pitch[level], L->w[level], L->h[level], hipMemcpyDeviceToHost, s));
-  SVO_HIP_TRY(hipStreamSynchronize(s));
-  return SVO_HIP_OK;
+  const int w = L->w[level], h = L->h[level];
+  void* tmp = nullptr;
+  SVO_HIP_TRY(hipMalloc(&tmp, (size_t)w * h));
+  const dim3 block(64, 4, 1), grid((w + 63) / 64, (h + 3) / 4, 1);
+  hipLaunchKernelGGL(unload_level_kernel, grid, block, 0, s, d_store + (int64_t)slot * L->slot_bytes + L->offset[level],
+                     L->pitch[level], w, h, static_cast<uint8_t*>(tmp));
+  int rc = check_launch();
+  if (rc == SVO_HIP_OK) {
+    hipError_t e = hipMemcpyAsync(out, tmp, (size_t)w * h, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) rc = hip_fail(e);
+  }
+  (void)hipFree(tmp);
+  return rc;
 }
 
 }  // extern "C"

@@ -290,9 +290,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       const bool okc = has && fu - 3.f >= 0.f && fv - 3.f >= 0.f && fu + 3.f < (float)cols && fv + 3.f < (float)rows;
       const int cu = okc ? (int)fu : 3, cv = okc ? (int)fv : 3;
       wc_u0 = (cu - 3) & ~3;
-      const uint8_t* base = cur_img + (int64_t)(cv - 3) * pitch;
-#pragma unroll
-      for (int r = 0; r < (WC ? 7 : 1); ++r) load_row12(base + (int64_t)r * pitch, wc_u0, wc[r]);
+      load_window12<(WC ? 7 : 1)>(cur_img, pitch, wc_u0, cv - 3, wc);
       wc_v0 = okc ? cv - 3 : -100000;
     }
 #endif
@@ -322,10 +320,12 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
         const float wbr = su * sv;
         float Bt[6][6];
         float Wp[7], Wc[7];
-        load_row7(ref_img + (int64_t)(v_i - 3) * pitch, u_i - 3, Wp);
+        const Cols3 rc = cols3((u_i - 3) & ~3);
+        const uint32_t rsel = (uint32_t)((u_i - 3) & 3);
+        load_row7(ref_img, svo_pyr::row_off(v_i - 3, pitch), rc, rsel, Wp);
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-          load_row7(ref_img + (int64_t)(v_i - 2 + r) * pitch, u_i - 3, Wc);
+          load_row7(ref_img, svo_pyr::row_off(v_i - 2 + r, pitch), rc, rsel, Wc);
 #pragma unroll
           for (int c = 0; c < 6; ++c) {
             const bool need = ((r >= 1 && r <= 4)) || ((c >= 1 && c <= 4));
@@ -432,9 +432,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
             if (!(r0 >= 0 && r0 <= 2 && bo >= 0 && bo <= 7)) {
               wc_v0 = v_i - 3;
               wc_u0 = (u_i - 3) & ~3;
-              const uint8_t* base = cur_img + (int64_t)wc_v0 * pitch;
-#pragma unroll
-              for (int r = 0; r < (WC ? 7 : 1); ++r) load_row12(base + (int64_t)r * pitch, wc_u0, wc[r]);
+              load_window12<(WC ? 7 : 1)>(cur_img, pitch, wc_u0, wc_v0, wc);
               r0 = 1;
               bo = (u_i - 2) - wc_u0;
             }
@@ -449,8 +447,10 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
               cut_row5(d0, d1, d2, bo, kup, W[r]);
             }
           } else {
+            const Cols3 cc = cols3((u_i - 2) & ~3);
+            const uint32_t csel = (uint32_t)((u_i - 2) & 3);
 #pragma unroll
-            for (int r = 0; r < 5; ++r) load_row5(cur_img + (int64_t)(v_i - 2 + r) * pitch, u_i - 2, W[r]);
+            for (int r = 0; r < 5; ++r) load_row5(cur_img, svo_pyr::row_off(v_i - 2 + r, pitch), cc, csel, W[r]);
           }
 #endif
           float Bt[6][6];

@@ -195,9 +195,7 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
       sv_k[k] = v_ref - (float)v_i;
       const int cu = inb ? u_i : 3, cv = inb ? v_i : 3;
       sel_ref[k] = (cu - 3) & 3;
-      const uint8_t* base = ref_img + (int64_t)(cv - 3) * pitch;
-#pragma unroll
-      for (int r = 0; r < 7; ++r) load_row12(base + (int64_t)r * pitch, (cu - 3) & ~3, rw[k][r]);
+      load_window12<7>(ref_img, pitch, (cu - 3) & ~3, cv - 3, rw[k]);
     }
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
@@ -231,9 +229,7 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
       const bool okc = will_see && fu - 3.f >= 0.f && fv - 3.f >= 0.f && fu + 3.f < (float)cols && fv + 3.f < (float)rows;
       const int cu = okc ? (int)fu : 3, cv = okc ? (int)fv : 3;
       const int v0 = cv - 3, u0 = (cu - 3) & ~3;
-      const uint8_t* base = cur_img + (int64_t)v0 * pitch;
-#pragma unroll
-      for (int r = 0; r < 7; ++r) load_row12(base + (int64_t)r * pitch, u0, p.wc[r]);
+      load_window12<7>(cur_img, pitch, u0, v0, p.wc);
       p.wc_u0 = u0;
       p.wc_v0 = okc ? v0 : -100000;
     }
@@ -324,10 +320,12 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
         const float wbr = su * sv;
         float Bt[6][6];
         float Wp[7], Wc[7];
-        load_row7(ref_img + (int64_t)(v_i - 3) * pitch, u_i - 3, Wp);
+        const Cols3 rc = cols3((u_i - 3) & ~3);
+        const uint32_t rsel = (uint32_t)((u_i - 3) & 3);
+        load_row7(ref_img, svo_pyr::row_off(v_i - 3, pitch), rc, rsel, Wp);
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-          load_row7(ref_img + (int64_t)(v_i - 2 + r) * pitch, u_i - 3, Wc);
+          load_row7(ref_img, svo_pyr::row_off(v_i - 2 + r, pitch), rc, rsel, Wc);
 #pragma unroll
           for (int c = 0; c < 6; ++c) {
             const bool need = ((r >= 1 && r <= 4)) || ((c >= 1 && c <= 4));
@@ -427,9 +425,7 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
             if (!(r0 >= 0 && r0 <= 2 && bo >= 0 && bo <= 7)) {
               p.wc_v0 = v_i - 3;
               p.wc_u0 = (u_i - 3) & ~3;
-              const uint8_t* base = cur_img + (int64_t)p.wc_v0 * pitch;
-#pragma unroll
-              for (int r = 0; r < 7; ++r) load_row12(base + (int64_t)r * pitch, p.wc_u0, p.wc[r]);
+              load_window12<7>(cur_img, pitch, p.wc_u0, p.wc_v0, p.wc);
               r0 = 1;
               bo = (u_i - 2) - p.wc_u0;
             }

@@ -38,7 +38,7 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   svo_hip::Lane& lane = dev.lane(L);
   std::lock_guard<std::mutex> guard(lane.mut);
   dev.beginCall(L);
-  svo_hip::StageTimer stage_timer(dev, svo_hip::Device::STAGE_DEPTH_FILTER);
+  svo_hip::StageTimer stage_timer(dev, lane, svo_hip::Device::STAGE_DEPTH_FILTER);
   svo_hip::Arena& a = lane.arena;
   a.reset();
   a.reserve(((size_t)1 << 16) + S * 256 + 4096 * 32);

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include <svo/feature.h>
@@ -49,11 +50,22 @@ inline SE3 poseFromRt(const double in[12]) {
 // Every candidate is verified on independent probes to 1e-8 px; a camera none of them reproduces
 // throws.  Recovered parameters agree with the constructor's to ~1e-13 relative; callers that want
 // them bit-exact register the block they constructed the camera from (registerCamera).
-inline std::map<const vk::AbstractCamera*, svo_hip_camera>& cameraRegistry() {
-  static std::map<const vk::AbstractCamera*, svo_hip_camera> r;
+// The registry is shared by the tracking and the mapping thread (both call cameraOf), so every access
+// holds its mutex; an entry is trusted only while it still reproduces the camera behind the pointer (a
+// camera freed and another allocated at the same address must not inherit stale intrinsics).
+struct CameraRegistry {
+  std::mutex mut;
+  std::map<const vk::AbstractCamera*, svo_hip_camera> map;
+};
+inline CameraRegistry& cameraRegistry() {
+  static CameraRegistry r;
   return r;
 }
-inline void registerCamera(const vk::AbstractCamera* cam, const svo_hip_camera& c) { cameraRegistry()[cam] = c; }
+inline void registerCamera(const vk::AbstractCamera* cam, const svo_hip_camera& c) {
+  CameraRegistry& reg = cameraRegistry();
+  std::lock_guard<std::mutex> g(reg.mut);
+  reg.map[cam] = c;
+}
 
 namespace detail {
 inline void modelWorld2cam(const svo_hip_camera& c, double x, double y, double px[2]) {
@@ -85,10 +97,19 @@ inline bool reproduces(const vk::AbstractCamera* cam, const svo_hip_camera& c) {
 }
 }  // namespace detail
 
+inline svo_hip_camera recoverCamera(const vk::AbstractCamera* cam);
+
 inline svo_hip_camera cameraOf(const vk::AbstractCamera* cam) {
-  std::map<const vk::AbstractCamera*, svo_hip_camera>& reg = cameraRegistry();
-  std::map<const vk::AbstractCamera*, svo_hip_camera>::const_iterator it = reg.find(cam);
-  if (it != reg.end()) return it->second;
+  CameraRegistry& registry = cameraRegistry();
+  std::lock_guard<std::mutex> g(registry.mut);
+  std::map<const vk::AbstractCamera*, svo_hip_camera>::const_iterator it = registry.map.find(cam);
+  if (it != registry.map.end() && it->second.width == cam->width() && it->second.height == cam->height() &&
+      detail::reproduces(cam, it->second))
+    return it->second;
+  return registry.map[cam] = recoverCamera(cam);
+}
+
+inline svo_hip_camera recoverCamera(const vk::AbstractCamera* cam) {
   svo_hip_camera c;
   std::memset(&c, 0, sizeof(c));
   c.width = cam->width(); c.height = cam->height();
@@ -100,7 +121,7 @@ inline svo_hip_camera cameraOf(const vk::AbstractCamera* cam) {
     const Vector2d y = cam->world2cam(Vector2d(0.0, 1.0));
     c.model = SVO_HIP_CAM_PINHOLE;
     c.fx = x[0] - o[0]; c.fy = y[1] - o[1];
-    if (detail::reproduces(cam, c)) return reg[cam] = c;
+    if (detail::reproduces(cam, c)) return c;
   }
   // (2) ATAN: inside r < 0.001 the model is exactly linear
   {
@@ -121,7 +142,7 @@ inline svo_hip_camera cameraOf(const vk::AbstractCamera* cam) {
     a.model = SVO_HIP_CAM_ATAN;
     const double tans = 2.0 * std::tan(s / 2.0);
     a.d[0] = s; a.d[1] = 1.0 / s; a.d[2] = tans; a.d[3] = 1.0 / tans; a.d[4] = 0.0;
-    if (detail::reproduces(cam, a)) return reg[cam] = a;
+    if (detail::reproduces(cam, a)) return a;
   }
   // (3) pinhole + radial-tangential.  On the x axis (y = 0) the model reads
   //        u(x) - cx = fx (x + k1 x^3 + k2 x^5 + k3 x^7) + fx p2 3 x^2,     v(x) - cy = fy p1 x^2
@@ -171,7 +192,7 @@ inline svo_hip_camera cameraOf(const vk::AbstractCamera* cam) {
       const double p2b = ((qyp[0] + qym[0]) / 2 - o[0]) / (r.fx * x * x);
       r.d[2] = 0.5 * (p1a + p1b);
       r.d[3] = 0.5 * (p2a + p2b);
-      if (detail::reproduces(cam, r)) return reg[cam] = r;
+      if (detail::reproduces(cam, r)) return r;
     }
   }
   throw svo_hip::Error("svo_hip drop-in: the camera is none of the vikit models the device implements "

@@ -23,7 +23,7 @@ void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const 
   svo_hip::Lane& lane = dev.lane(L);
   std::lock_guard<std::mutex> guard(lane.mut);
   dev.beginCall(L);
-  svo_hip::StageTimer stage_timer(dev, svo_hip::Device::STAGE_POSE_OPT);
+  svo_hip::StageTimer stage_timer(dev, lane, svo_hip::Device::STAGE_POSE_OPT);
   svo_hip::Arena& a = lane.arena;
   a.reset();
 

@@ -117,7 +117,7 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
       svo_hip::Lane& lane = dev.lane(L);
       std::lock_guard<std::mutex> guard(lane.mut);
       dev.beginCall(L);
-      svo_hip::StageTimer stage_timer(dev, svo_hip::Device::STAGE_REPROJECT);
+      svo_hip::StageTimer stage_timer(dev, lane, svo_hip::Device::STAGE_REPROJECT);
       svo_hip::Arena& a = lane.arena;
       a.reset();
       a.reserve(((size_t)1 << 16) + M * 512 + n_obs * 128 + 4096 * 32);

@@ -39,7 +39,7 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   svo_hip::Lane& lane = dev.lane(L);
   std::lock_guard<std::mutex> guard(lane.mut);
   dev.beginCall(L);
-  svo_hip::StageTimer stage_timer(dev, svo_hip::Device::STAGE_SPARSE_ALIGN);
+  svo_hip::StageTimer stage_timer(dev, lane, svo_hip::Device::STAGE_SPARSE_ALIGN);
 
   const size_t n = ref_frame->fts_.size();
   if (n > SVO_HIP_MAX_PATCHES) throw svo_hip::Error("SparseImgAlign: more than SVO_HIP_MAX_PATCHES features");

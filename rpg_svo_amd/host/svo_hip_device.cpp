@@ -70,7 +70,7 @@ void Arena::fetchBytes(uint8_t* host_block, size_t bytes, void* stream) {
 }
 
 // ---- Device --------------------------------------------------------------------------
-Device::Device() : d_store_(NULL), n_slots_(0), clock_(0) { std::memset(&layout_, 0, sizeof(layout_)); }
+Device::Device() : d_store_(NULL), n_slots_(0), clock_(0), next_lane_index_(0) { std::memset(&layout_, 0, sizeof(layout_)); }
 Device::~Device() { shutdown(); }
 
 namespace {
@@ -108,6 +108,8 @@ Device& Device::instance() {
 Lane* Device::makeLane() {
   Lane* l = new Lane();
   check(svo_hip_stream_create(&l->stream), "svo_hip_stream_create");
+  l->index = next_lane_index_++;
+  check(svo_hip_malloc(&l->d_stage, (size_t)layout_.w[0] * layout_.h[0]), "svo_hip_malloc(stage)");
   l->arena.reserve((size_t)4 << 20);
   // SVO_HIP_ARENA=mapped|mirrored selects how a call's arguments reach the device (Arena)
   const char* mode = std::getenv("SVO_HIP_ARENA");
@@ -135,6 +137,7 @@ void Device::shutdown() {
       if (l.stream) { svo_hip_stream_sync(l.stream); svo_hip_stream_destroy(l.stream); l.stream = NULL; }
       l.arena.release();
       if (l.d_workspace) { svo_hip_free(l.d_workspace); l.d_workspace = NULL; l.workspace_bytes = 0; }
+      if (l.d_stage) { svo_hip_free(l.d_stage); l.d_stage = NULL; }
       delete it->second;
     }
     lanes_.clear();
@@ -168,17 +171,40 @@ void Device::ensureConfigured(int width, int height, int n_levels) {
 }
 
 void Device::beginCall(Lane& lane) {
-  std::lock_guard<std::mutex> g(frames_mut_);
-  for (size_t i = 0; i < lane.touched.size(); ++i) {  // the previous call of this lane is over: unpin
-    std::map<int, Entry>::iterator it = frames_.find(lane.touched[i]);
-    if (it != frames_.end() && it->second.pins > 0) --it->second.pins;
+  {
+    std::lock_guard<std::mutex> g(frames_mut_);
+    for (size_t i = 0; i < lane.touched.size(); ++i) {  // the previous call of this lane is over: unpin
+      std::map<int, Entry>::iterator it = frames_.find(lane.touched[i]);
+      if (it != frames_.end() && it->second.pins > 0) --it->second.pins;
+    }
+    lane.touched.clear();
   }
-  lane.touched.clear();
+  std::lock_guard<std::mutex> g(stats_mut_);
   ++stats.calls;
+}
+
+Device::Stats Device::statsSnapshot() {
+  std::lock_guard<std::mutex> g(stats_mut_);
+  return stats;
+}
+
+void Device::addStage(int stage, double marshal_us, double device_us, double unmarshal_us, double payload_bytes) {
+  std::lock_guard<std::mutex> g(stats_mut_);
+  stats.marshal_us[stage] += marshal_us;
+  stats.device_us[stage] += device_us;
+  stats.unmarshal_us[stage] += unmarshal_us;
+  stats.payload_bytes[stage] += payload_bytes;
+  ++stats.n[stage];
 }
 
 int Device::slotOf(int frame_id, const uint8_t* level0, int stride, Lane& lane) {
   std::lock_guard<std::mutex> g(frames_mut_);
+  const int slot = slotOfLocked(frame_id, level0, stride, lane);
+  if (slot < 0) throw Error("svo_hip::Device::slotOf: frame " + std::to_string(frame_id) + " is not resident and no image was given");
+  return slot;
+}
+
+int Device::slotOfLocked(int frame_id, const uint8_t* level0, int stride, Lane& lane) {
   bool mine = false;
   for (size_t i = 0; i < lane.touched.size(); ++i) mine = mine || lane.touched[i] == frame_id;
   std::map<int, Entry>::iterator it = frames_.find(frame_id);
@@ -187,6 +213,8 @@ int Device::slotOf(int frame_id, const uint8_t* level0, int stride, Lane& lane) 
     if (!mine) { ++it->second.pins; lane.touched.push_back(frame_id); }
     return it->second.slot;
   }
+  if (level0 == NULL) return -1;
+  bool evicted = false;
   if (free_slots_.empty()) {  // evict the least recently used frame no running call has touched
     std::map<int, Entry>::iterator victim = frames_.end();
     for (std::map<int, Entry>::iterator e = frames_.begin(); e != frames_.end(); ++e)
@@ -196,23 +224,33 @@ int Device::slotOf(int frame_id, const uint8_t* level0, int stride, Lane& lane) 
                   " frames resident; configure() a larger pool");
     free_slots_.push_back(victim->second.slot);
     frames_.erase(victim);
-    ++stats.evictions;
+    evicted = true;
   }
   const int slot = free_slots_.back();
   free_slots_.pop_back();
   const double t_up = StageTimer::now();
-  check(svo_hip_pyramid_upload_level0(&layout_, d_store_, slot, level0, stride, lane.stream), "svo_hip_pyramid_upload_level0");
-  check(svo_hip_pyramid_build(&layout_, d_store_, slot, 1, SVO_HIP_HALFSAMPLE_AUTO, lane.stream), "svo_hip_pyramid_build");
-  // another lane may consume this slot next: complete the upload before publishing it
-  check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync(upload)");
+  try {
+    // H2D into the lane's packed staging buffer, then ONE kernel: tiled level 0 + every further level
+    check(svo_hip_pyramid_upload_build(&layout_, d_store_, slot, level0, stride, SVO_HIP_HALFSAMPLE_AUTO, lane.d_stage,
+                                       lane.stream), "svo_hip_pyramid_upload_build");
+    // another lane may consume this slot next: complete the upload before publishing it
+    check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync(upload)");
+  } catch (...) {
+    free_slots_.push_back(slot);  // not published: the slot stays free
+    throw;
+  }
   Entry en;
   en.slot = slot;
   en.last_use = ++clock_;
   en.pins = 1;
   lane.touched.push_back(frame_id);
   frames_[frame_id] = en;
+  const double dt = StageTimer::now() - t_up;
+  lane.pyr_upload_us += dt;
+  std::lock_guard<std::mutex> gs(stats_mut_);
   ++stats.uploads;
-  stats.pyr_upload_us += StageTimer::now() - t_up;
+  if (evicted) ++stats.evictions;
+  stats.pyr_upload_us += dt;
   return slot;
 }
 
@@ -226,21 +264,23 @@ int Device::scratchSlotOf(const uint8_t* image, int w, int h, int stride, int* l
     if (layout_.w[l] == w && layout_.h[l] == h) { level = l; break; }
   if (level < 0)
     throw Error("svo_hip::Device: a " + std::to_string(w) + "x" + std::to_string(h) + " image matches no pyramid level of the device context");
-  // scratch frames live under negative ids, one per level: a blank level-0 upload allocates the slot
-  const int id = -1 - level;
+  // scratch frames live under negative ids, one per (lane, level); look-up-or-create is ONE critical section
+  // (an entry found and then evicted by another lane before it is pinned would otherwise be re-created
+  // from a NULL image)
+  const int id = -1 - (lane.index * SVO_HIP_MAX_LEVELS + level);
   int slot;
   {
     std::lock_guard<std::mutex> g(frames_mut_);
-    std::map<int, Entry>::iterator it = frames_.find(id);
-    slot = it == frames_.end() ? -1 : it->second.slot;
+    slot = slotOfLocked(id, NULL, 0, lane);  // hit: pins it for this call
+    if (slot < 0) {
+      std::vector<uint8_t> blank((size_t)layout_.w[0] * layout_.h[0], 0);
+      slot = slotOfLocked(id, &blank[0], layout_.w[0], lane);  // synchronises: `blank` may go
+    }
   }
-  if (slot < 0) {
-    std::vector<uint8_t> blank((size_t)layout_.w[0] * layout_.h[0], 0);
-    slot = slotOf(id, &blank[0], layout_.w[0], lane);
-  } else {
-    slot = slotOf(id, NULL, 0, lane);  // hit: pins it for this call
-  }
-  check(svo_hip_pyramid_upload_level(&layout_, d_store_, slot, level, image, stride, lane.stream), "svo_hip_pyramid_upload_level");
+  // the lane's stream orders this upload behind the lane's earlier kernels and before its next ones; the
+  // staging buffer is the lane's own (the caller holds lane.mut)
+  check(svo_hip_pyramid_upload_level(&layout_, d_store_, slot, level, image, stride, lane.d_stage, lane.stream),
+        "svo_hip_pyramid_upload_level");
   *level_out = level;
   return slot;
 }

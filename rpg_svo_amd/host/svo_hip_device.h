@@ -4,7 +4,8 @@
 //
 // What it owns (one per process, see Device::instance()):
 //   * the pyramid store in HBM, one slot per live svo::Frame, keyed by Frame::id_; a frame is
-//     uploaded (level 0 H2D + K0 half-sampling on the device, replacing the host pyramid of
+//     uploaded (level 0 H2D into the lane's packed staging buffer + K0, which writes the tiled
+//     level 0 and every further level in one kernel, replacing the host pyramid of
 //     frame_utils::createImgPyramid, svo/src/frame.cpp:156-165, for every device consumer)
 //     the first time a kernel needs it; the pool is an LRU cache (a frame that was evicted
 //     while its host object still lives is simply uploaded again on its next use);
@@ -84,9 +85,12 @@ struct Lane {
   Arena arena;
   void* d_workspace;      // matcher / depth-filter scratch (svo_hip_match_workspace_bytes)
   size_t workspace_bytes;
+  void* d_stage;          // packed level-0 image on its way into the tiled store (svo_hip_pyramid_upload_*)
+  int index;              // unique per lane: scratch frames of different lanes never share a slot
+  double pyr_upload_us;   // time this lane spent uploading pyramids (StageTimer takes it out of "marshal")
   std::mutex mut;
   std::vector<int> touched;  // frames pinned by the lane's current call
-  Lane() : stream(NULL), d_workspace(NULL), workspace_bytes(0) {}
+  Lane() : stream(NULL), d_workspace(NULL), workspace_bytes(0), d_stage(NULL), index(0), pyr_upload_us(0) {}
 };
 
 class Device {
@@ -123,7 +127,9 @@ class Device {
   void forget(int frame_id);
   // A stand-alone image (not level 0 of a svo::Frame) as level *level_out of a scratch slot: the level
   // of the layout whose size is w x h.  Uploaded on every call (the caller's buffer may have changed);
-  // the slot is pinned like a frame until the lane's next beginCall().  Throws when no level matches.
+  // the slot is pinned like a frame until the lane's next beginCall().  Scratch slots belong to ONE lane
+  // (id = -1 - (lane.index * SVO_HIP_MAX_LEVELS + level)): two threads aligning against their own images
+  // never overwrite each other's.  Throws when no level matches.
   int scratchSlotOf(const uint8_t* image, int w, int h, int stride, int* level_out, Lane& lane);
 
   // The calling thread's lane of the given role (created on first use).
@@ -144,7 +150,9 @@ class Device {
       for (int i = 0; i < N_STAGES; ++i) { marshal_us[i] = device_us[i] = unmarshal_us[i] = payload_bytes[i] = 0; n[i] = 0; }
     }
   };
-  Stats stats;
+  Stats stats;             // written under stats_mut_ only; read it through statsSnapshot() while calls run
+  Stats statsSnapshot();
+  void addStage(int stage, double marshal_us, double device_us, double unmarshal_us, double payload_bytes);
 
  private:
   Device();
@@ -160,31 +168,32 @@ class Device {
   uint64_t clock_;
   std::mutex lanes_mut_;
   std::map<std::pair<std::thread::id, int>, Lane*> lanes_;
+  int next_lane_index_;
+  std::mutex stats_mut_;
   Lane* makeLane();
+  // frames_mut_ held: hit -> pin + slot; miss with level0 != NULL -> evict if needed, upload, publish;
+  // miss with level0 == NULL -> -1
+  int slotOfLocked(int frame_id, const uint8_t* level0, int stride, Lane& lane);
 };
 
 // Splits one drop-in call on the host clock (see Device::Stats).  marshal until device(), device until
-// unmarshal(), unmarshal until destruction; time spent uploading pyramids inside the marshal phase is
-// taken out of it.
+// unmarshal(), unmarshal until destruction; time THIS LANE spent uploading pyramids inside the marshal
+// phase is taken out of it (another lane's uploads do not enter: the counter is the lane's own).
 class StageTimer {
  public:
-  StageTimer(Device& dev, int stage) : dev_(dev), stage_(stage), phase_(0), up0_(dev.stats.pyr_upload_us) { t_[0] = now(); }
-  void device(size_t payload_bytes) { t_[1] = now(); phase_ = 1; up1_ = dev_.stats.pyr_upload_us; bytes_ = (double)payload_bytes; }
+  StageTimer(Device& dev, Lane& lane, int stage) : dev_(dev), lane_(lane), stage_(stage), phase_(0), up0_(lane.pyr_upload_us), up1_(0), bytes_(0) { t_[0] = now(); }
+  void device(size_t payload_bytes) { t_[1] = now(); phase_ = 1; up1_ = lane_.pyr_upload_us; bytes_ = (double)payload_bytes; }
   void unmarshal() { t_[2] = now(); phase_ = 2; }
   ~StageTimer() {
     if (phase_ < 2) return;  // the call left early (nothing to do): not a sample
     const double t3 = now();
-    Device::Stats& s = dev_.stats;
-    s.marshal_us[stage_] += (t_[1] - t_[0]) - (up1_ - up0_);
-    s.device_us[stage_] += t_[2] - t_[1];
-    s.unmarshal_us[stage_] += t3 - t_[2];
-    s.payload_bytes[stage_] += bytes_;
-    ++s.n[stage_];
+    dev_.addStage(stage_, (t_[1] - t_[0]) - (up1_ - up0_), t_[2] - t_[1], t3 - t_[2], bytes_);
   }
   static double now();  // microseconds, steady clock
 
  private:
   Device& dev_;
+  Lane& lane_;
   int stage_, phase_;
   double t_[3], up0_, up1_, bytes_;
 };

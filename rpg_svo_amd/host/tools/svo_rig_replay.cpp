@@ -59,13 +59,14 @@ int main(int argc, char** argv) {
   CK(svo_hip_malloc(&d_store, store_bytes));
   CK(svo_hip_memset(d_store, 0, store_bytes, stream));
   std::vector<uint8_t> img((size_t)W * H);
+  void* d_stage = NULL;  // packed image on its way into the tiled store
+  CK(svo_hip_malloc(&d_stage, (size_t)W * H));
   for (int k = 0; k <= n_frames; ++k) {
     for (int v = 0; v < H; ++v)
       for (int u = 0; u < W; ++u) img[(size_t)v * W + u] = (uint8_t)std::lround(texture(u - k * sx, v - k * sy));
-    CK(svo_hip_pyramid_upload_level0(&L, (uint8_t*)d_store, k, img.data(), W, stream));
-    CK(svo_hip_stream_sync(stream));
+    CK(svo_hip_pyramid_upload_build(&L, (uint8_t*)d_store, k, img.data(), W, SVO_HIP_HALFSAMPLE_AUTO, d_stage, stream));
+    CK(svo_hip_stream_sync(stream));  // img and d_stage are reused by the next frame
   }
-  CK(svo_hip_pyramid_build(&L, (uint8_t*)d_store, 0, n_frames + 1, SVO_HIP_HALFSAMPLE_AUTO, stream));
 
   std::vector<double> px((size_t)N * 2), xyz((size_t)N * 3), Tin(12, 0.0);
   for (int i = 0; i < N; ++i) {

@@ -1,9 +1,10 @@
 """Device-resident image pyramids ("pyramid store") -- host mirror of
 svo::Frame::img_pyr_ / frame_utils::createImgPyramid (svo/src/frame.cpp:156-165).
 
-One slot per frame; levels sit at fixed byte offsets with 64-byte aligned row
-pitch (see svo_hip_pyr_layout in include/svo_hip.h).  torch owns the HBM
-allocation; the K0 kernel in libsvo_hip.so fills levels 1.. from level 0.
+One slot per frame; levels sit at fixed byte offsets, each cut into 16 x 8 pixel
+tiles of one 128-byte line (see svo_hip_pyr_layout in include/svo_hip.h): the
+store is filled and read through the library only.  torch owns the HBM
+allocation; the K0 kernel in libsvo_hip.so fills the levels.
 """
 from __future__ import annotations
 
@@ -30,6 +31,8 @@ class PyramidStore:
         self.n_slots = n_slots
         self.halfsample = halfsample
         self.buf = torch.zeros(capi.pyr_store_bytes(self.layout, n_slots), dtype=torch.uint8, device=self.device)
+        # packed level-0 image on its way from the host into the tiled store (upload())
+        self._stage = torch.empty(width * height, dtype=torch.uint8, device=self.device)
 
     @property
     def ptr(self) -> int:
@@ -63,12 +66,17 @@ class PyramidStore:
         """image: uint8 [h,w] host array (a new camera frame)."""
         image = np.ascontiguousarray(image, dtype=np.uint8)
         assert image.shape == (self.layout.h[0], self.layout.w[0])
-        capi.check(self.lib.svo_hip_pyramid_upload_level0(C.byref(self.layout), self.ptr, slot,
-                                                          image.ctypes.data, image.shape[1], _stream_ptr(self.device)),
-                   "svo_hip_pyramid_upload_level0")
-        torch.cuda.current_stream(self.device).synchronize()  # host buffer may go away
-        if build:
-            self.build(slot, 1)
+        if build:  # H2D + one kernel: tiled level 0 and every further level
+            capi.check(self.lib.svo_hip_pyramid_upload_build(C.byref(self.layout), self.ptr, slot, image.ctypes.data,
+                                                             image.shape[1], self.halfsample, self._stage.data_ptr(),
+                                                             _stream_ptr(self.device)),
+                       "svo_hip_pyramid_upload_build")
+        else:
+            capi.check(self.lib.svo_hip_pyramid_upload_level0(C.byref(self.layout), self.ptr, slot,
+                                                              image.ctypes.data, image.shape[1], self._stage.data_ptr(),
+                                                              _stream_ptr(self.device)),
+                       "svo_hip_pyramid_upload_level0")
+        torch.cuda.current_stream(self.device).synchronize()  # host buffer and staging may be reused
 
     def build(self, first_slot: int = 0, n_slots: int | None = None, tile: int = 0) -> None:
         n = self.n_slots - first_slot if n_slots is None else n_slots

@@ -202,8 +202,8 @@ int pipe_add_image(void* h, const uint8_t* img, double timestamp, pipe_result* o
 void pipe_device_stats(uint64_t out[3]) {
   out[0] = out[1] = out[2] = 0;
 #ifdef SVO_PIPELINE_HIP
-  svo_hip::Device& d = svo_hip::Device::instance();
-  out[0] = d.stats.uploads; out[1] = d.stats.evictions; out[2] = d.stats.calls;
+  const svo_hip::Device::Stats st = svo_hip::Device::instance().statsSnapshot();
+  out[0] = st.uploads; out[1] = st.evictions; out[2] = st.calls;
 #endif
 }
 
@@ -212,7 +212,7 @@ void pipe_device_stats(uint64_t out[3]) {
 void pipe_stage_times(double out[21]) {
   for (int i = 0; i < 21; ++i) out[i] = 0;
 #ifdef SVO_PIPELINE_HIP
-  const svo_hip::Device::Stats& s = svo_hip::Device::instance().stats;
+  const svo_hip::Device::Stats s = svo_hip::Device::instance().statsSnapshot();
   for (int k = 0; k < svo_hip::Device::N_STAGES; ++k) {
     out[5 * k] = (double)s.n[k]; out[5 * k + 1] = s.marshal_us[k]; out[5 * k + 2] = s.device_us[k];
     out[5 * k + 3] = s.unmarshal_us[k]; out[5 * k + 4] = s.payload_bytes[k];

@@ -30,11 +30,31 @@ def test_layout_is_host_only(hip_lib):
     from rpg_svo_amd import capi
     L = capi.pyr_layout(640, 480, 4)
     assert list(L.w[:4]) == [640, 320, 160, 80] and list(L.h[:4]) == [480, 240, 120, 60]
-    assert all(p % 64 == 0 for p in L.pitch[:4])
+    assert L.tile == capi.PYR_TILED and all(p % 16 == 0 and p >= w for p, w in zip(L.pitch[:4], L.w[:4]))
+    assert all(o % 128 == 0 for o in L.offset[:4])  # a 16 x 8 tile is one 128-byte line
     assert L.slot_bytes % 4096 == 0 and L.slot_bytes >= 408000
     L5 = capi.pyr_layout(752, 480, 5)
     assert list(L5.w[:5]) == [752, 376, 188, 94, 47] and list(L5.h[:5]) == [480, 240, 120, 60, 30]
     assert capi.pyr_store_bytes(L, 3) == 3 * L.slot_bytes + capi.STORE_TAIL_PAD
+
+
+def test_tiled_addressing_is_a_bijection(hip_lib):
+    """Every pixel of every level has its own byte inside the slot, levels do not overlap, and the bytes of a
+    16 x 8 pixel tile form one 128-byte line (the host mirror of csrc/pyr_addr.h)."""
+    import numpy as np
+    from rpg_svo_amd import capi
+    for (w, h, n) in ((640, 480, 4), (752, 480, 5), (100, 37, 3)):
+        L = capi.pyr_layout(w, h, n)
+        seen = np.zeros(L.slot_bytes, dtype=np.int32)
+        for l in range(n):
+            ys, xs = np.mgrid[0:L.h[l], 0:L.w[l]]
+            off = capi.pyr_px_offset(L, l, xs, ys)
+            assert off.min() >= L.offset[l] and off.max() < L.slot_bytes
+            np.add.at(seen, off.ravel(), 1)
+            if L.w[l] >= 32 and L.h[l] >= 16:
+                tile = capi.pyr_px_offset(L, l, xs[8:16, 16:32], ys[8:16, 16:32])
+                assert tile.max() - tile.min() == 127 and tile.min() % 128 == 0
+        assert seen.max() == 1
 
 
 def test_error_strings(hip_lib):
