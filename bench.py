@@ -58,7 +58,7 @@ WORKLOADS = {
     "svo_default_752_l4to2_n120": (752, 480, 315.5, 5, 4, 2, 120, 56, 40),
     "xga5_n1000_sparse_align": (1280, 960, 800.0, 5, 4, 0, 1000, 56, 32),
 }
-EXTRA_KEYS = {"refine": "align_plus_refine", "full": "full_track", "noise": "noise_sigma2", "config3": "config3_xga5_b64",
+EXTRA_KEYS = {"f64": "f64_partials", "refine": "align_plus_refine", "full": "full_track", "noise": "noise_sigma2", "config3": "config3_xga5_b64",
               "k0": "k0_pyramid", "dropin": "dropin_sequence"}
 
 
@@ -237,11 +237,12 @@ def main() -> None:
                          "headline); full: configs[2] -- the whole track is the step (the default run reports it as the "
                          "extra key full_track instead)")
     ap.add_argument("--extras", default="all",
-                    help="comma list of the extra legs to run at N=1 (all, none, or any of: refine, full, noise, config3, rig, "
-                         "k0, dropin, pmc)")
+                    help="comma list of the extra legs to run at N=1 (all, none, or any of: f64, refine, full, noise, config3, "
+                         "rig, k0, dropin, pmc)")
     ap.add_argument("--k1-kernel", default="auto", choices=["auto", "workgroup"],
                     help="auto: svo_hip_sparse_align (one wave per frame up to 256 patches); workgroup: the workgroup-per-frame kernel")
     ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--dump-result", default="", help=argparse.SUPPRESS)  # child of the f64_partials leg: poses + iteration counts
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -272,7 +273,7 @@ def main() -> None:
     lib = capi.load()
     ev = Events(lib, dev)
     if args.extras == "all":
-        extras = {"refine", "full", "noise", "config3", "rig", "k0", "dropin", "pmc"}
+        extras = {"f64", "refine", "full", "noise", "config3", "rig", "k0", "dropin", "pmc"}
     elif args.extras == "none":
         extras = set()
     else:
@@ -413,7 +414,10 @@ def main() -> None:
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 pixels / f64 pose+normal equations",
+        # what the arithmetic of K1 is carried out in (the reference: f32 pixels / chi2, f64 everything else)
+        "dtype": "f32 pixels, residuals and chi2; f32 Jacobian rows and per-lane Jres/H partials, tree-reduced per wave "
+                 "(reference: f64, sequential); f64 projection, cross-wave sums, 6x6 solve and pose; f32 series for SE3::exp "
+                 "(reference: f64) -- see f64_partials for the reference-width build",
         "data": "synthetic",
         "config": {
             "workload": args.workload if full is None else args.workload.replace("sparse_align", "full_track"),
@@ -436,6 +440,8 @@ def main() -> None:
                              us_per_gn_iteration_of_the_batch=kernel_ms * 1e3 / max(float(iters.sum(1).mean()), 1e-9)),
         "setup_s": t_gen,
     }
+    if args.dump_result:
+        np.savez(args.dump_result, T_est_w=st["T_est_w"], iters=out.iters.cpu().numpy())
     if args.pmc_child:  # child of the PMC leg: nothing else is needed from this process
         print(json.dumps(result))
         return
@@ -467,6 +473,7 @@ def main() -> None:
             result["cpu_baseline"] = cpu_baseline(args, W, st["T_est_w"], result, out.iters.cpu().numpy())
         except Exception as e:
             result["cpu_baseline"] = {"skipped": repr(e)}
+    leg("f64", lambda: f64_partials_leg(args, st["T_est_w"], out.iters.cpu().numpy(), result))
     leg("refine", lambda: align_plus_refine(W, sia, ev, dev, args.steps))
     leg("full", lambda: full_track_leg(W, sia, ev, dev, rank, lib, not args.no_cpu_baseline))
     leg("k0", lambda: pyramid_roofline(ev, store, W.images))
@@ -861,6 +868,50 @@ def dropin_sequence(n_frames: int = 120) -> dict:
             "pyramid_uploads": host.get("uploads"), "pyramid_upload_us_per_frame": host.get("pyramid_upload_us_total", 0.0) / n_frames}
 
 
+_CPU_REF: dict = {}  # poses and iteration counts of the CPU reference run (cpu_baseline), for the f64_partials leg
+
+F64_VARIANT_LIB = os.path.join(ROOT, "rpg_svo_amd", "lib", "variants", "libsvo_hip_SIA_F64_PARTIALS.so")
+
+
+def f64_partials_leg(args, T_default, iters_default, result) -> dict:
+    """What reference-width arithmetic costs and buys.  The default K1 keeps Jacobian rows, per-pixel products,
+    per-lane partials and the wave reductions in f32 and evaluates SE3::exp as an f32 series; the reference keeps
+    them in f64 (sparse_img_align.cpp:228-230,253-258).  The same library built with -DSIA_F64_PARTIALS (built by
+    __graft_entry__.build()) does it the reference's way: this leg re-runs the headline workload on it in a child
+    process and reports its frames/s and its agreement with the CPU reference next to the default's."""
+    import tempfile
+    if not os.path.exists(F64_VARIANT_LIB):
+        return {"skipped": F64_VARIANT_LIB + " not built (python -m rpg_svo_amd.build -DSIA_F64_PARTIALS)"}
+    dump = tempfile.mktemp(suffix=".npz", dir="/tmp")
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(min(args.steps, 20)), "--warmup", "3", "--batch", str(args.batch),
+           "--workload", args.workload, "--noise", str(args.noise), "--n-iter", str(args.n_iter), "--no-cpu-baseline",
+           "--extras", "none", "--pmc-child", "f64", "--k1-kernel", "workgroup", "--dump-result", dump]
+    env = dict(os.environ, SVO_HIP_LIB=F64_VARIANT_LIB)
+    env.pop("SVO_BENCH_FORCE_DIST", None)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    if p.returncode != 0:
+        return {"skipped": f"child rc={p.returncode}: {p.stderr[-300:]}"}
+    child = json.loads(p.stdout.strip().splitlines()[-1])
+    z = np.load(dump)
+    os.unlink(dump)
+    T64, it64 = z["T_est_w"], z["iters"]
+    out = {"build": "-DSIA_F64_PARTIALS: f64 Jacobian rows, per-pixel products, per-lane partials, wave reductions and SE3::exp "
+                    "(142 VGPRs, 3 waves/SIMD instead of 128 / 4)",
+           "frames_per_s": child["value"], "kernel_ms": child["roofline"]["ms"],
+           "frames_per_s_default": result["value"], "kernel_ms_default": result["roofline"]["ms"],
+           "slowdown": result["value"] / child["value"],
+           "vs_default_kernel": {"se3_lognorm_max": float(se3.log_norm(T64, T_default).max()),
+                                 "same_iteration_counts_frac": float(np.mean((it64 == iters_default).all(1)))}}
+    if _CPU_REF:
+        S = len(_CPU_REF["iters"])
+        for name, T, it in (("f64_partials", T64, it64), ("default", T_default, iters_default)):
+            d = se3.log_norm(T[:S], _CPU_REF["T"])
+            out[f"{name}_vs_cpu_{_CPU_REF['which']}"] = {
+                "frames_compared": S, "se3_lognorm_max": float(d.max()), "se3_lognorm_median": float(np.median(d)),
+                "same_iteration_counts_frac": float(np.mean([np.array_equal(a, b) for a, b in zip(_CPU_REF["iters"], it[:S])]))}
+    return out
+
+
 def cpu_baseline(args, W: Workload, T_est_w, result, iters_gpu) -> dict:
     """Times the reference's own SparseImgAlign translation unit (oracle/_ref, kind "reference";
     the C port where that library is absent) on a bounded sample of the same problems, on this
@@ -901,6 +952,7 @@ def cpu_baseline(args, W: Workload, T_est_w, result, iters_gpu) -> dict:
             sweep[str(th)] = k / tt
             if k / tt > best_rate:
                 best_threads, best_rate = th, k / tt
+    _CPU_REF.update(T=T_cpu, iters=[r["iters"] for r in res], which=which)
     d = se3.log_norm(T_est_w[:S], T_cpu)
     pos_gpu = se3.inv(T_est_w[:S])[:, 9:]
     pos_cpu = se3.inv(T_cpu)[:, 9:]

@@ -140,7 +140,7 @@ int svo_hip_pyramid_build_from_images(const svo_hip_pyr_layout* layout, uint8_t*
                                       int n_slots, const uint8_t* d_images, int64_t image_stride,
                                       int row_stride, int halfsample_mode, void* stream);
 /* The two builders above with the level-0 tile of the fused kernel chosen by the caller instead of
- * by image size: 128 (128x64), 256 (256x32), 257 (256x32 with non-temporal level-0 traffic), 512
+ * by image size: 128 (128x64), 256 (256x32), 257 (256x32 with non-temporal source loads), 512
  * (256x64, two row blocks per lane), 0 = automatic (257 for widths >= 256).  d_images may be NULL
  * (level 0 already in the store).  Results do not depend on the tile; there is no global state. */
 int svo_hip_pyramid_build_tiled(const svo_hip_pyr_layout* layout, uint8_t* d_store, int first_slot, int n_slots,

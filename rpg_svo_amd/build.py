@@ -35,15 +35,18 @@ def _compile_one(src: str, obj: str, defines: list[str], verbose: bool) -> None:
     subprocess.run(cmd, check=True)
 
 
-def build_hip(force: bool = False, verbose: bool = False, defines: list[str] | None = None) -> str:
+def build_hip(force: bool = False, verbose: bool = False, defines: list[str] | None = None, out: str | None = None) -> str:
     """One object per translation unit (rebuilt only when it or a header changed), compiled in
-    parallel, then linked into libsvo_hip.so."""
+    parallel, then linked into libsvo_hip.so.  With `defines` (a WHOLE-LIBRARY variant for A/B timing, e.g.
+    ["SVO_PYR_ROWMAJOR"]) the objects and the library go to build/obj_<defines>/ and
+    build/variants/libsvo_hip_<defines>.so (or `out`); load it with SVO_HIP_LIB=<that file>."""
     from concurrent.futures import ThreadPoolExecutor
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
     objdir = os.path.join(ROOT, "build", "obj" + ("_" + "_".join(defines) if defines else ""))
+    lib = out or (os.path.join(ROOT, "build", "variants", "libsvo_hip_" + "_".join(defines) + ".so") if defines else LIB)
     os.makedirs(objdir, exist_ok=True)
-    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
     todo, objs = [], []
     for src in srcs:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
@@ -53,13 +56,14 @@ def build_hip(force: bool = False, verbose: bool = False, defines: list[str] | N
     if todo:
         with ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
             list(ex.map(lambda so: _compile_one(so[0], so[1], defines or [], verbose), todo))
-    if todo or force or not _newer(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lhipsolver", "-o", LIB]
+    if todo or force or not _newer(lib, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lhipsolver", "-o", lib]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_hip(force="--force" in sys.argv, verbose=True))
+    # python -m rpg_svo_amd.build [--force] [-DFOO ...]: the in-tree library, or a whole-library variant
+    print(build_hip(force="--force" in sys.argv, verbose=True, defines=[a[2:] for a in sys.argv[1:] if a.startswith("-D")] or None))

@@ -190,63 +190,77 @@ __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
         const uint8_t* img = a.store + (int64_t)slot * a.L.slot_bytes + s_off[level];
         const int cols = s_w[level], rows = s_h[level], pitch = s_p[level];
         const float sc = (float)(1 << slev);
-        // round 2: addresses and weights of the ten samples of this column, then all twenty loads
-        float w00[10], w01[10], w10[10], w11[10];
-        bool in[10];
-        uint16_t top[10], bot[10];
+        // round 2, five output rows at a time: addresses and weights of the five samples of this column, then all
+        // their loads, then the arithmetic.  A sample reads the 2 x 2 pixels (xi, yi) .. (xi+1, yi+1) as two 16-bit
+        // loads (gfx950 global memory takes any alignment).  In the tiled store the pair (xi, xi+1) straddles two
+        // tiles for one column in sixteen: those lanes fetch their right-hand pixels with two byte loads more, issued
+        // together with everything else (a fix-up that waited for its own round trip per row cost +70 %).
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float w00[5], w01[5], w10[5], w11[5];
+          bool in[5];
+          uint16_t top[5], bot[5];
 #if SVO_PYR_TILE
-        uint32_t fix_t[10], fix_b[10];  // where the right-hand pixels live when (xi, xi+1) straddle two tiles
-        bool cross[10];
+          uint32_t fix_t[5], fix_b[5];
+          uint8_t rt8[5], rb8[5];
+          bool cross[5];
+          bool any_cross = false;
 #endif
 #pragma unroll
-        for (int y = 0; y < 10; ++y) {
-          float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
-          pp0 *= sc;
-          pp1 *= sc;
-          const float px0 = (A.x * pp0 + A.y * pp1) + pyr.x;
-          const float px1 = (A.z * pp0 + A.w * pp1) + pyr.y;
-          in[y] = !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
-          // vk::interpolateMat_8u; samples outside the image read pixel (0,0) and are discarded
-          const float u = in[y] ? px0 : 0.f, v = in[y] ? px1 : 0.f;
-          const int xi = (int)floorf(u), yi = (int)floorf(v);
-          const float sx = u - (float)xi, sy = v - (float)yi;
-          w00[y] = (1.0f - sx) * (1.0f - sy);
-          w01[y] = (1.0f - sx) * sy;
-          w10[y] = sx * (1.0f - sy);
-          w11[y] = 1.0f - w00[y] - w01[y] - w10[y];
-          const uint32_t rt = svo_pyr::row_off(yi, pitch), rb = svo_pyr::row_off(yi + 1, pitch);
-          const uint32_t cl = svo_pyr::col_off(xi);
-          // two unaligned 16-bit loads (gfx950 global memory takes any alignment) instead of four bytes
-          __builtin_memcpy(&top[y], img + (rt + cl), 2);
+          for (int k = 0; k < 5; ++k) {
+            const int y = 5 * h + k;
+            float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
+            pp0 *= sc;
+            pp1 *= sc;
+            const float px0 = (A.x * pp0 + A.y * pp1) + pyr.x;
+            const float px1 = (A.z * pp0 + A.w * pp1) + pyr.y;
+            in[k] = !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
+            // vk::interpolateMat_8u; samples outside the image read pixel (0,0) and are discarded
+            const float u = in[k] ? px0 : 0.f, v = in[k] ? px1 : 0.f;
+            const int xi = (int)floorf(u), yi = (int)floorf(v);
+            const float sx = u - (float)xi, sy = v - (float)yi;
+            w00[k] = (1.0f - sx) * (1.0f - sy);
+            w01[k] = (1.0f - sx) * sy;
+            w10[k] = sx * (1.0f - sy);
+            w11[k] = 1.0f - w00[k] - w01[k] - w10[k];
+            const uint32_t rt = svo_pyr::row_off(yi, pitch), rb = svo_pyr::row_off(yi + 1, pitch);
+            const uint32_t cl = svo_pyr::col_off(xi);
+            __builtin_memcpy(&top[k], img + (rt + cl), 2);
 #ifdef WARP_DBG_HALF_LOADS  // timing experiment only (wrong pixels): how much of the kernel is the gathers?
-          bot[y] = top[y];
+            bot[k] = top[k];
 #else
-          __builtin_memcpy(&bot[y], img + (rb + cl), 2);
+            __builtin_memcpy(&bot[k], img + (rb + cl), 2);
 #endif
 #if SVO_PYR_TILE
-          cross[y] = (xi & 15) == 15;  // one column in sixteen: pixel xi+1 is the first byte of the next tile
-          const uint32_t cr = svo_pyr::col_off(xi + 1);
-          fix_t[y] = rt + cr;
-          fix_b[y] = rb + cr;
+            cross[k] = (xi & 15) == 15;  // pixel xi+1 is the first byte of the next tile
+            any_cross = any_cross || cross[k];
+            fix_t[k] = rt + cl + 113u;   // col_off(xi + 1) - col_off(xi) when xi % 16 == 15
+            fix_b[k] = rb + cl + 113u;
+            rt8[k] = rb8[k] = 0;
 #endif
-        }
-#if SVO_PYR_TILE
-#pragma unroll
-        for (int y = 0; y < 10; ++y) {
-          if (__builtin_amdgcn_ballot_w64(cross[y]) != 0ull) {
-            if (cross[y]) {
-              top[y] = (uint16_t)((top[y] & 0xffu) | ((uint32_t)img[fix_t[y]] << 8));
-              bot[y] = (uint16_t)((bot[y] & 0xffu) | ((uint32_t)img[fix_b[y]] << 8));
-            }
           }
-        }
+#if SVO_PYR_TILE
+          if (any_cross) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+              if (cross[k]) {
+                rt8[k] = img[fix_t[k]];
+                rb8[k] = img[fix_b[k]];
+              }
+          }
 #endif
 #pragma unroll
-        for (int y = 0; y < 10; ++y) {
-          const float p00 = (float)(top[y] & 0xffu), p10 = (float)(top[y] >> 8);
-          const float p01 = (float)(bot[y] & 0xffu), p11 = (float)(bot[y] >> 8);
-          const float val = w00[y] * p00 + w01[y] * p01 + w10[y] * p10 + w11[y] * p11;
-          out[y] = in[y] ? (uint8_t)val : (uint8_t)0;
+          for (int k = 0; k < 5; ++k) {
+#if SVO_PYR_TILE
+            const float p10 = cross[k] ? (float)rt8[k] : (float)(top[k] >> 8);
+            const float p11 = cross[k] ? (float)rb8[k] : (float)(bot[k] >> 8);
+#else
+            const float p10 = (float)(top[k] >> 8), p11 = (float)(bot[k] >> 8);
+#endif
+            const float p00 = (float)(top[k] & 0xffu), p01 = (float)(bot[k] & 0xffu);
+            const float val = w00[k] * p00 + w01[k] * p01 + w10[k] * p10 + w11[k] * p11;
+            out[5 * h + k] = in[k] ? (uint8_t)val : (uint8_t)0;
+          }
         }
       }
 #pragma unroll

@@ -36,11 +36,6 @@ constexpr int PW_WAVES = 4;  // frames per workgroup
 #endif
 constexpr double SVO_EPS = 0.0000000001;  // svo/include/svo/global.h:77
 
-__device__ __forceinline__ double mk_f64(uint32_t lo, uint32_t hi) {
-  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ uint32_t lo32(double v) { return (uint32_t)__double_as_longlong(v); }
-__device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)((unsigned long long)__double_as_longlong(v) >> 32); }
 
 // A wave-uniform value computed by the VALU lives in a VGPR pair; reading it back through
 // v_readfirstlane moves it to SGPRs.  The pose (R, t, quaternion, rollback copy) is 38 doubles:
@@ -57,24 +52,6 @@ __device__ __forceinline__ void uni_se3(Se3& T) {
   for (int k = 0; k < 3; ++k) T.t[k] = uni(T.t[k]);
 }
 
-// lanes < 32: a[l] + a[l+32];  lanes >= 32: b[l-32] + b[l]
-__device__ __forceinline__ double swap32_add(double a, double b) {
-  auto s0 = __builtin_amdgcn_permlane32_swap(lo32(a), lo32(b), false, false);
-  auto s1 = __builtin_amdgcn_permlane32_swap(hi32(a), hi32(b), false, false);
-  return mk_f64(s0[0], s1[0]) + mk_f64(s0[1], s1[1]);
-}
-// even 16-lane rows: a[l] + a[l+16];  odd rows: b[l-16] + b[l]
-__device__ __forceinline__ double swap16_add(double a, double b) {
-  auto s0 = __builtin_amdgcn_permlane16_swap(lo32(a), lo32(b), false, false);
-  auto s1 = __builtin_amdgcn_permlane16_swap(hi32(a), hi32(b), false, false);
-  return mk_f64(s0[0], s1[0]) + mk_f64(s0[1], s1[1]);
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-  const uint32_t l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo32(v), CTRL, 0xf, 0xf, true);
-  const uint32_t h = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi32(v), CTRL, 0xf, 0xf, true);
-  return mk_f64(l, h);
-}
 
 // Sums v[0..31] over the 64 lanes.  On return lanes 2j and 2j+1 hold the wave total of v[j].
 __device__ __forceinline__ double wave_reduce32_f64(const double v[32], int lane) {

@@ -29,16 +29,28 @@ namespace svo_pyr {
 
 constexpr int TILE_W = 16, TILE_H = 8;
 
+// a * b for factors below 2^24 (rows, columns, band strides): v_mul_u32_u24 / v_mad_u32_u24 on the device,
+// where a full 32-bit multiply issues at quarter rate
+__host__ __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __umul24(a, b);
+#else
+  return a * b;
+#endif
+}
+
 __host__ __device__ __forceinline__ uint32_t row_off(int y, int pitch) {
 #if SVO_PYR_TILE
-  return (uint32_t)(y >> 3) * ((uint32_t)pitch << 3) + ((uint32_t)(y & 7) << 4);
+  // == (y >> 3) * 8 * pitch + (y & 7) * 16, as one shift and two multiply-adds (v_mad_u32_u24)
+  return mul24((uint32_t)(y >> 3), ((uint32_t)pitch << 3) - 128u) + ((uint32_t)y << 4);
 #else
-  return (uint32_t)y * (uint32_t)pitch;
+  return mul24((uint32_t)y, (uint32_t)pitch);
 #endif
 }
 __host__ __device__ __forceinline__ uint32_t col_off(int x) {
 #if SVO_PYR_TILE
-  return (((uint32_t)x & ~15u) << 3) | ((uint32_t)x & 15u);
+  // == (x >> 4) * 128 + (x & 15), as one shift and one multiply-add
+  return mul24((uint32_t)(x >> 4), 112u) + (uint32_t)x;
 #else
   return (uint32_t)x;
 #endif

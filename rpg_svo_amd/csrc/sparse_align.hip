@@ -32,6 +32,10 @@
 // perturbation of J moves the Gauss-Newton fixed point by ~1e-11, far below the
 // stated parity tolerance.  Sums are tree- instead of sequentially reduced, so
 // results agree to rounding, not bit-for-bit.
+// -DSIA_F64_PARTIALS builds the REFERENCE-WIDTH variant of this kernel (sia_acc = double): Jacobian rows, the
+// per-pixel products res*dx / res*dy / dx*dx ..., the per-lane partials, the wave reductions and SE3::exp in
+// f64 like H_, Jres_ and jacobian_cache_ of the reference (sparse_img_align.cpp:228-230,253-258).  bench.py
+// times it next to the default (`f64_partials` in the JSON line) so the price of that width is a number.
 #include "sia_common.h"
 
 using namespace svo_capi;
@@ -63,6 +67,14 @@ namespace {
 
 constexpr int MAX_WAVES = SVO_HIP_MAX_PATCHES / 64;
 
+#ifdef SIA_F64_PARTIALS
+using sia_acc = double;
+#undef MINW
+#define MINW(BLOCK) 3  // the f64 accumulators do not fit 128 VGPRs
+#else
+using sia_acc = float;
+#endif
+
 // Gauss-Newton state kept by the solver wave of a workgroup (quaternion form, as Sophus stores it).
 struct WaveModel {
   double q[4], t[3];    // model: T_cur_from_ref as Sophus stores it (unit quaternion + t)
@@ -78,9 +90,9 @@ struct SiaLds {
   double H[21];                  // H_ of the last evaluated iteration (packed upper triangle)
   double Hinv[36];               // its inverse, row-major
   double A[36];                  // Gauss-Jordan scratch
-  float part[2][MAX_WAVES][8];   // per-wave partials of Jres[6], chi2, n_meas (double-buffered)
-  int chg[2][MAX_WAVES];         // per wave: some patch entered or left the current image (same buffering)
-  float Hpart[MAX_WAVES][24];    // per-wave partials of H (21 used)
+  sia_acc part[2][MAX_WAVES][8];  // per-wave partials of Jres[6], chi2, n_meas (double-buffered)
+  int chg[2][MAX_WAVES];          // per wave: some patch entered or left the current image (same buffering)
+  sia_acc Hpart[MAX_WAVES][24];   // per-wave partials of H (21 used)
   long long lo[SVO_HIP_MAX_LEVELS];  // pyramid geometry per level (copied from the kernel
   int lw[SVO_HIP_MAX_LEVELS];        // arguments so the level loop can index it dynamically)
   int lh[SVO_HIP_MAX_LEVELS];
@@ -210,9 +222,9 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
   }
   // normalised coordinates of xyz_ref: all of Frame::jacobian_xyz2uv (frame.h:116-138)
   // is a function of (x/z, y/z, 1/z)
-  const float zi = (float)(1.0 / Z);
-  const float xn = (float)(X / Z);
-  const float yn = (float)(Y / Z);
+  const sia_acc zi = (sia_acc)(1.0 / Z);
+  const sia_acc xn = (sia_acc)(X / Z);
+  const sia_acc yn = (sia_acc)(Y / Z);
   const uint8_t* ref_base = a.store + (int64_t)a.ref_slot[b] * a.L.slot_bytes;
   const uint8_t* cur_base = a.store + (int64_t)a.cur_slot[b] * a.L.slot_bytes;
 
@@ -250,8 +262,8 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
 
   // which wave runs the serial solve/update step (see below)
   const int sw = (NW > 1) ? (int)(blockIdx.x % NW) : 0;
-  float Sxx = 0.f, Sxy = 0.f, Syy = 0.f;
-  float gmask = 0.f;  // 0 while this lane's Jacobian columns are zero at this level
+  sia_acc Sxx = 0, Sxy = 0, Syy = 0;
+  sia_acc gmask = 0;  // 0 while this lane's Jacobian columns are zero at this level
   bool vis = false;   // visible_fts_[i]; never cleared between levels (:57)
 
   __syncthreads();
@@ -267,7 +279,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
     const uint8_t* cur_img = cur_base + g_s.lo[level];
     const float scale = 1.0f / (float)(1 << level);
     // focal_length / 2^level (:139-140), folded into the per-patch sums
-    const float fl = (float)(fabs(P.fx) / (double)(1 << level));
+    const sia_acc fl = (sia_acc)(fabs(P.fx) / (double)(1 << level));
 
     uint32_t wc[WC ? 7 : 1][3];
     int wc_u0 = 0, wc_v0 = -100000;  // cached columns [wc_u0, wc_u0+11], rows [wc_v0, wc_v0+6]
@@ -306,10 +318,10 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       const int u_i = (int)floorf(u_ref);
       const int v_i = (int)floorf(v_ref);
       const bool inb = has && !(u_i - 3 < 0 || v_i - 3 < 0 || u_i + 3 >= cols || v_i + 3 >= rows);
-      Sxx = Sxy = Syy = 0.f;
+      Sxx = Sxy = Syy = 0;
       if (inb) {
         vis = true;
-        gmask = 1.f;
+        gmask = 1;
         const float su = u_ref - (float)u_i, sv = v_ref - (float)v_i;
         // The reference forms these products in double and rounds to float (:118-121).  u >= 3 here, so su
         // and sv are multiples of 2^-22: 1-su and 1-sv are exact in f32, and the f32 product of two f32
@@ -340,9 +352,9 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
           for (int x = 0; x < 4; ++x) {
             const float dx = 0.5f * (Bt[y + 1][x + 2] - Bt[y + 1][x]);
             const float dy = 0.5f * (Bt[y + 2][x + 1] - Bt[y][x + 1]);
-            Sxx += dx * dx;
-            Sxy += dx * dy;
-            Syy += dy * dy;
+            Sxx += (sia_acc)dx * (sia_acc)dx;
+            Sxy += (sia_acc)dx * (sia_acc)dy;
+            Syy += (sia_acc)dy * (sia_acc)dy;
           }
         s_bt[0][tid] = make_float4(Bt[0][1], Bt[0][2], Bt[0][3], Bt[0][4]);
         s_bt[1][tid] = make_float4(Bt[1][0], Bt[1][1], Bt[1][2], Bt[1][3]);
@@ -355,7 +367,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       } else {
         // jacobian_cache_.setZero() (:64): the J columns of a feature skipped here
         // stay zero; a stale ref_patch_cache_ row (if any) is kept
-        gmask = 0.f;
+        gmask = 0;
       }
     }
 
@@ -376,7 +388,8 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       [[maybe_unused]] const long long tp0 = SIA_T();
       // -- computeResiduals (:147-243): this lane's patch -------------------
       bool m = false;
-      float gx = 0.f, gy = 0.f, c2 = 0.f;
+      sia_acc gx = 0, gy = 0;
+      float c2 = 0.f;
       if (vis) {
         const double xc = R[0] * X + R[1] * Y + R[2] * Z + tr[0];
         const double yc = R[3] * X + R[4] * Y + R[5] * Z + tr[1];
@@ -474,8 +487,8 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
               const float I = wtl * W[y][x] + wtr * W[y][x + 1] + wbl * W[y + 1][x] + wbr * W[y + 1][x + 1];
               const float res = I - Bt[y + 1][x + 1];
               c2 += res * res;
-              gx += res * (Bt[y + 1][x + 2] - Bt[y + 1][x]);
-              gy += res * (Bt[y + 2][x + 1] - Bt[y][x + 1]);
+              gx += (sia_acc)res * (sia_acc)(Bt[y + 1][x + 2] - Bt[y + 1][x]);
+              gy += (sia_acc)res * (sia_acc)(Bt[y + 2][x + 1] - Bt[y][x + 1]);
             }
           }
         }
@@ -484,24 +497,24 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       // Jres -= J res with J = dx*a + dy*b, a = fl*jac.row(0), b = fl*jac.row(1)
       {
         // dx, dy carry a factor 0.5 (central difference)
-        const float gsc = 0.5f * fl * gmask;
-        const float gxf = m ? gx * gsc : 0.f, gyf = m ? gy * gsc : 0.f;
-        float part[8];
-        float zi_ = zi, xn_ = xn, yn_ = yn;  // opaque, as in the H rebuild below: keeps xn*yn, 1+xn^2, ... inside the loop
+        const sia_acc gsc = (sia_acc)0.5 * fl * gmask;
+        const sia_acc gxf = m ? gx * gsc : (sia_acc)0, gyf = m ? gy * gsc : (sia_acc)0;
+        sia_acc part[8];
+        sia_acc zi_ = zi, xn_ = xn, yn_ = yn;  // opaque, as in the H rebuild below: keeps xn*yn, 1+xn^2, ... inside the loop
 #ifndef SIA_ALLOW_HOIST
         asm volatile("" : "+v"(zi_), "+v"(xn_), "+v"(yn_));
 #endif
         part[0] = zi_ * gxf;
         part[1] = zi_ * gyf;
         part[2] = -zi_ * (xn_ * gxf + yn_ * gyf);
-        part[3] = -(xn_ * yn_ * gxf + (1.f + yn_ * yn_) * gyf);
-        part[4] = (1.f + xn_ * xn_) * gxf + xn_ * yn_ * gyf;
+        part[3] = -(xn_ * yn_ * gxf + ((sia_acc)1 + yn_ * yn_) * gyf);
+        part[4] = ((sia_acc)1 + xn_ * xn_) * gxf + xn_ * yn_ * gyf;
         part[5] = xn_ * gyf - yn_ * gxf;
-        part[6] = c2;
-        part[7] = m ? 16.f : 0.f;
+        part[6] = (sia_acc)c2;
+        part[7] = m ? (sia_acc)16 : (sia_acc)0;
         [[maybe_unused]] const long long tp1 = SIA_T();
         SIA_ACC(0, tp0, tp1);
-        const float tot = wave_reduce8(part, lane);
+        const sia_acc tot = wave_reduce8(part, lane);
         if ((lane & 7) == 0) g_s.part[buf][wave][lane >> 3] = tot;
         // "did the set of patches inside the current image change" travels with the partials: one barrier,
         // where __syncthreads_or costs three and an LDS atomic
@@ -522,24 +535,25 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
         // H += J J' summed over the patch = Sxx aa' + Sxy (ab'+ba') + Syy bb'
         // (opaque copies: otherwise the ~60 products below, all invariant in the iteration loop, are hoisted
         // out of it and stay live across it -- 35 VGPRs, the difference between 3 and 4 waves per SIMD)
-        float zi_ = zi, xn_ = xn, yn_ = yn;
+        sia_acc zi_ = zi, xn_ = xn, yn_ = yn;
 #ifndef SIA_ALLOW_HOIST
         asm volatile("" : "+v"(zi_), "+v"(xn_), "+v"(yn_));
 #endif
-        const float ja[6] = {-zi_ * fl, 0.f, xn_ * zi_ * fl, xn_ * yn_ * fl, -(1.f + xn_ * xn_) * fl, yn_ * fl};
-        const float jb[6] = {0.f, -zi_ * fl, yn_ * zi_ * fl, (1.f + yn_ * yn_) * fl, -xn_ * yn_ * fl, -xn_ * fl};
-        float hp[24];
+        const sia_acc one = 1, zero = 0;
+        const sia_acc ja[6] = {-zi_ * fl, zero, xn_ * zi_ * fl, xn_ * yn_ * fl, -(one + xn_ * xn_) * fl, yn_ * fl};
+        const sia_acc jb[6] = {zero, -zi_ * fl, yn_ * zi_ * fl, (one + yn_ * yn_) * fl, -xn_ * yn_ * fl, -xn_ * fl};
+        sia_acc hp[24];
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
           for (int j = i; j < 6; ++j) {
-            const float v = Sxx * (ja[i] * ja[j]) + Sxy * (ja[i] * jb[j] + jb[i] * ja[j]) + Syy * (jb[i] * jb[j]);
-            hp[sym6(i, j)] = m ? v : 0.f;
+            const sia_acc v = Sxx * (ja[i] * ja[j]) + Sxy * (ja[i] * jb[j] + jb[i] * ja[j]) + Syy * (jb[i] * jb[j]);
+            hp[sym6(i, j)] = m ? v : zero;
           }
-        hp[21] = hp[22] = hp[23] = 0.f;
+        hp[21] = hp[22] = hp[23] = zero;
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
-          const float tot = wave_reduce8(hp + 8 * g, lane);
+          const sia_acc tot = wave_reduce8(hp + 8 * g, lane);
           if ((lane & 7) == 0) g_s.Hpart[wave][8 * g + (lane >> 3)] = tot;
         }
         inH = (int)m;
@@ -608,11 +622,17 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
           done = 1;
         } else {
           // update(): T_new = T_old * SE3::exp(-x_)  (:253-258)
+#ifdef SIA_F64_PARTIALS
+          const double mx[6] = {-x0, -x1, -x2, -x3, -x4, -x5};
+          double eq[4], et[3];
+          se3_exp(mx, eq, et);  // Sophus SE3::exp in f64, as the reference evaluates it
+#else
           const float mx[6] = {-(float)x0, -(float)x1, -(float)x2, -(float)x3, -(float)x4, -(float)x5};
           float eqf[4], etf[3];
           se3_exp_f32(mx, eqf, etf);
           const double eq[4] = {eqf[0], eqf[1], eqf[2], eqf[3]};
           const double et[3] = {etf[0], etf[1], etf[2]};
+#endif
           double oq[4], ot[3], rt[3];
 #pragma unroll
           for (int k = 0; k < 4; ++k) oq[k] = wm.q[k];

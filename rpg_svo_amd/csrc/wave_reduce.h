@@ -48,4 +48,47 @@ __device__ __forceinline__ float wave_reduce8(const float v[8], int lane) {
   return t;
 }
 
+// ---- the same for doubles (a 64-bit value is exchanged as two dwords) ----------------------------------
+__device__ __forceinline__ double mk_f64(uint32_t lo, uint32_t hi) {
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ uint32_t lo32(double v) { return (uint32_t)__double_as_longlong(v); }
+__device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)((unsigned long long)__double_as_longlong(v) >> 32); }
+
+// lanes < 32: a[l] + a[l+32];  lanes >= 32: b[l-32] + b[l]
+__device__ __forceinline__ double swap32_add(double a, double b) {
+  auto s0 = __builtin_amdgcn_permlane32_swap(lo32(a), lo32(b), false, false);
+  auto s1 = __builtin_amdgcn_permlane32_swap(hi32(a), hi32(b), false, false);
+  return mk_f64(s0[0], s1[0]) + mk_f64(s0[1], s1[1]);
+}
+// even 16-lane rows: a[l] + a[l+16];  odd rows: b[l-16] + b[l]
+__device__ __forceinline__ double swap16_add(double a, double b) {
+  auto s0 = __builtin_amdgcn_permlane16_swap(lo32(a), lo32(b), false, false);
+  auto s1 = __builtin_amdgcn_permlane16_swap(hi32(a), hi32(b), false, false);
+  return mk_f64(s0[0], s1[0]) + mk_f64(s0[1], s1[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const uint32_t l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo32(v), CTRL, 0xf, 0xf, true);
+  const uint32_t h = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi32(v), CTRL, 0xf, 0xf, true);
+  return mk_f64(l, h);
+}
+
+// wave_reduce8 for doubles: same exchange pattern, same result placement (group lane>>3 holds the total of v[g])
+__device__ __forceinline__ double wave_reduce8(const double v[8], int lane) {
+  double r[4], q[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r[k] = swap32_add(v[k], v[k + 4]);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) q[k] = swap16_add(r[k], r[k + 2]);
+  const bool hi = (lane & 8) != 0;
+  const double mine = hi ? q[1] : q[0];
+  const double send = hi ? q[0] : q[1];
+  double t = mine + dpp_f64<DPP_ROW_ROR8>(send);
+  t += dpp_f64<DPP_QUAD_XOR1>(t);
+  t += dpp_f64<DPP_QUAD_XOR2>(t);
+  t += dpp_f64<DPP_ROW_HALF_MIRROR>(t);
+  return t;
+}
+
 }  // namespace svo_dev

@@ -37,6 +37,7 @@ class Result(C.Structure):
 
 
 STAGE_DEFAULT_FRAME = 3
+STAGE_RELOCALIZING = 4  # FrameHandlerBase::Stage (svo/include/svo/frame_handler_base.h)
 
 
 def lib_path(flavour: str) -> str:
@@ -133,13 +134,14 @@ def range_map(cam, T_f_w):
     return (-c[2] / dw[..., 2]).astype(np.float32)
 
 
-def run_sequence(flavour, cam, images, T_gt, stats_out=None, **cfg):
-    """Feed a whole sequence; returns the per-frame result dicts (frame 0 = first frame)."""
+def run_sequence(flavour, cam, images, T_gt, stats_out=None, range0=None, **cfg):
+    """Feed a whole sequence; returns the per-frame result dicts (frame 0 = first frame).  range0: range map of
+    frame 0 when T_gt is not expressed in the world the plane z = 0 lives in."""
     p = Pipeline(flavour, cam, **cfg)
     try:
         s0 = p.device_stats()
         t0 = p.stage_times()
-        n0, r0 = p.set_first_frame(images[0], 0.0, T_gt[0], range_map(cam, T_gt[0]))
+        n0, r0 = p.set_first_frame(images[0], 0.0, T_gt[0], range_map(cam, T_gt[0]) if range0 is None else range0)
         r0["n_first_features"] = n0
         out = [r0]
         for i in range(1, len(images)):

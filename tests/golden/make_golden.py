@@ -2,11 +2,13 @@
 """Generates tests/golden/sparse_align_qvga.npz: a small, seeded SparseImgAlign
 problem set (inputs + outputs).
 
-Outputs come from oracle/libsvo_oracle.so (the C restatement).  When oracle/_ref
-(the reference's own translation units compiled against oracle/shim) is available
-the same inputs are run through it and the script asserts both agree before
-writing, which is what pins the fixture to the reference code.  Run from the repo
-root in the build container:  python tests/golden/make_golden.py
+Outputs come from oracle/_ref/libsvo_ref.so -- the reference's own sparse_img_align.cpp
+compiled where it lies under /root/reference against oracle/shim -- so the fixture is
+REFERENCE-GENERATED (pinned_by_ref = True, asserted by tests/test_golden.py).  The C
+restatement (oracle/libsvo_oracle.so) is run on the same inputs and must agree bit for
+bit before anything is written.  The script refuses to write a fixture without the
+reference library.  Run from the repo root in the build container (where /root/reference
+exists):  python tests/golden/make_golden.py
 """
 import os
 import sys
@@ -28,18 +30,16 @@ def main():
     hp = np.ones((4, 60), dtype=np.uint8)
     hp[1, ::7] = 0
     b = make_batch(seq, [(0, 1), (1, 2), (2, 3), (4, 3)], 3, n_valid=[60, 60, 37, 60], has_point=hp)
-    T, res, pyrs = run_oracle(pyoracle, b, 2, 0, n_threads=1)
-    ref = None
-    try:
-        from oracle import pyref
-        if pyref.available():
-            ref = pyref.sparse_img_align_batch(b, 2, 0)
-    except ImportError:
-        pass
-    if ref is not None:
-        d = np.abs(ref["T_cur_w"] - T).max()
-        assert d < 1e-9, f"oracle and oracle/_ref disagree: {d}"
-        print(f"oracle vs oracle/_ref: max |dT| = {d:.3e}")
+    if not pyoracle.ref_available():
+        pyoracle.build_ref()
+    assert pyoracle.ref_available(), "oracle/_ref/libsvo_ref.so is needed: the golden vectors come from the reference's own code"
+    T, res, pyrs = run_oracle(pyoracle, b, 2, 0, n_threads=1, which="ref")
+    T_port, res_port, _ = run_oracle(pyoracle, b, 2, 0, n_threads=1, which="orc")
+    assert np.array_equal(T, T_port), f"reference and C port disagree: {np.abs(T - T_port).max()}"
+    for r, q in zip(res, res_port):
+        assert r["n_tracked"] == q["n_tracked"] and np.array_equal(r["iters"], q["iters"])
+        assert np.array_equal(r["H"], q["H"]) and r["chi2"] == q["chi2"]
+    print("reference (oracle/_ref) == C port (oracle/libsvo_oracle.so), bit for bit")
     out = os.path.join(ROOT, "tests", "golden", "sparse_align_qvga.npz")
     np.savez_compressed(
         out, images=b.images, cam=np.array([cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy]),
@@ -47,7 +47,7 @@ def main():
         px=b.px, f=b.f, pos=b.pos, has_point=b.has_point, n_levels=3, max_level=2, min_level=0, n_iter=30,
         T_cur_w=T, n_tracked=np.array([r["n_tracked"] for r in res]), iters=np.stack([r["iters"] for r in res]),
         chi2=np.array([r["chi2"] for r in res]), H=np.stack([r["H"] for r in res]),
-        pyr_level2=np.stack([p[2] for p in pyrs]), pinned_by_ref=np.array(ref is not None))
+        pyr_level2=np.stack([p[2] for p in pyrs]), pinned_by_ref=np.array(True))
     print("wrote", out, os.path.getsize(out), "bytes")
 
 

@@ -106,6 +106,38 @@ def test_dropin_trajectory_matches_cpu_reference(pipeline_libs, gpu_device):
 
 
 @pytest.mark.gpu
+def test_tracking_loss_and_relocalization(pipeline_libs, gpu_device):
+    """FrameHandlerMono::relocalizeFrame (frame_handler_mono.cpp:237-265), the second production caller of
+    SparseImgAlign: three blank frames lose tracking (RESULT_FAILURE -> STAGE_RELOCALIZING), every frame handed in
+    while relocalizing is aligned against the closest keyframe starting from the IDENTITY world pose (a fresh
+    Frame's T_f_w_), and processFrame runs again when more than 30 patches were tracked.  The world is chosen so
+    that the camera is near the identity when the images come back, i.e. relocalization succeeds.  Both flavours
+    must take the same stage transitions frame by frame."""
+    cam, imgs, T = _sequence(52, seed=9)
+    k0 = 36
+    T2 = se3.mul(T, np.broadcast_to(se3.inv(T[k0][None])[0], T.shape).copy())  # frame k0 sits at the identity
+    imgs = imgs.copy()
+    imgs[30:33] = 0
+    r0 = pp.range_map(cam, T[0])
+    ref = pp.run_sequence("ref", cam, imgs, T2, range0=r0)
+    hip = pp.run_sequence("hip", cam, imgs, T2, range0=r0)
+    st_ref, st_hip = [r["stage"] for r in ref], [r["stage"] for r in hip]
+    assert st_ref[30:33] == [pp.STAGE_RELOCALIZING] * 3, st_ref      # the scenario does what it is meant to
+    assert st_ref[33] == pp.STAGE_DEFAULT_FRAME, st_ref              # ... and relocalizes with the first good image
+    assert st_hip == st_ref
+    assert [r["is_keyframe"] for r in ref] == [r["is_keyframe"] for r in hip]
+    for k in ("n_obs", "repr_n_new_references", "img_align_n_tracked"):
+        assert np.mean([a[k] == b[k] for a, b in zip(ref, hip)]) >= 0.95, k
+    # SparseImgAlign inside relocalizeFrame did run in the hip flavour (against blank images, then a real one)
+    assert all(r["img_align_n_tracked"] > 30 for r in hip[30:34])
+    Tr = np.stack([r["T_f_w"] for r in ref])
+    Th = np.stack([r["T_f_w"] for r in hip])
+    d = se3.log_norm(Th, Tr)
+    print(f"relocalization sequence: SE3 log-norm max {d.max():.3e} median {np.median(d):.3e}; stages {st_hip[28:36]}")
+    assert d.max() <= SE3_LOGNORM_TOL
+
+
+@pytest.mark.gpu
 def test_dropin_second_sequence_with_noise(pipeline_libs, gpu_device):
     cam, imgs, T = _sequence(80, seed=11)
     rng = np.random.default_rng(3)
