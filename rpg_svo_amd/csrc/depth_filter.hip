@@ -229,13 +229,13 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   w.mode[s] = MODE_SCAN;
 }
 
-// bytes [x0, x0+7] of the row at byte offset ro (svo_pyr::row_off) as two dwords; c = cols3(x0 & ~3), sel = x0 & 3
-__device__ __forceinline__ void load_row8(const uint8_t* __restrict__ img, uint32_t ro, const svo_pyr::Cols3& c,
-                                          uint32_t sel, uint32_t& lo, uint32_t& hi) {
-  uint32_t d[3];
-  svo_pyr::load3(img, ro, c, d);
-  lo = __builtin_amdgcn_alignbyte(d[1], d[0], sel);
-  hi = __builtin_amdgcn_alignbyte(d[2], d[1], sel);
+// bytes [bo, bo+7] (bo in 0..7) of a 12-byte run of three aligned dwords, as two dwords
+__device__ __forceinline__ void cut_row8(const uint32_t d[3], uint32_t bo, uint32_t& lo, uint32_t& hi) {
+  const bool up = bo >= 4u;  // then bo == 4: the run was moved one dword to the left to stay inside a tile row
+  const uint32_t a = up ? d[1] : d[0], b = up ? d[2] : d[1], c = up ? 0u : d[2];
+  const uint32_t sel = bo & 3u;
+  lo = __builtin_amdgcn_alignbyte(b, a, sel);
+  hi = __builtin_amdgcn_alignbyte(c, b, sel);
 }
 
 constexpr int SCAN_BLOCK = 256;
@@ -323,13 +323,16 @@ __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) 
         prv1 = cast_int(pps[1] * inv_lvl + 0.5);
       }
       if (!(pxi0 == prv0 && pxi1 == prv1) && is_in_frame_level(a.cam, pxi0, pxi1, 8, sl)) {
-        const svo_pyr::Cols3 wc3 = svo_pyr::cols3((pxi0 - 4) & ~3);
-        const uint32_t wsel = (uint32_t)((pxi0 - 4) & 3);
+        // 8 rows x 8 bytes [pxi0-4, pxi0+3]: 12-byte runs, inside one tile row of the store where the 8 bytes are
+        const int wxa = svo_pyr::run_start(pxi0 - 4, 8);
+        const uint32_t wbo = (uint32_t)(pxi0 - 4 - wxa);  // 0..4
+        uint32_t win[8][3];
+        svo_pyr::load_window12<8>(img, pitch, wxa, pxi1 - 4, win);
         uint32_t sumB = 0, sumBB = 0, sumAB = 0;
 #pragma unroll
         for (int y = 0; y < 8; ++y) {
           uint32_t lo, hi;
-          load_row8(img, svo_pyr::row_off(pxi1 - 4 + y, pitch), wc3, wsel, lo, hi);
+          cut_row8(win[y], wbo, lo, hi);
           sumB = __builtin_amdgcn_udot4(lo, 0x01010101u, sumB, false);
           sumB = __builtin_amdgcn_udot4(hi, 0x01010101u, sumB, false);
           sumBB = __builtin_amdgcn_udot4(lo, lo, sumBB, false);

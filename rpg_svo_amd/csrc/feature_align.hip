@@ -39,12 +39,16 @@ namespace {
 #define ALIGN_OPAQUE_TEMPLATE(g)
 #endif
 
-// bytes [x0, x0+8] of the image row at byte offset ro (svo_pyr::row_off) as floats: 3 aligned dwords,
-// c = cols3(x0 & ~3), sel = x0 & 3
-__device__ __forceinline__ void load_row9(const uint8_t* __restrict__ img, uint32_t ro, const svo_pyr::Cols3& c,
-                                          uint32_t sel, float out[9]) {
+__device__ __forceinline__ void cut_row9(const uint32_t d[3], uint32_t sel, float out[9]);
+// bytes [x0, x0+8] of the image row at byte offset ro (svo_pyr::row_off) as floats: one 12-byte run of three aligned
+// dwords starting at xa = x0 & ~3 (one load when it lies inside a tile row of the store, two otherwise), sel = x0 & 3
+__device__ __forceinline__ void load_row9(const uint8_t* __restrict__ img, uint32_t ro, int xa, uint32_t sel, float out[9]) {
   uint32_t d[3];
-  svo_pyr::load3(img, ro, c, d);
+  svo_pyr::load_run12(img, ro, xa, d);
+  cut_row9(d, sel, out);
+}
+// bytes [sel, sel+8] of three consecutive dwords as floats
+__device__ __forceinline__ void cut_row9(const uint32_t d[3], uint32_t sel, float out[9]) {
   const uint32_t d0 = d[0], d1 = d[1], d2 = d[2];
   const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sel);
   const uint32_t mid = __builtin_amdgcn_alignbyte(d2, d1, sel);
@@ -123,13 +127,23 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
     const float wBL = (float)((1.0 - subpix_x) * subpix_y);
     const float wBR = subpix_x * subpix_y;
     float Jres0 = 0, Jres1 = 0, Jres2 = 0;
-    const svo_pyr::Cols3 wc3 = svo_pyr::cols3((u_r - 4) & ~3);
+    const int wxa = (u_r - 4) & ~3;
     const uint32_t wsel = (uint32_t)((u_r - 4) & 3);
     float P0[9], P1[9];
-    load_row9(img, svo_pyr::row_off(v_r - 4, pitch), wc3, wsel, P0);
+#ifdef ALIGN_WINDOW_LOAD  // all nine rows fetched up front, ONE three-way branch on the tile position (27 registers)
+    uint32_t win[9][3];
+    svo_pyr::load_window12<9>(img, pitch, wxa, v_r - 4, win);
+    cut_row9(win[0], wsel, P0);
+#else
+    load_row9(img, svo_pyr::row_off(v_r - 4, pitch), wxa, wsel, P0);
+#endif
 #pragma unroll
     for (int y = 0; y < 8; ++y) {
-      load_row9(img, svo_pyr::row_off(v_r - 3 + y, pitch), wc3, wsel, P1);
+#ifdef ALIGN_WINDOW_LOAD
+      cut_row9(win[y + 1], wsel, P1);
+#else
+      load_row9(img, svo_pyr::row_off(v_r - 3 + y, pitch), wxa, wsel, P1);
+#endif
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
         const int c = (y + 1) * 10 + x + 1;
@@ -201,13 +215,23 @@ __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, in
     const float wBL = (float)((1.0 - subpix_x) * subpix_y);
     const float wBR = subpix_x * subpix_y;
     float new_chi2 = 0, Jres0 = 0, Jres1 = 0;
-    const svo_pyr::Cols3 wc3 = svo_pyr::cols3((u_r - 4) & ~3);
+    const int wxa = (u_r - 4) & ~3;
     const uint32_t wsel = (uint32_t)((u_r - 4) & 3);
     float P0[9], P1[9];
-    load_row9(img, svo_pyr::row_off(v_r - 4, pitch), wc3, wsel, P0);
+#ifdef ALIGN_WINDOW_LOAD  // all nine rows fetched up front, ONE three-way branch on the tile position (27 registers)
+    uint32_t win[9][3];
+    svo_pyr::load_window12<9>(img, pitch, wxa, v_r - 4, win);
+    cut_row9(win[0], wsel, P0);
+#else
+    load_row9(img, svo_pyr::row_off(v_r - 4, pitch), wxa, wsel, P0);
+#endif
 #pragma unroll
     for (int y = 0; y < 8; ++y) {
-      load_row9(img, svo_pyr::row_off(v_r - 3 + y, pitch), wc3, wsel, P1);
+#ifdef ALIGN_WINDOW_LOAD
+      cut_row9(win[y + 1], wsel, P1);
+#else
+      load_row9(img, svo_pyr::row_off(v_r - 3 + y, pitch), wxa, wsel, P1);
+#endif
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
         const int c = (y + 1) * 10 + x + 1;

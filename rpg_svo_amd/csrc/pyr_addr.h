@@ -66,25 +66,113 @@ __host__ __device__ __forceinline__ int64_t level_bytes(int pitch, int h) {
 #endif
 }
 
-// Three consecutive ALIGNED dwords of a row (columns xa .. xa+11, xa % 4 == 0): the column terms are the same
-// for every row of a window, so a window load is 3 column terms + one row term per row + one add per dword.
-struct Cols3 {
-  uint32_t c0, c1, c2;
-};
-__device__ __forceinline__ Cols3 cols3(int xa) {
-  Cols3 c;
-  c.c0 = col_off(xa);
-  c.c1 = col_off(xa + 4);
-  c.c2 = col_off(xa + 8);
-  return c;
+// ---- window rows: three consecutive ALIGNED dwords ("a run": columns xa .. xa+11, xa % 4 == 0) -------------------
+// What a gather costs is the number of cache-line look-ups the vector L1 performs for it: one per lane and load
+// instruction (measured: K1 went from 1.30 to 1.55 ms when its 12-byte row fetches were split into three dword
+// loads).  A run that lies inside one tile row (xa % 16 <= 4) is ONE 12-byte load; a run that continues in the next
+// tile is two (8 + 4 or 4 + 8 bytes).  run_start() therefore places the run inside a tile row whenever the bytes the
+// caller needs allow it.
+
+// First column of the run fetched for a window row whose needed bytes are columns [c, c + need - 1] (need <= 9):
+// 4-aligned, covers the needed bytes, and inside one tile row whenever the needed bytes are.
+__device__ __forceinline__ int run_start(int c, int need) {
+  int xa = c & ~3;
+#if SVO_PYR_TILE && !defined(SVO_PYR_SPLIT_RUNS)
+  if ((xa & 15) == 8 && (c & 15) + need <= 16) xa -= 4;  // [xa, xa+11] would cross, [c, c+need-1] does not
+#else
+  (void)need;
+#endif
+  return xa;
 }
+
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ uint32_t ld32(const uint8_t* __restrict__ lvl, uint32_t off) {
   return *reinterpret_cast<const uint32_t*>(lvl + off);
 }
-__device__ __forceinline__ void load3(const uint8_t* __restrict__ lvl, uint32_t ro, const Cols3& c, uint32_t d[3]) {
-  d[0] = ld32(lvl, ro + c.c0);
-  d[1] = ld32(lvl, ro + c.c1);
-  d[2] = ld32(lvl, ro + c.c2);
+// 8 / 12 bytes from a 4-byte aligned address (global_load_dwordx2 / x3 need dword alignment only)
+__device__ __forceinline__ u32x2_t ld64(const uint8_t* __restrict__ lvl, uint32_t off) {
+  typedef u32x2_t __attribute__((aligned(4))) u32x2_a4;
+  return *reinterpret_cast<const u32x2_a4*>(lvl + off);
+}
+__device__ __forceinline__ u32x3_t ld96(const uint8_t* __restrict__ lvl, uint32_t off) {
+  typedef u32x3_t __attribute__((aligned(4))) u32x3_a4;
+  return *reinterpret_cast<const u32x3_a4*>(lvl + off);
+}
+
+// The run [xa, xa+11] of the row at byte offset ro (row_off).  Per-row form: the three-way branch sits around one row.
+__device__ __forceinline__ void load_run12(const uint8_t* __restrict__ lvl, uint32_t ro, int xa, uint32_t d[3]) {
+#ifdef SVO_PYR_SPLIT_RUNS  // A/B build: every run as three dword loads (three look-ups per lane), no placement
+  d[0] = ld32(lvl, ro + col_off(xa));
+  d[1] = ld32(lvl, ro + col_off(xa + 4));
+  d[2] = ld32(lvl, ro + col_off(xa + 8));
+  return;
+#endif
+  const uint32_t a = ro + col_off(xa);
+#if SVO_PYR_TILE
+  const int o = xa & 15;
+  if (o <= 4) {  // one tile row
+    const u32x3_t v = ld96(lvl, a);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z;
+  } else if (o == 8) {  // bytes 8..15 here, 0..3 of the next tile (128 bytes further, 8 columns back)
+    const u32x2_t v = ld64(lvl, a);
+    d[0] = v.x; d[1] = v.y;
+    d[2] = ld32(lvl, a + 120u);
+  } else {  // bytes 12..15 here, 0..7 of the next tile
+    d[0] = ld32(lvl, a);
+    const u32x2_t v = ld64(lvl, a + 116u);
+    d[1] = v.x; d[2] = v.y;
+  }
+#else
+  const u32x3_t v = ld96(lvl, a);
+  d[0] = v.x; d[1] = v.y; d[2] = v.z;
+#endif
+}
+
+// NR rows x one run from row v0, column xa of a level.  Window form: the three-way branch sits around all rows, so
+// each case issues its NR (or 2 NR) loads back to back.
+template <int NR>
+__device__ __forceinline__ void load_window12(const uint8_t* __restrict__ lvl, int pitch, int xa, int v0,
+                                              uint32_t d[][3]) {
+#ifdef SVO_PYR_SPLIT_RUNS
+#pragma unroll
+  for (int r = 0; r < NR; ++r) load_run12(lvl, row_off(v0 + r, pitch), xa, d[r]);
+  return;
+#endif
+  uint32_t a[NR];
+  const uint32_t c = col_off(xa);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) a[r] = row_off(v0 + r, pitch) + c;
+#if SVO_PYR_TILE
+  const int o = xa & 15;
+  if (o <= 4) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const u32x3_t v = ld96(lvl, a[r]);
+      d[r][0] = v.x; d[r][1] = v.y; d[r][2] = v.z;
+    }
+  } else if (o == 8) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const u32x2_t v = ld64(lvl, a[r]);
+      d[r][0] = v.x; d[r][1] = v.y;
+      d[r][2] = ld32(lvl, a[r] + 120u);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      d[r][0] = ld32(lvl, a[r]);
+      const u32x2_t v = ld64(lvl, a[r] + 116u);
+      d[r][1] = v.x; d[r][2] = v.y;
+    }
+  }
+#else
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const u32x3_t v = ld96(lvl, a[r]);
+    d[r][0] = v.x; d[r][1] = v.y; d[r][2] = v.z;
+  }
+#endif
 }
 
 }  // namespace svo_pyr

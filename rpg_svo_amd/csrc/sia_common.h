@@ -32,52 +32,44 @@ struct SiaArgs {
   int32_t* status;
 };
 
-using svo_pyr::Cols3;
-using svo_pyr::cols3;
+using svo_pyr::load_window12;
+using svo_pyr::run_start;
 
-// Rows are addressed as (level base, byte offset of the row `ro` = svo_pyr::row_off(y, pitch), column terms of
-// the aligned dwords covering the bytes wanted): see pyr_addr.h for the tiled pyramid store.
+// Window rows are fetched as 12-byte runs of three aligned dwords (pyr_addr.h: run_start, load_run12, load_window12)
+// and cut to the bytes wanted in registers.
 
-// bytes [x0, x0+4] of a row as floats; c = cols3(x0 & ~3) (its third dword is not read), sel = x0 & 3
-__device__ __forceinline__ void load_row5(const uint8_t* __restrict__ lvl, uint32_t ro, const Cols3& c, uint32_t sel,
-                                          float out[5]) {
-  const uint32_t d0 = svo_pyr::ld32(lvl, ro + c.c0), d1 = svo_pyr::ld32(lvl, ro + c.c1);
-  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sel);  // bytes x0..x0+3
-  const uint32_t hi = d1 >> (8 * sel);                          // byte x0+4 in bits 0..7
+// bytes [bo, bo+6] (bo in 0..5) of three consecutive dwords as floats
+__device__ __forceinline__ void cut_row7(const uint32_t d[3], uint32_t bo, float out[7]) {
+  const bool up = bo >= 4u;
+  const uint32_t a = up ? d[1] : d[0], b = up ? d[2] : d[1], c = up ? 0u : d[2];
+  const uint32_t sel = bo & 3u;
+  const uint32_t lo = __builtin_amdgcn_alignbyte(b, a, sel);  // bytes 0..3
+  const uint32_t hi = __builtin_amdgcn_alignbyte(c, b, sel);  // bytes 4..7
   out[0] = (float)(lo & 0xffu);
   out[1] = (float)((lo >> 8) & 0xffu);
   out[2] = (float)((lo >> 16) & 0xffu);
   out[3] = (float)(lo >> 24);
   out[4] = (float)(hi & 0xffu);
+  out[5] = (float)((hi >> 8) & 0xffu);
+  out[6] = (float)((hi >> 16) & 0xffu);
 }
 
-// bytes [x0, x0+6] of a row as floats; c = cols3(x0 & ~3), sel = x0 & 3
-__device__ __forceinline__ void load_row7(const uint8_t* __restrict__ lvl, uint32_t ro, const Cols3& c, uint32_t sel,
-                                          float out[7]) {
+// bytes [x0, x0+4] of the row at byte offset ro as floats (the kernels without a window cache)
+__device__ __forceinline__ void load_row5(const uint8_t* __restrict__ lvl, uint32_t ro, int x0, float out[5]) {
+  const int xa = run_start(x0, 5);
   uint32_t d[3];
-  svo_pyr::load3(lvl, ro, c, d);
-  const uint32_t lo = __builtin_amdgcn_alignbyte(d[1], d[0], sel);  // bytes 0..3
-  const uint32_t hi = __builtin_amdgcn_alignbyte(d[2], d[1], sel);  // bytes 4..7
+  svo_pyr::load_run12(lvl, ro, xa, d);
+  const uint32_t bo = (uint32_t)(x0 - xa);  // 0..7
+  const bool up = bo >= 4u;
+  const uint32_t a = up ? d[1] : d[0], b = up ? d[2] : d[1];
+  const uint32_t sel = bo & 3u;
+  const uint32_t lo = __builtin_amdgcn_alignbyte(b, a, sel);  // bytes x0..x0+3
+  const uint32_t hi = b >> (8 * sel);                         // byte x0+4 in bits 0..7
   out[0] = (float)(lo & 0xffu);
   out[1] = (float)((lo >> 8) & 0xffu);
   out[2] = (float)((lo >> 16) & 0xffu);
   out[3] = (float)(lo >> 24);
   out[4] = (float)(hi & 0xffu);
-  out[5] = (float)((hi >> 8) & 0xffu);
-  out[6] = (float)((hi >> 16) & 0xffu);
-}
-
-// bytes [sel, sel+6] (sel in 0..3) of three consecutive dwords as floats: load_row7 on registers
-__device__ __forceinline__ void cut_row7(const uint32_t d[3], uint32_t sel, float out[7]) {
-  const uint32_t lo = __builtin_amdgcn_alignbyte(d[1], d[0], sel);  // bytes 0..3
-  const uint32_t hi = __builtin_amdgcn_alignbyte(d[2], d[1], sel);  // bytes 4..7
-  out[0] = (float)(lo & 0xffu);
-  out[1] = (float)((lo >> 8) & 0xffu);
-  out[2] = (float)((lo >> 16) & 0xffu);
-  out[3] = (float)(lo >> 24);
-  out[4] = (float)(hi & 0xffu);
-  out[5] = (float)((hi >> 8) & 0xffu);
-  out[6] = (float)((hi >> 16) & 0xffu);
 }
 
 // ---- window cache (template parameter WC) --------------------------------------------------------------
@@ -87,14 +79,6 @@ __device__ __forceinline__ void cut_row7(const uint32_t d[3], uint32_t sel, floa
 // lane fetches 7 rows x 3 aligned dwords around the patch (49+ bytes, once) and later iterations
 // cut their 5x5 window out of those 21 registers as long as the integer position stays within
 // +-1 row and the 12 cached columns; only then is nothing loaded at all.
-// NR rows x 3 aligned dwords from row v0, column xa (xa % 4 == 0) of a level
-template <int NR>
-__device__ __forceinline__ void load_window12(const uint8_t* __restrict__ lvl, int pitch, int xa, int v0,
-                                              uint32_t d[][3]) {
-  const Cols3 c = cols3(xa);
-#pragma unroll
-  for (int r = 0; r < NR; ++r) svo_pyr::load3(lvl, svo_pyr::row_off(v0 + r, pitch), c, d[r]);
-}
 // v_cndmask_b32 with the lane mask in an SGPR pair.  The VOP2 form the compiler prefers reads VCC and
 // issues ~3.6x slower on gfx950 (scripts/valu_ubench.hip: 10.7 against 2.95 SIMD cycles per
 // wave-instruction); K1 spends 45 selects per patch and iteration on its window cache.

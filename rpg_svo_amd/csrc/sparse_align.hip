@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       const float fu = floorf((float)pu * scale), fv = floorf((float)pv * scale);
       const bool okc = has && fu - 3.f >= 0.f && fv - 3.f >= 0.f && fu + 3.f < (float)cols && fv + 3.f < (float)rows;
       const int cu = okc ? (int)fu : 3, cv = okc ? (int)fv : 3;
-      wc_u0 = (cu - 3) & ~3;
+      wc_u0 = run_start(cu - 3, 7);
       load_window12<(WC ? 7 : 1)>(cur_img, pitch, wc_u0, cv - 3, wc);
       wc_v0 = okc ? cv - 3 : -100000;
     }
@@ -332,12 +332,15 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
         const float wbr = su * sv;
         float Bt[6][6];
         float Wp[7], Wc[7];
-        const Cols3 rc = cols3((u_i - 3) & ~3);
-        const uint32_t rsel = (uint32_t)((u_i - 3) & 3);
-        load_row7(ref_img, svo_pyr::row_off(v_i - 3, pitch), rc, rsel, Wp);
+        // the 7 x 7 window as 7 runs of 12 bytes, placed inside one tile row of the store where the 7 bytes allow it
+        uint32_t rw[7][3];
+        const int rxa = run_start(u_i - 3, 7);
+        const uint32_t rbo = (uint32_t)(u_i - 3 - rxa);  // 0..5
+        load_window12<7>(ref_img, pitch, rxa, v_i - 3, rw);
+        cut_row7(rw[0], rbo, Wp);
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-          load_row7(ref_img, svo_pyr::row_off(v_i - 2 + r, pitch), rc, rsel, Wc);
+          cut_row7(rw[r + 1], rbo, Wc);
 #pragma unroll
           for (int c = 0; c < 6; ++c) {
             const bool need = ((r >= 1 && r <= 4)) || ((c >= 1 && c <= 4));
@@ -444,7 +447,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
             int bo = (u_i - 2) - wc_u0;  // first cached byte needed
             if (!(r0 >= 0 && r0 <= 2 && bo >= 0 && bo <= 7)) {
               wc_v0 = v_i - 3;
-              wc_u0 = (u_i - 3) & ~3;
+              wc_u0 = run_start(u_i - 3, 7);
               load_window12<(WC ? 7 : 1)>(cur_img, pitch, wc_u0, wc_v0, wc);
               r0 = 1;
               bo = (u_i - 2) - wc_u0;
@@ -460,10 +463,8 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
               cut_row5(d0, d1, d2, bo, kup, W[r]);
             }
           } else {
-            const Cols3 cc = cols3((u_i - 2) & ~3);
-            const uint32_t csel = (uint32_t)((u_i - 2) & 3);
 #pragma unroll
-            for (int r = 0; r < 5; ++r) load_row5(cur_img, svo_pyr::row_off(v_i - 2 + r, pitch), cc, csel, W[r]);
+            for (int r = 0; r < 5; ++r) load_row5(cur_img, svo_pyr::row_off(v_i - 2 + r, pitch), u_i - 2, W[r]);
           }
 #endif
           float Bt[6][6];

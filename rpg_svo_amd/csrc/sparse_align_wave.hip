@@ -194,8 +194,9 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
       su_k[k] = u_ref - (float)u_i;
       sv_k[k] = v_ref - (float)v_i;
       const int cu = inb ? u_i : 3, cv = inb ? v_i : 3;
-      sel_ref[k] = (cu - 3) & 3;
-      load_window12<7>(ref_img, pitch, (cu - 3) & ~3, cv - 3, rw[k]);
+      const int rxa = run_start(cu - 3, 7);
+      sel_ref[k] = cu - 3 - rxa;  // 0..5
+      load_window12<7>(ref_img, pitch, rxa, cv - 3, rw[k]);
     }
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
@@ -228,7 +229,7 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
       const float fu = floorf((float)pu * scale), fv = floorf((float)pv * scale);
       const bool okc = will_see && fu - 3.f >= 0.f && fv - 3.f >= 0.f && fu + 3.f < (float)cols && fv + 3.f < (float)rows;
       const int cu = okc ? (int)fu : 3, cv = okc ? (int)fv : 3;
-      const int v0 = cv - 3, u0 = (cu - 3) & ~3;
+      const int v0 = cv - 3, u0 = run_start(cu - 3, 7);
       load_window12<7>(cur_img, pitch, u0, v0, p.wc);
       p.wc_u0 = u0;
       p.wc_v0 = okc ? v0 : -100000;
@@ -320,12 +321,14 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
         const float wbr = su * sv;
         float Bt[6][6];
         float Wp[7], Wc[7];
-        const Cols3 rc = cols3((u_i - 3) & ~3);
-        const uint32_t rsel = (uint32_t)((u_i - 3) & 3);
-        load_row7(ref_img, svo_pyr::row_off(v_i - 3, pitch), rc, rsel, Wp);
+        uint32_t rws[7][3];
+        const int rxa = run_start(u_i - 3, 7);
+        const uint32_t rbo = (uint32_t)(u_i - 3 - rxa);  // 0..5
+        load_window12<7>(ref_img, pitch, rxa, v_i - 3, rws);
+        cut_row7(rws[0], rbo, Wp);
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-          load_row7(ref_img, svo_pyr::row_off(v_i - 2 + r, pitch), rc, rsel, Wc);
+          cut_row7(rws[r + 1], rbo, Wc);
 #pragma unroll
           for (int c = 0; c < 6; ++c) {
             const bool need = ((r >= 1 && r <= 4)) || ((c >= 1 && c <= 4));
@@ -424,7 +427,7 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
             int bo = (u_i - 2) - p.wc_u0;  // first cached byte needed
             if (!(r0 >= 0 && r0 <= 2 && bo >= 0 && bo <= 7)) {
               p.wc_v0 = v_i - 3;
-              p.wc_u0 = (u_i - 3) & ~3;
+              p.wc_u0 = run_start(u_i - 3, 7);
               load_window12<7>(cur_img, pitch, p.wc_u0, p.wc_v0, p.wc);
               r0 = 1;
               bo = (u_i - 2) - p.wc_u0;
