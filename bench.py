@@ -58,7 +58,7 @@ WORKLOADS = {
     "svo_default_752_l4to2_n120": (752, 480, 315.5, 5, 4, 2, 120, 56, 40),
     "xga5_n1000_sparse_align": (1280, 960, 800.0, 5, 4, 0, 1000, 56, 32),
 }
-EXTRA_KEYS = {"f64": "f64_partials", "refine": "align_plus_refine", "full": "full_track", "noise": "noise_sigma2", "config3": "config3_xga5_b64",
+EXTRA_KEYS = {"f64": "f64_partials", "refine": "align_plus_refine", "full": "full_track", "full_easy": "full_track_easy", "noise": "noise_sigma2", "config3": "config3_xga5_b64",
               "k0": "k0_pyramid", "dropin": "dropin_sequence"}
 
 
@@ -237,8 +237,8 @@ def main() -> None:
                          "headline); full: configs[2] -- the whole track is the step (the default run reports it as the "
                          "extra key full_track instead)")
     ap.add_argument("--extras", default="all",
-                    help="comma list of the extra legs to run at N=1 (all, none, or any of: f64, refine, full, noise, config3, "
-                         "rig, k0, dropin, pmc)")
+                    help="comma list of the extra legs to run at N=1 (all, none, or any of: f64, refine, full, full_easy, noise, "
+                         "config3, rig, k0, dropin, pmc)")
     ap.add_argument("--k1-kernel", default="auto", choices=["auto", "workgroup"],
                     help="auto: svo_hip_sparse_align (one wave per frame up to 256 patches); workgroup: the workgroup-per-frame kernel")
     ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)
@@ -273,7 +273,7 @@ def main() -> None:
     lib = capi.load()
     ev = Events(lib, dev)
     if args.extras == "all":
-        extras = {"f64", "refine", "full", "noise", "config3", "rig", "k0", "dropin", "pmc"}
+        extras = {"f64", "refine", "full", "full_easy", "noise", "config3", "rig", "k0", "dropin", "pmc"}
     elif args.extras == "none":
         extras = set()
     else:
@@ -476,6 +476,7 @@ def main() -> None:
     leg("f64", lambda: f64_partials_leg(args, st["T_est_w"], out.iters.cpu().numpy(), result))
     leg("refine", lambda: align_plus_refine(W, sia, ev, dev, args.steps))
     leg("full", lambda: full_track_leg(W, sia, ev, dev, rank, lib, not args.no_cpu_baseline))
+    leg("full_easy", lambda: full_track_leg(W, sia, ev, dev, rank, lib, False, steps=3, mode="easy"))
     leg("k0", lambda: pyramid_roofline(ev, store, W.images))
     if args.noise == 0:
         leg("noise", lambda: noise_leg(W, sia, ev, dev, rank, args.steps))
@@ -498,6 +499,19 @@ def main() -> None:
                 result["roofline"]["cache_line_floor_bytes_per_launch"] = repr(e)
         if "roofline_valu" in pm:
             result["roofline_valu"] = pm.pop("roofline_valu")
+        if "full" in extras and isinstance(result.get("full_track"), dict) and "rooflines" in result["full_track"]:
+            try:
+                pf = pmc_full_track_leg(args)
+            except Exception as e:
+                pf = {"skipped": repr(e)}
+            pm["full_track"] = pf
+            for stage, st_ in pf.get("stages", {}).items():  # next to the stage's algorithmic bytes
+                rl_ = result["full_track"]["rooflines"].get(stage)
+                if rl_ and st_["traffic_bytes_per_step"] == st_["traffic_bytes_per_step"]:
+                    rl_["traffic"] = st_["traffic_bytes_per_step"]
+                    rl_["traffic_over_algorithmic"] = st_["traffic_bytes_per_step"] / rl_["algorithmic_bytes_per_launch"]
+                    rl_["traffic_by_kernel"] = st_["by_kernel"]
+            pm["leg_seconds"] = time.time() - t
         result["pmc"] = pm
     leg("dropin", dropin_sequence)
     if use_dist:
@@ -806,6 +820,85 @@ def pmc_leg(args, kernel_ms: float) -> dict:
     return out
 
 
+FULL_TRACK_KERNELS = {"find_match_direct": ("match_prepare_kernel", "warp_kernel", "align_kernel"),
+                      "update_seeds": ("seed_prepare_kernel", "warp_kernel", "epi_scan_kernel", "align_kernel", "seed_finish_kernel"),
+                      "pose_optimize": ("pose_opt_wave_kernel", "pose_opt_kernel")}
+
+
+def pmc_full_track_leg(args, n_steps: int = 2) -> dict:
+    """HBM traffic of the kernels of the full-track step (configs[2], representative workload), per kernel and per
+    stage: two child runs of `bench.py --pipeline full` under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE; one counter
+    per pass, corrected as for K1).  warp_kernel and align_kernel run twice per step -- first for findMatchDirect,
+    then for the depth filter -- and are told apart by their position in the dispatch order; the set-up of the
+    workload launches the same kernels, so only the dispatches of the last `n_steps` steps are read."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return {"skipped": "rocprofv3 not on PATH"}
+    base = [sys.executable, os.path.abspath(__file__), "--steps", str(n_steps), "--warmup", "0", "--batch", str(args.batch),
+            "--workload", args.workload, "--n-iter", str(args.n_iter), "--no-cpu-baseline", "--extras", "none",
+            "--pmc-child", "1", "--pipeline", "full"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("SVO_BENCH_FORCE_DIST", None)
+    regex = "|".join(sorted({k for ks in FULL_TRACK_KERNELS.values() for k in ks}))
+    per = {}  # counter -> kernel short name -> [values in dispatch order]
+    status = {}
+    for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        d = tempfile.mkdtemp(prefix=f"svo_pmc_full_{name}_", dir="/tmp")
+        cmd = [exe, "--pmc", ctr, "--kernel-include-regex", regex, "--output-format", "csv", "-d", d, "-o", name, "--", *base]
+        try:
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=2 * PMC_PASS_TIMEOUT_S)
+        except subprocess.TimeoutExpired:
+            status[name] = "timeout"
+            break
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            status[name] = f"rc={p.returncode}: {p.stderr[-200:]}"
+            break
+        rows = []
+        with open(files[0]) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") == ctr:
+                    rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"], float(row["Counter_Value"])))
+        rows.sort()
+        acc = per.setdefault(ctr, {})
+        for _, kn, v in rows:
+            short = next((k for k in regex.split("|") if k in kn), None)
+            if short:
+                acc.setdefault(short, []).append(v)
+        status[name] = "ok"
+        shutil.rmtree(d, ignore_errors=True)
+    if "FETCH_SIZE" not in per or "WRITE_SIZE" not in per:
+        return {"passes": status}
+
+    def per_launch(kernel, which, calls_per_step):
+        """bytes per launch (FETCH doubled + WRITE, KiB) of the `which`-th of calls_per_step launches of a step"""
+        out = []
+        for ctr, scale in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            v = per[ctr].get(kernel, [])
+            v = v[len(v) - n_steps * calls_per_step:]  # the timed steps come last
+            v = v[which::calls_per_step]
+            out.append(scale * float(np.mean(v)) * 1024.0 if v else float("nan"))
+        return out[0] + out[1]
+
+    twice = ("warp_kernel", "align_kernel")
+    stages = {}
+    for stage, kernels in FULL_TRACK_KERNELS.items():
+        kb = {}
+        for k in kernels:
+            if k in twice:
+                kb[k] = per_launch(k, 0 if stage == "find_match_direct" else 1, 2)
+            else:
+                kb[k] = per_launch(k, 0, 1)
+        stages[stage] = {"traffic_bytes_per_step": float(np.nansum(list(kb.values()))), "by_kernel": kb}
+    return {"passes": status, "stages": stages,
+            "how": f"child runs of `bench.py --pipeline full` ({n_steps} steps) under rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in "
+                   "separate passes, KiB, FETCH_SIZE doubled (gfx950); per kernel launch, averaged over the steps"}
+
+
 def pyramid_roofline(ev: Events, store, images, reps: int = 5) -> dict:
     """K0, the one HBM-streaming kernel of the path: image pyramids of the whole
     replay batch rebuilt from the packed images in a single fused pass.  Algorithmic bytes per
@@ -977,15 +1070,35 @@ def cpu_baseline(args, W: Workload, T_est_w, result, iters_gpu) -> dict:
 class FullTrack:
     """BASELINE configs[2]: what FrameHandlerMono::processFrame does after sparse alignment
     (frame_handler_mono.cpp:145-190) plus the depth-filter update of the mapping thread, for
-    the same B replay frames: reproject the reference frame's map points, findMatchDirect
-    (affine warp + align2D), pose_optimizer::optimizeGaussNewton, DepthFilter::updateSeeds."""
+    the same B replay frames: reproject map points, findMatchDirect (affine warp + align2D),
+    pose_optimizer::optimizeGaussNewton, DepthFilter::updateSeeds.
+
+    mode "representative" (the `full_track` leg) shapes the work like the reference's own trace
+    (svo/test/benchmark.csv:14-306: ~190 trials -> ~120 matches per frame) and like its depth filter, where a seed
+    is updated by EVERY later frame until it converges (depth_filter.cpp:197-291):
+      * map points of problem b are the features of the keyframe 8 frames back, observed a second time in the
+        keyframe 16 frames back (Point::getCloseViewObs picks between them), with 7 % depth error: the trial starts
+        f * baseline/depth * 0.07 ~ 2-3 px off, alignment needs several evaluations and a good part of the trials
+        does not converge; points that left the image are not tried (Reprojector::reprojectPoint);
+      * the seeds of problem b are the features of frames b, b-1, ... b-9 (ages 1..10), each in the state it has
+        after its earlier updates -- produced by running the update kernel itself over those earlier frames during
+        set-up -- minus the ones that converged or were dropped on the way; old seeds see a long baseline and scan
+        tens of epipolar positions (matcher.cpp:248-291).
+    mode "easy" (`full_track_easy`) is the workload of rounds 1-2, kept for continuity: points and seeds of the
+    previous frame only, 1 % depth error (every trial matches after 1.65 evaluations, the scan hardly moves)."""
 
     STAGES = ("compose_pose", "reproject", "find_match_direct", "cam2world", "pose_optimize", "update_seeds")
+    KF1, KF2 = 8, 16          # representative: keyframes the map points are observed in, frames back from b
+    DEPTH_NOISE = 0.07        # ... and their relative depth error
+    SEED_AGES = 10            # ... seeds created 0..9 frames before frame b
+    SEEDS_PER_AGE = 100       # ... features of each of those frames that carry a seed
 
-    def __init__(self, W: Workload, dev, rank):
+    def __init__(self, W: Workload, dev, rank, mode: str = "representative"):
         from rpg_svo_amd import tracking
+        assert mode in ("representative", "easy")
         self.tr = tracking
         self.W = W
+        self.mode = mode
         cam, store = W.cam, W.store
         self.cam, self.store, self.dev = cam, store, dev
         B, N = W.B, W.n_patches
@@ -1004,32 +1117,52 @@ class FullTrack:
         M = B * N
         self.M = M
         self.cur_frame = self.cur_rows.repeat_interleave(N).contiguous()
-        # map points: the reference frame's features, 1% depth error along the viewing ray
-        c_ref = -(T[:B, :9].reshape(B, 3, 3).transpose(1, 2) @ T[:B, 9:, None])[..., 0]
-        ray = pos_all - c_ref[:, None, :]
-        noise = 1.0 + 0.01 * torch.randn(B, N, 1, generator=g, dtype=torch.float64).to(dev)
-        self.pt_pos = (c_ref[:, None, :] + ray * noise).reshape(M, 3).contiguous()
-        # observations: the feature in frame b, and (where it projects inside) in frame b-2
         b_idx = torch.arange(B, device=dev)
-        older = (b_idx - 2).clamp(min=0)
-        self.older = older
-        R2 = T[older, :9].reshape(B, 3, 3)
-        p2 = (R2[:, None] @ pos_all[..., None])[..., 0] + T[older, None, 9:]
-        px2 = torch.stack([cam.fx * p2[..., 0] / p2[..., 2] + cam.cx, cam.fy * p2[..., 1] / p2[..., 2] + cam.cy], -1)
-        has2 = ((b_idx >= 2)[:, None] & (px2[..., 0] > 12) & (px2[..., 0] < cam.width - 12) & (px2[..., 1] > 12)
-                & (px2[..., 1] < cam.height - 12) & (p2[..., 2] > 0))
-        n_obs = 1 + has2.reshape(M).to(torch.int32)
+        centre = lambda rows: -(T[rows, :9].reshape(-1, 3, 3).transpose(1, 2) @ T[rows, 9:, None])[..., 0]
+
+        def project(rows, pts):  # pts [B,N,3] into frames `rows` [B]: pixels, depth
+            pc = (T[rows, :9].reshape(-1, 3, 3)[:, None] @ pts[..., None])[..., 0] + T[rows, None, 9:]
+            return torch.stack([cam.fx * pc[..., 0] / pc[..., 2] + cam.cx, cam.fy * pc[..., 1] / pc[..., 2] + cam.cy], -1), pc[..., 2]
+
+        def inside(px, z, border):
+            return (z > 0) & (px[..., 0] >= border) & (px[..., 0] < cam.width - border) & (px[..., 1] >= border) & (px[..., 1] < cam.height - border)
+
+        # ---- map points and their observations -------------------------------------------------------
+        if mode == "easy":
+            src, older = b_idx, (b_idx - 2).clamp(min=0)
+            depth_noise, has_older = 0.01, b_idx >= 2
+        else:
+            src, older = (b_idx - self.KF1).clamp(min=0), (b_idx - self.KF2).clamp(min=0)
+            depth_noise, has_older = self.DEPTH_NOISE, b_idx >= self.KF2
+        self.src, self.older = src, older
+        pos_src, px_src, f_src = pos_all[src], px_all[src], f_all[src]
+        c_src = centre(src)
+        ray = pos_src - c_src[:, None, :]
+        noise = 1.0 + depth_noise * torch.randn(B, N, 1, generator=g, dtype=torch.float64).to(dev)
+        self.pt_pos = (c_src[:, None, :] + ray * noise).reshape(M, 3).contiguous()
+        # Reprojector::reprojectPoint (reprojector.cpp:206-217): only points inside the frame (8 px border) are
+        # tried; decided here with the ground-truth pose of the tracked frame (a point without observations is
+        # skipped by the kernels)
+        if mode == "easy":
+            in_cur = torch.ones(B, N, dtype=torch.bool, device=dev)
+        else:
+            pxc, zc = project(b_idx + 1, self.pt_pos.view(B, N, 3))
+            in_cur = inside(pxc, zc, 8)
+        self.in_cur = in_cur
+        px2, z2 = project(older, pos_src)
+        has2 = has_older[:, None] & inside(px2, z2, 12) & in_cur
+        n_obs = (in_cur.to(torch.int32) + has2.to(torch.int32)).reshape(M)
         ptr = torch.zeros(M + 1, dtype=torch.int32, device=dev)
         ptr[1:] = torch.cumsum(n_obs, 0)
         n_total = int(ptr[-1].item())
-        first = ptr[:-1].long()
+        first = ptr[:-1].long()[in_cur.reshape(M)]
         o_frame = torch.zeros(n_total, dtype=torch.int32, device=dev)
         o_px = torch.zeros(n_total, 2, dtype=torch.float64, device=dev)
         o_f = torch.zeros(n_total, 3, dtype=torch.float64, device=dev)
-        o_frame[first] = b_idx.repeat_interleave(N).to(torch.int32)
-        o_px[first] = px_all.reshape(M, 2)
-        o_f[first] = f_all.reshape(M, 3)
-        sec = first[has2.reshape(M)] + 1
+        o_frame[first] = src.repeat_interleave(N).to(torch.int32)[in_cur.reshape(M)]
+        o_px[first] = px_src.reshape(M, 2)[in_cur.reshape(M)]
+        o_f[first] = f_src.reshape(M, 3)[in_cur.reshape(M)]
+        sec = ptr[:-1].long()[has2.reshape(M)] + 1
         o_frame[sec] = older.repeat_interleave(N)[has2.reshape(M)].to(torch.int32)
         o_px[sec] = px2.reshape(M, 2)[has2.reshape(M)]
         d2 = torch.stack([(o_px[sec][:, 0] - cam.cx) / cam.fx, (o_px[sec][:, 1] - cam.cy) / cam.fy,
@@ -1040,18 +1173,27 @@ class FullTrack:
                                        px=o_px, f=o_f)
         self.matcher = tracking.Matcher(align_max_iter=10, n_pyr_levels=W.n_levels)
         self.n = torch.full((B,), N, dtype=torch.int32, device=dev)
-        # seeds: one per reference feature, inverse depth known to 10 %, range from 0.6 x depth
-        depth = ray.norm(dim=-1).reshape(M)
-        dm = depth * (1.0 + 0.1 * torch.randn(M, generator=g, dtype=torch.float64).to(dev))
-        z_range = (1.0 / (0.6 * depth)).float()
-        self.seed0 = dict(a=torch.full((M,), 10.0, device=dev), b=torch.full((M,), 10.0, device=dev),
-                          mu=(1.0 / dm).float(), z_range=z_range, sigma2=z_range * z_range / 36.0)
-        self.seeds = tracking.SeedSet(**{k: v.clone() for k, v in self.seed0.items()},
-                                      batch_id=torch.zeros(M, dtype=torch.int32, device=dev))
-        self.seed_ftr = tracking.FeatureSet(frame=b_idx.repeat_interleave(N).to(torch.int32).contiguous(),
-                                            level=torch.zeros(M, dtype=torch.int32, device=dev),
-                                            px=px_all.reshape(M, 2).contiguous(), f=f_all.reshape(M, 3).contiguous())
         self.df = tracking.DepthFilter(n_pyr_levels=W.n_levels)
+        # ---- seeds ---------------------------------------------------------------------------------
+        if mode == "easy":
+            # one per reference feature, inverse depth known to 10 %, range from 0.6 x depth
+            depth = ray.norm(dim=-1).reshape(M)
+            dm = depth * (1.0 + 0.1 * torch.randn(M, generator=g, dtype=torch.float64).to(dev))
+            z_range = (1.0 / (0.6 * depth)).float()
+            self.seed0 = dict(a=torch.full((M,), 10.0, device=dev), b=torch.full((M,), 10.0, device=dev),
+                              mu=(1.0 / dm).float(), z_range=z_range, sigma2=z_range * z_range / 36.0)
+            self.seed_ftr = tracking.FeatureSet(frame=b_idx.repeat_interleave(N).to(torch.int32).contiguous(),
+                                                level=torch.zeros(M, dtype=torch.int32, device=dev),
+                                                px=px_all.reshape(M, 2).contiguous(), f=f_all.reshape(M, 3).contiguous())
+            self.seed_cur = self.cur_frame
+            self.seed_age = torch.ones(M, dtype=torch.int32, device=dev)
+            self.seed_frame_of = b_idx.repeat_interleave(N)
+        else:
+            self._make_seed_population(T, g)
+        S = self.seed0["mu"].shape[0]
+        self.S = S
+        self.seeds = tracking.SeedSet(**{k: v.clone() for k, v in self.seed0.items()},
+                                      batch_id=torch.zeros(S, dtype=torch.int32, device=dev))
         self.f_new = torch.empty(M, 3, dtype=torch.float64, device=dev)
         # result blocks reused by every step (no allocation / memset inside the timed stages)
         self.cell_px = (torch.zeros(M, dtype=torch.int32, device=dev), torch.zeros(M, 2, dtype=torch.float64, device=dev))
@@ -1062,10 +1204,72 @@ class FullTrack:
                                          torch.zeros(B, 4, dtype=torch.float64, device=dev),
                                          torch.zeros(B, dtype=torch.int32, device=dev),
                                          torch.empty(B, N, dtype=torch.uint8, device=dev))
-        self.seed_out = (torch.zeros(M, dtype=torch.int32, device=dev), torch.zeros(M, 3, dtype=torch.float64, device=dev),
-                         torch.zeros(M, 2, dtype=torch.float64, device=dev))
+        self.seed_out = (torch.zeros(S, dtype=torch.int32, device=dev), torch.zeros(S, 3, dtype=torch.float64, device=dev),
+                         torch.zeros(S, 2, dtype=torch.float64, device=dev))
         self.events = []
         self.last = {}
+
+    def _make_seed_population(self, T, g):
+        """Seeds as the depth filter holds them while frame b+1 arrives: created at frames b, b-1, ... (ages 1, 2, ...)
+        by DepthFilter::initializeSeeds (Seed ctor, depth_filter.cpp:37-46: a = b = 10, mu = 1/depth_mean,
+        z_range = 1/depth_min with depth_min = half the closest scene depth, sigma2 = z_range^2/36) and since updated
+        with every frame in between.  Those earlier updates are run here, with the update kernel and the ground-truth
+        poses: state[j] = the seeds of every frame after j updates.  A seed leaves the population when it converges,
+        turns NaN (depth_filter.cpp:261-287) or, in this replay, is no longer visible."""
+        tr, W, dev, cam = self.tr, self.W, self.dev, self.cam
+        B, Ns, A = self.B, self.SEEDS_PER_AGE, self.SEED_AGES
+        sel = torch.randperm(W.n_patches, generator=g)[:Ns].sort().values.to(dev)
+        px = W.px_all[:, sel].contiguous()      # [B,Ns,2] seed features of frame r
+        f = W.f_all[:, sel].contiguous()
+        pos = W.pos_all[:, sel]
+        c = -(T[:B, :9].reshape(B, 3, 3).transpose(1, 2) @ T[:B, 9:, None])[..., 0]
+        depth = (pos - c[:, None, :]).norm(dim=-1)
+        depth_mean, depth_min = depth.mean(1, keepdim=True), 0.5 * depth.min(1, keepdim=True).values
+        z_range = (1.0 / depth_min).expand(B, Ns).float()
+        state = dict(a=torch.full((B, Ns), 10.0, device=dev), b=torch.full((B, Ns), 10.0, device=dev),
+                     mu=(1.0 / depth_mean).expand(B, Ns).float().contiguous(), z_range=z_range.contiguous(),
+                     sigma2=(z_range * z_range / 36.0).contiguous())
+        alive = torch.ones(B, Ns, dtype=torch.bool, device=dev)
+        r_idx = torch.arange(B, device=dev)
+        ftr = tr.FeatureSet(frame=r_idx.repeat_interleave(Ns).to(torch.int32).contiguous(),
+                            level=torch.zeros(B * Ns, dtype=torch.int32, device=dev),
+                            px=px.reshape(-1, 2).contiguous(), f=f.reshape(-1, 3).contiguous())
+        # the population of problem b at age a is state[a-1] of frame r = b+1-a
+        parts = {k: [] for k in ("a", "b", "mu", "z_range", "sigma2")}
+        part_ftr, part_cur, part_age, part_b = [], [], [], []
+        GONE = (capi.SEED_CONVERGED, capi.SEED_NAN, capi.SEED_ERASED_OLD, capi.SEED_NOT_IN_FRAME, capi.SEED_BEHIND)
+        for j in range(A):  # j = updates already received = age - 1
+            b_of_r = r_idx + j          # problem whose tracked frame b+1 = r + j + 1 gives these seeds update j+1
+            ok = (alive & (b_of_r < B)[:, None]).reshape(-1)
+            keep = ok.nonzero()[:, 0]
+            for k in parts:
+                parts[k].append(state[k].reshape(-1)[keep].clone())
+            part_ftr.append(keep)
+            part_cur.append((B + 1 + b_of_r).repeat_interleave(Ns)[keep].to(torch.int32))
+            part_age.append(torch.full((len(keep),), j + 1, dtype=torch.int32, device=dev))
+            part_b.append(b_of_r.repeat_interleave(Ns)[keep])
+            if j == A - 1:
+                break
+            # update j+1 of every frame's seeds, against frame r+j+1 at its ground-truth pose (rows 0..B of the table)
+            cur = (r_idx + j + 1).clamp(max=B).repeat_interleave(Ns).to(torch.int32).contiguous()
+            seeds = tr.SeedSet(**{k: v.reshape(-1).contiguous() for k, v in state.items()},
+                               batch_id=torch.zeros(B * Ns, dtype=torch.int32, device=dev))
+            status, _, _ = self.df.update_seeds(self.store, cam, self.frames, cur, ftr, seeds, 0)
+            state = {k: getattr(seeds, k).view(B, Ns) for k in state}
+            st = status.view(B, Ns)
+            gone = torch.zeros_like(alive)
+            for code in GONE:
+                gone |= st == code
+            alive = alive & ~gone
+        order = torch.argsort(torch.cat(part_b), stable=True)  # seeds of one problem next to each other (as one frame's list)
+        cat = lambda xs: torch.cat(xs)[order].contiguous()
+        self.seed0 = {k: cat(v) for k, v in parts.items()}
+        fi = cat(part_ftr)
+        self.seed_ftr = tr.FeatureSet(frame=ftr.frame[fi].contiguous(), level=torch.zeros(len(fi), dtype=torch.int32, device=dev),
+                                      px=ftr.px[fi].contiguous(), f=ftr.f[fi].contiguous())
+        self.seed_cur = cat(part_cur)
+        self.seed_age = cat(part_age)
+        self.seed_frame_of = cat(part_b)
 
     def step(self, T_cur_from_ref, ev: Events | None):
         tr = self.tr
@@ -1089,7 +1293,7 @@ class FullTrack:
         mk()
         for k, v in self.seed0.items():
             getattr(self.seeds, k).copy_(v)
-        status, _, _ = self.df.update_seeds(self.store, self.cam, self.frames, self.cur_frame, self.seed_ftr, self.seeds, 0,
+        status, _, _ = self.df.update_seeds(self.store, self.cam, self.frames, self.seed_cur, self.seed_ftr, self.seeds, 0,
                                             out=self.seed_out)
         mk()
         self.last = dict(match=m, pose=po, seed_status=status, px_proj=px)
@@ -1105,10 +1309,17 @@ class FullTrack:
     def describe(self):
         m, po, st = self.last["match"], self.last["pose"], self.last["seed_status"].cpu().numpy()
         T_est = po.T_f_w.cpu().numpy()
-        return {"match_trials_per_frame": self.N, "matches_per_frame": float(m.ok.float().sum().item() / self.B),
+        names = {capi.SEED_ERASED_OLD: "erased_old", capi.SEED_BEHIND: "behind", capi.SEED_NOT_IN_FRAME: "not_in_frame",
+                 capi.SEED_NO_MATCH: "no_match", capi.SEED_UPDATED: "updated", capi.SEED_CONVERGED: "converged",
+                 capi.SEED_NAN: "nan"}
+        age = self.seed_age.cpu().numpy()
+        return {"mode": self.mode,
+                "match_trials_per_frame": float(self.in_cur.float().sum().item() / self.B),
+                "matches_per_frame": float(m.ok.float().sum().item() / self.B),
                 "pose_refine_obs_after_pruning": float(po.stats[:, 3].mean().item()),
-                "seeds_per_frame": self.N,
-                "seed_status_hist": {str(k): int((st == k).sum()) for k in np.unique(st)},
+                "seeds_per_frame": self.S / self.B,
+                "seeds_per_frame_by_age": {str(a): float((age == a).sum() / self.B) for a in np.unique(age)},
+                "seed_status_per_frame": {names.get(int(k), str(k)): float((st == k).sum() / self.B) for k in np.unique(st)},
                 "pipeline": "sparse_align -> reproject -> findMatchDirect -> pose_optimize -> updateSeeds",
                 "_T_refined": T_est}
 
@@ -1139,12 +1350,16 @@ class FullTrack:
         eval_hist = torch.bincount(evals[tried].long(), minlength=12)[:12].tolist()
         wave_max_mean = float(ev64.max(dim=1).values.float().mean().item())
         fm_bytes = n_tried * (121 + 100 + 48) + 81.0 * n_eval
+        S = self.S
         steps_ptr = lib.svo_hip_update_seeds_scan_steps(self.df.last_workspace.data_ptr())
-        scan = torch.empty(M, dtype=torch.int32, device=dev)
-        capi.check(lib.svo_hip_memcpy_d2d(scan.data_ptr(), steps_ptr, M * 4, stream), "svo_hip_memcpy_d2d")
+        scan = torch.empty(S, dtype=torch.int32, device=dev)
+        capi.check(lib.svo_hip_memcpy_d2d(scan.data_ptr(), steps_ptr, S * 4, stream), "svo_hip_memcpy_d2d")
         torch.cuda.synchronize()
         n_scan = float(scan.sum().item())
-        seed_bytes = M * 36.0 + 64.0 * n_scan + M * (121.0 + 100.0)
+        seed_bytes = S * 36.0 + 64.0 * n_scan + S * (121.0 + 100.0)
+        edges = [0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1001]
+        scan_hist = {f"{lo}..{hi - 1}": float(((scan >= lo) & (scan < hi)).sum().item() / self.B) for lo, hi in zip(edges[:-1], edges[1:])}
+        scan_by_age = {str(int(a)): float(scan[self.seed_age == a].float().mean().item()) for a in torch.unique(self.seed_age)}
         return {
             "find_match_direct": roofline("match_prepare + warp_kernel + align_kernel", fm_bytes, stages["find_match_direct"],
                                           trials=n_tried, alignment_evaluations_per_trial=n_eval / max(n_tried, 1),
@@ -1152,13 +1367,15 @@ class FullTrack:
                                           alignment_evaluations_per_wave_of_64_trials=wave_max_mean),
             "pose_optimize": roofline("pose_opt_wave_kernel", B * (N * 52.0 + 416.0), stages["pose_optimize"]),
             "update_seeds": roofline("seed_prepare + warp_kernel + epi_scan + align_kernel + seed_finish", seed_bytes,
-                                     stages["update_seeds"], scanned_positions_per_seed=n_scan / M),
+                                     stages["update_seeds"], seeds=S, scanned_positions_per_seed=n_scan / S,
+                                     scanned_positions_per_seed_by_age=scan_by_age,
+                                     seeds_per_frame_by_scanned_positions=scan_hist),
         }
 
 
-def full_track_leg(W: Workload, sia, ev: Events, dev, rank, lib, with_parity: bool, steps: int = 5) -> dict:
-    """BASELINE configs[2] on the headline frames: the whole track as one step."""
-    full = FullTrack(W, dev, rank)
+def full_track_leg(W: Workload, sia, ev: Events, dev, rank, lib, with_parity: bool, steps: int = 5, mode: str = "representative") -> dict:
+    """BASELINE configs[2] on the headline frames: the whole track as one step (FullTrack: representative / easy)."""
+    full = FullTrack(W, dev, rank, mode=mode)
     out = sia.alloc_result(W.B, dev)
     marks = []
 
@@ -1182,7 +1399,8 @@ def full_track_leg(W: Workload, sia, ev: Events, dev, rank, lib, with_parity: bo
     step_ms = float(np.mean([ev.ms(a, c) for a, _, c in marks]))
     d = full.describe()
     T_ref_est = d.pop("_T_refined")
-    res = {"workload": "vga4_n200_full_track", "frames_per_step": W.B, "frames_per_s": W.B / step_ms * 1e3, "ms_per_step": step_ms,
+    res = {"workload": "vga4_n200_full_track" + ("_easy" if mode == "easy" else ""), "frames_per_step": W.B,
+           "frames_per_s": W.B / step_ms * 1e3, "ms_per_step": step_ms,
            "ms_per_step_host_wall": wall, "stages_ms": stages,
            "median_pose_error_vs_gt_after_refine": float(np.median(se3.log_norm(T_ref_est, W.T_gt[1:W.B + 1])))}
     res.update(d)
@@ -1200,80 +1418,116 @@ def full_track_leg(W: Workload, sia, ev: Events, dev, rank, lib, with_parity: bo
     return res
 
 
-def full_track_parity(W: Workload, full: FullTrack, out, T_refined_gpu, n_sample: int = 48) -> dict:
+def full_track_parity(W: Workload, full: FullTrack, out, T_refined_gpu, n_sample: int = 32) -> dict:
     """The same chain on the host for a sample of frames -- the reference's own translation units
     where oracle/_ref is present (SparseImgAlign::run -> Matcher::findMatchDirect per point ->
-    pose_optimizer::optimizeGaussNewton -> DepthFilter::updateSeeds) -- compared stage by stage."""
+    pose_optimizer::optimizeGaussNewton -> DepthFilter::updateSeeds) -- compared stage by stage.  Every stage is run
+    twice on the host: fed by the previous stage of the HOST chain (differences accumulate along the chain, as they
+    would between two machines), and fed with the DEVICE's output of the previous stage (the stage on its own)."""
     from oracle import pytrack
     which = "ref" if pytrack.ref_available() else "orc"
     trk = pytrack.Track(which)
     B, N, cam = W.B, W.n_patches, W.cam
-    idx = np.unique(np.linspace(2, B - 1, n_sample).astype(int))
+    lo = max(FullTrack.KF2, FullTrack.SEED_AGES) + 1
+    idx = np.unique(np.linspace(lo, B - 1, n_sample).astype(int))
     m = full.last["match"]
     ok_g = m.ok.view(B, N).cpu().numpy()
     px_g = m.px_cur.view(B, N, 2).cpu().numpy()
-    st_g = full.last["seed_status"].view(B, N).cpu().numpy()
-    mu_g = full.seeds.mu.view(B, N).cpu().numpy()
     T_k1_g = se3.mul(out.T_cur_from_ref.cpu().numpy(), W.T_ref_w)
     pt_pos = full.pt_pos.view(B, N, 3).cpu().numpy()
     px_all, f_all, pos_all = W.px_all.cpu().numpy(), W.f_all.cpu().numpy(), W.pos_all.cpu().numpy()
     optr = full.obs_ptr.cpu().numpy()
-    o_px, o_f = full.obs.px.cpu().numpy(), full.obs.f.cpu().numpy()
-    seed0 = {k: v.view(B, N).cpu().numpy() for k, v in full.seed0.items()}
-    older = full.older.cpu().numpy()
+    o_px, o_f, o_fr = full.obs.px.cpu().numpy(), full.obs.f.cpu().numpy(), full.obs.frame.cpu().numpy()
+    # seeds of a problem are contiguous (sorted by problem)
+    s_b = full.seed_frame_of.cpu().numpy()
+    s_lo, s_hi = np.searchsorted(s_b, idx, "left"), np.searchsorted(s_b, idx, "right")
+    s_fr, s_px, s_f = full.seed_ftr.frame.cpu().numpy(), full.seed_ftr.px.cpu().numpy(), full.seed_ftr.f.cpu().numpy()
+    seed0 = {k: v.cpu().numpy() for k, v in full.seed0.items()}
+    st_g = full.last["seed_status"].cpu().numpy()
+    mu_g = full.seeds.mu.cpu().numpy()
     opt = pytrack.matcher_options(n_pyr_levels=W.n_levels)
-    d_k1, d_final, same_ok, same_px, same_status, mu_rel = [], [], [], [], [], []
+    acc = {k: [] for k in ("d_k1", "d_final", "d_final_same", "ok", "px", "ok_same", "px_same", "st", "st_same", "mu", "mu_same")}
     t0 = time.time()
-    for b in idx:
-        imgs = [W.images[i].cpu().numpy() for i in (b, older[b], b + 1)]
-        pyrs = [trk.create_img_pyramid(im, W.n_levels) for im in imgs]
+    for bi, b in enumerate(idx):
+        rows = sorted(set([b] + [int(o_fr[k]) for k in range(optr[b * N], optr[(b + 1) * N])] + [int(x) for x in s_fr[s_lo[bi]:s_hi[bi]]]))
+        local = {r: i for i, r in enumerate(rows)}
+        cur = len(rows)  # the tracked frame b+1 sits last
+        pyrs = [trk.create_img_pyramid(W.images[r].cpu().numpy(), W.n_levels) for r in rows + [b + 1]]
         hp = np.ones(N, dtype=np.uint8)
-        T_cur, _ = trk.sparse_img_align_run(pyrs[0], pyrs[2], cam, W.T_ref_w[b], W.T_prior_w[b], px_all[b], f_all[b], hp,
+        T_cur, _ = trk.sparse_img_align_run(pyrs[local[b]], pyrs[cur], cam, W.T_ref_w[b], W.T_prior_w[b], px_all[b], f_all[b], hp,
                                             pos_all[b], W.max_level, W.min_level)
-        d_k1.append(se3.log_norm(T_k1_g[b][None], T_cur[None])[0])
-        frames = pytrack.make_frames(pyrs, np.stack([W.T_gt[b], W.T_gt[older[b]], T_cur]))
-        ok_c = np.zeros(N, dtype=np.int32)
-        px_c = np.zeros((N, 2))
-        lvl_c = np.zeros(N, dtype=np.int32)
-        for i in range(N):
-            k0, k1 = optr[b * N + i], optr[b * N + i + 1]
-            obs = [pytrack.make_feature(0, o_px[k0], o_f[k0])]
-            if k1 - k0 == 2:
-                obs.append(pytrack.make_feature(1, o_px[k0 + 1], o_f[k0 + 1]))
-            _, px_init = trk.reproject_point(cam, T_cur, pt_pos[b, i], 30, (cam.width + 29) // 30)
-            ok, px, r = trk.find_match_direct(frames, cam, 2, pt_pos[b, i], obs, px_init, opt)
-            ok_c[i], px_c[i], lvl_c[i] = ok, px, r["search_level"]
-        same_ok.append(np.mean((ok_c > 0) == (ok_g[b] > 0)))
-        both = (ok_c > 0) & (ok_g[b] > 0)
-        same_px.append(np.mean(np.abs(px_c[both] - px_g[b][both]).max(1) < 1e-6) if both.any() else 1.0)
-        dd = np.stack([(px_c[:, 0] - cam.cx) / cam.fx, (px_c[:, 1] - cam.cy) / cam.fy, np.ones(N)], -1)
-        f_new = dd / np.linalg.norm(dd, axis=1, keepdims=True)
-        po = trk.pose_optimize(cam, T_cur, f_new, lvl_c, (ok_c > 0).astype(np.uint8), pt_pos[b], 2.0, 10)
-        d_final.append(se3.log_norm(T_refined_gpu[b][None], po["T_f_w"][None])[0])
-        frames2 = pytrack.make_frames(pyrs, np.stack([W.T_gt[b], W.T_gt[older[b]], po["T_f_w"]]))
-        seeds = []
-        for i in range(N):
-            s = pytrack.Seed()
-            s.ftr = pytrack.make_feature(0, px_all[b, i], f_all[b, i])
-            s.batch_id, s.a, s.b, s.mu = 0, float(seed0["a"][b, i]), float(seed0["b"][b, i]), float(seed0["mu"][b, i])
-            s.z_range, s.sigma2 = float(seed0["z_range"][b, i]), float(seed0["sigma2"][b, i])
-            seeds.append(s)
-        _, so, io = trk.update_seeds(frames2, cam, 2, seeds, batch_counter=0, opt=opt)
-        stc = np.array([x.status for x in io])
-        same_status.append(np.mean(stc == st_g[b]))
-        upd = (stc == st_g[b]) & np.isin(stc, (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED))
-        if upd.any():
-            muc = np.array([x.mu for x in so])
-            mu_rel.append(np.max(np.abs(muc[upd] - mu_g[b][upd]) / np.abs(muc[upd])))
+        acc["d_k1"].append(se3.log_norm(T_k1_g[b][None], T_cur[None])[0])
+        T_rows = [W.T_gt[r] for r in rows]
+
+        def match_all(T_pose):
+            frames = pytrack.make_frames(pyrs, np.stack(T_rows + [T_pose]))
+            ok_c, px_c, lvl_c = np.zeros(N, dtype=np.int32), np.zeros((N, 2)), np.zeros(N, dtype=np.int32)
+            for i in range(N):
+                k0, k1 = optr[b * N + i], optr[b * N + i + 1]
+                if k1 == k0:
+                    continue  # left the image: not tried (Reprojector::reprojectPoint)
+                obs = [pytrack.make_feature(local[int(o_fr[k])], o_px[k], o_f[k]) for k in range(k0, k1)]
+                _, px_init = trk.reproject_point(cam, T_pose, pt_pos[b, i], 30, (cam.width + 29) // 30)
+                ok, px, r = trk.find_match_direct(frames, cam, cur, pt_pos[b, i], obs, px_init, opt)
+                ok_c[i], px_c[i], lvl_c[i] = ok, px, r["search_level"]
+            return ok_c, px_c, lvl_c
+
+        def refine(T_pose, ok_c, px_c, lvl_c):
+            dd = np.stack([(px_c[:, 0] - cam.cx) / cam.fx, (px_c[:, 1] - cam.cy) / cam.fy, np.ones(N)], -1)
+            f_new = dd / np.linalg.norm(dd, axis=1, keepdims=True)
+            return trk.pose_optimize(cam, T_pose, f_new, lvl_c, (ok_c > 0).astype(np.uint8), pt_pos[b], 2.0, 10)["T_f_w"]
+
+        def seeds_all(T_pose):
+            frames = pytrack.make_frames(pyrs, np.stack(T_rows + [T_pose]))
+            seeds = []
+            for k in range(s_lo[bi], s_hi[bi]):
+                sd = pytrack.Seed()
+                sd.ftr = pytrack.make_feature(local[int(s_fr[k])], s_px[k], s_f[k])
+                sd.batch_id, sd.a, sd.b, sd.mu = 0, float(seed0["a"][k]), float(seed0["b"][k]), float(seed0["mu"][k])
+                sd.z_range, sd.sigma2 = float(seed0["z_range"][k]), float(seed0["sigma2"][k])
+                seeds.append(sd)
+            _, so, io = trk.update_seeds(frames, cam, cur, seeds, batch_counter=0, opt=opt)
+            return np.array([x.status for x in io]), np.array([x.mu for x in so])
+
+        def cmp_match(ok_c, px_c, key_ok, key_px):
+            acc[key_ok].append(np.mean((ok_c > 0) == (ok_g[b] > 0)))
+            both = (ok_c > 0) & (ok_g[b] > 0)
+            acc[key_px].append(np.mean(np.abs(px_c[both] - px_g[b][both]).max(1) < 1e-6) if both.any() else 1.0)
+
+        def cmp_seeds(stc, muc, key_st, key_mu):
+            sg, mg = st_g[s_lo[bi]:s_hi[bi]], mu_g[s_lo[bi]:s_hi[bi]]
+            acc[key_st].append(np.mean(stc == sg))
+            upd = (stc == sg) & np.isin(stc, (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED))
+            if upd.any():
+                acc[key_mu].append(np.max(np.abs(muc[upd] - mg[upd]) / np.abs(muc[upd])))
+
+        # (1) the host chain on its own outputs
+        ok_c, px_c, lvl_c = match_all(T_cur)
+        cmp_match(ok_c, px_c, "ok", "px")
+        T_po = refine(T_cur, ok_c, px_c, lvl_c)
+        acc["d_final"].append(se3.log_norm(T_refined_gpu[b][None], T_po[None])[0])
+        cmp_seeds(*seeds_all(T_po), "st", "mu")
+        # (2) each host stage fed with the device's previous stage
+        ok_s, px_s, lvl_s = match_all(T_k1_g[b])
+        cmp_match(ok_s, px_s, "ok_same", "px_same")
+        lvl_g = m.search_level.view(B, N)[b].cpu().numpy()
+        T_po_s = refine(T_k1_g[b], ok_g[b], px_g[b], lvl_g)
+        acc["d_final_same"].append(se3.log_norm(T_refined_gpu[b][None], T_po_s[None])[0])
+        cmp_seeds(*seeds_all(T_refined_gpu[b]), "st_same", "mu_same")
+    mx = lambda k: float(np.max(acc[k])) if acc[k] else None
     return {"frames_compared": int(len(idx)), "against": "reference" if which == "ref" else "port",
-            "sparse_align_se3_lognorm_max": float(np.max(d_k1)), "sparse_align_se3_lognorm_median": float(np.median(d_k1)),
-            "find_match_direct_same_verdict_frac": float(np.mean(same_ok)),
-            "find_match_direct_same_pixel_frac_of_common_matches": float(np.mean(same_px)),
-            "refined_pose_se3_lognorm_max": float(np.max(d_final)), "refined_pose_se3_lognorm_median": float(np.median(d_final)),
-            "seed_status_same_frac": float(np.mean(same_status)),
-            "seed_mu_max_rel_diff": float(np.max(mu_rel)) if mu_rel else None,
-            "seconds": time.time() - t0,
-            "note": "each stage is fed by the previous stage of ITS OWN chain: differences accumulate along the chain"}
+            "sparse_align_se3_lognorm_max": mx("d_k1"), "sparse_align_se3_lognorm_median": float(np.median(acc["d_k1"])),
+            "host_chain_on_its_own_outputs": {
+                "find_match_direct_same_verdict_frac": float(np.mean(acc["ok"])),
+                "find_match_direct_same_pixel_frac_of_common_matches": float(np.mean(acc["px"])),
+                "refined_pose_se3_lognorm_max": mx("d_final"), "refined_pose_se3_lognorm_median": float(np.median(acc["d_final"])),
+                "seed_status_same_frac": float(np.mean(acc["st"])), "seed_mu_max_rel_diff": mx("mu")},
+            "host_stage_fed_with_the_device_previous_stage": {
+                "find_match_direct_same_verdict_frac": float(np.mean(acc["ok_same"])),
+                "find_match_direct_same_pixel_frac_of_common_matches": float(np.mean(acc["px_same"])),
+                "refined_pose_se3_lognorm_max": mx("d_final_same"),
+                "seed_status_same_frac": float(np.mean(acc["st_same"])), "seed_mu_max_rel_diff": mx("mu_same")},
+            "seeds_compared_per_frame": float(np.mean(s_hi - s_lo)), "seconds": time.time() - t0}
 
 
 if __name__ == "__main__":

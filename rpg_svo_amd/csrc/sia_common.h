@@ -54,17 +54,13 @@ __device__ __forceinline__ void cut_row7(const uint32_t d[3], uint32_t bo, float
   out[6] = (float)((hi >> 16) & 0xffu);
 }
 
-// bytes [x0, x0+4] of the row at byte offset ro as floats (the kernels without a window cache)
-__device__ __forceinline__ void load_row5(const uint8_t* __restrict__ lvl, uint32_t ro, int x0, float out[5]) {
-  const int xa = run_start(x0, 5);
-  uint32_t d[3];
-  svo_pyr::load_run12(lvl, ro, xa, d);
-  const uint32_t bo = (uint32_t)(x0 - xa);  // 0..7
+// bytes [bo, bo+4] (bo in 0..7) of three consecutive dwords as floats (the kernels without a window cache)
+__device__ __forceinline__ void cut_row5_plain(const uint32_t d[3], uint32_t bo, float out[5]) {
   const bool up = bo >= 4u;
   const uint32_t a = up ? d[1] : d[0], b = up ? d[2] : d[1];
   const uint32_t sel = bo & 3u;
-  const uint32_t lo = __builtin_amdgcn_alignbyte(b, a, sel);  // bytes x0..x0+3
-  const uint32_t hi = b >> (8 * sel);                         // byte x0+4 in bits 0..7
+  const uint32_t lo = __builtin_amdgcn_alignbyte(b, a, sel);  // bytes bo..bo+3
+  const uint32_t hi = b >> (8 * sel);                         // byte bo+4 in bits 0..7
   out[0] = (float)(lo & 0xffu);
   out[1] = (float)((lo >> 8) & 0xffu);
   out[2] = (float)((lo >> 16) & 0xffu);

@@ -463,8 +463,13 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
               cut_row5(d0, d1, d2, bo, kup, W[r]);
             }
           } else {
+            // 5 rows x 5 bytes [u_i-2, u_i+2] as 12-byte runs (one three-way branch on the tile position for all rows)
+            uint32_t cw[5][3];
+            const int cxa = run_start(u_i - 2, 5);
+            const uint32_t cbo = (uint32_t)(u_i - 2 - cxa);  // 0..7
+            load_window12<5>(cur_img, pitch, cxa, v_i - 2, cw);
 #pragma unroll
-            for (int r = 0; r < 5; ++r) load_row5(cur_img, svo_pyr::row_off(v_i - 2 + r, pitch), u_i - 2, W[r]);
+            for (int r = 0; r < 5; ++r) cut_row5_plain(cw[r], cbo, W[r]);
           }
 #endif
           float Bt[6][6];
