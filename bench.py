@@ -1077,21 +1077,31 @@ class FullTrack:
     (svo/test/benchmark.csv:14-306: ~190 trials -> ~120 matches per frame) and like its depth filter, where a seed
     is updated by EVERY later frame until it converges (depth_filter.cpp:197-291):
       * map points of problem b are the features of the keyframe 8 frames back, observed a second time in the
-        keyframe 16 frames back (Point::getCloseViewObs picks between them), with 7 % depth error: the trial starts
-        f * baseline/depth * 0.07 ~ 2-3 px off, alignment needs several evaluations and a good part of the trials
-        does not converge; points that left the image are not tried (Reprojector::reprojectPoint);
-      * the seeds of problem b are the features of frames b, b-1, ... b-9 (ages 1..10), each in the state it has
-        after its earlier updates -- produced by running the update kernel itself over those earlier frames during
-        set-up -- minus the ones that converged or were dropped on the way; old seeds see a long baseline and scan
-        tens of epipolar positions (matcher.cpp:248-291).
+        keyframe 16 frames back (Point::getCloseViewObs picks between them).  65 % are good points with 7 % depth
+        error: the trial starts f * baseline/depth * 0.07 ~ 2-3 px off and alignment needs several evaluations.
+        35 % are bad points (in the reference: unconverged candidates, wrong matches of the depth filter) whose depth
+        is 25-60 % off: they project many pixels away, alignment walks its 10 iterations and mostly fails -- the
+        reference trace's 37 % failing trials.  Points that left the image are not tried (Reprojector::reprojectPoint);
+      * the seeds of problem b are what the depth filter holds when frame b+1 arrives.  Every frame starts seeds
+        (SEEDS_MATCHED + SEEDS_UNMATCHED of its features).  A "matched" seed has been updated by every frame since
+        (ages 1..12: its state is produced by running the update kernel itself over those earlier frames during set-up)
+        and leaves when it converges; sigma shrinks as the baseline grows, so its epipolar segment stays a few
+        pixels long.  An "unmatched" seed has failed every search so far -- only b was incremented
+        (depth_filter.cpp:238-245), sigma is still the initial one -- and stays until its keyframe batch is three
+        batches old (:216-219; ages 1..30 here): its segment grows with the baseline, tens to hundreds of ZMSSD
+        positions (matcher.cpp:248-291).  30 % of new seeds are taken to be of that kind; they are about half of
+        the live population and nearly all of the scan work.
     mode "easy" (`full_track_easy`) is the workload of rounds 1-2, kept for continuity: points and seeds of the
     previous frame only, 1 % depth error (every trial matches after 1.65 evaluations, the scan hardly moves)."""
 
     STAGES = ("compose_pose", "reproject", "find_match_direct", "cam2world", "pose_optimize", "update_seeds")
     KF1, KF2 = 8, 16          # representative: keyframes the map points are observed in, frames back from b
-    DEPTH_NOISE = 0.07        # ... and their relative depth error
-    SEED_AGES = 10            # ... seeds created 0..9 frames before frame b
-    SEEDS_PER_AGE = 100       # ... features of each of those frames that carry a seed
+    DEPTH_NOISE = 0.07        # ... relative depth error of the good points
+    BAD_POINTS = 0.35         # ... share of points whose depth is grossly wrong (25-60 %)
+    SEED_AGES = 12            # matched seeds: created 0..11 frames before frame b, updated by every frame since
+    SEEDS_MATCHED = 32        # ... of them per frame
+    SEED_AGES_UNMATCHED = 30  # unmatched seeds: every search failed so far; kept for three keyframe batches
+    SEEDS_UNMATCHED = 14      # ... of them per frame (30 % of the new seeds)
 
     def __init__(self, W: Workload, dev, rank, mode: str = "representative"):
         from rpg_svo_amd import tracking
@@ -1139,6 +1149,11 @@ class FullTrack:
         c_src = centre(src)
         ray = pos_src - c_src[:, None, :]
         noise = 1.0 + depth_noise * torch.randn(B, N, 1, generator=g, dtype=torch.float64).to(dev)
+        if mode != "easy":
+            bad = (torch.rand(B, N, 1, generator=g) < self.BAD_POINTS).to(dev)
+            gross = (0.25 + 0.35 * torch.rand(B, N, 1, generator=g, dtype=torch.float64)) * (2.0 * (torch.rand(B, N, 1, generator=g) < 0.5) - 1.0)
+            noise = torch.where(bad, 1.0 + gross.to(dev), noise)
+            self.bad_point = bad.reshape(M)
         self.pt_pos = (c_src[:, None, :] + ray * noise).reshape(M, 3).contiguous()
         # Reprojector::reprojectPoint (reprojector.cpp:206-217): only points inside the frame (8 px border) are
         # tried; decided here with the ground-truth pose of the tracked frame (a point without observations is
@@ -1188,6 +1203,7 @@ class FullTrack:
             self.seed_cur = self.cur_frame
             self.seed_age = torch.ones(M, dtype=torch.int32, device=dev)
             self.seed_frame_of = b_idx.repeat_interleave(N)
+            self.seed_unmatched = torch.zeros(M, dtype=torch.bool, device=dev)
         else:
             self._make_seed_population(T, g)
         S = self.seed0["mu"].shape[0]
@@ -1217,50 +1233,59 @@ class FullTrack:
         poses: state[j] = the seeds of every frame after j updates.  A seed leaves the population when it converges,
         turns NaN (depth_filter.cpp:261-287) or, in this replay, is no longer visible."""
         tr, W, dev, cam = self.tr, self.W, self.dev, self.cam
-        B, Ns, A = self.B, self.SEEDS_PER_AGE, self.SEED_AGES
+        B, Nm, Nu, A, Au = self.B, self.SEEDS_MATCHED, self.SEEDS_UNMATCHED, self.SEED_AGES, self.SEED_AGES_UNMATCHED
+        Ns = Nm + Nu
         sel = torch.randperm(W.n_patches, generator=g)[:Ns].sort().values.to(dev)
-        px = W.px_all[:, sel].contiguous()      # [B,Ns,2] seed features of frame r
+        px = W.px_all[:, sel].contiguous()      # [B,Ns,2] seed features of frame r: the first Nm matched, the rest unmatched
         f = W.f_all[:, sel].contiguous()
         pos = W.pos_all[:, sel]
         c = -(T[:B, :9].reshape(B, 3, 3).transpose(1, 2) @ T[:B, 9:, None])[..., 0]
-        depth = (pos - c[:, None, :]).norm(dim=-1)
-        depth_mean, depth_min = depth.mean(1, keepdim=True), 0.5 * depth.min(1, keepdim=True).values
+        depth_all = (W.pos_all - c[:, None, :]).norm(dim=-1)   # scene depth of the keyframe (frame_utils::getSceneDepth)
+        depth_mean, depth_min = depth_all.mean(1, keepdim=True), 0.5 * depth_all.min(1, keepdim=True).values
         z_range = (1.0 / depth_min).expand(B, Ns).float()
         state = dict(a=torch.full((B, Ns), 10.0, device=dev), b=torch.full((B, Ns), 10.0, device=dev),
                      mu=(1.0 / depth_mean).expand(B, Ns).float().contiguous(), z_range=z_range.contiguous(),
                      sigma2=(z_range * z_range / 36.0).contiguous())
+        is_matched = (torch.arange(Ns, device=dev) < Nm)[None, :].expand(B, Ns)
         alive = torch.ones(B, Ns, dtype=torch.bool, device=dev)
         r_idx = torch.arange(B, device=dev)
         ftr = tr.FeatureSet(frame=r_idx.repeat_interleave(Ns).to(torch.int32).contiguous(),
                             level=torch.zeros(B * Ns, dtype=torch.int32, device=dev),
                             px=px.reshape(-1, 2).contiguous(), f=f.reshape(-1, 3).contiguous())
-        # the population of problem b at age a is state[a-1] of frame r = b+1-a
+        # the population of problem b at age a is the state of the seeds of frame r = b+1-a after their a-1 earlier frames
         parts = {k: [] for k in ("a", "b", "mu", "z_range", "sigma2")}
-        part_ftr, part_cur, part_age, part_b = [], [], [], []
+        part_ftr, part_cur, part_age, part_b, part_kind = [], [], [], [], []
         GONE = (capi.SEED_CONVERGED, capi.SEED_NAN, capi.SEED_ERASED_OLD, capi.SEED_NOT_IN_FRAME, capi.SEED_BEHIND)
-        for j in range(A):  # j = updates already received = age - 1
-            b_of_r = r_idx + j          # problem whose tracked frame b+1 = r + j + 1 gives these seeds update j+1
-            ok = (alive & (b_of_r < B)[:, None]).reshape(-1)
-            keep = ok.nonzero()[:, 0]
+        init = {k: v.clone() for k, v in state.items()}
+        for j in range(max(A, Au)):  # j = frames seen so far = age - 1
+            b_of_r = r_idx + j          # problem whose tracked frame b+1 = r + j + 1 gives these seeds their next update
+            in_pop = (is_matched & alive & (j < A)) | (~is_matched & (j < Au))
+            keep = (in_pop & (b_of_r < B)[:, None]).reshape(-1).nonzero()[:, 0]
+            um = (~is_matched).reshape(-1)[keep]
             for k in parts:
-                parts[k].append(state[k].reshape(-1)[keep].clone())
+                v = state[k].reshape(-1)[keep].clone()
+                if k == "b":  # an unmatched seed: b++ for every failed search (depth_filter.cpp:238-245), the rest untouched
+                    v = torch.where(um, init["b"].reshape(-1)[keep] + float(j), v)
+                elif k != "z_range":
+                    v = torch.where(um, init[k].reshape(-1)[keep], v)
+                parts[k].append(v)
             part_ftr.append(keep)
             part_cur.append((B + 1 + b_of_r).repeat_interleave(Ns)[keep].to(torch.int32))
             part_age.append(torch.full((len(keep),), j + 1, dtype=torch.int32, device=dev))
             part_b.append(b_of_r.repeat_interleave(Ns)[keep])
-            if j == A - 1:
-                break
-            # update j+1 of every frame's seeds, against frame r+j+1 at its ground-truth pose (rows 0..B of the table)
-            cur = (r_idx + j + 1).clamp(max=B).repeat_interleave(Ns).to(torch.int32).contiguous()
-            seeds = tr.SeedSet(**{k: v.reshape(-1).contiguous() for k, v in state.items()},
-                               batch_id=torch.zeros(B * Ns, dtype=torch.int32, device=dev))
-            status, _, _ = self.df.update_seeds(self.store, cam, self.frames, cur, ftr, seeds, 0)
-            state = {k: getattr(seeds, k).view(B, Ns) for k in state}
-            st = status.view(B, Ns)
-            gone = torch.zeros_like(alive)
-            for code in GONE:
-                gone |= st == code
-            alive = alive & ~gone
+            part_kind.append(um)
+            if j + 1 < A:
+                # the next update of every frame's (matched) seeds, against frame r+j+1 at its ground-truth pose (rows 0..B)
+                cur = (r_idx + j + 1).clamp(max=B).repeat_interleave(Ns).to(torch.int32).contiguous()
+                seeds = tr.SeedSet(**{k: v.reshape(-1).contiguous() for k, v in state.items()},
+                                   batch_id=torch.zeros(B * Ns, dtype=torch.int32, device=dev))
+                status, _, _ = self.df.update_seeds(self.store, cam, self.frames, cur, ftr, seeds, 0)
+                state = {k: getattr(seeds, k).view(B, Ns) for k in state}
+                st = status.view(B, Ns)
+                gone = torch.zeros_like(alive)
+                for code in GONE:
+                    gone |= st == code
+                alive = alive & ~gone
         order = torch.argsort(torch.cat(part_b), stable=True)  # seeds of one problem next to each other (as one frame's list)
         cat = lambda xs: torch.cat(xs)[order].contiguous()
         self.seed0 = {k: cat(v) for k, v in parts.items()}
@@ -1270,6 +1295,7 @@ class FullTrack:
         self.seed_cur = cat(part_cur)
         self.seed_age = cat(part_age)
         self.seed_frame_of = cat(part_b)
+        self.seed_unmatched = cat(part_kind)
 
     def step(self, T_cur_from_ref, ev: Events | None):
         tr = self.tr
@@ -1316,8 +1342,12 @@ class FullTrack:
         return {"mode": self.mode,
                 "match_trials_per_frame": float(self.in_cur.float().sum().item() / self.B),
                 "matches_per_frame": float(m.ok.float().sum().item() / self.B),
+                **({"matches_per_frame_among_bad_points": float((m.ok > 0)[self.bad_point].float().sum().item() / self.B),
+                    "bad_points_tried_per_frame": float((self.bad_point & self.in_cur.reshape(-1)).float().sum().item() / self.B)}
+                   if self.mode != "easy" else {}),
                 "pose_refine_obs_after_pruning": float(po.stats[:, 3].mean().item()),
                 "seeds_per_frame": self.S / self.B,
+                "unmatched_seeds_per_frame": float(self.seed_unmatched.float().sum().item() / self.B),
                 "seeds_per_frame_by_age": {str(a): float((age == a).sum() / self.B) for a in np.unique(age)},
                 "seed_status_per_frame": {names.get(int(k), str(k)): float((st == k).sum() / self.B) for k in np.unique(st)},
                 "pipeline": "sparse_align -> reproject -> findMatchDirect -> pose_optimize -> updateSeeds",
@@ -1360,6 +1390,9 @@ class FullTrack:
         edges = [0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1001]
         scan_hist = {f"{lo}..{hi - 1}": float(((scan >= lo) & (scan < hi)).sum().item() / self.B) for lo, hi in zip(edges[:-1], edges[1:])}
         scan_by_age = {str(int(a)): float(scan[self.seed_age == a].float().mean().item()) for a in torch.unique(self.seed_age)}
+        um = self.seed_unmatched
+        scan_by_kind = {"matched": float(scan[~um].float().mean().item()) if (~um).any() else None,
+                        "unmatched": float(scan[um].float().mean().item()) if um.any() else None}
         return {
             "find_match_direct": roofline("match_prepare + warp_kernel + align_kernel", fm_bytes, stages["find_match_direct"],
                                           trials=n_tried, alignment_evaluations_per_trial=n_eval / max(n_tried, 1),
@@ -1368,7 +1401,7 @@ class FullTrack:
             "pose_optimize": roofline("pose_opt_wave_kernel", B * (N * 52.0 + 416.0), stages["pose_optimize"]),
             "update_seeds": roofline("seed_prepare + warp_kernel + epi_scan + align_kernel + seed_finish", seed_bytes,
                                      stages["update_seeds"], seeds=S, scanned_positions_per_seed=n_scan / S,
-                                     scanned_positions_per_seed_by_age=scan_by_age,
+                                     scanned_positions_per_seed_by_kind=scan_by_kind, scanned_positions_per_seed_by_age=scan_by_age,
                                      seeds_per_frame_by_scanned_positions=scan_hist),
         }
 
@@ -1428,7 +1461,7 @@ def full_track_parity(W: Workload, full: FullTrack, out, T_refined_gpu, n_sample
     which = "ref" if pytrack.ref_available() else "orc"
     trk = pytrack.Track(which)
     B, N, cam = W.B, W.n_patches, W.cam
-    lo = max(FullTrack.KF2, FullTrack.SEED_AGES) + 1
+    lo = max(FullTrack.KF2, FullTrack.SEED_AGES, FullTrack.SEED_AGES_UNMATCHED) + 1
     idx = np.unique(np.linspace(lo, B - 1, n_sample).astype(int))
     m = full.last["match"]
     ok_g = m.ok.view(B, N).cpu().numpy()
