@@ -300,6 +300,20 @@ int svo_hip_align_batch_counted(const svo_hip_pyr_layout* layout, const uint8_t*
                                 const uint8_t* d_use_1d, int n_iter, double* d_px, int32_t* d_ok,
                                 double* d_h_inv, int32_t* d_evaluations, void* stream);
 
+/* svo_hip_align_batch[_counted] in PHASES, for large batches.  A wave of the one-lane-per-trial kernel runs as long as
+ * its slowest trial; given scratch, the iterations are run in three launches (0-2, 3-5, 6...) and the trials still
+ * iterating are compacted in between, so later launches run dense waves.  Same results bit for bit (a resumed trial
+ * continues from its parked loop state).  svo_hip_align_workspace_bytes(M) is 0 for batches too small for the extra
+ * launches to pay: the call is then a single launch.  d_evaluations may be NULL.  svo_hip_find_match_direct and
+ * svo_hip_update_seeds do the same inside their own workspace. */
+size_t svo_hip_align_workspace_bytes(int M);
+int svo_hip_align_batch_phased(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int M,
+                               const int32_t* d_slot, const int32_t* d_level,
+                               const uint8_t* d_patch_with_border, const float* d_dir,
+                               const uint8_t* d_use_1d, int n_iter, double* d_px, int32_t* d_ok,
+                               double* d_h_inv, int32_t* d_evaluations, void* d_workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* bytes of scratch the matcher / depth-filter entry points need for M trials */
 size_t svo_hip_match_workspace_bytes(int M);
 

@@ -127,6 +127,8 @@ PROTOTYPES = {
     "svo_hip_solve6_hipsolver": (_i, [_i, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "svo_hip_align_batch": (_i, [_LP, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "svo_hip_align_batch_counted": (_i, [_LP, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "svo_hip_align_workspace_bytes": (C.c_size_t, [_i]),
+    "svo_hip_align_batch_phased": (_i, [_LP, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "svo_hip_update_seeds_scan_steps": (_vp, [_vp]),
     "svo_hip_match_workspace_bytes": (C.c_size_t, [_i]),
     "svo_hip_find_match_direct": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, _vp, _vp,

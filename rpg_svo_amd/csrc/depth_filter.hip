@@ -249,13 +249,13 @@ constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_G = SCAN_LANES;
 static_assert(SCAN_G == 4 || SCAN_G == 8 || SCAN_G == 16 || SCAN_G == 32 || SCAN_G == 64, "SCAN_LANES");
 
-// ZMSSD scan, matcher.cpp:248-291.  SCAN_LANES lanes per seed.
-__global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) {
-  const int s = blockIdx.x * (SCAN_BLOCK / SCAN_G) + (threadIdx.x / SCAN_G);
-  const int lane = threadIdx.x & (SCAN_G - 1);  // lane within the seed's group
-  if (s >= a.S) return;
+// Seeds per workgroup of the scan.  The seeds of a chunk are ordered by scan length inside the workgroup (below).
+constexpr int SCAN_CHUNK = 1024;
+constexpr int SCAN_BUCKETS = 8;
+
+// ZMSSD scan of one seed, matcher.cpp:248-291, by the SCAN_LANES lanes of a group (lane = position in the group).
+__device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, const int lane) {
   const SeedWs& w = a.ws;
-  if (w.mode[s] != MODE_SCAN) return;
   const int sl = w.search_level[s];
   const uint8_t* img = a.store + (int64_t)w.cur_slot[s] * a.L.slot_bytes + a.L.offset[sl];
   const int pitch = a.L.pitch[sl];
@@ -387,6 +387,62 @@ __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) 
     w.accepted_raw[s] = a.opt.subpix_refinement ? 0 : 1;
   }
   if (lane == 0 && !(win_score < ZMSSD_THRESHOLD)) w.status[s] = SVO_HIP_SEED_NO_MATCH;
+}
+
+// A workgroup owns SCAN_CHUNK consecutive seeds.  Scan lengths differ by two orders of magnitude between seeds (a
+// seed that has been matched a few times searches 2-6 positions, one that never was and sees a long baseline
+// hundreds), and a wave runs as long as the longest scan among the seeds it holds: taken in list order the lanes
+// idle two thirds of the time.  So the workgroup first sorts its chunk by scan length (counting sort over
+// power-of-two buckets of ceil(positions / SCAN_LANES), in LDS), longest first, and its waves then fetch groups of
+// 64 / SCAN_LANES neighbouring entries of that order from an LDS counter: the seeds a wave holds at a time need about
+// the same number of passes, and no wave waits for another.  Seeds that do not scan (short segment, not visible,
+// rejected) never enter the order.  Results do not depend on the order.
+__global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) {
+  __shared__ uint16_t s_order[SCAN_CHUNK];
+  __shared__ int s_hist[SCAN_BUCKETS], s_off[SCAN_BUCKETS], s_next, s_n;
+  constexpr int PER_LANE = SCAN_CHUNK / SCAN_BLOCK;
+  constexpr int GROUPS = 64 / SCAN_G;  // seeds a wave scans at a time
+  const int base = blockIdx.x * SCAN_CHUNK;
+  const SeedWs& w = a.ws;
+  if (threadIdx.x < SCAN_BUCKETS) s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  int bucket[PER_LANE], rank[PER_LANE];
+#pragma unroll
+  for (int k = 0; k < PER_LANE; ++k) {
+    const int s = base + threadIdx.x + SCAN_BLOCK * k;
+    bucket[k] = -1;
+    rank[k] = 0;
+    if (s < a.S && w.mode[s] == MODE_SCAN) {
+      const int passes = (w.n_steps[s] + 1 + SCAN_G - 1) / SCAN_G;  // n_steps + 1 positions (matcher.cpp:264)
+      bucket[k] = passes <= 1 ? 0 : min(SCAN_BUCKETS - 1, 32 - __clz(passes - 1));
+      rank[k] = atomicAdd(&s_hist[bucket[k]], 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int off = 0;
+    for (int b = SCAN_BUCKETS - 1; b >= 0; --b) {  // longest first: the tail of the chunk is made of short scans
+      s_off[b] = off;
+      off += s_hist[b];
+    }
+    s_n = off;
+    s_next = 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER_LANE; ++k)
+    if (bucket[k] >= 0) s_order[s_off[bucket[k]] + rank[k]] = (uint16_t)(threadIdx.x + SCAN_BLOCK * k);
+  __syncthreads();
+  const int n_scan = s_n;
+  const int wl = threadIdx.x & 63;
+  const int grp = wl / SCAN_G, lane = wl % SCAN_G;
+  for (;;) {
+    int p = 0;
+    if (wl == 0) p = atomicAdd(&s_next, GROUPS);
+    p = __builtin_amdgcn_readfirstlane(p);
+    if (p >= n_scan) break;
+    if (p + grp < n_scan) epi_scan_seed(a, base + (int)s_order[p + grp], lane);
+  }
 }
 
 // depthFromTriangulation, matcher.cpp:109-122
@@ -712,6 +768,9 @@ static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_sto
   w.px_cur = c.take<double>(2 * n);
   w.uv_best = c.take<double>(2 * n);
   if (!c.ok) return SVO_HIP_ERANGE;
+  const size_t phase_bytes = align_phase_workspace_bytes(S);
+  void* phase_ws = phase_bytes ? c.take<uint8_t>(phase_bytes) : nullptr;
+  if (!c.ok) phase_ws = nullptr;  // (a caller with an older, smaller workspace: single-launch alignment)
   hipLaunchKernelGGL(seed_prepare_kernel, dim3((S + 63) / 64), dim3(64), 0, st, a);
   int rc = check_launch();
   if (rc) return rc;
@@ -728,7 +787,7 @@ static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_sto
   wa.pwb = w.pwb;
   rc = launch_warp(wa, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(epi_scan_kernel, dim3((S + (SCAN_BLOCK / SCAN_G) - 1) / (SCAN_BLOCK / SCAN_G)), dim3(SCAN_BLOCK), 0, st, a);
+  hipLaunchKernelGGL(epi_scan_kernel, dim3((S + SCAN_CHUNK - 1) / SCAN_CHUNK), dim3(SCAN_BLOCK), 0, st, a);
   rc = check_launch();
   if (rc) return rc;
   AlignArgs al;
@@ -747,7 +806,7 @@ static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_sto
   al.scale_out = 1;
   al.ok = w.align_ok;
   al.h_inv = nullptr;
-  rc = launch_align(al, st);
+  rc = launch_align(al, st, phase_ws, phase_bytes);
   if (rc) return rc;
   hipLaunchKernelGGL(seed_finish_kernel, dim3((S + 63) / 64), dim3(64), 0, st, a);
   return check_launch();

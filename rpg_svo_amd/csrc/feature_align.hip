@@ -71,13 +71,21 @@ __device__ __forceinline__ int floor_int(float x) {
   return (int)f;
 }
 
-// align2D, feature_alignment.cpp:149-277.  Returns converged; (u,v) in/out.
+// Everything the iteration loops of align2D / align1D carry from one iteration to the next (a phased run parks it
+// between launches; f32 like the reference's locals, so a resumed trial continues bit for bit)
+struct AlignState {
+  float u, v, mean_diff, chi2, up0, up1;
+};
+
+// align2D, feature_alignment.cpp:149-277: iterations [it0, min(it1, n_iter)) of the loop.  Returns true when the trial
+// has to go on (the range ended before n_iter, without convergence or failure); else `converged` is the verdict.
 __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, int cols, int rows, int pitch,
-                                             uint32_t g[25], int n_iter, float& u, float& v, bool& wrote,
-                                             int& n_eval) {
-  bool converged = false;
+                                             uint32_t g[25], int n_iter, int it0, int it1, AlignState& st,
+                                             bool& converged, bool& wrote, int& n_eval) {
+  converged = false;
   wrote = true;
   n_eval = 0;  // residual evaluations (9x9 windows read); dead code unless the caller stores it
+  float u = st.u, v = st.v;
   // H = sum J J', J = (dx, dy, 1) (:166-181).  dx, dy are half-integers (byte differences / 2) and every
   // partial sum of the reference's float accumulation is a multiple of 0.25 below 2^22: no rounding ever
   // happens, so the sums can be formed in any order -- here as integers of the doubled gradients
@@ -108,13 +116,18 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
   }
   float Hinv[9];
   inv3f(H, Hinv);
-  float mean_diff = 0;
+  float mean_diff = st.mean_diff;
   const float min_update_squared = (float)(0.03 * 0.03);
-  for (int iter = 0; iter < n_iter; ++iter) {
+  const int it_end = it1 < n_iter ? it1 : n_iter;
+  bool left = false;  // the loop was left by a break
+  for (int iter = it0; iter < it_end; ++iter) {
     ALIGN_OPAQUE_TEMPLATE(g);
     const int u_r = floor_int(u);
     const int v_r = floor_int(v);
-    if (u_r < 4 || v_r < 4 || u_r >= cols - 4 || v_r >= rows - 4) break;
+    if (u_r < 4 || v_r < 4 || u_r >= cols - 4 || v_r >= rows - 4) {
+      left = true;
+      break;
+    }
     if (isnan(u) || isnan(v)) {  // unreachable after the bounds test, kept for the record (:209)
       wrote = false;
       return false;
@@ -165,19 +178,22 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
     mean_diff += up2;
     if (up0 * up0 + up1 * up1 < min_update_squared) {
       converged = true;
+      left = true;
       break;
     }
   }
-  return converged;
+  st.u = u; st.v = v; st.mean_diff = mean_diff;
+  return !left && it_end < n_iter;
 }
 
 // align1D, feature_alignment.cpp:30-147
 __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, int cols, int rows, int pitch,
-                                             uint32_t g[25], float dir0, float dir1, int n_iter, float& u,
-                                             float& v, double& h_inv, bool& wrote, int& n_eval) {
-  bool converged = false;
+                                             uint32_t g[25], float dir0, float dir1, int n_iter, int it0, int it1,
+                                             AlignState& st, double& h_inv, bool& converged, bool& wrote, int& n_eval) {
+  converged = false;
   wrote = true;
   n_eval = 0;
+  float u = st.u, v = st.v;
   float H[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int y = 0; y < 8; ++y)
@@ -195,15 +211,20 @@ __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, in
   h_inv = 1.0 / (double)H[0] * 8 * 8;
   float Hinv[4];
   inv2<float>(H, Hinv);
-  float mean_diff = 0;
+  float mean_diff = st.mean_diff;
   const float min_update_squared = (float)(0.03 * 0.03);
-  float chi2 = 0;
-  float up0 = 0, up1 = 0;
-  for (int iter = 0; iter < n_iter; ++iter) {
+  float chi2 = st.chi2;
+  float up0 = st.up0, up1 = st.up1;
+  const int it_end = it1 < n_iter ? it1 : n_iter;
+  bool left = false;
+  for (int iter = it0; iter < it_end; ++iter) {
     ALIGN_OPAQUE_TEMPLATE(g);
     const int u_r = floor_int(u);
     const int v_r = floor_int(v);
-    if (u_r < 4 || v_r < 4 || u_r >= cols - 4 || v_r >= rows - 4) break;
+    if (u_r < 4 || v_r < 4 || u_r >= cols - 4 || v_r >= rows - 4) {
+      left = true;
+      break;
+    }
     if (isnan(u) || isnan(v)) {
       wrote = false;
       return false;
@@ -250,6 +271,7 @@ __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, in
     if (iter > 0 && new_chi2 > chi2) {
       u -= up0;  // sic (:116-117)
       v -= up1;
+      left = true;
       break;
     }
     chi2 = new_chi2;
@@ -260,47 +282,31 @@ __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, in
     mean_diff += up1;
     if (up0 * up0 + up1 * up1 < min_update_squared) {
       converged = true;
+      left = true;
       break;
     }
   }
-  return converged;
+  st.u = u; st.v = v; st.mean_diff = mean_diff; st.chi2 = chi2; st.up0 = up0; st.up1 = up1;
+  return !left && it_end < n_iter;
 }
 
 constexpr int ALIGN_BLOCK = 64;
 
 template <bool COUNT>
 __global__ void __launch_bounds__(ALIGN_BLOCK) align_kernel(const AlignArgs a) {
-  const int t = blockIdx.x * ALIGN_BLOCK + threadIdx.x;
-  // ALIGN_TEMPLATE_LDS: the 64 templates of the workgroup are 6400 contiguous bytes.  Read per lane they are 25
-  // dword gathers with a 100-byte lane stride (64 cache lines per instruction); read as the contiguous block
-  // they are and handed out through LDS they are 7 coalesced 16-byte loads (a lane's 25 LDS words sit 25 banks
-  // apart from its neighbour's: conflict-free).  Measured: no difference (5.96 against 5.93 ms for the full-track
-  // step) -- the kernel is bound by its per-trial dependent arithmetic, not by these loads; off by default.
-#ifdef ALIGN_TEMPLATE_LDS
-  __shared__ uint32_t s_tpl[ALIGN_BLOCK * 25];
-  {
-    const long long first = (long long)blockIdx.x * ALIGN_BLOCK;               // first trial of the workgroup
-    const long long left = (long long)a.M - first;
-    const int n_dw = 25 * (int)(left < ALIGN_BLOCK ? left : ALIGN_BLOCK);      // dwords present (multiple of 25)
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.pwb + (size_t)first * 100);
-    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-#pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        const int q = 4 * (threadIdx.x + ALIGN_BLOCK * k);  // first dword of this lane's quad
-        if (q + 3 < n_dw) {
-          *reinterpret_cast<uint4*>(&s_tpl[q]) = *reinterpret_cast<const uint4*>(src + q);
-        } else {
-          for (int j = q; j < n_dw && j < q + 4; ++j) s_tpl[j] = src[j];
-        }
-      }
-    } else {  // the caller's buffer starts off a 16-byte boundary: dwords
-      for (int j = threadIdx.x; j < n_dw; j += ALIGN_BLOCK) s_tpl[j] = src[j];
-    }
+  // which trial: lane order in the first launch of a run, the queues filled by the previous launch afterwards
+  // (workgroup b drains queue b % ALIGN_NQ, 64 entries at a time)
+  int t;
+  if (a.queue_in) {
+    const int q = blockIdx.x % ALIGN_NQ, i = (blockIdx.x / ALIGN_NQ) * ALIGN_BLOCK + threadIdx.x;
+    if (i >= a.n_in[q]) return;
+    t = a.queue_in[(size_t)q * a.queue_cap + i];
+  } else {
+    t = blockIdx.x * ALIGN_BLOCK + threadIdx.x;
+    if (t >= a.M) return;
   }
-  __syncthreads();
-#endif
-  if (t >= a.M) return;
-  if (a.active && !a.active[t]) {
+  const bool first = a.it0 == 0;
+  if (first && a.active && !a.active[t]) {
     a.ok[t] = 0;  // px_out is left as it is (findMatchDirect returns before touching px_cur)
     if (COUNT) a.iters[t] = 0;
     return;
@@ -310,31 +316,48 @@ __global__ void __launch_bounds__(ALIGN_BLOCK) align_kernel(const AlignArgs a) {
   const int cols = a.L.w[level], rows = a.L.h[level], pitch = a.L.pitch[level];
   uint32_t g[25];
   {
-#ifdef ALIGN_TEMPLATE_LDS
-    const uint32_t* gp = &s_tpl[threadIdx.x * 25];
-#else
     const uint32_t* gp = reinterpret_cast<const uint32_t*>(a.pwb + (size_t)t * 100);
-#endif
 #pragma unroll
     for (int k = 0; k < 25; ++k) g[k] = gp[k];
   }
-  float u = (float)a.px_in[2 * t];
-  float v = (float)a.px_in[2 * t + 1];
-  bool wrote = true;
-  bool ok;
+  AlignState st;
+  if (first) {
+    st.u = (float)a.px_in[2 * t];
+    st.v = (float)a.px_in[2 * t + 1];
+    st.mean_diff = 0.f; st.chi2 = 0.f; st.up0 = 0.f; st.up1 = 0.f;
+  } else {
+    const float* sp = a.state + 6 * (size_t)t;
+    st.u = sp[0]; st.v = sp[1]; st.mean_diff = sp[2]; st.chi2 = sp[3]; st.up0 = sp[4]; st.up1 = sp[5];
+  }
+  bool wrote = true, ok = false, more;
   int n_eval = 0;
   const bool one_d = a.use_1d && a.use_1d[t];
   if (one_d) {
     double h_inv = 0;
-    ok = align1d_lane(img, cols, rows, pitch, g, a.dir[2 * t], a.dir[2 * t + 1], a.n_iter, u, v, h_inv, wrote, n_eval);
+    more = align1d_lane(img, cols, rows, pitch, g, a.dir[2 * t], a.dir[2 * t + 1], a.n_iter, a.it0, a.it1, st, h_inv, ok, wrote, n_eval);
     if (a.h_inv) a.h_inv[t] = h_inv;
   } else {
-    ok = align2d_lane(img, cols, rows, pitch, g, a.n_iter, u, v, wrote, n_eval);
+    more = align2d_lane(img, cols, rows, pitch, g, a.n_iter, a.it0, a.it1, st, ok, wrote, n_eval);
   }
-  if (COUNT) a.iters[t] = n_eval;
+  if (COUNT) a.iters[t] = (first ? 0 : a.iters[t]) + n_eval;
+  if (a.queue_out) {
+    // still iterating: park the loop state, append the trial to this workgroup's queue (one atomic per wave)
+    const uint64_t going = __builtin_amdgcn_ballot_w64(more);
+    if (more) {
+      float* sp = a.state + 6 * (size_t)t;
+      sp[0] = st.u; sp[1] = st.v; sp[2] = st.mean_diff; sp[3] = st.chi2; sp[4] = st.up0; sp[5] = st.up1;
+      const int q = blockIdx.x % ALIGN_NQ;
+      const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(going >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)going, 0u));
+      int base = 0;
+      if (rank == 0) base = atomicAdd(a.n_out + q, (int)__popcll(going));
+      base = __builtin_amdgcn_readfirstlane(base);
+      a.queue_out[(size_t)q * a.queue_cap + base + rank] = t;
+      return;
+    }
+  }
   a.ok[t] = ok ? 1 : 0;
-  double ou = wrote ? (double)u : a.px_in[2 * t];
-  double ov = wrote ? (double)v : a.px_in[2 * t + 1];
+  double ou = wrote ? (double)st.u : a.px_in[2 * t];
+  double ov = wrote ? (double)st.v : a.px_in[2 * t + 1];
   if (a.scale_out) {
     ou = ou * (double)(1 << level);
     ov = ov * (double)(1 << level);
@@ -346,19 +369,71 @@ __global__ void __launch_bounds__(ALIGN_BLOCK) align_kernel(const AlignArgs a) {
 }  // namespace
 
 namespace svo_track {
-int launch_align(const AlignArgs& a, hipStream_t s) {
-  if (a.M <= 0) return SVO_HIP_OK;
-  const dim3 grid((a.M + ALIGN_BLOCK - 1) / ALIGN_BLOCK), blk(ALIGN_BLOCK);
+
+// Alignment in phases.  A wave of one-lane-per-trial alignment runs as long as its slowest trial (on the
+// representative full-track workload: 4.3 evaluations per trial, 9.8 per wave of 64), and the arithmetic order
+// inside a trial must stay the reference's.  So the iterations are split over three launches -- 0..2, 3..5, 6.. --
+// and between launches the trials still iterating are compacted: a launch parks the loop state of every unfinished
+// trial (six floats, exactly the loop's locals) and appends its index to one of ALIGN_NQ queues; the next launch
+// runs dense waves over the queues.  A resumed trial rebuilds H^-1 from its template (same instructions, same
+// bits) and continues where it stopped: results are identical to the single launch.
+constexpr int ALIGN_PHASE_MIN_M = 1 << 16;  // below this the extra launches cost more than the idle lanes
+#ifndef ALIGN_PHASE_ITERS
+#define ALIGN_PHASE_ITERS 3
+#endif
+
+static int phase_queue_cap(int M) { return (M + ALIGN_NQ - 1) / ALIGN_NQ + 2 * ALIGN_BLOCK; }
+
+size_t align_phase_workspace_bytes(int M) {
+  if (M < ALIGN_PHASE_MIN_M) return 0;
+  const size_t cap = (size_t)phase_queue_cap(M);
+  return 2 * Carver::round(ALIGN_NQ * cap * sizeof(int32_t)) + Carver::round(2 * ALIGN_NQ * sizeof(int32_t)) +
+         Carver::round((size_t)M * 6 * sizeof(float));
+}
+
+static int launch_one(const AlignArgs& a, int n_blocks, hipStream_t s) {
+  const dim3 grid(n_blocks), blk(ALIGN_BLOCK);
   if (a.iters) hipLaunchKernelGGL(align_kernel<true>, grid, blk, 0, s, a);  // instrumented: also counts evaluations
   else hipLaunchKernelGGL(align_kernel<false>, grid, blk, 0, s, a);
   return check_launch();
+}
+
+int launch_align(const AlignArgs& a0, hipStream_t s, void* d_phase_ws, size_t phase_ws_bytes) {
+  if (a0.M <= 0) return SVO_HIP_OK;
+  const int all_blocks = (a0.M + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
+  const size_t need = align_phase_workspace_bytes(a0.M);
+  if (!d_phase_ws || need == 0 || phase_ws_bytes < need || a0.n_iter <= ALIGN_PHASE_ITERS) return launch_one(a0, all_blocks, s);
+  Carver c(d_phase_ws, phase_ws_bytes);
+  const int cap = phase_queue_cap(a0.M);
+  int32_t* queue[2] = {c.take<int32_t>((size_t)ALIGN_NQ * cap), c.take<int32_t>((size_t)ALIGN_NQ * cap)};
+  int32_t* count = c.take<int32_t>(2 * ALIGN_NQ);
+  float* state = c.take<float>((size_t)a0.M * 6);
+  if (!c.ok) return launch_one(a0, all_blocks, s);
+  SVO_HIP_TRY(hipMemsetAsync(count, 0, 2 * ALIGN_NQ * sizeof(int32_t), s));
+  // a queue holds the survivors of the workgroups b % ALIGN_NQ == q: at most cap entries; every launch after the first
+  // is sized for full queues (workgroups past a queue's end leave at once)
+  const int queue_blocks = ALIGN_NQ * ((cap + ALIGN_BLOCK - 1) / ALIGN_BLOCK);
+  AlignArgs a = a0;
+  a.state = state;
+  a.queue_cap = cap;
+  int rc = SVO_HIP_OK;
+  for (int phase = 0; phase < 3 && rc == SVO_HIP_OK; ++phase) {
+    a.it0 = phase * ALIGN_PHASE_ITERS;
+    a.it1 = phase == 2 ? (1 << 30) : (phase + 1) * ALIGN_PHASE_ITERS;
+    a.queue_in = phase == 0 ? nullptr : queue[(phase - 1) & 1];
+    a.n_in = phase == 0 ? nullptr : count + ((phase - 1) & 1) * ALIGN_NQ;
+    a.queue_out = phase == 2 ? nullptr : queue[phase & 1];
+    a.n_out = phase == 2 ? nullptr : count + (phase & 1) * ALIGN_NQ;
+    rc = launch_one(a, phase == 0 ? all_blocks : queue_blocks, s);
+  }
+  return rc;
 }
 }  // namespace svo_track
 
 static int align_batch(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int M, const int32_t* d_slot,
                        const int32_t* d_level, const uint8_t* d_patch_with_border, const float* d_dir,
                        const uint8_t* d_use_1d, int n_iter, double* d_px, int32_t* d_ok, double* d_h_inv,
-                       int32_t* d_iters, void* stream) {
+                       int32_t* d_iters, void* stream, void* d_phase_ws = nullptr, size_t phase_ws_bytes = 0) {
   if (!layout_ok(layout) || !d_store || M < 0 || n_iter < 0) return SVO_HIP_EINVAL;
   if (M == 0) return SVO_HIP_OK;
   if (!d_slot || !d_level || !d_patch_with_border || !d_px || !d_ok) return SVO_HIP_EINVAL;
@@ -381,7 +456,20 @@ static int align_batch(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
   a.ok = d_ok;
   a.h_inv = d_h_inv;
   a.iters = d_iters;
-  return launch_align(a, static_cast<hipStream_t>(stream));
+  return launch_align(a, static_cast<hipStream_t>(stream), d_phase_ws, phase_ws_bytes);
+}
+
+extern "C" size_t svo_hip_align_workspace_bytes(int M) { return M < 0 ? 0 : align_phase_workspace_bytes(M); }
+
+extern "C" int svo_hip_align_batch_phased(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int M,
+                                          const int32_t* d_slot, const int32_t* d_level,
+                                          const uint8_t* d_patch_with_border, const float* d_dir, const uint8_t* d_use_1d,
+                                          int n_iter, double* d_px, int32_t* d_ok, double* d_h_inv, int32_t* d_evaluations,
+                                          void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (M > 0 && workspace_bytes < align_phase_workspace_bytes(M)) return SVO_HIP_ERANGE;
+  if ((reinterpret_cast<uintptr_t>(d_workspace) & 255) != 0) return SVO_HIP_EINVAL;
+  return align_batch(layout, d_store, M, d_slot, d_level, d_patch_with_border, d_dir, d_use_1d, n_iter, d_px, d_ok, d_h_inv,
+                     d_evaluations, stream, d_workspace, workspace_bytes);
 }
 
 extern "C" int svo_hip_align_batch(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int M,

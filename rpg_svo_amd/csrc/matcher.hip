@@ -366,6 +366,8 @@ extern "C" size_t svo_hip_match_workspace_bytes(int M) {
   b += 8 * Carver::round(m * 2 * sizeof(double));  // px arrays, epipolar geometry
   b += 4 * Carver::round(m * sizeof(double));
   b += Carver::round(m * 12 * sizeof(double));     // T_cur_ref (quaternion + t padded)
+  b += align_phase_workspace_bytes(M) + 256;       // queues + parked loop state of the phased alignment
+  b += Carver::round(m * sizeof(uint16_t));        // (spare)
   return b + 4096;
 }
 
@@ -445,7 +447,9 @@ extern "C" int svo_hip_find_match_direct(const svo_hip_pyr_layout* layout, const
   al.scale_out = 1;
   al.ok = d_ok;
   al.h_inv = nullptr;
-  return launch_align(al, s);
+  const size_t phase_bytes = align_phase_workspace_bytes(M);
+  void* phase_ws = phase_bytes ? ws.take<uint8_t>(phase_bytes) : nullptr;
+  return launch_align(al, s, ws.ok ? phase_ws : nullptr, phase_bytes);
 }
 
 extern "C" int svo_hip_reproject_points(const svo_hip_camera* cam, const svo_hip_frames* frames, int M,

@@ -22,8 +22,23 @@ struct AlignArgs {
   int32_t* ok;             // [M]
   double* h_inv;           // [M] or NULL
   int32_t* iters = nullptr;  // [M] or NULL: residual evaluations per trial (instrumented kernel variant)
+  // Phased run (launch_align fills these; see feature_align.hip): iterations [it0, it1) of the trials listed in
+  // queue_in (NULL: all M trials); a trial that has neither converged nor failed by it1 < n_iter parks its loop
+  // state in `state` and its index in queue_out for the next launch.
+  int it0 = 0, it1 = 1 << 30;
+  const int32_t* queue_in = nullptr;   // [ALIGN_NQ][queue_cap]
+  const int32_t* n_in = nullptr;       // [ALIGN_NQ]
+  int32_t* queue_out = nullptr;
+  int32_t* n_out = nullptr;
+  int queue_cap = 0;
+  float* state = nullptr;              // [M][6]: u, v, mean_diff, chi2, up0, up1
 };
-int launch_align(const AlignArgs& a, hipStream_t s);
+// Scratch of a phased alignment (compaction of the trials still iterating between launches): with it (and M large enough
+// for the extra launches to pay) launch_align runs the iterations in three launches, 0-2 / 3-5 / 6..., each over the
+// trials still alive, so that a wave no longer runs as long as its slowest trial.  Results do not depend on it.
+constexpr int ALIGN_NQ = 64;           // queues (one atomic counter each: no single hot address)
+size_t align_phase_workspace_bytes(int M);
+int launch_align(const AlignArgs& a, hipStream_t s, void* d_phase_ws = nullptr, size_t phase_ws_bytes = 0);
 
 // K2b (matcher.hip): warp::warpAffine for M trials, 10x10 output, 32 lanes per trial
 struct WarpArgs {

@@ -73,11 +73,23 @@ class _Workspace:
 
 
 # ---- feature_alignment ----------------------------------------------------------------
-def align_batch(store: PyramidStore, slot, level, patch_with_border, px, n_iter: int, dir=None, use_1d=None):
+def align_batch(store: PyramidStore, slot, level, patch_with_border, px, n_iter: int, dir=None, use_1d=None, phased: bool = False,
+                evaluations=None):
     """feature_alignment::align2D (use_1d None/0) or align1D per trial.  px [M,2] f64 is refined
-    in place (level coordinates).  Returns (ok [M] i32, h_inv [M] f64)."""
+    in place (level coordinates).  Returns (ok [M] i32, h_inv [M] f64).  phased: run the iterations in three
+    launches with the unfinished trials compacted in between (svo_hip_align_batch_phased; same results)."""
     lib = capi.load()
     M = px.shape[0]
+    if phased:
+        _chk(slot, torch.int32); _chk(level, torch.int32); _chk(patch_with_border, torch.uint8); _chk(px, torch.float64)
+        ok = torch.zeros(M, dtype=torch.int32, device=px.device)
+        h_inv = torch.zeros(M, dtype=torch.float64, device=px.device)
+        ws = torch.empty(max(int(lib.svo_hip_align_workspace_bytes(M)), 256), dtype=torch.uint8, device=px.device)
+        capi.check(lib.svo_hip_align_batch_phased(C.byref(store.layout), store.ptr, M, slot.data_ptr(), level.data_ptr(),
+                                                  patch_with_border.data_ptr(), _ptr(dir), _ptr(use_1d), n_iter, px.data_ptr(),
+                                                  ok.data_ptr(), h_inv.data_ptr(), _ptr(evaluations), ws.data_ptr(), ws.numel(),
+                                                  _stream_ptr(store.device)), "svo_hip_align_batch_phased")
+        return ok, h_inv
     _chk(slot, torch.int32); _chk(level, torch.int32); _chk(patch_with_border, torch.uint8); _chk(px, torch.float64)
     assert patch_with_border.shape == (M, 100)
     ok = torch.zeros(M, dtype=torch.int32, device=px.device)

@@ -85,6 +85,60 @@ def test_align_batch_bit_exact(gpu_device, orc, scene, pyrs):
     assert n_conv > M // 4
 
 
+def test_phased_alignment_is_the_single_launch_bit_for_bit(gpu_device, scene, pyrs):
+    """svo_hip_align_batch_phased (three launches, the unfinished trials compacted in between -- the form
+    find_match_direct / update_seeds use for large batches) against the single launch on 73 728 trials: verdicts,
+    refined pixels (bits), h_inv and evaluation counts identical.  The single launch itself is pinned to the
+    reference by test_align_batch_bit_exact."""
+    store, _ = scene_store(scene)
+    rng = np.random.default_rng(11)
+    M0, REP = 3072, 24
+    imgs = scene.images.cpu().numpy()
+    slot = rng.integers(0, imgs.shape[0], size=M0).astype(np.int32)
+    level = rng.integers(0, 3, size=M0).astype(np.int32)
+    pwb = np.zeros((M0, 100), np.uint8)
+    px0 = np.zeros((M0, 2))
+    dirs = rng.normal(size=(M0, 2)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    use_1d = (rng.uniform(size=M0) < 0.3).astype(np.uint8)
+    for t in range(M0):
+        img = pyrs[slot[t]][level[t]]
+        h, w = img.shape
+        u, v = rng.integers(8, w - 8), rng.integers(8, h - 8)
+        src = pyrs[(slot[t] + (t % 2)) % imgs.shape[0]][level[t]]
+        pwb[t] = src[v - 5:v + 5, u - 5:u + 5].ravel()
+        px0[t] = [u + rng.uniform(-4.0, 4.0), v + rng.uniform(-4.0, 4.0)]  # far enough for many iterations
+        if t % 37 == 0:
+            px0[t] = [3.0 + rng.uniform(0, 2), v]
+        if t % 41 == 0:
+            pwb[t] = 77
+    perm = rng.permutation(M0 * REP)  # copies of a trial land in different waves / queues
+    tile = lambda a: np.ascontiguousarray(np.tile(a, (REP,) + (1,) * (a.ndim - 1))[perm])
+    M = M0 * REP
+    assert capi.load().svo_hip_align_workspace_bytes(M) > 0  # large enough for the phased path
+    args = (store, dev(tile(slot), torch.int32), dev(tile(level), torch.int32), dev(tile(pwb), torch.uint8))
+    kw = dict(dir=dev(tile(dirs), torch.float32), use_1d=dev(tile(use_1d), torch.uint8))
+    px_a, px_b = dev(tile(px0), torch.float64), dev(tile(px0), torch.float64)
+    ev_b = torch.zeros(M, dtype=torch.int32, device="cuda:0")
+    ok_a, h_a = tracking.align_batch(*args, px_a, 10, **kw)
+    ok_b, h_b = tracking.align_batch(*args, px_b, 10, phased=True, evaluations=ev_b, **kw)
+    ev_a = torch.zeros(M, dtype=torch.int32, device="cuda:0")
+    px_c = dev(tile(px0), torch.float64)
+    lib = capi.load()
+    import ctypes as C
+    ok_c = torch.zeros(M, dtype=torch.int32, device="cuda:0")
+    capi.check(lib.svo_hip_align_batch_counted(C.byref(store.layout), store.ptr, M, args[1].data_ptr(), args[2].data_ptr(),
+                                               args[3].data_ptr(), kw["dir"].data_ptr(), kw["use_1d"].data_ptr(), 10, px_c.data_ptr(),
+                                               ok_c.data_ptr(), None, ev_a.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(ok_a, ok_b)
+    assert np.array_equal(px_a.cpu().numpy().view(np.uint64), px_b.cpu().numpy().view(np.uint64))
+    assert np.array_equal(h_a.cpu().numpy().view(np.uint64), h_b.cpu().numpy().view(np.uint64))
+    assert torch.equal(ev_a, ev_b)
+    ev = ev_a.cpu().numpy()
+    assert (ev > 6).mean() > 0.02 and (ev <= 3).mean() > 0.2, np.bincount(ev)  # all three launches had work
+
+
 def test_find_match_direct(gpu_device, orc, scene, pyrs):
     T = scene.T_f_w.copy()
     T[scene.cur] = scene.T_cur_prior
