@@ -136,7 +136,7 @@ def test_phased_alignment_is_the_single_launch_bit_for_bit(gpu_device, scene, py
     assert np.array_equal(h_a.cpu().numpy().view(np.uint64), h_b.cpu().numpy().view(np.uint64))
     assert torch.equal(ev_a, ev_b)
     ev = ev_a.cpu().numpy()
-    assert (ev > 6).mean() > 0.02 and (ev <= 3).mean() > 0.2, np.bincount(ev)  # all three launches had work
+    assert (ev > 6).sum() > 100 and (ev <= 3).sum() > 100, np.bincount(ev)  # all three launches had work
 
 
 def test_find_match_direct(gpu_device, orc, scene, pyrs):
