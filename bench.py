@@ -58,7 +58,7 @@ WORKLOADS = {
     "svo_default_752_l4to2_n120": (752, 480, 315.5, 5, 4, 2, 120, 56, 40),
     "xga5_n1000_sparse_align": (1280, 960, 800.0, 5, 4, 0, 1000, 56, 32),
 }
-EXTRA_KEYS = {"f64": "f64_partials", "refine": "align_plus_refine", "full": "full_track", "full_easy": "full_track_easy", "noise": "noise_sigma2", "config3": "config3_xga5_b64",
+EXTRA_KEYS = {"f64": "f64_partials", "refine": "align_plus_refine", "full": "full_track", "full_easy": "full_track_easy", "stream": "stream_replay", "noise": "noise_sigma2", "config3": "config3_xga5_b64",
               "k0": "k0_pyramid", "dropin": "dropin_sequence"}
 
 
@@ -238,7 +238,7 @@ def main() -> None:
                          "extra key full_track instead)")
     ap.add_argument("--extras", default="all",
                     help="comma list of the extra legs to run at N=1 (all, none, or any of: f64, refine, full, full_easy, noise, "
-                         "config3, rig, k0, dropin, pmc)")
+                         "config3, stream, rig, k0, dropin, pmc)")
     ap.add_argument("--k1-kernel", default="auto", choices=["auto", "workgroup"],
                     help="auto: svo_hip_sparse_align (one wave per frame up to 256 patches); workgroup: the workgroup-per-frame kernel")
     ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)
@@ -273,7 +273,7 @@ def main() -> None:
     lib = capi.load()
     ev = Events(lib, dev)
     if args.extras == "all":
-        extras = {"f64", "refine", "full", "full_easy", "noise", "config3", "rig", "k0", "dropin", "pmc"}
+        extras = {"f64", "refine", "full", "full_easy", "noise", "config3", "stream", "rig", "k0", "dropin", "pmc"}
     elif args.extras == "none":
         extras = set()
     else:
@@ -480,7 +480,8 @@ def main() -> None:
     leg("k0", lambda: pyramid_roofline(ev, store, W.images))
     if args.noise == 0:
         leg("noise", lambda: noise_leg(W, sia, ev, dev, rank, args.steps))
-    leg("config3", lambda: config3_leg(ev, dev, rank, args.n_iter))
+    leg("config3", lambda: config3_leg(ev, dev, rank, args.n_iter, not args.no_cpu_baseline))
+    leg("stream", lambda: stream_replay_leg(W, sia, ev, dev))
     if "pmc" in extras:
         t = time.time()
         try:
@@ -654,21 +655,35 @@ def noise_leg(W: Workload, sia, ev: Events, dev, rank: int, steps: int) -> dict:
     return r
 
 
-def config3_leg(ev: Events, dev, rank: int, n_iter: int) -> dict:
-    """BASELINE configs[3]: 1280x960, 5 levels (4 -> 0), 1000 patches, 64 frames at once -- plus the two
-    numbers that say what bounds it: the same frames at a batch that fills the GPU, and the latency floor of
-    a 4-way split of a frame over workgroups (a 250-patch frame alone on a CU)."""
+def config3_leg(ev: Events, dev, rank: int, n_iter: int, with_cpu: bool = True) -> dict:
+    """BASELINE configs[3]: 1280x960, 5 levels (4 -> 0), 1000 patches, 64 frames at once.  A frame is one workgroup,
+    so 64 frames occupy 64 of the 256 CUs and the step time IS the latency of one frame's alignment: `ms_per_step`
+    is reported as that latency, the throughput of the configuration is the batch that fills the GPU
+    (`frames_per_s_at_batch_1024`), and the reference's own code on the host cores runs beside both."""
+    keep = {}
+
     def run(B, n_patches=None, reps=20):
         W = Workload("xga5_n1000_sparse_align", B, dev, rank + 7, n_patches=n_patches)
         sia = SparseImgAlign(W.max_level, W.min_level, n_iter)
         out = sia.alloc_result(W.B, dev)
         ms = ev.time(lambda: W.run_align(sia, out=out), reps, warmup=3)
         torch.cuda.synchronize()
+        if B == 64 and n_patches is None:
+            keep["W"], keep["out"] = W, out
         return ms, W.align_stats(out)
     ms, st = run(64)
+    cpu = None
+    if with_cpu:
+        try:
+            cpu = config3_cpu(keep["W"], st, keep["out"], n_iter)
+        except Exception as e:
+            cpu = {"skipped": repr(e)}
+    keep.clear()
     ms_big, st_big = run(1024, reps=10)
     ms_q, st_q = run(64, n_patches=250)
     return {"workload": "xga5_n1000_sparse_align", "frames_per_step": 64, "frames_per_s": 64 / ms * 1e3, "ms_per_step": ms,
+            "what_ms_per_step_is": "the latency of ONE 1000-patch frame (64 workgroups on 256 CUs run side by side)",
+            "cpu_baseline": cpu,
             "mean_gn_iterations_per_frame": float(st["iters"].sum(1).mean()), "mean_tracked_patches": float(st["n_tracked"].mean()),
             "median_pose_error_vs_gt": float(np.median(st["gt_err"])),
             "roofline": roofline("sia_kernel", st["alg_bytes"], ms),
@@ -679,6 +694,108 @@ def config3_leg(ev: Events, dev, rank: int, n_iter: int) -> dict:
             # a quarter of the patches per workgroup is this measurement, BEFORE any exchange cost
             "split4_latency_floor": {"patches_per_workgroup": 250, "ms_per_step": ms_q, "frames_per_s_upper_bound": 64 / ms_q * 1e3,
                                      "mean_gn_iterations_per_frame": float(st_q["iters"].sum(1).mean())}}
+
+
+def config3_cpu(W: Workload, st: dict, out, n_iter: int) -> dict:
+    """configs[3] on the host: the reference's own SparseImgAlign (oracle/_ref; the C port without it) on the same 64
+    frames, one thread and all threads, and its agreement with the device result."""
+    from oracle import pyoracle
+    S = W.B
+    pyrs = [pyoracle.create_img_pyramid(im, W.n_levels, pyoracle.HALFSAMPLE_AUTO) for im in W.images[:S + 1].cpu().numpy()]
+    rs = np.arange(S, dtype=np.int32)
+    nn = np.full(S, W.n_patches, dtype=np.int32)
+    px, f, pos = W.px_all[:S].cpu().numpy(), W.f_all[:S].cpu().numpy(), W.pos_all[:S].cpu().numpy()
+    hp = np.ones((S, W.n_patches), dtype=np.uint8)
+    which = "ref" if pyoracle.ref_available() else "orc"
+    cores = os.cpu_count() or 1
+
+    def timed(k, threads):
+        tm = {}
+        t0 = time.perf_counter()
+        T, r = pyoracle.sparse_img_align_batch(pyrs, rs[:k], rs[:k] + 1, W.cam, W.T_ref_w[:k], W.T_prior_w[:k], nn[:k], px[:k], f[:k],
+                                               hp[:k], pos[:k], W.max_level, W.min_level, n_iter, n_threads=threads, which=which, timing=tm)
+        return T, r, tm.get("run_seconds", time.perf_counter() - t0)
+    _, _, t1 = timed(16, 1)
+    T_cpu, res, tn = timed(S, min(cores, S))
+    d = se3.log_norm(st["T_est_w"], T_cpu)
+    it = out.iters.cpu().numpy()
+    return {"kind": "reference" if which == "ref" else "port", "frames_per_s_1core": 16 / t1, "ms_per_frame_1core": t1 / 16 * 1e3,
+            "frames_per_s_all_threads": S / tn, "threads": min(cores, S), "sample": f"{S} frames (16 for the 1-thread figure)",
+            "parity": {"se3_lognorm_max": float(d.max()), "se3_lognorm_median": float(np.median(d)),
+                       "same_iteration_counts_frac": float(np.mean([np.array_equal(r["iters"], x) for r, x in zip(res, it)]))}}
+
+
+def stream_replay_leg(W: Workload, sia, ev: Events, dev, n_frames: int = 4096, chunk: int = 256) -> dict:
+    """Image in -> pose out for an offline replay whose images live in HOST memory (second half): level-0
+    images in pinned memory, copied H2D chunk by chunk on a copy stream into one of two packed staging buffers while
+    the compute stream runs K0 (tiled level 0 + pyramid, one kernel) and K1 on the previous chunk.  The pyramid
+    store is a ring of two chunks, so the frame pair across a chunk boundary finds both pyramids resident.  The
+    bound is the host link: a VGA frame is 307 200 bytes."""
+    n_frames = min(n_frames, W.B)
+    chunk = min(chunk, n_frames // 2)
+    n_chunks = n_frames // chunk
+    n_frames = n_chunks * chunk
+    h, w = W.height, W.width
+    frame_bytes = h * w
+    host = W.images[:n_frames].cpu().pin_memory()                      # [n, h, w] u8, page-locked
+    staging = [torch.empty(chunk, h, w, dtype=torch.uint8, device=dev) for _ in range(2)]
+    store = PyramidStore(w, h, W.n_levels, 2 * chunk, device=dev)
+    copy_stream = torch.cuda.Stream(dev)
+    comp = torch.cuda.current_stream(dev)
+    out = sia.alloc_result(chunk, dev)
+    # problem of frame k*chunk + i: reference = the frame before it (the other half of the ring for i = 0), current = itself;
+    # features / priors of the frame pairs are the workload's own (device-resident, a few KB per frame)
+    slots = torch.arange(chunk, dtype=torch.int32, device=dev)
+    prob = []
+    for k in range(n_chunks):
+        base = (k & 1) * chunk
+        cur = (slots + base).contiguous()
+        ref = (cur - 1).clone()
+        ref[0] = ((k + 1) & 1) * chunk + chunk - 1 if k > 0 else cur[0]  # frame 0 has no predecessor: aligned against itself
+        j = (torch.arange(k * chunk, (k + 1) * chunk, device=dev) - 1).clamp(min=0)
+        prob.append((ref.contiguous(), cur, W.px_all[j].contiguous(), W.xyz_t[j].contiguous(), W.T_in[j].contiguous()))
+    n_t = W.n_t[:chunk].contiguous()
+    torch.cuda.synchronize()
+
+    def run(do_copy: bool, do_compute: bool) -> float:
+        copied = [torch.cuda.Event() for _ in range(n_chunks)]
+        consumed = [torch.cuda.Event() for _ in range(n_chunks)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n_chunks):
+            if do_copy:
+                with torch.cuda.stream(copy_stream):
+                    if k >= 2 and do_compute:
+                        copy_stream.wait_event(consumed[k - 2])          # K0 of chunk k-2 has read this staging buffer
+                    staging[k & 1].copy_(host[k * chunk:(k + 1) * chunk], non_blocking=True)
+                    copied[k].record(copy_stream)
+            if do_compute:
+                if do_copy:
+                    comp.wait_event(copied[k])
+                store.load_images(staging[k & 1], first_slot=(k & 1) * chunk)  # K0: tiled level 0 + levels 1.. in one kernel
+                consumed[k].record(comp)
+                ref, cur, px, xyz, T_in = prob[k]
+                sia.run(store, W.cam, ref, cur, n_t, px, xyz, T_in, out=out)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(True, True)  # warm-up (allocator, first-touch of the pinned pages)
+    t_stream = min(run(True, True) for _ in range(2))
+    t_copy = min(run(True, False) for _ in range(2))
+    t_comp = min(run(False, True) for _ in range(2))
+    gbps = n_frames * frame_bytes / t_copy / 1e9
+    bound = gbps * 1e9 / frame_bytes
+    res = {"frames": n_frames, "chunk_frames": chunk, "frames_per_s": n_frames / t_stream,
+           "h2d_GBps": gbps, "pcie_bound_frames_per_s": bound, "frac_of_pcie_bound": (n_frames / t_stream) / bound,
+           "seconds": {"streamed": t_stream, "copies_only": t_copy, "compute_only_K0_K1": t_comp},
+           # 1 = the shorter of the two activities is hidden completely behind the longer one, 0 = they run back to back
+           "overlap_frac": (t_copy + t_comp - t_stream) / min(t_copy, t_comp),
+           "resident_frames_per_s_K0_K1": n_frames / t_comp,
+           "what": "pinned host images -> H2D (copy stream, two staging buffers) -> K0 pyramid_fused_kernel -> K1 sia_kernel, per chunk; "
+                   "poses stay on the device"}
+    del host, staging, store
+    torch.cuda.empty_cache()
+    return res
 
 
 def line_floor_bytes(W: Workload, n_sample: int = 64) -> float:
@@ -707,6 +824,8 @@ def line_floor_bytes(W: Workload, n_sample: int = 64) -> float:
                 ok = (u - 3 >= 0) & (v - 3 >= 0) & (u + 3 < lay.w[l]) & (v + 3 < lay.h[l])
                 u, v = u[ok], v[ok]
                 c0 = (u - 3) & ~3
+                if lay.tile == capi.PYR_TILED:  # svo_pyr::run_start: the run stays inside a tile row when the 7 bytes do
+                    c0 = np.where(((c0 & 15) == 8) & (((u - 3) & 15) + 7 <= 16), c0 - 4, c0)
                 for r in range(-3, 4):
                     for cb in (c0, c0 + 4, c0 + 8):  # the three aligned dwords of a window row
                         lines.update((capi.pyr_px_offset(lay, l, cb, v + r) // 128).tolist())

@@ -16,7 +16,7 @@ for r in rows:
     name = r["Kernel_Name"]
     if "at::native" in name or "Cijk" in name or "rocprim" in name or "rocclr" in name:
         continue
-    short = name.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")[:48]
+    short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48]
     per.setdefault(short, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k, v in per.items():
     print(f"{k:50s} calls {len(v):4d}  last {n} (us): {[round(x) for x in v[-n:]]}")
