@@ -26,6 +26,7 @@
 #include "track_kernels.h"
 #include "track_math.h"
 #include "matcher_device.h"
+#include "wave_reduce.h"
 
 using namespace svo_capi;
 using namespace svo_dev;
@@ -253,8 +254,36 @@ static_assert(SCAN_G == 4 || SCAN_G == 8 || SCAN_G == 16 || SCAN_G == 32 || SCAN
 constexpr int SCAN_CHUNK = 1024;
 constexpr int SCAN_BUCKETS = 8;
 
+// The 8 lanes of a group look at 8 consecutive positions of an epipolar line, 0.7 px apart: their 8 x 8 windows
+// overlap almost completely, and what the scan costs is the number of cache-line look-ups its gathers make (8 rows x
+// 1-2 look-ups per position, ~12; the arithmetic of a position is ~100 instructions).  With SCAN_BOX the group fetches
+// the bounding box of its windows ONCE, as 16-byte tile rows of the store (one look-up each, at most 16 rows x 2
+// columns of tiles = 4 per lane), parks it in LDS and every lane cuts its window out of that; a group whose windows do
+// not fit a 16 x 32 box (never on an undistorted line) falls back to fetching per lane.
+#ifndef SCAN_NO_BOX
+#define SCAN_BOX (SCAN_LANES == 8)
+#else
+#define SCAN_BOX 0
+#endif
+constexpr int SCAN_BOX_DWORDS = 16 * 8 + 4;  // 16 rows x 32 bytes (+ one dword: the cut reads three dwords per row)
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+// minimum / maximum over the 8 lanes of a group (quad butterflies + mirror inside the 8 lanes: no LDS)
+__device__ __forceinline__ int group8_min(int v) {
+  v = min(v, dpp_i32<svo_dev::DPP_QUAD_XOR1>(v));
+  v = min(v, dpp_i32<svo_dev::DPP_QUAD_XOR2>(v));
+  return min(v, dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(v));
+}
+__device__ __forceinline__ int group8_max(int v) {
+  v = max(v, dpp_i32<svo_dev::DPP_QUAD_XOR1>(v));
+  v = max(v, dpp_i32<svo_dev::DPP_QUAD_XOR2>(v));
+  return max(v, dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(v));
+}
+
 // ZMSSD scan of one seed, matcher.cpp:248-291, by the SCAN_LANES lanes of a group (lane = position in the group).
-__device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, const int lane) {
+// box: the group's SCAN_BOX_DWORDS dwords of LDS.
+__device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, const int lane, uint32_t* box) {
   const SeedWs& w = a.ws;
   const int sl = w.search_level[s];
   const uint8_t* img = a.store + (int64_t)w.cur_slot[s] * a.L.slot_bytes + a.L.offset[sl];
@@ -306,14 +335,16 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
   }
   for (int base = 0; base < n_total; base += SCAN_G) {
     const int i = base + lane;
+    bool want = false;  // this lane's position is new (not the pixel of the step before) and its patch lies inside the frame
+    int pxi0 = 0, pxi1 = 0;
     if (i < n_total) {
       double pxs[2];
       {
         const double uvs[2] = {uv0, uv1};
         world2cam_uv(a.cam, uvs, pxs);  // cur_frame.cam_->world2cam(uv), matcher.cpp:269
       }
-      const int pxi0 = cast_int(pxs[0] * inv_lvl + 0.5);
-      const int pxi1 = cast_int(pxs[1] * inv_lvl + 0.5);
+      pxi0 = cast_int(pxs[0] * inv_lvl + 0.5);
+      pxi1 = cast_int(pxs[1] * inv_lvl + 0.5);
       int prv0 = 0, prv1 = 0;  // last_x, last_y before the first step
       if (i > 0) {
         double pps[2];
@@ -322,13 +353,66 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
         prv0 = cast_int(pps[0] * inv_lvl + 0.5);
         prv1 = cast_int(pps[1] * inv_lvl + 0.5);
       }
-      if (!(pxi0 == prv0 && pxi1 == prv1) && is_in_frame_level(a.cam, pxi0, pxi1, 8, sl)) {
+      want = !(pxi0 == prv0 && pxi1 == prv1) && is_in_frame_level(a.cam, pxi0, pxi1, 8, sl);
+    }
+    uint32_t sumB = 0, sumBB = 0, sumAB = 0;
+    bool boxed = false;
+#if SCAN_BOX
+    {
+      // bounding box of the group's windows [px-4, px+3]^2 (every lane of the group takes part, wanted or not)
+      const int x_lo = group8_min(want ? pxi0 - 4 : 0x7fffffff), x_hi = group8_max(want ? pxi0 + 3 : -1);
+      const int y_lo = group8_min(want ? pxi1 - 4 : 0x7fffffff), y_hi = group8_max(want ? pxi1 + 3 : -1);
+      const int cx0 = x_lo & ~15;                 // first tile column
+      const int n_rows = y_hi - y_lo + 1;
+      const bool two = x_hi - cx0 >= 16;          // a second tile column
+      boxed = x_hi >= 0 && n_rows <= 16 && x_hi - cx0 < 32;  // (uniform over the group)
+      if (boxed) {
+        const int n_chunks = two ? 2 * n_rows : n_rows;  // 16-byte tile rows to fetch: <= 32, four per lane
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = lane + 8 * k;
+          const int row = two ? (c >> 1) : c, cc = two ? (c & 1) : 0;
+          v[k] = make_uint4(0, 0, 0, 0);
+          if (c < n_chunks) v[k] = *reinterpret_cast<const uint4*>(img + (svo_pyr::row_off(y_lo + row, pitch) + svo_pyr::col_off(cx0 + 16 * cc)));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = lane + 8 * k;
+          const int row = two ? (c >> 1) : c, cc = two ? (c & 1) : 0;
+          if (c < n_chunks) *reinterpret_cast<uint4*>(box + row * 8 + cc * 4) = v[k];
+        }
+        // hand-over inside the wave: DS operations of one wave execute in order
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (want) {
+          const int bx = pxi0 - 4 - cx0;             // 0..24: first byte of the window inside the 32-byte box row
+          const uint32_t sel = (uint32_t)(bx & 3);
+          const uint32_t* r = box + (pxi1 - 4 - y_lo) * 8 + (bx >> 2);
+#pragma unroll
+          for (int y = 0; y < 8; ++y) {
+            const uint32_t d0 = r[8 * y], d1 = r[8 * y + 1], d2 = r[8 * y + 2];
+            const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sel), hi = __builtin_amdgcn_alignbyte(d2, d1, sel);
+            sumB = __builtin_amdgcn_udot4(lo, 0x01010101u, sumB, false);
+            sumB = __builtin_amdgcn_udot4(hi, 0x01010101u, sumB, false);
+            sumBB = __builtin_amdgcn_udot4(lo, lo, sumBB, false);
+            sumBB = __builtin_amdgcn_udot4(hi, hi, sumBB, false);
+            sumAB = __builtin_amdgcn_udot4(lo, ra[2 * y], sumAB, false);
+            sumAB = __builtin_amdgcn_udot4(hi, ra[2 * y + 1], sumAB, false);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+#endif
+    if (want) {
+      if (!boxed) {
         // 8 rows x 8 bytes [pxi0-4, pxi0+3]: 12-byte runs, inside one tile row of the store where the 8 bytes are
         const int wxa = svo_pyr::run_start(pxi0 - 4, 8);
         const uint32_t wbo = (uint32_t)(pxi0 - 4 - wxa);  // 0..4
         uint32_t win[8][3];
         svo_pyr::load_window12<8>(img, pitch, wxa, pxi1 - 4, win);
-        uint32_t sumB = 0, sumBB = 0, sumAB = 0;
 #pragma unroll
         for (int y = 0; y < 8; ++y) {
           uint32_t lo, hi;
@@ -340,14 +424,14 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
           sumAB = __builtin_amdgcn_udot4(lo, ra[2 * y], sumAB, false);
           sumAB = __builtin_amdgcn_udot4(hi, ra[2 * y + 1], sumAB, false);
         }
-        const int sB = (int)sumB, sBB = (int)sumBB, sAB = (int)sumAB;
-        const int zmssd = sumAA - 2 * sAB + sBB - (sumA * sumA - 2 * sumA * sB + sB * sB) / 64;
-        if (zmssd < best) {  // the lane's steps come in increasing order: keeps its first minimum
-          best = zmssd;
-          best_i = i;
-          best_uv0 = uv0;
-          best_uv1 = uv1;
-        }
+      }
+      const int sB = (int)sumB, sBB = (int)sumBB, sAB = (int)sumAB;
+      const int zmssd = sumAA - 2 * sAB + sBB - (sumA * sumA - 2 * sumA * sB + sB * sB) / 64;
+      if (zmssd < best) {  // the lane's steps come in increasing order: keeps its first minimum
+        best = zmssd;
+        best_i = i;
+        best_uv0 = uv0;
+        best_uv1 = uv1;
       }
     }
     if (base + SCAN_G < n_total) {  // on to this lane's next step: SCAN_G more additions
@@ -400,6 +484,7 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
 __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) {
   __shared__ uint16_t s_order[SCAN_CHUNK];
   __shared__ int s_hist[SCAN_BUCKETS], s_off[SCAN_BUCKETS], s_next, s_n;
+  __shared__ __attribute__((aligned(16))) uint32_t s_box[SCAN_BLOCK / SCAN_G][SCAN_BOX_DWORDS + 0];
   constexpr int PER_LANE = SCAN_CHUNK / SCAN_BLOCK;
   constexpr int GROUPS = 64 / SCAN_G;  // seeds a wave scans at a time
   const int base = blockIdx.x * SCAN_CHUNK;
@@ -441,7 +526,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) epi_scan_kernel(const SeedArgs a) 
     if (wl == 0) p = atomicAdd(&s_next, GROUPS);
     p = __builtin_amdgcn_readfirstlane(p);
     if (p >= n_scan) break;
-    if (p + grp < n_scan) epi_scan_seed(a, base + (int)s_order[p + grp], lane);
+    if (p + grp < n_scan) epi_scan_seed(a, base + (int)s_order[p + grp], lane, s_box[threadIdx.x / SCAN_G]);
   }
 }
 
