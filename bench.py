@@ -240,7 +240,8 @@ def main() -> None:
                     help="comma list of the extra legs to run at N=1 (all, none, or any of: f64, refine, full, full_easy, noise, "
                          "config3, stream, rig, k0, dropin, pmc)")
     ap.add_argument("--k1-kernel", default="auto", choices=["auto", "workgroup"],
-                    help="auto: svo_hip_sparse_align (one wave per frame up to 256 patches); workgroup: the workgroup-per-frame kernel")
+                    help="auto: svo_hip_sparse_align (the wave-per-frame kernel for batches >= 1024 of <= 192 patches, else the "
+                         "workgroup-per-frame kernel); workgroup: always the workgroup-per-frame kernel")
     ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)
     ap.add_argument("--dump-result", default="", help=argparse.SUPPRESS)  # child of the f64_partials leg: poses + iteration counts
     args = ap.parse_args()

@@ -468,7 +468,8 @@ int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint8_t* d_stor
  *   d_ok [S]            the function's result
  *   d_depth [S]         `depth` (triangulated, 0 where no match)
  *   d_px_cur [S][2]     Matcher::px_cur_ (may be NULL)
- *   d_search_level [S]  Matcher::search_level_ (may be NULL)
+ *   d_search_level [S]  Matcher::search_level_ (may be NULL); -1 where the function returned before computing it
+ *                       (an edgelet rejected by the angle filter, matcher.cpp:204-212: search_level_ keeps its old value)
  * Matcher::Options are taken from `opt` (the DepthFilter fields of the struct are ignored).
  */
 int svo_hip_find_epipolar_match_direct(const svo_hip_pyr_layout* layout, const uint8_t* d_store,

@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   w.use_1d[s] = a.opt.align_1d ? 1 : 0;
   w.mode[s] = MODE_NONE;
   w.status[s] = 0;
-  w.search_level[s] = 0;
+  w.search_level[s] = -1;  // not reached yet (an edgelet rejected by the angle filter returns before matcher.cpp:214)
   w.ref_slot[s] = 0;
   w.ref_level[s] = 0;
   w.n_steps[s] = 0;

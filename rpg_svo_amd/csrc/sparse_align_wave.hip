@@ -1,21 +1,23 @@
-// sparse_align_wave.hip -- K1, one WAVE per problem (the default for up to 256 patches per frame).
+// sparse_align_wave.hip -- K1, one WAVE per problem: taken by svo_hip_sparse_align for batches of >= 1024 problems
+// with at most 192 patches (64 under a distorted camera model); everything else -- single frames, the 200-patch
+// headline workload -- runs the workgroup-per-problem kernel of sparse_align.hip (sia_wave_applies() below).
 //
 // Same algorithm and numerics as sparse_align.hip (svo::SparseImgAlign::run + the Gauss-Newton loop of
 // vk::NLLSSolver, svo/src/sparse_img_align.cpp:43-258); what changes is who does the work.  There a
 // workgroup of four waves owns a frame, one lane per patch, and every iteration pays two workgroup
-// barriers and a serial solve that three of the four waves sit out; with 168 VGPRs only three such
-// workgroups fit a CU, so a SIMD mostly has one runnable wave and issues a VALU instruction every ~5.4
-// cycles (the SIMD can take one every ~2.4-3.5, scripts/valu_ubench.hip).  Here a frame is ONE wave:
+// barriers and a serial solve that three of the four waves sit out.  Here a frame is ONE wave:
 //
-//   * a lane carries PPL = ceil(n/64) patches (4 for the 200-patch headline workload), each with its own
-//     window cache, and runs them one after the other; the 8 sums of an iteration are accumulated over
-//     the lane's patches before ONE transposing wave reduction (wave_reduce.h);
+//   * a lane carries PPL = ceil(n/64) <= 3 patches, each with its own window cache, and runs them one after
+//     the other; the 8 sums of an iteration are accumulated over the lane's patches before ONE transposing
+//     wave reduction (wave_reduce.h);
 //   * the solve runs in the same wave straight after the reduction: no barrier, no LDS exchange of
 //     partials, no idle waves; the wave totals are read out of the lanes with v_readlane (SGPRs);
 //   * waves of different frames share nothing, so the two waves a SIMD holds (<= 256 VGPRs each) always
 //     have something to issue: one frame's serial solve overlaps the other's pixel work.
+//   A fourth patch per lane does not fit 256 VGPRs with its window cache (PPL = 4 spills in the loop): at 200
+//   patches the workgroup kernel is the faster one (1.39 against 1.63 ms, round 2), at 192 this one (1.26 / 1.36).
 //
-// LDS holds only the interpolated reference patches (128 bytes per patch: 25.6 KB for 200 patches, six
+// LDS holds only the interpolated reference patches (128 bytes per patch: 24.6 KB for 192 patches, six
 // frames per CU) and a few hundred bytes of per-frame scalars.
 #include "sia_common.h"
 

@@ -60,15 +60,15 @@ bool Matcher::findMatchDirect(const Point& pt, const Frame& cur_frame, Vector2d&
                                            lane.stream), "svo_hip_find_match_direct");
   a.download(lane.stream);
   svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
-  if (*ref < 0) return false;  // reference feature too close to its image border (:143-145)
+  // The reference returns before touching anything when no observation is close enough in view angle or the reference
+  // feature sits too close to its image border (:140-145): the kernel then leaves the warp matrix at zero.
+  if (*ref < 0 || (A[0] == 0.0 && A[1] == 0.0 && A[2] == 0.0 && A[3] == 0.0)) return false;
   search_level_ = *lvl;
   A_cur_ref_(0, 0) = A[0]; A_cur_ref_(0, 1) = A[1]; A_cur_ref_(1, 0) = A[2]; A_cur_ref_(1, 1) = A[3];
   std::memcpy(patch_with_border_, patch, sizeof(patch_with_border_));
   createPatchFromPatchWithBorder();
-  if (*ok) {
-    px_cur_ = Vector2d(px[0], px[1]);
-    px_cur = px_cur_;
-  }
+  // px_cur = px_scaled*(1<<search_level_) whether or not the alignment converged (:175); px_cur_ is not this function's
+  px_cur = Vector2d(px[0], px[1]);
   return *ok != 0;
 }
 
@@ -118,7 +118,7 @@ bool Matcher::findEpipolarMatchDirect(const Frame& ref_frame, const Frame& cur_f
                  "svo_hip_find_epipolar_match_direct");
   a.download(lane.stream);
   svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
-  search_level_ = *lvl;
+  if (*lvl >= 0) search_level_ = *lvl;  // (-1: returned before matcher.cpp:214, search_level_ keeps its value)
   if (!*ok) return false;
   px_cur_ = Vector2d(px[0], px[1]);
   depth = *z;

@@ -41,6 +41,21 @@ int envInt(const char* name, int fallback) {
 }
 }  // namespace
 
+namespace {
+// what a rank says before it is handed the blob: who it is and which job it belongs to
+struct Hello {
+  uint32_t magic, rank, world, token;
+};
+constexpr uint32_t HELLO_MAGIC = 0x53564f52u;  // "SVOR"
+struct Fd {  // closes on every path out of a scope
+  int fd;
+  explicit Fd(int f) : fd(f) {}
+  ~Fd() { if (fd >= 0) ::close(fd); }
+  Fd(const Fd&) = delete;
+  Fd& operator=(const Fd&) = delete;
+};
+}  // namespace
+
 void tcpBroadcast(int rank, int world, const std::string& addr, int port, void* blob, size_t bytes, int timeout_s) {
   if (world <= 1) return;
   sockaddr_in sa;
@@ -48,35 +63,55 @@ void tcpBroadcast(int rank, int world, const std::string& addr, int port, void* 
   sa.sin_family = AF_INET;
   sa.sin_port = htons((uint16_t)port);
   if (::inet_pton(AF_INET, addr.c_str(), &sa.sin_addr) != 1) throw std::runtime_error("pose exchange bootstrap: MASTER_ADDR must be an IPv4 address");
+  // a shared secret of the job (SVO_RIG_TOKEN, the launcher sets the same value for every rank; 0 when unset)
+  const uint32_t token = (uint32_t)envInt("SVO_RIG_TOKEN", 0);
   const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(timeout_s);
   if (rank == 0) {
-    const int ls = ::socket(AF_INET, SOCK_STREAM, 0);
+    Fd ls(::socket(AF_INET, SOCK_STREAM, 0));
+    if (ls.fd < 0) throw std::runtime_error("pose exchange bootstrap: socket() failed");
     int one = 1;
-    ::setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-    sockaddr_in any = sa;
-    any.sin_addr.s_addr = htonl(INADDR_ANY);
-    if (::bind(ls, reinterpret_cast<sockaddr*>(&any), sizeof(any)) != 0 || ::listen(ls, world) != 0) {
-      ::close(ls);
-      throw std::runtime_error("pose exchange bootstrap: cannot listen on the rig port");
-    }
+    if (::setsockopt(ls.fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one)) != 0)
+      throw std::runtime_error("pose exchange bootstrap: setsockopt(SO_REUSEADDR) failed");
+    // bind to MASTER_ADDR itself (127.0.0.1 on a single node), not to every interface
+    if (::bind(ls.fd, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) != 0 || ::listen(ls.fd, world) != 0)
+      throw std::runtime_error("pose exchange bootstrap: cannot listen on MASTER_ADDR:port");
     timeval tv = {timeout_s, 0};
-    ::setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
-    for (int k = 1; k < world; ++k) {
-      const int fd = ::accept(ls, NULL, NULL);
-      if (fd < 0) { ::close(ls); throw std::runtime_error("pose exchange bootstrap: a rank did not connect in time"); }
-      sendAll(fd, blob, bytes);
-      ::close(fd);
+    if (::setsockopt(ls.fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv)) != 0)
+      throw std::runtime_error("pose exchange bootstrap: setsockopt(SO_RCVTIMEO) failed");
+    // the blob goes to ranks 1..world-1 of THIS job, once each: a peer introduces itself first; anything else that
+    // connects (wrong magic / world / token, a rank seen before) is dropped without being sent a byte
+    std::vector<bool> served((size_t)world, false);
+    int n_served = 0;
+    while (n_served < world - 1) {
+      if (std::chrono::steady_clock::now() > deadline) throw std::runtime_error("pose exchange bootstrap: a rank did not connect in time");
+      Fd c(::accept(ls.fd, NULL, NULL));
+      if (c.fd < 0) throw std::runtime_error("pose exchange bootstrap: a rank did not connect in time");
+      ::setsockopt(c.fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+      Hello h;
+      try {
+        recvAll(c.fd, &h, sizeof(h));
+      } catch (const std::exception&) {
+        continue;  // not one of ours
+      }
+      if (h.magic != HELLO_MAGIC || h.world != (uint32_t)world || h.token != token || h.rank == 0 || h.rank >= (uint32_t)world ||
+          served[h.rank])
+        continue;
+      sendAll(c.fd, blob, bytes);
+      served[h.rank] = true;
+      ++n_served;
     }
-    ::close(ls);
   } else {
     for (;;) {
-      const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
-      if (::connect(fd, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) == 0) {
-        recvAll(fd, blob, bytes);
-        ::close(fd);
-        return;
+      {
+        Fd c(::socket(AF_INET, SOCK_STREAM, 0));
+        if (c.fd < 0) throw std::runtime_error("pose exchange bootstrap: socket() failed");
+        if (::connect(c.fd, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) == 0) {
+          const Hello h = {HELLO_MAGIC, (uint32_t)rank, (uint32_t)world, token};
+          sendAll(c.fd, &h, sizeof(h));
+          recvAll(c.fd, blob, bytes);
+          return;
+        }
       }
-      ::close(fd);
       if (std::chrono::steady_clock::now() > deadline) throw std::runtime_error("pose exchange bootstrap: rank 0 is not reachable");
       std::this_thread::sleep_for(std::chrono::milliseconds(50));
     }

@@ -52,8 +52,8 @@ class SparseImgAlign:
         self.eps = 0.000001  # sparse_img_align.cpp:40
         self.verbose = verbose
         self.lib = capi.load()
-        # "auto": svo_hip_sparse_align picks the kernel (one wave per frame up to 256 patches, one workgroup
-        # per frame beyond); "workgroup": the workgroup-per-frame kernel for any patch count
+        # "auto": svo_hip_sparse_align picks the kernel (one wave per frame for batches of >= 1024 frames with <= 192
+        # patches, one workgroup per frame otherwise); "workgroup": the workgroup-per-frame kernel whatever the sizes
         self.kernel = "auto"
 
     def params(self, cam) -> capi.SiaParams:

@@ -27,6 +27,33 @@ def test_unique_id_broadcast_three_processes(tmp_path):
     assert len(set(outs)) == 1 and outs[0] != "0"
 
 
+def test_bootstrap_ignores_strangers(tmp_path):
+    """Rank 0 hands the blob only to peers that introduce themselves as a rank of this job: a connection that says
+    something else gets no byte of it and does not use up a rank's place."""
+    import socket
+    import time
+    exe = str(tmp_path / "test_bootstrap")
+    subprocess.run(["g++", "-std=c++11", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", RIG, "-I", "/opt/rocm/include",
+                    os.path.join(ROOT, "tests", "host", "test_bootstrap.cpp"), os.path.join(RIG, "pose_exchange.cpp"),
+                    "-L", "/opt/rocm/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-pthread", "-o", exe], check=True)
+    port = 32000 + os.getpid() % 2000
+    p0 = subprocess.Popen([exe, "0", "2", str(port)], stdout=subprocess.PIPE, text=True)
+    got = None
+    for _ in range(100):  # the stranger: connects as soon as rank 0 listens, sends 16 bytes that are not a hello
+        try:
+            with socket.create_connection(("127.0.0.1", port), timeout=2) as so:
+                so.sendall(b"GET / HTTP/1.0\r\n")
+                so.settimeout(5)
+                got = so.recv(256)
+            break
+        except ConnectionRefusedError:
+            time.sleep(0.05)
+    assert got == b"", got  # closed without a byte
+    p1 = subprocess.Popen([exe, "1", "2", str(port)], stdout=subprocess.PIPE, text=True)
+    o0, o1 = p0.communicate(timeout=60)[0].strip(), p1.communicate(timeout=60)[0].strip()
+    assert p0.returncode == 0 and p1.returncode == 0 and o0 == o1 and o0 != "0"
+
+
 def _rig_exe():
     exe = os.path.join(ROOT, "build", "svo_rig_replay")
     if not os.path.exists(exe):
