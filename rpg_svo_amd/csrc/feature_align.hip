@@ -25,19 +25,15 @@ namespace {
 // byte i (compile-time) of the 100-byte template held in 25 dwords
 #define PWB(i) ((int)((g[(i) >> 2] >> (8 * ((i)&3))) & 0xffu))
 
-// ALIGN_REMAT_TEMPLATE keeps the byte extractions and the template gradients derived from g[] inside the
-// iteration that uses them (the compiler otherwise hoists them out of the loop as 192 floats: 255 VGPRs, 2 waves
-// per SIMD).  Measured: 165 VGPRs / 3 waves per SIMD but +50 % instructions per iteration -- no faster (0.82 ms
-// either way on 3.3 M trials), so the hoisted form stays the default.  Emits no instruction.
-#ifdef ALIGN_REMAT_TEMPLATE
+// ALIGN_OPAQUE_TEMPLATE(g) at the top of an iteration keeps whatever is derived from g[] after it inside the
+// iteration (the compiler otherwise hoists all 192 template-derived floats out of the loop and needs more than 256
+// registers: one wave per SIMD).  align2D hoists the 64 gradient pairs itself (they feed the packed accumulation) and
+// re-derives the 64 template intensities from the bytes in flight: one v_cvt_f32_ubyte per pixel.  Emits no instruction.
 #define ALIGN_OPAQUE_TEMPLATE(g)                                                                                   \
   asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]), "+v"(g[7]),  \
                "+v"(g[8]), "+v"(g[9]), "+v"(g[10]), "+v"(g[11]), "+v"(g[12]));                                        \
   asm volatile("" : "+v"(g[13]), "+v"(g[14]), "+v"(g[15]), "+v"(g[16]), "+v"(g[17]), "+v"(g[18]), "+v"(g[19]),       \
                "+v"(g[20]), "+v"(g[21]), "+v"(g[22]), "+v"(g[23]), "+v"(g[24]))
-#else
-#define ALIGN_OPAQUE_TEMPLATE(g)
-#endif
 
 __device__ __forceinline__ void cut_row9(const uint32_t d[3], uint32_t sel, float out[9]);
 // bytes [x0, x0+8] of the image row at byte offset ro (svo_pyr::row_off) as floats: one 12-byte run of three aligned
@@ -116,6 +112,17 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
   }
   float Hinv[9];
   inv3f(H, Hinv);
+#ifndef ALIGN_NO_PACKED
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 G[64];  // {dx, dy} of every template pixel (:176-181), formed once
+#pragma unroll
+  for (int y = 0; y < 8; ++y)
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const int c = (y + 1) * 10 + x + 1;
+      G[8 * y + x] = (f2){0.5f * (float)(PWB(c + 1) - PWB(c - 1)), 0.5f * (float)(PWB(c + 10) - PWB(c - 10))};
+    }
+#endif
   float mean_diff = st.mean_diff;
   const float min_update_squared = (float)(0.03 * 0.03);
   const int it_end = it1 < n_iter ? it1 : n_iter;
@@ -151,6 +158,46 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
 #else
     load_row9(img, svo_pyr::row_off(v_r - 4, pitch), wxa, wsel, P0);
 #endif
+#ifndef ALIGN_NO_PACKED
+    // The pixel loop in packed f32 (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per issue slot; every product and
+    // sum is rounded on its own, in the reference's order, so the bits do not change).  Pixels x and x+4 of a row
+    // form a pair for the interpolation and the residual -- the row is kept as Q[k] = {P[k], P[k+4]}, which serves
+    // as left AND right neighbour pair -- and the two gradient products of a pixel form a pair for the accumulation:
+    // {Jres0, Jres1} -= {res, res} * {dx, dy}, pixel after pixel in raster order (the third sum stays scalar).
+    const f2 wTL2 = {wTL, wTL}, wTR2 = {wTR, wTR}, wBL2 = {wBL, wBL}, wBR2 = {wBR, wBR}, md2 = {mean_diff, mean_diff};
+    f2 J01 = {0.f, 0.f};
+    f2 Q0[5], Q1[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) Q0[k] = (f2){P0[k], P0[k + 4]};
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+#ifndef ALIGN_ROW_LOADS
+      cut_row9(win[y + 1], wsel, P1);
+#else
+      load_row9(img, svo_pyr::row_off(v_r - 3 + y, pitch), wxa, wsel, P1);
+#endif
+#pragma unroll
+      for (int k = 0; k < 5; ++k) Q1[k] = (f2){P1[k], P1[k + 4]};
+      f2 res2[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int c = (y + 1) * 10 + x + 1;
+        const f2 sp = wTL2 * Q0[x] + wTR2 * Q0[x + 1] + wBL2 * Q1[x] + wBR2 * Q1[x + 1];
+        const f2 ref2 = {(float)PWB(c), (float)PWB(c + 4)};
+        res2[x] = sp - ref2 + md2;
+      }
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {  // raster order: x = 0..3 are the low halves, 4..7 the high halves
+        const float res = (x < 4) ? res2[x].x : res2[x - 4].y;
+        J01 -= (f2){res, res} * G[8 * y + x];
+        Jres2 -= res;
+      }
+#pragma unroll
+      for (int k = 0; k < 5; ++k) Q0[k] = Q1[k];
+    }
+    Jres0 = J01.x;
+    Jres1 = J01.y;
+#else
 #pragma unroll
     for (int y = 0; y < 8; ++y) {
 #ifndef ALIGN_ROW_LOADS
@@ -170,6 +217,7 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
 #pragma unroll
       for (int k = 0; k < 9; ++k) P0[k] = P1[k];
     }
+#endif
     const float up0 = Hinv[0] * Jres0 + Hinv[1] * Jres1 + Hinv[2] * Jres2;
     const float up1 = Hinv[3] * Jres0 + Hinv[4] * Jres1 + Hinv[5] * Jres2;
     const float up2 = Hinv[6] * Jres0 + Hinv[7] * Jres1 + Hinv[8] * Jres2;
@@ -195,6 +243,7 @@ __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, in
   n_eval = 0;
   float u = st.u, v = st.v;
   float H[4] = {0, 0, 0, 0};
+  float Jd[64];  // the directional derivative of every template pixel (:53-56), formed once
 #pragma unroll
   for (int y = 0; y < 8; ++y)
 #pragma unroll
@@ -203,6 +252,7 @@ __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, in
       // J[0] = 0.5*(dir[0]*(it[1]-it[-1]) + dir[1]*(it[ref_step]-it[-ref_step]))  (double 0.5 * float)
       const float s = dir0 * (float)(PWB(c + 1) - PWB(c - 1)) + dir1 * (float)(PWB(c + 10) - PWB(c - 10));
       const float J0 = (float)(0.5 * (double)s);
+      Jd[8 * y + x] = J0;
       H[0] += J0 * J0;
       H[1] += J0 * 1.f;
       H[2] += 1.f * J0;
@@ -260,8 +310,7 @@ __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, in
         const int c = (y + 1) * 10 + x + 1;
         const float search_pixel = wTL * P0[x] + wTR * P0[x + 1] + wBL * P1[x] + wBR * P1[x + 1];
         const float res = search_pixel - (float)PWB(c) + mean_diff;
-        const float s = dir0 * (float)(PWB(c + 1) - PWB(c - 1)) + dir1 * (float)(PWB(c + 10) - PWB(c - 10));
-        Jres0 -= res * (float)(0.5 * (double)s);
+        Jres0 -= res * Jd[8 * y + x];
         Jres1 -= res;
         new_chi2 += res * res;
       }
@@ -292,8 +341,13 @@ __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, in
 
 constexpr int ALIGN_BLOCK = 64;
 
+// Two waves per SIMD (<= 256 registers): with the bare __launch_bounds__(64) the compiler took 256 VGPRs plus 15-20
+// AGPRs, i.e. ONE wave per SIMD, and nothing hid the round trip of an iteration's window fetch.
+#ifndef ALIGN_MINW
+#define ALIGN_MINW 2
+#endif
 template <bool COUNT>
-__global__ void __launch_bounds__(ALIGN_BLOCK) align_kernel(const AlignArgs a) {
+__global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const AlignArgs a) {
   // which trial: lane order in the first launch of a run, the queues filled by the previous launch afterwards
   // (workgroup b drains queue b % ALIGN_NQ, 64 entries at a time)
   int t;
