@@ -4,7 +4,7 @@
 # gpurun_out/<tag>/ and are copied from there into profiles/ (prefix <tag>_).
 # usage: scripts/final_evidence.sh <tag>
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG; rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
@@ -26,6 +26,8 @@ stats $O/trace_align $O/align_kernel_stats.csv
 echo "== full track under kernel trace"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_full -o trace -- python $R/bench.py --pipeline full --steps 5 --warmup 2 --no-cpu-baseline --extras none > $O/full_bench_under_trace.json 2> $O/trace_full.err
 stats $O/trace_full $O/full_kernel_stats.csv
+# the set-up of the representative workload launches the same kernels at other sizes: the timed steps are the last dispatches
+python $R/scripts/kernel_last_steps.py $O/trace_full 10 > $O/full_kernel_last_steps.txt
 echo "== drop-in sequence under kernel trace"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_dropin -o trace -- python -c "import sys; sys.path.insert(0, '$R'); import bench, json; print(json.dumps(bench.dropin_sequence(120)))" > $O/dropin_under_trace.json 2> $O/trace_dropin.err
 stats $O/trace_dropin $O/dropin_kernel_stats.csv
