@@ -85,44 +85,38 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
   // H = sum J J', J = (dx, dy, 1) (:166-181).  dx, dy are half-integers (byte differences / 2) and every
   // partial sum of the reference's float accumulation is a multiple of 0.25 below 2^22: no rounding ever
   // happens, so the sums can be formed in any order -- here as integers of the doubled gradients
-  // (|2dx| <= 255, sum of squares <= 64 * 255^2 < 2^23), five v_mad_i32_i24 per pixel instead of nine
-  // multiply-adds, and converted once.  Same bits.
+  // (|2dx| <= 255, sum of squares <= 64 * 255^2 < 2^23).  Same bits.
+  // Here: in f32 with explicit fma -- the doubled gradients are differences of byte values (exact), their products
+  // are below 2^17 and the running sums below 2^23, so every fma is exact too: one v_cvt_f32_ubyte per template byte,
+  // then subtractions and fused multiply-adds, no integer extraction.
+  typedef float f2 __attribute__((ext_vector_type(2)));
   float H[9];
+  f2 G[64];  // {dx, dy} of every template pixel (:176-181), formed once
   {
-    int sxx = 0, sxy = 0, syy = 0, sx = 0, sy = 0;
+    float sxx = 0.f, sxy = 0.f, syy = 0.f, sx = 0.f, sy = 0.f;
 #pragma unroll
     for (int y = 0; y < 8; ++y)
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
         const int c = (y + 1) * 10 + x + 1;
-        const int gx2 = PWB(c + 1) - PWB(c - 1);    // 2 dx
-        const int gy2 = PWB(c + 10) - PWB(c - 10);  // 2 dy
-        sxx += gx2 * gx2;
-        sxy += gx2 * gy2;
-        syy += gy2 * gy2;
+        const float gx2 = (float)PWB(c + 1) - (float)PWB(c - 1);    // 2 dx
+        const float gy2 = (float)PWB(c + 10) - (float)PWB(c - 10);  // 2 dy
+        sxx = __builtin_fmaf(gx2, gx2, sxx);
+        sxy = __builtin_fmaf(gx2, gy2, sxy);
+        syy = __builtin_fmaf(gy2, gy2, syy);
         sx += gx2;
         sy += gy2;
+        G[8 * y + x] = (f2){0.5f * gx2, 0.5f * gy2};  // == 0.5f * (float)(int difference): the difference is exact either way
       }
-    H[0] = 0.25f * (float)sxx;
-    H[1] = H[3] = 0.25f * (float)sxy;
-    H[4] = 0.25f * (float)syy;
-    H[2] = H[6] = 0.5f * (float)sx;
-    H[5] = H[7] = 0.5f * (float)sy;
+    H[0] = 0.25f * sxx;
+    H[1] = H[3] = 0.25f * sxy;
+    H[4] = 0.25f * syy;
+    H[2] = H[6] = 0.5f * sx;
+    H[5] = H[7] = 0.5f * sy;
     H[8] = 64.f;
   }
   float Hinv[9];
   inv3f(H, Hinv);
-#ifndef ALIGN_NO_PACKED
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  f2 G[64];  // {dx, dy} of every template pixel (:176-181), formed once
-#pragma unroll
-  for (int y = 0; y < 8; ++y)
-#pragma unroll
-    for (int x = 0; x < 8; ++x) {
-      const int c = (y + 1) * 10 + x + 1;
-      G[8 * y + x] = (f2){0.5f * (float)(PWB(c + 1) - PWB(c - 1)), 0.5f * (float)(PWB(c + 10) - PWB(c - 10))};
-    }
-#endif
   float mean_diff = st.mean_diff;
   const float min_update_squared = (float)(0.03 * 0.03);
   const int it_end = it1 < n_iter ? it1 : n_iter;

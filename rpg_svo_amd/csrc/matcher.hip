@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(64) match_prepare_kernel(const PrepArgs a) {
 // 100 output bytes of a trial are assembled in LDS and the wave stores its 600 contiguous bytes as
 // coalesced dwords.  Arithmetic per sample is unchanged (bit-identical patches).
 constexpr int WARP_TPW = 6;  // trials per wave
+constexpr int WARP_REG_ROWS = 24;  // rows of the LDS copy of a trial's source region (48 bytes each)
 #ifndef WARP_WGS_PER_CU
 #define WARP_WGS_PER_CU 16
 #endif
@@ -159,6 +160,9 @@ __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
   __shared__ long long s_off[SVO_HIP_MAX_LEVELS];
   __shared__ int s_w[SVO_HIP_MAX_LEVELS], s_h[SVO_HIP_MAX_LEVELS], s_p[SVO_HIP_MAX_LEVELS];
   __shared__ uint32_t s_patch[4][WARP_TPW * 25 + 2];
+#ifndef WARP_NO_REGION
+  __shared__ __attribute__((aligned(16))) uint32_t s_region[4][WARP_TPW][WARP_REG_ROWS * 12 + 16];  // rows of 48 bytes
+#endif
   if (threadIdx.x < SVO_HIP_MAX_LEVELS) {
     s_off[threadIdx.x] = a.L.offset[threadIdx.x];
     s_w[threadIdx.x] = a.L.w[threadIdx.x];
@@ -190,76 +194,148 @@ __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
         const uint8_t* img = a.store + (int64_t)slot * a.L.slot_bytes + s_off[level];
         const int cols = s_w[level], rows = s_h[level], pitch = s_p[level];
         const float sc = (float)(1 << slev);
-        // round 2, five output rows at a time: addresses and weights of the five samples of this column, then all
-        // their loads, then the arithmetic.  A sample reads the 2 x 2 pixels (xi, yi) .. (xi+1, yi+1) as two 16-bit
-        // loads (gfx950 global memory takes any alignment).  In the tiled store the pair (xi, xi+1) straddles two
-        // tiles for one column in sixteen: those lanes fetch their right-hand pixels with two byte loads more, issued
-        // together with everything else (a fix-up that waited for its own round trip per row cost +70 %).
+        bool boxed = false;
+#ifndef WARP_NO_REGION
+        // ---- the source region through LDS ------------------------------------------------------------------
+        // The 100 samples of a trial lie in the parallelogram spanned by its four corner samples (the map is affine and
+        // every rounding in it is monotone, so the extremes ARE the corners).  Its bounding box, at most WARP_REG_ROWS x
+        // 48 bytes of 16-byte tile rows, is fetched once by the trial's 10 lanes (2-7 dwordx4 loads per lane instead of
+        // 20 two-byte gathers plus the tile-straddle fix-ups) and the samples read their four bytes from LDS: no tile
+        // address arithmetic, no 64-bit address per sample.  A trial whose box is larger (strong down-scaling) or not
+        // finite takes the gathers below.
+        {
+          float bx0 = 3.0e38f, bx1 = -3.0e38f, by0 = 3.0e38f, by1 = -3.0e38f;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          float w00[5], w01[5], w10[5], w11[5];
-          bool in[5];
-          uint16_t top[5], bot[5];
-#if SVO_PYR_TILE
-          uint32_t fix_t[5], fix_b[5];
-          uint8_t rt8[5], rb8[5];
-          bool cross[5];
-          bool any_cross = false;
-#endif
-#pragma unroll
-          for (int k = 0; k < 5; ++k) {
-            const int y = 5 * h + k;
-            float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
+          for (int k = 0; k < 4; ++k) {
+            float pp0 = (float)((k & 1) ? 4 : -5), pp1 = (float)((k & 2) ? 4 : -5);
             pp0 *= sc;
             pp1 *= sc;
-            const float px0 = (A.x * pp0 + A.y * pp1) + pyr.x;
-            const float px1 = (A.z * pp0 + A.w * pp1) + pyr.y;
-            in[k] = !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
-            // vk::interpolateMat_8u; samples outside the image read pixel (0,0) and are discarded
-            const float u = in[k] ? px0 : 0.f, v = in[k] ? px1 : 0.f;
-            const int xi = (int)floorf(u), yi = (int)floorf(v);
-            const float sx = u - (float)xi, sy = v - (float)yi;
-            w00[k] = (1.0f - sx) * (1.0f - sy);
-            w01[k] = (1.0f - sx) * sy;
-            w10[k] = sx * (1.0f - sy);
-            w11[k] = 1.0f - w00[k] - w01[k] - w10[k];
-            const uint32_t rt = svo_pyr::row_off(yi, pitch), rb = svo_pyr::row_off(yi + 1, pitch);
-            const uint32_t cl = svo_pyr::col_off(xi);
-            __builtin_memcpy(&top[k], img + (rt + cl), 2);
-#ifdef WARP_DBG_HALF_LOADS  // timing experiment only (wrong pixels): how much of the kernel is the gathers?
-            bot[k] = top[k];
-#else
-            __builtin_memcpy(&bot[k], img + (rb + cl), 2);
-#endif
-#if SVO_PYR_TILE
-            cross[k] = (xi & 15) == 15;  // pixel xi+1 is the first byte of the next tile
-            any_cross = any_cross || cross[k];
-            fix_t[k] = rt + cl + 113u;   // col_off(xi + 1) - col_off(xi) when xi % 16 == 15
-            fix_b[k] = rb + cl + 113u;
-            rt8[k] = rb8[k] = 0;
-#endif
+            const float q0 = (A.x * pp0 + A.y * pp1) + pyr.x;
+            const float q1 = (A.z * pp0 + A.w * pp1) + pyr.y;
+            bx0 = fminf(bx0, q0); bx1 = fmaxf(bx1, q0);
+            by0 = fminf(by0, q1); by1 = fmaxf(by1, q1);
           }
-#if SVO_PYR_TILE
-          if (any_cross) {
-#pragma unroll
-            for (int k = 0; k < 5; ++k)
-              if (cross[k]) {
-                rt8[k] = img[fix_t[k]];
-                rb8[k] = img[fix_b[k]];
+          // (comparisons are false for NaN: such a trial is not boxed)
+          if (bx0 > -1.0e6f && bx1 < 1.0e6f && by0 > -1.0e6f && by1 < 1.0e6f && bx0 <= bx1 && by0 <= by1) {
+            int xlo = (int)floorf(bx0), xhi = (int)floorf(bx1) + 1, ylo = (int)floorf(by0), yhi = (int)floorf(by1) + 1;
+            xlo = max(xlo, 0); ylo = max(ylo, 0);
+            xhi = min(xhi, cols - 1); yhi = min(yhi, rows - 1);
+            const int cx0 = xlo & ~15;
+            const int nch = xhi >= cx0 ? ((xhi - cx0) >> 4) + 1 : 0, nrow = yhi - ylo + 1;
+            if (xhi < xlo || yhi < ylo) {
+              boxed = true;  // every sample lies outside the image: the patch stays zero
+            } else if (nch <= 3 && nrow <= WARP_REG_ROWS) {
+              boxed = true;
+              uint8_t* const reg = reinterpret_cast<uint8_t*>(s_region[wave][t]);
+              const int n_chunks = nrow * nch;
+              const uint32_t inv = nch == 1 ? 65536u : (nch == 2 ? 32768u : 21846u);  // c / nch for c < 128
+              for (int c = x; c < n_chunks; c += 10) {
+                const int row = (int)(((uint32_t)c * inv) >> 16), cc = c - row * nch;
+                const uint4 v = *reinterpret_cast<const uint4*>(img + (svo_pyr::row_off(ylo + row, pitch) + svo_pyr::col_off(cx0 + 16 * cc)));
+                *reinterpret_cast<uint4*>(reg + row * 48 + cc * 16) = v;
               }
+              // hand-over inside the wave: DS operations of one wave execute in order
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+#pragma unroll
+              for (int y = 0; y < 10; ++y) {
+                float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
+                pp0 *= sc;
+                pp1 *= sc;
+                const float px0 = (A.x * pp0 + A.y * pp1) + pyr.x;
+                const float px1 = (A.z * pp0 + A.w * pp1) + pyr.y;
+                const bool in = !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
+                // vk::interpolateMat_8u (a sample outside the image is 0)
+                const float u = in ? px0 : (float)xlo, v = in ? px1 : (float)ylo;
+                const int xi = (int)floorf(u), yi = (int)floorf(v);
+                const float sx = u - (float)xi, sy = v - (float)yi;
+                const float w00 = (1.0f - sx) * (1.0f - sy);
+                const float w01 = (1.0f - sx) * sy;
+                const float w10 = sx * (1.0f - sy);
+                const float w11 = 1.0f - w00 - w01 - w10;
+                const uint8_t* q = reg + (yi - ylo) * 48 + (xi - cx0);
+                const float p00 = (float)q[0], p10 = (float)q[1], p01 = (float)q[48], p11 = (float)q[49];
+                const float val = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
+                out[y] = in ? (uint8_t)val : (uint8_t)0;
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+            }
           }
+        }
+#endif
+        if (!boxed) {
+        // round 2, five output rows at a time: addresses and weights of the five samples of this column, then all
+          // their loads, then the arithmetic.  A sample reads the 2 x 2 pixels (xi, yi) .. (xi+1, yi+1) as two 16-bit
+          // loads (gfx950 global memory takes any alignment).  In the tiled store the pair (xi, xi+1) straddles two
+          // tiles for one column in sixteen: those lanes fetch their right-hand pixels with two byte loads more, issued
+          // together with everything else (a fix-up that waited for its own round trip per row cost +70 %).
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float w00[5], w01[5], w10[5], w11[5];
+            bool in[5];
+            uint16_t top[5], bot[5];
+#if SVO_PYR_TILE
+            uint32_t fix_t[5], fix_b[5];
+            uint8_t rt8[5], rb8[5];
+            bool cross[5];
+            bool any_cross = false;
 #endif
 #pragma unroll
-          for (int k = 0; k < 5; ++k) {
-#if SVO_PYR_TILE
-            const float p10 = cross[k] ? (float)rt8[k] : (float)(top[k] >> 8);
-            const float p11 = cross[k] ? (float)rb8[k] : (float)(bot[k] >> 8);
+            for (int k = 0; k < 5; ++k) {
+              const int y = 5 * h + k;
+              float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
+              pp0 *= sc;
+              pp1 *= sc;
+              const float px0 = (A.x * pp0 + A.y * pp1) + pyr.x;
+              const float px1 = (A.z * pp0 + A.w * pp1) + pyr.y;
+              in[k] = !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
+              // vk::interpolateMat_8u; samples outside the image read pixel (0,0) and are discarded
+              const float u = in[k] ? px0 : 0.f, v = in[k] ? px1 : 0.f;
+              const int xi = (int)floorf(u), yi = (int)floorf(v);
+              const float sx = u - (float)xi, sy = v - (float)yi;
+              w00[k] = (1.0f - sx) * (1.0f - sy);
+              w01[k] = (1.0f - sx) * sy;
+              w10[k] = sx * (1.0f - sy);
+              w11[k] = 1.0f - w00[k] - w01[k] - w10[k];
+              const uint32_t rt = svo_pyr::row_off(yi, pitch), rb = svo_pyr::row_off(yi + 1, pitch);
+              const uint32_t cl = svo_pyr::col_off(xi);
+              __builtin_memcpy(&top[k], img + (rt + cl), 2);
+#ifdef WARP_DBG_HALF_LOADS  // timing experiment only (wrong pixels): how much of the kernel is the gathers?
+              bot[k] = top[k];
 #else
-            const float p10 = (float)(top[k] >> 8), p11 = (float)(bot[k] >> 8);
+              __builtin_memcpy(&bot[k], img + (rb + cl), 2);
 #endif
-            const float p00 = (float)(top[k] & 0xffu), p01 = (float)(bot[k] & 0xffu);
-            const float val = w00[k] * p00 + w01[k] * p01 + w10[k] * p10 + w11[k] * p11;
-            out[5 * h + k] = in[k] ? (uint8_t)val : (uint8_t)0;
+#if SVO_PYR_TILE
+              cross[k] = (xi & 15) == 15;  // pixel xi+1 is the first byte of the next tile
+              any_cross = any_cross || cross[k];
+              fix_t[k] = rt + cl + 113u;   // col_off(xi + 1) - col_off(xi) when xi % 16 == 15
+              fix_b[k] = rb + cl + 113u;
+              rt8[k] = rb8[k] = 0;
+#endif
+            }
+#if SVO_PYR_TILE
+            if (any_cross) {
+#pragma unroll
+              for (int k = 0; k < 5; ++k)
+                if (cross[k]) {
+                  rt8[k] = img[fix_t[k]];
+                  rb8[k] = img[fix_b[k]];
+                }
+            }
+#endif
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+#if SVO_PYR_TILE
+              const float p10 = cross[k] ? (float)rt8[k] : (float)(top[k] >> 8);
+              const float p11 = cross[k] ? (float)rb8[k] : (float)(bot[k] >> 8);
+#else
+              const float p10 = (float)(top[k] >> 8), p11 = (float)(bot[k] >> 8);
+#endif
+              const float p00 = (float)(top[k] & 0xffu), p01 = (float)(bot[k] & 0xffu);
+              const float val = w00[k] * p00 + w01[k] * p01 + w10[k] * p10 + w11[k] * p11;
+              out[5 * h + k] = in[k] ? (uint8_t)val : (uint8_t)0;
+            }
           }
         }
       }
