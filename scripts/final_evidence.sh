@@ -21,8 +21,9 @@ PY
 }
 echo "== default bench"; (time python $R/bench.py) > $O/bench_default.json 2> $O/bench_default.err
 echo "== headline under kernel trace"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_align -o trace -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --extras none > $O/align_bench_under_trace.json 2> $O/trace_align.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_align -o trace -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --extras none > $O/align_bench_under_trace.json 2> $O/trace_align.err
 stats $O/trace_align $O/align_kernel_stats.csv
+python $R/scripts/kernel_last_steps.py $O/trace_align 50 > $O/align_kernel_last_steps.txt  # every launch: warm-ups first
 echo "== full track under kernel trace"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_full -o trace -- python $R/bench.py --pipeline full --steps 5 --warmup 2 --no-cpu-baseline --extras none > $O/full_bench_under_trace.json 2> $O/trace_full.err
 stats $O/trace_full $O/full_kernel_stats.csv

@@ -27,20 +27,21 @@ def _check(store, oracle, imgs, levels, mode, first):
 
 @pytest.mark.parametrize("w,h,levels", SHAPES)
 @pytest.mark.parametrize("mode", [0, 1, 2])
-@pytest.mark.parametrize("tile", [128, 256, 257, 512])
-def test_pyramid_bit_exact(oracle, gpu_device, hip_lib, w, h, levels, mode, tile):
+def test_pyramid_bit_exact(oracle, gpu_device, hip_lib, w, h, levels, mode):
+    """One case per image shape and half-sample flavour; every level-0 tile of the fused kernel inside it."""
     from rpg_svo_amd.pyramid import PyramidStore
     rng = np.random.default_rng(w * 7 + h + mode)
     imgs = rng.integers(0, 256, size=(3, h, w), dtype=np.uint8)
     dimgs = torch.from_numpy(imgs).to(gpu_device)
-    # (a) fused, level 0 filled from the packed images in the same pass
-    store = PyramidStore(w, h, levels, 4, device=gpu_device, halfsample=mode)
-    store.load_images(dimgs, first_slot=1, tile=tile)
-    _check(store, oracle, imgs, levels, mode, 1)
-    # (b) level 0 copied first, fused build from the store
-    store2 = PyramidStore(w, h, levels, 4, device=gpu_device, halfsample=mode)
-    store2.load_images(dimgs, first_slot=0, fused=False, tile=tile)
-    _check(store2, oracle, imgs, levels, mode, 0)
+    for tile in (128, 256, 257, 512):
+        # (a) fused, level 0 filled from the packed images in the same pass
+        store = PyramidStore(w, h, levels, 4, device=gpu_device, halfsample=mode)
+        store.load_images(dimgs, first_slot=1, tile=tile)
+        _check(store, oracle, imgs, levels, mode, 1)
+        # (b) level 0 copied first, fused build from the store
+        store2 = PyramidStore(w, h, levels, 4, device=gpu_device, halfsample=mode)
+        store2.load_images(dimgs, first_slot=0, fused=False, tile=tile)
+        _check(store2, oracle, imgs, levels, mode, 0)
     # (c) the per-level builder
     store3 = PyramidStore(w, h, levels, 4, device=gpu_device, halfsample=mode)
     store3.load_images(dimgs, first_slot=0, build=False)
@@ -72,3 +73,27 @@ def test_upload_path_matches_load_path(oracle, gpu_device):
         assert np.array_equal(store.level(0, l), store.level(1, l))
     ref = oracle.create_img_pyramid(img, 4, oracle.HALFSAMPLE_AUTO)
     assert np.array_equal(store.level(0, 3), ref[3])
+
+
+def test_host_uploads_through_a_stream_ordered_temporary(oracle, gpu_device, hip_lib):
+    """svo_hip_pyramid_upload_level0 / upload_level / upload_build with d_staging = NULL (hipMallocAsync scratch), and
+    one level uploaded on its own (the cv::Mat a direct caller hands to feature_alignment::align2D): the tiled store
+    gives back the rows that went in."""
+    import ctypes as C
+    from rpg_svo_amd import capi
+    from rpg_svo_amd.pyramid import PyramidStore, _stream_ptr
+    rng = np.random.default_rng(21)
+    w, h = 188, 120
+    store = PyramidStore(w, h, 3, 3, device=gpu_device)
+    img = rng.integers(0, 256, size=(h, w + 5), dtype=np.uint8)  # row stride > width
+    lvl1 = rng.integers(0, 256, size=(h // 2, w // 2), dtype=np.uint8)
+    lib, L, st = hip_lib, store.layout, _stream_ptr(store.device)
+    capi.check(lib.svo_hip_pyramid_upload_level0(C.byref(L), store.ptr, 0, img.ctypes.data, img.shape[1], None, st))
+    capi.check(lib.svo_hip_pyramid_upload_level(C.byref(L), store.ptr, 0, 1, lvl1.ctypes.data, lvl1.shape[1], None, st))
+    capi.check(lib.svo_hip_pyramid_upload_build(C.byref(L), store.ptr, 1, img.ctypes.data, img.shape[1], capi.HALFSAMPLE_AUTO, None, st))
+    torch.cuda.synchronize()
+    assert np.array_equal(store.level(0, 0), img[:, :w])
+    assert np.array_equal(store.level(0, 1), lvl1)
+    ref = oracle.create_img_pyramid(np.ascontiguousarray(img[:, :w]), 3, oracle.HALFSAMPLE_AUTO)
+    for l in range(3):
+        assert np.array_equal(store.level(1, l), ref[l])
