@@ -402,6 +402,66 @@ def test_update_seeds(gpu_device, orc, scene, pyrs, align_1d, subpix):
     assert hist.get(pytrack.SEED_ERASED_OLD, 0) > 5 and hist.get(pytrack.SEED_BEHIND if orc.which == "orc" else 0, 0) > 2
 
 
+def test_large_batches_take_the_same_decisions(gpu_device, scene, orc):
+    """Batches of >= 65 536 trials run the alignment in phases inside svo_hip_find_match_direct / svo_hip_update_seeds,
+    and the epipolar scan orders the seeds of a workgroup by length: the same trials, tiled and shuffled into a large
+    batch, must come back with the results of the small batch (which the tests above pin to the reference)."""
+    T = scene.T_f_w.copy()
+    T[scene.cur] = scene.T_cur_prior
+    store, frames = scene_store(scene, T_override=T)
+    rng = np.random.default_rng(31)
+    # -- findMatchDirect
+    P = len(scene.obs)
+    obs_ptr, fs = obs_csr(scene.obs)
+    m = tracking.Matcher(align_max_iter=10, n_pyr_levels=5)
+    cur = lambda n: torch.full((n,), scene.cur, dtype=torch.int32, device="cuda:0")
+    small = m.find_match_direct(store, scene.cam, frames, cur(P), dev(scene.pt_pos, torch.float64), obs_ptr, fs,
+                                dev(scene.px_init, torch.float64))
+    rep = 65536 // P + 2
+    order = rng.permutation(P * rep) % P                       # trial k of the large batch is trial order[k] of the small one
+    ptr_s = obs_ptr.cpu().numpy()
+    cnt = (ptr_s[1:] - ptr_s[:-1])[order]
+    ptr_l = np.zeros(len(order) + 1, dtype=np.int32)
+    ptr_l[1:] = np.cumsum(cnt)
+    gather = np.concatenate([np.arange(ptr_s[i], ptr_s[i + 1]) for i in order])
+    gi = torch.as_tensor(gather, device="cuda:0")
+    fs_l = tracking.FeatureSet(frame=fs.frame[gi].contiguous(), level=fs.level[gi].contiguous(), px=fs.px[gi].contiguous(),
+                               f=fs.f[gi].contiguous(), type=fs.type[gi].contiguous(), grad=fs.grad[gi].contiguous())
+    big = tracking.Matcher(align_max_iter=10, n_pyr_levels=5).find_match_direct(
+        store, scene.cam, frames, cur(len(order)), dev(scene.pt_pos[order], torch.float64), dev(ptr_l, torch.int32), fs_l,
+        dev(scene.px_init[order], torch.float64))
+    torch.cuda.synchronize()
+    oi = torch.as_tensor(order, device="cuda:0")
+    assert torch.equal(big.ok, small.ok[oi]) and torch.equal(big.search_level, small.search_level[oi])
+    assert np.array_equal(big.px_cur.cpu().numpy().view(np.uint64), small.px_cur[oi].cpu().numpy().view(np.uint64))
+    assert torch.equal(big.patch_with_border, small.patch_with_border[oi])
+    # -- updateSeeds
+    seeds, feats = _make_seeds(scene, orc, rng)
+    S = len(seeds)
+    col = lambda f_, dt: dev([f_(x) for x in seeds], dt)
+
+    def run(idx):
+        n = len(idx)
+        ii = torch.as_tensor(idx, device="cuda:0")
+        fsd = tracking.FeatureSet(frame=dev([o[0] for o in feats], torch.int32)[ii].contiguous(), level=dev([o[3] for o in feats], torch.int32)[ii].contiguous(),
+                                  px=dev([o[1] for o in feats], torch.float64)[ii].contiguous(), f=dev([o[2] for o in feats], torch.float64)[ii].contiguous(),
+                                  type=dev([o[4] for o in feats], torch.uint8)[ii].contiguous(), grad=dev([o[5] for o in feats], torch.float64)[ii].contiguous())
+        ss = tracking.SeedSet(a=col(lambda s: s.a, torch.float32)[ii].contiguous(), b=col(lambda s: s.b, torch.float32)[ii].contiguous(),
+                              mu=col(lambda s: s.mu, torch.float32)[ii].contiguous(), z_range=col(lambda s: s.z_range, torch.float32)[ii].contiguous(),
+                              sigma2=col(lambda s: s.sigma2, torch.float32)[ii].contiguous(), batch_id=col(lambda s: s.batch_id, torch.int32)[ii].contiguous())
+        st, xyz, px = tracking.DepthFilter(n_pyr_levels=5).update_seeds(store, scene.cam, frames, cur(n), fsd, ss, batch_counter=5)
+        torch.cuda.synchronize()
+        return st, px, ss
+    st_s, px_s, ss_s = run(np.arange(S))
+    order = rng.permutation(S * (65536 // S + 2)) % S
+    st_l, px_l, ss_l = run(order)
+    oi = torch.as_tensor(order, device="cuda:0")
+    assert torch.equal(st_l, st_s[oi])
+    assert np.array_equal(px_l.cpu().numpy().view(np.uint64), px_s[oi].cpu().numpy().view(np.uint64))
+    for k in ("a", "b", "mu", "sigma2"):
+        assert np.array_equal(getattr(ss_l, k).cpu().numpy().view(np.uint32), getattr(ss_s, k)[oi].cpu().numpy().view(np.uint32)), k
+
+
 def test_update_seed_batch(gpu_device, orc):
     rng = np.random.default_rng(6)
     S = 4000
