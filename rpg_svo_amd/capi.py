@@ -169,6 +169,11 @@ def load() -> C.CDLL:
         raise SvoHipError(
             f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # The Python mirror hands torch's streams and device pointers to the library, so both must live on ONE HIP runtime.
+    # torch ships its own libamdhip64: imported first, the loader resolves libsvo_hip.so's dependency to that copy; in
+    # the other order /opt/rocm's runtime is loaded first and a later `import torch` ends up without a device
+    # (hipErrorNoDevice on the first launch; seen with build() and smoke() in one process).
+    import torch  # noqa: F401
     lib = C.CDLL(_LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
