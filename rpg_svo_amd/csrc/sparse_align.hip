@@ -172,6 +172,31 @@ __device__ __forceinline__ void sia_rebuild_hinv(int lane, int nw) {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// SIA_TOUCH_NEXT (on by default for the window-cache instantiation): fetch-ahead of the NEXT level's windows.
+// Every level starts with two dependent round trips to memory -- the reference window, then (after the projection)
+// the current window of iteration 0 -- and with the same arithmetic on cache-resident pyramids the kernel runs 16-20 %
+// faster (scripts/k1_cache_bound.py): that is the exposed latency.  Registers to land the next level's windows early
+// do not exist (128 VGPRs), but their cache lines can be pulled towards the CU: at the end of iteration 0 of level l
+// a lane touches the two diagonal corner tiles of its level l-1 reference window (a function of Feature::px) and of its
+// level l-1 current window (the patch sits near twice this level's position) with global_load_lds_dword into a dummy
+// LDS row nobody reads.  The touches are opaque inline assembly on purpose: the compiler tracks nothing for them,
+// so no barrier or LDS read waits for their round trip (vmcnt stays in order, so an ordinary load issued later waits
+// a little longer than it has to -- there is none until the next level).
+#if !defined(SIA_NO_TOUCH_NEXT) && !defined(SIA_F64_PARTIALS)
+#define SIA_TOUCH_NEXT 1
+#else
+#define SIA_TOUCH_NEXT 0
+#endif
+__device__ __forceinline__ void sia_touch(const uint8_t* base, uint32_t off, uint32_t lds_off) {
+  // base and lds_off are wave-uniform; v_readfirstlane tells the compiler so (SGPR operands)
+  const uint64_t b = reinterpret_cast<uint64_t>(base);
+  const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+  const uint64_t sb = ((uint64_t)bhi << 32) | blo;
+  const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_off);
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(sb), "s"(sl) : "m0", "memory");
+}
+
 // DIST: the camera is a distorted model (radial-tangential pinhole or ATAN); the undistorted pinhole
 // keeps its own instantiation so that its inner loop carries no model dispatch.
 template <int BLOCK, bool WC, bool DIST>
@@ -192,6 +217,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
   //   q0 = r0 c1..4 | q1 = r1 c0..3 | q2 = r1 c4,5 r2 c0,1 | q3 = r2 c2..5
   //   q4 = r3 c0..3 | q5 = r3 c4,5 r4 c0,1 | q6 = r4 c2..5 | q7 = r5 c1..4
   __shared__ float4 s_bt[8][BLOCK];
+  __shared__ uint32_t s_touch[(SIA_TOUCH_NEXT && WC) ? BLOCK : 1];  // landing row of the fetch-ahead touches (never read)
 
   int n = a.n[b];
   n = n > a.n_stride ? a.n_stride : n;  // contract: n <= n_stride (svo_hip.h); never read the next problem's rows
@@ -393,6 +419,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       bool m = false;
       sia_acc gx = 0, gy = 0;
       float c2 = 0.f;
+      [[maybe_unused]] int tu = 0, tv = 0;  // integer position of the current window (fetch-ahead below)
       if (vis) {
         const double xc = R[0] * X + R[1] * Y + R[2] * Z + tr[0];
         const double yc = R[3] * X + R[4] * Y + R[5] * Z + tr[1];
@@ -430,6 +457,8 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
         if (fu - 3.f >= 0.f && fv - 3.f >= 0.f && fu + 3.f < (float)cols && fv + 3.f < (float)rows) {
           m = true;
           const int u_i = (int)fu, v_i = (int)fv;
+          tu = u_i;
+          tv = v_i;
           const float su = u_cur - fu, sv = v_cur - fv;
           const float wtl = (1.f - su) * (1.f - sv);  // == the reference's rounded double products (:200-203), see above
           const float wtr = su * (1.f - sv);
@@ -528,6 +557,32 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
         if (lane == 0) g_s.chg[buf][wave] = mine;
         SIA_ACC(1, tp1, SIA_T());
       }
+#if SIA_TOUCH_NEXT
+      if (WC && iter == 0 && level > P.min_level) {
+        const int nl = level - 1;
+        const int ncols = g_s.lw[nl], nrows = g_s.lh[nl], npitch = g_s.lp[nl];
+        const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&s_touch[tid & ~63];
+        // reference window of level l-1: rows v-3..v+3, columns of the 12-byte run around u-3..u+3
+        if (has) {
+          const float nscale = 1.0f / (float)(1 << nl);
+          const int ru = (int)floorf((float)(a.px[2 * fo] * (double)nscale)), rv = (int)floorf((float)(a.px[2 * fo + 1] * (double)nscale));
+          if (ru - 3 >= 0 && rv - 3 >= 0 && ru + 3 < ncols && rv + 3 < nrows) {
+            const uint8_t* nref = ref_base + g_s.lo[nl];
+            sia_touch(nref, svo_pyr::px_off((ru - 3) & ~3, rv - 3, npitch), lds);
+            sia_touch(nref, svo_pyr::px_off((ru + 3) & ~3, rv + 3, npitch), lds);
+          }
+        }
+        // current window of level l-1: the patch sits near (2 tu, 2 tv)
+        if (m) {
+          const int cu = 2 * tu + 1, cv = 2 * tv + 1;
+          if (cu - 4 >= 0 && cv - 4 >= 0 && cu + 4 < ncols && cv + 4 < nrows) {
+            const uint8_t* ncur = cur_base + g_s.lo[nl];
+            sia_touch(ncur, svo_pyr::px_off((cu - 4) & ~3, cv - 4, npitch), lds);
+            sia_touch(ncur, svo_pyr::px_off((cu + 4) & ~3, cv + 4, npitch), lds);
+          }
+        }
+      }
+#endif
       // the one workgroup barrier of an iteration
       [[maybe_unused]] const long long tb0 = SIA_T();
       __syncthreads();
