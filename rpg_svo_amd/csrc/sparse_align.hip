@@ -172,19 +172,20 @@ __device__ __forceinline__ void sia_rebuild_hinv(int lane, int nw) {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-// SIA_TOUCH_NEXT (on by default for the window-cache instantiation): fetch-ahead of the NEXT level's windows.
-// Every level starts with two dependent round trips to memory -- the reference window, then (after the projection)
-// the current window of iteration 0 -- and with the same arithmetic on cache-resident pyramids the kernel runs 16-20 %
-// faster (scripts/k1_cache_bound.py): that is the exposed latency.  Registers to land the next level's windows early
-// do not exist (128 VGPRs), but their cache lines can be pulled towards the CU: at the end of iteration 0 of level l
-// a lane touches the two diagonal corner tiles of its level l-1 reference window (a function of Feature::px) and of its
-// level l-1 current window (the patch sits near twice this level's position) with global_load_lds_dword into a dummy
-// LDS row nobody reads.  The touches are opaque inline assembly on purpose: the compiler tracks nothing for them,
-// so no barrier or LDS read waits for their round trip (vmcnt stays in order, so an ordinary load issued later waits
-// a little longer than it has to -- there is none until the next level).
-#if !defined(SIA_NO_TOUCH_NEXT) && !defined(SIA_F64_PARTIALS)
+// SIA_TOUCH_NEXT (off; an experiment that measured WORSE: 1.30 against 1.21 ms): fetch-ahead of the next level's
+// windows.  Every level starts with two dependent round trips to memory -- the reference window, then (after the
+// projection) the current window of iteration 0 -- and with the same arithmetic on cache-resident pyramids the kernel
+// runs 16-20 % faster (scripts/k1_cache_bound.py): that is the exposed latency.  Registers to land the next level's
+// windows early do not exist (128 VGPRs), so the idea was to pull their cache lines towards the CU instead: at the
+// end of iteration 0 of level l a lane touches the two diagonal corner tiles of its level l-1 reference window and of
+// its level l-1 current window (near twice this level's position) with global_load_lds_dword into a dummy LDS row
+// nobody reads, as opaque inline assembly so that no barrier or LDS read waits for the round trip.  The four extra
+// gathers per patch and level cost more L1 look-ups and in-order vmcnt waiting than the warmer lines give back.
+#if defined(SIA_TOUCH_NEXT) && !defined(SIA_F64_PARTIALS)
+#undef SIA_TOUCH_NEXT
 #define SIA_TOUCH_NEXT 1
 #else
+#undef SIA_TOUCH_NEXT
 #define SIA_TOUCH_NEXT 0
 #endif
 __device__ __forceinline__ void sia_touch(const uint8_t* base, uint32_t off, uint32_t lds_off) {
