@@ -345,6 +345,34 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const Al
   // which trial: lane order in the first launch of a run, the queues filled by the previous launch afterwards
   // (workgroup b drains queue b % ALIGN_NQ, 64 entries at a time)
   int t;
+  // In list order the 64 templates of a workgroup are 6400 contiguous bytes.  Read per lane they are 25 dword gathers
+  // with a 100-byte lane stride -- 25 cache-line look-ups per lane, more than the window fetches of the one or two
+  // iterations most trials need; read as the block they are (seven coalesced 16-byte loads per lane, ~1 look-up per
+  // lane) and handed out through LDS (a lane's 25 words sit 25 banks from its neighbour's: conflict-free) they cost a
+  // twentieth of that.  (Trials drained from a queue are scattered: per-lane gathers.)
+#ifndef ALIGN_NO_TEMPLATE_LDS
+  __shared__ __attribute__((aligned(16))) uint32_t s_tpl[ALIGN_BLOCK * 25];
+  bool tpl_in_lds = false;
+  if (!a.queue_in) {
+    const long long first_t = (long long)blockIdx.x * ALIGN_BLOCK;  // wave-uniform: one wave per workgroup
+    const long long left = (long long)a.M - first_t;
+    const int n_dw = 25 * (int)(left < ALIGN_BLOCK ? left : ALIGN_BLOCK);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.pwb + (size_t)first_t * 100);
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+      tpl_in_lds = true;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int q = 4 * ((int)threadIdx.x + ALIGN_BLOCK * k);  // first dword of this lane's quad
+        if (q + 3 < n_dw) *reinterpret_cast<uint4*>(&s_tpl[q]) = *reinterpret_cast<const uint4*>(src + q);
+        else
+          for (int j = q; j < n_dw && j < q + 4; ++j) s_tpl[j] = src[j];
+      }
+      // one wave: DS operations execute in order; keep the compiler from moving the reads below above the writes
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#endif
   if (a.queue_in) {
     const int q = blockIdx.x % ALIGN_NQ, i = (blockIdx.x / ALIGN_NQ) * ALIGN_BLOCK + threadIdx.x;
     if (i >= a.n_in[q]) return;
@@ -364,7 +392,11 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const Al
   const int cols = a.L.w[level], rows = a.L.h[level], pitch = a.L.pitch[level];
   uint32_t g[25];
   {
+#ifndef ALIGN_NO_TEMPLATE_LDS
+    const uint32_t* gp = tpl_in_lds ? &s_tpl[threadIdx.x * 25] : reinterpret_cast<const uint32_t*>(a.pwb + (size_t)t * 100);
+#else
     const uint32_t* gp = reinterpret_cast<const uint32_t*>(a.pwb + (size_t)t * 100);
+#endif
 #pragma unroll
     for (int k = 0; k < 25; ++k) g[k] = gp[k];
   }
