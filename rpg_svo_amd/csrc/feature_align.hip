@@ -345,12 +345,12 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const Al
   // which trial: lane order in the first launch of a run, the queues filled by the previous launch afterwards
   // (workgroup b drains queue b % ALIGN_NQ, 64 entries at a time)
   int t;
-  // In list order the 64 templates of a workgroup are 6400 contiguous bytes.  Read per lane they are 25 dword gathers
-  // with a 100-byte lane stride -- 25 cache-line look-ups per lane, more than the window fetches of the one or two
-  // iterations most trials need; read as the block they are (seven coalesced 16-byte loads per lane, ~1 look-up per
-  // lane) and handed out through LDS (a lane's 25 words sit 25 banks from its neighbour's: conflict-free) they cost a
-  // twentieth of that.  (Trials drained from a queue are scattered: per-lane gathers.)
-#ifndef ALIGN_NO_TEMPLATE_LDS
+  // ALIGN_TEMPLATE_LDS (off: measured SLOWER twice, rounds 2 and 3 -- 12.25 against 11.90 ms for the full-track step).
+  // In list order the 64 templates of a workgroup are 6400 contiguous bytes; read per lane they are 25 dword gathers
+  // with a 100-byte lane stride, read as the block they are (seven coalesced 16-byte loads per lane) and handed out
+  // through LDS they are far fewer cache-line look-ups -- but the hand-over makes every lane wait for the whole block
+  // before its set-up arithmetic can start, and the gathers of neighbouring words hit the same line in L1 anyway.
+#ifdef ALIGN_TEMPLATE_LDS
   __shared__ __attribute__((aligned(16))) uint32_t s_tpl[ALIGN_BLOCK * 25];
   bool tpl_in_lds = false;
   if (!a.queue_in) {
@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const Al
   const int cols = a.L.w[level], rows = a.L.h[level], pitch = a.L.pitch[level];
   uint32_t g[25];
   {
-#ifndef ALIGN_NO_TEMPLATE_LDS
+#ifdef ALIGN_TEMPLATE_LDS
     const uint32_t* gp = tpl_in_lds ? &s_tpl[threadIdx.x * 25] : reinterpret_cast<const uint32_t*>(a.pwb + (size_t)t * 100);
 #else
     const uint32_t* gp = reinterpret_cast<const uint32_t*>(a.pwb + (size_t)t * 100);
