@@ -1058,8 +1058,13 @@ def dropin_sequence(n_frames: int = 120) -> dict:
     try:
         ref = pp.run_sequence("ref", cam, imgs, T)
         pp.run_sequence("hip", cam, imgs[:10], T[:10])  # warm-up: context creation, first launches
-        host = {}
+        host, host_ref, host_def = {}, {}, {}
         hip = pp.run_sequence("hip", cam, imgs, T, stats_out=host)
+        # the mapper off the frame's critical path, both ways: the reference's mapping thread (its default; timing
+        # dependent, so no frame-by-frame parity) and the drop-in's deferred mapping (opt-in, deterministic)
+        hip_def = pp.run_sequence("hip", cam, imgs, T, stats_out=host_def, defer_mapper=1)
+        ref_thr = pp.run_sequence("ref", cam, imgs, T, stats_out=host_ref, mapper_thread=1)
+        hip_thr = pp.run_sequence("hip", cam, imgs, T, mapper_thread=1)
     finally:
         os.dup2(saved, 2)
         os.close(devnull)
@@ -1074,6 +1079,15 @@ def dropin_sequence(n_frames: int = 120) -> dict:
             "same_keyframe_frames": [r["is_keyframe"] for r in ref] == [r["is_keyframe"] for r in hip],
             "median_ms_per_frame_cpu_reference": {k: med(ref, "t_" + k) for k in stages},
             "median_ms_per_frame_hip_dropin": {k: med(hip, "t_" + k) for k in stages},
+            # opt-in (svo_hip::Device::setDeferredMapping): updateSeeds returns with its kernels running, results
+            # reach the seed list / the map at the next reprojectMap -- same trajectory, bit for bit
+            "median_ms_per_frame_hip_dropin_deferred_mapper": {k: med(hip_def, "t_" + k) for k in stages},
+            "deferred_mapper_trajectory_identical": bool(np.array_equal(np.stack([r["T_f_w"] for r in hip_def]), Th)),
+            "frame_period_ms_back_to_back": {"hip_dropin": host.get("wall_ms_per_frame"),
+                                             "hip_dropin_deferred_mapper": host_def.get("wall_ms_per_frame")},
+            # DepthFilter's own thread running (the reference's default mode): tot_time then excludes the mapper
+            "median_ms_per_frame_mapper_thread": {"cpu_reference": med(ref_thr, "t_tot_time"), "hip_dropin": med(hip_thr, "t_tot_time")},
+            "predicted_pose_refinements": {"taken": host.get("predicted_pose_hits"), "not_taken": host.get("predicted_pose_misses")},
             # N2 evidence: per drop-in call, the host walking the reference's pointer graph into the pinned
             # arena and back (marshal/unmarshal) against the device round trip (H2D + kernels + D2H + sync)
             "host_vs_device_us_per_call": {k: {q: round(v, 2) if isinstance(v, float) else v for q, v in st.items()}

@@ -75,6 +75,9 @@ int svo_hip_event_create(void** event_out);
 int svo_hip_event_destroy(void* event);
 int svo_hip_event_record(void* event, void* stream);
 int svo_hip_event_elapsed_ms(void* start, void* stop, float* ms_out); /* syncs on stop */
+int svo_hip_event_sync(void* event);                      /* host waits for the work recorded before `event` */
+int svo_hip_event_query(void* event);                     /* 1: that work is done, 0: still running, <0: error */
+int svo_hip_stream_wait_event(void* stream, void* event); /* later work of `stream` waits for it on the device */
 
 /* HIP graphs: every entry point below only enqueues kernels / memsets on `stream`, so a fixed
  * chain of calls (same pointers, same sizes: e.g. one tracked frame of every camera of a rig) can
@@ -348,6 +351,26 @@ int svo_hip_find_match_direct(const svo_hip_pyr_layout* layout, const uint8_t* d
 int svo_hip_reproject_points(const svo_hip_camera* cam, const svo_hip_frames* frames, int M,
                              const int32_t* d_cur_frame, const double* d_pt_pos, int cell_size,
                              int grid_n_cols, int32_t* d_cell, double* d_px, void* stream);
+
+/* The cell loop of Reprojector::reprojectMap (svo/src/reprojector.cpp:131-139) with reprojectCell's "first success
+ * of the cell" (:150-200), applied on the device to the results of a batch of findMatchDirect trials, so that pose
+ * refinement can be enqueued behind the match kernels without the host in between.
+ *   The M trials are given in the order the reference visits them: cells in grid_.cell_order, the candidates of a
+ *   cell in the order of its sorted list; d_cell[m] identifies the cell (trials of one cell are adjacent), d_ok /
+ *   d_px / d_level are the outputs of svo_hip_find_match_direct, d_pos the points' positions.
+ *   A trial is selected when it matched and no earlier trial of its cell did; selection ends after max_fts + 1
+ *   selected trials (:137-138).  Selected trial number i (its position in Frame::fts_) yields the observation
+ *   pose_optimizer::optimizeGaussNewton reads from the new Feature (reprojector.cpp:182-187, feature.h:44-52):
+ *     d_sel[i] = trial index, d_f[i] = cam2world(px), d_level_out[i], d_pos_out[i], d_has_point[i] = 1;
+ *   d_n[0] = number selected.  Output arrays hold min(M, max_fts + 1) entries.
+ *   d_signal (may be NULL): *d_signal = signal_value is stored (release, system scope) as the kernel starts, i.e. once
+ *   everything enqueued on the stream before this call -- the match kernels -- has completed.  With d_signal and the
+ *   match outputs in host-mapped pinned memory a host thread can poll it instead of synchronising the stream, and
+ *   read the match results while this call and the pose refinement behind it are still running. */
+int svo_hip_select_matches(const svo_hip_camera* cam, int M, const int32_t* d_cell, const int32_t* d_ok,
+                           const double* d_px, const int32_t* d_level, const double* d_pos, int max_fts,
+                           int32_t* d_n, int32_t* d_sel, double* d_f, int32_t* d_level_out, double* d_pos_out,
+                           uint8_t* d_has_point, int32_t* d_signal, int32_t signal_value, void* stream);
 
 /* Frame glue that the reference does inline on the host, kept on the device so a tracked
  * frame never leaves HBM between kernels:

@@ -136,6 +136,8 @@ class Track:
         self._compute_tau.restype = C.c_double
         self._update_seeds = g("update_seeds")
         self._reproject_point = g("reproject_point")
+        self._cam2world = g("cam2world")
+        self._cam2world.restype = None
         self._sia_run = g("sparse_img_align_run")
         if which == "ref":
             self._create_pyr = self.lib.ref_create_img_pyramid
@@ -274,12 +276,41 @@ class Track:
                                 C.byref(opt))
         return int(nu), list(arr), list(info)
 
+    def cam2world(self, cam, px):
+        """Unit bearings [n,3] of pixels px [n,2] (Frame::c2f)."""
+        pc = make_cam(cam)
+        px = _f64(px).reshape(-1, 2)
+        f = np.zeros((px.shape[0], 3))
+        self._cam2world(C.byref(pc), C.c_int(px.shape[0]), _p(px), _p(f))
+        return f
+
     def reproject_point(self, cam, T_f_w, pos, cell_size, grid_n_cols):
         pc = make_cam(cam)
         px = np.zeros(2)
         k = self._reproject_point(C.byref(pc), _p(_f64(T_f_w)), _p(_f64(pos)), C.c_int(cell_size),
                                   C.c_int(grid_n_cols), _p(px))
         return int(k), px
+
+
+def select_matches(cam, cell, ok, px, level, pos, max_fts):
+    """Reprojector::reprojectMap's cell loop + reprojectCell (reprojector.cpp:131-139, 150-200) over trials with a
+    known outcome (restatement only: the reference's own version is private and entangled with the map).
+    Returns (sel, f, level_out, pos_out) of the new features in Frame::fts_ order."""
+    lib = pyoracle.lib()
+    pc = make_cam(cam)
+    cell = np.ascontiguousarray(cell, dtype=np.int32)
+    ok = np.ascontiguousarray(ok, dtype=np.int32)
+    level = np.ascontiguousarray(level, dtype=np.int32)
+    px, pos = _f64(px).reshape(-1, 2), _f64(pos).reshape(-1, 3)
+    M = cell.shape[0]
+    cap = max(1, min(M, max_fts + 1))
+    sel = np.zeros(cap, dtype=np.int32)
+    f, pos_out = np.zeros((cap, 3)), np.zeros((cap, 3))
+    level_out = np.zeros(cap, dtype=np.int32)
+    i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    n = lib.orc_select_matches(C.byref(pc), C.c_int(M), i32(cell), i32(ok), _p(px), i32(level), _p(pos), C.c_int(max_fts),
+                               i32(sel), _p(f), i32(level_out), _p(pos_out))
+    return sel[:n], f[:n], level_out[:n], pos_out[:n]
 
 
 def fast_detect_grid(pyr_levels, n_levels, cell_size, cols, rows, occupancy=None, fast_threshold=20,

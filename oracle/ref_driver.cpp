@@ -603,6 +603,16 @@ int ref_fast_detect(const orc_pyramid* pyr, const orc_pinhole* cam, int n_levels
   return n;
 }
 
+// Frame::c2f of n pixels through the reference's camera object: what the Feature constructor stores in Feature::f
+void ref_cam2world(const orc_pinhole* cam, int n, const double* px, double* f) {
+  vk::AbstractCamera* c = make_cam(cam);
+  for (int i = 0; i < n; ++i) {
+    const Vector3d v(c->cam2world(px[2 * i], px[2 * i + 1]));
+    f[3 * i] = v[0]; f[3 * i + 1] = v[1]; f[3 * i + 2] = v[2];
+  }
+  delete c;
+}
+
 int ref_reproject_point(const orc_pinhole* cam, const double T_f_w[12], const double pos[3], int cell_size,
                         int grid_n_cols, double px_out[2]) {
   // Reprojector::reprojectPoint is private; its three statements are frame->w2c(),

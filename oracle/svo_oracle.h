@@ -268,6 +268,15 @@ int orc_update_seeds(const orc_frame* frames, const orc_pinhole* cam, int cur_fr
 int orc_reproject_point(const orc_pinhole* cam, const double T_f_w[12], const double pos[3],
                         int cell_size, int grid_n_cols, double px_out[2]);
 
+/* reprojectMap's cell loop (:131-139) + reprojectCell (:150-200) over trials with known outcome, in visiting
+ * order (trials of one cell adjacent): per cell the first success, stop once more than max_fts cells matched.
+ * sel / f / level_out / pos_out [min(M, max_fts+1)]: the new features in Frame::fts_ order.  Returns their number. */
+int orc_select_matches(const orc_pinhole* cam, int M, const int32_t* cell, const int32_t* ok, const double* px,
+                       const int32_t* level, const double* pos, int max_fts, int32_t* sel, double* f,
+                       int32_t* level_out, double* pos_out);
+/* cam2world of n pixels */
+void orc_cam2world(const orc_pinhole* cam, int n, const double* px, double* f);
+
 /* ---- FastDetector (svo/src/feature_detection.cpp:66-114) -------------------- */
 /* Per grid cell the best corner over levels 0..n_levels-1: FAST-10 (threshold fast_threshold),
  * FAST score, 3x3 non-max (orc_fast.h), vk::shiTomasiScore; occupied cells skipped.

@@ -889,6 +889,39 @@ int orc_reproject_point(const orc_pinhole* cam, const double T_f_w[12], const do
   return -1;
 }
 
+/* ======================================================================== */
+/* The cell loop of Reprojector::reprojectMap (svo/src/reprojector.cpp:131-139) with                 */
+/* reprojectCell (:150-200), given the outcome of every findMatchDirect trial.  Trials in visiting   */
+/* order, those of one cell adjacent.  Emits what the new Feature holds for the pose optimizer:      */
+/* f = cam2world(px) (feature.h:44-52), level, point position.  Returns the number of new features.  */
+/* ======================================================================== */
+int orc_select_matches(const orc_pinhole* cam, int M, const int32_t* cell, const int32_t* ok, const double* px,
+                       const int32_t* level, const double* pos, int max_fts, int32_t* sel, double* f, int32_t* level_out,
+                       double* pos_out) {
+  int n_matches = 0, n = 0, m = 0;
+  while (m < M) {
+    const int c = cell[m];
+    int matched = 0;
+    for (; m < M && cell[m] == c; ++m) {  /* reprojectCell: walks the list until the first success (:153-199) */
+      if (matched || !ok[m]) continue;
+      sel[n] = m;
+      cam2world(cam, px[2 * m], px[2 * m + 1], f + 3 * n);
+      level_out[n] = level[m];
+      for (int k = 0; k < 3; ++k) pos_out[3 * n + k] = pos[3 * m + k];
+      ++n;
+      matched = 1;
+    }
+    if (matched) ++n_matches;          /* :135-136 */
+    if (n_matches > max_fts) break;    /* :137-138 */
+  }
+  return n;
+}
+
+/* vk::AbstractCamera::cam2world(px): the unit bearing (vikit pinhole_camera.cpp / atan_camera.cpp) */
+void orc_cam2world(const orc_pinhole* cam, int n, const double* px, double* f) {
+  for (int i = 0; i < n; ++i) cam2world(cam, px[2 * i], px[2 * i + 1], f + 3 * i);
+}
+
 /* ---- FastDetector::detect (svo/src/feature_detection.cpp:66-114) ----------------------- */
 #include "orc_fast.h"
 int orc_fast_detect_grid(const orc_pyramid* pyr, int n_levels, int fast_threshold, int cell_size, int grid_n_cols,

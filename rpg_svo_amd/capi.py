@@ -102,6 +102,9 @@ PROTOTYPES = {
     "svo_hip_event_destroy": (_i, [_vp]),
     "svo_hip_event_record": (_i, [_vp, _vp]),
     "svo_hip_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
+    "svo_hip_event_sync": (_i, [_vp]),
+    "svo_hip_event_query": (_i, [_vp]),
+    "svo_hip_stream_wait_event": (_i, [_vp, _vp]),
     "svo_hip_graph_begin_capture": (_i, [_vp]),
     "svo_hip_graph_end_capture": (_i, [_vp, C.POINTER(_vp)]),
     "svo_hip_graph_launch": (_i, [_vp, _vp]),
@@ -136,6 +139,7 @@ PROTOTYPES = {
     "svo_hip_reproject_points": (_i, [C.POINTER(Camera), C.POINTER(Frames), _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "svo_hip_compose_poses": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "svo_hip_cam2world": (_i, [C.POINTER(Camera), _i, _vp, _vp, _vp]),
+    "svo_hip_select_matches": (_i, [C.POINTER(Camera), _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "svo_hip_pose_optimize": (_i, [C.POINTER(Camera), _i, _vp, _i, _vp, _vp, _vp, _vp, C.c_double, _i, _vp, _vp, _vp,
                                    _vp, _vp]),
     "svo_hip_pose_optimize_ordered": (_i, [C.POINTER(Camera), _i, _vp, _i, _vp, _vp, _vp, _vp, C.c_double, _i, _vp, _vp,

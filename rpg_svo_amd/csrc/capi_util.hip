@@ -88,7 +88,8 @@ int svo_hip_memcpy_d2h(void* dst, const void* d_src, size_t bytes, void* stream)
 }
 
 int svo_hip_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream) {
-  SVO_HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  // (hipMemcpyDefault: either side may also be device-mapped pinned host memory, e.g. an output block of a hybrid arena)
+  SVO_HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDefault, static_cast<hipStream_t>(stream)));
   return SVO_HIP_OK;
 }
 
@@ -130,6 +131,27 @@ int svo_hip_event_destroy(void* event) {
 
 int svo_hip_event_record(void* event, void* stream) {
   SVO_HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_event_sync(void* event) {
+  SVO_HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+  return SVO_HIP_OK;
+}
+
+int svo_hip_event_query(void* event) {
+  const hipError_t e = hipEventQuery(static_cast<hipEvent_t>(event));
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();  // not an error: the work before the event is still running
+    return 0;
+  }
+  SVO_HIP_TRY(e);
+  return SVO_HIP_OK;
+}
+
+int svo_hip_stream_wait_event(void* stream, void* event) {
+  SVO_HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(event), 0));
   return SVO_HIP_OK;
 }
 

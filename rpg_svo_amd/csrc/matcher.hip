@@ -417,6 +417,69 @@ __global__ void __launch_bounds__(256) cam2world_kernel(const GlueArgs a) {
   a.f[3 * i + 2] = f[2];
 }
 
+// ---- the selection rule of Reprojector::reprojectMap's cell loop over a batch of trials ----------------------------
+// reprojector.cpp:131-139 visits the cells in grid_.cell_order and takes, per cell, the first candidate of the sorted
+// list whose findMatchDirect succeeds (reprojectCell, :150-200); it stops once more than maxFts cells have matched.  The
+// trials arrive in that visiting order (those of one cell next to each other), so "first success of its cell" is a look
+// back over the cell's run and the position in Frame::fts_ is the number of selected trials before it.  A selected
+// trial becomes the observation the pose optimizer reads: Feature(frame, px, level) with f = cam2world(px)
+// (feature.h:44-52), point->pos_.
+struct SelectArgs {
+  Cam cam;
+  int M;
+  const int32_t* cell;
+  const int32_t* ok;
+  const double* px;
+  const int32_t* level;
+  const double* pos;
+  int max_selected;
+  int32_t* n;
+  int32_t* sel;
+  double* f;
+  int32_t* level_out;
+  double* pos_out;
+  uint8_t* has_point;
+  int32_t* signal;  // or NULL
+  int32_t signal_value;
+};
+__global__ void __launch_bounds__(256) match_select_kernel(const SelectArgs a) {
+  __shared__ int s_wave[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // everything enqueued before this kernel has completed (stream order): tell a host that polls mapped memory
+  if (a.signal && tid == 0) __hip_atomic_store(a.signal, a.signal_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  int base = 0;  // selected trials before this pass (the same in every thread)
+  for (int m0 = 0; m0 < a.M && base < a.max_selected; m0 += 256) {
+    const int m = m0 + tid;
+    bool first = false;
+    if (m < a.M && a.ok[m] != 0) {
+      first = true;
+      const int c = a.cell[m];
+      for (int j = m - 1; j >= 0 && a.cell[j] == c; --j)
+        if (a.ok[j] != 0) { first = false; break; }
+    }
+    const unsigned long long b = __ballot(first);
+    if (lane == 0) s_wave[wave] = __popcll(b);
+    __syncthreads();
+    int rank = base + __popcll(b & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) rank += s_wave[w];
+    base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    if (first && rank < a.max_selected) {
+      double f[3];
+      cam2world(a.cam, a.px[2 * m], a.px[2 * m + 1], f);
+      a.sel[rank] = m;
+      a.level_out[rank] = a.level[m];
+      a.has_point[rank] = 1;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        a.f[3 * rank + k] = f[k];
+        a.pos_out[3 * rank + k] = a.pos[3 * m + k];
+      }
+    }
+  }
+  if (tid == 0) a.n[0] = base < a.max_selected ? base : a.max_selected;
+}
+
 }  // namespace
 
 namespace svo_track {
@@ -573,5 +636,33 @@ extern "C" int svo_hip_cam2world(const svo_hip_camera* cam, int n, const double*
   a.px = d_px;
   a.f = d_f;
   hipLaunchKernelGGL(cam2world_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch();
+}
+
+extern "C" int svo_hip_select_matches(const svo_hip_camera* cam, int M, const int32_t* d_cell, const int32_t* d_ok,
+                                      const double* d_px, const int32_t* d_level, const double* d_pos, int max_fts,
+                                      int32_t* d_n, int32_t* d_sel, double* d_f, int32_t* d_level_out, double* d_pos_out,
+                                      uint8_t* d_has_point, int32_t* d_signal, int32_t signal_value, void* stream) {
+  if (!cam || !cam_model_ok(cam) || M < 0 || max_fts < 0 || !d_n) return SVO_HIP_EINVAL;
+  if (M > 0 && (!d_cell || !d_ok || !d_px || !d_level || !d_pos || !d_sel || !d_f || !d_level_out || !d_pos_out || !d_has_point))
+    return SVO_HIP_EINVAL;
+  SelectArgs a{};
+  a.cam = make_cam(cam);
+  a.M = M;
+  a.cell = d_cell;
+  a.ok = d_ok;
+  a.px = d_px;
+  a.level = d_level;
+  a.pos = d_pos;
+  a.max_selected = max_fts + 1;  // "if (n_matches_ > maxFts) break" lets the (maxFts+1)-th match in (:137-138)
+  a.n = d_n;
+  a.sel = d_sel;
+  a.f = d_f;
+  a.level_out = d_level_out;
+  a.pos_out = d_pos_out;
+  a.has_point = d_has_point;
+  a.signal = d_signal;
+  a.signal_value = signal_value;
+  hipLaunchKernelGGL(match_select_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);  // M == 0: n = 0
   return check_launch();
 }

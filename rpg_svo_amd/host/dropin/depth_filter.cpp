@@ -9,10 +9,13 @@
 // mapping lane's stream.  The list surgery the reference interleaves with the arithmetic
 // (erase old / NaN seeds, create the Point of a converged seed and hand it to the callback,
 // mark the detector grid) is replayed on the host from the per-seed status, in list order.
+// With deferred mapping switched on (svo_hip::Device::deferredMapping(); only without the mapping thread) the call
+// returns after enqueueing and the replay runs at the next join point -- see svo_hip_device.h.
 #include <svo/depth_filter.h>
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
 
 #include <svo/config.h>
 #include <svo/feature.h>
@@ -27,6 +30,7 @@ namespace svo {
 
 // ---- the update, on the device ---------------------------------------------------------------
 void DepthFilter::updateSeeds(FramePtr frame) {
+  svo_hip::Device::joinDeferredAll();  // the previous frame's update writes into seeds_ first (takes seeds_mut_ itself)
   lock_t lock(seeds_mut_);
   if (seeds_updating_halt_) return;  // the halt flag is honoured between launches
   const size_t S = seeds_.size();
@@ -55,8 +59,10 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   // below and travels both ways (uploadAll / download)
   std::vector<float> st(4 * S);
   float *sa = &st[0], *sb = &st[S], *smu = &st[2 * S], *ss2 = &st[3 * S];
+  std::vector<int> ids(S);  // Seed::id, ascending along the list: how a later replay finds its seeds again
   size_t s = 0;
   for (std::list<Seed>::iterator it = seeds_.begin(); it != seeds_.end(); ++it, ++s) {
+    ids[s] = it->id;
     cur[s] = i_cur;
     batch[s] = it->batch_id;
     sa[s] = it->a; sb[s] = it->b; smu[s] = it->mu; szr[s] = it->z_range; ss2[s] = it->sigma2;
@@ -99,32 +105,56 @@ void DepthFilter::updateSeeds(FramePtr frame) {
                                       d_px, ws, lane.workspace_bytes, lane.stream),
                  "svo_hip_update_seeds");
   a.download(lane.stream);
-  svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
-  stage_timer.unmarshal();
 
   // ---- replay of the list surgery, in list order (:216-219, :238-245, :255-290) ---------------
+  // Seeds are found again by Seed::id (ascending along the list): in deferred mode the list may have lost seeds
+  // (removeKeyframe, reset) or gained some at its end (initializeSeeds) before the replay runs.
   const bool is_kf = frame->isKeyframe();
-  s = 0;
-  for (std::list<Seed>::iterator it = seeds_.begin(); it != seeds_.end(); ++s) {
-    const int st = status[s];
-    if (st == SVO_HIP_SEED_BEHIND || st == SVO_HIP_SEED_NOT_IN_FRAME) { ++it; continue; }
-    if (st == SVO_HIP_SEED_ERASED_OLD) { it = seeds_.erase(it); continue; }
-    it->a = sa[s]; it->b = sb[s]; it->mu = smu[s]; it->sigma2 = ss2[s];
-    if (st == SVO_HIP_SEED_NO_MATCH) { ++it; continue; }  // b was incremented on the device
-    if (is_kf)  // the detector must not start new seeds next to a matched one
-      feature_detector_->setGridOccpuancy(Vector2d(px_cur[2 * s], px_cur[2 * s + 1]));
-    if (st == SVO_HIP_SEED_CONVERGED) {
-      Point* point = new Point(Vector3d(xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2]), it->ftr);
-      it->ftr->point = point;
-      seed_converged_cb_(point, it->sigma2);  // into the map's candidate list
-      it = seeds_.erase(it);
-    } else if (st == SVO_HIP_SEED_NAN) {
-      SVO_WARN_STREAM("z_min is NaN");
-      it = seeds_.erase(it);
-    } else {
-      ++it;
+  void* const stream = lane.stream;
+  svo_hip::Device* const pdev = &dev;
+  const std::function<void()> replay = [this, frame, is_kf, S, ids, status, sa, sb, smu, ss2, xyz, px_cur]() {
+    size_t s = 0;
+    for (std::list<Seed>::iterator it = seeds_.begin(); it != seeds_.end() && s < S;) {
+      while (s < S && ids[s] < it->id) ++s;  // erased since the update was enqueued
+      if (s == S) break;
+      if (ids[s] != it->id) { ++it; continue; }
+      const int st = status[s];
+      const size_t k = s++;
+      if (st == SVO_HIP_SEED_BEHIND || st == SVO_HIP_SEED_NOT_IN_FRAME) { ++it; continue; }
+      if (st == SVO_HIP_SEED_ERASED_OLD) { it = seeds_.erase(it); continue; }
+      it->a = sa[k]; it->b = sb[k]; it->mu = smu[k]; it->sigma2 = ss2[k];
+      if (st == SVO_HIP_SEED_NO_MATCH) { ++it; continue; }  // b was incremented on the device
+      if (is_kf)  // the detector must not start new seeds next to a matched one
+        feature_detector_->setGridOccpuancy(Vector2d(px_cur[2 * k], px_cur[2 * k + 1]));
+      if (st == SVO_HIP_SEED_CONVERGED) {
+        Point* point = new Point(Vector3d(xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2]), it->ftr);
+        it->ftr->point = point;
+        seed_converged_cb_(point, it->sigma2);  // into the map's candidate list
+        it = seeds_.erase(it);
+      } else if (st == SVO_HIP_SEED_NAN) {
+        SVO_WARN_STREAM("z_min is NaN");
+        it = seeds_.erase(it);
+      } else {
+        ++it;
+      }
     }
+  };
+  if (thread_ == NULL && svo_hip::Device::deferredMapping()) {
+    // the caller is the tracking thread itself (addFrame without the mapping thread): leave the kernels running
+    stage_timer.unmarshal();  // this call's share is marshal + enqueue; the join adds its wait and the replay
+    lane.deferred = [this, replay, stream, pdev]() {
+      const double t0 = svo_hip::StageTimer::now();
+      svo_hip::check(svo_hip_stream_sync(stream), "svo_hip_stream_sync");
+      const double t1 = svo_hip::StageTimer::now();
+      lock_t relock(seeds_mut_);
+      replay();
+      pdev->addStage(svo_hip::Device::STAGE_DEPTH_FILTER, 0.0, t1 - t0, svo_hip::StageTimer::now() - t1, 0.0, false);
+    };
+    return;
   }
+  svo_hip::check(svo_hip_stream_sync(stream), "svo_hip_stream_sync");
+  stage_timer.unmarshal();
+  replay();  // seeds_mut_ is held
 }
 
 // ---- the two static helpers, also on the device (single measurement) --------------------------
@@ -134,6 +164,7 @@ void DepthFilter::updateSeed(const float x, const float tau2, Seed* seed) {
   const int L = svo_hip::Device::LANE_MAPPING;
   svo_hip::Lane& lane = dev.lane(L);
   std::lock_guard<std::mutex> guard(lane.mut);
+  dev.beginCall(lane);
   svo_hip::Arena& a = lane.arena;
   a.reset();
   float* d[7];
@@ -156,6 +187,7 @@ double DepthFilter::computeTau(const SE3& T_ref_cur, const Vector3d& f, const do
   const int L = svo_hip::Device::LANE_MAPPING;
   svo_hip::Lane& lane = dev.lane(L);
   std::lock_guard<std::mutex> guard(lane.mut);
+  dev.beginCall(lane);
   svo_hip::Arena& a = lane.arena;
   a.reset();
   double *d_t, *d_f, *d_z, *d_tau;

@@ -2,7 +2,11 @@
 // (svo/include/svo/pose_optimizer.h:37-45) on the MI355X through svo_hip_pose_optimize (K4).
 // Same signature, same side effects on the frame: T_f_w_, Cov_, and Feature::point reset to
 // NULL for observations pruned at reproj_thresh (pose_optimizer.cpp:129-145).
+// When Reprojector::reprojectMap's drop-in has already enqueued this very call behind its match kernels
+// (svo_hip::Speculation) and the frame is the one it predicted, the result is taken from there: one stream wait.
 #include <svo/pose_optimizer.h>
+
+#include <cstring>
 
 #include <svo/feature.h>
 #include <svo/frame.h>
@@ -13,6 +17,48 @@
 namespace svo {
 namespace pose_optimizer {
 
+namespace {
+// T_f_w_, Cov_ and the pruned observations back into the frame (pose_optimizer.cpp:119-145)
+void applyResult(FramePtr& frame, const double* T, const double* Cov, const double* stats, const uint8_t* has_out, bool verbose,
+                 double& estimated_scale, double& error_init, double& error_final, size_t& num_obs) {
+  frame->T_f_w_ = hip_dropin::poseFromRt(T);
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) frame->Cov_(r, c) = Cov[r * 6 + c];
+  size_t n_deleted_refs = 0;
+  size_t i = 0;
+  for (Features::iterator it = frame->fts_.begin(); it != frame->fts_.end(); ++it, ++i)
+    if ((*it)->point != NULL && !has_out[i]) {
+      (*it)->point = NULL;  // the point holds no reference to this feature yet (:139-141)
+      ++n_deleted_refs;
+    }
+  estimated_scale = stats[0];
+  error_init = stats[1];
+  error_final = stats[2];
+  num_obs = (size_t)stats[3];
+  if (verbose)
+    std::cout << "n deleted obs = " << n_deleted_refs << "\t scale = " << estimated_scale << "\t error init = " << error_init
+              << "\t error end = " << error_final << std::endl;
+}
+
+// Is `frame` what the reprojector predicted -- the same features in the same order, the same starting pose, the same
+// parameters?  Then its pose refinement is already running (or done) on the lane's stream.
+bool predicted(const svo_hip::Speculation& sp, const FramePtr& frame, double reproj_thresh, size_t n_iter) {
+  if (!sp.valid || sp.frame_id != frame->id_ || sp.point.size() != frame->fts_.size() || sp.reproj_thresh != reproj_thresh ||
+      sp.n_iter != (int)n_iter)
+    return false;
+  double T[12];
+  hip_dropin::poseToRt(frame->T_f_w_, T);
+  if (std::memcmp(T, sp.T_init, sizeof(T)) != 0) return false;
+  size_t i = 0;
+  for (Features::const_iterator it = frame->fts_.begin(); it != frame->fts_.end(); ++it, ++i) {
+    const Feature* ftr = *it;
+    if (ftr->point != sp.point[i] || ftr->px[0] != sp.px[2 * i] || ftr->px[1] != sp.px[2 * i + 1] || ftr->level != sp.level[i])
+      return false;
+  }
+  return true;
+}
+}  // namespace
+
 void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const bool verbose, FramePtr& frame,
                          double& estimated_scale, double& error_init, double& error_final, size_t& num_obs) {
   using namespace hip_dropin;
@@ -22,6 +68,27 @@ void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const 
   const int L = svo_hip::Device::LANE_TRACKING;
   svo_hip::Lane& lane = dev.lane(L);
   std::lock_guard<std::mutex> guard(lane.mut);
+  if (predicted(lane.spec, frame, reproj_thresh, n_iter)) {  // before beginCall(): the result blocks are in the arena
+    svo_hip::Speculation& sp = lane.spec;
+    bool agree;
+    {
+      svo_hip::StageTimer wait_timer(dev, lane, svo_hip::Device::STAGE_POSE_OPT);
+      wait_timer.device(0);
+      sp.valid = false;
+      sp.in_flight = false;
+      svo_hip::check(svo_hip_stream_sync(sp.stream), "svo_hip_stream_sync");
+      wait_timer.unmarshal();
+      // the device applied the selection rule on its own: it must have picked the trials the host picked; a frame the
+      // wave kernel left to the ordered kernel (ran == 2: singular normal equations) takes the ordinary call below
+      agree = *sp.n_sel == (int32_t)n && *sp.ran != 2;
+      for (size_t k = 0; agree && k < n; ++k) agree = sp.sel[k] == sp.trial[k];
+      dev.countSpeculation(agree);
+      if (agree) {
+        if (*sp.ran) applyResult(frame, sp.T, sp.Cov, sp.stats, sp.has_point, verbose, estimated_scale, error_init, error_final, num_obs);
+        return;  // ran == 0: no observation carried a point, the reference returns untouched (:57-58)
+      }
+    }
+  }
   dev.beginCall(L);
   svo_hip::StageTimer stage_timer(dev, lane, svo_hip::Device::STAGE_POSE_OPT);
   svo_hip::Arena& a = lane.arena;
@@ -73,23 +140,7 @@ void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const 
   stage_timer.unmarshal();
 
   if (!*ran) return;  // no observation carried a point: the reference returns untouched (:57-58)
-  frame->T_f_w_ = poseFromRt(Tout);
-  for (int r = 0; r < 6; ++r)
-    for (int c = 0; c < 6; ++c) frame->Cov_(r, c) = Cov[r * 6 + c];
-  size_t n_deleted_refs = 0;
-  i = 0;
-  for (Features::iterator it = frame->fts_.begin(); it != frame->fts_.end(); ++it, ++i)
-    if ((*it)->point != NULL && !has_out[i]) {
-      (*it)->point = NULL;  // the point holds no reference to this feature yet (:139-141)
-      ++n_deleted_refs;
-    }
-  estimated_scale = stats[0];
-  error_init = stats[1];
-  error_final = stats[2];
-  num_obs = (size_t)stats[3];
-  if (verbose)
-    std::cout << "n deleted obs = " << n_deleted_refs << "\t scale = " << estimated_scale << "\t error init = " << error_init
-              << "\t error end = " << error_final << std::endl;
+  applyResult(frame, Tout, Cov, stats, has_out, verbose, estimated_scale, error_init, error_final, num_obs);
 }
 
 }  // namespace pose_optimizer

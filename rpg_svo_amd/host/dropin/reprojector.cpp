@@ -12,11 +12,15 @@
 // is matched in one batched launch (svo_hip_find_match_direct, K2+K3) and the per-cell
 // selection then just reads the results.  A trial is a pure function of (point, frame), so
 // the selected features are the same.
+// The call also PREDICTS the next one: FrameHandlerMono::processFrame hands the frame straight to
+// pose_optimizer::optimizeGaussNewton (frame_handler_mono.cpp:164-176), whose input is exactly the features selected
+// here.  svo_hip_select_matches applies the selection rule on the device and svo_hip_pose_optimize is enqueued behind
+// it; this function returns when the MATCH results have arrived and does its list surgery while the optimizer runs
+// (svo_hip::Speculation; the pose optimizer's drop-in checks the prediction before it takes the result).
 #include <svo/reprojector.h>
 
 #include <algorithm>
 #include <stdexcept>
-#include <unordered_map>
 
 #include <svo/config.h>
 #include <svo/feature.h>
@@ -29,18 +33,14 @@
 namespace svo {
 
 namespace {
-struct Outcome {  // what one findMatchDirect trial left in the Matcher
-  bool ok;
-  Vector2d px;
-  int search_level;
-  Feature* ref_ftr;
-  Matrix2d A_cur_ref;
-};
 typedef std::pair<FramePtr, double> KfDist;
 bool closerKf(const KfDist& a, const KfDist& b) { return a.second < b.second; }
 }  // namespace
 
 void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, std::size_t> >& overlap_kfs) {
+  // deferred mapping: the depth filter's update of the previous frame hands its converged seeds to the map before
+  // the map is read (no-op otherwise)
+  svo_hip::Device::joinDeferredAll();
   resetGrid();
 
   // ---- 1. keyframes sharing the field of view, closest first; bin their points --------------
@@ -83,11 +83,20 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
 
   // ---- 3. device: one findMatchDirect trial per binned candidate -----------------------------
   SVO_START_TIMER("feature_align");
-  std::unordered_map<Point*, Outcome> outcome;
+  // What step 4 will find when it walks the cells: per visited candidate (cells in grid_.cell_order, each list in
+  // its sorted order, deleted points left out) the index of its trial in the device batch, or -1 when findMatchDirect
+  // fails before it reaches the image (no close view, matcher.cpp:137-138); the batch's results, in the arena.
+  std::vector<int32_t> visit;
+  std::vector<size_t> visit_begin(grid_.cells.size() + 1, 0);
+  std::vector<Feature*> obs_ftr;
+  const double *res_px = NULL, *res_A = NULL;
+  const int32_t *res_ok = NULL, *res_ref = NULL, *res_lvl = NULL;
+  bool predict = false;             // pose refinement of this frame has been enqueued behind the match kernels
+  svo_hip::Lane* spec_lane = NULL;  // ... on this lane
   if (options_.find_match_direct) {
     size_t n_binned = 0;
     for (size_t k = 0; k < grid_.cells.size(); ++k) n_binned += grid_.cells[k]->size();
-    outcome.reserve(2 * n_binned);
+    visit.reserve(n_binned);
     using namespace hip_dropin;
     // The reference observation of a trial (Point::getCloseViewObs, matcher.cpp:137) is chosen HERE,
     // by the reference's own host code: a trial then ships exactly one svo::Feature, and only the
@@ -95,20 +104,30 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
     // 40 keyframes no longer pins 40 pool slots for one 10x10 template).
     std::vector<Candidate*> trials;
     std::vector<Feature*> trial_ref;
+    std::vector<int32_t> trial_cell;
+    trials.reserve(n_binned); trial_ref.reserve(n_binned); trial_cell.reserve(n_binned);
     const Vector3d cur_pos(frame->pos());
-    for (size_t k = 0; k < grid_.cells.size(); ++k)
-      for (Cell::iterator c = grid_.cells[k]->begin(); c != grid_.cells[k]->end(); ++c) {
+    // Trials are listed in the order step 4 visits them: cells in grid_.cell_order, each cell's list sorted first
+    // (reprojectCell, :152: good points before unknown ones before candidates; stable, like std::list::sort).  A point
+    // lies in one cell only, so sorting every cell before the batch gives the lists the visiting loop would produce.
+    for (size_t i = 0; i < grid_.cells.size(); ++i) {
+      Cell& cell = *grid_.cells.at(grid_.cell_order[i]);
+      cell.sort([](Candidate& l, Candidate& r) { return l.pt->type_ > r.pt->type_; });
+      visit_begin[i] = visit.size();
+      for (Cell::iterator c = cell.begin(); c != cell.end(); ++c) {
         if (c->pt->type_ == Point::TYPE_DELETED) continue;
         Feature* ref_ftr = NULL;
         if (!c->pt->getCloseViewObs(cur_pos, ref_ftr)) {  // findMatchDirect returns false at once (:137-138)
-          Outcome r;
-          r.ok = false; r.px = c->px; r.search_level = 0; r.ref_ftr = NULL;
-          outcome[c->pt] = r;
+          visit.push_back(-1);
           continue;
         }
+        visit.push_back((int32_t)trials.size());
         trials.push_back(&*c);
         trial_ref.push_back(ref_ftr);
+        trial_cell.push_back((int32_t)i);
       }
+    }
+    visit_begin[grid_.cells.size()] = visit.size();
     const size_t M = trials.size();
     const size_t n_obs = M;
     if (M > 0) {
@@ -120,22 +139,27 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
       svo_hip::StageTimer stage_timer(dev, lane, svo_hip::Device::STAGE_REPROJECT);
       svo_hip::Arena& a = lane.arena;
       a.reset();
-      a.reserve(((size_t)1 << 16) + M * 512 + n_obs * 128 + 4096 * 32);
+      a.reserve(((size_t)1 << 17) + M * 768 + n_obs * 128 + 4096 * 32);
       FrameTable frames(dev, L);
       const int i_cur = frames.indexOf(frame.get());
+      // the frame gets its features here and nowhere else: what the pose optimizer will be handed is known
+      predict = svo_hip::Device::speculationEnabled() && frame->fts_.empty();
+      const size_t cap = std::min(M, (size_t)Config::maxFts() + 1);
 
-      int32_t *d_cur, *d_ptr; double* d_pos;
+      int32_t *d_cur, *d_ptr, *d_cell; double* d_pos;
       int32_t* cur = a.alloc<int32_t>(M, &d_cur);
       double* pos = a.alloc<double>(3 * M, &d_pos);
       int32_t* ptr = a.alloc<int32_t>(M + 1, &d_ptr);
+      int32_t* cellv = a.alloc<int32_t>(M, &d_cell);
       std::vector<double> px_in(2 * M);  // goes into the in/out block below
       FeatureColumns obs;
       obs.alloc(a, n_obs);
-      std::vector<Feature*> obs_ftr(n_obs);
+      obs_ftr.resize(n_obs);
       size_t o = 0;
       for (size_t m = 0; m < M; ++m) {
         const Point* pt = trials[m]->pt;
         cur[m] = i_cur;
+        cellv[m] = trial_cell[m];
         for (int k = 0; k < 3; ++k) pos[3 * m + k] = pt->pos_[k];
         px_in[2 * m] = trials[m]->px[0]; px_in[2 * m + 1] = trials[m]->px[1];
         ptr[m] = (int32_t)o;
@@ -146,7 +170,16 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
       ptr[M] = (int32_t)o;
       svo_hip_frames ft;
       frames.emit(a, &ft);
+      // the predicted pose refinement's observations: gathered on the device, never read by the host
+      double *d_sf = NULL, *d_spos = NULL;
+      int32_t* d_slvl = NULL;
+      if (predict) {
+        a.alloc<double>(3 * cap, &d_sf);
+        a.alloc<double>(3 * cap, &d_spos);
+        a.alloc<int32_t>(cap, &d_slvl);
+      }
       a.endInputs();
+      const size_t inputs_end = a.used();
 
       double *d_px, *d_A; int32_t *d_ok, *d_ref, *d_lvl;
       double* px = a.alloc<double>(2 * M, &d_px);  // in: projection, out: refined pixel (uploadAll + download)
@@ -155,6 +188,34 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
       int32_t* ref = a.alloc<int32_t>(M, &d_ref);
       int32_t* lvl = a.alloc<int32_t>(M, &d_lvl);
       double* A = a.alloc<double>(4 * M, &d_A);
+      const size_t match_end = a.used();
+
+      double *d_T = NULL, *d_Cov = NULL, *d_stats = NULL;
+      int32_t *d_nsel = NULL, *d_sel = NULL, *d_ran = NULL, *d_flag = NULL;
+      volatile int32_t* flag = NULL;
+      uint8_t* d_has = NULL;
+      size_t results_begin = match_end;
+      svo_hip::Speculation& sp = lane.spec;
+      if (predict) {
+        spec_lane = &lane;
+        sp.frame_id = frame->id_;
+        sp.point.clear(); sp.px.clear(); sp.level.clear(); sp.trial.clear();
+        results_begin = a.used();
+        // what comes back: the pose goes in and out like in the optimizer's own call
+        double* T = a.alloc<double>(12, &d_T);
+        poseToRt(frame->T_f_w_, T);
+        std::copy(T, T + 12, sp.T_init);
+        sp.T = T;
+        sp.n_sel = a.alloc<int32_t>(1, &d_nsel);
+        sp.sel = a.alloc<int32_t>(cap, &d_sel);
+        sp.has_point = a.alloc<uint8_t>(cap, &d_has);
+        sp.Cov = a.alloc<double>(36, &d_Cov);
+        sp.stats = a.alloc<double>(4, &d_stats);
+        sp.ran = a.alloc<int32_t>(1, &d_ran);
+        if (a.mode() != svo_hip::Arena::MIRRORED) flag = a.alloc<int32_t>(1, &d_flag);
+        sp.reproj_thresh = Config::poseOptimThresh();
+        sp.n_iter = (int)Config::poseOptimNumIter();
+      }
 
       const svo_hip_camera cam = cameraOf(frame->cam_);
       void* ws = dev.workspace(lane, (int)M);
@@ -164,40 +225,69 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
                                                Config::nPyrLevels(), matcher_.options_.align_max_iter, d_px, d_ok, d_ref, d_lvl,
                                                d_A, NULL, ws, lane.workspace_bytes, lane.stream),
                      "svo_hip_find_match_direct");
-      a.download(lane.stream);
-      svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+      a.downloadRange(inputs_end, match_end, lane.stream);
+      if (predict && flag != NULL) {
+        // Results land in host memory as the kernels write them (hybrid / mapped arena): the selection kernel stores
+        // `flag` when it starts, i.e. when the match kernels are through, and the host polls that instead of waiting
+        // for the stream -- pose refinement follows on the same stream, no event, no second queue.
+        *flag = 0;
+        svo_hip::check(svo_hip_select_matches(&cam, (int)M, d_cell, d_ok, d_px, d_lvl, d_pos, Config::maxFts(), d_nsel, d_sel, d_sf,
+                                              d_slvl, d_spos, d_has, d_flag, 1, lane.stream),
+                       "svo_hip_select_matches");
+        // (the wave kernel alone: a frame it hands over, ran == 2, is finished by the optimizer's drop-in)
+        svo_hip::check(svo_hip_pose_optimize_deferred(&cam, 1, d_nsel, (int)cap, d_sf, d_slvl, d_spos, d_has, sp.reproj_thresh,
+                                                      sp.n_iter, d_T, d_Cov, d_stats, d_ran, lane.stream),
+                       "svo_hip_pose_optimize_deferred");
+        sp.stream = lane.stream;
+        sp.in_flight = true;  // beginCall() of the lane's next call (or the optimizer's drop-in) waits for it
+        svo_hip::spinUntil(flag, 1, lane.stream);
+      } else if (predict) {
+        // mirrored arena: behind the match results on the lane's second stream, so that the wait below ends with the
+        // copy of the match results
+        void* const next = lane.stream_next;
+        svo_hip::check(svo_hip_event_record(lane.ev_results, lane.stream), "svo_hip_event_record");
+        svo_hip::check(svo_hip_stream_wait_event(next, lane.ev_results), "svo_hip_stream_wait_event");
+        svo_hip::check(svo_hip_select_matches(&cam, (int)M, d_cell, d_ok, d_px, d_lvl, d_pos, Config::maxFts(), d_nsel, d_sel, d_sf,
+                                              d_slvl, d_spos, d_has, NULL, 0, next),
+                       "svo_hip_select_matches");
+        svo_hip::check(svo_hip_pose_optimize_deferred(&cam, 1, d_nsel, (int)cap, d_sf, d_slvl, d_spos, d_has, sp.reproj_thresh,
+                                                      sp.n_iter, d_T, d_Cov, d_stats, d_ran, next),
+                       "svo_hip_pose_optimize_deferred");
+        a.downloadRange(results_begin, a.used(), next);
+        sp.stream = next;
+        sp.in_flight = true;
+        svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+      } else {
+        svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+      }
       stage_timer.unmarshal();
 
-      for (size_t m = 0; m < M; ++m) {
-        Outcome r;
-        r.ok = ok[m] != 0;
-        r.px = Vector2d(px[2 * m], px[2 * m + 1]);
-        r.search_level = lvl[m];
-        r.ref_ftr = ref[m] >= 0 ? obs_ftr[ref[m]] : NULL;
-        r.A_cur_ref(0, 0) = A[4 * m]; r.A_cur_ref(0, 1) = A[4 * m + 1];
-        r.A_cur_ref(1, 0) = A[4 * m + 2]; r.A_cur_ref(1, 1) = A[4 * m + 3];
-        outcome[trials[m]->pt] = r;
-      }
+      res_px = px; res_ok = ok; res_ref = ref; res_lvl = lvl; res_A = A;  // the arena stays until the lane's next call
     }
   }
 
   // ---- 4. per cell, in the shuffled order: the best-quality point that matched ---------------
   for (size_t i = 0; i < grid_.cells.size(); ++i) {
     Cell& cell = *grid_.cells.at(grid_.cell_order[i]);
-    // good points before unknown ones before candidates (stable, like std::list::sort)
-    cell.sort([](Candidate& l, Candidate& r) { return l.pt->type_ > r.pt->type_; });
+    if (!options_.find_match_direct)  // (sorted above otherwise) good points before unknown ones before candidates
+      cell.sort([](Candidate& l, Candidate& r) { return l.pt->type_ > r.pt->type_; });
     bool matched = false;
+    size_t v = visit_begin[i];  // the candidates step 3 listed for this cell, in this order
     for (Cell::iterator it = cell.begin(); it != cell.end() && !matched;) {
       ++n_trials_;
       Point* pt = it->pt;
       if (pt->type_ == Point::TYPE_DELETED) { it = cell.erase(it); continue; }
-      Outcome r;
+      struct { int trial; bool ok; Vector2d px; int search_level; Feature* ref_ftr; } r;
       if (options_.find_match_direct) {
-        std::unordered_map<Point*, Outcome>::iterator f = outcome.find(pt);
-        if (f == outcome.end()) throw std::logic_error("Reprojector: candidate without a device trial");
-        r = f->second;
+        if (v >= visit_begin[i + 1]) throw std::logic_error("Reprojector: candidate without a device trial");
+        r.trial = visit[v++];
+        const int m = r.trial;
+        r.ok = m >= 0 && res_ok[m] != 0;
+        r.px = m >= 0 ? Vector2d(res_px[2 * m], res_px[2 * m + 1]) : it->px;
+        r.search_level = m >= 0 ? res_lvl[m] : 0;
+        r.ref_ftr = (m >= 0 && res_ref[m] >= 0) ? obs_ftr[res_ref[m]] : NULL;
       } else {  // accept the projection as it is
-        r.ok = true; r.px = it->px; r.search_level = 0; r.ref_ftr = NULL;
+        r.trial = -1; r.ok = true; r.px = it->px; r.search_level = 0; r.ref_ftr = NULL;
       }
       if (!r.ok) {
         pt->n_failed_reproj_++;
@@ -214,8 +304,18 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
       new_feature->point = pt;  // the point learns about this observation only if the frame becomes a keyframe
       if (r.ref_ftr != NULL && r.ref_ftr->type == Feature::EDGELET) {
         new_feature->type = Feature::EDGELET;
-        new_feature->grad = r.A_cur_ref * r.ref_ftr->grad;
+        Matrix2d A_cur_ref;
+        A_cur_ref(0, 0) = res_A[4 * r.trial]; A_cur_ref(0, 1) = res_A[4 * r.trial + 1];
+        A_cur_ref(1, 0) = res_A[4 * r.trial + 2]; A_cur_ref(1, 1) = res_A[4 * r.trial + 3];
+        new_feature->grad = A_cur_ref * r.ref_ftr->grad;
         new_feature->grad.normalize();
+      }
+      if (predict) {  // what the device's selection must have picked, for the optimizer's drop-in to check
+        svo_hip::Speculation& sp = spec_lane->spec;
+        sp.point.push_back(pt);
+        sp.px.push_back(r.px[0]); sp.px.push_back(r.px[1]);
+        sp.level.push_back(r.search_level);
+        sp.trial.push_back(r.trial);
       }
       it = cell.erase(it);
       matched = true;  // at most one feature per cell
@@ -223,6 +323,7 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
     if (matched) ++n_matches_;
     if (n_matches_ > (size_t)Config::maxFts()) break;
   }
+  if (predict) spec_lane->spec.valid = !spec_lane->spec.point.empty();
   SVO_STOP_TIMER("feature_align");
 }
 

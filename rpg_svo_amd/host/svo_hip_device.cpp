@@ -1,6 +1,7 @@
 // svo_hip_device.cpp -- see svo_hip_device.h.
 #include "svo_hip_device.h"
 
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 
@@ -12,6 +13,20 @@ void check(int code, const char* what) {
   if (code >= 0) return;
   throw Error(std::string(what) + ": " + svo_hip_strerror(code) + " (hip error " +
               std::to_string(svo_hip_last_hip_error()) + ")");
+}
+
+void spinUntil(const volatile int32_t* flag, int32_t value, void* stream) {
+  const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0; *flag != value; ++spins) {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+    if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) {
+      check(svo_hip_stream_sync(stream), "svo_hip_stream_sync(signal)");
+      if (*flag != value) throw Error("svo_hip::spinUntil: the stream drained without the signal being stored");
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);  // the results the signal vouches for are read after it
 }
 
 // ---- Arena ---------------------------------------------------------------------------
@@ -55,17 +70,30 @@ void Arena::upload(void* stream) {
 
 void Arena::uploadAll(void* stream) {
   if (mode_ == MAPPED) return;
-  if (used_) check(svo_hip_memcpy_h2d(d_, h_, used_, stream), "arena upload");
+  const size_t n = mode_ == HYBRID && outputs_ ? in_end_ : used_;  // HYBRID: the in/out blocks are host memory
+  if (n) check(svo_hip_memcpy_h2d(d_, h_, n, stream), "arena upload");
 }
 
 void Arena::download(void* stream) {
-  if (mode_ == MAPPED) return;
+  if (mode_ != MIRRORED) return;
   if (used_ > in_end_) check(svo_hip_memcpy_d2h(h_ + in_end_, d_ + in_end_, used_ - in_end_, stream), "arena download");
+}
+
+void Arena::downloadRange(size_t begin, size_t end, void* stream) {
+  if (begin > end || end > used_) throw Error("svo_hip::Arena::downloadRange: not inside the arena");
+  if (mode_ == MAPPED || begin == end) return;
+  if (mode_ == HYBRID) {  // only what lies in the mirrored part
+    const size_t mirrored_end = outputs_ ? in_end_ : used_;
+    if (begin >= mirrored_end) return;
+    end = end < mirrored_end ? end : mirrored_end;
+  }
+  check(svo_hip_memcpy_d2h(h_ + begin, d_ + begin, end - begin, stream), "arena download");
 }
 
 void Arena::fetchBytes(uint8_t* host_block, size_t bytes, void* stream) {
   if (host_block < h_ || host_block + bytes > h_ + used_) throw Error("svo_hip::Arena::fetch: not an arena block");
   if (mode_ == MAPPED) return;
+  if (mode_ == HYBRID && outputs_ && (size_t)(host_block - h_) >= in_end_) return;  // an output block: written in place
   check(svo_hip_memcpy_d2h(host_block, d_ + (host_block - h_), bytes, stream), "arena fetch");
 }
 
@@ -108,13 +136,16 @@ Device& Device::instance() {
 Lane* Device::makeLane() {
   Lane* l = new Lane();
   check(svo_hip_stream_create(&l->stream), "svo_hip_stream_create");
+  check(svo_hip_stream_create(&l->stream_next), "svo_hip_stream_create");
+  check(svo_hip_event_create(&l->ev_results), "svo_hip_event_create");
   l->index = next_lane_index_++;
   check(svo_hip_malloc(&l->d_stage, (size_t)layout_.w[0] * layout_.h[0]), "svo_hip_malloc(stage)");
   l->arena.reserve((size_t)4 << 20);
   // SVO_HIP_ARENA=mapped|mirrored selects how a call's arguments reach the device (Arena)
   const char* mode = std::getenv("SVO_HIP_ARENA");
-  if (mode && std::string(mode) == "mapped") l->arena.setMode(Arena::MAPPED);
-  else if (mode && std::string(mode) != "mirrored") throw Error("SVO_HIP_ARENA must be 'mapped' or 'mirrored'");
+  if (!mode || std::string(mode) == "hybrid") l->arena.setMode(Arena::HYBRID);  // the default
+  else if (std::string(mode) == "mapped") l->arena.setMode(Arena::MAPPED);
+  else if (std::string(mode) != "mirrored") throw Error("SVO_HIP_ARENA must be 'hybrid', 'mirrored' or 'mapped'");
   return l;
 }
 
@@ -135,6 +166,9 @@ void Device::shutdown() {
     for (std::map<std::pair<std::thread::id, int>, Lane*>::iterator it = lanes_.begin(); it != lanes_.end(); ++it) {
       Lane& l = *it->second;
       if (l.stream) { svo_hip_stream_sync(l.stream); svo_hip_stream_destroy(l.stream); l.stream = NULL; }
+      if (l.stream_next) { svo_hip_stream_sync(l.stream_next); svo_hip_stream_destroy(l.stream_next); l.stream_next = NULL; }
+      if (l.ev_results) { svo_hip_event_destroy(l.ev_results); l.ev_results = NULL; }
+      l.deferred = nullptr;  // its owner is about to lose the device; nothing is written back
       l.arena.release();
       if (l.d_workspace) { svo_hip_free(l.d_workspace); l.d_workspace = NULL; l.workspace_bytes = 0; }
       if (l.d_stage) { svo_hip_free(l.d_stage); l.d_stage = NULL; }
@@ -143,6 +177,9 @@ void Device::shutdown() {
     lanes_.clear();
   }
   if (d_store_) { svo_hip_free(d_store_); d_store_ = NULL; }
+  for (size_t s = 0; s < slot_ready_.size(); ++s)
+    if (slot_ready_[s]) svo_hip_event_destroy(slot_ready_[s]);
+  slot_ready_.clear();
   frames_.clear();
   free_slots_.clear();
   n_slots_ = 0;
@@ -163,6 +200,8 @@ void Device::configure(int width, int height, int n_levels, int n_slots, int dev
   check(svo_hip_stream_sync(NULL), "svo_hip_stream_sync");
   n_slots_ = n_slots;
   for (int s = n_slots - 1; s >= 0; --s) free_slots_.push_back(s);
+  slot_ready_.assign((size_t)n_slots, NULL);
+  for (int s = 0; s < n_slots; ++s) check(svo_hip_event_create(&slot_ready_[s]), "svo_hip_event_create");
 }
 
 void Device::ensureConfigured(int width, int height, int n_levels) {
@@ -170,7 +209,59 @@ void Device::ensureConfigured(int width, int height, int n_levels) {
   configure(width, height, n_levels);
 }
 
+namespace {
+int g_deferred_mapping = -1;  // -1: ask the environment
+void runDeferred(Lane& lane) {
+  if (!lane.deferred) return;
+  std::function<void()> f;
+  f.swap(lane.deferred);
+  f();
+}
+}  // namespace
+
+bool Device::deferredMapping() {
+  if (g_deferred_mapping < 0) {
+    const char* v = std::getenv("SVO_HIP_MAPPER");
+    if (v && std::string(v) != "deferred" && std::string(v) != "sync") throw Error("SVO_HIP_MAPPER must be 'deferred' or 'sync'");
+    g_deferred_mapping = v && std::string(v) == "deferred";
+  }
+  return g_deferred_mapping != 0;
+}
+void Device::setDeferredMapping(bool on) { g_deferred_mapping = on; }
+
+void Device::joinDeferred(int which_lane) {
+  Lane* l = NULL;
+  {
+    std::lock_guard<std::mutex> g(lanes_mut_);
+    std::map<std::pair<std::thread::id, int>, Lane*>::iterator it = lanes_.find(std::make_pair(std::this_thread::get_id(), which_lane));
+    if (it != lanes_.end()) l = it->second;
+  }
+  if (!l) return;
+  std::lock_guard<std::mutex> g(l->mut);
+  runDeferred(*l);
+}
+
+void Device::joinDeferredAll() {
+  std::vector<Device*> all;
+  {
+    std::lock_guard<std::mutex> g(g_registry_mut);
+    all = g_registry;
+  }
+  for (size_t i = 0; i < all.size(); ++i)
+    for (int which = 0; which < N_LANES; ++which) all[i]->joinDeferred(which);
+}
+
 void Device::beginCall(Lane& lane) {
+  runDeferred(lane);  // the caller holds lane.mut
+  // work a previous call left running reads and writes the arena this call is about to refill
+  if (lane.spec.in_flight) {
+    lane.spec.in_flight = false;
+    check(svo_hip_stream_sync(lane.spec.stream), "svo_hip_stream_sync(speculation)");
+  }
+  if (lane.spec.valid) {
+    lane.spec.valid = false;
+    countSpeculation(false);
+  }
   {
     std::lock_guard<std::mutex> g(frames_mut_);
     for (size_t i = 0; i < lane.touched.size(); ++i) {  // the previous call of this lane is over: unpin
@@ -188,13 +279,26 @@ Device::Stats Device::statsSnapshot() {
   return stats;
 }
 
-void Device::addStage(int stage, double marshal_us, double device_us, double unmarshal_us, double payload_bytes) {
+void Device::countSpeculation(bool hit) {
+  std::lock_guard<std::mutex> g(stats_mut_);
+  if (hit) ++stats.spec_hits; else ++stats.spec_misses;
+}
+
+bool Device::speculationEnabled() {
+  static const bool on = [] {
+    const char* v = std::getenv("SVO_HIP_SPECULATE");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
+
+void Device::addStage(int stage, double marshal_us, double device_us, double unmarshal_us, double payload_bytes, bool count) {
   std::lock_guard<std::mutex> g(stats_mut_);
   stats.marshal_us[stage] += marshal_us;
   stats.device_us[stage] += device_us;
   stats.unmarshal_us[stage] += unmarshal_us;
   stats.payload_bytes[stage] += payload_bytes;
-  ++stats.n[stage];
+  if (count) ++stats.n[stage];
 }
 
 int Device::slotOf(int frame_id, const uint8_t* level0, int stride, Lane& lane) {
@@ -204,14 +308,21 @@ int Device::slotOf(int frame_id, const uint8_t* level0, int stride, Lane& lane) 
   return slot;
 }
 
-int Device::slotOfLocked(int frame_id, const uint8_t* level0, int stride, Lane& lane) {
+int Device::slotOfLocked(int frame_id, const uint8_t* level0, int stride, Lane& lane, bool wait_upload) {
   bool mine = false;
   for (size_t i = 0; i < lane.touched.size(); ++i) mine = mine || lane.touched[i] == frame_id;
   std::map<int, Entry>::iterator it = frames_.find(frame_id);
   if (it != frames_.end()) {
-    it->second.last_use = ++clock_;
-    if (!mine) { ++it->second.pins; lane.touched.push_back(frame_id); }
-    return it->second.slot;
+    Entry& e = it->second;
+    e.last_use = ++clock_;
+    if (!mine) { ++e.pins; lane.touched.push_back(frame_id); }
+    if (!e.settled && e.owner != lane.index) {  // uploaded on another stream and not known to be complete
+      const int done = svo_hip_event_query(slot_ready_[e.slot]);
+      check(done, "svo_hip_event_query(upload)");
+      if (done) e.settled = true;
+      else check(svo_hip_stream_wait_event(lane.stream, slot_ready_[e.slot]), "svo_hip_stream_wait_event(upload)");
+    }
+    return e.slot;
   }
   if (level0 == NULL) return -1;
   bool evicted = false;
@@ -233,8 +344,9 @@ int Device::slotOfLocked(int frame_id, const uint8_t* level0, int stride, Lane& 
     // H2D into the lane's packed staging buffer, then ONE kernel: tiled level 0 + every further level
     check(svo_hip_pyramid_upload_build(&layout_, d_store_, slot, level0, stride, SVO_HIP_HALFSAMPLE_AUTO, lane.d_stage,
                                        lane.stream), "svo_hip_pyramid_upload_build");
-    // another lane may consume this slot next: complete the upload before publishing it
-    check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync(upload)");
+    // no host sync: this lane's kernels follow in stream order, other lanes go through the slot's event
+    check(svo_hip_event_record(slot_ready_[slot], lane.stream), "svo_hip_event_record(upload)");
+    if (wait_upload) check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync(upload)");
   } catch (...) {
     free_slots_.push_back(slot);  // not published: the slot stays free
     throw;
@@ -243,6 +355,8 @@ int Device::slotOfLocked(int frame_id, const uint8_t* level0, int stride, Lane& 
   en.slot = slot;
   en.last_use = ++clock_;
   en.pins = 1;
+  en.owner = lane.index;
+  en.settled = wait_upload;
   lane.touched.push_back(frame_id);
   frames_[frame_id] = en;
   const double dt = StageTimer::now() - t_up;
@@ -274,7 +388,7 @@ int Device::scratchSlotOf(const uint8_t* image, int w, int h, int stride, int* l
     slot = slotOfLocked(id, NULL, 0, lane);  // hit: pins it for this call
     if (slot < 0) {
       std::vector<uint8_t> blank((size_t)layout_.w[0] * layout_.h[0], 0);
-      slot = slotOfLocked(id, &blank[0], layout_.w[0], lane);  // synchronises: `blank` may go
+      slot = slotOfLocked(id, &blank[0], layout_.w[0], lane, true);  // synchronises: `blank` may go
     }
   }
   // the lane's stream orders this upload behind the lane's earlier kernels and before its next ones; the

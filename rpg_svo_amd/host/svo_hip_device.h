@@ -19,6 +19,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -35,6 +36,11 @@ struct Error : std::runtime_error {
   explicit Error(const std::string& what) : std::runtime_error(what) {}
 };
 void check(int code, const char* what);  // throws Error on a negative svo_hip status
+// Spins until *flag == value.  `flag` lies in device-mapped pinned host memory and a kernel on `stream` stores the
+// value (svo_hip_select_matches' d_signal): the host gets there without a runtime call, and with work still running
+// behind the signalling kernel.  After a second without the value the stream is synchronised instead, so that a
+// failed launch surfaces as an Error rather than a hang.
+void spinUntil(const volatile int32_t* flag, int32_t value, void* stream);
 
 // Bump allocator over a pinned host buffer and its same-sized device mirror.  Input blocks
 // are carved from the front, output blocks after them; both sides share offsets.
@@ -42,28 +48,32 @@ void check(int code, const char* what);  // throws Error on a negative svo_hip s
 // device-mapped) host buffer over the host link directly, so a call is kernels + one stream sync
 // with no copy commands at all -- the shorter round trip for the few-KB payloads of a single
 // camera (DESIGN.md "single-stream latency"); upload()/download() are then no-ops.
+// HYBRID mirrors the inputs and maps the outputs: blocks allocated before endInputs() live in the device mirror and
+// travel in the one H2D copy, blocks allocated after it ARE the pinned host buffer -- kernels write results (a few KB,
+// posted writes) straight into host memory and the D2H copy of a call disappears.
 class Arena {
  public:
-  enum Mode { MIRRORED = 0, MAPPED = 1 };
-  Arena() : h_(NULL), d_(NULL), cap_(0), used_(0), in_end_(0), mode_(MIRRORED) {}
+  enum Mode { MIRRORED = 0, MAPPED = 1, HYBRID = 2 };
+  Arena() : h_(NULL), d_(NULL), cap_(0), used_(0), in_end_(0), mode_(MIRRORED), outputs_(false) {}
   void setMode(Mode m);  // before the first alloc of a call
   Mode mode() const { return mode_; }
   void reserve(size_t bytes);
-  void reset() { used_ = 0; in_end_ = 0; }
+  void reset() { used_ = 0; in_end_ = 0; outputs_ = false; }
   // n elements of T, 256-byte aligned; *dev receives the device address of the same block
   template <typename T> T* alloc(size_t n, T** dev) {
     size_t off = (used_ + 255) & ~(size_t)255;
     size_t end = off + n * sizeof(T);
     if (end > cap_) grow(end);
     used_ = end;
-    *dev = reinterpret_cast<T*>((mode_ == MAPPED ? h_ : d_) + off);
+    *dev = reinterpret_cast<T*>((mode_ == MAPPED || (mode_ == HYBRID && outputs_) ? h_ : d_) + off);
     return reinterpret_cast<T*>(h_ + off);
   }
-  void endInputs() { in_end_ = used_; }          // everything allocated so far is kernel input
+  void endInputs() { in_end_ = used_; outputs_ = true; }  // everything allocated so far is kernel input
   void upload(void* stream);                      // H2D of [0, in_end)
   void uploadAll(void* stream);                   // H2D of [0, used): also blocks a kernel updates in place,
                                                   // allocated after endInputs() and pre-filled by the host
   void download(void* stream);                    // D2H of [in_end, used)
+  void downloadRange(size_t begin, size_t end, void* stream);  // D2H of [begin, end), offsets as used() reports them
   // D2H of one block handed out by alloc() (for arrays a kernel updates in place)
   template <typename T> void fetch(T* host_block, size_t n, void* stream) {
     fetchBytes(reinterpret_cast<uint8_t*>(host_block), n * sizeof(T), stream);
@@ -78,10 +88,47 @@ class Arena {
   uint8_t* d_;
   size_t cap_, used_, in_end_;
   Mode mode_;
+  bool outputs_;  // endInputs() has been called since reset()
+};
+
+// Work a call leaves RUNNING on the lane's stream for the lane's next call to pick up.  The reprojector's drop-in
+// enqueues pose refinement behind its match kernels (svo_hip_select_matches + svo_hip_pose_optimize) and returns as
+// soon as the match results have arrived; pose_optimizer's drop-in takes the result when the frame it is handed is
+// the frame that was predicted (same features, same pose, same parameters) and runs the call itself otherwise.
+// The blocks live in the lane's arena: beginCall() of any other call drains the stream and drops the prediction.
+struct Speculation {
+  bool valid;      // a prediction is waiting
+  bool in_flight;  // kernels / copies enqueued and not waited for yet ...
+  void* stream;    // ... on this stream
+  int frame_id;
+  std::vector<const void*> point;  // the features predicted for Frame::fts_, in order: Feature::point,
+  std::vector<double> px;          //   Feature::px [n][2],
+  std::vector<int32_t> level;      //   Feature::level,
+  std::vector<int32_t> trial;      //   and the trial each came from (what the device's own selection must say)
+  double T_init[12], reproj_thresh;
+  int n_iter;
+  // host addresses of the results (arena blocks)
+  const int32_t* n_sel;
+  const int32_t* sel;
+  const int32_t* ran;
+  const double* T;
+  const double* Cov;
+  const double* stats;
+  const uint8_t* has_point;
+  Speculation() : valid(false), in_flight(false), stream(NULL), frame_id(-1), reproj_thresh(0), n_iter(0), n_sel(NULL), sel(NULL), ran(NULL),
+                  T(NULL), Cov(NULL), stats(NULL), has_point(NULL) {}
 };
 
 struct Lane {
   void* stream;
+  void* stream_next;      // the predicted next call runs here, behind ev_results: the lane's own stream -- and the host's
+                          // wait on it -- ends with the results the current call returns
+  void* ev_results;       // recorded on `stream` behind those results
+  Speculation spec;
+  // The second half of a call that returned with its kernels still running (DepthFilter::updateSeeds in deferred
+  // mode): waits for the stream and writes the results back.  Run by the lane's next beginCall() or by
+  // Device::joinDeferred(), whichever comes first; the arena and the pinned frames stay as the call left them until then.
+  std::function<void()> deferred;
   Arena arena;
   void* d_workspace;      // matcher / depth-filter scratch (svo_hip_match_workspace_bytes)
   size_t workspace_bytes;
@@ -90,7 +137,7 @@ struct Lane {
   double pyr_upload_us;   // time this lane spent uploading pyramids (StageTimer takes it out of "marshal")
   std::mutex mut;
   std::vector<int> touched;  // frames pinned by the lane's current call
-  Lane() : stream(NULL), d_workspace(NULL), workspace_bytes(0), d_stage(NULL), index(0), pyr_upload_us(0) {}
+  Lane() : stream(NULL), stream_next(NULL), ev_results(NULL), d_workspace(NULL), workspace_bytes(0), d_stage(NULL), index(0), pyr_upload_us(0) {}
 };
 
 class Device {
@@ -119,6 +166,19 @@ class Device {
   // pinned (never evicted) until the lane's next beginCall().
   void beginCall(int which_lane) { beginCall(lane(which_lane)); }
   void beginCall(Lane& lane);
+  // Completes a deferred call of the calling thread's lane of that role, if there is one (no lane is created).
+  void joinDeferred(int which_lane);
+  static void joinDeferredAll();  // the same for every context of the process
+  // Deferred mapping (opt-in: SVO_HIP_MAPPER=deferred or setDeferredMapping(true)).  For hosts that run the depth
+  // filter synchronously inside addFrame() (DepthFilter without its thread, depth_filter.cpp:82-95): updateSeeds()
+  // returns once its kernels are enqueued on the mapping lane's stream; results are written into the seed list,
+  // converged seeds handed to the map, at the next point where the reference's control flow reads them -- the next
+  // Reprojector::reprojectMap, the next DepthFilter::updateSeeds, FastDetector::detect (DepthFilter::initializeSeeds)
+  // -- so every consumer sees the state the synchronous filter would have left.  The mapping then overlaps the end of
+  // frame t and pyramid + sparse alignment of frame t+1 the way the reference's mapping thread does, deterministically.
+  // Contract: DepthFilter::getSeeds() readers and the DepthFilter destructor need joinDeferredAll() first.
+  static bool deferredMapping();
+  static void setDeferredMapping(bool on);
   // Slot of frame `id`; on a miss the level-0 image (8-bit, `stride` bytes per row) is
   // uploaded and the pyramid built on the lane's stream, evicting the least recently used
   // unpinned frame when the pool is full.
@@ -143,22 +203,31 @@ class Device {
   enum { STAGE_SPARSE_ALIGN = 0, STAGE_REPROJECT = 1, STAGE_POSE_OPT = 2, STAGE_DEPTH_FILTER = 3, N_STAGES = 4 };
   struct Stats {
     uint64_t uploads, evictions, calls;
+    uint64_t spec_hits, spec_misses;  // pose refinements taken from / not taken from the reprojector's prediction
     double pyr_upload_us;
     double marshal_us[N_STAGES], device_us[N_STAGES], unmarshal_us[N_STAGES], payload_bytes[N_STAGES];
     uint64_t n[N_STAGES];
-    Stats() : uploads(0), evictions(0), calls(0), pyr_upload_us(0) {
+    Stats() : uploads(0), evictions(0), calls(0), spec_hits(0), spec_misses(0), pyr_upload_us(0) {
       for (int i = 0; i < N_STAGES; ++i) { marshal_us[i] = device_us[i] = unmarshal_us[i] = payload_bytes[i] = 0; n[i] = 0; }
     }
   };
   Stats stats;             // written under stats_mut_ only; read it through statsSnapshot() while calls run
   Stats statsSnapshot();
-  void addStage(int stage, double marshal_us, double device_us, double unmarshal_us, double payload_bytes);
+  // count = false: the second half of a call already counted (a deferred call's join)
+  void addStage(int stage, double marshal_us, double device_us, double unmarshal_us, double payload_bytes, bool count = true);
+  void countSpeculation(bool hit);
+  // SVO_HIP_SPECULATE=0 switches the reprojector's prediction off (every stage then ends with its own stream sync)
+  static bool speculationEnabled();
 
  private:
   Device();
   ~Device();
   Device(const Device&);
-  struct Entry { int slot; uint64_t last_use; int pins; };
+  // owner / settled: a pyramid is published as soon as its upload is ENQUEUED on the owner lane's stream.  The
+  // owner's later work is ordered behind it by the stream; another lane that finds the entry first asks the slot's
+  // event (recorded behind the upload) and, while that has not fired, makes its own stream wait for it.
+  struct Entry { int slot; uint64_t last_use; int pins; int owner; bool settled; };
+  std::vector<void*> slot_ready_;  // one event per slot
   svo_hip_pyr_layout layout_;
   uint8_t* d_store_;
   int n_slots_;
@@ -172,8 +241,8 @@ class Device {
   std::mutex stats_mut_;
   Lane* makeLane();
   // frames_mut_ held: hit -> pin + slot; miss with level0 != NULL -> evict if needed, upload, publish;
-  // miss with level0 == NULL -> -1
-  int slotOfLocked(int frame_id, const uint8_t* level0, int stride, Lane& lane);
+  // miss with level0 == NULL -> -1.  wait_upload: the caller's image buffer goes away right after the call
+  int slotOfLocked(int frame_id, const uint8_t* level0, int stride, Lane& lane, bool wait_upload = false);
 };
 
 // Splits one drop-in call on the host clock (see Device::Stats).  marshal until device(), device until

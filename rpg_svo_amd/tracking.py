@@ -212,6 +212,30 @@ def cam2world(cam, px, out=None):
     return out
 
 
+def select_matches(cam, cell, ok, px, level, pos, max_fts):
+    """Reprojector::reprojectMap's cell loop over the results of M trials given in visiting order
+    (svo/src/reprojector.cpp:131-139, 150-200): per cell the first trial that matched, at most max_fts + 1 of them.
+    Returns (n [1] int32, sel, f, level_out, pos_out, has_point), the arrays min(M, max_fts + 1) long: the
+    observations of the selected trials in Frame::fts_ order, as svo_hip_pose_optimize reads them."""
+    lib = capi.load()
+    M = cell.shape[0]
+    dev = px.device
+    cap = max(1, min(M, max_fts + 1))
+    n = torch.zeros(1, dtype=torch.int32, device=dev)
+    sel = torch.full((cap,), -1, dtype=torch.int32, device=dev)
+    f = torch.zeros(cap, 3, dtype=torch.float64, device=dev)
+    level_out = torch.zeros(cap, dtype=torch.int32, device=dev)
+    pos_out = torch.zeros(cap, 3, dtype=torch.float64, device=dev)
+    has_point = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    c = capi.camera(cam)
+    capi.check(lib.svo_hip_select_matches(C.byref(c), M, _chk(cell, torch.int32).data_ptr(), _chk(ok, torch.int32).data_ptr(),
+                                          _chk(px, torch.float64).data_ptr(), _chk(level, torch.int32).data_ptr(),
+                                          _chk(pos, torch.float64).data_ptr(), int(max_fts), n.data_ptr(), sel.data_ptr(),
+                                          f.data_ptr(), level_out.data_ptr(), pos_out.data_ptr(), has_point.data_ptr(),
+                                          None, 0, _stream_ptr(dev)), "svo_hip_select_matches")
+    return n, sel, f, level_out, pos_out, has_point
+
+
 # ---- pose_optimizer ---------------------------------------------------------------------
 @dataclass
 class PoseOptResult:

@@ -45,6 +45,8 @@ typedef struct pipe_config {
   int32_t poseoptim_num_iter, shuffle_seed;
   int32_t mapper_thread;  // 1: keep DepthFilter's own thread running (asynchronous mapping)
   int32_t pool_slots;     // >0 (hip flavour): size of the device pyramid pool, to exercise LRU eviction
+  int32_t defer_mapper;   // 1 (hip flavour, mapper_thread = 0): svo_hip::Device::setDeferredMapping(true) -- updateSeeds
+                          // returns with its kernels running; n_seeds of a result is then the count BEFORE that update
   double kfselect_mindist, poseoptim_thresh, triang_min_corner_score;
 } pipe_config;
 
@@ -66,6 +68,7 @@ void pipe_config_default(pipe_config* c) {
   c->n_pyr_levels = 3; c->klt_max_level = 4; c->klt_min_level = 2; c->grid_size = 30; c->max_fts = 120;
   c->max_n_kfs = 10; c->quality_min_fts = 50; c->quality_max_drop_fts = 40; c->structureoptim_max_pts = 20;
   c->structureoptim_num_iter = 5; c->poseoptim_num_iter = 10; c->shuffle_seed = 1; c->mapper_thread = 0; c->pool_slots = 0;
+  c->defer_mapper = 0;
   c->kfselect_mindist = 0.12; c->poseoptim_thresh = 2.0; c->triang_min_corner_score = 20.0;
 }
 
@@ -104,6 +107,9 @@ void* pipe_create_cam(int width, int height, int cam_model, const double* p9, co
     svo_hip::Device::instance().configure(width, height, levels, c->pool_slots);
   }
 #endif
+#ifdef SVO_PIPELINE_HIP
+  svo_hip::Device::setDeferredMapping(c->defer_mapper != 0 && !c->mapper_thread);
+#endif
   std::srand((unsigned)c->shuffle_seed);  // Reprojector::initializeGrid's random_shuffle (reprojector.cpp:54)
   p->vo = new FrameHandlerMono(p->cam);
   p->vo->start();
@@ -115,6 +121,9 @@ void* pipe_create_cam(int width, int height, int cam_model, const double* p9, co
 
 void pipe_destroy(void* h) {
   Pipe* p = (Pipe*)h;
+#ifdef SVO_PIPELINE_HIP
+  svo_hip::Device::joinDeferredAll();  // a deferred update writes into the DepthFilter that is about to go
+#endif
   delete p->vo;
 #ifdef SVO_TRACE
   // ~FrameHandlerBase deletes the process-global trace monitor (frame_handler_base.cpp:82-84);
@@ -199,11 +208,12 @@ int pipe_add_image(void* h, const uint8_t* img, double timestamp, pipe_result* o
 }
 
 // pyramid-cache statistics of the device context (hip flavour; zeros otherwise)
-void pipe_device_stats(uint64_t out[3]) {
-  out[0] = out[1] = out[2] = 0;
+void pipe_device_stats(uint64_t out[5]) {
+  out[0] = out[1] = out[2] = out[3] = out[4] = 0;
 #ifdef SVO_PIPELINE_HIP
   const svo_hip::Device::Stats st = svo_hip::Device::instance().statsSnapshot();
   out[0] = st.uploads; out[1] = st.evictions; out[2] = st.calls;
+  out[3] = st.spec_hits; out[4] = st.spec_misses;  // pose refinements taken from / not taken from the reprojector's prediction
 #endif
 }
 

@@ -17,7 +17,7 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_pyr_levels", "klt_max_level", "klt_min_level", "grid_size", "max_fts",
                                          "max_n_kfs", "quality_min_fts", "quality_max_drop_fts",
                                          "structureoptim_max_pts", "structureoptim_num_iter", "poseoptim_num_iter",
-                                         "shuffle_seed", "mapper_thread", "pool_slots")] + \
+                                         "shuffle_seed", "mapper_thread", "pool_slots", "defer_mapper")] + \
                [(n, C.c_double) for n in ("kfselect_mindist", "poseoptim_thresh", "triang_min_corner_score")]
 
 
@@ -100,8 +100,9 @@ class Pipeline:
         return r.as_dict()
 
     def device_stats(self):
-        """(pyramid uploads, evictions, device calls) of the process-wide svo_hip::Device."""
-        out = (C.c_uint64 * 3)()
+        """(pyramid uploads, evictions, device calls, predicted pose refinements taken, not taken) of the process-wide
+        svo_hip::Device."""
+        out = (C.c_uint64 * 5)()
         self.lib.pipe_device_stats(out)
         return tuple(int(x) for x in out)
 
@@ -144,11 +145,17 @@ def run_sequence(flavour, cam, images, T_gt, stats_out=None, range0=None, **cfg)
         n0, r0 = p.set_first_frame(images[0], 0.0, T_gt[0], range_map(cam, T_gt[0]) if range0 is None else range0)
         r0["n_first_features"] = n0
         out = [r0]
+        import time
+        t_loop = time.perf_counter()
         for i in range(1, len(images)):
             out.append(p.add_image(images[i], float(i)))
+        t_loop = time.perf_counter() - t_loop
         if stats_out is not None:
+            # frame period with the frames fed back to back (includes the harness' own per-call overhead)
+            stats_out["wall_ms_per_frame"] = 1e3 * t_loop / max(1, len(images) - 1)
             s1 = p.device_stats()
-            stats_out.update(uploads=s1[0] - s0[0], evictions=s1[1] - s0[1], calls=s1[2] - s0[2])
+            stats_out.update(uploads=s1[0] - s0[0], evictions=s1[1] - s0[1], calls=s1[2] - s0[2],
+                             predicted_pose_hits=s1[3] - s0[3], predicted_pose_misses=s1[4] - s0[4])
             dt = p.stage_times() - t0
             stages = {}
             for k, name in enumerate(Pipeline.STAGES):

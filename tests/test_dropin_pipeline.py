@@ -86,13 +86,17 @@ def test_dropin_library_links_every_symbol(pipeline_libs):
 def test_dropin_trajectory_matches_cpu_reference(pipeline_libs, gpu_device):
     cam, imgs, T = _sequence(120)
     ref = pp.run_sequence("ref", cam, imgs, T)
-    hip = pp.run_sequence("hip", cam, imgs, T)
+    st = {}
+    hip = pp.run_sequence("hip", cam, imgs, T, stats_out=st)
     Tr = np.stack([r["T_f_w"] for r in ref])
     Th = np.stack([r["T_f_w"] for r in hip])
     d = se3.log_norm(Th, Tr)
     ate = _horn_ate(se3.inv(Th)[:, 9:], se3.inv(Tr)[:, 9:])
     print(f"drop-in vs CPU reference over {len(imgs)} frames: SE3 log-norm max {d.max():.3e} median {np.median(d):.3e}; "
-          f"ATE {ate:.3e} m; keyframes {sum(r['is_keyframe'] for r in ref)}")
+          f"ATE {ate:.3e} m; keyframes {sum(r['is_keyframe'] for r in ref)}; pose refinements taken from the reprojector's "
+          f"prediction {st['predicted_pose_hits']}, not taken {st['predicted_pose_misses']}")
+    # every frame's pose refinement was enqueued behind its match kernels, with the device picking the host's features
+    assert st["predicted_pose_misses"] == 0 and st["predicted_pose_hits"] == len(imgs) - 1
     assert d.max() <= SE3_LOGNORM_TOL
     assert ate <= ATE_TOL_M
     # same decisions: keyframes at the same frames, same match / tracking counts
@@ -222,6 +226,28 @@ def test_dropin_with_asynchronous_mapper_thread(pipeline_libs, gpu_device):
 
 
 @pytest.mark.gpu
+def test_dropin_deferred_mapper_is_the_synchronous_one(pipeline_libs, gpu_device):
+    """svo_hip::Device::setDeferredMapping(true): DepthFilter::updateSeeds returns with its kernels running and its
+    results reach the seed list / the map at the next reprojectMap, updateSeeds or detect.  Every consumer sees what the
+    synchronous filter would have left, so the trajectory is IDENTICAL; only the harness' own read-out of the seed and
+    candidate counts (taken right after addImage) lags by that one update."""
+    cam, imgs, T = _sequence(120)
+    a_st, b_st = {}, {}
+    a = pp.run_sequence("hip", cam, imgs, T, stats_out=a_st)
+    b = pp.run_sequence("hip", cam, imgs, T, stats_out=b_st, defer_mapper=1)
+    assert np.array_equal(np.stack([r["T_f_w"] for r in a]), np.stack([r["T_f_w"] for r in b]))
+    for k in ("is_keyframe", "n_obs", "repr_n_mps", "repr_n_new_references", "n_kfs", "stage"):
+        assert [r[k] for r in a] == [r[k] for r in b], k
+    assert a[-1]["n_seeds"] > 0 and sum(r["n_candidates"] for r in b) > 0
+    ta, tb = (np.median([r["t_tot_time"] for r in x[1:]]) * 1e3 for x in (a, b))
+    print(f"addImage median {ta:.3f} ms synchronous, {tb:.3f} ms with the mapper deferred; frame period "
+          f"{a_st['wall_ms_per_frame']:.3f} / {b_st['wall_ms_per_frame']:.3f} ms")
+    # a second sequence in the same process after a deferred one: nothing pending leaks across handlers
+    c = pp.run_sequence("hip", cam, imgs[:30], T[:30])
+    assert np.array_equal(np.stack([r["T_f_w"] for r in c]), np.stack([r["T_f_w"] for r in a[:30]]))
+
+
+@pytest.mark.gpu
 def test_dropin_small_pyramid_pool_evicts_and_reuploads(pipeline_libs, gpu_device):
     """A device pool of 7 pyramid slots for a run that keeps up to 5 keyframes + 2 working frames
     alive: live frames get evicted (LRU) and uploaded again on their next use; the trajectory
@@ -261,9 +287,40 @@ def test_two_cameras_of_different_geometry_in_one_process(pipeline_libs, gpu_dev
 
 
 @pytest.mark.gpu
-def test_dropin_mapped_arena_follows_the_mirrored_one(pipeline_libs, gpu_device, tmp_path):
-    """SVO_HIP_ARENA=mapped (kernels read and write the pinned host arena, no copy commands) against the default
-    mirrored arena: same kernels on the same bytes.  The mode is fixed when a lane is created, hence one process each."""
+def test_dropin_without_prediction_follows_the_predicting_one(pipeline_libs, gpu_device, tmp_path):
+    """SVO_HIP_SPECULATE=0 (pose refinement as a call of its own, observations marshalled by the host) against the
+    default (enqueued by the reprojector, observations gathered on the device): the same optimizer on the same
+    observations up to the summation order of a wave with a different number of observations per lane."""
+    import subprocess
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {HERE!r}); sys.path.insert(0, {os.path.join(HERE, 'dropin')!r})\n"
+        "import pypipeline as pp\n"
+        "import test_dropin_pipeline as t\n"
+        "cam, imgs, T = t._sequence(60)\n"
+        "st = {}\n"
+        "hip = pp.run_sequence('hip', cam, imgs, T, stats_out=st)\n"
+        "np.save(sys.argv[1], np.stack([r['T_f_w'] for r in hip]))\n"
+        "print(st['predicted_pose_hits'], st['predicted_pose_misses'])\n")
+    out, hits = {}, {}
+    for mode in ("1", "0"):
+        path = str(tmp_path / f"traj_{mode}.npy")
+        p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, SVO_HIP_SPECULATE=mode), capture_output=True,
+                           text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out[mode] = np.load(path)
+        hits[mode] = [int(x) for x in p.stdout.split()[-2:]]
+    assert hits["1"] == [59, 0] and hits["0"] == [0, 0]
+    d = se3.log_norm(out["0"], out["1"])
+    assert d.max() <= SE3_LOGNORM_TOL, d.max()
+
+
+@pytest.mark.gpu
+def test_dropin_arena_modes_agree(pipeline_libs, gpu_device, tmp_path):
+    """SVO_HIP_ARENA=hybrid (the default: inputs mirrored in HBM, results written by the kernels straight into the pinned
+    host arena, the host polling the selection kernel's signal instead of waiting for the stream), =mirrored (every block
+    copied both ways, prediction on a second stream) and =mapped (no copy commands at all): the same kernels on the same
+    bytes.  The mode is fixed when a lane is created, hence one process each."""
     import subprocess
     code = (
         "import sys, numpy as np\n"
@@ -274,11 +331,12 @@ def test_dropin_mapped_arena_follows_the_mirrored_one(pipeline_libs, gpu_device,
         "hip = pp.run_sequence('hip', cam, imgs, T)\n"
         "np.save(sys.argv[1], np.stack([r['T_f_w'] for r in hip]))\n")
     out = {}
-    for mode in ("mirrored", "mapped"):
+    for mode in ("hybrid", "mirrored", "mapped"):
         path = str(tmp_path / f"traj_{mode}.npy")
         p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, SVO_HIP_ARENA=mode), capture_output=True,
                            text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-2000:]
         out[mode] = np.load(path)
-    d = se3.log_norm(out["mapped"], out["mirrored"])
-    assert d.max() <= SE3_LOGNORM_TOL, d.max()
+    for mode in ("mirrored", "mapped"):
+        d = se3.log_norm(out[mode], out["hybrid"])
+        assert d.max() <= SE3_LOGNORM_TOL, (mode, d.max())

@@ -334,3 +334,55 @@ def test_reproject_point(libs, scene):
         k_o, p_o = orc.reproject_point(scene.cam, scene.T_cur_prior, scene.pt_pos[i], 30, 22)
         k_r, p_r = ref.reproject_point(scene.cam, scene.T_cur_prior, scene.pt_pos[i], 30, 22)
         assert k_o == k_r and same(p_o, p_r)
+
+
+def test_cam2world(libs, cam):
+    """Frame::c2f -- what the Feature constructor stores in Feature::f (feature.h:44-52) -- for pixels all over the image"""
+    orc, ref = libs
+    rng = np.random.default_rng(8)
+    px = np.stack([rng.uniform(0, cam.width, 500), rng.uniform(0, cam.height, 500)], axis=1)
+    assert same(orc.cam2world(cam, px), ref.cam2world(cam, px))
+
+
+def _walk_cells(cell, ok, max_fts):
+    """Reprojector::reprojectMap's cell loop as the reference writes it (reprojector.cpp:131-139, 150-200): a list per
+    cell, erase on failure, return at the first success."""
+    cells, order = {}, []
+    for m, c in enumerate(cell):
+        if c not in cells:
+            cells[c] = []
+            order.append(c)
+        cells[c].append(m)
+    chosen, n_matches = [], 0
+    for c in order:
+        lst = cells[c]
+        matched = False
+        while lst:
+            m = lst.pop(0)
+            if not ok[m]:
+                continue
+            chosen.append(m)
+            matched = True
+            break
+        if matched:
+            n_matches += 1
+        if n_matches > max_fts:
+            break
+    return chosen
+
+
+@pytest.mark.parametrize("max_fts", [0, 5, 120, 10000])
+def test_select_matches(libs, cam, max_fts):
+    orc, _ = libs
+    rng = np.random.default_rng(max_fts + 1)
+    for M in (0, 1, 7, 300, 1500):
+        runs = rng.integers(1, 9, size=M + 1)
+        cell = np.repeat(rng.permutation(M + 1), runs)[:M].astype(np.int32)   # cells in a shuffled order, runs of 1-8 trials
+        ok = (rng.uniform(size=M) < 0.4).astype(np.int32)
+        px = np.stack([rng.uniform(0, cam.width, M), rng.uniform(0, cam.height, M)], axis=1).reshape(M, 2)
+        level = rng.integers(0, 4, size=M).astype(np.int32)
+        pos = rng.normal(size=(M, 3))
+        sel, f, lvl, p = pytrack.select_matches(cam, cell, ok, px, level, pos, max_fts)
+        want = _walk_cells(cell.tolist(), ok.tolist(), max_fts)
+        assert sel.tolist() == want and len(want) <= max_fts + 1
+        assert same(f, orc.cam2world(cam, px[want]).reshape(-1, 3)) and same(lvl, level[want]) and same(p, pos[want])

@@ -488,3 +488,28 @@ def test_update_seed_batch(gpu_device, orc):
     assert np.allclose(g[:, 2], w[:, 2], rtol=2e-6, atol=0)                                   # mu
     assert (np.abs(g[:, 3] - w[:, 3]) <= 1e-4 * np.abs(w[:, 3]) + 1e-6 * w[:, 2] ** 2).all()    # sigma2 (see above)
     assert np.allclose(g[:, :2], w[:, :2], rtol=5e-3, atol=1e-5)                               # a, b
+
+
+@pytest.mark.parametrize("kind", CAMERA_KINDS)
+def test_select_matches_like_the_cell_loop(gpu_device, kind):
+    """svo_hip_select_matches against the restated cell loop of Reprojector::reprojectMap (reprojector.cpp:131-139,
+    150-200): which trials become features, in which order, and the observation each one hands to the pose optimizer.
+    Indices / levels / positions identical; the bearing within 1e-14 (device tan / sqrt of the ATAN model)."""
+    cam = camera_models()[kind]
+    rng = np.random.default_rng(77)
+    for M, max_fts in ((0, 120), (1, 120), (7, 0), (130, 120), (300, 120), (300, 40), (1500, 120), (1500, 10000), (5000, 700)):
+        runs = rng.integers(1, 9, size=M + 1)
+        cell = np.repeat(rng.permutation(M + 1), runs)[:M].astype(np.int32)
+        ok = (rng.uniform(size=M) < 0.45).astype(np.int32)
+        px = np.stack([rng.uniform(0, cam.width, M), rng.uniform(0, cam.height, M)], axis=1).reshape(M, 2)
+        level = rng.integers(0, 4, size=M).astype(np.int32)
+        pos = rng.normal(size=(M, 3))
+        sel_o, f_o, lvl_o, pos_o = pytrack.select_matches(cam, cell, ok, px, level, pos, max_fts)
+        n, sel, f, lvl, p, has = tracking.select_matches(cam, dev(cell, torch.int32), dev(ok, torch.int32), dev(px, torch.float64),
+                                                         dev(level, torch.int32), dev(pos, torch.float64), max_fts)
+        k = int(n.item())
+        assert k == len(sel_o)
+        assert np.array_equal(sel[:k].cpu().numpy(), sel_o) and np.array_equal(lvl[:k].cpu().numpy(), lvl_o)
+        assert np.array_equal(p[:k].cpu().numpy(), pos_o) and bool((has[:k] == 1).all())
+        if k:
+            assert np.abs(f[:k].cpu().numpy() - f_o).max() <= 1e-14
