@@ -32,6 +32,12 @@ python $R/scripts/kernel_last_steps.py $O/trace_full 10 > $O/full_kernel_last_st
 echo "== drop-in sequence under kernel trace"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_dropin -o trace -- python -c "import sys; sys.path.insert(0, '$R'); import bench, json; print(json.dumps(bench.dropin_sequence(120)))" > $O/dropin_under_trace.json 2> $O/trace_dropin.err
 stats $O/trace_dropin $O/dropin_kernel_stats.csv
+echo "== drop-in frame timeline (HIP API + kernels + copies of a median frame)"
+rocprofv3 --hip-trace --kernel-trace --memory-copy-trace --output-format csv -d $O/trace_timeline -- python $R/scripts/dropin_trace.py > $O/dropin_traced_run.txt 2> $O/trace_timeline.err
+python $R/scripts/dropin_trace.py --report $O/trace_timeline 100 > $O/dropin_frame_timeline.txt
+python $R/scripts/dropin_trace.py > $O/dropin_untraced_sync.txt 2>/dev/null
+python $R/scripts/dropin_trace.py defer > $O/dropin_untraced_deferred.txt 2>/dev/null
+rm -rf $O/trace_timeline
 echo "== valu microbenchmark"; [ -x $R/build/valu_ubench ] && $R/build/valu_ubench > $O/valu_ubench.json
 find $O -name "*.csv" -size +300k -delete; find $O -name "*.db" -delete
 ls -la $O
