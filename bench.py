@@ -1092,7 +1092,7 @@ def dropin_sequence(n_frames: int = 120) -> dict:
             # arena and back (marshal/unmarshal) against the device round trip (H2D + kernels + D2H + sync)
             "host_vs_device_us_per_call": {k: {q: round(v, 2) if isinstance(v, float) else v for q, v in st.items()}
                                            for k, st in host.get("stages", {}).items()},
-            "pyramid_uploads": host.get("uploads"), "pyramid_upload_us_per_frame": host.get("pyramid_upload_us_total", 0.0) / n_frames}
+            "pyramid_uploads": host.get("uploads"), "pyramid_upload_us_per_frame": host.get("pyramid_upload_us_total", 0.0) / max(1, n_frames - 1)}
 
 
 _CPU_REF: dict = {}  # poses and iteration counts of the CPU reference run (cpu_baseline), for the f64_partials leg

@@ -444,18 +444,43 @@ struct SelectArgs {
 };
 __global__ void __launch_bounds__(256) match_select_kernel(const SelectArgs a) {
   __shared__ int s_wave[4];
+  __shared__ int s_ok[256], s_cell[256];
+  __shared__ int s_carry[2];  // cell of the last trial of the pass before, and whether that cell has matched already
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // everything enqueued before this kernel has completed (stream order): tell a host that polls mapped memory
   if (a.signal && tid == 0) __hip_atomic_store(a.signal, a.signal_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tid == 0) { s_carry[0] = -1; s_carry[1] = 0; }
   int base = 0;  // selected trials before this pass (the same in every thread)
   for (int m0 = 0; m0 < a.M && base < a.max_selected; m0 += 256) {
     const int m = m0 + tid;
-    bool first = false;
-    if (m < a.M && a.ok[m] != 0) {
-      first = true;
-      const int c = a.cell[m];
-      for (int j = m - 1; j >= 0 && a.cell[j] == c; --j)
-        if (a.ok[j] != 0) { first = false; break; }
+    const bool valid = m < a.M;
+    // every global read of the pass is issued here, before anything depends on one: the match results may live in
+    // host-mapped memory, where a dependent chain of loads costs a link round trip per link
+    const int ok = valid ? (a.ok[m] != 0) : 0;
+    const int cell = valid ? a.cell[m] : -2;
+    const double u = valid ? a.px[2 * m] : 0.0, v = valid ? a.px[2 * m + 1] : 0.0;
+    const int lvl = valid ? a.level[m] : 0;
+    double pos[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pos[k] = valid ? a.pos[3 * m + k] : 0.0;
+    s_ok[tid] = ok;
+    s_cell[tid] = cell;
+    __syncthreads();
+    // first success of its cell: nothing matched among the cell's earlier trials (this pass: LDS; earlier passes: carry)
+    bool first = ok != 0;
+    if (first) {
+      int j = tid - 1;
+      for (; j >= 0 && s_cell[j] == cell; --j)
+        if (s_ok[j]) { first = false; break; }
+      if (first && j < 0 && cell == s_carry[0] && s_carry[1]) first = false;
+    }
+    int carry_cell = 0, carry_matched = 0;
+    if (tid == 255) {  // (only read when another pass follows, i.e. when this pass was full)
+      carry_cell = cell;
+      carry_matched = ok;
+      int j = 254;
+      for (; !carry_matched && j >= 0 && s_cell[j] == cell; --j) carry_matched = s_ok[j];
+      if (!carry_matched && j < 0 && cell == s_carry[0]) carry_matched = s_carry[1];
     }
     const unsigned long long b = __ballot(first);
     if (lane == 0) s_wave[wave] = __popcll(b);
@@ -463,17 +488,18 @@ __global__ void __launch_bounds__(256) match_select_kernel(const SelectArgs a) {
     int rank = base + __popcll(b & ((1ull << lane) - 1ull));
     for (int w = 0; w < wave; ++w) rank += s_wave[w];
     base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (tid == 255) { s_carry[0] = carry_cell; s_carry[1] = carry_matched; }
     __syncthreads();
     if (first && rank < a.max_selected) {
       double f[3];
-      cam2world(a.cam, a.px[2 * m], a.px[2 * m + 1], f);
+      cam2world(a.cam, u, v, f);
       a.sel[rank] = m;
-      a.level_out[rank] = a.level[m];
+      a.level_out[rank] = lvl;
       a.has_point[rank] = 1;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         a.f[3 * rank + k] = f[k];
-        a.pos_out[3 * rank + k] = a.pos[3 * m + k];
+        a.pos_out[3 * rank + k] = pos[k];
       }
     }
   }

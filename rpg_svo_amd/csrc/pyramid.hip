@@ -253,6 +253,13 @@ struct Staging {
   }
 };
 
+// h rows of w bytes from a host image into the packed staging buffer.  Packed rows (the usual cv::Mat) go as ONE linear
+// copy: from pageable memory the runtime stages a 2-D copy through a blit kernel of its own, which a linear copy avoids.
+hipError_t copy_rows_h2d(uint8_t* d_dst, const uint8_t* image, int w, int h, int row_stride, hipStream_t s) {
+  if (row_stride == w) return hipMemcpyAsync(d_dst, image, (size_t)w * h, hipMemcpyHostToDevice, s);
+  return hipMemcpy2DAsync(d_dst, w, image, row_stride, w, h, hipMemcpyHostToDevice, s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -284,7 +291,7 @@ static int upload_one_level(const svo_hip_pyr_layout* L, uint8_t* d_store, int s
   Staging st(s);
   int rc = st.get(d_staging, (size_t)w * h);
   if (rc) return rc;
-  SVO_HIP_TRY(hipMemcpy2DAsync(st.p, w, image, row_stride, w, h, hipMemcpyHostToDevice, s));
+  SVO_HIP_TRY(copy_rows_h2d(st.p, image, w, h, row_stride, s));
   const dim3 block(64, 4, 1), grid((w / 4 + 1 + 63) / 64, (h + 3) / 4, 1);
   hipLaunchKernelGGL(load_level_kernel, grid, block, 0, s, d_store, L->slot_bytes, slot, L->offset[level], L->pitch[level],
                      w, h, st.p, (int64_t)0, w);
@@ -435,7 +442,7 @@ int svo_hip_pyramid_upload_build(const svo_hip_pyr_layout* L, uint8_t* d_store, 
   Staging st(s);
   int rc = st.get(d_staging, (size_t)w * h);
   if (rc) return rc;
-  SVO_HIP_TRY(hipMemcpy2DAsync(st.p, w, image, row_stride, w, h, hipMemcpyHostToDevice, s));
+  SVO_HIP_TRY(copy_rows_h2d(st.p, image, w, h, row_stride, s));
   return build_impl(L, d_store, slot, 1, st.p, (int64_t)w * h, w, halfsample_mode, 0, s);
 }
 

@@ -34,7 +34,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_dropin -o trace
 stats $O/trace_dropin $O/dropin_kernel_stats.csv
 echo "== drop-in frame timeline (HIP API + kernels + copies of a median frame)"
 rocprofv3 --hip-trace --kernel-trace --memory-copy-trace --output-format csv -d $O/trace_timeline -- python $R/scripts/dropin_trace.py > $O/dropin_traced_run.txt 2> $O/trace_timeline.err
-python $R/scripts/dropin_trace.py --report $O/trace_timeline 100 > $O/dropin_frame_timeline.txt
+python $R/scripts/dropin_trace.py --report $O/trace_timeline > $O/dropin_frame_timeline.txt
 python $R/scripts/dropin_trace.py > $O/dropin_untraced_sync.txt 2>/dev/null
 python $R/scripts/dropin_trace.py defer > $O/dropin_untraced_deferred.txt 2>/dev/null
 rm -rf $O/trace_timeline

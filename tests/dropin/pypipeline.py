@@ -141,10 +141,10 @@ def run_sequence(flavour, cam, images, T_gt, stats_out=None, range0=None, **cfg)
     p = Pipeline(flavour, cam, **cfg)
     try:
         s0 = p.device_stats()
-        t0 = p.stage_times()
         n0, r0 = p.set_first_frame(images[0], 0.0, T_gt[0], range_map(cam, T_gt[0]) if range0 is None else range0)
         r0["n_first_features"] = n0
         out = [r0]
+        t0 = p.stage_times()  # per-call times of addImage() only (the first frame also pays for first-use set-up)
         import time
         t_loop = time.perf_counter()
         for i in range(1, len(images)):

@@ -37,6 +37,11 @@ def test_bad_arguments_are_rejected(hip_lib, gpu_device):
                                     None, None, None, None, 0, None) < 0
     assert lib.svo_hip_update_seed_batch(3, None, None, C.byref(sd), None) == EINVAL
     assert lib.svo_hip_compute_tau_batch(3, None, None, None, 0.001, None, None) == EINVAL
+    # the reprojector's selection rule
+    assert lib.svo_hip_select_matches(None, 4, p, p, p, p, p, 120, p, p, p, p, p, p, None, 0, None) == EINVAL
+    assert lib.svo_hip_select_matches(C.byref(cam), -1, p, p, p, p, p, 120, p, p, p, p, p, p, None, 0, None) == EINVAL
+    assert lib.svo_hip_select_matches(C.byref(cam), 4, None, p, p, p, p, 120, p, p, p, p, p, p, None, 0, None) == EINVAL
+    assert lib.svo_hip_select_matches(C.byref(cam), 4, p, p, p, p, p, -1, p, p, p, p, p, p, None, 0, None) == EINVAL
     # pose / point optimizers
     assert lib.svo_hip_pose_optimize(None, 1, None, 10, None, None, None, None, 2.0, 10, None, None, None, None, None) == EINVAL
     assert lib.svo_hip_pose_optimize(C.byref(cam), 1, p, 1 << 20, p, p, p, p, 2.0, 10, p, None, p, p, None) == ERANGE
