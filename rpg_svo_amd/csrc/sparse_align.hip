@@ -200,6 +200,18 @@ __device__ __forceinline__ void sia_touch(const uint8_t* base, uint32_t off, uin
 
 // DIST: the camera is a distorted model (radial-tangential pinhole or ATAN); the undistorted pinhole
 // keeps its own instantiation so that its inner loop carries no model dispatch.
+// SIA_PACKED: the pixel loop of an evaluation on v_pk_*_f32, two pixels per instruction (default; the
+// reference-width build keeps its f64 sums and the scalar loop).  -DSIA_PACKED=0 builds the scalar loop for A/B timing.
+#ifndef SIA_PACKED
+#ifdef SIA_F64_PARTIALS
+#define SIA_PACKED 0
+#else
+#define SIA_PACKED 1
+#endif
+#endif
+#if SIA_PACKED && defined(SIA_F64_PARTIALS)
+#error "the packed pixel loop keeps its sums in f32 pairs"
+#endif
 template <int BLOCK, bool WC, bool DIST>
 __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK)) sia_kernel(const SiaArgs a) {
   constexpr int NW = BLOCK / 64;
@@ -386,6 +398,17 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
             Sxy += (sia_acc)dx * (sia_acc)dy;
             Syy += (sia_acc)dy * (sia_acc)dy;
           }
+#if SIA_PACKED
+        // columns in the order the packed pixel loop pairs them: (0,2) (1,3) (4,5) per row, (1,3) (2,4) in rows 0 and 5
+        s_bt[0][tid] = make_float4(Bt[0][1], Bt[0][3], Bt[0][2], Bt[0][4]);
+        s_bt[1][tid] = make_float4(Bt[1][0], Bt[1][2], Bt[1][1], Bt[1][3]);
+        s_bt[2][tid] = make_float4(Bt[1][4], Bt[1][5], Bt[2][0], Bt[2][2]);
+        s_bt[3][tid] = make_float4(Bt[2][1], Bt[2][3], Bt[2][4], Bt[2][5]);
+        s_bt[4][tid] = make_float4(Bt[3][0], Bt[3][2], Bt[3][1], Bt[3][3]);
+        s_bt[5][tid] = make_float4(Bt[3][4], Bt[3][5], Bt[4][0], Bt[4][2]);
+        s_bt[6][tid] = make_float4(Bt[4][1], Bt[4][3], Bt[4][4], Bt[4][5]);
+        s_bt[7][tid] = make_float4(Bt[5][1], Bt[5][3], Bt[5][2], Bt[5][4]);
+#else
         s_bt[0][tid] = make_float4(Bt[0][1], Bt[0][2], Bt[0][3], Bt[0][4]);
         s_bt[1][tid] = make_float4(Bt[1][0], Bt[1][1], Bt[1][2], Bt[1][3]);
         s_bt[2][tid] = make_float4(Bt[1][4], Bt[1][5], Bt[2][0], Bt[2][1]);
@@ -394,6 +417,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
         s_bt[5][tid] = make_float4(Bt[3][4], Bt[3][5], Bt[4][0], Bt[4][1]);
         s_bt[6][tid] = make_float4(Bt[4][2], Bt[4][3], Bt[4][4], Bt[4][5]);
         s_bt[7][tid] = make_float4(Bt[5][1], Bt[5][2], Bt[5][3], Bt[5][4]);
+#endif
       } else {
         // jacobian_cache_.setZero() (:64): the J columns of a feature skipped here
         // stay zero; a stale ref_patch_cache_ row (if any) is kept
@@ -466,6 +490,109 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
           const float wbl = (1.f - su) * sv;
           const float wbr = su * sv;
           {
+#if SIA_PACKED
+          // Two pixels per instruction (v_pk_mul/fma/add_f32): columns x = 0, 2 in one register pair, x = 1, 3 in
+          // another.  Every pixel sees the same operations in the same order as in the scalar loop (its intensity and
+          // residual are the same bits); the sums over the patch are formed as two interleaved partial sums.
+          // Rows slide: window row y+2 is cut and tile row y+3 is fetched from LDS while rows y, y+1 are used, so that a
+          // third of the 5x5 window and half of the 6x6 tile are live at a time (all of both at once does not fit 128
+          // VGPRs: 13 spills).  The empty asm statements keep the compiler from gathering all rows up front again.
+          typedef float f2 __attribute__((ext_vector_type(2)));
+          uint32_t cw[5][3];
+          uint32_t cbo = 0;
+          uint64_t k0 = 0, k1 = 0, kup = 0;
+          int bo = 0;
+          if (WC) {
+            int r0 = (v_i - 2) - wc_v0;  // first cached row needed
+            bo = (u_i - 2) - wc_u0;      // first cached byte needed
+            if (!(r0 >= 0 && r0 <= 2 && bo >= 0 && bo <= 7)) {
+              wc_v0 = v_i - 3;
+              wc_u0 = run_start(u_i - 3, 7);
+              load_window12<(WC ? 7 : 1)>(cur_img, pitch, wc_u0, wc_v0, wc);
+              r0 = 1;
+              bo = (u_i - 2) - wc_u0;
+            }
+            k0 = __builtin_amdgcn_ballot_w64(r0 == 0);
+            k1 = __builtin_amdgcn_ballot_w64(r0 == 1);
+            kup = __builtin_amdgcn_ballot_w64(bo >= 4);
+          } else {
+            const int cxa = run_start(u_i - 2, 5);
+            cbo = (uint32_t)(u_i - 2 - cxa);  // 0..7
+            load_window12<5>(cur_img, pitch, cxa, v_i - 2, cw);
+          }
+          // window row r as the three column pairs (0,2) (1,3) (2,4)
+#define SIA_WIN_ROW(r, p02, p13, p24)                                                                                   \
+  do {                                                                                                                  \
+    float o_[5];                                                                                                        \
+    if (WC) {                                                                                                           \
+      constexpr int S_ = WC ? 1 : 0;                                                                                    \
+      const uint32_t d0_ = sel_e64(k0, wc[(r) * S_][0], sel_e64(k1, wc[((r) + 1) * S_][0], wc[((r) + 2) * S_][0]));     \
+      const uint32_t d1_ = sel_e64(k0, wc[(r) * S_][1], sel_e64(k1, wc[((r) + 1) * S_][1], wc[((r) + 2) * S_][1]));     \
+      const uint32_t d2_ = sel_e64(k0, wc[(r) * S_][2], sel_e64(k1, wc[((r) + 1) * S_][2], wc[((r) + 2) * S_][2]));     \
+      cut_row5(d0_, d1_, d2_, bo, kup, o_);                                                                             \
+    } else {                                                                                                            \
+      cut_row5_plain(cw[WC ? 0 : (r)], cbo, o_);                                                                        \
+    }                                                                                                                   \
+    p02 = f2{o_[0], o_[2]};                                                                                             \
+    p13 = f2{o_[1], o_[3]};                                                                                             \
+    p24 = f2{o_[2], o_[4]};                                                                                             \
+  } while (0)
+          // tile rows from LDS as float2 (layout written by the precompute block): row 0 / 5: (1,3) (2,4);
+          // rows 1-4: (0,2) (1,3) (4,5), from which (2,4) and (3,5) are put together
+          const float2* const bt2 = reinterpret_cast<const float2*>(&s_bt[0][0]);
+          // float2 index of (quad q, half h) of this lane: (q * BLOCK + tid) * 2 + h
+#define SIA_BT2(q, h) bt2[((q) * BLOCK + tid) * 2 + (h)]
+          const f2 vtl = f2{wtl, wtl}, vtr = f2{wtr, wtr}, vbl = f2{wbl, wbl}, vbr = f2{wbr, wbr};
+          f2 c2v = f2{0.f, 0.f}, gxv = f2{0.f, 0.f}, gyv = f2{0.f, 0.f};
+          f2 t02, t13, t24, b02, b13, b24;  // window rows y and y+1
+          SIA_WIN_ROW(0, t02, t13, t24);
+          SIA_WIN_ROW(1, b02, b13, b24);
+          // tile rows y (a), y+1 (b), y+2 (c)
+          f2 a13, a24, b02t, b13t, b45t, c02, c13, c45;
+          { const float2 v0 = SIA_BT2(0, 0), v1 = SIA_BT2(0, 1); a13 = f2{v0.x, v0.y}; a24 = f2{v1.x, v1.y}; }
+          { const float2 v0 = SIA_BT2(1, 0), v1 = SIA_BT2(1, 1), v2 = SIA_BT2(2, 0);
+            b02t = f2{v0.x, v0.y}; b13t = f2{v1.x, v1.y}; b45t = f2{v2.x, v2.y}; }
+          { const float2 v0 = SIA_BT2(2, 1), v1 = SIA_BT2(3, 0), v2 = SIA_BT2(3, 1);
+            c02 = f2{v0.x, v0.y}; c13 = f2{v1.x, v1.y}; c45 = f2{v2.x, v2.y}; }
+#pragma unroll
+          for (int y = 0; y < 4; ++y) {
+            // next rows on their way: tile row y+3, window row y+2
+            f2 n02 = f2{0.f, 0.f}, n13 = f2{0.f, 0.f}, n45 = f2{0.f, 0.f};
+            if (y == 0) { const float2 v0 = SIA_BT2(4, 0), v1 = SIA_BT2(4, 1), v2 = SIA_BT2(5, 0);
+                          n02 = f2{v0.x, v0.y}; n13 = f2{v1.x, v1.y}; n45 = f2{v2.x, v2.y}; }
+            if (y == 1) { const float2 v0 = SIA_BT2(5, 1), v1 = SIA_BT2(6, 0), v2 = SIA_BT2(6, 1);
+                          n02 = f2{v0.x, v0.y}; n13 = f2{v1.x, v1.y}; n45 = f2{v2.x, v2.y}; }
+            if (y == 2) { const float2 v0 = SIA_BT2(7, 0), v1 = SIA_BT2(7, 1);
+                          n13 = f2{v0.x, v0.y}; n45 = f2{v1.x, v1.y}; }  // row 5: (1,3) and (2,4)
+            const f2 b24t = f2{b02t.y, b45t.x}, b35t = f2{b13t.y, b45t.y};
+            // row y+2's (2,4): put together for rows 2-4, stored as such for row 5
+            const f2 c24 = (y < 3) ? f2{c02.y, c45.x} : c45;
+            const f2 Ia = vtl * t02 + vtr * t13 + vbl * b02 + vbr * b13;  // pixels x = 0, 2
+            const f2 Ib = vtl * t13 + vtr * t24 + vbl * b13 + vbr * b24;  // pixels x = 1, 3
+            const f2 ra = Ia - b13t, rb = Ib - b24t;
+            c2v += ra * ra;
+            c2v += rb * rb;
+            gxv += ra * (b24t - b02t);
+            gxv += rb * (b35t - b13t);
+            gyv += ra * (c13 - a13);
+            gyv += rb * (c24 - a24);
+            if (y < 3) {
+              f2 w02, w13, w24;
+              SIA_WIN_ROW(y + 2, w02, w13, w24);
+              t02 = b02; t13 = b13; t24 = b24;
+              b02 = w02; b13 = w13; b24 = w24;
+              a13 = b13t; a24 = b24t;
+              b02t = c02; b13t = c13; b45t = c45;
+              c02 = n02; c13 = n13; c45 = n45;
+              asm volatile("" ::: "memory");
+            }
+          }
+#undef SIA_WIN_ROW
+#undef SIA_BT2
+          c2 += c2v.x + c2v.y;
+          gx += gxv.x + gxv.y;
+          gy += gyv.x + gyv.y;
+#else
           float W[5][5];
 #ifdef SIA_DBG_NOLOAD
 #pragma unroll
@@ -526,6 +653,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
               gx += (sia_acc)res * (sia_acc)(Bt[y + 1][x + 2] - Bt[y + 1][x]);
               gy += (sia_acc)res * (sia_acc)(Bt[y + 2][x + 1] - Bt[y][x + 1]);
             }
+#endif
           }
         }
       }

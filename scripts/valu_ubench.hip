@@ -47,14 +47,15 @@
 enum Kind {
   FMA_F32, MUL_F32, ADD_F32, FMA_F64, MUL_F64, ADD_F64, CNDMASK, CVT_UBYTE, ALIGNBYTE, CVT_F32_F64, CVT_F64_F32,
   RCP_F32, RSQ_F32, RCP_F64, FLOOR_F32, CVT_I32_F32, AND_B32, LSHR_B32, MUL_LO_U32, MOV_DPP, CMP_F32, READLANE,
-  DEP_FMA_F32, DEP_FMA_F64, CNDMASK_E64, CNDMASK_VCC_ONES, BFI_B32, PERM_B32, FMAC_F32, N_KINDS
+  DEP_FMA_F32, DEP_FMA_F64, CNDMASK_E64, CNDMASK_VCC_ONES, BFI_B32, PERM_B32, FMAC_F32, PK_FMA_F32, PK_MUL_F32,
+  PK_ADD_F32, N_KINDS
 };
 static const char* kind_name[N_KINDS] = {
     "v_fma_f32", "v_mul_f32", "v_add_f32", "v_fma_f64", "v_mul_f64", "v_add_f64", "v_cndmask_b32", "v_cvt_f32_ubyte0",
     "v_alignbyte_b32", "v_cvt_f32_f64", "v_cvt_f64_f32", "v_rcp_f32", "v_rsq_f32", "v_rcp_f64", "v_floor_f32",
     "v_cvt_i32_f32", "v_and_b32", "v_lshrrev_b32", "v_mul_lo_u32", "v_mov_b32 dpp row_shr:1", "v_cmp_lt_f32 (vcc)",
     "v_readlane_b32", "v_fma_f32 dependent chain", "v_fma_f64 dependent chain", "v_cndmask_b32_e64 (sgpr pair)",
-    "v_cndmask_b32 vcc=-1", "v_bfi_b32", "v_perm_b32", "v_fmac_f32"};
+    "v_cndmask_b32 vcc=-1", "v_bfi_b32", "v_perm_b32", "v_fmac_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"};
 
 template <int KIND>
 __global__ void __launch_bounds__(256) bench(long long* cycles, float* sink) {
@@ -132,6 +133,9 @@ __global__ void __launch_bounds__(256) bench(long long* cycles, float* sink) {
     if (KIND == BFI_B32) OP8_F32("v_bfi_b32");
     if (KIND == PERM_B32) OP8_F32("v_perm_b32");
     if (KIND == FMAC_F32) OP8_2("v_fmac_f32");
+    if (KIND == PK_FMA_F32) OP8_F64("v_pk_fma_f32");  // (two f32 per register pair)
+    if (KIND == PK_MUL_F32) OP8_F64_2("v_pk_mul_f32");
+    if (KIND == PK_ADD_F32) OP8_F64_2("v_pk_add_f32");
     if (KIND == DEP_FMA_F32) asm volatile(
         "v_fma_f32 %0, %0, %1, %2\nv_fma_f32 %0, %0, %1, %2\nv_fma_f32 %0, %0, %1, %2\nv_fma_f32 %0, %0, %1, %2\n"
         "v_fma_f32 %0, %0, %1, %2\nv_fma_f32 %0, %0, %1, %2\nv_fma_f32 %0, %0, %1, %2\nv_fma_f32 %0, %0, %1, %2\n"
