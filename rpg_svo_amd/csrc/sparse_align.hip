@@ -200,6 +200,19 @@ __device__ __forceinline__ void sia_touch(const uint8_t* base, uint32_t off, uin
 
 // DIST: the camera is a distorted model (radial-tangential pinhole or ATAN); the undistorted pinhole
 // keeps its own instantiation so that its inner loop carries no model dispatch.
+// The bilinear sample, with the order of its one multiplication and three fused multiply-adds spelled out: the template
+// (precompute block) and the warped patch (every evaluation, scalar or packed) must round alike -- a frame aligned
+// against itself has residuals that are exactly zero -- and left to itself the compiler may fuse a*b + c*d either way
+// round, differently for scalars and for register pairs.
+__device__ __forceinline__ float sia_bilerp(float wtl, float wtr, float wbl, float wbr, float tl, float tr, float bl, float br) {
+  return __builtin_fmaf(wbr, br, __builtin_fmaf(wbl, bl, __builtin_fmaf(wtr, tr, wtl * tl)));
+}
+typedef float sia_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ sia_f2 sia_bilerp2(sia_f2 wtl, sia_f2 wtr, sia_f2 wbl, sia_f2 wbr, sia_f2 tl, sia_f2 tr, sia_f2 bl,
+                                              sia_f2 br) {
+  return __builtin_elementwise_fma(wbr, br, __builtin_elementwise_fma(wbl, bl, __builtin_elementwise_fma(wtr, tr, wtl * tl)));
+}
+
 // SIA_PACKED: the pixel loop of an evaluation on v_pk_*_f32, two pixels per instruction (default; the
 // reference-width build keeps its f64 sums and the scalar loop).  -DSIA_PACKED=0 builds the scalar loop for A/B timing.
 #ifndef SIA_PACKED
@@ -383,7 +396,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
 #pragma unroll
           for (int c = 0; c < 6; ++c) {
             const bool need = ((r >= 1 && r <= 4)) || ((c >= 1 && c <= 4));
-            if (need) Bt[r][c] = wtl * Wp[c] + wtr * Wp[c + 1] + wbl * Wc[c] + wbr * Wc[c + 1];
+            if (need) Bt[r][c] = sia_bilerp(wtl, wtr, wbl, wbr, Wp[c], Wp[c + 1], Wc[c], Wc[c + 1]);
           }
 #pragma unroll
           for (int c = 0; c < 7; ++c) Wp[c] = Wc[c];
@@ -567,8 +580,8 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
             const f2 b24t = f2{b02t.y, b45t.x}, b35t = f2{b13t.y, b45t.y};
             // row y+2's (2,4): put together for rows 2-4, stored as such for row 5
             const f2 c24 = (y < 3) ? f2{c02.y, c45.x} : c45;
-            const f2 Ia = vtl * t02 + vtr * t13 + vbl * b02 + vbr * b13;  // pixels x = 0, 2
-            const f2 Ib = vtl * t13 + vtr * t24 + vbl * b13 + vbr * b24;  // pixels x = 1, 3
+            const f2 Ia = sia_bilerp2(vtl, vtr, vbl, vbr, t02, t13, b02, b13);  // pixels x = 0, 2
+            const f2 Ib = sia_bilerp2(vtl, vtr, vbl, vbr, t13, t24, b13, b24);  // pixels x = 1, 3
             const f2 ra = Ia - b13t, rb = Ib - b24t;
             c2v += ra * ra;
             c2v += rb * rb;
@@ -647,7 +660,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
           for (int y = 0; y < 4; ++y)
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-              const float I = wtl * W[y][x] + wtr * W[y][x + 1] + wbl * W[y + 1][x] + wbr * W[y + 1][x + 1];
+              const float I = sia_bilerp(wtl, wtr, wbl, wbr, W[y][x], W[y][x + 1], W[y + 1][x], W[y + 1][x + 1]);
               const float res = I - Bt[y + 1][x + 1];
               c2 += res * res;
               gx += (sia_acc)res * (sia_acc)(Bt[y + 1][x + 2] - Bt[y + 1][x]);
