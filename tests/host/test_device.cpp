@@ -1,9 +1,11 @@
 // tests/host/test_device.cpp -- unit test of the product's C++ host layer (rpg_svo_amd/host/
 // svo_hip_device.{h,cpp}) over the C ABI; built with plain g++ by tests/test_host_device_gpu.py and
-// run on the GPU box.  Prints "ok <name>" per check, exits non-zero on the first failure.
+// run on the GPU box; the same source linked against tests/host/mock_svo_hip.cpp instead of libsvo_hip.so checks the
+// host LOGIC where there is no GPU.  Prints "ok <name>" per check, exits non-zero on the first failure.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -66,6 +68,75 @@ int main() {
   a.reset();
   std::puts("ok arena");
 
+  // ---- where blocks live: hybrid (the default) keeps inputs in the mirror and makes outputs the pinned host block
+  //      itself; mirrored copies everything both ways; mapped has no mirror (SVO_HIP_ARENA selects) ---------------------
+  {
+    const char* mode_env = std::getenv("SVO_HIP_ARENA");
+    const std::string mode = mode_env ? mode_env : "hybrid";
+    CHECK(a.mode() == (mode == "mapped" ? Arena::MAPPED : mode == "mirrored" ? Arena::MIRRORED : Arena::HYBRID));
+    a.reset();
+    int32_t *d_i, *d_o, *d_o2;
+    int32_t* hi = a.alloc<int32_t>(64, &d_i);
+    a.endInputs();
+    const size_t inputs_end = a.used();
+    int32_t* ho = a.alloc<int32_t>(64, &d_o);
+    int32_t* ho2 = a.alloc<int32_t>(64, &d_o2);
+    CHECK(((void*)hi == (void*)d_i) == (a.mode() == Arena::MAPPED));
+    CHECK(((void*)ho == (void*)d_o) == (a.mode() != Arena::MIRRORED) && ((void*)ho2 == (void*)d_o2) == (a.mode() != Arena::MIRRORED));
+    for (int i = 0; i < 64; ++i) { hi[i] = 3 * i; ho[i] = -1; ho2[i] = 7; }
+    a.uploadAll(lane.stream);  // the inputs only: the in/out blocks are host memory already
+    check(svo_hip_memcpy_d2d(d_o, d_i, 64 * sizeof(int32_t), lane.stream), "d2d");  // "a kernel writes a result"
+    a.download(lane.stream);                                                          // nothing to copy
+    a.downloadRange(inputs_end, a.used(), lane.stream);
+    a.fetch(ho, 64, lane.stream);
+    check(svo_hip_stream_sync(lane.stream), "sync");
+    for (int i = 0; i < 64; ++i) CHECK(ho[i] == 3 * i && ho2[i] == 7);
+    check(svo_hip_memset(d_i, 0, 8, lane.stream), "memset");  // device-side change of an INPUT block: fetch() copies it
+    a.fetch(hi, 64, lane.stream);
+    check(svo_hip_stream_sync(lane.stream), "sync");
+    CHECK(hi[0] == 0 && hi[1] == 0 && hi[2] == 6);
+    threw = false;
+    try { a.downloadRange(8, a.used() + 1, lane.stream); } catch (const Error&) { threw = true; }
+    CHECK(threw);
+    a.reset();
+  }
+  std::puts("ok arena modes");
+
+  // ---- work left running for the lane's next call: prediction and deferred second halves -----------------------
+  {
+    const Device::Stats st0 = dev.statsSnapshot();
+    lane.spec.valid = true;          // a prediction nobody takes: the next call of the lane drains and drops it
+    lane.spec.in_flight = true;
+    lane.spec.stream = lane.stream;
+    dev.beginCall(lane);
+    CHECK(!lane.spec.valid && !lane.spec.in_flight);
+    dev.countSpeculation(true);
+    const Device::Stats st1 = dev.statsSnapshot();
+    CHECK(st1.spec_misses == st0.spec_misses + 1 && st1.spec_hits == st0.spec_hits + 1 && st1.calls == st0.calls + 1);
+    int ran = 0;
+    lane.deferred = [&ran]() { ++ran; };
+    dev.beginCall(lane);             // the second half of a deferred call runs before the arena is handed out again
+    CHECK(ran == 1 && !lane.deferred);
+    dev.beginCall(lane);
+    CHECK(ran == 1);
+    lane.deferred = [&ran]() { ran += 10; };
+    dev.joinDeferred(Device::LANE_MAPPING);  // another lane: nothing of its own to join (and no lane is created for it)
+    CHECK(ran == 1);
+    dev.joinDeferred(Device::LANE_TRACKING);
+    CHECK(ran == 11 && !lane.deferred);
+    lane.deferred = [&ran]() { ran += 100; };
+    Device::joinDeferredAll();
+    CHECK(ran == 111);
+    Device::joinDeferredAll();
+    CHECK(ran == 111);
+    dev.addStage(Device::STAGE_DEPTH_FILTER, 1.0, 2.0, 3.0, 4.0);
+    dev.addStage(Device::STAGE_DEPTH_FILTER, 0.0, 5.0, 6.0, 0.0, false);  // the join of a deferred call: same sample
+    const Device::Stats st2 = dev.statsSnapshot();
+    CHECK(st2.n[Device::STAGE_DEPTH_FILTER] == st1.n[Device::STAGE_DEPTH_FILTER] + 1);
+    CHECK(st2.device_us[Device::STAGE_DEPTH_FILTER] == st1.device_us[Device::STAGE_DEPTH_FILTER] + 7.0);
+  }
+  std::puts("ok prediction / deferred bookkeeping");
+
   // ---- pyramid cache: hit, LRU eviction, pinning, re-upload --------------------------------------
   dev.configure(W, H, LEVELS, /*n_slots=*/3);
   const uint64_t up0 = dev.stats.uploads;
@@ -85,7 +156,8 @@ int main() {
   dev.slotOf(100, img[0].data(), W, Device::LANE_TRACKING);            // touch 100 -> 101 is the oldest
   const int s3 = dev.slotOf(103, img[3].data(), W, Device::LANE_TRACKING);
   CHECK(s3 == s1 && dev.stats.evictions >= 1);
-  // the mapping lane pins independently
+  // the mapping lane pins independently (and takes the frame over through the slot's event: uploads are published
+  // when enqueued, not when complete)
   dev.beginCall(Device::LANE_MAPPING);
   CHECK(dev.slotOf(102, img[2].data(), W, Device::LANE_MAPPING) == s2);
   dev.beginCall(Device::LANE_TRACKING);

@@ -21,6 +21,23 @@ def _build():
                     "-o", EXE], check=True)
 
 
+MOCK_EXE = os.path.join(ROOT, "build", "test_device_mock")
+
+
+def test_host_logic_against_the_mock_abi():
+    """The same unit test linked against tests/host/mock_svo_hip.cpp (host memory, synchronous streams) instead of
+    libsvo_hip.so: arena addressing in all its modes, slot cache / LRU / pinning, prediction and deferred-call
+    bookkeeping, lanes of several threads -- the host layer's logic, checked where there is no GPU."""
+    os.makedirs(os.path.dirname(MOCK_EXE), exist_ok=True)
+    host = os.path.join(ROOT, "rpg_svo_amd", "host")
+    subprocess.run(["g++", "-std=c++11", "-O1", "-g", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", host, SRC,
+                    os.path.join(host, "svo_hip_device.cpp"), os.path.join(ROOT, "tests", "host", "mock_svo_hip.cpp"), "-pthread",
+                    "-o", MOCK_EXE], check=True)
+    for mode in ("hybrid", "mirrored", "mapped"):
+        r = subprocess.run([MOCK_EXE], capture_output=True, text=True, timeout=120, env=dict(os.environ, SVO_HIP_ARENA=mode))
+        assert r.returncode == 0 and "ALL OK" in r.stdout, (mode, r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_host_layer_builds_with_plain_gxx(hip_lib):
     """No HIP, Eigen or reference headers needed: this is what lets libsvo keep building with g++."""
     _build()
