@@ -1,0 +1,280 @@
+// tests/dropin/mock_compute_oracle.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// The COMPUTE entry points of the C ABI (include/svo_hip.h) that the drop-in bodies under rpg_svo_amd/host/dropin/ call,
+// served by the CPU oracle (oracle/svo_oracle.h) -- together with tests/host/mock_svo_hip.cpp (memory, streams, a
+// row-major pyramid store) this gives tests/dropin/_build/libsvo_pipeline_hipmock.so: the reference's control plane +
+// the product's drop-in HOST code + a mock device.  It exists so that the host logic of the drop-ins -- marshalling,
+// trial ordering, the predicted pose refinement, the deferred mapper's replay, slot bookkeeping -- runs end to end in
+// the CPU test suite, where there is no GPU (tests/test_dropin_pipeline.py::test_dropin_host_logic_on_the_mock_device).
+// It is NOT a fallback: nothing of the product links it, libsvo_hip.so has no such path, and the GPU tests run the same
+// host code against the real kernels.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include <svo_hip.h>
+
+extern "C" {
+#include "svo_oracle.h"
+}
+
+namespace {
+
+orc_pinhole camOf(const svo_hip_camera* c) {
+  orc_pinhole o;
+  o.fx = c->fx; o.fy = c->fy; o.cx = c->cx; o.cy = c->cy;
+  o.width = c->width; o.height = c->height;
+  o.model = c->model;  // SVO_HIP_CAM_* and ORC_CAM_* share their values
+  o.pad_ = 0;
+  for (int i = 0; i < 5; ++i) o.d[i] = c->d[i];
+  return o;
+}
+
+// the mock store (tests/host/mock_svo_hip.cpp) is row-major with pitch == width: a level is a continuous image
+orc_pyramid pyrOf(const svo_hip_pyr_layout* L, const uint8_t* store, int slot) {
+  orc_pyramid p;
+  std::memset(&p, 0, sizeof(p));
+  p.n_levels = L->n_levels;
+  for (int l = 0; l < L->n_levels; ++l) {
+    p.w[l] = L->w[l];
+    p.h[l] = L->h[l];
+    p.data[l] = store + (int64_t)slot * L->slot_bytes + L->offset[l];
+  }
+  return p;
+}
+
+std::vector<orc_frame> framesOf(const svo_hip_pyr_layout* L, const uint8_t* store, const svo_hip_frames* ft) {
+  std::vector<orc_frame> fr((size_t)ft->n_frames);
+  for (int i = 0; i < ft->n_frames; ++i) {
+    fr[i].pyr = pyrOf(L, store, ft->d_slot[i]);
+    std::memcpy(fr[i].T_f_w, ft->d_T_f_w + 12 * i, 12 * sizeof(double));
+  }
+  return fr;
+}
+
+orc_feature featureOf(const svo_hip_features* f, int i) {
+  orc_feature o;
+  std::memset(&o, 0, sizeof(o));
+  o.frame = f->d_frame[i];
+  o.level = f->d_level[i];
+  o.type = f->d_type ? f->d_type[i] : ORC_FTR_CORNER;
+  o.px[0] = f->d_px[2 * i]; o.px[1] = f->d_px[2 * i + 1];
+  for (int k = 0; k < 3; ++k) o.f[k] = f->d_f[3 * i + k];
+  o.grad[0] = f->d_grad ? f->d_grad[2 * i] : 1.0;
+  o.grad[1] = f->d_grad ? f->d_grad[2 * i + 1] : 0.0;
+  return o;
+}
+
+int poseOptimize(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride, const double* d_f, const int32_t* d_level,
+                 const double* d_pos, uint8_t* d_has_point, double reproj_thresh, int n_iter, double* d_T, double* d_Cov,
+                 double* d_stats, int32_t* d_ran) {
+  if (!cam || B < 0 || n_stride < 1) return SVO_HIP_EINVAL;
+  const orc_pinhole c = camOf(cam);
+  for (int b = 0; b < B; ++b) {
+    const int n = d_n[b];
+    std::vector<int> level(d_level + (size_t)b * n_stride, d_level + (size_t)b * n_stride + n);
+    orc_pose_opt_result r;
+    std::memset(&r, 0, sizeof(r));
+    orc_pose_optimize(reproj_thresh, n_iter, &c, d_T + 12 * b, n, d_f + (size_t)3 * b * n_stride, level.data(),
+                      d_has_point + (size_t)b * n_stride, d_pos + (size_t)3 * b * n_stride, &r);
+    d_ran[b] = r.ran;
+    if (!r.ran) continue;
+    std::memcpy(d_T + 12 * b, r.T_f_w, 12 * sizeof(double));
+    if (d_Cov) std::memcpy(d_Cov + 36 * b, r.Cov, 36 * sizeof(double));
+    d_stats[4 * b] = r.estimated_scale; d_stats[4 * b + 1] = r.error_init; d_stats[4 * b + 2] = r.error_final;
+    d_stats[4 * b + 3] = (double)r.num_obs;
+  }
+  return SVO_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int svo_hip_sparse_align(const svo_hip_pyr_layout* L, const uint8_t* store, int B, const int32_t* d_ref_slot,
+                         const int32_t* d_cur_slot, const int32_t* d_n, int n_stride, const double* d_px, const double* d_xyz_ref,
+                         const uint8_t* d_valid, const svo_hip_sia_params* P, const double* d_T_in, double* d_T_out,
+                         double* d_H_out, int32_t* d_n_tracked, int32_t* d_iters, double* d_chi2, int32_t* d_status, void*) {
+  orc_pinhole cam;
+  std::memset(&cam, 0, sizeof(cam));
+  cam.fx = P->fx; cam.fy = P->fy; cam.cx = P->cx; cam.cy = P->cy;
+  cam.width = L->w[0]; cam.height = L->h[0];
+  cam.model = P->cam_model;
+  for (int i = 0; i < 5; ++i) cam.d[i] = P->d[i];
+  orc_sia_options opt;
+  opt.max_level = P->max_level; opt.min_level = P->min_level; opt.n_iter = P->n_iter; opt.eps = P->eps;
+  const double I12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+  for (int b = 0; b < B; ++b) {
+    const int n = d_n[b];
+    const orc_pyramid rp = pyrOf(L, store, d_ref_slot[b]), cp = pyrOf(L, store, d_cur_slot[b]);
+    // the reference frame is the world: a point's position is f * depth (sparse_img_align.cpp:107-108), the prior on
+    // the current frame's pose is T_cur_from_ref
+    std::vector<double> f((size_t)3 * n), pos((size_t)3 * n);
+    std::vector<uint8_t> has((size_t)n);
+    for (int i = 0; i < n; ++i) {
+      const double* x = d_xyz_ref + ((size_t)b * n_stride + i) * 3;
+      const double nn = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+      has[i] = (d_valid ? d_valid[(size_t)b * n_stride + i] : 1) && nn > 0;
+      for (int k = 0; k < 3; ++k) { pos[3 * i + k] = x[k]; f[3 * i + k] = nn > 0 ? x[k] / nn : 0.0; }
+    }
+    double T[12];
+    std::memcpy(T, d_T_in + 12 * b, sizeof(T));
+    orc_sia_result r;
+    std::memset(&r, 0, sizeof(r));
+    orc_sparse_img_align_run(&rp, &cp, &cam, I12, T, n, d_px + (size_t)2 * b * n_stride, f.data(), has.data(), pos.data(), &opt,
+                             &r, NULL);
+    std::memcpy(d_T_out + 12 * b, r.T_cur_from_ref, 12 * sizeof(double));
+    if (d_H_out) std::memcpy(d_H_out + 36 * b, r.H, 36 * sizeof(double));
+    d_n_tracked[b] = r.n_tracked;
+    if (d_iters)
+      for (int l = 0; l < SVO_HIP_MAX_LEVELS; ++l) d_iters[(size_t)b * SVO_HIP_MAX_LEVELS + l] = l < ORC_MAX_LEVELS ? r.iters[l] : 0;
+    if (d_chi2) d_chi2[b] = r.chi2;
+    if (d_status) d_status[b] = r.stop ? SVO_HIP_SIA_STOP : 0;
+  }
+  return SVO_HIP_OK;
+}
+
+int svo_hip_find_match_direct(const svo_hip_pyr_layout* L, const uint8_t* store, const svo_hip_camera* cam,
+                              const svo_hip_frames* frames, int M, const int32_t* d_cur_frame, const double* d_pt_pos,
+                              const int32_t* d_obs_ptr, const svo_hip_features* obs, int n_pyr_levels, int align_max_iter,
+                              double* d_px_cur, int32_t* d_ok, int32_t* d_ref_obs, int32_t* d_search_level, double* d_A_cur_ref,
+                              uint8_t* d_patch_out, void*, size_t, void*) {
+  const orc_pinhole c = camOf(cam);
+  const std::vector<orc_frame> fr = framesOf(L, store, frames);
+  orc_matcher_options opt;
+  orc_matcher_options_default(&opt);
+  opt.n_pyr_levels = n_pyr_levels;
+  opt.align_max_iter = align_max_iter;
+  for (int m = 0; m < M; ++m) {
+    const int o0 = d_obs_ptr[m], n_obs = d_obs_ptr[m + 1] - o0;
+    std::vector<orc_feature> ob((size_t)n_obs);
+    for (int k = 0; k < n_obs; ++k) ob[k] = featureOf(obs, o0 + k);
+    orc_match_result r;
+    std::memset(&r, 0, sizeof(r));
+    double px[2] = {d_px_cur[2 * m], d_px_cur[2 * m + 1]};
+    const int ok = orc_find_match_direct(fr.data(), &c, d_cur_frame[m], d_pt_pos + 3 * m, n_obs, ob.data(), &opt, px, &r);
+    d_px_cur[2 * m] = px[0]; d_px_cur[2 * m + 1] = px[1];
+    d_ok[m] = ok;
+    d_ref_obs[m] = r.ref_obs >= 0 ? o0 + r.ref_obs : -1;
+    d_search_level[m] = r.search_level;
+    if (d_A_cur_ref) std::memcpy(d_A_cur_ref + 4 * m, r.A_cur_ref, 4 * sizeof(double));
+    if (d_patch_out) std::memcpy(d_patch_out + 100 * m, r.patch_with_border, 100);
+  }
+  return SVO_HIP_OK;
+}
+
+int svo_hip_select_matches(const svo_hip_camera* cam, int M, const int32_t* d_cell, const int32_t* d_ok, const double* d_px,
+                           const int32_t* d_level, const double* d_pos, int max_fts, int32_t* d_n, int32_t* d_sel, double* d_f,
+                           int32_t* d_level_out, double* d_pos_out, uint8_t* d_has_point, int32_t* d_signal, int32_t signal_value,
+                           void*) {
+  if (d_signal) *d_signal = signal_value;  // the mock's streams are synchronous: everything before is complete
+  const orc_pinhole c = camOf(cam);
+  const int n = M > 0 ? orc_select_matches(&c, M, d_cell, d_ok, d_px, d_level, d_pos, max_fts, d_sel, d_f, d_level_out, d_pos_out) : 0;
+  for (int i = 0; i < n; ++i) d_has_point[i] = 1;
+  d_n[0] = n;
+  return SVO_HIP_OK;
+}
+
+int svo_hip_pose_optimize(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride, const double* d_f,
+                          const int32_t* d_level, const double* d_pos, uint8_t* d_has_point, double reproj_thresh, int n_iter,
+                          double* d_T, double* d_Cov, double* d_stats, int32_t* d_ran, void*) {
+  return poseOptimize(cam, B, d_n, n_stride, d_f, d_level, d_pos, d_has_point, reproj_thresh, n_iter, d_T, d_Cov, d_stats, d_ran);
+}
+int svo_hip_pose_optimize_deferred(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride, const double* d_f,
+                                   const int32_t* d_level, const double* d_pos, uint8_t* d_has_point, double reproj_thresh,
+                                   int n_iter, double* d_T, double* d_Cov, double* d_stats, int32_t* d_ran, void*) {
+  return poseOptimize(cam, B, d_n, n_stride, d_f, d_level, d_pos, d_has_point, reproj_thresh, n_iter, d_T, d_Cov, d_stats, d_ran);
+}
+int svo_hip_pose_optimize_ordered(const svo_hip_camera* cam, int B, const int32_t* d_n, int n_stride, const double* d_f,
+                                  const int32_t* d_level, const double* d_pos, uint8_t* d_has_point, double reproj_thresh,
+                                  int n_iter, double* d_T, double* d_Cov, double* d_stats, int32_t* d_ran, void*) {
+  return poseOptimize(cam, B, d_n, n_stride, d_f, d_level, d_pos, d_has_point, reproj_thresh, n_iter, d_T, d_Cov, d_stats, d_ran);
+}
+
+int svo_hip_update_seeds(const svo_hip_pyr_layout* L, const uint8_t* store, const svo_hip_camera* cam, const svo_hip_frames* frames,
+                         int S, const int32_t* d_cur_frame, const svo_hip_features* ftr, const svo_hip_seeds* seeds,
+                         const svo_hip_depth_filter_options* opt, int32_t* d_status, double* d_xyz_world, double* d_px_cur, void*,
+                         size_t, void*) {
+  const orc_pinhole c = camOf(cam);
+  const std::vector<orc_frame> fr = framesOf(L, store, frames);
+  orc_depth_filter_options dopt;
+  dopt.max_n_kfs = opt->max_n_kfs;
+  dopt.batch_counter = opt->batch_counter;
+  dopt.seed_convergence_sigma2_thresh = opt->seed_convergence_sigma2_thresh;
+  orc_matcher_options mopt;
+  orc_matcher_options_default(&mopt);
+  mopt.align_1d = opt->align_1d;
+  mopt.align_max_iter = opt->align_max_iter;
+  mopt.max_epi_search_steps = opt->max_epi_search_steps;
+  mopt.subpix_refinement = opt->subpix_refinement;
+  mopt.epi_search_edgelet_filtering = opt->epi_search_edgelet_filtering;
+  mopt.epi_search_edgelet_max_angle = opt->epi_search_edgelet_max_angle;
+  mopt.n_pyr_levels = opt->n_pyr_levels;
+  // orc_update_seeds takes one measurement frame for the whole list, as DepthFilter::updateSeeds does: runs of equal
+  // d_cur_frame are handed over one by one (the drop-in passes a single frame)
+  int s0 = 0;
+  while (s0 < S) {
+    int s1 = s0;
+    while (s1 < S && d_cur_frame[s1] == d_cur_frame[s0]) ++s1;
+    const int n = s1 - s0;
+    std::vector<orc_seed> sd((size_t)n);
+    std::vector<orc_seed_update_info> info((size_t)n);
+    for (int i = 0; i < n; ++i) {
+      const int s = s0 + i;
+      std::memset(&sd[i], 0, sizeof(orc_seed));
+      sd[i].ftr = featureOf(ftr, s);
+      sd[i].batch_id = seeds->d_batch_id ? seeds->d_batch_id[s] : 0;
+      sd[i].a = seeds->d_a[s]; sd[i].b = seeds->d_b[s]; sd[i].mu = seeds->d_mu[s];
+      sd[i].z_range = seeds->d_z_range[s]; sd[i].sigma2 = seeds->d_sigma2[s];
+    }
+    std::memset(info.data(), 0, info.size() * sizeof(orc_seed_update_info));
+    orc_update_seeds(fr.data(), &c, d_cur_frame[s0], n, sd.data(), info.data(), &dopt, &mopt);
+    for (int i = 0; i < n; ++i) {
+      const int s = s0 + i;
+      seeds->d_a[s] = sd[i].a; seeds->d_b[s] = sd[i].b; seeds->d_mu[s] = sd[i].mu; seeds->d_sigma2[s] = sd[i].sigma2;
+      d_status[s] = info[i].status;  // SVO_HIP_SEED_* and ORC_SEED_* share their values
+      for (int k = 0; k < 3; ++k) d_xyz_world[3 * s + k] = info[i].xyz_world[k];
+      if (d_px_cur) { d_px_cur[2 * s] = info[i].px_cur[0]; d_px_cur[2 * s + 1] = info[i].px_cur[1]; }
+    }
+    s0 = s1;
+  }
+  return SVO_HIP_OK;
+}
+
+int svo_hip_update_seed_batch(int S, const float* d_x, const float* d_tau2, const svo_hip_seeds* seeds, void*) {
+  for (int s = 0; s < S; ++s) {
+    orc_seed sd;
+    std::memset(&sd, 0, sizeof(sd));
+    sd.a = seeds->d_a[s]; sd.b = seeds->d_b[s]; sd.mu = seeds->d_mu[s]; sd.z_range = seeds->d_z_range[s]; sd.sigma2 = seeds->d_sigma2[s];
+    orc_update_seed(d_x[s], d_tau2[s], &sd);
+    seeds->d_a[s] = sd.a; seeds->d_b[s] = sd.b; seeds->d_mu[s] = sd.mu; seeds->d_sigma2[s] = sd.sigma2;
+  }
+  return SVO_HIP_OK;
+}
+
+int svo_hip_compute_tau_batch(int S, const double* d_t, const double* d_f, const double* d_z, double px_error_angle, double* d_tau,
+                              void*) {
+  for (int s = 0; s < S; ++s) {
+    double T[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, d_t[3 * s], d_t[3 * s + 1], d_t[3 * s + 2]};
+    d_tau[s] = orc_compute_tau(T, d_f + 3 * s, d_z[s], px_error_angle);
+  }
+  return SVO_HIP_OK;
+}
+
+size_t svo_hip_fast_workspace_bytes(const svo_hip_pyr_layout*, int, int) { return 256; }
+
+int svo_hip_fast_detect(const svo_hip_pyr_layout* L, const uint8_t* store, int n_frames, const int32_t* d_slot, int n_levels,
+                        int fast_threshold, int cell_size, int grid_n_cols, int grid_n_rows, const uint8_t* d_occupancy,
+                        double detection_threshold, int32_t* d_corner_xy, int32_t* d_corner_level, float* d_corner_score, void*,
+                        size_t, void*) {
+  const size_t cells = (size_t)grid_n_cols * grid_n_rows;
+  for (int i = 0; i < n_frames; ++i) {
+    const orc_pyramid p = pyrOf(L, store, d_slot[i]);
+    orc_fast_detect_grid(&p, n_levels, fast_threshold, cell_size, grid_n_cols, grid_n_rows, d_occupancy ? d_occupancy + i * cells : NULL,
+                         detection_threshold, d_corner_xy + 2 * i * cells, d_corner_level + i * cells, d_corner_score + i * cells);
+  }
+  return SVO_HIP_OK;
+}
+
+}  // extern "C"

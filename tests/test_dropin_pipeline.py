@@ -82,6 +82,143 @@ def test_dropin_library_links_every_symbol(pipeline_libs):
         assert hasattr(lib, name)
 
 
+# ---- the drop-ins' HOST code on a mock device (CPU suite) ------------------------------------------------------------
+# tests/dropin/_build/libsvo_pipeline_hipmock.so links the same objects as the hip flavour -- the reference's control
+# plane + rpg_svo_amd/host/dropin/*.cpp + svo_hip_device.cpp -- against tests/host/mock_svo_hip.cpp and
+# tests/dropin/mock_compute_oracle.cpp (the C ABI served by host memory and the CPU oracle) instead of libsvo_hip.so.
+# Everything the host layer decides -- marshalling, trial order, the predicted pose refinement and its verification, the
+# deferred mapper's replay, slot pinning and eviction -- is therefore exercised here, where there is no GPU; the
+# arithmetic is the oracle's, so the trajectory must follow the reference's own to rounding (poses cross the boundary as
+# rotation matrices, sparse alignment gets f * depth instead of f and depth: 1e-15 per frame, 1e-8 after 80 frames).
+MOCK_TOL = 1e-7
+
+
+@pytest.fixture(scope="module")
+def mock_lib(pipeline_libs):
+    if not pp.available("hipmock"):
+        pytest.skip("tests/dropin/_build/libsvo_pipeline_hipmock.so absent and no reference checkout to build it from")
+    return True
+
+
+def _same_decisions(a, b, keys=("is_keyframe", "n_obs", "repr_n_mps", "repr_n_new_references", "n_kfs", "stage", "img_align_n_tracked")):
+    for k in keys:
+        assert [r[k] for r in a] == [r[k] for r in b], k
+
+
+def test_dropin_host_logic_on_the_mock_device(mock_lib):
+    cam, imgs, T = _sequence(80)
+    ref = pp.run_sequence("ref", cam, imgs, T)
+    st = {}
+    mock = pp.run_sequence("hipmock", cam, imgs, T, stats_out=st)
+    d = se3.log_norm(np.stack([r["T_f_w"] for r in mock]), np.stack([r["T_f_w"] for r in ref]))
+    assert d.max() <= MOCK_TOL, d.max()
+    _same_decisions(ref, mock, ("is_keyframe", "n_obs", "repr_n_mps", "repr_n_new_references", "n_kfs", "stage",
+                                "img_align_n_tracked", "n_seeds", "n_candidates", "sfba_n_edges_final"))
+    assert sum(r["is_keyframe"] for r in mock) >= 3 and max(r["n_candidates"] for r in mock) > 50
+    # every frame's pose refinement was the one the reprojector predicted and enqueued
+    assert st["predicted_pose_misses"] == 0 and st["predicted_pose_hits"] == len(imgs) - 1
+    assert st["uploads"] == len(imgs) and st["evictions"] == len(imgs) - 64  # 64 slots: old frames leave, none comes back
+
+
+def test_mock_device_deferred_mapper_and_small_pool(mock_lib):
+    """Deferred mapping (results of DepthFilter::updateSeeds joined at the next reprojectMap / updateSeeds / detect) and
+    a pyramid pool so small that live frames are evicted and uploaded again: the trajectory must not notice either."""
+    cam, imgs, T = _sequence(80)
+    base = pp.run_sequence("hipmock", cam, imgs, T)
+    Tb = np.stack([r["T_f_w"] for r in base])
+    deferred = pp.run_sequence("hipmock", cam, imgs, T, defer_mapper=1)
+    assert np.array_equal(np.stack([r["T_f_w"] for r in deferred]), Tb)
+    _same_decisions(base, deferred)
+    assert sum(r["n_candidates"] for r in deferred) > 0
+    st = {}
+    small = pp.run_sequence("hipmock", cam, imgs, T, stats_out=st, pool_slots=7, defer_mapper=1)
+    assert np.array_equal(np.stack([r["T_f_w"] for r in small]), Tb)
+    assert st["evictions"] > 50 and st["uploads"] >= len(imgs)
+    # a sequence after a deferred one in the same process: nothing pending leaks into the next handler
+    again = pp.run_sequence("hipmock", cam, imgs[:30], T[:30])
+    assert np.array_equal(np.stack([r["T_f_w"] for r in again]), Tb[:30])
+
+
+def test_mock_device_tracking_loss_and_relocalization(mock_lib):
+    """The scenario of test_tracking_loss_and_relocalization on the mock device: a prediction enqueued for a frame whose
+    pose refinement never comes (RESULT_FAILURE) must be dropped by the lane's next call, relocalization runs the
+    sparse alignment outside processFrame, and the deferred mapper meets FrameHandlerMono's reset paths."""
+    cam, imgs, T = _sequence(52, seed=9)
+    k0 = 36
+    T2 = se3.mul(T, np.broadcast_to(se3.inv(T[k0][None])[0], T.shape).copy())
+    imgs = imgs.copy()
+    imgs[30:33] = 0
+    r0 = pp.range_map(cam, T[0])
+    ref = pp.run_sequence("ref", cam, imgs, T2, range0=r0)
+    for defer in (0, 1):
+        st = {}
+        mock = pp.run_sequence("hipmock", cam, imgs, T2, range0=r0, stats_out=st, defer_mapper=defer)
+        assert [r["stage"] for r in mock] == [r["stage"] for r in ref]
+        assert [r["stage"] for r in ref][30:34] == [pp.STAGE_RELOCALIZING] * 3 + [pp.STAGE_DEFAULT_FRAME]
+        _same_decisions(ref, mock, ("is_keyframe", "n_obs", "repr_n_new_references", "img_align_n_tracked"))
+        d = se3.log_norm(np.stack([r["T_f_w"] for r in mock]), np.stack([r["T_f_w"] for r in ref]))
+        assert d.max() <= MOCK_TOL, (defer, d.max())
+        assert st["predicted_pose_hits"] > 40
+
+
+@pytest.mark.parametrize("kind", ["atan", "radtan"])
+def test_mock_device_with_the_reference_launch_file_cameras(mock_lib, kind):
+    """Camera recovery through the abstract interface, device cam2world for the predicted observations, distorted models."""
+    from helpers import camera_models
+    cam = camera_models()[kind]
+    cam_, imgs, T = _sequence(40, cam=cam)
+    ref = pp.run_sequence("ref", cam, imgs, T)
+    st = {}
+    mock = pp.run_sequence("hipmock", cam, imgs, T, stats_out=st)
+    d = se3.log_norm(np.stack([r["T_f_w"] for r in mock]), np.stack([r["T_f_w"] for r in ref]))
+    # (the camera's parameters are recovered by probing world2cam through the abstract interface: 1e-12 relative, and the
+    # radial-tangential cam2world rounds to float)
+    assert d.max() <= 1e-5, d.max()
+    _same_decisions(ref, mock)
+    assert st["predicted_pose_misses"] == 0
+
+
+def test_mock_device_with_the_mapping_thread(mock_lib):
+    """DepthFilter's own thread running: tracking lane and mapping lane of two host threads, deferral off by itself
+    (thread_ != NULL).  Timing dependent like the reference: checked against ground truth."""
+    cam, imgs, T = _sequence(80)
+    for _ in range(2):
+        mock = pp.run_sequence("hipmock", cam, imgs, T, mapper_thread=1, defer_mapper=1)
+        est = np.stack([r["T_f_w"] for r in mock])
+        assert all(r["stage"] == pp.STAGE_DEFAULT_FRAME for r in mock)
+        assert se3.log_norm(est, T).max() < 5e-3
+        assert sum(r["is_keyframe"] for r in mock) >= 3
+
+
+def test_mock_device_arena_modes_and_no_prediction(mock_lib, tmp_path):
+    """SVO_HIP_ARENA = hybrid / mirrored / mapped and SVO_HIP_SPECULATE = 0 (fixed when a lane / the process starts:
+    one process each): the host code paths differ -- where blocks live, which copies are issued, polling a signal or
+    waiting for a stream, prediction on the same or on a second stream or none -- the results do not."""
+    import subprocess
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {HERE!r}); sys.path.insert(0, {os.path.join(HERE, 'dropin')!r})\n"
+        "import pypipeline as pp\n"
+        "import test_dropin_pipeline as t\n"
+        "cam, imgs, T = t._sequence(50)\n"
+        "st = {}\n"
+        "r = pp.run_sequence('hipmock', cam, imgs, T, stats_out=st)\n"
+        "np.save(sys.argv[1], np.stack([x['T_f_w'] for x in r]))\n"
+        "print(st['predicted_pose_hits'], st['predicted_pose_misses'])\n")
+    out, hits = {}, {}
+    for name, env in (("hybrid", {}), ("mirrored", {"SVO_HIP_ARENA": "mirrored"}), ("mapped", {"SVO_HIP_ARENA": "mapped"}),
+                      ("no_prediction", {"SVO_HIP_SPECULATE": "0"})):
+        path = str(tmp_path / f"traj_{name}.npy")
+        p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True,
+                           timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out[name] = np.load(path)
+        hits[name] = [int(x) for x in p.stdout.split()[-2:]]
+    for name in ("mirrored", "mapped", "no_prediction"):
+        assert np.array_equal(out[name], out["hybrid"]), name
+    assert hits["hybrid"] == [49, 0] and hits["mirrored"] == [49, 0] and hits["mapped"] == [49, 0] and hits["no_prediction"] == [0, 0]
+
+
 @pytest.mark.gpu
 def test_dropin_trajectory_matches_cpu_reference(pipeline_libs, gpu_device):
     cam, imgs, T = _sequence(120)
