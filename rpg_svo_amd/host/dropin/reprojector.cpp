@@ -35,6 +35,52 @@ namespace svo {
 namespace {
 typedef std::pair<FramePtr, double> KfDist;
 bool closerKf(const KfDist& a, const KfDist& b) { return a.second < b.second; }
+
+// Point::getCloseViewObs (svo/src/point.cpp:97-117), statement for statement, except that Frame::pos() -- an SE3 inversion
+// per call (frame.h:112) -- is looked up: every candidate of a frame asks for the positions of the same dozen keyframes,
+// and the batch asks for ALL binned candidates where the reference asks only for the ones it gets to try.
+// Reprojector::reprojectCell's cell.sort(pointQualityComparator) (:152; stable: std::list::sort is a merge sort).  Most
+// cells hold one candidate or candidates of one type, and libstdc++'s list::sort builds 65 scratch lists before it looks
+// at anything: a cell that is in order already -- no neighbour pair the comparator would swap -- is left alone.
+// (Reprojector::Cell / Candidate are private: the types are deduced)
+template <class CellList>
+void sortCell(CellList& cell) {
+  typedef typename CellList::value_type Cand;
+  typename CellList::iterator a = cell.begin();
+  if (a == cell.end()) return;
+  typename CellList::iterator b = a;
+  for (++b; b != cell.end(); ++a, ++b)
+    if (b->pt->type_ > a->pt->type_) {
+      cell.sort([](Cand& l, Cand& r) { return l.pt->type_ > r.pt->type_; });
+      return;
+    }
+}
+
+struct FramePositions {
+  std::vector<std::pair<const Frame*, Vector3d> > known;
+  Vector3d of(const Frame* f) {
+    for (size_t i = 0; i < known.size(); ++i)
+      if (known[i].first == f) return known[i].second;
+    known.push_back(std::make_pair(f, f->pos()));
+    return known.back().second;
+  }
+};
+bool closeViewObs(const Point& pt, const Vector3d& framepos, FramePositions& positions, Feature*& ftr) {
+  if (pt.obs_.empty()) return false;
+  Vector3d obs_dir(framepos - pt.pos_); obs_dir.normalize();
+  std::list<Feature*>::const_iterator min_it = pt.obs_.begin();
+  double min_cos_angle = 0;
+  for (std::list<Feature*>::const_iterator it = pt.obs_.begin(), ite = pt.obs_.end(); it != ite; ++it) {
+    Vector3d dir(positions.of((*it)->frame) - pt.pos_); dir.normalize();
+    const double cos_angle = obs_dir.dot(dir);
+    if (cos_angle > min_cos_angle) {
+      min_cos_angle = cos_angle;
+      min_it = it;
+    }
+  }
+  ftr = *min_it;
+  return !(min_cos_angle < 0.5);  // observations more than 60 degrees apart are useless
+}
 }  // namespace
 
 void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, std::size_t> >& overlap_kfs) {
@@ -107,17 +153,18 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
     std::vector<int32_t> trial_cell;
     trials.reserve(n_binned); trial_ref.reserve(n_binned); trial_cell.reserve(n_binned);
     const Vector3d cur_pos(frame->pos());
+    FramePositions positions;
     // Trials are listed in the order step 4 visits them: cells in grid_.cell_order, each cell's list sorted first
     // (reprojectCell, :152: good points before unknown ones before candidates; stable, like std::list::sort).  A point
     // lies in one cell only, so sorting every cell before the batch gives the lists the visiting loop would produce.
     for (size_t i = 0; i < grid_.cells.size(); ++i) {
       Cell& cell = *grid_.cells.at(grid_.cell_order[i]);
-      cell.sort([](Candidate& l, Candidate& r) { return l.pt->type_ > r.pt->type_; });
+      sortCell(cell);
       visit_begin[i] = visit.size();
       for (Cell::iterator c = cell.begin(); c != cell.end(); ++c) {
         if (c->pt->type_ == Point::TYPE_DELETED) continue;
         Feature* ref_ftr = NULL;
-        if (!c->pt->getCloseViewObs(cur_pos, ref_ftr)) {  // findMatchDirect returns false at once (:137-138)
+        if (!closeViewObs(*c->pt, cur_pos, positions, ref_ftr)) {  // findMatchDirect returns false at once (:137-138)
           visit.push_back(-1);
           continue;
         }
@@ -269,8 +316,7 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
   // ---- 4. per cell, in the shuffled order: the best-quality point that matched ---------------
   for (size_t i = 0; i < grid_.cells.size(); ++i) {
     Cell& cell = *grid_.cells.at(grid_.cell_order[i]);
-    if (!options_.find_match_direct)  // (sorted above otherwise) good points before unknown ones before candidates
-      cell.sort([](Candidate& l, Candidate& r) { return l.pt->type_ > r.pt->type_; });
+    if (!options_.find_match_direct) sortCell(cell);  // (sorted above otherwise)
     bool matched = false;
     size_t v = visit_begin[i];  // the candidates step 3 listed for this cell, in this order
     for (Cell::iterator it = cell.begin(); it != cell.end() && !matched;) {
