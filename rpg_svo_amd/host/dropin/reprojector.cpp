@@ -20,6 +20,7 @@
 #include <svo/reprojector.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 
 #include <svo/config.h>
@@ -131,18 +132,26 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
   SVO_START_TIMER("feature_align");
   // What step 4 will find when it walks the cells: per visited candidate (cells in grid_.cell_order, each list in
   // its sorted order, deleted points left out) the index of its trial in the device batch, or -1 when findMatchDirect
-  // fails before it reaches the image (no close view, matcher.cpp:137-138); the batch's results, in the arena.
+  // fails before it reaches the image (no close view, matcher.cpp:137-138); and the trials' results.
+  const size_t n_cells = grid_.cells.size();
   std::vector<int32_t> visit;
-  std::vector<size_t> visit_begin(grid_.cells.size() + 1, 0);
-  std::vector<Feature*> obs_ftr;
-  const double *res_px = NULL, *res_A = NULL;
-  const int32_t *res_ok = NULL, *res_ref = NULL, *res_lvl = NULL;
+  std::vector<size_t> visit_begin(n_cells + 1, 0);
+  std::vector<double> R_px, R_A;                 // [trial][2], [trial][4]
+  std::vector<int32_t> R_ok, R_lvl;              // [trial]
+  std::vector<Feature*> R_ref;                   // [trial] Matcher::ref_ftr_
   bool predict = false;             // pose refinement of this frame has been enqueued behind the match kernels
   svo_hip::Lane* spec_lane = NULL;  // ... on this lane
-  if (options_.find_match_direct) {
-    size_t n_binned = 0;
-    for (size_t k = 0; k < grid_.cells.size(); ++k) n_binned += grid_.cells[k]->size();
-    visit.reserve(n_binned);
+  size_t enumerated_end = 0;        // cells [0, enumerated_end) of the visiting order have their trials
+  // The visiting loop stops once more than maxFts cells have matched (:137-138): of ~300 cells with candidates it
+  // typically sees the first ~125, and what lies behind the stop is never looked at (nor are its counters touched).
+  // The first batch therefore takes the cells a success rate of 3 in 4 would need; should step 4 run out of them before
+  // it stops (it then has matched less than three quarters of the cells), a second batch takes the rest.
+  // (SVO_HIP_FIRST_BATCH_CELLS overrides the size of the first batch: the tests use it to force the second one)
+  static const long first_batch_override = [] { const char* v = std::getenv("SVO_HIP_FIRST_BATCH_CELLS"); return v ? std::atol(v) : 0L; }();
+  const size_t first_batch_cells = first_batch_override > 0 ? (size_t)first_batch_override
+                                                            : (size_t)Config::maxFts() + 1 + ((size_t)Config::maxFts() + 1) / 3 + 8;
+  // [first_cell, return value): the cells whose candidates were listed and matched
+  auto runBatch = [&](const size_t first_cell, const size_t max_cells_with_trials) -> size_t {
     using namespace hip_dropin;
     // The reference observation of a trial (Point::getCloseViewObs, matcher.cpp:137) is chosen HERE,
     // by the reference's own host code: a trial then ships exactly one svo::Feature, and only the
@@ -151,16 +160,18 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
     std::vector<Candidate*> trials;
     std::vector<Feature*> trial_ref;
     std::vector<int32_t> trial_cell;
-    trials.reserve(n_binned); trial_ref.reserve(n_binned); trial_cell.reserve(n_binned);
     const Vector3d cur_pos(frame->pos());
     FramePositions positions;
+    const size_t base = R_ok.size();  // trials of earlier batches keep their indices
     // Trials are listed in the order step 4 visits them: cells in grid_.cell_order, each cell's list sorted first
     // (reprojectCell, :152: good points before unknown ones before candidates; stable, like std::list::sort).  A point
-    // lies in one cell only, so sorting every cell before the batch gives the lists the visiting loop would produce.
-    for (size_t i = 0; i < grid_.cells.size(); ++i) {
+    // lies in one cell only, so sorting a cell before the batch gives the list the visiting loop would produce.
+    size_t i = first_cell, cells_with_trials = 0;
+    for (; i < n_cells && cells_with_trials < max_cells_with_trials; ++i) {
       Cell& cell = *grid_.cells.at(grid_.cell_order[i]);
       sortCell(cell);
       visit_begin[i] = visit.size();
+      const size_t before = trials.size();
       for (Cell::iterator c = cell.begin(); c != cell.end(); ++c) {
         if (c->pt->type_ == Point::TYPE_DELETED) continue;
         Feature* ref_ftr = NULL;
@@ -168,13 +179,15 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
           visit.push_back(-1);
           continue;
         }
-        visit.push_back((int32_t)trials.size());
+        visit.push_back((int32_t)(base + trials.size()));
         trials.push_back(&*c);
         trial_ref.push_back(ref_ftr);
         trial_cell.push_back((int32_t)i);
       }
+      if (trials.size() > before) ++cells_with_trials;
     }
-    visit_begin[grid_.cells.size()] = visit.size();
+    const size_t end_cell = i;
+    for (size_t k = end_cell; k <= n_cells; ++k) visit_begin[k] = visit.size();
     const size_t M = trials.size();
     const size_t n_obs = M;
     if (M > 0) {
@@ -190,7 +203,7 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
       FrameTable frames(dev, L);
       const int i_cur = frames.indexOf(frame.get());
       // the frame gets its features here and nowhere else: what the pose optimizer will be handed is known
-      predict = svo_hip::Device::speculationEnabled() && frame->fts_.empty();
+      predict = first_cell == 0 && svo_hip::Device::speculationEnabled() && frame->fts_.empty();
       const size_t cap = std::min(M, (size_t)Config::maxFts() + 1);
 
       int32_t *d_cur, *d_ptr, *d_cell; double* d_pos;
@@ -201,7 +214,7 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
       std::vector<double> px_in(2 * M);  // goes into the in/out block below
       FeatureColumns obs;
       obs.alloc(a, n_obs);
-      obs_ftr.resize(n_obs);
+      std::vector<Feature*> obs_ftr(n_obs);
       size_t o = 0;
       for (size_t m = 0; m < M; ++m) {
         const Point* pt = trials[m]->pt;
@@ -309,14 +322,27 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
       }
       stage_timer.unmarshal();
 
-      res_px = px; res_ok = ok; res_ref = ref; res_lvl = lvl; res_A = A;  // the arena stays until the lane's next call
+      // out of the arena: a later batch (or anything else on this lane) may reuse it
+      R_px.insert(R_px.end(), px, px + 2 * M);
+      R_A.insert(R_A.end(), A, A + 4 * M);
+      R_ok.insert(R_ok.end(), ok, ok + M);
+      R_lvl.insert(R_lvl.end(), lvl, lvl + M);
+      for (size_t m = 0; m < M; ++m) R_ref.push_back(ref[m] >= 0 ? obs_ftr[ref[m]] : NULL);
     }
-  }
+    return end_cell;
+  };
+  if (options_.find_match_direct) enumerated_end = runBatch(0, first_batch_cells);
 
   // ---- 4. per cell, in the shuffled order: the best-quality point that matched ---------------
   for (size_t i = 0; i < grid_.cells.size(); ++i) {
     Cell& cell = *grid_.cells.at(grid_.cell_order[i]);
     if (!options_.find_match_direct) sortCell(cell);  // (sorted above otherwise)
+    if (options_.find_match_direct && i == enumerated_end) {
+      // the cells of the first batch are used up and the loop has not stopped: the rest, without the prediction (the
+      // device selected among the first batch's trials only)
+      predict = false;
+      enumerated_end = runBatch(i, n_cells);
+    }
     bool matched = false;
     size_t v = visit_begin[i];  // the candidates step 3 listed for this cell, in this order
     for (Cell::iterator it = cell.begin(); it != cell.end() && !matched;) {
@@ -328,10 +354,10 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
         if (v >= visit_begin[i + 1]) throw std::logic_error("Reprojector: candidate without a device trial");
         r.trial = visit[v++];
         const int m = r.trial;
-        r.ok = m >= 0 && res_ok[m] != 0;
-        r.px = m >= 0 ? Vector2d(res_px[2 * m], res_px[2 * m + 1]) : it->px;
-        r.search_level = m >= 0 ? res_lvl[m] : 0;
-        r.ref_ftr = (m >= 0 && res_ref[m] >= 0) ? obs_ftr[res_ref[m]] : NULL;
+        r.ok = m >= 0 && R_ok[m] != 0;
+        r.px = m >= 0 ? Vector2d(R_px[2 * m], R_px[2 * m + 1]) : it->px;
+        r.search_level = m >= 0 ? R_lvl[m] : 0;
+        r.ref_ftr = m >= 0 ? R_ref[m] : NULL;
       } else {  // accept the projection as it is
         r.trial = -1; r.ok = true; r.px = it->px; r.search_level = 0; r.ref_ftr = NULL;
       }
@@ -351,8 +377,8 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
       if (r.ref_ftr != NULL && r.ref_ftr->type == Feature::EDGELET) {
         new_feature->type = Feature::EDGELET;
         Matrix2d A_cur_ref;
-        A_cur_ref(0, 0) = res_A[4 * r.trial]; A_cur_ref(0, 1) = res_A[4 * r.trial + 1];
-        A_cur_ref(1, 0) = res_A[4 * r.trial + 2]; A_cur_ref(1, 1) = res_A[4 * r.trial + 3];
+        A_cur_ref(0, 0) = R_A[4 * r.trial]; A_cur_ref(0, 1) = R_A[4 * r.trial + 1];
+        A_cur_ref(1, 0) = R_A[4 * r.trial + 2]; A_cur_ref(1, 1) = R_A[4 * r.trial + 3];
         new_feature->grad = A_cur_ref * r.ref_ftr->grad;
         new_feature->grad.normalize();
       }
