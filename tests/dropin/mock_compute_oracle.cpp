@@ -262,6 +262,56 @@ int svo_hip_compute_tau_batch(int S, const double* d_t, const double* d_f, const
   return SVO_HIP_OK;
 }
 
+// the stand-alone seams (hipm flavour: Matcher::findEpipolarMatchDirect, feature_alignment::align1D / align2D)
+int svo_hip_find_epipolar_match_direct(const svo_hip_pyr_layout* L, const uint8_t* store, const svo_hip_camera* cam,
+                                       const svo_hip_frames* frames, int S, const int32_t* d_cur_frame, const svo_hip_features* ftr,
+                                       const double* d_d_estimate, const double* d_d_min, const double* d_d_max,
+                                       const svo_hip_depth_filter_options* opt, int32_t* d_ok, double* d_depth, double* d_px_cur,
+                                       int32_t* d_search_level, void*, size_t, void*) {
+  const orc_pinhole c = camOf(cam);
+  const std::vector<orc_frame> fr = framesOf(L, store, frames);
+  orc_matcher_options mopt;
+  orc_matcher_options_default(&mopt);
+  mopt.align_1d = opt->align_1d;
+  mopt.align_max_iter = opt->align_max_iter;
+  mopt.max_epi_search_steps = opt->max_epi_search_steps;
+  mopt.subpix_refinement = opt->subpix_refinement;
+  mopt.epi_search_edgelet_filtering = opt->epi_search_edgelet_filtering;
+  mopt.epi_search_edgelet_max_angle = opt->epi_search_edgelet_max_angle;
+  mopt.n_pyr_levels = opt->n_pyr_levels;
+  for (int s = 0; s < S; ++s) {
+    const orc_feature f = featureOf(ftr, s);
+    orc_match_result r;
+    std::memset(&r, 0, sizeof(r));
+    const int ok = orc_find_epipolar_match_direct(fr.data(), &c, f.frame, d_cur_frame[s], &f, d_d_estimate[s], d_d_min[s], d_d_max[s],
+                                                  &mopt, &r);
+    d_ok[s] = ok;
+    d_depth[s] = ok ? r.depth : 0.0;
+    if (d_px_cur) { d_px_cur[2 * s] = r.px_cur[0]; d_px_cur[2 * s + 1] = r.px_cur[1]; }
+    if (d_search_level) d_search_level[s] = r.reject ? -1 : r.search_level;  // rejected before matcher.cpp:214
+  }
+  return SVO_HIP_OK;
+}
+
+int svo_hip_align_batch(const svo_hip_pyr_layout* L, const uint8_t* store, int M, const int32_t* d_slot, const int32_t* d_level,
+                        const uint8_t* d_pwb, const float* d_dir, const uint8_t* d_use_1d, int n_iter, double* d_px, int32_t* d_ok,
+                        double* d_h_inv, void*) {
+  for (int t = 0; t < M; ++t) {
+    const int l = d_level[t];
+    const uint8_t* img = store + (int64_t)d_slot[t] * L->slot_bytes + L->offset[l];
+    const uint8_t* pwb = d_pwb + 100 * t;
+    uint8_t patch[64];  // Matcher::createPatchFromPatchWithBorder: the interior of the 10x10
+    for (int y = 0; y < 8; ++y) std::memcpy(patch + 8 * y, pwb + 10 * (y + 1) + 1, 8);
+    double px[2] = {d_px[2 * t], d_px[2 * t + 1]};
+    double hinv = 0.0;
+    if (d_use_1d && d_use_1d[t]) d_ok[t] = orc_align1d(img, L->w[l], L->h[l], L->pitch[l], d_dir + 2 * t, pwb, patch, n_iter, px, &hinv);
+    else d_ok[t] = orc_align2d(img, L->w[l], L->h[l], L->pitch[l], pwb, patch, n_iter, px);
+    d_px[2 * t] = px[0]; d_px[2 * t + 1] = px[1];
+    if (d_h_inv) d_h_inv[t] = hinv;
+  }
+  return SVO_HIP_OK;
+}
+
 size_t svo_hip_fast_workspace_bytes(const svo_hip_pyr_layout*, int, int) { return 256; }
 
 int svo_hip_fast_detect(const svo_hip_pyr_layout* L, const uint8_t* store, int n_frames, const int32_t* d_slot, int n_levels,

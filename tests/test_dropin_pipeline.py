@@ -222,6 +222,21 @@ def test_mock_device_arena_modes_and_no_prediction(mock_lib, tmp_path):
     assert hits["second_batch"] == [0, 0]
 
 
+def test_mock_device_standalone_seams(mock_lib):
+    """Flavour "hipm" on the mock device: the reference's own Reprojector / DepthFilter / FastDetector calling the drop-in
+    Matcher::findMatchDirect / findEpipolarMatchDirect (one trial per call) and feature_alignment::align1D / align2D --
+    their marshalling (one Feature, one frame pair, scratch slots for stand-alone images) against the all-reference run."""
+    if not pp.available("hipmmock"):
+        pytest.skip("tests/dropin/_build/libsvo_pipeline_hipmmock.so not built")
+    cam, imgs, T = _sequence(45, seed=5)
+    ref = pp.run_sequence("ref", cam, imgs, T)
+    mock = pp.run_sequence("hipmmock", cam, imgs, T)
+    d = se3.log_norm(np.stack([r["T_f_w"] for r in mock]), np.stack([r["T_f_w"] for r in ref]))
+    assert d.max() <= MOCK_TOL, d.max()
+    _same_decisions(ref, mock, ("is_keyframe", "n_obs", "repr_n_mps", "repr_n_new_references", "n_kfs", "stage",
+                                "img_align_n_tracked", "n_seeds", "n_candidates"))
+
+
 @pytest.mark.gpu
 def test_dropin_trajectory_matches_cpu_reference(pipeline_libs, gpu_device):
     cam, imgs, T = _sequence(120)
