@@ -210,7 +210,7 @@ void Device::ensureConfigured(int width, int height, int n_levels) {
 }
 
 namespace {
-int g_deferred_mapping = -1;  // -1: ask the environment
+std::atomic<int> g_deferred_mapping(-1);  // -1: ask the environment
 void runDeferred(Lane& lane) {
   if (!lane.deferred) return;
   std::function<void()> f;
@@ -220,14 +220,16 @@ void runDeferred(Lane& lane) {
 }  // namespace
 
 bool Device::deferredMapping() {
-  if (g_deferred_mapping < 0) {
+  int m = g_deferred_mapping.load();
+  if (m < 0) {
     const char* v = std::getenv("SVO_HIP_MAPPER");
     if (v && std::string(v) != "deferred" && std::string(v) != "sync") throw Error("SVO_HIP_MAPPER must be 'deferred' or 'sync'");
-    g_deferred_mapping = v && std::string(v) == "deferred";
+    m = v && std::string(v) == "deferred";
+    g_deferred_mapping.store(m);
   }
-  return g_deferred_mapping != 0;
+  return m != 0;
 }
-void Device::setDeferredMapping(bool on) { g_deferred_mapping = on; }
+void Device::setDeferredMapping(bool on) { g_deferred_mapping.store(on ? 1 : 0); }
 
 void Device::joinDeferred(int which_lane) {
   Lane* l = NULL;
