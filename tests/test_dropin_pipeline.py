@@ -222,6 +222,31 @@ def test_mock_device_arena_modes_and_no_prediction(mock_lib, tmp_path):
     assert hits["second_batch"] == [0, 0]
 
 
+def test_mock_device_two_cameras_of_different_geometry(mock_lib):
+    """Two FrameHandlerMono instances (752x480 and 640x480) fed alternately in one process: one device context per image
+    geometry, each with its own store layout, lanes and predictions; deferred mapping on for both."""
+    cam_a, imgs_a, T_a = _sequence(40)
+    cam_b = synth.Camera(640, 480, 400.0, 400.0, 320.0, 240.0)
+    T_b = synth.make_trajectory(40, seed=9, max_step=0.02, max_rot_deg=0.3)
+    imgs_b = synth.render(synth.make_texture(seed=12345), T_b, cam_b).numpy()
+    ref_a = pp.run_sequence("ref", cam_a, imgs_a, T_a)
+    ref_b = pp.run_sequence("ref", cam_b, imgs_b, T_b)
+    pa, pb = pp.Pipeline("hipmock", cam_a, defer_mapper=1), pp.Pipeline("hipmock", cam_b, defer_mapper=1)
+    try:
+        pa.set_first_frame(imgs_a[0], 0.0, T_a[0], pp.range_map(cam_a, T_a[0]))
+        pb.set_first_frame(imgs_b[0], 0.0, T_b[0], pp.range_map(cam_b, T_b[0]))
+        for i in range(1, 40):
+            ra = pa.add_image(imgs_a[i], float(i))
+            rb = pb.add_image(imgs_b[i], float(i))
+            assert se3.log_norm(ra["T_f_w"][None], ref_a[i]["T_f_w"][None])[0] <= MOCK_TOL
+            assert se3.log_norm(rb["T_f_w"][None], ref_b[i]["T_f_w"][None])[0] <= MOCK_TOL
+            assert ra["is_keyframe"] == ref_a[i]["is_keyframe"] and rb["is_keyframe"] == ref_b[i]["is_keyframe"]
+            assert ra["n_obs"] == ref_a[i]["n_obs"] and rb["n_obs"] == ref_b[i]["n_obs"]
+    finally:
+        pa.close()
+        pb.close()
+
+
 def test_mock_device_standalone_seams(mock_lib):
     """Flavour "hipm" on the mock device: the reference's own Reprojector / DepthFilter / FastDetector calling the drop-in
     Matcher::findMatchDirect / findEpipolarMatchDirect (one trial per call) and feature_alignment::align1D / align2D --
