@@ -161,6 +161,7 @@ class Device {
   const svo_hip_pyr_layout& layout() const { return layout_; }
   const uint8_t* store() const { return d_store_; }
   int nLevels() const { return layout_.n_levels; }
+  int slots() const { return n_slots_; }  // size of the pyramid pool
 
   // Every entry point brackets its work with beginCall(): slots touched since then are
   // pinned (never evicted) until the lane's next beginCall().

@@ -102,9 +102,13 @@ void* pipe_create_cam(int width, int height, int cam_model, const double* p9, co
   else
     p->cam = new vk::PinholeCamera(width, height, p9[0], p9[1], p9[2], p9[3], p9[4], p9[5], p9[6], p9[7], p9[8]);
 #ifdef SVO_PIPELINE_HIP
-  if (c->pool_slots > 0) {
-    int levels = c->n_pyr_levels > c->klt_max_level + 1 ? c->n_pyr_levels : c->klt_max_level + 1;  // frame.cpp:58
-    svo_hip::Device::instance().configure(width, height, levels, c->pool_slots);
+  {
+    // the device context of this image geometry, with the pool size this pipeline asks for (contexts outlive the
+    // pipelines of a process: an earlier pipeline's small pool must not be inherited)
+    const int levels = c->n_pyr_levels > c->klt_max_level + 1 ? c->n_pyr_levels : c->klt_max_level + 1;  // frame.cpp:58
+    const int want = c->pool_slots > 0 ? c->pool_slots : 64;
+    svo_hip::Device& dev = svo_hip::Device::forGeometry(width, height, levels);
+    if (dev.slots() != want) dev.configure(width, height, levels, want);
   }
 #endif
 #ifdef SVO_PIPELINE_HIP
