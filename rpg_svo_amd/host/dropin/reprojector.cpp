@@ -338,9 +338,9 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
     Cell& cell = *grid_.cells.at(grid_.cell_order[i]);
     if (!options_.find_match_direct) sortCell(cell);  // (sorted above otherwise)
     if (options_.find_match_direct && i == enumerated_end) {
-      // the cells of the first batch are used up and the loop has not stopped: the rest, without the prediction (the
-      // device selected among the first batch's trials only)
-      predict = false;
+      // the cells of the first batch are used up and the loop has not stopped: the rest.  If that brings new trials the
+      // prediction goes (the device selected among the first batch's trials only): runBatch() clears `predict` and its
+      // beginCall() drains what was enqueued
       enumerated_end = runBatch(i, n_cells);
     }
     bool matched = false;
