@@ -18,6 +18,8 @@
 // bench.py --pipeline dropin).  No arithmetic of the path lives here.
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
+#include <string>
 
 #include <svo/config.h>
 #include <svo/depth_filter.h>
@@ -202,11 +204,22 @@ int pipe_set_first_frame(void* h, const uint8_t* img, double timestamp, const do
   return n;
 }
 
+static std::string g_last_error;
+const char* pipe_last_error(void) { return g_last_error.c_str(); }
+
+// Returns the handler's stage, or -1 when a drop-in body threw (svo_hip::Error: no device, pool too small, a failed
+// launch ...): the message is in pipe_last_error() and the pipeline should be closed (the reference's control plane is
+// not written to be resumed after an exception).
 int pipe_add_image(void* h, const uint8_t* img, double timestamp, pipe_result* out) {
   Pipe* p = (Pipe*)h;
   const int w = p->cam->width(), hh = p->cam->height();
   cv::Mat m(hh, w, CV_8UC1, (void*)img);
-  p->vo->addImage(m, timestamp);  // addImage clones (frame_handler_mono.cpp:69)
+  try {
+    p->vo->addImage(m, timestamp);  // addImage clones (frame_handler_mono.cpp:69)
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return -1;
+  }
   fill_result(p, out);
   return (int)p->vo->stage();
 }

@@ -96,7 +96,9 @@ class Pipeline:
     def add_image(self, img, ts):
         img = np.ascontiguousarray(img, dtype=np.uint8)
         r = Result()
-        self.lib.pipe_add_image(self.h, img.ctypes.data, ts, C.byref(r))
+        if self.lib.pipe_add_image(self.h, img.ctypes.data, ts, C.byref(r)) < 0:
+            self.lib.pipe_last_error.restype = C.c_char_p
+            raise RuntimeError("drop-in body threw: " + self.lib.pipe_last_error().decode(errors="replace"))
         return r.as_dict()
 
     def device_stats(self):

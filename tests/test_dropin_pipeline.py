@@ -247,6 +247,16 @@ def test_mock_device_two_cameras_of_different_geometry(mock_lib):
         pb.close()
 
 
+def test_mock_device_pool_too_small_is_an_error(mock_lib):
+    """Two pyramid slots for a pipeline that needs the current frame and its reference keyframes resident at once: the
+    host layer refuses (svo_hip::Error names the remedy) instead of evicting a frame a running call uses."""
+    cam, imgs, T = _sequence(12)
+    with pytest.raises(RuntimeError, match="larger pool"):
+        pp.run_sequence("hipmock", cam, imgs, T, pool_slots=2)
+    ok = pp.run_sequence("hipmock", cam, imgs, T)  # the context recovers with the next pipeline's own pool
+    assert all(r["stage"] == pp.STAGE_DEFAULT_FRAME for r in ok)
+
+
 def test_mock_device_standalone_seams(mock_lib):
     """Flavour "hipm" on the mock device: the reference's own Reprojector / DepthFilter / FastDetector calling the drop-in
     Matcher::findMatchDirect / findEpipolarMatchDirect (one trial per call) and feature_alignment::align1D / align2D --
