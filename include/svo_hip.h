@@ -78,6 +78,10 @@ int svo_hip_event_elapsed_ms(void* start, void* stop, float* ms_out); /* syncs o
 int svo_hip_event_sync(void* event);                      /* host waits for the work recorded before `event` */
 int svo_hip_event_query(void* event);                     /* 1: that work is done, 0: still running, <0: error */
 int svo_hip_stream_wait_event(void* stream, void* event); /* later work of `stream` waits for it on the device */
+/* *ptr = value, written by the stream's command processor once everything enqueued before has completed (no kernel
+ * launch).  `ptr` is device-visible memory, e.g. page-locked host memory of svo_hip_host_alloc: a host thread can then
+ * poll it instead of calling svo_hip_stream_sync. */
+int svo_hip_stream_write_value32(void* stream, int32_t* ptr, int32_t value);
 
 /* HIP graphs: every entry point below only enqueues kernels / memsets on `stream`, so a fixed
  * chain of calls (same pointers, same sizes: e.g. one tracked frame of every camera of a rig) can

@@ -105,6 +105,7 @@ PROTOTYPES = {
     "svo_hip_event_sync": (_i, [_vp]),
     "svo_hip_event_query": (_i, [_vp]),
     "svo_hip_stream_wait_event": (_i, [_vp, _vp]),
+    "svo_hip_stream_write_value32": (_i, [_vp, _vp, _i]),
     "svo_hip_graph_begin_capture": (_i, [_vp]),
     "svo_hip_graph_end_capture": (_i, [_vp, C.POINTER(_vp)]),
     "svo_hip_graph_launch": (_i, [_vp, _vp]),

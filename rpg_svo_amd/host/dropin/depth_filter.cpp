@@ -152,7 +152,7 @@ void DepthFilter::updateSeeds(FramePtr frame) {
     };
     return;
   }
-  svo_hip::check(svo_hip_stream_sync(stream), "svo_hip_stream_sync");
+  dev.finish(lane);
   stage_timer.unmarshal();
   replay();  // seeds_mut_ is held
 }

@@ -76,7 +76,8 @@ void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const 
       wait_timer.device(0);
       sp.valid = false;
       sp.in_flight = false;
-      svo_hip::check(svo_hip_stream_sync(sp.stream), "svo_hip_stream_sync");
+      if (sp.stream == lane.stream) dev.finish(lane);
+      else svo_hip::check(svo_hip_stream_sync(sp.stream), "svo_hip_stream_sync");
       wait_timer.unmarshal();
       // the device applied the selection rule on its own: it must have picked the trials the host picked; a frame the
       // wave kernel left to the ordered kernel (ran == 2: singular normal equations) takes the ordinary call below
@@ -129,7 +130,7 @@ void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const 
                                                 (int)n_iter, d_Tout, d_Cov, d_stats, d_ran, lane.stream),
                  "svo_hip_pose_optimize_deferred");
   a.download(lane.stream);
-  svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+  dev.finish(lane);
   if (*ran == 2) {  // untouched by the wave kernel: the ordered kernel on the same blocks
     svo_hip::check(svo_hip_pose_optimize_ordered(&cam, 1, d_n, (int)n, d_f, d_level, d_pos, d_has_out, reproj_thresh,
                                                  (int)n_iter, d_Tout, d_Cov, d_stats, d_ran, lane.stream),

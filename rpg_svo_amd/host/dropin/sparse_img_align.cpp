@@ -96,7 +96,7 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
                                       d_valid, &P, d_Tin, d_Tout, d_H, d_ntracked, d_iters, d_chi2, d_status, lane.stream),
                  "svo_hip_sparse_align");
   a.download(lane.stream);
-  svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+  dev.finish(lane);
   stage_timer.unmarshal();
 
   cur_frame->T_f_w_ = poseFromRt(Tout) * ref_frame->T_f_w_;  // :70

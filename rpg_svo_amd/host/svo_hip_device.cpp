@@ -140,6 +140,17 @@ Lane* Device::makeLane() {
   check(svo_hip_event_create(&l->ev_results), "svo_hip_event_create");
   l->index = next_lane_index_++;
   check(svo_hip_malloc(&l->d_stage, (size_t)layout_.w[0] * layout_.h[0]), "svo_hip_malloc(stage)");
+  {
+    const char* w = std::getenv("SVO_HIP_WAIT");
+    if (w && std::string(w) == "signal") {
+      void* f = NULL;
+      check(svo_hip_host_alloc(&f, 256), "svo_hip_host_alloc(done flag)");
+      l->done_flag = static_cast<int32_t*>(f);
+      *l->done_flag = 0;
+    } else if (w && std::string(w) != "sync") {
+      throw Error("SVO_HIP_WAIT must be 'sync' or 'signal'");
+    }
+  }
   l->arena.reserve((size_t)4 << 20);
   // SVO_HIP_ARENA=mapped|mirrored selects how a call's arguments reach the device (Arena)
   const char* mode = std::getenv("SVO_HIP_ARENA");
@@ -172,6 +183,7 @@ void Device::shutdown() {
       l.arena.release();
       if (l.d_workspace) { svo_hip_free(l.d_workspace); l.d_workspace = NULL; l.workspace_bytes = 0; }
       if (l.d_stage) { svo_hip_free(l.d_stage); l.d_stage = NULL; }
+      if (l.done_flag) { svo_hip_host_free(l.done_flag); l.done_flag = NULL; }
       delete it->second;
     }
     lanes_.clear();
@@ -230,6 +242,16 @@ bool Device::deferredMapping() {
   return m != 0;
 }
 void Device::setDeferredMapping(bool on) { g_deferred_mapping.store(on ? 1 : 0); }
+
+void Device::finish(Lane& lane) {
+  if (!lane.done_flag) {
+    check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+    return;
+  }
+  const int32_t seq = ++lane.done_seq;
+  check(svo_hip_stream_write_value32(lane.stream, lane.done_flag, seq), "svo_hip_stream_write_value32");
+  spinUntil(lane.done_flag, seq, lane.stream);
+}
 
 void Device::joinDeferred(int which_lane) {
   Lane* l = NULL;

@@ -191,8 +191,9 @@ def test_mock_device_with_the_mapping_thread(mock_lib):
 
 
 def test_mock_device_arena_modes_and_no_prediction(mock_lib, tmp_path):
-    """SVO_HIP_ARENA = hybrid / mirrored / mapped, SVO_HIP_SPECULATE = 0 and a first match batch too small to reach the
-    visiting loop's stop (fixed when a lane / the process starts: one process each): the host code paths differ -- where blocks live, which copies are issued, polling a signal or
+    """SVO_HIP_ARENA = hybrid / mirrored / mapped, SVO_HIP_SPECULATE = 0, a first match batch too small to reach the
+    visiting loop's stop, and SVO_HIP_WAIT = signal (the host polls a word the stream writes instead of synchronising;
+    all fixed when a lane / the process starts: one process each): the host code paths differ -- where blocks live, which copies are issued, polling a signal or
     waiting for a stream, prediction on the same or on a second stream or none -- the results do not."""
     import subprocess
     code = (
@@ -207,14 +208,15 @@ def test_mock_device_arena_modes_and_no_prediction(mock_lib, tmp_path):
         "print(st['predicted_pose_hits'], st['predicted_pose_misses'])\n")
     out, hits = {}, {}
     for name, env in (("hybrid", {}), ("mirrored", {"SVO_HIP_ARENA": "mirrored"}), ("mapped", {"SVO_HIP_ARENA": "mapped"}),
-                      ("no_prediction", {"SVO_HIP_SPECULATE": "0"}), ("second_batch", {"SVO_HIP_FIRST_BATCH_CELLS": "40"})):
+                      ("no_prediction", {"SVO_HIP_SPECULATE": "0"}), ("second_batch", {"SVO_HIP_FIRST_BATCH_CELLS": "40"}),
+                      ("signal_wait", {"SVO_HIP_WAIT": "signal"})):
         path = str(tmp_path / f"traj_{name}.npy")
         p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True,
                            timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         out[name] = np.load(path)
         hits[name] = [int(x) for x in p.stdout.split()[-2:]]
-    for name in ("mirrored", "mapped", "no_prediction", "second_batch"):
+    for name in ("mirrored", "mapped", "no_prediction", "second_batch", "signal_wait"):
         assert np.array_equal(out[name], out["hybrid"]), name
     assert hits["hybrid"] == [49, 0] and hits["mirrored"] == [49, 0] and hits["mapped"] == [49, 0] and hits["no_prediction"] == [0, 0]
     # a first batch of 40 cells never reaches the stop at 121 matches: the rest of the cells goes in a second batch and the
