@@ -1,5 +1,7 @@
 // capi_util.hip -- error strings, raw device helpers and the pyramid-store
 // layout of the C ABI (include/svo_hip.h).  No kernels here.
+#include <dlfcn.h>
+
 #include <cstring>
 
 #include <cmath>
@@ -157,7 +159,11 @@ int svo_hip_stream_wait_event(void* stream, void* event) {
 
 int svo_hip_stream_write_value32(void* stream, int32_t* ptr, int32_t value) {
   if (!ptr) return SVO_HIP_EINVAL;
-  SVO_HIP_TRY(hipStreamWriteValue32(static_cast<hipStream_t>(stream), ptr, (uint32_t)value, 0));
+  // looked up at first use, not at load time: an experimental path must not be able to keep the library from loading
+  typedef hipError_t (*write32_fn)(hipStream_t, void*, uint32_t, unsigned int);
+  static const write32_fn fn = reinterpret_cast<write32_fn>(dlsym(RTLD_DEFAULT, "hipStreamWriteValue32"));
+  if (!fn) return SVO_HIP_EINVAL;
+  SVO_HIP_TRY(fn(static_cast<hipStream_t>(stream), ptr, (uint32_t)value, 0));
   return SVO_HIP_OK;
 }
 
