@@ -62,3 +62,34 @@ def test_valu_roofline_pricing():
     raw.pop("SQ_BUSY_CU_CYCLES")
     r2 = bench.valu_roofline(raw, kernel_ms=1.0)
     assert abs(r2["cu_cycles_per_launch"] - 1e-3 * bench.CLOCK_GHZ * 1e9) < 1e-6
+
+
+def test_last_stdout_line_is_compact_and_round_trips():
+    """the driver could not parse a 21 KB line.  The last stdout line is compact_line(result): below 4 KB
+    whatever the legs put into the full object, valid JSON, and carrying the contract keys + roofline (with counter
+    traffic) + cpu_baseline + parity."""
+    import json
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_default.json")))   # a real 21 KB result object
+    assert len(json.dumps(full)) > 15000
+    full["dtype_short"] = "f32 pixels, f64 pose"
+    full["cpu_baseline"]["sample_short"] = "2048 frame pairs, 1 thread"
+    line = json.dumps(bench.compact_line(full, "bench_details.json"))
+    assert len(line) < bench.COMPACT_LIMIT and "\n" not in line
+    c = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "details"):
+        assert k in c, k
+    assert c["config"]["workload"] == "vga4_n200_sparse_align" and "model" not in c["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "ms", "kernel"):
+        assert k in c["roofline"], k
+    assert abs(c["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-5 * full["roofline"]["frac"]
+    assert abs(c["value"] - full["value"]) <= 1e-5 * full["value"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c["cpu_baseline"], k
+    assert c["legs"]["full_track"]["ms_per_step"] > 0 and c["legs"]["dropin_sequence"]["ms_hip"] > 0
+    # an absurdly large leg cannot push the line over the limit: optional blocks are dropped, the contract keys stay
+    full["full_track"]["stages_ms"] = {f"stage{i}": float(i) for i in range(2000)}
+    c2 = bench.compact_line(full, None)
+    assert len(json.dumps(c2)) < bench.COMPACT_LIMIT and "roofline" in c2 and "cpu_baseline" in c2
+    # NaN / inf never reach the line as bare tokens json.loads of a strict parser would refuse
+    assert "NaN" not in line and "Infinity" not in line
