@@ -1203,18 +1203,22 @@ def pyramid_roofline(ev: Events, store, images, reps: int = 5) -> dict:
             "ms_level0_copy_plus_one_launch_per_level": unfused, "ms_by_tile_width": tiles}
 
 
-def dropin_sequence(n_frames: int = 120) -> dict:
+def dropin_sequence(n_frames: int = 600) -> dict:
     """Single-stream, image-in -> pose-out: the reference's own svo::FrameHandlerMono on a
     752x480 synthetic sequence, once with all-reference translation units on the host CPU and
     once with the drop-in HIP bodies (tests/dropin, rpg_svo_amd/host/dropin).  Reports the
-    trajectory agreement (the metric's "ATE vs CPU ref") and the per-frame latency of both."""
+    trajectory agreement (the metric's "ATE vs CPU ref") and the per-frame latency of both.
+
+    600 frames: the map then holds what the reference's own trace shows (svo/test/benchmark.csv:
+    max_n_kfs = 10 overlapping keyframes, ~950 candidate points) -- 10 keyframes from frame ~150 on and 1400-1900
+    candidates; `map_size` reports the medians over the frames the latencies are taken from."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "dropin"))
     import pypipeline as pp
     if not (pp.available("ref") and pp.available("hip")):
         raise RuntimeError("tests/dropin/_build/*.so not built")
     cam = synth.Camera(752, 480, 315.5, 315.5, 376.0, 240.0)
     T = synth.make_trajectory(n_frames, seed=5, max_step=0.02, max_rot_deg=0.3)
-    imgs = synth.render(synth.make_texture(seed=12345), T, cam).numpy()
+    imgs = synth.render(synth.make_texture(seed=12345), T, cam, device="cuda" if torch.cuda.is_available() else "cpu").cpu().numpy()
     devnull = os.open(os.devnull, os.O_WRONLY)
     saved = os.dup(2)
     os.dup2(devnull, 2)  # the reference logs every frame to stderr
@@ -1236,7 +1240,15 @@ def dropin_sequence(n_frames: int = 120) -> dict:
     d = se3.log_norm(Th, Tr)
     med = lambda rs, k: float(np.median([r[k] for r in rs[1:]]) * 1e3)
     stages = ("tot_time", "sparse_img_align", "reproject", "pose_optimizer")
-    return {"frames": n_frames, "image": "752x480", "se3_lognorm_max": float(d.max()), "se3_lognorm_median": float(np.median(d)),
+    medi = lambda rs, k: float(np.median([r[k] for r in rs[1:]]))
+    map_size = {"frames_with_full_keyframe_set": int(sum(r["n_kfs"] >= 10 for r in hip)),
+                "n_kfs": medi(hip, "n_kfs"), "overlap_kfs": medi(hip, "n_overlap_kfs"),
+                "n_candidates": medi(hip, "n_candidates"), "n_candidates_max": int(max(r["n_candidates"] for r in hip)),
+                "kf_points_in_frame": medi(hip, "n_kf_points_in_frame"), "n_seeds": medi(hip, "n_seeds"),
+                "trials": medi(hip, "repr_n_mps"), "matches": medi(hip, "repr_n_new_references"),
+                "same_as_cpu_reference": all(all(a[k] == b[k] for k in ("n_kfs", "n_overlap_kfs", "n_kf_points_in_frame", "repr_n_mps", "repr_n_new_references"))
+                                             for a, b in zip(ref, hip))}
+    return {"frames": n_frames, "map_size": map_size, "image": "752x480", "se3_lognorm_max": float(d.max()), "se3_lognorm_median": float(np.median(d)),
             "ate_rmse_vs_cpu_m": horn_ate(se3.inv(Th)[:, 9:], se3.inv(Tr)[:, 9:]),
             "keyframes": int(sum(r["is_keyframe"] for r in hip)),
             "same_keyframe_frames": [r["is_keyframe"] for r in ref] == [r["is_keyframe"] for r in hip],

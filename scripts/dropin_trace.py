@@ -16,20 +16,30 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "dropin"))
 
 
+def _frames():
+    for a in sys.argv[1:]:
+        if a.startswith("frames="):
+            return int(a.split("=")[1])
+    return 120
+
+
 def run(defer):
     import numpy as np
     import pypipeline as pp
     from rpg_svo_amd import synth
     cam = synth.Camera(752, 480, 315.5, 315.5, 376.0, 240.0)
-    T = synth.make_trajectory(120, seed=5, max_step=0.02, max_rot_deg=0.3)
-    imgs = synth.render(synth.make_texture(seed=12345), T, cam).numpy()
+    T = synth.make_trajectory(_frames(), seed=5, max_step=0.02, max_rot_deg=0.3)
+    import torch
+    imgs = synth.render(synth.make_texture(seed=12345), T, cam, device="cuda" if torch.cuda.is_available() else "cpu").cpu().numpy()
     devnull = os.open(os.devnull, os.O_WRONLY)
     os.dup2(devnull, 2)
     pp.run_sequence("hip", cam, imgs[:20], T[:20], defer_mapper=defer)
     st = {}
     res = pp.run_sequence("hip", cam, imgs, T, stats_out=st, defer_mapper=defer)
-    print("tot_time median %.1f us, frame period %.1f us" % (np.median([r["t_tot_time"] for r in res[1:]]) * 1e6,
-                                                           st["wall_ms_per_frame"] * 1e3))
+    tail = res[-min(len(res) - 1, 400):]  # with frames=600: the frames that see the full map (10 keyframes)
+    print("tot_time median %.1f us (last %d frames: %.1f us, %g keyframes, %g candidates), frame period %.1f us" % (
+        np.median([r["t_tot_time"] for r in res[1:]]) * 1e6, len(tail), np.median([r["t_tot_time"] for r in tail]) * 1e6,
+        np.median([r["n_kfs"] for r in tail]), np.median([r["n_candidates"] for r in tail]), st["wall_ms_per_frame"] * 1e3))
     for k, v in st["stages"].items():
         print(k, {a: round(b, 1) for a, b in v.items()})
 
@@ -55,7 +65,7 @@ def report(d, frame=-1):
     ev.sort()
     # frames are delimited by the sparse-alignment kernel (one launch per frame; the last 120-frame run counts)
     sia = [e for e in ev if e[2] == "gpu" and "sia_kernel" in e[3]]
-    sia = sia[-119:]
+    sia = sia[-(_frames() - 1):]
     if frame < 0:  # the frame of median length (tracing itself produces outliers)
         periods = sorted((sia[i][0] - sia[i - 1][0], i) for i in range(20, len(sia)))
         frame = periods[len(periods) // 2][1]

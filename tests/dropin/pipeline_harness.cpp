@@ -59,11 +59,20 @@ typedef struct pipe_result {
   double img_align_n_tracked, repr_n_mps, repr_n_new_references, sfba_thresh, sfba_error_init, sfba_error_final,
       sfba_n_edges_final, dropout;
   double t_pyramid_creation, t_sparse_img_align, t_reproject, t_pose_optimizer, t_point_optimizer, t_tot_time;
+  // map size seen by Reprojector::reprojectMap of this frame: keyframes with an overlapping field of view
+  // (overlap_kfs_, <= max_n_kfs) and how many of their points fell inside the frame (the sum of the pairs' counts)
+  int32_t n_overlap_kfs, n_kf_points_in_frame;
 } pipe_result;
+
+// FrameHandlerMono::overlap_kfs_ is protected (frame_handler_mono.h:69)
+struct ExposedVo : public FrameHandlerMono {
+  explicit ExposedVo(vk::AbstractCamera* cam) : FrameHandlerMono(cam) {}
+  const std::vector<std::pair<FramePtr, size_t> >& overlap() const { return overlap_kfs_; }
+};
 
 struct Pipe {
   vk::AbstractCamera* cam;
-  FrameHandlerMono* vo;
+  ExposedVo* vo;
 };
 
 void pipe_config_default(pipe_config* c) {
@@ -117,7 +126,7 @@ void* pipe_create_cam(int width, int height, int cam_model, const double* p9, co
   svo_hip::Device::setDeferredMapping(c->defer_mapper != 0 && !c->mapper_thread);
 #endif
   std::srand((unsigned)c->shuffle_seed);  // Reprojector::initializeGrid's random_shuffle (reprojector.cpp:54)
-  p->vo = new FrameHandlerMono(p->cam);
+  p->vo = new ExposedVo(p->cam);
   p->vo->start();
   // run the mapper synchronously inside addFrame()/addKeyframe() (depth_filter.cpp:82-107):
   // deterministic interleaving of tracking and mapping for both libraries
@@ -157,6 +166,8 @@ static void fill_result(Pipe* p, pipe_result* r) {
   r->n_kfs = (int)p->vo->map().size();
   r->n_candidates = (int)p->vo->map().point_candidates_.candidates_.size();
   r->n_seeds = (int)p->vo->depthFilter()->getSeeds().size();
+  r->n_overlap_kfs = (int)p->vo->overlap().size();
+  for (size_t i = 0; i < p->vo->overlap().size(); ++i) r->n_kf_points_in_frame += (int)p->vo->overlap()[i].second;
 #ifdef SVO_TRACE
   vk::PerformanceMonitor* m = g_permon;
   r->img_align_n_tracked = m->get("img_align_n_tracked");

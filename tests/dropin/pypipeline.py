@@ -28,7 +28,8 @@ class Result(C.Structure):
                [(n, C.c_double) for n in ("img_align_n_tracked", "repr_n_mps", "repr_n_new_references", "sfba_thresh",
                                           "sfba_error_init", "sfba_error_final", "sfba_n_edges_final", "dropout",
                                           "t_pyramid_creation", "t_sparse_img_align", "t_reproject",
-                                          "t_pose_optimizer", "t_point_optimizer", "t_tot_time")]
+                                          "t_pose_optimizer", "t_point_optimizer", "t_tot_time")] + \
+               [(n, C.c_int32) for n in ("n_overlap_kfs", "n_kf_points_in_frame")]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "T_f_w"}

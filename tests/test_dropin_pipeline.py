@@ -532,3 +532,28 @@ def test_dropin_arena_modes_agree(pipeline_libs, gpu_device, tmp_path):
     for mode in ("mirrored", "mapped"):
         d = se3.log_norm(out[mode], out["hybrid"])
         assert d.max() <= SE3_LOGNORM_TOL, (mode, d.max())
+
+
+@pytest.mark.gpu
+def test_dropin_wait_modes_agree(pipeline_libs, gpu_device, tmp_path):
+    """SVO_HIP_WAIT=signal (a stream write-value command stores a sequence number behind a call's last command and the
+    host polls the pinned word: svo_hip_stream_write_value32, Device::finish) against the default hipStreamSynchronize:
+    the same kernels on the same bytes, only the way the host learns that they are through differs -- the trajectories
+    are equal bit for bit.  The mode is fixed when a lane is created, hence one process each."""
+    import subprocess
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {HERE!r}); sys.path.insert(0, {os.path.join(HERE, 'dropin')!r})\n"
+        "import pypipeline as pp\n"
+        "import test_dropin_pipeline as t\n"
+        "cam, imgs, T = t._sequence(40)\n"
+        "hip = pp.run_sequence('hip', cam, imgs, T)\n"
+        "np.save(sys.argv[1], np.stack([r['T_f_w'] for r in hip]))\n")
+    out = {}
+    for mode in ("sync", "signal"):
+        path = str(tmp_path / f"traj_{mode}.npy")
+        p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, SVO_HIP_WAIT=mode), capture_output=True,
+                           text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out[mode] = np.load(path)
+    assert np.array_equal(out["signal"], out["sync"])
