@@ -157,13 +157,14 @@ def compact_line(result: dict, details_path: str | None) -> dict:
             legs[key] = _pick(result[key], keys + ("skipped",))
     ds = result.get("dropin_sequence")
     if isinstance(ds, dict):
-        legs["dropin_sequence"] = _pick(ds, ("frames", "keyframes", "se3_lognorm_max", "ate_rmse_vs_cpu_m", "same_keyframe_frames", "skipped"))
+        legs["dropin_sequence"] = _pick(ds, ("frames", "keyframes", "first_frame_with_a_different_decision", "se3_lognorm_max_before_it",
+                                             "ate_rmse_vs_cpu_m", "ate_rmse_vs_ground_truth_m", "skipped"))
         for k_out, k_in in (("ms_cpu_ref", "median_ms_per_frame_cpu_reference"), ("ms_hip", "median_ms_per_frame_hip_dropin"),
                             ("ms_hip_deferred_mapper", "median_ms_per_frame_hip_dropin_deferred_mapper")):
             if isinstance(ds.get(k_in), dict):
                 legs["dropin_sequence"][k_out] = ds[k_in].get("tot_time")
         if isinstance(ds.get("map_size"), dict):
-            legs["dropin_sequence"]["map_size"] = ds["map_size"]
+            legs["dropin_sequence"]["map_size"] = _pick(ds["map_size"], ("n_kfs", "n_candidates", "kf_points_in_frame", "trials", "matches"))
     for key in ("gather", "rig_replay", "stages_ms"):  # small objects of the multi-GPU / --pipeline full runs: whole
         if isinstance(result.get(key), dict):
             c[key] = result[key]
@@ -1238,6 +1239,16 @@ def dropin_sequence(n_frames: int = 600) -> dict:
     Tr = np.stack([r["T_f_w"] for r in ref])
     Th = np.stack([r["T_f_w"] for r in hip])
     d = se3.log_norm(Th, Tr)
+    # A pipeline of thresholds is chaotic over hundreds of frames: the first discrete decision that falls the other way
+    # (a seed whose variance sits on the convergence threshold converges one update later; the mock device, which runs
+    # the oracle's arithmetic, does so at frame 137 of this sequence) changes the map, and the two runs are different
+    # -- equally good -- SLAM runs from there on.  So: frame-by-frame agreement up to that frame, and the accuracy of
+    # BOTH runs against the ground-truth trajectory over the whole sequence.
+    dec_keys = ("is_keyframe", "n_obs", "repr_n_mps", "repr_n_new_references", "n_kfs", "stage", "img_align_n_tracked",
+                "n_candidates", "n_seeds")
+    first_diff = next((i for i, (a, b) in enumerate(zip(ref, hip)) if any(a[k] != b[k] for k in dec_keys)), None)
+    pre = slice(0, first_diff if first_diff is not None else n_frames)
+    pos = lambda TT: se3.inv(TT)[:, 9:]
     med = lambda rs, k: float(np.median([r[k] for r in rs[1:]]) * 1e3)
     stages = ("tot_time", "sparse_img_align", "reproject", "pose_optimizer")
     medi = lambda rs, k: float(np.median([r[k] for r in rs[1:]]))
@@ -1248,7 +1259,10 @@ def dropin_sequence(n_frames: int = 600) -> dict:
                 "trials": medi(hip, "repr_n_mps"), "matches": medi(hip, "repr_n_new_references"),
                 "same_as_cpu_reference": all(all(a[k] == b[k] for k in ("n_kfs", "n_overlap_kfs", "n_kf_points_in_frame", "repr_n_mps", "repr_n_new_references"))
                                              for a, b in zip(ref, hip))}
-    return {"frames": n_frames, "map_size": map_size, "image": "752x480", "se3_lognorm_max": float(d.max()), "se3_lognorm_median": float(np.median(d)),
+    return {"frames": n_frames, "map_size": map_size,
+            "first_frame_with_a_different_decision": first_diff,
+            "se3_lognorm_max_before_it": float(d[pre].max()), "se3_lognorm_median_before_it": float(np.median(d[pre])),
+            "ate_rmse_vs_ground_truth_m": {"cpu_reference": horn_ate(pos(Tr), pos(T)), "hip_dropin": horn_ate(pos(Th), pos(T))}, "image": "752x480", "se3_lognorm_max": float(d.max()), "se3_lognorm_median": float(np.median(d)),
             "ate_rmse_vs_cpu_m": horn_ate(se3.inv(Th)[:, 9:], se3.inv(Tr)[:, 9:]),
             "keyframes": int(sum(r["is_keyframe"] for r in hip)),
             "same_keyframe_frames": [r["is_keyframe"] for r in ref] == [r["is_keyframe"] for r in hip],

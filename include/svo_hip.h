@@ -78,10 +78,6 @@ int svo_hip_event_elapsed_ms(void* start, void* stop, float* ms_out); /* syncs o
 int svo_hip_event_sync(void* event);                      /* host waits for the work recorded before `event` */
 int svo_hip_event_query(void* event);                     /* 1: that work is done, 0: still running, <0: error */
 int svo_hip_stream_wait_event(void* stream, void* event); /* later work of `stream` waits for it on the device */
-/* *ptr = value, written by the stream's command processor once everything enqueued before has completed (no kernel
- * launch).  `ptr` is device-visible memory, e.g. page-locked host memory of svo_hip_host_alloc: a host thread can then
- * poll it instead of calling svo_hip_stream_sync. */
-int svo_hip_stream_write_value32(void* stream, int32_t* ptr, int32_t value);
 
 /* HIP graphs: every entry point below only enqueues kernels / memsets on `stream`, so a fixed
  * chain of calls (same pointers, same sizes: e.g. one tracked frame of every camera of a rig) can
@@ -375,6 +371,119 @@ int svo_hip_select_matches(const svo_hip_camera* cam, int M, const int32_t* d_ce
                            const double* d_px, const int32_t* d_level, const double* d_pos, int max_fts,
                            int32_t* d_n, int32_t* d_sel, double* d_f, int32_t* d_level_out, double* d_pos_out,
                            uint8_t* d_has_point, int32_t* d_signal, int32_t signal_value, void* stream);
+
+/* ---- Row N2: a device-resident mirror of the map for Reprojector::reprojectMap ------------------------------------
+ * reprojectMap (svo/src/reprojector.cpp:64-142) walks the pointer graph Map -> keyframes -> Frame::fts_ -> Point (and
+ * MapPointCandidates::candidates_) on the host for every frame: ~2000 reprojectPoint calls into std::list cells, a
+ * list sort per cell, Point::getCloseViewObs per candidate.  The mirror keeps what that walk reads resident in HBM as
+ * SoA -- svo::Point records (point.h:35-62) with their observation lists, svo::Feature records (feature.h:26-71) --
+ * updated incrementally by the host (svo_hip_map_patch: the entries that changed since the last call), so that one
+ * kernel does the walk: projection, grid binning, the per-cell order, the close-view test and the list of
+ * findMatchDirect trials in visiting order, and the match kernels follow on the stream without the host in between.
+ * All arrays are device memory owned by the caller. */
+typedef struct svo_hip_map {
+  int32_t n_points;      /* entries [0, n_points): the points of the map's keyframes and the depth filter's candidates */
+  int32_t n_obs;         /* observation records [0, n_obs) */
+  double* d_pos;         /* [P][3] Point::pos_ */
+  int32_t* d_type;       /* [P] Point::type_ (point.h:38-43): 0 deleted = the entry is dead, 1 candidate, 2 unknown, 3 good */
+  int32_t* d_order;      /* [P] candidates: position in MapPointCandidates::candidates_ (any key increasing along the list,
+                                < 65536); other points: unused */
+  int32_t* d_obs_begin;  /* [P] Point::obs_ in list order = records [d_obs_begin[p], d_obs_begin[p] + d_obs_count[p]) */
+  int32_t* d_obs_count;  /* [P] */
+  int32_t* d_obs_frame;  /* [O] Feature::frame as an index into the frame table of the call */
+  int32_t* d_obs_order;  /* [O] position of the Feature in its frame's fts_ list (< 4096); -1: not in a keyframe's list
+                                (the Feature of a candidate, map.cpp:215-218) */
+  int32_t* d_obs_level;  /* [O] Feature::level */
+  uint8_t* d_obs_type;   /* [O] SVO_HIP_FTR_* */
+  double* d_obs_px;      /* [O][2] Feature::px */
+  double* d_obs_f;       /* [O][3] Feature::f */
+  double* d_obs_grad;    /* [O][2] Feature::grad */
+} svo_hip_map;
+
+/* Entries the host rewrites before the map is read (applied by svo_hip_reproject_map itself, on its stream): whole
+ * point records, whole observation records.  n = 0 with NULL arrays is "no change". */
+typedef struct svo_hip_map_patch {
+  int32_t n_points;
+  int32_t n_obs;
+  const int32_t* d_index;      /* [n_points] entry written */
+  const double* d_pos;         /* [n_points][3] */
+  const int32_t* d_type;       /* [n_points] */
+  const int32_t* d_order;      /* [n_points] */
+  const int32_t* d_obs_begin;  /* [n_points] */
+  const int32_t* d_obs_count;  /* [n_points] */
+  const int32_t* d_obs_index;  /* [n_obs] record written */
+  const int32_t* d_obs_order;  /* [n_obs] */
+  svo_hip_features obs;        /* [n_obs] frame (index into the frame table), level, type, px, f, grad: none NULL */
+} svo_hip_map_patch;
+
+/* Reprojector::Grid (reprojector.h:79-86): d_cell_rank[k] = position of cell k in grid_.cell_order, the order
+ * reprojectMap visits the cells in (:131-139). */
+typedef struct svo_hip_grid {
+  int32_t cell_size, n_cols, n_rows, n_cells;
+  const int32_t* d_cell_rank; /* [n_cells] */
+} svo_hip_grid;
+
+#define SVO_HIP_REPROJ_MAX_IN_FRAME 4096 /* points inside the frame one call can order (status 1 beyond) */
+#define SVO_HIP_REPROJ_MAX_CELLS 2048
+#define SVO_HIP_REPROJ_HEADER 8
+typedef struct svo_hip_reprojection {
+  int32_t* d_header;        /* [SVO_HIP_REPROJ_HEADER]: 0 status (0 ok; 1 a capacity was exceeded: nothing below is valid),
+                               1 points inside the frame, 2 V = visits, 3 M = trials, 4 end_cell */
+  int32_t* d_point_cell;    /* [P] grid cell of the projection (reprojectPoint, :206-217); -1: outside the frame;
+                               -2: not projected (dead entry, or none of the point's keyframes is among the overlapping ones) */
+  double* d_point_px;       /* [P][2] the projection (defined where d_point_cell >= -1) */
+  int32_t* d_kf_count;      /* [n_frames] overlap_kfs[i].second (:87-102): points first met through that keyframe that
+                               fell inside the frame */
+  /* the candidates of cells [first_cell, end_cell) of the visiting order, in the order reprojectCell walks them
+     (:151-153: per cell good before unknown before candidate points, otherwise in the order they were binned) */
+  int32_t* d_visit_point;   /* [max_visits] entry in the map */
+  int32_t* d_visit_cell;    /* [max_visits] position of its cell in the visiting order */
+  int32_t* d_visit_trial;   /* [max_visits] its findMatchDirect trial, or -1: no close view, findMatchDirect returns false at once
+                               (matcher.cpp:137-138) */
+  /* the trials: the inputs of svo_hip_find_match_direct_indirect / svo_hip_select_matches_indirect */
+  int32_t* d_trial_cur;       /* [max_trials] = cur_frame */
+  double* d_trial_pos;        /* [max_trials][3] */
+  int32_t* d_trial_obs_begin; /* [max_trials] the observation Point::getCloseViewObs chose ... */
+  int32_t* d_trial_obs_end;   /* [max_trials] ... + 1 */
+  int32_t* d_trial_cell;      /* [max_trials] = d_visit_cell of the visit */
+  double* d_trial_px;         /* [max_trials][2] Candidate::px: the projection (in), refined by the match kernels (out) */
+} svo_hip_reprojection;
+
+/* Reprojector::reprojectMap up to the first findMatchDirect (svo/src/reprojector.cpp:64-142, 151-153, 206-217;
+ * Point::getCloseViewObs, svo/src/point.cpp:97-117) for ONE frame, on the mirror:
+ *   - applies `patch` (may be NULL);
+ *   - every live map point (type >= 2) that has an observation in a keyframe with d_kf_rank[frame] >= 0 is projected
+ *     into frame `cur_frame` once, at the place the reference meets it first: the keyframe of smallest rank, the
+ *     smallest position in that keyframe's fts_ (:85-101, last_projected_kf_id_); every candidate (type 1) is
+ *     projected, in list order, after them (:108-123);
+ *   - points inside the frame (8 px border) fall into their grid cell; per cell the order is the reference's stable
+ *     sort by type, descending (:153);
+ *   - cells are taken in visiting order from `first_cell` until `max_cells_with_trials` of them hold at least one
+ *     candidate with a close view (or the cells run out): end_cell.  Their candidates become the visit list, those
+ *     with a close view the trials.
+ * d_kf_rank [frames->n_frames]: rank among the overlapping keyframes, closest = 0, < 16; -1: not one of them.
+ * One workgroup; results are complete when the stream reaches the next command. */
+int svo_hip_reproject_map(const svo_hip_camera* cam, const svo_hip_frames* frames, int cur_frame,
+                          const int32_t* d_kf_rank, const svo_hip_map* map, const svo_hip_map_patch* patch,
+                          const svo_hip_grid* grid, int first_cell, int max_cells_with_trials, int max_visits,
+                          int max_trials, const svo_hip_reprojection* out, void* stream);
+
+/* svo_hip_find_match_direct / svo_hip_select_matches for a batch whose size is known on the device only: the number
+ * of trials is read from d_M[0] by the kernels (clamped to M_cap, the capacity of the arrays; launches are sized for
+ * M_cap <= 65536), and the observations of trial m are the records [d_obs_begin[m], d_obs_end[m]) of `obs`. */
+int svo_hip_find_match_direct_indirect(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
+                                       const svo_hip_camera* cam, const svo_hip_frames* frames, int M_cap,
+                                       const int32_t* d_M, const int32_t* d_cur_frame, const double* d_pt_pos,
+                                       const int32_t* d_obs_begin, const int32_t* d_obs_end,
+                                       const svo_hip_features* obs, int n_pyr_levels, int align_max_iter,
+                                       double* d_px_cur, int32_t* d_ok, int32_t* d_ref_obs, int32_t* d_search_level,
+                                       double* d_A_cur_ref, uint8_t* d_patch_out, void* d_workspace,
+                                       size_t workspace_bytes, void* stream);
+int svo_hip_select_matches_indirect(const svo_hip_camera* cam, int M_cap, const int32_t* d_M, const int32_t* d_cell,
+                                    const int32_t* d_ok, const double* d_px, const int32_t* d_level,
+                                    const double* d_pos, int max_fts, int32_t* d_n, int32_t* d_sel, double* d_f,
+                                    int32_t* d_level_out, double* d_pos_out, uint8_t* d_has_point, int32_t* d_signal,
+                                    int32_t signal_value, void* stream);
 
 /* Frame glue that the reference does inline on the host, kept on the device so a tracked
  * frame never leaves HBM between kernels:

@@ -313,6 +313,42 @@ def select_matches(cam, cell, ok, px, level, pos, max_fts):
     return sel[:n], f[:n], level_out[:n], pos_out[:n]
 
 
+def reproject_map(cam, frames_T, cur_frame, kf_rank, pos, type, order, obs_begin, obs_count, obs_frame, obs_order, cell_size,
+                  n_cols, n_cells, cell_rank, first_cell=0, max_cells_with_trials=1 << 30):
+    """Reprojector::reprojectMap up to the first findMatchDirect on the plain-array form of the map (orc_reproject_map,
+    svo_oracle_track.c): returns a dict of numpy arrays named like svo_hip_reprojection's fields."""
+    lib = pyoracle.lib()
+    pc = make_cam(cam)
+    i32a = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    frames_T = _f64(frames_T).reshape(-1, 12)
+    pos = _f64(pos).reshape(-1, 3)
+    P = pos.shape[0]
+    kf_rank, type, order, obs_begin, obs_count = map(i32a, (kf_rank, type, order, obs_begin, obs_count))
+    obs_frame, obs_order, cell_rank = map(i32a, (obs_frame, obs_order, cell_rank))
+    header = np.zeros(8, dtype=np.int32)
+    cap = max(P, 1)
+    out = {"point_cell": np.zeros(cap, dtype=np.int32), "point_px": np.zeros((cap, 2)), "kf_count": np.zeros(frames_T.shape[0], dtype=np.int32),
+           "visit_point": np.zeros(cap, dtype=np.int32), "visit_cell": np.zeros(cap, dtype=np.int32),
+           "visit_trial": np.zeros(cap, dtype=np.int32), "trial_obs": np.zeros(cap, dtype=np.int32),
+           "trial_cell": np.zeros(cap, dtype=np.int32), "trial_px": np.zeros((cap, 2)), "trial_pos": np.zeros((cap, 3))}
+    lib.orc_reproject_map.restype = C.c_int
+    lib.orc_reproject_map(C.byref(pc), C.c_int(frames_T.shape[0]), _p(frames_T), C.c_int(cur_frame), i32(kf_rank), C.c_int(P), _p(pos),
+                          i32(type), i32(order), i32(obs_begin), i32(obs_count), i32(obs_frame), i32(obs_order), C.c_int(cell_size),
+                          C.c_int(n_cols), C.c_int(n_cells), i32(cell_rank), C.c_int(first_cell),
+                          C.c_int(min(max_cells_with_trials, 1 << 30)), i32(header), i32(out["point_cell"]), _p(out["point_px"]),
+                          i32(out["kf_count"]), i32(out["visit_point"]), i32(out["visit_cell"]), i32(out["visit_trial"]),
+                          i32(out["trial_obs"]), i32(out["trial_cell"]), _p(out["trial_px"]), _p(out["trial_pos"]))
+    V, M = int(header[2]), int(header[3])
+    out["header"] = header
+    for k in ("visit_point", "visit_cell", "visit_trial"):
+        out[k] = out[k][:V]
+    for k in ("trial_obs", "trial_cell", "trial_px", "trial_pos"):
+        out[k] = out[k][:M]
+    out["point_cell"], out["point_px"] = out["point_cell"][:P], out["point_px"][:P]
+    return out
+
+
 def fast_detect_grid(pyr_levels, n_levels, cell_size, cols, rows, occupancy=None, fast_threshold=20,
                      detection_threshold=20.0):
     """C restatement of FastDetector::detect: (xy [cells,2], level [cells], score [cells], n_features)."""

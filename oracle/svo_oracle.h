@@ -268,6 +268,15 @@ int orc_update_seeds(const orc_frame* frames, const orc_pinhole* cam, int cur_fr
 int orc_reproject_point(const orc_pinhole* cam, const double T_f_w[12], const double pos[3],
                         int cell_size, int grid_n_cols, double px_out[2]);
 
+/* reprojectMap up to the first findMatchDirect (:64-142, 151-153) on the plain-array form of the map
+ * (svo_hip_map of include/svo_hip.h): header[5] = {status, points in frame, V, M, end_cell}; see svo_oracle_track.c */
+int orc_reproject_map(const orc_pinhole* cam, int n_frames, const double* frame_T, int cur_frame, const int32_t* kf_rank,
+                      int P, const double* pos, const int32_t* type, const int32_t* order, const int32_t* obs_begin,
+                      const int32_t* obs_count, const int32_t* obs_frame, const int32_t* obs_order, int cell_size,
+                      int n_cols, int n_cells, const int32_t* cell_rank, int first_cell, int max_cells_with_trials,
+                      int32_t* header, int32_t* point_cell, double* point_px, int32_t* kf_count, int32_t* visit_point,
+                      int32_t* visit_cell, int32_t* visit_trial, int32_t* trial_obs, int32_t* trial_cell, double* trial_px,
+                      double* trial_pos);
 /* reprojectMap's cell loop (:131-139) + reprojectCell (:150-200) over trials with known outcome, in visiting
  * order (trials of one cell adjacent): per cell the first success, stop once more than max_fts cells matched.
  * sel / f / level_out / pos_out [min(M, max_fts+1)]: the new features in Frame::fts_ order.  Returns their number. */

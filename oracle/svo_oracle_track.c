@@ -917,6 +917,136 @@ int orc_select_matches(const orc_pinhole* cam, int M, const int32_t* cell, const
   return n;
 }
 
+/* ======================================================================== */
+/* Reprojector::reprojectMap up to the first findMatchDirect (svo/src/reprojector.cpp:64-142), on the  */
+/* plain-array form of the map (the device mirror's records, include/svo_hip.h svo_hip_map): the        */
+/* keyframe loop with its "project a point only once" flag (:85-102), the candidate loop (:108-123),    */
+/* reprojectPoint into grid cells (:206-217), the per-cell stable sort by point quality (:151-153), and  */
+/* -- what the batched drop-in adds -- Point::getCloseViewObs (point.cpp:97-117) for every candidate    */
+/* of the cells the visiting loop can reach: cells in visiting order from first_cell until              */
+/* max_cells_with_trials of them hold a candidate with a close view.                                     */
+/* Written the way the reference does it (lists filled in walking order, a stable sort per cell), NOT   */
+/* the way the kernel does it (keys, counting, ranking).                                                 */
+/* ======================================================================== */
+typedef struct rm_item { int ord, p; } rm_item;
+static int rm_item_cmp(const void* a, const void* b) { return ((const rm_item*)a)->ord - ((const rm_item*)b)->ord; }
+
+int orc_reproject_map(const orc_pinhole* cam, int n_frames, const double* frame_T, int cur_frame, const int32_t* kf_rank,
+                      int P, const double* pos, const int32_t* type, const int32_t* order, const int32_t* obs_begin,
+                      const int32_t* obs_count, const int32_t* obs_frame, const int32_t* obs_order, int cell_size,
+                      int n_cols, int n_cells, const int32_t* cell_rank, int first_cell, int max_cells_with_trials,
+                      int32_t* header, int32_t* point_cell, double* point_px, int32_t* kf_count, int32_t* visit_point,
+                      int32_t* visit_cell, int32_t* visit_trial, int32_t* trial_obs, int32_t* trial_cell, double* trial_px,
+                      double* trial_pos) {
+  /* cells: Reprojector::Grid::cells, each a list of Candidate(pt, px) in push_back order */
+  int* cell_n = (int*)calloc((size_t)n_cells, sizeof(int));
+  int** cell_items = (int**)calloc((size_t)n_cells, sizeof(int*));
+  for (int k = 0; k < n_cells; ++k) cell_items[k] = (int*)malloc(sizeof(int) * (size_t)(P > 0 ? P : 1));
+  char* last_projected = (char*)calloc((size_t)(P > 0 ? P : 1), 1);  /* Point::last_projected_kf_id_ == frame->id_ */
+  rm_item* fts = (rm_item*)malloc(sizeof(rm_item) * (size_t)(P > 0 ? P : 1));
+  orc_se3* fq = (orc_se3*)malloc(sizeof(orc_se3) * (size_t)n_frames);
+  for (int i = 0; i < n_frames; ++i) orc_se3_from_Rt(frame_T + 12 * i, &fq[i]);
+  for (int p = 0; p < P; ++p) point_cell[p] = -2;
+  for (int i = 0; i < n_frames; ++i) kf_count[i] = 0;
+  int n_in_frame = 0;
+  /* :82-102 the closest keyframes first; every feature of the keyframe that has a map point */
+  for (int rank = 0; rank < n_frames; ++rank) {
+    int f = -1;
+    for (int i = 0; i < n_frames; ++i)
+      if (kf_rank[i] == rank) f = i;
+    if (f < 0) continue;
+    int n = 0;  /* ref_frame->fts_ in list order */
+    for (int p = 0; p < P; ++p) {
+      if (type[p] < 2) continue;  /* a Feature::point of a keyframe is a live UNKNOWN / GOOD point */
+      for (int o = obs_begin[p]; o < obs_begin[p] + obs_count[p]; ++o)
+        if (obs_frame[o] == f && obs_order[o] >= 0) { fts[n].ord = obs_order[o]; fts[n].p = p; ++n; }
+    }
+    qsort(fts, (size_t)n, sizeof(rm_item), rm_item_cmp);
+    for (int i = 0; i < n; ++i) {
+      const int p = fts[i].p;
+      if (last_projected[p]) continue;      /* :97-99 */
+      last_projected[p] = 1;
+      const int k = orc_reproject_point(cam, frame_T + 12 * cur_frame, pos + 3 * p, cell_size, n_cols, point_px + 2 * p);
+      point_cell[p] = k;
+      if (k >= 0) {
+        cell_items[k][cell_n[k]++] = p;
+        ++kf_count[f];                      /* overlap_kfs.back().second++ */
+        ++n_in_frame;
+      }
+    }
+  }
+  /* :108-123 all point candidates, in list order */
+  {
+    int n = 0;
+    for (int p = 0; p < P; ++p)
+      if (type[p] == 1) { fts[n].ord = order[p]; fts[n].p = p; ++n; }
+    qsort(fts, (size_t)n, sizeof(rm_item), rm_item_cmp);
+    for (int i = 0; i < n; ++i) {
+      const int p = fts[i].p;
+      const int k = orc_reproject_point(cam, frame_T + 12 * cur_frame, pos + 3 * p, cell_size, n_cols, point_px + 2 * p);
+      point_cell[p] = k;
+      if (k >= 0) { cell_items[k][cell_n[k]++] = p; ++n_in_frame; }
+    }
+  }
+  /* the visiting order: grid_.cell_order[i] = the cell whose rank is i */
+  int* cell_of_rank = (int*)malloc(sizeof(int) * (size_t)n_cells);
+  for (int k = 0; k < n_cells; ++k) cell_of_rank[cell_rank[k]] = k;
+  double cur_pos[3];
+  frame_pos(&fq[cur_frame], cur_pos);
+  int V = 0, M = 0, cells_with_trials = 0, i = first_cell;
+  for (; i < n_cells && cells_with_trials < max_cells_with_trials; ++i) {
+    const int k = cell_of_rank[i];
+    int* it = cell_items[k];
+    const int n = cell_n[k];
+    /* :153 cell.sort(pointQualityComparator): stable, "lhs.type_ > rhs.type_" first */
+    for (int a = 1; a < n; ++a) {
+      const int v = it[a];
+      int b = a - 1;
+      while (b >= 0 && type[v] > type[it[b]]) { it[b + 1] = it[b]; --b; }
+      it[b + 1] = v;
+    }
+    const int before = M;
+    for (int a = 0; a < n; ++a) {
+      const int p = it[a];
+      visit_point[V] = p;
+      visit_cell[V] = i;
+      /* Point::getCloseViewObs (point.cpp:97-117) */
+      int best = -1, close = 0;
+      if (obs_count[p] > 0) {
+        double obs_dir[3] = {cur_pos[0] - pos[3 * p], cur_pos[1] - pos[3 * p + 1], cur_pos[2] - pos[3 * p + 2]};
+        normalize3(obs_dir);
+        double min_cos_angle = 0;
+        best = obs_begin[p];
+        for (int o = obs_begin[p]; o < obs_begin[p] + obs_count[p]; ++o) {
+          double fp[3];
+          frame_pos(&fq[obs_frame[o]], fp);
+          double dir[3] = {fp[0] - pos[3 * p], fp[1] - pos[3 * p + 1], fp[2] - pos[3 * p + 2]};
+          normalize3(dir);
+          const double cos_angle = dot3(obs_dir, dir);
+          if (cos_angle > min_cos_angle) { min_cos_angle = cos_angle; best = o; }
+        }
+        close = !(min_cos_angle < 0.5);
+      }
+      if (close) {
+        visit_trial[V] = M;
+        trial_obs[M] = best;
+        trial_cell[M] = i;
+        trial_px[2 * M] = point_px[2 * p]; trial_px[2 * M + 1] = point_px[2 * p + 1];
+        for (int c = 0; c < 3; ++c) trial_pos[3 * M + c] = pos[3 * p + c];
+        ++M;
+      } else {
+        visit_trial[V] = -1;
+      }
+      ++V;
+    }
+    if (M > before) ++cells_with_trials;
+  }
+  header[0] = 0; header[1] = n_in_frame; header[2] = V; header[3] = M; header[4] = i;
+  for (int k = 0; k < n_cells; ++k) free(cell_items[k]);
+  free(cell_items); free(cell_n); free(last_projected); free(fts); free(fq); free(cell_of_rank);
+  return 0;
+}
+
 /* vk::AbstractCamera::cam2world(px): the unit bearing (vikit pinhole_camera.cpp / atan_camera.cpp) */
 void orc_cam2world(const orc_pinhole* cam, int n, const double* px, double* f) {
   for (int i = 0; i < n; ++i) cam2world(cam, px[2 * i], px[2 * i + 1], f + 3 * i);

@@ -74,6 +74,34 @@ class DepthFilterOptions(C.Structure):
                 ("n_pyr_levels", C.c_int32), ("epi_search_edgelet_max_angle", C.c_double)]
 
 
+class Map(C.Structure):
+    """svo_hip_map: the device-resident mirror of the map's points and observations (row N2)."""
+    _fields_ = [("n_points", C.c_int32), ("n_obs", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("d_pos", "d_type", "d_order", "d_obs_begin", "d_obs_count", "d_obs_frame",
+                                          "d_obs_order", "d_obs_level", "d_obs_type", "d_obs_px", "d_obs_f", "d_obs_grad")]
+
+
+class MapPatch(C.Structure):
+    """svo_hip_map_patch: entries rewritten before the map is read."""
+    _fields_ = [("n_points", C.c_int32), ("n_obs", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("d_index", "d_pos", "d_type", "d_order", "d_obs_begin", "d_obs_count",
+                                          "d_obs_index", "d_obs_order")] + [("obs", Features)]
+
+
+class Grid(C.Structure):
+    """svo_hip_grid: Reprojector::Grid with the visiting rank of every cell."""
+    _fields_ = [("cell_size", C.c_int32), ("n_cols", C.c_int32), ("n_rows", C.c_int32), ("n_cells", C.c_int32),
+                ("d_cell_rank", C.c_void_p)]
+
+
+class Reprojection(C.Structure):
+    """svo_hip_reprojection: outputs of svo_hip_reproject_map."""
+    _fields_ = [(n, C.c_void_p) for n in ("d_header", "d_point_cell", "d_point_px", "d_kf_count", "d_visit_point",
+                                          "d_visit_cell", "d_visit_trial", "d_trial_cur", "d_trial_pos",
+                                          "d_trial_obs_begin", "d_trial_obs_end", "d_trial_cell", "d_trial_px")]
+
+
+REPROJ_MAX_IN_FRAME, REPROJ_MAX_CELLS, REPROJ_HEADER = 4096, 2048, 8
 FTR_CORNER, FTR_EDGELET = 0, 1
 SEED_ERASED_OLD, SEED_BEHIND, SEED_NOT_IN_FRAME, SEED_NO_MATCH, SEED_UPDATED, SEED_CONVERGED, SEED_NAN = range(1, 8)
 
@@ -105,7 +133,6 @@ PROTOTYPES = {
     "svo_hip_event_sync": (_i, [_vp]),
     "svo_hip_event_query": (_i, [_vp]),
     "svo_hip_stream_wait_event": (_i, [_vp, _vp]),
-    "svo_hip_stream_write_value32": (_i, [_vp, _vp, _i]),
     "svo_hip_graph_begin_capture": (_i, [_vp]),
     "svo_hip_graph_end_capture": (_i, [_vp, C.POINTER(_vp)]),
     "svo_hip_graph_launch": (_i, [_vp, _vp]),
@@ -137,6 +164,12 @@ PROTOTYPES = {
     "svo_hip_match_workspace_bytes": (C.c_size_t, [_i]),
     "svo_hip_find_match_direct": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, _vp, _vp,
                                        C.POINTER(Features), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "svo_hip_reproject_map": (_i, [C.POINTER(Camera), C.POINTER(Frames), _i, _vp, C.POINTER(Map), C.POINTER(MapPatch),
+                                   C.POINTER(Grid), _i, _i, _i, _i, C.POINTER(Reprojection), _vp]),
+    "svo_hip_find_match_direct_indirect": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, _vp, _vp, _vp, _vp,
+                                                C.POINTER(Features), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "svo_hip_select_matches_indirect": (_i, [C.POINTER(Camera), _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp,
+                                             _vp, _vp, _i, _vp]),
     "svo_hip_reproject_points": (_i, [C.POINTER(Camera), C.POINTER(Frames), _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "svo_hip_compose_poses": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "svo_hip_cam2world": (_i, [C.POINTER(Camera), _i, _vp, _vp, _vp]),

@@ -157,16 +157,6 @@ int svo_hip_stream_wait_event(void* stream, void* event) {
   return SVO_HIP_OK;
 }
 
-int svo_hip_stream_write_value32(void* stream, int32_t* ptr, int32_t value) {
-  if (!ptr) return SVO_HIP_EINVAL;
-  // looked up at first use, not at load time: an experimental path must not be able to keep the library from loading
-  typedef hipError_t (*write32_fn)(hipStream_t, void*, uint32_t, unsigned int);
-  static const write32_fn fn = reinterpret_cast<write32_fn>(dlsym(RTLD_DEFAULT, "hipStreamWriteValue32"));
-  if (!fn) return SVO_HIP_EINVAL;
-  SVO_HIP_TRY(fn(static_cast<hipStream_t>(stream), ptr, (uint32_t)value, 0));
-  return SVO_HIP_OK;
-}
-
 int svo_hip_event_elapsed_ms(void* start, void* stop, float* ms_out) {
   if (!ms_out) return SVO_HIP_EINVAL;
   SVO_HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(stop)));

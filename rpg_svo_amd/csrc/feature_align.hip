@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const Al
     t = a.queue_in[(size_t)q * a.queue_cap + i];
   } else {
     t = blockIdx.x * ALIGN_BLOCK + threadIdx.x;
-    if (t >= a.M) return;
+    if (t >= (a.M_dev ? min(*a.M_dev, a.M) : a.M)) return;
   }
   const bool first = a.it0 == 0;
   if (first && a.active && !a.active[t]) {

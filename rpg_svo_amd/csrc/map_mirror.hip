@@ -1,0 +1,417 @@
+// map_mirror.hip -- row N2: Reprojector::reprojectMap up to the first findMatchDirect, on a device-resident mirror
+// of the map (svo/src/reprojector.cpp:64-142, 151-153, 206-217; Point::getCloseViewObs, svo/src/point.cpp:97-117).
+//
+// The reference walks Map -> keyframes -> Frame::fts_ -> Point (and MapPointCandidates::candidates_) on the host for
+// every frame: a reprojectPoint per point (w2c, isInFrame, a std::list node pushed into the point's grid cell), a
+// stable list sort per cell, getCloseViewObs per candidate it gets to try.  Here the records that walk reads live in
+// HBM (svo_hip_map, patched incrementally by the host) and ONE workgroup does the walk for a frame:
+//
+//   patch -> project every live point once (at the place the reference's keyframe loop meets it first) -> count per
+//   cell (LDS atomics) -> scan over the cells in VISITING order -> scatter into cell buckets -> rank inside the bucket
+//   by (type descending, binning order) -> close-view test per candidate -> cells until `max_cells_with_trials` hold a
+//   trial -> visit list + trial list in the order reprojectCell would walk them.
+//
+// A single frame is ~2000 points: the kernel is latency-bound (a dozen barriers), not throughput-bound; what it buys
+// is that the match kernels follow on the stream with no host pass in between ("Row N2").
+// The projection and the close-view arithmetic are the ones of reproject_kernel / match_prepare_kernel (matcher.hip).
+#pragma clang fp contract(off)
+#include "track_kernels.h"
+#include "track_math.h"
+
+using namespace svo_capi;
+using namespace svo_dev;
+using namespace svo_track;
+
+namespace {
+
+constexpr int RM_BLOCK = 1024;
+constexpr int RM_MAX_E = SVO_HIP_REPROJ_MAX_IN_FRAME;  // points inside the frame
+constexpr int RM_MAX_CELLS = SVO_HIP_REPROJ_MAX_CELLS;
+constexpr int RM_MAX_FRAMES = 64;
+constexpr int RM_EPT = RM_MAX_E / RM_BLOCK;  // sorted elements per thread in the ordered phases
+
+struct ReprojMapArgs {
+  Cam cam;
+  int n_frames, cur_frame;
+  const double* frame_T;
+  const int32_t* kf_rank;
+  svo_hip_map map;
+  svo_hip_map_patch patch;
+  svo_hip_grid grid;
+  int first_cell, max_cells_with_trials, max_visits, max_trials;
+  svo_hip_reprojection out;
+};
+
+// exclusive scan of one int per thread over the workgroup; *total = sum.  Two barriers.
+__device__ __forceinline__ int block_exclusive_scan(int v, int* s_wave /*[RM_BLOCK/64 + 1]*/, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int w = 0; w < RM_BLOCK / 64; ++w) {
+      const int t = s_wave[w];
+      s_wave[w] = run;
+      run += t;
+    }
+    s_wave[RM_BLOCK / 64] = run;
+  }
+  __syncthreads();
+  *total = s_wave[RM_BLOCK / 64];
+  const int r = s_wave[wave] + inc - v;
+  __syncthreads();  // s_wave is reused by the next scan
+  return r;
+}
+
+__global__ void __launch_bounds__(RM_BLOCK) reproject_map_kernel(const ReprojMapArgs a) {
+  __shared__ int s_cnt[RM_MAX_CELLS];    // per visiting rank: points binned; later: 1 where the cell holds a trial
+  __shared__ int s_base[RM_MAX_CELLS + 1];  // exclusive scan of s_cnt
+  __shared__ uint32_t s_bkey[RM_MAX_E];  // bucketed: (3 - type) << 28 | binning order
+  __shared__ uint16_t s_bidx[RM_MAX_E];  //           map entry
+  __shared__ uint16_t s_sidx[RM_MAX_E];  // sorted:   map entry
+  __shared__ uint16_t s_srank[RM_MAX_E]; //           visiting rank of its cell
+  __shared__ double s_fpos[RM_MAX_FRAMES][3];  // Frame::pos() of the frame table
+  __shared__ int s_kfcount[RM_MAX_FRAMES];
+  __shared__ int s_wave[RM_BLOCK / 64 + 1];
+  __shared__ int s_E, s_end_cell, s_overflow;
+  const int tid = threadIdx.x;
+  const svo_hip_map& mp = a.map;
+  const int P = mp.n_points, n_cells = a.grid.n_cells;
+
+  // ---- 0. the host's changes since the last call -------------------------------------------------------------------
+  for (int i = tid; i < a.patch.n_obs; i += RM_BLOCK) {
+    const int o = a.patch.d_obs_index[i];
+    mp.d_obs_frame[o] = a.patch.obs.d_frame[i];
+    mp.d_obs_order[o] = a.patch.d_obs_order[i];
+    mp.d_obs_level[o] = a.patch.obs.d_level[i];
+    mp.d_obs_type[o] = a.patch.obs.d_type[i];
+    mp.d_obs_px[2 * o] = a.patch.obs.d_px[2 * i];
+    mp.d_obs_px[2 * o + 1] = a.patch.obs.d_px[2 * i + 1];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mp.d_obs_f[3 * o + k] = a.patch.obs.d_f[3 * i + k];
+    mp.d_obs_grad[2 * o] = a.patch.obs.d_grad[2 * i];
+    mp.d_obs_grad[2 * o + 1] = a.patch.obs.d_grad[2 * i + 1];
+  }
+  for (int i = tid; i < a.patch.n_points; i += RM_BLOCK) {
+    const int p = a.patch.d_index[i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mp.d_pos[3 * p + k] = a.patch.d_pos[3 * i + k];
+    mp.d_type[p] = a.patch.d_type[i];
+    mp.d_order[p] = a.patch.d_order[i];
+    mp.d_obs_begin[p] = a.patch.d_obs_begin[i];
+    mp.d_obs_count[p] = a.patch.d_obs_count[i];
+  }
+  for (int k = tid; k < n_cells; k += RM_BLOCK) s_cnt[k] = 0;
+  if (tid < a.n_frames) {
+    Se3 T;
+    se3_from_Rt(a.frame_T + 12 * tid, T);
+    double fp[3];
+    frame_pos(T, fp);
+    s_fpos[tid][0] = fp[0]; s_fpos[tid][1] = fp[1]; s_fpos[tid][2] = fp[2];
+    s_kfcount[tid] = 0;
+  }
+  if (tid == 0) { s_E = 0; s_end_cell = n_cells; s_overflow = 0; }
+  __syncthreads();  // (also orders the patch stores before the reads below: one workgroup, workgroup-scope fence)
+
+  // ---- 1. reprojectPoint for every live point, once (:85-123, :206-217) -------------------------------------------
+  Se3 Tc;
+  se3_from_Rt(a.frame_T + 12 * a.cur_frame, Tc);
+  for (int p0 = 0; p0 < P; p0 += RM_BLOCK) {
+    const int p = p0 + tid;
+    int cell = -2;
+    if (p < P) {
+      const int type = mp.d_type[p];
+      bool projected = false;
+      int first_frame = -1;
+      if (type == 1) {  // a candidate: after every keyframe point, in list order
+        projected = true;
+      } else if (type >= 2) {
+        // where the keyframe loop meets the point first: smallest (keyframe rank, position in that keyframe's fts_)
+        const int o0 = mp.d_obs_begin[p], n = mp.d_obs_count[p];
+        uint32_t best = 0xffffffffu;
+        for (int o = o0; o < o0 + n; ++o) {
+          const int fr = mp.d_obs_frame[o], ord = mp.d_obs_order[o];
+          const int r = a.kf_rank[fr];
+          if (r >= 0 && ord >= 0) {
+            const uint32_t k = (uint32_t)r << 12 | (uint32_t)(ord & 0xfff);
+            if (k < best) { best = k; first_frame = fr; }
+          }
+        }
+        projected = best != 0xffffffffu;
+      }
+      if (projected) {
+        const double pos[3] = {mp.d_pos[3 * p], mp.d_pos[3 * p + 1], mp.d_pos[3 * p + 2]};
+        double q[3], px[2];
+        se3_apply(Tc, pos, q);
+        world2cam(a.cam, q, px);
+        a.out.d_point_px[2 * p] = px[0];
+        a.out.d_point_px[2 * p + 1] = px[1];
+        cell = -1;
+        if (is_in_frame(a.cam, cast_int(px[0]), cast_int(px[1]), 8)) {
+          const int k = cast_int(px[1] / a.grid.cell_size) * a.grid.n_cols + cast_int(px[0] / a.grid.cell_size);
+          if (k >= 0 && k < n_cells) {  // (always, for a grid that covers the image)
+            cell = k;
+            atomicAdd(&s_cnt[a.grid.d_cell_rank[k]], 1);
+            atomicAdd(&s_E, 1);
+            if (first_frame >= 0) atomicAdd(&s_kfcount[first_frame], 1);
+          }
+        }
+      }
+      a.out.d_point_cell[p] = cell;
+    }
+  }
+  __syncthreads();
+  const int E = s_E;
+  if (E > RM_MAX_E) {  // more points inside the frame than one call orders: the host takes its list-walking path
+    if (tid == 0) {
+      a.out.d_header[0] = 1;
+      a.out.d_header[1] = E;
+      a.out.d_header[2] = a.out.d_header[3] = a.out.d_header[5] = 0;
+      a.out.d_header[4] = a.first_cell;
+    }
+    return;
+  }
+
+  // ---- 2. exclusive scan of the per-cell counts over the VISITING order --------------------------------------------
+  {
+    constexpr int CPT = RM_MAX_CELLS / RM_BLOCK;
+    int c[CPT], sum = 0;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      const int r = tid * CPT + k;
+      c[k] = r < n_cells ? s_cnt[r] : 0;
+      sum += c[k];
+    }
+    int total;
+    int run = block_exclusive_scan(sum, s_wave, &total);
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      const int r = tid * CPT + k;
+      if (r < n_cells) s_base[r] = run;
+      run += c[k];
+    }
+    if (tid == 0) s_base[n_cells] = total;
+  }
+  __syncthreads();
+
+  // ---- 3. scatter into the cell buckets (any order inside a bucket) -------------------------------------------------
+  // (the key of a binned point is derived here, from the same records: the loop above keeps nothing per point)
+  for (int k = tid; k < n_cells; k += RM_BLOCK) s_cnt[k] = 0;
+  __syncthreads();
+  for (int p0 = 0; p0 < P; p0 += RM_BLOCK) {
+    const int p = p0 + tid;
+    if (p < P) {
+      const int cell = a.out.d_point_cell[p];
+      if (cell >= 0) {
+        const int type = mp.d_type[p];
+        uint32_t key;
+        if (type == 1) {
+          key = (3u - 1u) << 28 | (uint32_t)(mp.d_order[p] & 0xffff);
+        } else {
+          const int o0 = mp.d_obs_begin[p], n = mp.d_obs_count[p];
+          uint32_t best = 0xffffffffu;
+          for (int o = o0; o < o0 + n; ++o) {
+            const int r = a.kf_rank[mp.d_obs_frame[o]], ord = mp.d_obs_order[o];
+            if (r >= 0 && ord >= 0) {
+              const uint32_t k = (uint32_t)r << 12 | (uint32_t)(ord & 0xfff);
+              best = k < best ? k : best;
+            }
+          }
+          key = (uint32_t)(3 - type) << 28 | best;
+        }
+        const int rank = a.grid.d_cell_rank[cell];
+        const int at = s_base[rank] + atomicAdd(&s_cnt[rank], 1);
+        s_bkey[at] = key;
+        s_bidx[at] = (uint16_t)p;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 4. order inside a bucket: type descending, then binning order (the stable sort of :153) ----------------------
+  // keys of one cell are distinct, so the position is the number of smaller keys
+  {
+    constexpr int CPT = RM_MAX_CELLS / RM_BLOCK;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      const int r = tid * CPT + k;
+      if (r < n_cells) {
+        const int b0 = s_base[r], b1 = s_base[r + 1];
+        for (int i = b0; i < b1; ++i) {
+          const uint32_t key = s_bkey[i];
+          int smaller = 0;
+          for (int j = b0; j < b1; ++j) smaller += s_bkey[j] < key ? 1 : 0;
+          s_sidx[b0 + smaller] = s_bidx[i];
+          s_srank[b0 + smaller] = (uint16_t)r;
+        }
+      }
+    }
+  }
+  for (int k = tid; k < n_cells; k += RM_BLOCK) s_cnt[k] = 0;  // from here: 1 where the cell holds a trial
+  __syncthreads();
+
+  // ---- 5. Point::getCloseViewObs per binned point (point.cpp:97-117; matcher.cpp:137-138) ---------------------------
+  int best_obs[RM_EPT];
+  bool has_view[RM_EPT];
+#pragma unroll
+  for (int e = 0; e < RM_EPT; ++e) {
+    const int i = tid + RM_BLOCK * e;
+    best_obs[e] = -1;
+    has_view[e] = false;
+    if (i < E) {
+      const int p = s_sidx[i];
+      const int o0 = mp.d_obs_begin[p], n = mp.d_obs_count[p];
+      if (n > 0) {
+        const double pt[3] = {mp.d_pos[3 * p], mp.d_pos[3 * p + 1], mp.d_pos[3 * p + 2]};
+        double obs_dir[3] = {s_fpos[a.cur_frame][0] - pt[0], s_fpos[a.cur_frame][1] - pt[1], s_fpos[a.cur_frame][2] - pt[2]};
+        normalize3(obs_dir);
+        int best = o0;
+        double min_cos_angle = 0;
+        for (int o = o0; o < o0 + n; ++o) {
+          const int fr = mp.d_obs_frame[o];
+          double dir[3] = {s_fpos[fr][0] - pt[0], s_fpos[fr][1] - pt[1], s_fpos[fr][2] - pt[2]};
+          normalize3(dir);
+          const double cos_angle = dot3(obs_dir, dir);
+          if (cos_angle > min_cos_angle) {
+            min_cos_angle = cos_angle;
+            best = o;
+          }
+        }
+        best_obs[e] = best;
+        has_view[e] = !(min_cos_angle < 0.5);
+        if (has_view[e]) s_cnt[s_srank[i]] = 1;  // (benign race: every writer stores 1)
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 6. cells from first_cell until max_cells_with_trials of them hold a trial -----------------------------------
+  {
+    constexpr int CPT = RM_MAX_CELLS / RM_BLOCK;
+    int c[CPT], sum = 0;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      const int r = tid * CPT + k;
+      c[k] = (r < n_cells && r >= a.first_cell) ? s_cnt[r] : 0;
+      sum += c[k];
+    }
+    int total;
+    int run = block_exclusive_scan(sum, s_wave, &total);
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      const int r = tid * CPT + k;
+      run += c[k];
+      // the loop of the host stops right after the cell that brought the count to the maximum
+      if (c[k] && run == a.max_cells_with_trials) atomicMin(&s_end_cell, r + 1);
+    }
+    if (tid == 0 && a.max_cells_with_trials <= 0) s_end_cell = a.first_cell;
+  }
+  __syncthreads();
+  const int end_cell = s_end_cell < a.first_cell ? a.first_cell : s_end_cell;
+  const int v0 = a.first_cell < n_cells ? s_base[a.first_cell] : E;  // sorted positions [v0, v1) are the visits
+  const int v1 = s_base[end_cell];
+  const int V = v1 - v0;
+
+  // ---- 7. trial numbers: exclusive count of the visits with a close view -------------------------------------------
+  // thread t owns the sorted positions t, t + RM_BLOCK, ...: scan pass by pass, carrying the running total
+  int trial[RM_EPT];
+  int M = 0;
+#pragma unroll
+  for (int e = 0; e < RM_EPT; ++e) {
+    const int i = tid + RM_BLOCK * e;
+    const int flag = (i >= v0 && i < v1 && has_view[e]) ? 1 : 0;
+    int total;
+    const int ex = block_exclusive_scan(flag, s_wave, &total);
+    trial[e] = flag ? M + ex : -1;
+    M += total;
+  }
+  const bool overflow = V > a.max_visits || M > a.max_trials;
+  if (tid == 0) {
+    a.out.d_header[0] = overflow ? 1 : 0;
+    a.out.d_header[1] = E;
+    a.out.d_header[2] = overflow ? 0 : V;
+    a.out.d_header[3] = overflow ? 0 : M;
+    a.out.d_header[4] = overflow ? a.first_cell : end_cell;
+    a.out.d_header[5] = 0;
+    a.out.d_header[6] = a.out.d_header[7] = 0;
+  }
+  if (tid < a.n_frames) a.out.d_kf_count[tid] = s_kfcount[tid];
+  if (overflow) return;
+#pragma unroll
+  for (int e = 0; e < RM_EPT; ++e) {
+    const int i = tid + RM_BLOCK * e;
+    if (i >= v0 && i < v1) {
+      const int v = i - v0, p = s_sidx[i], r = s_srank[i], m = trial[e];
+      a.out.d_visit_point[v] = p;
+      a.out.d_visit_cell[v] = r;
+      a.out.d_visit_trial[v] = m;
+      if (m >= 0) {
+        a.out.d_trial_cur[m] = a.cur_frame;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.out.d_trial_pos[3 * m + k] = mp.d_pos[3 * p + k];
+        a.out.d_trial_obs_begin[m] = best_obs[e];
+        a.out.d_trial_obs_end[m] = best_obs[e] + 1;
+        a.out.d_trial_cell[m] = r;
+        a.out.d_trial_px[2 * m] = a.out.d_point_px[2 * p];
+        a.out.d_trial_px[2 * m + 1] = a.out.d_point_px[2 * p + 1];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int svo_hip_reproject_map(const svo_hip_camera* cam, const svo_hip_frames* frames, int cur_frame,
+                                     const int32_t* d_kf_rank, const svo_hip_map* map, const svo_hip_map_patch* patch,
+                                     const svo_hip_grid* grid, int first_cell, int max_cells_with_trials, int max_visits,
+                                     int max_trials, const svo_hip_reprojection* out, void* stream) {
+  if (!cam || !cam_model_ok(cam) || !frames || !map || !grid || !out || !d_kf_rank) return SVO_HIP_EINVAL;
+  if (frames->n_frames < 1 || frames->n_frames > RM_MAX_FRAMES || cur_frame < 0 || cur_frame >= frames->n_frames || !frames->d_T_f_w)
+    return SVO_HIP_EINVAL;
+  if (map->n_points < 0 || map->n_points > 65535 || map->n_obs < 0) return SVO_HIP_ERANGE;  // (entries are carried as 16 bits)
+  if (grid->cell_size < 1 || grid->n_cols < 1 || grid->n_cells < 1 || grid->n_cells > RM_MAX_CELLS || !grid->d_cell_rank)
+    return grid->n_cells > RM_MAX_CELLS ? SVO_HIP_ERANGE : SVO_HIP_EINVAL;
+  if (first_cell < 0 || first_cell > grid->n_cells || max_visits < 0 || max_trials < 0) return SVO_HIP_EINVAL;
+  if (map->n_points > 0 && (!map->d_pos || !map->d_type || !map->d_order || !map->d_obs_begin || !map->d_obs_count)) return SVO_HIP_EINVAL;
+  if (map->n_obs > 0 && (!map->d_obs_frame || !map->d_obs_order || !map->d_obs_level || !map->d_obs_type || !map->d_obs_px ||
+                         !map->d_obs_f || !map->d_obs_grad))
+    return SVO_HIP_EINVAL;
+  if (!out->d_header || !out->d_kf_count || (map->n_points > 0 && (!out->d_point_cell || !out->d_point_px))) return SVO_HIP_EINVAL;
+  if (max_visits > 0 && (!out->d_visit_point || !out->d_visit_cell || !out->d_visit_trial)) return SVO_HIP_EINVAL;
+  if (max_trials > 0 && (!out->d_trial_cur || !out->d_trial_pos || !out->d_trial_obs_begin || !out->d_trial_obs_end ||
+                         !out->d_trial_cell || !out->d_trial_px))
+    return SVO_HIP_EINVAL;
+  ReprojMapArgs a;
+  a.cam = make_cam(cam);
+  a.n_frames = frames->n_frames;
+  a.cur_frame = cur_frame;
+  a.frame_T = frames->d_T_f_w;
+  a.kf_rank = d_kf_rank;
+  a.map = *map;
+  if (patch) {
+    a.patch = *patch;
+    if (patch->n_points < 0 || patch->n_obs < 0) return SVO_HIP_EINVAL;
+    if (patch->n_points > 0 && (!patch->d_index || !patch->d_pos || !patch->d_type || !patch->d_order || !patch->d_obs_begin ||
+                                !patch->d_obs_count))
+      return SVO_HIP_EINVAL;
+    if (patch->n_obs > 0 && (!patch->d_obs_index || !patch->d_obs_order || !patch->obs.d_frame || !patch->obs.d_level ||
+                             !patch->obs.d_type || !patch->obs.d_px || !patch->obs.d_f || !patch->obs.d_grad))
+      return SVO_HIP_EINVAL;
+  } else {
+    a.patch = svo_hip_map_patch{};
+  }
+  a.grid = *grid;
+  a.first_cell = first_cell;
+  a.max_cells_with_trials = max_cells_with_trials;
+  a.max_visits = max_visits;
+  a.max_trials = max_trials;
+  a.out = *out;
+  hipLaunchKernelGGL(reproject_map_kernel, dim3(1), dim3(RM_BLOCK), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch();
+}

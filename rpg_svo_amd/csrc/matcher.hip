@@ -34,7 +34,10 @@ struct PrepArgs {
   const double* frame_T;
   const int32_t* cur_frame;
   const double* pt_pos;
-  const int32_t* obs_ptr;
+  const int32_t* obs_ptr;    // [M+1] CSR, or NULL and then:
+  const int32_t* obs_begin;  // [M]
+  const int32_t* obs_end;    // [M]
+  const int32_t* M_dev;      // NULL, or the batch size lives on the device (min(*M_dev, M))
   svo_hip_features obs;
   const double* px_cur;  // [M][2] level-0 estimate
   // outputs for the caller
@@ -55,7 +58,7 @@ struct PrepArgs {
 
 __global__ void __launch_bounds__(64) match_prepare_kernel(const PrepArgs a) {
   const int m = blockIdx.x * 64 + threadIdx.x;
-  if (m >= a.M) return;
+  if (m >= (a.M_dev ? min(*a.M_dev, a.M) : a.M)) return;
   a.active[m] = 0;
   a.ref_obs[m] = -1;
   a.search_level[m] = 0;
@@ -71,7 +74,7 @@ __global__ void __launch_bounds__(64) match_prepare_kernel(const PrepArgs a) {
   if (a.A_cur_ref) {
     a.A_cur_ref[4 * m] = a.A_cur_ref[4 * m + 1] = a.A_cur_ref[4 * m + 2] = a.A_cur_ref[4 * m + 3] = 0.0;
   }
-  const int o0 = a.obs_ptr[m], o1 = a.obs_ptr[m + 1];
+  const int o0 = a.obs_ptr ? a.obs_ptr[m] : a.obs_begin[m], o1 = a.obs_ptr ? a.obs_ptr[m + 1] : a.obs_end[m];
   if (o1 <= o0) return;
   Se3 Tc;
   se3_from_Rt(a.frame_T + 12 * cf, Tc);
@@ -173,11 +176,12 @@ __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int t = lane / 10, x = lane - 10 * t;
   uint8_t* const my_patch = reinterpret_cast<uint8_t*>(s_patch[wave]);
-  const long long n_wave_groups = ((long long)a.M + WARP_TPW - 1) / WARP_TPW;
+  const int M = a.M_dev ? min(*a.M_dev, a.M) : a.M;
+  const long long n_wave_groups = ((long long)M + WARP_TPW - 1) / WARP_TPW;
   for (long long gw = (long long)blockIdx.x * 4 + wave; gw < n_wave_groups; gw += (long long)gridDim.x * 4) {
     const long long m0 = gw * WARP_TPW;
     const long long m = m0 + t;
-    const bool lane_on = lane < 10 * WARP_TPW && m < a.M;
+    const bool lane_on = lane < 10 * WARP_TPW && m < M;
     uint8_t out[10];
 #pragma unroll
     for (int y = 0; y < 10; ++y) out[y] = 0;
@@ -345,7 +349,7 @@ __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
     // same-wave LDS hand-over: DS operations of one wave execute in order
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const long long left = (long long)a.M - m0;
+    const long long left = (long long)M - m0;
     const int n_dw = 25 * (int)(left < WARP_TPW ? left : WARP_TPW);
     uint32_t* dst = reinterpret_cast<uint32_t*>(a.pwb + (size_t)m0 * 100);
 #pragma unroll
@@ -441,6 +445,7 @@ struct SelectArgs {
   uint8_t* has_point;
   int32_t* signal;  // or NULL
   int32_t signal_value;
+  const int32_t* M_dev;  // NULL, or the batch size lives on the device (min(*M_dev, M))
 };
 __global__ void __launch_bounds__(256) match_select_kernel(const SelectArgs a) {
   __shared__ int s_wave[4];
@@ -450,10 +455,11 @@ __global__ void __launch_bounds__(256) match_select_kernel(const SelectArgs a) {
   // everything enqueued before this kernel has completed (stream order): tell a host that polls mapped memory
   if (a.signal && tid == 0) __hip_atomic_store(a.signal, a.signal_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   if (tid == 0) { s_carry[0] = -1; s_carry[1] = 0; }
+  const int M = a.M_dev ? min(*a.M_dev, a.M) : a.M;
   int base = 0;  // selected trials before this pass (the same in every thread)
-  for (int m0 = 0; m0 < a.M && base < a.max_selected; m0 += 256) {
+  for (int m0 = 0; m0 < M && base < a.max_selected; m0 += 256) {
     const int m = m0 + tid;
-    const bool valid = m < a.M;
+    const bool valid = m < M;
     // every global read of the pass is issued here, before anything depends on one: the match results may live in
     // host-mapped memory, where a dependent chain of loads costs a link round trip per link
     const int ok = valid ? (a.ok[m] != 0) : 0;
@@ -536,16 +542,17 @@ extern "C" size_t svo_hip_match_workspace_bytes(int M) {
   return b + 4096;
 }
 
-extern "C" int svo_hip_find_match_direct(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
-                                         const svo_hip_camera* cam, const svo_hip_frames* frames, int M,
-                                         const int32_t* d_cur_frame, const double* d_pt_pos,
-                                         const int32_t* d_obs_ptr, const svo_hip_features* obs, int n_pyr_levels,
-                                         int align_max_iter, double* d_px_cur, int32_t* d_ok, int32_t* d_ref_obs,
-                                         int32_t* d_search_level, double* d_A_cur_ref, uint8_t* d_patch_out,
-                                         void* d_workspace, size_t workspace_bytes, void* stream) {
+static int find_match_direct_impl(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
+                                  const svo_hip_camera* cam, const svo_hip_frames* frames, int M, const int32_t* d_M,
+                                  const int32_t* d_cur_frame, const double* d_pt_pos,
+                                  const int32_t* d_obs_ptr, const int32_t* d_obs_begin, const int32_t* d_obs_end,
+                                  const svo_hip_features* obs, int n_pyr_levels,
+                                  int align_max_iter, double* d_px_cur, int32_t* d_ok, int32_t* d_ref_obs,
+                                  int32_t* d_search_level, double* d_A_cur_ref, uint8_t* d_patch_out,
+                                  void* d_workspace, size_t workspace_bytes, void* stream) {
   if (!layout_ok(layout) || !d_store || !cam || !cam_model_ok(cam) || !frames || !obs || M < 0) return SVO_HIP_EINVAL;
   if (M == 0) return SVO_HIP_OK;
-  if (!d_cur_frame || !d_pt_pos || !d_obs_ptr || !d_px_cur || !d_ok || !d_ref_obs || !d_search_level ||
+  if (!d_cur_frame || !d_pt_pos || !(d_obs_ptr || (d_obs_begin && d_obs_end)) || !d_px_cur || !d_ok || !d_ref_obs || !d_search_level ||
       !frames->d_slot || !frames->d_T_f_w || !obs->d_frame || !obs->d_level || !obs->d_px || !obs->d_f)
     return SVO_HIP_EINVAL;
   if (obs->d_type && !obs->d_grad) return SVO_HIP_EINVAL;
@@ -558,12 +565,15 @@ extern "C" int svo_hip_find_match_direct(const svo_hip_pyr_layout* layout, const
   PrepArgs p;
   p.cam = make_cam(cam);
   p.M = M;
+  p.M_dev = d_M;
   p.n_pyr_levels = n_pyr_levels;
   p.frame_slot = frames->d_slot;
   p.frame_T = frames->d_T_f_w;
   p.cur_frame = d_cur_frame;
   p.pt_pos = d_pt_pos;
   p.obs_ptr = d_obs_ptr;
+  p.obs_begin = d_obs_begin;
+  p.obs_end = d_obs_end;
   p.obs = *obs;
   p.px_cur = d_px_cur;
   p.ref_obs = d_ref_obs;
@@ -594,6 +604,7 @@ extern "C" int svo_hip_find_match_direct(const svo_hip_pyr_layout* layout, const
   w.A_ref_cur = p.A_ref_cur;
   w.px_ref_pyr = p.px_ref_pyr;
   w.pwb = pwb;
+  w.M_dev = d_M;
   rc = launch_warp(w, s);
   if (rc) return rc;
   AlignArgs al;
@@ -612,9 +623,37 @@ extern "C" int svo_hip_find_match_direct(const svo_hip_pyr_layout* layout, const
   al.scale_out = 1;
   al.ok = d_ok;
   al.h_inv = nullptr;
-  const size_t phase_bytes = align_phase_workspace_bytes(M);
+  al.M_dev = d_M;
+  const size_t phase_bytes = d_M ? 0 : align_phase_workspace_bytes(M);  // (phases compact by queues sized from M)
   void* phase_ws = phase_bytes ? ws.take<uint8_t>(phase_bytes) : nullptr;
   return launch_align(al, s, ws.ok ? phase_ws : nullptr, phase_bytes);
+}
+
+extern "C" int svo_hip_find_match_direct(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
+                                         const svo_hip_camera* cam, const svo_hip_frames* frames, int M,
+                                         const int32_t* d_cur_frame, const double* d_pt_pos,
+                                         const int32_t* d_obs_ptr, const svo_hip_features* obs, int n_pyr_levels,
+                                         int align_max_iter, double* d_px_cur, int32_t* d_ok, int32_t* d_ref_obs,
+                                         int32_t* d_search_level, double* d_A_cur_ref, uint8_t* d_patch_out,
+                                         void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (M > 0 && !d_obs_ptr) return SVO_HIP_EINVAL;
+  return find_match_direct_impl(layout, d_store, cam, frames, M, nullptr, d_cur_frame, d_pt_pos, d_obs_ptr, nullptr, nullptr, obs,
+                                n_pyr_levels, align_max_iter, d_px_cur, d_ok, d_ref_obs, d_search_level, d_A_cur_ref, d_patch_out,
+                                d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int svo_hip_find_match_direct_indirect(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
+                                                  const svo_hip_camera* cam, const svo_hip_frames* frames, int M_cap,
+                                                  const int32_t* d_M, const int32_t* d_cur_frame, const double* d_pt_pos,
+                                                  const int32_t* d_obs_begin, const int32_t* d_obs_end,
+                                                  const svo_hip_features* obs, int n_pyr_levels, int align_max_iter,
+                                                  double* d_px_cur, int32_t* d_ok, int32_t* d_ref_obs, int32_t* d_search_level,
+                                                  double* d_A_cur_ref, uint8_t* d_patch_out, void* d_workspace,
+                                                  size_t workspace_bytes, void* stream) {
+  if (M_cap < 0 || M_cap > 65536 || !d_M || (M_cap > 0 && (!d_obs_begin || !d_obs_end))) return SVO_HIP_EINVAL;
+  return find_match_direct_impl(layout, d_store, cam, frames, M_cap, d_M, d_cur_frame, d_pt_pos, nullptr, d_obs_begin, d_obs_end, obs,
+                                n_pyr_levels, align_max_iter, d_px_cur, d_ok, d_ref_obs, d_search_level, d_A_cur_ref, d_patch_out,
+                                d_workspace, workspace_bytes, stream);
 }
 
 extern "C" int svo_hip_reproject_points(const svo_hip_camera* cam, const svo_hip_frames* frames, int M,
@@ -665,16 +704,17 @@ extern "C" int svo_hip_cam2world(const svo_hip_camera* cam, int n, const double*
   return check_launch();
 }
 
-extern "C" int svo_hip_select_matches(const svo_hip_camera* cam, int M, const int32_t* d_cell, const int32_t* d_ok,
-                                      const double* d_px, const int32_t* d_level, const double* d_pos, int max_fts,
-                                      int32_t* d_n, int32_t* d_sel, double* d_f, int32_t* d_level_out, double* d_pos_out,
-                                      uint8_t* d_has_point, int32_t* d_signal, int32_t signal_value, void* stream) {
+static int select_matches_impl(const svo_hip_camera* cam, int M, const int32_t* d_M, const int32_t* d_cell, const int32_t* d_ok,
+                               const double* d_px, const int32_t* d_level, const double* d_pos, int max_fts,
+                               int32_t* d_n, int32_t* d_sel, double* d_f, int32_t* d_level_out, double* d_pos_out,
+                               uint8_t* d_has_point, int32_t* d_signal, int32_t signal_value, void* stream) {
   if (!cam || !cam_model_ok(cam) || M < 0 || max_fts < 0 || !d_n) return SVO_HIP_EINVAL;
   if (M > 0 && (!d_cell || !d_ok || !d_px || !d_level || !d_pos || !d_sel || !d_f || !d_level_out || !d_pos_out || !d_has_point))
     return SVO_HIP_EINVAL;
   SelectArgs a{};
   a.cam = make_cam(cam);
   a.M = M;
+  a.M_dev = d_M;
   a.cell = d_cell;
   a.ok = d_ok;
   a.px = d_px;
@@ -691,4 +731,22 @@ extern "C" int svo_hip_select_matches(const svo_hip_camera* cam, int M, const in
   a.signal_value = signal_value;
   hipLaunchKernelGGL(match_select_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);  // M == 0: n = 0
   return check_launch();
+}
+
+extern "C" int svo_hip_select_matches(const svo_hip_camera* cam, int M, const int32_t* d_cell, const int32_t* d_ok,
+                                      const double* d_px, const int32_t* d_level, const double* d_pos, int max_fts,
+                                      int32_t* d_n, int32_t* d_sel, double* d_f, int32_t* d_level_out, double* d_pos_out,
+                                      uint8_t* d_has_point, int32_t* d_signal, int32_t signal_value, void* stream) {
+  return select_matches_impl(cam, M, nullptr, d_cell, d_ok, d_px, d_level, d_pos, max_fts, d_n, d_sel, d_f, d_level_out, d_pos_out,
+                             d_has_point, d_signal, signal_value, stream);
+}
+
+extern "C" int svo_hip_select_matches_indirect(const svo_hip_camera* cam, int M_cap, const int32_t* d_M, const int32_t* d_cell,
+                                               const int32_t* d_ok, const double* d_px, const int32_t* d_level,
+                                               const double* d_pos, int max_fts, int32_t* d_n, int32_t* d_sel, double* d_f,
+                                               int32_t* d_level_out, double* d_pos_out, uint8_t* d_has_point, int32_t* d_signal,
+                                               int32_t signal_value, void* stream) {
+  if (!d_M) return SVO_HIP_EINVAL;
+  return select_matches_impl(cam, M_cap, d_M, d_cell, d_ok, d_px, d_level, d_pos, max_fts, d_n, d_sel, d_f, d_level_out, d_pos_out,
+                             d_has_point, d_signal, signal_value, stream);
 }

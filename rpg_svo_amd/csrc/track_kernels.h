@@ -22,6 +22,7 @@ struct AlignArgs {
   int32_t* ok;             // [M]
   double* h_inv;           // [M] or NULL
   int32_t* iters = nullptr;  // [M] or NULL: residual evaluations per trial (instrumented kernel variant)
+  const int32_t* M_dev = nullptr;  // or the batch size lives on the device: min(*M_dev, M) trials (launches sized for M)
   // Phased run (launch_align fills these; see feature_align.hip): iterations [it0, it1) of the trials listed in
   // queue_in (NULL: all M trials); a trial that has neither converged nor failed by it1 < n_iter parks its loop
   // state in `state` and its index in queue_out for the next launch.
@@ -52,6 +53,7 @@ struct WarpArgs {
   const float* A_ref_cur;     // [M][4] row-major (A_cur_ref^-1 cast to float)
   const float* px_ref_pyr;    // [M][2] px_ref.cast<float>() / (1 << level_ref)
   uint8_t* pwb;               // [M][100]
+  const int32_t* M_dev = nullptr;  // see AlignArgs::M_dev
 };
 int launch_warp(const WarpArgs& a, hipStream_t s);
 

@@ -133,30 +133,42 @@ Device& Device::instance() {
   return *g_last;
 }
 
+namespace {
+void destroyLane(Lane* l) {  // everything makeLane() / workspace() may have given it; streams are drained first
+  if (l->stream) { svo_hip_stream_sync(l->stream); svo_hip_stream_destroy(l->stream); l->stream = NULL; }
+  if (l->stream_next) { svo_hip_stream_sync(l->stream_next); svo_hip_stream_destroy(l->stream_next); l->stream_next = NULL; }
+  if (l->ev_results) { svo_hip_event_destroy(l->ev_results); l->ev_results = NULL; }
+  l->deferred = nullptr;  // its owner is about to lose the device; nothing is written back
+  l->arena.release();
+  if (l->d_workspace) { svo_hip_free(l->d_workspace); l->d_workspace = NULL; l->workspace_bytes = 0; }
+  if (l->d_stage) { svo_hip_free(l->d_stage); l->d_stage = NULL; }
+  delete l;
+}
+}  // namespace
+
 Lane* Device::makeLane() {
-  Lane* l = new Lane();
-  check(svo_hip_stream_create(&l->stream), "svo_hip_stream_create");
-  check(svo_hip_stream_create(&l->stream_next), "svo_hip_stream_create");
-  check(svo_hip_event_create(&l->ev_results), "svo_hip_event_create");
-  l->index = next_lane_index_++;
-  check(svo_hip_malloc(&l->d_stage, (size_t)layout_.w[0] * layout_.h[0]), "svo_hip_malloc(stage)");
-  {
-    const char* w = std::getenv("SVO_HIP_WAIT");
-    if (w && std::string(w) == "signal") {
-      void* f = NULL;
-      check(svo_hip_host_alloc(&f, 256), "svo_hip_host_alloc(done flag)");
-      l->done_flag = static_cast<int32_t*>(f);
-      *l->done_flag = 0;
-    } else if (w && std::string(w) != "sync") {
-      throw Error("SVO_HIP_WAIT must be 'sync' or 'signal'");
-    }
+  // the environment switches first: a bad value must not leave streams and buffers behind
+  // SVO_HIP_ARENA=hybrid|mapped|mirrored selects how a call's arguments reach the device (Arena)
+  Arena::Mode arena_mode = Arena::HYBRID;  // the default
+  if (const char* mode = std::getenv("SVO_HIP_ARENA")) {
+    const std::string m(mode);
+    if (m == "mapped") arena_mode = Arena::MAPPED;
+    else if (m == "mirrored") arena_mode = Arena::MIRRORED;
+    else if (m != "hybrid") throw Error("SVO_HIP_ARENA must be 'hybrid', 'mirrored' or 'mapped'");
   }
-  l->arena.reserve((size_t)4 << 20);
-  // SVO_HIP_ARENA=mapped|mirrored selects how a call's arguments reach the device (Arena)
-  const char* mode = std::getenv("SVO_HIP_ARENA");
-  if (!mode || std::string(mode) == "hybrid") l->arena.setMode(Arena::HYBRID);  // the default
-  else if (std::string(mode) == "mapped") l->arena.setMode(Arena::MAPPED);
-  else if (std::string(mode) != "mirrored") throw Error("SVO_HIP_ARENA must be 'hybrid', 'mirrored' or 'mapped'");
+  Lane* l = new Lane();
+  try {
+    check(svo_hip_stream_create(&l->stream), "svo_hip_stream_create");
+    check(svo_hip_stream_create(&l->stream_next), "svo_hip_stream_create");
+    check(svo_hip_event_create(&l->ev_results), "svo_hip_event_create");
+    check(svo_hip_malloc(&l->d_stage, (size_t)layout_.w[0] * layout_.h[0]), "svo_hip_malloc(stage)");
+    l->arena.reserve((size_t)4 << 20);
+    l->arena.setMode(arena_mode);
+  } catch (...) {
+    destroyLane(l);  // not in lanes_ yet: shutdown() would never see it
+    throw;
+  }
+  l->index = next_lane_index_++;  // only a lane that exists takes an index
   return l;
 }
 
@@ -174,18 +186,8 @@ Lane& Device::lane(int which) {
 void Device::shutdown() {
   {
     std::lock_guard<std::mutex> g(lanes_mut_);
-    for (std::map<std::pair<std::thread::id, int>, Lane*>::iterator it = lanes_.begin(); it != lanes_.end(); ++it) {
-      Lane& l = *it->second;
-      if (l.stream) { svo_hip_stream_sync(l.stream); svo_hip_stream_destroy(l.stream); l.stream = NULL; }
-      if (l.stream_next) { svo_hip_stream_sync(l.stream_next); svo_hip_stream_destroy(l.stream_next); l.stream_next = NULL; }
-      if (l.ev_results) { svo_hip_event_destroy(l.ev_results); l.ev_results = NULL; }
-      l.deferred = nullptr;  // its owner is about to lose the device; nothing is written back
-      l.arena.release();
-      if (l.d_workspace) { svo_hip_free(l.d_workspace); l.d_workspace = NULL; l.workspace_bytes = 0; }
-      if (l.d_stage) { svo_hip_free(l.d_stage); l.d_stage = NULL; }
-      if (l.done_flag) { svo_hip_host_free(l.done_flag); l.done_flag = NULL; }
-      delete it->second;
-    }
+    for (std::map<std::pair<std::thread::id, int>, Lane*>::iterator it = lanes_.begin(); it != lanes_.end(); ++it)
+      destroyLane(it->second);
     lanes_.clear();
   }
   if (d_store_) { svo_hip_free(d_store_); d_store_ = NULL; }
@@ -243,15 +245,7 @@ bool Device::deferredMapping() {
 }
 void Device::setDeferredMapping(bool on) { g_deferred_mapping.store(on ? 1 : 0); }
 
-void Device::finish(Lane& lane) {
-  if (!lane.done_flag) {
-    check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
-    return;
-  }
-  const int32_t seq = ++lane.done_seq;
-  check(svo_hip_stream_write_value32(lane.stream, lane.done_flag, seq), "svo_hip_stream_write_value32");
-  spinUntil(lane.done_flag, seq, lane.stream);
-}
+void Device::finish(Lane& lane) { check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync"); }
 
 void Device::joinDeferred(int which_lane) {
   Lane* l = NULL;

@@ -132,14 +132,12 @@ struct Lane {
   Arena arena;
   void* d_workspace;      // matcher / depth-filter scratch (svo_hip_match_workspace_bytes)
   size_t workspace_bytes;
-  int32_t* done_flag;     // SVO_HIP_WAIT=signal: pinned word the stream writes behind a call's last command, polled by
-  int32_t done_seq;       //   Device::finish(); the value expected next
   void* d_stage;          // packed level-0 image on its way into the tiled store (svo_hip_pyramid_upload_*)
   int index;              // unique per lane: scratch frames of different lanes never share a slot
   double pyr_upload_us;   // time this lane spent uploading pyramids (StageTimer takes it out of "marshal")
   std::mutex mut;
   std::vector<int> touched;  // frames pinned by the lane's current call
-  Lane() : stream(NULL), stream_next(NULL), ev_results(NULL), done_flag(NULL), done_seq(0), d_workspace(NULL), workspace_bytes(0), d_stage(NULL), index(0), pyr_upload_us(0) {}
+  Lane() : stream(NULL), stream_next(NULL), ev_results(NULL), d_workspace(NULL), workspace_bytes(0), d_stage(NULL), index(0), pyr_upload_us(0) {}
 };
 
 class Device {
@@ -169,9 +167,10 @@ class Device {
   // pinned (never evicted) until the lane's next beginCall().
   void beginCall(int which_lane) { beginCall(lane(which_lane)); }
   void beginCall(Lane& lane);
-  // The host waits for everything enqueued on the lane's stream.  Default: svo_hip_stream_sync.  SVO_HIP_WAIT=signal
-  // (opt-in, for timing experiments): a stream write-value command stores a sequence number into a pinned word behind the
-  // call's last command and the host polls it -- no runtime call on the way back, no wake-up.
+  // The host waits for everything enqueued on the lane's stream (svo_hip_stream_sync).  Round 4 timed the alternative --
+  // a stream write-value command storing a sequence number into a pinned word the host polls -- on the GPU box: 5-20 us
+  // SLOWER per frame on both map sizes (profiles/r04b_wait_modes_*.txt: the command processor's write lands later than
+  // the runtime's own completion signal), so it was removed.
   void finish(Lane& lane);
   // Completes a deferred call of the calling thread's lane of that role, if there is one (no lane is created).
   void joinDeferred(int which_lane);

@@ -164,6 +164,103 @@ int svo_hip_find_match_direct(const svo_hip_pyr_layout* L, const uint8_t* store,
   return SVO_HIP_OK;
 }
 
+// the device-resident map mirror (row N2): the mock's "device memory" is host memory, so the patch is a plain copy and
+// the walk is the oracle's restatement of Reprojector::reprojectMap
+int svo_hip_reproject_map(const svo_hip_camera* cam, const svo_hip_frames* frames, int cur_frame, const int32_t* d_kf_rank,
+                          const svo_hip_map* map, const svo_hip_map_patch* patch, const svo_hip_grid* grid, int first_cell,
+                          int max_cells_with_trials, int max_visits, int max_trials, const svo_hip_reprojection* out, void*) {
+  if (patch) {
+    for (int i = 0; i < patch->n_obs; ++i) {
+      const int o = patch->d_obs_index[i];
+      map->d_obs_frame[o] = patch->obs.d_frame[i];
+      map->d_obs_order[o] = patch->d_obs_order[i];
+      map->d_obs_level[o] = patch->obs.d_level[i];
+      map->d_obs_type[o] = patch->obs.d_type[i];
+      for (int k = 0; k < 2; ++k) map->d_obs_px[2 * o + k] = patch->obs.d_px[2 * i + k];
+      for (int k = 0; k < 3; ++k) map->d_obs_f[3 * o + k] = patch->obs.d_f[3 * i + k];
+      for (int k = 0; k < 2; ++k) map->d_obs_grad[2 * o + k] = patch->obs.d_grad[2 * i + k];
+    }
+    for (int i = 0; i < patch->n_points; ++i) {
+      const int p = patch->d_index[i];
+      for (int k = 0; k < 3; ++k) map->d_pos[3 * p + k] = patch->d_pos[3 * i + k];
+      map->d_type[p] = patch->d_type[i];
+      map->d_order[p] = patch->d_order[i];
+      map->d_obs_begin[p] = patch->d_obs_begin[i];
+      map->d_obs_count[p] = patch->d_obs_count[i];
+    }
+  }
+  const orc_pinhole c = camOf(cam);
+  const int P = map->n_points;
+  const size_t cap = (size_t)(P > 0 ? P : 1);
+  std::vector<int32_t> vp(cap), vc(cap), vt(cap), tobs(cap), tcell(cap);
+  std::vector<double> tpx(2 * cap), tpos(3 * cap);
+  int32_t header[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  orc_reproject_map(&c, frames->n_frames, frames->d_T_f_w, cur_frame, d_kf_rank, P, map->d_pos, map->d_type, map->d_order,
+                    map->d_obs_begin, map->d_obs_count, map->d_obs_frame, map->d_obs_order, grid->cell_size, grid->n_cols,
+                    grid->n_cells, grid->d_cell_rank, first_cell, max_cells_with_trials, header, out->d_point_cell, out->d_point_px,
+                    out->d_kf_count, vp.data(), vc.data(), vt.data(), tobs.data(), tcell.data(), tpx.data(), tpos.data());
+  const int V = header[2], M = header[3];
+  if (header[1] > SVO_HIP_REPROJ_MAX_IN_FRAME || V > max_visits || M > max_trials) {  // the kernel's capacity rule
+    header[0] = 1; header[2] = header[3] = 0; header[4] = first_cell;
+  } else {
+    for (int v = 0; v < V; ++v) { out->d_visit_point[v] = vp[v]; out->d_visit_cell[v] = vc[v]; out->d_visit_trial[v] = vt[v]; }
+    for (int m = 0; m < M; ++m) {
+      out->d_trial_cur[m] = cur_frame;
+      for (int k = 0; k < 3; ++k) out->d_trial_pos[3 * m + k] = tpos[3 * m + k];
+      out->d_trial_obs_begin[m] = tobs[m];
+      out->d_trial_obs_end[m] = tobs[m] + 1;
+      out->d_trial_cell[m] = tcell[m];
+      out->d_trial_px[2 * m] = tpx[2 * m]; out->d_trial_px[2 * m + 1] = tpx[2 * m + 1];
+    }
+  }
+  for (int k = 0; k < SVO_HIP_REPROJ_HEADER; ++k) out->d_header[k] = header[k];
+  return SVO_HIP_OK;
+}
+
+int svo_hip_find_match_direct_indirect(const svo_hip_pyr_layout* L, const uint8_t* store, const svo_hip_camera* cam,
+                                       const svo_hip_frames* frames, int M_cap, const int32_t* d_M, const int32_t* d_cur_frame,
+                                       const double* d_pt_pos, const int32_t* d_obs_begin, const int32_t* d_obs_end,
+                                       const svo_hip_features* obs, int n_pyr_levels, int align_max_iter, double* d_px_cur,
+                                       int32_t* d_ok, int32_t* d_ref_obs, int32_t* d_search_level, double* d_A_cur_ref,
+                                       uint8_t* d_patch_out, void*, size_t, void*) {
+  const int M = d_M[0] < M_cap ? d_M[0] : M_cap;
+  const orc_pinhole c = camOf(cam);
+  const std::vector<orc_frame> fr = framesOf(L, store, frames);
+  orc_matcher_options opt;
+  orc_matcher_options_default(&opt);
+  opt.n_pyr_levels = n_pyr_levels;
+  opt.align_max_iter = align_max_iter;
+  for (int m = 0; m < M; ++m) {
+    const int o0 = d_obs_begin[m], n_obs = d_obs_end[m] - o0;
+    std::vector<orc_feature> ob((size_t)(n_obs > 0 ? n_obs : 0));
+    for (int k = 0; k < n_obs; ++k) ob[k] = featureOf(obs, o0 + k);
+    orc_match_result r;
+    std::memset(&r, 0, sizeof(r));
+    double px[2] = {d_px_cur[2 * m], d_px_cur[2 * m + 1]};
+    const int ok = orc_find_match_direct(fr.data(), &c, d_cur_frame[m], d_pt_pos + 3 * m, n_obs, ob.data(), &opt, px, &r);
+    d_px_cur[2 * m] = px[0]; d_px_cur[2 * m + 1] = px[1];
+    d_ok[m] = ok;
+    d_ref_obs[m] = r.ref_obs >= 0 ? o0 + r.ref_obs : -1;
+    d_search_level[m] = r.search_level;
+    if (d_A_cur_ref) std::memcpy(d_A_cur_ref + 4 * m, r.A_cur_ref, 4 * sizeof(double));
+    if (d_patch_out) std::memcpy(d_patch_out + 100 * m, r.patch_with_border, 100);
+  }
+  return SVO_HIP_OK;
+}
+
+int svo_hip_select_matches_indirect(const svo_hip_camera* cam, int M_cap, const int32_t* d_M, const int32_t* d_cell,
+                                    const int32_t* d_ok, const double* d_px, const int32_t* d_level, const double* d_pos, int max_fts,
+                                    int32_t* d_n, int32_t* d_sel, double* d_f, int32_t* d_level_out, double* d_pos_out,
+                                    uint8_t* d_has_point, int32_t* d_signal, int32_t signal_value, void*) {
+  if (d_signal) *d_signal = signal_value;
+  const int M = d_M[0] < M_cap ? d_M[0] : M_cap;
+  const orc_pinhole c = camOf(cam);
+  const int n = M > 0 ? orc_select_matches(&c, M, d_cell, d_ok, d_px, d_level, d_pos, max_fts, d_sel, d_f, d_level_out, d_pos_out) : 0;
+  for (int i = 0; i < n; ++i) d_has_point[i] = 1;
+  d_n[0] = n;
+  return SVO_HIP_OK;
+}
+
 int svo_hip_select_matches(const svo_hip_camera* cam, int M, const int32_t* d_cell, const int32_t* d_ok, const double* d_px,
                            const int32_t* d_level, const double* d_pos, int max_fts, int32_t* d_n, int32_t* d_sel, double* d_f,
                            int32_t* d_level_out, double* d_pos_out, uint8_t* d_has_point, int32_t* d_signal, int32_t signal_value,

@@ -126,3 +126,74 @@ def camera_models():
 
 
 CAMERA_KINDS = ("pinhole", "radtan", "atan")
+
+
+# ---- random maps for Reprojector::reprojectMap (row N2) ------------------------------------------------------------
+def random_map(cam, n_kfs=12, n_points=900, n_candidates=700, seed=0, n_overlap=10, cell_size=30, dead_frac=0.05):
+    """A map in the plain-array form of svo_hip_map: keyframes on a random walk above the plane z = 0 looking down,
+    map points (GOOD / UNKNOWN) observed in 1..n keyframes at random positions of their fts_ lists, candidates with
+    one observation that is in no keyframe's list, some dead entries; the current frame is the last entry of the frame
+    table; `n_overlap` keyframes ranked by distance, the rest not overlapping; a random visiting order of the cells."""
+    rng = np.random.default_rng(seed)
+    n_frames = n_kfs + 1
+    # keyframe centres up to 3 m from the current one at ~2 m height: viewing directions of a point differ by up to
+    # ~70 degrees between frames, so Point::getCloseViewObs (cos < 0.5) rejects some candidates
+    R0 = np.diag([1.0, -1.0, -1.0])
+    T = np.zeros((n_frames, 12))
+    for i in range(n_frames):
+        rv = rng.normal(0, 0.05, 3)
+        R = se3.split(se3.exp(np.concatenate([np.zeros(3), rv])))[0] @ R0
+        ctr = np.array([rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(1.6, 2.4)]) if i < n_kfs else np.array([0.1, -0.2, 2.0])
+        T[i] = se3.join(R, -R @ ctr)
+    c = se3.inv(T)[:, 9:]
+    cur = n_frames - 1
+    dist = np.linalg.norm(c[:n_kfs] - c[cur], axis=1)
+    kf_rank = np.full(n_frames, -1, dtype=np.int32)
+    for r, f in enumerate(np.argsort(dist, kind="stable")[:n_overlap]):
+        kf_rank[f] = r
+    P = n_points + n_candidates
+    # points on and around the plane, spread over more than the field of view (some project outside)
+    span = 1.3 * 2.0 * max(cam.width / cam.fx, cam.height / cam.fy) / 2
+    pos = np.stack([rng.uniform(-span, span, P), rng.uniform(-span, span, P), rng.normal(0, 0.05, P)], -1)
+    pos[:, :2] += c[cur, :2]
+    type_ = np.zeros(P, dtype=np.int32)
+    type_[:n_points] = rng.choice([2, 3], size=n_points)
+    type_[n_points:] = 1
+    type_[rng.uniform(size=P) < dead_frac] = 0
+    order = np.zeros(P, dtype=np.int32)
+    perm = rng.permutation(n_candidates)           # list order of the candidates is NOT entry order
+    order[n_points:] = perm
+    obs_begin, obs_count = np.zeros(P, dtype=np.int32), np.zeros(P, dtype=np.int32)
+    obs_frame, obs_order = [], []
+    next_ord = np.zeros(n_kfs, dtype=np.int64)
+    slots = [rng.permutation(4000)[:P] for _ in range(n_kfs)]   # distinct fts_ positions per keyframe
+    for p in range(P):
+        obs_begin[p] = len(obs_frame)
+        if p < n_points:
+            k = rng.integers(1, min(6, n_kfs) + 1)
+            for f in rng.choice(n_kfs, size=k, replace=False):
+                obs_frame.append(f)
+                obs_order.append(int(slots[f][next_ord[f]]))
+                next_ord[f] += 1
+            if rng.uniform() < 0.03:   # an observation whose Feature is in no keyframe's list
+                obs_frame.append(int(rng.integers(n_kfs))); obs_order.append(-1)
+        else:
+            obs_frame.append(int(rng.integers(n_kfs))); obs_order.append(-1)
+        obs_count[p] = len(obs_frame) - obs_begin[p]
+    O = len(obs_frame)
+    n_cols, n_rows = -(-cam.width // cell_size), -(-cam.height // cell_size)
+    cell_order = rng.permutation(n_cols * n_rows)
+    cell_rank = np.empty(n_cols * n_rows, dtype=np.int32)
+    cell_rank[cell_order] = np.arange(n_cols * n_rows, dtype=np.int32)
+    return dict(T=T, cur=cur, kf_rank=kf_rank, pos=pos, type=type_, order=order, obs_begin=obs_begin, obs_count=obs_count,
+                obs_frame=np.array(obs_frame, dtype=np.int32), obs_order=np.array(obs_order, dtype=np.int32),
+                obs_level=rng.integers(0, 3, O).astype(np.int32), obs_type=(rng.uniform(size=O) < 0.2).astype(np.uint8),
+                obs_px=rng.uniform(20, 400, (O, 2)), obs_f=rng.normal(size=(O, 3)), obs_grad=rng.normal(size=(O, 2)),
+                cell_size=cell_size, n_cols=n_cols, n_rows=n_rows, cell_order=cell_order, cell_rank=cell_rank)
+
+
+def oracle_reproject_map(mp, cam, first_cell=0, max_cells=1 << 30):
+    from oracle import pytrack
+    return pytrack.reproject_map(cam, mp["T"], mp["cur"], mp["kf_rank"], mp["pos"], mp["type"], mp["order"], mp["obs_begin"],
+                                 mp["obs_count"], mp["obs_frame"], mp["obs_order"], mp["cell_size"], mp["n_cols"],
+                                 mp["n_cols"] * mp["n_rows"], mp["cell_rank"], first_cell, max_cells)

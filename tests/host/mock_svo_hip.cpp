@@ -43,7 +43,6 @@ int svo_hip_event_record(void* e, void*) { *static_cast<int*>(e) = 1; return SVO
 int svo_hip_event_sync(void*) { return SVO_HIP_OK; }
 int svo_hip_event_query(void* e) { return *static_cast<int*>(e); }  // 1 once recorded: the mock's streams are synchronous
 int svo_hip_stream_wait_event(void*, void*) { return SVO_HIP_OK; }
-int svo_hip_stream_write_value32(void*, int32_t* p, int32_t v) { *p = v; return SVO_HIP_OK; }
 
 size_t svo_hip_match_workspace_bytes(int M) { return (size_t)(M > 0 ? M : 1) * 1024; }
 

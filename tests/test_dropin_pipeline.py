@@ -192,9 +192,9 @@ def test_mock_device_with_the_mapping_thread(mock_lib):
 
 def test_mock_device_arena_modes_and_no_prediction(mock_lib, tmp_path):
     """SVO_HIP_ARENA = hybrid / mirrored / mapped, SVO_HIP_SPECULATE = 0, a first match batch too small to reach the
-    visiting loop's stop, and SVO_HIP_WAIT = signal (the host polls a word the stream writes instead of synchronising;
-    all fixed when a lane / the process starts: one process each): the host code paths differ -- where blocks live, which copies are issued, polling a signal or
-    waiting for a stream, prediction on the same or on a second stream or none -- the results do not."""
+    visiting loop's stop (all fixed when a lane / the process starts: one process each): the host code paths differ --
+    where blocks live, which copies are issued, polling a signal or waiting for a stream, prediction on the same or on a
+    second stream or none -- the results do not."""
     import subprocess
     code = (
         "import sys, numpy as np\n"
@@ -208,15 +208,14 @@ def test_mock_device_arena_modes_and_no_prediction(mock_lib, tmp_path):
         "print(st['predicted_pose_hits'], st['predicted_pose_misses'])\n")
     out, hits = {}, {}
     for name, env in (("hybrid", {}), ("mirrored", {"SVO_HIP_ARENA": "mirrored"}), ("mapped", {"SVO_HIP_ARENA": "mapped"}),
-                      ("no_prediction", {"SVO_HIP_SPECULATE": "0"}), ("second_batch", {"SVO_HIP_FIRST_BATCH_CELLS": "40"}),
-                      ("signal_wait", {"SVO_HIP_WAIT": "signal"})):
+                      ("no_prediction", {"SVO_HIP_SPECULATE": "0"}), ("second_batch", {"SVO_HIP_FIRST_BATCH_CELLS": "40"})):
         path = str(tmp_path / f"traj_{name}.npy")
         p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True,
                            timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         out[name] = np.load(path)
         hits[name] = [int(x) for x in p.stdout.split()[-2:]]
-    for name in ("mirrored", "mapped", "no_prediction", "second_batch", "signal_wait"):
+    for name in ("mirrored", "mapped", "no_prediction", "second_batch"):
         assert np.array_equal(out[name], out["hybrid"]), name
     assert hits["hybrid"] == [49, 0] and hits["mirrored"] == [49, 0] and hits["mapped"] == [49, 0] and hits["no_prediction"] == [0, 0]
     # a first batch of 40 cells never reaches the stop at 121 matches: the rest of the cells goes in a second batch and the
@@ -532,28 +531,3 @@ def test_dropin_arena_modes_agree(pipeline_libs, gpu_device, tmp_path):
     for mode in ("mirrored", "mapped"):
         d = se3.log_norm(out[mode], out["hybrid"])
         assert d.max() <= SE3_LOGNORM_TOL, (mode, d.max())
-
-
-@pytest.mark.gpu
-def test_dropin_wait_modes_agree(pipeline_libs, gpu_device, tmp_path):
-    """SVO_HIP_WAIT=signal (a stream write-value command stores a sequence number behind a call's last command and the
-    host polls the pinned word: svo_hip_stream_write_value32, Device::finish) against the default hipStreamSynchronize:
-    the same kernels on the same bytes, only the way the host learns that they are through differs -- the trajectories
-    are equal bit for bit.  The mode is fixed when a lane is created, hence one process each."""
-    import subprocess
-    code = (
-        "import sys, numpy as np\n"
-        f"sys.path.insert(0, {HERE!r}); sys.path.insert(0, {os.path.join(HERE, 'dropin')!r})\n"
-        "import pypipeline as pp\n"
-        "import test_dropin_pipeline as t\n"
-        "cam, imgs, T = t._sequence(40)\n"
-        "hip = pp.run_sequence('hip', cam, imgs, T)\n"
-        "np.save(sys.argv[1], np.stack([r['T_f_w'] for r in hip]))\n")
-    out = {}
-    for mode in ("sync", "signal"):
-        path = str(tmp_path / f"traj_{mode}.npy")
-        p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, SVO_HIP_WAIT=mode), capture_output=True,
-                           text=True, timeout=300)
-        assert p.returncode == 0, p.stderr[-2000:]
-        out[mode] = np.load(path)
-    assert np.array_equal(out["signal"], out["sync"])
