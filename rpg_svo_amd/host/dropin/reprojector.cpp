@@ -21,6 +21,9 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 
 #include <svo/config.h>
@@ -29,6 +32,7 @@
 #include <svo/map.h>
 #include <svo/point.h>
 
+#include "map_mirror.h"
 #include "marshal.h"
 
 namespace svo {
@@ -82,13 +86,333 @@ bool closeViewObs(const Point& pt, const Vector3d& framepos, FramePositions& pos
   ftr = *min_it;
   return !(min_cos_angle < 0.5);  // observations more than 60 degrees apart are useless
 }
+
+// ---- row N2: the same call on the device-resident mirror of the map (map_mirror.h, svo_hip_reproject_map) -----------
+// One mirror per svo::Map (a process may run several handlers); entries live until process exit, like the device contexts.
+struct MirrorRegistry {
+  std::mutex mut;
+  std::map<const Map*, hip_dropin::MapMirror*> all;
+};
+MirrorRegistry& mirrors() {
+  static MirrorRegistry r;
+  return r;
+}
+hip_dropin::MapMirror& mirrorOf(const Map* map) {
+  MirrorRegistry& r = mirrors();
+  std::lock_guard<std::mutex> g(r.mut);
+  hip_dropin::MapMirror*& m = r.all[map];
+  if (m == NULL) m = new hip_dropin::MapMirror();
+  return *m;
+}
+
+// Steps 1-4 of reprojectMap with the walk of the pointer graph replaced by one kernel over the mirror: the host finds
+// the overlapping keyframes (the reference's own getCloseKeyframes: a dozen keyframes, five key points each), sends what
+// changed in the map since the last frame, and enqueues  reproject_map -> match kernels -> selection -> pose refinement
+// back to back; it then replays the candidate bookkeeping (:108-123) and the cell loop (:131-139, 151-200) from the
+// result tables.  Returns false -- having changed nothing -- when the frame has to take the list-walking path below.
+template <class GridT>
+bool reprojectMapMirrored(const FramePtr& frame, std::vector<std::pair<FramePtr, std::size_t> >& overlap_kfs, Map& map_,
+                          const GridT& grid_, const Reprojector::Options& options_, int align_max_iter, size_t& n_matches_,
+                          size_t& n_trials_) {
+  using namespace hip_dropin;
+  const size_t n_cells = grid_.cells.size();
+  const size_t T_CAP = 4096, V_CAP = 4096;  // trials / visits one batch can hold (status 1 beyond: the other path)
+  if (n_cells > (size_t)SVO_HIP_REPROJ_MAX_CELLS || options_.max_n_kfs > 16) return false;
+  MapMirror& mm = mirrorOf(&map_);
+  ++mm.stats.calls;
+  std::list<KfDist> close_kfs;
+  map_.getCloseKeyframes(frame, close_kfs);
+  close_kfs.sort(closerKf);
+  if (!mm.sync(map_)) { ++mm.stats.fallbacks; return false; }
+  svo_hip::Device& dev = ensureDevice(*frame);
+  const size_t n_tab = mm.frames().size() + 1;  // the mirror's frames, then the current one
+  if ((size_t)dev.slots() < n_tab + 2) { ++mm.stats.fallbacks; return false; }  // every keyframe resident at once
+  std::vector<int32_t> rank_of(n_tab, -1);
+  std::vector<std::pair<FramePtr, int> > ranked;  // (keyframe, its index in the frame table), closest first
+  for (std::list<KfDist>::iterator kf = close_kfs.begin(); kf != close_kfs.end() && ranked.size() < options_.max_n_kfs; ++kf) {
+    const int idx = mm.frameIndex(kf->first.get());
+    if (idx < 0) { ++mm.stats.fallbacks; return false; }  // (a keyframe of the map the mirror does not know: cannot happen after sync)
+    rank_of[(size_t)idx] = (int32_t)ranked.size();
+    ranked.push_back(std::make_pair(kf->first, idx));
+  }
+  const int L = svo_hip::Device::LANE_TRACKING;
+  svo_hip::Lane& lane = dev.lane(L);
+
+  // the tables of the batch in flight (host addresses of arena blocks)
+  struct View {
+    const int32_t *header, *visit_point, *visit_cell, *visit_trial, *ok, *lvl, *ref;
+    const double *px, *A;
+    size_t V, end_cell;
+  } view;
+  std::memset(&view, 0, sizeof(view));
+  bool predict = false;
+  const int32_t* point_cell = NULL;
+  const int32_t* kf_count = NULL;
+
+  // one batch: cells [first_cell, ...) until max_cells of them hold a trial.  false: capacity exceeded on the device
+  auto runBatch = [&](const size_t first_cell, const size_t max_cells) -> bool {
+    std::lock_guard<std::mutex> guard(lane.mut);
+    dev.beginCall(L);
+    svo_hip::StageTimer stage_timer(dev, lane, svo_hip::Device::STAGE_REPROJECT);
+    svo_hip::Arena& a = lane.arena;
+    a.reset();
+    mm.ensureDevice(grid_.cell_order, T_CAP);
+    const size_t P = mm.entries().size();
+    a.reserve(((size_t)1 << 17) + mm.patchBytes() + P * 8 + T_CAP * 128 + V_CAP * 16 + n_tab * 128);
+    FrameTable frames(dev, L);
+    for (size_t i = 0; i + 1 < n_tab; ++i)
+      if (frames.indexOf(mm.frames()[i]) != (int)i) throw std::logic_error("Reprojector: frame table out of order");
+    const int i_cur = frames.indexOf(frame.get());
+    predict = first_cell == 0 && svo_hip::Device::speculationEnabled() && frame->fts_.empty();
+    const size_t cap = (size_t)Config::maxFts() + 1;
+
+    // ---- inputs: what changed in the map, the ranks of the overlapping keyframes, the frame table
+    const svo_hip_map_patch patch = mm.emitPatch(a);
+    int32_t* d_rank;
+    int32_t* rank = a.alloc<int32_t>(n_tab, &d_rank);
+    std::copy(rank_of.begin(), rank_of.end(), rank);
+    svo_hip_frames ft;
+    frames.emit(a, &ft);
+    double *d_sf = NULL, *d_spos = NULL;
+    int32_t* d_slvl = NULL;
+    if (predict) {  // the predicted pose refinement's observations: gathered on the device, never read by the host
+      a.alloc<double>(3 * cap, &d_sf);
+      a.alloc<double>(3 * cap, &d_spos);
+      a.alloc<int32_t>(cap, &d_slvl);
+    }
+    a.endInputs();
+    const size_t inputs_end = a.used();
+
+    // ---- outputs the host reads
+    svo_hip_reprojection out;
+    std::memset(&out, 0, sizeof(out));
+    int32_t* header = a.alloc<int32_t>(SVO_HIP_REPROJ_HEADER, &out.d_header);
+    header[0] = -1;
+    const int32_t* h_point_cell = a.alloc<int32_t>(P ? P : 1, &out.d_point_cell);
+    const int32_t* h_kf_count = a.alloc<int32_t>(n_tab, &out.d_kf_count);
+    const int32_t* h_vp = a.alloc<int32_t>(V_CAP, &out.d_visit_point);
+    const int32_t* h_vc = a.alloc<int32_t>(V_CAP, &out.d_visit_cell);
+    const int32_t* h_vt = a.alloc<int32_t>(V_CAP, &out.d_visit_trial);
+    const double* h_px = a.alloc<double>(2 * T_CAP, &out.d_trial_px);
+    double* d_A; int32_t *d_ok, *d_ref, *d_lvl;
+    const int32_t* h_ok = a.alloc<int32_t>(T_CAP, &d_ok);
+    const int32_t* h_ref = a.alloc<int32_t>(T_CAP, &d_ref);
+    const int32_t* h_lvl = a.alloc<int32_t>(T_CAP, &d_lvl);
+    const double* h_A = a.alloc<double>(4 * T_CAP, &d_A);
+    const size_t match_end = a.used();
+    out.d_point_px = mm.pointPx();
+    out.d_trial_cur = mm.trialCur(); out.d_trial_pos = mm.trialPos();
+    out.d_trial_obs_begin = mm.trialObsBegin(); out.d_trial_obs_end = mm.trialObsEnd(); out.d_trial_cell = mm.trialCell();
+    int32_t* const d_M = out.d_header + 3;
+
+    double *d_T = NULL, *d_Cov = NULL, *d_stats = NULL;
+    int32_t *d_nsel = NULL, *d_sel = NULL, *d_ran = NULL, *d_flag = NULL;
+    volatile int32_t* flag = NULL;
+    uint8_t* d_has = NULL;
+    size_t results_begin = match_end;
+    svo_hip::Speculation& sp = lane.spec;
+    if (predict) {
+      sp.frame_id = frame->id_;
+      sp.point.clear(); sp.px.clear(); sp.level.clear(); sp.trial.clear();
+      results_begin = a.used();
+      double* T = a.alloc<double>(12, &d_T);
+      poseToRt(frame->T_f_w_, T);
+      std::copy(T, T + 12, sp.T_init);
+      sp.T = T;
+      sp.n_sel = a.alloc<int32_t>(1, &d_nsel);
+      sp.sel = a.alloc<int32_t>(cap, &d_sel);
+      sp.has_point = a.alloc<uint8_t>(cap, &d_has);
+      sp.Cov = a.alloc<double>(36, &d_Cov);
+      sp.stats = a.alloc<double>(4, &d_stats);
+      sp.ran = a.alloc<int32_t>(1, &d_ran);
+      if (a.mode() != svo_hip::Arena::MIRRORED) flag = a.alloc<int32_t>(1, &d_flag);
+      sp.reproj_thresh = Config::poseOptimThresh();
+      sp.n_iter = (int)Config::poseOptimNumIter();
+    }
+
+    const svo_hip_camera cam = cameraOf(frame->cam_);
+    const svo_hip_map dmap = mm.deviceMap();
+    const svo_hip_features dobs = mm.deviceObs();
+    svo_hip_grid g;
+    g.cell_size = grid_.cell_size; g.n_cols = grid_.grid_n_cols; g.n_rows = grid_.grid_n_rows; g.n_cells = (int32_t)n_cells;
+    g.d_cell_rank = mm.cellRank();
+    void* ws = dev.workspace(lane, (int)T_CAP);
+    stage_timer.device(a.used());
+    a.uploadAll(lane.stream);
+    svo_hip::check(svo_hip_reproject_map(&cam, &ft, i_cur, d_rank, &dmap, &patch, &g, (int)first_cell,
+                                         (int)std::min(max_cells, (size_t)1 << 30), (int)V_CAP, (int)T_CAP, &out, lane.stream),
+                   "svo_hip_reproject_map");
+    svo_hip::check(svo_hip_find_match_direct_indirect(&dev.layout(), dev.store(), &cam, &ft, (int)T_CAP, d_M, out.d_trial_cur,
+                                                      out.d_trial_pos, out.d_trial_obs_begin, out.d_trial_obs_end, &dobs,
+                                                      Config::nPyrLevels(), align_max_iter, out.d_trial_px, d_ok, d_ref, d_lvl, d_A,
+                                                      NULL, ws, lane.workspace_bytes, lane.stream),
+                   "svo_hip_find_match_direct_indirect");
+    a.downloadRange(inputs_end, match_end, lane.stream);
+    if (predict && flag != NULL) {
+      // hybrid / mapped arena: the selection kernel stores `flag` when it starts, i.e. when the match kernels are through;
+      // the host polls that, pose refinement follows on the same stream (see the list-walking path below)
+      *flag = 0;
+      svo_hip::check(svo_hip_select_matches_indirect(&cam, (int)T_CAP, d_M, out.d_trial_cell, d_ok, out.d_trial_px, d_lvl,
+                                                     out.d_trial_pos, Config::maxFts(), d_nsel, d_sel, d_sf, d_slvl, d_spos, d_has,
+                                                     d_flag, 1, lane.stream),
+                     "svo_hip_select_matches_indirect");
+      svo_hip::check(svo_hip_pose_optimize_deferred(&cam, 1, d_nsel, (int)cap, d_sf, d_slvl, d_spos, d_has, sp.reproj_thresh,
+                                                    sp.n_iter, d_T, d_Cov, d_stats, d_ran, lane.stream),
+                     "svo_hip_pose_optimize_deferred");
+      sp.stream = lane.stream;
+      sp.in_flight = true;
+      svo_hip::spinUntil(flag, 1, lane.stream);
+    } else if (predict) {
+      void* const next = lane.stream_next;
+      svo_hip::check(svo_hip_event_record(lane.ev_results, lane.stream), "svo_hip_event_record");
+      svo_hip::check(svo_hip_stream_wait_event(next, lane.ev_results), "svo_hip_stream_wait_event");
+      svo_hip::check(svo_hip_select_matches_indirect(&cam, (int)T_CAP, d_M, out.d_trial_cell, d_ok, out.d_trial_px, d_lvl,
+                                                     out.d_trial_pos, Config::maxFts(), d_nsel, d_sel, d_sf, d_slvl, d_spos, d_has,
+                                                     NULL, 0, next),
+                     "svo_hip_select_matches_indirect");
+      svo_hip::check(svo_hip_pose_optimize_deferred(&cam, 1, d_nsel, (int)cap, d_sf, d_slvl, d_spos, d_has, sp.reproj_thresh,
+                                                    sp.n_iter, d_T, d_Cov, d_stats, d_ran, next),
+                     "svo_hip_pose_optimize_deferred");
+      a.downloadRange(results_begin, a.used(), next);
+      sp.stream = next;
+      sp.in_flight = true;
+      svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+    } else {
+      svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
+    }
+    stage_timer.unmarshal();
+    if (header[0] != 0) {  // a capacity was exceeded (or, -1, the kernel never ran): drop what was enqueued behind it
+      if (predict) {
+        sp.in_flight = false;
+        svo_hip::check(svo_hip_stream_sync(sp.stream), "svo_hip_stream_sync");
+        predict = false;
+      }
+      return false;
+    }
+    view.header = header; view.visit_point = h_vp; view.visit_cell = h_vc; view.visit_trial = h_vt;
+    view.ok = h_ok; view.lvl = h_lvl; view.ref = h_ref; view.px = h_px; view.A = h_A;
+    view.V = (size_t)header[2];
+    view.end_cell = (size_t)header[4];
+    point_cell = h_point_cell;
+    kf_count = h_kf_count;
+    return true;
+  };
+
+  // The first batch takes the cells a success rate of 3 in 4 would need (see the list-walking path)
+  static const long first_batch_override = [] { const char* v = std::getenv("SVO_HIP_FIRST_BATCH_CELLS"); return v ? std::atol(v) : 0L; }();
+  const size_t first_batch_cells = first_batch_override > 0 ? (size_t)first_batch_override
+                                                            : (size_t)Config::maxFts() + 1 + ((size_t)Config::maxFts() + 1) / 3 + 8;
+  if (!runBatch(0, first_batch_cells)) { ++mm.stats.fallbacks; return false; }
+
+  // ---- 1. overlap_kfs: (keyframe, points of it that fell inside the frame), closest first (:82-102)
+  overlap_kfs.reserve(options_.max_n_kfs);
+  for (size_t k = 0; k < ranked.size(); ++k)
+    overlap_kfs.push_back(std::pair<FramePtr, size_t>(ranked[k].first, (size_t)kf_count[ranked[k].second]));
+
+  // ---- 2. candidates that do not reproject lose credit (:108-123), in list order
+  {
+    boost::unique_lock<boost::mutex> lock(map_.point_candidates_.mut_);
+    MapPointCandidates::PointCandidateList& cl = map_.point_candidates_.candidates_;
+    const std::vector<int32_t> cands = mm.candidateEntries();  // (a copy: markDead edits the list)
+    for (size_t k = 0; k < cands.size(); ++k) {
+      const int32_t e = cands[k];
+      if (point_cell[e] >= 0) continue;
+      const MapMirror::Entry& x = mm.entries()[(size_t)e];
+      x.pt->n_failed_reproj_ += 3;
+      if (x.pt->n_failed_reproj_ > 30) {
+        map_.point_candidates_.deleteCandidate(*x.cand);
+        cl.erase(x.cand);
+        mm.markDead(e);
+      }
+    }
+  }
+
+  // ---- 4. per cell, in the shuffled order: the best-quality point that matched (:131-139, 151-200)
+  svo_hip::Speculation& sp = lane.spec;
+  std::vector<int32_t> selected;
+  size_t v = 0;
+  for (size_t i = 0; i < n_cells; ++i) {
+    if (i == view.end_cell) {
+      // the cells of the batch are used up and the loop has not stopped: the rest (the prediction, made on the first
+      // batch's trials only, is dropped: beginCall() drains what was enqueued)
+      predict = false;
+      ++mm.stats.second_batches;
+      if (!runBatch(i, n_cells)) throw svo_hip::Error("Reprojector: the second match batch exceeds the mirror's capacity");
+      v = 0;
+    }
+    bool matched = false;
+    for (; v < view.V && (size_t)view.visit_cell[v] == i; ++v) {
+      if (matched) continue;  // reprojectCell returns at the first success: the rest of the cell is not looked at
+      ++n_trials_;
+      const int32_t e = view.visit_point[v];
+      Point* pt = mm.entries()[(size_t)e].pt;
+      const int m = view.visit_trial[v];
+      if (!(m >= 0 && view.ok[m] != 0)) {
+        pt->n_failed_reproj_++;
+        if (pt->type_ == Point::TYPE_UNKNOWN && pt->n_failed_reproj_ > 15) { map_.safeDeletePoint(pt); mm.markDead(e); }
+        if (pt->type_ == Point::TYPE_CANDIDATE && pt->n_failed_reproj_ > 30) { map_.point_candidates_.deleteCandidatePoint(pt); mm.markDead(e); }
+        continue;
+      }
+      pt->n_succeeded_reproj_++;
+      if (pt->type_ == Point::TYPE_UNKNOWN && pt->n_succeeded_reproj_ > 10) { pt->type_ = Point::TYPE_GOOD; mm.markType(e, 3); }
+      const Vector2d px(view.px[2 * m], view.px[2 * m + 1]);
+      Feature* new_feature = new Feature(frame.get(), px, view.lvl[m]);
+      frame->addFeature(new_feature);
+      new_feature->point = pt;
+      const Feature* ref_ftr = view.ref[m] >= 0 ? mm.obsFeature(view.ref[m]) : NULL;
+      if (ref_ftr != NULL && ref_ftr->type == Feature::EDGELET) {
+        new_feature->type = Feature::EDGELET;
+        Matrix2d A_cur_ref;
+        A_cur_ref(0, 0) = view.A[4 * m]; A_cur_ref(0, 1) = view.A[4 * m + 1];
+        A_cur_ref(1, 0) = view.A[4 * m + 2]; A_cur_ref(1, 1) = view.A[4 * m + 3];
+        new_feature->grad = A_cur_ref * ref_ftr->grad;
+        new_feature->grad.normalize();
+      }
+      if (predict) {
+        sp.point.push_back(pt);
+        sp.px.push_back(px[0]); sp.px.push_back(px[1]);
+        sp.level.push_back(view.lvl[m]);
+        sp.trial.push_back(m);
+      }
+      selected.push_back(e);
+      matched = true;
+    }
+    if (matched) ++n_matches_;
+    if (n_matches_ > (size_t)Config::maxFts()) break;
+  }
+  if (predict) sp.valid = !sp.point.empty();
+  mm.watch(selected);  // FrameHandlerBase::optimizeStructure may move these before the next frame
+  return true;
+}
 }  // namespace
+
+namespace hip_dropin {
+// calls, rebuilds, fallbacks to the list-walking path, point records sent, observation records sent, second batches --
+// summed over the mirrors of the process (read-outs of the tests and the benchmark; not synchronised with running calls)
+void mapMirrorStats(uint64_t out[6]) {
+  for (int i = 0; i < 6; ++i) out[i] = 0;
+  MirrorRegistry& r = mirrors();
+  std::lock_guard<std::mutex> g(r.mut);
+  for (std::map<const Map*, MapMirror*>::const_iterator it = r.all.begin(); it != r.all.end(); ++it) {
+    const MapMirror::Stats& s = it->second->stats;
+    out[0] += s.calls; out[1] += s.rebuilds; out[2] += s.fallbacks; out[3] += s.patched_points; out[4] += s.patched_obs;
+    out[5] += s.second_batches;
+  }
+}
+}  // namespace hip_dropin
 
 void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, std::size_t> >& overlap_kfs) {
   // deferred mapping: the depth filter's update of the previous frame hands its converged seeds to the map before
   // the map is read (no-op otherwise)
   svo_hip::Device::joinDeferredAll();
   resetGrid();
+  // the device-resident mirror of the map (row N2): SVO_HIP_MAP_MIRROR=on (default) | verify | off
+  if (options_.find_match_direct && hip_dropin::MapMirror::mode() != hip_dropin::MapMirror::OFF) {
+    SVO_START_TIMER("feature_align");
+    const bool done = reprojectMapMirrored(frame, overlap_kfs, map_, grid_, options_, matcher_.options_.align_max_iter, n_matches_, n_trials_);
+    SVO_STOP_TIMER("feature_align");
+    if (done) return;
+  }
 
   // ---- 1. keyframes sharing the field of view, closest first; bin their points --------------
   SVO_START_TIMER("reproject_kfs");

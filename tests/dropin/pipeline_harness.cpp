@@ -34,6 +34,8 @@
 #include <vikit/vision.h>
 #ifdef SVO_PIPELINE_HIP
 #include "svo_hip_device.h"
+// rpg_svo_amd/host/dropin/reprojector.cpp; absent from the stand-alone-seams flavour (hipm), which links the reference's reprojector
+namespace svo { namespace hip_dropin { void mapMirrorStats(uint64_t out[6]) __attribute__((weak)); } }
 #endif
 
 
@@ -242,6 +244,15 @@ void pipe_device_stats(uint64_t out[5]) {
   const svo_hip::Device::Stats st = svo_hip::Device::instance().statsSnapshot();
   out[0] = st.uploads; out[1] = st.evictions; out[2] = st.calls;
   out[3] = st.spec_hits; out[4] = st.spec_misses;  // pose refinements taken from / not taken from the reprojector's prediction
+#endif
+}
+
+// the map mirror of the reprojector's drop-in (row N2): calls, rebuilds, fallbacks to the list-walking path, point records
+// sent, observation records sent, second batches (hip flavour; zeros otherwise)
+void pipe_mirror_stats(uint64_t out[6]) {
+  for (int i = 0; i < 6; ++i) out[i] = 0;
+#ifdef SVO_PIPELINE_HIP
+  if (svo::hip_dropin::mapMirrorStats) svo::hip_dropin::mapMirrorStats(out);
 #endif
 }
 

@@ -109,6 +109,13 @@ class Pipeline:
         self.lib.pipe_device_stats(out)
         return tuple(int(x) for x in out)
 
+    def mirror_stats(self):
+        """(calls, rebuilds, fallbacks, point records sent, observation records sent, second batches) of the
+        reprojector's map mirror, process-wide."""
+        out = (C.c_uint64 * 6)()
+        self.lib.pipe_mirror_stats(out)
+        return tuple(int(x) for x in out)
+
     STAGES = ("sparse_align", "reproject", "pose_opt", "depth_filter")
 
     def stage_times(self):
@@ -144,6 +151,7 @@ def run_sequence(flavour, cam, images, T_gt, stats_out=None, range0=None, **cfg)
     p = Pipeline(flavour, cam, **cfg)
     try:
         s0 = p.device_stats()
+        m0 = p.mirror_stats()
         n0, r0 = p.set_first_frame(images[0], 0.0, T_gt[0], range_map(cam, T_gt[0]) if range0 is None else range0)
         r0["n_first_features"] = n0
         out = [r0]
@@ -159,6 +167,9 @@ def run_sequence(flavour, cam, images, T_gt, stats_out=None, range0=None, **cfg)
             s1 = p.device_stats()
             stats_out.update(uploads=s1[0] - s0[0], evictions=s1[1] - s0[1], calls=s1[2] - s0[2],
                              predicted_pose_hits=s1[3] - s0[3], predicted_pose_misses=s1[4] - s0[4])
+            m1 = p.mirror_stats()
+            stats_out["map_mirror"] = dict(zip(("calls", "rebuilds", "fallbacks", "point_records_sent", "obs_records_sent",
+                                                "second_batches"), (b - a for a, b in zip(m0, m1))))
             dt = p.stage_times() - t0
             stages = {}
             for k, name in enumerate(Pipeline.STAGES):

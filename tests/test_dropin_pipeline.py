@@ -273,6 +273,64 @@ def test_mock_device_standalone_seams(mock_lib):
                                 "img_align_n_tracked", "n_seeds", "n_candidates"))
 
 
+MIRROR_CODE = (
+    "import sys, json, numpy as np\n"
+    "sys.path.insert(0, {here!r}); sys.path.insert(0, {dropin!r})\n"
+    "import pypipeline as pp\n"
+    "import test_dropin_pipeline as t\n"
+    "cam, imgs, T = t._sequence({n})\n"
+    "st = {{}}\n"
+    "r = pp.run_sequence({flavour!r}, cam, imgs, T, stats_out=st, **{cfg!r})\n"
+    "np.save(sys.argv[1], np.stack([x['T_f_w'] for x in r]))\n"
+    "print(json.dumps(dict(st['map_mirror'], hits=st['predicted_pose_hits'], kfs=int(sum(x['is_keyframe'] for x in r)),\n"
+    "                      counts=[[x['repr_n_mps'], x['repr_n_new_references'], x['n_kf_points_in_frame'], x['n_candidates']] for x in r])))\n")
+
+
+def _run_mirror(flavour, n, env, tmp_path, tag, **cfg):
+    import json
+    import subprocess
+    path = str(tmp_path / f"traj_{tag}.npy")
+    code = MIRROR_CODE.format(here=HERE, dropin=os.path.join(HERE, "dropin"), n=n, flavour=flavour, cfg=cfg)
+    p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return np.load(path), json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def test_mock_device_map_mirror_is_the_list_walk(mock_lib, tmp_path):
+    """Row N2, host side (rpg_svo_amd/host/dropin/map_mirror.h): Reprojector::reprojectMap on the device-resident mirror of
+    the map against the list-walking path (SVO_HIP_MAP_MIRROR=off) on a sequence with keyframe insertions AND removals
+    (max_n_kfs = 4): bit-identical trajectories, the same trials / matches / projected keyframe points / candidates in
+    every frame.  `verify` re-walks the reference's pointer graph on every call and throws on the first record the
+    incremental protocol missed (positions moved by Point::optimize, types changed and points deleted by the cell loop,
+    candidates appended by the depth filter's callback, candidates deleted for failing to reproject).  The mode is
+    read once per process."""
+    n = 220
+    off, s_off = _run_mirror("hipmock", n, {"SVO_HIP_MAP_MIRROR": "off"}, tmp_path, "off", max_n_kfs=4)
+    ver, s_ver = _run_mirror("hipmock", n, {"SVO_HIP_MAP_MIRROR": "verify"}, tmp_path, "verify", max_n_kfs=4)
+    assert np.array_equal(ver, off)
+    assert s_ver["counts"] == s_off["counts"]
+    assert s_off["calls"] == 0
+    assert s_ver["calls"] == n - 1 and s_ver["fallbacks"] == 0 and s_ver["hits"] == n - 1
+    assert s_ver["kfs"] >= 6                                       # more keyframes than the map holds: removals happened
+    assert s_ver["kfs"] - 1 <= s_ver["rebuilds"] <= s_ver["kfs"] + 1   # one walk of the graph per keyframe, none in between
+    # between keyframes a frame sends a handful of records, not the map
+    per_frame = (s_ver["point_records_sent"] - s_ver["rebuilds"] * 600) / n
+    assert per_frame < 60, s_ver
+    # the second batch (the first one too small to reach the visiting loop's stop) continues on the mirror
+    sb, s_sb = _run_mirror("hipmock", 60, {"SVO_HIP_MAP_MIRROR": "verify", "SVO_HIP_FIRST_BATCH_CELLS": "40"}, tmp_path, "sb")
+    ref60, _ = _run_mirror("hipmock", 60, {"SVO_HIP_MAP_MIRROR": "off"}, tmp_path, "off60")
+    assert np.array_equal(sb, ref60) and s_sb["second_batches"] >= 50 and s_sb["fallbacks"] == 0
+    # the depth filter on its own thread appends candidates while the tracker runs (timing dependent: no frame-by-frame
+    # comparison, but verify must hold -- it tolerates only candidates that arrived after the call's tail read)
+    _, s_thr = _run_mirror("hipmock", 100, {"SVO_HIP_MAP_MIRROR": "verify"}, tmp_path, "thr", mapper_thread=1)
+    assert s_thr["calls"] == 99 and s_thr["fallbacks"] == 0
+    # a pool that cannot hold every keyframe at once: the frame takes the list-walking path (which pins only the
+    # keyframes that serve as reference), same result
+    small, s_small = _run_mirror("hipmock", 130, {"SVO_HIP_MAP_MIRROR": "on"}, tmp_path, "small", pool_slots=7)
+    ref130, _ = _run_mirror("hipmock", 130, {"SVO_HIP_MAP_MIRROR": "off"}, tmp_path, "off130", pool_slots=7)
+    assert np.array_equal(small, ref130) and 0 < s_small["fallbacks"] < 129   # (mirrored while the keyframes still fit)
+
+
 @pytest.mark.gpu
 def test_dropin_trajectory_matches_cpu_reference(pipeline_libs, gpu_device):
     cam, imgs, T = _sequence(120)
@@ -531,3 +589,16 @@ def test_dropin_arena_modes_agree(pipeline_libs, gpu_device, tmp_path):
     for mode in ("mirrored", "mapped"):
         d = se3.log_norm(out[mode], out["hybrid"])
         assert d.max() <= SE3_LOGNORM_TOL, (mode, d.max())
+
+
+@pytest.mark.gpu
+def test_dropin_map_mirror_is_the_list_walk_on_the_gpu(pipeline_libs, gpu_device, tmp_path):
+    """The same on the real device: svo_hip_reproject_map + the indirect match batch against the list-walking path that
+    marshals every trial on the host -- same kernels on the same trials, so the trajectories are equal bit for bit; verify
+    mode holds over keyframe insertions and removals."""
+    n = 160
+    off, s_off = _run_mirror("hip", n, {"SVO_HIP_MAP_MIRROR": "off"}, tmp_path, "off", max_n_kfs=4)
+    ver, s_ver = _run_mirror("hip", n, {"SVO_HIP_MAP_MIRROR": "verify"}, tmp_path, "verify", max_n_kfs=4)
+    assert np.array_equal(ver, off)
+    assert s_ver["counts"] == s_off["counts"]
+    assert s_ver["calls"] == n - 1 and s_ver["fallbacks"] == 0 and s_ver["hits"] == n - 1 and s_ver["kfs"] >= 5
