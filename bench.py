@@ -58,7 +58,7 @@ WORKLOADS = {
     "svo_default_752_l4to2_n120": (752, 480, 315.5, 5, 4, 2, 120, 56, 40),
     "xga5_n1000_sparse_align": (1280, 960, 800.0, 5, 4, 0, 1000, 56, 32),
 }
-EXTRA_KEYS = {"f64": "f64_partials", "refine": "align_plus_refine", "full": "full_track", "full_easy": "full_track_easy", "stream": "stream_replay", "noise": "noise_sigma2", "config3": "config3_xga5_b64",
+EXTRA_KEYS = {"f64": "f64_partials", "refine": "align_plus_refine", "full": "full_track", "full_easy": "full_track_easy", "long_scan": "full_track_long_scan", "stream": "stream_replay", "noise": "noise_sigma2", "config3": "config3_xga5_b64",
               "k0": "k0_pyramid", "dropin": "dropin_sequence"}
 
 
@@ -415,7 +415,7 @@ def main() -> None:
     lib = capi.load()
     ev = Events(lib, dev)
     if args.extras == "all":
-        extras = {"f64", "refine", "full", "full_easy", "noise", "config3", "stream", "rig", "k0", "dropin", "pmc"}
+        extras = {"f64", "refine", "full", "full_easy", "long_scan", "noise", "config3", "stream", "rig", "k0", "dropin", "pmc"}
     elif args.extras == "none":
         extras = set()
     else:
@@ -640,6 +640,7 @@ def _extras_and_print(args, result, extras, full, ev, W, sia, out, st, store, li
     leg("refine", lambda: align_plus_refine(W, sia, ev, dev, args.steps))
     leg("full", lambda: full_track_leg(W, sia, ev, dev, rank, lib, not args.no_cpu_baseline))
     leg("full_easy", lambda: full_track_leg(W, sia, ev, dev, rank, lib, False, steps=3, mode="easy"))
+    leg("long_scan", lambda: long_scan_leg(W, ev, dev, lib))
     leg("k0", lambda: pyramid_roofline(ev, store, W.images))
     if args.noise == 0:
         leg("noise", lambda: noise_leg(W, sia, ev, dev, rank, args.steps))
@@ -1731,6 +1732,71 @@ class FullTrack:
                                      scanned_positions_per_seed_by_kind=scan_by_kind, scanned_positions_per_seed_by_age=scan_by_age,
                                      seeds_per_frame_by_scanned_positions=scan_hist),
         }
+
+
+def long_scan_leg(W: Workload, ev: Events, dev, lib, ages=(60, 120, 240, 480), seeds_per_frame: int = 24, reps: int = 5) -> dict:
+    """The long-scan regime of the epipolar search.  The reference scans up to
+    max_epi_search_steps = 1000 positions per seed (svo/src/matcher.cpp:248-291); the representative workload tops out at
+    ~130.  Here every seed is a NEW one (a = b = 10, mu = 1 / mean scene depth, sigma = z_range / 6: the Seed constructor,
+    depth_filter.cpp:37-46) of a keyframe `age` frames back, searched in the current frame of each problem: the baseline
+    grows with the age, and with it the segment the interval mu +- sigma projects to -- hundreds of positions.  Reports
+    the scanned positions per seed and the time of the whole update per scanned position (the update is the scan here)."""
+    from rpg_svo_amd import tracking
+    B = W.B
+    T = torch.as_tensor(W.T_gt, dtype=torch.float64, device=dev)
+    frames = tracking.FrameTable(torch.arange(0, B + 1, dtype=torch.int32, device=dev), T.contiguous())
+    df = tracking.DepthFilter(n_pyr_levels=W.n_levels)
+    g = torch.Generator().manual_seed(991)
+    sel = torch.randperm(W.n_patches, generator=g)[:seeds_per_frame].sort().values.to(dev)
+    c = -(T[:B, :9].reshape(B, 3, 3).transpose(1, 2) @ T[:B, 9:, None])[..., 0]
+    depth_all = (W.pos_all - c[:, None, :]).norm(dim=-1)
+    depth_mean, depth_min = depth_all.mean(1), 0.5 * depth_all.min(1).values
+    out = {"seeds_per_frame_and_age": seeds_per_frame, "by_age": {}}
+    tot_pos = tot_ms = 0.0
+    for age in ages:
+        r = torch.arange(0, B - age, device=dev)            # keyframe r, searched in frame r + age
+        n = len(r) * seeds_per_frame
+        if n == 0:
+            continue
+        ftr = tracking.FeatureSet(frame=r.repeat_interleave(seeds_per_frame).to(torch.int32).contiguous(),
+                                  level=torch.zeros(n, dtype=torch.int32, device=dev),
+                                  px=W.px_all[r][:, sel].reshape(n, 2).contiguous(), f=W.f_all[r][:, sel].reshape(n, 3).contiguous())
+        cur = (r + age).repeat_interleave(seeds_per_frame).to(torch.int32).contiguous()
+        zr = (1.0 / depth_min[r]).repeat_interleave(seeds_per_frame).float().contiguous()
+        init = dict(a=torch.full((n,), 10.0, device=dev), b=torch.full((n,), 10.0, device=dev),
+                    mu=(1.0 / depth_mean[r]).repeat_interleave(seeds_per_frame).float().contiguous(), z_range=zr,
+                    sigma2=(zr * zr / 36.0).contiguous())
+        seeds = tracking.SeedSet(**{k: v.clone() for k, v in init.items()}, batch_id=torch.zeros(n, dtype=torch.int32, device=dev))
+        res = (torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, 3, dtype=torch.float64, device=dev),
+               torch.zeros(n, 2, dtype=torch.float64, device=dev))
+
+        def run():
+            for k, v in init.items():
+                getattr(seeds, k).copy_(v)
+            df.update_seeds(W.store, W.cam, frames, cur, ftr, seeds, 0, out=res)
+
+        ms = ev.time(run, reps, warmup=1)
+        steps_ptr = lib.svo_hip_update_seeds_scan_steps(df.last_workspace.data_ptr())
+        scan = torch.empty(n, dtype=torch.int32, device=dev)
+        capi.check(lib.svo_hip_memcpy_d2d(scan.data_ptr(), steps_ptr, n * 4, torch.cuda.current_stream(dev).cuda_stream), "svo_hip_memcpy_d2d")
+        torch.cuda.synchronize()
+        st = res[0]
+        n_pos = float(scan.sum().item())
+        out["by_age"][str(age)] = {
+            "seeds": n, "ms": ms, "scanned_positions_per_seed": n_pos / n, "scanned_positions_max": int(scan.max().item()),
+            "seeds_scanning_128_or_more_frac": float((scan >= 128).float().mean().item()),
+            "skipped_not_visible_frac": float(((st == capi.SEED_NOT_IN_FRAME) | (st == capi.SEED_BEHIND)).float().mean().item()),
+            "matched_frac": float(((st == capi.SEED_UPDATED) | (st == capi.SEED_CONVERGED)).float().mean().item()),
+            "update_seeds_ns_per_scanned_position": ms * 1e6 / max(n_pos, 1.0),
+            # what the scan has to read at least: the union of the 8 x 8 windows along the segment (64 + 8 * 0.7 * n *
+            # (|cos| + |sin|) bytes, 4 / pi on average over directions) -- not 64 bytes per position
+            "scan_compulsory_GBs": (64.0 * n + 7.13 * n_pos) / (ms * 1e-3) / 1e9}
+        tot_pos += n_pos
+        tot_ms += ms
+    out["scanned_positions_per_seed"] = tot_pos / max(1, sum(v["seeds"] for v in out["by_age"].values()))
+    out["ms_per_step"] = tot_ms
+    out["epi_scan_ns_per_position"] = tot_ms * 1e6 / max(tot_pos, 1.0)
+    return out
 
 
 def full_track_leg(W: Workload, sia, ev: Events, dev, rank, lib, with_parity: bool, steps: int = 5, mode: str = "representative") -> dict:

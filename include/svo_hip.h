@@ -382,7 +382,7 @@ int svo_hip_select_matches(const svo_hip_camera* cam, int M, const int32_t* d_ce
  * findMatchDirect trials in visiting order, and the match kernels follow on the stream without the host in between.
  * All arrays are device memory owned by the caller. */
 typedef struct svo_hip_map {
-  int32_t n_points;      /* entries [0, n_points): the points of the map's keyframes and the depth filter's candidates */
+  int32_t n_points;      /* entries [0, n_points), <= 16384: the points of the map's keyframes and the depth filter's candidates */
   int32_t n_obs;         /* observation records [0, n_obs) */
   double* d_pos;         /* [P][3] Point::pos_ */
   int32_t* d_type;       /* [P] Point::type_ (point.h:38-43): 0 deleted = the entry is dead, 1 candidate, 2 unknown, 3 good */
@@ -391,8 +391,9 @@ typedef struct svo_hip_map {
   int32_t* d_obs_begin;  /* [P] Point::obs_ in list order = records [d_obs_begin[p], d_obs_begin[p] + d_obs_count[p]) */
   int32_t* d_obs_count;  /* [P] */
   int32_t* d_obs_frame;  /* [O] Feature::frame as an index into the frame table of the call */
-  int32_t* d_obs_order;  /* [O] position of the Feature in its frame's fts_ list (< 4096); -1: not in a keyframe's list
-                                (the Feature of a candidate, map.cpp:215-218) */
+  int32_t* d_obs_order;  /* [O] written by the patch step as Feature::frame << 16 | position of the Feature in its frame's
+                                fts_ list (< 4096; 0xffff: in no keyframe's list -- the Feature of a candidate,
+                                map.cpp:215-218); the patch itself carries the position, -1 for "in no list" */
   int32_t* d_obs_level;  /* [O] Feature::level */
   uint8_t* d_obs_type;   /* [O] SVO_HIP_FTR_* */
   double* d_obs_px;      /* [O][2] Feature::px */

@@ -507,13 +507,14 @@ int ref_update_seeds(const orc_frame* frames, const orc_pinhole* cam, int cur_fr
   Config::nPyrLevels() = mopt->n_pyr_levels;
 
   std::map<Feature*, int> ftr2seed;
-  struct Conv { double xyz[3]; };
+  struct Conv { double xyz[3]; double sigma2; };
   std::map<int, Conv> converged;
   std::vector<Point*> new_points;
-  DepthFilter::callback_t cb = [&](Point* p, double) {
+  DepthFilter::callback_t cb = [&](Point* p, double sigma2_after) {
     Feature* ftr = p->obs_.front();
     Conv cv_;
     cv_.xyz[0] = p->pos_[0]; cv_.xyz[1] = p->pos_[1]; cv_.xyz[2] = p->pos_[2];
+    cv_.sigma2 = sigma2_after;  // seed_converged_cb_(point, it->sigma2), depth_filter.cpp:278: the seed's variance AFTER the update
     converged[ftr2seed[ftr]] = cv_;
     new_points.push_back(p);
   };
@@ -551,6 +552,15 @@ int ref_update_seeds(const orc_frame* frames, const orc_pinhole* cam, int cur_fr
     if (converged.count(i)) {
       info[i].status = ORC_SEED_CONVERGED;
       for (int k = 0; k < 3; ++k) info[i].xyz_world[k] = converged[i].xyz[k];
+      // The seed is erased from the list (depth_filter.cpp:280), but its state after the update is not lost: sigma2 is
+      // what the callback was handed, and the new point sits at T_f_w^-1 * (f / mu) (:264), i.e. 1 / mu = its distance
+      // from the seed's frame (f is a unit vector; the double round trip is 1e-15 relative, far inside a float's 6e-8:
+      // rounding returns mu's own bits).  a and b leave no trace: they stay at their values before the update.
+      {
+        const Vector3d p_f = get(before[i].ftr.frame)->T_f_w_ * Vector3d(converged[i].xyz[0], converged[i].xyz[1], converged[i].xyz[2]);
+        seeds[i].mu = (float)(1.0 / p_f.norm());
+        seeds[i].sigma2 = (float)converged[i].sigma2;
+      }
       ++n_updates;
     } else if (!alive[i]) {
       // erased without a callback: too old, or NaN after an update (cannot be told apart from

@@ -69,6 +69,42 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* s_wave /*[RM_BLO
   return r;
 }
 
+// Where the keyframe loop meets a map point first: the smallest (keyframe rank, position in that keyframe's fts_) over
+// the point's observations in overlapping keyframes.  An observation record's d_obs_order word is Feature::frame << 16
+// | position (0xffff: in no keyframe's list), written by the patch step.  The records of a point are contiguous: up to
+// eight are fetched by independent loads before any is looked at (one memory round trip, not one per record).
+__device__ __forceinline__ uint32_t first_meeting(const int32_t* __restrict__ obs_word, int o0, int n, const int* s_kfrank,
+                                                  int* first_frame) {
+  uint32_t w[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = k < n ? (uint32_t)obs_word[o0 + k] : 0xffffffffu;
+  uint32_t best = 0xffffffffu;
+  int ff = -1;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint32_t fr = w[k] >> 16, ord = w[k] & 0xffffu;
+    if (k < n && ord != 0xffffu) {
+      const int r = s_kfrank[fr & (RM_MAX_FRAMES - 1)];
+      const uint32_t key = (uint32_t)r << 12 | (ord & 0xfffu);
+      if (r >= 0 && key < best) { best = key; ff = (int)fr; }
+    }
+  }
+  for (int k = 8; k < n; ++k) {  // (a point seen from more than eight keyframes)
+    const uint32_t x = (uint32_t)obs_word[o0 + k];
+    const uint32_t fr = x >> 16, ord = x & 0xffffu;
+    if (ord != 0xffffu) {
+      const int r = s_kfrank[fr & (RM_MAX_FRAMES - 1)];
+      const uint32_t key = (uint32_t)r << 12 | (ord & 0xfffu);
+      if (r >= 0 && key < best) { best = key; ff = (int)fr; }
+    }
+  }
+  *first_frame = ff;
+  return best;
+}
+
+// PPT: map entries per thread (n_points <= PPT * RM_BLOCK): what a thread learns about its entries in the projection
+// phase -- cell, sort key -- stays in registers for the scatter phase.
+template <int PPT>
 __global__ void __launch_bounds__(RM_BLOCK) reproject_map_kernel(const ReprojMapArgs a) {
   __shared__ int s_cnt[RM_MAX_CELLS];    // per visiting rank: points binned; later: 1 where the cell holds a trial
   __shared__ int s_base[RM_MAX_CELLS + 1];  // exclusive scan of s_cnt
@@ -77,9 +113,9 @@ __global__ void __launch_bounds__(RM_BLOCK) reproject_map_kernel(const ReprojMap
   __shared__ uint16_t s_sidx[RM_MAX_E];  // sorted:   map entry
   __shared__ uint16_t s_srank[RM_MAX_E]; //           visiting rank of its cell
   __shared__ double s_fpos[RM_MAX_FRAMES][3];  // Frame::pos() of the frame table
-  __shared__ int s_kfcount[RM_MAX_FRAMES];
+  __shared__ int s_kfcount[RM_MAX_FRAMES], s_kfrank[RM_MAX_FRAMES];
   __shared__ int s_wave[RM_BLOCK / 64 + 1];
-  __shared__ int s_E, s_end_cell, s_overflow;
+  __shared__ int s_E, s_end_cell;
   const int tid = threadIdx.x;
   const svo_hip_map& mp = a.map;
   const int P = mp.n_points, n_cells = a.grid.n_cells;
@@ -87,8 +123,9 @@ __global__ void __launch_bounds__(RM_BLOCK) reproject_map_kernel(const ReprojMap
   // ---- 0. the host's changes since the last call -------------------------------------------------------------------
   for (int i = tid; i < a.patch.n_obs; i += RM_BLOCK) {
     const int o = a.patch.d_obs_index[i];
-    mp.d_obs_frame[o] = a.patch.obs.d_frame[i];
-    mp.d_obs_order[o] = a.patch.d_obs_order[i];
+    const int fr = a.patch.obs.d_frame[i], ord = a.patch.d_obs_order[i];
+    mp.d_obs_frame[o] = fr;
+    mp.d_obs_order[o] = (int32_t)((uint32_t)fr << 16 | (ord < 0 ? 0xffffu : (uint32_t)ord & 0xffffu));
     mp.d_obs_level[o] = a.patch.obs.d_level[i];
     mp.d_obs_type[o] = a.patch.obs.d_type[i];
     mp.d_obs_px[2 * o] = a.patch.obs.d_px[2 * i];
@@ -108,62 +145,78 @@ __global__ void __launch_bounds__(RM_BLOCK) reproject_map_kernel(const ReprojMap
     mp.d_obs_count[p] = a.patch.d_obs_count[i];
   }
   for (int k = tid; k < n_cells; k += RM_BLOCK) s_cnt[k] = 0;
+  if (tid < RM_MAX_FRAMES) {
+    s_kfrank[tid] = tid < a.n_frames ? a.kf_rank[tid] : -1;
+    s_kfcount[tid] = 0;
+  }
   if (tid < a.n_frames) {
     Se3 T;
     se3_from_Rt(a.frame_T + 12 * tid, T);
     double fp[3];
     frame_pos(T, fp);
     s_fpos[tid][0] = fp[0]; s_fpos[tid][1] = fp[1]; s_fpos[tid][2] = fp[2];
-    s_kfcount[tid] = 0;
   }
-  if (tid == 0) { s_E = 0; s_end_cell = n_cells; s_overflow = 0; }
+  if (tid == 0) { s_E = 0; s_end_cell = n_cells; }
   __syncthreads();  // (also orders the patch stores before the reads below: one workgroup, workgroup-scope fence)
 
   // ---- 1. reprojectPoint for every live point, once (:85-123, :206-217) -------------------------------------------
   Se3 Tc;
   se3_from_Rt(a.frame_T + 12 * a.cur_frame, Tc);
-  for (int p0 = 0; p0 < P; p0 += RM_BLOCK) {
-    const int p = p0 + tid;
-    int cell = -2;
-    if (p < P) {
-      const int type = mp.d_type[p];
-      bool projected = false;
-      int first_frame = -1;
-      if (type == 1) {  // a candidate: after every keyframe point, in list order
-        projected = true;
-      } else if (type >= 2) {
-        // where the keyframe loop meets the point first: smallest (keyframe rank, position in that keyframe's fts_)
-        const int o0 = mp.d_obs_begin[p], n = mp.d_obs_count[p];
-        uint32_t best = 0xffffffffu;
-        for (int o = o0; o < o0 + n; ++o) {
-          const int fr = mp.d_obs_frame[o], ord = mp.d_obs_order[o];
-          const int r = a.kf_rank[fr];
-          if (r >= 0 && ord >= 0) {
-            const uint32_t k = (uint32_t)r << 12 | (uint32_t)(ord & 0xfff);
-            if (k < best) { best = k; first_frame = fr; }
+  int my_rank[PPT];        // visiting rank of the point's cell, -1: not binned
+  uint32_t my_key[PPT];
+  {
+    // every record of the thread's entries first (independent loads), then the dependent round: the observation words
+    int type[PPT], o0[PPT], on[PPT];
+    double pos[PPT][3];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int p = tid + RM_BLOCK * j;
+      const bool in = p < P;
+      type[j] = in ? mp.d_type[p] : 0;
+      o0[j] = in ? mp.d_obs_begin[p] : 0;
+      on[j] = in ? mp.d_obs_count[p] : 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pos[j][k] = in ? mp.d_pos[3 * p + k] : 0.0;
+      my_key[j] = in && type[j] == 1 ? (uint32_t)(mp.d_order[p] & 0xffff) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int p = tid + RM_BLOCK * j;
+      my_rank[j] = -1;
+      if (p < P) {
+        bool projected = false;
+        int first_frame = -1;
+        uint32_t key = 0;
+        if (type[j] == 1) {  // a candidate: after every keyframe point, in list order
+          projected = true;
+          key = (3u - 1u) << 28 | my_key[j];
+        } else if (type[j] >= 2) {
+          const uint32_t best = first_meeting(mp.d_obs_order, o0[j], on[j], s_kfrank, &first_frame);
+          projected = best != 0xffffffffu;
+          key = (uint32_t)(3 - type[j]) << 28 | best;
+        }
+        my_key[j] = key;
+        int cell = -2;
+        if (projected) {
+          double q[3], px[2];
+          se3_apply(Tc, pos[j], q);
+          world2cam(a.cam, q, px);
+          a.out.d_point_px[2 * p] = px[0];
+          a.out.d_point_px[2 * p + 1] = px[1];
+          cell = -1;
+          if (is_in_frame(a.cam, cast_int(px[0]), cast_int(px[1]), 8)) {
+            const int k = cast_int(px[1] / a.grid.cell_size) * a.grid.n_cols + cast_int(px[0] / a.grid.cell_size);
+            if (k >= 0 && k < n_cells) {  // (always, for a grid that covers the image)
+              cell = k;
+              my_rank[j] = a.grid.d_cell_rank[k];
+              atomicAdd(&s_cnt[my_rank[j]], 1);
+              atomicAdd(&s_E, 1);
+              if (first_frame >= 0) atomicAdd(&s_kfcount[first_frame], 1);
+            }
           }
         }
-        projected = best != 0xffffffffu;
+        a.out.d_point_cell[p] = cell;
       }
-      if (projected) {
-        const double pos[3] = {mp.d_pos[3 * p], mp.d_pos[3 * p + 1], mp.d_pos[3 * p + 2]};
-        double q[3], px[2];
-        se3_apply(Tc, pos, q);
-        world2cam(a.cam, q, px);
-        a.out.d_point_px[2 * p] = px[0];
-        a.out.d_point_px[2 * p + 1] = px[1];
-        cell = -1;
-        if (is_in_frame(a.cam, cast_int(px[0]), cast_int(px[1]), 8)) {
-          const int k = cast_int(px[1] / a.grid.cell_size) * a.grid.n_cols + cast_int(px[0] / a.grid.cell_size);
-          if (k >= 0 && k < n_cells) {  // (always, for a grid that covers the image)
-            cell = k;
-            atomicAdd(&s_cnt[a.grid.d_cell_rank[k]], 1);
-            atomicAdd(&s_E, 1);
-            if (first_frame >= 0) atomicAdd(&s_kfcount[first_frame], 1);
-          }
-        }
-      }
-      a.out.d_point_cell[p] = cell;
     }
   }
   __syncthreads();
@@ -193,7 +246,7 @@ __global__ void __launch_bounds__(RM_BLOCK) reproject_map_kernel(const ReprojMap
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
       const int r = tid * CPT + k;
-      if (r < n_cells) s_base[r] = run;
+      if (r < n_cells) { s_base[r] = run; s_cnt[r] = 0; }
       run += c[k];
     }
     if (tid == 0) s_base[n_cells] = total;
@@ -201,37 +254,13 @@ __global__ void __launch_bounds__(RM_BLOCK) reproject_map_kernel(const ReprojMap
   __syncthreads();
 
   // ---- 3. scatter into the cell buckets (any order inside a bucket) -------------------------------------------------
-  // (the key of a binned point is derived here, from the same records: the loop above keeps nothing per point)
-  for (int k = tid; k < n_cells; k += RM_BLOCK) s_cnt[k] = 0;
-  __syncthreads();
-  for (int p0 = 0; p0 < P; p0 += RM_BLOCK) {
-    const int p = p0 + tid;
-    if (p < P) {
-      const int cell = a.out.d_point_cell[p];
-      if (cell >= 0) {
-        const int type = mp.d_type[p];
-        uint32_t key;
-        if (type == 1) {
-          key = (3u - 1u) << 28 | (uint32_t)(mp.d_order[p] & 0xffff);
-        } else {
-          const int o0 = mp.d_obs_begin[p], n = mp.d_obs_count[p];
-          uint32_t best = 0xffffffffu;
-          for (int o = o0; o < o0 + n; ++o) {
-            const int r = a.kf_rank[mp.d_obs_frame[o]], ord = mp.d_obs_order[o];
-            if (r >= 0 && ord >= 0) {
-              const uint32_t k = (uint32_t)r << 12 | (uint32_t)(ord & 0xfff);
-              best = k < best ? k : best;
-            }
-          }
-          key = (uint32_t)(3 - type) << 28 | best;
-        }
-        const int rank = a.grid.d_cell_rank[cell];
-        const int at = s_base[rank] + atomicAdd(&s_cnt[rank], 1);
-        s_bkey[at] = key;
-        s_bidx[at] = (uint16_t)p;
-      }
+#pragma unroll
+  for (int j = 0; j < PPT; ++j)
+    if (my_rank[j] >= 0) {
+      const int at = s_base[my_rank[j]] + atomicAdd(&s_cnt[my_rank[j]], 1);
+      s_bkey[at] = my_key[j];
+      s_bidx[at] = (uint16_t)(tid + RM_BLOCK * j);
     }
-  }
   __syncthreads();
 
   // ---- 4. order inside a bucket: type descending, then binning order (the stable sort of :153) ----------------------
@@ -240,7 +269,7 @@ __global__ void __launch_bounds__(RM_BLOCK) reproject_map_kernel(const ReprojMap
     constexpr int CPT = RM_MAX_CELLS / RM_BLOCK;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-      const int r = tid * CPT + k;
+      const int r = tid + RM_BLOCK * k;  // (neighbouring threads take neighbouring cells)
       if (r < n_cells) {
         const int b0 = s_base[r], b1 = s_base[r + 1];
         for (int i = b0; i < b1; ++i) {
@@ -259,30 +288,46 @@ __global__ void __launch_bounds__(RM_BLOCK) reproject_map_kernel(const ReprojMap
   // ---- 5. Point::getCloseViewObs per binned point (point.cpp:97-117; matcher.cpp:137-138) ---------------------------
   int best_obs[RM_EPT];
   bool has_view[RM_EPT];
+  {
+    int p_[RM_EPT], o0[RM_EPT], on[RM_EPT];
+    double pt[RM_EPT][3];
 #pragma unroll
-  for (int e = 0; e < RM_EPT; ++e) {
-    const int i = tid + RM_BLOCK * e;
-    best_obs[e] = -1;
-    has_view[e] = false;
-    if (i < E) {
-      const int p = s_sidx[i];
-      const int o0 = mp.d_obs_begin[p], n = mp.d_obs_count[p];
-      if (n > 0) {
-        const double pt[3] = {mp.d_pos[3 * p], mp.d_pos[3 * p + 1], mp.d_pos[3 * p + 2]};
-        double obs_dir[3] = {s_fpos[a.cur_frame][0] - pt[0], s_fpos[a.cur_frame][1] - pt[1], s_fpos[a.cur_frame][2] - pt[2]};
+    for (int e = 0; e < RM_EPT; ++e) {
+      const int i = tid + RM_BLOCK * e;
+      const bool in = i < E;
+      p_[e] = in ? (int)s_sidx[i] : 0;
+      o0[e] = in ? mp.d_obs_begin[p_[e]] : 0;
+      on[e] = in ? mp.d_obs_count[p_[e]] : 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pt[e][k] = in ? mp.d_pos[3 * p_[e] + k] : 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < RM_EPT; ++e) {
+      const int i = tid + RM_BLOCK * e;
+      best_obs[e] = -1;
+      has_view[e] = false;
+      if (i < E && on[e] > 0) {
+        uint32_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = k < on[e] ? (uint32_t)mp.d_obs_order[o0[e] + k] : 0u;
+        double obs_dir[3] = {s_fpos[a.cur_frame][0] - pt[e][0], s_fpos[a.cur_frame][1] - pt[e][1], s_fpos[a.cur_frame][2] - pt[e][2]};
         normalize3(obs_dir);
-        int best = o0;
+        int best = o0[e];
         double min_cos_angle = 0;
-        for (int o = o0; o < o0 + n; ++o) {
-          const int fr = mp.d_obs_frame[o];
-          double dir[3] = {s_fpos[fr][0] - pt[0], s_fpos[fr][1] - pt[1], s_fpos[fr][2] - pt[2]};
+        auto look = [&](const uint32_t word, const int k) {
+          const int fr = (int)(word >> 16) & (RM_MAX_FRAMES - 1);
+          double dir[3] = {s_fpos[fr][0] - pt[e][0], s_fpos[fr][1] - pt[e][1], s_fpos[fr][2] - pt[e][2]};
           normalize3(dir);
           const double cos_angle = dot3(obs_dir, dir);
           if (cos_angle > min_cos_angle) {
             min_cos_angle = cos_angle;
-            best = o;
+            best = o0[e] + k;
           }
-        }
+        };
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k < on[e]) look(w[k], k);
+        for (int k = 8; k < on[e]; ++k) look((uint32_t)mp.d_obs_order[o0[e] + k], k);
         best_obs[e] = best;
         has_view[e] = !(min_cos_angle < 0.5);
         if (has_view[e]) s_cnt[s_srank[i]] = 1;  // (benign race: every writer stores 1)
@@ -325,11 +370,14 @@ __global__ void __launch_bounds__(RM_BLOCK) reproject_map_kernel(const ReprojMap
 #pragma unroll
   for (int e = 0; e < RM_EPT; ++e) {
     const int i = tid + RM_BLOCK * e;
-    const int flag = (i >= v0 && i < v1 && has_view[e]) ? 1 : 0;
-    int total;
-    const int ex = block_exclusive_scan(flag, s_wave, &total);
-    trial[e] = flag ? M + ex : -1;
-    M += total;
+    trial[e] = -1;
+    if (RM_BLOCK * e < v1 && RM_BLOCK * (e + 1) > v0) {  // (uniform: a pass without visits costs no barrier)
+      const int flag = (i >= v0 && i < v1 && has_view[e]) ? 1 : 0;
+      int total;
+      const int ex = block_exclusive_scan(flag, s_wave, &total);
+      trial[e] = flag ? M + ex : -1;
+      M += total;
+    }
   }
   const bool overflow = V > a.max_visits || M > a.max_trials;
   if (tid == 0) {
@@ -338,8 +386,7 @@ __global__ void __launch_bounds__(RM_BLOCK) reproject_map_kernel(const ReprojMap
     a.out.d_header[2] = overflow ? 0 : V;
     a.out.d_header[3] = overflow ? 0 : M;
     a.out.d_header[4] = overflow ? a.first_cell : end_cell;
-    a.out.d_header[5] = 0;
-    a.out.d_header[6] = a.out.d_header[7] = 0;
+    a.out.d_header[5] = a.out.d_header[6] = a.out.d_header[7] = 0;
   }
   if (tid < a.n_frames) a.out.d_kf_count[tid] = s_kfcount[tid];
   if (overflow) return;
@@ -374,7 +421,7 @@ extern "C" int svo_hip_reproject_map(const svo_hip_camera* cam, const svo_hip_fr
   if (!cam || !cam_model_ok(cam) || !frames || !map || !grid || !out || !d_kf_rank) return SVO_HIP_EINVAL;
   if (frames->n_frames < 1 || frames->n_frames > RM_MAX_FRAMES || cur_frame < 0 || cur_frame >= frames->n_frames || !frames->d_T_f_w)
     return SVO_HIP_EINVAL;
-  if (map->n_points < 0 || map->n_points > 65535 || map->n_obs < 0) return SVO_HIP_ERANGE;  // (entries are carried as 16 bits)
+  if (map->n_points < 0 || map->n_points > 16 * RM_BLOCK || map->n_obs < 0) return SVO_HIP_ERANGE;  // (a thread carries <= 16 entries)
   if (grid->cell_size < 1 || grid->n_cols < 1 || grid->n_cells < 1 || grid->n_cells > RM_MAX_CELLS || !grid->d_cell_rank)
     return grid->n_cells > RM_MAX_CELLS ? SVO_HIP_ERANGE : SVO_HIP_EINVAL;
   if (first_cell < 0 || first_cell > grid->n_cells || max_visits < 0 || max_trials < 0) return SVO_HIP_EINVAL;
@@ -412,6 +459,9 @@ extern "C" int svo_hip_reproject_map(const svo_hip_camera* cam, const svo_hip_fr
   a.max_visits = max_visits;
   a.max_trials = max_trials;
   a.out = *out;
-  hipLaunchKernelGGL(reproject_map_kernel, dim3(1), dim3(RM_BLOCK), 0, static_cast<hipStream_t>(stream), a);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (map->n_points <= 4 * RM_BLOCK) hipLaunchKernelGGL(reproject_map_kernel<4>, dim3(1), dim3(RM_BLOCK), 0, st, a);
+  else if (map->n_points <= 8 * RM_BLOCK) hipLaunchKernelGGL(reproject_map_kernel<8>, dim3(1), dim3(RM_BLOCK), 0, st, a);
+  else hipLaunchKernelGGL(reproject_map_kernel<16>, dim3(1), dim3(RM_BLOCK), 0, st, a);
   return check_launch();
 }

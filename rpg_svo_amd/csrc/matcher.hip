@@ -447,9 +447,13 @@ struct SelectArgs {
   int32_t signal_value;
   const int32_t* M_dev;  // NULL, or the batch size lives on the device (min(*M_dev, M))
 };
-__global__ void __launch_bounds__(256) match_select_kernel(const SelectArgs a) {
-  __shared__ int s_wave[4];
-  __shared__ int s_ok[256], s_cell[256];
+// NT threads take NT trials per pass.  The match results may live in host-mapped memory (the single-stream drop-in), where
+// every pass costs a round trip over the link: batches of more than 256 trials run with 1024 threads (one pass for the
+// ~700 trials of a frame on a full map instead of three).
+template <int NT>
+__global__ void __launch_bounds__(NT) match_select_kernel(const SelectArgs a) {
+  __shared__ int s_wave[NT / 64];
+  __shared__ int s_ok[NT], s_cell[NT];
   __shared__ int s_carry[2];  // cell of the last trial of the pass before, and whether that cell has matched already
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // everything enqueued before this kernel has completed (stream order): tell a host that polls mapped memory
@@ -457,7 +461,7 @@ __global__ void __launch_bounds__(256) match_select_kernel(const SelectArgs a) {
   if (tid == 0) { s_carry[0] = -1; s_carry[1] = 0; }
   const int M = a.M_dev ? min(*a.M_dev, a.M) : a.M;
   int base = 0;  // selected trials before this pass (the same in every thread)
-  for (int m0 = 0; m0 < M && base < a.max_selected; m0 += 256) {
+  for (int m0 = 0; m0 < M && base < a.max_selected; m0 += NT) {
     const int m = m0 + tid;
     const bool valid = m < M;
     // every global read of the pass is issued here, before anything depends on one: the match results may live in
@@ -481,10 +485,11 @@ __global__ void __launch_bounds__(256) match_select_kernel(const SelectArgs a) {
       if (first && j < 0 && cell == s_carry[0] && s_carry[1]) first = false;
     }
     int carry_cell = 0, carry_matched = 0;
-    if (tid == 255) {  // (only read when another pass follows, i.e. when this pass was full)
+    if (tid == NT - 1 && m0 + NT < M) {  // only when another pass follows (a partial pass ends in idle lanes that all share
+                                         // the cell id -2: one lane walking back over them cost 80 us at NT = 1024)
       carry_cell = cell;
       carry_matched = ok;
-      int j = 254;
+      int j = NT - 2;
       for (; !carry_matched && j >= 0 && s_cell[j] == cell; --j) carry_matched = s_ok[j];
       if (!carry_matched && j < 0 && cell == s_carry[0]) carry_matched = s_carry[1];
     }
@@ -493,8 +498,8 @@ __global__ void __launch_bounds__(256) match_select_kernel(const SelectArgs a) {
     __syncthreads();
     int rank = base + __popcll(b & ((1ull << lane) - 1ull));
     for (int w = 0; w < wave; ++w) rank += s_wave[w];
-    base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    if (tid == 255) { s_carry[0] = carry_cell; s_carry[1] = carry_matched; }
+    for (int w = 0; w < NT / 64; ++w) base += s_wave[w];
+    if (tid == NT - 1) { s_carry[0] = carry_cell; s_carry[1] = carry_matched; }
     __syncthreads();
     if (first && rank < a.max_selected) {
       double f[3];
@@ -729,7 +734,9 @@ static int select_matches_impl(const svo_hip_camera* cam, int M, const int32_t* 
   a.has_point = d_has_point;
   a.signal = d_signal;
   a.signal_value = signal_value;
-  hipLaunchKernelGGL(match_select_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);  // M == 0: n = 0
+  // (M == 0: n = 0)
+  if (M <= 256) hipLaunchKernelGGL(match_select_kernel<256>, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL(match_select_kernel<1024>, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
   return check_launch();
 }
 

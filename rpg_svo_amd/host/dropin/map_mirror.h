@@ -322,7 +322,7 @@ class MapMirror {
       for (CandList::iterator c = cl.begin(); c != cl.end(); ++c)
         if (!appendCandidate(c, ftr_order)) return false;
     }
-    if (pts_.size() > 65535 || frames_.size() + 1 > 64) return false;
+    if (pts_.size() > 16384 || frames_.size() + 1 > 64) return false;
     resendAll();
     return true;
   }
@@ -362,7 +362,7 @@ class MapMirror {
     } else if (first_new != cl.begin()) {
       return false;
     }
-    if (pts_.size() + (n - live_cands_) > 65535) return false;
+    if (pts_.size() + (n - live_cands_) > 16384) return false;
     static const std::unordered_map<const Feature*, int> none;  // a candidate's Feature is in no keyframe's list yet
     for (CandList::iterator c = first_new; c != cl.end(); ++c)
       if (!appendCandidate(c, none)) return false;

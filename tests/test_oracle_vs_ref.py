@@ -324,6 +324,10 @@ def test_update_seeds(libs, scene, scene_frames):
             assert bytes(a)[-20:] == bytes(b)[-20:], k
         if st == pytrack.SEED_CONVERGED:
             assert same(np.array(ia.xyz_world[:]), np.array(ib.xyz_world[:]))
+            # the state AFTER the converging update: the port reports it, the reference's driver recovers mu and sigma2 from
+            # the converged callback (the variance it is handed; the new point's distance from the seed's frame = 1 / mu)
+            assert np.float32(a.mu).tobytes() == np.float32(b.mu).tobytes(), (k, a.mu, b.mu)
+            assert np.float32(a.sigma2).tobytes() == np.float32(b.sigma2).tobytes(), (k, a.sigma2, b.sigma2)
     assert hist.get(pytrack.SEED_UPDATED, 0) > 20 and hist.get(pytrack.SEED_CONVERGED, 0) > 2
     assert hist.get(pytrack.SEED_ERASED_OLD, 0) > 2
 

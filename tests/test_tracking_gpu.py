@@ -17,6 +17,16 @@ from rpg_svo_amd import capi, se3, synth, tracking
 
 pytestmark = pytest.mark.gpu
 
+# DepthFilter::updateSeed's a and b, device against CPU.  (e - f) / (f - e / f) cancels: a last-bit difference of an input
+# comes out amplified.  Measured on 200 000 seeds with IDENTICAL float inputs (scripts/update_seed_parity.py on the GPU box,
+# profiles/r04_update_seed_parity.json, the same against the C port and the reference's own translation unit): 99.98 % of
+# the seeds come back with identical bits in all four fields (the rest: an exp that rounds the other way); largest
+# relative deviation a 2.07e-5, b 2.04e-5, mu 1.7e-7, sigma2 1.7e-4 (a difference of two nearly equal products).
+AB_RTOL_SAME_INPUTS = 1e-4   # 5 x the measured maximum
+# In updateSeeds the inputs themselves (x = 1 / z, tau^2) come out of f64 geometry through acos / atan / sin, which differ in
+# the last bits between glibc and the GPU's libm, and x is then rounded to float: a and b see that amplified.
+AB_RTOL = 5e-3
+
 
 @pytest.fixture(scope="module")
 def orc(oracle, checker):
@@ -368,6 +378,7 @@ def test_update_seeds(gpu_device, orc, scene, pyrs, align_1d, subpix):
         status = np.where(np.isin(status, (pytrack.SEED_BEHIND, pytrack.SEED_NOT_IN_FRAME)), 0, status)
     a, b, mu, s2 = (t.cpu().numpy() for t in (ss.a, ss.b, ss.mu, ss.sigma2))
     hist = {}
+    ab_dev = []
     for i in range(S):
         st = io[i].status
         hist[st] = hist.get(st, 0) + 1
@@ -381,23 +392,27 @@ def test_update_seeds(gpu_device, orc, scene, pyrs, align_1d, subpix):
                 assert status[i] in (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED)
         else:
             assert status[i] == st, (i, status[i], st)
-        # (a converged seed is erased from the reference's list: its driver can only report the state
-        #  BEFORE the last update for it, the C port reports the state after)
-        cmp_state = (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED, pytrack.SEED_NO_MATCH) if orc.which == "orc" else \
-            (pytrack.SEED_UPDATED, pytrack.SEED_NO_MATCH)
-        if st in cmp_state:
+        # (a converged seed is erased from the reference's list; its driver recovers mu and sigma2 AFTER the last update
+        #  from what the converged callback is handed -- the variance, and the new point, whose distance from the seed's
+        #  frame is 1 / mu -- while a and b leave no trace there; the C port reports all four)
+        ab_known = not (orc.which == "ref" and st == pytrack.SEED_CONVERGED)
+        if st in (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED, pytrack.SEED_NO_MATCH):
             # Bayesian update: float arithmetic fed by an f64 depth that may differ in the last
             # bits (acos/atan/sin on the GPU) and by expf.  mu: 2e-6 relative.  sigma2 is formed as
             # C1*(s2+m^2) + C2*(sigma2+mu^2) - mu_new^2 in float, i.e. it carries an absolute
             # rounding noise of ~eps*mu^2 whatever its size; a and b come from (e-f)/(f-e/f).
             assert np.isclose(mu[i], so[i].mu, rtol=2e-6, atol=0), (i, mu[i], so[i].mu)
             assert abs(float(s2[i]) - so[i].sigma2) <= 1e-4 * abs(so[i].sigma2) + 1e-6 * so[i].mu ** 2, (i, s2[i], so[i].sigma2)
-            assert np.allclose([a[i], b[i]], [so[i].a, so[i].b], rtol=5e-3, atol=1e-5), (i, a[i], so[i].a, b[i], so[i].b)
+            if ab_known:
+                ab_dev.append(max(abs(float(a[i]) - so[i].a) / abs(so[i].a), abs(float(b[i]) - so[i].b) / abs(so[i].b)))
+                assert np.allclose([a[i], b[i]], [so[i].a, so[i].b], rtol=AB_RTOL, atol=1e-5), (i, a[i], so[i].a, b[i], so[i].b)
         if st in (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED) and orc.which == "orc":
             # (the reference's DepthFilter does not expose Matcher::px_cur_ per seed: C port only)
             assert np.abs(px[i] - np.array(io[i].px_cur[:])).max() < 1e-9      # float alignment, identical start
         if st == pytrack.SEED_CONVERGED:
             assert np.abs(xyz[i] - np.array(io[i].xyz_world[:])).max() < 1e-5
+    print(f"update_seeds[{orc.which}, align_1d={align_1d}, subpix={subpix}]: max relative deviation of a / b over "
+          f"{len(ab_dev)} compared seeds = {max(ab_dev):.3e}")
     assert hist.get(pytrack.SEED_UPDATED, 0) > 50 and hist.get(pytrack.SEED_CONVERGED, 0) > 2
     assert hist.get(pytrack.SEED_ERASED_OLD, 0) > 5 and hist.get(pytrack.SEED_BEHIND if orc.which == "orc" else 0, 0) > 2
 
@@ -487,7 +502,7 @@ def test_update_seed_batch(gpu_device, orc):
     g, w = got[fin], want[fin]
     assert np.allclose(g[:, 2], w[:, 2], rtol=2e-6, atol=0)                                   # mu
     assert (np.abs(g[:, 3] - w[:, 3]) <= 1e-4 * np.abs(w[:, 3]) + 1e-6 * w[:, 2] ** 2).all()    # sigma2 (see above)
-    assert np.allclose(g[:, :2], w[:, :2], rtol=5e-3, atol=1e-5)                               # a, b
+    assert np.allclose(g[:, :2], w[:, :2], rtol=AB_RTOL_SAME_INPUTS, atol=0)                   # a, b
 
 
 @pytest.mark.parametrize("kind", CAMERA_KINDS)
