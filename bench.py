@@ -141,11 +141,13 @@ def compact_line(result: dict, details_path: str | None) -> dict:
     if isinstance(ft, dict):
         legs["full_track"] = _pick(ft, ("ms_per_step", "frames_per_s", "skipped"))
         if isinstance(ft.get("stages_ms"), dict):
-            legs["full_track"]["stages_ms"] = ft["stages_ms"]
+            legs["full_track"]["stages_ms"] = _num({k: v for k, v in ft["stages_ms"].items() if v >= 0.05}, 4)
         if isinstance(ft.get("rooflines"), dict):
-            legs["full_track"]["frac"] = {k: v.get("frac") for k, v in ft["rooflines"].items() if isinstance(v, dict)}
-        if isinstance(ft.get("kernels"), dict):
-            legs["full_track"]["kernel_ms"] = {k: v.get("ms") for k, v in ft["kernels"].items() if isinstance(v, dict)}
+            legs["full_track"]["frac"] = _num({k: v.get("frac") for k, v in ft["rooflines"].items() if isinstance(v, dict)}, 3)
+        if isinstance(ft.get("kernels"), dict):  # per kernel: [rocprof ms per step, fraction of the HBM roofline by compulsory bytes]
+            short = lambda k: k.replace("find_match_direct/", "fm/").replace("update_seeds/", "us/").replace("pose_optimize/", "po/").replace("_kernel", "")
+            legs["full_track"]["kernels_ms_frac"] = {short(k): [_num(v.get("ms"), 3), _num(v.get("frac"), 3)] for k, v in ft["kernels"].items()
+                                                     if isinstance(v, dict) and (v.get("ms") or 0) >= 0.05}
     for key, keys in (("align_plus_refine", ("frames_per_s", "ms_per_step")),
                       ("noise_sigma2", ("frames_per_s", "ms_per_step")),
                       ("f64_partials", ("frames_per_s", "slowdown")),
@@ -159,28 +161,37 @@ def compact_line(result: dict, details_path: str | None) -> dict:
     if isinstance(ds, dict):
         legs["dropin_sequence"] = _pick(ds, ("frames", "keyframes", "first_frame_with_a_different_decision", "se3_lognorm_max_before_it",
                                              "ate_rmse_vs_cpu_m", "ate_rmse_vs_ground_truth_m", "skipped"))
+        lw = ds.get("median_ms_per_frame_hip_dropin_list_walking_reprojector")
+        if isinstance(lw, dict) and "tot_time" in lw:
+            legs["dropin_sequence"]["ms_hip_map_mirror_off"] = lw["tot_time"]
+            legs["dropin_sequence"]["map_mirror_same_trajectory"] = lw.get("trajectory_identical_to_the_mirror_path")
         for k_out, k_in in (("ms_cpu_ref", "median_ms_per_frame_cpu_reference"), ("ms_hip", "median_ms_per_frame_hip_dropin"),
                             ("ms_hip_deferred_mapper", "median_ms_per_frame_hip_dropin_deferred_mapper")):
             if isinstance(ds.get(k_in), dict):
                 legs["dropin_sequence"][k_out] = ds[k_in].get("tot_time")
         if isinstance(ds.get("map_size"), dict):
             legs["dropin_sequence"]["map_size"] = _pick(ds["map_size"], ("n_kfs", "n_candidates", "kf_points_in_frame", "trials", "matches"))
-    for key in ("gather", "rig_replay", "stages_ms"):  # small objects of the multi-GPU / --pipeline full runs: whole
+    for key in ("gather", "stages_ms"):  # small objects of the multi-GPU / --pipeline full runs: whole
         if isinstance(result.get(key), dict):
             c[key] = result[key]
+    if isinstance(result.get("rig_replay"), dict):
+        c["rig_replay"] = _pick(result["rig_replay"], ("cameras", "rig_frames_per_s", "us_per_frame_set", "us_per_frame_set_without_gather",
+                                                        "gather_bytes_per_frame_set", "skipped"))
     if legs:
         c["legs"] = legs
     c["details"] = details_path
     c = _num(c)
     # never exceed the limit: drop the optional blocks, least important first
-    for victim in ("legs", "rig_replay", "stages_ms", "parity"):
+    order = ("stream_replay", "k0_pyramid", "config3_xga5_b64", "noise_sigma2", "f64_partials", "align_plus_refine", "full_track_long_scan",
+             "dropin_sequence", "full_track")
+    for victim in ("rig_replay", "legs", "stages_ms", "parity"):
         if len(json.dumps(c)) <= COMPACT_LIMIT:
             break
         if victim == "legs" and "legs" in c:
-            for k in list(c["legs"]):
+            for k in [k for k in order if k in c["legs"]] + [k for k in c["legs"] if k not in order]:
                 if len(json.dumps(c)) <= COMPACT_LIMIT:
                     break
-                c["legs"].pop(k)
+                c["legs"].pop(k, None)
         else:
             c.pop(victim, None)
     return c
@@ -670,6 +681,10 @@ def _extras_and_print(args, result, extras, full, ev, W, sia, out, st, store, li
             except Exception as e:
                 pf = {"skipped": repr(e)}
             pm["full_track"] = pf
+            try:
+                result["full_track"]["kernels"] = full_track_kernel_rooflines(result["full_track"], pf, B, W.n_patches)
+            except Exception as e:
+                result["full_track"]["kernels"] = {"skipped": repr(e)}
             for stage, st_ in pf.get("stages", {}).items():  # next to the stage's algorithmic bytes
                 rl_ = result["full_track"]["rooflines"].get(stage)
                 if rl_ and st_["traffic_bytes_per_step"] == st_["traffic_bytes_per_step"]:
@@ -1105,6 +1120,50 @@ def pmc_leg(args, kernel_ms: float) -> dict:
     return out
 
 
+def full_track_kernel_rooflines(ft: dict, pf: dict, frames_per_step: int, patches: int) -> dict:
+    """Per kernel of the full-track step: rocprofv3's duration (kernel-trace pass of pmc_full_track_leg), counter traffic,
+    and the bytes the kernel has to move AS IT IS CUT -- its inputs once, its outputs once, windows by their footprint --
+    with the fraction of the HBM roofline those bytes reach.  Formulas (bytes per unit):
+      match_prepare   candidate: 52 in (frame, position, observation range, projection); observation record: 52;
+                      tried trial: 62 of warp / alignment parameters + 8 of results
+      warp_kernel     trial: 37 parameters + 121 footprint of the 10 x 10 template in the reference level + 100 written
+      align_kernel    trial: 100 template + 50 parameters / results; evaluation: 81 (the 9 x 9 window)
+      pose_opt        frame: 52 per observation + 416
+      seed_prepare    seed: 76 in (seed state, its feature, the frame indices) + 64 of warp / scan parameters
+      epi_scan        scanning seed: 148 (template + segment) + 64 + 7.13 per scanned position: the UNION of the 8 x 8
+                      windows along the segment (0.7 px apart; 8 * 0.7 * (|cos| + |sin|), 4 / pi on average) -- the 64 bytes
+                      per position of SURVEY 8(d) count every window in full although neighbours overlap by 7/8
+      seed_finish     seed: 96 (state in / out, bearing, refined pixel, flags, status)
+    The depth filter's align_kernel has no evaluation count of its own (only the matcher's launches are instrumented):
+    its bytes are left null."""
+    rl = ft.get("rooflines", {})
+    fm, us = rl.get("find_match_direct", {}), rl.get("update_seeds", {})
+    n_tried, M, n_obs = fm.get("trials", 0.0), fm.get("candidates", 0.0), fm.get("observations", 0.0)
+    n_eval = fm.get("alignment_evaluations_per_trial", 0.0) * n_tried
+    S, n_pos, S_scan = us.get("seeds", 0.0), us.get("scanned_positions_per_seed", 0.0) * us.get("seeds", 0.0), us.get("seeds_scanning", 0.0)
+    need = {"find_match_direct/match_prepare_kernel": M * 52.0 + n_obs * 52.0 + n_tried * 70.0,
+            "find_match_direct/warp_kernel": n_tried * 258.0,
+            "find_match_direct/align_kernel": n_tried * 150.0 + n_eval * 81.0,
+            "pose_optimize/pose_opt_wave_kernel": frames_per_step * (patches * 52.0 + 416.0),
+            "update_seeds/seed_prepare_kernel": S * 140.0,
+            "update_seeds/warp_kernel": S * 258.0,
+            "update_seeds/epi_scan_kernel": S_scan * 212.0 + n_pos * 7.13,
+            "update_seeds/align_kernel": None,
+            "update_seeds/seed_finish_kernel": S * 96.0}
+    out = {}
+    for kn, kd in pf.get("kernels", {}).items():
+        e = dict(kd)
+        b = need.get(kn)
+        e["compulsory_bytes"] = b
+        if b and kd.get("ms", 0) > 0:
+            e["achieved_GBs"] = b / (kd["ms"] * 1e-3) / 1e9
+            e["frac"] = e["achieved_GBs"] / HBM_PEAK_GBS
+            if kd.get("traffic_bytes"):
+                e["traffic_over_compulsory"] = kd["traffic_bytes"] / b
+        out[kn] = e
+    return out
+
+
 FULL_TRACK_KERNELS = {"find_match_direct": ("match_prepare_kernel", "warp_kernel", "align_kernel"),
                       "update_seeds": ("seed_prepare_kernel", "warp_kernel", "epi_scan_kernel", "align_kernel", "seed_finish_kernel"),
                       "pose_optimize": ("pose_opt_wave_kernel", "pose_opt_kernel")}
@@ -1179,7 +1238,95 @@ def pmc_full_track_leg(args, n_steps: int = 2) -> dict:
             else:
                 kb[k] = per_launch(k, 0, 1)
         stages[stage] = {"traffic_bytes_per_step": float(np.nansum(list(kb.values()))), "by_kernel": kb}
-    return {"passes": status, "stages": stages,
+
+    # ---- per kernel: duration (a kernel-trace pass of the same child) and VALU issue (an SQ counter pass) --------------
+    # align_kernel runs in up to three phased launches per use: its launches of a step are summed per use (the first
+    # half of a step's align launches belongs to findMatchDirect -- it is enqueued first -- the rest to the depth filter)
+    kernels = {}
+    try:
+        d = tempfile.mkdtemp(prefix="svo_trace_full_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "trace", "--", *base]
+        p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=2 * PMC_PASS_TIMEOUT_S)
+        files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            status["trace"] = f"rc={p.returncode}: {p.stderr[-200:]}"
+        else:
+            rows = []
+            with open(files[0]) as fh:
+                for row in csv.DictReader(fh):
+                    short = next((k for k in regex.split("|") if k in row["Kernel_Name"]), None)
+                    if short:
+                        rows.append((int(row["Start_Timestamp"]), short, (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6))
+            rows.sort()
+            # the timed steps come last: cut at the last n_steps launches of seed_finish_kernel (one per step, the step's last kernel)
+            ends = [i for i, r in enumerate(rows) if r[1] == "seed_finish_kernel"]
+            first = ends[-n_steps - 1] + 1 if len(ends) > n_steps else 0
+            per_step = {}
+            for _, short, ms in rows[first:]:
+                per_step.setdefault(short, []).append(ms)
+            for short, v in per_step.items():
+                if short in twice:
+                    # dispatch order inside a step: findMatchDirect's launches, then the depth filter's
+                    n_per_step = len(v) // n_steps
+                    steps = [v[i * n_per_step:(i + 1) * n_per_step] for i in range(n_steps)]
+                    if short == "warp_kernel":
+                        kernels["find_match_direct/warp_kernel"] = {"ms": float(np.mean([st[0] for st in steps])), "launches_per_step": 1}
+                        kernels["update_seeds/warp_kernel"] = {"ms": float(np.mean([sum(st[1:]) for st in steps])), "launches_per_step": n_per_step - 1}
+                    else:
+                        h = n_per_step // 2
+                        kernels["find_match_direct/align_kernel"] = {"ms": float(np.mean([sum(st[:h]) for st in steps])), "launches_per_step": h}
+                        kernels["update_seeds/align_kernel"] = {"ms": float(np.mean([sum(st[h:]) for st in steps])), "launches_per_step": n_per_step - h}
+                else:
+                    stage = next(sg for sg, ks in FULL_TRACK_KERNELS.items() if short in ks)
+                    kernels[f"{stage}/{short}"] = {"ms": float(np.sum(v) / n_steps), "launches_per_step": len(v) / n_steps}
+            status["trace"] = "ok"
+        shutil.rmtree(d, ignore_errors=True)
+    except subprocess.TimeoutExpired:
+        status["trace"] = "timeout"
+    try:
+        d = tempfile.mkdtemp(prefix="svo_pmc_full_sq_", dir="/tmp")
+        ctrs = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU",
+                "SQ_BUSY_CU_CYCLES"]
+        cmd = [exe, "--pmc", *ctrs, "--kernel-include-regex", regex, "--output-format", "csv", "-d", d, "-o", "sq", "--", *base]
+        p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=2 * PMC_PASS_TIMEOUT_S)
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            status["sq"] = f"rc={p.returncode}: {p.stderr[-200:]}"
+        else:
+            rows = []
+            with open(files[0]) as fh:
+                for row in csv.DictReader(fh):
+                    short = next((k for k in regex.split("|") if k in row["Kernel_Name"]), None)
+                    if short:
+                        rows.append((int(row["Dispatch_Id"]), short, row["Counter_Name"], float(row["Counter_Value"])))
+            rows.sort()
+            by = {}
+            for did, short, cn, v in rows:
+                by.setdefault(short, {}).setdefault(cn, []).append(v)
+            for short, cs in by.items():
+                # per-launch averages over every launch of the kernel in the child run (the set-up of the workload launches the
+                # same kernels on the same kind of data); warp / align: both uses together.  The ratio does not depend on the
+                # launch's size: instruction counts over the busy-CU cycles of the same launch
+                raw = {cn: float(np.mean(v)) for cn, v in cs.items()}
+                if raw.get("SQ_BUSY_CU_CYCLES", 0) > 0 and raw.get("SQ_INSTS_VALU", 0) > 0:
+                    vr = valu_roofline(raw, 1.0)
+                    for kn in kernels:
+                        if kn.endswith("/" + short):
+                            kernels[kn]["valu"] = {"busy_frac_at_3_cycles_per_instruction": vr["frac"],
+                                                   "busy_frac_lower_bound_2_cycles": vr["lower_bound_2_cycles_per_instruction"],
+                                                   "wave_cycles_waiting_frac": vr["wave_cycles_waiting_frac"],
+                                                   "wave_cycles_at_waitcnt_frac": vr["wave_cycles_at_waitcnt_frac"]}
+            status["sq"] = "ok"
+        shutil.rmtree(d, ignore_errors=True)
+    except subprocess.TimeoutExpired:
+        status["sq"] = "timeout"
+    for kn, kd in kernels.items():
+        stage, short = kn.split("/")
+        t = stages.get(stage, {}).get("by_kernel", {}).get(short)
+        if t is not None and t == t:
+            kd["traffic_bytes"] = t
+            kd["traffic_GBs"] = t / (kd["ms"] * 1e-3) / 1e9 if kd["ms"] > 0 else None
+    return {"passes": status, "stages": stages, "kernels": kernels,
             "how": f"child runs of `bench.py --pipeline full` ({n_steps} steps) under rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in "
                    "separate passes, KiB, FETCH_SIZE doubled (gfx950); per kernel launch, averaged over the steps"}
 
@@ -1260,7 +1407,26 @@ def dropin_sequence(n_frames: int = 600) -> dict:
                 "trials": medi(hip, "repr_n_mps"), "matches": medi(hip, "repr_n_new_references"),
                 "same_as_cpu_reference": all(all(a[k] == b[k] for k in ("n_kfs", "n_overlap_kfs", "n_kf_points_in_frame", "repr_n_mps", "repr_n_new_references"))
                                              for a, b in zip(ref, hip))}
+    # Reprojector::reprojectMap on the list-walking path (SVO_HIP_MAP_MIRROR=off) in a child process: what the
+    # device-resident map mirror (row N2, the default) buys, and that it changes nothing
+    list_walk = None
+    try:
+        import tempfile
+        dump = tempfile.mktemp(suffix=".npy", dir="/tmp")
+        code = f"import sys, json; sys.path.insert(0, {ROOT!r}); import bench; print(json.dumps(bench.dropin_hip_only({n_frames}, {dump!r})))"
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SVO_HIP_MAP_MIRROR="off"), capture_output=True, text=True,
+                           timeout=300)
+        if p.returncode == 0:
+            list_walk = json.loads(p.stdout.strip().splitlines()[-1])
+            list_walk["trajectory_identical_to_the_mirror_path"] = bool(np.array_equal(np.load(dump), Th))
+            list_walk.pop("map_mirror", None)
+            os.unlink(dump)
+        else:
+            list_walk = {"skipped": p.stderr[-300:]}
+    except Exception as e:
+        list_walk = {"skipped": repr(e)}
     return {"frames": n_frames, "map_size": map_size,
+            "map_mirror": host.get("map_mirror"), "median_ms_per_frame_hip_dropin_list_walking_reprojector": list_walk,
             "first_frame_with_a_different_decision": first_diff,
             "se3_lognorm_max_before_it": float(d[pre].max()), "se3_lognorm_median_before_it": float(np.median(d[pre])),
             "ate_rmse_vs_ground_truth_m": {"cpu_reference": horn_ate(pos(Tr), pos(T)), "hip_dropin": horn_ate(pos(Th), pos(T))}, "image": "752x480", "se3_lognorm_max": float(d.max()), "se3_lognorm_median": float(np.median(d)),
@@ -1283,6 +1449,23 @@ def dropin_sequence(n_frames: int = 600) -> dict:
             "host_vs_device_us_per_call": {k: {q: round(v, 2) if isinstance(v, float) else v for q, v in st.items()}
                                            for k, st in host.get("stages", {}).items()},
             "pyramid_uploads": host.get("uploads"), "pyramid_upload_us_per_frame": host.get("pyramid_upload_us_total", 0.0) / max(1, n_frames - 1)}
+
+
+def dropin_hip_only(n_frames: int, dump: str) -> dict:
+    """child of dropin_sequence (one process per SVO_HIP_MAP_MIRROR mode: the mode is read once): the hip flavour alone"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "dropin"))
+    import pypipeline as pp
+    cam = synth.Camera(752, 480, 315.5, 315.5, 376.0, 240.0)
+    T = synth.make_trajectory(n_frames, seed=5, max_step=0.02, max_rot_deg=0.3)
+    imgs = synth.render(synth.make_texture(seed=12345), T, cam, device="cuda" if torch.cuda.is_available() else "cpu").cpu().numpy()
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 2)
+    pp.run_sequence("hip", cam, imgs[:10], T[:10])
+    st = {}
+    hip = pp.run_sequence("hip", cam, imgs, T, stats_out=st)
+    np.save(dump, np.stack([r["T_f_w"] for r in hip]))
+    med = lambda k: float(np.median([r[k] for r in hip[1:]]) * 1e3)
+    return {"tot_time": med("t_tot_time"), "reproject": med("t_reproject"), "map_mirror": st.get("map_mirror")}
 
 
 _CPU_REF: dict = {}  # poses and iteration counts of the CPU reference run (cpu_baseline), for the f64_partials leg
@@ -1723,12 +1906,14 @@ class FullTrack:
                         "unmatched": float(scan[um].float().mean().item()) if um.any() else None}
         return {
             "find_match_direct": roofline("match_prepare + warp_kernel + align_kernel", fm_bytes, stages["find_match_direct"],
-                                          trials=n_tried, alignment_evaluations_per_trial=n_eval / max(n_tried, 1),
+                                          trials=n_tried, candidates=float(M), observations=float(self.obs_ptr[-1].item()),
+                                          alignment_evaluations_per_trial=n_eval / max(n_tried, 1),
                                           alignment_evaluations_histogram=eval_hist,
                                           alignment_evaluations_per_wave_of_64_trials=wave_max_mean),
             "pose_optimize": roofline("pose_opt_wave_kernel", B * (N * 52.0 + 416.0), stages["pose_optimize"]),
             "update_seeds": roofline("seed_prepare + warp_kernel + epi_scan + align_kernel + seed_finish", seed_bytes,
                                      stages["update_seeds"], seeds=S, scanned_positions_per_seed=n_scan / S,
+                                     seeds_scanning=float((scan > 0).sum().item()),
                                      scanned_positions_per_seed_by_kind=scan_by_kind, scanned_positions_per_seed_by_age=scan_by_age,
                                      seeds_per_frame_by_scanned_positions=scan_hist),
         }

@@ -94,21 +94,18 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   const int s = blockIdx.x * 64 + threadIdx.x;
   if (s >= a.S) return;
   const SeedWs& w = a.ws;
+  // What every seed needs whatever happens to it.  Arrays only the warp / scan / alignment of an ACTIVE seed read
+  // (ref_slot, ref_level, dir, px_scaled, px_cur) are written where the seed becomes active, and seed_finish reads
+  // px_cur / align_ok only for seeds that got that far: an early exit costs 19 bytes of workspace, not 71 (round 3:
+  // 230 B per seed through these arrays against 36 B of seed state).
   w.warp_active[s] = 0;
   w.align_active[s] = 0;
   w.use_1d[s] = a.opt.align_1d ? 1 : 0;
   w.mode[s] = MODE_NONE;
   w.status[s] = 0;
   w.search_level[s] = -1;  // not reached yet (an edgelet rejected by the angle filter returns before matcher.cpp:214)
-  w.ref_slot[s] = 0;
-  w.ref_level[s] = 0;
   w.n_steps[s] = 0;
-  w.align_ok[s] = 0;
   w.accepted_raw[s] = 0;
-  w.dir[2 * s] = 1.f;
-  w.dir[2 * s + 1] = 0.f;
-  w.px_scaled[2 * s] = w.px_scaled[2 * s + 1] = 0.0;
-  w.px_cur[2 * s] = w.px_cur[2 * s + 1] = 0.0;
   const int cf = a.cur_frame[s];
   w.cur_slot[s] = a.frame_slot[cf];
   // check if seed is not already too old (:216-219)
@@ -622,9 +619,13 @@ __global__ void __launch_bounds__(64) seed_finish_kernel(const SeedArgs a) {
   if (s >= a.S) return;
   const SeedWs& w = a.ws;
   int status = w.status[s];
+  const bool aligned = w.align_active[s] != 0;  // a short segment, or a scan match handed to the sub-pixel alignment
   if (a.px_cur_out) {
-    a.px_cur_out[2 * s] = w.px_cur[2 * s];
-    a.px_cur_out[2 * s + 1] = w.px_cur[2 * s + 1];
+    // Matcher::px_cur_ exists once the seed reached the alignment (set by seed_prepare for a short segment, by the scan
+    // for a match, refined by the alignment) or was accepted straight from the scan; 0 otherwise
+    const bool has_px = aligned || w.accepted_raw[s] != 0;
+    a.px_cur_out[2 * s] = has_px ? w.px_cur[2 * s] : 0.0;
+    a.px_cur_out[2 * s + 1] = has_px ? w.px_cur[2 * s + 1] : 0.0;
   }
   if (status == SVO_HIP_SEED_ERASED_OLD || status == SVO_HIP_SEED_BEHIND || status == SVO_HIP_SEED_NOT_IN_FRAME) {
     a.status_out[s] = status;
@@ -639,9 +640,9 @@ __global__ void __launch_bounds__(64) seed_finish_kernel(const SeedArgs a) {
   bool matched = false;
   double z = 0;
   if (status == 0) {
-    const int aok = w.align_ok[s];
+    const int aok = aligned ? w.align_ok[s] : 0;  // (written by the alignment kernel for every trial it is launched on)
     const Se3 T_cur_ref = se3_compose(Tc, se3_inverse(Tr));
-    if (w.align_active[s] && aok == 1) {
+    if (aligned && aok == 1) {
       // px_cur_ = px_scaled*(1<<search_level_) was written by the alignment kernel
       double fc[3];
       cam2world(a.cam, w.px_cur[2 * s], w.px_cur[2 * s + 1], fc);

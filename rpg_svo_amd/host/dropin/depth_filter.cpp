@@ -157,6 +157,15 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   replay();  // seeds_mut_ is held
 }
 
+// The reference's destructor (depth_filter.cpp:58-62) behind the join a deferred update needs: its closure writes into
+// THIS filter's seed list and feature detector, and would otherwise run -- from the next beginCall() of the mapping lane
+// or the next reprojectMap -- after they are gone.  (No-op unless SVO_HIP_MAPPER=deferred left an update pending.)
+DepthFilter::~DepthFilter() {
+  svo_hip::Device::joinDeferredAll();
+  stopThread();
+  SVO_INFO_STREAM("DepthFilter destructed.");
+}
+
 // ---- the two static helpers, also on the device (single measurement) --------------------------
 void DepthFilter::updateSeed(const float x, const float tau2, Seed* seed) {
   svo_hip::Device& dev = svo_hip::Device::instance();

@@ -7,7 +7,9 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -72,10 +74,25 @@ void tcpBroadcast(int rank, int world, const std::string& addr, int port, void* 
     int one = 1;
     if (::setsockopt(ls.fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one)) != 0)
       throw std::runtime_error("pose exchange bootstrap: setsockopt(SO_REUSEADDR) failed");
-    // bind to MASTER_ADDR itself (127.0.0.1 on a single node), not to every interface
-    if (::bind(ls.fd, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) != 0 || ::listen(ls.fd, world) != 0)
-      throw std::runtime_error("pose exchange bootstrap: cannot listen on MASTER_ADDR:port");
+    // bind to MASTER_ADDR itself (127.0.0.1 on a single node), not to every interface.  MASTER_ADDR need not be an
+    // address of a local interface (a NAT or service address, another NIC of a multi-homed host): SVO_RIG_BIND names
+    // the address to listen on then, and without it EADDRNOTAVAIL falls back to every interface, as torch's TCPStore
+    // listens -- the hello (magic / world / token) is what keeps strangers out in that case.
+    sockaddr_in la = sa;
+    if (const char* b = std::getenv("SVO_RIG_BIND")) {
+      if (::inet_pton(AF_INET, b, &la.sin_addr) != 1) throw std::runtime_error("pose exchange bootstrap: SVO_RIG_BIND must be an IPv4 address");
+    }
+    int rc = ::bind(ls.fd, reinterpret_cast<sockaddr*>(&la), sizeof(la));
+    if (rc != 0 && errno == EADDRNOTAVAIL && !std::getenv("SVO_RIG_BIND")) {
+      la.sin_addr.s_addr = htonl(INADDR_ANY);
+      rc = ::bind(ls.fd, reinterpret_cast<sockaddr*>(&la), sizeof(la));
+      if (rc == 0 && token == 0)
+        std::fprintf(stderr, "pose exchange bootstrap: listening on every interface without SVO_RIG_TOKEN: set a job secret\n");
+    }
+    if (rc != 0 || ::listen(ls.fd, world) != 0) throw std::runtime_error("pose exchange bootstrap: cannot listen on MASTER_ADDR:port");
     timeval tv = {timeout_s, 0};
+    // a connection has this long to introduce itself: one silent stranger must not use up the whole deadline
+    timeval tv_hello = {timeout_s < 2 ? timeout_s : 2, 0};
     if (::setsockopt(ls.fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv)) != 0)
       throw std::runtime_error("pose exchange bootstrap: setsockopt(SO_RCVTIMEO) failed");
     // the blob goes to ranks 1..world-1 of THIS job, once each: a peer introduces itself first; anything else that
@@ -86,7 +103,7 @@ void tcpBroadcast(int rank, int world, const std::string& addr, int port, void* 
       if (std::chrono::steady_clock::now() > deadline) throw std::runtime_error("pose exchange bootstrap: a rank did not connect in time");
       Fd c(::accept(ls.fd, NULL, NULL));
       if (c.fd < 0) throw std::runtime_error("pose exchange bootstrap: a rank did not connect in time");
-      ::setsockopt(c.fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+      ::setsockopt(c.fd, SOL_SOCKET, SO_RCVTIMEO, &tv_hello, sizeof(tv_hello));
       Hello h;
       try {
         recvAll(c.fd, &h, sizeof(h));

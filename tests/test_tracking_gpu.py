@@ -23,9 +23,10 @@ pytestmark = pytest.mark.gpu
 # the seeds come back with identical bits in all four fields (the rest: an exp that rounds the other way); largest
 # relative deviation a 2.07e-5, b 2.04e-5, mu 1.7e-7, sigma2 1.7e-4 (a difference of two nearly equal products).
 AB_RTOL_SAME_INPUTS = 1e-4   # 5 x the measured maximum
-# In updateSeeds the inputs themselves (x = 1 / z, tau^2) come out of f64 geometry through acos / atan / sin, which differ in
-# the last bits between glibc and the GPU's libm, and x is then rounded to float: a and b see that amplified.
-AB_RTOL = 5e-3
+# In updateSeeds the inputs themselves (x = 1 / z, tau^2) come out of f64 geometry through acos / atan / sin, which can differ
+# in the last bits between glibc and the GPU's libm before x is rounded to float.  Measured on the GPU box (this test prints
+# it): 0.0 -- identical a and b -- on all 255 compared seeds of each of the six runs (3 option sets x 2 checkers).
+AB_RTOL = 1e-4
 
 
 @pytest.fixture(scope="module")
