@@ -87,6 +87,7 @@ struct SeedArgs {
   double* depth_out;
   int32_t* ok_out;
   int32_t* search_level_out;
+  double px_error_angle;  // atan(1 / (2 |fx|)) * 2
   SeedWs ws;
 };
 
@@ -667,11 +668,10 @@ __global__ void __launch_bounds__(64) seed_finish_kernel(const SeedArgs a) {
     a.status_out[s] = SVO_HIP_SEED_NO_MATCH;
     return;
   }
-  const double focal_length = fabs(a.cam.fx);
-  const double px_noise = 1.0;
-  const double px_error_angle = atan(px_noise / (2.0 * focal_length)) * 2.0;
+  // law of chord (depth_filter.cpp:252-255): atan(px_noise / (2 * focal_length)) * 2 depends on the camera alone -- computed
+  // once on the host (run_seed_chain), by the libm the reference itself runs on
   const Se3 T_ref_cur = se3_compose(Tr, se3_inverse(Tc));
-  const double tau = compute_tau(T_ref_cur, f, z, px_error_angle);
+  const double tau = compute_tau(T_ref_cur, f, z, a.px_error_angle);
   const double zmt = (0.0000001 < z - tau) ? z - tau : 0.0000001;
   const double tau_inverse = 0.5 * (1.0 / zmt - 1.0 / (z + tau));
   update_seed((float)(1. / z), (float)(tau_inverse * tau_inverse), sa, sb, smu, zr, ssig);
@@ -835,6 +835,10 @@ static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_sto
                           size_t workspace_bytes, hipStream_t st) {
   Carver c(d_workspace, workspace_bytes);
   const size_t n = (size_t)S;
+  {
+    const double focal_length = fabs(a.cam.fx), px_noise = 1.0;
+    a.px_error_angle = atan(px_noise / (2.0 * focal_length)) * 2.0;
+  }
   SeedWs& w = a.ws;
   w.n_steps = c.take<int32_t>(n);  // first array of the workspace: svo_hip_update_seeds_scan_steps
   w.pwb = c.take<uint8_t>(n * 100);
