@@ -255,6 +255,96 @@ __device__ __forceinline__ void se3_exp_f32(const float xi[6], float q[4], float
   t[2] = uz + c1 * wz + c2 * wwz;
 }
 
+// The two halves of se3_exp_f32 on their own, for a solve that is split over two waves (sparse_align.hip): the rotation
+// part -- the unit quaternion of exp(omega^) -- and the translation part V(omega) * upsilon.  Same series, same
+// coefficients, same order of operations as se3_exp_f32, so each half returns the bits the whole returns.
+__device__ __forceinline__ void se3_exp_rot_f32(const float xi[6], float q[4]) {
+  const float ox = xi[3], oy = xi[4], oz = xi[5];
+  const float z = ox * ox + oy * oy + oz * oz;
+  const float y = 0.25f * z;
+  float a, w;
+#ifndef SE3_EXP_LONG_ONLY
+  if (z < 0.01f) {
+    a = 1.f / 5040.f;
+    a = a * -y + 1.f / 120.f;
+    a = a * -y + 1.f / 6.f;
+    a = a * -y + 1.f;
+    w = 1.f / 720.f;
+    w = w * -y + 1.f / 24.f;
+    w = w * -y + 0.5f;
+    w = w * -y + 1.f;
+  } else
+#endif
+  {
+    a = 1.f / 355687428096000.f;
+    a = a * -y + 1.f / 1307674368000.f;
+    a = a * -y + 1.f / 6227020800.f;
+    a = a * -y + 1.f / 39916800.f;
+    a = a * -y + 1.f / 362880.f;
+    a = a * -y + 1.f / 5040.f;
+    a = a * -y + 1.f / 120.f;
+    a = a * -y + 1.f / 6.f;
+    a = a * -y + 1.f;
+    w = 1.f / 20922789888000.f;
+    w = w * -y + 1.f / 87178291200.f;
+    w = w * -y + 1.f / 479001600.f;
+    w = w * -y + 1.f / 3628800.f;
+    w = w * -y + 1.f / 40320.f;
+    w = w * -y + 1.f / 720.f;
+    w = w * -y + 1.f / 24.f;
+    w = w * -y + 0.5f;
+    w = w * -y + 1.f;
+  }
+  const float imag = 0.5f * a;
+  q[0] = w;
+  q[1] = imag * ox;
+  q[2] = imag * oy;
+  q[3] = imag * oz;
+}
+__device__ __forceinline__ void se3_exp_trans_f32(const float xi[6], float t[3]) {
+  const float ox = xi[3], oy = xi[4], oz = xi[5];
+  const float z = ox * ox + oy * oy + oz * oz;
+  float c1, c2;
+#ifndef SE3_EXP_LONG_ONLY
+  if (z < 0.01f) {
+    c1 = 1.f / 40320.f;
+    c1 = c1 * -z + 1.f / 720.f;
+    c1 = c1 * -z + 1.f / 24.f;
+    c1 = c1 * -z + 0.5f;
+    c2 = 1.f / 362880.f;
+    c2 = c2 * -z + 1.f / 5040.f;
+    c2 = c2 * -z + 1.f / 120.f;
+    c2 = c2 * -z + 1.f / 6.f;
+  } else
+#endif
+  {
+    c1 = 1.f / 6402373705728000.f;
+    c1 = c1 * -z + 1.f / 20922789888000.f;
+    c1 = c1 * -z + 1.f / 87178291200.f;
+    c1 = c1 * -z + 1.f / 479001600.f;
+    c1 = c1 * -z + 1.f / 3628800.f;
+    c1 = c1 * -z + 1.f / 40320.f;
+    c1 = c1 * -z + 1.f / 720.f;
+    c1 = c1 * -z + 1.f / 24.f;
+    c1 = c1 * -z + 0.5f;
+    c2 = 1.f / 121645100408832000.f;
+    c2 = c2 * -z + 1.f / 355687428096000.f;
+    c2 = c2 * -z + 1.f / 1307674368000.f;
+    c2 = c2 * -z + 1.f / 6227020800.f;
+    c2 = c2 * -z + 1.f / 39916800.f;
+    c2 = c2 * -z + 1.f / 362880.f;
+    c2 = c2 * -z + 1.f / 5040.f;
+    c2 = c2 * -z + 1.f / 120.f;
+    c2 = c2 * -z + 1.f / 6.f;
+  }
+  const float ux = xi[0], uy = xi[1], uz = xi[2];
+  const float wx = oy * uz - oz * uy, wy = oz * ux - ox * uz, wz = ox * uy - oy * ux;
+  const float wwx = oy * wz - oz * wy, wwy = oz * wx - ox * wz, wwz = ox * wy - oy * wx;
+  t[0] = ux + c1 * wx + c2 * wwx;
+  t[1] = uy + c1 * wy + c2 * wwy;
+  t[2] = uz + c1 * wz + c2 * wwz;
+}
+
 // q <- q / |q| for a quaternion that is already close to unit length or not:
 // v_rsq_f64 seed + two Newton steps (no f64 sqrt / division sequences).
 __device__ __forceinline__ void quat_normalize_fast(double q[4]) {

@@ -82,10 +82,26 @@ struct WaveModel {
 };
 
 // Workgroup state (file-scope LDS).
+// Round 4: the serial solve / update step of an iteration is split over TWO waves of the workgroup (default; build with
+// -DSIA_SINGLE_SOLVER for the one-solver-wave step of rounds 2-3): 1.119 against 1.139 ms per 16384-frame launch in three
+// alternating pairs (profiles/r04j_k1_split_solve_ab.txt), 120 VGPRs, parity unchanged.
+#ifndef SIA_SINGLE_SOLVER
+#define SIA_SPLIT_SOLVE 1
+#endif
+
+// SIA_SPLIT_SOLVE: the model as TWO solver waves share it.  q and t are double-buffered by update parity: an update reads
+// buffer `cur` and writes buffer `cur ^ 1`, so the wave that composes the translation can read the quaternion the other
+// wave is replacing, and old_model (the rollback of vk::NLLSSolver) is simply the buffer the last update came from --
+// no copies.
+struct SplitModel {
+  double q[2][4], t[2][3];
+};
+
 struct SiaLds {
   WaveModel wm[MAX_WAVES];
+  SplitModel sm;
   double Rt[12];                 // pose published by the solver wave of the iteration
-  int sw_done, sw_stop, sw_nmeas;
+  int sw_done, sw_stop, sw_nmeas, sw_cur, sw_old;
   double sw_chi2;
   double H[21];                  // H_ of the last evaluated iteration (packed upper triangle)
   double Hinv[36];               // its inverse, row-major
@@ -305,7 +321,16 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       for (int k = 0; k < 4; ++k) wm.q[k] = wm.oq[k] = q[k];
       for (int k = 0; k < 3; ++k) wm.t[k] = wm.ot[k] = tr[k];
     }
+#ifdef SIA_SPLIT_SOLVE
+    if (tid == 0) {
+      for (int k = 0; k < 4; ++k) g_s.sm.q[0][k] = q[k];
+      for (int k = 0; k < 3; ++k) g_s.sm.t[0][k] = tr[k];
+    }
+#endif
   }
+#ifdef SIA_SPLIT_SOLVE
+  int m_cur = 0, m_old = 0;  // parity buffer holding the model / old_model (uniform over the workgroup)
+#endif
   // vk::NLLSSolver::reset(): wave-uniform solver state
   double chi2_prev = 1e10;
   int stop = 0;
@@ -441,6 +466,9 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
     // ---- vk::NLLSSolver::optimizeGaussNewton ------------------------------
     // old_model = model at the start of every optimize() call: a stop at the first evaluation of
     // this level (NaN solve, stop_ carried over) keeps the pose the previous level ended with
+#ifdef SIA_SPLIT_SOLVE
+    m_old = m_cur;
+#else
     if (wave == sw && lane == 0) {
       WaveModel& wm0 = g_s.wm[wave];
 #pragma unroll
@@ -448,6 +476,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
 #pragma unroll
       for (int k = 0; k < 3; ++k) wm0.ot[k] = wm0.t[k];
     }
+#endif
     int inH = -1;  // membership of this lane in the sum that g_s.H currently holds
     int evals = 0;
     SIA_ACC(5, tl0, SIA_T());
@@ -783,6 +812,126 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       // issue slots on it); which wave rotates with the workgroup id so that the solver waves of the
       // workgroups sharing a CU do not pile up on one SIMD.  The others take the second barrier
       // and pick the new pose up from LDS.
+#ifdef SIA_SPLIT_SOLVE
+      // TWO waves share the serial step: wave `sw` composes the rotation (quaternion part of SE3::exp, quaternion product,
+      // normalisation, q -> R), wave `sw + 1` the translation (V(omega) upsilon, rotated by the OLD quaternion, added to
+      // the old translation).  Each forms the totals, x = H^-1 Jres and the stop / rollback decision for itself (the
+      // same ~40 instructions on the same LDS words, hence the same decision) and then runs its half: the dependent
+      // chain between the two barriers is ~130 instructions instead of ~310, on two SIMDs.
+      const int swb = (NW > 1) ? (sw + 1) % NW : sw;
+      const bool rot_wave = wave == sw, trans_wave = wave == swb;
+      int m_next = m_cur;  // (both solver waves compute it; the others read it from LDS behind the barrier)
+      if (rot_wave || trans_wave) {
+#ifndef SIA_NO_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        double colsum = 0.0;
+        {
+          const int k = lane & 7;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) colsum += (double)g_s.part[buf][w][k];
+        }
+        const double b0 = readlane_f64<0>(colsum), b1 = readlane_f64<1>(colsum), b2 = readlane_f64<2>(colsum);
+        const double b3 = readlane_f64<3>(colsum), b4 = readlane_f64<4>(colsum), b5 = readlane_f64<5>(colsum);
+        const float chi2_sum = (float)readlane_f64<6>(colsum);
+        const int n_meas = (int)readlane_f64<7>(colsum);
+        double xi;
+        {
+          const double* row = &g_s.Hinv[6 * (lane < 6 ? lane : 0)];
+          xi = row[0] * b0 + row[1] * b1 + row[2] * b2 + row[3] * b3 + row[4] * b4 + row[5] * b5;
+        }
+        const double x0 = readlane_f64<0>(xi), x1 = readlane_f64<1>(xi), x2 = readlane_f64<2>(xi);
+        const double x3 = readlane_f64<3>(xi), x4 = readlane_f64<4>(xi), x5 = readlane_f64<5>(xi);
+        n_meas_last = n_meas;
+        const double new_chi2 = (double)(chi2_sum / (float)n_meas);
+        if (isnan(x0)) stop = 1;  // solve(), :248-249
+        const SplitModel& sm = g_s.sm;
+        const bool rollback = (iter > 0 && new_chi2 > chi2_prev) || stop;
+        if (rollback) {
+          m_next = m_old;  // model = old_model: the buffer the last update came from
+          done = 1;
+        } else {
+          m_next = m_cur ^ 1;
+          m_old = m_cur;
+          chi2_prev = new_chi2;
+          const double nm = fmax(fmax(fmax(fabs(x0), fabs(x1)), fmax(fabs(x2), fabs(x3))), fmax(fabs(x4), fabs(x5)));
+          if (nm <= P.eps) done = 1;
+        }
+        // update(): T_new = T_old * SE3::exp(-x_)  (:253-258), each wave its half
+        const float mx[6] = {-(float)x0, -(float)x1, -(float)x2, -(float)x3, -(float)x4, -(float)x5};
+        if (rot_wave) {
+          double q[4];
+          if (rollback) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = sm.q[m_next][k];
+          } else {
+#ifdef SIA_F64_PARTIALS
+            const double mxd[6] = {-x0, -x1, -x2, -x3, -x4, -x5};
+            double eq[4], et_unused[3];
+            se3_exp(mxd, eq, et_unused);  // Sophus SE3::exp in f64, as the reference evaluates it
+#else
+            float eqf[4];
+            se3_exp_rot_f32(mx, eqf);
+            const double eq[4] = {eqf[0], eqf[1], eqf[2], eqf[3]};
+#endif
+            double oq[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) oq[k] = sm.q[m_cur][k];
+            quat_mul(oq, eq, q);
+            quat_normalize_fast(q);
+            if (lane == 0) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) g_s.sm.q[m_next][k] = q[k];
+            }
+          }
+          quat_to_R(q, R);
+          if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) g_s.Rt[k] = R[k];
+            g_s.sw_done = done;
+            g_s.sw_stop = stop;
+            g_s.sw_nmeas = n_meas_last;
+            g_s.sw_chi2 = chi2_prev;
+            g_s.sw_cur = m_next;
+            g_s.sw_old = m_old;
+          }
+        }
+        if (trans_wave) {
+          if (rollback) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tr[k] = sm.t[m_next][k];
+          } else {
+#ifdef SIA_F64_PARTIALS
+            const double mxd[6] = {-x0, -x1, -x2, -x3, -x4, -x5};
+            double eq_unused[4], et[3];
+            se3_exp(mxd, eq_unused, et);
+#else
+            float etf[3];
+            se3_exp_trans_f32(mx, etf);
+            const double et[3] = {etf[0], etf[1], etf[2]};
+#endif
+            double oq[4], rt[3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) oq[k] = sm.q[m_cur][k];
+            quat_rot(oq, et, rt);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tr[k] = sm.t[m_cur][k] + rt[k];
+            if (lane == 0) {
+#pragma unroll
+              for (int k = 0; k < 3; ++k) g_s.sm.t[m_next][k] = tr[k];
+            }
+          }
+          if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) g_s.Rt[9 + k] = tr[k];
+          }
+        }
+#ifndef SIA_NO_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+      }
+      m_cur = m_next;
+#else
       if (wave == sw)
 #ifndef SIA_DBG_NOSOLVE
       {
@@ -879,6 +1028,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
 #endif
       }
 #endif
+#endif
       if (NW > 1) {
         __syncthreads();
 #pragma unroll
@@ -889,6 +1039,10 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
         stop = g_s.sw_stop;
         n_meas_last = g_s.sw_nmeas;
         chi2_prev = g_s.sw_chi2;
+#ifdef SIA_SPLIT_SOLVE
+        m_cur = g_s.sw_cur;
+        m_old = g_s.sw_old;
+#endif
       }
       buf ^= 1;
       SIA_ACC(4, ts0, SIA_T());
