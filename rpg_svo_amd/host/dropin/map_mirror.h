@@ -105,6 +105,10 @@ class MapMirror {
     return true;
   }
 
+  // The caller hands this frame to the list-walking path: what that path does to the map (types, deletions, the points
+  // Point::optimize moves afterwards) goes unobserved, so the next call starts from a fresh walk.
+  void invalidate() { valid_ = false; }
+
   // this call's own changes (reprojector.cpp:108-123, 165-180)
   void markType(int32_t e, int32_t type) { pts_[(size_t)e].type = type; touch(e); }
   void markDead(int32_t e) {

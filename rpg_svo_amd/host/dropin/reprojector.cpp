@@ -116,22 +116,25 @@ bool reprojectMapMirrored(const FramePtr& frame, std::vector<std::pair<FramePtr,
                           size_t& n_trials_) {
   using namespace hip_dropin;
   const size_t n_cells = grid_.cells.size();
-  const size_t T_CAP = 4096, V_CAP = 4096;  // trials / visits one batch can hold (status 1 beyond: the other path)
+  // trials / visits one batch can hold (status 1 beyond: the frame takes the list-walking path; SVO_HIP_MIRROR_TRIALS
+  // overrides the trial capacity: the tests use it to force that hand-over)
+  static const long t_cap_override = [] { const char* v = std::getenv("SVO_HIP_MIRROR_TRIALS"); return v ? std::atol(v) : 0L; }();
+  const size_t T_CAP = t_cap_override > 0 ? (size_t)t_cap_override : 4096, V_CAP = 4096;
   if (n_cells > (size_t)SVO_HIP_REPROJ_MAX_CELLS || options_.max_n_kfs > 16) return false;
   MapMirror& mm = mirrorOf(&map_);
   ++mm.stats.calls;
   std::list<KfDist> close_kfs;
   map_.getCloseKeyframes(frame, close_kfs);
   close_kfs.sort(closerKf);
-  if (!mm.sync(map_)) { ++mm.stats.fallbacks; return false; }
+  if (!mm.sync(map_)) { ++mm.stats.fallbacks; mm.invalidate(); return false; }
   svo_hip::Device& dev = ensureDevice(*frame);
   const size_t n_tab = mm.frames().size() + 1;  // the mirror's frames, then the current one
-  if ((size_t)dev.slots() < n_tab + 2) { ++mm.stats.fallbacks; return false; }  // every keyframe resident at once
+  if ((size_t)dev.slots() < n_tab + 2) { ++mm.stats.fallbacks; mm.invalidate(); return false; }  // every keyframe resident at once
   std::vector<int32_t> rank_of(n_tab, -1);
   std::vector<std::pair<FramePtr, int> > ranked;  // (keyframe, its index in the frame table), closest first
   for (std::list<KfDist>::iterator kf = close_kfs.begin(); kf != close_kfs.end() && ranked.size() < options_.max_n_kfs; ++kf) {
     const int idx = mm.frameIndex(kf->first.get());
-    if (idx < 0) { ++mm.stats.fallbacks; return false; }  // (a keyframe of the map the mirror does not know: cannot happen after sync)
+    if (idx < 0) { ++mm.stats.fallbacks; mm.invalidate(); return false; }  // (a keyframe of the map the mirror does not know: cannot happen after sync)
     rank_of[(size_t)idx] = (int32_t)ranked.size();
     ranked.push_back(std::make_pair(kf->first, idx));
   }
@@ -302,7 +305,7 @@ bool reprojectMapMirrored(const FramePtr& frame, std::vector<std::pair<FramePtr,
   static const long first_batch_override = [] { const char* v = std::getenv("SVO_HIP_FIRST_BATCH_CELLS"); return v ? std::atol(v) : 0L; }();
   const size_t first_batch_cells = first_batch_override > 0 ? (size_t)first_batch_override
                                                             : (size_t)Config::maxFts() + 1 + ((size_t)Config::maxFts() + 1) / 3 + 8;
-  if (!runBatch(0, first_batch_cells)) { ++mm.stats.fallbacks; return false; }
+  if (!runBatch(0, first_batch_cells)) { ++mm.stats.fallbacks; mm.invalidate(); return false; }
 
   // ---- 1. overlap_kfs: (keyframe, points of it that fell inside the frame), closest first (:82-102)
   overlap_kfs.reserve(options_.max_n_kfs);

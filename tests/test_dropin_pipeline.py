@@ -324,9 +324,13 @@ def test_mock_device_map_mirror_is_the_list_walk(mock_lib, tmp_path):
     # comparison, but verify must hold -- it tolerates only candidates that arrived after the call's tail read)
     _, s_thr = _run_mirror("hipmock", 100, {"SVO_HIP_MAP_MIRROR": "verify"}, tmp_path, "thr", mapper_thread=1)
     assert s_thr["calls"] == 99 and s_thr["fallbacks"] == 0
+    # a batch with more trials than the call has room for (capacity forced down to 64): the kernel reports it, what was
+    # enqueued behind it is dropped and the frame takes the list-walking path -- every frame here
+    cap, s_cap = _run_mirror("hipmock", 60, {"SVO_HIP_MAP_MIRROR": "verify", "SVO_HIP_MIRROR_TRIALS": "64"}, tmp_path, "cap")
+    assert np.array_equal(cap, ref60) and s_cap["fallbacks"] >= 55 and s_cap["hits"] == 59
     # a pool that cannot hold every keyframe at once: the frame takes the list-walking path (which pins only the
     # keyframes that serve as reference), same result
-    small, s_small = _run_mirror("hipmock", 130, {"SVO_HIP_MAP_MIRROR": "on"}, tmp_path, "small", pool_slots=7)
+    small, s_small = _run_mirror("hipmock", 130, {"SVO_HIP_MAP_MIRROR": "verify"}, tmp_path, "small", pool_slots=7)
     ref130, _ = _run_mirror("hipmock", 130, {"SVO_HIP_MAP_MIRROR": "off"}, tmp_path, "off130", pool_slots=7)
     assert np.array_equal(small, ref130) and 0 < s_small["fallbacks"] < 129   # (mirrored while the keyframes still fit)
 
