@@ -50,6 +50,12 @@ namespace {
 // (1.40 against 1.50 ms on the headline batch); one 8-byte value is spilled once per level.  64/128-lane
 // workgroups are not limited by registers.  The distorted-camera instantiations (no window cache, the model's
 // world2cam in the loop) stay at 3 waves per SIMD where the workgroup size allows: at 4 they spill 22 dwords.
+// SIA_FIVE_FRAMES (experiment, round 4): five frames per CU instead of four -- the reference tile sized to 208 patches
+// (32.2 KB of LDS per frame instead of 38.4) and the register allocation held to 96 VGPRs (15 dwords spilled)
+#ifdef SIA_FIVE_FRAMES
+#define SIA_TILE_SLOTS 208
+#define MINW(BLOCK) ((BLOCK) == 256 ? 5 : ((BLOCK) > 256 ? 4 : 3))
+#endif
 #ifndef MINW
 #define MINW(BLOCK) ((BLOCK) >= 256 ? 4 : 3)
 #endif
@@ -258,7 +264,15 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
   // dx,dy (:133-136) are central differences of Bt, rebuilt in flight.
   //   q0 = r0 c1..4 | q1 = r1 c0..3 | q2 = r1 c4,5 r2 c0,1 | q3 = r2 c2..5
   //   q4 = r3 c0..3 | q5 = r3 c4,5 r4 c0,1 | q6 = r4 c2..5 | q7 = r5 c1..4
-  __shared__ float4 s_bt[8][BLOCK];
+  // SIA_TILE_SLOTS (experiment: five frames per CU): the tile holds that many patches instead of one per lane; a frame
+  // must not have more (lanes beyond share the last slot: they carry no patch)
+#ifdef SIA_TILE_SLOTS
+  constexpr int TS = (BLOCK == 256) ? SIA_TILE_SLOTS : BLOCK;
+#else
+  constexpr int TS = BLOCK;
+#endif
+  __shared__ float4 s_bt[8][TS];
+  const int ts = TS == BLOCK ? (int)threadIdx.x : ((int)threadIdx.x < TS ? (int)threadIdx.x : TS - 1);
   __shared__ uint32_t s_touch[(SIA_TOUCH_NEXT && WC) ? BLOCK : 1];  // landing row of the fetch-ahead touches (never read)
 
   int n = a.n[b];
@@ -583,7 +597,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
           // rows 1-4: (0,2) (1,3) (4,5), from which (2,4) and (3,5) are put together
           const float2* const bt2 = reinterpret_cast<const float2*>(&s_bt[0][0]);
           // float2 index of (quad q, half h) of this lane: (q * BLOCK + tid) * 2 + h
-#define SIA_BT2(q, h) bt2[((q) * BLOCK + tid) * 2 + (h)]
+#define SIA_BT2(q, h) bt2[((q) * TS + ts) * 2 + (h)]
           const f2 vtl = f2{wtl, wtl}, vtr = f2{wtr, wtr}, vbl = f2{wbl, wbl}, vbr = f2{wbr, wbr};
           f2 c2v = f2{0.f, 0.f}, gxv = f2{0.f, 0.f}, gyv = f2{0.f, 0.f};
           f2 t02, t13, t24, b02, b13, b24;  // window rows y and y+1
@@ -673,8 +687,8 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
 #endif
           float Bt[6][6];
           {
-            const float4 q0 = s_bt[0][tid], q1 = s_bt[1][tid], q2 = s_bt[2][tid], q3 = s_bt[3][tid];
-            const float4 q4 = s_bt[4][tid], q5 = s_bt[5][tid], q6 = s_bt[6][tid], q7 = s_bt[7][tid];
+            const float4 q0 = s_bt[0][ts], q1 = s_bt[1][ts], q2 = s_bt[2][ts], q3 = s_bt[3][ts];
+            const float4 q4 = s_bt[4][ts], q5 = s_bt[5][ts], q6 = s_bt[6][ts], q7 = s_bt[7][ts];
             Bt[0][0] = Bt[0][5] = Bt[5][0] = Bt[5][5] = 0.f;
             Bt[0][1] = q0.x; Bt[0][2] = q0.y; Bt[0][3] = q0.z; Bt[0][4] = q0.w;
             Bt[1][0] = q1.x; Bt[1][1] = q1.y; Bt[1][2] = q1.z; Bt[1][3] = q1.w;

@@ -415,6 +415,8 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
     const bool done = reprojectMapMirrored(frame, overlap_kfs, map_, grid_, options_, matcher_.options_.align_max_iter, n_matches_, n_trials_);
     SVO_STOP_TIMER("feature_align");
     if (done) return;
+  } else if (hip_dropin::MapMirror::mode() != hip_dropin::MapMirror::OFF) {
+    mirrorOf(&map_).invalidate();  // this call changes the map without the mirror looking
   }
 
   // ---- 1. keyframes sharing the field of view, closest first; bin their points --------------
