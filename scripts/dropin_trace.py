@@ -91,6 +91,7 @@ def report(d, frame=-1):
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--report":
-        report(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else -1)
+        rest = [a for a in sys.argv[3:] if not a.startswith("frames=")]
+        report(sys.argv[2], int(rest[0]) if rest else -1)
     else:
         run(1 if "defer" in sys.argv[1:] else 0)
