@@ -323,35 +323,37 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
   // position of the step before, and does the expensive part -- camera model, rounding, the 8x8 ZMSSD -- for its
   // own steps only, all lanes of the group at once.  "Same pixel as the last step looked at" is "same pixel as step i-1":
   // last_x/last_y are overwritten by every step that differs from them, so they always hold step i-1's pixel.
-  double pv0 = 0, pv1 = 0;  // position of step i-1
+  // The pixel of step i-1 is the pixel the lane to the left computed in this pass (the same chain of additions, the same
+  // arithmetic: the same bits), and for the group's first lane the pixel its last lane computed in the pass before:
+  // one DPP move per coordinate instead of a second camera projection and rounding per position (round 4).
   {
     const int lead = lane < n_total ? lane : n_total;
     for (int j = 0; j < lead; ++j) {
-      pv0 = uv0; pv1 = uv1;
       uv0 += step0; uv1 += step1;
     }
   }
+  int carry0 = 0, carry1 = 0;  // pixel of the last step of the pass before (last_x, last_y before the first step: 0, 0)
   for (int base = 0; base < n_total; base += SCAN_G) {
     const int i = base + lane;
     bool want = false;  // this lane's position is new (not the pixel of the step before) and its patch lies inside the frame
     int pxi0 = 0, pxi1 = 0;
     if (i < n_total) {
       double pxs[2];
-      {
-        const double uvs[2] = {uv0, uv1};
-        world2cam_uv(a.cam, uvs, pxs);  // cur_frame.cam_->world2cam(uv), matcher.cpp:269
-      }
+      const double uvs[2] = {uv0, uv1};
+      world2cam_uv(a.cam, uvs, pxs);  // cur_frame.cam_->world2cam(uv), matcher.cpp:269
       pxi0 = cast_int(pxs[0] * inv_lvl + 0.5);
       pxi1 = cast_int(pxs[1] * inv_lvl + 0.5);
-      int prv0 = 0, prv1 = 0;  // last_x, last_y before the first step
-      if (i > 0) {
-        double pps[2];
-        const double pvs[2] = {pv0, pv1};
-        world2cam_uv(a.cam, pvs, pps);
-        prv0 = cast_int(pps[0] * inv_lvl + 0.5);
-        prv1 = cast_int(pps[1] * inv_lvl + 0.5);
-      }
-      want = !(pxi0 == prv0 && pxi1 == prv1) && is_in_frame_level(a.cam, pxi0, pxi1, 8, sl);
+    }
+    {
+      // (every lane takes part in the cross-lane moves; a lane whose step does not exist is never anybody's i-1)
+      // (row_shr:1 stays inside a row of 16 lanes: groups of more lanes -- experimental builds -- take a shuffle)
+      const int left0 = SCAN_G <= 16 ? __builtin_amdgcn_update_dpp(0, pxi0, 0x111 /* row_shr:1 */, 0xf, 0xf, true) : __shfl_up(pxi0, 1, 64);
+      const int left1 = SCAN_G <= 16 ? __builtin_amdgcn_update_dpp(0, pxi1, 0x111, 0xf, 0xf, true) : __shfl_up(pxi1, 1, 64);
+      const int prv0 = lane == 0 ? carry0 : left0, prv1 = lane == 0 ? carry1 : left1;
+      want = i < n_total && !(pxi0 == prv0 && pxi1 == prv1) && is_in_frame_level(a.cam, pxi0, pxi1, 8, sl);
+      const int last = (int)(threadIdx.x & 63u & ~(unsigned)(SCAN_G - 1)) + SCAN_G - 1;  // the group's last lane
+      carry0 = __shfl(pxi0, last, 64);
+      carry1 = __shfl(pxi1, last, 64);
     }
     uint32_t sumB = 0, sumBB = 0, sumAB = 0;
     bool boxed = false;
@@ -433,11 +435,9 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
       }
     }
     if (base + SCAN_G < n_total) {  // on to this lane's next step: SCAN_G more additions
-      for (int j = 0; j < SCAN_G - 1; ++j) {
+      for (int j = 0; j < SCAN_G; ++j) {
         uv0 += step0; uv1 += step1;
       }
-      pv0 = uv0; pv1 = uv1;
-      uv0 += step0; uv1 += step1;
     }
   }
   // first strictly smaller score along the line == lexicographic minimum of (score, step)
