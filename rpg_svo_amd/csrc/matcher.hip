@@ -15,6 +15,8 @@
 // Everything a later stage needs travels through a caller-provided workspace, so the whole
 // chain is three launches on one stream with no host synchronisation.
 #pragma clang fp contract(off)
+#include <type_traits>
+
 #include "track_kernels.h"
 #include "track_math.h"
 #include "matcher_device.h"
@@ -241,27 +243,39 @@ __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
               // hand-over inside the wave: DS operations of one wave execute in order
               __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
               __builtin_amdgcn_wave_barrier();
+              // The samples lie between the corner samples (see above), so when the box of the corners is inside the
+              // image every sample is: the usual trial skips the four comparisons and three selects per sample (the
+              // values are the same: `in` would be true everywhere).
+              const bool all_in = bx0 >= 0.f && by0 >= 0.f && bx1 < (float)(cols - 1) && by1 < (float)(rows - 1);
+              auto rows10 = [&](auto check_tag) {
+                constexpr bool CHECK = decltype(check_tag)::value;
 #pragma unroll
-              for (int y = 0; y < 10; ++y) {
-                float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
-                pp0 *= sc;
-                pp1 *= sc;
-                const float px0 = (A.x * pp0 + A.y * pp1) + pyr.x;
-                const float px1 = (A.z * pp0 + A.w * pp1) + pyr.y;
-                const bool in = !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
-                // vk::interpolateMat_8u (a sample outside the image is 0)
-                const float u = in ? px0 : (float)xlo, v = in ? px1 : (float)ylo;
-                const int xi = (int)floorf(u), yi = (int)floorf(v);
-                const float sx = u - (float)xi, sy = v - (float)yi;
-                const float w00 = (1.0f - sx) * (1.0f - sy);
-                const float w01 = (1.0f - sx) * sy;
-                const float w10 = sx * (1.0f - sy);
-                const float w11 = 1.0f - w00 - w01 - w10;
-                const uint8_t* q = reg + (yi - ylo) * 48 + (xi - cx0);
-                const float p00 = (float)q[0], p10 = (float)q[1], p01 = (float)q[48], p11 = (float)q[49];
-                const float val = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
-                out[y] = in ? (uint8_t)val : (uint8_t)0;
-              }
+                for (int y = 0; y < 10; ++y) {
+                  float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
+                  pp0 *= sc;
+                  pp1 *= sc;
+                  const float px0 = (A.x * pp0 + A.y * pp1) + pyr.x;
+                  const float px1 = (A.z * pp0 + A.w * pp1) + pyr.y;
+                  const bool in = !CHECK || !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
+                  // vk::interpolateMat_8u (a sample outside the image is 0)
+                  const float u = in ? px0 : (float)xlo, v = in ? px1 : (float)ylo;
+                  // (float)(int)floorf(u) IS floorf(u) here: the fraction is formed from the floor itself (two conversions
+                  // fewer per sample); the row offset is a 24-bit multiply (v_mul_lo_u32 issues at a quarter of the rate)
+                  const float fu = floorf(u), fv = floorf(v);
+                  const int xi = (int)fu, yi = (int)fv;
+                  const float sx = u - fu, sy = v - fv;
+                  const float w00 = (1.0f - sx) * (1.0f - sy);
+                  const float w01 = (1.0f - sx) * sy;
+                  const float w10 = sx * (1.0f - sy);
+                  const float w11 = 1.0f - w00 - w01 - w10;
+                  const uint8_t* q = reg + __mul24(yi - ylo, 48) + (xi - cx0);
+                  const float p00 = (float)q[0], p10 = (float)q[1], p01 = (float)q[48], p11 = (float)q[49];
+                  const float val = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
+                  out[y] = in ? (uint8_t)val : (uint8_t)0;
+                }
+              };
+              if (all_in) rows10(std::false_type{});
+              else rows10(std::true_type{});
               __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
               __builtin_amdgcn_wave_barrier();
             }
