@@ -160,6 +160,7 @@ def compact_line(result: dict, details_path: str | None) -> dict:
     ds = result.get("dropin_sequence")
     if isinstance(ds, dict):
         legs["dropin_sequence"] = _pick(ds, ("frames", "keyframes", "first_frame_with_a_different_decision", "se3_lognorm_max_before_it",
+                                             "first_frame_with_a_different_tracking_decision", "se3_lognorm_max_before_the_first_tracking_difference",
                                              "ate_rmse_vs_cpu_m", "ate_rmse_vs_ground_truth_m", "skipped"))
         lw = ds.get("median_ms_per_frame_hip_dropin_list_walking_reprojector")
         if isinstance(lw, dict) and "tot_time" in lw:
@@ -1395,6 +1396,10 @@ def dropin_sequence(n_frames: int = 600) -> dict:
     dec_keys = ("is_keyframe", "n_obs", "repr_n_mps", "repr_n_new_references", "n_kfs", "stage", "img_align_n_tracked",
                 "n_candidates", "n_seeds")
     first_diff = next((i for i, (a, b) in enumerate(zip(ref, hip)) if any(a[k] != b[k] for k in dec_keys)), None)
+    # ... and of the TRACKER's decisions alone (keyframes, matches, trials, tracked patches: the keys
+    # tests/test_dropin_pipeline.py compares over 120 frames), which the mapper's one-update shifts reach only later
+    trk_keys = ("is_keyframe", "n_obs", "repr_n_mps", "repr_n_new_references", "n_kfs", "stage", "img_align_n_tracked")
+    first_trk = next((i for i, (a, b) in enumerate(zip(ref, hip)) if any(a[k] != b[k] for k in trk_keys)), None)
     pre = slice(0, first_diff if first_diff is not None else n_frames)
     pos = lambda TT: se3.inv(TT)[:, 9:]
     med = lambda rs, k: float(np.median([r[k] for r in rs[1:]]) * 1e3)
@@ -1428,6 +1433,8 @@ def dropin_sequence(n_frames: int = 600) -> dict:
     return {"frames": n_frames, "map_size": map_size,
             "map_mirror": host.get("map_mirror"), "median_ms_per_frame_hip_dropin_list_walking_reprojector": list_walk,
             "first_frame_with_a_different_decision": first_diff,
+            "first_frame_with_a_different_tracking_decision": first_trk,
+            "se3_lognorm_max_before_the_first_tracking_difference": float(d[:first_trk if first_trk is not None else n_frames].max()),
             "se3_lognorm_max_before_it": float(d[pre].max()), "se3_lognorm_median_before_it": float(np.median(d[pre])),
             "ate_rmse_vs_ground_truth_m": {"cpu_reference": horn_ate(pos(Tr), pos(T)), "hip_dropin": horn_ate(pos(Th), pos(T))}, "image": "752x480", "se3_lognorm_max": float(d.max()), "se3_lognorm_median": float(np.median(d)),
             "ate_rmse_vs_cpu_m": horn_ate(se3.inv(Th)[:, 9:], se3.inv(Tr)[:, 9:]),
