@@ -56,16 +56,31 @@ def test_device_arena_and_pyramid_cache(hip_lib, gpu_device):
 EXAMPLE = os.path.join(ROOT, "build", "sparse_align_batch")
 
 
-def _build_example():
-    os.makedirs(os.path.dirname(EXAMPLE), exist_ok=True)
+EXAMPLE_MAP = os.path.join(ROOT, "build", "reproject_map")
+
+
+def _build_example(src="sparse_align_batch.cpp", exe=None):
+    exe = exe or EXAMPLE
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
     lib = os.path.join(ROOT, "rpg_svo_amd", "lib")
     subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "examples", "sparse_align_batch.cpp"), "-L", lib, "-lsvo_hip", f"-Wl,-rpath,{lib}",
-                    "-o", EXAMPLE], check=True)
+                    os.path.join(ROOT, "examples", src), "-L", lib, "-lsvo_hip", f"-Wl,-rpath,{lib}",
+                    "-o", exe], check=True)
 
 
 def test_cxx_example_builds(hip_lib):
     _build_example()
+    _build_example("reproject_map.cpp", EXAMPLE_MAP)
+
+
+@pytest.mark.gpu
+def test_cxx_map_mirror_example(hip_lib, gpu_device):
+    """svo_hip_reproject_map from plain C++ (examples/reproject_map.cpp): a map filled through a patch, one frame
+    reprojected, the visit list compared with a host walk written the reference's way."""
+    _build_example("reproject_map.cpp", EXAMPLE_MAP)
+    r = subprocess.run([EXAMPLE_MAP], capture_output=True, text=True, timeout=120)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "OK" in r.stdout and "equals the host walk" in r.stdout
 
 
 @pytest.mark.gpu
