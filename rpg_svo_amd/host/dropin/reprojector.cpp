@@ -333,6 +333,9 @@ bool reprojectMapMirrored(const FramePtr& frame, std::vector<std::pair<FramePtr,
   // ---- 4. per cell, in the shuffled order: the best-quality point that matched (:131-139, 151-200)
   svo_hip::Speculation& sp = lane.spec;
   std::vector<int32_t> selected;
+  std::vector<const void*> pred_point;  // what the device's selection must have picked, for the optimizer's drop-in to check
+  std::vector<double> pred_px;
+  std::vector<int32_t> pred_level, pred_trial;
   size_t v = 0;
   for (size_t i = 0; i < n_cells; ++i) {
     if (i == view.end_cell) {
@@ -372,10 +375,10 @@ bool reprojectMapMirrored(const FramePtr& frame, std::vector<std::pair<FramePtr,
         new_feature->grad.normalize();
       }
       if (predict) {
-        sp.point.push_back(pt);
-        sp.px.push_back(px[0]); sp.px.push_back(px[1]);
-        sp.level.push_back(view.lvl[m]);
-        sp.trial.push_back(m);
+        pred_point.push_back(pt);
+        pred_px.push_back(px[0]); pred_px.push_back(px[1]);
+        pred_level.push_back(view.lvl[m]);
+        pred_trial.push_back(m);
       }
       selected.push_back(e);
       matched = true;
@@ -383,7 +386,11 @@ bool reprojectMapMirrored(const FramePtr& frame, std::vector<std::pair<FramePtr,
     if (matched) ++n_matches_;
     if (n_matches_ > (size_t)Config::maxFts()) break;
   }
-  if (predict) sp.valid = !sp.point.empty();
+  if (predict) {  // published under the lane's mutex, in one piece (the lane's next call reads it under the same mutex)
+    std::lock_guard<std::mutex> guard(lane.mut);
+    sp.point.swap(pred_point); sp.px.swap(pred_px); sp.level.swap(pred_level); sp.trial.swap(pred_trial);
+    sp.valid = !sp.point.empty();
+  }
   mm.watch(selected);  // FrameHandlerBase::optimizeStructure may move these before the next frame
   return true;
 }
@@ -468,6 +475,9 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
   std::vector<double> R_px, R_A;                 // [trial][2], [trial][4]
   std::vector<int32_t> R_ok, R_lvl;              // [trial]
   std::vector<Feature*> R_ref;                   // [trial] Matcher::ref_ftr_
+  std::vector<const void*> pred_point;  // the prediction's features as the host selects them (published at the end)
+  std::vector<double> pred_px;
+  std::vector<int32_t> pred_level, pred_trial;
   bool predict = false;             // pose refinement of this frame has been enqueued behind the match kernels
   svo_hip::Lane* spec_lane = NULL;  // ... on this lane
   size_t enumerated_end = 0;        // cells [0, enumerated_end) of the visiting order have their trials
@@ -712,11 +722,10 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
         new_feature->grad.normalize();
       }
       if (predict) {  // what the device's selection must have picked, for the optimizer's drop-in to check
-        svo_hip::Speculation& sp = spec_lane->spec;
-        sp.point.push_back(pt);
-        sp.px.push_back(r.px[0]); sp.px.push_back(r.px[1]);
-        sp.level.push_back(r.search_level);
-        sp.trial.push_back(r.trial);
+        pred_point.push_back(pt);
+        pred_px.push_back(r.px[0]); pred_px.push_back(r.px[1]);
+        pred_level.push_back(r.search_level);
+        pred_trial.push_back(r.trial);
       }
       it = cell.erase(it);
       matched = true;  // at most one feature per cell
@@ -724,7 +733,12 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
     if (matched) ++n_matches_;
     if (n_matches_ > (size_t)Config::maxFts()) break;
   }
-  if (predict) spec_lane->spec.valid = !spec_lane->spec.point.empty();
+  if (predict) {  // published under the lane's mutex, in one piece
+    std::lock_guard<std::mutex> guard(spec_lane->mut);
+    svo_hip::Speculation& sp = spec_lane->spec;
+    sp.point.swap(pred_point); sp.px.swap(pred_px); sp.level.swap(pred_level); sp.trial.swap(pred_trial);
+    sp.valid = !sp.point.empty();
+  }
   SVO_STOP_TIMER("feature_align");
 }
 
