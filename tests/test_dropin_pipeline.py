@@ -606,3 +606,7 @@ def test_dropin_map_mirror_is_the_list_walk_on_the_gpu(pipeline_libs, gpu_device
     assert np.array_equal(ver, off)
     assert s_ver["counts"] == s_off["counts"]
     assert s_ver["calls"] == n - 1 and s_ver["fallbacks"] == 0 and s_ver["hits"] == n - 1 and s_ver["kfs"] >= 5
+    # the depth filter on its own thread (its kernels on the mapping lane's stream, candidates appended to the map while the
+    # tracker runs): verify holds, no frame leaves the mirror
+    _, s_thr = _run_mirror("hip", 100, {"SVO_HIP_MAP_MIRROR": "verify"}, tmp_path, "thr", mapper_thread=1)
+    assert s_thr["calls"] == 99 and s_thr["fallbacks"] == 0
