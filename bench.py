@@ -1049,6 +1049,24 @@ def valu_roofline(raw: dict, kernel_ms: float) -> dict:
             "wave_cycles_at_waitcnt_frac": frac_of_wave("SQ_WAIT_INST_ANY")}
 
 
+def lds_port_use(raw: dict) -> dict:
+    """Use of the LDS port from per-launch counter averages: SQ_LDS_IDX_ACTIVE are the cycles the LDS arrays of all CUs
+    work on indexed operations, SQ_LDS_BANK_CONFLICT the part of them lost to bank conflicts; GRBM_GUI_ACTIVE x 256 CUs
+    are the CU cycles of the launch (the formula of rocprofiler-sdk's derived LDS utilisation).  Every ratio is None
+    when its denominator was not collected."""
+    gui = raw.get("GRBM_GUI_ACTIVE")
+    idx, conf, n = raw.get("SQ_LDS_IDX_ACTIVE"), raw.get("SQ_LDS_BANK_CONFLICT"), raw.get("SQ_INSTS_LDS")
+    wc = raw.get("SQ_WAVE_CYCLES")
+    ratio = lambda a, b: (a / b) if (a is not None and b) else None
+    return {"port_busy_frac": ratio(idx, gui * N_CU if gui else None),
+            "bank_conflict_frac_of_port_cycles": ratio(conf, idx),
+            "port_cycles_per_lds_instruction": ratio(idx, n),
+            "lds_instructions_per_launch": n,
+            "wave_cycles_waiting_for_lds_issue_frac": ratio(4.0 * raw["SQ_WAIT_INST_LDS"] if "SQ_WAIT_INST_LDS" in raw else None, wc),
+            "wave_cycles_in_lds_instructions_frac": ratio(raw.get("SQ_ACTIVE_INST_LDS"), wc),
+            "port_busy_frac_vs_busy_cu_cycles": ratio(idx, raw.get("SQ_BUSY_CU_CYCLES"))}
+
+
 def pmc_leg(args, kernel_ms: float) -> dict:
     """HBM traffic and VALU issue of the headline kernel, measured on THIS box by re-running this
     command (headline leg only, 3 steps) under rocprofv3 --pmc, one counter group per pass as
@@ -1321,6 +1339,33 @@ def pmc_full_track_leg(args, n_steps: int = 2) -> dict:
         shutil.rmtree(d, ignore_errors=True)
     except subprocess.TimeoutExpired:
         status["sq"] = "timeout"
+    # ---- LDS pass: how busy the CU's one LDS port is (the four SIMDs of a CU share it) ----------------------------------
+    try:
+        d = tempfile.mkdtemp(prefix="svo_pmc_full_lds_", dir="/tmp")
+        ctrs = ["SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS", "SQ_WAVE_CYCLES",
+                "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"]
+        cmd = [exe, "--pmc", *ctrs, "--kernel-include-regex", regex, "--output-format", "csv", "-d", d, "-o", "lds", "--", *base]
+        p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=2 * PMC_PASS_TIMEOUT_S)
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            status["lds"] = f"rc={p.returncode}: {p.stderr[-200:]}"
+        else:
+            by = {}
+            with open(files[0]) as fh:
+                for row in csv.DictReader(fh):
+                    short = next((k for k in regex.split("|") if k in row["Kernel_Name"]), None)
+                    if short:
+                        by.setdefault(short, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for short, cs in by.items():
+                raw = {cn: float(np.mean(v)) for cn, v in cs.items()}
+                lds = lds_port_use(raw)
+                for kn in kernels:
+                    if kn.endswith("/" + short):
+                        kernels[kn]["lds"] = lds
+            status["lds"] = "ok"
+        shutil.rmtree(d, ignore_errors=True)
+    except subprocess.TimeoutExpired:
+        status["lds"] = "timeout"
     for kn, kd in kernels.items():
         stage, short = kn.split("/")
         t = stages.get(stage, {}).get("by_kernel", {}).get(short)

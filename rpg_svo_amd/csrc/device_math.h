@@ -7,6 +7,13 @@
 
 namespace svo_dev {
 
+// (int)floorf(x) in one instruction (v_cvt_flr_i32_f32; the compiler emits v_floor_f32 + v_cvt_i32_f32 for the C form)
+__device__ __forceinline__ int floor_to_int(float x) {
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 // Eigen QuaternionBase::toRotationMatrix; q = (w, x, y, z)
 __device__ __forceinline__ void quat_to_R(const double q[4], double R[9]) {
   const double w = q[0], x = q[1], y = q[2], z = q[3];

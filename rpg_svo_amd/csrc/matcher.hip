@@ -158,10 +158,13 @@ __global__ void __launch_bounds__(64) match_prepare_kernel(const PrepArgs a) {
 // coalesced dwords.  Arithmetic per sample is unchanged (bit-identical patches).
 constexpr int WARP_TPW = 6;  // trials per wave
 constexpr int WARP_REG_ROWS = 24;  // rows of the LDS copy of a trial's source region (48 bytes each)
+#ifndef WARP_MINW
+#define WARP_MINW 4  // waves per SIMD the register budget is held to
+#endif
 #ifndef WARP_WGS_PER_CU
 #define WARP_WGS_PER_CU 16
 #endif
-__global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
+__global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) {
   __shared__ long long s_off[SVO_HIP_MAX_LEVELS];
   __shared__ int s_w[SVO_HIP_MAX_LEVELS], s_h[SVO_HIP_MAX_LEVELS], s_p[SVO_HIP_MAX_LEVELS];
   __shared__ uint32_t s_patch[4][WARP_TPW * 25 + 2];
@@ -180,21 +183,48 @@ __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
   uint8_t* const my_patch = reinterpret_cast<uint8_t*>(s_patch[wave]);
   const int M = a.M_dev ? min(*a.M_dev, a.M) : a.M;
   const long long n_wave_groups = ((long long)M + WARP_TPW - 1) / WARP_TPW;
-  for (long long gw = (long long)blockIdx.x * 4 + wave; gw < n_wave_groups; gw += (long long)gridDim.x * 4) {
+  // An iteration of a wave is a chain of two memory round trips -- the parameters of its trials, then their source
+  // regions -- and the arithmetic; at four waves per SIMD the chain, not an execution unit, sets the pace (see the
+  // sample loop).  The parameters of the NEXT iteration are therefore requested before this iteration's work starts.
+  struct TrialParams {
+    float4 A;
+    float2 pyr;
+    int act, level, slot, slev;
+  };
+  auto load_params = [&](long long gw) {  // round 1: parameters of the trial (the 10 lanes of a trial read the same words)
+    TrialParams p;
+    p.A = make_float4(0.f, 0.f, 0.f, 0.f);
+    p.pyr = make_float2(0.f, 0.f);
+    p.act = p.level = p.slot = p.slev = 0;
+    const long long m = gw * WARP_TPW + t;
+    if (lane < 10 * WARP_TPW && m < M) {
+      p.A = *reinterpret_cast<const float4*>(a.A_ref_cur + 4 * (size_t)m);
+      p.pyr = *reinterpret_cast<const float2*>(a.px_ref_pyr + 2 * (size_t)m);
+      p.act = a.active[m];
+      p.level = a.ref_level[m];  // (masked where it is used: nothing here may wait for a load)
+      p.slot = a.ref_slot[m];
+      p.slev = a.search_level[m];
+    }
+    return p;
+  };
+  const long long gw_step = (long long)gridDim.x * 4;
+  long long gw = (long long)blockIdx.x * 4 + wave;
+  TrialParams nxt = load_params(gw < n_wave_groups ? gw : 0);
+  for (; gw < n_wave_groups; gw += gw_step) {
     const long long m0 = gw * WARP_TPW;
     const long long m = m0 + t;
     const bool lane_on = lane < 10 * WARP_TPW && m < M;
+    const TrialParams cur = nxt;
+#ifndef WARP_NO_PREFETCH
+    if (gw + gw_step < n_wave_groups) nxt = load_params(gw + gw_step);
+#endif
     uint8_t out[10];
 #pragma unroll
     for (int y = 0; y < 10; ++y) out[y] = 0;
     if (lane_on) {
-      // round 1: parameters of the trial (the 10 lanes of a trial read the same words)
-      const float4 A = *reinterpret_cast<const float4*>(a.A_ref_cur + 4 * (size_t)m);
-      const float2 pyr = *reinterpret_cast<const float2*>(a.px_ref_pyr + 2 * (size_t)m);
-      const int act = a.active[m];
-      const int level = a.ref_level[m] & (SVO_HIP_MAX_LEVELS - 1);
-      const int slot = a.ref_slot[m];
-      const int slev = a.search_level[m];
+      const float4 A = cur.A;
+      const float2 pyr = cur.pyr;
+      const int act = cur.act, level = cur.level & (SVO_HIP_MAX_LEVELS - 1), slot = cur.slot, slev = cur.slev;
       // "Affine warp is NaN": the reference leaves the previous patch in place; here: zeros
       if (act && !isnan(A.x)) {
         const uint8_t* img = a.store + (int64_t)slot * a.L.slot_bytes + s_off[level];
@@ -235,7 +265,24 @@ __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
               uint8_t* const reg = reinterpret_cast<uint8_t*>(s_region[wave][t]);
               const int n_chunks = nrow * nch;
               const uint32_t inv = nch == 1 ? 65536u : (nch == 2 ? 32768u : 21846u);  // c / nch for c < 128
-              for (int c = x; c < n_chunks; c += 10) {
+              // the first four chunks of a lane (boxes of up to 40 chunks: the usual 12 rows x 2 are 24) are requested
+              // together and parked afterwards -- as a loop of load-then-store the lane paid one round trip PER chunk
+              {
+                uint4 v[4];
+                int dst[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  const int c = x + 10 * k;
+                  const int row = (int)(((uint32_t)c * inv) >> 16), cc = c - row * nch;
+                  dst[k] = row * 48 + cc * 16;
+                  v[k] = make_uint4(0, 0, 0, 0);
+                  if (c < n_chunks) v[k] = *reinterpret_cast<const uint4*>(img + (svo_pyr::row_off(ylo + row, pitch) + svo_pyr::col_off(cx0 + 16 * cc)));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  if (x + 10 * k < n_chunks) *reinterpret_cast<uint4*>(reg + dst[k]) = v[k];
+              }
+              for (int c = x + 40; c < n_chunks; c += 10) {
                 const int row = (int)(((uint32_t)c * inv) >> 16), cc = c - row * nch;
                 const uint4 v = *reinterpret_cast<const uint4*>(img + (svo_pyr::row_off(ylo + row, pitch) + svo_pyr::col_off(cx0 + 16 * cc)));
                 *reinterpret_cast<uint4*>(reg + row * 48 + cc * 16) = v;
@@ -247,6 +294,16 @@ __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
               // image every sample is: the usual trial skips the four comparisons and three selects per sample (the
               // values are the same: `in` would be true everywhere).
               const bool all_in = bx0 >= 0.f && by0 >= 0.f && bx1 < (float)(cols - 1) && by1 < (float)(rows - 1);
+              // round 4b: floor and fraction of a coordinate with one instruction each (v_cvt_flr_i32_f32, v_fract_f32:
+              // u - floor(u) is exact for u >= 0, so the fraction has the same bits) and the sample's LDS address with one
+              // 24-bit multiply and one three-operand add: four vector instructions fewer per sample, same bits -- and
+              // the same time (profiles/r04q_*).  Neither are the LDS reads what the kernel waits for: the pixel pairs as
+              // 16-bit words from a second, shifted copy of the region (two aligned reads per sample instead of four)
+              // cost 3 % MORE for the extra byte gather of the fill (r04s_*), a bank-friendlier stride between the regions
+              // changed nothing (r04r_*); 16-bit reads at odd addresses, which gfx950 executes, doubled the kernel's time
+              // (r04p_*).  A wave's iteration is a chain of two memory round trips (the trial's parameters, then its
+              // region) and ~1300 cycles of arithmetic at four waves per SIMD: see the parameter prefetch at the loop head.
+              const uint8_t* const reg_o = reg - (__mul24(ylo, 48) + cx0);  // so that pixel (xi, yi) is reg_o[48 yi + xi]
               auto rows10 = [&](auto check_tag) {
                 constexpr bool CHECK = decltype(check_tag)::value;
 #pragma unroll
@@ -259,16 +316,13 @@ __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
                   const bool in = !CHECK || !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
                   // vk::interpolateMat_8u (a sample outside the image is 0)
                   const float u = in ? px0 : (float)xlo, v = in ? px1 : (float)ylo;
-                  // (float)(int)floorf(u) IS floorf(u) here: the fraction is formed from the floor itself (two conversions
-                  // fewer per sample); the row offset is a 24-bit multiply (v_mul_lo_u32 issues at a quarter of the rate)
-                  const float fu = floorf(u), fv = floorf(v);
-                  const int xi = (int)fu, yi = (int)fv;
-                  const float sx = u - fu, sy = v - fv;
+                  const int xi = svo_dev::floor_to_int(u), yi = svo_dev::floor_to_int(v);
+                  const float sx = __builtin_amdgcn_fractf(u), sy = __builtin_amdgcn_fractf(v);
                   const float w00 = (1.0f - sx) * (1.0f - sy);
                   const float w01 = (1.0f - sx) * sy;
                   const float w10 = sx * (1.0f - sy);
                   const float w11 = 1.0f - w00 - w01 - w10;
-                  const uint8_t* q = reg + __mul24(yi - ylo, 48) + (xi - cx0);
+                  const uint8_t* q = reg_o + (__mul24(yi, 48) + xi);
                   const float p00 = (float)q[0], p10 = (float)q[1], p01 = (float)q[48], p11 = (float)q[49];
                   const float val = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
                   out[y] = in ? (uint8_t)val : (uint8_t)0;
@@ -373,6 +427,9 @@ __global__ void __launch_bounds__(256) warp_kernel(const WarpArgs a) {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+#ifdef WARP_NO_PREFETCH
+    if (gw + gw_step < n_wave_groups) nxt = load_params(gw + gw_step);  // (A/B build: requested when they are needed)
+#endif
   }
 }
 
