@@ -1051,20 +1051,22 @@ def valu_roofline(raw: dict, kernel_ms: float) -> dict:
 
 def lds_port_use(raw: dict) -> dict:
     """Use of the LDS port from per-launch counter averages: SQ_LDS_IDX_ACTIVE are the cycles the LDS arrays of all CUs
-    work on indexed operations, SQ_LDS_BANK_CONFLICT the part of them lost to bank conflicts; GRBM_GUI_ACTIVE x 256 CUs
-    are the CU cycles of the launch (the formula of rocprofiler-sdk's derived LDS utilisation).  Every ratio is None
+    work on indexed operations, SQ_LDS_BANK_CONFLICT the part of them lost to bank conflicts, SQ_BUSY_CU_CYCLES the busy
+    cycles summed over the CUs (for K1 it equals 256 x kernel time x clock within 7 %).  rocprofiler-sdk's derived LDS
+    utilisation divides by GRBM_GUI_ACTIVE x CU_NUM instead; on this box that counter comes out about eight times the
+    kernel's cycles (one count per XCD), so that form is reported under its own name and not used.  Every ratio is None
     when its denominator was not collected."""
     gui = raw.get("GRBM_GUI_ACTIVE")
     idx, conf, n = raw.get("SQ_LDS_IDX_ACTIVE"), raw.get("SQ_LDS_BANK_CONFLICT"), raw.get("SQ_INSTS_LDS")
     wc = raw.get("SQ_WAVE_CYCLES")
     ratio = lambda a, b: (a / b) if (a is not None and b) else None
-    return {"port_busy_frac": ratio(idx, gui * N_CU if gui else None),
+    return {"port_busy_frac": ratio(idx, raw.get("SQ_BUSY_CU_CYCLES")),
             "bank_conflict_frac_of_port_cycles": ratio(conf, idx),
             "port_cycles_per_lds_instruction": ratio(idx, n),
             "lds_instructions_per_launch": n,
             "wave_cycles_waiting_for_lds_issue_frac": ratio(4.0 * raw["SQ_WAIT_INST_LDS"] if "SQ_WAIT_INST_LDS" in raw else None, wc),
             "wave_cycles_in_lds_instructions_frac": ratio(raw.get("SQ_ACTIVE_INST_LDS"), wc),
-            "port_busy_frac_vs_busy_cu_cycles": ratio(idx, raw.get("SQ_BUSY_CU_CYCLES"))}
+            "sdk_formula_idx_active_over_gui_active_x_cus": ratio(idx, gui * N_CU if gui else None)}
 
 
 def pmc_leg(args, kernel_ms: float) -> dict:
