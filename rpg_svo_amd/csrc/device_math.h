@@ -84,7 +84,12 @@ __device__ __forceinline__ void quat_rot(const double q[4], const double v[3], d
 // Taylor coefficients of sin (x^3..x^17, sign included, highest first) and cos
 // (x^2..x^16).  Kept in constant memory and read through a laundered pointer so the
 // compiler loads them into SGPRs at the point of use instead of hoisting sixteen f64
-// literals into VGPRs for the lifetime of the calling kernel.
+// literals into VGPRs for the lifetime of the calling kernel.  The laundered pointer
+// keeps its CONSTANT address space: through a generic pointer the sixteen values came as
+// eight flat_load_dwordx4, each waited for on its own inside the Horner chain (round 4:
+// found in K4's ISA, 8 vector-memory round trips per SE3::exp); from the constant address
+// space they are scalar loads into SGPRs, requested together.
+typedef const double __attribute__((address_space(4))) const_as_double;
 __constant__ double kSinCoef[8] = {-1.0 / 355687428096000.0, 1.0 / 1307674368000.0, -1.0 / 6227020800.0,
                                    1.0 / 39916800.0,         -1.0 / 362880.0,       1.0 / 5040.0,
                                    -1.0 / 120.0,             1.0 / 6.0};
@@ -102,8 +107,13 @@ __device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
     x *= 0.5;
     ++k;
   }
+#ifndef SINCOS_COEF_GENERIC_POINTER
+  const_as_double* cs = (const_as_double*)kSinCoef;
+  const_as_double* cc = (const_as_double*)kCosCoef;
+#else  // A/B build: the form of rounds 1-4a
   const double* cs = kSinCoef;
   const double* cc = kCosCoef;
+#endif
   asm volatile("" : "+s"(cs), "+s"(cc));
   const double z = x * x;
   double ps = cs[0];
