@@ -121,6 +121,39 @@ __global__ void __launch_bounds__(RM_BLOCK) reproject_map_kernel(const ReprojMap
   const int P = mp.n_points, n_cells = a.grid.n_cells;
 
   // ---- 0. the host's changes since the last call -------------------------------------------------------------------
+#ifdef RM_PATCH_LOAD_FIRST
+  // (round-5 queue, UNMEASURED: every field of a record is read before the first store.  The loops below interleave loads
+  // and stores to arrays the compiler cannot prove distinct, so each load is waited for on its own: 10 `s_waitcnt vmcnt(0)`
+  // in the ISA of the point loop, one memory round trip each, on the critical path of a single-stream frame.)
+  for (int i = tid; i < a.patch.n_obs; i += RM_BLOCK) {
+    const int o = a.patch.d_obs_index[i];
+    const int fr = a.patch.obs.d_frame[i], ord = a.patch.d_obs_order[i];
+    const int lv = a.patch.obs.d_level[i];
+    const uint8_t ty = a.patch.obs.d_type[i];
+    const double px0 = a.patch.obs.d_px[2 * i], px1 = a.patch.obs.d_px[2 * i + 1];
+    const double f0 = a.patch.obs.d_f[3 * i], f1 = a.patch.obs.d_f[3 * i + 1], f2 = a.patch.obs.d_f[3 * i + 2];
+    const double g0 = a.patch.obs.d_grad[2 * i], g1 = a.patch.obs.d_grad[2 * i + 1];
+    mp.d_obs_frame[o] = fr;
+    mp.d_obs_order[o] = (int32_t)((uint32_t)fr << 16 | (ord < 0 ? 0xffffu : (uint32_t)ord & 0xffffu));
+    mp.d_obs_level[o] = lv;
+    mp.d_obs_type[o] = ty;
+    mp.d_obs_px[2 * o] = px0;
+    mp.d_obs_px[2 * o + 1] = px1;
+    mp.d_obs_f[3 * o] = f0; mp.d_obs_f[3 * o + 1] = f1; mp.d_obs_f[3 * o + 2] = f2;
+    mp.d_obs_grad[2 * o] = g0;
+    mp.d_obs_grad[2 * o + 1] = g1;
+  }
+  for (int i = tid; i < a.patch.n_points; i += RM_BLOCK) {
+    const int p = a.patch.d_index[i];
+    const double x0 = a.patch.d_pos[3 * i], x1 = a.patch.d_pos[3 * i + 1], x2 = a.patch.d_pos[3 * i + 2];
+    const int ty = a.patch.d_type[i], od = a.patch.d_order[i], ob = a.patch.d_obs_begin[i], oc = a.patch.d_obs_count[i];
+    mp.d_pos[3 * p] = x0; mp.d_pos[3 * p + 1] = x1; mp.d_pos[3 * p + 2] = x2;
+    mp.d_type[p] = ty;
+    mp.d_order[p] = od;
+    mp.d_obs_begin[p] = ob;
+    mp.d_obs_count[p] = oc;
+  }
+#else
   for (int i = tid; i < a.patch.n_obs; i += RM_BLOCK) {
     const int o = a.patch.d_obs_index[i];
     const int fr = a.patch.obs.d_frame[i], ord = a.patch.d_obs_order[i];
@@ -144,6 +177,7 @@ __global__ void __launch_bounds__(RM_BLOCK) reproject_map_kernel(const ReprojMap
     mp.d_obs_begin[p] = a.patch.d_obs_begin[i];
     mp.d_obs_count[p] = a.patch.d_obs_count[i];
   }
+#endif
   for (int k = tid; k < n_cells; k += RM_BLOCK) s_cnt[k] = 0;
   if (tid < RM_MAX_FRAMES) {
     s_kfrank[tid] = tid < a.n_frames ? a.kf_rank[tid] : -1;

@@ -1,0 +1,27 @@
+#!/bin/bash
+# The experiments queued at the end of round 4 (GPU minutes had run out): opt-in compile-time variants that were
+# cross-compiled and read in the ISA but never executed.  For each: parity tests ON THE VARIANT LIBRARY first, then the
+# A/B timing.  Build the variants on the CPU side before calling gpurun:
+#   for f in WARP_PACKED RM_PATCH_LOAD_FIRST; do python -m rpg_svo_amd.build -D$f; done
+#   gpurun --timeout 600 -- 'bash scripts/round5_queue.sh 2>&1 | tee gpurun_out/r05a_queue.txt'
+# A variant that fails a test is dropped; one that wins becomes the default and its flag is inverted.
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$R"
+V=build/variants
+echo "== WARP_PACKED: packed f32 for the bilinear arithmetic of warp_kernel (expected: -10..15 % of warp's 2.4 ms)"
+if [ -f $V/libsvo_hip_WARP_PACKED.so ]; then
+  SVO_HIP_LIB=$PWD/$V/libsvo_hip_WARP_PACKED.so python -m pytest tests/test_tracking_gpu.py -q -m gpu -x 2>&1 | tail -2
+  bash scripts/full_variants.sh main svo_hip_WARP_PACKED main svo_hip_WARP_PACKED 2>&1 | cut -c1-220
+fi
+echo "== RM_PATCH_LOAD_FIRST: the map patch applied with all loads before the first store (expected: -3..6 us per frame)"
+if [ -f $V/libsvo_hip_RM_PATCH_LOAD_FIRST.so ]; then
+  SVO_HIP_LIB=$PWD/$V/libsvo_hip_RM_PATCH_LOAD_FIRST.so python -m pytest tests/test_map_mirror_gpu.py -q -m gpu -x 2>&1 | tail -2
+  for k in 1 2; do python scripts/dropin_trace.py frames=600 2>/dev/null | grep "tot_time median"; done
+  cp rpg_svo_amd/lib/libsvo_hip.so /tmp/libsvo_hip_main.so
+  cp $V/libsvo_hip_RM_PATCH_LOAD_FIRST.so rpg_svo_amd/lib/libsvo_hip.so  # the pipeline library finds libsvo_hip.so by rpath
+  echo "-- variant"
+  for k in 1 2; do python scripts/dropin_trace.py frames=600 2>/dev/null | grep "tot_time median"; done
+  SVO_HIP_MAP_MIRROR=verify python -m pytest tests/test_dropin_pipeline.py -q -m gpu -x -k mirror 2>&1 | tail -2
+  cp /tmp/libsvo_hip_main.so rpg_svo_amd/lib/libsvo_hip.so
+fi
