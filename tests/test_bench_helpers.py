@@ -93,3 +93,19 @@ def test_last_stdout_line_is_compact_and_round_trips():
     assert len(json.dumps(c2)) < bench.COMPACT_LIMIT and "roofline" in c2 and "cpu_baseline" in c2
     # NaN / inf never reach the line as bare tokens json.loads of a strict parser would refuse
     assert "NaN" not in line and "Infinity" not in line
+
+
+def test_lds_port_use_ratios_and_missing_counters():
+    """bench.lds_port_use: LDS port busy = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES (both summed over the CUs); a counter that was
+    not collected gives None, never an exception (the leg runs unattended under rocprofv3)."""
+    raw = {"GRBM_GUI_ACTIVE": 8000.0, "SQ_LDS_IDX_ACTIVE": 128000.0, "SQ_LDS_BANK_CONFLICT": 32000.0, "SQ_INSTS_LDS": 50000.0,
+           "SQ_WAVE_CYCLES": 1e6, "SQ_WAIT_INST_LDS": 100.0, "SQ_ACTIVE_INST_LDS": 2e5, "SQ_BUSY_CU_CYCLES": 256000.0}
+    r = bench.lds_port_use(raw)
+    assert r["port_busy_frac"] == 0.5
+    assert r["bank_conflict_frac_of_port_cycles"] == 0.25
+    assert r["port_cycles_per_lds_instruction"] == 2.56
+    assert r["wave_cycles_waiting_for_lds_issue_frac"] == 4.0 * 100.0 / 1e6  # the counter is in units of 4 cycles
+    assert abs(r["sdk_formula_idx_active_over_gui_active_x_cus"] - 128000.0 / (8000.0 * 256)) < 1e-12
+    empty = bench.lds_port_use({})
+    assert set(empty) == set(r) and all(v is None for v in empty.values())
+    __import__("json").dumps(r)
