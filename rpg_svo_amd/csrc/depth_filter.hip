@@ -108,6 +108,30 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   w.n_steps[s] = 0;
   w.accepted_raw[s] = 0;
   const int cf = a.cur_frame[s];
+#ifdef SEED_LOAD_FIRST
+  // (round-5 queue, UNMEASURED: every record of the seed is requested before the first early exit -- two memory round
+  // trips, (cf, rfi, batch id, mu, sigma2, f) then (the two poses, the slot), instead of three or four: a load below an
+  // early exit cannot be issued above it by the compiler.  The kernel waits 54 % of its wave cycles.)
+  const int rfi = a.ftr.d_frame[s];
+  const int batch_id = a.match_only ? 0 : a.seeds.d_batch_id[s];
+  const float mu = a.match_only ? 1.f : a.seeds.d_mu[s], sigma2 = a.match_only ? 0.f : a.seeds.d_sigma2[s];
+  const double f[3] = {a.ftr.d_f[3 * s], a.ftr.d_f[3 * s + 1], a.ftr.d_f[3 * s + 2]};
+  double RtR[12], RtC[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    RtR[k] = a.frame_T[12 * rfi + k];
+    RtC[k] = a.frame_T[12 * cf + k];
+  }
+  w.cur_slot[s] = a.frame_slot[cf];
+  // check if seed is not already too old (:216-219)
+  if (!a.match_only && (a.opt.batch_counter - batch_id) > a.opt.max_n_kfs) {
+    w.status[s] = SVO_HIP_SEED_ERASED_OLD;
+    return;
+  }
+  Se3 Tr, Tc;
+  se3_from_Rt(RtR, Tr);
+  se3_from_Rt(RtC, Tc);
+#else
   w.cur_slot[s] = a.frame_slot[cf];
   // check if seed is not already too old (:216-219)
   if (!a.match_only && (a.opt.batch_counter - a.seeds.d_batch_id[s]) > a.opt.max_n_kfs) {
@@ -120,6 +144,7 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   se3_from_Rt(a.frame_T + 12 * cf, Tc);
   const float mu = a.match_only ? 1.f : a.seeds.d_mu[s], sigma2 = a.match_only ? 0.f : a.seeds.d_sigma2[s];
   const double f[3] = {a.ftr.d_f[3 * s], a.ftr.d_f[3 * s + 1], a.ftr.d_f[3 * s + 2]};
+#endif
   // visibility (:221-232)
   if (!a.match_only) {
     const Se3 T_ref_cur = se3_compose(Tr, se3_inverse(Tc));
@@ -823,38 +848,82 @@ __device__ __forceinline__ double compute_tau(const Se3& T_ref_cur, const double
   return (z_plus - z);
 }
 
-__global__ void __launch_bounds__(64) seed_finish_kernel(const SeedArgs a) {
+#ifdef SEED_LOAD_FIRST
+#define SEED_FINISH_BOUNDS __launch_bounds__(64, 5)  // the early loads cost six registers: held to five waves per SIMD as before
+#else
+#define SEED_FINISH_BOUNDS __launch_bounds__(64)
+#endif
+__global__ void SEED_FINISH_BOUNDS seed_finish_kernel(const SeedArgs a) {
   const int s = blockIdx.x * 64 + threadIdx.x;
   if (s >= a.S) return;
   const SeedWs& w = a.ws;
+#ifdef SEED_LOAD_FIRST
+  // (round-5 queue, UNMEASURED: every record the seed may need is requested before the first early exit -- see
+  // seed_prepare_kernel.  Workspace words of a seed that did not get that far hold whatever they held: read, not used.)
+  const int cf = a.cur_frame[s];
+  const int rfi = a.ftr.d_frame[s];
+  const int aok_early = w.align_ok[s];
+  const double pxc0 = w.px_cur[2 * s], pxc1 = w.px_cur[2 * s + 1];
+  const double f[3] = {a.ftr.d_f[3 * s], a.ftr.d_f[3 * s + 1], a.ftr.d_f[3 * s + 2]};
+  float sa = 0.f, sb = 0.f, smu = 0.f, ssig = 0.f, zr_early = 0.f;
+  if (!a.match_only) {
+    sa = a.seeds.d_a[s]; sb = a.seeds.d_b[s]; smu = a.seeds.d_mu[s]; ssig = a.seeds.d_sigma2[s];
+    zr_early = a.seeds.d_z_range[s];
+  }
+  double RtR[12], RtC[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    RtR[k] = a.frame_T[12 * rfi + k];
+    RtC[k] = a.frame_T[12 * cf + k];
+  }
+#endif
   int status = w.status[s];
   const bool aligned = w.align_active[s] != 0;  // a short segment, or a scan match handed to the sub-pixel alignment
   if (a.px_cur_out) {
     // Matcher::px_cur_ exists once the seed reached the alignment (set by seed_prepare for a short segment, by the scan
     // for a match, refined by the alignment) or was accepted straight from the scan; 0 otherwise
     const bool has_px = aligned || w.accepted_raw[s] != 0;
+#ifdef SEED_LOAD_FIRST
+    a.px_cur_out[2 * s] = has_px ? pxc0 : 0.0;
+    a.px_cur_out[2 * s + 1] = has_px ? pxc1 : 0.0;
+#else
     a.px_cur_out[2 * s] = has_px ? w.px_cur[2 * s] : 0.0;
     a.px_cur_out[2 * s + 1] = has_px ? w.px_cur[2 * s + 1] : 0.0;
+#endif
   }
   if (status == SVO_HIP_SEED_ERASED_OLD || status == SVO_HIP_SEED_BEHIND || status == SVO_HIP_SEED_NOT_IN_FRAME) {
     a.status_out[s] = status;
     return;
   }
+#ifdef SEED_LOAD_FIRST
+  Se3 Tr, Tc;
+  se3_from_Rt(RtR, Tr);
+  se3_from_Rt(RtC, Tc);
+#else
   const int cf = a.cur_frame[s];
   const int rfi = a.ftr.d_frame[s];
   Se3 Tr, Tc;
   se3_from_Rt(a.frame_T + 12 * rfi, Tr);
   se3_from_Rt(a.frame_T + 12 * cf, Tc);
   const double f[3] = {a.ftr.d_f[3 * s], a.ftr.d_f[3 * s + 1], a.ftr.d_f[3 * s + 2]};
+#endif
   bool matched = false;
   double z = 0;
   if (status == 0) {
+#ifdef SEED_LOAD_FIRST
+    const int aok = aligned ? aok_early : 0;
+#else
     const int aok = aligned ? w.align_ok[s] : 0;  // (written by the alignment kernel for every trial it is launched on)
+#endif
     const Se3 T_cur_ref = se3_compose(Tc, se3_inverse(Tr));
     if (aligned && aok == 1) {
       // px_cur_ = px_scaled*(1<<search_level_) was written by the alignment kernel
       double fc[3];
+#ifdef SEED_LOAD_FIRST
+      cam2world(a.cam, pxc0, pxc1, fc);
+#else
       cam2world(a.cam, w.px_cur[2 * s], w.px_cur[2 * s + 1], fc);
+#endif
       matched = depth_from_triangulation(T_cur_ref, f, fc, &z);
     } else if (w.accepted_raw[s]) {
       // subpix_refinement == false: vk::unproject2d(uv_best).normalized()
@@ -869,8 +938,12 @@ __global__ void __launch_bounds__(64) seed_finish_kernel(const SeedArgs a) {
     if (a.search_level_out) a.search_level_out[s] = w.search_level[s];
     return;
   }
+#ifdef SEED_LOAD_FIRST
+  const float zr = zr_early;
+#else
   float sa = a.seeds.d_a[s], sb = a.seeds.d_b[s], smu = a.seeds.d_mu[s], ssig = a.seeds.d_sigma2[s];
   const float zr = a.seeds.d_z_range[s];
+#endif
   if (!matched) {
     a.seeds.d_b[s] = sb + 1.0f;  // it->b++ (:240)
     a.status_out[s] = SVO_HIP_SEED_NO_MATCH;
