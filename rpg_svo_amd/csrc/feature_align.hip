@@ -35,6 +35,12 @@ namespace {
   asm volatile("" : "+v"(g[13]), "+v"(g[14]), "+v"(g[15]), "+v"(g[16]), "+v"(g[17]), "+v"(g[18]), "+v"(g[19]),       \
                "+v"(g[20]), "+v"(g[21]), "+v"(g[22]), "+v"(g[23]), "+v"(g[24]))
 
+// the same for the 64 gradient words of the ALIGN_G_F16 build: their conversions to f32 stay inside the iteration
+#define ALIGN_OPAQUE_G(G)                                         \
+  asm volatile("" : "+v"(G[0]), "+v"(G[1]), "+v"(G[2]), "+v"(G[3]), "+v"(G[4]), "+v"(G[5]), "+v"(G[6]), "+v"(G[7]), "+v"(G[8]), "+v"(G[9]), "+v"(G[10]), "+v"(G[11]), "+v"(G[12]), "+v"(G[13]), "+v"(G[14]), "+v"(G[15]));  \
+  asm volatile("" : "+v"(G[16]), "+v"(G[17]), "+v"(G[18]), "+v"(G[19]), "+v"(G[20]), "+v"(G[21]), "+v"(G[22]), "+v"(G[23]), "+v"(G[24]), "+v"(G[25]), "+v"(G[26]), "+v"(G[27]), "+v"(G[28]), "+v"(G[29]), "+v"(G[30]), "+v"(G[31]));  \
+  asm volatile("" : "+v"(G[32]), "+v"(G[33]), "+v"(G[34]), "+v"(G[35]), "+v"(G[36]), "+v"(G[37]), "+v"(G[38]), "+v"(G[39]), "+v"(G[40]), "+v"(G[41]), "+v"(G[42]), "+v"(G[43]), "+v"(G[44]), "+v"(G[45]), "+v"(G[46]), "+v"(G[47]));  \
+  asm volatile("" : "+v"(G[48]), "+v"(G[49]), "+v"(G[50]), "+v"(G[51]), "+v"(G[52]), "+v"(G[53]), "+v"(G[54]), "+v"(G[55]), "+v"(G[56]), "+v"(G[57]), "+v"(G[58]), "+v"(G[59]), "+v"(G[60]), "+v"(G[61]), "+v"(G[62]), "+v"(G[63]))
 __device__ __forceinline__ void cut_row9(const uint32_t d[3], uint32_t sel, float out[9]);
 // bytes [x0, x0+8] of the image row at byte offset ro (svo_pyr::row_off) as floats: one 12-byte run of three aligned
 // dwords starting at xa = x0 & ~3 (one load when it lies inside a tile row of the store, two otherwise), sel = x0 & 3
@@ -91,7 +97,15 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
   // then subtractions and fused multiply-adds, no integer extraction.
   typedef float f2 __attribute__((ext_vector_type(2)));
   float H[9];
+#ifdef ALIGN_G_F16
+  // (round-5 queue, UNMEASURED: the gradients are half-integers of magnitude <= 127.5 -- EXACT in f16 -- so the 64 {dx, dy}
+  // pairs fit 64 registers instead of 128 and the kernel three waves per SIMD instead of two (it waits for an iteration's
+  // window fetch 48 % of its wave cycles); two conversions per pixel and iteration bring them back, same values.)
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  uint32_t G[64];  // {dx, dy} as two f16
+#else
   f2 G[64];  // {dx, dy} of every template pixel (:176-181), formed once
+#endif
   {
     float sxx = 0.f, sxy = 0.f, syy = 0.f, sx = 0.f, sy = 0.f;
 #pragma unroll
@@ -106,7 +120,11 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
         syy = __builtin_fmaf(gy2, gy2, syy);
         sx += gx2;
         sy += gy2;
+#ifdef ALIGN_G_F16
+        G[8 * y + x] = __builtin_bit_cast(uint32_t, (h2){(_Float16)(0.5f * gx2), (_Float16)(0.5f * gy2)});
+#else
         G[8 * y + x] = (f2){0.5f * gx2, 0.5f * gy2};  // == 0.5f * (float)(int difference): the difference is exact either way
+#endif
       }
     H[0] = 0.25f * sxx;
     H[1] = H[3] = 0.25f * sxy;
@@ -123,6 +141,9 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
   bool left = false;  // the loop was left by a break
   for (int iter = it0; iter < it_end; ++iter) {
     ALIGN_OPAQUE_TEMPLATE(g);
+#ifdef ALIGN_G_F16
+    ALIGN_OPAQUE_G(G);
+#endif
     const int u_r = floor_int(u);
     const int v_r = floor_int(v);
     if (u_r < 4 || v_r < 4 || u_r >= cols - 4 || v_r >= rows - 4) {
@@ -183,7 +204,14 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
 #pragma unroll
       for (int x = 0; x < 8; ++x) {  // raster order: x = 0..3 are the low halves, 4..7 the high halves
         const float res = (x < 4) ? res2[x].x : res2[x - 4].y;
+#ifdef ALIGN_G_F16
+        {
+          const h2 gh = __builtin_bit_cast(h2, G[8 * y + x]);
+          J01 -= (f2){res, res} * (f2){(float)gh.x, (float)gh.y};
+        }
+#else
         J01 -= (f2){res, res} * G[8 * y + x];
+#endif
         Jres2 -= res;
       }
 #pragma unroll
@@ -338,7 +366,11 @@ constexpr int ALIGN_BLOCK = 64;
 // Two waves per SIMD (<= 256 registers): with the bare __launch_bounds__(64) the compiler took 256 VGPRs plus 15-20
 // AGPRs, i.e. ONE wave per SIMD, and nothing hid the round trip of an iteration's window fetch.
 #ifndef ALIGN_MINW
+#ifdef ALIGN_G_F16
+#define ALIGN_MINW 3
+#else
 #define ALIGN_MINW 2
+#endif
 #endif
 template <bool COUNT>
 __global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const AlignArgs a) {
