@@ -302,6 +302,17 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
     Y = a.xyz[3 * fo + 1];
     Z = a.xyz[3 * fo + 2];
   }
+#ifdef SIA_KEEP_PX
+  // (round-5 queue, UNMEASURED: Feature::px kept in four registers instead of re-read at the top of every level.  The
+  // re-read is a memory round trip the level's reference-window gather has to wait for -- `s_waitcnt vmcnt(0)` right
+  // after it in the ISA -- i.e. two dependent round trips per level where the current-window gather and the reference-
+  // window gather could leave together: ~0.7 us x 4 levels on the critical path of a 52 us frame.)
+  double px_kept0 = 0, px_kept1 = 0;
+  if (has) {
+    px_kept0 = a.px[2 * fo];
+    px_kept1 = a.px[2 * fo + 1];
+  }
+#endif
   // normalised coordinates of xyz_ref: all of Frame::jacobian_xyz2uv (frame.h:116-138)
   // is a function of (x/z, y/z, 1/z)
   const sia_acc zi = (sia_acc)(1.0 / Z);
@@ -399,11 +410,15 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
 #endif
     // ---- precomputeReferencePatches (:84-145) ----------------------------
     {
+#ifdef SIA_KEEP_PX
+      const double pxx = px_kept0, pxy = px_kept1;
+#else
       double pxx = 0, pxy = 0;
       if (has) {
         pxx = a.px[2 * fo];
         pxy = a.px[2 * fo + 1];
       }
+#endif
       const float u_ref = (float)(pxx * (double)scale);
       const float v_ref = (float)(pxy * (double)scale);
       const int u_i = (int)floorf(u_ref);
@@ -750,7 +765,11 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
         // reference window of level l-1: rows v-3..v+3, columns of the 12-byte run around u-3..u+3
         if (has) {
           const float nscale = 1.0f / (float)(1 << nl);
+#ifdef SIA_KEEP_PX
+          const int ru = (int)floorf((float)(px_kept0 * (double)nscale)), rv = (int)floorf((float)(px_kept1 * (double)nscale));
+#else
           const int ru = (int)floorf((float)(a.px[2 * fo] * (double)nscale)), rv = (int)floorf((float)(a.px[2 * fo + 1] * (double)nscale));
+#endif
           if (ru - 3 >= 0 && rv - 3 >= 0 && ru + 3 < ncols && rv + 3 < nrows) {
             const uint8_t* nref = ref_base + g_s.lo[nl];
             sia_touch(nref, svo_pyr::px_off((ru - 3) & ~3, rv - 3, npitch), lds);

@@ -2,7 +2,7 @@
 # The experiments queued at the end of round 4 (GPU minutes had run out): opt-in compile-time variants that were
 # cross-compiled and read in the ISA but never executed.  For each: parity tests ON THE VARIANT LIBRARY first, then the
 # A/B timing.  Build the variants on the CPU side before calling gpurun:
-#   for f in WARP_PACKED RM_PATCH_LOAD_FIRST SCAN_PREFETCH SEED_LOAD_FIRST ALIGN_G_F16; do python -m rpg_svo_amd.build -D$f; done
+#   for f in WARP_PACKED RM_PATCH_LOAD_FIRST SCAN_PREFETCH SEED_LOAD_FIRST ALIGN_G_F16 SIA_KEEP_PX; do python -m rpg_svo_amd.build -D$f; done
 #   python -m rpg_svo_amd.build -DSCAN_PREFETCH -DSCAN_MINW=4
 #   gpurun --timeout 600 -- 'bash scripts/round5_queue.sh 2>&1 | tee gpurun_out/r05a_queue.txt'
 # A variant that fails a test is dropped; one that wins becomes the default and its flag is inverted.
@@ -10,6 +10,11 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 V=build/variants
+echo "== SIA_KEEP_PX: K1 keeps Feature::px in registers (one dependent memory round trip per level less; expected +2..5 % frames/s)"
+if [ -f $V/libsvo_hip_SIA_KEEP_PX.so ]; then
+  SVO_HIP_LIB=$PWD/$V/libsvo_hip_SIA_KEEP_PX.so python -m pytest tests/test_sparse_align_gpu.py -q -m gpu -x 2>&1 | tail -2
+  bash scripts/k1_variants.sh main svo_hip_SIA_KEEP_PX main svo_hip_SIA_KEEP_PX main svo_hip_SIA_KEEP_PX -- --steps 40 --warmup 15
+fi
 echo "== WARP_PACKED: packed f32 for the bilinear arithmetic of warp_kernel (expected: -10..15 % of warp's 2.4 ms)"
 if [ -f $V/libsvo_hip_WARP_PACKED.so ]; then
   SVO_HIP_LIB=$PWD/$V/libsvo_hip_WARP_PACKED.so python -m pytest tests/test_tracking_gpu.py -q -m gpu -x 2>&1 | tail -2
