@@ -3,15 +3,33 @@
 // SE3::exp / operator*, Eigen quaternion <-> matrix), written for registers:
 // everything is fully unrolled, no dynamically indexed local arrays.
 #pragma once
+// SVO_HOST_MATH_TEST: the CPU test suite compiles these same functions with g++ (tests/host/device_math_on_host.cpp) and
+// checks them against the oracle without a GPU.  Whatever needs the wave (cross-lane moves, v_rsq) is left out there.
+#ifdef SVO_HOST_MATH_TEST
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __constant__ static const
+using std::fabs;
+using std::sqrt;
+#else
 #include <hip/hip_runtime.h>
+#endif
 
 namespace svo_dev {
 
 // (int)floorf(x) in one instruction (v_cvt_flr_i32_f32; the compiler emits v_floor_f32 + v_cvt_i32_f32 for the C form)
 __device__ __forceinline__ int floor_to_int(float x) {
+#ifdef SVO_HOST_MATH_TEST
+  return (int)floorf(x);
+#else
   int r;
   asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
   return r;
+#endif
 }
 
 // Eigen QuaternionBase::toRotationMatrix; q = (w, x, y, z)
@@ -89,7 +107,9 @@ __device__ __forceinline__ void quat_rot(const double q[4], const double v[3], d
 // eight flat_load_dwordx4, each waited for on its own inside the Horner chain (round 4:
 // found in K4's ISA, 8 vector-memory round trips per SE3::exp); from the constant address
 // space they are scalar loads into SGPRs, requested together.
+#ifndef SVO_HOST_MATH_TEST
 typedef const double __attribute__((address_space(4))) const_as_double;
+#endif
 __constant__ double kSinCoef[8] = {-1.0 / 355687428096000.0, 1.0 / 1307674368000.0, -1.0 / 6227020800.0,
                                    1.0 / 39916800.0,         -1.0 / 362880.0,       1.0 / 5040.0,
                                    -1.0 / 120.0,             1.0 / 6.0};
@@ -107,14 +127,18 @@ __device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
     x *= 0.5;
     ++k;
   }
-#ifndef SINCOS_COEF_GENERIC_POINTER
+#if defined(SVO_HOST_MATH_TEST)
+  const double* cs = kSinCoef;
+  const double* cc = kCosCoef;
+#elif !defined(SINCOS_COEF_GENERIC_POINTER)
   const_as_double* cs = (const_as_double*)kSinCoef;
   const_as_double* cc = (const_as_double*)kCosCoef;
+  asm volatile("" : "+s"(cs), "+s"(cc));
 #else  // A/B build: the form of rounds 1-4a
   const double* cs = kSinCoef;
   const double* cc = kCosCoef;
-#endif
   asm volatile("" : "+s"(cs), "+s"(cc));
+#endif
   const double z = x * x;
   double ps = cs[0];
 #pragma unroll
@@ -362,6 +386,7 @@ __device__ __forceinline__ void se3_exp_trans_f32(const float xi[6], float t[3])
   t[2] = uz + c1 * wz + c2 * wwz;
 }
 
+#ifndef SVO_HOST_MATH_TEST  // (v_rsq_f64, v_readlane: no host counterpart)
 // q <- q / |q| for a quaternion that is already close to unit length or not:
 // v_rsq_f64 seed + two Newton steps (no f64 sqrt / division sequences).
 __device__ __forceinline__ void quat_normalize_fast(double q[4]) {
@@ -380,6 +405,7 @@ __device__ __forceinline__ double readlane_f64(double v) {
   const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), SRC);
   return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
+#endif  // SVO_HOST_MATH_TEST
 
 // index into the packed upper triangle of a symmetric 6x6 (row-major, i<=j)
 __host__ __device__ constexpr int sym6(int i, int j) {
@@ -433,11 +459,13 @@ __device__ __forceinline__ void ldlt6_solve(const double LD[21], const double b[
   }
 }
 
+#ifndef SVO_HOST_MATH_TEST
 // full-wave (64 lanes) sum; every lane receives the total
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+#endif
 
 }  // namespace svo_dev

@@ -10,7 +10,9 @@
 // Conventions: SE(3) as Sophus stores it (unit quaternion w,x,y,z + translation); poses
 // cross the C ABI as 12 doubles [R row-major | t].
 #pragma once
+#ifndef SVO_HOST_MATH_TEST  // (see device_math.h)
 #include <hip/hip_runtime.h>
+#endif
 
 #include "device_math.h"
 #include "svo_hip.h"

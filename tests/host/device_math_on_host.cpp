@@ -1,0 +1,84 @@
+// device_math_on_host.cpp -- TEST INFRASTRUCTURE.  The device math of the kernels (rpg_svo_amd/csrc/device_math.h,
+// track_math.h, matcher_device.h) compiled by g++ for the CPU (SVO_HOST_MATH_TEST: the headers drop the HIP include and
+// whatever needs the wave), behind a C interface tests/test_device_math_host.py loads with ctypes and checks against the
+// oracle.  What this shows is that the FORMULAS the kernels run are the reference's; the bits the GPU produces (fused
+// multiply-adds where a translation unit allows contraction) are the GPU parity tests' business.
+#define SVO_HOST_MATH_TEST
+#include "matcher_device.h"
+
+using namespace svo_dev;
+
+namespace {
+Cam make_cam(const double* k /* fx fy cx cy */, int width, int height, int model, const double* d) {
+  Cam c;
+  c.fx = k[0]; c.fy = k[1]; c.cx = k[2]; c.cy = k[3];
+  c.width = width; c.height = height; c.model = model;
+  for (int i = 0; i < 5; ++i) c.d[i] = d[i];
+  return c;
+}
+}  // namespace
+
+extern "C" {
+
+// Sophus SE3::exp as the kernels run it (quaternion + translation), returned as [R row-major | t]
+void hm_se3_exp(const double xi[6], double T_out[12]) {
+  Se3 s;
+  se3_exp(xi, s.q, s.t);
+  se3_to_Rt(s, T_out);
+}
+// the f32 variant of K1's solver (short series below |omega| < 0.01 unless long_only)
+void hm_se3_exp_f32(const float xi[6], float q[4], float t[3]) { se3_exp_f32(xi, q, t); }
+
+void hm_se3_mul(const double A[12], const double B[12], double out[12]) {
+  Se3 a, b;
+  se3_from_Rt(A, a);
+  se3_from_Rt(B, b);
+  se3_to_Rt(se3_compose(a, b), out);
+}
+void hm_se3_inv(const double A[12], double out[12]) {
+  Se3 a;
+  se3_from_Rt(A, a);
+  se3_to_Rt(se3_inverse(a), out);
+}
+void hm_frame_pos(const double T_f_w[12], double p[3]) {
+  Se3 a;
+  se3_from_Rt(T_f_w, a);
+  frame_pos(a, p);
+}
+void hm_quat_round_trip(const double R[9], double R_out[9]) {
+  double q[4];
+  quat_from_R(R, q);
+  quat_to_R(q, R_out);
+}
+
+void hm_world2cam(const double k[4], int width, int height, int model, const double d[5], const double xyz[3], double px[2]) {
+  const Cam c = make_cam(k, width, height, model, d);
+  world2cam(c, xyz, px);
+}
+void hm_cam2world(const double k[4], int width, int height, int model, const double d[5], const double px[2], double f[3]) {
+  const Cam c = make_cam(k, width, height, model, d);
+  cam2world(c, px[0], px[1], f);
+}
+
+void hm_warp_matrix_affine(const double k[4], int width, int height, int model, const double d[5], const double px_ref[2],
+                           const double f_ref[3], double depth_ref, const double T_cur_ref[12], int level_ref, double A[4]) {
+  const Cam c = make_cam(k, width, height, model, d);
+  Se3 T;
+  se3_from_Rt(T_cur_ref, T);
+  svo_track::warp_matrix_affine(c, px_ref, f_ref, depth_ref, T, level_ref, A);
+}
+int hm_best_search_level(const double A[4], int max_level) { return svo_track::best_search_level(A, max_level); }
+
+// Eigen's LDLT with pivoting as the pose optimizer's kernels run it (6 x 6)
+void hm_ldlt6_solve_pivoted(const double A[36], const double b[6], double x[6]) { ldlt_solve_pivoted<6>(A, b, x); }
+// the unpivoted packed LDLT of K1's solver: H as the packed upper triangle (21 values, row-major, i <= j)
+void hm_ldlt6_solve_packed(const double H21[21], const double b[6], double x[6]) {
+  double LD[21];
+  ldlt6_factor(H21, LD);
+  ldlt6_solve(LD, b, x);
+}
+void hm_inv3f(const float m[9], float r[9]) { inv3f(m, r); }
+int hm_floor_to_int(float x) { return floor_to_int(x); }
+void hm_sincos_small(double x, double* s, double* c) { sincos_small(x, s, c); }
+
+}  // extern "C"

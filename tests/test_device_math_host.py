@@ -1,0 +1,232 @@
+"""The device math of the kernels, compiled for the CPU and checked against the oracle WITHOUT a GPU.
+
+rpg_svo_amd/csrc/device_math.h, track_math.h and matcher_device.h hold the formulas every kernel after K1 runs (SE(3)
+exp / compose / inverse as Sophus does them on quaternions, the three camera models of vikit, the affine warp matrix and
+its search level, the LDLT solves).  tests/host/device_math_on_host.cpp compiles those same headers with g++
+(SVO_HOST_MATH_TEST) behind a C interface; here every function is compared with the oracle's restatement of the
+reference on seeded inputs.  Both sides are built without floating-point contraction, and where both follow the
+reference's order of operations the results are equal bit for bit -- asserted where that holds, to 1e-12 otherwise.
+The bits the GPU produces are the business of the `-m gpu` parity tests."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle  # noqa: E402
+
+SRC = os.path.join(ROOT, "tests", "host", "device_math_on_host.cpp")
+LIB = os.path.join(ROOT, "build", "libdevice_math_on_host.so")
+D = C.POINTER(C.c_double)
+F = C.POINTER(C.c_float)
+
+
+def _p(a, t=D):
+    return a.ctypes.data_as(t)
+
+
+@pytest.fixture(scope="module")
+def hm():
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    deps = [SRC] + [os.path.join(ROOT, "rpg_svo_amd", "csrc", h) for h in ("device_math.h", "track_math.h", "matcher_device.h")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-math-errno", "-fPIC", "-shared", "-Wall",
+                        "-Wno-unknown-pragmas", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "rpg_svo_amd", "csrc"),
+                        SRC, "-o", LIB], check=True)
+    lib = C.CDLL(LIB)
+    lib.hm_best_search_level.restype = C.c_int
+    lib.hm_floor_to_int.restype = C.c_int
+    lib.hm_floor_to_int.argtypes = [C.c_float]
+    lib.hm_sincos_small.argtypes = [C.c_double, D, D]
+    return lib
+
+
+def _random_pose(rng, angle=0.5, trans=1.0):
+    xi = np.concatenate([rng.uniform(-trans, trans, 3), rng.normal(size=3)])
+    xi[3:] *= rng.uniform(0, angle) / np.linalg.norm(xi[3:])
+    return pyoracle.se3_exp(xi)
+
+
+def test_se3_exp_follows_sophus(hm):
+    """se3_exp (quaternion form, own sin / cos series) against the oracle's Sophus SE3::exp: tiny angles, the angles a
+    Gauss-Newton step produces, and large ones (the series halves its argument and doubles back).  Sophus forms the
+    translation's coefficients as (1 - cos t) / t^2 and (t - sin t) / t^3, which cancel for 1e-10 < t < 1e-5 (below 1e-10
+    it switches to V = R): there the two sides -- libm on one, the series on the other -- round the cancellation differently,
+    by up to ~2e-16 / t relative to |upsilon| (a GN step has |upsilon| ~ t, i.e. 1e-16 absolute)."""
+    rng = np.random.default_rng(1)
+    for scale in (0.0, 1e-12, 1e-8, 1e-6, 1e-4, 1e-2, 0.3, 1.0, 3.0):
+        for _ in range(100):
+            xi = np.concatenate([rng.uniform(-1, 1, 3), rng.normal(size=3) * scale])
+            T = np.empty(12)
+            hm.hm_se3_exp(_p(xi), _p(T))
+            T_o = pyoracle.se3_exp(xi)
+            theta = np.linalg.norm(xi[3:])
+            assert np.abs(T[:9] - T_o[:9]).max() < 5e-15, (scale, xi)
+            tol_t = 1e-14 * max(1.0, np.abs(T_o).max()) + (4e-16 / theta * np.linalg.norm(xi[:3]) if theta >= 1e-10 else 0.0)
+            assert np.abs(T[9:] - T_o[9:]).max() < tol_t, (scale, xi, np.abs(T[9:] - T_o[9:]).max(), tol_t)
+            # a Gauss-Newton step: translation and rotation parts of the same magnitude
+            xi_s = xi.copy()
+            xi_s[:3] *= max(theta, 1e-12)
+            hm.hm_se3_exp(_p(xi_s), _p(T))
+            T_s = pyoracle.se3_exp(xi_s)
+            assert np.abs(T - T_s).max() < 5e-15 * max(1.0, np.abs(T_s).max()), (scale, xi_s)
+
+
+def test_sincos_small_is_accurate_to_the_last_bits(hm):
+    """|x| <= 0.5 (half the angle of any Gauss-Newton step): the series alone, a few 1e-16.  Larger arguments are halved
+    until they fit and doubled back with the double-angle identities: every doubling doubles the error."""
+    rng = np.random.default_rng(2)
+
+    def worst(xs):
+        w = 0.0
+        for x in xs:
+            s, c = C.c_double(), C.c_double()
+            hm.hm_sincos_small(float(x), C.byref(s), C.byref(c))
+            w = max(w, abs(s.value - np.sin(x)), abs(c.value - np.cos(x)))
+        return w
+
+    assert worst(np.concatenate([rng.uniform(-0.5, 0.5, 4000), [0.0, 0.5, -0.5, 1e-300, 1e-9]])) < 4e-16
+    assert worst(rng.uniform(-4, 4, 1000)) < 1e-14
+    assert worst(rng.uniform(-40, 40, 1000)) < 1e-13
+
+
+def test_se3_f32_series_agree_with_the_f64_exponential(hm):
+    """K1's f32 solver path: the short series (|omega| < 0.01) and the long one against the f64 exponential."""
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for scale in (1e-6, 1e-3, 0.009, 0.011, 0.1):
+        for _ in range(100):
+            xi = np.concatenate([rng.uniform(-0.1, 0.1, 3), rng.normal(size=3) * scale]).astype(np.float32)
+            q, t = np.empty(4, np.float32), np.empty(3, np.float32)
+            hm.hm_se3_exp_f32(_p(xi, F), _p(q, F), _p(t, F))
+            T = pyoracle.se3_exp(xi.astype(np.float64))
+            w, x, y, z = q.astype(np.float64)
+            R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                          [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                          [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+            worst = max(worst, np.abs(R.ravel() - T[:9]).max(), np.abs(t - T[9:]).max())
+    assert worst < 5e-7, worst
+
+
+def test_compose_inverse_and_frame_position(hm):
+    rng = np.random.default_rng(4)
+    worst = 0.0
+    for _ in range(200):
+        A, B = _random_pose(rng, 2.0), _random_pose(rng, 2.0)
+        out = np.empty(12)
+        hm.hm_se3_mul(_p(A), _p(B), _p(out))
+        worst = max(worst, np.abs(out - pyoracle.se3_mul(A, B)).max())
+        hm.hm_se3_inv(_p(A), _p(out))
+        inv = pyoracle.se3_inv(A)
+        worst = max(worst, np.abs(out - inv).max())
+        pos = np.empty(3)
+        hm.hm_frame_pos(_p(A), _p(pos))  # Frame::pos() = T_f_w.inverse().translation()
+        worst = max(worst, np.abs(pos - inv[9:]).max())
+        R2 = np.empty(9)
+        hm.hm_quat_round_trip(_p(np.ascontiguousarray(A[:9])), _p(R2))
+        worst = max(worst, np.abs(R2 - A[:9]).max())
+    assert worst < 1e-14, worst
+
+
+CAMS = [  # (model, k, size, d): the three vk::AbstractCamera implementations (include/svo_hip.h)
+    (0, (315.5, 315.5, 376.0, 240.0), (752, 480), (0, 0, 0, 0, 0)),
+    (1, (420.0, 418.0, 370.0, 236.0), (752, 480), (-0.28, 0.07, 1e-4, -2e-4, 0.0)),
+    (2, (0.51 * 752, 0.79 * 480, 0.495 * 752 - 0.5, 0.51 * 480 - 0.5), (752, 480), None),  # ATAN: s = 0.93
+]
+
+
+def _cam_struct(model, k, size, d):
+    from types import SimpleNamespace
+    if model == 2:
+        s = 0.93
+        d = (s, 1.0 / s, 2.0 * np.tan(s / 2.0), 1.0 / (2.0 * np.tan(s / 2.0)), 0.0)
+    ns = SimpleNamespace(fx=k[0], fy=k[1], cx=k[2], cy=k[3], width=size[0], height=size[1], model=model, d=d)
+    return ns, np.array(k, np.float64), np.array(d, np.float64)
+
+
+@pytest.mark.parametrize("model,k,size,d", CAMS)
+def test_camera_models_match_the_oracle(hm, model, k, size, d):
+    """world2cam / cam2world of the pinhole, the radial-tangential pinhole (cv::undistortPoints' float round trips) and
+    the ATAN camera: equal to the oracle bit for bit."""
+    ns, kk, dd = _cam_struct(model, k, size, d)
+    pc = pyoracle.make_cam(ns)
+    lib = pyoracle.lib()
+    rng = np.random.default_rng(5 + model)
+    px = np.stack([rng.uniform(0, size[0], 500), rng.uniform(0, size[1], 500)], 1)
+    f_o = np.empty((500, 3))
+    lib.orc_cam2world(C.byref(pc), C.c_int(500), _p(np.ascontiguousarray(px)), _p(f_o))
+    for i in range(500):
+        f = np.empty(3)
+        hm.hm_cam2world(_p(kk), size[0], size[1], model, _p(dd), _p(np.ascontiguousarray(px[i])), _p(f))
+        assert np.array_equal(f, f_o[i]), (i, f, f_o[i])
+        # and back through world2cam, against the oracle's reprojectPoint (identity pose)
+        xyz = f * rng.uniform(0.5, 5.0)
+        p = np.empty(2)
+        hm.hm_world2cam(_p(kk), size[0], size[1], model, _p(dd), _p(xyz), _p(p))
+        p_o = np.empty(2)
+        T = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float64)
+        lib.orc_reproject_point(C.byref(pc), _p(T), _p(xyz), C.c_int(30), C.c_int(26), _p(p_o))
+        assert np.array_equal(p, p_o), (i, p, p_o)
+        assert np.abs(p - px[i]).max() < (1e-9 if model != 1 else 1.0)  # (radtan: cv::undistortPoints stops after five fixed-point iterations, in float: 0.25 px off at the image border for k1 = -0.28)
+
+
+@pytest.mark.parametrize("model,k,size,d", CAMS)
+def test_affine_warp_matrix_and_search_level(hm, model, k, size, d):
+    """warp::getWarpMatrixAffine / getBestSearchLevel (matcher.cpp:33-70) as the kernels compute them, against the oracle:
+    equal bit for bit, for every camera model and reference level."""
+    ns, kk, dd = _cam_struct(model, k, size, d)
+    pc = pyoracle.make_cam(ns)
+    lib = pyoracle.lib()
+    lib.orc_get_best_search_level.restype = C.c_int
+    rng = np.random.default_rng(9 + model)
+    for i in range(300):
+        px = np.array([rng.uniform(40, size[0] - 40), rng.uniform(40, size[1] - 40)])
+        f = np.empty(3)
+        hm.hm_cam2world(_p(kk), size[0], size[1], model, _p(dd), _p(px), _p(f))
+        depth = rng.uniform(0.5, 8.0)
+        T = _random_pose(rng, 0.6, 0.8)
+        level = int(rng.integers(0, 4))
+        A, A_o = np.empty(4), np.empty(4)
+        hm.hm_warp_matrix_affine(_p(kk), size[0], size[1], model, _p(dd), _p(px), _p(f), C.c_double(depth), _p(T), level, _p(A))
+        lib.orc_get_warp_matrix_affine(C.byref(pc), C.byref(pc), _p(px), _p(f), C.c_double(depth), _p(T), C.c_int(level), _p(A_o))
+        assert np.array_equal(A, A_o), (i, A, A_o)
+        for max_level in (0, 2, 4):
+            assert hm.hm_best_search_level(_p(A), max_level) == lib.orc_get_best_search_level(_p(A_o), C.c_int(max_level))
+
+
+def test_ldlt_solves(hm):
+    """The pose optimizer's pivoted LDLT (Eigen's algorithm) and K1's packed unpivoted one on 6 x 6 normal equations of
+    a wide range of conditioning."""
+    rng = np.random.default_rng(12)
+    for trial in range(200):
+        J = rng.normal(size=(40, 6)) * 10.0 ** rng.uniform(-3, 3, 6)
+        H = J.T @ J
+        b = rng.normal(size=6) * np.sqrt(np.diag(H))
+        x_ref = np.linalg.solve(H, b)
+        x = np.empty(6)
+        hm.hm_ldlt6_solve_pivoted(_p(np.ascontiguousarray(H)), _p(b), _p(x))
+        scale = np.abs(x_ref) + 1e-300
+        cond = np.linalg.cond(H)
+        assert np.abs((x - x_ref) / scale).max() < 1e-15 * cond * 50 + 1e-9, (trial, cond)
+        x_o = pyoracle.ldlt_solve(H, b)
+        assert np.abs((x - x_o) / scale).max() < 1e-15 * cond * 50 + 1e-9
+        H21 = np.array([H[i, j] for i in range(6) for j in range(i, 6)])
+        hm.hm_ldlt6_solve_packed(_p(H21), _p(b), _p(x))
+        assert np.abs((x - x_ref) / scale).max() < 1e-15 * cond * 200 + 1e-9, (trial, cond)
+
+
+def test_inv3f_and_floor(hm):
+    rng = np.random.default_rng(13)
+    for _ in range(200):
+        J = rng.normal(size=(64, 3)).astype(np.float32)
+        J[:, 2] = 1.0
+        Hm = (J.T @ J).astype(np.float32)
+        r = np.empty(9, np.float32)
+        hm.hm_inv3f(_p(np.ascontiguousarray(Hm.ravel()), F), _p(r, F))
+        assert np.abs(r.reshape(3, 3).astype(np.float64) @ Hm.astype(np.float64) - np.eye(3)).max() < 1e-3
+    for x in (0.0, 0.5, 0.999999, 1.0, 17.25, 639.9999, -0.0, 3.0000002):
+        assert hm.hm_floor_to_int(x) == int(np.floor(np.float32(x)))
