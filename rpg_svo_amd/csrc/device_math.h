@@ -14,6 +14,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __constant__ static const
 using std::fabs;
+using std::isnan;
 using std::sqrt;
 #else
 #include <hip/hip_runtime.h>

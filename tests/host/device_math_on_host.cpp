@@ -5,6 +5,7 @@
 // multiply-adds where a translation unit allows contraction) are the GPU parity tests' business.
 #define SVO_HOST_MATH_TEST
 #include "matcher_device.h"
+#include "seed_math.h"
 
 using namespace svo_dev;
 
@@ -80,5 +81,22 @@ void hm_ldlt6_solve_packed(const double H21[21], const double b[6], double x[6])
 void hm_inv3f(const float m[9], float r[9]) { inv3f(m, r); }
 int hm_floor_to_int(float x) { return floor_to_int(x); }
 void hm_sincos_small(double x, double* s, double* c) { sincos_small(x, s, c); }
+
+// ---- the depth filter's closed-form pieces (seed_math.h) ------------------------------------------------------------
+int hm_depth_from_triangulation(const double T_search_ref[12], const double f_ref[3], const double f_cur[3], double* depth) {
+  Se3 T;
+  se3_from_Rt(T_search_ref, T);
+  return svo_track::depth_from_triangulation(T, f_ref, f_cur, depth) ? 1 : 0;
+}
+// state = {a, b, mu, sigma2} in and out
+void hm_update_seed(float x, float tau2, float z_range, float state[4]) {
+  svo_track::update_seed(x, tau2, state[0], state[1], state[2], z_range, state[3]);
+}
+double hm_compute_tau(const double T_ref_cur[12], const double f[3], double z, double px_error_angle) {
+  Se3 T;
+  se3_from_Rt(T_ref_cur, T);
+  return svo_track::compute_tau(T, f, z, px_error_angle);
+}
+float hm_normal_pdf(float x, float mean, float sd) { return svo_track::normal_pdff(x, mean, sd); }
 
 }  // extern "C"

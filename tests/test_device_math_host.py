@@ -32,7 +32,7 @@ def _p(a, t=D):
 @pytest.fixture(scope="module")
 def hm():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    deps = [SRC] + [os.path.join(ROOT, "rpg_svo_amd", "csrc", h) for h in ("device_math.h", "track_math.h", "matcher_device.h")]
+    deps = [SRC] + [os.path.join(ROOT, "rpg_svo_amd", "csrc", h) for h in ("device_math.h", "track_math.h", "matcher_device.h", "seed_math.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-math-errno", "-fPIC", "-shared", "-Wall",
                         "-Wno-unknown-pragmas", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "rpg_svo_amd", "csrc"),
@@ -230,3 +230,71 @@ def test_inv3f_and_floor(hm):
         assert np.abs(r.reshape(3, 3).astype(np.float64) @ Hm.astype(np.float64) - np.eye(3)).max() < 1e-3
     for x in (0.0, 0.5, 0.999999, 1.0, 17.25, 639.9999, -0.0, 3.0000002):
         assert hm.hm_floor_to_int(x) == int(np.floor(np.float32(x)))
+
+
+# ---- the depth filter's closed-form pieces (csrc/seed_math.h) -------------------------------------------------------
+def test_update_seed_against_the_oracle(hm):
+    """DepthFilter::updateSeed (f32 with the reference's double sub-expressions, boost's normal pdf through the f64 exp):
+    the kernels' function compiled for the CPU against the oracle's, chained over 30 measurements per seed -- equal bit
+    for bit on this host (the oracle's expf and the f64 exp rounded to float agree on all but ~0.3 % of arguments; the
+    chain is asserted to 1e-6 relative and the share of identical seeds to 97 %)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import pytrack
+    lib = pyoracle.lib()
+    hm.hm_update_seed.argtypes = [C.c_float, C.c_float, C.c_float, F]
+    lib.orc_update_seed.argtypes = [C.c_float, C.c_float, C.POINTER(pytrack.Seed)]
+    lib.orc_seed_init.argtypes = [C.POINTER(pytrack.Seed), C.c_float, C.c_float]
+    rng = np.random.default_rng(21)
+    identical = 0
+    n = 400
+    for k in range(n):
+        seed = pytrack.Seed()
+        depth_mean, depth_min = rng.uniform(1.0, 4.0), rng.uniform(0.3, 0.9)
+        lib.orc_seed_init(C.byref(seed), depth_mean, depth_min)
+        st = np.array([seed.a, seed.b, seed.mu, seed.sigma2], np.float32)
+        zr = seed.z_range
+        true_inv = 1.0 / rng.uniform(depth_min * 1.2, depth_mean * 2)
+        same = True
+        for it in range(30):
+            outlier = rng.uniform() < 0.2
+            x = np.float32(rng.uniform(0.05, 1.0 / depth_min) if outlier else true_inv + rng.normal() * 0.01)
+            tau2 = np.float32(rng.uniform(1e-5, 1e-3))
+            lib.orc_update_seed(x, tau2, C.byref(seed))
+            hm.hm_update_seed(x, tau2, zr, _p(st, F))
+            ref = np.array([seed.a, seed.b, seed.mu, seed.sigma2], np.float32)
+            same = same and np.array_equal(st, ref)
+            assert np.allclose(st, ref, rtol=1e-6, atol=0), (k, it, st, ref)
+        identical += same
+    assert identical >= 0.97 * n, identical
+
+
+def test_compute_tau_and_triangulation(hm):
+    """DepthFilter::computeTau against the oracle, bit for bit; depthFromTriangulation recovers the depth of a point seen
+    from two poses (the oracle keeps that function private: checked on geometry)."""
+    lib = pyoracle.lib()
+    lib.orc_compute_tau.restype = C.c_double
+    hm.hm_compute_tau.restype = C.c_double
+    hm.hm_compute_tau.argtypes = [D, D, C.c_double, C.c_double]
+    lib.orc_compute_tau.argtypes = [D, D, C.c_double, C.c_double]
+    rng = np.random.default_rng(22)
+    px_error_angle = np.arctan(1.0 / (2.0 * 315.5)) * 2.0
+    for k in range(500):
+        T_ref_cur = _random_pose(rng, 0.4, 0.5)
+        f = rng.normal(size=3) * 0.3 + np.array([0, 0, 1.0])
+        f /= np.linalg.norm(f)
+        z = rng.uniform(0.5, 10.0)
+        a = hm.hm_compute_tau(_p(T_ref_cur), _p(f), z, px_error_angle)
+        b = lib.orc_compute_tau(_p(T_ref_cur), _p(f), z, px_error_angle)
+        assert a == b or (np.isnan(a) and np.isnan(b)), (k, a, b)
+        # triangulation: the point at depth z along f in the reference frame, seen from the search frame
+        T_search_ref = pyoracle.se3_inv(T_ref_cur)
+        p_ref = f * z
+        R, t = T_search_ref[:9].reshape(3, 3), T_search_ref[9:]
+        p_cur = R @ p_ref + t
+        if p_cur[2] < 0.1 or np.linalg.norm(t) < 0.05:
+            continue
+        f_cur = p_cur / np.linalg.norm(p_cur)
+        depth = C.c_double()
+        ok = hm.hm_depth_from_triangulation(_p(T_search_ref), _p(f), _p(f_cur), C.byref(depth))
+        if ok:  # (matcher.cpp:116: the two bearings nearly parallel -> no depth)
+            assert abs(depth.value - z) < 1e-8 * max(1.0, z) / max(1e-3, np.linalg.norm(np.cross(R @ f, f_cur)) ** 2), (k, depth.value, z)
