@@ -180,7 +180,7 @@ def test_affine_warp_matrix_and_search_level(hm, model, k, size, d):
     equal bit for bit, for every camera model and reference level."""
     ns, kk, dd = _cam_struct(model, k, size, d)
     pc = pyoracle.make_cam(ns)
-    lib = pyoracle.lib()
+    lib = C.CDLL(pyoracle.lib()._name)
     lib.orc_get_best_search_level.restype = C.c_int
     rng = np.random.default_rng(9 + model)
     for i in range(300):
@@ -240,7 +240,7 @@ def test_update_seed_against_the_oracle(hm):
     chain is asserted to 1e-6 relative and the share of identical seeds to 97 %)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle import pytrack
-    lib = pyoracle.lib()
+    lib = C.CDLL(pyoracle.lib()._name)  # (an own handle: prototypes set here must not leak into the other tests' calls)
     hm.hm_update_seed.argtypes = [C.c_float, C.c_float, C.c_float, F]
     lib.orc_update_seed.argtypes = [C.c_float, C.c_float, C.POINTER(pytrack.Seed)]
     lib.orc_seed_init.argtypes = [C.POINTER(pytrack.Seed), C.c_float, C.c_float]
@@ -271,7 +271,7 @@ def test_update_seed_against_the_oracle(hm):
 def test_compute_tau_and_triangulation(hm):
     """DepthFilter::computeTau against the oracle, bit for bit; depthFromTriangulation recovers the depth of a point seen
     from two poses (the oracle keeps that function private: checked on geometry)."""
-    lib = pyoracle.lib()
+    lib = C.CDLL(pyoracle.lib()._name)  # (an own handle, see above)
     lib.orc_compute_tau.restype = C.c_double
     hm.hm_compute_tau.restype = C.c_double
     hm.hm_compute_tau.argtypes = [D, D, C.c_double, C.c_double]
