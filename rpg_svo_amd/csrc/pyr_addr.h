@@ -17,7 +17,9 @@
 #pragma once
 #include <stdint.h>
 
+#ifndef SVO_HOST_MATH_TEST  // (the CPU tests compile the window loaders with the host compiler, see device_math.h)
 #include <hip/hip_runtime.h>
+#endif
 
 #ifdef SVO_PYR_ROWMAJOR
 #define SVO_PYR_TILE 0

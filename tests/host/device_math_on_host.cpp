@@ -6,6 +6,7 @@
 #define SVO_HOST_MATH_TEST
 #include "matcher_device.h"
 #include "seed_math.h"
+#include "align_lanes.h"
 
 using namespace svo_dev;
 
@@ -98,5 +99,47 @@ double hm_compute_tau(const double T_ref_cur[12], const double f[3], double z, d
   return svo_track::compute_tau(T, f, z, px_error_angle);
 }
 float hm_normal_pdf(float x, float mean, float sd) { return svo_track::normal_pdff(x, mean, sd); }
+
+// ---- K3's lane bodies (align_lanes.h) on a level of the TILED store (pyr_addr.h) ---------------------------------------
+// pwb: the 10 x 10 template with border; px: in / out (level coordinates); returns the verdict of the reference's function
+int hm_align2d(const uint8_t* level, int cols, int rows, int pitch, const uint8_t pwb[100], int n_iter, int phase, double px[2]) {
+  uint32_t g[25];
+  std::memcpy(g, pwb, 100);
+  svo_track::AlignState st;
+  st.u = (float)px[0]; st.v = (float)px[1]; st.mean_diff = 0.f; st.chi2 = 0.f; st.up0 = st.up1 = 0.f;
+  bool converged = false, wrote = true;
+  int n_eval = 0;
+  // `phase` > 0: the iterations in runs of `phase` with the state parked in between, as the phased launches do
+  const int step = phase > 0 ? phase : n_iter;
+  for (int it0 = 0; it0 < n_iter; it0 += step) {
+    const bool go_on = svo_track::align2d_lane(level, cols, rows, pitch, g, n_iter, it0, it0 + step, st, converged, wrote, n_eval);
+    if (!go_on) break;
+  }
+  px[0] = (double)st.u;
+  px[1] = (double)st.v;
+  return converged ? 1 : 0;
+}
+int hm_align1d(const uint8_t* level, int cols, int rows, int pitch, const uint8_t pwb[100], const float dir[2], int n_iter, int phase,
+               double px[2], double* h_inv) {
+  uint32_t g[25];
+  std::memcpy(g, pwb, 100);
+  svo_track::AlignState st;
+  st.u = (float)px[0]; st.v = (float)px[1]; st.mean_diff = 0.f; st.chi2 = 0.f; st.up0 = st.up1 = 0.f;
+  bool converged = false, wrote = true;
+  int n_eval = 0;
+  *h_inv = 0.0;
+  const int step = phase > 0 ? phase : n_iter;
+  for (int it0 = 0; it0 < n_iter; it0 += step) {
+    const bool go_on = svo_track::align1d_lane(level, cols, rows, pitch, g, dir[0], dir[1], n_iter, it0, it0 + step, st, *h_inv, converged,
+                                               wrote, n_eval);
+    if (!go_on) break;
+  }
+  px[0] = (double)st.u;
+  px[1] = (double)st.v;
+  return converged ? 1 : 0;
+}
+// byte offset of pixel (x, y) in a level of the store (for the test to lay an image out)
+unsigned hm_px_off(int x, int y, int pitch) { return svo_pyr::px_off(x, y, pitch); }
+long long hm_level_bytes(int pitch, int h) { return (long long)svo_pyr::level_bytes(pitch, h); }
 
 }  // extern "C"

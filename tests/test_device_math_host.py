@@ -29,20 +29,33 @@ def _p(a, t=D):
     return a.ctypes.data_as(t)
 
 
-@pytest.fixture(scope="module")
-def hm():
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    deps = [SRC] + [os.path.join(ROOT, "rpg_svo_amd", "csrc", h) for h in ("device_math.h", "track_math.h", "matcher_device.h", "seed_math.h")]
-    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
-        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-math-errno", "-fPIC", "-shared", "-Wall",
-                        "-Wno-unknown-pragmas", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "rpg_svo_amd", "csrc"),
-                        SRC, "-o", LIB], check=True)
-    lib = C.CDLL(LIB)
+def _build_host_lib(lib_path, defines=()):
+    os.makedirs(os.path.dirname(lib_path), exist_ok=True)
+    deps = [SRC] + [os.path.join(ROOT, "rpg_svo_amd", "csrc", h)
+                    for h in ("device_math.h", "track_math.h", "matcher_device.h", "seed_math.h", "align_lanes.h", "pyr_addr.h")]
+    if not os.path.exists(lib_path) or any(os.path.getmtime(d) > os.path.getmtime(lib_path) for d in deps):
+        # ROCm's clang++ as a plain C++ compiler for the host (the lane bodies use clang's ext_vector_type pairs)
+        cxx = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang++")
+        subprocess.run([cxx, "-std=c++17", "-O2", "-ffp-contract=off", "-fno-math-errno", "-fPIC", "-shared", "-Wall",
+                        "-Wno-unknown-pragmas", "-Wno-pass-failed", *[f"-D{d}" for d in defines], "-I", os.path.join(ROOT, "include"),
+                        "-I", os.path.join(ROOT, "rpg_svo_amd", "csrc"), SRC, "-o", lib_path], check=True)
+    lib = C.CDLL(lib_path)
     lib.hm_best_search_level.restype = C.c_int
     lib.hm_floor_to_int.restype = C.c_int
     lib.hm_floor_to_int.argtypes = [C.c_float]
     lib.hm_sincos_small.argtypes = [C.c_double, D, D]
     return lib
+
+
+@pytest.fixture(scope="module")
+def hm():
+    return _build_host_lib(LIB)
+
+
+@pytest.fixture(scope="module")
+def hm_g_f16():
+    """the same with -DALIGN_G_F16: align2D's gradient pairs held as f16 (a queued, opt-in build of K3)"""
+    return _build_host_lib(LIB.replace(".so", "_ALIGN_G_F16.so"), ("ALIGN_G_F16",))
 
 
 def _random_pose(rng, angle=0.5, trans=1.0):
@@ -298,3 +311,96 @@ def test_compute_tau_and_triangulation(hm):
         ok = hm.hm_depth_from_triangulation(_p(T_search_ref), _p(f), _p(f_cur), C.byref(depth))
         if ok:  # (matcher.cpp:116: the two bearings nearly parallel -> no depth)
             assert abs(depth.value - z) < 1e-8 * max(1.0, z) / max(1e-3, np.linalg.norm(np.cross(R @ f, f_cur)) ** 2), (k, depth.value, z)
+
+
+# ---- K3's lane bodies (csrc/align_lanes.h) on the tiled store --------------------------------------------------------
+def _texture(rng, h, w):
+    """band-limited noise: smooth enough for Lucas-Kanade, textured enough to converge"""
+    img = rng.uniform(0, 255, (h // 4 + 3, w // 4 + 3))
+    ys, xs = np.arange(h) / 4.0, np.arange(w) / 4.0
+    y0, x0 = ys.astype(int), xs.astype(int)
+    fy, fx = (ys - y0)[:, None], (xs - x0)[None, :]
+    a = img[y0][:, x0] * (1 - fy) * (1 - fx) + img[y0][:, x0 + 1] * (1 - fy) * fx
+    b = img[y0 + 1][:, x0] * fy * (1 - fx) + img[y0 + 1][:, x0 + 1] * fy * fx
+    return np.clip(a + b + rng.normal(0, 2.0, (h, w)), 0, 255).astype(np.uint8)
+
+
+def _tiled(hm, img):
+    h, w = img.shape
+    pitch = (w + 15) & ~15
+    hm.hm_level_bytes.restype = C.c_longlong
+    hm.hm_px_off.restype = C.c_uint
+    buf = np.zeros(hm.hm_level_bytes(pitch, h) + 256, np.uint8)  # (+ slack: the window rows are read as 12-byte runs)
+    ys, xs = np.mgrid[0:h, 0:w]
+    off = (ys >> 3) * 8 * pitch + (ys & 7) * 16 + (xs >> 4) * 128 + (xs & 15)
+    assert off[5, 37] == hm.hm_px_off(37, 5, pitch) and off[h - 1, w - 1] == hm.hm_px_off(w - 1, h - 1, pitch)
+    buf[off.ravel()] = img.ravel()
+    return buf, pitch
+
+
+@pytest.mark.parametrize("phase", [0, 3])
+def test_align2d_lane_is_the_reference_bit_for_bit(hm, phase):
+    """align2D of one trial as the kernel's lane runs it -- on the TILED store, window rows as 12-byte runs cut with
+    v_alignbyte, packed-f32 pixel loop -- against the oracle on the row-major image: the same verdict and the same refined
+    pixel, in every bit, whether the ten iterations run in one go or in phases of three with the state parked in between
+    (as the phased launches do).  Includes trials that leave the image and trials that do not converge."""
+    from oracle import pytrack
+    tr = pytrack.Track("orc")
+    rng = np.random.default_rng(31)
+    img = _texture(rng, 120, 160)
+    buf, pitch = _tiled(hm, img)
+    n_conv = n_fail = 0
+    for k in range(400):
+        x0, y0 = int(rng.integers(8, 152)), int(rng.integers(8, 112))
+        pwb = np.ascontiguousarray(img[y0 - 5:y0 + 5, x0 - 5:x0 + 5])
+        patch = np.ascontiguousarray(pwb[1:9, 1:9])
+        start = np.array([x0 + rng.uniform(-2.5, 2.5), y0 + rng.uniform(-2.5, 2.5)])
+        if k % 10 == 0:
+            start = np.array([rng.choice([3.5, 156.2]), y0])  # next to the border: the loop leaves at once
+        ok_o, px_o = tr.align2d(img, pwb, patch, 10, start)
+        px = start.copy()
+        ok = hm.hm_align2d(_p(buf, C.POINTER(C.c_uint8)), 160, 120, pitch, _p(pwb, C.POINTER(C.c_uint8)), 10, phase, _p(px))
+        assert bool(ok) == ok_o, (k, start, px, px_o)
+        if ok_o:  # (the reference writes the pixel back only on convergence)
+            assert np.array_equal(px, px_o), (k, start, px, px_o)
+            n_conv += 1
+        else:
+            n_fail += 1
+    assert n_conv > 200 and n_fail > 30, (n_conv, n_fail)
+
+
+@pytest.mark.parametrize("phase", [0, 4])
+def test_align1d_lane_is_the_reference_bit_for_bit(hm, phase):
+    """The same for align1D (edgelets / the epipolar 1-D refinement), h_inv included."""
+    from oracle import pytrack
+    tr = pytrack.Track("orc")
+    rng = np.random.default_rng(32)
+    img = _texture(rng, 120, 160)
+    buf, pitch = _tiled(hm, img)
+    n_conv = 0
+    for k in range(300):
+        x0, y0 = int(rng.integers(8, 152)), int(rng.integers(8, 112))
+        pwb = np.ascontiguousarray(img[y0 - 5:y0 + 5, x0 - 5:x0 + 5])
+        patch = np.ascontiguousarray(pwb[1:9, 1:9])
+        ang = rng.uniform(0, 2 * np.pi)
+        d = np.array([np.cos(ang), np.sin(ang)], np.float32)
+        s = rng.uniform(-2.0, 2.0)
+        start = np.array([x0 + s * d[0], y0 + s * d[1]], np.float64)
+        ok_o, px_o, h_o = tr.align1d(img, d, pwb, patch, 10, start)
+        px = start.copy()
+        h_inv = C.c_double(0)
+        ok = hm.hm_align1d(_p(buf, C.POINTER(C.c_uint8)), 160, 120, pitch, _p(pwb, C.POINTER(C.c_uint8)), _p(d, F), 10, phase, _p(px),
+                           C.byref(h_inv))
+        assert bool(ok) == ok_o, (k, start, px, px_o)
+        if ok_o:
+            assert np.array_equal(px, px_o), (k, start, px, px_o)
+            assert h_inv.value == h_o, (k, h_inv.value, h_o)
+            n_conv += 1
+    assert n_conv > 100, n_conv
+
+
+def test_align2d_with_f16_gradients_is_still_the_reference(hm_g_f16):
+    """The queued -DALIGN_G_F16 build of K3 (gradient pairs as f16: half-integers up to 127.5 are exact there) gives the
+    same bits as the oracle -- checked here on the CPU before the variant ever runs on a GPU."""
+    test_align2d_lane_is_the_reference_bit_for_bit(hm_g_f16, 0)
+    test_align2d_lane_is_the_reference_bit_for_bit(hm_g_f16, 3)
