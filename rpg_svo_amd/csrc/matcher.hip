@@ -20,6 +20,7 @@
 #include "track_kernels.h"
 #include "track_math.h"
 #include "matcher_device.h"
+#include "warp_sample.h"
 
 using namespace svo_capi;
 using namespace svo_dev;
@@ -329,44 +330,11 @@ __global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) 
                 }
               };
 #ifdef WARP_PACKED
-              // (round-5 queue, UNMEASURED: with the region fetch out of the way the kernel is bound by vector-instruction
-              // issue (90 % at 3 cycles per instruction).  Two output rows of a lane as the two halves of packed f32
-              // operations -- v_pk_mul_f32 / v_pk_add_f32 issue in 3.5 cycles against 2 x 2.4 and round every product and
-              // sum on its own, in the expression's order: the same bits -- for the 16 multiplies and additions of a
-              // sample; floor, fraction, the byte reads and the conversions stay scalar.)
-              if (all_in) {
-                typedef float f2 __attribute__((ext_vector_type(2)));
-                float pp0 = (float)(x - 5);
-                pp0 *= sc;
-                const float ax = A.x * pp0, az = A.z * pp0;
-                const f2 AX = {ax, ax}, AZ = {az, az}, AY = {A.y, A.y}, AW = {A.w, A.w}, PX = {pyr.x, pyr.x}, PY = {pyr.y, pyr.y};
-                const f2 ONE = {1.0f, 1.0f}, SC = {sc, sc};
-#pragma unroll
-                for (int y = 0; y < 10; y += 2) {
-                  f2 pp1 = {(float)(y - 5), (float)(y - 4)};
-                  pp1 = pp1 * SC;
-                  const f2 u = (AX + AY * pp1) + PX;
-                  const f2 v = (AZ + AW * pp1) + PY;
-                  const int xa = svo_dev::floor_to_int(u.x), ya = svo_dev::floor_to_int(v.x);
-                  const int xb = svo_dev::floor_to_int(u.y), yb = svo_dev::floor_to_int(v.y);
-                  const f2 sx = {__builtin_amdgcn_fractf(u.x), __builtin_amdgcn_fractf(u.y)};
-                  const f2 sy = {__builtin_amdgcn_fractf(v.x), __builtin_amdgcn_fractf(v.y)};
-                  const f2 omx = ONE - sx, omy = ONE - sy;
-                  const f2 w00 = omx * omy;
-                  const f2 w01 = omx * sy;
-                  const f2 w10 = sx * omy;
-                  const f2 w11 = ONE - w00 - w01 - w10;
-                  const uint8_t* qa = reg_o + (__mul24(ya, 48) + xa);
-                  const uint8_t* qb = reg_o + (__mul24(yb, 48) + xb);
-                  const f2 p00 = {(float)qa[0], (float)qb[0]}, p10 = {(float)qa[1], (float)qb[1]};
-                  const f2 p01 = {(float)qa[48], (float)qb[48]}, p11 = {(float)qa[49], (float)qb[49]};
-                  const f2 val = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
-                  out[y] = (uint8_t)val.x;
-                  out[y + 1] = (uint8_t)val.y;
-                }
-              } else {
-                rows10(std::true_type{});
-              }
+              // (round-5 queue: the packed-f32 sample arithmetic of warp_sample.h -- checked against the oracle bit for bit
+              // on the CPU by tests/test_device_math_host.py, not yet executed on a GPU.  The default build keeps the loop
+              // above, whose ISA is the measured one; warp_sample.h's warp_column<> is the same arithmetic as a function.)
+              if (all_in) warp_column_packed(A.x, A.y, A.z, A.w, pyr.x, pyr.y, sc, x, reg_o, out);
+              else warp_column<true>(A.x, A.y, A.z, A.w, pyr.x, pyr.y, sc, x, cols, rows, xlo, ylo, reg_o, out);
 #else
               if (all_in) rows10(std::false_type{});
               else rows10(std::true_type{});

@@ -1,0 +1,86 @@
+// warp_sample.h -- the sample arithmetic of warp::warpAffine (matcher.cpp:72-105) as warp_kernel's lanes run it: one
+// output COLUMN x of a trial's 10 x 10 patch, ten samples down the rows, read from a copy of the source region laid out
+// in rows of 48 bytes (reg_o[48 yi + xi] is pixel (xi, yi) of the level).  Device functions of matcher.hip; also
+// compiled for the CPU by the test suite (SVO_HOST_MATH_TEST, see device_math.h) and compared with the oracle bit for bit.
+// The including translation unit sets `#pragma clang fp contract(off)`: every product and sum rounds on its own.
+#pragma once
+#include "track_math.h"
+
+#ifdef SVO_HOST_MATH_TEST
+#define __builtin_amdgcn_fractf(x) ((x)-floorf(x))  // (exact for x >= 0: the only arguments it sees here)
+#define __mul24(a, b) ((a) * (b))
+#endif
+
+namespace svo_track {
+
+// CHECK: the per-sample bounds test of vk::interpolateMat_8u (a sample outside the image is 0); without it the caller
+// has shown that every sample lies inside (the box of the four corner samples does).
+// floor and fraction of a coordinate are one instruction each on the device (v_cvt_flr_i32_f32, v_fract_f32: u - floor(u)
+// is exact for u >= 0, so the fraction has the same bits), the sample's address one 24-bit multiply and one add.
+template <bool CHECK>
+__device__ __forceinline__ void warp_column(const float Ax, const float Ay, const float Az, const float Aw, const float pyrx,
+                                            const float pyry, const float sc, const int x, const int cols, const int rows,
+                                            const int xlo, const int ylo, const uint8_t* const reg_o, uint8_t out[10]) {
+#pragma unroll
+  for (int y = 0; y < 10; ++y) {
+    float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
+    pp0 *= sc;
+    pp1 *= sc;
+    const float px0 = (Ax * pp0 + Ay * pp1) + pyrx;
+    const float px1 = (Az * pp0 + Aw * pp1) + pyry;
+    const bool in = !CHECK || !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
+    // vk::interpolateMat_8u (a sample outside the image is 0)
+    const float u = in ? px0 : (float)xlo, v = in ? px1 : (float)ylo;
+    const int xi = svo_dev::floor_to_int(u), yi = svo_dev::floor_to_int(v);
+    const float sx = __builtin_amdgcn_fractf(u), sy = __builtin_amdgcn_fractf(v);
+    const float w00 = (1.0f - sx) * (1.0f - sy);
+    const float w01 = (1.0f - sx) * sy;
+    const float w10 = sx * (1.0f - sy);
+    const float w11 = 1.0f - w00 - w01 - w10;
+    const uint8_t* q = reg_o + (__mul24(yi, 48) + xi);
+    const float p00 = (float)q[0], p10 = (float)q[1], p01 = (float)q[48], p11 = (float)q[49];
+    const float val = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
+    out[y] = in ? (uint8_t)val : (uint8_t)0;
+  }
+}
+
+// (round-5 queue, UNMEASURED on the GPU; -DWARP_PACKED selects it in the kernel: with the region fetch out of the way the
+// kernel is bound by vector-instruction issue (90 % at 3 cycles per instruction).  Two output rows of a lane as the two
+// halves of packed f32 operations -- v_pk_mul_f32 / v_pk_add_f32 issue in 3.5 cycles against 2 x 2.4 and round every
+// product and sum on its own, in the expression's order: the same bits -- for the 16 multiplies and additions of a
+// sample; floor, fraction, the byte reads and the conversions stay scalar.  Every sample inside the image.)
+__device__ __forceinline__ void warp_column_packed(const float Ax, const float Ay, const float Az, const float Aw, const float pyrx,
+                                                   const float pyry, const float sc, const int x, const uint8_t* const reg_o,
+                                                   uint8_t out[10]) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  float pp0 = (float)(x - 5);
+  pp0 *= sc;
+  const float ax = Ax * pp0, az = Az * pp0;
+  const f2 AX = {ax, ax}, AZ = {az, az}, AY = {Ay, Ay}, AW = {Aw, Aw}, PX = {pyrx, pyrx}, PY = {pyry, pyry};
+  const f2 ONE = {1.0f, 1.0f}, SC = {sc, sc};
+#pragma unroll
+  for (int y = 0; y < 10; y += 2) {
+    f2 pp1 = {(float)(y - 5), (float)(y - 4)};
+    pp1 = pp1 * SC;
+    const f2 u = (AX + AY * pp1) + PX;
+    const f2 v = (AZ + AW * pp1) + PY;
+    const int xa = svo_dev::floor_to_int(u.x), ya = svo_dev::floor_to_int(v.x);
+    const int xb = svo_dev::floor_to_int(u.y), yb = svo_dev::floor_to_int(v.y);
+    const f2 sx = {__builtin_amdgcn_fractf(u.x), __builtin_amdgcn_fractf(u.y)};
+    const f2 sy = {__builtin_amdgcn_fractf(v.x), __builtin_amdgcn_fractf(v.y)};
+    const f2 omx = ONE - sx, omy = ONE - sy;
+    const f2 w00 = omx * omy;
+    const f2 w01 = omx * sy;
+    const f2 w10 = sx * omy;
+    const f2 w11 = ONE - w00 - w01 - w10;
+    const uint8_t* qa = reg_o + (__mul24(ya, 48) + xa);
+    const uint8_t* qb = reg_o + (__mul24(yb, 48) + xb);
+    const f2 p00 = {(float)qa[0], (float)qb[0]}, p10 = {(float)qa[1], (float)qb[1]};
+    const f2 p01 = {(float)qa[48], (float)qb[48]}, p11 = {(float)qa[49], (float)qb[49]};
+    const f2 val = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
+    out[y] = (uint8_t)val.x;
+    out[y + 1] = (uint8_t)val.y;
+  }
+}
+
+}  // namespace svo_track

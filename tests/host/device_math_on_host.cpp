@@ -7,6 +7,7 @@
 #include "matcher_device.h"
 #include "seed_math.h"
 #include "align_lanes.h"
+#include "warp_sample.h"
 
 using namespace svo_dev;
 
@@ -141,5 +142,40 @@ int hm_align1d(const uint8_t* level, int cols, int rows, int pitch, const uint8_
 // byte offset of pixel (x, y) in a level of the store (for the test to lay an image out)
 unsigned hm_px_off(int x, int y, int pitch) { return svo_pyr::px_off(x, y, pitch); }
 long long hm_level_bytes(int pitch, int h) { return (long long)svo_pyr::level_bytes(pitch, h); }
+
+// ---- warp_kernel's sample arithmetic (warp_sample.h) -----------------------------------------------------------------
+// The level is a 48-byte-wide image, i.e. it IS a region in the kernel's layout (reg_o = level, xlo = ylo = 0).
+// mode 0: warp_column<true> (per-sample bounds test), 1: warp_column<false>, 2: warp_column_packed; modes 1 and 2 need the
+// box of the four corner samples inside the image, as in the kernel: -1 when it is not.  Returns 0 when A^-1 is NaN.
+int hm_warp_patch(const uint8_t* level48, int rows, const double A_cur_ref[4], const double px_ref[2], int level_ref, int search_level,
+                  int mode, uint8_t out[100]) {
+  const int cols = 48;
+  double Ainv[4];
+  inv2<double>(A_cur_ref, Ainv);
+  const float Ax = (float)Ainv[0], Ay = (float)Ainv[1], Az = (float)Ainv[2], Aw = (float)Ainv[3];
+  if (Ax != Ax) return 0;
+  const float pyrx = (float)px_ref[0] / (float)(1 << level_ref), pyry = (float)px_ref[1] / (float)(1 << level_ref);
+  const float sc = (float)(1 << search_level);
+  float bx0 = 3.0e38f, bx1 = -3.0e38f, by0 = 3.0e38f, by1 = -3.0e38f;
+  for (int k = 0; k < 4; ++k) {
+    float pp0 = (float)((k & 1) ? 4 : -5), pp1 = (float)((k & 2) ? 4 : -5);
+    pp0 *= sc;
+    pp1 *= sc;
+    const float q0 = (Ax * pp0 + Ay * pp1) + pyrx;
+    const float q1 = (Az * pp0 + Aw * pp1) + pyry;
+    bx0 = fminf(bx0, q0); bx1 = fmaxf(bx1, q0);
+    by0 = fminf(by0, q1); by1 = fmaxf(by1, q1);
+  }
+  const bool all_in = bx0 >= 0.f && by0 >= 0.f && bx1 < (float)(cols - 1) && by1 < (float)(rows - 1);
+  if (mode != 0 && !all_in) return -1;
+  for (int x = 0; x < 10; ++x) {
+    uint8_t col[10];
+    if (mode == 0) svo_track::warp_column<true>(Ax, Ay, Az, Aw, pyrx, pyry, sc, x, cols, rows, 0, 0, level48, col);
+    else if (mode == 1) svo_track::warp_column<false>(Ax, Ay, Az, Aw, pyrx, pyry, sc, x, cols, rows, 0, 0, level48, col);
+    else svo_track::warp_column_packed(Ax, Ay, Az, Aw, pyrx, pyry, sc, x, level48, col);
+    for (int y = 0; y < 10; ++y) out[y * 10 + x] = col[y];
+  }
+  return 1;
+}
 
 }  // extern "C"

@@ -32,7 +32,7 @@ def _p(a, t=D):
 def _build_host_lib(lib_path, defines=()):
     os.makedirs(os.path.dirname(lib_path), exist_ok=True)
     deps = [SRC] + [os.path.join(ROOT, "rpg_svo_amd", "csrc", h)
-                    for h in ("device_math.h", "track_math.h", "matcher_device.h", "seed_math.h", "align_lanes.h", "pyr_addr.h")]
+                    for h in ("device_math.h", "track_math.h", "matcher_device.h", "seed_math.h", "align_lanes.h", "pyr_addr.h", "warp_sample.h")]
     if not os.path.exists(lib_path) or any(os.path.getmtime(d) > os.path.getmtime(lib_path) for d in deps):
         # ROCm's clang++ as a plain C++ compiler for the host (the lane bodies use clang's ext_vector_type pairs)
         cxx = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang++")
@@ -404,3 +404,38 @@ def test_align2d_with_f16_gradients_is_still_the_reference(hm_g_f16):
     same bits as the oracle -- checked here on the CPU before the variant ever runs on a GPU."""
     test_align2d_lane_is_the_reference_bit_for_bit(hm_g_f16, 0)
     test_align2d_lane_is_the_reference_bit_for_bit(hm_g_f16, 3)
+
+
+# ---- warp_kernel's sample arithmetic (csrc/warp_sample.h) ------------------------------------------------------------
+def test_warp_samples_are_the_reference_bit_for_bit(hm):
+    """warp::warpAffine's 10 x 10 patch as warp_kernel's lanes compute it -- one output column per lane, floor and fraction
+    as the single-instruction forms, a region in rows of 48 bytes -- against the oracle: the same bytes, for the checked
+    form (samples outside the image are 0), the unchecked form (box of the corner samples inside the image) and the
+    queued packed-f32 form (-DWARP_PACKED: two output rows per packed operation), over rotations, scales 0.4-2.4, search
+    levels 0-2 and reference levels 0-2."""
+    from oracle import pytrack
+    tr = pytrack.Track("orc")
+    rng = np.random.default_rng(41)
+    img = _texture(rng, 64, 48)  # 48 bytes wide: the level is a region in the kernel's layout as it is
+    U8 = C.POINTER(C.c_uint8)
+    counts = {0: 0, 1: 0, 2: 0}
+    zeros_seen = 0
+    for k in range(1500):
+        ang, scale = rng.uniform(0, 2 * np.pi), rng.uniform(0.4, 2.4)
+        shear = rng.uniform(-0.2, 0.2)
+        A = scale * np.array([[np.cos(ang), -np.sin(ang) + shear], [np.sin(ang), np.cos(ang)]])
+        level_ref, search_level = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        centre = np.array([rng.uniform(-2, 50), rng.uniform(-2, 66)])  # (level coordinates; some near or over the border)
+        px_ref = centre * (1 << level_ref)
+        ok_o, patch_o = tr.warp_affine(A, img, px_ref, level_ref, search_level, 5)
+        for mode in (0, 1, 2):
+            out = np.zeros(100, np.uint8)
+            r = hm.hm_warp_patch(_p(img, U8), 64, _p(np.ascontiguousarray(A.ravel())), _p(px_ref), level_ref, search_level, mode, _p(out, U8))
+            if r < 0:
+                continue
+            assert bool(r) == ok_o
+            assert np.array_equal(out, patch_o), (k, mode, A, px_ref, level_ref, search_level, out.reshape(10, 10), patch_o.reshape(10, 10))
+            counts[mode] += 1
+        zeros_seen += int((patch_o == 0).sum() > 20)
+    assert counts[0] == 1500 and counts[1] > 150 and counts[2] == counts[1], counts
+    assert zeros_seen > 100  # (patches hanging over the border exercised the bounds test)
