@@ -1091,7 +1091,9 @@ def pmc_leg(args, kernel_ms: float) -> dict:
               "mix": ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F64",
                       "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32"],
               "mix2": ["SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_INT64", "SQ_INSTS", "SQ_INSTS_SALU",
-                       "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_BRANCH"]}
+                       "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_BRANCH"],
+              # the LDS port of the CU (lds_port_use); last: a failure here costs nothing that came before
+              "lds": ["SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS"]}
     status, raw = {}, {}
     env = dict(os.environ, TMPDIR="/tmp")
     env.pop("SVO_BENCH_FORCE_DIST", None)
@@ -1138,6 +1140,11 @@ def pmc_leg(args, kernel_ms: float) -> dict:
         out["write_bytes_per_launch"] = raw["WRITE_SIZE"] * 1024.0
     if "SQ_INSTS_VALU" in raw:
         out["roofline_valu"] = valu_roofline(raw, kernel_ms)
+        if "SQ_LDS_IDX_ACTIVE" in raw:
+            try:
+                out["roofline_valu"]["lds"] = lds_port_use(raw)
+            except Exception as e:  # (never in the way of the line)
+                out["roofline_valu"]["lds"] = {"skipped": repr(e)}
     return out
 
 
