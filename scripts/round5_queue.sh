@@ -20,7 +20,8 @@ if [ -f $V/libsvo_hip_WARP_PACKED.so ]; then
   SVO_HIP_LIB=$PWD/$V/libsvo_hip_WARP_PACKED.so python -m pytest tests/test_tracking_gpu.py -q -m gpu -x 2>&1 | tail -2
   bash scripts/full_variants.sh main svo_hip_WARP_PACKED main svo_hip_WARP_PACKED 2>&1 | cut -c1-220
 fi
-echo "== SCAN_PREFETCH: the next pass's box requested before this pass is scored (expected: up to -1 ms of epi_scan's 2.6)"
+echo "== SCAN_PREFETCH: the next pass's box requested before this pass is scored (expected: up to -1 ms of epi_scan's 2.6;"
+echo "   identical to the default scan on the CPU emulation, tests/test_scan_emulated.py)"
 for v in svo_hip_SCAN_PREFETCH "svo_hip_SCAN_PREFETCH_SCAN_MINW=4"; do
   if [ -f "$V/lib$v.so" ]; then
     SVO_HIP_LIB="$PWD/$V/lib$v.so" python -m pytest tests/test_tracking_gpu.py tests/test_full_size_gpu.py -q -m gpu -x 2>&1 | tail -2

@@ -1,0 +1,69 @@
+// scan_emulated.cpp -- TEST INFRASTRUCTURE.  The epipolar ZMSSD scan of epi_scan_kernel (rpg_svo_amd/csrc/epi_scan.h) run on
+// the CPU through tests/host/simt_emu.h, in its default form and in the queued -DSCAN_PREFETCH form, on the same seeds:
+// tests/test_scan_emulated.py compares what the two write.
+#define SVO_HOST_MATH_TEST
+#define SCAN_PREFETCH  // (compiles epi_scan_seed_prefetch next to epi_scan_seed)
+#include "simt_emu.h"
+
+#include <thread>
+#include <vector>
+
+#include "epi_scan.h"
+
+extern "C" {
+
+// Scans seeds [0, S) with form 0 (epi_scan_seed) or 1 (epi_scan_seed_prefetch).  One level-`n_levels` store of one slot;
+// workspace arrays as SeedWs names them (only what the scan reads and writes).
+int scan_emulated(int form, int S, const uint8_t* store, long long slot_bytes, int n_levels, const long long* level_offset,
+                  const int* level_w, const int* level_h, const int* level_pitch, const double cam_k[4], int width, int height,
+                  int subpix_refinement, const int32_t* search_level, const int32_t* cur_slot, const int32_t* n_steps, const double* B,
+                  const double* step, const uint8_t* pwb, double* uv_best, double* px_cur, double* px_scaled, uint8_t* align_active,
+                  uint8_t* accepted_raw, int32_t* status) {
+  SeedArgs a;
+  std::memset(&a, 0, sizeof(a));
+  for (int l = 0; l < n_levels && l < SVO_HIP_MAX_LEVELS; ++l) {
+    a.L.offset[l] = level_offset[l];
+    a.L.w[l] = level_w[l];
+    a.L.h[l] = level_h[l];
+    a.L.pitch[l] = level_pitch[l];
+  }
+  a.L.n_levels = n_levels;
+  a.L.slot_bytes = slot_bytes;
+  a.store = store;
+  a.cam.fx = cam_k[0]; a.cam.fy = cam_k[1]; a.cam.cx = cam_k[2]; a.cam.cy = cam_k[3];
+  a.cam.width = width; a.cam.height = height; a.cam.model = SVO_HIP_CAM_PINHOLE;
+  a.S = S;
+  a.opt.subpix_refinement = subpix_refinement;
+  a.ws.search_level = const_cast<int32_t*>(search_level);
+  a.ws.cur_slot = const_cast<int32_t*>(cur_slot);
+  a.ws.n_steps = const_cast<int32_t*>(n_steps);
+  a.ws.B = const_cast<double*>(B);
+  a.ws.step = const_cast<double*>(step);
+  a.ws.pwb = const_cast<uint8_t*>(pwb);
+  a.ws.uv_best = uv_best;
+  a.ws.px_cur = px_cur;
+  a.ws.px_scaled = px_scaled;
+  a.ws.align_active = align_active;
+  a.ws.accepted_raw = accepted_raw;
+  a.ws.status = status;
+  // a "wave" of 8 groups at a time: group g of the wave scans seed s0 + g (threadIdx.x = 8 g + lane)
+  for (int s0 = 0; s0 < S; s0 += 8) {
+    const int n_groups = S - s0 < 8 ? S - s0 : 8;
+    std::vector<svo_emu::Group> groups(n_groups);
+    std::vector<std::vector<uint32_t>> boxes(n_groups, std::vector<uint32_t>(SCAN_BOX_DWORDS + 8, 0u));
+    std::vector<std::thread> threads;
+    for (int g = 0; g < n_groups; ++g)
+      for (int lane = 0; lane < svo_emu::GROUP; ++lane)
+        threads.emplace_back([&, g, lane] {
+          svo_emu::t_group = &groups[g];
+          svo_emu::t_lane = lane;
+          svo_emu::t_thread = (unsigned)(8 * g + lane);
+          if (form == 0) epi_scan_seed(a, s0 + g, lane, boxes[g].data());
+          else epi_scan_seed_prefetch(a, s0 + g, lane, boxes[g].data());
+        });
+    for (auto& t : threads) t.join();
+  }
+  return 0;
+}
+
+}  // extern "C"
