@@ -36,6 +36,8 @@ def _build_host_lib(lib_path, defines=()):
     if not os.path.exists(lib_path) or any(os.path.getmtime(d) > os.path.getmtime(lib_path) for d in deps):
         # ROCm's clang++ as a plain C++ compiler for the host (the lane bodies use clang's ext_vector_type pairs)
         cxx = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang++")
+        if not os.path.exists(cxx):
+            pytest.skip("no ROCm clang++ to compile the kernels' headers for the host")
         subprocess.run([cxx, "-std=c++17", "-O2", "-ffp-contract=off", "-fno-math-errno", "-fPIC", "-shared", "-Wall",
                         "-Wno-unknown-pragmas", "-Wno-pass-failed", *[f"-D{d}" for d in defines], "-I", os.path.join(ROOT, "include"),
                         "-I", os.path.join(ROOT, "rpg_svo_amd", "csrc"), SRC, "-o", lib_path], check=True)
