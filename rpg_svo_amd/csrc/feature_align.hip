@@ -75,6 +75,56 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const Al
     t = blockIdx.x * ALIGN_BLOCK + threadIdx.x;
     if (t >= (a.M_dev ? min(*a.M_dev, a.M) : a.M)) return;
   }
+#ifdef ALIGN_LOAD_FIRST
+  // (round-5 queue, UNMEASURED: everything the trial needs before its first window -- the active flag, slot and level, the
+  // 25 template dwords, the start pixel or the parked state, the 1-D flag and direction -- is requested before the first
+  // of these values is looked at.  The default order tests the flag, then reads slot / level, then the template, then the
+  // pixel, then the 1-D flag, each behind its own wait: six memory round trips before the first of ~3 iterations of a
+  // phase, which is one round trip each.  Lanes that leave at once have read 130 bytes for nothing.)
+  // (a load under a condition -- even a uniform one -- is waited for inside its branch, where its value is turned into
+  // a mask: the optional arrays are read through a stand-in pointer to memory that is always there instead)
+  const bool first = a.it0 == 0;
+  const bool has_act = first && a.active != nullptr;
+  const uint8_t act_raw = (has_act ? a.active : a.pwb)[t];
+  const int level = a.level[t];
+  const int slot_t = a.slot[t];
+  uint32_t g[25];
+  {
+    const uint32_t* gp = reinterpret_cast<const uint32_t*>(a.pwb + (size_t)t * 100);
+#pragma unroll
+    for (int k = 0; k < 25; ++k) g[k] = gp[k];
+  }
+  const double pin0 = a.px_in[2 * t], pin1 = a.px_in[2 * t + 1];
+  // (the parked state of a resumed trial; in the first phase six floats of the template array, read and not used)
+  const float* const sp = (first ? reinterpret_cast<const float*>(a.pwb) : a.state) + 6 * (size_t)t;
+  const float s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5];
+  const uint8_t u1d_raw = (a.use_1d ? a.use_1d : a.pwb)[t];
+  const bool has_dir = a.use_1d != nullptr && a.dir != nullptr;
+  const float* const dirp = has_dir ? a.dir : reinterpret_cast<const float*>(a.px_in);  // ([M][2] doubles: floats 2t, 2t + 1 exist)
+  const float dir0 = dirp[2 * t], dir1 = dirp[2 * t + 1];
+  const uint8_t u1d = a.use_1d ? u1d_raw : (uint8_t)0;
+  if (has_act && act_raw == 0) {
+    a.ok[t] = 0;  // px_out is left as it is (findMatchDirect returns before touching px_cur)
+    if (COUNT) a.iters[t] = 0;
+    return;
+  }
+  AlignState st;
+  st.u = first ? (float)pin0 : s0;
+  st.v = first ? (float)pin1 : s1;
+  st.mean_diff = first ? 0.f : s2; st.chi2 = first ? 0.f : s3; st.up0 = first ? 0.f : s4; st.up1 = first ? 0.f : s5;
+  const uint8_t* img = a.store + (int64_t)slot_t * a.L.slot_bytes + a.L.offset[level];
+  const int cols = a.L.w[level], rows = a.L.h[level], pitch = a.L.pitch[level];
+  bool wrote = true, ok = false, more;
+  int n_eval = 0;
+  const bool one_d = u1d != 0;
+  if (one_d) {
+    double h_inv = 0;
+    more = align1d_lane(img, cols, rows, pitch, g, dir0, dir1, a.n_iter, a.it0, a.it1, st, h_inv, ok, wrote, n_eval);
+    if (a.h_inv) a.h_inv[t] = h_inv;
+  } else {
+    more = align2d_lane(img, cols, rows, pitch, g, a.n_iter, a.it0, a.it1, st, ok, wrote, n_eval);
+  }
+#else
   const bool first = a.it0 == 0;
   if (first && a.active && !a.active[t]) {
     a.ok[t] = 0;  // px_out is left as it is (findMatchDirect returns before touching px_cur)
@@ -113,6 +163,7 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const Al
   } else {
     more = align2d_lane(img, cols, rows, pitch, g, a.n_iter, a.it0, a.it1, st, ok, wrote, n_eval);
   }
+#endif
   if (COUNT) a.iters[t] = (first ? 0 : a.iters[t]) + n_eval;
   if (a.queue_out) {
     // still iterating: park the loop state, append the trial to this workgroup's queue (one atomic per wave)
