@@ -58,15 +58,27 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   // trips, (cf, rfi, batch id, mu, sigma2, f) then (the two poses, the slot), instead of three or four: a load below an
   // early exit cannot be issued above it by the compiler.  The kernel waits 54 % of its wave cycles.)
   const int rfi = a.ftr.d_frame[s];
-  const int batch_id = a.match_only ? 0 : a.seeds.d_batch_id[s];
-  const float mu = a.match_only ? 1.f : a.seeds.d_mu[s], sigma2 = a.match_only ? 0.f : a.seeds.d_sigma2[s];
+  // (the seed state does not exist in match-only calls: read through stand-in pointers, see below)
+  const int batch_raw = (a.match_only ? a.ftr.d_level : a.seeds.d_batch_id)[s];
+  const float mu_raw = (a.match_only ? reinterpret_cast<const float*>(a.ftr.d_px) : a.seeds.d_mu)[s];
+  const float sigma2_raw = (a.match_only ? reinterpret_cast<const float*>(a.ftr.d_px) : a.seeds.d_sigma2)[s];
+  const int batch_id = a.match_only ? 0 : batch_raw;
+  const float mu = a.match_only ? 1.f : mu_raw, sigma2 = a.match_only ? 0.f : sigma2_raw;
   const double f[3] = {a.ftr.d_f[3 * s], a.ftr.d_f[3 * s + 1], a.ftr.d_f[3 * s + 2]};
+  // (what the epipolar set-up reads further down, behind two more early exits: the feature's level, pixel, type and
+  // gradient -- the optional type array through a stand-in pointer, a load under a condition is waited for in its branch)
+  const int rlevel_early = a.ftr.d_level[s];
+  const double rpx0_early = a.ftr.d_px[2 * s], rpx1_early = a.ftr.d_px[2 * s + 1];
+  const uint8_t type_early = (a.ftr.d_type ? a.ftr.d_type : reinterpret_cast<const uint8_t*>(a.ftr.d_px))[s];
+  const double* const gradp = (a.ftr.d_type && a.ftr.d_grad) ? a.ftr.d_grad : a.ftr.d_px;
+  const double gx_early = gradp[2 * s], gy_early = gradp[2 * s + 1];
   double RtR[12], RtC[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
     RtR[k] = a.frame_T[12 * rfi + k];
     RtC[k] = a.frame_T[12 * cf + k];
   }
+  const int ref_slot_early = a.frame_slot[rfi];
   w.cur_slot[s] = a.frame_slot[cf];
   // check if seed is not already too old (:216-219)
   if (!a.match_only && (a.opt.batch_counter - batch_id) > a.opt.max_n_kfs) {
@@ -129,12 +141,22 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   se3_apply(T_cur_ref, p, q);
   project2d(q, B);
   const double epi_dir[2] = {A[0] - B[0], A[1] - B[1]};
+#ifdef SEED_LOAD_FIRST
+  const int rlevel = rlevel_early;
+  const double rpx[2] = {rpx0_early, rpx1_early};
+#else
   const int rlevel = a.ftr.d_level[s];
   const double rpx[2] = {a.ftr.d_px[2 * s], a.ftr.d_px[2 * s + 1]};
+#endif
   double Am[4];
   warp_matrix_affine(a.cam, rpx, f, d_estimate, T_cur_ref, rlevel, Am);
+#ifdef SEED_LOAD_FIRST
+  if (a.ftr.d_type && type_early == SVO_HIP_FTR_EDGELET && a.opt.epi_search_edgelet_filtering) {
+    const double gx = gx_early, gy = gy_early;
+#else
   if (a.ftr.d_type && a.ftr.d_type[s] == SVO_HIP_FTR_EDGELET && a.opt.epi_search_edgelet_filtering) {
     const double gx = a.ftr.d_grad[2 * s], gy = a.ftr.d_grad[2 * s + 1];
+#endif
     double g[2] = {Am[0] * gx + Am[1] * gy, Am[2] * gx + Am[3] * gy};
     const double gn = norm2(g);
     g[0] /= gn;
@@ -165,7 +187,11 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   w.A_ref_cur[4 * s + 3] = (float)Ainv[3];
   w.px_ref_pyr[2 * s] = (float)rpx[0] / (float)(1 << rlevel);
   w.px_ref_pyr[2 * s + 1] = (float)rpx[1] / (float)(1 << rlevel);
+#ifdef SEED_LOAD_FIRST
+  w.ref_slot[s] = ref_slot_early;
+#else
   w.ref_slot[s] = a.frame_slot[rfi];
+#endif
   w.ref_level[s] = rlevel;
   w.warp_active[s] = 1;
   {  // (px_A-px_B).cast<float>().normalized()
