@@ -62,6 +62,64 @@ struct PrepArgs {
 __global__ void __launch_bounds__(64) match_prepare_kernel(const PrepArgs a) {
   const int m = blockIdx.x * 64 + threadIdx.x;
   if (m >= (a.M_dev ? min(*a.M_dev, a.M) : a.M)) return;
+#ifdef PREP_LOAD_FIRST
+  // (round-5 queue, UNMEASURED: the trial's own records -- frame, projection, observation range, position -- are requested
+  // before anything is stored or looked at, the frame's pose and slot in a second round; in the closest-view loop the frame
+  // index of observation o + 1 is requested while observation o is worked on, so that an observation costs one dependent
+  // memory round trip, not two.  The default order makes ~8 round trips before the loop and two per observation.)
+  const int cf = a.cur_frame[m];
+  const double pxc0 = a.px_cur[2 * m], pxc1 = a.px_cur[2 * m + 1];
+  // (either CSR offsets or begin / end arrays: read through one pointer each, a load under a condition is waited for in its branch)
+  const int o0 = (a.obs_ptr ? a.obs_ptr : a.obs_begin)[m], o1 = (a.obs_ptr ? a.obs_ptr + 1 : a.obs_end)[m];
+  const double pt[3] = {a.pt_pos[3 * m], a.pt_pos[3 * m + 1], a.pt_pos[3 * m + 2]};
+  double RtC[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) RtC[k] = a.frame_T[12 * cf + k];
+  const int cur_slot_v = a.frame_slot[cf];
+  int fi_next = o1 > o0 ? a.obs.d_frame[o0] : 0;
+  a.active[m] = 0;
+  a.ref_obs[m] = -1;
+  a.search_level[m] = 0;
+  a.ref_slot[m] = 0;
+  a.ref_level[m] = 0;
+  a.use_1d[m] = 0;
+  a.dir[2 * m] = 1.f;
+  a.dir[2 * m + 1] = 0.f;
+  a.cur_slot[m] = cur_slot_v;
+  a.px_scaled[2 * m] = pxc0;
+  a.px_scaled[2 * m + 1] = pxc1;
+  if (a.A_cur_ref) {
+    a.A_cur_ref[4 * m] = a.A_cur_ref[4 * m + 1] = a.A_cur_ref[4 * m + 2] = a.A_cur_ref[4 * m + 3] = 0.0;
+  }
+  if (o1 <= o0) return;
+  Se3 Tc;
+  se3_from_Rt(RtC, Tc);
+  double cur_pos[3];
+  frame_pos(Tc, cur_pos);
+  // Point::getCloseViewObs (point.cpp:97-117)
+  double obs_dir[3] = {cur_pos[0] - pt[0], cur_pos[1] - pt[1], cur_pos[2] - pt[2]};
+  normalize3(obs_dir);
+  int best = o0;
+  double min_cos_angle = 0;
+  for (int o = o0; o < o1; ++o) {
+    const int fi = fi_next;
+    double RtF[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) RtF[k] = a.frame_T[12 * fi + k];
+    fi_next = a.obs.d_frame[o + 1 < o1 ? o + 1 : o];  // (the next observation's frame, on its way while this one is worked on)
+    Se3 Tf;
+    se3_from_Rt(RtF, Tf);
+    double fp[3];
+    frame_pos(Tf, fp);
+    double dir[3] = {fp[0] - pt[0], fp[1] - pt[1], fp[2] - pt[2]};
+    normalize3(dir);
+    const double cos_angle = dot3(obs_dir, dir);
+    if (cos_angle > min_cos_angle) {
+      min_cos_angle = cos_angle;
+      best = o;
+    }
+  }
+#else
   a.active[m] = 0;
   a.ref_obs[m] = -1;
   a.search_level[m] = 0;
@@ -102,6 +160,7 @@ __global__ void __launch_bounds__(64) match_prepare_kernel(const PrepArgs a) {
       best = o;
     }
   }
+#endif
   a.ref_obs[m] = best;
   if (min_cos_angle < 0.5) return;
   const int rfi = a.obs.d_frame[best];

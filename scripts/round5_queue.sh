@@ -2,7 +2,7 @@
 # The experiments queued at the end of round 4 (GPU minutes had run out): opt-in compile-time variants that were
 # cross-compiled and read in the ISA but never executed.  For each: parity tests ON THE VARIANT LIBRARY first, then the
 # A/B timing.  Build the variants on the CPU side before calling gpurun:
-#   for f in WARP_PACKED RM_PATCH_LOAD_FIRST SCAN_PREFETCH SEED_LOAD_FIRST ALIGN_G_F16 SIA_KEEP_PX POSE_LOAD_FIRST ALIGN_LOAD_FIRST; do python -m rpg_svo_amd.build -D$f; done
+#   for f in WARP_PACKED RM_PATCH_LOAD_FIRST SCAN_PREFETCH SEED_LOAD_FIRST ALIGN_G_F16 SIA_KEEP_PX POSE_LOAD_FIRST ALIGN_LOAD_FIRST PREP_LOAD_FIRST; do python -m rpg_svo_amd.build -D$f; done
 #   python -m rpg_svo_amd.build -DSCAN_PREFETCH -DSCAN_MINW=4
 #   gpurun --timeout 600 -- 'bash scripts/round5_queue.sh 2>&1 | tee gpurun_out/r05a_queue.txt'
 # A variant that fails a test is dropped; one that wins becomes the default and its flag is inverted.
@@ -43,6 +43,11 @@ echo "   (six dependent round trips before the ~3 iterations of a phase become o
 if [ -f $V/libsvo_hip_ALIGN_LOAD_FIRST.so ]; then
   SVO_HIP_LIB=$PWD/$V/libsvo_hip_ALIGN_LOAD_FIRST.so python -m pytest tests/test_tracking_gpu.py tests/test_full_size_gpu.py -q -m gpu -x 2>&1 | tail -2
   bash scripts/full_variants.sh main svo_hip_ALIGN_LOAD_FIRST main svo_hip_ALIGN_LOAD_FIRST 2>&1 | cut -c1-220
+fi
+echo "== PREP_LOAD_FIRST: match_prepare requests the trial's records first and walks the observations one round trip each (expected -20 % of 0.25 ms; -3 us single stream)"
+if [ -f $V/libsvo_hip_PREP_LOAD_FIRST.so ]; then
+  SVO_HIP_LIB=$PWD/$V/libsvo_hip_PREP_LOAD_FIRST.so python -m pytest tests/test_tracking_gpu.py tests/test_map_mirror_gpu.py -q -m gpu -x 2>&1 | tail -2
+  bash scripts/full_variants.sh main svo_hip_PREP_LOAD_FIRST main svo_hip_PREP_LOAD_FIRST 2>&1 | cut -c1-220
 fi
 echo "== ALIGN_G_F16: align2D's 64 gradient pairs as f16 (exact), three waves per SIMD (81-91 spilled dwords: may well lose)"
 if [ -f $V/libsvo_hip_ALIGN_G_F16.so ]; then
