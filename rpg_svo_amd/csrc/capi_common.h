@@ -1,6 +1,8 @@
 // capi_common.h -- host-side helpers shared by the C-ABI translation units.
 #pragma once
+#ifndef SVO_HOST_MATH_TEST  // (the CPU tests compile kernels for the host through tests/host/hip_emu.h)
 #include <hip/hip_runtime.h>
+#endif
 
 #include "pyr_addr.h"
 #include "svo_hip.h"

@@ -9,10 +9,12 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#ifndef __device__  // (tests/host/hip_emu.h has defined them already when whole kernels are compiled for the host)
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __constant__ static const
+#endif
 using std::fabs;
 using std::isnan;
 using std::sqrt;
