@@ -22,6 +22,20 @@ using std::sqrt;
 #include <hip/hip_runtime.h>
 #endif
 
+// Hand-over of LDS data between lanes of ONE wave: the DS operations of a wave execute in order, so all it takes is to
+// keep the compiler from moving the reads above the writes.  Two names for the same two builtins, by who takes part:
+// SVO_WAVE_LDS_HANDOVER: every live lane of the wave reaches this line; SVO_LANES_LDS_HANDOVER: the lanes that took this
+// branch (a trial's ten lanes, a seed's eight).  The CPU emulation of the test suite (tests/host/hip_emu.h) gives them
+// the barrier each one stands for.
+#ifndef SVO_HOST_MATH_TEST
+#define SVO_WAVE_LDS_HANDOVER()                             \
+  do {                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  \
+    __builtin_amdgcn_wave_barrier();                        \
+  } while (0)
+#define SVO_LANES_LDS_HANDOVER() SVO_WAVE_LDS_HANDOVER()
+#endif
+
 namespace svo_dev {
 
 // (int)floorf(x) in one instruction (v_cvt_flr_i32_f32; the compiler emits v_floor_f32 + v_cvt_i32_f32 for the C form)

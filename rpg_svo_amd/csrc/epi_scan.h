@@ -1,7 +1,7 @@
 // epi_scan.h -- the depth filter's workspace layout and the ZMSSD scan along the epipolar line (matcher.cpp:248-291) of ONE
 // seed by a group of SCAN_LANES lanes, as epi_scan_kernel (depth_filter.hip) runs it; the queued variant that requests
 // the next pass's box ahead (-DSCAN_PREFETCH) next to it.  Also compiled for the CPU by the test suite: there the
-// cross-lane moves are served by a small SIMT emulation (tests/host/simt_emu.h: one host thread per lane of a group) and the
+// cross-lane moves are served by a small SIMT emulation (tests/host/hip_emu.h: one fiber per lane) and the
 // two forms are run on the same seeds and compared bit for bit (tests/test_scan_emulated.py).
 #pragma once
 #include "track_math.h"
@@ -232,8 +232,7 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
           if (c < n_chunks) *reinterpret_cast<uint4*>(box + row * 8 + cc * 4) = v[k];
         }
         // hand-over inside the wave: DS operations of one wave execute in order
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        SVO_LANES_LDS_HANDOVER();
         if (want) {
           const int bx = pxi0 - 4 - cx0;             // 0..24: first byte of the window inside the 32-byte box row
           const uint32_t sel = (uint32_t)(bx & 3);
@@ -250,8 +249,7 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
             sumAB = __builtin_amdgcn_udot4(hi, ra[2 * y + 1], sumAB, false);
           }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        SVO_LANES_LDS_HANDOVER();
       }
     }
 #endif
@@ -425,8 +423,7 @@ __device__ __forceinline__ void epi_scan_seed_prefetch(const SeedArgs& a, const 
       const int row = g.two ? (c >> 1) : c, cc = g.two ? (c & 1) : 0;
       if (c < g.n_chunks) *reinterpret_cast<uint4*>(box + row * 8 + cc * 4) = v[k];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    SVO_LANES_LDS_HANDOVER();
   };
   auto score = [&](const ScanPass& g) {
     uint32_t sumB = 0, sumBB = 0, sumAB = 0;
@@ -473,8 +470,7 @@ __device__ __forceinline__ void epi_scan_seed_prefetch(const SeedArgs& a, const 
       }
     }
     // the box is stored again at the top of the next iteration: after these reads
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    SVO_LANES_LDS_HANDOVER();
   };
 
   ScanPass cur, nxt;

@@ -62,8 +62,7 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const Al
           for (int j = q; j < n_dw && j < q + 4; ++j) s_tpl[j] = src[j];
       }
       // one wave: DS operations execute in order; keep the compiler from moving the reads below above the writes
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      SVO_WAVE_LDS_HANDOVER();
     }
   }
 #endif

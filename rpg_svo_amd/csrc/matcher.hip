@@ -348,8 +348,7 @@ __global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) 
                 *reinterpret_cast<uint4*>(reg + row * 48 + cc * 16) = v;
               }
               // hand-over inside the wave: DS operations of one wave execute in order
-              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-              __builtin_amdgcn_wave_barrier();
+              SVO_LANES_LDS_HANDOVER();
               // The samples lie between the corner samples (see above), so when the box of the corners is inside the
               // image every sample is: the usual trial skips the four comparisons and three selects per sample (the
               // values are the same: `in` would be true everywhere).
@@ -398,8 +397,7 @@ __global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) 
               if (all_in) rows10(std::false_type{});
               else rows10(std::true_type{});
 #endif
-              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-              __builtin_amdgcn_wave_barrier();
+              SVO_LANES_LDS_HANDOVER();
             }
           }
         }
@@ -483,8 +481,7 @@ __global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) 
       for (int y = 0; y < 10; ++y) my_patch[t * 100 + y * 10 + x] = out[y];
     }
     // same-wave LDS hand-over: DS operations of one wave execute in order
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    SVO_WAVE_LDS_HANDOVER();
     const long long left = (long long)M - m0;
     const int n_dw = 25 * (int)(left < WARP_TPW ? left : WARP_TPW);
     uint32_t* dst = reinterpret_cast<uint32_t*>(a.pwb + (size_t)m0 * 100);
@@ -493,8 +490,7 @@ __global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) 
       const int idx = lane + 64 * k;
       if (idx < n_dw) dst[idx] = s_patch[wave][idx];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    SVO_WAVE_LDS_HANDOVER();
 #ifdef WARP_NO_PREFETCH
     if (gw + gw_step < n_wave_groups) nxt = load_params(gw + gw_step);  // (A/B build: requested when they are needed)
 #endif

@@ -1,0 +1,40 @@
+"""TEST INFRASTRUCTURE.  The host-emulated build of the C-ABI library: the .hip translation units of rpg_svo_amd/csrc compiled by
+ROCm's clang++ as plain C++ through tests/host/hip_emu.h (work-items as fibers, barriers, LDS, cross-lane rendezvous) and
+linked into build/libsvo_hip_emulated[_<defines>].so.  The same entry points as libsvo_hip.so, on host memory; no timing."""
+import ctypes as C
+import glob
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+UNITS = ("common", "pyramid", "map_mirror", "matcher", "feature_align")
+
+
+def build_emulated(defines=()):
+    tag = "".join("_" + d.replace("=", "-") for d in defines)
+    lib_path = os.path.join(ROOT, "build", f"libsvo_hip_emulated{tag}.so")
+    objdir = os.path.join(ROOT, "build", f"emu_obj{tag}")
+    os.makedirs(objdir, exist_ok=True)
+    csrc = os.path.join(ROOT, "rpg_svo_amd", "csrc")
+    cxx = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang++")
+    if not os.path.exists(cxx):
+        pytest.skip("no ROCm clang++ to compile the kernels for the host")
+    deps = glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip")) + \
+        [os.path.join(ROOT, "include", "svo_hip.h"), os.path.join(ROOT, "tests", "host", "hip_emu.h")]
+    newest = max(os.path.getmtime(d) for d in deps)
+    objs = []
+    for u in UNITS:
+        src = os.path.join(ROOT, "tests", "host", f"emu_tu_{u}.cpp")
+        obj = os.path.join(objdir, f"{u}.o")
+        objs.append(obj)
+        if not os.path.exists(obj) or os.path.getmtime(obj) < max(newest, os.path.getmtime(src)):
+            subprocess.run([cxx, "-std=c++17", "-O2", "-ffp-contract=off", "-fno-math-errno", "-fPIC", "-c", "-Wall", "-Wno-unknown-pragmas",
+                            "-Wno-pass-failed", "-Wno-unused-function", "-Wno-unused-variable", *[f"-D{d}" for d in defines],
+                            "-I", os.path.join(ROOT, "include"), "-I", csrc, "-I", os.path.join(ROOT, "tests", "host"), src, "-o", obj],
+                           check=True)
+    if not os.path.exists(lib_path) or any(os.path.getmtime(o) > os.path.getmtime(lib_path) for o in objs):
+        subprocess.run([cxx, "-shared", "-o", lib_path, *objs], check=True)
+    lib = C.CDLL(lib_path)
+    return lib

@@ -1,0 +1,3 @@
+// TEST INFRASTRUCTURE: rpg_svo_amd/csrc/feature_align.hip compiled for the host (tests/host/hip_emu.h)
+#include "hip_emu.h"
+#include "../../rpg_svo_amd/csrc/feature_align.hip"

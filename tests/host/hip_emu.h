@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <functional>
+#include <map>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -68,12 +69,23 @@ struct Fiber {
   dim3 tid;
   unsigned flat = 0;
   bool done = false;
-  int waiting_on = -1;           // -1 runnable; 0 the workgroup barrier; 1 + w: the exchange barrier of wave w
-  unsigned long long slot = 0;   // value offered to an exchange
+  int waiting_on = -1;           // -1 runnable; 0 the workgroup barrier; 1 .. WAVE_BARRIER-1: a cross-lane rendezvous (site id);
+                                 // WAVE_BARRIER + w: the barrier of all live lanes of wave w
+  unsigned long long slot = 0;   // value offered to a rendezvous
+  const struct Rendezvous* met = nullptr;  // the one this work-item was released from
+};
+
+constexpr int WAVE_BARRIER = 1 << 24;
+
+// What the lanes of one wave that met at one call site offered: who took part, and their values.
+struct Rendezvous {
+  unsigned long long mask = 0;
+  unsigned long long val[64];
 };
 
 struct Block {
   std::vector<Fiber> fibers;
+  std::map<std::pair<int, unsigned>, Rendezvous> met;  // (site, wave) -> the last meeting there
   ucontext_t scheduler;
   dim3 bid, bdim, gdim;
   unsigned alive = 0;
@@ -127,26 +139,53 @@ inline void run_block(Block& b, std::function<void()>& body, size_t stack_bytes)
       swapcontext(&b.scheduler, &f.ctx);
       progressed = true;
     }
-    // release the barriers every live work-item of the scope has reached
+    if (progressed) continue;
+    // nobody can run.  In this order: the workgroup barrier if every live work-item stands at it; the barriers of whole
+    // waves that are complete; else, per wave, the cross-lane rendezvous at the EARLIEST call site -- the lanes that stand
+    // there are the ones that execute it together (whoever was going to arrive has arrived: everybody else is blocked
+    // further down or gone), and the lanes waiting further down must not go on before these have caught up.
     unsigned at_block = 0;
     std::vector<unsigned> at_wave(b.wave_alive.size(), 0);
+    std::vector<int> first_site(b.wave_alive.size(), 0);
     for (unsigned t = 0; t < n; ++t) {
       const Fiber& f = b.fibers[t];
       if (f.done) continue;
+      const size_t w = f.flat / 64;
       if (f.waiting_on == 0) ++at_block;
-      else if (f.waiting_on > 0) ++at_wave[f.waiting_on - 1];
+      else if (f.waiting_on >= WAVE_BARRIER) ++at_wave[w];
+      else if (f.waiting_on > 0 && (first_site[w] == 0 || f.waiting_on < first_site[w])) first_site[w] = f.waiting_on;
     }
     if (b.alive > 0 && at_block == b.alive) {
       for (Fiber& f : b.fibers) if (!f.done && f.waiting_on == 0) f.waiting_on = -1;
-      progressed = true;
+      continue;
     }
+    bool released = false;
     for (size_t w = 0; w < at_wave.size(); ++w)
       if (b.wave_alive[w] > 0 && at_wave[w] == b.wave_alive[w]) {
-        for (Fiber& f : b.fibers) if (!f.done && f.waiting_on == (int)w + 1) f.waiting_on = -1;
-        progressed = true;
+        for (Fiber& f : b.fibers) if (!f.done && f.flat / 64 == w && f.waiting_on >= WAVE_BARRIER) f.waiting_on = -1;
+        released = true;
       }
-    if (!progressed && b.alive > 0) {
-      std::fprintf(stderr, "hip_emu: deadlock (work-items wait on different barriers)\n");
+    if (released) continue;
+    b.met.clear();
+    for (Fiber& f : b.fibers) {
+      const size_t w = f.flat / 64;
+      if (!f.done && f.waiting_on > 0 && f.waiting_on < WAVE_BARRIER && f.waiting_on == first_site[w]) {
+        Rendezvous& r = b.met[std::make_pair(f.waiting_on, (unsigned)w)];
+        r.mask |= 1ull << (f.flat & 63u);
+        r.val[f.flat & 63u] = f.slot;
+      }
+    }
+    for (Fiber& f : b.fibers) {
+      const size_t w = f.flat / 64;
+      if (!f.done && f.waiting_on > 0 && f.waiting_on < WAVE_BARRIER && f.waiting_on == first_site[w]) {
+        f.met = &b.met[std::make_pair(f.waiting_on, (unsigned)w)];
+        f.waiting_on = -1;
+        released = true;
+      }
+    }
+    if (released) continue;
+    if (b.alive > 0) {
+      std::fprintf(stderr, "hip_emu: deadlock (work-items stand at barriers that cannot complete)\n");
       std::abort();
     }
   }
@@ -171,23 +210,85 @@ void launch(dim3 grid, dim3 block, F&& body_in) {
       }
 }
 
+// the running work-item meets the other lanes of its wave that reach call site `site`; returns what they offered
 template <typename T>
-inline T shfl_up(T v, unsigned delta, int /*width*/) {
-  static_assert(sizeof(T) <= 8, "exchange slot");
-  Fiber& me = *g_fiber;
-  Block& b = *g_block;
+inline const Rendezvous& meet(int site, T v) {
+  static_assert(sizeof(T) <= 8, "rendezvous slot");
   unsigned long long bits = 0;
   std::memcpy(&bits, &v, sizeof(T));
-  me.slot = bits;
-  const int wave_id = 1 + (int)(me.flat / 64);
-  barrier_wait(wave_id);   // every live lane of the wave has offered its value
-  const unsigned lane = me.flat & 63u;
-  const unsigned long long got = b.fibers[lane >= delta ? me.flat - delta : me.flat].slot;
-  barrier_wait(wave_id);   // every lane has read before anyone offers again
-  T r;
-  std::memcpy(&r, &got, sizeof(T));
-  return r;
+  g_fiber->slot = bits;
+  barrier_wait(site);
+  return *g_fiber->met;
 }
+template <typename T>
+inline T lane_value(const Rendezvous& r, int src_lane, T own) {  // the value lane `src_lane` offered; `own` if it did not take part
+  if (src_lane < 0 || src_lane > 63 || !((r.mask >> src_lane) & 1ull)) return own;
+  T out;
+  std::memcpy(&out, &r.val[src_lane], sizeof(T));
+  return out;
+}
+inline int my_lane() { return (int)(g_fiber->flat & 63u); }
+inline void wave_barrier() { barrier_wait(WAVE_BARRIER + (int)(g_fiber->flat / 64)); }  // every live lane of the wave
+// a value from every live lane of the wave (collectives every lane executes: ballot, readfirstlane)
+template <typename T>
+inline void wave_gather(T v, unsigned long long* mask, unsigned long long vals[64]) {
+  unsigned long long bits = 0;
+  std::memcpy(&bits, &v, sizeof(T));
+  g_fiber->slot = bits;
+  wave_barrier();
+  const unsigned w0 = (g_fiber->flat / 64) * 64;
+  *mask = 0;
+  for (unsigned l = 0; l < 64 && w0 + l < g_block->fibers.size(); ++l) {
+    const Fiber& f = g_block->fibers[w0 + l];
+    if (!f.done) { *mask |= 1ull << l; vals[l] = f.slot; }
+  }
+  wave_barrier();  // everybody has read before anybody offers again
+}
+
+template <typename T>
+inline T shfl_up(int site, T v, unsigned delta, int /*width*/) { return lane_value(meet(site, v), my_lane() - (int)delta, v); }
+template <typename T>
+inline T shfl(int site, T v, int src, int /*width*/) { return lane_value(meet(site, v), src & 63, v); }
+template <typename T>
+inline T shfl_xor(int site, T v, int mask, int /*width*/) { return lane_value(meet(site, v), my_lane() ^ mask, v); }
+inline unsigned long long ballot(bool pred) {
+  unsigned long long mask, vals[64], m = 0;
+  wave_gather((unsigned long long)(pred ? 1 : 0), &mask, vals);
+  for (int l = 0; l < 64; ++l)
+    if (((mask >> l) & 1ull) && vals[l]) m |= 1ull << l;
+  return m;
+}
+template <typename T>
+inline T readfirstlane(T v) {
+  unsigned long long mask, vals[64];
+  wave_gather(v, &mask, vals);
+  T out;
+  std::memcpy(&out, &vals[__builtin_ctzll(mask)], sizeof(T));
+  return out;
+}
+// the DPP controls the kernels use (bound_ctrl: a lane without a source gets 0)
+inline int update_dpp(int site, int /*old*/, int v, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool /*bound_ctrl*/) {
+  const Rendezvous& r = meet(site, v);
+  const int l = my_lane();
+  int src;
+  switch (ctrl) {
+    case 0x111: src = (l & 15) >= 1 ? l - 1 : -1; break;                  // row_shr:1
+    case 0xB1: src = l ^ 1; break;                                        // quad_perm [1,0,3,2]
+    case 0x4E: src = l ^ 2; break;                                        // quad_perm [2,3,0,1]
+    case 0x141: src = (l & ~7) | (7 - (l & 7)); break;                    // row_half_mirror
+    case 0x128: src = (l & ~15) | ((l + 8) & 15); break;                  // row_ror:8
+    default: std::fprintf(stderr, "hip_emu: DPP control %#x not emulated\n", ctrl); std::abort();
+  }
+  return lane_value(r, src, 0);
+}
+inline uint32_t udot4(uint32_t a, uint32_t b, uint32_t c, bool /*clamp*/) {
+  for (int k = 0; k < 4; ++k) c += ((a >> (8 * k)) & 0xffu) * ((b >> (8 * k)) & 0xffu);
+  return c;
+}
+inline uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sel) {
+  return (uint32_t)(((((uint64_t)hi) << 32) | (uint64_t)lo) >> (8u * (sel & 3u)));
+}
+inline uint32_t mbcnt(unsigned long long mask_part_shifted, uint32_t base) { return base + (uint32_t)__builtin_popcountll(mask_part_shifted); }
 
 }  // namespace svo_emu
 
@@ -205,7 +306,25 @@ using std::min;
 #define __shared__ static
 #define __launch_bounds__(...)
 #define __syncthreads() (svo_emu::barrier_wait(0))
-#define __shfl_up(...) svo_emu::shfl_up(__VA_ARGS__)
+#define __shfl_up(...) svo_emu::shfl_up(__LINE__, __VA_ARGS__)
+#define __shfl(...) svo_emu::shfl(__LINE__, __VA_ARGS__)
+#define __shfl_xor(...) svo_emu::shfl_xor(__LINE__, __VA_ARGS__)
+#define __ballot(p) svo_emu::ballot((p))
+#define __builtin_amdgcn_ballot_w64(p) svo_emu::ballot((p))
+#define __builtin_amdgcn_readfirstlane(v) svo_emu::readfirstlane((v))
+#define __builtin_amdgcn_update_dpp(...) svo_emu::update_dpp(__LINE__, __VA_ARGS__)
+#define __builtin_amdgcn_mbcnt_lo(m, base) svo_emu::mbcnt((unsigned long long)(uint32_t)(m) & ((svo_emu::my_lane() >= 32 ? 0xffffffffull : ((1ull << svo_emu::my_lane()) - 1ull))), (base))
+#define __builtin_amdgcn_mbcnt_hi(m, base) svo_emu::mbcnt(svo_emu::my_lane() > 32 ? ((unsigned long long)(uint32_t)(m) & ((1ull << (svo_emu::my_lane() - 32)) - 1ull)) : 0ull, (base))
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_wave_barrier() svo_emu::wave_barrier()
+#define SVO_WAVE_LDS_HANDOVER() svo_emu::wave_barrier()
+#define SVO_LANES_LDS_HANDOVER() ((void)svo_emu::meet(__LINE__, 0))
+#define __builtin_amdgcn_udot4(...) svo_emu::udot4(__VA_ARGS__)
+#define __builtin_amdgcn_alignbyte(...) svo_emu::alignbyte(__VA_ARGS__)
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __popcll(x) __builtin_popcountll(x)
+#define __clz(x) ((x) ? __builtin_clz(x) : 32)
+#define __ffsll(x) __builtin_ffsll(x)
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline int atomicMin(int* p, int v) {

@@ -1,11 +1,9 @@
 // scan_emulated.cpp -- TEST INFRASTRUCTURE.  The epipolar ZMSSD scan of epi_scan_kernel (rpg_svo_amd/csrc/epi_scan.h) run on
-// the CPU through tests/host/simt_emu.h, in its default form and in the queued -DSCAN_PREFETCH form, on the same seeds:
+// the CPU through tests/host/hip_emu.h, in its default form and in the queued -DSCAN_PREFETCH form, on the same seeds:
 // tests/test_scan_emulated.py compares what the two write.
-#define SVO_HOST_MATH_TEST
 #define SCAN_PREFETCH  // (compiles epi_scan_seed_prefetch next to epi_scan_seed)
-#include "simt_emu.h"
+#include "hip_emu.h"
 
-#include <thread>
 #include <vector>
 
 #include "epi_scan.h"
@@ -46,22 +44,16 @@ int scan_emulated(int form, int S, const uint8_t* store, long long slot_bytes, i
   a.ws.align_active = align_active;
   a.ws.accepted_raw = accepted_raw;
   a.ws.status = status;
-  // a "wave" of 8 groups at a time: group g of the wave scans seed s0 + g (threadIdx.x = 8 g + lane)
+  // a wave of 8 groups at a time, as epi_scan_kernel hands seeds to a wave: group g scans seed s0 + g
   for (int s0 = 0; s0 < S; s0 += 8) {
     const int n_groups = S - s0 < 8 ? S - s0 : 8;
-    std::vector<svo_emu::Group> groups(n_groups);
-    std::vector<std::vector<uint32_t>> boxes(n_groups, std::vector<uint32_t>(SCAN_BOX_DWORDS + 8, 0u));
-    std::vector<std::thread> threads;
-    for (int g = 0; g < n_groups; ++g)
-      for (int lane = 0; lane < svo_emu::GROUP; ++lane)
-        threads.emplace_back([&, g, lane] {
-          svo_emu::t_group = &groups[g];
-          svo_emu::t_lane = lane;
-          svo_emu::t_thread = (unsigned)(8 * g + lane);
-          if (form == 0) epi_scan_seed(a, s0 + g, lane, boxes[g].data());
-          else epi_scan_seed_prefetch(a, s0 + g, lane, boxes[g].data());
-        });
-    for (auto& t : threads) t.join();
+    std::vector<std::vector<uint32_t>> boxes(8, std::vector<uint32_t>(SCAN_BOX_DWORDS + 8, 0u));
+    svo_emu::launch(dim3(1), dim3(64), [&] {
+      const int grp = (int)threadIdx.x / 8, lane = (int)threadIdx.x % 8;
+      if (grp >= n_groups) return;
+      if (form == 0) epi_scan_seed(a, s0 + grp, lane, boxes[grp].data());
+      else epi_scan_seed_prefetch(a, s0 + grp, lane, boxes[grp].data());
+    });
   }
   return 0;
 }

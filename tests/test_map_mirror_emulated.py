@@ -13,29 +13,12 @@ from helpers import camera_models, oracle_reproject_map, random_map
 from rpg_svo_amd import capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "tests", "host", "map_mirror_emulated.cpp")
-
-
-def _build(defines=()):
-    lib_path = os.path.join(ROOT, "build", "libmap_mirror_emulated" + "".join("_" + d for d in defines) + ".so")
-    os.makedirs(os.path.dirname(lib_path), exist_ok=True)
-    csrc = os.path.join(ROOT, "rpg_svo_amd", "csrc")
-    deps = [SRC, os.path.join(ROOT, "tests", "host", "hip_emu.h"), os.path.join(ROOT, "include", "svo_hip.h")] + \
-           [os.path.join(csrc, h) for h in ("map_mirror.hip", "track_math.h", "device_math.h", "capi_common.h", "track_kernels.h", "pyr_addr.h")]
-    if not os.path.exists(lib_path) or any(os.path.getmtime(d) > os.path.getmtime(lib_path) for d in deps):
-        cxx = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang++")
-        if not os.path.exists(cxx):
-            pytest.skip("no ROCm clang++ to compile the kernel for the host")
-        subprocess.run([cxx, "-std=c++17", "-O2", "-ffp-contract=off", "-fno-math-errno", "-fPIC", "-shared", "-pthread", "-Wall",
-                        "-Wno-unknown-pragmas", "-Wno-pass-failed", "-Wno-unused-function", "-Wno-unused-variable",
-                        *[f"-D{d}" for d in defines], "-I", os.path.join(ROOT, "include"), "-I", csrc,
-                        "-I", os.path.join(ROOT, "tests", "host"), SRC, "-o", lib_path], check=True)
-    return C.CDLL(lib_path)
 
 
 @pytest.fixture(scope="module", params=[(), ("RM_PATCH_LOAD_FIRST",)], ids=["default", "RM_PATCH_LOAD_FIRST"])
 def emu(request):
-    return _build(request.param)
+    from emu_build import build_emulated
+    return build_emulated(request.param)
 
 
 def _ptr(a):

@@ -12,24 +12,12 @@ import pytest
 from rpg_svo_amd import capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "tests", "host", "pyramid_emulated.cpp")
-LIB = os.path.join(ROOT, "build", "libpyramid_emulated.so")
 
 
 @pytest.fixture(scope="module")
 def emu():
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    csrc = os.path.join(ROOT, "rpg_svo_amd", "csrc")
-    deps = [SRC, os.path.join(ROOT, "tests", "host", "hip_emu.h"), os.path.join(ROOT, "include", "svo_hip.h")] + \
-           [os.path.join(csrc, h) for h in ("pyramid.hip", "capi_common.h", "pyr_addr.h")]
-    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
-        cxx = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang++")
-        if not os.path.exists(cxx):
-            pytest.skip("no ROCm clang++ to compile the kernel for the host")
-        subprocess.run([cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-Wall", "-Wno-unknown-pragmas", "-Wno-pass-failed",
-                        "-Wno-unused-function", "-Wno-unused-variable", "-I", os.path.join(ROOT, "include"), "-I", csrc,
-                        "-I", os.path.join(ROOT, "tests", "host"), SRC, "-o", LIB], check=True)
-    return C.CDLL(LIB)
+    from emu_build import build_emulated
+    return build_emulated()
 
 
 class HostStore:

@@ -2,8 +2,8 @@
 
 rpg_svo_amd/csrc/epi_scan.h holds the scan of one seed by a group of eight lanes -- cross-lane moves (DPP, shuffles), an
 LDS box handed over inside the wave -- in its default form and in the queued -DSCAN_PREFETCH form, which computes the next
-pass's geometry and requests its box before the current pass is scored.  tests/host/simt_emu.h runs that code with one
-host thread per lane; here both forms scan the same seeds and everything they write is compared bit for bit, and the
+pass's geometry and requests its box before the current pass is scored.  tests/host/hip_emu.h runs that code with one
+fiber per lane; here both forms scan the same seeds and everything they write is compared bit for bit, and the
 default form is checked against a plain numpy scan.  (The timing of the variant is the GPU's business: scripts/round5_queue.sh.)"""
 import ctypes as C
 import os
@@ -27,7 +27,7 @@ def _p(a, t=None):
 def emu():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     csrc = os.path.join(ROOT, "rpg_svo_amd", "csrc")
-    deps = [SRC, os.path.join(ROOT, "tests", "host", "simt_emu.h")] + [os.path.join(csrc, h) for h in
+    deps = [SRC, os.path.join(ROOT, "tests", "host", "hip_emu.h")] + [os.path.join(csrc, h) for h in
                                                                        ("epi_scan.h", "track_math.h", "device_math.h", "pyr_addr.h", "matcher_device.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         cxx = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang++")
