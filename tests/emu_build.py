@@ -9,7 +9,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-UNITS = ("common", "pyramid", "map_mirror", "matcher", "feature_align")
+UNITS = ("common", "pyramid", "map_mirror", "matcher", "feature_align", "depth_filter")
 
 
 def build_emulated(defines=()):

@@ -88,3 +88,94 @@ def test_emulated_find_match_direct(emu, oracle, scene):
         n_ok += o_ok
         n_edge += o_ok and scene.obs[i][r["ref_obs"]][4] == 1
     assert n_ok > 200 and n_edge > 20
+
+
+# ---- row a12: svo_hip_update_seeds (seed_prepare -> warp -> epipolar scan -> alignment -> seed_finish) -----------------
+SEED_VARIANTS = [(), ("SEED_LOAD_FIRST", "SCAN_PREFETCH", "WARP_PACKED", "ALIGN_LOAD_FIRST", "ALIGN_G_F16")]
+
+
+@pytest.fixture(scope="module", params=SEED_VARIANTS, ids=["default", "queued-variants"])
+def emu_seeds(request):
+    from emu_build import build_emulated
+    return build_emulated(request.param)
+
+
+def _make_seeds(scene, orc, rng):  # (tests/test_tracking_gpu.py)
+    seeds, feats = [], []
+    for i in range(len(scene.obs)):
+        o = [x for x in scene.obs[i] if x[0] != scene.cur][0]
+        c_ref = -scene.T_f_w[o[0], :9].reshape(3, 3).T @ scene.T_f_w[o[0], 9:]
+        d_true = np.linalg.norm(scene.pt_pos[i] - c_ref)
+        s = orc.seed_init(d_true * (1 + 0.1 * rng.normal()), d_true * 0.6)
+        s.ftr = pytrack.make_feature(*o)
+        s.batch_id = int(rng.integers(0, 6))
+        if i % 7 == 0:
+            s.sigma2 = np.float32(s.sigma2 * 7e-4)
+        if i % 31 == 0:
+            s.mu = np.float32(-0.3)
+        if i % 5 == 0:
+            s.sigma2 = np.float32(s.sigma2 * 1e-3)
+        seeds.append(s)
+        feats.append(o)
+    return seeds, feats
+
+
+@pytest.mark.parametrize("align_1d,subpix", [(0, 1), (1, 1), (0, 0)])
+def test_emulated_update_seeds(emu_seeds, oracle, scene, align_1d, subpix):
+    """DepthFilter::updateSeeds as the five kernels of svo_hip_update_seeds run it, on the CPU, with the requirements of the
+    GPU test -- and, the geometry being host-compiled without contraction like the oracle's, tighter ones: statuses identical
+    (off the convergence threshold), mu / sigma2 / a / b to 1e-5, refined pixels to 1e-9."""
+    emu = emu_seeds
+    orc = pytrack.Track("orc")
+    pyrs = [orc.create_img_pyramid(im, 5) for im in scene.images.cpu().numpy()]
+    layout, store = _store(emu, scene)
+    T = np.ascontiguousarray(scene.T_f_w)
+    n_frames = T.shape[0]
+    slots = np.arange(n_frames, dtype=np.int32)
+    frames = capi.Frames(n_frames, 0, slots.ctypes.data, T.ctypes.data)
+    rng = np.random.default_rng(8)
+    seeds, feats = _make_seeds(scene, orc, rng)
+    S = len(seeds)
+    opt = pytrack.matcher_options(n_pyr_levels=5, align_1d=align_1d, subpix_refinement=subpix)
+    oframes = pytrack.make_frames(pyrs, scene.T_f_w)
+    nu, so, io = orc.update_seeds(oframes, scene.cam, scene.cur, seeds, batch_counter=5, opt=opt)
+    c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+    f_frame, f_level = c([o[0] for o in feats], np.int32), c([o[3] for o in feats], np.int32)
+    f_px, f_f = c([o[1] for o in feats], np.float64), c([o[2] for o in feats], np.float64)
+    f_type, f_grad = c([o[4] for o in feats], np.uint8), c([o[5] for o in feats], np.float64)
+    ftr = capi.Features(f_frame.ctypes.data, f_level.ctypes.data, f_type.ctypes.data, f_px.ctypes.data, f_f.ctypes.data, f_grad.ctypes.data)
+    a, b = c([s.a for s in seeds], np.float32), c([s.b for s in seeds], np.float32)
+    mu, zr = c([s.mu for s in seeds], np.float32), c([s.z_range for s in seeds], np.float32)
+    s2, bid = c([s.sigma2 for s in seeds], np.float32), c([s.batch_id for s in seeds], np.int32)
+    sd = capi.Seeds(a.ctypes.data, b.ctypes.data, mu.ctypes.data, zr.ctypes.data, s2.ctypes.data, bid.ctypes.data)
+    dopt = capi.DepthFilterOptions(3, 5, 200.0, int(align_1d), 10, 1000, int(subpix), 1, 5, 0.7)
+    cur = np.full(S, scene.cur, np.int32)
+    status, xyz, px = np.zeros(S, np.int32), np.zeros((S, 3)), np.zeros((S, 2))
+    emu.svo_hip_match_workspace_bytes.restype = C.c_size_t
+    ws = np.zeros(emu.svo_hip_match_workspace_bytes(S) + 256, np.uint8)
+    cam = capi.camera(scene.cam)
+    rc = emu.svo_hip_update_seeds(C.byref(layout), _p(store), C.byref(cam), C.byref(frames), S, _p(cur), C.byref(ftr), C.byref(sd),
+                                  C.byref(dopt), _p(status), _p(xyz), _p(px), _p(ws), C.c_size_t(ws.size), None)
+    assert rc == 0, rc
+    hist = {}
+    for i in range(S):
+        st = io[i].status
+        hist[st] = hist.get(st, 0) + 1
+        if st in (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED):
+            margin = abs(np.sqrt(max(so[i].sigma2, 0.0)) * 200.0 / so[i].z_range - 1.0)
+            if margin > 1e-3:
+                assert status[i] == st, (i, status[i], st)
+            else:
+                assert status[i] in (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED)
+        else:
+            assert status[i] == st, (i, status[i], st)
+        if st in (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED, pytrack.SEED_NO_MATCH):
+            assert np.isclose(mu[i], so[i].mu, rtol=2e-6, atol=0), (i, mu[i], so[i].mu)
+            assert abs(float(s2[i]) - so[i].sigma2) <= 1e-4 * abs(so[i].sigma2) + 1e-6 * so[i].mu ** 2, (i, s2[i], so[i].sigma2)
+            assert np.allclose([a[i], b[i]], [so[i].a, so[i].b], rtol=1e-4, atol=1e-5), (i, a[i], so[i].a, b[i], so[i].b)
+        if st in (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED):
+            assert np.abs(px[i] - np.array(io[i].px_cur[:])).max() < 1e-9
+        if st == pytrack.SEED_CONVERGED:
+            assert np.abs(xyz[i] - np.array(io[i].xyz_world[:])).max() < 1e-5
+    assert hist.get(pytrack.SEED_UPDATED, 0) > 50 and hist.get(pytrack.SEED_CONVERGED, 0) > 2
+    assert hist.get(pytrack.SEED_ERASED_OLD, 0) > 5 and hist.get(pytrack.SEED_BEHIND, 0) > 2
