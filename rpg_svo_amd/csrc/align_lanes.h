@@ -8,7 +8,7 @@
 #include "track_math.h"
 #include "pyr_addr.h"
 
-#ifdef SVO_HOST_MATH_TEST
+#if defined(SVO_HOST_MATH_TEST) && !defined(__builtin_amdgcn_alignbyte)
 #define __builtin_amdgcn_alignbyte(hi, lo, sel) \
   ((uint32_t)(((((uint64_t)(uint32_t)(hi)) << 32) | (uint64_t)(uint32_t)(lo)) >> (8u * ((sel)&3u))))
 #endif

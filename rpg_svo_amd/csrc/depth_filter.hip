@@ -28,9 +28,7 @@
 #include "matcher_device.h"
 #include "seed_math.h"
 #include "epi_scan.h"
-#ifndef SVO_HOST_MATH_TEST  // (epi_scan.h brings the DPP controls the scan uses; the reductions need the real wave)
 #include "wave_reduce.h"
-#endif
 
 using namespace svo_capi;
 using namespace svo_dev;

@@ -34,6 +34,12 @@ using std::sqrt;
     __builtin_amdgcn_wave_barrier();                        \
   } while (0)
 #define SVO_LANES_LDS_HANDOVER() SVO_WAVE_LDS_HANDOVER()
+// the same where the code orders its own instructions and only the compiler has to be held back: the fence alone
+#define SVO_WAVE_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+#define SVO_LANES_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+// a ballot inside a divergent branch: the mask of the lanes that are active there (a caller that only looks at its own
+// bit, e.g. a select by lane mask, may stand anywhere); the plain builtin is used where every live lane of the wave votes
+#define SVO_BALLOT_ACTIVE(pred) __builtin_amdgcn_ballot_w64(pred)
 #endif
 
 namespace svo_dev {
@@ -403,7 +409,7 @@ __device__ __forceinline__ void se3_exp_trans_f32(const float xi[6], float t[3])
   t[2] = uz + c1 * wz + c2 * wwz;
 }
 
-#ifndef SVO_HOST_MATH_TEST  // (v_rsq_f64, v_readlane: no host counterpart)
+#if !defined(SVO_HOST_MATH_TEST) || defined(SVO_HIP_EMU)  // (v_rsq_f64, v_readlane: served by tests/host/hip_emu.h only)
 // q <- q / |q| for a quaternion that is already close to unit length or not:
 // v_rsq_f64 seed + two Newton steps (no f64 sqrt / division sequences).
 __device__ __forceinline__ void quat_normalize_fast(double q[4]) {
@@ -422,7 +428,7 @@ __device__ __forceinline__ double readlane_f64(double v) {
   const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), SRC);
   return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
-#endif  // SVO_HOST_MATH_TEST
+#endif
 
 // index into the packed upper triangle of a symmetric 6x6 (row-major, i<=j)
 __host__ __device__ constexpr int sym6(int i, int j) {
@@ -476,7 +482,7 @@ __device__ __forceinline__ void ldlt6_solve(const double LD[21], const double b[
   }
 }
 
-#ifndef SVO_HOST_MATH_TEST
+#if !defined(SVO_HOST_MATH_TEST) || defined(SVO_HIP_EMU)
 // full-wave (64 lanes) sum; every lane receives the total
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

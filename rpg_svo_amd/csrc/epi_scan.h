@@ -7,13 +7,7 @@
 #include "track_math.h"
 #include "pyr_addr.h"
 #include "matcher_device.h"
-#ifndef SVO_HOST_MATH_TEST
 #include "wave_reduce.h"
-#else  // (the DPP controls the scan uses; wave_reduce.h's reductions need the real wave)
-namespace svo_dev {
-constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141;
-}
-#endif
 
 using namespace svo_dev;
 using namespace svo_track;

@@ -135,14 +135,14 @@ __device__ __forceinline__ void sia_rebuild_hinv(int lane, int nw) {
     for (int w = 0; w < nw; ++w) v += (double)g_s.Hpart[w][lane];
     g_s.H[lane] = v;
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  SVO_WAVE_LDS_FENCE();
   const int gi = lane / 6, gj = lane - 6 * gi;
   if (lane < 36) {
     g_s.A[lane] = g_s.H[sym6_rt(gi, gj)];
     g_s.Hinv[lane] = (gi == gj) ? 1.0 : 0.0;
   }
   for (int k = 0; k < 6; ++k) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    SVO_WAVE_LDS_FENCE();
     if (lane < 36) {
       const double p = g_s.A[k * 6 + k];
       const double aik = g_s.A[gi * 6 + k];
@@ -154,7 +154,7 @@ __device__ __forceinline__ void sia_rebuild_hinv(int lane, int nw) {
       const double ip = (fabs(p) > 2.2250738585072014e-308) ? 1.0 / p : 0.0;
       const double na = (gi == k) ? akj * ip : aij - aik * (akj * ip);
       const double nb = (gi == k) ? bkj * ip : bij - aik * (bkj * ip);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      SVO_LANES_LDS_FENCE();
       g_s.A[lane] = na;
       g_s.Hinv[lane] = nb;
     }
@@ -191,7 +191,7 @@ __device__ __forceinline__ void sia_rebuild_hinv(int lane, int nw) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) g_s.Hinv[6 * lane + i] = x[i];
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  SVO_WAVE_LDS_FENCE();
 }
 
 // SIA_TOUCH_NEXT (off; an experiment that measured WORSE: 1.30 against 1.21 ms): fetch-ahead of the next level's
@@ -217,7 +217,11 @@ __device__ __forceinline__ void sia_touch(const uint8_t* base, uint32_t off, uin
   const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
   const uint64_t sb = ((uint64_t)bhi << 32) | blo;
   const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_off);
+#ifndef SVO_HOST_MATH_TEST  // (a cache touch: nothing to do where the kernel is compiled for the CPU tests)
   asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(sb), "s"(sl) : "m0", "memory");
+#else
+  (void)off; (void)sb; (void)sl;
+#endif
 }
 
 // DIST: the camera is a distorted model (radial-tangential pinhole or ATAN); the undistorted pinhole
@@ -583,9 +587,9 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
               r0 = 1;
               bo = (u_i - 2) - wc_u0;
             }
-            k0 = __builtin_amdgcn_ballot_w64(r0 == 0);
-            k1 = __builtin_amdgcn_ballot_w64(r0 == 1);
-            kup = __builtin_amdgcn_ballot_w64(bo >= 4);
+            k0 = SVO_BALLOT_ACTIVE(r0 == 0);
+            k1 = SVO_BALLOT_ACTIVE(r0 == 1);
+            kup = SVO_BALLOT_ACTIVE(bo >= 4);
           } else {
             const int cxa = run_start(u_i - 2, 5);
             cbo = (uint32_t)(u_i - 2 - cxa);  // 0..7
@@ -680,8 +684,8 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
               r0 = 1;
               bo = (u_i - 2) - wc_u0;
             }
-            const uint64_t k0 = __builtin_amdgcn_ballot_w64(r0 == 0), k1 = __builtin_amdgcn_ballot_w64(r0 == 1);
-            const uint64_t kup = __builtin_amdgcn_ballot_w64(bo >= 4);
+            const uint64_t k0 = SVO_BALLOT_ACTIVE(r0 == 0), k1 = SVO_BALLOT_ACTIVE(r0 == 1);
+            const uint64_t kup = SVO_BALLOT_ACTIVE(bo >= 4);
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
               constexpr int S = WC ? 1 : 0;  // keeps the indices in range when the cache is compiled out

@@ -7,7 +7,9 @@
 // 3 in-group steps.  Exchanges use v_permlane32_swap / v_permlane16_swap
 // (gfx950) and DPP row operations -- no ds_bpermute, no LDS.
 #pragma once
+#ifndef SVO_HOST_MATH_TEST  // (tests/host/hip_emu.h serves the cross-lane builtins when the kernels are compiled for the CPU tests)
 #include <hip/hip_runtime.h>
+#endif
 
 namespace svo_dev {
 

@@ -7,6 +7,7 @@
 // Include first in the test's translation unit (it defines SVO_HOST_MATH_TEST for the product headers).
 #pragma once
 #define SVO_HOST_MATH_TEST
+#define SVO_HIP_EMU
 
 #include <algorithm>
 #include <cmath>
@@ -185,7 +186,19 @@ inline void run_block(Block& b, std::function<void()>& body, size_t stack_bytes)
     }
     if (released) continue;
     if (b.alive > 0) {
-      std::fprintf(stderr, "hip_emu: deadlock (work-items stand at barriers that cannot complete)\n");
+      std::fprintf(stderr, "hip_emu: deadlock (work-items stand at barriers that cannot complete); workgroup (%u,%u,%u), per wave: ",
+                   b.bid.x, b.bid.y, b.bid.z);
+      for (size_t w = 0; w < b.wave_alive.size(); ++w) {
+        std::map<int, int> where;
+        for (const Fiber& f : b.fibers)
+          if (!f.done && f.flat / 64 == w) ++where[f.waiting_on];
+        std::fprintf(stderr, "[wave %zu:", w);
+        for (auto& kv : where)
+          std::fprintf(stderr, " %d lanes at %s%d", kv.second, kv.first == 0 ? "syncthreads " : (kv.first >= WAVE_BARRIER ? "wave barrier " : "line "),
+                       kv.first >= WAVE_BARRIER ? kv.first - WAVE_BARRIER : kv.first);
+        std::fprintf(stderr, "] ");
+      }
+      std::fprintf(stderr, "\n");
       std::abort();
     }
   }
@@ -229,7 +242,14 @@ inline T lane_value(const Rendezvous& r, int src_lane, T own) {  // the value la
 }
 inline int my_lane() { return (int)(g_fiber->flat & 63u); }
 inline void wave_barrier() { barrier_wait(WAVE_BARRIER + (int)(g_fiber->flat / 64)); }  // every live lane of the wave
-// a value from every live lane of the wave (collectives every lane executes: ballot, readfirstlane)
+template <typename T>
+inline T shfl_up(int site, T v, unsigned delta, int /*width*/) { return lane_value(meet(site, v), my_lane() - (int)delta, v); }
+template <typename T>
+inline T shfl(int site, T v, int src, int /*width*/) { return lane_value(meet(site, v), src & 63, v); }
+template <typename T>
+inline T shfl_xor(int site, T v, int mask, int /*width*/) { return lane_value(meet(site, v), my_lane() ^ mask, v); }
+// a value from every live lane of the wave: collectives that every lane of the wave executes (ballot, readfirstlane,
+// readlane, the permlane swaps)
 template <typename T>
 inline void wave_gather(T v, unsigned long long* mask, unsigned long long vals[64]) {
   unsigned long long bits = 0;
@@ -244,18 +264,19 @@ inline void wave_gather(T v, unsigned long long* mask, unsigned long long vals[6
   }
   wave_barrier();  // everybody has read before anybody offers again
 }
-
-template <typename T>
-inline T shfl_up(int site, T v, unsigned delta, int /*width*/) { return lane_value(meet(site, v), my_lane() - (int)delta, v); }
-template <typename T>
-inline T shfl(int site, T v, int src, int /*width*/) { return lane_value(meet(site, v), src & 63, v); }
-template <typename T>
-inline T shfl_xor(int site, T v, int mask, int /*width*/) { return lane_value(meet(site, v), my_lane() ^ mask, v); }
 inline unsigned long long ballot(bool pred) {
   unsigned long long mask, vals[64], m = 0;
   wave_gather((unsigned long long)(pred ? 1 : 0), &mask, vals);
   for (int l = 0; l < 64; ++l)
     if (((mask >> l) & 1ull) && vals[l]) m |= 1ull << l;
+  return m;
+}
+// the ballot of the lanes that are active in a divergent branch (SVO_BALLOT_ACTIVE): those that arrive
+inline unsigned long long ballot_active(int site, bool pred) {
+  const Rendezvous& r = meet(site, (unsigned long long)(pred ? 1 : 0));
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l)
+    if (((r.mask >> l) & 1ull) && r.val[l]) m |= 1ull << l;
   return m;
 }
 template <typename T>
@@ -288,6 +309,42 @@ inline uint32_t udot4(uint32_t a, uint32_t b, uint32_t c, bool /*clamp*/) {
 inline uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sel) {
   return (uint32_t)(((((uint64_t)hi) << 32) | (uint64_t)lo) >> (8u * (sel & 3u)));
 }
+// v_permlane32_swap / v_permlane16_swap: the upper half (odd 16-lane rows) of the first operand changes places with the
+// lower half (even rows) of the second; both results come back (rpg_svo_amd/csrc/wave_reduce.h states what the kernels
+// rely on: lanes < 32 see {a[l], a[l+32]}, lanes >= 32 {b[l-32], b[l]}).  Every lane of the wave executes it.
+struct Pair32 {
+  uint32_t v[2];
+  uint32_t operator[](int i) const { return v[i]; }
+};
+inline Pair32 permlane_swap(uint32_t a, uint32_t b, int half) {
+  unsigned long long mask, vals[64];
+  wave_gather(((unsigned long long)b << 32) | a, &mask, vals);
+  const int l = my_lane();
+  const bool upper = (l & half) != 0;
+  auto A = [&](int lane) { return ((mask >> lane) & 1ull) ? (uint32_t)vals[lane] : 0u; };
+  auto B = [&](int lane) { return ((mask >> lane) & 1ull) ? (uint32_t)(vals[lane] >> 32) : 0u; };
+  Pair32 r;
+  if (!upper) { r.v[0] = A(l); r.v[1] = A(l + half); }
+  else { r.v[0] = B(l - half); r.v[1] = B(l); }
+  return r;
+}
+inline bool syncthreads_or(bool pred) {
+  static int flag;          // (one workgroup at a time)
+  barrier_wait(0);
+  if (g_fiber->flat == 0) flag = 0;
+  barrier_wait(0);
+  if (pred) flag = 1;
+  barrier_wait(0);
+  return flag != 0;
+}
+
+inline int readlane(int v, int src) {
+  unsigned long long mask, vals[64];
+  wave_gather(v, &mask, vals);
+  int out = 0;
+  if ((mask >> (src & 63)) & 1ull) std::memcpy(&out, &vals[src & 63], sizeof(int));
+  return out;
+}
 inline uint32_t mbcnt(unsigned long long mask_part_shifted, uint32_t base) { return base + (uint32_t)__builtin_popcountll(mask_part_shifted); }
 
 }  // namespace svo_emu
@@ -311,6 +368,7 @@ using std::min;
 #define __shfl_xor(...) svo_emu::shfl_xor(__LINE__, __VA_ARGS__)
 #define __ballot(p) svo_emu::ballot((p))
 #define __builtin_amdgcn_ballot_w64(p) svo_emu::ballot((p))
+#define SVO_BALLOT_ACTIVE(p) svo_emu::ballot_active(__LINE__, (p))
 #define __builtin_amdgcn_readfirstlane(v) svo_emu::readfirstlane((v))
 #define __builtin_amdgcn_update_dpp(...) svo_emu::update_dpp(__LINE__, __VA_ARGS__)
 #define __builtin_amdgcn_mbcnt_lo(m, base) svo_emu::mbcnt((unsigned long long)(uint32_t)(m) & ((svo_emu::my_lane() >= 32 ? 0xffffffffull : ((1ull << svo_emu::my_lane()) - 1ull))), (base))
@@ -319,9 +377,31 @@ using std::min;
 #define __builtin_amdgcn_wave_barrier() svo_emu::wave_barrier()
 #define SVO_WAVE_LDS_HANDOVER() svo_emu::wave_barrier()
 #define SVO_LANES_LDS_HANDOVER() ((void)svo_emu::meet(__LINE__, 0))
+#define SVO_WAVE_LDS_FENCE() svo_emu::wave_barrier()
+#define SVO_LANES_LDS_FENCE() ((void)svo_emu::meet(__LINE__, 0))
 #define __builtin_amdgcn_udot4(...) svo_emu::udot4(__VA_ARGS__)
 #define __builtin_amdgcn_alignbyte(...) svo_emu::alignbyte(__VA_ARGS__)
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) svo_emu::permlane_swap((a), (b), 32)
+#define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) svo_emu::permlane_swap((a), (b), 16)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_readlane(v, l) svo_emu::readlane((v), (l))
+#define __builtin_amdgcn_rcp(x) (1.0 / (x))
+#define __builtin_amdgcn_rsq(x) (1.0 / std::sqrt(x))
+#define __syncthreads_or(p) svo_emu::syncthreads_or((p))
+template <typename To, typename From>
+inline To svo_bits(From v) {
+  static_assert(sizeof(To) == sizeof(From), "bit cast");
+  To r;
+  std::memcpy(&r, &v, sizeof(To));
+  return r;
+}
+#define __int_as_float(x) svo_bits<float>((int)(x))
+#define __uint_as_float(x) svo_bits<float>((unsigned)(x))
+#define __float_as_int(x) svo_bits<int>((float)(x))
+#define __float_as_uint(x) svo_bits<unsigned>((float)(x))
+#define __longlong_as_double(x) svo_bits<double>((long long)(x))
+#define __double_as_longlong(x) svo_bits<long long>((double)(x))
 #define __popcll(x) __builtin_popcountll(x)
 #define __clz(x) ((x) ? __builtin_clz(x) : 32)
 #define __ffsll(x) __builtin_ffsll(x)

@@ -1,0 +1,76 @@
+"""K1 -- the headline kernel -- without a GPU: rpg_svo_amd/csrc/sparse_align.hip in the host-emulated library
+(tests/emu_build.py): svo_hip_sparse_align runs sia_kernel, one workgroup of 256 work-items per frame with its LDS tiles,
+wave reductions (DPP, permlane swaps), the two-wave solve and its barriers, on the CPU, against the oracle's
+SparseImgAlign::run with the requirements of the GPU test (tests/test_sparse_align_gpu.py): poses to 1e-4 in SE(3)
+log-norm (measured here: see the assert), tracked counts identical, iteration counts per level equal for nearly every
+frame.  Also the queued -DSIA_KEEP_PX build."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import make_batch, marshal_problem, run_oracle
+from rpg_svo_amd import capi, se3, synth
+
+
+@pytest.fixture(scope="module", params=[(), ("SIA_KEEP_PX",)], ids=["default", "SIA_KEEP_PX"])
+def emu(request):
+    from emu_build import build_emulated
+    return build_emulated(request.param)
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def run_emulated(emu, b, max_level, min_level, n_iter=30):
+    imgs = np.ascontiguousarray(b.images)
+    n, h, w = imgs.shape
+    layout = capi.pyr_layout(w, h, b.n_levels)
+    store = np.zeros(capi.pyr_store_bytes(layout, n), np.uint8)
+    assert emu.svo_hip_pyramid_build_tiled(C.byref(layout), _p(store), 0, n, _p(imgs), C.c_longlong(h * w), w, capi.HALFSAMPLE_AUTO, 0, None) == 0
+    T_cr, xyz = marshal_problem(b.T_ref_w, b.T_cur_w, b.f, b.pos)
+    c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+    ref_slot, cur_slot, nn = c(b.ref_slot, np.int32), c(b.cur_slot, np.int32), c(b.n, np.int32)
+    px, xyz, T_in, valid = c(b.px, np.float64), c(xyz, np.float64), c(T_cr, np.float64), c(b.has_point, np.uint8)
+    B, ns = px.shape[0], px.shape[1]
+    d = tuple(getattr(b.cam, "d", (0.0,) * 5))
+    P = capi.SiaParams(b.cam.fx, b.cam.fy, b.cam.cx, b.cam.cy, max_level, min_level, n_iter, int(getattr(b.cam, "model", 0)), 1e-6,
+                       (C.c_double * 5)(*d))
+    T_out, H = np.zeros((B, 12)), np.zeros((B, 36))
+    n_tracked, iters = np.zeros(B, np.int32), np.zeros((B, capi.MAX_LEVELS), np.int32)
+    chi2, status = np.zeros(B), np.zeros(B, np.int32)
+    rc = emu.svo_hip_sparse_align(C.byref(layout), _p(store), B, _p(ref_slot), _p(cur_slot), _p(nn), ns, _p(px), _p(xyz), _p(valid),
+                                  C.byref(P), _p(T_in), _p(T_out), _p(H), _p(n_tracked), _p(iters), _p(chi2), _p(status), None)
+    assert rc == 0, rc
+    return se3.mul(T_out, b.T_ref_w), n_tracked, iters, H, status
+
+
+def test_emulated_sparse_align_follows_the_oracle(emu, oracle):
+    seq = synth.make_sequence(7, 200)
+    b = make_batch(seq, [(i, i + 1) for i in range(6)], 4)
+    T_h, n_tracked, iters, H, status = run_emulated(emu, b, 3, 0)
+    T_o, res_o, _ = run_oracle(oracle, b, 3, 0)
+    d = se3.log_norm(T_h, T_o)
+    err = se3.log_norm(T_h, b.T_gt_w)
+    assert d.max() <= 1e-5, d                      # (the GPU test's bound is 1e-4)
+    assert err.max() < 5e-3, err                   # and the motion is recovered
+    assert np.array_equal(n_tracked, np.array([r["n_tracked"] for r in res_o]))
+    it_o = np.array([r["iters"][:4] for r in res_o])
+    assert np.mean(np.all(iters[:, :4] == it_o, axis=1)) >= 0.8, (iters[:, :4], it_o)
+    Ho = np.array([np.asarray(r["H"]).ravel() for r in res_o])
+    assert np.abs(H - Ho).max() <= 1e-4 * np.abs(Ho).max()
+
+
+def test_emulated_sparse_align_edge_cases(emu, oracle):
+    """ragged feature counts, features without a point, an empty frame (pose untouched, nothing tracked), the reference's
+    default schedule (levels 4 -> 2 of a 5-level pyramid)"""
+    seq = synth.make_sequence(4, 120)
+    rng = np.random.default_rng(3)
+    hp = (rng.uniform(size=(3, 120)) > 0.2).astype(np.uint8)
+    b = make_batch(seq, [(0, 1), (1, 2), (2, 3)], 5, n_valid=[120, 37, 0], has_point=hp)
+    T_h, n_tracked, iters, H, status = run_emulated(emu, b, 4, 2)
+    T_o, res_o, _ = run_oracle(oracle, b, 4, 2)
+    assert se3.log_norm(T_h, T_o).max() <= 1e-5
+    assert np.array_equal(n_tracked, np.array([r["n_tracked"] for r in res_o]))
+    assert n_tracked[2] == 0 and np.abs(T_h[2] - b.T_cur_w[2]).max() < 1e-12  # (the prior, up to the product T_cur_ref * T_ref)
