@@ -12,8 +12,43 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 UNITS = ("common", "pyramid", "map_mirror", "matcher", "feature_align", "depth_filter", "sparse_align")
 
 
+def sanitizer():
+    """SVO_EMU_SANITIZE=address|thread: the emulated library instrumented by that sanitizer (the process must have the
+    runtime preloaded: scripts/emu_sanitize.sh)."""
+    return os.environ.get("SVO_EMU_SANITIZE", "")
+
+
+def sanitizer_runtime(kind):
+    cxx = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang++")
+    name = {"address": "asan", "thread": "tsan"}[kind]
+    out = subprocess.run([cxx, f"-print-file-name=libclang_rt.{name}-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    return out if os.path.isabs(out) and os.path.exists(out) else None
+
+
+def build_race_probe():
+    """tests/host/emu_race_probe.cpp (a kernel with and without the barrier it needs) with the sanitizer of SVO_EMU_SANITIZE."""
+    san = sanitizer()
+    cxx = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang++")
+    lib_path = os.path.join(ROOT, "build", f"libemu_race_probe_{san or 'plain'}.so")
+    src = os.path.join(ROOT, "tests", "host", "emu_race_probe.cpp")
+    hdr = os.path.join(ROOT, "tests", "host", "hip_emu.h")
+    os.makedirs(os.path.dirname(lib_path), exist_ok=True)
+    if not os.path.exists(lib_path) or os.path.getmtime(lib_path) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        flags = [f"-fsanitize={san}", "-shared-libsan", "-fno-omit-frame-pointer", "-g"] if san else []
+        subprocess.run([cxx, "-std=c++17", "-O1", "-fPIC", "-shared", *flags, "-I", os.path.join(ROOT, "tests", "host"), src, "-o", lib_path],
+                       check=True)
+    lib = C.CDLL(lib_path)
+    lib.probe_neighbour_sum.restype = C.c_int
+    lib.probe_neighbour_sum.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    return lib
+
+
 def build_emulated(defines=()):
     tag = "".join("_" + d.replace("=", "-") for d in defines)
+    san = sanitizer()
+    san_flags = [f"-fsanitize={san}", "-shared-libsan", "-fno-omit-frame-pointer", "-g"] if san else []
+    if san:
+        tag += "_" + san
     lib_path = os.path.join(ROOT, "build", f"libsvo_hip_emulated{tag}.so")
     objdir = os.path.join(ROOT, "build", f"emu_obj{tag}")
     os.makedirs(objdir, exist_ok=True)
@@ -31,7 +66,7 @@ def build_emulated(defines=()):
         objs.append(obj)
         if not os.path.exists(obj) or os.path.getmtime(obj) < max(newest, os.path.getmtime(src)):
             todo.append([cxx, "-std=c++17", "-O1", "-ffp-contract=off", "-fno-math-errno", "-fPIC", "-c", "-Wall", "-Wno-unknown-pragmas",
-                         "-Wno-pass-failed", "-Wno-unused-function", "-Wno-unused-variable",
+                         "-Wno-pass-failed", "-Wno-unused-function", "-Wno-unused-variable", *san_flags,
                          *[f"-D{d}" for d in defines], "-I", os.path.join(ROOT, "include"), "-I", csrc,
                          "-I", os.path.join(ROOT, "tests", "host"), src, "-o", obj])
     if todo:  # the translation units in parallel: a cold build of one variant set takes about as long as its slowest unit
@@ -39,6 +74,6 @@ def build_emulated(defines=()):
         with ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
             list(ex.map(lambda cmd: subprocess.run(cmd, check=True), todo))
     if not os.path.exists(lib_path) or any(os.path.getmtime(o) > os.path.getmtime(lib_path) for o in objs):
-        subprocess.run([cxx, "-shared", "-o", lib_path, *objs], check=True)
+        subprocess.run([cxx, "-shared", *san_flags, "-o", lib_path, *objs], check=True)
     lib = C.CDLL(lib_path)
     return lib

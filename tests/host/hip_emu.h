@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <ucontext.h>
 #include <vector>
@@ -74,6 +75,7 @@ struct Fiber {
                                  // WAVE_BARRIER + w: the barrier of all live lanes of wave w
   unsigned long long slot = 0;   // value offered to a rendezvous
   const struct Rendezvous* met = nullptr;  // the one this work-item was released from
+  void* tsan = nullptr;          // (ThreadSanitizer builds: the fiber as the sanitizer knows it)
 };
 
 constexpr int WAVE_BARRIER = 1 << 24;
@@ -85,7 +87,7 @@ struct Rendezvous {
 };
 
 struct Block {
-  std::vector<Fiber> fibers;
+  std::deque<Fiber> fibers;      // (a deque: a suspended fiber's saved context must not move)
   std::map<std::pair<int, unsigned>, Rendezvous> met;  // (site, wave) -> the last meeting there
   ucontext_t scheduler;
   dim3 bid, bdim, gdim;
@@ -97,23 +99,105 @@ inline Block* g_block = nullptr;   // (one OS thread runs the emulation)
 inline Fiber* g_fiber = nullptr;
 inline std::function<void()>* g_body = nullptr;
 
-inline void fiber_main() {
-  (*g_body)();
-  g_fiber->done = true;
-  --g_block->alive;
-  --g_block->wave_alive[g_fiber->flat / 64];
-  swapcontext(&g_fiber->ctx, &g_block->scheduler);
+// Sanitizer builds (tests/emu_build.py with SVO_EMU_SANITIZE=address or thread; scripts/emu_sanitize.sh).
+//  address: the kernels' loads and stores checked against the bounds of the buffers they were handed and of their LDS
+//           arrays; the sanitizer is told about every change of stack.
+//  thread:  every work-item is a fiber of its own to ThreadSanitizer, switches carry NO ordering, and the only ordering
+//           between work-items is what the kernel asks for: __syncthreads (workgroup), the wave-wide collectives and
+//           hand-overs (wave), the cross-lane moves and lane-group hand-overs (the lanes that meet at the call site).
+//           A store to LDS or global memory by one work-item and a load or store of the same bytes by another with none
+//           of these in between -- a missing barrier, or a hand-over that relies on lock step without telling the
+//           compiler -- is reported as a data race with both source lines.  Workgroups are ordered one after the other
+//           (they share the static LDS arrays here), so races BETWEEN workgroups are not looked for.
+//           The emulator's own bookkeeping is exempt (SVO_EMU_NOTSAN).
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define SVO_EMU_ASAN 1
+extern "C" void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
+#endif
+#if __has_feature(thread_sanitizer)
+#define SVO_EMU_TSAN 1
+extern "C" void* __tsan_get_current_fiber(void);
+extern "C" void* __tsan_create_fiber(unsigned flags);
+extern "C" void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+extern "C" void __tsan_acquire(void* addr);
+extern "C" void __tsan_release(void* addr);
+#endif
+#endif
+#ifdef SVO_EMU_TSAN
+#define SVO_EMU_NOTSAN __attribute__((no_sanitize("thread"), noinline))
+#else
+#define SVO_EMU_NOTSAN
+#endif
+inline const void* g_sched_stack = nullptr;  // the scheduler's (= the calling thread's) stack, learnt at a fiber's first entry
+inline size_t g_sched_stack_size = 0;
+inline void* g_sched_tsan = nullptr;         // the calling thread, as ThreadSanitizer knows it
+// what a barrier's arrivals publish and its departures pick up (addresses only; ThreadSanitizer keeps a clock per address)
+inline char g_sync_block, g_sync_start, g_sync_exit, g_sync_wave[64], g_sync_site[16][8192];
+SVO_EMU_NOTSAN inline void* sync_object(int id, unsigned flat) {
+  if (id == 0) return &g_sync_block;
+  if (id >= WAVE_BARRIER) return &g_sync_wave[(id - WAVE_BARRIER) & 63];
+  return &g_sync_site[(flat / 64) & 15][id & 8191];
+}
+
+// from the running work-item back to the scheduler
+SVO_EMU_NOTSAN inline void yield_to_scheduler() {
+  Fiber* self = g_fiber;
+#ifdef SVO_EMU_ASAN
+  void* fake = nullptr;
+  __sanitizer_start_switch_fiber(&fake, g_sched_stack, g_sched_stack_size);
+#endif
+#ifdef SVO_EMU_TSAN
+  __tsan_switch_to_fiber(g_sched_tsan, 1u /* no ordering */);
+#endif
+  swapcontext(&self->ctx, &g_block->scheduler);
+#ifdef SVO_EMU_ASAN
+  __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
+}
+
+// a work-item's fiber lives as long as the emulator: it runs the kernel body of one workgroup after the other
+SVO_EMU_NOTSAN inline void fiber_main() {
+#ifdef SVO_EMU_ASAN
+  __sanitizer_finish_switch_fiber(nullptr, &g_sched_stack, &g_sched_stack_size);
+#endif
+  for (;;) {
+#ifdef SVO_EMU_TSAN
+    __tsan_acquire(&g_sync_start);  // what the host and the workgroups before this one wrote
+#endif
+    (*g_body)();
+#ifdef SVO_EMU_TSAN
+    __tsan_release(&g_sync_exit);
+#endif
+    g_fiber->done = true;
+    --g_block->alive;
+    --g_block->wave_alive[g_fiber->flat / 64];
+    yield_to_scheduler();
+  }
 }
 
 // park the running work-item on barrier `id` until all live work-items of its scope have arrived
-inline void barrier_wait(int id) {
+SVO_EMU_NOTSAN inline void barrier_wait(int id) {
   g_fiber->waiting_on = id;
-  swapcontext(&g_fiber->ctx, &g_block->scheduler);
+#ifdef SVO_EMU_TSAN
+  void* so = sync_object(id, g_fiber->flat);
+  __tsan_release(so);
+#endif
+  yield_to_scheduler();
+#ifdef SVO_EMU_TSAN
+  __tsan_acquire(so);
+#endif
 }
 
-inline void run_block(Block& b, std::function<void()>& body, size_t stack_bytes) {
+SVO_EMU_NOTSAN inline void run_block(Block& b, std::function<void()>& body, size_t stack_bytes) {
   g_block = &b;
   g_body = &body;
+#ifdef SVO_EMU_TSAN
+  g_sched_tsan = __tsan_get_current_fiber();
+  __tsan_acquire(&g_sync_exit);   // the workgroup before this one
+  __tsan_release(&g_sync_start);
+#endif
   const unsigned n = (unsigned)b.fibers.size();
   b.alive = n;
   b.wave_alive.assign((n + 63) / 64, 0);
@@ -124,12 +208,17 @@ inline void run_block(Block& b, std::function<void()>& body, size_t stack_bytes)
     f.done = false;
     f.waiting_on = -1;
     ++b.wave_alive[t / 64];
-    if (f.stack.size() != stack_bytes) f.stack.resize(stack_bytes);
-    getcontext(&f.ctx);
-    f.ctx.uc_stack.ss_sp = f.stack.data();
-    f.ctx.uc_stack.ss_size = f.stack.size();
-    f.ctx.uc_link = &b.scheduler;
-    makecontext(&f.ctx, fiber_main, 0);
+    if (f.stack.size() != stack_bytes) {  // a new work-item: its fiber starts at the top of fiber_main's loop
+      f.stack.resize(stack_bytes);
+      getcontext(&f.ctx);
+      f.ctx.uc_stack.ss_sp = f.stack.data();
+      f.ctx.uc_stack.ss_size = f.stack.size();
+      f.ctx.uc_link = &b.scheduler;
+      makecontext(&f.ctx, fiber_main, 0);
+#ifdef SVO_EMU_TSAN
+      f.tsan = __tsan_create_fiber(0);
+#endif
+    }
   }
   while (b.alive > 0) {
     bool progressed = false;
@@ -137,7 +226,17 @@ inline void run_block(Block& b, std::function<void()>& body, size_t stack_bytes)
       Fiber& f = b.fibers[t];
       if (f.done || f.waiting_on >= 0) continue;
       g_fiber = &f;
+#ifdef SVO_EMU_ASAN
+      void* fake = nullptr;
+      __sanitizer_start_switch_fiber(&fake, f.stack.data(), f.stack.size());
+#endif
+#ifdef SVO_EMU_TSAN
+      __tsan_switch_to_fiber(f.tsan, 1u /* no ordering */);
+#endif
       swapcontext(&b.scheduler, &f.ctx);
+#ifdef SVO_EMU_ASAN
+      __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
       progressed = true;
     }
     if (progressed) continue;
@@ -202,6 +301,9 @@ inline void run_block(Block& b, std::function<void()>& body, size_t stack_bytes)
       std::abort();
     }
   }
+#ifdef SVO_EMU_TSAN
+  __tsan_acquire(&g_sync_exit);  // the host reads what the kernel wrote
+#endif
   g_block = nullptr;
   g_fiber = nullptr;
 }
@@ -225,19 +327,19 @@ void launch(dim3 grid, dim3 block, F&& body_in) {
 
 // the running work-item meets the other lanes of its wave that reach call site `site`; returns what they offered
 template <typename T>
-inline const Rendezvous& meet(int site, T v) {
+SVO_EMU_NOTSAN inline const Rendezvous& meet(int site, T v) {
   static_assert(sizeof(T) <= 8, "rendezvous slot");
   unsigned long long bits = 0;
-  std::memcpy(&bits, &v, sizeof(T));
+  __builtin_memcpy(&bits, &v, sizeof(T));
   g_fiber->slot = bits;
   barrier_wait(site);
   return *g_fiber->met;
 }
 template <typename T>
-inline T lane_value(const Rendezvous& r, int src_lane, T own) {  // the value lane `src_lane` offered; `own` if it did not take part
+SVO_EMU_NOTSAN inline T lane_value(const Rendezvous& r, int src_lane, T own) {  // the value lane `src_lane` offered; `own` if it did not take part
   if (src_lane < 0 || src_lane > 63 || !((r.mask >> src_lane) & 1ull)) return own;
   T out;
-  std::memcpy(&out, &r.val[src_lane], sizeof(T));
+  __builtin_memcpy(&out, &r.val[src_lane], sizeof(T));
   return out;
 }
 inline int my_lane() { return (int)(g_fiber->flat & 63u); }
@@ -251,9 +353,9 @@ inline T shfl_xor(int site, T v, int mask, int /*width*/) { return lane_value(me
 // a value from every live lane of the wave: collectives that every lane of the wave executes (ballot, readfirstlane,
 // readlane, the permlane swaps)
 template <typename T>
-inline void wave_gather(T v, unsigned long long* mask, unsigned long long vals[64]) {
+SVO_EMU_NOTSAN inline void wave_gather(T v, unsigned long long* mask, unsigned long long vals[64]) {
   unsigned long long bits = 0;
-  std::memcpy(&bits, &v, sizeof(T));
+  __builtin_memcpy(&bits, &v, sizeof(T));
   g_fiber->slot = bits;
   wave_barrier();
   const unsigned w0 = (g_fiber->flat / 64) * 64;
@@ -264,7 +366,7 @@ inline void wave_gather(T v, unsigned long long* mask, unsigned long long vals[6
   }
   wave_barrier();  // everybody has read before anybody offers again
 }
-inline unsigned long long ballot(bool pred) {
+SVO_EMU_NOTSAN inline unsigned long long ballot(bool pred) {
   unsigned long long mask, vals[64], m = 0;
   wave_gather((unsigned long long)(pred ? 1 : 0), &mask, vals);
   for (int l = 0; l < 64; ++l)
@@ -272,7 +374,7 @@ inline unsigned long long ballot(bool pred) {
   return m;
 }
 // the ballot of the lanes that are active in a divergent branch (SVO_BALLOT_ACTIVE): those that arrive
-inline unsigned long long ballot_active(int site, bool pred) {
+SVO_EMU_NOTSAN inline unsigned long long ballot_active(int site, bool pred) {
   const Rendezvous& r = meet(site, (unsigned long long)(pred ? 1 : 0));
   unsigned long long m = 0;
   for (int l = 0; l < 64; ++l)
@@ -280,15 +382,15 @@ inline unsigned long long ballot_active(int site, bool pred) {
   return m;
 }
 template <typename T>
-inline T readfirstlane(T v) {
+SVO_EMU_NOTSAN inline T readfirstlane(T v) {
   unsigned long long mask, vals[64];
   wave_gather(v, &mask, vals);
   T out;
-  std::memcpy(&out, &vals[__builtin_ctzll(mask)], sizeof(T));
+  __builtin_memcpy(&out, &vals[__builtin_ctzll(mask)], sizeof(T));
   return out;
 }
 // the DPP controls the kernels use (bound_ctrl: a lane without a source gets 0)
-inline int update_dpp(int site, int /*old*/, int v, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool /*bound_ctrl*/) {
+SVO_EMU_NOTSAN inline int update_dpp(int site, int /*old*/, int v, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool /*bound_ctrl*/) {
   const Rendezvous& r = meet(site, v);
   const int l = my_lane();
   int src;
@@ -316,7 +418,7 @@ struct Pair32 {
   uint32_t v[2];
   uint32_t operator[](int i) const { return v[i]; }
 };
-inline Pair32 permlane_swap(uint32_t a, uint32_t b, int half) {
+SVO_EMU_NOTSAN inline Pair32 permlane_swap(uint32_t a, uint32_t b, int half) {
   unsigned long long mask, vals[64];
   wave_gather(((unsigned long long)b << 32) | a, &mask, vals);
   const int l = my_lane();
@@ -328,7 +430,7 @@ inline Pair32 permlane_swap(uint32_t a, uint32_t b, int half) {
   else { r.v[0] = B(l - half); r.v[1] = B(l); }
   return r;
 }
-inline bool syncthreads_or(bool pred) {
+SVO_EMU_NOTSAN inline bool syncthreads_or(bool pred) {
   static int flag;          // (one workgroup at a time)
   barrier_wait(0);
   if (g_fiber->flat == 0) flag = 0;
@@ -338,11 +440,11 @@ inline bool syncthreads_or(bool pred) {
   return flag != 0;
 }
 
-inline int readlane(int v, int src) {
+SVO_EMU_NOTSAN inline int readlane(int v, int src) {
   unsigned long long mask, vals[64];
   wave_gather(v, &mask, vals);
   int out = 0;
-  if ((mask >> (src & 63)) & 1ull) std::memcpy(&out, &vals[src & 63], sizeof(int));
+  if ((mask >> (src & 63)) & 1ull) __builtin_memcpy(&out, &vals[src & 63], sizeof(int));
   return out;
 }
 inline uint32_t mbcnt(unsigned long long mask_part_shifted, uint32_t base) { return base + (uint32_t)__builtin_popcountll(mask_part_shifted); }
@@ -381,7 +483,7 @@ using std::min;
 #define SVO_LANES_LDS_FENCE() ((void)svo_emu::meet(__LINE__, 0))
 #define __builtin_amdgcn_udot4(...) svo_emu::udot4(__VA_ARGS__)
 #define __builtin_amdgcn_alignbyte(...) svo_emu::alignbyte(__VA_ARGS__)
-#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_RELAXED)
 #define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) svo_emu::permlane_swap((a), (b), 32)
 #define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) svo_emu::permlane_swap((a), (b), 16)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
