@@ -40,6 +40,8 @@ using std::sqrt;
 // a ballot inside a divergent branch: the mask of the lanes that are active there (a caller that only looks at its own
 // bit, e.g. a select by lane mask, may stand anywhere); the plain builtin is used where every live lane of the wave votes
 #define SVO_BALLOT_ACTIVE(pred) __builtin_amdgcn_ballot_w64(pred)
+// the workgroup's dynamically sized LDS (the byte count is the launch's), as an array `name` of `type`
+#define SVO_DYNAMIC_LDS(type, name) extern __shared__ type name[]
 #endif
 
 namespace svo_dev {

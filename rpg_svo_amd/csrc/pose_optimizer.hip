@@ -102,7 +102,7 @@ struct PoseDyn {
 
 __global__ void __launch_bounds__(PO_BLOCK, PO_MINW) pose_opt_kernel(const PoseArgs a) {
   __shared__ PoseLds s;
-  extern __shared__ double po_dyn[];
+  SVO_DYNAMIC_LDS(double, po_dyn);
   const int ns8 = (a.n_stride + 7) & ~7;
   PoseDyn d;
   d.vals = po_dyn;

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
   //   q4 = r3 c0..3 | q5 = r3 c4,5 r4 c0,1 | q6 = r4 c2..5 | q7 = r5 c1..4
   // Patches 64k..64k+63 (the lanes' k-th patches) form one block [8][64] float4, so that every address is
   // the lane's base plus a compile-time offset; the last block is [8][last_n], last_n = n_slots - 64 (PPL-1).
-  extern __shared__ float4 s_bt[];
+  SVO_DYNAMIC_LDS(float4, s_bt);
   __shared__ WaveLds g;
   const int last_n = n_slots - 64 * (PPL - 1);
 #define SIA_BT(k, q) s_bt[((k) < PPL - 1) ? ((k) * 512 + (q) * 64 + lane) : ((PPL - 1) * 512 + (q) * last_n + lane)]
@@ -434,8 +434,8 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
               r0 = 1;
               bo = (u_i - 2) - p.wc_u0;
             }
-            const uint64_t k0 = __builtin_amdgcn_ballot_w64(r0 == 0), k1 = __builtin_amdgcn_ballot_w64(r0 == 1);
-            const uint64_t kup = __builtin_amdgcn_ballot_w64(bo >= 4);
+            const uint64_t k0 = SVO_BALLOT_ACTIVE(r0 == 0), k1 = SVO_BALLOT_ACTIVE(r0 == 1);
+            const uint64_t kup = SVO_BALLOT_ACTIVE(bo >= 4);
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
               const uint32_t d0 = sel_e64(k0, p.wc[r][0], sel_e64(k1, p.wc[r + 1][0], p.wc[r + 2][0]));
@@ -520,21 +520,21 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
           const float t8 = wave_reduce8(hp + 8 * gq, lane);
           if ((lane & 7) == 0) g.red[8 * gq + (lane >> 3)] = t8;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // same-wave LDS hand-over: keep the order
+        SVO_WAVE_LDS_FENCE();  // same-wave LDS hand-over: keep the order
         // H^-1 by Gauss-Jordan on a 6x6 tile held one element per lane (36 lanes), LDS as the row/column
         // exchange: a few registers instead of the ~90 a register LDL^T keeps live, which matters here
         // because the lane also carries the state of up to four patches.  A zero pivot contributes nothing,
         // like the D^-1 step of Eigen's LDLT::solve.  Runs when the set of patches inside the image changes
         // (about once per level).
         if (lane < 21) g.H[lane] = (double)g.red[lane];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        SVO_WAVE_LDS_FENCE();
         const int gi = lane / 6, gj = lane - 6 * gi;
         if (lane < 36) {
           g.A[lane] = g.H[sym6_rt(gi, gj)];
           g.Hinv[lane] = (gi == gj) ? 1.0 : 0.0;
         }
         for (int kk = 0; kk < 6; ++kk) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          SVO_WAVE_LDS_FENCE();
           if (lane < 36) {
             const double pv = g.A[kk * 6 + kk];
             const double aik = g.A[gi * 6 + kk];
@@ -545,12 +545,12 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
             const double ip = (fabs(pv) > 2.2250738585072014e-308) ? 1.0 / pv : 0.0;
             const double na = (gi == kk) ? akj * ip : aij - aik * (akj * ip);
             const double nb = (gi == kk) ? bkj * ip : bij - aik * (bkj * ip);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            SVO_LANES_LDS_FENCE();
             g.A[lane] = na;
             g.Hinv[lane] = nb;
           }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        SVO_WAVE_LDS_FENCE();
       }
       ++evals;
 

@@ -9,7 +9,8 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-UNITS = ("common", "pyramid", "map_mirror", "matcher", "feature_align", "depth_filter", "sparse_align")
+UNITS = ("common", "pyramid", "map_mirror", "matcher", "feature_align", "depth_filter", "sparse_align", "sparse_align_wave",
+         "pose_optimizer_wave", "pose_optimizer", "point_optimizer", "fast_detect")
 
 
 def sanitizer():

@@ -74,6 +74,7 @@ struct Fiber {
   int waiting_on = -1;           // -1 runnable; 0 the workgroup barrier; 1 .. WAVE_BARRIER-1: a cross-lane rendezvous (site id);
                                  // WAVE_BARRIER + w: the barrier of all live lanes of wave w
   unsigned long long slot = 0;   // value offered to a rendezvous
+  int site = 0;                  // call site of the wave-wide collective the work-item stands at
   const struct Rendezvous* met = nullptr;  // the one this work-item was released from
   void* tsan = nullptr;          // (ThreadSanitizer builds: the fiber as the sanitizer knows it)
 };
@@ -95,6 +96,8 @@ struct Block {
   std::vector<unsigned> wave_alive;
 };
 
+struct alignas(16) Lds16 { char b[16]; };
+inline std::vector<Lds16> g_dyn_lds;  // the running launch's dynamic LDS
 inline Block* g_block = nullptr;   // (one OS thread runs the emulation)
 inline Fiber* g_fiber = nullptr;
 inline std::function<void()>* g_body = nullptr;
@@ -353,22 +356,30 @@ inline T shfl_xor(int site, T v, int mask, int /*width*/) { return lane_value(me
 // a value from every live lane of the wave: collectives that every lane of the wave executes (ballot, readfirstlane,
 // readlane, the permlane swaps)
 template <typename T>
-SVO_EMU_NOTSAN inline void wave_gather(T v, unsigned long long* mask, unsigned long long vals[64]) {
+SVO_EMU_NOTSAN inline void wave_gather(T v, unsigned long long* mask, unsigned long long vals[64], int site = 0) {
   unsigned long long bits = 0;
   __builtin_memcpy(&bits, &v, sizeof(T));
   g_fiber->slot = bits;
+  g_fiber->site = site;
   wave_barrier();
   const unsigned w0 = (g_fiber->flat / 64) * 64;
   *mask = 0;
   for (unsigned l = 0; l < 64 && w0 + l < g_block->fibers.size(); ++l) {
     const Fiber& f = g_block->fibers[w0 + l];
-    if (!f.done) { *mask |= 1ull << l; vals[l] = f.slot; }
+    if (f.done) continue;
+    *mask |= 1ull << l;
+    vals[l] = f.slot;
+    if (f.site != site) {  // a collective of the whole wave that only part of the wave executes: SVO_BALLOT_ACTIVE & co. are for that
+      std::fprintf(stderr, "hip_emu: lanes %u and %u of a wave stand at different wave-wide collectives (lines %d and %d)\n",
+                   g_fiber->flat & 63u, l, site, f.site);
+      std::abort();
+    }
   }
   wave_barrier();  // everybody has read before anybody offers again
 }
-SVO_EMU_NOTSAN inline unsigned long long ballot(bool pred) {
+SVO_EMU_NOTSAN inline unsigned long long ballot(bool pred, int site = 0) {
   unsigned long long mask, vals[64], m = 0;
-  wave_gather((unsigned long long)(pred ? 1 : 0), &mask, vals);
+  wave_gather((unsigned long long)(pred ? 1 : 0), &mask, vals, site);
   for (int l = 0; l < 64; ++l)
     if (((mask >> l) & 1ull) && vals[l]) m |= 1ull << l;
   return m;
@@ -382,9 +393,9 @@ SVO_EMU_NOTSAN inline unsigned long long ballot_active(int site, bool pred) {
   return m;
 }
 template <typename T>
-SVO_EMU_NOTSAN inline T readfirstlane(T v) {
+SVO_EMU_NOTSAN inline T readfirstlane(T v, int site = 0) {
   unsigned long long mask, vals[64];
-  wave_gather(v, &mask, vals);
+  wave_gather(v, &mask, vals, site);
   T out;
   __builtin_memcpy(&out, &vals[__builtin_ctzll(mask)], sizeof(T));
   return out;
@@ -418,9 +429,9 @@ struct Pair32 {
   uint32_t v[2];
   uint32_t operator[](int i) const { return v[i]; }
 };
-SVO_EMU_NOTSAN inline Pair32 permlane_swap(uint32_t a, uint32_t b, int half) {
+SVO_EMU_NOTSAN inline Pair32 permlane_swap(uint32_t a, uint32_t b, int half, int site = 0) {
   unsigned long long mask, vals[64];
-  wave_gather(((unsigned long long)b << 32) | a, &mask, vals);
+  wave_gather(((unsigned long long)b << 32) | a, &mask, vals, site);
   const int l = my_lane();
   const bool upper = (l & half) != 0;
   auto A = [&](int lane) { return ((mask >> lane) & 1ull) ? (uint32_t)vals[lane] : 0u; };
@@ -440,9 +451,9 @@ SVO_EMU_NOTSAN inline bool syncthreads_or(bool pred) {
   return flag != 0;
 }
 
-SVO_EMU_NOTSAN inline int readlane(int v, int src) {
+SVO_EMU_NOTSAN inline int readlane(int v, int src, int site = 0) {
   unsigned long long mask, vals[64];
-  wave_gather(v, &mask, vals);
+  wave_gather(v, &mask, vals, site);
   int out = 0;
   if ((mask >> (src & 63)) & 1ull) __builtin_memcpy(&out, &vals[src & 63], sizeof(int));
   return out;
@@ -468,10 +479,10 @@ using std::min;
 #define __shfl_up(...) svo_emu::shfl_up(__LINE__, __VA_ARGS__)
 #define __shfl(...) svo_emu::shfl(__LINE__, __VA_ARGS__)
 #define __shfl_xor(...) svo_emu::shfl_xor(__LINE__, __VA_ARGS__)
-#define __ballot(p) svo_emu::ballot((p))
-#define __builtin_amdgcn_ballot_w64(p) svo_emu::ballot((p))
+#define __ballot(p) svo_emu::ballot((p), __LINE__)
+#define __builtin_amdgcn_ballot_w64(p) svo_emu::ballot((p), __LINE__)
 #define SVO_BALLOT_ACTIVE(p) svo_emu::ballot_active(__LINE__, (p))
-#define __builtin_amdgcn_readfirstlane(v) svo_emu::readfirstlane((v))
+#define __builtin_amdgcn_readfirstlane(v) svo_emu::readfirstlane((v), __LINE__)
 #define __builtin_amdgcn_update_dpp(...) svo_emu::update_dpp(__LINE__, __VA_ARGS__)
 #define __builtin_amdgcn_mbcnt_lo(m, base) svo_emu::mbcnt((unsigned long long)(uint32_t)(m) & ((svo_emu::my_lane() >= 32 ? 0xffffffffull : ((1ull << svo_emu::my_lane()) - 1ull))), (base))
 #define __builtin_amdgcn_mbcnt_hi(m, base) svo_emu::mbcnt(svo_emu::my_lane() > 32 ? ((unsigned long long)(uint32_t)(m) & ((1ull << (svo_emu::my_lane() - 32)) - 1ull)) : 0ull, (base))
@@ -484,10 +495,10 @@ using std::min;
 #define __builtin_amdgcn_udot4(...) svo_emu::udot4(__VA_ARGS__)
 #define __builtin_amdgcn_alignbyte(...) svo_emu::alignbyte(__VA_ARGS__)
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_RELAXED)
-#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) svo_emu::permlane_swap((a), (b), 32)
-#define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) svo_emu::permlane_swap((a), (b), 16)
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) svo_emu::permlane_swap((a), (b), 32, __LINE__)
+#define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) svo_emu::permlane_swap((a), (b), 16, __LINE__)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
-#define __builtin_amdgcn_readlane(v, l) svo_emu::readlane((v), (l))
+#define __builtin_amdgcn_readlane(v, l) svo_emu::readlane((v), (l), __LINE__)
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))
 #define __builtin_amdgcn_rsq(x) (1.0 / std::sqrt(x))
 #define __syncthreads_or(p) svo_emu::syncthreads_or((p))
@@ -498,12 +509,12 @@ inline To svo_bits(From v) {
   std::memcpy(&r, &v, sizeof(To));
   return r;
 }
-#define __int_as_float(x) svo_bits<float>((int)(x))
-#define __uint_as_float(x) svo_bits<float>((unsigned)(x))
-#define __float_as_int(x) svo_bits<int>((float)(x))
-#define __float_as_uint(x) svo_bits<unsigned>((float)(x))
-#define __longlong_as_double(x) svo_bits<double>((long long)(x))
-#define __double_as_longlong(x) svo_bits<long long>((double)(x))
+inline float __int_as_float(int x) { return svo_bits<float>(x); }
+inline float __uint_as_float(unsigned x) { return svo_bits<float>(x); }
+inline int __float_as_int(float x) { return svo_bits<int>(x); }
+inline unsigned __float_as_uint(float x) { return svo_bits<unsigned>(x); }
+inline double __longlong_as_double(long long x) { return svo_bits<double>(x); }
+inline long long __double_as_longlong(double x) { return svo_bits<long long>(x); }
 #define __popcll(x) __builtin_popcountll(x)
 #define __clz(x) ((x) ? __builtin_clz(x) : 32)
 #define __ffsll(x) __builtin_ffsll(x)
@@ -519,5 +530,12 @@ inline int atomicMax(int* p, int v) {
   while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
   return old;
 }
+inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) {
+  unsigned long long old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
+// dynamically sized LDS: one buffer per launch, sized by the launch's byte count
+#define SVO_DYNAMIC_LDS(type, name) type* const name = reinterpret_cast<type*>(svo_emu::g_dyn_lds.data())
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-  svo_emu::launch((grid), (block), [&] { kernel(__VA_ARGS__); })
+  (svo_emu::g_dyn_lds.assign(((size_t)(shmem) + 15) / 16 + 1, svo_emu::Lds16{}), svo_emu::launch((grid), (block), [&] { kernel(__VA_ARGS__); }))

@@ -1,0 +1,144 @@
+"""Rows a11 and a13 without a GPU: svo_hip_pose_optimize (the wave kernel, its hand-over to the ordered kernel, the
+deferred entry), svo_hip_pose_optimize_ordered and svo_hip_point_optimize of the host-emulated library (tests/emu_build.py:
+pose_optimizer_wave.hip, pose_optimizer.hip, point_optimizer.hip compiled for the CPU through tests/host/hip_emu.h) against
+the oracle's pose_optimizer::optimizeGaussNewton and Point::optimize, with the requirements of tests/test_tracking_gpu.py.
+Also the queued -DPOSE_LOAD_FIRST build of the wave kernel."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import camera_models
+from oracle import pytrack
+from rpg_svo_amd import capi, se3, synth
+
+
+@pytest.fixture(scope="module", params=[(), ("POSE_LOAD_FIRST",)], ids=["default", "POSE_LOAD_FIRST"])
+def emu(request):
+    from emu_build import build_emulated
+    return build_emulated(request.param)
+
+
+@pytest.fixture(scope="module", params=["pinhole", "atan"])
+def scene(request):
+    return synth.make_track_scene(n_kf=4, n_feat=100, cam=camera_models()[request.param])
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def pose_optimize(emu, cam, n, f, level, pos, hp, T0, thresh, n_iter, entry="svo_hip_pose_optimize"):
+    c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+    n, f, level, pos = c(n, np.int32), c(f, np.float64), c(level, np.int32), c(pos, np.float64)
+    B, ns = f.shape[0], f.shape[1]
+    T, hpo = c(T0, np.float64).copy(), c(hp, np.uint8).copy()
+    Cov, stats, ran = np.zeros((B, 36)), np.zeros((B, 4)), np.zeros(B, np.int32)
+    cs = capi.camera(cam)
+    rc = getattr(emu, entry)(C.byref(cs), B, _p(n), ns, _p(f), _p(level), _p(pos), _p(hpo), C.c_double(thresh), n_iter, _p(T), _p(Cov),
+                             _p(stats), _p(ran), None)
+    assert rc == 0, rc
+    return T, Cov, stats, ran, hpo
+
+
+@pytest.mark.parametrize("ordered", [True, False], ids=["ordered", "wave"])
+def test_emulated_pose_optimize(emu, oracle, scene, ordered):
+    orc = pytrack.Track("orc")
+    rng = np.random.default_rng(2)
+    P = len(scene.pt_pos)
+    B, ns = 12, P
+    f = synth._bearing(scene.cam, scene.px_true + rng.normal(size=(P, 2)) * 0.3)
+    level = rng.integers(0, 3, size=P).astype(np.int32)
+    pos = scene.pt_pos.copy()
+    pos[::15] += rng.normal(size=pos[::15].shape) * 0.2
+    n = np.array([P, 200, 120, 40, 7, 3, P, P, 1, 150, 64, 5], dtype=np.int32)
+    hp = (rng.uniform(size=(B, ns)) > 0.2).astype(np.uint8)
+    hp[9] = 0                                                           # no observation has a point
+    T0 = np.stack([se3.mul(se3.exp(rng.normal(size=6) * 5e-3), scene.T_f_w[scene.cur]) for _ in range(B)])
+    n_iter = 10
+    Tg, Cov, stats, ran, hpg = pose_optimize(emu, scene.cam, n, np.tile(f, (B, 1, 1)), np.tile(level, (B, 1)), np.tile(pos, (B, 1, 1)), hp, T0,
+                                             2.0, n_iter, "svo_hip_pose_optimize_ordered" if ordered else "svo_hip_pose_optimize")
+    for b in range(B):
+        o = orc.pose_optimize(scene.cam, T0[b], f[:n[b]], level[:n[b]], hp[b, :n[b]], pos[:n[b]], 2.0, n_iter)
+        assert ran[b] == o["ran"], b
+        if not o["ran"]:
+            assert np.array_equal(Tg[b], T0[b]) and np.array_equal(hpg[b], hp[b])
+            continue
+        assert se3.log_norm(Tg[b][None], o["T_f_w"][None])[0] < (1e-10 if ordered else 1e-9), b
+        assert np.array_equal(hpg[b, :n[b]], o["has_point"]), b
+        assert stats[b, 3] == o["num_obs"]
+        assert np.allclose(stats[b, :3], [o["estimated_scale"], o["error_init"], o["error_final"]], rtol=1e-9, atol=1e-12)
+        if n[b] >= 40:
+            assert np.allclose(Cov[b].reshape(6, 6), o["Cov"], rtol=1e-6, atol=1e-14), b
+    assert se3.log_norm(Tg[0][None], scene.T_f_w[scene.cur][None])[0] < 2e-3
+
+
+def test_emulated_pose_optimize_deferred(emu, scene):
+    """(tests/test_tracking_gpu.py::test_pose_optimize_deferred)"""
+    rng = np.random.default_rng(4)
+    P = min(len(scene.pt_pos), 200)
+    B = 6
+    pt_pos = scene.pt_pos[:P]
+    f = synth._bearing(scene.cam, scene.px_true[:P] + rng.normal(size=(P, 2)) * 0.3)
+    level = rng.integers(0, 3, size=P).astype(np.int32)
+    n = np.array([P, 150, 2, 64, 1, 40], dtype=np.int32)
+    hp = np.ones((B, P), dtype=np.uint8)
+    T0 = np.stack([se3.mul(se3.exp(rng.normal(size=6) * 5e-3), scene.T_f_w[scene.cur]) for _ in range(B)])
+
+    def run(n_iter, entry="svo_hip_pose_optimize"):
+        T, _, st, ran, hpo = pose_optimize(emu, scene.cam, n, np.tile(f, (B, 1, 1)), np.tile(level, (B, 1)), np.tile(pt_pos, (B, 1, 1)), hp, T0,
+                                           2.0, n_iter, entry)
+        return T, ran, hpo, st
+
+    Tf, ran_f, hp_f, _ = run(10)
+    Tp, ran_p, hp_p, _ = run(10, "svo_hip_pose_optimize_deferred")
+    assert not (ran_f == 2).any()
+    taken = ran_p != 2
+    assert taken.any()
+    assert np.array_equal(Tf[taken], Tp[taken]) and np.array_equal(ran_f[taken], ran_p[taken]) and np.array_equal(hp_f[taken], hp_p[taken])
+    assert np.array_equal(Tp[~taken], T0[~taken]) and np.array_equal(hp_p[~taken], hp[~taken])
+    T0f, ran0f, hp0f, st0f = run(0)
+    T0p, ran0p, hp0p, _ = run(0, "svo_hip_pose_optimize_deferred")
+    assert (ran0p == 2).all() and np.array_equal(T0p, T0) and np.array_equal(hp0p, hp)
+    T0o, ran0o, hp0o, st0o = run(0, "svo_hip_pose_optimize_ordered")
+    assert np.array_equal(T0o, T0f) and np.array_equal(ran0o, ran0f) and np.array_equal(hp0o, hp0f) and np.array_equal(st0o, st0f)
+
+
+def test_emulated_point_optimize(emu, oracle, scene):
+    orc = pytrack.Track("orc")
+    rng = np.random.default_rng(4)
+    T = np.ascontiguousarray(scene.T_f_w)
+    slots = np.arange(T.shape[0], dtype=np.int32)
+    frames = capi.Frames(T.shape[0], 0, slots.ctypes.data, T.ctypes.data)
+    ptr = np.zeros(len(scene.obs) + 1, dtype=np.int32)
+    fr, ff = [], []
+    for i, o in enumerate(scene.obs):
+        ptr[i + 1] = ptr[i] + len(o)
+        for x in o:
+            fr.append(x[0])
+            ff.append(x[2] + rng.normal(size=3) * 1e-3)
+    fr, ff = np.array(fr, np.int32), np.ascontiguousarray(ff, dtype=np.float64)
+    p0 = scene.pt_pos + rng.normal(size=scene.pt_pos.shape) * 0.05
+    out = np.ascontiguousarray(p0).copy()
+    assert emu.svo_hip_point_optimize(C.byref(frames), len(scene.obs), _p(ptr), _p(fr), _p(ff), 5, _p(out), None) == 0
+    for i in range(0, len(scene.obs), 3):
+        Ti = np.array([scene.T_f_w[x[0]] for x in scene.obs[i]])
+        o = orc.point_optimize(Ti, ff[ptr[i]:ptr[i + 1]], p0[i], 5)
+        assert np.abs(o - out[i]).max() < 1e-11, i
+
+
+def test_emulated_reproject_points(emu, oracle, scene):
+    orc = pytrack.Track("orc")
+    T = np.ascontiguousarray(scene.T_f_w)
+    slots = np.arange(T.shape[0], dtype=np.int32)
+    frames = capi.Frames(T.shape[0], 0, slots.ctypes.data, T.ctypes.data)
+    P = len(scene.pt_pos)
+    cur = np.full(P, scene.cur, np.int32)
+    pos = np.ascontiguousarray(scene.pt_pos, dtype=np.float64)
+    cell, px = np.zeros(P, np.int32), np.zeros((P, 2))
+    cs = capi.camera(scene.cam)
+    assert emu.svo_hip_reproject_points(C.byref(cs), C.byref(frames), P, _p(cur), _p(pos), 30, 22, _p(cell), _p(px), None) == 0
+    for i in range(P):
+        k, p = orc.reproject_point(scene.cam, scene.T_f_w[scene.cur], scene.pt_pos[i], 30, 22)
+        assert k == cell[i] and np.abs(p - px[i]).max() < 1e-10
+    assert (cell >= 0).sum() > P // 2

@@ -23,7 +23,7 @@ def _p(a):
     return C.c_void_p(a.ctypes.data)
 
 
-def run_emulated(emu, b, max_level, min_level, n_iter=30):
+def run_emulated(emu, b, max_level, min_level, n_iter=30, entry="svo_hip_sparse_align"):
     imgs = np.ascontiguousarray(b.images)
     n, h, w = imgs.shape
     layout = capi.pyr_layout(w, h, b.n_levels)
@@ -40,7 +40,7 @@ def run_emulated(emu, b, max_level, min_level, n_iter=30):
     T_out, H = np.zeros((B, 12)), np.zeros((B, 36))
     n_tracked, iters = np.zeros(B, np.int32), np.zeros((B, capi.MAX_LEVELS), np.int32)
     chi2, status = np.zeros(B), np.zeros(B, np.int32)
-    rc = emu.svo_hip_sparse_align(C.byref(layout), _p(store), B, _p(ref_slot), _p(cur_slot), _p(nn), ns, _p(px), _p(xyz), _p(valid),
+    rc = getattr(emu, entry)(C.byref(layout), _p(store), B, _p(ref_slot), _p(cur_slot), _p(nn), ns, _p(px), _p(xyz), _p(valid),
                                   C.byref(P), _p(T_in), _p(T_out), _p(H), _p(n_tracked), _p(iters), _p(chi2), _p(status), None)
     assert rc == 0, rc
     return se3.mul(T_out, b.T_ref_w), n_tracked, iters, H, status
@@ -74,3 +74,26 @@ def test_emulated_sparse_align_edge_cases(emu, oracle):
     assert se3.log_norm(T_h, T_o).max() <= 1e-5
     assert np.array_equal(n_tracked, np.array([r["n_tracked"] for r in res_o]))
     assert n_tracked[2] == 0 and np.abs(T_h[2] - b.T_cur_w[2]).max() < 1e-12  # (the prior, up to the product T_cur_ref * T_ref)
+
+
+@pytest.mark.parametrize("n_patches", [60, 190])
+def test_emulated_wave_per_frame_kernel(emu, oracle, n_patches):
+    """sparse_align_wave.hip -- a frame per wave, one and three patches per lane, no workgroup barrier, the solve in the same
+    wave behind a transposing wave reduction -- through a test-only entry (svo_hip_sparse_align gives it batches of >= 1024
+    frames only): the oracle's poses, and the workgroup kernel's, with the bounds of tests/test_sparse_align_gpu.py."""
+    seq = synth.make_sequence(7, n_patches, seed=23)
+    b = make_batch(seq, [(i, i + 1) for i in range(6)], 4)
+    b.n[3] = n_patches - 7
+    b.has_point[5, ::3] = 0
+    T_w, ntr_w, it_w, H_w, st_w = run_emulated(emu, b, 3, 0, entry="emu_sparse_align_wave")
+    T_g, ntr_g, it_g, _, _ = run_emulated(emu, b, 3, 0)
+    T_o, res_o, _ = run_oracle(oracle, b, 3, 0)
+    assert np.all(np.isfinite(T_w))
+    d = se3.log_norm(T_w, T_o)
+    assert d.max() <= 1e-4 and np.median(d) <= 1e-5, d
+    assert se3.log_norm(T_w, T_g).max() <= 1e-4
+    it_o = np.array([r["iters"][:4] for r in res_o])
+    same = np.all(it_o == it_w[:, :4], axis=1)
+    assert (~same).sum() <= 1, (it_w[:, :4], it_o)
+    assert np.array_equal(ntr_w[same], np.array([r["n_tracked"] for r in res_o])[same])
+    assert np.array_equal(st_w, np.array([r["stop"] for r in res_o]))
