@@ -65,5 +65,7 @@ def build_hip(force: bool = False, verbose: bool = False, defines: list[str] | N
 
 
 if __name__ == "__main__":
-    # python -m rpg_svo_amd.build [--force] [-DFOO ...]: the in-tree library, or a whole-library variant
-    print(build_hip(force="--force" in sys.argv, verbose=True, defines=[a[2:] for a in sys.argv[1:] if a.startswith("-D")] or None))
+    # python -m rpg_svo_amd.build [--force] [--out=FILE] [-DFOO ...]: the in-tree library, or a whole-library variant
+    # (--out=<file>: where a variant goes instead of build/variants/libsvo_hip_<defines>.so)
+    print(build_hip(force="--force" in sys.argv, verbose=True, defines=[a[2:] for a in sys.argv[1:] if a.startswith("-D")] or None,
+                    out=next((os.path.abspath(a[6:]) for a in sys.argv[1:] if a.startswith("--out=")), None)))

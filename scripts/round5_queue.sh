@@ -1,15 +1,32 @@
 #!/bin/bash
 # The experiments queued at the end of round 4 (GPU minutes had run out): opt-in compile-time variants that were
-# cross-compiled and read in the ISA but never executed.  For each: parity tests ON THE VARIANT LIBRARY first, then the
-# A/B timing.  Build the variants on the CPU side before calling gpurun:
-#   for f in WARP_PACKED RM_PATCH_LOAD_FIRST SCAN_PREFETCH SEED_LOAD_FIRST ALIGN_G_F16 SIA_KEEP_PX POSE_LOAD_FIRST ALIGN_LOAD_FIRST PREP_LOAD_FIRST; do python -m rpg_svo_amd.build -D$f; done
-#   python -m rpg_svo_amd.build -DSCAN_PREFETCH -DSCAN_MINW=4
-#   gpurun --timeout 600 -- 'bash scripts/round5_queue.sh 2>&1 | tee gpurun_out/r05a_queue.txt'
-# A variant that fails a test is dropped; one that wins becomes the default and its flag is inverted.
+# cross-compiled, read in the ISA and -- all nine -- run on the CPU emulation against the oracle (tests/test_*_emulated.py,
+# also under AddressSanitizer / ThreadSanitizer), but never executed on a GPU.
+#   CPU side first:   bash scripts/round5_queue.sh build
+#   then              gpurun --timeout 900 -- 'bash scripts/round5_queue.sh 2>&1 | tee gpurun_out/r05a_queue.txt'
+# Stage 0 times ALL candidates together (one library, `svo_hip_queue`) against the default build: K1, the full track per
+# stage, the single-stream frame -- three minutes that say whether the set as a whole wins.  Stage 1 (skipped with
+# `bash scripts/round5_queue.sh stage0`) runs the GPU parity tests on each variant library and times it alone, so that a
+# loser inside the set can be found.  A variant that fails a test is dropped; one that wins becomes the default and its
+# flag is inverted.
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 V=build/variants
+ALL="SIA_KEEP_PX WARP_PACKED SCAN_PREFETCH SEED_LOAD_FIRST POSE_LOAD_FIRST ALIGN_LOAD_FIRST PREP_LOAD_FIRST RM_PATCH_LOAD_FIRST"
+if [ "${1:-}" == "build" ]; then
+  for f in $ALL ALIGN_G_F16; do python -m rpg_svo_amd.build -D$f > /dev/null || exit 1; done
+  python -m rpg_svo_amd.build -DSCAN_PREFETCH -DSCAN_MINW=4 > /dev/null || exit 1
+  python -m rpg_svo_amd.build --out=$V/libsvo_hip_queue.so $(for f in $ALL; do echo -n "-D$f "; done) > /dev/null || exit 1
+  ls -la $V; exit 0
+fi
+echo "== stage 0: every candidate in one library (svo_hip_queue: $ALL) against the default build"
+if [ -f $V/libsvo_hip_queue.so ]; then
+  SVO_HIP_LIB=$PWD/$V/libsvo_hip_queue.so python -m pytest tests/test_sparse_align_gpu.py tests/test_tracking_gpu.py tests/test_map_mirror_gpu.py -q -m gpu -x 2>&1 | tail -2
+  bash scripts/k1_variants.sh main svo_hip_queue main svo_hip_queue -- --steps 40 --warmup 15
+  bash scripts/full_variants.sh main svo_hip_queue main svo_hip_queue 2>&1 | cut -c1-220
+fi
+[ "${1:-}" == "stage0" ] && exit 0
 echo "== SIA_KEEP_PX: K1 keeps Feature::px in registers (one dependent memory round trip per level less; expected +2..5 % frames/s)"
 if [ -f $V/libsvo_hip_SIA_KEEP_PX.so ]; then
   SVO_HIP_LIB=$PWD/$V/libsvo_hip_SIA_KEEP_PX.so python -m pytest tests/test_sparse_align_gpu.py -q -m gpu -x 2>&1 | tail -2

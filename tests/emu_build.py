@@ -45,7 +45,12 @@ def build_race_probe():
 
 
 def build_emulated(defines=()):
+    # SVO_EMU_EXTRA_DEFINES="A B": added to every emulated build of the run (e.g. the whole round-5 queue on the default tests)
+    defines = tuple(dict.fromkeys(tuple(defines) + tuple(os.environ.get("SVO_EMU_EXTRA_DEFINES", "").split())))
     tag = "".join("_" + d.replace("=", "-") for d in defines)
+    if len(tag) > 80:
+        import hashlib
+        tag = "_set" + hashlib.sha1(tag.encode()).hexdigest()[:10]
     san = sanitizer()
     san_flags = [f"-fsanitize={san}", "-shared-libsan", "-fno-omit-frame-pointer", "-g"] if san else []
     if san:
