@@ -73,3 +73,24 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "pyoracle" not in txt and "svo_oracle" not in txt and "orc_" not in txt, f
+
+
+def test_product_has_no_cpu_path():
+    """The kernels compile for the CPU only inside the test suite (tests/emu_build.py defines SVO_HOST_MATH_TEST / SVO_HIP_EMU
+    through tests/host/hip_emu.h): nothing in the package defines those macros, loads the emulated library or mentions the
+    emulator, the build recipe passes no such define, and the in-tree library carries no emulator symbol."""
+    import subprocess
+    pkg = os.path.join(ROOT, "rpg_svo_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "#define SVO_HOST_MATH_TEST" not in txt and "#define SVO_HIP_EMU" not in txt, f
+                assert "libsvo_hip_emulated" not in txt and "emu_build" not in txt and '"hip_emu.h"' not in txt, f
+    for f in ("bench.py", "__graft_entry__.py"):
+        txt = open(os.path.join(ROOT, f)).read()
+        assert "libsvo_hip_emulated" not in txt and "emu_build" not in txt and "SVO_HOST_MATH_TEST" not in txt, f
+    lib = os.path.join(pkg, "lib", "libsvo_hip.so")
+    if os.path.exists(lib):
+        syms = subprocess.run(["nm", "-D", "-C", lib], capture_output=True, text=True).stdout
+        assert "svo_emu" not in syms
