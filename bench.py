@@ -49,6 +49,18 @@ from rpg_svo_amd.sparse_img_align import SparseImgAlign, marshal_problem  # noqa
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 N_CU = 256
 PMC_PASS_TIMEOUT_S = 90  # per rocprofv3 --pmc child run of the pmc leg
+T_PROCESS_START = time.time()
+# --time-budget: seconds (since this process started) after which no further OPTIONAL work is begun: extra legs, the counter
+# passes beyond the three the headline line needs (FETCH_SIZE, WRITE_SIZE, the SQ group), the full-track counter leg.  The
+# headline measurement, its roofline / traffic and the CPU baseline are never skipped; whatever is skipped says so.
+FULL_TRACK_PMC_RESERVE_S = 130.0
+PMC_PASS_RESERVE_S = 25.0
+
+
+def time_left(budget_s: float, now: float | None = None) -> float:
+    if not budget_s or budget_s <= 0:
+        return float("inf")
+    return budget_s - ((time.time() if now is None else now) - T_PROCESS_START)
 N_SIMD = 1024          # 256 CUs x 4 SIMD-32
 CLOCK_GHZ = 2.4
 
@@ -395,6 +407,9 @@ def main() -> None:
     ap.add_argument("--full-line", action="store_true",
                     help="print the FULL result object as the last stdout line (scripts/); default: the compact summary "
                          f"(< {COMPACT_LIMIT} B) with the full object in {DETAILS_FILE}")
+    ap.add_argument("--time-budget", type=float, default=300.0,
+                    help="seconds since process start after which no further optional leg or counter pass is begun (0: no limit); "
+                         "the default run takes about four minutes on an MI355X box and stays below this")
     ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)
     ap.add_argument("--dump-result", default="", help=argparse.SUPPRESS)  # child of the f64_partials leg: poses + iteration counts
     args = ap.parse_args()
@@ -634,6 +649,9 @@ def _extras_and_print(args, result, extras, full, ev, W, sia, out, st, store, li
     def leg(name, fn):
         if name not in extras:
             return
+        if time_left(args.time_budget) < 10.0:
+            result[EXTRA_KEYS[name]] = {"skipped": f"time budget ({args.time_budget:.0f} s since process start) used up"}
+            return
         t = time.time()
         try:
             r = fn()
@@ -660,8 +678,9 @@ def _extras_and_print(args, result, extras, full, ev, W, sia, out, st, store, li
     leg("stream", lambda: stream_replay_leg(W, sia, ev, dev))
     if "pmc" in extras:
         t = time.time()
+        want_full = "full" in extras and isinstance(result.get("full_track"), dict) and "rooflines" in result["full_track"]
         try:
-            pm = pmc_leg(args, kernel_ms)
+            pm = pmc_leg(args, kernel_ms, reserve_s=FULL_TRACK_PMC_RESERVE_S if want_full else 0.0)
         except Exception as e:
             pm = {"skipped": repr(e)}
         pm["leg_seconds"] = time.time() - t
@@ -676,9 +695,12 @@ def _extras_and_print(args, result, extras, full, ev, W, sia, out, st, store, li
                 result["roofline"]["cache_line_floor_bytes_per_launch"] = repr(e)
         if "roofline_valu" in pm:
             result["roofline_valu"] = pm.pop("roofline_valu")
-        if "full" in extras and isinstance(result.get("full_track"), dict) and "rooflines" in result["full_track"]:
+        if want_full:
             try:
-                pf = pmc_full_track_leg(args)
+                if time_left(args.time_budget) < FULL_TRACK_PMC_RESERVE_S - 30.0:
+                    pf = {"skipped": f"time budget ({args.time_budget:.0f} s since process start)"}
+                else:
+                    pf = pmc_full_track_leg(args)
             except Exception as e:
                 pf = {"skipped": repr(e)}
             pm["full_track"] = pf
@@ -1069,7 +1091,7 @@ def lds_port_use(raw: dict) -> dict:
             "sdk_formula_idx_active_over_gui_active_x_cus": ratio(idx, gui * N_CU if gui else None)}
 
 
-def pmc_leg(args, kernel_ms: float) -> dict:
+def pmc_leg(args, kernel_ms: float, reserve_s: float = 0.0) -> dict:
     """HBM traffic and VALU issue of the headline kernel, measured on THIS box by re-running this
     command (headline leg only, 3 steps) under rocprofv3 --pmc, one counter group per pass as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit one
@@ -1103,6 +1125,10 @@ def pmc_leg(args, kernel_ms: float) -> dict:
     for name, ctrs in passes.items():
         if broken:
             status[name] = "skipped (an earlier pass failed)"
+            continue
+        # (the instruction-mix and LDS passes give way to what is still to come: --time-budget)
+        if name not in ("fetch", "write", "sq") and time_left(getattr(args, "time_budget", 0.0)) < PMC_PASS_RESERVE_S + reserve_s:
+            status[name] = "skipped (time budget)"
             continue
         d = tempfile.mkdtemp(prefix=f"svo_pmc_{name}_", dir="/tmp")
         cmd = [exe, "--pmc", *ctrs, "--kernel-include-regex", "sia_(wave_)?kernel", "--output-format", "csv", "-d", d, "-o", name, "--", *base]

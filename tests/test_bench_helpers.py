@@ -109,3 +109,16 @@ def test_lds_port_use_ratios_and_missing_counters():
     empty = bench.lds_port_use({})
     assert set(empty) == set(r) and all(v is None for v in empty.values())
     __import__("json").dumps(r)
+
+
+def test_time_budget_arithmetic():
+    """--time-budget: seconds since process start; 0 = no limit"""
+    import bench
+    t0 = bench.T_PROCESS_START
+    assert bench.time_left(0.0) == float("inf") and bench.time_left(-1.0) == float("inf")
+    assert abs(bench.time_left(300.0, now=t0 + 100.0) - 200.0) < 1e-9
+    assert bench.time_left(300.0, now=t0 + 400.0) < 0
+    # the optional passes stand back for the full-track counter leg: with 100 s left none of them starts, the three the
+    # headline needs still do (pmc_leg's condition)
+    left = bench.time_left(300.0, now=t0 + 200.0)
+    assert left < bench.PMC_PASS_RESERVE_S + bench.FULL_TRACK_PMC_RESERVE_S and left > bench.PMC_PASS_RESERVE_S
