@@ -398,7 +398,11 @@ __global__ void SEED_FINISH_BOUNDS seed_finish_kernel(const SeedArgs a) {
   // law of chord (depth_filter.cpp:252-255): atan(px_noise / (2 * focal_length)) * 2 depends on the camera alone -- computed
   // once on the host (run_seed_chain), by the libm the reference itself runs on
   const Se3 T_ref_cur = se3_compose(Tr, se3_inverse(Tc));
+#ifdef TAU_ALGEBRAIC
+  const double tau = compute_tau(T_ref_cur, f, z, a.tau_k);
+#else
   const double tau = compute_tau(T_ref_cur, f, z, a.px_error_angle);
+#endif
   const double zmt = (0.0000001 < z - tau) ? z - tau : 0.0000001;
   const double tau_inverse = 0.5 * (1.0 / zmt - 1.0 / (z + tau));
   update_seed((float)(1. / z), (float)(tau_inverse * tau_inverse), sa, sb, smu, zr, ssig);
@@ -449,6 +453,9 @@ struct TauArgs {
   const double* f;
   const double* z;
   double px_error_angle;
+#ifdef TAU_ALGEBRAIC
+  TauConsts tau_k;
+#endif
   double* tau;
 };
 __global__ void __launch_bounds__(256) compute_tau_kernel(const TauArgs a) {
@@ -458,7 +465,11 @@ __global__ void __launch_bounds__(256) compute_tau_kernel(const TauArgs a) {
   T.q[0] = 1.0; T.q[1] = T.q[2] = T.q[3] = 0.0;  // only the translation enters computeTau
   for (int k = 0; k < 3; ++k) T.t[k] = a.t_ref_cur[3 * s + k];
   const double f[3] = {a.f[3 * s], a.f[3 * s + 1], a.f[3 * s + 2]};
+#ifdef TAU_ALGEBRAIC
+  a.tau[s] = compute_tau(T, f, a.z[s], a.tau_k);
+#else
   a.tau[s] = compute_tau(T, f, a.z[s], a.px_error_angle);
+#endif
 }
 
 }  // namespace
@@ -470,6 +481,9 @@ extern "C" int svo_hip_compute_tau_batch(int S, const double* d_t_ref_cur, const
   if (!d_t_ref_cur || !d_f || !d_z || !d_tau) return SVO_HIP_EINVAL;
   TauArgs a;
   a.S = S; a.t_ref_cur = d_t_ref_cur; a.f = d_f; a.z = d_z; a.px_error_angle = px_error_angle; a.tau = d_tau;
+#ifdef TAU_ALGEBRAIC
+  a.tau_k = tau_consts(px_error_angle);
+#endif
   hipLaunchKernelGGL(compute_tau_kernel, dim3((S + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return check_launch();
 }
@@ -565,6 +579,9 @@ static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_sto
   {
     const double focal_length = fabs(a.cam.fx), px_noise = 1.0;
     a.px_error_angle = atan(px_noise / (2.0 * focal_length)) * 2.0;
+#ifdef TAU_ALGEBRAIC
+    a.tau_k = tau_consts(a.px_error_angle);
+#endif
   }
   SeedWs& w = a.ws;
   w.n_steps = c.take<int32_t>(n);  // first array of the workspace: svo_hip_update_seeds_scan_steps

@@ -68,6 +68,9 @@ struct SeedArgs {
   int32_t* ok_out;
   int32_t* search_level_out;
   double px_error_angle;  // atan(1 / (2 |fx|)) * 2
+#ifdef TAU_ALGEBRAIC
+  TauConsts tau_k;         // its sines and cosines (seed_math.h)
+#endif
   SeedWs ws;
 };
 

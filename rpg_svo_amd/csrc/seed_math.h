@@ -92,4 +92,37 @@ __device__ __forceinline__ double compute_tau(const Se3& T_ref_cur, const double
   return (z_plus - z);
 }
 
+#ifdef TAU_ALGEBRAIC
+// (round-5 queue, UNMEASURED: computeTau without its two acos and two sin.  With c_a = cos(alpha), c_b = cos(beta) -- the
+// two normalised dot products the reference hands to acos -- and s = sqrt(1 - c^2) (both angles lie in [0, pi]),
+//   sin(beta_plus)  = s_b cos(e) + c_b sin(e)
+//   sin(gamma_plus) = sin(SVO_PI - alpha - beta - e) = sin(alpha + beta + e'),  e' = e + (pi - SVO_PI)
+//                   = (s_a c_b + c_a s_b) cos(e') + (c_a c_b - s_a s_b) sin(e')
+// where e = px_error_angle is the same for every seed of a launch: its sines and cosines come with the arguments.  The
+// same function of the same inputs, evaluated differently: tau agrees with the acos / sin form to ~1e-13 relative (the
+// subtraction z_plus - z amplifies either form's rounding alike), which moves a seed's f32 state in about one update in a
+// million.  seed_finish is f64-transcendental-bound (65 % VALU busy): its instruction count drops by about a third.)
+struct TauConsts {
+  double se, ce, sed, ced;
+};
+inline TauConsts tau_consts(double px_error_angle) {
+  const double delta = 3.14159265358979323846 - SVO_PI;
+  return TauConsts{sin(px_error_angle), cos(px_error_angle), sin(px_error_angle + delta), cos(px_error_angle + delta)};
+}
+__device__ __forceinline__ double compute_tau(const Se3& T_ref_cur, const double f[3], const double z, const TauConsts& k) {
+  const double t[3] = {T_ref_cur.t[0], T_ref_cur.t[1], T_ref_cur.t[2]};
+  const double av[3] = {f[0] * z - t[0], f[1] * z - t[1], f[2] * z - t[2]};
+  const double t_norm = norm3(t);
+  const double a_norm = norm3(av);
+  const double ca = dot3(f, t) / t_norm;
+  const double mt[3] = {-t[0], -t[1], -t[2]};
+  const double cb = dot3(av, mt) / (t_norm * a_norm);
+  const double sa = sqrt(1.0 - ca * ca), sb = sqrt(1.0 - cb * cb);  // (NaN where acos would have been)
+  const double sin_beta_plus = sb * k.ce + cb * k.se;
+  const double sin_gamma_plus = (sa * cb + ca * sb) * k.ced + (ca * cb - sa * sb) * k.sed;
+  const double z_plus = t_norm * sin_beta_plus / sin_gamma_plus;
+  return (z_plus - z);
+}
+#endif
+
 }  // namespace svo_track

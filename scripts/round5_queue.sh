@@ -15,7 +15,7 @@ cd "$R"
 V=build/variants
 ALL="SIA_KEEP_PX WARP_PACKED SCAN_PREFETCH SEED_LOAD_FIRST POSE_LOAD_FIRST ALIGN_LOAD_FIRST PREP_LOAD_FIRST RM_PATCH_LOAD_FIRST"
 if [ "${1:-}" == "build" ]; then
-  for f in $ALL ALIGN_G_F16; do python -m rpg_svo_amd.build -D$f > /dev/null || exit 1; done
+  for f in $ALL ALIGN_G_F16 TAU_ALGEBRAIC; do python -m rpg_svo_amd.build -D$f > /dev/null || exit 1; done
   python -m rpg_svo_amd.build -DSCAN_PREFETCH -DSCAN_MINW=4 > /dev/null || exit 1
   python -m rpg_svo_amd.build --out=$V/libsvo_hip_queue.so $(for f in $ALL; do echo -n "-D$f "; done) > /dev/null || exit 1
   ls -la $V; exit 0
@@ -70,6 +70,12 @@ echo "== ALIGN_G_F16: align2D's 64 gradient pairs as f16 (exact), three waves pe
 if [ -f $V/libsvo_hip_ALIGN_G_F16.so ]; then
   SVO_HIP_LIB=$PWD/$V/libsvo_hip_ALIGN_G_F16.so python -m pytest tests/test_tracking_gpu.py tests/test_full_size_gpu.py -q -m gpu -x 2>&1 | tail -2
   bash scripts/full_variants.sh main svo_hip_ALIGN_G_F16 main svo_hip_ALIGN_G_F16 2>&1 | cut -c1-220
+fi
+echo "== TAU_ALGEBRAIC: computeTau from the two cosines and angle-sum formulas instead of 2 acos + 2 sin (seed_finish: 2772 -> 2299"
+echo "   instructions in the ISA, f64 1701 -> 1418; tau agrees to 7e-13 relative: NOT in the combined set, the numbers move in the last bits)"
+if [ -f $V/libsvo_hip_TAU_ALGEBRAIC.so ]; then
+  SVO_HIP_LIB=$PWD/$V/libsvo_hip_TAU_ALGEBRAIC.so python -m pytest tests/test_tracking_gpu.py tests/test_full_size_gpu.py -q -m gpu -x 2>&1 | tail -2
+  bash scripts/full_variants.sh main svo_hip_TAU_ALGEBRAIC main svo_hip_TAU_ALGEBRAIC 2>&1 | cut -c1-220
 fi
 echo "== RM_PATCH_LOAD_FIRST: the map patch applied with all loads before the first store (expected: -3..6 us per frame)"
 if [ -f $V/libsvo_hip_RM_PATCH_LOAD_FIRST.so ]; then

@@ -99,6 +99,13 @@ double hm_compute_tau(const double T_ref_cur[12], const double f[3], double z, d
   se3_from_Rt(T_ref_cur, T);
   return svo_track::compute_tau(T, f, z, px_error_angle);
 }
+#ifdef TAU_ALGEBRAIC
+double hm_compute_tau_algebraic(const double T_ref_cur[12], const double f[3], double z, double px_error_angle) {
+  Se3 T;
+  se3_from_Rt(T_ref_cur, T);
+  return svo_track::compute_tau(T, f, z, svo_track::tau_consts(px_error_angle));
+}
+#endif
 float hm_normal_pdf(float x, float mean, float sd) { return svo_track::normal_pdff(x, mean, sd); }
 
 // ---- K3's lane bodies (align_lanes.h) on a level of the TILED store (pyr_addr.h) ---------------------------------------

@@ -91,7 +91,7 @@ def test_emulated_find_match_direct(emu, oracle, scene):
 
 
 # ---- row a12: svo_hip_update_seeds (seed_prepare -> warp -> epipolar scan -> alignment -> seed_finish) -----------------
-SEED_VARIANTS = [(), ("SEED_LOAD_FIRST", "SCAN_PREFETCH", "WARP_PACKED", "ALIGN_LOAD_FIRST", "ALIGN_G_F16")]
+SEED_VARIANTS = [(), ("SEED_LOAD_FIRST", "SCAN_PREFETCH", "WARP_PACKED", "ALIGN_LOAD_FIRST", "ALIGN_G_F16", "TAU_ALGEBRAIC")]
 
 
 @pytest.fixture(scope="module", params=SEED_VARIANTS, ids=["default", "queued-variants"])
