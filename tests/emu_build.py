@@ -13,6 +13,14 @@ UNITS = ("common", "pyramid", "map_mirror", "matcher", "feature_align", "depth_f
          "pose_optimizer_wave", "pose_optimizer", "point_optimizer", "fast_detect")
 
 
+# the opt-in builds queued for timing on a GPU (scripts/round5_queue.sh), all in ONE emulated library: every emulated parity
+# test runs on the default build and on this one
+QUEUED = ("SIA_KEEP_PX", "WARP_PACKED", "SCAN_PREFETCH", "SEED_LOAD_FIRST", "POSE_LOAD_FIRST", "ALIGN_LOAD_FIRST", "PREP_LOAD_FIRST",
+          "RM_PATCH_LOAD_FIRST", "ALIGN_G_F16", "TAU_ALGEBRAIC")
+BUILDS = [(), QUEUED]
+BUILD_IDS = ["default", "queued-variants"]
+
+
 def sanitizer():
     """SVO_EMU_SANITIZE=address|thread: the emulated library instrumented by that sanitizer (the process must have the
     runtime preloaded: scripts/emu_sanitize.sh)."""

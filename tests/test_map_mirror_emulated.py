@@ -1,7 +1,7 @@
 """Row N2 without a GPU: rpg_svo_amd/csrc/map_mirror.hip compiled for the host through tests/host/hip_emu.h -- the C-ABI
 entry point svo_hip_reproject_map itself, its one-workgroup kernel run by 1024 host threads (barriers, LDS, the scan's
 __shfl_up, LDS atomics emulated) -- against the oracle's restatement of Reprojector::reprojectMap on random maps, exactly
-as tests/test_map_mirror_gpu.py does on the device.  Also the queued -DRM_PATCH_LOAD_FIRST build."""
+as tests/test_map_mirror_gpu.py does on the device.  Also the library with every queued opt-in build on (emu_build.QUEUED: here -DRM_PATCH_LOAD_FIRST)."""
 import ctypes as C
 import os
 import subprocess
@@ -15,10 +15,11 @@ from rpg_svo_amd import capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module", params=[(), ("RM_PATCH_LOAD_FIRST",)], ids=["default", "RM_PATCH_LOAD_FIRST"])
+@pytest.fixture(scope="module", params=[0, 1], ids=["default", "queued-variants"])
 def emu(request):
     from emu_build import build_emulated
-    return build_emulated(request.param)
+    from emu_build import BUILDS
+    return build_emulated(BUILDS[request.param])
 
 
 def _ptr(a):

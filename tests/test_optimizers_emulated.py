@@ -2,7 +2,7 @@
 deferred entry), svo_hip_pose_optimize_ordered and svo_hip_point_optimize of the host-emulated library (tests/emu_build.py:
 pose_optimizer_wave.hip, pose_optimizer.hip, point_optimizer.hip compiled for the CPU through tests/host/hip_emu.h) against
 the oracle's pose_optimizer::optimizeGaussNewton and Point::optimize, with the requirements of tests/test_tracking_gpu.py.
-Also the queued -DPOSE_LOAD_FIRST build of the wave kernel."""
+Also the library with every queued opt-in build switched on (emu_build.QUEUED: here -DPOSE_LOAD_FIRST matters)."""
 import ctypes as C
 
 import numpy as np
@@ -13,10 +13,11 @@ from oracle import pytrack
 from rpg_svo_amd import capi, se3, synth
 
 
-@pytest.fixture(scope="module", params=[(), ("POSE_LOAD_FIRST",)], ids=["default", "POSE_LOAD_FIRST"])
+@pytest.fixture(scope="module", params=[0, 1], ids=["default", "queued-variants"])
 def emu(request):
     from emu_build import build_emulated
-    return build_emulated(request.param)
+    from emu_build import BUILDS
+    return build_emulated(BUILDS[request.param])
 
 
 @pytest.fixture(scope="module", params=["pinhole", "atan"])

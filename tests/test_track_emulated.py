@@ -12,13 +12,13 @@ from helpers import camera_models
 from oracle import pytrack
 from rpg_svo_amd import capi, synth
 
-VARIANTS = [(), ("PREP_LOAD_FIRST", "WARP_PACKED", "ALIGN_LOAD_FIRST", "ALIGN_G_F16")]
 
 
-@pytest.fixture(scope="module", params=VARIANTS, ids=["default", "queued-variants"])
+@pytest.fixture(scope="module", params=[0, 1], ids=["default", "queued-variants"])
 def emu(request):
     from emu_build import build_emulated
-    return build_emulated(request.param)
+    from emu_build import BUILDS
+    return build_emulated(BUILDS[request.param])
 
 
 @pytest.fixture(scope="module", params=["pinhole", "atan"])
@@ -91,13 +91,13 @@ def test_emulated_find_match_direct(emu, oracle, scene):
 
 
 # ---- row a12: svo_hip_update_seeds (seed_prepare -> warp -> epipolar scan -> alignment -> seed_finish) -----------------
-SEED_VARIANTS = [(), ("SEED_LOAD_FIRST", "SCAN_PREFETCH", "WARP_PACKED", "ALIGN_LOAD_FIRST", "ALIGN_G_F16", "TAU_ALGEBRAIC")]
 
 
-@pytest.fixture(scope="module", params=SEED_VARIANTS, ids=["default", "queued-variants"])
+@pytest.fixture(scope="module", params=[0, 1], ids=["default", "queued-variants"])
 def emu_seeds(request):
     from emu_build import build_emulated
-    return build_emulated(request.param)
+    from emu_build import BUILDS
+    return build_emulated(BUILDS[request.param])
 
 
 def _make_seeds(scene, orc, rng):  # (tests/test_tracking_gpu.py)
