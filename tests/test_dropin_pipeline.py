@@ -304,9 +304,23 @@ def test_mock_device_map_mirror_is_the_list_walk(mock_lib, tmp_path):
     incremental protocol missed (positions moved by Point::optimize, types changed and points deleted by the cell loop,
     candidates appended by the depth filter's callback, candidates deleted for failing to reproject).  The mode is
     read once per process."""
+    from concurrent.futures import ThreadPoolExecutor
     n = 220
-    off, s_off = _run_mirror("hipmock", n, {"SVO_HIP_MAP_MIRROR": "off"}, tmp_path, "off", max_n_kfs=4)
-    ver, s_ver = _run_mirror("hipmock", n, {"SVO_HIP_MAP_MIRROR": "verify"}, tmp_path, "verify", max_n_kfs=4)
+    V = {"SVO_HIP_MAP_MIRROR": "verify"}
+    runs = {  # independent child processes: started together
+        "off": ("hipmock", n, {"SVO_HIP_MAP_MIRROR": "off"}, dict(max_n_kfs=4)),
+        "verify": ("hipmock", n, V, dict(max_n_kfs=4)),
+        "sb": ("hipmock", 60, dict(V, SVO_HIP_FIRST_BATCH_CELLS="40"), {}),
+        "off60": ("hipmock", 60, {"SVO_HIP_MAP_MIRROR": "off"}, {}),
+        "thr": ("hipmock", 100, V, dict(mapper_thread=1)),
+        "cap": ("hipmock", 60, dict(V, SVO_HIP_MIRROR_TRIALS="64"), {}),
+        "small": ("hipmock", 130, V, dict(pool_slots=7)),
+        "off130": ("hipmock", 130, {"SVO_HIP_MAP_MIRROR": "off"}, dict(pool_slots=7)),
+    }
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        fut = {tag: ex.submit(_run_mirror, fl, k, env, tmp_path, tag, **cfg) for tag, (fl, k, env, cfg) in runs.items()}
+        res = {tag: f.result() for tag, f in fut.items()}
+    (off, s_off), (ver, s_ver) = res["off"], res["verify"]
     assert np.array_equal(ver, off)
     assert s_ver["counts"] == s_off["counts"]
     assert s_off["calls"] == 0
@@ -317,21 +331,19 @@ def test_mock_device_map_mirror_is_the_list_walk(mock_lib, tmp_path):
     per_frame = (s_ver["point_records_sent"] - s_ver["rebuilds"] * 600) / n
     assert per_frame < 60, s_ver
     # the second batch (the first one too small to reach the visiting loop's stop) continues on the mirror
-    sb, s_sb = _run_mirror("hipmock", 60, {"SVO_HIP_MAP_MIRROR": "verify", "SVO_HIP_FIRST_BATCH_CELLS": "40"}, tmp_path, "sb")
-    ref60, _ = _run_mirror("hipmock", 60, {"SVO_HIP_MAP_MIRROR": "off"}, tmp_path, "off60")
+    (sb, s_sb), (ref60, _) = res["sb"], res["off60"]
     assert np.array_equal(sb, ref60) and s_sb["second_batches"] >= 50 and s_sb["fallbacks"] == 0
     # the depth filter on its own thread appends candidates while the tracker runs (timing dependent: no frame-by-frame
     # comparison, but verify must hold -- it tolerates only candidates that arrived after the call's tail read)
-    _, s_thr = _run_mirror("hipmock", 100, {"SVO_HIP_MAP_MIRROR": "verify"}, tmp_path, "thr", mapper_thread=1)
+    _, s_thr = res["thr"]
     assert s_thr["calls"] == 99 and s_thr["fallbacks"] == 0
     # a batch with more trials than the call has room for (capacity forced down to 64): the kernel reports it, what was
     # enqueued behind it is dropped and the frame takes the list-walking path -- every frame here
-    cap, s_cap = _run_mirror("hipmock", 60, {"SVO_HIP_MAP_MIRROR": "verify", "SVO_HIP_MIRROR_TRIALS": "64"}, tmp_path, "cap")
+    cap, s_cap = res["cap"]
     assert np.array_equal(cap, ref60) and s_cap["fallbacks"] >= 55 and s_cap["hits"] == 59
     # a pool that cannot hold every keyframe at once: the frame takes the list-walking path (which pins only the
     # keyframes that serve as reference), same result
-    small, s_small = _run_mirror("hipmock", 130, {"SVO_HIP_MAP_MIRROR": "verify"}, tmp_path, "small", pool_slots=7)
-    ref130, _ = _run_mirror("hipmock", 130, {"SVO_HIP_MAP_MIRROR": "off"}, tmp_path, "off130", pool_slots=7)
+    (small, s_small), (ref130, _) = res["small"], res["off130"]
     assert np.array_equal(small, ref130) and 0 < s_small["fallbacks"] < 129   # (mirrored while the keyframes still fit)
 
 
