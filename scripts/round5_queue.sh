@@ -26,6 +26,8 @@ if [ -f $V/libsvo_hip_queue.so ]; then
   bash scripts/k1_variants.sh main svo_hip_queue main svo_hip_queue -- --steps 40 --warmup 15
   bash scripts/full_variants.sh main svo_hip_queue main svo_hip_queue 2>&1 | cut -c1-220
 fi
+echo "== the two K1 kernels at 128 / 192 / 200 patches (auto = wave-per-frame up to 192: its three-patches-per-lane form spills 305 dwords today)"
+bash scripts/k1_patches.sh 2>&1 | cut -c1-160
 [ "${1:-}" == "stage0" ] && exit 0
 echo "== SIA_KEEP_PX: K1 keeps Feature::px in registers (one dependent memory round trip per level less; expected +2..5 % frames/s)"
 if [ -f $V/libsvo_hip_SIA_KEEP_PX.so ]; then
