@@ -98,3 +98,62 @@ def test_emulated_wave_per_frame_kernel(emu, oracle, n_patches):
     assert (~same).sum() <= 1, (it_w[:, :4], it_o)
     assert np.array_equal(ntr_w[same], np.array([r["n_tracked"] for r in res_o])[same])
     assert np.array_equal(st_w, np.array([r["stop"] for r in res_o]))
+
+
+@pytest.mark.parametrize("kind", ["radtan", "atan"])
+def test_emulated_distorted_camera_models(emu, oracle, kind):
+    """the DIST instantiation of sia_kernel (the camera model's world2cam in the loop, no window cache) -- and, for 60 patches
+    per frame, of the wave-per-frame kernel: the oracle's poses through the vikit models' projection"""
+    from helpers import camera_models
+    cam = camera_models()[kind]
+    seq = synth.make_sequence(4, 60, cam=cam, seed=9, margin=56, cell=40)
+    b = make_batch(seq, [(i, i + 1) for i in range(3)], 5)
+    T_o, res_o, _ = run_oracle(oracle, b, 4, 2)
+    T_h, ntr, _, _, _ = run_emulated(emu, b, 4, 2)
+    assert se3.log_norm(T_h, T_o).max() <= 1e-4 and np.median(se3.log_norm(T_h, T_o)) <= 1e-5
+    assert np.array_equal(ntr, np.array([r["n_tracked"] for r in res_o]))
+    T_w, ntr_w, _, _, _ = run_emulated(emu, b, 4, 2, entry="emu_sparse_align_wave")
+    assert se3.log_norm(T_w, T_o).max() <= 1e-4 and se3.log_norm(T_w, T_h).max() <= 1e-4
+    assert se3.log_norm(T_h, b.T_gt_w).max() < 5e-3   # both solved the problem (60 patches, levels 4 -> 2)
+
+
+def test_emulated_border_features_outside_patches_and_iteration_caps(emu, oracle):
+    """features in the 3..30 px band next to a border (invisible at coarse levels, joining at finer ones: the H rebuild when
+    the set of patches inside the image changes); a prior so wrong that nothing projects into the image (H = 0, x = 0, the
+    pose kept); n_iter = 0, 1, 2"""
+    import torch
+    seq = synth.make_sequence(4, 200, seed=3)
+    rng = np.random.default_rng(3)
+    for i in range(4):
+        k = rng.choice(200, 40, replace=False)
+        side = rng.integers(0, 4, size=40)
+        off = rng.uniform(3.0, 30.0, size=40)
+        u, v = seq.px[i, k, 0].numpy().copy(), seq.px[i, k, 1].numpy().copy()
+        u[side == 0] = off[side == 0]
+        u[side == 1] = 639.0 - off[side == 1]
+        v[side == 2] = off[side == 2]
+        v[side == 3] = 479.0 - off[side == 3]
+        seq.px[i, k, 0] = torch.from_numpy(u)
+        seq.px[i, k, 1] = torch.from_numpy(v)
+    seq.f, seq.pos = synth.features_3d(seq.T_f_w, seq.cam, seq.px)
+    b = make_batch(seq, [(0, 1), (1, 2), (2, 3)], 4)
+    for lo in (0, 2):   # the full schedule (every feature joins eventually) and a stop at level 2 (some never do)
+        T_o, res_o, _ = run_oracle(oracle, b, 3, lo)
+        T_h, ntr, _, _, _ = run_emulated(emu, b, 3, lo)
+        assert se3.log_norm(T_h, T_o).max() <= 1e-4
+        assert np.array_equal(ntr, np.array([r["n_tracked"] for r in res_o]))
+    assert np.all(ntr < 200) and np.all(ntr > 100), ntr
+    # nothing inside the image
+    b2 = make_batch(seq, [(0, 1), (2, 3)], 4)
+    b2.T_cur_w = se3.mul(se3.exp(np.array([[50.0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0.0, 0]])), b2.T_cur_w)
+    T_o, res_o, _ = run_oracle(oracle, b2, 3, 0)
+    T_h, ntr, _, _, _ = run_emulated(emu, b2, 3, 0)
+    assert res_o[0]["n_tracked"] == 0 and ntr[0] == 0
+    assert se3.log_norm(T_h[:1], T_o[:1]).max() < 1e-12 and se3.log_norm(T_h[1:], T_o[1:]).max() <= 1e-4
+    # iteration caps
+    for n_iter in (0, 1, 2):
+        b3 = make_batch(seq, [(0, 1)], 4)
+        T_o, res_o, _ = run_oracle(oracle, b3, 3, 0, n_iter=n_iter)
+        T_h, ntr, iters, _, _ = run_emulated(emu, b3, 3, 0, n_iter=n_iter)
+        assert se3.log_norm(T_h, T_o).max() <= 1e-4
+        assert np.array_equal(iters[:, :4], np.array([r["iters"][:4] for r in res_o]))
