@@ -201,7 +201,10 @@ namespace svo_track {
 // trial (six floats, exactly the loop's locals) and appends its index to one of ALIGN_NQ queues; the next launch
 // runs dense waves over the queues.  A resumed trial rebuilds H^-1 from its template (same instructions, same
 // bits) and continues where it stopped: results are identical to the single launch.
-constexpr int ALIGN_PHASE_MIN_M = 1 << 16;  // below this the extra launches cost more than the idle lanes
+#ifndef ALIGN_PHASE_MIN_M_VALUE  // (the CPU emulation of the test suite lowers it to reach the phased path with small batches)
+#define ALIGN_PHASE_MIN_M_VALUE (1 << 16)
+#endif
+constexpr int ALIGN_PHASE_MIN_M = ALIGN_PHASE_MIN_M_VALUE;  // below this the extra launches cost more than the idle lanes
 #ifndef ALIGN_PHASE_ITERS
 #define ALIGN_PHASE_ITERS 3
 #endif

@@ -1,0 +1,235 @@
+"""The remaining C-ABI entry points of the tracking kernels without a GPU (host-emulated library, tests/emu_build.py), each with
+the requirements of its GPU test in tests/test_tracking_gpu.py: svo_hip_align_batch / _counted / _phased (the phased form --
+three launches, survivors compacted through atomically filled queues, parked loop state -- starts at 2048 trials in the
+emulated build), svo_hip_find_epipolar_match_direct, svo_hip_update_seed_batch, svo_hip_compute_tau_batch,
+svo_hip_select_matches, svo_hip_compose_poses, svo_hip_cam2world."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import camera_models
+from oracle import pytrack
+from rpg_svo_amd import capi, se3, synth
+
+
+@pytest.fixture(scope="module", params=[0, 1], ids=["default", "queued-variants"])
+def emu(request):
+    from emu_build import BUILDS, build_emulated
+    return build_emulated(BUILDS[request.param])
+
+
+@pytest.fixture(scope="module")
+def scene():
+    return synth.make_track_scene(n_kf=4, n_feat=100, cam=camera_models()["pinhole"])
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def _store(emu, images, n_levels=5):
+    imgs = np.ascontiguousarray(images)
+    n, h, w = imgs.shape
+    layout = capi.pyr_layout(w, h, n_levels)
+    buf = np.zeros(capi.pyr_store_bytes(layout, n), np.uint8)
+    assert emu.svo_hip_pyramid_build_tiled(C.byref(layout), _p(buf), 0, n, _p(imgs), C.c_longlong(h * w), w, capi.HALFSAMPLE_AUTO, 0, None) == 0
+    return layout, buf
+
+
+def test_emulated_align_batch_and_its_phased_form(emu, oracle, scene):
+    orc = pytrack.Track("orc")
+    imgs = scene.images.cpu().numpy()
+    pyrs = [orc.create_img_pyramid(im, 5) for im in imgs]
+    layout, store = _store(emu, imgs)
+    rng = np.random.default_rng(3)
+    M = 4096
+    slot = rng.integers(0, imgs.shape[0], size=M).astype(np.int32)
+    level = rng.integers(0, 3, size=M).astype(np.int32)
+    pwb, px0 = np.zeros((M, 100), np.uint8), np.zeros((M, 2))
+    dirs = rng.normal(size=(M, 2)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    use_1d = (rng.uniform(size=M) < 0.3).astype(np.uint8)
+    for t in range(M):
+        img = pyrs[slot[t]][level[t]]
+        h, w = img.shape
+        u, v = rng.integers(8, w - 8), rng.integers(8, h - 8)
+        src = pyrs[(slot[t] + (t % 2)) % imgs.shape[0]][level[t]]
+        pwb[t] = src[v - 5:v + 5, u - 5:u + 5].ravel()
+        px0[t] = [u + rng.uniform(-4.0, 4.0), v + rng.uniform(-4.0, 4.0)]
+        if t % 37 == 0:
+            px0[t] = [3.0 + rng.uniform(0, 2), v]                       # leaves the image
+        if t % 41 == 0:
+            pwb[t] = 77                                                 # singular H -> NaN
+    n_iter = 10
+
+    def run(entry, extra):
+        px, ok, h_inv = px0.copy(), np.zeros(M, np.int32), np.zeros(M)
+        rc = getattr(emu, entry)(C.byref(layout), _p(store), M, _p(slot), _p(level), _p(pwb), _p(dirs), _p(use_1d), n_iter, _p(px), _p(ok),
+                                 _p(h_inv), *extra, None)
+        assert rc == 0, (entry, rc)
+        return px, ok, h_inv
+
+    px_a, ok_a, h_a = run("svo_hip_align_batch", ())
+    ev_c = np.zeros(M, np.int32)
+    px_c, ok_c, h_c = run("svo_hip_align_batch_counted", (_p(ev_c),))
+    emu.svo_hip_align_workspace_bytes.restype = C.c_size_t
+    need = emu.svo_hip_align_workspace_bytes(M)
+    assert need > 0                                                     # (the emulated build's threshold: the phased path)
+    raw, ev_p = np.zeros(need + 512, np.uint8), np.zeros(M, np.int32)
+    ws = raw[(-raw.ctypes.data) % 256:][:need + 256]                     # (the entry wants 256-byte alignment, like hipMalloc's)
+    px_p, ok_p, h_p = run("svo_hip_align_batch_phased", (_p(ev_p), _p(ws), C.c_size_t(ws.size)))
+    for px, ok, h in ((px_c, ok_c, h_c), (px_p, ok_p, h_p)):
+        assert np.array_equal(ok, ok_a) and np.array_equal(px.view(np.uint64), px_a.view(np.uint64))
+        assert np.array_equal(h.view(np.uint64), h_a.view(np.uint64))
+    assert np.array_equal(ev_c, ev_p)
+    assert (ev_c > 6).sum() > 20 and (ev_c <= 3).sum() > 100, np.bincount(ev_c)   # all three launches had work
+    n_conv = 0
+    for t in range(0, M, 4):                                             # the single launch against the reference's functions
+        img = pyrs[slot[t]][level[t]]
+        patch = pwb[t].reshape(10, 10)[1:9, 1:9].ravel()
+        if use_1d[t]:
+            o, p, hi = orc.align1d(img, dirs[t], pwb[t], patch, n_iter, px0[t])
+            assert hi == h_a[t] or (np.isnan(hi) and np.isnan(h_a[t])) or (np.isinf(hi) and np.isinf(h_a[t])), t
+        else:
+            o, p = orc.align2d(img, pwb[t], patch, n_iter, px0[t])
+        assert bool(ok_a[t]) == o, t
+        assert np.array_equal(p, px_a[t], equal_nan=True), (t, p, px_a[t])
+        n_conv += o
+    assert n_conv > M // 16
+
+
+def test_emulated_find_epipolar_match_direct(emu, oracle, scene):
+    orc = pytrack.Track("orc")
+    imgs = scene.images.cpu().numpy()
+    pyrs = [orc.create_img_pyramid(im, 5) for im in imgs]
+    layout, store = _store(emu, imgs)
+    T = np.ascontiguousarray(scene.T_f_w)
+    slots = np.arange(T.shape[0], dtype=np.int32)
+    frames = capi.Frames(T.shape[0], 0, slots.ctypes.data, T.ctypes.data)
+    oframes = pytrack.make_frames(pyrs, scene.T_f_w)
+    rng = np.random.default_rng(11)
+    feats, de, dmin, dmax = [], [], [], []
+    for i in range(0, len(scene.obs), 2):
+        o = [x for x in scene.obs[i] if x[0] != scene.cur][0]
+        c_ref = -scene.T_f_w[o[0], :9].reshape(3, 3).T @ scene.T_f_w[o[0], 9:]
+        d_true = np.linalg.norm(scene.pt_pos[i] - c_ref)
+        spread = [0.4, 0.1, 0.0005][(i // 2) % 3]
+        d_est = d_true * (1 + rng.normal() * spread * 0.3)
+        feats.append(o); de.append(d_est); dmin.append(d_est * (1 - spread)); dmax.append(d_est * (1 + spread))
+    S = len(feats)
+    c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+    f_frame, f_level = c([o[0] for o in feats], np.int32), c([o[3] for o in feats], np.int32)
+    f_px, f_f = c([o[1] for o in feats], np.float64), c([o[2] for o in feats], np.float64)
+    f_type, f_grad = c([o[4] for o in feats], np.uint8), c([o[5] for o in feats], np.float64)
+    ftr = capi.Features(f_frame.ctypes.data, f_level.ctypes.data, f_type.ctypes.data, f_px.ctypes.data, f_f.ctypes.data, f_grad.ctypes.data)
+    cur = np.full(S, scene.cur, np.int32)
+    de, dmin, dmax = c(de, np.float64), c(dmin, np.float64), c(dmax, np.float64)
+    cam = capi.camera(scene.cam)
+    emu.svo_hip_match_workspace_bytes.restype = C.c_size_t
+    ws = np.zeros(emu.svo_hip_match_workspace_bytes(S) + 256, np.uint8)
+    for align_1d in (0, 1):
+        o_ = capi.DepthFilterOptions(0, 0, 0.0, int(align_1d), 10, 1000, 1, 1, 5, 0.7)
+        ok, depth, px, lvl = np.zeros(S, np.int32), np.zeros(S), np.zeros((S, 2)), np.zeros(S, np.int32)
+        rc = emu.svo_hip_find_epipolar_match_direct(C.byref(layout), _p(store), C.byref(cam), C.byref(frames), S, _p(cur), C.byref(ftr), _p(de),
+                                                    _p(dmin), _p(dmax), C.byref(o_), _p(ok), _p(depth), _p(px), _p(lvl), _p(ws),
+                                                    C.c_size_t(ws.size), None)
+        assert rc == 0, rc
+        opt = pytrack.matcher_options(n_pyr_levels=5, align_1d=align_1d)
+        n_ok = 0
+        for k in range(S):
+            ok_o, r = orc.find_epipolar_match_direct(oframes, scene.cam, feats[k][0], scene.cur, pytrack.make_feature(*feats[k]),
+                                                     de[k], dmin[k], dmax[k], opt)
+            assert bool(ok[k]) == ok_o, (k, ok[k], ok_o)
+            if ok_o:
+                n_ok += 1
+                assert lvl[k] == r["search_level"]
+                assert np.abs(px[k] - r["px_cur"]).max() < 1e-9 and abs(depth[k] - r["depth"]) < 1e-9 * abs(r["depth"])
+        assert n_ok > S // 3
+
+
+def test_emulated_update_seed_and_compute_tau_batches(emu, oracle):
+    orc = pytrack.Track("orc")
+    rng = np.random.default_rng(6)
+    S = 3000
+    seeds = []
+    for i in range(S):
+        s = orc.seed_init(rng.uniform(0.5, 5), rng.uniform(0.2, 0.5))
+        s.a, s.b = np.float32(rng.uniform(5, 30)), np.float32(rng.uniform(5, 30))
+        seeds.append(s)
+    x = (1.0 / rng.uniform(0.5, 5, size=S)).astype(np.float32)
+    tau2 = (10.0 ** rng.uniform(-8, 0, size=S)).astype(np.float32)
+    tau2[::50] = 0.0
+    x[::77] = 50.0
+    c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+    a, b, mu = c([s.a for s in seeds], np.float32), c([s.b for s in seeds], np.float32), c([s.mu for s in seeds], np.float32)
+    zr, s2, bid = c([s.z_range for s in seeds], np.float32), c([s.sigma2 for s in seeds], np.float32), np.zeros(S, np.int32)
+    ss = capi.Seeds(a.ctypes.data, b.ctypes.data, mu.ctypes.data, zr.ctypes.data, s2.ctypes.data, bid.ctypes.data)
+    assert emu.svo_hip_update_seed_batch(S, _p(x), _p(tau2), C.byref(ss), None) == 0
+    got = np.stack([a, b, mu, s2], axis=1).astype(np.float64)
+    want = np.array([[n.a, n.b, n.mu, n.sigma2] for n in (orc.update_seed(x[i], tau2[i], seeds[i]) for i in range(S))])
+    fin = np.isfinite(want).all(axis=1)
+    assert np.array_equal(np.isfinite(got).all(axis=1), fin)
+    g, w = got[fin], want[fin]
+    # host-compiled without contraction, libm's exp on both sides: the reference's bits in all but a few seeds
+    assert np.mean(np.all(g == w, axis=1)) >= 0.97
+    assert np.allclose(g[:, 2], w[:, 2], rtol=2e-6, atol=0)
+    assert (np.abs(g[:, 3] - w[:, 3]) <= 1e-4 * np.abs(w[:, 3]) + 1e-6 * w[:, 2] ** 2).all()
+    assert np.allclose(g[:, :2], w[:, :2], rtol=1e-4, atol=0)
+    # computeTau for S independent measurements
+    n = 500
+    t_rc = rng.normal(size=(n, 3)) * 0.3
+    f = rng.normal(size=(n, 3)) * 0.3 + np.array([0, 0, 1.0])
+    f /= np.linalg.norm(f, axis=1, keepdims=True)
+    z = rng.uniform(0.5, 10.0, size=n)
+    ang = np.arctan(1.0 / (2.0 * 315.5)) * 2.0
+    tau = np.zeros(n)
+    assert emu.svo_hip_compute_tau_batch(n, _p(np.ascontiguousarray(t_rc)), _p(np.ascontiguousarray(f)), _p(z), C.c_double(ang), _p(tau), None) == 0
+    for i in range(n):
+        T = np.concatenate([np.eye(3).ravel(), t_rc[i]])
+        want_tau = orc.compute_tau(T, f[i], z[i], ang)
+        assert np.isnan(tau[i]) == np.isnan(want_tau)
+        if not np.isnan(want_tau):
+            assert abs(tau[i] - want_tau) <= 1e-9 * abs(want_tau), (i, tau[i], want_tau)   # (bit-equal in the default build)
+
+
+@pytest.mark.parametrize("kind", ["pinhole", "atan"])
+def test_emulated_select_matches_compose_poses_cam2world(emu, oracle, kind):
+    cam = camera_models()[kind]
+    cs = capi.camera(cam)
+    rng = np.random.default_rng(77)
+    for M, max_fts in ((0, 120), (1, 120), (7, 0), (130, 120), (300, 40), (1500, 120), (1500, 10000)):
+        runs = rng.integers(1, 9, size=M + 1)
+        cell = np.repeat(rng.permutation(M + 1), runs)[:M].astype(np.int32)
+        ok = (rng.uniform(size=M) < 0.45).astype(np.int32)
+        px = np.ascontiguousarray(np.stack([rng.uniform(0, cam.width, M), rng.uniform(0, cam.height, M)], axis=1).reshape(M, 2))
+        level = rng.integers(0, 4, size=M).astype(np.int32)
+        pos = rng.normal(size=(M, 3))
+        sel_o, f_o, lvl_o, pos_o = pytrack.select_matches(cam, cell, ok, px, level, pos, max_fts)
+        cap = max(M, 1)
+        n, sel, f = np.zeros(1, np.int32), np.zeros(cap, np.int32), np.zeros((cap, 3))
+        lvl, p, has = np.zeros(cap, np.int32), np.zeros((cap, 3)), np.zeros(cap, np.uint8)
+        rc = emu.svo_hip_select_matches(C.byref(cs), M, _p(cell), _p(ok), _p(px), _p(level), _p(pos), max_fts, _p(n), _p(sel), _p(f), _p(lvl),
+                                        _p(p), _p(has), None, 0, None)
+        assert rc == 0, rc
+        k = int(n[0])
+        assert k == len(sel_o)
+        assert np.array_equal(sel[:k], sel_o) and np.array_equal(lvl[:k], lvl_o)
+        assert np.array_equal(p[:k], pos_o) and bool((has[:k] == 1).all())
+        if k:
+            assert np.abs(f[:k] - f_o).max() <= 1e-14
+    # glue: SE(3) products (optionally scattered) and bearings
+    n = 300
+    A = np.stack([se3.exp(rng.normal(size=6) * 0.3) for _ in range(n)])
+    B = np.stack([se3.exp(rng.normal(size=6) * 0.3) for _ in range(n)])
+    out = np.zeros((n, 12))
+    assert emu.svo_hip_compose_poses(n, _p(A), _p(B), _p(out), None, None) == 0
+    assert np.abs(out - se3.mul(A, B)).max() < 1e-14
+    idx = rng.permutation(n).astype(np.int32)
+    out2 = np.zeros((n, 12))
+    assert emu.svo_hip_compose_poses(n, _p(A), _p(B), _p(out2), _p(idx), None) == 0
+    assert np.array_equal(out2[idx], out)
+    px = np.ascontiguousarray(np.stack([rng.uniform(0, cam.width, n), rng.uniform(0, cam.height, n)], axis=1))
+    fb = np.zeros((n, 3))
+    assert emu.svo_hip_cam2world(C.byref(cs), n, _p(px), _p(fb), None) == 0
+    assert np.abs(fb - synth._bearing(cam, px)).max() < 1e-14
