@@ -233,3 +233,69 @@ def test_emulated_select_matches_compose_poses_cam2world(emu, oracle, kind):
     fb = np.zeros((n, 3))
     assert emu.svo_hip_cam2world(C.byref(cs), n, _p(px), _p(fb), None) == 0
     assert np.abs(fb - synth._bearing(cam, px)).max() < 1e-14
+
+
+def test_emulated_indirect_match_batch_is_the_direct_one(emu, scene):
+    """svo_hip_find_match_direct_indirect / svo_hip_select_matches_indirect (batch size read by the kernels, observation ranges
+    instead of CSR offsets: what follows svo_hip_reproject_map on the mirror's path) against the plain entry points on the
+    same trials: identical outputs, nothing written beyond the device-side batch size (tests/test_map_mirror_gpu.py)."""
+    imgs = scene.images.cpu().numpy()
+    layout, store = _store(emu, imgs)
+    T = scene.T_f_w.copy()
+    T[scene.cur] = scene.T_cur_prior
+    T = np.ascontiguousarray(T)
+    slots = np.arange(T.shape[0], dtype=np.int32)
+    frames = capi.Frames(T.shape[0], 0, slots.ctypes.data, T.ctypes.data)
+    M = len(scene.obs)
+    ptr = np.zeros(M + 1, np.int32)
+    flat = []
+    for i, o in enumerate(scene.obs):
+        ptr[i + 1] = ptr[i] + len(o)
+        flat.extend(o)
+    c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+    o_frame, o_level = c([o[0] for o in flat], np.int32), c([o[3] for o in flat], np.int32)
+    o_px, o_f = c([o[1] for o in flat], np.float64), c([o[2] for o in flat], np.float64)
+    o_type, o_grad = c([o[4] for o in flat], np.uint8), c([o[5] for o in flat], np.float64)
+    obs = capi.Features(o_frame.ctypes.data, o_level.ctypes.data, o_type.ctypes.data, o_px.ctypes.data, o_f.ctypes.data, o_grad.ctypes.data)
+    cam = capi.camera(scene.cam)
+    emu.svo_hip_match_workspace_bytes.restype = C.c_size_t
+    cap = M + 37
+    pad = lambda x: np.ascontiguousarray(np.concatenate([x, np.zeros((cap - M,) + x.shape[1:], x.dtype)]))
+    cur, pos = np.full(M, scene.cur, np.int32), c(scene.pt_pos, np.float64)
+
+    def outputs(n, fill):
+        return dict(px=pad(c(scene.px_init, np.float64))[:n].copy(), ok=np.full(n, fill, np.int32), ref_obs=np.zeros(n, np.int32),
+                    sl=np.zeros(n, np.int32), A=np.zeros((n, 4)), patches=np.zeros((n, 100), np.uint8))
+
+    ref = outputs(M, 0)
+    ws = np.zeros(emu.svo_hip_match_workspace_bytes(cap) + 256, np.uint8)
+    rc = emu.svo_hip_find_match_direct(C.byref(layout), _p(store), C.byref(cam), C.byref(frames), M, _p(cur), _p(pos), _p(ptr), C.byref(obs),
+                                       5, 10, _p(ref["px"]), _p(ref["ok"]), _p(ref["ref_obs"]), _p(ref["sl"]), _p(ref["A"]), _p(ref["patches"]),
+                                       _p(ws), C.c_size_t(ws.size), None)
+    assert rc == 0, rc
+    res = outputs(cap, -7)
+    d_M = np.array([M], np.int32)
+    ob_begin, ob_end, cur_p, pos_p = pad(ptr[:-1].copy()), pad(ptr[1:].copy()), pad(cur), pad(pos)
+    rc = emu.svo_hip_find_match_direct_indirect(C.byref(layout), _p(store), C.byref(cam), C.byref(frames), cap, _p(d_M), _p(cur_p), _p(pos_p),
+                                                _p(ob_begin), _p(ob_end), C.byref(obs), 5, 10, _p(res["px"]), _p(res["ok"]), _p(res["ref_obs"]),
+                                                _p(res["sl"]), _p(res["A"]), _p(res["patches"]), _p(ws), C.c_size_t(ws.size), None)
+    assert rc == 0, rc
+    for k in ref:
+        assert np.array_equal(res[k][:M], ref[k]), k
+    assert (res["ok"][M:] == -7).all() and ref["ok"].sum() > M // 2
+    cell = (np.arange(M) // 3).astype(np.int32)
+    outs = []
+    for indirect in (False, True):
+        n, sel = np.zeros(1, np.int32), np.full(121, -1, np.int32)
+        f, pos_o, lvl_o, has = np.zeros((121, 3)), np.zeros((121, 3)), np.zeros(121, np.int32), np.zeros(121, np.uint8)
+        if indirect:
+            rc = emu.svo_hip_select_matches_indirect(C.byref(cam), cap, _p(d_M), _p(pad(cell)), _p(res["ok"]), _p(res["px"]), _p(res["sl"]),
+                                                     _p(pos_p), 120, _p(n), _p(sel), _p(f), _p(lvl_o), _p(pos_o), _p(has), None, 0, None)
+        else:
+            rc = emu.svo_hip_select_matches(C.byref(cam), M, _p(cell), _p(ref["ok"]), _p(ref["px"]), _p(ref["sl"]), _p(pos), 120, _p(n),
+                                            _p(sel), _p(f), _p(lvl_o), _p(pos_o), _p(has), None, 0, None)
+        assert rc == 0, rc
+        outs.append((n, sel, f, lvl_o, pos_o, has))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert outs[0][0][0] > 20
