@@ -184,7 +184,8 @@ def test_emulated_update_seed_and_compute_tau_batches(emu, oracle):
     z = rng.uniform(0.5, 10.0, size=n)
     ang = np.arctan(1.0 / (2.0 * 315.5)) * 2.0
     tau = np.zeros(n)
-    assert emu.svo_hip_compute_tau_batch(n, _p(np.ascontiguousarray(t_rc)), _p(np.ascontiguousarray(f)), _p(z), C.c_double(ang), _p(tau), None) == 0
+    t_rc, f = np.ascontiguousarray(t_rc), np.ascontiguousarray(f)
+    assert emu.svo_hip_compute_tau_batch(n, _p(t_rc), _p(f), _p(z), C.c_double(ang), _p(tau), None) == 0
     for i in range(n):
         T = np.concatenate([np.eye(3).ravel(), t_rc[i]])
         want_tau = orc.compute_tau(T, f[i], z[i], ang)
@@ -284,12 +285,13 @@ def test_emulated_indirect_match_batch_is_the_direct_one(emu, scene):
         assert np.array_equal(res[k][:M], ref[k]), k
     assert (res["ok"][M:] == -7).all() and ref["ok"].sum() > M // 2
     cell = (np.arange(M) // 3).astype(np.int32)
+    cell_p = pad(cell)   # (kept in a name: a temporary would be gone before the call reads it)
     outs = []
     for indirect in (False, True):
         n, sel = np.zeros(1, np.int32), np.full(121, -1, np.int32)
         f, pos_o, lvl_o, has = np.zeros((121, 3)), np.zeros((121, 3)), np.zeros(121, np.int32), np.zeros(121, np.uint8)
         if indirect:
-            rc = emu.svo_hip_select_matches_indirect(C.byref(cam), cap, _p(d_M), _p(pad(cell)), _p(res["ok"]), _p(res["px"]), _p(res["sl"]),
+            rc = emu.svo_hip_select_matches_indirect(C.byref(cam), cap, _p(d_M), _p(cell_p), _p(res["ok"]), _p(res["px"]), _p(res["sl"]),
                                                      _p(pos_p), 120, _p(n), _p(sel), _p(f), _p(lvl_o), _p(pos_o), _p(has), None, 0, None)
         else:
             rc = emu.svo_hip_select_matches(C.byref(cam), M, _p(cell), _p(ref["ok"]), _p(ref["px"]), _p(ref["sl"]), _p(pos), 120, _p(n),

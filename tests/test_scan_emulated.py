@@ -101,9 +101,10 @@ def _run(emu, form, S, store, slot_bytes, offs, ws, hs, ps, cam, size, sl, n_ste
     out = dict(uv_best=np.zeros((S, 2)), px_cur=np.zeros((S, 2)), px_scaled=np.zeros((S, 2)), align_active=np.zeros(S, np.uint8),
                accepted_raw=np.zeros(S, np.uint8), status=np.zeros(S, np.int32))
     cur_slot = np.zeros(S, np.int32)
+    cam_a, B, step, pwb = np.array(cam, np.float64), np.ascontiguousarray(B), np.ascontiguousarray(step), np.ascontiguousarray(pwb)
     emu.scan_emulated(C.c_int(form), C.c_int(S), _p(store), C.c_longlong(slot_bytes), C.c_int(len(ws)), _p(offs), _p(ws), _p(hs), _p(ps),
-                      _p(np.array(cam, np.float64)), C.c_int(size[0]), C.c_int(size[1]), C.c_int(subpix), _p(sl), _p(cur_slot), _p(n_steps),
-                      _p(np.ascontiguousarray(B)), _p(np.ascontiguousarray(step)), _p(np.ascontiguousarray(pwb)), _p(out["uv_best"]),
+                      _p(cam_a), C.c_int(size[0]), C.c_int(size[1]), C.c_int(subpix), _p(sl), _p(cur_slot), _p(n_steps),
+                      _p(B), _p(step), _p(pwb), _p(out["uv_best"]),
                       _p(out["px_cur"]), _p(out["px_scaled"]), _p(out["align_active"]), _p(out["accepted_raw"]), _p(out["status"]))
     return out
 
