@@ -25,7 +25,7 @@ def scene():
 
 
 def _p(a):
-    return None if a is None else C.c_void_p(a.ctypes.data)
+    return None if a is None else a.ctypes.data_as(C.c_void_p)  # (the pointer object keeps the array alive)
 
 
 def _store(emu, images, n_levels=5):

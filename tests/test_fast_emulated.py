@@ -18,7 +18,7 @@ def emu():
 
 
 def _p(a):
-    return C.c_void_p(a.ctypes.data)
+    return a.ctypes.data_as(C.c_void_p)  # (the pointer object keeps the array alive)
 
 
 def detect(emu, imgs, n_pyr, levels, cell, occ, thresh=20.0):

@@ -26,7 +26,7 @@ def scene(request):
 
 
 def _p(a):
-    return C.c_void_p(a.ctypes.data)
+    return a.ctypes.data_as(C.c_void_p)  # (the pointer object keeps the array alive)
 
 
 def pose_optimize(emu, cam, n, f, level, pos, hp, T0, thresh, n_iter, entry="svo_hip_pose_optimize"):

@@ -21,7 +21,7 @@ def emu(request):
 
 
 def _p(a):
-    return C.c_void_p(a.ctypes.data)
+    return a.ctypes.data_as(C.c_void_p)  # (the pointer object keeps the array alive)
 
 
 def run_emulated(emu, b, max_level, min_level, n_iter=30, entry="svo_hip_sparse_align"):

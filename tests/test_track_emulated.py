@@ -27,7 +27,7 @@ def scene(request):
 
 
 def _p(a):
-    return C.c_void_p(a.ctypes.data)
+    return a.ctypes.data_as(C.c_void_p)  # (the pointer object keeps the array alive)
 
 
 def _store(emu, scene, n_levels=5):
