@@ -29,7 +29,7 @@ def sanitizer():
 
 def sanitizer_runtime(kind):
     cxx = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang++")
-    name = {"address": "asan", "thread": "tsan"}[kind]
+    name = {"address": "asan", "thread": "tsan", "undefined": "ubsan_standalone"}[kind]
     out = subprocess.run([cxx, f"-print-file-name=libclang_rt.{name}-x86_64.so"], capture_output=True, text=True).stdout.strip()
     return out if os.path.isabs(out) and os.path.exists(out) else None
 
@@ -61,6 +61,11 @@ def build_emulated(defines=()):
         tag = "_set" + hashlib.sha1(tag.encode()).hexdigest()[:10]
     san = sanitizer()
     san_flags = [f"-fsanitize={san}", "-shared-libsan", "-fno-omit-frame-pointer", "-g"] if san else []
+    if san == "undefined":
+        # + float-cast-overflow (a float -> int conversion out of range: the kernels guard theirs to reproduce cvttss2si).
+        # float-divide-by-zero stays off: IEEE defines it and the kernels rely on it where the reference does (1 / tau2 with
+        # tau2 = 0, the inverse of a singular H, chi2 / n_meas with nothing tracked: six sites, all the reference's own)
+        san_flags += ["-fsanitize=float-cast-overflow", "-fno-sanitize=vptr,function"]
     if san:
         tag += "_" + san
     lib_path = os.path.join(ROOT, "build", f"libsvo_hip_emulated{tag}.so")
