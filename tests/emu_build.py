@@ -78,6 +78,12 @@ def build_emulated(defines=()):
     deps = glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip")) + \
         [os.path.join(ROOT, "include", "svo_hip.h"), os.path.join(ROOT, "tests", "host", "hip_emu.h")]
     newest = max(os.path.getmtime(d) for d in deps)
+    # (a change of flags rebuilds too: the object directory remembers what it was compiled with)
+    stamp, flags_now = os.path.join(objdir, "flags.txt"), " ".join([*san_flags, *defines, "-O1"])
+    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        for o in glob.glob(os.path.join(objdir, "*.o")):
+            os.remove(o)
+        open(stamp, "w").write(flags_now)
     objs, todo = [], []
     for u in UNITS:
         src = os.path.join(ROOT, "tests", "host", f"emu_tu_{u}.cpp")
