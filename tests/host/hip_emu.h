@@ -32,7 +32,8 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 typedef void* hipStream_t;
 // memory: "device" memory is host memory, copies are memcpy, streams are synchronous
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
-inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : 2; }
+// (fresh "device" memory is poisoned -- NaN as a float, -1 as an integer -- so that a kernel reading what nobody wrote shows)
+inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); if (*p) std::memset(*p, 0xFF, n ? n : 1); return *p ? hipSuccess : 2; }
 inline hipError_t hipMallocAsync(void** p, size_t n, hipStream_t) { return hipMalloc(p, n); }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipFreeAsync(void* p, hipStream_t) { std::free(p); return hipSuccess; }

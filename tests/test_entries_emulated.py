@@ -76,7 +76,7 @@ def test_emulated_align_batch_and_its_phased_form(emu, oracle, scene):
     emu.svo_hip_align_workspace_bytes.restype = C.c_size_t
     need = emu.svo_hip_align_workspace_bytes(M)
     assert need > 0                                                     # (the emulated build's threshold: the phased path)
-    raw, ev_p = np.zeros(need + 512, np.uint8), np.zeros(M, np.int32)
+    raw, ev_p = np.full(need + 512, 0xFF, np.uint8), np.zeros(M, np.int32)
     ws = raw[(-raw.ctypes.data) % 256:][:need + 256]                     # (the entry wants 256-byte alignment, like hipMalloc's)
     px_p, ok_p, h_p = run("svo_hip_align_batch_phased", (_p(ev_p), _p(ws), C.c_size_t(ws.size)))
     for px, ok, h in ((px_c, ok_c, h_c), (px_p, ok_p, h_p)):
@@ -127,7 +127,7 @@ def test_emulated_find_epipolar_match_direct(emu, oracle, scene):
     de, dmin, dmax = c(de, np.float64), c(dmin, np.float64), c(dmax, np.float64)
     cam = capi.camera(scene.cam)
     emu.svo_hip_match_workspace_bytes.restype = C.c_size_t
-    ws = np.zeros(emu.svo_hip_match_workspace_bytes(S) + 256, np.uint8)
+    ws = np.full(emu.svo_hip_match_workspace_bytes(S) + 256, 0xFF, np.uint8)   # (poisoned: NaN / -1 to whoever reads scratch it did not write)
     for align_1d in (0, 1):
         o_ = capi.DepthFilterOptions(0, 0, 0.0, int(align_1d), 10, 1000, 1, 1, 5, 0.7)
         ok, depth, px, lvl = np.zeros(S, np.int32), np.zeros(S), np.zeros((S, 2)), np.zeros(S, np.int32)
@@ -269,7 +269,7 @@ def test_emulated_indirect_match_batch_is_the_direct_one(emu, scene):
                     sl=np.zeros(n, np.int32), A=np.zeros((n, 4)), patches=np.zeros((n, 100), np.uint8))
 
     ref = outputs(M, 0)
-    ws = np.zeros(emu.svo_hip_match_workspace_bytes(cap) + 256, np.uint8)
+    ws = np.full(emu.svo_hip_match_workspace_bytes(cap) + 256, 0xFF, np.uint8)   # (poisoned: NaN / -1 to whoever reads scratch it did not write)
     rc = emu.svo_hip_find_match_direct(C.byref(layout), _p(store), C.byref(cam), C.byref(frames), M, _p(cur), _p(pos), _p(ptr), C.byref(obs),
                                        5, 10, _p(ref["px"]), _p(ref["ok"]), _p(ref["ref_obs"]), _p(ref["sl"]), _p(ref["A"]), _p(ref["patches"]),
                                        _p(ws), C.c_size_t(ws.size), None)

@@ -30,7 +30,7 @@ def detect(emu, imgs, n_pyr, levels, cell, occ, thresh=20.0):
     cols, rows = -(-w // cell), -(-h // cell)
     nc = cols * rows
     emu.svo_hip_fast_workspace_bytes.restype = C.c_size_t
-    ws = np.zeros(emu.svo_hip_fast_workspace_bytes(C.byref(layout), n, nc), np.uint8)
+    ws = np.full(emu.svo_hip_fast_workspace_bytes(C.byref(layout), n, nc), 0xFF, np.uint8)   # (poisoned: NaN / -1 to whoever reads scratch it did not write)
     slots = np.arange(n, dtype=np.int32)
     xy, lvl, sc = np.zeros((n, nc, 2), np.int32), np.zeros((n, nc), np.int32), np.zeros((n, nc), np.float32)
     rc = emu.svo_hip_fast_detect(C.byref(layout), _p(store), n, _p(slots), levels, 20, cell, cols, rows, None if occ is None else _p(occ),

@@ -67,7 +67,7 @@ def test_emulated_find_match_direct(emu, oracle, scene):
     ok, ref_obs, sl = np.zeros(P, np.int32), np.zeros(P, np.int32), np.zeros(P, np.int32)
     A, patches = np.zeros((P, 4)), np.zeros((P, 100), np.uint8)
     emu.svo_hip_match_workspace_bytes.restype = C.c_size_t
-    ws = np.zeros(emu.svo_hip_match_workspace_bytes(P) + 256, np.uint8)
+    ws = np.full(emu.svo_hip_match_workspace_bytes(P) + 256, 0xFF, np.uint8)   # (poisoned: NaN / -1 to whoever reads scratch it did not write)
     cam = capi.camera(scene.cam)
     rc = emu.svo_hip_find_match_direct(C.byref(layout), _p(store), C.byref(cam), C.byref(frames), P, _p(cur), _p(pos), _p(ptr), C.byref(obs),
                                        5, 10, _p(px), _p(ok), _p(ref_obs), _p(sl), _p(A), _p(patches), _p(ws), C.c_size_t(ws.size), None)
@@ -152,7 +152,7 @@ def test_emulated_update_seeds(emu_seeds, oracle, scene, align_1d, subpix):
     cur = np.full(S, scene.cur, np.int32)
     status, xyz, px = np.zeros(S, np.int32), np.zeros((S, 3)), np.zeros((S, 2))
     emu.svo_hip_match_workspace_bytes.restype = C.c_size_t
-    ws = np.zeros(emu.svo_hip_match_workspace_bytes(S) + 256, np.uint8)
+    ws = np.full(emu.svo_hip_match_workspace_bytes(S) + 256, 0xFF, np.uint8)   # (poisoned: NaN / -1 to whoever reads scratch it did not write)
     cam = capi.camera(scene.cam)
     rc = emu.svo_hip_update_seeds(C.byref(layout), _p(store), C.byref(cam), C.byref(frames), S, _p(cur), C.byref(ftr), C.byref(sd),
                                   C.byref(dopt), _p(status), _p(xyz), _p(px), _p(ws), C.c_size_t(ws.size), None)
