@@ -13,8 +13,15 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-SUBSET = ["tests/test_sparse_align_emulated.py", "tests/test_track_emulated.py", "tests/test_map_mirror_emulated.py",
-          "-q", "-x", "-p", "no:cacheprovider", "-k", "default"]
+# one test per kernel chain, on the default build (the script without arguments runs all emulated tests on both builds:
+# profiles/r04w_emulated_sanitizers.txt)
+SUBSET = ["tests/test_sparse_align_emulated.py::test_emulated_sparse_align_edge_cases[default]",
+          "tests/test_track_emulated.py::test_emulated_find_match_direct[default-pinhole]",
+          "tests/test_track_emulated.py::test_emulated_update_seeds[default-pinhole-0-1]",
+          "tests/test_optimizers_emulated.py::test_emulated_pose_optimize[default-pinhole-wave]",
+          "tests/test_map_mirror_emulated.py::test_emulated_batches_and_patches[default]",
+          "tests/test_fast_emulated.py::test_emulated_fast_detect_empty_and_full_occupancy",
+          "-q", "-x", "-p", "no:cacheprovider"]
 
 
 def _runtime_or_skip(kind):
