@@ -79,6 +79,10 @@ if [ -f $V/libsvo_hip_TAU_ALGEBRAIC.so ]; then
   SVO_HIP_LIB=$PWD/$V/libsvo_hip_TAU_ALGEBRAIC.so python -m pytest tests/test_tracking_gpu.py tests/test_full_size_gpu.py -q -m gpu -x 2>&1 | tail -2
   bash scripts/full_variants.sh main svo_hip_TAU_ALGEBRAIC main svo_hip_TAU_ALGEBRAIC 2>&1 | cut -c1-220
 fi
+echo "== the host pyramid (dropin/frame.cpp keeps level 0 only since the end of round 4, untimed): single-stream frame with and without"
+for k in 1 2; do python scripts/dropin_trace.py frames=600 2>/dev/null | grep "tot_time median"; done
+echo "-- SVO_HIP_HOST_PYRAMID=1 (the reference's behaviour)"
+for k in 1 2; do SVO_HIP_HOST_PYRAMID=1 python scripts/dropin_trace.py frames=600 2>/dev/null | grep "tot_time median"; done
 echo "== RM_PATCH_LOAD_FIRST: the map patch applied with all loads before the first store (expected: -3..6 us per frame)"
 if [ -f $V/libsvo_hip_RM_PATCH_LOAD_FIRST.so ]; then
   SVO_HIP_LIB=$PWD/$V/libsvo_hip_RM_PATCH_LOAD_FIRST.so python -m pytest tests/test_map_mirror_gpu.py -q -m gpu -x 2>&1 | tail -2

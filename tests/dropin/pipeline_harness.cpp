@@ -284,4 +284,16 @@ int pipe_last_features(void* h, int max_n, double* px, int32_t* level, double* p
   return n;
 }
 
+// the last frame's host pyramid: number of levels, and how many of them hold an image (the full drop-in leaves the levels
+// above 0 empty: rpg_svo_amd/host/dropin/frame.cpp)
+int pipe_last_host_pyramid(void* h, int* n_levels) {
+  Pipe* p = (Pipe*)h;
+  FramePtr f = p->vo->lastFrame();
+  if (!f) return -1;
+  *n_levels = (int)f->img_pyr_.size();
+  int filled = 0;
+  for (size_t i = 0; i < f->img_pyr_.size(); ++i) filled += (f->img_pyr_[i].data != NULL && f->img_pyr_[i].rows > 0) ? 1 : 0;
+  return filled;
+}
+
 }  // extern "C"

@@ -126,6 +126,13 @@ class Pipeline:
         v = np.array(out[:], dtype=np.float64)
         return v
 
+    def last_host_pyramid(self):
+        """(levels, levels that hold an image) of the last frame's Frame::img_pyr_"""
+        n = C.c_int(0)
+        self.lib.pipe_last_host_pyramid.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        filled = self.lib.pipe_last_host_pyramid(self.h, C.byref(n))
+        return n.value, filled
+
     def last_features(self, max_n=2048):
         px = np.zeros((max_n, 2)); lvl = np.zeros(max_n, dtype=np.int32); pos = np.zeros((max_n, 3))
         n = self.lib.pipe_last_features(self.h, max_n, px.ctypes.data, lvl.ctypes.data, pos.ctypes.data)
@@ -162,6 +169,7 @@ def run_sequence(flavour, cam, images, T_gt, stats_out=None, range0=None, **cfg)
             out.append(p.add_image(images[i], float(i)))
         t_loop = time.perf_counter() - t_loop
         if stats_out is not None:
+            stats_out["host_pyramid"] = p.last_host_pyramid()
             # frame period with the frames fed back to back (includes the harness' own per-call overhead)
             stats_out["wall_ms_per_frame"] = 1e3 * t_loop / max(1, len(images) - 1)
             s1 = p.device_stats()

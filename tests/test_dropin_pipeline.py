@@ -120,6 +120,37 @@ def test_dropin_host_logic_on_the_mock_device(mock_lib):
     assert st["uploads"] == len(imgs) and st["evictions"] == len(imgs) - 64  # 64 slots: old frames leave, none comes back
 
 
+def test_full_dropin_builds_no_host_pyramid(mock_lib):
+    """rpg_svo_amd/host/dropin/frame.cpp: in the full drop-in every reader of the host pyramid's upper levels is a drop-in,
+    so frame_utils::createImgPyramid keeps level 0 and leaves the rest empty (the reference builds them all: three to five
+    halfSample passes per frame nobody reads) -- same decisions, same trajectory as with the levels built
+    (SVO_HIP_HOST_PYRAMID=1, read once per process: a child)."""
+    import json
+    import subprocess
+    cam, imgs, T = _sequence(40)
+    st = {}
+    res = pp.run_sequence("hipmock", cam, imgs, T, stats_out=st)
+    n_levels, filled = st["host_pyramid"]
+    assert n_levels >= 5 and filled == 1, st["host_pyramid"]
+    st_ref = {}
+    pp.run_sequence("ref", cam, imgs[:3], T[:3], stats_out=st_ref)
+    assert st_ref["host_pyramid"] == (n_levels, n_levels)           # the reference's own frame.cpp
+    code = ("import sys, json, numpy as np\n"
+            f"sys.path.insert(0, {HERE!r}); sys.path.insert(0, {os.path.join(HERE, 'dropin')!r})\n"
+            "import pypipeline as pp\n"
+            "from test_dropin_pipeline import _sequence\n"
+            "cam, imgs, T = _sequence(40)\n"
+            "st = {}\n"
+            "res = pp.run_sequence('hipmock', cam, imgs, T, stats_out=st)\n"
+            "print(json.dumps(dict(pyr=st['host_pyramid'], T=[list(map(float, r['T_f_w'])) for r in res], kf=[int(r['is_keyframe']) for r in res])))\n")
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SVO_HIP_HOST_PYRAMID="1"), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    other = json.loads(p.stdout.strip().splitlines()[-1])
+    assert tuple(other["pyr"]) == (n_levels, n_levels)
+    assert np.array_equal(np.array(other["T"]), np.stack([r["T_f_w"] for r in res]))
+    assert other["kf"] == [int(r["is_keyframe"]) for r in res]
+
+
 def test_mock_device_deferred_mapper_and_small_pool(mock_lib):
     """Deferred mapping (results of DepthFilter::updateSeeds joined at the next reprojectMap / updateSeeds / detect) and
     a pyramid pool so small that live frames are evicted and uploaded again: the trajectory must not notice either."""
