@@ -38,7 +38,7 @@ def build_race_probe():
     """tests/host/emu_race_probe.cpp (a kernel with and without the barrier it needs) with the sanitizer of SVO_EMU_SANITIZE."""
     san = sanitizer()
     cxx = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang++")
-    lib_path = os.path.join(ROOT, "build", f"libemu_race_probe_{san or 'plain'}.so")
+    lib_path = os.path.join(ROOT, "build", "emu", f"libemu_race_probe_{san or 'plain'}.so")
     src = os.path.join(ROOT, "tests", "host", "emu_race_probe.cpp")
     hdr = os.path.join(ROOT, "tests", "host", "hip_emu.h")
     os.makedirs(os.path.dirname(lib_path), exist_ok=True)
@@ -68,8 +68,8 @@ def build_emulated(defines=()):
         san_flags += ["-fsanitize=float-cast-overflow", "-fno-sanitize=vptr,function"]
     if san:
         tag += "_" + san
-    lib_path = os.path.join(ROOT, "build", f"libsvo_hip_emulated{tag}.so")
-    objdir = os.path.join(ROOT, "build", f"emu_obj{tag}")
+    lib_path = os.path.join(ROOT, "build", "emu", f"libsvo_hip_emulated{tag}.so")
+    objdir = os.path.join(ROOT, "build", "emu", f"obj{tag}")
     os.makedirs(objdir, exist_ok=True)
     csrc = os.path.join(ROOT, "rpg_svo_amd", "csrc")
     cxx = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang++")

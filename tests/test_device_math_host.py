@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 from oracle import pyoracle  # noqa: E402
 
 SRC = os.path.join(ROOT, "tests", "host", "device_math_on_host.cpp")
-LIB = os.path.join(ROOT, "build", "libdevice_math_on_host.so")
+LIB = os.path.join(ROOT, "build", "emu", "libdevice_math_on_host.so")
 D = C.POINTER(C.c_double)
 F = C.POINTER(C.c_float)
 

@@ -14,7 +14,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "host", "scan_emulated.cpp")
-LIB = os.path.join(ROOT, "build", "libscan_emulated.so")
+LIB = os.path.join(ROOT, "build", "emu", "libscan_emulated.so")
 ZMSSD_THRESHOLD = 2000 * 64
 
 
