@@ -11,5 +11,5 @@ case $kind in address) name=asan; opts="ASAN_OPTIONS=detect_leaks=0";; thread) n
 rt=$(${ROCM_PATH:-/opt/rocm}/lib/llvm/bin/clang++ -print-file-name=libclang_rt.$name-x86_64.so)
 [ -f "$rt" ] || { echo "no $name runtime next to ROCm's clang++"; exit 3; }
 cd "$(dirname "$0")/.."
-[ $# -gt 0 ] || set -- tests/test_sparse_align_emulated.py tests/test_track_emulated.py tests/test_optimizers_emulated.py tests/test_entries_emulated.py tests/test_map_mirror_emulated.py tests/test_fast_emulated.py tests/test_pyramid_emulated.py -q
+[ $# -gt 0 ] || set -- tests/test_sparse_align_emulated.py tests/test_track_emulated.py tests/test_optimizers_emulated.py tests/test_entries_emulated.py tests/test_map_mirror_emulated.py tests/test_fast_emulated.py tests/test_pyramid_emulated.py tests/test_emulated_shapes.py -q
 env LD_PRELOAD=$rt $opts SVO_EMU_SANITIZE=$kind python -m pytest "$@"
