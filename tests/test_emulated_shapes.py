@@ -72,3 +72,14 @@ def test_sparse_align_on_any_shape(emu, oracle, w, h, n, levels, lo, hi):
     T_h, ntr, iters, H, status = run_emulated(emu, b, hi, lo)
     assert se3.log_norm(T_h, T_o).max() <= 1e-4
     assert np.array_equal(ntr, np.array([r["n_tracked"] for r in res_o]))
+
+
+@pytest.mark.parametrize("kind", ["pinhole", "atan"])
+def test_matcher_and_depth_filter_on_an_odd_image_size(emu, oracle, kind):
+    """find_match_direct and update_seeds (tests/test_track_emulated.py) on 438 x 410 images: 27.4 x 51.25 tiles of the store"""
+    import test_track_emulated as tte
+    cam = synth.Camera(438, 410, 260.0, 260.0, 219.0, 205.0) if kind == "pinhole" else \
+        synth.Camera.atan(438, 410, 0.509326, 0.796651, 0.45905, 0.510056, 0.9320)
+    scene = synth.make_track_scene(n_kf=4, n_feat=100, cam=cam)
+    tte.test_emulated_find_match_direct(emu, oracle, scene)
+    tte.test_emulated_update_seeds(emu, oracle, scene, 0, 1)
