@@ -16,6 +16,14 @@ __global__ void neighbour_sum(const int* in, int* out) {
   const int nb = MODE == 3 ? ((t & ~63) | ((t + 1) & 63)) : ((t + 1) & 127);
   out[t] = s[t] + s[nb];
 }
+// two workgroups: the second one adds 1 to the neighbour's value -- read from the input (MODE 4: clean) or from what the FIRST
+// workgroup wrote (MODE 5: nothing orders two workgroups of a launch; seen only with SVO_EMU_TSAN_BETWEEN_WORKGROUPS=1)
+template <int MODE>
+__global__ void two_workgroups(const int* in, int* out) {
+  const int t = (int)threadIdx.x, b = (int)blockIdx.x;
+  if (b == 0) out[t] = in[t];
+  else out[128 + t] = (MODE == 5 ? out[(t + 1) & 127] : in[(t + 1) & 127]) + 1;
+}
 }  // namespace
 
 extern "C" int probe_neighbour_sum(int mode, const int* in, int* out) {
@@ -24,6 +32,8 @@ extern "C" int probe_neighbour_sum(int mode, const int* in, int* out) {
     case 1: hipLaunchKernelGGL(neighbour_sum<1>, dim3(1), dim3(128), 0, nullptr, in, out); break;
     case 2: hipLaunchKernelGGL(neighbour_sum<2>, dim3(1), dim3(128), 0, nullptr, in, out); break;
     case 3: hipLaunchKernelGGL(neighbour_sum<3>, dim3(1), dim3(128), 0, nullptr, in, out); break;
+    case 4: hipLaunchKernelGGL(two_workgroups<4>, dim3(2), dim3(128), 0, nullptr, in, out); break;
+    case 5: hipLaunchKernelGGL(two_workgroups<5>, dim3(2), dim3(128), 0, nullptr, in, out); break;
     default: return -1;
   }
   return 0;

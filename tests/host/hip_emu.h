@@ -98,7 +98,7 @@ struct Block {
 };
 
 struct alignas(16) Lds16 { char b[16]; };
-inline std::vector<Lds16> g_dyn_lds;  // the running launch's dynamic LDS
+inline std::vector<Lds16> g_dyn_lds = [] { std::vector<Lds16> v; v.reserve(160 * 1024 / 16 + 1); return v; }();  // the running launch's dynamic LDS (one address for good)
 inline Block* g_block = nullptr;   // (one OS thread runs the emulation)
 inline Fiber* g_fiber = nullptr;
 inline std::function<void()>* g_body = nullptr;
@@ -127,8 +127,21 @@ extern "C" void* __tsan_create_fiber(unsigned flags);
 extern "C" void __tsan_switch_to_fiber(void* fiber, unsigned flags);
 extern "C" void __tsan_acquire(void* addr);
 extern "C" void __tsan_release(void* addr);
+extern "C" void AnnotateBenignRaceSized(const char* file, int line, const volatile void* mem, size_t size, const char* description);
+// the static LDS arrays of a library (ThreadSanitizer builds put them into one section: see __shared__ below)
+extern "C" char __start_svo_lds[] __attribute__((weak, visibility("hidden")));
+extern "C" char __stop_svo_lds[] __attribute__((weak, visibility("hidden")));
 #endif
 #endif
+// SVO_EMU_TSAN_BETWEEN_WORKGROUPS=1 (ThreadSanitizer builds): the workgroups of a launch are NOT ordered one after the other
+// any more -- as on the device, where nothing orders them -- and the LDS arrays (every workgroup's own there, the same static
+// arrays here) are exempt.  What is reported then is global memory that one workgroup writes and another
+// reads or writes without an atomic: results that depend on the order the workgroups happen to run in.  (A work-item
+// of one workgroup and the work-item of the same index of the next are the same sanitizer thread: not looked at.)
+inline bool between_workgroups_mode() {
+  static const bool on = [] { const char* e = std::getenv("SVO_EMU_TSAN_BETWEEN_WORKGROUPS"); return e && e[0] == '1'; }();
+  return on;
+}
 #ifdef SVO_EMU_TSAN
 #define SVO_EMU_NOTSAN __attribute__((no_sanitize("thread"), noinline))
 #else
@@ -194,12 +207,26 @@ SVO_EMU_NOTSAN inline void barrier_wait(int id) {
 #endif
 }
 
-SVO_EMU_NOTSAN inline void run_block(Block& b, std::function<void()>& body, size_t stack_bytes) {
+SVO_EMU_NOTSAN inline void run_block(Block& b, std::function<void()>& body, size_t stack_bytes, bool first_of_launch = true,
+                                     bool last_of_launch = true) {
   g_block = &b;
   g_body = &body;
 #ifdef SVO_EMU_TSAN
   g_sched_tsan = __tsan_get_current_fiber();
-  __tsan_acquire(&g_sync_exit);   // the workgroup before this one
+  const bool xwg = between_workgroups_mode();
+  if (!xwg || first_of_launch) __tsan_acquire(&g_sync_exit);   // the workgroup (or, between workgroups: the launch) before this one
+  if (xwg) {  // LDS is every workgroup's own on the device and the same static arrays here: not looked at in this mode
+    static bool lds_exempt = false;
+    static const void* dyn_exempt = nullptr;
+    if (!lds_exempt && __start_svo_lds && __stop_svo_lds > __start_svo_lds) {
+      AnnotateBenignRaceSized(__FILE__, __LINE__, __start_svo_lds, (size_t)(__stop_svo_lds - __start_svo_lds), "LDS (between-workgroups mode)");
+      lds_exempt = true;
+    }
+    if (!g_dyn_lds.empty() && dyn_exempt != g_dyn_lds.data()) {
+      dyn_exempt = g_dyn_lds.data();
+      AnnotateBenignRaceSized(__FILE__, __LINE__, g_dyn_lds.data(), g_dyn_lds.capacity() * sizeof(Lds16), "dynamic LDS (between-workgroups mode)");
+    }
+  }
   __tsan_release(&g_sync_start);
 #endif
   const unsigned n = (unsigned)b.fibers.size();
@@ -306,14 +333,15 @@ SVO_EMU_NOTSAN inline void run_block(Block& b, std::function<void()>& body, size
     }
   }
 #ifdef SVO_EMU_TSAN
-  __tsan_acquire(&g_sync_exit);  // the host reads what the kernel wrote
+  if (!xwg || last_of_launch) __tsan_acquire(&g_sync_exit);  // the host reads what the kernel wrote
 #endif
+  (void)first_of_launch; (void)last_of_launch;
   g_block = nullptr;
   g_fiber = nullptr;
 }
 
 template <typename F>
-void launch(dim3 grid, dim3 block, F&& body_in) {
+SVO_EMU_NOTSAN void launch(dim3 grid, dim3 block, F&& body_in) {
   std::function<void()> body = body_in;
   const unsigned n = block.x * block.y * block.z;
   static thread_local Block blk;  // (stacks are kept between launches)
@@ -325,7 +353,7 @@ void launch(dim3 grid, dim3 block, F&& body_in) {
     for (unsigned by = 0; by < grid.y; ++by)
       for (unsigned bx = 0; bx < grid.x; ++bx) {
         blk.bid = dim3(bx, by, bz);
-        run_block(blk, body, stack_bytes);
+        run_block(blk, body, stack_bytes, bx + by + bz == 0, bx + 1 == grid.x && by + 1 == grid.y && bz + 1 == grid.z);
       }
 }
 
@@ -474,7 +502,11 @@ using std::min;
 #define __forceinline__ inline __attribute__((always_inline))
 #define __constant__ static const
 #define __global__
+#ifdef SVO_EMU_TSAN
+#define __shared__ static __attribute__((section("svo_lds")))
+#else
 #define __shared__ static
+#endif
 #define __launch_bounds__(...)
 #define __syncthreads() (svo_emu::barrier_wait(0))
 #define __shfl_up(...) svo_emu::shfl_up(__LINE__, __VA_ARGS__)

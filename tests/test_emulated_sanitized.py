@@ -134,3 +134,26 @@ def test_the_race_detector_sees_a_missing_barrier(tmp_path, mode, racy):
         assert n >= 1 and "emu_race_probe.cpp:13" in text and "emu_race_probe.cpp:17" in text, text[:4000]   # the store and the load
     else:
         assert n == 0, text[:4000]
+
+
+@pytest.mark.parametrize("mode,between,racy", [(4, "1", False), (5, "0", False), (5, "1", True)],
+                         ids=["disjoint-workgroups", "ordered-workgroups-hide-it", "one-workgroup-reads-what-another-writes"])
+def test_the_race_detector_between_workgroups(tmp_path, mode, between, racy):
+    """SVO_EMU_TSAN_BETWEEN_WORKGROUPS=1: the workgroups of a launch are not ordered (as on the device) and LDS is exempt; a
+    workgroup that reads global memory another workgroup of the same launch writes is a report (tests/host/emu_race_probe.cpp)."""
+    rt = _runtime_or_skip("thread")
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, 'tests')\n"
+        "from emu_build import build_race_probe\n"
+        "lib = build_race_probe()\n"
+        "a = np.arange(128, dtype=np.int32); o = np.zeros(256, np.int32)\n"
+        f"assert lib.probe_neighbour_sum({mode}, a.ctypes.data, o.ctypes.data) == 0\n"
+        "print('exact', int((o[128:] == np.roll(a, -1) + 1).sum()))\n")
+    log = str(tmp_path / "tsan")
+    env = dict(os.environ, LD_PRELOAD=rt, TSAN_OPTIONS=f"report_signal_unsafe=0:log_path={log}", SVO_EMU_SANITIZE="thread", OMP_NUM_THREADS="1",
+               SVO_EMU_TSAN_BETWEEN_WORKGROUPS=between)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    n, text = _races(log)
+    assert "exact 128" in r.stdout, r.stderr[-3000:]
+    assert (n >= 1 and "two_workgroups" in text) if racy else n == 0, text[:4000]
