@@ -20,6 +20,13 @@ def emu(request):
 
 
 @pytest.fixture(scope="module")
+def emu_default():
+    """(the default build only: tests of kernels no queued flag touches)"""
+    from emu_build import build_emulated
+    return build_emulated(())
+
+
+@pytest.fixture(scope="module")
 def scene():
     return synth.make_track_scene(n_kf=4, n_feat=100, cam=camera_models()["pinhole"])
 
@@ -195,7 +202,8 @@ def test_emulated_update_seed_and_compute_tau_batches(emu, oracle):
 
 
 @pytest.mark.parametrize("kind", ["pinhole", "atan"])
-def test_emulated_select_matches_compose_poses_cam2world(emu, oracle, kind):
+def test_emulated_select_matches_compose_poses_cam2world(emu_default, oracle, kind):
+    emu = emu_default
     cam = camera_models()[kind]
     cs = capi.camera(cam)
     rng = np.random.default_rng(77)

@@ -20,6 +20,13 @@ def emu(request):
     return build_emulated(BUILDS[request.param])
 
 
+@pytest.fixture(scope="module")
+def emu_default():
+    """(the default build only: tests of kernels no queued flag touches)"""
+    from emu_build import build_emulated
+    return build_emulated(())
+
+
 @pytest.fixture(scope="module", params=["pinhole", "atan"])
 def scene(request):
     return synth.make_track_scene(n_kf=4, n_feat=100, cam=camera_models()[request.param])
@@ -105,7 +112,8 @@ def test_emulated_pose_optimize_deferred(emu, scene):
     assert np.array_equal(T0o, T0f) and np.array_equal(ran0o, ran0f) and np.array_equal(hp0o, hp0f) and np.array_equal(st0o, st0f)
 
 
-def test_emulated_point_optimize(emu, oracle, scene):
+def test_emulated_point_optimize(emu_default, oracle, scene):
+    emu = emu_default
     orc = pytrack.Track("orc")
     rng = np.random.default_rng(4)
     T = np.ascontiguousarray(scene.T_f_w)
@@ -128,7 +136,8 @@ def test_emulated_point_optimize(emu, oracle, scene):
         assert np.abs(o - out[i]).max() < 1e-11, i
 
 
-def test_emulated_reproject_points(emu, oracle, scene):
+def test_emulated_reproject_points(emu_default, oracle, scene):
+    emu = emu_default
     orc = pytrack.Track("orc")
     T = np.ascontiguousarray(scene.T_f_w)
     slots = np.arange(T.shape[0], dtype=np.int32)

@@ -20,6 +20,13 @@ def emu(request):
     return build_emulated(BUILDS[request.param])
 
 
+@pytest.fixture(scope="module")
+def emu_default():
+    """(the default build only: tests of kernels no queued flag touches)"""
+    from emu_build import build_emulated
+    return build_emulated(())
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)  # (the pointer object keeps the array alive)
 
@@ -78,10 +85,11 @@ def test_emulated_sparse_align_edge_cases(emu, oracle):
 
 
 @pytest.mark.parametrize("n_patches", [60, 190])
-def test_emulated_wave_per_frame_kernel(emu, oracle, n_patches):
+def test_emulated_wave_per_frame_kernel(emu_default, oracle, n_patches):
     """sparse_align_wave.hip -- a frame per wave, one and three patches per lane, no workgroup barrier, the solve in the same
     wave behind a transposing wave reduction -- through a test-only entry (svo_hip_sparse_align gives it batches of >= 1024
     frames only): the oracle's poses, and the workgroup kernel's, with the bounds of tests/test_sparse_align_gpu.py."""
+    emu = emu_default
     seq = synth.make_sequence(7, n_patches, seed=23)
     b = make_batch(seq, [(i, i + 1) for i in range(6)], 4)
     b.n[3] = n_patches - 7
