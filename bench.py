@@ -178,6 +178,9 @@ def compact_line(result: dict, details_path: str | None) -> dict:
         if isinstance(lw, dict) and "tot_time" in lw:
             legs["dropin_sequence"]["ms_hip_map_mirror_off"] = lw["tot_time"]
             legs["dropin_sequence"]["map_mirror_same_trajectory"] = lw.get("trajectory_identical_to_the_mirror_path")
+        wp = ds.get("median_ms_per_frame_hip_dropin_with_the_host_pyramid_built")
+        if isinstance(wp, dict) and "tot_time" in wp:
+            legs["dropin_sequence"]["ms_hip_host_pyramid_built"] = wp["tot_time"]
         for k_out, k_in in (("ms_cpu_ref", "median_ms_per_frame_cpu_reference"), ("ms_hip", "median_ms_per_frame_hip_dropin"),
                             ("ms_hip_deferred_mapper", "median_ms_per_frame_hip_dropin_deferred_mapper")):
             if isinstance(ds.get(k_in), dict):
@@ -1510,7 +1513,24 @@ def dropin_sequence(n_frames: int = 600) -> dict:
             list_walk = {"skipped": p.stderr[-300:]}
     except Exception as e:
         list_walk = {"skipped": repr(e)}
-    return {"frames": n_frames, "map_size": map_size,
+    # the same sequence with the host pyramid built as the reference builds it (SVO_HIP_HOST_PYRAMID=1, read once per process: a
+    # child): what rpg_svo_amd/host/dropin/frame.cpp saves by keeping level 0 only
+    try:
+        dump = tempfile.mktemp(suffix=".npy", dir="/tmp")
+        code = f"import sys, json; sys.path.insert(0, {ROOT!r}); import bench; print(json.dumps(bench.dropin_hip_only({n_frames}, {dump!r})))"
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SVO_HIP_HOST_PYRAMID="1"), capture_output=True, text=True,
+                           timeout=300)
+        if p.returncode == 0:
+            with_pyr = json.loads(p.stdout.strip().splitlines()[-1])
+            with_pyr["trajectory_identical"] = bool(np.array_equal(np.load(dump), Th))
+            with_pyr.pop("map_mirror", None)
+            os.unlink(dump)
+        else:
+            with_pyr = {"skipped": p.stderr[-300:]}
+    except Exception as e:
+        with_pyr = {"skipped": repr(e)}
+    return {"frames": n_frames, "map_size": map_size, "host_pyramid_levels_built_of": host.get("host_pyramid"),
+            "median_ms_per_frame_hip_dropin_with_the_host_pyramid_built": with_pyr,
             "map_mirror": host.get("map_mirror"), "median_ms_per_frame_hip_dropin_list_walking_reprojector": list_walk,
             "first_frame_with_a_different_decision": first_diff,
             "first_frame_with_a_different_tracking_decision": first_trk,
