@@ -34,7 +34,15 @@ ATE_TOL_M = 5e-5
 
 
 def _sequence(n_frames, seed=5, cam=None):
+    default_cam = cam is None
     cam = cam or synth.Camera(752, 480, 315.5, 315.5, 376.0, 240.0)  # svo/test/test_pipeline.cpp:46-47 intrinsics
+    # child processes of one test share the parent's rendering (SVO_TEST_SEQ_FILE: the default sequence, at least this long;
+    # a shorter sequence is a prefix of a longer one: the trajectory is a seeded walk, a frame depends on its pose only)
+    f = os.environ.get("SVO_TEST_SEQ_FILE")
+    if f and default_cam and seed == 5 and os.path.exists(f):
+        d = np.load(f)
+        if d["T"].shape[0] >= n_frames:
+            return cam, np.ascontiguousarray(d["imgs"][:n_frames]), np.ascontiguousarray(d["T"][:n_frames])
     tex = synth.make_texture(seed=12345)
     T = synth.make_trajectory(n_frames, seed=seed, max_step=0.02, max_rot_deg=0.3)
     return cam, synth.render(tex, T, cam).numpy(), T
@@ -237,15 +245,24 @@ def test_mock_device_arena_modes_and_no_prediction(mock_lib, tmp_path):
         "r = pp.run_sequence('hipmock', cam, imgs, T, stats_out=st)\n"
         "np.save(sys.argv[1], np.stack([x['T_f_w'] for x in r]))\n"
         "print(st['predicted_pose_hits'], st['predicted_pose_misses'])\n")
+    from concurrent.futures import ThreadPoolExecutor
+    _, imgs_, T_ = _sequence(50)                        # rendered once, here; the children load it and start together
+    seq_file = str(tmp_path / "sequence.npz")
+    np.savez(seq_file, imgs=imgs_, T=T_)
     out, hits = {}, {}
-    for name, env in (("hybrid", {}), ("mirrored", {"SVO_HIP_ARENA": "mirrored"}), ("mapped", {"SVO_HIP_ARENA": "mapped"}),
-                      ("no_prediction", {"SVO_HIP_SPECULATE": "0"}), ("second_batch", {"SVO_HIP_FIRST_BATCH_CELLS": "40"})):
+
+    def child(name, env):
         path = str(tmp_path / f"traj_{name}.npy")
-        p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True,
-                           timeout=600)
+        p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, SVO_TEST_SEQ_FILE=seq_file, **env), capture_output=True,
+                           text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
-        out[name] = np.load(path)
-        hits[name] = [int(x) for x in p.stdout.split()[-2:]]
+        return np.load(path), [int(x) for x in p.stdout.split()[-2:]]
+
+    modes = (("hybrid", {}), ("mirrored", {"SVO_HIP_ARENA": "mirrored"}), ("mapped", {"SVO_HIP_ARENA": "mapped"}),
+             ("no_prediction", {"SVO_HIP_SPECULATE": "0"}), ("second_batch", {"SVO_HIP_FIRST_BATCH_CELLS": "40"}))
+    with ThreadPoolExecutor(max_workers=len(modes)) as ex:
+        for (name, _), res in zip(modes, ex.map(lambda m: child(*m), modes)):
+            out[name], hits[name] = res
     for name in ("mirrored", "mapped", "no_prediction", "second_batch"):
         assert np.array_equal(out[name], out["hybrid"]), name
     assert hits["hybrid"] == [49, 0] and hits["mirrored"] == [49, 0] and hits["mapped"] == [49, 0] and hits["no_prediction"] == [0, 0]
@@ -348,8 +365,12 @@ def test_mock_device_map_mirror_is_the_list_walk(mock_lib, tmp_path):
         "small": ("hipmock", 130, V, dict(pool_slots=7)),
         "off130": ("hipmock", 130, {"SVO_HIP_MAP_MIRROR": "off"}, dict(pool_slots=7)),
     }
+    cam_, imgs_, T_ = _sequence(n)                      # rendered once, here; the children load it
+    seq_file = str(tmp_path / "sequence.npz")
+    np.savez(seq_file, imgs=imgs_, T=T_)
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        fut = {tag: ex.submit(_run_mirror, fl, k, env, tmp_path, tag, **cfg) for tag, (fl, k, env, cfg) in runs.items()}
+        fut = {tag: ex.submit(_run_mirror, fl, k, dict(env, SVO_TEST_SEQ_FILE=seq_file), tmp_path, tag, **cfg)
+               for tag, (fl, k, env, cfg) in runs.items()}
         res = {tag: f.result() for tag, f in fut.items()}
     (off, s_off), (ver, s_ver) = res["off"], res["verify"]
     assert np.array_equal(ver, off)
