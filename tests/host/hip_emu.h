@@ -138,6 +138,13 @@ extern "C" char __stop_svo_lds[] __attribute__((weak, visibility("hidden")));
 // arrays here) are exempt.  What is reported then is global memory that one workgroup writes and another
 // reads or writes without an atomic: results that depend on the order the workgroups happen to run in.  (A work-item
 // of one workgroup and the work-item of the same index of the next are the same sanitizer thread: not looked at.)
+inline int schedule_mode() {  // 0: in order; 1: SVO_EMU_SCHEDULE=reverse; 2: =waves
+  static const int m = [] {
+    const char* e = std::getenv("SVO_EMU_SCHEDULE");
+    return !e ? 0 : (e[0] == 'r' ? 1 : (e[0] == 'w' ? 2 : 0));
+  }();
+  return m;
+}
 inline bool between_workgroups_mode() {
   static const bool on = [] { const char* e = std::getenv("SVO_EMU_TSAN_BETWEEN_WORKGROUPS"); return e && e[0] == '1'; }();
   return on;
@@ -253,7 +260,11 @@ SVO_EMU_NOTSAN inline void run_block(Block& b, std::function<void()>& body, size
   }
   while (b.alive > 0) {
     bool progressed = false;
-    for (unsigned t = 0; t < n; ++t) {  // run every runnable work-item up to its next barrier
+    for (unsigned k = 0; k < n; ++k) {  // run every runnable work-item up to its next barrier
+      // SVO_EMU_SCHEDULE=reverse: the work-items (and, in launch(), the workgroups) take their turns in the opposite order;
+      // =waves: the waves in the opposite order, the lanes of a wave in order.  Nothing a kernel computes may depend on it.
+      const unsigned t = schedule_mode() == 1 ? n - 1 - k : (schedule_mode() == 2 ? (((n - 1 - k) & ~63u) | (k & 63u)) : k);
+      if (t >= n) continue;
       Fiber& f = b.fibers[t];
       if (f.done || f.waiting_on >= 0) continue;
       g_fiber = &f;
@@ -349,12 +360,12 @@ SVO_EMU_NOTSAN void launch(dim3 grid, dim3 block, F&& body_in) {
   blk.bdim = block;
   blk.gdim = grid;
   const size_t stack_bytes = 256 * 1024;
-  for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx) {
-        blk.bid = dim3(bx, by, bz);
-        run_block(blk, body, stack_bytes, bx + by + bz == 0, bx + 1 == grid.x && by + 1 == grid.y && bz + 1 == grid.z);
-      }
+  const unsigned long long n_blocks = (unsigned long long)grid.x * grid.y * grid.z;
+  for (unsigned long long i = 0; i < n_blocks; ++i) {
+    const unsigned long long j = schedule_mode() ? n_blocks - 1 - i : i;  // (reversed schedules: the last workgroup first)
+    blk.bid = dim3((unsigned)(j % grid.x), (unsigned)((j / grid.x) % grid.y), (unsigned)(j / ((unsigned long long)grid.x * grid.y)));
+    run_block(blk, body, stack_bytes, i == 0, i + 1 == n_blocks);
+  }
 }
 
 // the running work-item meets the other lanes of its wave that reach call site `site`; returns what they offered

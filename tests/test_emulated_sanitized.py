@@ -157,3 +157,15 @@ def test_the_race_detector_between_workgroups(tmp_path, mode, between, racy):
     n, text = _races(log)
     assert "exact 128" in r.stdout, r.stderr[-3000:]
     assert (n >= 1 and "two_workgroups" in text) if racy else n == 0, text[:4000]
+
+
+@pytest.mark.parametrize("schedule", ["reverse", "waves"])
+def test_results_do_not_depend_on_the_schedule(schedule):
+    """SVO_EMU_SCHEDULE: the emulator lets the work-items and workgroups (reverse), or the waves (waves), take their turns in the
+    opposite order.  The parity tests -- bit-exact ones among them: the phased alignment with its atomically filled queues,
+    FAST's per-cell maxima, the scan's dynamic group fetch -- must not notice (a child: the mode is read once per process)."""
+    tests = [t for t in SUBSET if t.startswith("tests/")] + ["tests/test_entries_emulated.py::test_emulated_align_batch_and_its_phased_form[default]",
+                                                             "tests/test_fast_emulated.py::test_emulated_fast_detect_bit_exact"]
+    r = subprocess.run([sys.executable, "-m", "pytest", *tests, "-q", "-x", "-p", "no:cacheprovider"], capture_output=True, text=True,
+                       timeout=1500, cwd=ROOT, env=dict(os.environ, SVO_EMU_SCHEDULE=schedule))
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout + r.stderr)[-4000:]
