@@ -1,6 +1,6 @@
 #!/bin/bash
 # The experiments queued at the end of round 4 (GPU minutes had run out): opt-in compile-time variants that were
-# cross-compiled, read in the ISA and -- all nine -- run on the CPU emulation against the oracle (tests/test_*_emulated.py,
+# cross-compiled, read in the ISA and -- all ten -- run on the CPU emulation against the oracle (tests/test_*_emulated.py,
 # also under AddressSanitizer / ThreadSanitizer), but never executed on a GPU.
 #   CPU side first:   bash scripts/round5_queue.sh build
 #   then              gpurun --timeout 900 -- 'bash scripts/round5_queue.sh 2>&1 | tee gpurun_out/r05a_queue.txt'
