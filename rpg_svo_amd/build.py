@@ -25,7 +25,13 @@ def _newer(target: str, sources: list[str]) -> bool:
     return all(os.path.getmtime(s) <= t for s in sources)
 
 
+# Compile-time flags of the DEFAULT library.  An opt-in build that wins its A/B on the GPU (scripts/round5_queue.sh) becomes
+# the default by being named here -- one line (the test suite compiles its CPU checks of the kernels with the same list).
+DEFAULT_DEFINES: list[str] = []
+
+
 def _compile_one(src: str, obj: str, defines: list[str], verbose: bool) -> None:
+    defines = list(dict.fromkeys([*DEFAULT_DEFINES, *defines]))
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
            # SLP packing (v_pk_*_f32) costs register pairs + moves in the pixel loops
            "-fno-slp-vectorize",

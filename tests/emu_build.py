@@ -54,7 +54,8 @@ def build_race_probe():
 
 def build_emulated(defines=()):
     # SVO_EMU_EXTRA_DEFINES="A B": added to every emulated build of the run (e.g. the whole round-5 queue on the default tests)
-    defines = tuple(dict.fromkeys(tuple(defines) + tuple(os.environ.get("SVO_EMU_EXTRA_DEFINES", "").split())))
+    from rpg_svo_amd.build import DEFAULT_DEFINES   # (the default library's own flags: the emulated default build has them too)
+    defines = tuple(dict.fromkeys(tuple(DEFAULT_DEFINES) + tuple(defines) + tuple(os.environ.get("SVO_EMU_EXTRA_DEFINES", "").split())))
     tag = "".join("_" + d.replace("=", "-") for d in defines)
     if len(tag) > 80:
         import hashlib
