@@ -7,8 +7,8 @@
 # Stage 0 times ALL candidates together (one library, `svo_hip_queue`) against the default build: K1, the full track per
 # stage, the single-stream frame -- three minutes that say whether the set as a whole wins.  Stage 1 (skipped with
 # `bash scripts/round5_queue.sh stage0`) runs the GPU parity tests on each variant library and times it alone, so that a
-# loser inside the set can be found.  A variant that fails a test is dropped; one that wins becomes the default and its
-# flag is inverted.
+# loser inside the set can be found.  A variant that fails a test is dropped; one that wins becomes the default by being
+# named in rpg_svo_amd/build.py::DEFAULT_DEFINES (the emulated default build of the CPU suite follows that list).
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
