@@ -31,16 +31,22 @@ namespace svo {
 // ---- the update, on the device ---------------------------------------------------------------
 void DepthFilter::updateSeeds(FramePtr frame) {
   svo_hip::Device::joinDeferredAll();  // the previous frame's update writes into seeds_ first (takes seeds_mut_ itself)
-  lock_t lock(seeds_mut_);
-  if (seeds_updating_halt_) return;  // the halt flag is honoured between launches
-  const size_t S = seeds_.size();
-  if (S == 0) return;
-
+  {  // (nothing to do: do not touch the device)
+    lock_t peek(seeds_mut_);
+    if (seeds_updating_halt_ || seeds_.empty()) return;
+  }
   using namespace hip_dropin;
   svo_hip::Device& dev = ensureDevice(*frame);
   const int L = svo_hip::Device::LANE_MAPPING;
   svo_hip::Lane& lane = dev.lane(L);
+  // Lock order: the lane, then the seed list -- the order the deferred closure below takes them in when a later call joins it
+  // (it runs under the lane's mutex and locks seeds_mut_ itself).  The other way round here would be a lock-order inversion
+  // (ThreadSanitizer names it), harmless only as long as every path joins before it locks.
   std::lock_guard<std::mutex> guard(lane.mut);
+  lock_t lock(seeds_mut_);
+  if (seeds_updating_halt_) return;  // the halt flag is honoured between launches
+  const size_t S = seeds_.size();
+  if (S == 0) return;
   dev.beginCall(L);
   svo_hip::StageTimer stage_timer(dev, lane, svo_hip::Device::STAGE_DEPTH_FILTER);
   svo_hip::Arena& a = lane.arena;
