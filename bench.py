@@ -140,9 +140,15 @@ def compact_line(result: dict, details_path: str | None) -> dict:
                                                        "algorithmic_bytes_per_frame", "ms_last_10_launches", "kernel_ms_avg"))
     if isinstance(result.get("roofline_valu"), dict):
         c["roofline"]["valu_busy_frac"] = result["roofline_valu"].get("frac")
+    f64 = result.get("f64_partials")
+    if isinstance(f64, dict) and isinstance(f64.get("roofline"), dict):
+        # the reference-width build of the same kernel (-DSIA_F64_PARTIALS), measured in the same run: its own line
+        c["roofline_f64_build"] = dict(_pick(f64["roofline"], ("achieved", "peak", "frac", "ms", "traffic", "traffic_over_algorithmic")),
+                                       value=f64.get("frames_per_s"), unit="frames/s")
     if "cpu_baseline" in result:
-        c["cpu_baseline"] = _pick(result["cpu_baseline"], ("value", "unit", "cores", "kind", "sample_short", "cpu_model",
-                                                           "value_best_threads", "best_threads", "host_logical_cpus", "skipped"))
+        c["cpu_baseline"] = _pick(result["cpu_baseline"], ("value", "unit", "cores", "kind", "sample_short", "cpu_model", "value_release_flags",
+                                                           "value_best_threads", "value_release_flags_best_threads", "best_threads",
+                                                           "host_logical_cpus", "skipped"))
         if "sample_short" in c["cpu_baseline"]:
             c["cpu_baseline"]["sample"] = c["cpu_baseline"].pop("sample_short")
     if "parity" in result:
@@ -1094,11 +1100,13 @@ def lds_port_use(raw: dict) -> dict:
             "sdk_formula_idx_active_over_gui_active_x_cus": ratio(idx, gui * N_CU if gui else None)}
 
 
-def pmc_leg(args, kernel_ms: float, reserve_s: float = 0.0) -> dict:
+def pmc_leg(args, kernel_ms: float, reserve_s: float = 0.0, only: tuple | None = None, lib_path: str | None = None,
+            k1_kernel: str | None = None) -> dict:
     """HBM traffic and VALU issue of the headline kernel, measured on THIS box by re-running this
     command (headline leg only, 3 steps) under rocprofv3 --pmc, one counter group per pass as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit one
-    pass; no trace domain is combined with --pmc)."""
+    pass; no trace domain is combined with --pmc).  only: the passes to run (default all); lib_path: the library
+    variant the children load (SVO_HIP_LIB; default: the one this process runs on)."""
     import csv
     import glob
     import shutil
@@ -1108,7 +1116,7 @@ def pmc_leg(args, kernel_ms: float, reserve_s: float = 0.0) -> dict:
         return {"skipped": "rocprofv3 not on PATH"}
     base = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--batch", str(args.batch),
             "--workload", args.workload, "--noise", str(args.noise), "--n-iter", str(args.n_iter), "--no-cpu-baseline",
-            "--extras", "none", "--pmc-child", "1", "--k1-kernel", args.k1_kernel]
+            "--extras", "none", "--pmc-child", "1", "--k1-kernel", k1_kernel or args.k1_kernel]
     passes = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
               "sq": ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
                      "SQ_INSTS_VALU", "SQ_BUSY_CU_CYCLES"],
@@ -1119,8 +1127,12 @@ def pmc_leg(args, kernel_ms: float, reserve_s: float = 0.0) -> dict:
                        "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_BRANCH"],
               # the LDS port of the CU (lds_port_use); last: a failure here costs nothing that came before
               "lds": ["SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS"]}
+    if only is not None:
+        passes = {k: v for k, v in passes.items() if k in only}
     status, raw = {}, {}
     env = dict(os.environ, TMPDIR="/tmp")
+    if lib_path:
+        env["SVO_HIP_LIB"] = lib_path
     env.pop("SVO_BENCH_FORCE_DIST", None)
     # a pass takes ~16 s; a profiler that hangs or fails must not hold the headline line back: one strike and the
     # remaining passes are skipped (worst case PMC_PASS_TIMEOUT_S on top of the run)
@@ -1609,6 +1621,19 @@ def f64_partials_leg(args, T_default, iters_default, result) -> dict:
            "slowdown": result["value"] / child["value"],
            "vs_default_kernel": {"se3_lognorm_max": float(se3.log_norm(T64, T_default).max()),
                                  "same_iteration_counts_frac": float(np.mean((it64 == iters_default).all(1)))}}
+    # its own roofline line: the child's HIP-event average over its timed launches, its own algorithmic bytes (its own
+    # iteration counts), and the counter traffic of two more children under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE)
+    rl = dict(child["roofline"])
+    try:
+        pm = pmc_leg(args, child["roofline"]["ms"], only=("fetch", "write"), lib_path=F64_VARIANT_LIB, k1_kernel="workgroup")
+        rl["traffic"] = pm.get("traffic_bytes_per_launch")
+        if rl["traffic"]:
+            rl["traffic_over_algorithmic"] = rl["traffic"] / rl["algorithmic_bytes_per_launch"]
+        rl["pmc_passes"] = pm.get("passes")
+    except Exception as e:
+        rl["traffic"] = None
+        rl["pmc_passes"] = repr(e)
+    out["roofline"] = rl
     if _CPU_REF:
         S = len(_CPU_REF["iters"])
         for name, T, it in (("f64_partials", T64, it64), ("default", T_default, iters_default)):
@@ -1675,9 +1700,26 @@ def cpu_baseline(args, W: Workload, T_est_w, result, iters_gpu) -> dict:
         model = "unknown"
     impl = ("the reference's own sparse_img_align.cpp (oracle/_ref/libsvo_ref.so, g++ -O3 against dependency shims), "
             "run() calls only") if which == "ref" else "oracle/libsvo_oracle.so (C port, gcc -O3)"
+    # the same translation unit built with the reference's own release flags (svo/CMakeLists.txt:34-45: -O3 -funroll-loops
+    # -fno-signed-zeros ..., -march=native as x86-64-v3; oracle/Makefile target ref_release): what the CPU path does when it
+    # is built for speed, not for bit-comparability -- one thread and the best thread count of the sweep above
+    release = {}
+    if which == "ref" and pyoracle.ref_release_available():
+        try:
+            which_saved, which = which, "ref_release"
+            _, _, t1r = timed(s1, 1)
+            Tr_, _, tnr = timed(S, best_threads)
+            which = which_saved
+            release = {"value_release_flags": s1 / t1r, "value_release_flags_best_threads": S / tnr,
+                       "release_flags": "g++ -O3 -march=x86-64-v3 -funroll-loops -fno-signed-zeros -fomit-frame-pointer -fsee "
+                                        "-fno-math-errno (svo/CMakeLists.txt:34-45 with -march=native -> x86-64-v3)",
+                       "release_vs_bit_comparable_build_se3_lognorm_max": float(se3.log_norm(Tr_, T_cpu).max())}
+        except Exception as e:
+            which = which_saved
+            release = {"value_release_flags": None, "release_flags_skipped": repr(e)}
     # headline: ONE core, the reference's own execution model (tracking is single-threaded, frame_handler_mono.cpp);
     # the thread sweep over frame pairs is the throughput comparison for batched replay and sits beside it
-    return {"value": s1 / t1, "unit": "frames/s", "cores": 1, "kind": "reference" if which == "ref" else "port",
+    return {**release, "value": s1 / t1, "unit": "frames/s", "cores": 1, "kind": "reference" if which == "ref" else "port",
             "sample": f"{s1} of the benchmark's own frame pairs on one thread, {impl}",
             "sample_short": f"{s1} of the same frame pairs, 1 thread, " + ("reference's own sparse_img_align.cpp" if which == "ref" else "C port"),
             "value_best_threads": best_rate, "best_threads": best_threads,

@@ -102,8 +102,8 @@ typedef struct svo_hip_pyr_layout {
 /* svo_hip_pyr_layout::tile.  TILED (what svo_hip_pyr_layout_init produces): byte offset of pixel (x, y) inside
  * its level = (y / 8) * 8 * pitch + (x / 16) * 128 + (y % 8) * 16 + x % 16, i.e. 16 x 8 pixel tiles of one
  * 128-byte line each, the tiles of an 8-row band consecutive; a level occupies pitch * roundup8(h) bytes.
- * ROWMAJOR (y * pitch + x) exists only in -DSVO_PYR_ROWMAJOR builds of the library (A/B timing); every entry
- * point rejects a layout of the other kind with SVO_HIP_EINVAL. */
+ * ROWMAJOR (y * pitch + x) names the layout of rounds 1-2, which no kernel of this library addresses any more: every
+ * entry point rejects a layout that is not TILED with SVO_HIP_EINVAL. */
 #define SVO_HIP_PYR_ROWMAJOR 0
 #define SVO_HIP_PYR_TILED 1
 

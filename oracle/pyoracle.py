@@ -83,6 +83,25 @@ def ref_lib() -> C.CDLL:
     return _ref_lib
 
 
+_ref_release_lib = None
+
+
+def ref_release_available() -> bool:
+    from . import pytrack
+    return os.path.exists(pytrack.REF_RELEASE_LIB_PATH)
+
+
+def ref_release_lib() -> C.CDLL:
+    """oracle/_ref/libsvo_ref_release.so: the reference's translation units with the reference's release flags
+    (oracle/Makefile, target ref_release) -- timed by bench.py's cpu_baseline next to the bit-comparable build, never
+    compared bit for bit.  RTLD_DEEPBIND: it exports the same symbols as libsvo_ref.so and must bind to its own."""
+    global _ref_release_lib
+    if _ref_release_lib is None:
+        from . import pytrack
+        _ref_release_lib = C.CDLL(pytrack.REF_RELEASE_LIB_PATH, mode=os.RTLD_LOCAL | os.RTLD_NOW | os.RTLD_DEEPBIND)
+    return _ref_release_lib
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -208,9 +227,9 @@ def sparse_img_align_batch(pyrs, ref_slot, cur_slot, cam, T_ref_w, T_cur_w, n, p
     nn = np.ascontiguousarray(n, dtype=np.int32)
     opt = SiaOptions(max_level, min_level, n_iter, eps)
     res = (SiaResult * B)()
-    if which == "ref":  # the reference's own SparseImgAlign (oracle/_ref/libsvo_ref.so)
+    if which in ("ref", "ref_release"):  # the reference's own SparseImgAlign (oracle/_ref/libsvo_ref[_release].so)
         secs = C.c_double(0)
-        ref_lib().ref_sparse_img_align_batch(C.c_int(B), arr, _p(rs), _p(cs), C.byref(pc), _p(Tr), _p(Tc), _p(nn),
+        (ref_lib() if which == "ref" else ref_release_lib()).ref_sparse_img_align_batch(C.c_int(B), arr, _p(rs), _p(cs), C.byref(pc), _p(Tr), _p(Tc), _p(nn),
                                              C.c_int(n_stride), _p(px), _p(f), _p(hp), _p(pos), C.byref(opt), res,
                                              C.c_int(n_threads), C.byref(secs))
         if timing is not None:

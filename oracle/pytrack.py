@@ -19,6 +19,7 @@ from .pyoracle import MAX_LEVELS, Pinhole, Pyramid, SiaOptions, SiaResult, _f64,
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_LIB_PATH = os.path.join(HERE, "_ref", "libsvo_ref.so")
+REF_RELEASE_LIB_PATH = os.path.join(HERE, "_ref", "libsvo_ref_release.so")  # the same units, the reference's release flags
 REFERENCE_ROOT = os.environ.get("SVO_REFERENCE", "/root/reference")
 
 SEED_ERASED_OLD, SEED_BEHIND, SEED_NOT_IN_FRAME, SEED_NO_MATCH, SEED_UPDATED, SEED_CONVERGED, SEED_NAN = range(1, 8)
@@ -105,7 +106,7 @@ def build_ref(force: bool = False) -> bool:
     Returns True when oracle/_ref/libsvo_ref.so exists afterwards."""
     if not os.path.isdir(os.path.join(REFERENCE_ROOT, "svo", "src")):
         return ref_available()
-    args = ["make", "-C", HERE, "ref", f"REF={REFERENCE_ROOT}"] + (["-B"] if force else [])
+    args = ["make", "-C", HERE, "ref", "ref_release", f"REF={REFERENCE_ROOT}"] + (["-B"] if force else [])
     subprocess.run(args, check=True, stdout=subprocess.DEVNULL)
     return ref_available()
 

@@ -25,20 +25,12 @@ using namespace svo_dev;
 // re-derives the 64 template intensities from the bytes in flight: one v_cvt_f32_ubyte per pixel.  Emits no instruction.
 #ifdef SVO_HOST_MATH_TEST
 #define ALIGN_OPAQUE_TEMPLATE(g) ((void)0)
-#define ALIGN_OPAQUE_G(G) ((void)0)
 #else
 #define ALIGN_OPAQUE_TEMPLATE(g)                                                                                   \
   asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]), "+v"(g[7]),  \
                "+v"(g[8]), "+v"(g[9]), "+v"(g[10]), "+v"(g[11]), "+v"(g[12]));                                        \
   asm volatile("" : "+v"(g[13]), "+v"(g[14]), "+v"(g[15]), "+v"(g[16]), "+v"(g[17]), "+v"(g[18]), "+v"(g[19]),       \
                "+v"(g[20]), "+v"(g[21]), "+v"(g[22]), "+v"(g[23]), "+v"(g[24]))
-
-// the same for the 64 gradient words of the ALIGN_G_F16 build: their conversions to f32 stay inside the iteration
-#define ALIGN_OPAQUE_G(G)                                         \
-  asm volatile("" : "+v"(G[0]), "+v"(G[1]), "+v"(G[2]), "+v"(G[3]), "+v"(G[4]), "+v"(G[5]), "+v"(G[6]), "+v"(G[7]), "+v"(G[8]), "+v"(G[9]), "+v"(G[10]), "+v"(G[11]), "+v"(G[12]), "+v"(G[13]), "+v"(G[14]), "+v"(G[15]));  \
-  asm volatile("" : "+v"(G[16]), "+v"(G[17]), "+v"(G[18]), "+v"(G[19]), "+v"(G[20]), "+v"(G[21]), "+v"(G[22]), "+v"(G[23]), "+v"(G[24]), "+v"(G[25]), "+v"(G[26]), "+v"(G[27]), "+v"(G[28]), "+v"(G[29]), "+v"(G[30]), "+v"(G[31]));  \
-  asm volatile("" : "+v"(G[32]), "+v"(G[33]), "+v"(G[34]), "+v"(G[35]), "+v"(G[36]), "+v"(G[37]), "+v"(G[38]), "+v"(G[39]), "+v"(G[40]), "+v"(G[41]), "+v"(G[42]), "+v"(G[43]), "+v"(G[44]), "+v"(G[45]), "+v"(G[46]), "+v"(G[47]));  \
-  asm volatile("" : "+v"(G[48]), "+v"(G[49]), "+v"(G[50]), "+v"(G[51]), "+v"(G[52]), "+v"(G[53]), "+v"(G[54]), "+v"(G[55]), "+v"(G[56]), "+v"(G[57]), "+v"(G[58]), "+v"(G[59]), "+v"(G[60]), "+v"(G[61]), "+v"(G[62]), "+v"(G[63]))
 #endif
 __device__ __forceinline__ void cut_row9(const uint32_t d[3], uint32_t sel, float out[9]);
 // bytes [x0, x0+8] of the image row at byte offset ro (svo_pyr::row_off) as floats: one 12-byte run of three aligned
@@ -96,15 +88,7 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
   // then subtractions and fused multiply-adds, no integer extraction.
   typedef float f2 __attribute__((ext_vector_type(2)));
   float H[9];
-#ifdef ALIGN_G_F16
-  // (round-5 queue, UNMEASURED: the gradients are half-integers of magnitude <= 127.5 -- EXACT in f16 -- so the 64 {dx, dy}
-  // pairs fit 64 registers instead of 128 and the kernel three waves per SIMD instead of two (it waits for an iteration's
-  // window fetch 48 % of its wave cycles); two conversions per pixel and iteration bring them back, same values.)
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  uint32_t G[64];  // {dx, dy} as two f16
-#else
   f2 G[64];  // {dx, dy} of every template pixel (:176-181), formed once
-#endif
   {
     float sxx = 0.f, sxy = 0.f, syy = 0.f, sx = 0.f, sy = 0.f;
 #pragma unroll
@@ -119,11 +103,7 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
         syy = __builtin_fmaf(gy2, gy2, syy);
         sx += gx2;
         sy += gy2;
-#ifdef ALIGN_G_F16
-        G[8 * y + x] = __builtin_bit_cast(uint32_t, (h2){(_Float16)(0.5f * gx2), (_Float16)(0.5f * gy2)});
-#else
         G[8 * y + x] = (f2){0.5f * gx2, 0.5f * gy2};  // == 0.5f * (float)(int difference): the difference is exact either way
-#endif
       }
     H[0] = 0.25f * sxx;
     H[1] = H[3] = 0.25f * sxy;
@@ -140,9 +120,6 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
   bool left = false;  // the loop was left by a break
   for (int iter = it0; iter < it_end; ++iter) {
     ALIGN_OPAQUE_TEMPLATE(g);
-#ifdef ALIGN_G_F16
-    ALIGN_OPAQUE_G(G);
-#endif
     const int u_r = floor_int(u);
     const int v_r = floor_int(v);
     if (u_r < 4 || v_r < 4 || u_r >= cols - 4 || v_r >= rows - 4) {
@@ -164,15 +141,10 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
     const int wxa = (u_r - 4) & ~3;
     const uint32_t wsel = (uint32_t)((u_r - 4) & 3);
     float P0[9], P1[9];
-#ifndef ALIGN_ROW_LOADS  // all nine rows fetched up front, ONE three-way branch on the tile position for the window
     // (a branch per row measured 2.15 against 1.68 ms for findMatchDirect on 3.3 M trials)
     uint32_t win[9][3];
     svo_pyr::load_window12<9>(img, pitch, wxa, v_r - 4, win);
     cut_row9(win[0], wsel, P0);
-#else
-    load_row9(img, svo_pyr::row_off(v_r - 4, pitch), wxa, wsel, P0);
-#endif
-#ifndef ALIGN_NO_PACKED
     // The pixel loop in packed f32 (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per issue slot; every product and
     // sum is rounded on its own, in the reference's order, so the bits do not change).  Pixels x and x+4 of a row
     // form a pair for the interpolation and the residual -- the row is kept as Q[k] = {P[k], P[k+4]}, which serves
@@ -185,11 +157,7 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
     for (int k = 0; k < 5; ++k) Q0[k] = (f2){P0[k], P0[k + 4]};
 #pragma unroll
     for (int y = 0; y < 8; ++y) {
-#ifndef ALIGN_ROW_LOADS
       cut_row9(win[y + 1], wsel, P1);
-#else
-      load_row9(img, svo_pyr::row_off(v_r - 3 + y, pitch), wxa, wsel, P1);
-#endif
 #pragma unroll
       for (int k = 0; k < 5; ++k) Q1[k] = (f2){P1[k], P1[k + 4]};
       f2 res2[4];
@@ -203,14 +171,7 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
 #pragma unroll
       for (int x = 0; x < 8; ++x) {  // raster order: x = 0..3 are the low halves, 4..7 the high halves
         const float res = (x < 4) ? res2[x].x : res2[x - 4].y;
-#ifdef ALIGN_G_F16
-        {
-          const h2 gh = __builtin_bit_cast(h2, G[8 * y + x]);
-          J01 -= (f2){res, res} * (f2){(float)gh.x, (float)gh.y};
-        }
-#else
         J01 -= (f2){res, res} * G[8 * y + x];
-#endif
         Jres2 -= res;
       }
 #pragma unroll
@@ -218,27 +179,6 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
     }
     Jres0 = J01.x;
     Jres1 = J01.y;
-#else
-#pragma unroll
-    for (int y = 0; y < 8; ++y) {
-#ifndef ALIGN_ROW_LOADS
-      cut_row9(win[y + 1], wsel, P1);
-#else
-      load_row9(img, svo_pyr::row_off(v_r - 3 + y, pitch), wxa, wsel, P1);
-#endif
-#pragma unroll
-      for (int x = 0; x < 8; ++x) {
-        const int c = (y + 1) * 10 + x + 1;
-        const float search_pixel = wTL * P0[x] + wTR * P0[x + 1] + wBL * P1[x] + wBR * P1[x + 1];
-        const float res = search_pixel - (float)PWB(c) + mean_diff;
-        Jres0 -= res * (0.5f * (float)(PWB(c + 1) - PWB(c - 1)));
-        Jres1 -= res * (0.5f * (float)(PWB(c + 10) - PWB(c - 10)));
-        Jres2 -= res;
-      }
-#pragma unroll
-      for (int k = 0; k < 9; ++k) P0[k] = P1[k];
-    }
-#endif
     const float up0 = Hinv[0] * Jres0 + Hinv[1] * Jres1 + Hinv[2] * Jres2;
     const float up1 = Hinv[3] * Jres0 + Hinv[4] * Jres1 + Hinv[5] * Jres2;
     const float up2 = Hinv[6] * Jres0 + Hinv[7] * Jres1 + Hinv[8] * Jres2;
@@ -311,21 +251,13 @@ __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, in
     const int wxa = (u_r - 4) & ~3;
     const uint32_t wsel = (uint32_t)((u_r - 4) & 3);
     float P0[9], P1[9];
-#ifndef ALIGN_ROW_LOADS  // all nine rows fetched up front, ONE three-way branch on the tile position for the window
     // (a branch per row measured 2.15 against 1.68 ms for findMatchDirect on 3.3 M trials)
     uint32_t win[9][3];
     svo_pyr::load_window12<9>(img, pitch, wxa, v_r - 4, win);
     cut_row9(win[0], wsel, P0);
-#else
-    load_row9(img, svo_pyr::row_off(v_r - 4, pitch), wxa, wsel, P0);
-#endif
 #pragma unroll
     for (int y = 0; y < 8; ++y) {
-#ifndef ALIGN_ROW_LOADS
       cut_row9(win[y + 1], wsel, P1);
-#else
-      load_row9(img, svo_pyr::row_off(v_r - 3 + y, pitch), wxa, wsel, P1);
-#endif
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
         const int c = (y + 1) * 10 + x + 1;

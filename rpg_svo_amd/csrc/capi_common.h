@@ -32,7 +32,7 @@ inline int check_launch() {
 
 inline bool layout_ok(const svo_hip_pyr_layout* L) {
   if (!L || L->n_levels < 1 || L->n_levels > SVO_HIP_MAX_LEVELS) return false;
-  if (L->tile != (SVO_PYR_TILE ? SVO_HIP_PYR_TILED : SVO_HIP_PYR_ROWMAJOR)) return false;  // made for the other build
+  if (L->tile != SVO_HIP_PYR_TILED) return false;  // the only layout the kernels address (pyr_addr.h)
   for (int i = 0; i < L->n_levels; ++i)
     if (L->w[i] < 1 || L->h[i] < 1 || L->pitch[i] < L->w[i] || (L->pitch[i] & 15) || (L->offset[i] & 127)) return false;
   return L->slot_bytes > 0;

@@ -233,15 +233,14 @@ int svo_hip_pyr_layout_init(int width, int height, int n_levels, svo_hip_pyr_lay
   if (!out || width < 1 || height < 1 || n_levels < 1 || n_levels > SVO_HIP_MAX_LEVELS) return SVO_HIP_EINVAL;
   std::memset(out, 0, sizeof(*out));
   out->n_levels = n_levels;
-  out->tile = SVO_PYR_TILE ? SVO_HIP_PYR_TILED : SVO_HIP_PYR_ROWMAJOR;
+  out->tile = SVO_HIP_PYR_TILED;
   int w = width, h = height;
   int64_t off = 0;
   for (int i = 0; i < n_levels; ++i) {
     if (w < 1 || h < 1) return SVO_HIP_EINVAL;  // pyramid deeper than the image allows
     out->w[i] = w;
     out->h[i] = h;
-    // tiled: 16-byte tile columns; the row-major A/B build keeps the 64-byte pitch of rounds 1-2
-    out->pitch[i] = SVO_PYR_TILE ? ((w + 15) & ~15) : ((w + 63) & ~63);
+    out->pitch[i] = (w + 15) & ~15;  // 16-byte tile columns
     out->offset[i] = off;
     off += svo_pyr::level_bytes(out->pitch[i], h);
     off = (off + 255) & ~static_cast<int64_t>(255);

@@ -53,10 +53,9 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   w.n_steps[s] = 0;
   w.accepted_raw[s] = 0;
   const int cf = a.cur_frame[s];
-#ifdef SEED_LOAD_FIRST
-  // (round-5 queue, UNMEASURED: every record of the seed is requested before the first early exit -- two memory round
-  // trips, (cf, rfi, batch id, mu, sigma2, f) then (the two poses, the slot), instead of three or four: a load below an
-  // early exit cannot be issued above it by the compiler.  The kernel waits 54 % of its wave cycles.)
+  // Every record of the seed is requested before the first early exit -- two memory round trips, (cf, rfi, batch id, mu,
+  // sigma2, f) then (the two poses, the slot), instead of three or four: a load below an early exit cannot be issued above
+  // it by the compiler (360 -> 315 us per 3.3 M seeds, profiles/r05a_queue_drain.txt).
   const int rfi = a.ftr.d_frame[s];
   // (the seed state does not exist in match-only calls: read through stand-in pointers, see below)
   const int batch_raw = (a.match_only ? a.ftr.d_level : a.seeds.d_batch_id)[s];
@@ -88,20 +87,6 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   Se3 Tr, Tc;
   se3_from_Rt(RtR, Tr);
   se3_from_Rt(RtC, Tc);
-#else
-  w.cur_slot[s] = a.frame_slot[cf];
-  // check if seed is not already too old (:216-219)
-  if (!a.match_only && (a.opt.batch_counter - a.seeds.d_batch_id[s]) > a.opt.max_n_kfs) {
-    w.status[s] = SVO_HIP_SEED_ERASED_OLD;
-    return;
-  }
-  const int rfi = a.ftr.d_frame[s];
-  Se3 Tr, Tc;
-  se3_from_Rt(a.frame_T + 12 * rfi, Tr);
-  se3_from_Rt(a.frame_T + 12 * cf, Tc);
-  const float mu = a.match_only ? 1.f : a.seeds.d_mu[s], sigma2 = a.match_only ? 0.f : a.seeds.d_sigma2[s];
-  const double f[3] = {a.ftr.d_f[3 * s], a.ftr.d_f[3 * s + 1], a.ftr.d_f[3 * s + 2]};
-#endif
   // visibility (:221-232)
   if (!a.match_only) {
     const Se3 T_ref_cur = se3_compose(Tr, se3_inverse(Tc));
@@ -141,22 +126,12 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   se3_apply(T_cur_ref, p, q);
   project2d(q, B);
   const double epi_dir[2] = {A[0] - B[0], A[1] - B[1]};
-#ifdef SEED_LOAD_FIRST
   const int rlevel = rlevel_early;
   const double rpx[2] = {rpx0_early, rpx1_early};
-#else
-  const int rlevel = a.ftr.d_level[s];
-  const double rpx[2] = {a.ftr.d_px[2 * s], a.ftr.d_px[2 * s + 1]};
-#endif
   double Am[4];
   warp_matrix_affine(a.cam, rpx, f, d_estimate, T_cur_ref, rlevel, Am);
-#ifdef SEED_LOAD_FIRST
   if (a.ftr.d_type && type_early == SVO_HIP_FTR_EDGELET && a.opt.epi_search_edgelet_filtering) {
     const double gx = gx_early, gy = gy_early;
-#else
-  if (a.ftr.d_type && a.ftr.d_type[s] == SVO_HIP_FTR_EDGELET && a.opt.epi_search_edgelet_filtering) {
-    const double gx = a.ftr.d_grad[2 * s], gy = a.ftr.d_grad[2 * s + 1];
-#endif
     double g[2] = {Am[0] * gx + Am[1] * gy, Am[2] * gx + Am[3] * gy};
     const double gn = norm2(g);
     g[0] /= gn;
@@ -187,11 +162,7 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   w.A_ref_cur[4 * s + 3] = (float)Ainv[3];
   w.px_ref_pyr[2 * s] = (float)rpx[0] / (float)(1 << rlevel);
   w.px_ref_pyr[2 * s + 1] = (float)rpx[1] / (float)(1 << rlevel);
-#ifdef SEED_LOAD_FIRST
   w.ref_slot[s] = ref_slot_early;
-#else
-  w.ref_slot[s] = a.frame_slot[rfi];
-#endif
   w.ref_level[s] = rlevel;
   w.warp_active[s] = 1;
   {  // (px_A-px_B).cast<float>().normalized()
@@ -234,13 +205,7 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
 // rejected) never enter the order.  Results do not depend on the order.
 // four waves per SIMD (128 VGPRs, 29 dwords spilled outside the position loop) measured 2 % faster for update_seeds
 // than three (162 VGPRs, no spills): the scan waits on its box fetch once per pass
-#ifndef SCAN_MINW
-#ifdef SCAN_PREFETCH
-#define SCAN_MINW 3  // the box in flight and the next pass's geometry need ~30 registers more: no spills inside the pass loop at 168
-#else
-#define SCAN_MINW 4
-#endif
-#endif
+constexpr int SCAN_MINW = 4;
 __global__ void __launch_bounds__(SCAN_BLOCK, SCAN_MINW) epi_scan_kernel(const SeedArgs a) {
   __shared__ uint16_t s_order[SCAN_CHUNK];
   __shared__ int s_hist[SCAN_BUCKETS], s_off[SCAN_BUCKETS], s_next, s_n;
@@ -286,26 +251,17 @@ __global__ void __launch_bounds__(SCAN_BLOCK, SCAN_MINW) epi_scan_kernel(const S
     if (wl == 0) p = atomicAdd(&s_next, GROUPS);
     p = __builtin_amdgcn_readfirstlane(p);
     if (p >= n_scan) break;
-#if defined(SCAN_PREFETCH) && SCAN_BOX
-    if (p + grp < n_scan) epi_scan_seed_prefetch(a, base + (int)s_order[p + grp], lane, s_box[threadIdx.x / SCAN_G]);
-#else
     if (p + grp < n_scan) epi_scan_seed(a, base + (int)s_order[p + grp], lane, s_box[threadIdx.x / SCAN_G]);
-#endif
   }
 }
 
-#ifdef SEED_LOAD_FIRST
 #define SEED_FINISH_BOUNDS __launch_bounds__(64, 5)  // the early loads cost six registers: held to five waves per SIMD as before
-#else
-#define SEED_FINISH_BOUNDS __launch_bounds__(64)
-#endif
 __global__ void SEED_FINISH_BOUNDS seed_finish_kernel(const SeedArgs a) {
   const int s = blockIdx.x * 64 + threadIdx.x;
   if (s >= a.S) return;
   const SeedWs& w = a.ws;
-#ifdef SEED_LOAD_FIRST
-  // (round-5 queue, UNMEASURED: every record the seed may need is requested before the first early exit -- see
-  // seed_prepare_kernel.  Workspace words of a seed that did not get that far hold whatever they held: read, not used.)
+  // every record the seed may need is requested before the first early exit, as in seed_prepare_kernel (259 -> 243 us).
+  // Workspace words of a seed that did not get that far hold whatever they held: read, not used.
   const int cf = a.cur_frame[s];
   const int rfi = a.ftr.d_frame[s];
   const int aok_early = w.align_ok[s];
@@ -322,54 +278,31 @@ __global__ void SEED_FINISH_BOUNDS seed_finish_kernel(const SeedArgs a) {
     RtR[k] = a.frame_T[12 * rfi + k];
     RtC[k] = a.frame_T[12 * cf + k];
   }
-#endif
   int status = w.status[s];
   const bool aligned = w.align_active[s] != 0;  // a short segment, or a scan match handed to the sub-pixel alignment
   if (a.px_cur_out) {
     // Matcher::px_cur_ exists once the seed reached the alignment (set by seed_prepare for a short segment, by the scan
     // for a match, refined by the alignment) or was accepted straight from the scan; 0 otherwise
     const bool has_px = aligned || w.accepted_raw[s] != 0;
-#ifdef SEED_LOAD_FIRST
     a.px_cur_out[2 * s] = has_px ? pxc0 : 0.0;
     a.px_cur_out[2 * s + 1] = has_px ? pxc1 : 0.0;
-#else
-    a.px_cur_out[2 * s] = has_px ? w.px_cur[2 * s] : 0.0;
-    a.px_cur_out[2 * s + 1] = has_px ? w.px_cur[2 * s + 1] : 0.0;
-#endif
   }
   if (status == SVO_HIP_SEED_ERASED_OLD || status == SVO_HIP_SEED_BEHIND || status == SVO_HIP_SEED_NOT_IN_FRAME) {
     a.status_out[s] = status;
     return;
   }
-#ifdef SEED_LOAD_FIRST
   Se3 Tr, Tc;
   se3_from_Rt(RtR, Tr);
   se3_from_Rt(RtC, Tc);
-#else
-  const int cf = a.cur_frame[s];
-  const int rfi = a.ftr.d_frame[s];
-  Se3 Tr, Tc;
-  se3_from_Rt(a.frame_T + 12 * rfi, Tr);
-  se3_from_Rt(a.frame_T + 12 * cf, Tc);
-  const double f[3] = {a.ftr.d_f[3 * s], a.ftr.d_f[3 * s + 1], a.ftr.d_f[3 * s + 2]};
-#endif
   bool matched = false;
   double z = 0;
   if (status == 0) {
-#ifdef SEED_LOAD_FIRST
     const int aok = aligned ? aok_early : 0;
-#else
-    const int aok = aligned ? w.align_ok[s] : 0;  // (written by the alignment kernel for every trial it is launched on)
-#endif
     const Se3 T_cur_ref = se3_compose(Tc, se3_inverse(Tr));
     if (aligned && aok == 1) {
       // px_cur_ = px_scaled*(1<<search_level_) was written by the alignment kernel
       double fc[3];
-#ifdef SEED_LOAD_FIRST
       cam2world(a.cam, pxc0, pxc1, fc);
-#else
-      cam2world(a.cam, w.px_cur[2 * s], w.px_cur[2 * s + 1], fc);
-#endif
       matched = depth_from_triangulation(T_cur_ref, f, fc, &z);
     } else if (w.accepted_raw[s]) {
       // subpix_refinement == false: vk::unproject2d(uv_best).normalized()
@@ -384,12 +317,7 @@ __global__ void SEED_FINISH_BOUNDS seed_finish_kernel(const SeedArgs a) {
     if (a.search_level_out) a.search_level_out[s] = w.search_level[s];
     return;
   }
-#ifdef SEED_LOAD_FIRST
   const float zr = zr_early;
-#else
-  float sa = a.seeds.d_a[s], sb = a.seeds.d_b[s], smu = a.seeds.d_mu[s], ssig = a.seeds.d_sigma2[s];
-  const float zr = a.seeds.d_z_range[s];
-#endif
   if (!matched) {
     a.seeds.d_b[s] = sb + 1.0f;  // it->b++ (:240)
     a.status_out[s] = SVO_HIP_SEED_NO_MATCH;
@@ -398,11 +326,7 @@ __global__ void SEED_FINISH_BOUNDS seed_finish_kernel(const SeedArgs a) {
   // law of chord (depth_filter.cpp:252-255): atan(px_noise / (2 * focal_length)) * 2 depends on the camera alone -- computed
   // once on the host (run_seed_chain), by the libm the reference itself runs on
   const Se3 T_ref_cur = se3_compose(Tr, se3_inverse(Tc));
-#ifdef TAU_ALGEBRAIC
   const double tau = compute_tau(T_ref_cur, f, z, a.tau_k);
-#else
-  const double tau = compute_tau(T_ref_cur, f, z, a.px_error_angle);
-#endif
   const double zmt = (0.0000001 < z - tau) ? z - tau : 0.0000001;
   const double tau_inverse = 0.5 * (1.0 / zmt - 1.0 / (z + tau));
   update_seed((float)(1. / z), (float)(tau_inverse * tau_inverse), sa, sb, smu, zr, ssig);
@@ -453,9 +377,7 @@ struct TauArgs {
   const double* f;
   const double* z;
   double px_error_angle;
-#ifdef TAU_ALGEBRAIC
   TauConsts tau_k;
-#endif
   double* tau;
 };
 __global__ void __launch_bounds__(256) compute_tau_kernel(const TauArgs a) {
@@ -465,11 +387,7 @@ __global__ void __launch_bounds__(256) compute_tau_kernel(const TauArgs a) {
   T.q[0] = 1.0; T.q[1] = T.q[2] = T.q[3] = 0.0;  // only the translation enters computeTau
   for (int k = 0; k < 3; ++k) T.t[k] = a.t_ref_cur[3 * s + k];
   const double f[3] = {a.f[3 * s], a.f[3 * s + 1], a.f[3 * s + 2]};
-#ifdef TAU_ALGEBRAIC
   a.tau[s] = compute_tau(T, f, a.z[s], a.tau_k);
-#else
-  a.tau[s] = compute_tau(T, f, a.z[s], a.px_error_angle);
-#endif
 }
 
 }  // namespace
@@ -481,9 +399,7 @@ extern "C" int svo_hip_compute_tau_batch(int S, const double* d_t_ref_cur, const
   if (!d_t_ref_cur || !d_f || !d_z || !d_tau) return SVO_HIP_EINVAL;
   TauArgs a;
   a.S = S; a.t_ref_cur = d_t_ref_cur; a.f = d_f; a.z = d_z; a.px_error_angle = px_error_angle; a.tau = d_tau;
-#ifdef TAU_ALGEBRAIC
   a.tau_k = tau_consts(px_error_angle);
-#endif
   hipLaunchKernelGGL(compute_tau_kernel, dim3((S + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return check_launch();
 }
@@ -579,9 +495,7 @@ static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_sto
   {
     const double focal_length = fabs(a.cam.fx), px_noise = 1.0;
     a.px_error_angle = atan(px_noise / (2.0 * focal_length)) * 2.0;
-#ifdef TAU_ALGEBRAIC
     a.tau_k = tau_consts(a.px_error_angle);
-#endif
   }
   SeedWs& w = a.ws;
   w.n_steps = c.take<int32_t>(n);  // first array of the workspace: svo_hip_update_seeds_scan_steps

@@ -238,7 +238,6 @@ __device__ __forceinline__ void se3_exp_f32(const float xi[6], float q[4], float
   const float ox = xi[3], oy = xi[4], oz = xi[5];
   const float z = ox * ox + oy * oy + oz * oz;  // theta^2
   const float y = 0.25f * z;                    // (theta/2)^2
-#ifndef SE3_EXP_LONG_ONLY
   if (z < 0.01f) {
     float a = 1.f / 5040.f;
     a = a * -y + 1.f / 120.f;
@@ -269,7 +268,6 @@ __device__ __forceinline__ void se3_exp_f32(const float xi[6], float q[4], float
     t[2] = uz + c1 * wz + c2 * wwz;
     return;
   }
-#endif
   // sinc(th/2) = sum (-1)^k y^k/(2k+1)!,  cos(th/2) = sum (-1)^k y^k/(2k)!
   float a = 1.f / 355687428096000.f;
   a = a * -y + 1.f / 1307674368000.f;
@@ -329,7 +327,6 @@ __device__ __forceinline__ void se3_exp_rot_f32(const float xi[6], float q[4]) {
   const float z = ox * ox + oy * oy + oz * oz;
   const float y = 0.25f * z;
   float a, w;
-#ifndef SE3_EXP_LONG_ONLY
   if (z < 0.01f) {
     a = 1.f / 5040.f;
     a = a * -y + 1.f / 120.f;
@@ -340,7 +337,6 @@ __device__ __forceinline__ void se3_exp_rot_f32(const float xi[6], float q[4]) {
     w = w * -y + 0.5f;
     w = w * -y + 1.f;
   } else
-#endif
   {
     a = 1.f / 355687428096000.f;
     a = a * -y + 1.f / 1307674368000.f;
@@ -371,7 +367,6 @@ __device__ __forceinline__ void se3_exp_trans_f32(const float xi[6], float t[3])
   const float ox = xi[3], oy = xi[4], oz = xi[5];
   const float z = ox * ox + oy * oy + oz * oz;
   float c1, c2;
-#ifndef SE3_EXP_LONG_ONLY
   if (z < 0.01f) {
     c1 = 1.f / 40320.f;
     c1 = c1 * -z + 1.f / 720.f;
@@ -382,7 +377,6 @@ __device__ __forceinline__ void se3_exp_trans_f32(const float xi[6], float t[3])
     c2 = c2 * -z + 1.f / 120.f;
     c2 = c2 * -z + 1.f / 6.f;
   } else
-#endif
   {
     c1 = 1.f / 6402373705728000.f;
     c1 = c1 * -z + 1.f / 20922789888000.f;

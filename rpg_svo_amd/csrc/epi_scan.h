@@ -1,12 +1,14 @@
 // epi_scan.h -- the depth filter's workspace layout and the ZMSSD scan along the epipolar line (matcher.cpp:248-291) of ONE
-// seed by a group of SCAN_LANES lanes, as epi_scan_kernel (depth_filter.hip) runs it; the queued variant that requests
-// the next pass's box ahead (-DSCAN_PREFETCH) next to it.  Also compiled for the CPU by the test suite: there the
-// cross-lane moves are served by a small SIMT emulation (tests/host/hip_emu.h: one fiber per lane) and the
-// two forms are run on the same seeds and compared bit for bit (tests/test_scan_emulated.py).
+// seed by a group of SCAN_LANES lanes, as epi_scan_kernel (depth_filter.hip) runs it.  Also compiled for the CPU by the
+// test suite: there the cross-lane moves are served by a small SIMT emulation (tests/host/hip_emu.h: one fiber per lane,
+// tests/test_scan_emulated.py).
+// (Requesting the NEXT pass's box before this pass is scored -- 16 registers in flight, three waves per SIMD -- measured
+// 8 % slower, and 42 % slower held to four waves: profiles/r05a_queue_drain.txt.)
 #pragma once
 #include "track_math.h"
 #include "pyr_addr.h"
 #include "matcher_device.h"
+#include "seed_math.h"
 #include "wave_reduce.h"
 
 using namespace svo_dev;
@@ -68,9 +70,7 @@ struct SeedArgs {
   int32_t* ok_out;
   int32_t* search_level_out;
   double px_error_angle;  // atan(1 / (2 |fx|)) * 2
-#ifdef TAU_ALGEBRAIC
   TauConsts tau_k;         // its sines and cosines (seed_math.h)
-#endif
   SeedWs ws;
 };
 
@@ -88,11 +88,9 @@ constexpr int SCAN_BLOCK = 256;
 // lanes had no step of their own, and every lane still replays the chain of additions.  8 lanes per seed
 // share the chain replay between eight seeds of a wave and keep the lanes busy (update_seeds on 3.3 M seeds:
 // 3.24 ms at 64 lanes per seed, 2.74 at 32, 2.47 at 16, 2.33 at 8).
-#ifndef SCAN_LANES
-#define SCAN_LANES 8
-#endif
+constexpr int SCAN_LANES = 8;
 constexpr int SCAN_G = SCAN_LANES;
-static_assert(SCAN_G == 4 || SCAN_G == 8 || SCAN_G == 16 || SCAN_G == 32 || SCAN_G == 64, "SCAN_LANES");
+static_assert(SCAN_G == 8, "the box fetch and the DPP minima below are written for groups of 8 lanes");
 
 // Seeds per workgroup of the scan.  The seeds of a chunk are ordered by scan length inside the workgroup (below).
 constexpr int SCAN_CHUNK = 1024;
@@ -104,11 +102,6 @@ constexpr int SCAN_BUCKETS = 8;
 // the bounding box of its windows ONCE, as 16-byte tile rows of the store (one look-up each, at most 16 rows x 2
 // columns of tiles = 4 per lane), parks it in LDS and every lane cuts its window out of that; a group whose windows do
 // not fit a 16 x 32 box (never on an undistorted line) falls back to fetching per lane.
-#ifndef SCAN_NO_BOX
-#define SCAN_BOX (SCAN_LANES == 8)
-#else
-#define SCAN_BOX 0
-#endif
 constexpr int SCAN_BOX_DWORDS = 16 * 8 + 4;  // 16 rows x 32 bytes (+ one dword: the cut reads three dwords per row)
 
 template <int CTRL>
@@ -203,7 +196,6 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
     }
     uint32_t sumB = 0, sumBB = 0, sumAB = 0;
     bool boxed = false;
-#if SCAN_BOX
     {
       // bounding box of the group's windows [px-4, px+3]^2 (every lane of the group takes part, wanted or not)
       const int x_lo = group8_min(want ? pxi0 - 4 : 0x7fffffff), x_hi = group8_max(want ? pxi0 + 3 : -1);
@@ -249,7 +241,6 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
         SVO_LANES_LDS_HANDOVER();
       }
     }
-#endif
     if (want) {
       if (!boxed) {
         // 8 rows x 8 bytes [pxi0-4, pxi0+3]: 12-byte runs, inside one tile row of the store where the 8 bytes are
@@ -315,202 +306,5 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
   if (lane == 0 && !(win_score < ZMSSD_THRESHOLD)) w.status[s] = SVO_HIP_SEED_NO_MATCH;
 }
 
-#if defined(SCAN_PREFETCH) && SCAN_BOX
-// (round-5 queue, UNMEASURED.)  The same scan with the NEXT pass's box requested before this pass is scored.  A pass is
-// "positions -> box -> fetch -> wait -> score" and the wave waits for the fetch once per pass (57 % of the wave cycles at
-// four waves per SIMD, profiles/r04u_*); the positions of pass k + 1 do not depend on the scores of pass k -- the chain of
-// additions is known -- so its geometry is computed and its box requested while the box of pass k is still being scored.
-// The box of a pass travels in 16 registers from its fetch to its store into LDS at the top of the next iteration (the
-// LDS box is single: stored after the previous pass's reads, in program order of one wave).  Results are the reference's:
-// the same positions, in the same order, with the same arithmetic.
-struct ScanPass {
-  int i, pxi0, pxi1, y_lo, cx0, n_chunks;
-  bool want, two, boxed;
-  double uv0, uv1;
-};
-__device__ __forceinline__ void epi_scan_seed_prefetch(const SeedArgs& a, const int s, const int lane, uint32_t* box) {
-  const SeedWs& w = a.ws;
-  const int sl = w.search_level[s];
-  const uint8_t* img = a.store + (int64_t)w.cur_slot[s] * a.L.slot_bytes + a.L.offset[sl];
-  const int pitch = a.L.pitch[sl];
-  uint32_t ra[16];
-  {
-    const uint8_t* pw = w.pwb + (size_t)s * 100;
-#pragma unroll
-    for (int y = 0; y < 8; ++y) {
-      const uint8_t* r = pw + (y + 1) * 10 + 1;
-      uint32_t lo, hi;
-      __builtin_memcpy(&lo, r, 4);
-      __builtin_memcpy(&hi, r + 4, 4);
-      ra[2 * y] = lo;
-      ra[2 * y + 1] = hi;
-    }
-  }
-  uint32_t sumA_u = 0, sumAA_u = 0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    sumA_u = __builtin_amdgcn_udot4(ra[k], 0x01010101u, sumA_u, false);
-    sumAA_u = __builtin_amdgcn_udot4(ra[k], ra[k], sumAA_u, false);
-  }
-  const int sumA = (int)sumA_u, sumAA = (int)sumAA_u;
-  const double step0 = w.step[2 * s], step1 = w.step[2 * s + 1];
-  double uv0 = w.B[2 * s] - step0, uv1 = w.B[2 * s + 1] - step1;
-  const int n_total = w.n_steps[s] + 1;
-  int best = ZMSSD_THRESHOLD;
-  int best_i = 0x7fffffff;
-  double best_uv0 = 0, best_uv1 = 0;
-  const double lvl = (double)(1 << sl);
-  const double inv_lvl = 1.0 / lvl;
-  {
-    const int lead = lane < n_total ? lane : n_total;
-    for (int j = 0; j < lead; ++j) {
-      uv0 += step0; uv1 += step1;
-    }
-  }
-  int carry0 = 0, carry1 = 0;
-
-  // positions, "is a new pixel inside the frame", box of the group's windows for the pass that starts at step `base`;
-  // leaves uv0 / uv1 at this lane's step of the pass after it
-  auto geometry = [&](const int base, ScanPass& g) {
-    g.i = base + lane;
-    g.uv0 = uv0;
-    g.uv1 = uv1;
-    g.pxi0 = g.pxi1 = 0;
-    if (g.i < n_total) {
-      double pxs[2];
-      const double uvs[2] = {uv0, uv1};
-      world2cam_uv(a.cam, uvs, pxs);
-      g.pxi0 = cast_int(pxs[0] * inv_lvl + 0.5);
-      g.pxi1 = cast_int(pxs[1] * inv_lvl + 0.5);
-    }
-    const int left0 = __builtin_amdgcn_update_dpp(0, g.pxi0, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
-    const int left1 = __builtin_amdgcn_update_dpp(0, g.pxi1, 0x111, 0xf, 0xf, true);
-    const int prv0 = lane == 0 ? carry0 : left0, prv1 = lane == 0 ? carry1 : left1;
-    g.want = g.i < n_total && !(g.pxi0 == prv0 && g.pxi1 == prv1) && is_in_frame_level(a.cam, g.pxi0, g.pxi1, 8, sl);
-    const int last = (int)(threadIdx.x & 63u & ~(unsigned)(SCAN_G - 1)) + SCAN_G - 1;
-    carry0 = __shfl(g.pxi0, last, 64);
-    carry1 = __shfl(g.pxi1, last, 64);
-    const int x_lo = group8_min(g.want ? g.pxi0 - 4 : 0x7fffffff), x_hi = group8_max(g.want ? g.pxi0 + 3 : -1);
-    const int y_lo = group8_min(g.want ? g.pxi1 - 4 : 0x7fffffff), y_hi = group8_max(g.want ? g.pxi1 + 3 : -1);
-    g.y_lo = y_lo;
-    g.cx0 = x_lo & ~15;
-    const int n_rows = y_hi - y_lo + 1;
-    g.two = x_hi - g.cx0 >= 16;
-    g.boxed = x_hi >= 0 && n_rows <= 16 && x_hi - g.cx0 < 32;
-    g.n_chunks = g.boxed ? (g.two ? 2 * n_rows : n_rows) : 0;
-    if (base + SCAN_G < n_total) {
-      for (int j = 0; j < SCAN_G; ++j) {
-        uv0 += step0; uv1 += step1;
-      }
-    }
-  };
-  auto request = [&](const ScanPass& g, uint4 v[4]) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = lane + 8 * k;
-      const int row = g.two ? (c >> 1) : c, cc = g.two ? (c & 1) : 0;
-      v[k] = make_uint4(0, 0, 0, 0);
-      if (c < g.n_chunks) v[k] = *reinterpret_cast<const uint4*>(img + (svo_pyr::row_off(g.y_lo + row, pitch) + svo_pyr::col_off(g.cx0 + 16 * cc)));
-    }
-  };
-  auto park = [&](const ScanPass& g, const uint4 v[4]) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = lane + 8 * k;
-      const int row = g.two ? (c >> 1) : c, cc = g.two ? (c & 1) : 0;
-      if (c < g.n_chunks) *reinterpret_cast<uint4*>(box + row * 8 + cc * 4) = v[k];
-    }
-    SVO_LANES_LDS_HANDOVER();
-  };
-  auto score = [&](const ScanPass& g) {
-    uint32_t sumB = 0, sumBB = 0, sumAB = 0;
-    if (g.want) {
-      if (g.boxed) {
-        const int bx = g.pxi0 - 4 - g.cx0;
-        const uint32_t sel = (uint32_t)(bx & 3);
-        const uint32_t* r = box + (g.pxi1 - 4 - g.y_lo) * 8 + (bx >> 2);
-#pragma unroll
-        for (int y = 0; y < 8; ++y) {
-          const uint32_t d0 = r[8 * y], d1 = r[8 * y + 1], d2 = r[8 * y + 2];
-          const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sel), hi = __builtin_amdgcn_alignbyte(d2, d1, sel);
-          sumB = __builtin_amdgcn_udot4(lo, 0x01010101u, sumB, false);
-          sumB = __builtin_amdgcn_udot4(hi, 0x01010101u, sumB, false);
-          sumBB = __builtin_amdgcn_udot4(lo, lo, sumBB, false);
-          sumBB = __builtin_amdgcn_udot4(hi, hi, sumBB, false);
-          sumAB = __builtin_amdgcn_udot4(lo, ra[2 * y], sumAB, false);
-          sumAB = __builtin_amdgcn_udot4(hi, ra[2 * y + 1], sumAB, false);
-        }
-      } else {
-        const int wxa = svo_pyr::run_start(g.pxi0 - 4, 8);
-        const uint32_t wbo = (uint32_t)(g.pxi0 - 4 - wxa);
-        uint32_t win[8][3];
-        svo_pyr::load_window12<8>(img, pitch, wxa, g.pxi1 - 4, win);
-#pragma unroll
-        for (int y = 0; y < 8; ++y) {
-          uint32_t lo, hi;
-          cut_row8(win[y], wbo, lo, hi);
-          sumB = __builtin_amdgcn_udot4(lo, 0x01010101u, sumB, false);
-          sumB = __builtin_amdgcn_udot4(hi, 0x01010101u, sumB, false);
-          sumBB = __builtin_amdgcn_udot4(lo, lo, sumBB, false);
-          sumBB = __builtin_amdgcn_udot4(hi, hi, sumBB, false);
-          sumAB = __builtin_amdgcn_udot4(lo, ra[2 * y], sumAB, false);
-          sumAB = __builtin_amdgcn_udot4(hi, ra[2 * y + 1], sumAB, false);
-        }
-      }
-      const int sB = (int)sumB, sBB = (int)sumBB, sAB = (int)sumAB;
-      const int zmssd = sumAA - 2 * sAB + sBB - (sumA * sumA - 2 * sumA * sB + sB * sB) / 64;
-      if (zmssd < best) {
-        best = zmssd;
-        best_i = g.i;
-        best_uv0 = g.uv0;
-        best_uv1 = g.uv1;
-      }
-    }
-    // the box is stored again at the top of the next iteration: after these reads
-    SVO_LANES_LDS_HANDOVER();
-  };
-
-  ScanPass cur, nxt;
-  uint4 v[4];
-  geometry(0, cur);
-  request(cur, v);
-  nxt = cur;
-  for (int base = 0; base < n_total; base += SCAN_G) {
-    park(cur, v);
-    if (base + SCAN_G < n_total) {
-      geometry(base + SCAN_G, nxt);
-      request(nxt, v);
-    }
-    score(cur);
-    cur = nxt;
-  }
-
-  unsigned long long key = ((unsigned long long)(unsigned)best << 32) | (unsigned)best_i;
-#pragma unroll
-  for (int off = SCAN_G / 2; off > 0; off >>= 1) {
-    const unsigned long long o = __shfl_xor(key, off, 64);
-    key = o < key ? o : key;
-  }
-  const int win_score = (int)(key >> 32);
-  const int win_i = (int)(key & 0xffffffffu);
-  if (win_score < ZMSSD_THRESHOLD && win_i == best_i && best < ZMSSD_THRESHOLD) {
-    w.uv_best[2 * s] = best_uv0;
-    w.uv_best[2 * s + 1] = best_uv1;
-    double pcs[2];
-    {
-      const double uvb[2] = {best_uv0, best_uv1};
-      world2cam_uv(a.cam, uvb, pcs);
-    }
-    const double pc0 = pcs[0], pc1 = pcs[1];
-    w.px_cur[2 * s] = pc0;
-    w.px_cur[2 * s + 1] = pc1;
-    w.px_scaled[2 * s] = pc0 / lvl;
-    w.px_scaled[2 * s + 1] = pc1 / lvl;
-    w.align_active[s] = a.opt.subpix_refinement ? 1 : 0;
-    w.accepted_raw[s] = a.opt.subpix_refinement ? 0 : 1;
-  }
-  if (lane == 0 && !(win_score < ZMSSD_THRESHOLD)) w.status[s] = SVO_HIP_SEED_NO_MATCH;
-}
-#endif
 
 }  // namespace

@@ -27,45 +27,15 @@ constexpr int ALIGN_BLOCK = 64;
 
 // Two waves per SIMD (<= 256 registers): with the bare __launch_bounds__(64) the compiler took 256 VGPRs plus 15-20
 // AGPRs, i.e. ONE wave per SIMD, and nothing hid the round trip of an iteration's window fetch.
-#ifndef ALIGN_MINW
-#ifdef ALIGN_G_F16
-#define ALIGN_MINW 3
-#else
-#define ALIGN_MINW 2
-#endif
-#endif
+constexpr int ALIGN_MINW = 2;
 template <bool COUNT>
 __global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const AlignArgs a) {
   // which trial: lane order in the first launch of a run, the queues filled by the previous launch afterwards
   // (workgroup b drains queue b % ALIGN_NQ, 64 entries at a time)
   int t;
-  // ALIGN_TEMPLATE_LDS (off: measured SLOWER twice, rounds 2 and 3 -- 12.25 against 11.90 ms for the full-track step).
-  // In list order the 64 templates of a workgroup are 6400 contiguous bytes; read per lane they are 25 dword gathers
-  // with a 100-byte lane stride, read as the block they are (seven coalesced 16-byte loads per lane) and handed out
-  // through LDS they are far fewer cache-line look-ups -- but the hand-over makes every lane wait for the whole block
-  // before its set-up arithmetic can start, and the gathers of neighbouring words hit the same line in L1 anyway.
-#ifdef ALIGN_TEMPLATE_LDS
-  __shared__ __attribute__((aligned(16))) uint32_t s_tpl[ALIGN_BLOCK * 25];
-  bool tpl_in_lds = false;
-  if (!a.queue_in) {
-    const long long first_t = (long long)blockIdx.x * ALIGN_BLOCK;  // wave-uniform: one wave per workgroup
-    const long long left = (long long)a.M - first_t;
-    const int n_dw = 25 * (int)(left < ALIGN_BLOCK ? left : ALIGN_BLOCK);
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.pwb + (size_t)first_t * 100);
-    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-      tpl_in_lds = true;
-#pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        const int q = 4 * ((int)threadIdx.x + ALIGN_BLOCK * k);  // first dword of this lane's quad
-        if (q + 3 < n_dw) *reinterpret_cast<uint4*>(&s_tpl[q]) = *reinterpret_cast<const uint4*>(src + q);
-        else
-          for (int j = q; j < n_dw && j < q + 4; ++j) s_tpl[j] = src[j];
-      }
-      // one wave: DS operations execute in order; keep the compiler from moving the reads below above the writes
-      SVO_WAVE_LDS_HANDOVER();
-    }
-  }
-#endif
+  // (The 64 templates of a workgroup read as the contiguous 6400-byte block they are and handed out through LDS measured
+  // slower twice, 12.25 against 11.90 ms per full-track step: every lane then waits for the whole block before its set-up
+  // arithmetic can start, and the per-lane gathers of neighbouring words hit the same line in L1 anyway.)
   if (a.queue_in) {
     const int q = blockIdx.x % ALIGN_NQ, i = (blockIdx.x / ALIGN_NQ) * ALIGN_BLOCK + threadIdx.x;
     if (i >= a.n_in[q]) return;
@@ -74,12 +44,11 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const Al
     t = blockIdx.x * ALIGN_BLOCK + threadIdx.x;
     if (t >= (a.M_dev ? min(*a.M_dev, a.M) : a.M)) return;
   }
-#ifdef ALIGN_LOAD_FIRST
-  // (round-5 queue, UNMEASURED: everything the trial needs before its first window -- the active flag, slot and level, the
-  // 25 template dwords, the start pixel or the parked state, the 1-D flag and direction -- is requested before the first
-  // of these values is looked at.  The default order tests the flag, then reads slot / level, then the template, then the
-  // pixel, then the 1-D flag, each behind its own wait: six memory round trips before the first of ~3 iterations of a
-  // phase, which is one round trip each.  Lanes that leave at once have read 130 bytes for nothing.)
+  // Everything the trial needs before its first window -- the active flag, slot and level, the 25 template dwords, the
+  // start pixel or the parked state, the 1-D flag and direction -- is requested before the first of these values is looked
+  // at.  Testing the flag, then reading slot / level, then the template, then the pixel, then the 1-D flag, each behind
+  // its own wait, was six memory round trips before the first of ~3 iterations of a phase, which is one round trip each
+  // (285 -> 279 us per launch, profiles/r05a_queue_drain.txt).  Lanes that leave at once have read 130 bytes for nothing.
   // (a load under a condition -- even a uniform one -- is waited for inside its branch, where its value is turned into
   // a mask: the optional arrays are read through a stand-in pointer to memory that is always there instead)
   const bool first = a.it0 == 0;
@@ -123,46 +92,6 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const Al
   } else {
     more = align2d_lane(img, cols, rows, pitch, g, a.n_iter, a.it0, a.it1, st, ok, wrote, n_eval);
   }
-#else
-  const bool first = a.it0 == 0;
-  if (first && a.active && !a.active[t]) {
-    a.ok[t] = 0;  // px_out is left as it is (findMatchDirect returns before touching px_cur)
-    if (COUNT) a.iters[t] = 0;
-    return;
-  }
-  const int level = a.level[t];
-  const uint8_t* img = a.store + (int64_t)a.slot[t] * a.L.slot_bytes + a.L.offset[level];
-  const int cols = a.L.w[level], rows = a.L.h[level], pitch = a.L.pitch[level];
-  uint32_t g[25];
-  {
-#ifdef ALIGN_TEMPLATE_LDS
-    const uint32_t* gp = tpl_in_lds ? &s_tpl[threadIdx.x * 25] : reinterpret_cast<const uint32_t*>(a.pwb + (size_t)t * 100);
-#else
-    const uint32_t* gp = reinterpret_cast<const uint32_t*>(a.pwb + (size_t)t * 100);
-#endif
-#pragma unroll
-    for (int k = 0; k < 25; ++k) g[k] = gp[k];
-  }
-  AlignState st;
-  if (first) {
-    st.u = (float)a.px_in[2 * t];
-    st.v = (float)a.px_in[2 * t + 1];
-    st.mean_diff = 0.f; st.chi2 = 0.f; st.up0 = 0.f; st.up1 = 0.f;
-  } else {
-    const float* sp = a.state + 6 * (size_t)t;
-    st.u = sp[0]; st.v = sp[1]; st.mean_diff = sp[2]; st.chi2 = sp[3]; st.up0 = sp[4]; st.up1 = sp[5];
-  }
-  bool wrote = true, ok = false, more;
-  int n_eval = 0;
-  const bool one_d = a.use_1d && a.use_1d[t];
-  if (one_d) {
-    double h_inv = 0;
-    more = align1d_lane(img, cols, rows, pitch, g, a.dir[2 * t], a.dir[2 * t + 1], a.n_iter, a.it0, a.it1, st, h_inv, ok, wrote, n_eval);
-    if (a.h_inv) a.h_inv[t] = h_inv;
-  } else {
-    more = align2d_lane(img, cols, rows, pitch, g, a.n_iter, a.it0, a.it1, st, ok, wrote, n_eval);
-  }
-#endif
   if (COUNT) a.iters[t] = (first ? 0 : a.iters[t]) + n_eval;
   if (a.queue_out) {
     // still iterating: park the loop state, append the trial to this workgroup's queue (one atomic per wave)
@@ -205,9 +134,7 @@ namespace svo_track {
 #define ALIGN_PHASE_MIN_M_VALUE (1 << 16)
 #endif
 constexpr int ALIGN_PHASE_MIN_M = ALIGN_PHASE_MIN_M_VALUE;  // below this the extra launches cost more than the idle lanes
-#ifndef ALIGN_PHASE_ITERS
-#define ALIGN_PHASE_ITERS 3
-#endif
+constexpr int ALIGN_PHASE_ITERS = 3;
 
 static int phase_queue_cap(int M) { return (M + ALIGN_NQ - 1) / ALIGN_NQ + 2 * ALIGN_BLOCK; }
 

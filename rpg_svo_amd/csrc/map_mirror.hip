@@ -121,10 +121,9 @@ __global__ void __launch_bounds__(RM_BLOCK) reproject_map_kernel(const ReprojMap
   const int P = mp.n_points, n_cells = a.grid.n_cells;
 
   // ---- 0. the host's changes since the last call -------------------------------------------------------------------
-#ifdef RM_PATCH_LOAD_FIRST
-  // (round-5 queue, UNMEASURED: every field of a record is read before the first store.  The loops below interleave loads
-  // and stores to arrays the compiler cannot prove distinct, so each load is waited for on its own: 10 `s_waitcnt vmcnt(0)`
-  // in the ISA of the point loop, one memory round trip each, on the critical path of a single-stream frame.)
+  // Every field of a record is read before the first store: the loops interleave loads and stores to arrays the compiler
+  // cannot prove distinct, so a load placed after a store is waited for on its own -- one memory round trip each, on the
+  // critical path of a single-stream frame.
   for (int i = tid; i < a.patch.n_obs; i += RM_BLOCK) {
     const int o = a.patch.d_obs_index[i];
     const int fr = a.patch.obs.d_frame[i], ord = a.patch.d_obs_order[i];
@@ -153,31 +152,6 @@ __global__ void __launch_bounds__(RM_BLOCK) reproject_map_kernel(const ReprojMap
     mp.d_obs_begin[p] = ob;
     mp.d_obs_count[p] = oc;
   }
-#else
-  for (int i = tid; i < a.patch.n_obs; i += RM_BLOCK) {
-    const int o = a.patch.d_obs_index[i];
-    const int fr = a.patch.obs.d_frame[i], ord = a.patch.d_obs_order[i];
-    mp.d_obs_frame[o] = fr;
-    mp.d_obs_order[o] = (int32_t)((uint32_t)fr << 16 | (ord < 0 ? 0xffffu : (uint32_t)ord & 0xffffu));
-    mp.d_obs_level[o] = a.patch.obs.d_level[i];
-    mp.d_obs_type[o] = a.patch.obs.d_type[i];
-    mp.d_obs_px[2 * o] = a.patch.obs.d_px[2 * i];
-    mp.d_obs_px[2 * o + 1] = a.patch.obs.d_px[2 * i + 1];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) mp.d_obs_f[3 * o + k] = a.patch.obs.d_f[3 * i + k];
-    mp.d_obs_grad[2 * o] = a.patch.obs.d_grad[2 * i];
-    mp.d_obs_grad[2 * o + 1] = a.patch.obs.d_grad[2 * i + 1];
-  }
-  for (int i = tid; i < a.patch.n_points; i += RM_BLOCK) {
-    const int p = a.patch.d_index[i];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) mp.d_pos[3 * p + k] = a.patch.d_pos[3 * i + k];
-    mp.d_type[p] = a.patch.d_type[i];
-    mp.d_order[p] = a.patch.d_order[i];
-    mp.d_obs_begin[p] = a.patch.d_obs_begin[i];
-    mp.d_obs_count[p] = a.patch.d_obs_count[i];
-  }
-#endif
   for (int k = tid; k < n_cells; k += RM_BLOCK) s_cnt[k] = 0;
   if (tid < RM_MAX_FRAMES) {
     s_kfrank[tid] = tid < a.n_frames ? a.kf_rank[tid] : -1;

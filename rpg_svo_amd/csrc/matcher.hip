@@ -62,11 +62,11 @@ struct PrepArgs {
 __global__ void __launch_bounds__(64) match_prepare_kernel(const PrepArgs a) {
   const int m = blockIdx.x * 64 + threadIdx.x;
   if (m >= (a.M_dev ? min(*a.M_dev, a.M) : a.M)) return;
-#ifdef PREP_LOAD_FIRST
-  // (round-5 queue, UNMEASURED: the trial's own records -- frame, projection, observation range, position -- are requested
-  // before anything is stored or looked at, the frame's pose and slot in a second round; in the closest-view loop the frame
-  // index of observation o + 1 is requested while observation o is worked on, so that an observation costs one dependent
-  // memory round trip, not two.  The default order makes ~8 round trips before the loop and two per observation.)
+  // The trial's own records -- frame, projection, observation range, position -- are requested before anything is stored
+  // or looked at, the frame's pose and slot in a second round; in the closest-view loop the frame index of observation
+  // o + 1 is requested while observation o is worked on, so that an observation costs one dependent memory round trip, not
+  // two (reading each value where it is first needed made ~8 round trips before the loop and two per observation: 262
+  // against 223 us per 16 384 frames, profiles/r05a_queue_drain.txt).
   const int cf = a.cur_frame[m];
   const double pxc0 = a.px_cur[2 * m], pxc1 = a.px_cur[2 * m + 1];
   // (either CSR offsets or begin / end arrays: read through one pointer each, a load under a condition is waited for in its branch)
@@ -119,48 +119,6 @@ __global__ void __launch_bounds__(64) match_prepare_kernel(const PrepArgs a) {
       best = o;
     }
   }
-#else
-  a.active[m] = 0;
-  a.ref_obs[m] = -1;
-  a.search_level[m] = 0;
-  a.ref_slot[m] = 0;
-  a.ref_level[m] = 0;
-  a.use_1d[m] = 0;
-  a.dir[2 * m] = 1.f;
-  a.dir[2 * m + 1] = 0.f;
-  const int cf = a.cur_frame[m];
-  a.cur_slot[m] = a.frame_slot[cf];
-  a.px_scaled[2 * m] = a.px_cur[2 * m];
-  a.px_scaled[2 * m + 1] = a.px_cur[2 * m + 1];
-  if (a.A_cur_ref) {
-    a.A_cur_ref[4 * m] = a.A_cur_ref[4 * m + 1] = a.A_cur_ref[4 * m + 2] = a.A_cur_ref[4 * m + 3] = 0.0;
-  }
-  const int o0 = a.obs_ptr ? a.obs_ptr[m] : a.obs_begin[m], o1 = a.obs_ptr ? a.obs_ptr[m + 1] : a.obs_end[m];
-  if (o1 <= o0) return;
-  Se3 Tc;
-  se3_from_Rt(a.frame_T + 12 * cf, Tc);
-  double cur_pos[3];
-  frame_pos(Tc, cur_pos);
-  const double pt[3] = {a.pt_pos[3 * m], a.pt_pos[3 * m + 1], a.pt_pos[3 * m + 2]};
-  // Point::getCloseViewObs (point.cpp:97-117)
-  double obs_dir[3] = {cur_pos[0] - pt[0], cur_pos[1] - pt[1], cur_pos[2] - pt[2]};
-  normalize3(obs_dir);
-  int best = o0;
-  double min_cos_angle = 0;
-  for (int o = o0; o < o1; ++o) {
-    Se3 Tf;
-    se3_from_Rt(a.frame_T + 12 * a.obs.d_frame[o], Tf);
-    double fp[3];
-    frame_pos(Tf, fp);
-    double dir[3] = {fp[0] - pt[0], fp[1] - pt[1], fp[2] - pt[2]};
-    normalize3(dir);
-    const double cos_angle = dot3(obs_dir, dir);
-    if (cos_angle > min_cos_angle) {
-      min_cos_angle = cos_angle;
-      best = o;
-    }
-  }
-#endif
   a.ref_obs[m] = best;
   if (min_cos_angle < 0.5) return;
   const int rfi = a.obs.d_frame[best];
@@ -218,19 +176,13 @@ __global__ void __launch_bounds__(64) match_prepare_kernel(const PrepArgs a) {
 // coalesced dwords.  Arithmetic per sample is unchanged (bit-identical patches).
 constexpr int WARP_TPW = 6;  // trials per wave
 constexpr int WARP_REG_ROWS = 24;  // rows of the LDS copy of a trial's source region (48 bytes each)
-#ifndef WARP_MINW
-#define WARP_MINW 4  // waves per SIMD the register budget is held to
-#endif
-#ifndef WARP_WGS_PER_CU
-#define WARP_WGS_PER_CU 16
-#endif
+constexpr int WARP_MINW = 4;  // waves per SIMD the register budget is held to
+constexpr int WARP_WGS_PER_CU = 16;
 __global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) {
   __shared__ long long s_off[SVO_HIP_MAX_LEVELS];
   __shared__ int s_w[SVO_HIP_MAX_LEVELS], s_h[SVO_HIP_MAX_LEVELS], s_p[SVO_HIP_MAX_LEVELS];
   __shared__ uint32_t s_patch[4][WARP_TPW * 25 + 2];
-#ifndef WARP_NO_REGION
   __shared__ __attribute__((aligned(16))) uint32_t s_region[4][WARP_TPW][WARP_REG_ROWS * 12 + 16];  // rows of 48 bytes
-#endif
   if (threadIdx.x < SVO_HIP_MAX_LEVELS) {
     s_off[threadIdx.x] = a.L.offset[threadIdx.x];
     s_w[threadIdx.x] = a.L.w[threadIdx.x];
@@ -275,9 +227,7 @@ __global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) 
     const long long m = m0 + t;
     const bool lane_on = lane < 10 * WARP_TPW && m < M;
     const TrialParams cur = nxt;
-#ifndef WARP_NO_PREFETCH
     if (gw + gw_step < n_wave_groups) nxt = load_params(gw + gw_step);
-#endif
     uint8_t out[10];
 #pragma unroll
     for (int y = 0; y < 10; ++y) out[y] = 0;
@@ -291,7 +241,6 @@ __global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) 
         const int cols = s_w[level], rows = s_h[level], pitch = s_p[level];
         const float sc = (float)(1 << slev);
         bool boxed = false;
-#ifndef WARP_NO_REGION
         // ---- the source region through LDS ------------------------------------------------------------------
         // The 100 samples of a trial lie in the parallelogram spanned by its four corner samples (the map is affine and
         // every rounding in it is monotone, so the extremes ARE the corners).  Its bounding box, at most WARP_REG_ROWS x
@@ -387,21 +336,12 @@ __global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) 
                   out[y] = in ? (uint8_t)val : (uint8_t)0;
                 }
               };
-#ifdef WARP_PACKED
-              // (round-5 queue: the packed-f32 sample arithmetic of warp_sample.h -- checked against the oracle bit for bit
-              // on the CPU by tests/test_device_math_host.py, not yet executed on a GPU.  The default build keeps the loop
-              // above, whose ISA is the measured one; warp_sample.h's warp_column<> is the same arithmetic as a function.)
-              if (all_in) warp_column_packed(A.x, A.y, A.z, A.w, pyr.x, pyr.y, sc, x, reg_o, out);
-              else warp_column<true>(A.x, A.y, A.z, A.w, pyr.x, pyr.y, sc, x, cols, rows, xlo, ylo, reg_o, out);
-#else
               if (all_in) rows10(std::false_type{});
               else rows10(std::true_type{});
-#endif
               SVO_LANES_LDS_HANDOVER();
             }
           }
         }
-#endif
         if (!boxed) {
         // round 2, five output rows at a time: addresses and weights of the five samples of this column, then all
           // their loads, then the arithmetic.  A sample reads the 2 x 2 pixels (xi, yi) .. (xi+1, yi+1) as two 16-bit
@@ -413,12 +353,10 @@ __global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) 
             float w00[5], w01[5], w10[5], w11[5];
             bool in[5];
             uint16_t top[5], bot[5];
-#if SVO_PYR_TILE
             uint32_t fix_t[5], fix_b[5];
             uint8_t rt8[5], rb8[5];
             bool cross[5];
             bool any_cross = false;
-#endif
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
               const int y = 5 * h + k;
@@ -439,20 +377,13 @@ __global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) 
               const uint32_t rt = svo_pyr::row_off(yi, pitch), rb = svo_pyr::row_off(yi + 1, pitch);
               const uint32_t cl = svo_pyr::col_off(xi);
               __builtin_memcpy(&top[k], img + (rt + cl), 2);
-#ifdef WARP_DBG_HALF_LOADS  // timing experiment only (wrong pixels): how much of the kernel is the gathers?
-              bot[k] = top[k];
-#else
               __builtin_memcpy(&bot[k], img + (rb + cl), 2);
-#endif
-#if SVO_PYR_TILE
               cross[k] = (xi & 15) == 15;  // pixel xi+1 is the first byte of the next tile
               any_cross = any_cross || cross[k];
               fix_t[k] = rt + cl + 113u;   // col_off(xi + 1) - col_off(xi) when xi % 16 == 15
               fix_b[k] = rb + cl + 113u;
               rt8[k] = rb8[k] = 0;
-#endif
             }
-#if SVO_PYR_TILE
             if (any_cross) {
 #pragma unroll
               for (int k = 0; k < 5; ++k)
@@ -461,15 +392,10 @@ __global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) 
                   rb8[k] = img[fix_b[k]];
                 }
             }
-#endif
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-#if SVO_PYR_TILE
               const float p10 = cross[k] ? (float)rt8[k] : (float)(top[k] >> 8);
               const float p11 = cross[k] ? (float)rb8[k] : (float)(bot[k] >> 8);
-#else
-              const float p10 = (float)(top[k] >> 8), p11 = (float)(bot[k] >> 8);
-#endif
               const float p00 = (float)(top[k] & 0xffu), p01 = (float)(bot[k] & 0xffu);
               const float val = w00[k] * p00 + w01[k] * p01 + w10[k] * p10 + w11[k] * p11;
               out[5 * h + k] = in[k] ? (uint8_t)val : (uint8_t)0;
@@ -491,9 +417,6 @@ __global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) 
       if (idx < n_dw) dst[idx] = s_patch[wave][idx];
     }
     SVO_WAVE_LDS_HANDOVER();
-#ifdef WARP_NO_PREFETCH
-    if (gw + gw_step < n_wave_groups) nxt = load_params(gw + gw_step);  // (A/B build: requested when they are needed)
-#endif
   }
 }
 

@@ -21,9 +21,7 @@ using namespace svo_dev;
 
 namespace {
 
-#ifndef PO_MINW
-#define PO_MINW 4
-#endif
+constexpr int PO_MINW = 4;
 constexpr int PO_HALF = 32;
 constexpr int PO_BLOCK = 64;  // one wave per frame: the serial parts dominate, occupancy comes from many small workgroups
 constexpr int PO_MAXN = 1024;

@@ -31,9 +31,7 @@ namespace {
 using svo_track::PoseWaveArgs;
 
 constexpr int PW_WAVES = 4;  // frames per workgroup
-#ifndef PW_MINW
-#define PW_MINW 3  // waves per SIMD asked of the register allocator (<= 168 VGPRs)
-#endif
+constexpr int PW_MINW = 3;  // waves per SIMD asked of the register allocator (<= 168 VGPRs)
 constexpr double SVO_EPS = 0.0000000001;  // svo/include/svo/global.h:77
 
 
@@ -252,52 +250,6 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_MINW) pose_opt_wave_kernel(c
   float kk[NPL];
   bool live[NPL];
   int n_err = 0;
-#ifdef POSE_LOAD_FIRST
-  // (round-5 queue, UNMEASURED: the flags of all NPL observations of the lane first, then all their records, then the
-  // arithmetic on them -- two memory round trips instead of two per observation slot: the loop below tests a flag, loads
-  // the record behind it and divides, slot after slot (`ld, wait, ld x5, wait` four times in the ISA of <4>).)
-  {
-    uint8_t hp[NPL];
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-      const int i = j * 64 + lane;
-      // (an unconditional load from a clamped index -- the row has n_stride >= 1 entries -- so that the NPL flag loads
-      // leave together; a load under `i < n` is waited for inside its own branch)
-      const uint8_t flag = a.has_point[base + (i < n ? i : 0)];
-      hp[j] = (i < n) ? flag : (uint8_t)0;
-    }
-    double f0[NPL], f1[NPL], f2[NPL];
-    int lvl[NPL];
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-      const int i = j * 64 + lane;
-      live[j] = hp[j] != 0;
-      px[j] = py[j] = 0.0;
-      pz[j] = 1.0;
-      f0[j] = f1[j] = 0.0;
-      f2[j] = 1.0;
-      lvl[j] = 0;
-      if (live[j]) {
-        const double* p = a.pos + 3 * (base + i);
-        const double* f = a.f + 3 * (base + i);
-        px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
-        f0[j] = f[0]; f1[j] = f[1]; f2[j] = f[2];
-        lvl[j] = a.level[base + i];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-      ux[j] = uy[j] = 0.0;
-      kk[j] = 1.f;
-      if (live[j]) {
-        ux[j] = f0[j] / f2[j];  // vk::project2d(f), once
-        uy[j] = f1[j] / f2[j];
-        kk[j] = 1.0f / (float)(1 << lvl[j]);
-      }
-      n_err += __popcll(__ballot(live[j]));
-    }
-  }
-#else
 #pragma unroll
   for (int j = 0; j < NPL; ++j) {
     const int i = j * 64 + lane;
@@ -316,7 +268,6 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_MINW) pose_opt_wave_kernel(c
     }
     n_err += __popcll(__ballot(live[j]));
   }
-#endif
   if (n_err == 0) {  // errors.empty(): return before touching anything (:57-58)
     if (lane == 0) a.ran[b] = 0;
     return;

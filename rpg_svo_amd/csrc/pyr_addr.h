@@ -12,19 +12,13 @@
 //
 // The offset separates into a row term and a column term in either layout, which is all the kernels rely on; a
 // run of bytes may be read with one load only if it does not cross a multiple of 16 in x (aligned dwords never do).
-// -DSVO_PYR_ROWMAJOR builds the row-major store of rounds 1-2 (row_off = y * pitch, col_off = x) for A/B timing;
-// svo_hip_pyr_layout::tile records which one a layout was made for and layout_ok() rejects the other.
+// (The row-major store of rounds 1-2 -- row_off = y * pitch, col_off = x -- measured slower in every kernel that gathers
+// windows: profiles/r03b_*.  svo_hip_pyr_layout::tile still names the layout and layout_ok() rejects anything but TILED.)
 #pragma once
 #include <stdint.h>
 
 #ifndef SVO_HOST_MATH_TEST  // (the CPU tests compile the window loaders with the host compiler, see device_math.h)
 #include <hip/hip_runtime.h>
-#endif
-
-#ifdef SVO_PYR_ROWMAJOR
-#define SVO_PYR_TILE 0
-#else
-#define SVO_PYR_TILE 1
 #endif
 
 namespace svo_pyr {
@@ -42,30 +36,18 @@ __host__ __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
 }
 
 __host__ __device__ __forceinline__ uint32_t row_off(int y, int pitch) {
-#if SVO_PYR_TILE
   // == (y >> 3) * 8 * pitch + (y & 7) * 16, as one shift and two multiply-adds (v_mad_u32_u24)
   return mul24((uint32_t)(y >> 3), ((uint32_t)pitch << 3) - 128u) + ((uint32_t)y << 4);
-#else
-  return mul24((uint32_t)y, (uint32_t)pitch);
-#endif
 }
 __host__ __device__ __forceinline__ uint32_t col_off(int x) {
-#if SVO_PYR_TILE
   // == (x >> 4) * 128 + (x & 15), as one shift and one multiply-add
   return mul24((uint32_t)(x >> 4), 112u) + (uint32_t)x;
-#else
-  return (uint32_t)x;
-#endif
 }
 __host__ __device__ __forceinline__ uint32_t px_off(int x, int y, int pitch) { return row_off(y, pitch) + col_off(x); }
 
 // bytes one level occupies
 __host__ __device__ __forceinline__ int64_t level_bytes(int pitch, int h) {
-#if SVO_PYR_TILE
   return (int64_t)pitch * ((h + 7) & ~7);
-#else
-  return (int64_t)pitch * h;
-#endif
 }
 
 // ---- window rows: three consecutive ALIGNED dwords ("a run": columns xa .. xa+11, xa % 4 == 0) -------------------
@@ -79,11 +61,7 @@ __host__ __device__ __forceinline__ int64_t level_bytes(int pitch, int h) {
 // 4-aligned, covers the needed bytes, and inside one tile row whenever the needed bytes are.
 __device__ __forceinline__ int run_start(int c, int need) {
   int xa = c & ~3;
-#if SVO_PYR_TILE && !defined(SVO_PYR_SPLIT_RUNS)
   if ((xa & 15) == 8 && (c & 15) + need <= 16) xa -= 4;  // [xa, xa+11] would cross, [c, c+need-1] does not
-#else
-  (void)need;
-#endif
   return xa;
 }
 
@@ -104,14 +82,7 @@ __device__ __forceinline__ u32x3_t ld96(const uint8_t* __restrict__ lvl, uint32_
 
 // The run [xa, xa+11] of the row at byte offset ro (row_off).  Per-row form: the three-way branch sits around one row.
 __device__ __forceinline__ void load_run12(const uint8_t* __restrict__ lvl, uint32_t ro, int xa, uint32_t d[3]) {
-#ifdef SVO_PYR_SPLIT_RUNS  // A/B build: every run as three dword loads (three look-ups per lane), no placement
-  d[0] = ld32(lvl, ro + col_off(xa));
-  d[1] = ld32(lvl, ro + col_off(xa + 4));
-  d[2] = ld32(lvl, ro + col_off(xa + 8));
-  return;
-#endif
   const uint32_t a = ro + col_off(xa);
-#if SVO_PYR_TILE
   const int o = xa & 15;
   if (o <= 4) {  // one tile row
     const u32x3_t v = ld96(lvl, a);
@@ -125,10 +96,6 @@ __device__ __forceinline__ void load_run12(const uint8_t* __restrict__ lvl, uint
     const u32x2_t v = ld64(lvl, a + 116u);
     d[1] = v.x; d[2] = v.y;
   }
-#else
-  const u32x3_t v = ld96(lvl, a);
-  d[0] = v.x; d[1] = v.y; d[2] = v.z;
-#endif
 }
 
 // NR rows x one run from row v0, column xa of a level.  Window form: the three-way branch sits around all rows, so
@@ -136,16 +103,10 @@ __device__ __forceinline__ void load_run12(const uint8_t* __restrict__ lvl, uint
 template <int NR>
 __device__ __forceinline__ void load_window12(const uint8_t* __restrict__ lvl, int pitch, int xa, int v0,
                                               uint32_t d[][3]) {
-#ifdef SVO_PYR_SPLIT_RUNS
-#pragma unroll
-  for (int r = 0; r < NR; ++r) load_run12(lvl, row_off(v0 + r, pitch), xa, d[r]);
-  return;
-#endif
   uint32_t a[NR];
   const uint32_t c = col_off(xa);
 #pragma unroll
   for (int r = 0; r < NR; ++r) a[r] = row_off(v0 + r, pitch) + c;
-#if SVO_PYR_TILE
   const int o = xa & 15;
   if (o <= 4) {
 #pragma unroll
@@ -168,13 +129,6 @@ __device__ __forceinline__ void load_window12(const uint8_t* __restrict__ lvl, i
       d[r][1] = v.x; d[r][2] = v.y;
     }
   }
-#else
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const u32x3_t v = ld96(lvl, a[r]);
-    d[r][0] = v.x; d[r][1] = v.y; d[r][2] = v.z;
-  }
-#endif
 }
 
 }  // namespace svo_pyr

@@ -92,16 +92,17 @@ __device__ __forceinline__ double compute_tau(const Se3& T_ref_cur, const double
   return (z_plus - z);
 }
 
-#ifdef TAU_ALGEBRAIC
-// (round-5 queue, UNMEASURED: computeTau without its two acos and two sin.  With c_a = cos(alpha), c_b = cos(beta) -- the
-// two normalised dot products the reference hands to acos -- and s = sqrt(1 - c^2) (both angles lie in [0, pi]),
+// computeTau without its two acos and two sin -- what seed_finish_kernel runs (233 against 258 us per 3.3 M seeds,
+// profiles/r05a_queue_drain.txt; the acos / sin form above stays as the statement of the reference's formula, and
+// tests/test_device_math_host.py compares the two).  With c_a = cos(alpha), c_b = cos(beta) -- the two normalised dot
+// products the reference hands to acos -- and s = sqrt(1 - c^2) (both angles lie in [0, pi]),
 //   sin(beta_plus)  = s_b cos(e) + c_b sin(e)
 //   sin(gamma_plus) = sin(SVO_PI - alpha - beta - e) = sin(alpha + beta + e'),  e' = e + (pi - SVO_PI)
 //                   = (s_a c_b + c_a s_b) cos(e') + (c_a c_b - s_a s_b) sin(e')
 // where e = px_error_angle is the same for every seed of a launch: its sines and cosines come with the arguments.  The
 // same function of the same inputs, evaluated differently: tau agrees with the acos / sin form to ~1e-13 relative (the
 // subtraction z_plus - z amplifies either form's rounding alike), which moves a seed's f32 state in about one update in a
-// million.  seed_finish is f64-transcendental-bound (65 % VALU busy): its instruction count drops by about a third.)
+// million.
 struct TauConsts {
   double se, ce, sed, ced;
 };
@@ -123,6 +124,5 @@ __device__ __forceinline__ double compute_tau(const Se3& T_ref_cur, const double
   const double z_plus = t_norm * sin_beta_plus / sin_gamma_plus;
   return (z_plus - z);
 }
-#endif
 
 }  // namespace svo_track

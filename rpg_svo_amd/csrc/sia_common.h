@@ -100,19 +100,13 @@ __device__ __forceinline__ void cut_row5(uint32_t a, uint32_t b, uint32_t c, int
   out[4] = (float)(hi & 0xffu);
 }
 
-// SIA_SGPR_POSE: the pose published by the solver wave is wave-uniform; reading it back through
-// v_readfirstlane keeps its 24 dwords in SGPRs instead of VGPRs
+// a wave-uniform value read back through v_readfirstlane: its dwords stay in SGPRs instead of VGPRs
 __device__ __forceinline__ double sia_uni(double v) {
   const unsigned long long u = (unsigned long long)__double_as_longlong(v);
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
   const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-#ifdef SIA_SGPR_POSE
-#define SIA_UNI(x) sia_uni(x)
-#else
-#define SIA_UNI(x) (x)
-#endif
 
 
 __device__ __forceinline__ int sym6_rt(int i, int j) {

@@ -50,15 +50,9 @@ namespace {
 // (1.40 against 1.50 ms on the headline batch); one 8-byte value is spilled once per level.  64/128-lane
 // workgroups are not limited by registers.  The distorted-camera instantiations (no window cache, the model's
 // world2cam in the loop) stay at 3 waves per SIMD where the workgroup size allows: at 4 they spill 22 dwords.
-// SIA_FIVE_FRAMES (experiment, round 4): five frames per CU instead of four -- the reference tile sized to 208 patches
-// (32.2 KB of LDS per frame instead of 38.4) and the register allocation held to 96 VGPRs (15 dwords spilled)
-#ifdef SIA_FIVE_FRAMES
-#define SIA_TILE_SLOTS 208
-#define MINW(BLOCK) ((BLOCK) == 256 ? 5 : ((BLOCK) > 256 ? 4 : 3))
-#endif
-#ifndef MINW
+// (Five frames per CU -- the reference tile cut to 208 patches, 96 VGPRs -- measured 24 % slower in round 4:
+// profiles/r04k_k1_five_frames_per_cu.txt.)
 #define MINW(BLOCK) ((BLOCK) >= 256 ? 4 : 3)
-#endif
 
 // SIA_PROFILE: per-phase shader-clock totals of wave 0 of every workgroup, written over H_out[b][0..7]
 // (pixel work, reduce, barrier 1, H rebuild, solve + barrier 2, per-level precompute, total, #iterations).
@@ -73,38 +67,35 @@ namespace {
 
 constexpr int MAX_WAVES = SVO_HIP_MAX_PATCHES / 64;
 
-#ifdef SIA_F64_PARTIALS
+// Arithmetic widths.  sia_pix: the per-pixel products res*dx, res*dy, dx*dx ... and their 16-term sums over a patch;
+// sia_acc: everything from the patch upwards -- the Jacobian rows a / b, the per-lane Jres and H partials, the wave
+// reductions, the per-wave partials in LDS.  The reference keeps all of it in f64 (jacobian_cache_, H_, Jres_:
+// sparse_img_align.cpp:139-140,228-230).  Default: products of two f32 values summed 16 at a time in f32, the rest in f64.
+//   -DSIA_F64_PARTIALS   the reference's width throughout (also SE3::exp in f64): three waves per SIMD
+//   -DSIA_F32_ROWS       rounds 2-4: everything below the solve in f32
+#if defined(SIA_F64_PARTIALS)
+using sia_pix = double;
 using sia_acc = double;
 #undef MINW
 #define MINW(BLOCK) 3  // the f64 accumulators do not fit 128 VGPRs
-#else
+#elif defined(SIA_F32_ROWS)
+using sia_pix = float;
 using sia_acc = float;
+#else
+using sia_pix = float;
+using sia_acc = double;
 #endif
 
-// Gauss-Newton state kept by the solver wave of a workgroup (quaternion form, as Sophus stores it).
-struct WaveModel {
-  double q[4], t[3];    // model: T_cur_from_ref as Sophus stores it (unit quaternion + t)
-  double oq[4], ot[3];  // old_model (rollback)
-};
-
-// Workgroup state (file-scope LDS).
-// Round 4: the serial solve / update step of an iteration is split over TWO waves of the workgroup (default; build with
-// -DSIA_SINGLE_SOLVER for the one-solver-wave step of rounds 2-3): 1.119 against 1.139 ms per 16384-frame launch in three
-// alternating pairs (profiles/r04j_k1_split_solve_ab.txt), 120 VGPRs, parity unchanged.
-#ifndef SIA_SINGLE_SOLVER
-#define SIA_SPLIT_SOLVE 1
-#endif
-
-// SIA_SPLIT_SOLVE: the model as TWO solver waves share it.  q and t are double-buffered by update parity: an update reads
-// buffer `cur` and writes buffer `cur ^ 1`, so the wave that composes the translation can read the quaternion the other
-// wave is replacing, and old_model (the rollback of vk::NLLSSolver) is simply the buffer the last update came from --
-// no copies.
+// Gauss-Newton state (quaternion form, as Sophus stores it), shared by the TWO waves of a workgroup that run the serial
+// solve / update step of an iteration between them (one solver wave: 1.139 against 1.119 ms per 16384-frame launch,
+// profiles/r04j_k1_split_solve_ab.txt).  q and t are double-buffered by update parity: an update reads buffer `cur` and
+// writes buffer `cur ^ 1`, so the wave that composes the translation can read the quaternion the other wave is
+// replacing, and old_model (the rollback of vk::NLLSSolver) is simply the buffer the last update came from -- no copies.
 struct SplitModel {
   double q[2][4], t[2][3];
 };
 
 struct SiaLds {
-  WaveModel wm[MAX_WAVES];
   SplitModel sm;
   double Rt[12];                 // pose published by the solver wave of the iteration
   int sw_done, sw_stop, sw_nmeas, sw_cur, sw_old;
@@ -161,68 +152,8 @@ __device__ __forceinline__ void sia_rebuild_hinv(int lane, int nw) {
   }
 }
 
-// SIA_LDLT_REBUILD (off by default): the same through a register LDL^T, run by the SOLVER wave itself: H = sum
-// of the per-wave partials (lane k < 21 owns entry k, v_readlane broadcasts them), one unpivoted factorisation
-// executed redundantly by every lane (zero pivot -> 0, as above), then lane j < 6 solves for unit vector j,
-// i.e. row j of the symmetric inverse.  Saves the barrier after a rebuild, but keeps ~84 f64 registers live
-// in a block that runs once per level: with it the 256-lane kernel does not fit 128 VGPRs without spilling in
-// the loop (4 spilled dwords against 2 cold ones; 1.42 against 1.40 ms), so the LDS Gauss-Jordan is the default.
-[[maybe_unused]] __device__ __forceinline__ void sia_rebuild_hinv_ldlt(int lane, int nw) {
-  asm volatile("" : "+v"(lane));
-  double v = 0.0;
-  if (lane < 21) {
-    for (int w = 0; w < nw; ++w) v += (double)g_s.Hpart[w][lane];
-    g_s.H[lane] = v;
-  }
-  double H[21];
-  H[0] = readlane_f64<0>(v); H[1] = readlane_f64<1>(v); H[2] = readlane_f64<2>(v); H[3] = readlane_f64<3>(v);
-  H[4] = readlane_f64<4>(v); H[5] = readlane_f64<5>(v); H[6] = readlane_f64<6>(v); H[7] = readlane_f64<7>(v);
-  H[8] = readlane_f64<8>(v); H[9] = readlane_f64<9>(v); H[10] = readlane_f64<10>(v); H[11] = readlane_f64<11>(v);
-  H[12] = readlane_f64<12>(v); H[13] = readlane_f64<13>(v); H[14] = readlane_f64<14>(v); H[15] = readlane_f64<15>(v);
-  H[16] = readlane_f64<16>(v); H[17] = readlane_f64<17>(v); H[18] = readlane_f64<18>(v); H[19] = readlane_f64<19>(v);
-  H[20] = readlane_f64<20>(v);
-  double LD[21];
-  ldlt6_factor(H, LD);
-  double e[6], x[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) e[i] = (i == lane) ? 1.0 : 0.0;
-  ldlt6_solve(LD, e, x);
-  if (lane < 6) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) g_s.Hinv[6 * lane + i] = x[i];
-  }
-  SVO_WAVE_LDS_FENCE();
-}
-
-// SIA_TOUCH_NEXT (off; an experiment that measured WORSE: 1.30 against 1.21 ms): fetch-ahead of the next level's
-// windows.  Every level starts with two dependent round trips to memory -- the reference window, then (after the
-// projection) the current window of iteration 0 -- and with the same arithmetic on cache-resident pyramids the kernel
-// runs 16-20 % faster (scripts/k1_cache_bound.py): that is the exposed latency.  Registers to land the next level's
-// windows early do not exist (128 VGPRs), so the idea was to pull their cache lines towards the CU instead: at the
-// end of iteration 0 of level l a lane touches the two diagonal corner tiles of its level l-1 reference window and of
-// its level l-1 current window (near twice this level's position) with global_load_lds_dword into a dummy LDS row
-// nobody reads, as opaque inline assembly so that no barrier or LDS read waits for the round trip.  The four extra
-// gathers per patch and level cost more L1 look-ups and in-order vmcnt waiting than the warmer lines give back.
-#if defined(SIA_TOUCH_NEXT) && !defined(SIA_F64_PARTIALS)
-#undef SIA_TOUCH_NEXT
-#define SIA_TOUCH_NEXT 1
-#else
-#undef SIA_TOUCH_NEXT
-#define SIA_TOUCH_NEXT 0
-#endif
-__device__ __forceinline__ void sia_touch(const uint8_t* base, uint32_t off, uint32_t lds_off) {
-  // base and lds_off are wave-uniform; v_readfirstlane tells the compiler so (SGPR operands)
-  const uint64_t b = reinterpret_cast<uint64_t>(base);
-  const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
-  const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
-  const uint64_t sb = ((uint64_t)bhi << 32) | blo;
-  const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_off);
-#ifndef SVO_HOST_MATH_TEST  // (a cache touch: nothing to do where the kernel is compiled for the CPU tests)
-  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(sb), "s"(sl) : "m0", "memory");
-#else
-  (void)off; (void)sb; (void)sl;
-#endif
-}
+// (A fetch-ahead of the next level's windows -- global_load_lds touches of their corner tiles during iteration 0 -- measured
+// worse, 1.30 against 1.21 ms: the extra gathers cost more L1 look-ups and in-order vmcnt waiting than warm lines give back.)
 
 // DIST: the camera is a distorted model (radial-tangential pinhole or ATAN); the undistorted pinhole
 // keeps its own instantiation so that its inner loop carries no model dispatch.
@@ -239,17 +170,12 @@ __device__ __forceinline__ sia_f2 sia_bilerp2(sia_f2 wtl, sia_f2 wtr, sia_f2 wbl
   return __builtin_elementwise_fma(wbr, br, __builtin_elementwise_fma(wbl, bl, __builtin_elementwise_fma(wtr, tr, wtl * tl)));
 }
 
-// SIA_PACKED: the pixel loop of an evaluation on v_pk_*_f32, two pixels per instruction (default; the
-// reference-width build keeps its f64 sums and the scalar loop).  -DSIA_PACKED=0 builds the scalar loop for A/B timing.
-#ifndef SIA_PACKED
+// SIA_PACKED: the pixel loop of an evaluation on v_pk_*_f32, two pixels per instruction; the reference-width build
+// keeps its f64 sums and the scalar loop.
 #ifdef SIA_F64_PARTIALS
 #define SIA_PACKED 0
 #else
 #define SIA_PACKED 1
-#endif
-#endif
-#if SIA_PACKED && defined(SIA_F64_PARTIALS)
-#error "the packed pixel loop keeps its sums in f32 pairs"
 #endif
 template <int BLOCK, bool WC, bool DIST>
 __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK)) sia_kernel(const SiaArgs a) {
@@ -268,16 +194,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
   // dx,dy (:133-136) are central differences of Bt, rebuilt in flight.
   //   q0 = r0 c1..4 | q1 = r1 c0..3 | q2 = r1 c4,5 r2 c0,1 | q3 = r2 c2..5
   //   q4 = r3 c0..3 | q5 = r3 c4,5 r4 c0,1 | q6 = r4 c2..5 | q7 = r5 c1..4
-  // SIA_TILE_SLOTS (experiment: five frames per CU): the tile holds that many patches instead of one per lane; a frame
-  // must not have more (lanes beyond share the last slot: they carry no patch)
-#ifdef SIA_TILE_SLOTS
-  constexpr int TS = (BLOCK == 256) ? SIA_TILE_SLOTS : BLOCK;
-#else
-  constexpr int TS = BLOCK;
-#endif
-  __shared__ float4 s_bt[8][TS];
-  const int ts = TS == BLOCK ? (int)threadIdx.x : ((int)threadIdx.x < TS ? (int)threadIdx.x : TS - 1);
-  __shared__ uint32_t s_touch[(SIA_TOUCH_NEXT && WC) ? BLOCK : 1];  // landing row of the fetch-ahead touches (never read)
+  __shared__ float4 s_bt[8][BLOCK];
 
   int n = a.n[b];
   n = n > a.n_stride ? a.n_stride : n;  // contract: n <= n_stride (svo_hip.h); never read the next problem's rows
@@ -306,17 +223,14 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
     Y = a.xyz[3 * fo + 1];
     Z = a.xyz[3 * fo + 2];
   }
-#ifdef SIA_KEEP_PX
-  // (round-5 queue, UNMEASURED: Feature::px kept in four registers instead of re-read at the top of every level.  The
-  // re-read is a memory round trip the level's reference-window gather has to wait for -- `s_waitcnt vmcnt(0)` right
-  // after it in the ISA -- i.e. two dependent round trips per level where the current-window gather and the reference-
-  // window gather could leave together: ~0.7 us x 4 levels on the critical path of a 52 us frame.)
+  // Feature::px kept in four registers instead of re-read at the top of every level: the re-read is a memory round trip
+  // the level's reference-window gather has to wait for, i.e. two dependent round trips per level where the gathers could
+  // leave together (1.122 -> 1.101 ms per 16 384 frames, profiles/r05a_queue_drain.txt)
   double px_kept0 = 0, px_kept1 = 0;
   if (has) {
     px_kept0 = a.px[2 * fo];
     px_kept1 = a.px[2 * fo + 1];
   }
-#endif
   // normalised coordinates of xyz_ref: all of Frame::jacobian_xyz2uv (frame.h:116-138)
   // is a function of (x/z, y/z, 1/z)
   const sia_acc zi = (sia_acc)(1.0 / Z);
@@ -345,21 +259,12 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
     for (int k = 0; k < 3; ++k) tr[k] = a.T_in[12 * b + 9 + k];
     quat_from_R(R, q);
     quat_to_R(q, R);
-    if (lane == 0) {
-      WaveModel& wm = g_s.wm[wave];
-      for (int k = 0; k < 4; ++k) wm.q[k] = wm.oq[k] = q[k];
-      for (int k = 0; k < 3; ++k) wm.t[k] = wm.ot[k] = tr[k];
-    }
-#ifdef SIA_SPLIT_SOLVE
     if (tid == 0) {
       for (int k = 0; k < 4; ++k) g_s.sm.q[0][k] = q[k];
       for (int k = 0; k < 3; ++k) g_s.sm.t[0][k] = tr[k];
     }
-#endif
   }
-#ifdef SIA_SPLIT_SOLVE
   int m_cur = 0, m_old = 0;  // parity buffer holding the model / old_model (uniform over the workgroup)
-#endif
   // vk::NLLSSolver::reset(): wave-uniform solver state
   double chi2_prev = 1e10;
   int stop = 0;
@@ -368,7 +273,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
 
   // which wave runs the serial solve/update step (see below)
   const int sw = (NW > 1) ? (int)(blockIdx.x % NW) : 0;
-  sia_acc Sxx = 0, Sxy = 0, Syy = 0;
+  sia_pix Sxx = 0, Sxy = 0, Syy = 0;
   sia_acc gmask = 0;  // 0 while this lane's Jacobian columns are zero at this level
   bool vis = false;   // visible_fts_[i]; never cleared between levels (:57)
 
@@ -393,36 +298,9 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
 #pragma unroll
       for (int r = 0; r < (WC ? 7 : 1); ++r) wc[r][0] = wc[r][1] = wc[r][2] = 0u;
     }
-#ifdef SIA_PREFETCH_CUR
-    // fill the window cache for iteration 0 with the pose the level starts from, ahead of the reference-patch
-    // work: the round trip of the current image overlaps the one of the reference image and the tile arithmetic
-    if (WC && !DIST) {
-      const double xc = R[0] * X + R[1] * Y + R[2] * Z + tr[0];
-      const double yc = R[3] * X + R[4] * Y + R[5] * Z + tr[1];
-      const double zc = R[6] * X + R[7] * Y + R[8] * Z + tr[2];
-      double izc = __builtin_amdgcn_rcp(zc);
-      izc = fma(fma(-zc, izc, 1.0), izc, izc);
-      izc = fma(fma(-zc, izc, 1.0), izc, izc);
-      const double pu = P.fx * (xc * izc) + P.cx, pv = P.fy * (yc * izc) + P.cy;
-      const float fu = floorf((float)pu * scale), fv = floorf((float)pv * scale);
-      const bool okc = has && fu - 3.f >= 0.f && fv - 3.f >= 0.f && fu + 3.f < (float)cols && fv + 3.f < (float)rows;
-      const int cu = okc ? (int)fu : 3, cv = okc ? (int)fv : 3;
-      wc_u0 = run_start(cu - 3, 7);
-      load_window12<(WC ? 7 : 1)>(cur_img, pitch, wc_u0, cv - 3, wc);
-      wc_v0 = okc ? cv - 3 : -100000;
-    }
-#endif
     // ---- precomputeReferencePatches (:84-145) ----------------------------
     {
-#ifdef SIA_KEEP_PX
       const double pxx = px_kept0, pxy = px_kept1;
-#else
-      double pxx = 0, pxy = 0;
-      if (has) {
-        pxx = a.px[2 * fo];
-        pxy = a.px[2 * fo + 1];
-      }
-#endif
       const float u_ref = (float)(pxx * (double)scale);
       const float v_ref = (float)(pxy * (double)scale);
       const int u_i = (int)floorf(u_ref);
@@ -465,9 +343,9 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
           for (int x = 0; x < 4; ++x) {
             const float dx = 0.5f * (Bt[y + 1][x + 2] - Bt[y + 1][x]);
             const float dy = 0.5f * (Bt[y + 2][x + 1] - Bt[y][x + 1]);
-            Sxx += (sia_acc)dx * (sia_acc)dx;
-            Sxy += (sia_acc)dx * (sia_acc)dy;
-            Syy += (sia_acc)dy * (sia_acc)dy;
+            Sxx += (sia_pix)dx * (sia_pix)dx;
+            Sxy += (sia_pix)dx * (sia_pix)dy;
+            Syy += (sia_pix)dy * (sia_pix)dy;
           }
 #if SIA_PACKED
         // columns in the order the packed pixel loop pairs them: (0,2) (1,3) (4,5) per row, (1,3) (2,4) in rows 0 and 5
@@ -499,17 +377,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
     // ---- vk::NLLSSolver::optimizeGaussNewton ------------------------------
     // old_model = model at the start of every optimize() call: a stop at the first evaluation of
     // this level (NaN solve, stop_ carried over) keeps the pose the previous level ended with
-#ifdef SIA_SPLIT_SOLVE
     m_old = m_cur;
-#else
-    if (wave == sw && lane == 0) {
-      WaveModel& wm0 = g_s.wm[wave];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) wm0.oq[k] = wm0.q[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) wm0.ot[k] = wm0.t[k];
-    }
-#endif
     int inH = -1;  // membership of this lane in the sum that g_s.H currently holds
     int evals = 0;
     SIA_ACC(5, tl0, SIA_T());
@@ -517,22 +385,17 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       [[maybe_unused]] const long long tp0 = SIA_T();
       // -- computeResiduals (:147-243): this lane's patch -------------------
       bool m = false;
-      sia_acc gx = 0, gy = 0;
+      sia_pix gx = 0, gy = 0;
       float c2 = 0.f;
-      [[maybe_unused]] int tu = 0, tv = 0;  // integer position of the current window (fetch-ahead below)
       if (vis) {
         const double xc = R[0] * X + R[1] * Y + R[2] * Z + tr[0];
         const double yc = R[3] * X + R[4] * Y + R[5] * Z + tr[1];
         const double zc = R[6] * X + R[7] * Y + R[8] * Z + tr[2];
         // cam_->world2cam(project2d(xyz)) (:183), one reciprocal (v_rcp_f64 + two Newton steps: the
         // IEEE division sequence is twice as long and sits on the critical path of every iteration)
-#ifdef SIA_IEEE_DIV
-        const double izc = 1.0 / zc;
-#else
         double izc = __builtin_amdgcn_rcp(zc);
         izc = fma(fma(-zc, izc, 1.0), izc, izc);
         izc = fma(fma(-zc, izc, 1.0), izc, izc);
-#endif
         double pu, pv;
         if (DIST) {
           Cam cm;
@@ -557,8 +420,6 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
         if (fu - 3.f >= 0.f && fv - 3.f >= 0.f && fu + 3.f < (float)cols && fv + 3.f < (float)rows) {
           m = true;
           const int u_i = (int)fu, v_i = (int)fv;
-          tu = u_i;
-          tv = v_i;
           const float su = u_cur - fu, sv = v_cur - fv;
           const float wtl = (1.f - su) * (1.f - sv);  // == the reference's rounded double products (:200-203), see above
           const float wtr = su * (1.f - sv);
@@ -615,8 +476,8 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
           // tile rows from LDS as float2 (layout written by the precompute block): row 0 / 5: (1,3) (2,4);
           // rows 1-4: (0,2) (1,3) (4,5), from which (2,4) and (3,5) are put together
           const float2* const bt2 = reinterpret_cast<const float2*>(&s_bt[0][0]);
-          // float2 index of (quad q, half h) of this lane: (q * BLOCK + tid) * 2 + h
-#define SIA_BT2(q, h) bt2[((q) * TS + ts) * 2 + (h)]
+          // float2 index of (quad q, half h) of this lane
+#define SIA_BT2(q, h) bt2[((q) * BLOCK + tid) * 2 + (h)]
           const f2 vtl = f2{wtl, wtl}, vtr = f2{wtr, wtr}, vbl = f2{wbl, wbl}, vbr = f2{wbr, wbr};
           f2 c2v = f2{0.f, 0.f}, gxv = f2{0.f, 0.f}, gyv = f2{0.f, 0.f};
           f2 t02, t13, t24, b02, b13, b24;  // window rows y and y+1
@@ -669,11 +530,6 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
           gy += gyv.x + gyv.y;
 #else
           float W[5][5];
-#ifdef SIA_DBG_NOLOAD
-#pragma unroll
-          for (int r = 0; r < 5; ++r)
-            for (int c = 0; c < 5; ++c) W[r][c] = su * (float)(r * 5 + c);
-#else
           if (WC) {
             int r0 = (v_i - 2) - wc_v0;  // first cached row needed
             int bo = (u_i - 2) - wc_u0;  // first cached byte needed
@@ -703,11 +559,10 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
 #pragma unroll
             for (int r = 0; r < 5; ++r) cut_row5_plain(cw[r], cbo, W[r]);
           }
-#endif
           float Bt[6][6];
           {
-            const float4 q0 = s_bt[0][ts], q1 = s_bt[1][ts], q2 = s_bt[2][ts], q3 = s_bt[3][ts];
-            const float4 q4 = s_bt[4][ts], q5 = s_bt[5][ts], q6 = s_bt[6][ts], q7 = s_bt[7][ts];
+            const float4 q0 = s_bt[0][tid], q1 = s_bt[1][tid], q2 = s_bt[2][tid], q3 = s_bt[3][tid];
+            const float4 q4 = s_bt[4][tid], q5 = s_bt[5][tid], q6 = s_bt[6][tid], q7 = s_bt[7][tid];
             Bt[0][0] = Bt[0][5] = Bt[5][0] = Bt[5][5] = 0.f;
             Bt[0][1] = q0.x; Bt[0][2] = q0.y; Bt[0][3] = q0.z; Bt[0][4] = q0.w;
             Bt[1][0] = q1.x; Bt[1][1] = q1.y; Bt[1][2] = q1.z; Bt[1][3] = q1.w;
@@ -725,8 +580,8 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
               const float I = sia_bilerp(wtl, wtr, wbl, wbr, W[y][x], W[y][x + 1], W[y + 1][x], W[y + 1][x + 1]);
               const float res = I - Bt[y + 1][x + 1];
               c2 += res * res;
-              gx += (sia_acc)res * (sia_acc)(Bt[y + 1][x + 2] - Bt[y + 1][x]);
-              gy += (sia_acc)res * (sia_acc)(Bt[y + 2][x + 1] - Bt[y][x + 1]);
+              gx += (sia_pix)res * (sia_pix)(Bt[y + 1][x + 2] - Bt[y + 1][x]);
+              gy += (sia_pix)res * (sia_pix)(Bt[y + 2][x + 1] - Bt[y][x + 1]);
             }
 #endif
           }
@@ -737,12 +592,10 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       {
         // dx, dy carry a factor 0.5 (central difference)
         const sia_acc gsc = (sia_acc)0.5 * fl * gmask;
-        const sia_acc gxf = m ? gx * gsc : (sia_acc)0, gyf = m ? gy * gsc : (sia_acc)0;
+        const sia_acc gxf = m ? (sia_acc)gx * gsc : (sia_acc)0, gyf = m ? (sia_acc)gy * gsc : (sia_acc)0;
         sia_acc part[8];
         sia_acc zi_ = zi, xn_ = xn, yn_ = yn;  // opaque, as in the H rebuild below: keeps xn*yn, 1+xn^2, ... inside the loop
-#ifndef SIA_ALLOW_HOIST
         asm volatile("" : "+v"(zi_), "+v"(xn_), "+v"(yn_));
-#endif
         part[0] = zi_ * gxf;
         part[1] = zi_ * gyf;
         part[2] = -zi_ * (xn_ * gxf + yn_ * gyf);
@@ -761,36 +614,6 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
         if (lane == 0) g_s.chg[buf][wave] = mine;
         SIA_ACC(1, tp1, SIA_T());
       }
-#if SIA_TOUCH_NEXT
-      if (WC && iter == 0 && level > P.min_level) {
-        const int nl = level - 1;
-        const int ncols = g_s.lw[nl], nrows = g_s.lh[nl], npitch = g_s.lp[nl];
-        const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&s_touch[tid & ~63];
-        // reference window of level l-1: rows v-3..v+3, columns of the 12-byte run around u-3..u+3
-        if (has) {
-          const float nscale = 1.0f / (float)(1 << nl);
-#ifdef SIA_KEEP_PX
-          const int ru = (int)floorf((float)(px_kept0 * (double)nscale)), rv = (int)floorf((float)(px_kept1 * (double)nscale));
-#else
-          const int ru = (int)floorf((float)(a.px[2 * fo] * (double)nscale)), rv = (int)floorf((float)(a.px[2 * fo + 1] * (double)nscale));
-#endif
-          if (ru - 3 >= 0 && rv - 3 >= 0 && ru + 3 < ncols && rv + 3 < nrows) {
-            const uint8_t* nref = ref_base + g_s.lo[nl];
-            sia_touch(nref, svo_pyr::px_off((ru - 3) & ~3, rv - 3, npitch), lds);
-            sia_touch(nref, svo_pyr::px_off((ru + 3) & ~3, rv + 3, npitch), lds);
-          }
-        }
-        // current window of level l-1: the patch sits near (2 tu, 2 tv)
-        if (m) {
-          const int cu = 2 * tu + 1, cv = 2 * tv + 1;
-          if (cu - 4 >= 0 && cv - 4 >= 0 && cu + 4 < ncols && cv + 4 < nrows) {
-            const uint8_t* ncur = cur_base + g_s.lo[nl];
-            sia_touch(ncur, svo_pyr::px_off((cu - 4) & ~3, cv - 4, npitch), lds);
-            sia_touch(ncur, svo_pyr::px_off((cu + 4) & ~3, cv + 4, npitch), lds);
-          }
-        }
-      }
-#endif
       // the one workgroup barrier of an iteration
       [[maybe_unused]] const long long tb0 = SIA_T();
       __syncthreads();
@@ -805,9 +628,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
         // (opaque copies: otherwise the ~60 products below, all invariant in the iteration loop, are hoisted
         // out of it and stay live across it -- 35 VGPRs, the difference between 3 and 4 waves per SIMD)
         sia_acc zi_ = zi, xn_ = xn, yn_ = yn;
-#ifndef SIA_ALLOW_HOIST
         asm volatile("" : "+v"(zi_), "+v"(xn_), "+v"(yn_));
-#endif
         const sia_acc one = 1, zero = 0;
         const sia_acc ja[6] = {-zi_ * fl, zero, xn_ * zi_ * fl, xn_ * yn_ * fl, -(one + xn_ * xn_) * fl, yn_ * fl};
         const sia_acc jb[6] = {zero, -zi_ * fl, yn_ * zi_ * fl, (one + yn_ * yn_) * fl, -xn_ * yn_ * fl, -xn_ * fl};
@@ -816,7 +637,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
         for (int i = 0; i < 6; ++i)
 #pragma unroll
           for (int j = i; j < 6; ++j) {
-            const sia_acc v = Sxx * (ja[i] * ja[j]) + Sxy * (ja[i] * jb[j] + jb[i] * ja[j]) + Syy * (jb[i] * jb[j]);
+            const sia_acc v = (sia_acc)Sxx * (ja[i] * ja[j]) + (sia_acc)Sxy * (ja[i] * jb[j] + jb[i] * ja[j]) + (sia_acc)Syy * (jb[i] * jb[j]);
             hp[sym6(i, j)] = m ? v : zero;
           }
         hp[21] = hp[22] = hp[23] = zero;
@@ -827,12 +648,8 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
         }
         inH = (int)m;
         __syncthreads();
-#ifndef SIA_LDLT_REBUILD
         if (wave == 0) sia_rebuild_hinv(lane, NW);
         __syncthreads();
-#else
-        if (wave == sw) sia_rebuild_hinv_ldlt(lane, NW);  // its only reader: no barrier needed
-#endif
       }
       ++evals;
       [[maybe_unused]] const long long ts0 = SIA_T();
@@ -844,12 +661,10 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       // -- solve() / update() and the stop / rollback rules of
       //    vk::NLLSSolver::optimizeGaussNewton (:245-258) --
       int done = 0;
-      // ONE wave per workgroup runs the serial step (it is ~300 VALU instructions against ~250 for
-      // a wave's pixel work, so running it in all waves redundantly spent more than half of the
-      // issue slots on it); which wave rotates with the workgroup id so that the solver waves of the
-      // workgroups sharing a CU do not pile up on one SIMD.  The others take the second barrier
-      // and pick the new pose up from LDS.
-#ifdef SIA_SPLIT_SOLVE
+      // The serial step is ~300 VALU instructions against ~250 for a wave's pixel work: running it in all waves redundantly
+      // spent more than half of the issue slots on it.  Which waves run it rotates with the workgroup id so that the solver
+      // waves of the workgroups sharing a CU do not pile up on one SIMD; the others take the second barrier and pick the
+      // new pose up from LDS.
       // TWO waves share the serial step: wave `sw` composes the rotation (quaternion part of SE3::exp, quaternion product,
       // normalisation, q -> R), wave `sw + 1` the translation (V(omega) upsilon, rotated by the OLD quaternion, added to
       // the old translation).  Each forms the totals, x = H^-1 Jres and the stop / rollback decision for itself (the
@@ -859,9 +674,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       const bool rot_wave = wave == sw, trans_wave = wave == swb;
       int m_next = m_cur;  // (both solver waves compute it; the others read it from LDS behind the barrier)
       if (rot_wave || trans_wave) {
-#ifndef SIA_NO_PRIO
-        __builtin_amdgcn_s_setprio(3);
-#endif
+        __builtin_amdgcn_s_setprio(3);  // the other waves of the workgroup wait for these two: let them win the issue arbitration
         double colsum = 0.0;
         {
           const int k = lane & 7;
@@ -963,129 +776,25 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
             for (int k = 0; k < 3; ++k) g_s.Rt[9 + k] = tr[k];
           }
         }
-#ifndef SIA_NO_PRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
       }
       m_cur = m_next;
-#else
-      if (wave == sw)
-#ifndef SIA_DBG_NOSOLVE
-      {
-#ifndef SIA_NO_PRIO
-        // the three other waves of the workgroup wait for this one: let it win the issue arbitration
-        // against the pixel waves of the other workgroups on its SIMD
-        __builtin_amdgcn_s_setprio(3);
-#endif
-        // totals over the waves: lane k (<8) owns column k
-        double colsum = 0.0;
-        {
-          const int k = lane & 7;
-#pragma unroll
-          for (int w = 0; w < NW; ++w) colsum += (double)g_s.part[buf][w][k];
-        }
-        const double b0 = readlane_f64<0>(colsum), b1 = readlane_f64<1>(colsum), b2 = readlane_f64<2>(colsum);
-        const double b3 = readlane_f64<3>(colsum), b4 = readlane_f64<4>(colsum), b5 = readlane_f64<5>(colsum);
-        const float chi2_sum = (float)readlane_f64<6>(colsum);
-        const int n_meas = (int)readlane_f64<7>(colsum);
-        // x_ = H_.ldlt().solve(Jres_) (:247), here x = H^-1 Jres: lane i (<6) owns row i
-        double xi;
-        {
-          const double* row = &g_s.Hinv[6 * (lane < 6 ? lane : 0)];
-          xi = row[0] * b0 + row[1] * b1 + row[2] * b2 + row[3] * b3 + row[4] * b4 + row[5] * b5;
-        }
-        const double x0 = readlane_f64<0>(xi), x1 = readlane_f64<1>(xi), x2 = readlane_f64<2>(xi);
-        const double x3 = readlane_f64<3>(xi), x4 = readlane_f64<4>(xi), x5 = readlane_f64<5>(xi);
-        n_meas_last = n_meas;
-        // return chi2/n_meas_  (float / size_t -> float), :242
-        const double new_chi2 = (double)(chi2_sum / (float)n_meas);
-        if (isnan(x0)) stop = 1;  // solve(), :248-249
-        WaveModel& wm = g_s.wm[wave];
-        double q[4];
-        if ((iter > 0 && new_chi2 > chi2_prev) || stop) {
-          // rollback: model = old_model
-#pragma unroll
-          for (int k = 0; k < 4; ++k) q[k] = wm.oq[k];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) tr[k] = wm.ot[k];
-          done = 1;
-        } else {
-          // update(): T_new = T_old * SE3::exp(-x_)  (:253-258)
-#ifdef SIA_F64_PARTIALS
-          const double mx[6] = {-x0, -x1, -x2, -x3, -x4, -x5};
-          double eq[4], et[3];
-          se3_exp(mx, eq, et);  // Sophus SE3::exp in f64, as the reference evaluates it
-#else
-          const float mx[6] = {-(float)x0, -(float)x1, -(float)x2, -(float)x3, -(float)x4, -(float)x5};
-          float eqf[4], etf[3];
-          se3_exp_f32(mx, eqf, etf);
-          const double eq[4] = {eqf[0], eqf[1], eqf[2], eqf[3]};
-          const double et[3] = {etf[0], etf[1], etf[2]};
-#endif
-          double oq[4], ot[3], rt[3];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) oq[k] = wm.q[k];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) ot[k] = wm.t[k];
-          quat_rot(oq, et, rt);
-          quat_mul(oq, eq, q);
-          quat_normalize_fast(q);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) tr[k] = ot[k] + rt[k];
-          if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) wm.oq[k] = oq[k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) wm.ot[k] = ot[k];
-          }
-          chi2_prev = new_chi2;
-          // vk::norm_max(x_) <= eps_
-          const double nm = fmax(fmax(fmax(fabs(x0), fabs(x1)), fmax(fabs(x2), fabs(x3))), fmax(fabs(x4), fabs(x5)));
-          if (nm <= P.eps) done = 1;
-        }
-        quat_to_R(q, R);
-        if (lane == 0) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) wm.q[k] = q[k];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) wm.t[k] = tr[k];
-        }
-        if (NW > 1 && lane == 0) {
-#pragma unroll
-          for (int k = 0; k < 9; ++k) g_s.Rt[k] = R[k];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) g_s.Rt[9 + k] = tr[k];
-          g_s.sw_done = done;
-          g_s.sw_stop = stop;
-          g_s.sw_nmeas = n_meas_last;
-          g_s.sw_chi2 = chi2_prev;
-        }
-#ifndef SIA_NO_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-      }
-#endif
-#endif
       if (NW > 1) {
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 9; ++k) R[k] = SIA_UNI(g_s.Rt[k]);
+        for (int k = 0; k < 9; ++k) R[k] = g_s.Rt[k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) tr[k] = SIA_UNI(g_s.Rt[9 + k]);
+        for (int k = 0; k < 3; ++k) tr[k] = g_s.Rt[9 + k];
         done = g_s.sw_done;
         stop = g_s.sw_stop;
         n_meas_last = g_s.sw_nmeas;
         chi2_prev = g_s.sw_chi2;
-#ifdef SIA_SPLIT_SOLVE
         m_cur = g_s.sw_cur;
         m_old = g_s.sw_old;
-#endif
       }
       buf ^= 1;
       SIA_ACC(4, ts0, SIA_T());
-#ifndef SIA_DBG_FIXED_ITERS
       if (done) break;
-#endif
     }
     if (tid == 0 && a.iters) a.iters[SVO_HIP_MAX_LEVELS * b + level] = evals;
   }
@@ -1107,20 +816,14 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
   }
 }
 
-// workgroup sizes that carry the window cache (256 lanes: +25 % at 4 levels x 3.4 iterations; 64/128 lanes run
+// the workgroup size that carries the window cache (256 lanes: +25 % at 4 levels x 3.4 iterations; 64/128 lanes run
 // few iterations per level at the default 4->2 schedule; 512/1024 lanes measured the same with and without it
 // and spill less without)
-#ifndef SIA_WC_MIN_BLOCK
-#define SIA_WC_MIN_BLOCK 256
-#endif
-#ifndef SIA_WC_MAX_BLOCK
-#define SIA_WC_MAX_BLOCK 256
-#endif
 
 template <int BLOCK>
 int launch(const SiaArgs& args, int B, hipStream_t s) {
   // window cache where the workgroup is large enough for the extra registers to pay (see MINW)
-  constexpr bool WC = (BLOCK >= SIA_WC_MIN_BLOCK && BLOCK <= SIA_WC_MAX_BLOCK);
+  constexpr bool WC = BLOCK == 256;
   if (args.P.cam_model == SVO_HIP_CAM_PINHOLE)
     hipLaunchKernelGGL((sia_kernel<BLOCK, WC, false>), dim3(B), dim3(BLOCK), 0, s, args);
   else

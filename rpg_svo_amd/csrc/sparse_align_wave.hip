@@ -28,9 +28,7 @@ using namespace svo_sia;
 namespace {
 
 // Waves per SIMD asked of the register allocator (2 -> at most 256 VGPRs per wave)
-#ifndef SIAW_MINW
-#define SIAW_MINW 2
-#endif
+constexpr int SIAW_MINW = 2;
 
 // One 4x4 reference patch as a lane carries it through the coarse-to-fine schedule.
 struct Patch {
@@ -172,7 +170,6 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
     // iteration finds it valid).  A single wave has nobody to hide a round trip behind: taken patch by patch
     // these are 2 x PPL dependent round trips per level, taken together one.  Lanes without a usable patch load
     // from a clamped position and throw the bytes away (keeps the block free of branches).
-#ifndef SIAW_SERIAL_LOADS
     uint32_t rw[PPL][7][3];
     int sel_ref[PPL];
     bool inb_k[PPL];
@@ -292,81 +289,6 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
         p.gmask = 0.f;
       }
     }
-#else
-#pragma unroll
-    for (int k = 0; k < PPL; ++k) {
-      Patch& p = pt[k];
-      const int slot = lane + 64 * k;
-      const size_t fo = (size_t)b * a.n_stride + slot;
-      double pxx = 0, pxy = 0;
-      if (p.has) {
-        pxx = a.px[2 * fo];
-        pxy = a.px[2 * fo + 1];
-      }
-      const float u_ref = (float)(pxx * (double)scale);
-      const float v_ref = (float)(pxy * (double)scale);
-      const int u_i = (int)floorf(u_ref);
-      const int v_i = (int)floorf(v_ref);
-      const bool inb = p.has && !(u_i - 3 < 0 || v_i - 3 < 0 || u_i + 3 >= cols || v_i + 3 >= rows);
-      p.Sxx = p.Sxy = p.Syy = 0.f;
-      p.inH = -1;
-      p.wc_v0 = -100000;  // the cache holds rows of the previous level
-      if (inb) {
-        p.vis = true;
-        p.gmask = 1.f;
-        const float su = u_ref - (float)u_i, sv = v_ref - (float)v_i;
-        // == the reference's rounded double products (:118-121): u >= 3, so su, sv are multiples of 2^-22,
-        // 1-su and 1-sv are exact in f32 and an f32 product is the correctly rounded exact product
-        const float wtl = (1.f - su) * (1.f - sv);
-        const float wtr = su * (1.f - sv);
-        const float wbl = (1.f - su) * sv;
-        const float wbr = su * sv;
-        float Bt[6][6];
-        float Wp[7], Wc[7];
-        uint32_t rws[7][3];
-        const int rxa = run_start(u_i - 3, 7);
-        const uint32_t rbo = (uint32_t)(u_i - 3 - rxa);  // 0..5
-        load_window12<7>(ref_img, pitch, rxa, v_i - 3, rws);
-        cut_row7(rws[0], rbo, Wp);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          cut_row7(rws[r + 1], rbo, Wc);
-#pragma unroll
-          for (int c = 0; c < 6; ++c) {
-            const bool need = ((r >= 1 && r <= 4)) || ((c >= 1 && c <= 4));
-            if (need) Bt[r][c] = wtl * Wp[c] + wtr * Wp[c + 1] + wbl * Wc[c] + wbr * Wc[c + 1];
-          }
-#pragma unroll
-          for (int c = 0; c < 7; ++c) Wp[c] = Wc[c];
-        }
-        float Sxx = 0.f, Sxy = 0.f, Syy = 0.f;
-#pragma unroll
-        for (int y = 0; y < 4; ++y)
-#pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            const float dx = 0.5f * (Bt[y + 1][x + 2] - Bt[y + 1][x]);
-            const float dy = 0.5f * (Bt[y + 2][x + 1] - Bt[y][x + 1]);
-            Sxx += dx * dx;
-            Sxy += dx * dy;
-            Syy += dy * dy;
-          }
-        p.Sxx = Sxx; p.Sxy = Sxy; p.Syy = Syy;
-        SIA_BT(k, 0) = make_float4(Bt[0][1], Bt[0][2], Bt[0][3], Bt[0][4]);
-        SIA_BT(k, 1) = make_float4(Bt[1][0], Bt[1][1], Bt[1][2], Bt[1][3]);
-        SIA_BT(k, 2) = make_float4(Bt[1][4], Bt[1][5], Bt[2][0], Bt[2][1]);
-        SIA_BT(k, 3) = make_float4(Bt[2][2], Bt[2][3], Bt[2][4], Bt[2][5]);
-        SIA_BT(k, 4) = make_float4(Bt[3][0], Bt[3][1], Bt[3][2], Bt[3][3]);
-        SIA_BT(k, 5) = make_float4(Bt[3][4], Bt[3][5], Bt[4][0], Bt[4][1]);
-        SIA_BT(k, 6) = make_float4(Bt[4][2], Bt[4][3], Bt[4][4], Bt[4][5]);
-        SIA_BT(k, 7) = make_float4(Bt[5][1], Bt[5][2], Bt[5][3], Bt[5][4]);
-      } else {
-        // jacobian_cache_.setZero() (:64): the J columns of a feature skipped here stay zero; a stale
-        // ref_patch_cache_ row (if any) is kept
-        p.gmask = 0.f;
-      }
-    }
-
-#endif
 
     // ---- vk::NLLSSolver::optimizeGaussNewton ------------------------------------------------------------
     // old_model = model at the start of every optimize() call
@@ -671,9 +593,7 @@ namespace svo_sia {
 // waves turns the saved barriers and the idle solver-wave partners into throughput.  Measured on the 640x480
 // batch of 16384 frames: 1.29 against 1.36 ms at 192 patches per frame (3 per lane); at 200 (4 per lane, the
 // fourth pass for 8 patches) the workgroup kernel wins, 1.41 against 1.62 ms.
-#ifndef SIAW_MAX_PATCHES
-#define SIAW_MAX_PATCHES 192
-#endif
+constexpr int SIAW_MAX_PATCHES = 192;
 // Distorted cameras: the model's world2cam in the loop costs registers (26 / 89 spilled dwords at 2 / 3 patches
 // per lane), so they take this kernel only with one patch per lane.
 bool sia_wave_applies(const SiaArgs& args, int B) {

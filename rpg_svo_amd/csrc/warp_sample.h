@@ -44,43 +44,7 @@ __device__ __forceinline__ void warp_column(const float Ax, const float Ay, cons
   }
 }
 
-// (round-5 queue, UNMEASURED on the GPU; -DWARP_PACKED selects it in the kernel: with the region fetch out of the way the
-// kernel is bound by vector-instruction issue (90 % at 3 cycles per instruction).  Two output rows of a lane as the two
-// halves of packed f32 operations -- v_pk_mul_f32 / v_pk_add_f32 issue in 3.5 cycles against 2 x 2.4 and round every
-// product and sum on its own, in the expression's order: the same bits -- for the 16 multiplies and additions of a
-// sample; floor, fraction, the byte reads and the conversions stay scalar.  Every sample inside the image.)
-__device__ __forceinline__ void warp_column_packed(const float Ax, const float Ay, const float Az, const float Aw, const float pyrx,
-                                                   const float pyry, const float sc, const int x, const uint8_t* const reg_o,
-                                                   uint8_t out[10]) {
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  float pp0 = (float)(x - 5);
-  pp0 *= sc;
-  const float ax = Ax * pp0, az = Az * pp0;
-  const f2 AX = {ax, ax}, AZ = {az, az}, AY = {Ay, Ay}, AW = {Aw, Aw}, PX = {pyrx, pyrx}, PY = {pyry, pyry};
-  const f2 ONE = {1.0f, 1.0f}, SC = {sc, sc};
-#pragma unroll
-  for (int y = 0; y < 10; y += 2) {
-    f2 pp1 = {(float)(y - 5), (float)(y - 4)};
-    pp1 = pp1 * SC;
-    const f2 u = (AX + AY * pp1) + PX;
-    const f2 v = (AZ + AW * pp1) + PY;
-    const int xa = svo_dev::floor_to_int(u.x), ya = svo_dev::floor_to_int(v.x);
-    const int xb = svo_dev::floor_to_int(u.y), yb = svo_dev::floor_to_int(v.y);
-    const f2 sx = {__builtin_amdgcn_fractf(u.x), __builtin_amdgcn_fractf(u.y)};
-    const f2 sy = {__builtin_amdgcn_fractf(v.x), __builtin_amdgcn_fractf(v.y)};
-    const f2 omx = ONE - sx, omy = ONE - sy;
-    const f2 w00 = omx * omy;
-    const f2 w01 = omx * sy;
-    const f2 w10 = sx * omy;
-    const f2 w11 = ONE - w00 - w01 - w10;
-    const uint8_t* qa = reg_o + (__mul24(ya, 48) + xa);
-    const uint8_t* qb = reg_o + (__mul24(yb, 48) + xb);
-    const f2 p00 = {(float)qa[0], (float)qb[0]}, p10 = {(float)qa[1], (float)qb[1]};
-    const f2 p01 = {(float)qa[48], (float)qb[48]}, p11 = {(float)qa[49], (float)qb[49]};
-    const f2 val = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
-    out[y] = (uint8_t)val.x;
-    out[y + 1] = (uint8_t)val.y;
-  }
-}
+// (Two output rows of a lane as the halves of v_pk_*_f32 operations -- the same bits -- measured 4 % slower than this
+// scalar column on the GPU: profiles/r05a_queue_drain.txt.)
 
 }  // namespace svo_track

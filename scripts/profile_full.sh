@@ -4,6 +4,8 @@ cd "$(dirname "$0")/.."; R=$PWD; export TMPDIR=/tmp; out=${1:-gpurun_out/prof_fu
 rm -rf $out; mkdir -p $out
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out -o trace -- \
    python $R/bench.py --pipeline full --extras none --no-cpu-baseline --steps 5 --warmup 2 > $R/$out/bench.log 2>&1)
+# keep the summaries only (the raw traces are ~18 MB per run; gpurun copies back at most 64 MiB)
+find $out -type f ! -name '*kernel_stats.csv' ! -name 'bench.log' -delete
 python - "$out" <<'PY'
 import csv,glob,sys
 f=glob.glob(sys.argv[1]+'/**/*kernel_stats.csv',recursive=True)[0]

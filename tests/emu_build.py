@@ -13,12 +13,11 @@ UNITS = ("common", "pyramid", "map_mirror", "matcher", "feature_align", "depth_f
          "pose_optimizer_wave", "pose_optimizer", "point_optimizer", "fast_detect")
 
 
-# the opt-in builds queued for timing on a GPU (scripts/round5_queue.sh), all in ONE emulated library: every emulated parity
-# test runs on the default build and on this one
-QUEUED = ("SIA_KEEP_PX", "WARP_PACKED", "SCAN_PREFETCH", "SEED_LOAD_FIRST", "POSE_LOAD_FIRST", "ALIGN_LOAD_FIRST", "PREP_LOAD_FIRST",
-          "RM_PATCH_LOAD_FIRST", "ALIGN_G_F16", "TAU_ALGEBRAIC")
-BUILDS = [(), QUEUED]
-BUILD_IDS = ["default", "queued-variants"]
+# Compile-time variants of the library the emulated parity tests run on besides the default build (round 4 queued ten of
+# them for timing; round 5 measured them on the GPU, the winners became the only code and the losers were deleted:
+# profiles/r05a_queue_drain.txt).  Tests take their build from this list: a new opt-in flag is one more tuple here.
+BUILDS = [()]
+BUILD_IDS = ["default"]
 
 
 def sanitizer():

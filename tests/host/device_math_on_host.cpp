@@ -99,13 +99,11 @@ double hm_compute_tau(const double T_ref_cur[12], const double f[3], double z, d
   se3_from_Rt(T_ref_cur, T);
   return svo_track::compute_tau(T, f, z, px_error_angle);
 }
-#ifdef TAU_ALGEBRAIC
 double hm_compute_tau_algebraic(const double T_ref_cur[12], const double f[3], double z, double px_error_angle) {
   Se3 T;
   se3_from_Rt(T_ref_cur, T);
   return svo_track::compute_tau(T, f, z, svo_track::tau_consts(px_error_angle));
 }
-#endif
 float hm_normal_pdf(float x, float mean, float sd) { return svo_track::normal_pdff(x, mean, sd); }
 
 // ---- K3's lane bodies (align_lanes.h) on a level of the TILED store (pyr_addr.h) ---------------------------------------
@@ -152,7 +150,7 @@ long long hm_level_bytes(int pitch, int h) { return (long long)svo_pyr::level_by
 
 // ---- warp_kernel's sample arithmetic (warp_sample.h) -----------------------------------------------------------------
 // The level is a 48-byte-wide image, i.e. it IS a region in the kernel's layout (reg_o = level, xlo = ylo = 0).
-// mode 0: warp_column<true> (per-sample bounds test), 1: warp_column<false>, 2: warp_column_packed; modes 1 and 2 need the
+// mode 0: warp_column<true> (per-sample bounds test), 1: warp_column<false>; mode 1 needs the
 // box of the four corner samples inside the image, as in the kernel: -1 when it is not.  Returns 0 when A^-1 is NaN.
 int hm_warp_patch(const uint8_t* level48, int rows, const double A_cur_ref[4], const double px_ref[2], int level_ref, int search_level,
                   int mode, uint8_t out[100]) {
@@ -178,8 +176,7 @@ int hm_warp_patch(const uint8_t* level48, int rows, const double A_cur_ref[4], c
   for (int x = 0; x < 10; ++x) {
     uint8_t col[10];
     if (mode == 0) svo_track::warp_column<true>(Ax, Ay, Az, Aw, pyrx, pyry, sc, x, cols, rows, 0, 0, level48, col);
-    else if (mode == 1) svo_track::warp_column<false>(Ax, Ay, Az, Aw, pyrx, pyry, sc, x, cols, rows, 0, 0, level48, col);
-    else svo_track::warp_column_packed(Ax, Ay, Az, Aw, pyrx, pyry, sc, x, level48, col);
+    else svo_track::warp_column<false>(Ax, Ay, Az, Aw, pyrx, pyry, sc, x, cols, rows, 0, 0, level48, col);
     for (int y = 0; y < 10; ++y) out[y * 10 + x] = col[y];
   }
   return 1;

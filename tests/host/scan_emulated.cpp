@@ -1,7 +1,5 @@
 // scan_emulated.cpp -- TEST INFRASTRUCTURE.  The epipolar ZMSSD scan of epi_scan_kernel (rpg_svo_amd/csrc/epi_scan.h) run on
-// the CPU through tests/host/hip_emu.h, in its default form and in the queued -DSCAN_PREFETCH form, on the same seeds:
-// tests/test_scan_emulated.py compares what the two write.
-#define SCAN_PREFETCH  // (compiles epi_scan_seed_prefetch next to epi_scan_seed)
+// the CPU through tests/host/hip_emu.h: tests/test_scan_emulated.py compares what it writes with a sequential numpy scan.
 #include "hip_emu.h"
 
 #include <vector>
@@ -10,7 +8,7 @@
 
 extern "C" {
 
-// Scans seeds [0, S) with form 0 (epi_scan_seed) or 1 (epi_scan_seed_prefetch).  One level-`n_levels` store of one slot;
+// Scans seeds [0, S) (`form` is unused: there is one form of the scan).  One level-`n_levels` store of one slot;
 // workspace arrays as SeedWs names them (only what the scan reads and writes).
 int scan_emulated(int form, int S, const uint8_t* store, long long slot_bytes, int n_levels, const long long* level_offset,
                   const int* level_w, const int* level_h, const int* level_pitch, const double cam_k[4], int width, int height,
@@ -51,8 +49,8 @@ int scan_emulated(int form, int S, const uint8_t* store, long long slot_bytes, i
     svo_emu::launch(dim3(1), dim3(64), [&] {
       const int grp = (int)threadIdx.x / 8, lane = (int)threadIdx.x % 8;
       if (grp >= n_groups) return;
-      if (form == 0) epi_scan_seed(a, s0 + grp, lane, boxes[grp].data());
-      else epi_scan_seed_prefetch(a, s0 + grp, lane, boxes[grp].data());
+      (void)form;
+      epi_scan_seed(a, s0 + grp, lane, boxes[grp].data());
     });
   }
   return 0;

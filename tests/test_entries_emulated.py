@@ -13,7 +13,7 @@ from oracle import pytrack
 from rpg_svo_amd import capi, se3, synth
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["default", "queued-variants"])
+@pytest.fixture(scope="module", params=[0], ids=["default"])
 def emu(request):
     from emu_build import BUILDS, build_emulated
     return build_emulated(BUILDS[request.param])

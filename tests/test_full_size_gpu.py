@@ -1,7 +1,9 @@
 """BASELINE.json full-size configurations, checked through size-independent properties (the
 oracle only sees a bounded sample): determinism, independence of a problem from the batch it
 travels in, invariance to the order of the patches, zero-motion fixed point, recovery of the
-ground-truth motion; plus oracle parity at configs[3] / configs[4] shapes."""
+ground-truth motion; plus parity at configs[1] / configs[3] / configs[4] shapes against BOTH checkers (the C
+restatement and the reference's own SparseImgAlign translation unit, `checker` fixture): the reference sees the
+1000-patch frames and the rig shape too."""
 import numpy as np
 import pytest
 import torch
@@ -22,7 +24,7 @@ def big_vga(gpu_device):
     return seq
 
 
-def test_config1_bench_scale_properties(oracle, gpu_device, big_vga):
+def test_config1_bench_scale_properties(oracle, gpu_device, big_vga, checker):
     B = 2048
     b = make_batch(big_vga, [(i, i + 1) for i in range(B)], 4)
     T1, out1, _ = run_hip(b, 3, 0)
@@ -41,7 +43,7 @@ def test_config1_bench_scale_properties(oracle, gpu_device, big_vga):
     # (4) oracle parity on a bounded sample of the same launch
     S = 64
     bs = make_batch(big_vga, [(i, i + 1) for i in range(0, B, B // S)], 4)
-    To, _, _ = run_oracle(oracle, bs, 3, 0)
+    To, _, _ = run_oracle(oracle, bs, 3, 0, which=checker)
     assert se3.log_norm(T1[:: B // S], To).max() <= 1e-4
 
 
@@ -68,13 +70,13 @@ def test_zero_motion_fixed_point_at_scale(gpu_device, big_vga):
     assert (out.iters.cpu().numpy()[:, :4] <= 2).all()  # first step is ~0: chi2 cannot improve
 
 
-def test_config3_xga5_n1000_parity(oracle, gpu_device):
+def test_config3_xga5_n1000_parity(oracle, gpu_device, checker):
     """configs[3] shape: 1280x960, 5 levels (4->0), 1000 patches per frame (1024-lane workgroups)."""
     cam = synth.Camera(1280, 960, 800.0, 800.0, 640.0, 480.0)
     seq = synth.make_sequence(9, 1000, cam=cam, seed=3, margin=56, cell=32, device=gpu_device)
     seq.images = seq.images.cpu(); seq.px, seq.f, seq.pos = seq.px.cpu(), seq.f.cpu(), seq.pos.cpu()
     b = make_batch(seq, [(i, i + 1) for i in range(8)], 5)
-    To, res_o, _ = run_oracle(oracle, b, 4, 0)
+    To, res_o, _ = run_oracle(oracle, b, 4, 0, which=checker)
     Th, out, _ = run_hip(b, 4, 0)
     d = se3.log_norm(Th, To)
     assert d.max() <= 1e-4 and np.median(d) <= 2e-6
@@ -82,13 +84,13 @@ def test_config3_xga5_n1000_parity(oracle, gpu_device):
     assert se3.log_norm(Th, b.T_gt_w).max() < 5e-4
 
 
-def test_config4_rig_752_default_schedule_parity(oracle, gpu_device):
+def test_config4_rig_752_default_schedule_parity(oracle, gpu_device, checker):
     """configs[4] shape: 752x480 cameras, reference default schedule (levels 4->2), 64 frames."""
     cam = synth.Camera(752, 480, 315.5, 315.5, 376.0, 240.0)
     seq = synth.make_sequence(65, 120, cam=cam, seed=11, margin=56, cell=40, device=gpu_device)
     seq.images = seq.images.cpu(); seq.px, seq.f, seq.pos = seq.px.cpu(), seq.f.cpu(), seq.pos.cpu()
     b = make_batch(seq, [(i, i + 1) for i in range(64)], 5)
-    To, res_o, _ = run_oracle(oracle, b, 4, 2, n_threads=8)
+    To, res_o, _ = run_oracle(oracle, b, 4, 2, n_threads=8, which=checker)
     Th, out, _ = run_hip(b, 4, 2)
     d = se3.log_norm(Th, To)
     assert d.max() <= 1e-4 and np.median(d) <= 1e-5

@@ -1,7 +1,7 @@
 """Row N2 without a GPU: rpg_svo_amd/csrc/map_mirror.hip compiled for the host through tests/host/hip_emu.h -- the C-ABI
 entry point svo_hip_reproject_map itself, its one-workgroup kernel run by 1024 host threads (barriers, LDS, the scan's
 __shfl_up, LDS atomics emulated) -- against the oracle's restatement of Reprojector::reprojectMap on random maps, exactly
-as tests/test_map_mirror_gpu.py does on the device.  Also the library with every queued opt-in build on (emu_build.QUEUED: here -DRM_PATCH_LOAD_FIRST)."""
+as tests/test_map_mirror_gpu.py does on the device."""
 import ctypes as C
 import os
 import subprocess
@@ -15,7 +15,7 @@ from rpg_svo_amd import capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["default", "queued-variants"])
+@pytest.fixture(scope="module", params=[0], ids=["default"])
 def emu(request):
     from emu_build import build_emulated
     from emu_build import BUILDS

@@ -1,8 +1,7 @@
 """Rows a11 and a13 without a GPU: svo_hip_pose_optimize (the wave kernel, its hand-over to the ordered kernel, the
 deferred entry), svo_hip_pose_optimize_ordered and svo_hip_point_optimize of the host-emulated library (tests/emu_build.py:
 pose_optimizer_wave.hip, pose_optimizer.hip, point_optimizer.hip compiled for the CPU through tests/host/hip_emu.h) against
-the oracle's pose_optimizer::optimizeGaussNewton and Point::optimize, with the requirements of tests/test_tracking_gpu.py.
-Also the library with every queued opt-in build switched on (emu_build.QUEUED: here -DPOSE_LOAD_FIRST matters)."""
+the oracle's pose_optimizer::optimizeGaussNewton and Point::optimize, with the requirements of tests/test_tracking_gpu.py."""
 import ctypes as C
 
 import numpy as np
@@ -13,7 +12,7 @@ from oracle import pytrack
 from rpg_svo_amd import capi, se3, synth
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["default", "queued-variants"])
+@pytest.fixture(scope="module", params=[0], ids=["default"])
 def emu(request):
     from emu_build import build_emulated
     from emu_build import BUILDS

@@ -3,7 +3,7 @@
 wave reductions (DPP, permlane swaps), the two-wave solve and its barriers, on the CPU, against the oracle's
 SparseImgAlign::run with the requirements of the GPU test (tests/test_sparse_align_gpu.py): poses to 1e-4 in SE(3)
 log-norm (measured here: see the assert), tracked counts identical, iteration counts per level equal for nearly every
-frame.  Also the library with every queued opt-in build switched on (emu_build.QUEUED: here -DSIA_KEEP_PX matters)."""
+frame."""
 import ctypes as C
 
 import numpy as np
@@ -13,7 +13,7 @@ from helpers import make_batch, marshal_problem, run_oracle
 from rpg_svo_amd import capi, se3, synth
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["default", "queued-variants"])
+@pytest.fixture(scope="module", params=[0], ids=["default"])
 def emu(request):
     from emu_build import build_emulated
     from emu_build import BUILDS

@@ -330,6 +330,102 @@ def test_find_epipolar_match_direct(gpu_device, orc, scene, pyrs):
         assert n_ok > S // 3
 
 
+@pytest.mark.parametrize("cap", [6, 20])
+def test_max_epi_search_steps_cap(gpu_device, orc, scene, pyrs, cap):
+    """Matcher::Options::max_epi_search_steps below the scan length (matcher.cpp:248-256: "skip epipolar search",
+    `return false` before the first position is scored): the queries whose line is longer than `cap` steps fail, the others
+    are untouched by the cap -- verdict, search level, px_cur_ and depth like the checker's with the same cap, and the
+    cap really fired (queries that match at 1000 and not at `cap`)."""
+    store, frames = scene_store(scene)
+    oframes = pytrack.make_frames(pyrs, scene.T_f_w)
+    rng = np.random.default_rng(23)
+    feats, de, dmin, dmax = [], [], [], []
+    for i in range(0, len(scene.obs), 2):
+        o = [x for x in scene.obs[i] if x[0] != scene.cur][0]
+        c_ref = -scene.T_f_w[o[0], :9].reshape(3, 3).T @ scene.T_f_w[o[0], 9:]
+        d_true = np.linalg.norm(scene.pt_pos[i] - c_ref)
+        spread = [0.5, 0.25, 0.05][(i // 2) % 3]
+        d_est = d_true * (1 + rng.normal() * spread * 0.2)
+        feats.append(o); de.append(d_est); dmin.append(d_est * (1 - spread)); dmax.append(d_est * (1 + spread))
+    S = len(feats)
+    fs = tracking.FeatureSet(frame=dev([o[0] for o in feats], torch.int32), level=dev([o[3] for o in feats], torch.int32),
+                             px=dev([o[1] for o in feats], torch.float64), f=dev([o[2] for o in feats], torch.float64),
+                             type=dev([o[4] for o in feats], torch.uint8), grad=dev([o[5] for o in feats], torch.float64))
+    cur = torch.full((S,), scene.cur, dtype=torch.int32, device="cuda:0")
+    run = lambda c: [t.cpu().numpy() for t in tracking.find_epipolar_match_direct(
+        store, scene.cam, frames, cur, fs, dev(de, torch.float64), dev(dmin, torch.float64), dev(dmax, torch.float64),
+        n_pyr_levels=5, max_epi_search_steps=c)]
+    ok_free, *_ = run(1000)
+    ok, depth, px, lvl = run(cap)
+    opt = pytrack.matcher_options(n_pyr_levels=5, max_epi_search_steps=cap)
+    opt_free = pytrack.matcher_options(n_pyr_levels=5)
+    n_ok = n_cut = 0
+    for k in range(S):
+        ok_o, r = orc.find_epipolar_match_direct(oframes, scene.cam, feats[k][0], scene.cur, pytrack.make_feature(*feats[k]),
+                                                 de[k], dmin[k], dmax[k], opt)
+        assert bool(ok[k]) == ok_o, (k, ok[k], ok_o)
+        if ok_o:
+            n_ok += 1
+            assert lvl[k] == r["search_level"]
+            assert np.abs(px[k] - r["px_cur"]).max() < 1e-9 and abs(depth[k] - r["depth"]) < 1e-9 * abs(r["depth"])
+        elif ok_free[k]:
+            ok_f, _ = orc.find_epipolar_match_direct(oframes, scene.cam, feats[k][0], scene.cur, pytrack.make_feature(*feats[k]),
+                                                     de[k], dmin[k], dmax[k], opt_free)
+            assert ok_f  # the checker, too, matches this query without the cap: the cap is what failed it
+            n_cut += 1
+            assert depth[k] == 0.0  # nothing of the match leaks out of a skipped search
+    assert n_cut >= 5 and n_ok >= 5, (n_cut, n_ok)
+
+
+def test_update_seeds_with_search_step_cap(gpu_device, orc, scene, pyrs):
+    """DepthFilter::updateSeeds with Matcher::Options::max_epi_search_steps = 8: a seed whose line is longer is a failed
+    match (b + 1, depth_filter.cpp:238-242), everything else as without the cap; statuses and seed state like the checker's."""
+    store, frames = scene_store(scene)
+    rng = np.random.default_rng(8)
+    seeds, feats = _make_seeds(scene, orc, rng)
+    S = len(seeds)
+    oframes = pytrack.make_frames(pyrs, scene.T_f_w)
+    b_before = np.array([s.b for s in seeds], dtype=np.float32)
+    mk = lambda: (tracking.FeatureSet(frame=dev([o[0] for o in feats], torch.int32), level=dev([o[3] for o in feats], torch.int32),
+                                      px=dev([o[1] for o in feats], torch.float64), f=dev([o[2] for o in feats], torch.float64),
+                                      type=dev([o[4] for o in feats], torch.uint8), grad=dev([o[5] for o in feats], torch.float64)),
+                  tracking.SeedSet(a=dev([s.a for s in seeds], torch.float32), b=dev([s.b for s in seeds], torch.float32),
+                                   mu=dev([s.mu for s in seeds], torch.float32), z_range=dev([s.z_range for s in seeds], torch.float32),
+                                   sigma2=dev([s.sigma2 for s in seeds], torch.float32),
+                                   batch_id=dev([s.batch_id for s in seeds], torch.int32)))
+    cur = torch.full((S,), scene.cur, dtype=torch.int32, device="cuda:0")
+    res = {}
+    for cap in (1000, 8):
+        fs, ss = mk()
+        df = tracking.DepthFilter(n_pyr_levels=5, max_epi_search_steps=cap)
+        status, _, _ = df.update_seeds(store, scene.cam, frames, cur, fs, ss, batch_counter=5)
+        torch.cuda.synchronize()
+        res[cap] = (status.cpu().numpy(), ss.a.cpu().numpy(), ss.b.cpu().numpy(), ss.mu.cpu().numpy(), ss.sigma2.cpu().numpy())
+    # (the checker mutates its seed list: run it last)
+    opt = pytrack.matcher_options(n_pyr_levels=5, max_epi_search_steps=8)
+    nu, so, io = orc.update_seeds(oframes, scene.cam, scene.cur, seeds, batch_counter=5, opt=opt)
+    status, a, b, mu, s2 = res[8]
+    if orc.which == "ref":
+        status = np.where(np.isin(status, (pytrack.SEED_BEHIND, pytrack.SEED_NOT_IN_FRAME)), 0, status)
+    n_cut = 0
+    for i in range(S):
+        st = io[i].status
+        if st in (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED):
+            margin = abs(np.sqrt(max(so[i].sigma2, 0.0)) * 200.0 / so[i].z_range - 1.0)
+            assert status[i] == st if margin > 1e-3 else status[i] in (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED), (i, status[i], st)
+        else:
+            assert status[i] == st, (i, status[i], st)
+        if st == pytrack.SEED_NO_MATCH:
+            # it->b++ and nothing else
+            assert b[i] == np.float32(b_before[i] + np.float32(1.0)) and b[i] == np.float32(so[i].b)
+            assert a[i] == np.float32(so[i].a) and mu[i] == np.float32(so[i].mu) and s2[i] == np.float32(so[i].sigma2)
+            if res[1000][0][i] in (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED):
+                n_cut += 1
+        elif st == pytrack.SEED_UPDATED:
+            assert np.isclose(mu[i], so[i].mu, rtol=2e-6, atol=0)
+    assert n_cut >= 5, n_cut
+
+
 def _make_seeds(scene, orc, rng):
     seeds, feats = [], []
     for i in range(len(scene.obs)):
