@@ -593,10 +593,11 @@ def main() -> None:
         "scaling": "weak",
         "vs_baseline": None,
         # what the arithmetic of K1 is carried out in (the reference: f32 pixels / chi2, f64 everything else)
-        "dtype": "f32 pixels, residuals and chi2; f32 Jacobian rows and per-lane Jres/H partials, tree-reduced per wave "
-                 "(reference: f64, sequential); f64 projection, cross-wave sums, 6x6 solve and pose; f32 series for SE3::exp "
-                 "(reference: f64) -- see f64_partials for the reference-width build",
-        "dtype_short": "f32 pixels/residuals/chi2/Jacobian partials, f64 projection/solve/pose",
+        "dtype": "f32 pixels, residuals, chi2 and per-pixel Jacobian products (16-term patch sums); f64 projection, per-patch "
+                 "Jacobian rows, per-lane Jres/H partials (tree-reduced per wave; reference: sequential), cross-wave sums, 6x6 "
+                 "solve and pose; f32 series for SE3::exp (reference: f64 sin/cos) -- see f64_partials / roofline_f64_build for "
+                 "the build that is f64 throughout",
+        "dtype_short": "f32 pixels/residuals/chi2/per-pixel products, f64 Jacobian rows/partials/reductions/projection/solve/pose",
         "data": "synthetic",
         "config": {
             "workload": args.workload if full is None else args.workload.replace("sparse_align", "full_track"),
@@ -1593,9 +1594,9 @@ F64_VARIANT_LIB = os.path.join(ROOT, "rpg_svo_amd", "lib", "variants", "libsvo_h
 
 
 def f64_partials_leg(args, T_default, iters_default, result) -> dict:
-    """What reference-width arithmetic costs and buys.  The default K1 keeps Jacobian rows, per-pixel products,
-    per-lane partials and the wave reductions in f32 and evaluates SE3::exp as an f32 series; the reference keeps
-    them in f64 (sparse_img_align.cpp:228-230,253-258).  The same library built with -DSIA_F64_PARTIALS (built by
+    """What reference-width arithmetic costs and buys.  The default K1 forms the per-pixel products and their 16-term
+    patch sums in f32 and evaluates SE3::exp as an f32 series (Jacobian rows, partials and reductions are f64 since round
+    5); the reference keeps all of it in f64 (sparse_img_align.cpp:228-230,253-258).  The same library built with -DSIA_F64_PARTIALS (built by
     __graft_entry__.build()) does it the reference's way: this leg re-runs the headline workload on it in a child
     process and reports its frames/s and its agreement with the CPU reference next to the default's."""
     import tempfile

@@ -13,7 +13,7 @@
 //   convergence test (:261-262, :283-287)                                /
 //
 // The epipolar scan is the only part with real per-seed parallelism (up to 1000 candidate
-// positions x 64 pixels of integer ZMSSD): SCAN_LANES (8) lanes share a seed and take its steps
+// positions x 64 pixels of integer ZMSSD): 8 lanes share a seed and take its steps
 // round-robin, score them with v_dot4_u32_u8, and a lexicographic (score, step) minimum over the
 // group reproduces the reference's "first strictly smaller score wins".  A lane replays only the
 // chain of f64 additions (uv += step) up to its own step and keeps the position of the step before
@@ -199,13 +199,14 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
 // seed that has been matched a few times searches 2-6 positions, one that never was and sees a long baseline
 // hundreds), and a wave runs as long as the longest scan among the seeds it holds: taken in list order the lanes
 // idle two thirds of the time.  So the workgroup first sorts its chunk by scan length (counting sort over
-// power-of-two buckets of ceil(positions / SCAN_LANES), in LDS), longest first, and its waves then fetch groups of
-// 64 / SCAN_LANES neighbouring entries of that order from an LDS counter: the seeds a wave holds at a time need about
+// power-of-two buckets of ceil(positions / 16), in LDS), longest first, and its waves then fetch groups of
+// 8 neighbouring entries of that order from an LDS counter: the seeds a wave holds at a time need about
 // the same number of passes, and no wave waits for another.  Seeds that do not scan (short segment, not visible,
 // rejected) never enter the order.  Results do not depend on the order.
 // four waves per SIMD (128 VGPRs, 29 dwords spilled outside the position loop) measured 2 % faster for update_seeds
 // than three (162 VGPRs, no spills): the scan waits on its box fetch once per pass
 constexpr int SCAN_MINW = 4;
+template <bool PINHOLE>
 __global__ void __launch_bounds__(SCAN_BLOCK, SCAN_MINW) epi_scan_kernel(const SeedArgs a) {
   __shared__ uint16_t s_order[SCAN_CHUNK];
   __shared__ int s_hist[SCAN_BUCKETS], s_off[SCAN_BUCKETS], s_next, s_n;
@@ -223,7 +224,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK, SCAN_MINW) epi_scan_kernel(const S
     bucket[k] = -1;
     rank[k] = 0;
     if (s < a.S && w.mode[s] == MODE_SCAN) {
-      const int passes = (w.n_steps[s] + 1 + SCAN_G - 1) / SCAN_G;  // n_steps + 1 positions (matcher.cpp:264)
+      const int passes = (w.n_steps[s] + 1 + SCAN_PP - 1) / SCAN_PP;  // n_steps + 1 positions (matcher.cpp:264)
       bucket[k] = passes <= 1 ? 0 : min(SCAN_BUCKETS - 1, 32 - __clz(passes - 1));
       rank[k] = atomicAdd(&s_hist[bucket[k]], 1);
     }
@@ -251,7 +252,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK, SCAN_MINW) epi_scan_kernel(const S
     if (wl == 0) p = atomicAdd(&s_next, GROUPS);
     p = __builtin_amdgcn_readfirstlane(p);
     if (p >= n_scan) break;
-    if (p + grp < n_scan) epi_scan_seed(a, base + (int)s_order[p + grp], lane, s_box[threadIdx.x / SCAN_G]);
+    if (p + grp < n_scan) epi_scan_seed<PINHOLE>(a, base + (int)s_order[p + grp], lane, s_box[threadIdx.x / SCAN_G]);
   }
 }
 
@@ -540,7 +541,10 @@ static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_sto
   wa.pwb = w.pwb;
   rc = launch_warp(wa, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(epi_scan_kernel, dim3((S + SCAN_CHUNK - 1) / SCAN_CHUNK), dim3(SCAN_BLOCK), 0, st, a);
+  if (a.cam.model == SVO_HIP_CAM_PINHOLE)
+    hipLaunchKernelGGL(epi_scan_kernel<true>, dim3((S + SCAN_CHUNK - 1) / SCAN_CHUNK), dim3(SCAN_BLOCK), 0, st, a);
+  else
+    hipLaunchKernelGGL(epi_scan_kernel<false>, dim3((S + SCAN_CHUNK - 1) / SCAN_CHUNK), dim3(SCAN_BLOCK), 0, st, a);
   rc = check_launch();
   if (rc) return rc;
   AlignArgs al;

@@ -88,65 +88,104 @@ constexpr int SCAN_BLOCK = 256;
 // lanes had no step of their own, and every lane still replays the chain of additions.  8 lanes per seed
 // share the chain replay between eight seeds of a wave and keep the lanes busy (update_seeds on 3.3 M seeds:
 // 3.24 ms at 64 lanes per seed, 2.74 at 32, 2.47 at 16, 2.33 at 8).
-constexpr int SCAN_LANES = 8;
-constexpr int SCAN_G = SCAN_LANES;
-static_assert(SCAN_G == 8, "the box fetch and the DPP minima below are written for groups of 8 lanes");
+constexpr int SCAN_G = 8;
+// Positions a group looks at per pass: two per lane, CONSECUTIVE ones (lane l: steps 2l and 2l+1 of the pass).
+constexpr int SCAN_PP = 2 * SCAN_G;
 
 // Seeds per workgroup of the scan.  The seeds of a chunk are ordered by scan length inside the workgroup (below).
 constexpr int SCAN_CHUNK = 1024;
 constexpr int SCAN_BUCKETS = 8;
 
-// The 8 lanes of a group look at 8 consecutive positions of an epipolar line, 0.7 px apart: their 8 x 8 windows
-// overlap almost completely, and what the scan costs is the number of cache-line look-ups its gathers make (8 rows x
-// 1-2 look-ups per position, ~12; the arithmetic of a position is ~100 instructions).  With SCAN_BOX the group fetches
-// the bounding box of its windows ONCE, as 16-byte tile rows of the store (one look-up each, at most 16 rows x 2
-// columns of tiles = 4 per lane), parks it in LDS and every lane cuts its window out of that; a group whose windows do
-// not fit a 16 x 32 box (never on an undistorted line) falls back to fetching per lane.
-constexpr int SCAN_BOX_DWORDS = 16 * 8 + 4;  // 16 rows x 32 bytes (+ one dword: the cut reads three dwords per row)
+// The lanes of a group look at 16 consecutive positions of an epipolar line, 0.7 px apart: their 8 x 8 windows overlap
+// almost completely, and what the scan costs is (a) the number of cache-line look-ups its gathers make and (b) the memory
+// round trip a pass waits for.  The group therefore fetches the bounding box of its windows ONCE per pass, as 16-byte
+// tile rows of the store (one look-up each), parks it in LDS and every lane cuts its windows out of that.  Round 5: the
+// box covers 16 positions instead of 8 (half the round trips and half the box bookkeeping per position: the kernel
+// waited 57 % of its wave cycles), is up to 16 rows x 3 tile columns (48 bytes: a row of the box is 12 dwords, which
+// spreads the rows of a window over the banks -- rows r and r + 4 of the 8-dword rows of round 3 shared theirs, 34 % of
+// the port cycles were conflicts), and the 8 x 8 template lives in LDS next to it instead of in 16 registers of every
+// lane.  A pass whose 16 windows do not fit 16 rows (a line steeper than ~50 degrees) is done as two half passes, the box of
+// lanes 0-3 and then the box of lanes 4-7; a group whose half box does not fit either (never on an undistorted line)
+// fetches per lane.
+constexpr int SCAN_BOX_ROWS = 16, SCAN_BOX_ROW_DWORDS = 12;
+constexpr int SCAN_TPL_OFF = SCAN_BOX_ROWS * SCAN_BOX_ROW_DWORDS + 4;  // (+ 4 dwords: the cut reads three dwords per row)
+constexpr int SCAN_BOX_DWORDS = SCAN_TPL_OFF + 16;                     // box, then the template's 8 rows of 2 dwords
+static_assert(SCAN_BOX_DWORDS % 4 == 0 && SCAN_TPL_OFF % 4 == 0, "16-byte LDS stores");
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
-// minimum / maximum over the 8 lanes of a group (quad butterflies + mirror inside the 8 lanes: no LDS)
-__device__ __forceinline__ int group8_min(int v) {
+// minimum / maximum over the 4 lanes of a half group (a quad: two butterflies), then over the group (mirror inside 8 lanes)
+__device__ __forceinline__ int quad_min(int v) {
   v = min(v, dpp_i32<svo_dev::DPP_QUAD_XOR1>(v));
-  v = min(v, dpp_i32<svo_dev::DPP_QUAD_XOR2>(v));
-  return min(v, dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(v));
+  return min(v, dpp_i32<svo_dev::DPP_QUAD_XOR2>(v));
 }
-__device__ __forceinline__ int group8_max(int v) {
+__device__ __forceinline__ int quad_max(int v) {
   v = max(v, dpp_i32<svo_dev::DPP_QUAD_XOR1>(v));
-  v = max(v, dpp_i32<svo_dev::DPP_QUAD_XOR2>(v));
-  return max(v, dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(v));
+  return max(v, dpp_i32<svo_dev::DPP_QUAD_XOR2>(v));
+}
+__device__ __forceinline__ int group8_sum(int v) {
+  v += dpp_i32<svo_dev::DPP_QUAD_XOR1>(v);
+  v += dpp_i32<svo_dev::DPP_QUAD_XOR2>(v);
+  return v + dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(v);
 }
 
-// ZMSSD scan of one seed, matcher.cpp:248-291, by the SCAN_LANES lanes of a group (lane = position in the group).
-// box: the group's SCAN_BOX_DWORDS dwords of LDS.
+// the three sums of a ZMSSD over the 8 x 8 window whose top-left byte is (bx, row r0) of the box, against the template
+struct ScanSums {
+  uint32_t B, BB, AB;
+};
+__device__ __forceinline__ void scan_row(const uint32_t* __restrict__ r, const uint32_t sel, const uint32_t t0, const uint32_t t1, ScanSums& s) {
+  const uint32_t d0 = r[0], d1 = r[1], d2 = r[2];
+  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sel), hi = __builtin_amdgcn_alignbyte(d2, d1, sel);
+  s.B = __builtin_amdgcn_udot4(lo, 0x01010101u, s.B, false);
+  s.B = __builtin_amdgcn_udot4(hi, 0x01010101u, s.B, false);
+  s.BB = __builtin_amdgcn_udot4(lo, lo, s.BB, false);
+  s.BB = __builtin_amdgcn_udot4(hi, hi, s.BB, false);
+  s.AB = __builtin_amdgcn_udot4(lo, t0, s.AB, false);
+  s.AB = __builtin_amdgcn_udot4(hi, t1, s.AB, false);
+}
+
+// cur_frame.cam_->world2cam(uv).  PINHOLE: the undistorted model on its own (the same two expressions as
+// world2cam_uv's first branch), so that the instantiation the undistorted camera runs carries neither the code nor the
+// registers of the radial-tangential and ATAN models.
+template <bool PINHOLE>
+__device__ __forceinline__ void scan_world2cam(const Cam& c, const double uv[2], double px[2]) {
+  if (PINHOLE) {
+    px[0] = c.fx * uv[0] + c.cx;
+    px[1] = c.fy * uv[1] + c.cy;
+  } else {
+    world2cam_uv(c, uv, px);
+  }
+}
+
+// ZMSSD scan of one seed, matcher.cpp:248-291, by the SCAN_G lanes of a group (lane = position in the group).
+// box: the group's SCAN_BOX_DWORDS dwords of LDS (16-byte aligned).
+template <bool PINHOLE>
 __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, const int lane, uint32_t* box) {
   const SeedWs& w = a.ws;
   const int sl = w.search_level[s];
   const uint8_t* img = a.store + (int64_t)w.cur_slot[s] * a.L.slot_bytes + a.L.offset[sl];
   const int pitch = a.L.pitch[sl];
-  // reference patch: interior of patch_with_border (createPatchFromPatchWithBorder), 8 rows of 8
-  uint32_t ra[16];
+  // reference patch: interior of patch_with_border (createPatchFromPatchWithBorder), 8 rows of 8; lane y parks row y
+  uint32_t* const tpl = box + SCAN_TPL_OFF;
+  int sumA, sumAA;
   {
-    const uint8_t* pw = w.pwb + (size_t)s * 100;
-#pragma unroll
-    for (int y = 0; y < 8; ++y) {
-      const uint8_t* r = pw + (y + 1) * 10 + 1;
-      // one unaligned 8-byte load per row (gfx950 global memory takes any alignment)
-      uint32_t lo, hi;
-      __builtin_memcpy(&lo, r, 4);
-      __builtin_memcpy(&hi, r + 4, 4);
-      ra[2 * y] = lo;
-      ra[2 * y + 1] = hi;
-    }
+    const uint8_t* r = w.pwb + (size_t)s * 100 + (lane + 1) * 10 + 1;
+    // one unaligned 8-byte load per row (gfx950 global memory takes any alignment)
+    uint32_t lo, hi;
+    __builtin_memcpy(&lo, r, 4);
+    __builtin_memcpy(&hi, r + 4, 4);
+    // (the scan of the seed this group held before has read its template for the last time: DS operations of a wave
+    // execute in order)
+    SVO_LANES_LDS_HANDOVER();
+    tpl[2 * lane] = lo;
+    tpl[2 * lane + 1] = hi;
+    SVO_LANES_LDS_HANDOVER();
+    uint32_t sa = __builtin_amdgcn_udot4(lo, 0x01010101u, 0u, false), saa = __builtin_amdgcn_udot4(lo, lo, 0u, false);
+    sa = __builtin_amdgcn_udot4(hi, 0x01010101u, sa, false);
+    saa = __builtin_amdgcn_udot4(hi, hi, saa, false);
+    sumA = group8_sum((int)sa);
+    sumAA = group8_sum((int)saa);
   }
-  uint32_t sumA_u = 0, sumAA_u = 0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    sumA_u = __builtin_amdgcn_udot4(ra[k], 0x01010101u, sumA_u, false);
-    sumAA_u = __builtin_amdgcn_udot4(ra[k], ra[k], sumAA_u, false);
-  }
-  const int sumA = (int)sumA_u, sumAA = (int)sumAA_u;
   const double step0 = w.step[2 * s], step1 = w.step[2 * s + 1];
   double uv0 = w.B[2 * s] - step0, uv1 = w.B[2 * s + 1] - step1;
   const int n_total = w.n_steps[s] + 1;
@@ -157,120 +196,161 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
   // Dividing by 2^level is exact, so multiplying by 2^-level gives the same bits without f64 division sequences.
   const double inv_lvl = 1.0 / lvl;
   // The reference walks the line sequentially (matcher.cpp:268: uv += step, in f64) and skips a step whose
-  // integer pixel equals the previous step's.  Lane l of the seed's group takes the steps l, l+SCAN_G, ...: it replays only the CHAIN of
-  // additions up to its step (two v_add_f64 per step, so the positions carry the reference's rounding), keeps the
-  // position of the step before, and does the expensive part -- camera model, rounding, the 8x8 ZMSSD -- for its
-  // own steps only, all lanes of the group at once.  "Same pixel as the last step looked at" is "same pixel as step i-1":
-  // last_x/last_y are overwritten by every step that differs from them, so they always hold step i-1's pixel.
-  // The pixel of step i-1 is the pixel the lane to the left computed in this pass (the same chain of additions, the same
-  // arithmetic: the same bits), and for the group's first lane the pixel its last lane computed in the pass before:
-  // one DPP move per coordinate instead of a second camera projection and rounding per position (round 4).
-  {
-    const int lead = lane < n_total ? lane : n_total;
-    for (int j = 0; j < lead; ++j) {
-      uv0 += step0; uv1 += step1;
-    }
+  // integer pixel equals the previous step's.  Lane l of the seed's group takes the steps 2l, 2l+1, 2l+16, 2l+17, ...: it
+  // replays only the CHAIN of additions up to its steps (two v_add_f64 per step, so the positions carry the reference's
+  // rounding) and does the expensive part -- camera model, rounding, the 8x8 ZMSSD -- for its own steps only, all lanes
+  // of the group at once.  "Same pixel as the last step looked at" is "same pixel as step i-1": last_x/last_y are
+  // overwritten by every step that differs from them, so they always hold step i-1's pixel.  The pixel of step i-1 is the
+  // lane's own first pixel (for its second step), the second pixel of the lane to the left (the same chain of additions,
+  // the same arithmetic: the same bits), and for the group's first lane the second pixel of its last lane in the pass
+  // before: DPP moves, no second camera projection and no LDS.
+  for (int j = 0; j < 2 * lane; ++j) {
+    uv0 += step0; uv1 += step1;
   }
   int carry0 = 0, carry1 = 0;  // pixel of the last step of the pass before (last_x, last_y before the first step: 0, 0)
-  for (int base = 0; base < n_total; base += SCAN_G) {
-    const int i = base + lane;
-    bool want = false;  // this lane's position is new (not the pixel of the step before) and its patch lies inside the frame
-    int pxi0 = 0, pxi1 = 0;
-    if (i < n_total) {
+  for (int base = 0; base < n_total; base += SCAN_PP) {
+    const int ia = base + 2 * lane, ib = ia + 1;
+    const double ub0 = uv0 + step0, ub1 = uv1 + step1;  // the lane's second step
+    int xa = 0, ya = 0, xb = 0, yb = 0;
+    if (ia < n_total) {
       double pxs[2];
       const double uvs[2] = {uv0, uv1};
-      world2cam_uv(a.cam, uvs, pxs);  // cur_frame.cam_->world2cam(uv), matcher.cpp:269
-      pxi0 = cast_int(pxs[0] * inv_lvl + 0.5);
-      pxi1 = cast_int(pxs[1] * inv_lvl + 0.5);
+      scan_world2cam<PINHOLE>(a.cam, uvs, pxs);  // cur_frame.cam_->world2cam(uv), matcher.cpp:269
+      xa = cast_int(pxs[0] * inv_lvl + 0.5);
+      ya = cast_int(pxs[1] * inv_lvl + 0.5);
     }
+    if (ib < n_total) {
+      double pxs[2];
+      const double uvs[2] = {ub0, ub1};
+      scan_world2cam<PINHOLE>(a.cam, uvs, pxs);
+      xb = cast_int(pxs[0] * inv_lvl + 0.5);
+      yb = cast_int(pxs[1] * inv_lvl + 0.5);
+    }
+    bool want_a, want_b;  // the position is new (not the pixel of the step before) and its patch lies inside the frame
     {
-      // (every lane takes part in the cross-lane moves; a lane whose step does not exist is never anybody's i-1)
-      // (row_shr:1 stays inside a row of 16 lanes: groups of more lanes -- experimental builds -- take a shuffle)
-      const int left0 = SCAN_G <= 16 ? __builtin_amdgcn_update_dpp(0, pxi0, 0x111 /* row_shr:1 */, 0xf, 0xf, true) : __shfl_up(pxi0, 1, 64);
-      const int left1 = SCAN_G <= 16 ? __builtin_amdgcn_update_dpp(0, pxi1, 0x111, 0xf, 0xf, true) : __shfl_up(pxi1, 1, 64);
+      // (every lane takes part in the cross-lane moves; a lane whose step does not exist is never anybody's i-1;
+      // row_shr:1 stays inside a row of 16 lanes, and the first lane of a group takes the carry instead)
+      const int left0 = dpp_i32<0x111 /* row_shr:1 */>(xb), left1 = dpp_i32<0x111>(yb);
       const int prv0 = lane == 0 ? carry0 : left0, prv1 = lane == 0 ? carry1 : left1;
-      want = i < n_total && !(pxi0 == prv0 && pxi1 == prv1) && is_in_frame_level(a.cam, pxi0, pxi1, 8, sl);
-      const int last = (int)(threadIdx.x & 63u & ~(unsigned)(SCAN_G - 1)) + SCAN_G - 1;  // the group's last lane
-      carry0 = __shfl(pxi0, last, 64);
-      carry1 = __shfl(pxi1, last, 64);
+      want_a = ia < n_total && !(xa == prv0 && ya == prv1) && is_in_frame_level(a.cam, xa, ya, 8, sl);
+      want_b = ib < n_total && !(xb == xa && yb == ya) && is_in_frame_level(a.cam, xb, yb, 8, sl);
+      carry0 = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(xb);  // lane 0 <- lane 7 (the only lane that looks at it)
+      carry1 = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(yb);
     }
-    uint32_t sumB = 0, sumBB = 0, sumAB = 0;
-    bool boxed = false;
-    {
-      // bounding box of the group's windows [px-4, px+3]^2 (every lane of the group takes part, wanted or not)
-      const int x_lo = group8_min(want ? pxi0 - 4 : 0x7fffffff), x_hi = group8_max(want ? pxi0 + 3 : -1);
-      const int y_lo = group8_min(want ? pxi1 - 4 : 0x7fffffff), y_hi = group8_max(want ? pxi1 + 3 : -1);
-      const int cx0 = x_lo & ~15;                 // first tile column
-      const int n_rows = y_hi - y_lo + 1;
-      const bool two = x_hi - cx0 >= 16;          // a second tile column
-      boxed = x_hi >= 0 && n_rows <= 16 && x_hi - cx0 < 32;  // (uniform over the group)
-      if (boxed) {
-        const int n_chunks = two ? 2 * n_rows : n_rows;  // 16-byte tile rows to fetch: <= 32, four per lane
-        uint4 v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int c = lane + 8 * k;
-          const int row = two ? (c >> 1) : c, cc = two ? (c & 1) : 0;
-          v[k] = make_uint4(0, 0, 0, 0);
-          if (c < n_chunks) v[k] = *reinterpret_cast<const uint4*>(img + (svo_pyr::row_off(y_lo + row, pitch) + svo_pyr::col_off(cx0 + 16 * cc)));
+    // bounding boxes of the windows [px-4, px+3]^2: of this lane's two, of its half group (a quad), of the group
+    constexpr int BIG = 0x3fffffff;
+    int x_lo = min(want_a ? xa - 4 : BIG, want_b ? xb - 4 : BIG), x_hi = max(want_a ? xa + 3 : -1, want_b ? xb + 3 : -1);
+    int y_lo = min(want_a ? ya - 4 : BIG, want_b ? yb - 4 : BIG), y_hi = max(want_a ? ya + 3 : -1, want_b ? yb + 3 : -1);
+    x_lo = quad_min(x_lo); x_hi = quad_max(x_hi); y_lo = quad_min(y_lo); y_hi = quad_max(y_hi);
+    // (ox, oy: the bounds of the OTHER half group, from the mirror lane)
+    const int ox_lo = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(x_lo), ox_hi = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(x_hi);
+    const int oy_lo = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(y_lo), oy_hi = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(y_hi);
+    const int gx_lo = min(x_lo, ox_lo), gx_hi = max(x_hi, ox_hi), gy_lo = min(y_lo, oy_lo), gy_hi = max(y_hi, oy_hi);
+    // one box for the whole group if it fits (uniform over the group); else a box per half group, one after the other
+    const bool whole = gy_hi - gy_lo < SCAN_BOX_ROWS && gx_hi - (gx_lo & ~15) < 48;
+    if (gx_hi < 0) {
+      // nobody wants anything in this pass (uniform over the group)
+    } else {
+      ScanSums sa = {0, 0, 0}, sb = {0, 0, 0};
+      bool scored = false;
+      const int n_rounds = whole ? 1 : 2;
+      for (int h = 0; h < n_rounds; ++h) {
+        // bounds of this round's box: the group's, or (all lanes compute them alike) those of the half group h
+        int bx_lo = gx_lo, bx_hi = gx_hi, by_lo = gy_lo, by_hi = gy_hi;
+        if (!whole) {
+          const bool own = (lane >> 2) == h;
+          bx_lo = own ? x_lo : ox_lo; bx_hi = own ? x_hi : ox_hi; by_lo = own ? y_lo : oy_lo; by_hi = own ? y_hi : oy_hi;
         }
+        const bool mine = whole || (lane >> 2) == h;
+        const int cx0 = bx_lo & ~15;                 // first tile column
+        const int n_rows = by_hi - by_lo + 1;
+        const int n_cols = ((bx_hi - cx0) >> 4) + 1;  // tile columns
+        const bool boxed = bx_hi >= 0 && n_rows <= SCAN_BOX_ROWS && n_cols <= 3;  // (uniform over the group)
+        if (bx_hi < 0) continue;  // nothing wanted in this half
+        if (!boxed) continue;     // (left to the per-lane path below)
+        // the box: rows lane and lane + 8, up to three 16-byte tile rows each -- all requested, then all parked
+        uint4 v[2][3];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int c = lane + 8 * k;
-          const int row = two ? (c >> 1) : c, cc = two ? (c & 1) : 0;
-          if (c < n_chunks) *reinterpret_cast<uint4*>(box + row * 8 + cc * 4) = v[k];
-        }
-        // hand-over inside the wave: DS operations of one wave execute in order
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) {
+            const int row = lane + 8 * k;
+            v[k][cc] = make_uint4(0, 0, 0, 0);
+            if (row < n_rows && cc < n_cols)
+              v[k][cc] = *reinterpret_cast<const uint4*>(img + (svo_pyr::row_off(by_lo + row, pitch) + svo_pyr::col_off(cx0 + 16 * cc)));
+          }
+        // (the reads of the round before are done: DS operations of one wave execute in order)
         SVO_LANES_LDS_HANDOVER();
-        if (want) {
-          const int bx = pxi0 - 4 - cx0;             // 0..24: first byte of the window inside the 32-byte box row
-          const uint32_t sel = (uint32_t)(bx & 3);
-          const uint32_t* r = box + (pxi1 - 4 - y_lo) * 8 + (bx >> 2);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) {
+            const int row = lane + 8 * k;
+            if (row < n_rows && cc < n_cols) *reinterpret_cast<uint4*>(box + row * SCAN_BOX_ROW_DWORDS + cc * 4) = v[k][cc];
+          }
+        // hand-over inside the wave
+        SVO_LANES_LDS_HANDOVER();
+        if (mine && (want_a || want_b)) {
+          scored = true;
+          // (a position that is not wanted reads the window of the one that is: valid addresses, sums not used)
+          const int pxa = want_a ? xa : xb, pya = want_a ? ya : yb, pxb = want_b ? xb : xa, pyb = want_b ? yb : ya;
+          const int ba = pxa - 4 - cx0, bb = pxb - 4 - cx0;  // first byte of the window inside the 48-byte box row
+          const uint32_t sela = (uint32_t)(ba & 3), selb = (uint32_t)(bb & 3);
+          const uint32_t* ra = box + (pya - 4 - by_lo) * SCAN_BOX_ROW_DWORDS + (ba >> 2);
+          const uint32_t* rb = box + (pyb - 4 - by_lo) * SCAN_BOX_ROW_DWORDS + (bb >> 2);
+          const uint2* t2 = reinterpret_cast<const uint2*>(tpl);
 #pragma unroll
           for (int y = 0; y < 8; ++y) {
-            const uint32_t d0 = r[8 * y], d1 = r[8 * y + 1], d2 = r[8 * y + 2];
-            const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sel), hi = __builtin_amdgcn_alignbyte(d2, d1, sel);
-            sumB = __builtin_amdgcn_udot4(lo, 0x01010101u, sumB, false);
-            sumB = __builtin_amdgcn_udot4(hi, 0x01010101u, sumB, false);
-            sumBB = __builtin_amdgcn_udot4(lo, lo, sumBB, false);
-            sumBB = __builtin_amdgcn_udot4(hi, hi, sumBB, false);
-            sumAB = __builtin_amdgcn_udot4(lo, ra[2 * y], sumAB, false);
-            sumAB = __builtin_amdgcn_udot4(hi, ra[2 * y + 1], sumAB, false);
+            const uint2 t = t2[y];
+            scan_row(ra + SCAN_BOX_ROW_DWORDS * y, sela, t.x, t.y, sa);
+            scan_row(rb + SCAN_BOX_ROW_DWORDS * y, selb, t.x, t.y, sb);
           }
         }
-        SVO_LANES_LDS_HANDOVER();
       }
-    }
-    if (want) {
-      if (!boxed) {
-        // 8 rows x 8 bytes [pxi0-4, pxi0+3]: 12-byte runs, inside one tile row of the store where the 8 bytes are
-        const int wxa = svo_pyr::run_start(pxi0 - 4, 8);
-        const uint32_t wbo = (uint32_t)(pxi0 - 4 - wxa);  // 0..4
-        uint32_t win[8][3];
-        svo_pyr::load_window12<8>(img, pitch, wxa, pxi1 - 4, win);
+      if (!scored && (want_a || want_b)) {
+        // 8 rows x 8 bytes [px-4, px+3]: 12-byte runs, inside one tile row of the store where the 8 bytes are
 #pragma unroll
-        for (int y = 0; y < 8; ++y) {
-          uint32_t lo, hi;
-          cut_row8(win[y], wbo, lo, hi);
-          sumB = __builtin_amdgcn_udot4(lo, 0x01010101u, sumB, false);
-          sumB = __builtin_amdgcn_udot4(hi, 0x01010101u, sumB, false);
-          sumBB = __builtin_amdgcn_udot4(lo, lo, sumBB, false);
-          sumBB = __builtin_amdgcn_udot4(hi, hi, sumBB, false);
-          sumAB = __builtin_amdgcn_udot4(lo, ra[2 * y], sumAB, false);
-          sumAB = __builtin_amdgcn_udot4(hi, ra[2 * y + 1], sumAB, false);
+        for (int q = 0; q < 2; ++q) {
+          const bool wq = q == 0 ? want_a : want_b;
+          if (!wq) continue;
+          const int px = q == 0 ? xa : xb, py = q == 0 ? ya : yb;
+          ScanSums& sq = q == 0 ? sa : sb;
+          const int wxa = svo_pyr::run_start(px - 4, 8);
+          const uint32_t wbo = (uint32_t)(px - 4 - wxa);  // 0..4
+          uint32_t win[8][3];
+          svo_pyr::load_window12<8>(img, pitch, wxa, py - 4, win);
+#pragma unroll
+          for (int y = 0; y < 8; ++y) {
+            uint32_t lo, hi;
+            cut_row8(win[y], wbo, lo, hi);
+            const uint32_t t0 = tpl[2 * y], t1 = tpl[2 * y + 1];
+            sq.B = __builtin_amdgcn_udot4(lo, 0x01010101u, sq.B, false);
+            sq.B = __builtin_amdgcn_udot4(hi, 0x01010101u, sq.B, false);
+            sq.BB = __builtin_amdgcn_udot4(lo, lo, sq.BB, false);
+            sq.BB = __builtin_amdgcn_udot4(hi, hi, sq.BB, false);
+            sq.AB = __builtin_amdgcn_udot4(lo, t0, sq.AB, false);
+            sq.AB = __builtin_amdgcn_udot4(hi, t1, sq.AB, false);
+          }
         }
       }
-      const int sB = (int)sumB, sBB = (int)sumBB, sAB = (int)sumAB;
-      const int zmssd = sumAA - 2 * sAB + sBB - (sumA * sumA - 2 * sumA * sB + sB * sB) / 64;
-      if (zmssd < best) {  // the lane's steps come in increasing order: keeps its first minimum
-        best = zmssd;
-        best_i = i;
-        best_uv0 = uv0;
-        best_uv1 = uv1;
+      // the lane's steps come in increasing order: it keeps its first minimum
+      if (want_a) {
+        const int sB = (int)sa.B, sBB = (int)sa.BB, sAB = (int)sa.AB;
+        const int zmssd = sumAA - 2 * sAB + sBB - (sumA * sumA - 2 * sumA * sB + sB * sB) / 64;
+        if (zmssd < best) {
+          best = zmssd; best_i = ia; best_uv0 = uv0; best_uv1 = uv1;
+        }
+      }
+      if (want_b) {
+        const int sB = (int)sb.B, sBB = (int)sb.BB, sAB = (int)sb.AB;
+        const int zmssd = sumAA - 2 * sAB + sBB - (sumA * sumA - 2 * sumA * sB + sB * sB) / 64;
+        if (zmssd < best) {
+          best = zmssd; best_i = ib; best_uv0 = ub0; best_uv1 = ub1;
+        }
       }
     }
-    if (base + SCAN_G < n_total) {  // on to this lane's next step: SCAN_G more additions
-      for (int j = 0; j < SCAN_G; ++j) {
+    if (base + SCAN_PP < n_total) {  // on to this lane's next pair of steps: SCAN_PP more additions
+      for (int j = 0; j < SCAN_PP; ++j) {
         uv0 += step0; uv1 += step1;
       }
     }
@@ -291,7 +371,7 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
     double pcs[2];
     {
       const double uvb[2] = {best_uv0, best_uv1};
-      world2cam_uv(a.cam, uvb, pcs);  // px_cur_ = cur_frame.cam_->world2cam(uv_best), matcher.cpp:297,316
+      scan_world2cam<PINHOLE>(a.cam, uvb, pcs);  // px_cur_ = cur_frame.cam_->world2cam(uv_best), matcher.cpp:297,316
     }
     const double pc0 = pcs[0], pc1 = pcs[1];
     w.px_cur[2 * s] = pc0;
@@ -305,6 +385,5 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
   }
   if (lane == 0 && !(win_score < ZMSSD_THRESHOLD)) w.status[s] = SVO_HIP_SEED_NO_MATCH;
 }
-
 
 }  // namespace

@@ -26,16 +26,13 @@
 //     partials from LDS, multiplies by the cached H^-1, applies the stop / rollback
 //     rules and publishes the new pose through LDS; the others wait at a barrier.
 //
-// Numerics: pixel math in f32 (like the reference); projection, the solve and the
-// pose in f64 (like the reference).  The per-patch Jacobian rows and the per-lane
-// Jres / H partials are f32 (the reference keeps them in f64): a 1e-7 relative
-// perturbation of J moves the Gauss-Newton fixed point by ~1e-11, far below the
-// stated parity tolerance.  Sums are tree- instead of sequentially reduced, so
-// results agree to rounding, not bit-for-bit.
-// -DSIA_F64_PARTIALS builds the REFERENCE-WIDTH variant of this kernel (sia_acc = double): Jacobian rows, the
-// per-pixel products res*dx / res*dy / dx*dx ..., the per-lane partials, the wave reductions and SE3::exp in
-// f64 like H_, Jres_ and jacobian_cache_ of the reference (sparse_img_align.cpp:228-230,253-258).  bench.py
-// times it next to the default (`f64_partials` in the JSON line) so the price of that width is a number.
+// Numerics: pixel math in f32 (like the reference); projection, the Jacobian rows, the Jres / H partials and their
+// reductions, the solve and the pose in f64 (like the reference).  The 16 per-pixel products of a patch and their sums
+// are f32 (the reference forms them in f64): exact products of 24-bit factors, summed 16 at a time.  Sums are tree-
+// instead of sequentially reduced, so results agree to rounding, not bit-for-bit.
+// -DSIA_F64_PARTIALS builds the REFERENCE-WIDTH variant of this kernel: also the per-pixel products and SE3::exp in f64
+// like H_, Jres_ and jacobian_cache_ of the reference (sparse_img_align.cpp:228-230,253-258).  bench.py times it next to
+// the default (`f64_partials` / `roofline_f64_build` in the JSON line) so the price of that width is a number.
 #include "sia_common.h"
 
 using namespace svo_capi;
@@ -70,17 +67,16 @@ constexpr int MAX_WAVES = SVO_HIP_MAX_PATCHES / 64;
 // Arithmetic widths.  sia_pix: the per-pixel products res*dx, res*dy, dx*dx ... and their 16-term sums over a patch;
 // sia_acc: everything from the patch upwards -- the Jacobian rows a / b, the per-lane Jres and H partials, the wave
 // reductions, the per-wave partials in LDS.  The reference keeps all of it in f64 (jacobian_cache_, H_, Jres_:
-// sparse_img_align.cpp:139-140,228-230).  Default: products of two f32 values summed 16 at a time in f32, the rest in f64.
-//   -DSIA_F64_PARTIALS   the reference's width throughout (also SE3::exp in f64): three waves per SIMD
-//   -DSIA_F32_ROWS       rounds 2-4: everything below the solve in f32
+// sparse_img_align.cpp:139-140,228-230).  Default: products of two f32 values summed 16 at a time in f32, the rest in
+// f64 -- 13.5 M frames/s against 14.9 M with the rows and partials in f32 as in rounds 2-4, and the same agreement with the
+// reference as the all-f64 build below (max 1.0e-5 / 1.4e-5, 99.5 % identical iteration counts over 8192 frames:
+// profiles/r05b_k1_width_ab.txt).
+//   -DSIA_F64_PARTIALS   the reference's width throughout (also SE3::exp in f64): three waves per SIMD, 10.5 M frames/s
 #if defined(SIA_F64_PARTIALS)
 using sia_pix = double;
 using sia_acc = double;
 #undef MINW
 #define MINW(BLOCK) 3  // the f64 accumulators do not fit 128 VGPRs
-#elif defined(SIA_F32_ROWS)
-using sia_pix = float;
-using sia_acc = float;
 #else
 using sia_pix = float;
 using sia_acc = double;

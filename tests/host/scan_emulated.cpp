@@ -50,7 +50,7 @@ int scan_emulated(int form, int S, const uint8_t* store, long long slot_bytes, i
       const int grp = (int)threadIdx.x / 8, lane = (int)threadIdx.x % 8;
       if (grp >= n_groups) return;
       (void)form;
-      epi_scan_seed(a, s0 + grp, lane, boxes[grp].data());
+      epi_scan_seed<true>(a, s0 + grp, lane, boxes[grp].data());
     });
   }
   return 0;

