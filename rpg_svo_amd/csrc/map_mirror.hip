@@ -84,7 +84,8 @@ __device__ __forceinline__ uint32_t first_meeting(const int32_t* __restrict__ ob
   for (int k = 0; k < 8; ++k) {
     const uint32_t fr = w[k] >> 16, ord = w[k] & 0xffffu;
     if (k < n && ord != 0xffffu) {
-      const int r = s_kfrank[fr & (RM_MAX_FRAMES - 1)];
+      // (a stale record whose frame field lies beyond the table must not alias a live slot: it never wins)
+      const int r = fr < (uint32_t)RM_MAX_FRAMES ? s_kfrank[fr] : -1;
       const uint32_t key = (uint32_t)r << 12 | (ord & 0xfffu);
       if (r >= 0 && key < best) { best = key; ff = (int)fr; }
     }
@@ -93,12 +94,12 @@ __device__ __forceinline__ uint32_t first_meeting(const int32_t* __restrict__ ob
     const uint32_t x = (uint32_t)obs_word[o0 + k];
     const uint32_t fr = x >> 16, ord = x & 0xffffu;
     if (ord != 0xffffu) {
-      const int r = s_kfrank[fr & (RM_MAX_FRAMES - 1)];
+      const int r = fr < (uint32_t)RM_MAX_FRAMES ? s_kfrank[fr] : -1;
       const uint32_t key = (uint32_t)r << 12 | (ord & 0xfffu);
       if (r >= 0 && key < best) { best = key; ff = (int)fr; }
     }
   }
-  *first_frame = ff;
+  *first_frame = ff;  // < RM_MAX_FRAMES when >= 0: it indexes s_kfcount
   return best;
 }
 
@@ -154,7 +155,10 @@ __global__ void __launch_bounds__(RM_BLOCK) reproject_map_kernel(const ReprojMap
   }
   for (int k = tid; k < n_cells; k += RM_BLOCK) s_cnt[k] = 0;
   if (tid < RM_MAX_FRAMES) {
-    s_kfrank[tid] = tid < a.n_frames ? a.kf_rank[tid] : -1;
+    // (ranks are the positions of the overlapping keyframes, 0..15: four bits of the sort key.  A larger value in the
+    // device-resident array -- the C entry point cannot see it -- would spill into the key's type bits: such a frame is skipped)
+    const int r = tid < a.n_frames ? a.kf_rank[tid] : -1;
+    s_kfrank[tid] = r < 16 ? r : -1;
     s_kfcount[tid] = 0;
   }
   if (tid < a.n_frames) {

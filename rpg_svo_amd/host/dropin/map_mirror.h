@@ -370,6 +370,9 @@ class MapMirror {
     static const std::unordered_map<const Feature*, int> none;  // a candidate's Feature is in no keyframe's list yet
     for (CandList::iterator c = first_new; c != cl.end(); ++c)
       if (!appendCandidate(c, none)) return false;
+    // (a candidate's observation may have brought a frame the table did not hold: the limits rebuild() enforces hold
+    // on this path too -- false sends the caller through rebuild(), which hands the frame to the list-walking path)
+    if (pts_.size() > 16384 || frames_.size() + 1 > 64) return false;
     return true;
   }
 

@@ -88,7 +88,9 @@ bool closeViewObs(const Point& pt, const Vector3d& framepos, FramePositions& pos
 }
 
 // ---- row N2: the same call on the device-resident mirror of the map (map_mirror.h, svo_hip_reproject_map) -----------
-// One mirror per svo::Map (a process may run several handlers); entries live until process exit, like the device contexts.
+// One mirror per svo::Map (a process may run several handlers).  An entry lives as long as the Reprojector that reads the map:
+// the drop-in's destructor below releases it (the reference's Reprojector holds its Map by reference for its whole life),
+// so a Map allocated later at the same address never inherits a shadow full of dangling Point* / Feature* / Frame*.
 struct MirrorRegistry {
   std::mutex mut;
   std::map<const Map*, hip_dropin::MapMirror*> all;
@@ -103,6 +105,14 @@ hip_dropin::MapMirror& mirrorOf(const Map* map) {
   hip_dropin::MapMirror*& m = r.all[map];
   if (m == NULL) m = new hip_dropin::MapMirror();
   return *m;
+}
+void releaseMirror(const Map* map) {
+  MirrorRegistry& r = mirrors();
+  std::lock_guard<std::mutex> g(r.mut);
+  std::map<const Map*, hip_dropin::MapMirror*>::iterator it = r.all.find(map);
+  if (it == r.all.end()) return;
+  delete it->second;  // host vectors and the device buffers of the shadow (MapMirror::~MapMirror)
+  r.all.erase(it);
 }
 
 // Steps 1-4 of reprojectMap with the walk of the pointer graph replaced by one kernel over the mirror: the host finds
@@ -411,6 +421,12 @@ void mapMirrorStats(uint64_t out[6]) {
 }
 }  // namespace hip_dropin
 
+// The reference's destructor (reprojector.cpp:39-42) plus the release of the map's device-resident shadow.
+Reprojector::~Reprojector() {
+  std::for_each(grid_.cells.begin(), grid_.cells.end(), [&](Cell* c) { delete c; });
+  releaseMirror(&map_);
+}
+
 void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, std::size_t> >& overlap_kfs) {
   // deferred mapping: the depth filter's update of the previous frame hands its converged seeds to the map before
   // the map is read (no-op otherwise)
@@ -419,7 +435,15 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
   // the device-resident mirror of the map (row N2): SVO_HIP_MAP_MIRROR=on (default) | verify | off
   if (options_.find_match_direct && hip_dropin::MapMirror::mode() != hip_dropin::MapMirror::OFF) {
     SVO_START_TIMER("feature_align");
-    const bool done = reprojectMapMirrored(frame, overlap_kfs, map_, grid_, options_, matcher_.options_.align_max_iter, n_matches_, n_trials_);
+    bool done = false;
+    try {
+      done = reprojectMapMirrored(frame, overlap_kfs, map_, grid_, options_, matcher_.options_.align_max_iter, n_matches_, n_trials_);
+    } catch (...) {
+      // an error between the patch (which marks the shadow's records as sent) and a completed launch leaves the device
+      // copy behind the shadow: the next call starts from a fresh walk of the map
+      mirrorOf(&map_).invalidate();
+      throw;
+    }
     SVO_STOP_TIMER("feature_align");
     if (done) return;
   } else if (hip_dropin::MapMirror::mode() != hip_dropin::MapMirror::OFF) {

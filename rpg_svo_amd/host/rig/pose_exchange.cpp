@@ -76,18 +76,21 @@ void tcpBroadcast(int rank, int world, const std::string& addr, int port, void* 
       throw std::runtime_error("pose exchange bootstrap: setsockopt(SO_REUSEADDR) failed");
     // bind to MASTER_ADDR itself (127.0.0.1 on a single node), not to every interface.  MASTER_ADDR need not be an
     // address of a local interface (a NAT or service address, another NIC of a multi-homed host): SVO_RIG_BIND names
-    // the address to listen on then, and without it EADDRNOTAVAIL falls back to every interface, as torch's TCPStore
-    // listens -- the hello (magic / world / token) is what keeps strangers out in that case.
+    // the address to listen on then (0.0.0.0: every interface, the operator's explicit choice).  Without SVO_RIG_BIND,
+    // EADDRNOTAVAIL falls back to every interface ONLY for a job that carries a secret (SVO_RIG_TOKEN != 0): the hello
+    // (magic / world / token) is all that keeps a stranger from being handed the ncclUniqueId, and magic and world
+    // size are no secret.
     sockaddr_in la = sa;
     if (const char* b = std::getenv("SVO_RIG_BIND")) {
       if (::inet_pton(AF_INET, b, &la.sin_addr) != 1) throw std::runtime_error("pose exchange bootstrap: SVO_RIG_BIND must be an IPv4 address");
     }
     int rc = ::bind(ls.fd, reinterpret_cast<sockaddr*>(&la), sizeof(la));
     if (rc != 0 && errno == EADDRNOTAVAIL && !std::getenv("SVO_RIG_BIND")) {
+      if (token == 0)
+        throw std::runtime_error("pose exchange bootstrap: MASTER_ADDR is not an address of this host; set SVO_RIG_BIND to the "
+                                 "address to listen on, or SVO_RIG_TOKEN (a job secret) to listen on every interface");
       la.sin_addr.s_addr = htonl(INADDR_ANY);
       rc = ::bind(ls.fd, reinterpret_cast<sockaddr*>(&la), sizeof(la));
-      if (rc == 0 && token == 0)
-        std::fprintf(stderr, "pose exchange bootstrap: listening on every interface without SVO_RIG_TOKEN: set a job secret\n");
     }
     if (rc != 0 || ::listen(ls.fd, world) != 0) throw std::runtime_error("pose exchange bootstrap: cannot listen on MASTER_ADDR:port");
     timeval tv = {timeout_s, 0};
@@ -113,7 +116,11 @@ void tcpBroadcast(int rank, int world, const std::string& addr, int port, void* 
       if (h.magic != HELLO_MAGIC || h.world != (uint32_t)world || h.token != token || h.rank == 0 || h.rank >= (uint32_t)world ||
           served[h.rank])
         continue;
-      sendAll(c.fd, blob, bytes);
+      try {
+        sendAll(c.fd, blob, bytes);
+      } catch (const std::exception&) {
+        continue;  // the peer went away mid-transfer: its rank is not served, it may connect again
+      }
       served[h.rank] = true;
       ++n_served;
     }

@@ -18,6 +18,7 @@
 // bench.py --pipeline dropin).  No arithmetic of the path lives here.
 #include <cstdlib>
 #include <cstring>
+#include <list>
 #include <stdexcept>
 #include <string>
 
@@ -280,6 +281,21 @@ int pipe_last_features(void* h, int max_n, double* px, int32_t* level, double* p
     px[2 * n] = (*it)->px[0]; px[2 * n + 1] = (*it)->px[1];
     level[n] = (*it)->level;
     for (int k = 0; k < 3; ++k) pos[3 * n + k] = (*it)->point ? (*it)->point->pos_[k] : 0.0;
+  }
+  return n;
+}
+
+// the depth filter's seed list, for inspection (scripts/dropin_many.py: which seed sits on the convergence threshold where two
+// runs part ways): per seed batch_id, the feature's frame id, px, py, a, b, mu, z_range, sigma2 (9 doubles)
+int pipe_seeds(void* h, int max_n, double* out) {
+  Pipe* p = (Pipe*)h;
+  int n = 0;
+  std::list<Seed>& seeds = p->vo->depthFilter()->getSeeds();
+  for (std::list<Seed>::iterator it = seeds.begin(); it != seeds.end() && n < max_n; ++it, ++n) {
+    double* o = out + 9 * n;
+    o[0] = it->batch_id; o[1] = it->ftr && it->ftr->frame ? it->ftr->frame->id_ : -1;
+    o[2] = it->ftr ? it->ftr->px[0] : 0.0; o[3] = it->ftr ? it->ftr->px[1] : 0.0;
+    o[4] = it->a; o[5] = it->b; o[6] = it->mu; o[7] = it->z_range; o[8] = it->sigma2;
   }
   return n;
 }

@@ -133,6 +133,13 @@ class Pipeline:
         filled = self.lib.pipe_last_host_pyramid(self.h, C.byref(n))
         return n.value, filled
 
+    def seeds(self, max_n=8192):
+        """DepthFilter's seed list: rows of (batch_id, frame id of the feature, px, py, a, b, mu, z_range, sigma2)"""
+        out = np.zeros((max_n, 9))
+        self.lib.pipe_seeds.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        n = self.lib.pipe_seeds(self.h, max_n, out.ctypes.data)
+        return out[:n]
+
     def last_features(self, max_n=2048):
         px = np.zeros((max_n, 2)); lvl = np.zeros(max_n, dtype=np.int32); pos = np.zeros((max_n, 3))
         n = self.lib.pipe_last_features(self.h, max_n, px.ctypes.data, lvl.ctypes.data, pos.ctypes.data)
