@@ -101,13 +101,15 @@ constexpr int SCAN_BUCKETS = 8;
 // round trip a pass waits for.  The group therefore fetches the bounding box of its windows ONCE per pass, as 16-byte
 // tile rows of the store (one look-up each), parks it in LDS and every lane cuts its windows out of that.  Round 5: the
 // box covers 16 positions instead of 8 (half the round trips and half the box bookkeeping per position: the kernel
-// waited 57 % of its wave cycles), is up to 16 rows x 3 tile columns (48 bytes: a row of the box is 12 dwords, which
-// spreads the rows of a window over the banks -- rows r and r + 4 of the 8-dword rows of round 3 shared theirs, 34 % of
-// the port cycles were conflicts), and the 8 x 8 template lives in LDS next to it instead of in 16 registers of every
-// lane.  A pass whose 16 windows do not fit 16 rows (a line steeper than ~50 degrees) is done as two half passes, the box of
-// lanes 0-3 and then the box of lanes 4-7; a group whose half box does not fit either (never on an undistorted line)
-// fetches per lane.
-constexpr int SCAN_BOX_ROWS = 16, SCAN_BOX_ROW_DWORDS = 12;
+// waited 57 % of its wave cycles), is up to 20 rows x 3 tile columns (16 positions span 10.5 px: 19 rows on a vertical
+// line, 19 columns on a horizontal one; at most 48 of the 60 tile rows are ever needed, six per lane) of 48 bytes (a row
+// of the box is 12 dwords, which spreads the rows of a window over the banks -- rows r and r + 4 of the 8-dword rows of
+// round 3 shared theirs), and the 8 x 8 template lives in LDS next to it instead of in 16 registers of every lane.  (16
+// box rows and a second round for steeper lines measured only -5 %: a wave holds eight lines, nearly always a steep one
+// among them, and every group of the wave then sits through both rounds.)  A pass whose windows do not fit (a distorted
+// line) is done as two half passes, the box of lanes 0-3 and then the box of lanes 4-7; a group whose half box does not fit
+// either fetches per lane.
+constexpr int SCAN_BOX_ROWS = 20, SCAN_BOX_ROW_DWORDS = 12;
 constexpr int SCAN_TPL_OFF = SCAN_BOX_ROWS * SCAN_BOX_ROW_DWORDS + 4;  // (+ 4 dwords: the cut reads three dwords per row)
 constexpr int SCAN_BOX_DWORDS = SCAN_TPL_OFF + 16;                     // box, then the template's 8 rows of 2 dwords
 static_assert(SCAN_BOX_DWORDS % 4 == 0 && SCAN_TPL_OFF % 4 == 0, "16-byte LDS stores");
@@ -247,7 +249,8 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
     const int oy_lo = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(y_lo), oy_hi = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(y_hi);
     const int gx_lo = min(x_lo, ox_lo), gx_hi = max(x_hi, ox_hi), gy_lo = min(y_lo, oy_lo), gy_hi = max(y_hi, oy_hi);
     // one box for the whole group if it fits (uniform over the group); else a box per half group, one after the other
-    const bool whole = gy_hi - gy_lo < SCAN_BOX_ROWS && gx_hi - (gx_lo & ~15) < 48;
+    const bool whole = gy_hi - gy_lo < SCAN_BOX_ROWS && gx_hi - (gx_lo & ~15) < 48 &&
+                       (gy_hi - gy_lo + 1) * (((gx_hi - (gx_lo & ~15)) >> 4) + 1) <= 48;
     if (gx_hi < 0) {
       // nobody wants anything in this pass (uniform over the group)
     } else {
@@ -265,29 +268,28 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
         const int cx0 = bx_lo & ~15;                 // first tile column
         const int n_rows = by_hi - by_lo + 1;
         const int n_cols = ((bx_hi - cx0) >> 4) + 1;  // tile columns
-        const bool boxed = bx_hi >= 0 && n_rows <= SCAN_BOX_ROWS && n_cols <= 3;  // (uniform over the group)
+        const bool boxed = bx_hi >= 0 && n_rows <= SCAN_BOX_ROWS && n_cols <= 3 && n_rows * n_cols <= 48;  // (uniform over the group)
         if (bx_hi < 0) continue;  // nothing wanted in this half
         if (!boxed) continue;     // (left to the per-lane path below)
-        // the box: rows lane and lane + 8, up to three 16-byte tile rows each -- all requested, then all parked
-        uint4 v[2][3];
+        // the box: 16-byte tile rows, chunk c = row * n_cols + column, lane l takes the chunks l, l + 8, ... (at most 48:
+        // a box of many rows is narrow) -- all requested, then all parked
+        const int n_chunks = n_rows * n_cols;
+        const uint32_t inv = n_cols == 1 ? 65536u : (n_cols == 2 ? 32768u : 21846u);  // c / n_cols for c < 128
+        uint4 v[6];
+        int dst[6];
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-          for (int cc = 0; cc < 3; ++cc) {
-            const int row = lane + 8 * k;
-            v[k][cc] = make_uint4(0, 0, 0, 0);
-            if (row < n_rows && cc < n_cols)
-              v[k][cc] = *reinterpret_cast<const uint4*>(img + (svo_pyr::row_off(by_lo + row, pitch) + svo_pyr::col_off(cx0 + 16 * cc)));
-          }
+        for (int k = 0; k < 6; ++k) {
+          const int c = lane + 8 * k;
+          const int row = (int)(((uint32_t)c * inv) >> 16), cc = c - row * n_cols;
+          dst[k] = row * SCAN_BOX_ROW_DWORDS + cc * 4;
+          v[k] = make_uint4(0, 0, 0, 0);
+          if (c < n_chunks) v[k] = *reinterpret_cast<const uint4*>(img + (svo_pyr::row_off(by_lo + row, pitch) + svo_pyr::col_off(cx0 + 16 * cc)));
+        }
         // (the reads of the round before are done: DS operations of one wave execute in order)
         SVO_LANES_LDS_HANDOVER();
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-          for (int cc = 0; cc < 3; ++cc) {
-            const int row = lane + 8 * k;
-            if (row < n_rows && cc < n_cols) *reinterpret_cast<uint4*>(box + row * SCAN_BOX_ROW_DWORDS + cc * 4) = v[k][cc];
-          }
+        for (int k = 0; k < 6; ++k)
+          if (lane + 8 * k < n_chunks) *reinterpret_cast<uint4*>(box + dst[k]) = v[k];
         // hand-over inside the wave
         SVO_LANES_LDS_HANDOVER();
         if (mine && (want_a || want_b)) {
