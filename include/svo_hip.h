@@ -599,6 +599,35 @@ int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint8_t* d_stor
                          void* d_workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Row N2, seeds: DepthFilter::seeds_ (depth_filter.h:140, a std::list<Seed> of the struct at :35-51) kept RESIDENT in
+ * HBM between frames instead of being flattened and shipped both ways by every updateSeeds call.  The store is a set
+ * of caller-owned SoA columns (`svo_hip_features` for Seed::ftr, `svo_hip_seeds` for the state) indexed by SLOT; a seed
+ * keeps its slot for life.  Feature::frame is stored as a key into the frame table of the call (the caller keeps the
+ * keys of its keyframes stable; the current frame is entry `cur_frame` of the table).
+ *   svo_hip_seed_store_patch     writes n new records (SoA in `src_*`, record i) to slots d_slot[i]: what
+ *                                DepthFilter::initializeSeeds appended since the last call (depth_filter.cpp:121-151)
+ *   svo_hip_update_seeds_resident  svo_hip_update_seeds for the S seeds at slots d_slot_of[s], s in list order: the
+ *                                state is updated in place in the store; d_status / d_xyz_world / d_px_cur are dense
+ *                                (index s) as above, and d_state_out [4][S] receives a, b, mu, sigma2 after the update
+ *                                (dense, for the host's std::list<Seed>; may be NULL).  Same arithmetic, same results.
+ */
+typedef struct svo_hip_seed_patch {
+  int32_t n;
+  int32_t reserved;
+  const int32_t* d_slot;   /* [n] destination slots */
+  svo_hip_features src_ftr; /* [n] records (d_frame = the caller's frame key) */
+  svo_hip_seeds src_seeds;  /* [n] records */
+} svo_hip_seed_patch;
+int svo_hip_seed_store_patch(const svo_hip_seed_patch* patch, const svo_hip_features* store_ftr,
+                             const svo_hip_seeds* store_seeds, void* stream);
+int svo_hip_update_seeds_resident(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
+                                  const svo_hip_camera* cam, const svo_hip_frames* frames, int cur_frame, int S,
+                                  const int32_t* d_slot_of, const svo_hip_features* store_ftr,
+                                  const svo_hip_seeds* store_seeds, const svo_hip_depth_filter_options* opt,
+                                  int32_t* d_status, double* d_xyz_world, double* d_px_cur, float* d_state_out,
+                                  void* d_workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Batched Matcher::findEpipolarMatchDirect (svo/src/matcher.cpp:179-321; matcher.h:113-123) on its own:
  * query s searches along the epipolar segment of feature s of `ftr` (a feature of frame ftr->d_frame[s])
  * in frame d_cur_frame[s], for depths d_d_min[s] .. d_d_max[s] around d_d_estimate[s].

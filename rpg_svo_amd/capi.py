@@ -66,6 +66,11 @@ class Seeds(C.Structure):
                 ("d_sigma2", C.c_void_p), ("d_batch_id", C.c_void_p)]
 
 
+class SeedPatch(C.Structure):
+    """svo_hip_seed_patch: n new seed records (SoA) and the slots of the resident store they go to."""
+    _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("d_slot", C.c_void_p), ("src_ftr", Features), ("src_seeds", Seeds)]
+
+
 class DepthFilterOptions(C.Structure):
     _fields_ = [("max_n_kfs", C.c_int32), ("batch_counter", C.c_int32),
                 ("seed_convergence_sigma2_thresh", C.c_double), ("align_1d", C.c_int32),
@@ -183,6 +188,9 @@ PROTOTYPES = {
     "svo_hip_point_optimize": (_i, [C.POINTER(Frames), _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "svo_hip_update_seeds": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, C.POINTER(Features),
                                   C.POINTER(Seeds), C.POINTER(DepthFilterOptions), _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "svo_hip_seed_store_patch": (_i, [C.POINTER(SeedPatch), C.POINTER(Features), C.POINTER(Seeds), _vp]),
+    "svo_hip_update_seeds_resident": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _i, _vp, C.POINTER(Features),
+                                           C.POINTER(Seeds), C.POINTER(DepthFilterOptions), _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "svo_hip_find_epipolar_match_direct": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, C.POINTER(Features),
                                                 _vp, _vp, _vp, C.POINTER(DepthFilterOptions), _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "svo_hip_update_seed_batch": (_i, [_i, _vp, _vp, C.POINTER(Seeds), _vp]),

@@ -52,25 +52,26 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   w.search_level[s] = -1;  // not reached yet (an edgelet rejected by the angle filter returns before matcher.cpp:214)
   w.n_steps[s] = 0;
   w.accepted_raw[s] = 0;
-  const int cf = a.cur_frame[s];
+  const int cf = a.cur_frame ? a.cur_frame[s] : a.cur_index;
+  const int rec = a.slot_of ? a.slot_of[s] : s;  // the seed's record (resident store: its slot)
   // Every record of the seed is requested before the first early exit -- two memory round trips, (cf, rfi, batch id, mu,
   // sigma2, f) then (the two poses, the slot), instead of three or four: a load below an early exit cannot be issued above
   // it by the compiler (360 -> 315 us per 3.3 M seeds, profiles/r05a_queue_drain.txt).
-  const int rfi = a.ftr.d_frame[s];
+  const int rfi = a.ftr.d_frame[rec];
   // (the seed state does not exist in match-only calls: read through stand-in pointers, see below)
-  const int batch_raw = (a.match_only ? a.ftr.d_level : a.seeds.d_batch_id)[s];
-  const float mu_raw = (a.match_only ? reinterpret_cast<const float*>(a.ftr.d_px) : a.seeds.d_mu)[s];
-  const float sigma2_raw = (a.match_only ? reinterpret_cast<const float*>(a.ftr.d_px) : a.seeds.d_sigma2)[s];
+  const int batch_raw = (a.match_only ? a.ftr.d_level : a.seeds.d_batch_id)[rec];
+  const float mu_raw = (a.match_only ? reinterpret_cast<const float*>(a.ftr.d_px) : a.seeds.d_mu)[rec];
+  const float sigma2_raw = (a.match_only ? reinterpret_cast<const float*>(a.ftr.d_px) : a.seeds.d_sigma2)[rec];
   const int batch_id = a.match_only ? 0 : batch_raw;
   const float mu = a.match_only ? 1.f : mu_raw, sigma2 = a.match_only ? 0.f : sigma2_raw;
-  const double f[3] = {a.ftr.d_f[3 * s], a.ftr.d_f[3 * s + 1], a.ftr.d_f[3 * s + 2]};
+  const double f[3] = {a.ftr.d_f[3 * rec], a.ftr.d_f[3 * rec + 1], a.ftr.d_f[3 * rec + 2]};
   // (what the epipolar set-up reads further down, behind two more early exits: the feature's level, pixel, type and
   // gradient -- the optional type array through a stand-in pointer, a load under a condition is waited for in its branch)
-  const int rlevel_early = a.ftr.d_level[s];
-  const double rpx0_early = a.ftr.d_px[2 * s], rpx1_early = a.ftr.d_px[2 * s + 1];
-  const uint8_t type_early = (a.ftr.d_type ? a.ftr.d_type : reinterpret_cast<const uint8_t*>(a.ftr.d_px))[s];
+  const int rlevel_early = a.ftr.d_level[rec];
+  const double rpx0_early = a.ftr.d_px[2 * rec], rpx1_early = a.ftr.d_px[2 * rec + 1];
+  const uint8_t type_early = (a.ftr.d_type ? a.ftr.d_type : reinterpret_cast<const uint8_t*>(a.ftr.d_px))[rec];
   const double* const gradp = (a.ftr.d_type && a.ftr.d_grad) ? a.ftr.d_grad : a.ftr.d_px;
-  const double gx_early = gradp[2 * s], gy_early = gradp[2 * s + 1];
+  const double gx_early = gradp[2 * rec], gy_early = gradp[2 * rec + 1];
   double RtR[12], RtC[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
@@ -199,7 +200,7 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
 // seed that has been matched a few times searches 2-6 positions, one that never was and sees a long baseline
 // hundreds), and a wave runs as long as the longest scan among the seeds it holds: taken in list order the lanes
 // idle two thirds of the time.  So the workgroup first sorts its chunk by scan length (counting sort over
-// power-of-two buckets of ceil(positions / 16), in LDS), longest first, and its waves then fetch groups of
+// buckets: up to 8 positions, then powers of two of ceil(positions / 16); in LDS), longest first, and its waves then fetch groups of
 // 8 neighbouring entries of that order from an LDS counter: the seeds a wave holds at a time need about
 // the same number of passes, and no wave waits for another.  Seeds that do not scan (short segment, not visible,
 // rejected) never enter the order.  Results do not depend on the order.
@@ -224,8 +225,11 @@ __global__ void __launch_bounds__(SCAN_BLOCK, SCAN_MINW) epi_scan_kernel(const S
     bucket[k] = -1;
     rank[k] = 0;
     if (s < a.S && w.mode[s] == MODE_SCAN) {
-      const int passes = (w.n_steps[s] + 1 + SCAN_PP - 1) / SCAN_PP;  // n_steps + 1 positions (matcher.cpp:264)
-      bucket[k] = passes <= 1 ? 0 : min(SCAN_BUCKETS - 1, 32 - __clz(passes - 1));
+      // n_steps + 1 positions (matcher.cpp:264): lines of up to SCAN_G positions (one pass of one position per lane) in
+      // bucket 0, then power-of-two buckets of the passes of 2 SCAN_G positions
+      const int n_pos = w.n_steps[s] + 1;
+      const int passes = (n_pos + SCAN_PP - 1) / SCAN_PP;
+      bucket[k] = n_pos <= SCAN_G ? 0 : min(SCAN_BUCKETS - 1, 1 + (passes <= 1 ? 0 : 32 - __clz(passes - 1)));
       rank[k] = atomicAdd(&s_hist[bucket[k]], 1);
     }
   }
@@ -263,15 +267,16 @@ __global__ void SEED_FINISH_BOUNDS seed_finish_kernel(const SeedArgs a) {
   const SeedWs& w = a.ws;
   // every record the seed may need is requested before the first early exit, as in seed_prepare_kernel (259 -> 243 us).
   // Workspace words of a seed that did not get that far hold whatever they held: read, not used.
-  const int cf = a.cur_frame[s];
-  const int rfi = a.ftr.d_frame[s];
+  const int cf = a.cur_frame ? a.cur_frame[s] : a.cur_index;
+  const int rec = a.slot_of ? a.slot_of[s] : s;  // the seed's record (resident store: its slot)
+  const int rfi = a.ftr.d_frame[rec];
   const int aok_early = w.align_ok[s];
   const double pxc0 = w.px_cur[2 * s], pxc1 = w.px_cur[2 * s + 1];
-  const double f[3] = {a.ftr.d_f[3 * s], a.ftr.d_f[3 * s + 1], a.ftr.d_f[3 * s + 2]};
+  const double f[3] = {a.ftr.d_f[3 * rec], a.ftr.d_f[3 * rec + 1], a.ftr.d_f[3 * rec + 2]};
   float sa = 0.f, sb = 0.f, smu = 0.f, ssig = 0.f, zr_early = 0.f;
   if (!a.match_only) {
-    sa = a.seeds.d_a[s]; sb = a.seeds.d_b[s]; smu = a.seeds.d_mu[s]; ssig = a.seeds.d_sigma2[s];
-    zr_early = a.seeds.d_z_range[s];
+    sa = a.seeds.d_a[rec]; sb = a.seeds.d_b[rec]; smu = a.seeds.d_mu[rec]; ssig = a.seeds.d_sigma2[rec];
+    zr_early = a.seeds.d_z_range[rec];
   }
   double RtR[12], RtC[12];
 #pragma unroll
@@ -320,7 +325,10 @@ __global__ void SEED_FINISH_BOUNDS seed_finish_kernel(const SeedArgs a) {
   }
   const float zr = zr_early;
   if (!matched) {
-    a.seeds.d_b[s] = sb + 1.0f;  // it->b++ (:240)
+    a.seeds.d_b[rec] = sb + 1.0f;  // it->b++ (:240)
+    if (a.state_out) {
+      a.state_out[s] = sa; a.state_out[a.S + s] = sb + 1.0f; a.state_out[2 * a.S + s] = smu; a.state_out[3 * a.S + s] = ssig;
+    }
     a.status_out[s] = SVO_HIP_SEED_NO_MATCH;
     return;
   }
@@ -331,10 +339,13 @@ __global__ void SEED_FINISH_BOUNDS seed_finish_kernel(const SeedArgs a) {
   const double zmt = (0.0000001 < z - tau) ? z - tau : 0.0000001;
   const double tau_inverse = 0.5 * (1.0 / zmt - 1.0 / (z + tau));
   update_seed((float)(1. / z), (float)(tau_inverse * tau_inverse), sa, sb, smu, zr, ssig);
-  a.seeds.d_a[s] = sa;
-  a.seeds.d_b[s] = sb;
-  a.seeds.d_mu[s] = smu;
-  a.seeds.d_sigma2[s] = ssig;
+  a.seeds.d_a[rec] = sa;
+  a.seeds.d_b[rec] = sb;
+  a.seeds.d_mu[rec] = smu;
+  a.seeds.d_sigma2[rec] = ssig;
+  if (a.state_out) {
+    a.state_out[s] = sa; a.state_out[a.S + s] = sb; a.state_out[2 * a.S + s] = smu; a.state_out[3 * a.S + s] = ssig;
+  }
   if ((double)sqrtf(ssig) < (double)zr / a.opt.seed_convergence_sigma2_thresh) {
     const Se3 Tr_inv = se3_inverse(Tr);
     const double kk = 1.0 / (double)smu;
@@ -432,6 +443,9 @@ extern "C" int svo_hip_find_epipolar_match_direct(const svo_hip_pyr_layout* layo
   a.frame_slot = frames->d_slot;
   a.frame_T = frames->d_T_f_w;
   a.cur_frame = d_cur_frame;
+  a.cur_index = 0;
+  a.slot_of = nullptr;
+  a.state_out = nullptr;
   a.ftr = *ftr;
   a.seeds.d_a = a.seeds.d_b = a.seeds.d_mu = a.seeds.d_z_range = a.seeds.d_sigma2 = nullptr;
   a.seeds.d_batch_id = nullptr;
@@ -474,6 +488,103 @@ extern "C" int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint
   a.frame_slot = frames->d_slot;
   a.frame_T = frames->d_T_f_w;
   a.cur_frame = d_cur_frame;
+  a.cur_index = 0;
+  a.slot_of = nullptr;
+  a.state_out = nullptr;
+  a.ftr = *ftr;
+  a.seeds = *seeds;
+  a.opt = *opt;
+  a.status_out = d_status;
+  a.xyz_world = d_xyz_world;
+  a.px_cur_out = d_px_cur;
+  a.match_only = 0;
+  a.d_est = a.d_min = a.d_max = nullptr;
+  a.depth_out = nullptr;
+  a.ok_out = nullptr;
+  a.search_level_out = nullptr;
+  return run_seed_chain(layout, d_store, a, S, d_workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+// ---- row N2, seeds: the resident store (include/svo_hip.h) ------------------------------------------------------------
+namespace {
+struct SeedPatchArgs {
+  svo_hip_seed_patch p;
+  svo_hip_features ftr;
+  svo_hip_seeds seeds;
+};
+__global__ void __launch_bounds__(256) seed_patch_kernel(const SeedPatchArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.p.n) return;
+  const int q = a.p.d_slot[i];
+  const svo_hip_features& sf = a.p.src_ftr;
+  const svo_hip_seeds& ss = a.p.src_seeds;
+  // (every field read before the first store: the arrays cannot be proven distinct)
+  const int32_t fr = sf.d_frame[i], lv = sf.d_level[i], bid = ss.d_batch_id[i];
+  const uint8_t ty = sf.d_type ? sf.d_type[i] : (uint8_t)SVO_HIP_FTR_CORNER;
+  const double px0 = sf.d_px[2 * i], px1 = sf.d_px[2 * i + 1];
+  const double f0 = sf.d_f[3 * i], f1 = sf.d_f[3 * i + 1], f2 = sf.d_f[3 * i + 2];
+  const double g0 = sf.d_grad ? sf.d_grad[2 * i] : 1.0, g1 = sf.d_grad ? sf.d_grad[2 * i + 1] : 0.0;
+  const float sa = ss.d_a[i], sb = ss.d_b[i], smu = ss.d_mu[i], szr = ss.d_z_range[i], ss2 = ss.d_sigma2[i];
+  const_cast<int32_t*>(a.ftr.d_frame)[q] = fr;
+  const_cast<int32_t*>(a.ftr.d_level)[q] = lv;
+  const_cast<uint8_t*>(a.ftr.d_type)[q] = ty;
+  const_cast<double*>(a.ftr.d_px)[2 * q] = px0; const_cast<double*>(a.ftr.d_px)[2 * q + 1] = px1;
+  const_cast<double*>(a.ftr.d_f)[3 * q] = f0; const_cast<double*>(a.ftr.d_f)[3 * q + 1] = f1; const_cast<double*>(a.ftr.d_f)[3 * q + 2] = f2;
+  const_cast<double*>(a.ftr.d_grad)[2 * q] = g0; const_cast<double*>(a.ftr.d_grad)[2 * q + 1] = g1;
+  a.seeds.d_a[q] = sa; a.seeds.d_b[q] = sb; a.seeds.d_mu[q] = smu; a.seeds.d_z_range[q] = szr; a.seeds.d_sigma2[q] = ss2;
+  const_cast<int32_t*>(a.seeds.d_batch_id)[q] = bid;
+}
+}  // namespace
+
+extern "C" int svo_hip_seed_store_patch(const svo_hip_seed_patch* patch, const svo_hip_features* store_ftr,
+                                        const svo_hip_seeds* store_seeds, void* stream) {
+  if (!patch || !store_ftr || !store_seeds || patch->n < 0) return SVO_HIP_EINVAL;
+  if (patch->n == 0) return SVO_HIP_OK;
+  const svo_hip_features& sf = patch->src_ftr;
+  const svo_hip_seeds& ss = patch->src_seeds;
+  if (!patch->d_slot || !sf.d_frame || !sf.d_level || !sf.d_px || !sf.d_f || !ss.d_a || !ss.d_b || !ss.d_mu || !ss.d_z_range ||
+      !ss.d_sigma2 || !ss.d_batch_id)
+    return SVO_HIP_EINVAL;
+  if (!store_ftr->d_frame || !store_ftr->d_level || !store_ftr->d_type || !store_ftr->d_px || !store_ftr->d_f || !store_ftr->d_grad ||
+      !store_seeds->d_a || !store_seeds->d_b || !store_seeds->d_mu || !store_seeds->d_z_range || !store_seeds->d_sigma2 ||
+      !store_seeds->d_batch_id)
+    return SVO_HIP_EINVAL;  // the store carries every column (type and gradient included)
+  SeedPatchArgs a;
+  a.p = *patch;
+  a.ftr = *store_ftr;
+  a.seeds = *store_seeds;
+  hipLaunchKernelGGL(seed_patch_kernel, dim3((patch->n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch();
+}
+
+extern "C" int svo_hip_update_seeds_resident(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
+                                             const svo_hip_camera* cam, const svo_hip_frames* frames, int cur_frame, int S,
+                                             const int32_t* d_slot_of, const svo_hip_features* ftr,
+                                             const svo_hip_seeds* seeds, const svo_hip_depth_filter_options* opt,
+                                             int32_t* d_status, double* d_xyz_world, double* d_px_cur, float* d_state_out,
+                                             void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (!layout_ok(layout) || !d_store || !cam || !cam_model_ok(cam) || !frames || !ftr || !seeds || !opt || S < 0) return SVO_HIP_EINVAL;
+  if (S == 0) return SVO_HIP_OK;
+  if (!d_slot_of || !d_status || !frames->d_slot || !frames->d_T_f_w || cur_frame < 0 || cur_frame >= frames->n_frames ||
+      !ftr->d_frame || !ftr->d_level || !ftr->d_px || !ftr->d_f || !seeds->d_a || !seeds->d_b || !seeds->d_mu ||
+      !seeds->d_z_range || !seeds->d_sigma2 || !seeds->d_batch_id)
+    return SVO_HIP_EINVAL;
+  if (ftr->d_type && !ftr->d_grad) return SVO_HIP_EINVAL;
+  if (opt->n_pyr_levels < 1 || opt->n_pyr_levels > layout->n_levels || opt->align_max_iter < 0 ||
+      opt->max_epi_search_steps < 0)
+    return SVO_HIP_EINVAL;
+  if (!d_workspace || workspace_bytes < svo_hip_match_workspace_bytes(S)) return SVO_HIP_ERANGE;
+  SeedArgs a;
+  a.L = *layout;
+  a.store = d_store;
+  a.cam = make_cam(cam);
+  a.S = S;
+  a.frame_slot = frames->d_slot;
+  a.frame_T = frames->d_T_f_w;
+  a.cur_frame = nullptr;
+  a.cur_index = cur_frame;
+  a.slot_of = d_slot_of;
+  a.state_out = d_state_out;
   a.ftr = *ftr;
   a.seeds = *seeds;
   a.opt = *opt;

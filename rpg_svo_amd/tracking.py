@@ -339,6 +339,34 @@ class DepthFilter:
                                                  ws.data_ptr(), ws.numel(), _stream_ptr(dev)), "svo_hip_update_seeds")
         return status, xyz, px
 
+    def update_seeds_resident(self, store: PyramidStore, cam, frames: FrameTable, cur_frame: int, slot_of, store_ftr: FeatureSet,
+                              store_seeds: SeedSet, batch_counter: int):
+        """svo_hip_update_seeds_resident (row N2): the S seeds at slots `slot_of` [S] i32 of a resident store (store_ftr /
+        store_seeds: columns indexed by slot, FeatureSet.frame holding frame-table indices), all updated with frame
+        `cur_frame` of the table.  Returns (status [S], xyz_world [S,3], px_cur [S,2], state [4,S] = a, b, mu, sigma2)."""
+        S = slot_of.shape[0]
+        dev = store.device
+        self.opt.batch_counter = batch_counter
+        status = torch.zeros(S, dtype=torch.int32, device=dev)
+        xyz = torch.zeros(S, 3, dtype=torch.float64, device=dev)
+        px = torch.zeros(S, 2, dtype=torch.float64, device=dev)
+        state = torch.zeros(4, S, dtype=torch.float32, device=dev)
+        ws = self._ws.get(self.lib, S, dev)
+        c, fr, ft, sd = capi.camera(cam), frames.struct(), store_ftr.struct(), store_seeds.struct()
+        capi.check(self.lib.svo_hip_update_seeds_resident(
+            C.byref(store.layout), store.ptr, C.byref(c), C.byref(fr), int(cur_frame), S, _chk(slot_of, torch.int32).data_ptr(),
+            C.byref(ft), C.byref(sd), C.byref(self.opt), status.data_ptr(), xyz.data_ptr(), px.data_ptr(), state.data_ptr(),
+            ws.data_ptr(), ws.numel(), _stream_ptr(dev)), "svo_hip_update_seeds_resident")
+        return status, xyz, px, state
+
+    @staticmethod
+    def seed_store_patch(slots, src_ftr: FeatureSet, src_seeds: SeedSet, store_ftr: FeatureSet, store_seeds: SeedSet):
+        """svo_hip_seed_store_patch: record i of src_* goes to slot slots[i] of the store's columns."""
+        lib = capi.load()
+        p = capi.SeedPatch(int(slots.shape[0]), 0, _chk(slots, torch.int32).data_ptr(), src_ftr.struct(), src_seeds.struct())
+        ft, sd = store_ftr.struct(), store_seeds.struct()
+        capi.check(lib.svo_hip_seed_store_patch(C.byref(p), C.byref(ft), C.byref(sd), _stream_ptr(slots.device)), "svo_hip_seed_store_patch")
+
     @staticmethod
     def update_seed(x, tau2, seeds: SeedSet):
         """static DepthFilter::updateSeed(x, tau2, seed) for S independent measurements."""

@@ -179,3 +179,69 @@ def test_emulated_update_seeds(emu_seeds, oracle, scene, align_1d, subpix):
             assert np.abs(xyz[i] - np.array(io[i].xyz_world[:])).max() < 1e-5
     assert hist.get(pytrack.SEED_UPDATED, 0) > 50 and hist.get(pytrack.SEED_CONVERGED, 0) > 2
     assert hist.get(pytrack.SEED_ERASED_OLD, 0) > 5 and hist.get(pytrack.SEED_BEHIND, 0) > 2
+
+
+def test_emulated_update_seeds_on_the_resident_store(emu_seeds, scene):
+    """Row N2, seeds, on the CPU: the seeds scattered over a resident store (svo_hip_seed_store_patch) and updated in list
+    order through svo_hip_update_seeds_resident give the bits svo_hip_update_seeds gives on the flattened list -- statuses,
+    points, px_cur, the state in the store and in the dense read-back -- and leave every other slot alone."""
+    emu = emu_seeds
+    orc = pytrack.Track("orc")
+    layout, store = _store(emu, scene)
+    T = np.ascontiguousarray(scene.T_f_w)
+    n_frames = T.shape[0]
+    slots_f = np.arange(n_frames, dtype=np.int32)
+    frames = capi.Frames(n_frames, 0, slots_f.ctypes.data, T.ctypes.data)
+    rng = np.random.default_rng(8)
+    seeds, feats = _make_seeds(scene, orc, rng)
+    S = len(seeds)
+    c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+
+    def columns(idx):
+        f = [c([feats[i][0] for i in idx], np.int32), c([feats[i][3] for i in idx], np.int32), c([feats[i][4] for i in idx], np.uint8),
+             c([feats[i][1] for i in idx], np.float64), c([feats[i][2] for i in idx], np.float64), c([feats[i][5] for i in idx], np.float64)]
+        sd = [c([seeds[i].a for i in idx], np.float32), c([seeds[i].b for i in idx], np.float32), c([seeds[i].mu for i in idx], np.float32),
+              c([seeds[i].z_range for i in idx], np.float32), c([seeds[i].sigma2 for i in idx], np.float32), c([seeds[i].batch_id for i in idx], np.int32)]
+        return f, sd
+    structs = lambda f, sd: (capi.Features(*[x.ctypes.data for x in f]), capi.Seeds(*[x.ctypes.data for x in sd]))
+    dopt = capi.DepthFilterOptions(3, 5, 200.0, 0, 10, 1000, 1, 1, 5, 0.7)
+    cam = capi.camera(scene.cam)
+    emu.svo_hip_match_workspace_bytes.restype = C.c_size_t
+    ws = np.full(emu.svo_hip_match_workspace_bytes(S) + 256, 0xFF, np.uint8)
+    # flattened list
+    f0, s0 = columns(range(S))
+    ftr0, sd0 = structs(f0, s0)
+    cur = np.full(S, scene.cur, np.int32)
+    st0, xyz0, px0 = np.zeros(S, np.int32), np.zeros((S, 3)), np.zeros((S, 2))
+    assert emu.svo_hip_update_seeds(C.byref(layout), _p(store), C.byref(cam), C.byref(frames), S, _p(cur), C.byref(ftr0), C.byref(sd0),
+                                    C.byref(dopt), _p(st0), _p(xyz0), _p(px0), _p(ws), C.c_size_t(ws.size), None) == 0
+    # resident store of 3 S slots, patched in two instalments
+    cap = 3 * S
+    slot_of = rng.permutation(cap)[:S].astype(np.int32)
+    fS = [np.full(cap, 77, np.int32), np.full(cap, 77, np.int32), np.full(cap, 77, np.uint8), np.full((cap, 2), 77.0), np.full((cap, 3), 77.0), np.full((cap, 2), 77.0)]
+    sS = [np.full(cap, 77, np.float32) for _ in range(5)] + [np.full(cap, 77, np.int32)]
+    ftrS, sdS = structs(fS, sS)
+    for part in (list(range(S // 2)), list(range(S // 2, S))):
+        fp, sp = columns(part)
+        sl = np.ascontiguousarray(slot_of[part])
+        ftp, sdp = structs(fp, sp)
+        patch = capi.SeedPatch(len(part), 0, sl.ctypes.data, ftp, sdp)
+        assert emu.svo_hip_seed_store_patch(C.byref(patch), C.byref(ftrS), C.byref(sdS), None) == 0
+    ws[:] = 0xFF
+    st1, xyz1, px1, state = np.zeros(S, np.int32), np.zeros((S, 3)), np.zeros((S, 2)), np.zeros((4, S), np.float32)
+    assert emu.svo_hip_update_seeds_resident(C.byref(layout), _p(store), C.byref(cam), C.byref(frames), int(scene.cur), S, _p(slot_of), C.byref(ftrS),
+                                             C.byref(sdS), C.byref(dopt), _p(st1), _p(xyz1), _p(px1), _p(state), _p(ws), C.c_size_t(ws.size), None) == 0
+    assert np.array_equal(st0, st1) and np.array_equal(px0, px1)
+    conv = st0 == pytrack.SEED_CONVERGED
+    assert np.array_equal(xyz0[conv], xyz1[conv]) and conv.sum() > 2
+    touched = np.isin(st0, (pytrack.SEED_NO_MATCH, pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED, pytrack.SEED_NAN))
+    for k, name in enumerate(("a", "b", "mu", None, "sigma2")):
+        if name is None:
+            continue
+        flat, resident = s0[k], sS[k][slot_of]
+        assert np.array_equal(flat.view(np.int32), resident.view(np.int32)), name
+        row = {"a": 0, "b": 1, "mu": 2, "sigma2": 3}[name]
+        assert np.array_equal(state[row][touched].view(np.int32), flat[touched].view(np.int32)), name
+    free = np.ones(cap, bool)
+    free[slot_of] = False
+    assert (sS[2][free] == 77).all() and (fS[1][free] == 77).all() and (sS[5][free] == 77).all() and touched.sum() > 100

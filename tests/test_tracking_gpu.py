@@ -514,6 +514,54 @@ def test_update_seeds(gpu_device, orc, scene, pyrs, align_1d, subpix):
     assert hist.get(pytrack.SEED_ERASED_OLD, 0) > 5 and hist.get(pytrack.SEED_BEHIND if orc.which == "orc" else 0, 0) > 2
 
 
+def test_update_seeds_on_the_resident_store(gpu_device, scene, pyrs, orc):
+    """Row N2, seeds: the seeds scattered over the slots of a resident store (svo_hip_seed_store_patch), updated through
+    svo_hip_update_seeds_resident in list order: statuses, new points, px_cur and the state -- in the store AND in the
+    dense read-back -- are the bits svo_hip_update_seeds produces on the flattened list; slots nobody named are untouched."""
+    store, frames = scene_store(scene)
+    rng = np.random.default_rng(8)
+    seeds, feats = _make_seeds(scene, orc, rng)
+    S = len(seeds)
+    mk_f = lambda idx: tracking.FeatureSet(frame=dev([feats[i][0] for i in idx], torch.int32), level=dev([feats[i][3] for i in idx], torch.int32),
+                                           px=dev([feats[i][1] for i in idx], torch.float64), f=dev([feats[i][2] for i in idx], torch.float64),
+                                           type=dev([feats[i][4] for i in idx], torch.uint8), grad=dev([feats[i][5] for i in idx], torch.float64))
+    mk_s = lambda idx: tracking.SeedSet(a=dev([seeds[i].a for i in idx], torch.float32), b=dev([seeds[i].b for i in idx], torch.float32),
+                                        mu=dev([seeds[i].mu for i in idx], torch.float32), z_range=dev([seeds[i].z_range for i in idx], torch.float32),
+                                        sigma2=dev([seeds[i].sigma2 for i in idx], torch.float32),
+                                        batch_id=dev([seeds[i].batch_id for i in idx], torch.int32))
+    allidx = list(range(S))
+    # the flattened list through the plain entry point
+    fs, ss = mk_f(allidx), mk_s(allidx)
+    df = tracking.DepthFilter(n_pyr_levels=5)
+    st0, xyz0, px0 = df.update_seeds(store, scene.cam, frames, torch.full((S,), scene.cur, dtype=torch.int32, device="cuda:0"), fs, ss, batch_counter=5)
+    torch.cuda.synchronize()
+    # the same seeds in a store of 3 S slots, at random slots, patched in two instalments
+    cap = 3 * S
+    slots = rng.permutation(cap)[:S].astype(np.int32)
+    z = lambda n, dt: torch.full((n,) if isinstance(n, int) else n, 77, dtype=dt, device="cuda:0")
+    sf = tracking.FeatureSet(frame=z(cap, torch.int32), level=z(cap, torch.int32), px=z((cap, 2), torch.float64), f=z((cap, 3), torch.float64),
+                             type=z(cap, torch.uint8), grad=z((cap, 2), torch.float64))
+    sst = tracking.SeedSet(a=z(cap, torch.float32), b=z(cap, torch.float32), mu=z(cap, torch.float32), z_range=z(cap, torch.float32),
+                           sigma2=z(cap, torch.float32), batch_id=z(cap, torch.int32))
+    half = S // 2
+    for part in (allidx[:half], allidx[half:]):
+        tracking.DepthFilter.seed_store_patch(dev(slots[part], torch.int32), mk_f(part), mk_s(part), sf, sst)
+    st1, xyz1, px1, state = df.update_seeds_resident(store, scene.cam, frames, scene.cur, dev(slots, torch.int32), sf, sst, batch_counter=5)
+    torch.cuda.synchronize()
+    assert torch.equal(st0, st1) and torch.equal(px0, px1)
+    conv = st0 == pytrack.SEED_CONVERGED
+    assert torch.equal(xyz0[conv], xyz1[conv]) and int(conv.sum()) > 2
+    sl = torch.as_tensor(slots.astype(np.int64), device="cuda:0")
+    for name, k in (("a", 0), ("b", 1), ("mu", 2), ("sigma2", 3)):
+        flat, resident = getattr(ss, name), getattr(sst, name)[sl]
+        assert torch.equal(flat.view(torch.int32), resident.view(torch.int32)), name  # (bit patterns: NaN seeds included)
+        touched = torch.isin(st0, torch.tensor([pytrack.SEED_NO_MATCH, pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED, pytrack.SEED_NAN], device="cuda:0"))
+        assert torch.equal(state[k][touched].view(torch.int32), flat[touched].view(torch.int32)), name
+    free = torch.ones(cap, dtype=torch.bool, device="cuda:0")
+    free[sl] = False
+    assert (sst.mu[free] == 77).all() and (sf.level[free] == 77).all() and (sst.batch_id[free] == 77).all()
+
+
 def test_large_batches_take_the_same_decisions(gpu_device, scene, orc):
     """Batches of >= 65 536 trials run the alignment in phases inside svo_hip_find_match_direct / svo_hip_update_seeds,
     and the epipolar scan orders the seeds of a workgroup by length: the same trials, tiled and shuffled into a large
