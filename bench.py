@@ -1544,7 +1544,8 @@ def dropin_sequence(n_frames: int = 600) -> dict:
         with_pyr = {"skipped": repr(e)}
     return {"frames": n_frames, "map_size": map_size, "host_pyramid_levels_built_of": host.get("host_pyramid"),
             "median_ms_per_frame_hip_dropin_with_the_host_pyramid_built": with_pyr,
-            "map_mirror": host.get("map_mirror"), "median_ms_per_frame_hip_dropin_list_walking_reprojector": list_walk,
+            "map_mirror": host.get("map_mirror"), "seed_store": host.get("seed_store"),
+            "median_ms_per_frame_hip_dropin_list_walking_reprojector": list_walk,
             "first_frame_with_a_different_decision": first_diff,
             "first_frame_with_a_different_tracking_decision": first_trk,
             "se3_lognorm_max_before_the_first_tracking_difference": float(d[:first_trk if first_trk is not None else n_frames].max()),

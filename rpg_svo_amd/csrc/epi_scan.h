@@ -246,9 +246,9 @@ __device__ __forceinline__ void scan_line(const SeedArgs& a, const int sl, const
         if (bx_hi < 0) continue;  // nothing wanted in this half
         if (!boxed) continue;     // (left to the per-lane path below)
         // the box: 16-byte tile rows, chunk c = row * n_cols + column, lane l takes the chunks l, l + 8, ... (at most 48:
-        // a box of many rows is narrow; a pass of one position per lane never needs more than 24) -- all requested, then
+        // a box of many rows is narrow; a pass of one position per lane needs at most 28) -- all requested, then
         // all parked
-        constexpr int NK = PP == 2 ? 6 : 3;
+        constexpr int NK = PP == 2 ? 6 : 4;  // (8 windows 0.7 px apart span <= 14 rows x 2 tile columns = 28 chunks)
         const int n_chunks = n_rows * n_cols;
         uint4 v[NK];
         int dst[NK];
@@ -261,7 +261,7 @@ __device__ __forceinline__ void scan_line(const SeedArgs& a, const int sl, const
           v[k] = make_uint4(0, 0, 0, 0);
           if (c < n_chunks) v[k] = *reinterpret_cast<const uint4*>(img + (svo_pyr::row_off(by_lo + row, pitch) + svo_pyr::col_off(cx0 + 16 * cc)));
         }
-        if (PP == 1 && n_chunks > 8 * NK) {  // (a one-position pass whose box is larger than 24 chunks: cannot happen for 8 windows 0.7 px apart)
+        if (PP == 1 && n_chunks > 8 * NK) {  // (a one-position pass whose box is larger than 32 chunks: a distorted line; one round trip per chunk)
           for (int c = lane + 8 * NK; c < n_chunks; c += 8) {
             const int row = n_cols == 1 ? c : (n_cols == 2 ? (c >> 1) : (int)(svo_pyr::mul24((uint32_t)c, 43u) >> 7)), cc = c - row * n_cols;
             const uint4 w = *reinterpret_cast<const uint4*>(img + (svo_pyr::row_off(by_lo + row, pitch) + svo_pyr::col_off(cx0 + 16 * cc)));

@@ -16,6 +16,9 @@
 #include <algorithm>
 #include <cmath>
 #include <functional>
+#include <map>
+#include <mutex>
+#include <string>
 
 #include <svo/config.h>
 #include <svo/feature.h>
@@ -25,8 +28,53 @@
 #include <svo/point.h>
 
 #include "marshal.h"
+#include "seed_store.h"
 
 namespace svo {
+
+namespace hip_dropin {
+// Row N2, seeds: one resident store per DepthFilter (seed_store.h), alive as long as the filter (released by the
+// drop-in's destructor below).  SVO_HIP_SEED_STORE=off flattens and ships the whole list per call, as rounds 1-4 did.
+struct SeedStoreRegistry {
+  std::mutex mut;
+  std::map<const DepthFilter*, SeedStore*> all;
+  uint64_t calls, records_sent, rebuilds;
+  SeedStoreRegistry() : calls(0), records_sent(0), rebuilds(0) {}
+};
+static SeedStoreRegistry& seedStores() {
+  static SeedStoreRegistry r;
+  return r;
+}
+static SeedStore& seedStoreOf(const DepthFilter* df) {
+  SeedStoreRegistry& r = seedStores();
+  std::lock_guard<std::mutex> g(r.mut);
+  SeedStore*& s = r.all[df];
+  if (s == NULL) s = new SeedStore();
+  return *s;
+}
+static void releaseSeedStore(const DepthFilter* df) {
+  SeedStoreRegistry& r = seedStores();
+  std::lock_guard<std::mutex> g(r.mut);
+  std::map<const DepthFilter*, SeedStore*>::iterator it = r.all.find(df);
+  if (it == r.all.end()) return;
+  r.calls += it->second->stats.calls; r.records_sent += it->second->stats.records_sent; r.rebuilds += it->second->stats.rebuilds;
+  delete it->second;
+  r.all.erase(it);
+}
+static bool seedStoreOn() {
+  static const bool on = [] { const char* v = std::getenv("SVO_HIP_SEED_STORE"); return !(v && std::string(v) == "off"); }();
+  return on;
+}
+// calls / records sent / rebuilds, summed over the stores of the process (read-outs of the tests and the benchmark)
+void seedStoreStats(uint64_t out[3]) {
+  SeedStoreRegistry& r = seedStores();
+  std::lock_guard<std::mutex> g(r.mut);
+  out[0] = r.calls; out[1] = r.records_sent; out[2] = r.rebuilds;
+  for (std::map<const DepthFilter*, SeedStore*>::const_iterator it = r.all.begin(); it != r.all.end(); ++it) {
+    out[0] += it->second->stats.calls; out[1] += it->second->stats.records_sent; out[2] += it->second->stats.rebuilds;
+  }
+}
+}  // namespace hip_dropin
 
 // ---- the update, on the device ---------------------------------------------------------------
 void DepthFilter::updateSeeds(FramePtr frame) {
@@ -52,45 +100,60 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   svo_hip::Arena& a = lane.arena;
   a.reset();
   a.reserve(((size_t)1 << 16) + S * 256 + 4096 * 32);
-  FrameTable frames(dev, L);
-  const int i_cur = frames.indexOf(frame.get());
-
-  int32_t *d_cur, *d_batch; float *d_a, *d_b, *d_mu, *d_zr, *d_s2;
-  int32_t* cur = a.alloc<int32_t>(S, &d_cur);
-  int32_t* batch = a.alloc<int32_t>(S, &d_batch);
-  float* szr = a.alloc<float>(S, &d_zr);
-  FeatureColumns ftr;
-  ftr.alloc(a, S);
-  // the seed state is updated in place by the kernel: it lives in the output block, is filled
-  // below and travels both ways (uploadAll / download)
-  std::vector<float> st(4 * S);
-  float *sa = &st[0], *sb = &st[S], *smu = &st[2 * S], *ss2 = &st[3 * S];
+  const bool resident = seedStoreOn();
   std::vector<int> ids(S);  // Seed::id, ascending along the list: how a later replay finds its seeds again
-  size_t s = 0;
-  for (std::list<Seed>::iterator it = seeds_.begin(); it != seeds_.end(); ++it, ++s) {
-    ids[s] = it->id;
-    cur[s] = i_cur;
-    batch[s] = it->batch_id;
-    sa[s] = it->a; sb[s] = it->b; smu[s] = it->mu; szr[s] = it->z_range; ss2[s] = it->sigma2;
-    ftr.set(s, frames.indexOf(it->ftr->frame), it->ftr);
-  }
+  std::vector<float> st;
+  float *sa = NULL, *sb = NULL, *smu = NULL, *ss2 = NULL;
+  int32_t *d_cur = NULL, *d_status; double *d_xyz, *d_px; float* d_state = NULL;
   svo_hip_frames ft;
-  frames.emit(a, &ft);
-  a.endInputs();
-  {
-    float* h;
-    h = a.alloc<float>(S, &d_a);  std::copy(sa, sa + S, h);  sa = h;
-    h = a.alloc<float>(S, &d_b);  std::copy(sb, sb + S, h);  sb = h;
-    h = a.alloc<float>(S, &d_mu); std::copy(smu, smu + S, h); smu = h;
-    h = a.alloc<float>(S, &d_s2); std::copy(ss2, ss2 + S, h); ss2 = h;
+  svo_hip_seeds seeds;
+  FeatureColumns ftr;
+  SeedStore::Call rc;
+  if (resident) {
+    // row N2: state and Feature of every seed stay in HBM; this call sends the slots in list order, the records of the
+    // seeds it meets for the first time and the frame table (seed_store.h)
+    rc = seedStoreOf(this).sync(seeds_, frame.get(), dev, L, a);
+    size_t s = 0;
+    for (std::list<Seed>::iterator it = seeds_.begin(); it != seeds_.end(); ++it, ++s) ids[s] = it->id;
+    ft = rc.frames;
+    a.endInputs();
+    float* h_state = a.alloc<float>(4 * S, &d_state);  // a, b, mu, sigma2 after the update, dense in list order
+    sa = h_state; sb = h_state + S; smu = h_state + 2 * S; ss2 = h_state + 3 * S;
+  } else {
+    FrameTable frames(dev, L);
+    const int i_cur = frames.indexOf(frame.get());
+    int32_t* d_batch; float *d_a, *d_b, *d_mu, *d_zr, *d_s2;
+    int32_t* cur = a.alloc<int32_t>(S, &d_cur);
+    int32_t* batch = a.alloc<int32_t>(S, &d_batch);
+    float* szr = a.alloc<float>(S, &d_zr);
+    ftr.alloc(a, S);
+    // the seed state is updated in place by the kernel: it lives in the output block, is filled
+    // below and travels both ways (uploadAll / download)
+    st.resize(4 * S);
+    sa = &st[0]; sb = &st[S]; smu = &st[2 * S]; ss2 = &st[3 * S];
+    size_t s = 0;
+    for (std::list<Seed>::iterator it = seeds_.begin(); it != seeds_.end(); ++it, ++s) {
+      ids[s] = it->id;
+      cur[s] = i_cur;
+      batch[s] = it->batch_id;
+      sa[s] = it->a; sb[s] = it->b; smu[s] = it->mu; szr[s] = it->z_range; ss2[s] = it->sigma2;
+      ftr.set(s, frames.indexOf(it->ftr->frame), it->ftr);
+    }
+    frames.emit(a, &ft);
+    a.endInputs();
+    {
+      float* h;
+      h = a.alloc<float>(S, &d_a);  std::copy(sa, sa + S, h);  sa = h;
+      h = a.alloc<float>(S, &d_b);  std::copy(sb, sb + S, h);  sb = h;
+      h = a.alloc<float>(S, &d_mu); std::copy(smu, smu + S, h); smu = h;
+      h = a.alloc<float>(S, &d_s2); std::copy(ss2, ss2 + S, h); ss2 = h;
+    }
+    seeds.d_a = d_a; seeds.d_b = d_b; seeds.d_mu = d_mu; seeds.d_z_range = d_zr; seeds.d_sigma2 = d_s2; seeds.d_batch_id = d_batch;
   }
-  int32_t* d_status; double *d_xyz, *d_px;
   int32_t* status = a.alloc<int32_t>(S, &d_status);
   double* xyz = a.alloc<double>(3 * S, &d_xyz);
   double* px_cur = a.alloc<double>(2 * S, &d_px);
 
-  svo_hip_seeds seeds;
-  seeds.d_a = d_a; seeds.d_b = d_b; seeds.d_mu = d_mu; seeds.d_z_range = d_zr; seeds.d_sigma2 = d_s2; seeds.d_batch_id = d_batch;
   svo_hip_depth_filter_options opt;
   opt.max_n_kfs = options_.max_n_kfs;
   opt.batch_counter = Seed::batch_counter;
@@ -106,10 +169,19 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   void* ws = dev.workspace(lane, (int)S);
 
   stage_timer.device(a.used());
-  a.uploadAll(lane.stream);
-  svo_hip::check(svo_hip_update_seeds(&dev.layout(), dev.store(), &cam, &ft, (int)S, d_cur, &ftr.dev, &seeds, &opt, d_status, d_xyz,
-                                      d_px, ws, lane.workspace_bytes, lane.stream),
-                 "svo_hip_update_seeds");
+  if (resident) {
+    a.upload(lane.stream);
+    if (rc.patch.n > 0)
+      svo_hip::check(svo_hip_seed_store_patch(&rc.patch, &rc.ftr, &rc.seeds, lane.stream), "svo_hip_seed_store_patch");
+    svo_hip::check(svo_hip_update_seeds_resident(&dev.layout(), dev.store(), &cam, &ft, rc.cur_key, (int)S, rc.d_slot_of, &rc.ftr,
+                                                 &rc.seeds, &opt, d_status, d_xyz, d_px, d_state, ws, lane.workspace_bytes, lane.stream),
+                   "svo_hip_update_seeds_resident");
+  } else {
+    a.uploadAll(lane.stream);
+    svo_hip::check(svo_hip_update_seeds(&dev.layout(), dev.store(), &cam, &ft, (int)S, d_cur, &ftr.dev, &seeds, &opt, d_status, d_xyz,
+                                        d_px, ws, lane.workspace_bytes, lane.stream),
+                   "svo_hip_update_seeds");
+  }
   a.download(lane.stream);
 
   // ---- replay of the list surgery, in list order (:216-219, :238-245, :255-290) ---------------
@@ -169,6 +241,7 @@ void DepthFilter::updateSeeds(FramePtr frame) {
 DepthFilter::~DepthFilter() {
   svo_hip::Device::joinDeferredAll();
   stopThread();
+  hip_dropin::releaseSeedStore(this);
   SVO_INFO_STREAM("DepthFilter destructed.");
 }
 

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round 5, sixth GPU call: scan (one / two positions per lane, 4 / 6 chunks per lane) per-kernel + counters; the resident
+# seed store: parity test and the single-stream frame with the store on / off.
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$R"; O=gpurun_out/r05f; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
+{
+echo "== parity: tracking suite (incl. the resident seed store), drop-in pipeline, replay"
+timeout 900 python -m pytest tests/test_tracking_gpu.py tests/test_dropin_pipeline.py tests/test_replay_gpu.py -q -m gpu 2>&1 | tail -4
+for v in main main; do
+  echo "== per-kernel (rocprofv3 kernel trace, full-track step): $v"
+  bash scripts/profile_full.sh "$O/prof_${v}_$RANDOM" 2>&1 | grep -v rocprim | head -9 | cut -c1-150
+done
+echo "== full track untraced"
+bash scripts/full_variants.sh main main 2>&1 | cut -c1-230
+echo "== counters of epi_scan_kernel (rocprofv3 --pmc, one group per pass), per launch"
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_BUSY_CU_CYCLES" "SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM"; do
+  d=/tmp/pmc_$RANDOM
+  (cd /tmp && timeout 300 rocprofv3 --pmc $grp --kernel-include-regex epi_scan --output-format csv -d $d -o p -- python $R/bench.py --pipeline full --extras none --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2>&1)
+  python - "$d" main <<'PY'
+import csv, glob, sys, collections
+fs = glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True)
+acc = collections.defaultdict(list)
+for f in fs:
+    for r in csv.DictReader(open(f)):
+        if 'epi_scan' in r.get('Kernel_Name', ''): acc[r['Counter_Name']].append(float(r['Counter_Value']))
+print(sys.argv[2], {k: round(sum(v[-6:]) / max(1, len(v[-6:])), 1) for k, v in acc.items()})
+PY
+  rm -rf $d
+done
+echo "== single-stream drop-in frame (600 frames): resident seed store on (default), then off"
+for k in 1 2; do python scripts/dropin_trace.py frames=600 2>/dev/null | grep "tot_time median"; done
+for k in 1 2; do SVO_HIP_SEED_STORE=off python scripts/dropin_trace.py frames=600 2>/dev/null | grep "tot_time median"; done
+} 2>&1 | tee $O/log.txt

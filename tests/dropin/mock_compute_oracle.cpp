@@ -339,6 +339,54 @@ int svo_hip_update_seeds(const svo_hip_pyr_layout* L, const uint8_t* store, cons
   return SVO_HIP_OK;
 }
 
+// row N2, seeds: the resident store on host memory (the mock's "device" memory is the host's)
+int svo_hip_seed_store_patch(const svo_hip_seed_patch* p, const svo_hip_features* sf, const svo_hip_seeds* ss, void*) {
+  if (!p || !sf || !ss || p->n < 0) return SVO_HIP_EINVAL;
+  for (int i = 0; i < p->n; ++i) {
+    const int q = p->d_slot[i];
+    const_cast<int32_t*>(sf->d_frame)[q] = p->src_ftr.d_frame[i];
+    const_cast<int32_t*>(sf->d_level)[q] = p->src_ftr.d_level[i];
+    const_cast<uint8_t*>(sf->d_type)[q] = p->src_ftr.d_type ? p->src_ftr.d_type[i] : (uint8_t)SVO_HIP_FTR_CORNER;
+    for (int k = 0; k < 2; ++k) const_cast<double*>(sf->d_px)[2 * q + k] = p->src_ftr.d_px[2 * i + k];
+    for (int k = 0; k < 3; ++k) const_cast<double*>(sf->d_f)[3 * q + k] = p->src_ftr.d_f[3 * i + k];
+    for (int k = 0; k < 2; ++k) const_cast<double*>(sf->d_grad)[2 * q + k] = p->src_ftr.d_grad ? p->src_ftr.d_grad[2 * i + k] : (k == 0 ? 1.0 : 0.0);
+    ss->d_a[q] = p->src_seeds.d_a[i]; ss->d_b[q] = p->src_seeds.d_b[i]; ss->d_mu[q] = p->src_seeds.d_mu[i];
+    ss->d_z_range[q] = p->src_seeds.d_z_range[i]; ss->d_sigma2[q] = p->src_seeds.d_sigma2[i];
+    const_cast<int32_t*>(ss->d_batch_id)[q] = p->src_seeds.d_batch_id[i];
+  }
+  return SVO_HIP_OK;
+}
+
+int svo_hip_update_seeds_resident(const svo_hip_pyr_layout* L, const uint8_t* store, const svo_hip_camera* cam, const svo_hip_frames* frames,
+                                  int cur_frame, int S, const int32_t* d_slot_of, const svo_hip_features* ftr, const svo_hip_seeds* seeds,
+                                  const svo_hip_depth_filter_options* opt, int32_t* d_status, double* d_xyz_world, double* d_px_cur,
+                                  float* d_state_out, void* ws, size_t ws_bytes, void* stream) {
+  // gather the list's records, run the flattened call, scatter the state back
+  std::vector<int32_t> frame((size_t)S), level((size_t)S), batch((size_t)S), cur((size_t)S, cur_frame);
+  std::vector<uint8_t> type((size_t)S);
+  std::vector<double> px(2 * (size_t)S), f(3 * (size_t)S), grad(2 * (size_t)S);
+  std::vector<float> a((size_t)S), b((size_t)S), mu((size_t)S), zr((size_t)S), s2((size_t)S);
+  for (int s = 0; s < S; ++s) {
+    const int q = d_slot_of[s];
+    frame[s] = ftr->d_frame[q]; level[s] = ftr->d_level[q]; type[s] = ftr->d_type[q]; batch[s] = seeds->d_batch_id[q];
+    for (int k = 0; k < 2; ++k) { px[2 * s + k] = ftr->d_px[2 * q + k]; grad[2 * s + k] = ftr->d_grad[2 * q + k]; }
+    for (int k = 0; k < 3; ++k) f[3 * s + k] = ftr->d_f[3 * q + k];
+    a[s] = seeds->d_a[q]; b[s] = seeds->d_b[q]; mu[s] = seeds->d_mu[q]; zr[s] = seeds->d_z_range[q]; s2[s] = seeds->d_sigma2[q];
+  }
+  svo_hip_features ff;
+  ff.d_frame = frame.data(); ff.d_level = level.data(); ff.d_type = type.data(); ff.d_px = px.data(); ff.d_f = f.data(); ff.d_grad = grad.data();
+  svo_hip_seeds sd;
+  sd.d_a = a.data(); sd.d_b = b.data(); sd.d_mu = mu.data(); sd.d_z_range = zr.data(); sd.d_sigma2 = s2.data(); sd.d_batch_id = batch.data();
+  const int rc = svo_hip_update_seeds(L, store, cam, frames, S, cur.data(), &ff, &sd, opt, d_status, d_xyz_world, d_px_cur, ws, ws_bytes, stream);
+  if (rc) return rc;
+  for (int s = 0; s < S; ++s) {
+    const int q = d_slot_of[s];
+    seeds->d_a[q] = a[s]; seeds->d_b[q] = b[s]; seeds->d_mu[q] = mu[s]; seeds->d_sigma2[q] = s2[s];
+    if (d_state_out) { d_state_out[s] = a[s]; d_state_out[S + s] = b[s]; d_state_out[2 * S + s] = mu[s]; d_state_out[3 * S + s] = s2[s]; }
+  }
+  return SVO_HIP_OK;
+}
+
 int svo_hip_update_seed_batch(int S, const float* d_x, const float* d_tau2, const svo_hip_seeds* seeds, void*) {
   for (int s = 0; s < S; ++s) {
     orc_seed sd;

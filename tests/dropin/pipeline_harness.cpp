@@ -37,6 +37,7 @@
 #include "svo_hip_device.h"
 // rpg_svo_amd/host/dropin/reprojector.cpp; absent from the stand-alone-seams flavour (hipm), which links the reference's reprojector
 namespace svo { namespace hip_dropin { void mapMirrorStats(uint64_t out[6]) __attribute__((weak)); } }
+namespace svo { namespace hip_dropin { void seedStoreStats(uint64_t out[3]) __attribute__((weak)); } }
 #endif
 
 
@@ -254,6 +255,14 @@ void pipe_mirror_stats(uint64_t out[6]) {
   for (int i = 0; i < 6; ++i) out[i] = 0;
 #ifdef SVO_PIPELINE_HIP
   if (svo::hip_dropin::mapMirrorStats) svo::hip_dropin::mapMirrorStats(out);
+#endif
+}
+
+// the resident seed store of the depth filter's drop-in (row N2): calls, seed records sent, rebuilds (hip flavour; zeros otherwise)
+void pipe_seed_store_stats(uint64_t out[3]) {
+  for (int i = 0; i < 3; ++i) out[i] = 0;
+#ifdef SVO_PIPELINE_HIP
+  if (svo::hip_dropin::seedStoreStats) svo::hip_dropin::seedStoreStats(out);
 #endif
 }
 

@@ -116,6 +116,12 @@ class Pipeline:
         self.lib.pipe_mirror_stats(out)
         return tuple(int(x) for x in out)
 
+    def seed_store_stats(self):
+        """(calls, seed records sent, rebuilds) of the depth filter's resident seed store, process-wide."""
+        out = (C.c_uint64 * 3)()
+        self.lib.pipe_seed_store_stats(out)
+        return tuple(int(x) for x in out)
+
     STAGES = ("sparse_align", "reproject", "pose_opt", "depth_filter")
 
     def stage_times(self):
@@ -166,6 +172,7 @@ def run_sequence(flavour, cam, images, T_gt, stats_out=None, range0=None, **cfg)
     try:
         s0 = p.device_stats()
         m0 = p.mirror_stats()
+        q0 = p.seed_store_stats()
         n0, r0 = p.set_first_frame(images[0], 0.0, T_gt[0], range_map(cam, T_gt[0]) if range0 is None else range0)
         r0["n_first_features"] = n0
         out = [r0]
@@ -185,6 +192,7 @@ def run_sequence(flavour, cam, images, T_gt, stats_out=None, range0=None, **cfg)
             m1 = p.mirror_stats()
             stats_out["map_mirror"] = dict(zip(("calls", "rebuilds", "fallbacks", "point_records_sent", "obs_records_sent",
                                                 "second_batches"), (b - a for a, b in zip(m0, m1))))
+            stats_out["seed_store"] = dict(zip(("calls", "seed_records_sent", "rebuilds"), (b - a for a, b in zip(q0, p.seed_store_stats()))))
             dt = p.stage_times() - t0
             stages = {}
             for k, name in enumerate(Pipeline.STAGES):
