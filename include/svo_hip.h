@@ -382,7 +382,7 @@ int svo_hip_select_matches(const svo_hip_camera* cam, int M, const int32_t* d_ce
  * findMatchDirect trials in visiting order, and the match kernels follow on the stream without the host in between.
  * All arrays are device memory owned by the caller. */
 typedef struct svo_hip_map {
-  int32_t n_points;      /* entries [0, n_points), <= 16384: the points of the map's keyframes and the depth filter's candidates */
+  int32_t n_points;      /* entries [0, n_points), <= 8192: the points of the map's keyframes and the depth filter's candidates */
   int32_t n_obs;         /* observation records [0, n_obs) */
   double* d_pos;         /* [P][3] Point::pos_ */
   int32_t* d_type;       /* [P] Point::type_ (point.h:38-43): 0 deleted = the entry is dead, 1 candidate, 2 unknown, 3 good */

@@ -162,198 +162,6 @@ __device__ __forceinline__ void scan_world2cam(const Cam& c, const double uv[2],
   }
 }
 
-// What a group carries along a line.
-struct ScanLine {
-  double uv0, uv1;            // this lane's (first) position of the pass
-  int carry0, carry1;         // pixel of the last step of the pass before (last_x, last_y before the first step: 0, 0)
-  int best, best_i;
-  double best_uv0, best_uv1;
-};
-
-// The passes of one seed's scan with PP positions per lane and pass (PP * SCAN_G positions per pass): PP = 2 for a
-// line of more than SCAN_G positions (lane l: steps 2l, 2l+1 of the pass), PP = 1 for a line that fits one pass of one
-// position per lane (half of the scanning seeds search 2-8 positions: at two positions per lane their only pass would
-// issue the second position's work for nobody).
-template <bool PINHOLE, int PP>
-__device__ __forceinline__ void scan_line(const SeedArgs& a, const int sl, const uint8_t* __restrict__ img, const int pitch, const int lane,
-                                          uint32_t* box, const uint32_t* tpl, const int sumA, const int sumAA, const double step0,
-                                          const double step1, const double inv_lvl, const int n_total, ScanLine& L) {
-  constexpr int NPOS = PP * SCAN_G;
-  for (int j = 0; j < PP * lane; ++j) {
-    L.uv0 += step0; L.uv1 += step1;
-  }
-  for (int base = 0; base < n_total; base += NPOS) {
-    const int ia = base + PP * lane, ib = ia + 1;
-    const double ub0 = L.uv0 + step0, ub1 = L.uv1 + step1;  // the lane's second step (PP == 2)
-    int xa = 0, ya = 0, xb = 0, yb = 0;
-    if (ia < n_total) {
-      double pxs[2];
-      const double uvs[2] = {L.uv0, L.uv1};
-      scan_world2cam<PINHOLE>(a.cam, uvs, pxs);  // cur_frame.cam_->world2cam(uv), matcher.cpp:269
-      xa = cast_int(pxs[0] * inv_lvl + 0.5);
-      ya = cast_int(pxs[1] * inv_lvl + 0.5);
-    }
-    if (PP == 2 && ib < n_total) {
-      double pxs[2];
-      const double uvs[2] = {ub0, ub1};
-      scan_world2cam<PINHOLE>(a.cam, uvs, pxs);
-      xb = cast_int(pxs[0] * inv_lvl + 0.5);
-      yb = cast_int(pxs[1] * inv_lvl + 0.5);
-    }
-    const int xl = PP == 2 ? xb : xa, yl = PP == 2 ? yb : ya;  // the lane's LAST pixel of the pass
-    bool want_a, want_b = false;  // the position is new (not the pixel of the step before) and its patch lies inside the frame
-    {
-      // (every lane takes part in the cross-lane moves; a lane whose step does not exist is never anybody's i-1;
-      // row_shr:1 stays inside a row of 16 lanes, and the first lane of a group takes the carry instead)
-      const int left0 = dpp_i32<0x111 /* row_shr:1 */>(xl), left1 = dpp_i32<0x111>(yl);
-      const int prv0 = lane == 0 ? L.carry0 : left0, prv1 = lane == 0 ? L.carry1 : left1;
-      want_a = ia < n_total && !(xa == prv0 && ya == prv1) && is_in_frame_level(a.cam, xa, ya, 8, sl);
-      if (PP == 2) want_b = ib < n_total && !(xb == xa && yb == ya) && is_in_frame_level(a.cam, xb, yb, 8, sl);
-      L.carry0 = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(xl);  // lane 0 <- lane 7 (the only lane that looks at it)
-      L.carry1 = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(yl);
-    }
-    // bounding boxes of the windows [px-4, px+3]^2: of this lane's, of its half group (a quad), of the group
-    constexpr int BIG = 0x3fffffff;
-    int x_lo = want_a ? xa - 4 : BIG, x_hi = want_a ? xa + 3 : -1, y_lo = want_a ? ya - 4 : BIG, y_hi = want_a ? ya + 3 : -1;
-    if (PP == 2) {
-      x_lo = min(x_lo, want_b ? xb - 4 : BIG); x_hi = max(x_hi, want_b ? xb + 3 : -1);
-      y_lo = min(y_lo, want_b ? yb - 4 : BIG); y_hi = max(y_hi, want_b ? yb + 3 : -1);
-    }
-    x_lo = quad_min(x_lo); x_hi = quad_max(x_hi); y_lo = quad_min(y_lo); y_hi = quad_max(y_hi);
-    // (ox, oy: the bounds of the OTHER half group, from the mirror lane)
-    const int ox_lo = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(x_lo), ox_hi = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(x_hi);
-    const int oy_lo = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(y_lo), oy_hi = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(y_hi);
-    const int gx_lo = min(x_lo, ox_lo), gx_hi = max(x_hi, ox_hi), gy_lo = min(y_lo, oy_lo), gy_hi = max(y_hi, oy_hi);
-    // one box for the whole group if it fits (uniform over the group); else a box per half group, one after the other
-    const bool whole = gy_hi - gy_lo < SCAN_BOX_ROWS && gx_hi - (gx_lo & ~15) < 48 &&
-                       (gy_hi - gy_lo + 1) * (((gx_hi - (gx_lo & ~15)) >> 4) + 1) <= 48;
-    if (gx_hi >= 0) {  // (else: nobody wants anything in this pass -- uniform over the group)
-      ScanSums sa = {0, 0, 0}, sb = {0, 0, 0};
-      bool scored = false;
-      const int n_rounds = whole ? 1 : 2;
-      for (int h = 0; h < n_rounds; ++h) {
-        // bounds of this round's box: the group's, or (all lanes compute them alike) those of the half group h
-        int bx_lo = gx_lo, bx_hi = gx_hi, by_lo = gy_lo, by_hi = gy_hi;
-        if (!whole) {
-          const bool own = (lane >> 2) == h;
-          bx_lo = own ? x_lo : ox_lo; bx_hi = own ? x_hi : ox_hi; by_lo = own ? y_lo : oy_lo; by_hi = own ? y_hi : oy_hi;
-        }
-        const bool mine = whole || (lane >> 2) == h;
-        const int cx0 = bx_lo & ~15;                 // first tile column
-        const int n_rows = by_hi - by_lo + 1;
-        const int n_cols = ((bx_hi - cx0) >> 4) + 1;  // tile columns
-        const bool boxed = bx_hi >= 0 && n_rows <= SCAN_BOX_ROWS && n_cols <= 3 && n_rows * n_cols <= 48;  // (uniform over the group)
-        if (bx_hi < 0) continue;  // nothing wanted in this half
-        if (!boxed) continue;     // (left to the per-lane path below)
-        // the box: 16-byte tile rows, chunk c = row * n_cols + column, lane l takes the chunks l, l + 8, ... (at most 48:
-        // a box of many rows is narrow; a pass of one position per lane needs at most 28) -- all requested, then
-        // all parked
-        constexpr int NK = PP == 2 ? 6 : 4;  // (8 windows 0.7 px apart span <= 14 rows x 2 tile columns = 28 chunks)
-        const int n_chunks = n_rows * n_cols;
-        uint4 v[NK];
-        int dst[NK];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-          const int c = lane + 8 * k;
-          // c / n_cols for c < 48 and n_cols in 1..3 without an integer multiply (quarter rate): c, c >> 1, (c * 43) >> 7
-          const int row = n_cols == 1 ? c : (n_cols == 2 ? (c >> 1) : (int)(svo_pyr::mul24((uint32_t)c, 43u) >> 7)), cc = c - (int)svo_pyr::mul24((uint32_t)row, (uint32_t)n_cols);
-          dst[k] = (int)svo_pyr::mul24((uint32_t)row, (uint32_t)SCAN_BOX_ROW_DWORDS) + cc * 4;
-          v[k] = make_uint4(0, 0, 0, 0);
-          if (c < n_chunks) v[k] = *reinterpret_cast<const uint4*>(img + (svo_pyr::row_off(by_lo + row, pitch) + svo_pyr::col_off(cx0 + 16 * cc)));
-        }
-        if (PP == 1 && n_chunks > 8 * NK) {  // (a one-position pass whose box is larger than 32 chunks: a distorted line; one round trip per chunk)
-          for (int c = lane + 8 * NK; c < n_chunks; c += 8) {
-            const int row = n_cols == 1 ? c : (n_cols == 2 ? (c >> 1) : (int)(svo_pyr::mul24((uint32_t)c, 43u) >> 7)), cc = c - row * n_cols;
-            const uint4 w = *reinterpret_cast<const uint4*>(img + (svo_pyr::row_off(by_lo + row, pitch) + svo_pyr::col_off(cx0 + 16 * cc)));
-            SVO_LANES_LDS_HANDOVER();
-            *reinterpret_cast<uint4*>(box + row * SCAN_BOX_ROW_DWORDS + cc * 4) = w;
-          }
-        }
-        // (the reads of the round before are done: DS operations of one wave execute in order)
-        SVO_LANES_LDS_HANDOVER();
-#pragma unroll
-        for (int k = 0; k < NK; ++k)
-          if (lane + 8 * k < n_chunks) *reinterpret_cast<uint4*>(box + dst[k]) = v[k];
-        // hand-over inside the wave
-        SVO_LANES_LDS_HANDOVER();
-        if (mine && (want_a || want_b)) {
-          scored = true;
-          // (a position that is not wanted reads the window of the one that is: valid addresses, sums not used)
-          const int pxa = want_a ? xa : xb, pya = want_a ? ya : yb;
-          const int ba = pxa - 4 - cx0;  // first byte of the window inside the 48-byte box row
-          const uint32_t sela = (uint32_t)(ba & 3);
-          const uint32_t* ra = box + (pya - 4 - by_lo) * SCAN_BOX_ROW_DWORDS + (ba >> 2);
-          const uint2* t2 = reinterpret_cast<const uint2*>(tpl);
-          if (PP == 2) {
-            const int pxb = want_b ? xb : xa, pyb = want_b ? yb : ya;
-            const int bb = pxb - 4 - cx0;
-            const uint32_t selb = (uint32_t)(bb & 3);
-            const uint32_t* rb = box + (pyb - 4 - by_lo) * SCAN_BOX_ROW_DWORDS + (bb >> 2);
-#pragma unroll
-            for (int y = 0; y < 8; ++y) {
-              const uint2 t = t2[y];
-              scan_row(ra + SCAN_BOX_ROW_DWORDS * y, sela, t.x, t.y, sa);
-              scan_row(rb + SCAN_BOX_ROW_DWORDS * y, selb, t.x, t.y, sb);
-            }
-          } else {
-#pragma unroll
-            for (int y = 0; y < 8; ++y) {
-              const uint2 t = t2[y];
-              scan_row(ra + SCAN_BOX_ROW_DWORDS * y, sela, t.x, t.y, sa);
-            }
-          }
-        }
-      }
-      if (!scored && (want_a || want_b)) {
-        // 8 rows x 8 bytes [px-4, px+3]: 12-byte runs, inside one tile row of the store where the 8 bytes are
-#pragma unroll
-        for (int q = 0; q < PP; ++q) {
-          const bool wq = q == 0 ? want_a : want_b;
-          if (!wq) continue;
-          const int px = q == 0 ? xa : xb, py = q == 0 ? ya : yb;
-          ScanSums& sq = q == 0 ? sa : sb;
-          const int wxa = svo_pyr::run_start(px - 4, 8);
-          const uint32_t wbo = (uint32_t)(px - 4 - wxa);  // 0..4
-          uint32_t win[8][3];
-          svo_pyr::load_window12<8>(img, pitch, wxa, py - 4, win);
-#pragma unroll
-          for (int y = 0; y < 8; ++y) {
-            uint32_t lo, hi;
-            cut_row8(win[y], wbo, lo, hi);
-            const uint32_t t0 = tpl[2 * y], t1 = tpl[2 * y + 1];
-            sq.B = __builtin_amdgcn_udot4(lo, 0x01010101u, sq.B, false);
-            sq.B = __builtin_amdgcn_udot4(hi, 0x01010101u, sq.B, false);
-            sq.BB = __builtin_amdgcn_udot4(lo, lo, sq.BB, false);
-            sq.BB = __builtin_amdgcn_udot4(hi, hi, sq.BB, false);
-            sq.AB = __builtin_amdgcn_udot4(lo, t0, sq.AB, false);
-            sq.AB = __builtin_amdgcn_udot4(hi, t1, sq.AB, false);
-          }
-        }
-      }
-      // the lane's steps come in increasing order: it keeps its first minimum
-      if (want_a) {
-        const int sB = (int)sa.B, sBB = (int)sa.BB, sAB = (int)sa.AB;
-        const int zmssd = sumAA - 2 * sAB + sBB - (sumA * sumA - 2 * sumA * sB + sB * sB) / 64;
-        if (zmssd < L.best) {
-          L.best = zmssd; L.best_i = ia; L.best_uv0 = L.uv0; L.best_uv1 = L.uv1;
-        }
-      }
-      if (PP == 2 && want_b) {
-        const int sB = (int)sb.B, sBB = (int)sb.BB, sAB = (int)sb.AB;
-        const int zmssd = sumAA - 2 * sAB + sBB - (sumA * sumA - 2 * sumA * sB + sB * sB) / 64;
-        if (zmssd < L.best) {
-          L.best = zmssd; L.best_i = ib; L.best_uv0 = ub0; L.best_uv1 = ub1;
-        }
-      }
-    }
-    if (base + NPOS < n_total) {  // on to this lane's next step(s): NPOS more additions
-      for (int j = 0; j < NPOS; ++j) {
-        L.uv0 += step0; L.uv1 += step1;
-      }
-    }
-  }
-}
-
 // ZMSSD scan of one seed, matcher.cpp:248-291, by the SCAN_G lanes of a group (lane = position in the group).
 // box: the group's SCAN_BOX_DWORDS dwords of LDS (16-byte aligned).
 template <bool PINHOLE>
@@ -384,29 +192,188 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
     sumAA = group8_sum((int)saa);
   }
   const double step0 = w.step[2 * s], step1 = w.step[2 * s + 1];
+  double uv0 = w.B[2 * s] - step0, uv1 = w.B[2 * s + 1] - step1;
   const int n_total = w.n_steps[s] + 1;
+  int best = ZMSSD_THRESHOLD;
+  int best_i = 0x7fffffff;
+  double best_uv0 = 0, best_uv1 = 0;
   const double lvl = (double)(1 << sl);
   // Dividing by 2^level is exact, so multiplying by 2^-level gives the same bits without f64 division sequences.
   const double inv_lvl = 1.0 / lvl;
   // The reference walks the line sequentially (matcher.cpp:268: uv += step, in f64) and skips a step whose
-  // integer pixel equals the previous step's.  A lane replays only the CHAIN of additions up to its steps (two
-  // v_add_f64 per step, so the positions carry the reference's rounding) and does the expensive part -- camera model,
-  // rounding, the 8x8 ZMSSD -- for its own steps only, all lanes of the group at once.  "Same pixel as the last step
-  // looked at" is "same pixel as step i-1": last_x/last_y are overwritten by every step that differs from them, so they
-  // always hold step i-1's pixel.  The pixel of step i-1 is the lane's own first pixel (for its second step), the last pixel
-  // of the lane to the left (the same chain of additions, the same arithmetic: the same bits), and for the group's first
-  // lane the last pixel of its last lane in the pass before: DPP moves, no second camera projection and no LDS.
-  ScanLine L;
-  L.uv0 = w.B[2 * s] - step0;
-  L.uv1 = w.B[2 * s + 1] - step1;
-  L.carry0 = L.carry1 = 0;
-  L.best = ZMSSD_THRESHOLD;
-  L.best_i = 0x7fffffff;
-  L.best_uv0 = L.best_uv1 = 0;
-  if (n_total <= SCAN_G) scan_line<PINHOLE, 1>(a, sl, img, pitch, lane, box, tpl, sumA, sumAA, step0, step1, inv_lvl, n_total, L);
-  else scan_line<PINHOLE, 2>(a, sl, img, pitch, lane, box, tpl, sumA, sumAA, step0, step1, inv_lvl, n_total, L);
-  const int best = L.best, best_i = L.best_i;
-  const double best_uv0 = L.best_uv0, best_uv1 = L.best_uv1;
+  // integer pixel equals the previous step's.  Lane l of the seed's group takes the steps 2l, 2l+1, 2l+16, 2l+17, ...: it
+  // replays only the CHAIN of additions up to its steps (two v_add_f64 per step, so the positions carry the reference's
+  // rounding) and does the expensive part -- camera model, rounding, the 8x8 ZMSSD -- for its own steps only, all lanes
+  // of the group at once.  "Same pixel as the last step looked at" is "same pixel as step i-1": last_x/last_y are
+  // overwritten by every step that differs from them, so they always hold step i-1's pixel.  The pixel of step i-1 is the
+  // lane's own first pixel (for its second step), the second pixel of the lane to the left (the same chain of additions,
+  // the same arithmetic: the same bits), and for the group's first lane the second pixel of its last lane in the pass
+  // before: DPP moves, no second camera projection and no LDS.
+  // A line of up to SCAN_G positions (half of the scanning seeds search 2-8) takes ONE position per lane -- lane l = step l,
+  // no second position; the second position's work sits in branches of its own, which a wave whose eight lines are all
+  // short jumps over (the seeds of a wave are neighbours in the order by length).  One code path for both: a second
+  // instantiation next to this one cost nine spilled registers and two scratch round trips per seed (profiles/r05e_*).
+  const bool two = n_total > SCAN_G;  // (uniform over the group)
+  const int PP = two ? 2 : 1;
+  for (int j = 0; j < PP * lane; ++j) {
+    uv0 += step0; uv1 += step1;
+  }
+  int carry0 = 0, carry1 = 0;  // pixel of the last step of the pass before (last_x, last_y before the first step: 0, 0)
+  for (int base = 0; base < n_total; base += PP * SCAN_G) {
+    const int ia = base + PP * lane, ib = ia + 1;
+    const double ub0 = uv0 + step0, ub1 = uv1 + step1;  // the lane's second step
+    int xa = 0, ya = 0, xb = 0, yb = 0;
+    if (ia < n_total) {
+      double pxs[2];
+      const double uvs[2] = {uv0, uv1};
+      scan_world2cam<PINHOLE>(a.cam, uvs, pxs);  // cur_frame.cam_->world2cam(uv), matcher.cpp:269
+      xa = cast_int(pxs[0] * inv_lvl + 0.5);
+      ya = cast_int(pxs[1] * inv_lvl + 0.5);
+    }
+    if (two && ib < n_total) {
+      double pxs[2];
+      const double uvs[2] = {ub0, ub1};
+      scan_world2cam<PINHOLE>(a.cam, uvs, pxs);
+      xb = cast_int(pxs[0] * inv_lvl + 0.5);
+      yb = cast_int(pxs[1] * inv_lvl + 0.5);
+    }
+    bool want_a, want_b;  // the position is new (not the pixel of the step before) and its patch lies inside the frame
+    {
+      // (every lane takes part in the cross-lane moves; a lane whose step does not exist is never anybody's i-1;
+      // row_shr:1 stays inside a row of 16 lanes, and the first lane of a group takes the carry instead)
+      const int xl = two ? xb : xa, yl = two ? yb : ya;  // the lane's LAST pixel of the pass
+      const int left0 = dpp_i32<0x111 /* row_shr:1 */>(xl), left1 = dpp_i32<0x111>(yl);
+      const int prv0 = lane == 0 ? carry0 : left0, prv1 = lane == 0 ? carry1 : left1;
+      want_a = ia < n_total && !(xa == prv0 && ya == prv1) && is_in_frame_level(a.cam, xa, ya, 8, sl);
+      want_b = two && ib < n_total && !(xb == xa && yb == ya) && is_in_frame_level(a.cam, xb, yb, 8, sl);
+      carry0 = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(xl);  // lane 0 <- lane 7 (the only lane that looks at it)
+      carry1 = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(yl);
+    }
+    // bounding boxes of the windows [px-4, px+3]^2: of this lane's two, of its half group (a quad), of the group
+    constexpr int BIG = 0x3fffffff;
+    int x_lo = min(want_a ? xa - 4 : BIG, want_b ? xb - 4 : BIG), x_hi = max(want_a ? xa + 3 : -1, want_b ? xb + 3 : -1);
+    int y_lo = min(want_a ? ya - 4 : BIG, want_b ? yb - 4 : BIG), y_hi = max(want_a ? ya + 3 : -1, want_b ? yb + 3 : -1);
+    x_lo = quad_min(x_lo); x_hi = quad_max(x_hi); y_lo = quad_min(y_lo); y_hi = quad_max(y_hi);
+    // (ox, oy: the bounds of the OTHER half group, from the mirror lane)
+    const int ox_lo = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(x_lo), ox_hi = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(x_hi);
+    const int oy_lo = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(y_lo), oy_hi = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(y_hi);
+    const int gx_lo = min(x_lo, ox_lo), gx_hi = max(x_hi, ox_hi), gy_lo = min(y_lo, oy_lo), gy_hi = max(y_hi, oy_hi);
+    // one box for the whole group if it fits (uniform over the group); else a box per half group, one after the other
+    const bool whole = gy_hi - gy_lo < SCAN_BOX_ROWS && gx_hi - (gx_lo & ~15) < 48 &&
+                       (gy_hi - gy_lo + 1) * (((gx_hi - (gx_lo & ~15)) >> 4) + 1) <= 48;
+    if (gx_hi < 0) {
+      // nobody wants anything in this pass (uniform over the group)
+    } else {
+      ScanSums sa = {0, 0, 0}, sb = {0, 0, 0};
+      bool scored = false;
+      const int n_rounds = whole ? 1 : 2;
+      for (int h = 0; h < n_rounds; ++h) {
+        // bounds of this round's box: the group's, or (all lanes compute them alike) those of the half group h
+        int bx_lo = gx_lo, bx_hi = gx_hi, by_lo = gy_lo, by_hi = gy_hi;
+        if (!whole) {
+          const bool own = (lane >> 2) == h;
+          bx_lo = own ? x_lo : ox_lo; bx_hi = own ? x_hi : ox_hi; by_lo = own ? y_lo : oy_lo; by_hi = own ? y_hi : oy_hi;
+        }
+        const bool mine = whole || (lane >> 2) == h;
+        const int cx0 = bx_lo & ~15;                 // first tile column
+        const int n_rows = by_hi - by_lo + 1;
+        const int n_cols = ((bx_hi - cx0) >> 4) + 1;  // tile columns
+        const bool boxed = bx_hi >= 0 && n_rows <= SCAN_BOX_ROWS && n_cols <= 3 && n_rows * n_cols <= 48;  // (uniform over the group)
+        if (bx_hi < 0) continue;  // nothing wanted in this half
+        if (!boxed) continue;     // (left to the per-lane path below)
+        // the box: 16-byte tile rows, chunk c = row * n_cols + column, lane l takes the chunks l, l + 8, ... (at most 48:
+        // a box of many rows is narrow) -- all requested, then all parked
+        const int n_chunks = n_rows * n_cols;
+        const uint32_t inv = n_cols == 1 ? 65536u : (n_cols == 2 ? 32768u : 21846u);  // c / n_cols for c < 128
+        uint4 v[6];
+        int dst[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const int c = lane + 8 * k;
+          const int row = (int)(((uint32_t)c * inv) >> 16), cc = c - row * n_cols;
+          dst[k] = row * SCAN_BOX_ROW_DWORDS + cc * 4;
+          v[k] = make_uint4(0, 0, 0, 0);
+          if (c < n_chunks) v[k] = *reinterpret_cast<const uint4*>(img + (svo_pyr::row_off(by_lo + row, pitch) + svo_pyr::col_off(cx0 + 16 * cc)));
+        }
+        // (the reads of the round before are done: DS operations of one wave execute in order)
+        SVO_LANES_LDS_HANDOVER();
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          if (lane + 8 * k < n_chunks) *reinterpret_cast<uint4*>(box + dst[k]) = v[k];
+        // hand-over inside the wave
+        SVO_LANES_LDS_HANDOVER();
+        // (each position in a branch of its own: a wave in which no lane has a second position jumps over that block)
+        const uint2* t2 = reinterpret_cast<const uint2*>(tpl);
+        if (mine && (want_a || want_b)) scored = true;
+        if (mine && want_a) {
+          const int ba = xa - 4 - cx0;  // first byte of the window inside the 48-byte box row
+          const uint32_t sela = (uint32_t)(ba & 3);
+          const uint32_t* ra = box + (ya - 4 - by_lo) * SCAN_BOX_ROW_DWORDS + (ba >> 2);
+#pragma unroll
+          for (int y = 0; y < 8; ++y) {
+            const uint2 t = t2[y];
+            scan_row(ra + SCAN_BOX_ROW_DWORDS * y, sela, t.x, t.y, sa);
+          }
+        }
+        if (mine && want_b) {
+          const int bb = xb - 4 - cx0;
+          const uint32_t selb = (uint32_t)(bb & 3);
+          const uint32_t* rb = box + (yb - 4 - by_lo) * SCAN_BOX_ROW_DWORDS + (bb >> 2);
+#pragma unroll
+          for (int y = 0; y < 8; ++y) {
+            const uint2 t = t2[y];
+            scan_row(rb + SCAN_BOX_ROW_DWORDS * y, selb, t.x, t.y, sb);
+          }
+        }
+      }
+      if (!scored && (want_a || want_b)) {
+        // 8 rows x 8 bytes [px-4, px+3]: 12-byte runs, inside one tile row of the store where the 8 bytes are
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const bool wq = q == 0 ? want_a : want_b;
+          if (!wq) continue;
+          const int px = q == 0 ? xa : xb, py = q == 0 ? ya : yb;
+          ScanSums& sq = q == 0 ? sa : sb;
+          const int wxa = svo_pyr::run_start(px - 4, 8);
+          const uint32_t wbo = (uint32_t)(px - 4 - wxa);  // 0..4
+          uint32_t win[8][3];
+          svo_pyr::load_window12<8>(img, pitch, wxa, py - 4, win);
+#pragma unroll
+          for (int y = 0; y < 8; ++y) {
+            uint32_t lo, hi;
+            cut_row8(win[y], wbo, lo, hi);
+            const uint32_t t0 = tpl[2 * y], t1 = tpl[2 * y + 1];
+            sq.B = __builtin_amdgcn_udot4(lo, 0x01010101u, sq.B, false);
+            sq.B = __builtin_amdgcn_udot4(hi, 0x01010101u, sq.B, false);
+            sq.BB = __builtin_amdgcn_udot4(lo, lo, sq.BB, false);
+            sq.BB = __builtin_amdgcn_udot4(hi, hi, sq.BB, false);
+            sq.AB = __builtin_amdgcn_udot4(lo, t0, sq.AB, false);
+            sq.AB = __builtin_amdgcn_udot4(hi, t1, sq.AB, false);
+          }
+        }
+      }
+      // the lane's steps come in increasing order: it keeps its first minimum
+      if (want_a) {
+        const int sB = (int)sa.B, sBB = (int)sa.BB, sAB = (int)sa.AB;
+        const int zmssd = sumAA - 2 * sAB + sBB - (sumA * sumA - 2 * sumA * sB + sB * sB) / 64;
+        if (zmssd < best) {
+          best = zmssd; best_i = ia; best_uv0 = uv0; best_uv1 = uv1;
+        }
+      }
+      if (want_b) {
+        const int sB = (int)sb.B, sBB = (int)sb.BB, sAB = (int)sb.AB;
+        const int zmssd = sumAA - 2 * sAB + sBB - (sumA * sumA - 2 * sumA * sB + sB * sB) / 64;
+        if (zmssd < best) {
+          best = zmssd; best_i = ib; best_uv0 = ub0; best_uv1 = ub1;
+        }
+      }
+    }
+    if (base + PP * SCAN_G < n_total) {  // on to this lane's next step(s): PP * SCAN_G more additions
+      for (int j = 0; j < PP * SCAN_G; ++j) {
+        uv0 += step0; uv1 += step1;
+      }
+    }
+  }
   // first strictly smaller score along the line == lexicographic minimum of (score, step)
   unsigned long long key = ((unsigned long long)(unsigned)best << 32) | (unsigned)best_i;
 #pragma unroll

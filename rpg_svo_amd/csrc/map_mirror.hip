@@ -433,7 +433,9 @@ extern "C" int svo_hip_reproject_map(const svo_hip_camera* cam, const svo_hip_fr
   if (!cam || !cam_model_ok(cam) || !frames || !map || !grid || !out || !d_kf_rank) return SVO_HIP_EINVAL;
   if (frames->n_frames < 1 || frames->n_frames > RM_MAX_FRAMES || cur_frame < 0 || cur_frame >= frames->n_frames || !frames->d_T_f_w)
     return SVO_HIP_EINVAL;
-  if (map->n_points < 0 || map->n_points > 16 * RM_BLOCK || map->n_obs < 0) return SVO_HIP_ERANGE;  // (a thread carries <= 16 entries)
+  // a thread carries <= 8 entries in registers (a 1024-thread workgroup has 128 VGPRs per thread: the 16-entry form spilled
+  // 188 dwords).  8192 entries are three times what the reference's map holds (10 keyframes + candidates: ~2600)
+  if (map->n_points < 0 || map->n_points > 8 * RM_BLOCK || map->n_obs < 0) return SVO_HIP_ERANGE;
   if (grid->cell_size < 1 || grid->n_cols < 1 || grid->n_cells < 1 || grid->n_cells > RM_MAX_CELLS || !grid->d_cell_rank)
     return grid->n_cells > RM_MAX_CELLS ? SVO_HIP_ERANGE : SVO_HIP_EINVAL;
   if (first_cell < 0 || first_cell > grid->n_cells || max_visits < 0 || max_trials < 0) return SVO_HIP_EINVAL;
@@ -473,7 +475,6 @@ extern "C" int svo_hip_reproject_map(const svo_hip_camera* cam, const svo_hip_fr
   a.out = *out;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (map->n_points <= 4 * RM_BLOCK) hipLaunchKernelGGL(reproject_map_kernel<4>, dim3(1), dim3(RM_BLOCK), 0, st, a);
-  else if (map->n_points <= 8 * RM_BLOCK) hipLaunchKernelGGL(reproject_map_kernel<8>, dim3(1), dim3(RM_BLOCK), 0, st, a);
-  else hipLaunchKernelGGL(reproject_map_kernel<16>, dim3(1), dim3(RM_BLOCK), 0, st, a);
+  else hipLaunchKernelGGL(reproject_map_kernel<8>, dim3(1), dim3(RM_BLOCK), 0, st, a);
   return check_launch();
 }

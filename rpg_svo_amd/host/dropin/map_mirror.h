@@ -326,7 +326,7 @@ class MapMirror {
       for (CandList::iterator c = cl.begin(); c != cl.end(); ++c)
         if (!appendCandidate(c, ftr_order)) return false;
     }
-    if (pts_.size() > 16384 || frames_.size() + 1 > 64) return false;
+    if (pts_.size() > 8192 || frames_.size() + 1 > 64) return false;
     resendAll();
     return true;
   }
@@ -366,13 +366,13 @@ class MapMirror {
     } else if (first_new != cl.begin()) {
       return false;
     }
-    if (pts_.size() + (n - live_cands_) > 16384) return false;
+    if (pts_.size() + (n - live_cands_) > 8192) return false;
     static const std::unordered_map<const Feature*, int> none;  // a candidate's Feature is in no keyframe's list yet
     for (CandList::iterator c = first_new; c != cl.end(); ++c)
       if (!appendCandidate(c, none)) return false;
     // (a candidate's observation may have brought a frame the table did not hold: the limits rebuild() enforces hold
     // on this path too -- false sends the caller through rebuild(), which hands the frame to the list-walking path)
-    if (pts_.size() > 16384 || frames_.size() + 1 > 64) return false;
+    if (pts_.size() > 8192 || frames_.size() + 1 > 64) return false;
     return true;
   }
 

@@ -72,7 +72,7 @@ class Reprojection:
 
 class MapMirror:
     def __init__(self, capacity_points: int, capacity_obs: int, device):
-        assert capacity_points <= 16384
+        assert capacity_points <= 8192
         self.device = torch.device(device)
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.device)
         P, O = capacity_points, capacity_obs

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""The "Measured" table of DESIGN.md section 3 from a bench details file:
+python scripts/design_table.py [bench_details.json] > table.md   (or --write: replaces the block between the
+<!-- measured:begin --> / <!-- measured:end --> markers of DESIGN.md).  Every number is the file's own."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def f(v, fmt="{:.2f}"):
+    return "-" if v is None or (isinstance(v, float) and v != v) else fmt.format(v)
+
+
+def table(d: dict, src: str) -> str:
+    L = []
+    r = d["roofline"]
+    B = d["config"]["frames_per_step_per_gpu"]
+    L.append(f"Source: `{src}` (default `bench.py` run: 50 timed launches of {B} frames after 5 warm-ups).")
+    L.append("")
+    L.append("| kernel (per launch / step of 16 384 frames) | ms | algorithmic bytes per unit | GB/s | frac of 8 TB/s | counter traffic / algorithmic | VALU busy | wave cycles waiting |")
+    L.append("|---|---|---|---|---|---|---|---|")
+    rv = d.get("roofline_valu") or {}
+    L.append(f"| **K1** `sia_kernel<256>` (headline, {d['value'] / 1e6:.2f} M frames/s) | {f(r['ms'], '{:.3f}')} (last 10: {f(r.get('ms_last_10_launches'), '{:.3f}')}) | "
+             f"{r['algorithmic_bytes_per_frame'] / 1e3:.1f} KB / frame | {f(r['achieved'], '{:.0f}')} | **{f(r['frac'], '{:.3f}')}** | {f(r.get('traffic_over_algorithmic'))} | "
+             f"{f(rv.get('frac'))} | {f(rv.get('wave_cycles_waiting_frac'))} |")
+    f64 = d.get("f64_partials") or {}
+    if isinstance(f64.get("roofline"), dict):
+        q = f64["roofline"]
+        L.append(f"| K1, `-DSIA_F64_PARTIALS` build ({f64['frames_per_s'] / 1e6:.2f} M frames/s) | {f(q['ms'], '{:.3f}')} | {q['algorithmic_bytes_per_frame'] / 1e3:.1f} KB / frame | "
+                 f"{f(q['achieved'], '{:.0f}')} | {f(q['frac'], '{:.3f}')} | {f(q.get('traffic_over_algorithmic'))} | - | - |")
+    k0 = d.get("k0_pyramid") or {}
+    if "ms" in k0:
+        L.append(f"| K0 `pyramid_fused_kernel` ({k0['frames']} frames) | {f(k0['ms'], '{:.3f}')} | {k0['algorithmic_bytes_per_frame']} B / frame | {f(k0['achieved'], '{:.0f}')} | "
+                 f"**{f(k0['frac'], '{:.3f}')}** | - | - | - |")
+    ft = d.get("full_track") or {}
+    unit = {"match_prepare": "48 B geometry / trial", "warp": "<= 121 B footprint + 100 B written / trial", "align": "100 + 81 I B / trial",
+            "pose_opt_wave": "52 M + 416 B / frame", "seed_prepare": "89 B in + ~90 B workspace / seed", "epi_scan": "64 + 7.13 B / position (union of the windows)",
+            "seed_finish": "36 B state + workspace / seed"}
+    for name, v in (ft.get("kernels") or {}).items():
+        if not isinstance(v, dict) or (v.get("ms") or 0) < 0.05:
+            continue
+        key = name.split("/")[-1].replace("_kernel", "")
+        valu, lds = v.get("valu") or {}, v.get("lds") or {}
+        extra = ""
+        if lds.get("bank_conflict_frac_of_port_cycles") is not None:
+            extra = f" (LDS port {f(lds.get('port_busy_frac_vs_busy_cu_cycles', lds.get('port_busy_frac')))} busy, {f(lds['bank_conflict_frac_of_port_cycles'])} of it conflicts)"
+        L.append(f"| `{name}` | {f(v['ms'], '{:.3f}')} | {unit.get(key, '-')} | {f(v.get('achieved_GBs'), '{:.0f}')} | {f(v.get('frac'), '{:.3f}')} | "
+                 f"{f(v.get('traffic_over_compulsory'))} | {f(valu.get('busy_frac_at_3_cycles_per_instruction'))} | {f(valu.get('wave_cycles_waiting_frac'))}{extra} |")
+    if "ms_per_step" in ft:
+        st = ft["stages_ms"]
+        L.append("")
+        L.append(f"Full track (configs[2], representative workload): **{ft['ms_per_step']:.2f} ms per step** = {ft['frames_per_s'] / 1e6:.2f} M frames/s; stages: "
+                 + ", ".join(f"{k} {v:.3f}" for k, v in st.items() if v >= 0.02) + " ms.")
+    c3 = d.get("config3_xga5_b64") or {}
+    if "ms_per_step" in c3:
+        L.append(f"configs[3] (1280x960, 5 levels, 1000 patches): B = 64: {c3['ms_per_step']:.3f} ms (latency of one frame, 64 of 256 CUs; frac "
+                 f"{c3['roofline']['frac']:.3f}); B = 1024: {c3['frames_per_s_at_batch_1024'] / 1e6:.2f} M frames/s (frac {c3['roofline_at_batch_1024']['frac']:.3f}); the "
+                 f"reference's own code on the host: {c3['cpu_baseline']['frames_per_s_1core']:.0f} frames/s on one core.")
+    ds = d.get("dropin_sequence") or {}
+    if "median_ms_per_frame_hip_dropin" in ds:
+        L.append(f"Single stream (drop-in, 752x480, 600 frames, map of the reference trace's size): **{ds['median_ms_per_frame_hip_dropin']['tot_time']:.3f} ms** per frame "
+                 f"({ds['median_ms_per_frame_hip_dropin_deferred_mapper']['tot_time']:.3f} with the deferred mapper) against {ds['median_ms_per_frame_cpu_reference']['tot_time']:.3f} ms for the "
+                 f"all-CPU reference on the same host.")
+    cb = d.get("cpu_baseline") or {}
+    if "value" in cb:
+        L.append(f"CPU baseline (the reference's own `sparse_img_align.cpp`, {cb.get('cpu_model', 'host')}): {cb['value']:.0f} frames/s on one core in the bit-comparable build, "
+                 f"{f(cb.get('value_release_flags'), '{:.0f}')} with the reference's release flags; best thread count ({cb.get('best_threads')}): {cb['value_best_threads']:.0f} / "
+                 f"{f(cb.get('value_release_flags_best_threads'), '{:.0f}')} frames/s.")
+    par = d.get("parity") or {}
+    if par:
+        L.append(f"Parity of the headline run against that translation unit over {par['frames_compared']} frames: SE(3) log-norm max {par['se3_lognorm_max']:.2e}, median "
+                 f"{par['se3_lognorm_median']:.1e}; identical per-level iteration counts {par['same_iteration_counts_frac']:.4f}.")
+    return "\n".join(L)
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    src = args[0] if args else "bench_details.json"
+    d = json.load(open(src))
+    t = table(d, os.path.relpath(src, ROOT) if os.path.isabs(src) else src)
+    if "--write" in sys.argv:
+        p = os.path.join(ROOT, "DESIGN.md")
+        s = open(p).read()
+        b, e = "<!-- measured:begin -->", "<!-- measured:end -->"
+        i, j = s.index(b) + len(b), s.index(e)
+        open(p, "w").write(s[:i] + "\n" + t + "\n" + s[j:])
+    else:
+        print(t)
+
+
+if __name__ == "__main__":
+    main()
