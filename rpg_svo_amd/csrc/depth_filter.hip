@@ -204,8 +204,9 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
 // 8 neighbouring entries of that order from an LDS counter: the seeds a wave holds at a time need about
 // the same number of passes, and no wave waits for another.  Seeds that do not scan (short segment, not visible,
 // rejected) never enter the order.  Results do not depend on the order.
-// four waves per SIMD (128 VGPRs, 29 dwords spilled outside the position loop) measured 2 % faster for update_seeds
-// than three (162 VGPRs, no spills): the scan waits on its box fetch once per pass
+// Four waves per SIMD: the scan waits on its box fetch once per pass.  The undistorted instantiation fits (127 VGPRs, no
+// scratch, 35.4 KB of LDS per workgroup); the distorted cameras' one carries the models' f64 code in the loop and spills
+// outside it.  (What registers cost here: nine spilled dwords per seed took 10 % of the kernel, profiles/r05e_*.)
 constexpr int SCAN_MINW = 4;
 template <bool PINHOLE>
 __global__ void __launch_bounds__(SCAN_BLOCK, SCAN_MINW) epi_scan_kernel(const SeedArgs a) {

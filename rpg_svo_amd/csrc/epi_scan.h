@@ -92,7 +92,8 @@ constexpr int SCAN_BLOCK = 256;
 // share the chain replay between eight seeds of a wave and keep the lanes busy (update_seeds on 3.3 M seeds:
 // 3.24 ms at 64 lanes per seed, 2.74 at 32, 2.47 at 16, 2.33 at 8).
 constexpr int SCAN_G = 8;
-// Positions a group looks at per pass: two per lane, CONSECUTIVE ones (lane l: steps 2l and 2l+1 of the pass).
+// Positions a group looks at per pass on a line of more than SCAN_G positions: two per lane, CONSECUTIVE ones (lane l: steps 2l
+// and 2l+1 of the pass); a shorter line takes one per lane in its only pass.
 constexpr int SCAN_PP = 2 * SCAN_G;
 
 // Seeds per workgroup of the scan.  The seeds of a chunk are ordered by scan length inside the workgroup (below).
