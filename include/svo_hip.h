@@ -605,7 +605,7 @@ int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint8_t* d_stor
  * keeps its slot for life.  Feature::frame is stored as a key into the frame table of the call (the caller keeps the
  * keys of its keyframes stable; the current frame is entry `cur_frame` of the table).
  *   svo_hip_seed_store_patch     writes n new records (SoA in `src_*`, record i) to slots d_slot[i]: what
- *                                DepthFilter::initializeSeeds appended since the last call (depth_filter.cpp:121-151)
+ *                                DepthFilter::initializeSeeds appended since the last call (depth_filter.cpp:114-132)
  *   svo_hip_update_seeds_resident  svo_hip_update_seeds for the S seeds at slots d_slot_of[s], s in list order: the
  *                                state is updated in place in the store; d_status / d_xyz_world / d_px_cur are dense
  *                                (index s) as above, and d_state_out [4][S] receives a, b, mu, sigma2 after the update

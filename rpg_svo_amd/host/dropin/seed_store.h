@@ -5,7 +5,7 @@
 // Feature of every seed, 89 bytes each -- into the arena and shipped it both ways on every updateSeeds call.  The
 // state is only ever changed by the update itself and a seed's Feature never changes, so both live in HBM now:
 //   * a seed gets a SLOT of the store when the drop-in first meets it (the reference's own initializeSeeds appended
-//     it, depth_filter.cpp:121-151) and keeps it until it leaves the list; new records travel once, as a patch;
+//     it, depth_filter.cpp:114-132) and keeps it until it leaves the list; new records travel once, as a patch;
 //   * per call the host sends the slots in LIST ORDER (4 bytes per seed) and the frame table; the kernels read and
 //     update the records in place and return status / state / points densely, in list order, for the replay of the
 //     list surgery (depth_filter.cpp:216-219, 238-245, 255-290), which is unchanged.
