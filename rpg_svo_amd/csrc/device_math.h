@@ -155,13 +155,9 @@ __device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
 #if defined(SVO_HOST_MATH_TEST)
   const double* cs = kSinCoef;
   const double* cc = kCosCoef;
-#elif !defined(SINCOS_COEF_GENERIC_POINTER)
+#else  // (constant address space: scalar loads; a generic pointer measured 3 % slower in K4, profiles/r04v_*)
   const_as_double* cs = (const_as_double*)kSinCoef;
   const_as_double* cc = (const_as_double*)kCosCoef;
-  asm volatile("" : "+s"(cs), "+s"(cc));
-#else  // A/B build: the form of rounds 1-4a
-  const double* cs = kSinCoef;
-  const double* cc = kCosCoef;
   asm volatile("" : "+s"(cs), "+s"(cc));
 #endif
   const double z = x * x;

@@ -331,6 +331,7 @@ MIRROR_CODE = (
     "r = pp.run_sequence({flavour!r}, cam, imgs, T, stats_out=st, **{cfg!r})\n"
     "np.save(sys.argv[1], np.stack([x['T_f_w'] for x in r]))\n"
     "print(json.dumps(dict(st['map_mirror'], hits=st['predicted_pose_hits'], kfs=int(sum(x['is_keyframe'] for x in r)),\n"
+    "                      seed_store=st.get('seed_store'), seeds=[x['n_seeds'] for x in r],\n"
     "                      counts=[[x['repr_n_mps'], x['repr_n_new_references'], x['n_kf_points_in_frame'], x['n_candidates']] for x in r])))\n")
 
 
@@ -657,6 +658,36 @@ def test_dropin_arena_modes_agree(pipeline_libs, gpu_device, tmp_path):
     for mode in ("mirrored", "mapped"):
         d = se3.log_norm(out[mode], out["hybrid"])
         assert d.max() <= SE3_LOGNORM_TOL, (mode, d.max())
+
+
+def _seed_store_on_and_off(flavour, n, tmp_path):
+    """the same sequence with the resident seed store (default) and with the list flattened per call, keyframes being
+    inserted AND removed (max_n_kfs = 4: removeKeyframe erases a keyframe's seeds behind the store's back), plus the deferred
+    mapper (the replay's erasures reach the store one call later)"""
+    on, s_on = _run_mirror(flavour, n, {}, tmp_path, "store_on", max_n_kfs=4)
+    off, s_off = _run_mirror(flavour, n, {"SVO_HIP_SEED_STORE": "off"}, tmp_path, "store_off", max_n_kfs=4)
+    assert np.array_equal(on, off)                                   # same trajectory, bit for bit
+    assert s_on["seeds"] == s_off["seeds"] and s_on["counts"] == s_off["counts"]
+    st = s_on["seed_store"]
+    assert s_off["seed_store"]["calls"] == 0 and st["calls"] > n // 2
+    assert s_on["kfs"] >= 6                                          # more keyframes than the map holds: seeds were removed with them
+    # a seed's record travels once: what was sent is the seeds ever created (plus at most the one full re-send of a grown store),
+    # not seeds x calls
+    created = sum(max(0, b - a) for a, b in zip(s_on["seeds"], s_on["seeds"][1:])) + s_on["seeds"][0]
+    assert st["seed_records_sent"] <= 2 * created + 1024 and st["seed_records_sent"] * 8 < sum(s_on["seeds"]), (st, created)
+    dfr, s_dfr = _run_mirror(flavour, n, {}, tmp_path, "store_deferred", max_n_kfs=4, defer_mapper=1)
+    assert np.array_equal(dfr, on) and s_dfr["seed_store"]["calls"] == st["calls"]
+
+
+def test_mock_device_resident_seed_store_is_the_flattened_list(mock_lib, tmp_path):
+    """Row N2, seeds, host side (rpg_svo_amd/host/dropin/seed_store.h) on the mock device."""
+    _seed_store_on_and_off("hipmock", 200, tmp_path)
+
+
+@pytest.mark.gpu
+def test_dropin_resident_seed_store_is_the_flattened_list_on_the_gpu(pipeline_libs, gpu_device, tmp_path):
+    """The same on the real device: svo_hip_seed_store_patch + svo_hip_update_seeds_resident against svo_hip_update_seeds."""
+    _seed_store_on_and_off("hip", 160, tmp_path)
 
 
 @pytest.mark.gpu

@@ -1,0 +1,44 @@
+"""The two small source tools of round 5: scripts/unifdef.py (how losing compile-time experiments were deleted) and
+scripts/design_table.py (DESIGN.md's measured table from a bench details file)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+def test_unifdef_resolves_one_symbol_and_keeps_the_rest():
+    from unifdef import unifdef
+    src = "\n".join([
+        "a", "#ifdef KEEP_ME", "k1", "#else", "k2", "#endif",
+        "#ifdef GONE", "g1", "#ifdef KEEP_ME", "nested", "#endif", "#else", "g2", "#endif",
+        "#ifndef GONE", "n1", "#endif", "#if defined(GONE)", "d1", "#else", "d2", "#endif", "z"])
+    off = unifdef(src, "GONE", False).split("\n")
+    assert off == ["a", "#ifdef KEEP_ME", "k1", "#else", "k2", "#endif", "g2", "n1", "d2", "z"]
+    on = unifdef(src, "GONE", True).split("\n")
+    assert on == ["a", "#ifdef KEEP_ME", "k1", "#else", "k2", "#endif", "g1", "#ifdef KEEP_ME", "nested", "#endif", "d1", "z"]
+
+
+def test_no_experiment_switch_is_left_in_the_kernels():
+    """csrc/ keeps three switches: the reference-width build the bench times, the phase counters, the CPU test seams."""
+    import glob
+    import re
+    allowed = {"SIA_F64_PARTIALS", "SIA_PROFILE", "SIA_PACKED", "SVO_HOST_MATH_TEST", "SIA_VCC_SELECT", "ALIGN_PHASE_MIN_M_VALUE",
+               "__HIP_DEVICE_COMPILE__", "SVO_HIP_EMU"}  # (SVO_HIP_EMU: set by tests/host/hip_emu.h next to SVO_HOST_MATH_TEST)
+    found = set()
+    for f in glob.glob(os.path.join(ROOT, "rpg_svo_amd", "csrc", "*")):
+        for m in re.finditer(r"^\s*#\s*(?:ifdef|ifndef|if|elif)\s+(.*)$", open(f).read(), re.M):
+            found |= set(re.findall(r"[A-Z_][A-Z0-9_]{3,}", m.group(1)))
+    assert found <= allowed, sorted(found - allowed)
+
+
+def test_design_table_from_a_committed_details_file(tmp_path):
+    src = os.path.join(ROOT, "profiles", "r05y_bench_default_details.json")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "design_table.py"), src], capture_output=True, text=True, check=True).stdout
+    d = json.load(open(src))
+    assert f"{d['value'] / 1e6:.2f} M frames/s" in out and "epi_scan_kernel" in out and "SIA_F64_PARTIALS" in out
+    # DESIGN.md carries exactly this table
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert out.strip() in design
