@@ -231,6 +231,38 @@ def test_find_epipolar_match_direct(libs, scene, scene_frames):
     assert n_ok > 60 and n_short > 7
 
 
+def test_find_epipolar_match_direct_search_step_cap(libs, scene, scene_frames):
+    """Matcher::Options::max_epi_search_steps below the scan length (matcher.cpp:248-256, "skip epipolar search"): the C port
+    leaves the search where the reference does -- same verdict, and what the reference's Matcher holds at its early return
+    (search level, warp matrix, segment length) is what the port reports."""
+    orc, ref = libs
+    frames = pytrack.make_frames(scene_frames, scene.T_f_w)
+    rng = np.random.default_rng(23)
+    n_cut = n_ok = 0
+    for i in range(0, len(scene.obs), 3):
+        o = [x for x in scene.obs[i] if x[0] != scene.cur][0]
+        ftr = pytrack.make_feature(*o)
+        c_ref = -scene.T_f_w[o[0], :9].reshape(3, 3).T @ scene.T_f_w[o[0], 9:]
+        d_true = np.linalg.norm(scene.pt_pos[i] - c_ref)
+        spread = [0.5, 0.25, 0.05][(i // 3) % 3]
+        d_est = d_true * (1 + rng.normal() * spread * 0.2)
+        d_min, d_max = d_est * (1 - spread), d_est * (1 + spread)
+        free = pytrack.matcher_options(n_pyr_levels=5)
+        ok_free, _ = ref.find_epipolar_match_direct(frames, scene.cam, o[0], scene.cur, ftr, d_est, d_min, d_max, free)
+        for cap in (6, 20):
+            opt = pytrack.matcher_options(n_pyr_levels=5, max_epi_search_steps=cap)
+            ok_o, r_o = orc.find_epipolar_match_direct(frames, scene.cam, o[0], scene.cur, ftr, d_est, d_min, d_max, opt)
+            ok_r, r_r = ref.find_epipolar_match_direct(frames, scene.cam, o[0], scene.cur, ftr, d_est, d_min, d_max, opt)
+            assert ok_o == ok_r, (i, cap)
+            for k in ("search_level", "reject", "A_cur_ref", "epi_length"):
+                assert same(r_o[k], r_r[k]), (i, cap, k)
+            if ok_o:
+                assert same(r_o["depth"], r_r["depth"]) and same(r_o["px_cur"], r_r["px_cur"])
+                n_ok += 1
+            n_cut += int(ok_free and not ok_r and r_r["epi_length"] / 0.7 > cap)
+    assert n_cut > 20 and n_ok > 20, (n_cut, n_ok)
+
+
 def test_pose_optimize(libs, scene):
     orc, ref = libs
     rng = np.random.default_rng(2)
