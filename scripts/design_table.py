@@ -72,7 +72,18 @@ def table(d: dict, src: str) -> str:
     if par:
         L.append(f"Parity of the headline run against that translation unit over {par['frames_compared']} frames: SE(3) log-norm max {par['se3_lognorm_max']:.2e}, median "
                  f"{par['se3_lognorm_median']:.1e}; identical per-level iteration counts {par['same_iteration_counts_frac']:.4f}.")
-    return "\n".join(L)
+    import textwrap
+    out, in_table = [], False
+    for l in L:
+        if l.startswith("|"):
+            out.append(l)
+            in_table = True
+            continue
+        if l and out and out[-1] != "" and not in_table and not l.startswith("Source:"):
+            out.append("")  # paragraphs of their own
+        in_table = False
+        out.extend(textwrap.wrap(l, 108, break_long_words=False, break_on_hyphens=False) if len(l) > 110 else [l])
+    return "\n".join(out)
 
 
 def main():
