@@ -17,6 +17,10 @@ namespace svo {
 SparseImgAlign::SparseImgAlign(int max_level, int min_level, int n_iter, Method method, bool display, bool verbose)
     : display_(display), max_level_(max_level), min_level_(min_level) {
   // same solver settings as the reference constructor (sparse_img_align.cpp:29-41)
+  // The kernel runs vk::NLLSSolver's Gauss-Newton loop, the only method the reference pipeline constructs
+  // (frame_handler_mono.cpp:136-137, 247-248).  A caller asking for LevenbergMarquardt is told so here instead of
+  // silently getting Gauss-Newton (the Python mirror raises the same way, rpg_svo_amd/sparse_img_align.py).
+  if (method != GaussNewton) throw svo_hip::Error("SparseImgAlign: only the GaussNewton method runs on the device");
   n_iter_ = n_iter;
   n_iter_init_ = n_iter_;
   method_ = method;

@@ -30,6 +30,7 @@
 #include <svo/frame_handler_mono.h>
 #include <svo/map.h>
 #include <svo/point.h>
+#include <svo/sparse_img_align.h>
 #include <vikit/atan_camera.h>
 #include <vikit/pinhole_camera.h>
 #include <vikit/vision.h>
@@ -319,6 +320,18 @@ int pipe_last_host_pyramid(void* h, int* n_levels) {
   int filled = 0;
   for (size_t i = 0; i < f->img_pyr_.size(); ++i) filled += (f->img_pyr_[i].data != NULL && f->img_pyr_[i].rows > 0) ? 1 : 0;
   return filled;
+}
+
+// Does constructing SparseImgAlign with vk::NLLSSolver's LevenbergMarquardt method throw?  The all-CPU reference accepts it
+// (0); the drop-in, whose kernel runs the Gauss-Newton loop only, must say so (1) instead of silently running Gauss-Newton.
+int pipe_sparse_align_rejects_levenberg_marquardt(void) {
+  try {
+    SparseImgAlign a(2, 0, 10, SparseImgAlign::LevenbergMarquardt, false, false);
+    (void)a;
+  } catch (const std::exception&) {
+    return 1;
+  }
+  return 0;
 }
 
 }  // extern "C"

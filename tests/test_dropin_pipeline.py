@@ -128,6 +128,17 @@ def test_dropin_host_logic_on_the_mock_device(mock_lib):
     assert st["uploads"] == len(imgs) and st["evictions"] == len(imgs) - 64  # 64 slots: old frames leave, none comes back
 
 
+def test_dropin_sparse_align_says_no_to_levenberg_marquardt(mock_lib):
+    """vk::NLLSSolver offers two methods (sparse_img_align.h:43-49); the reference pipeline constructs GaussNewton only
+    (frame_handler_mono.cpp:136-137) and the kernel runs that loop.  The drop-in's constructor must refuse the other one
+    instead of silently running Gauss-Newton (as the Python mirror does); the all-CPU reference accepts both."""
+    import ctypes
+    for flavour, expect in (("ref", 0), ("hipmock", 1)):
+        lib = ctypes.CDLL(pp.lib_path(flavour))
+        lib.pipe_sparse_align_rejects_levenberg_marquardt.restype = ctypes.c_int
+        assert lib.pipe_sparse_align_rejects_levenberg_marquardt() == expect, flavour
+
+
 def test_full_dropin_builds_no_host_pyramid(mock_lib):
     """rpg_svo_amd/host/dropin/frame.cpp: in the full drop-in every reader of the host pyramid's upper levels is a drop-in,
     so frame_utils::createImgPyramid keeps level 0 and leaves the rest empty (the reference builds them all: three to five
