@@ -94,9 +94,11 @@ def main():
     path = "/tmp/svo_env_knobs_seq.npz"
     np.savez(path, imgs=imgs, T=np.asarray(T), range0=pp.range_map(cam, T[0]),
              cam=np.array([cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy], dtype=np.float64))
-    results = {name: [] for name, _ in SETTINGS}
-    for rep in range(2):
-        for name, env in SETTINGS:
+    only = _arg("only", "")
+    settings = [x for x in SETTINGS if not only or x[0] == "default" or any(o in x[0] for o in only.split(","))]
+    results = {name: [] for name, _ in settings}
+    for rep in range(int(_arg("reps", "2"))):
+        for name, env in settings:
             r = run_child(path, flavour, env, False)
             results[name].append(r)
             print(f"[{rep}] {name:55s} {json.dumps(r)[:230]}", flush=True)
@@ -108,9 +110,9 @@ def main():
     base = best("default")
     # the settings that gained more than 1.5 % on their own, together; then with the deferred mapper, against the default
     winners = {}
-    for name, env in SETTINGS[1:]:
+    for name, env in settings[1:]:
         b = best(name)
-        if base and b and b < 0.985 * base and not name.startswith("SVO_HIP_ARENA"):
+        if base and b and b < 0.985 * base and not name.startswith("SVO_HIP_"):
             winners.update(env)
     extra = {}
     if winners:
@@ -127,7 +129,7 @@ def main():
     with open(os.path.join(out_dir, "env_knobs.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
     print("\nsetting, best of two tot_time medians (us), change against the default, same trajectory")
-    for name, _ in SETTINGS:
+    for name, _ in settings:
         b = best(name)
         print(f"  {name:55s} {b if b is None else round(b, 1)!s:>8s} {'' if not (b and base) else '%+.1f %%' % (100 * (b / base - 1)):>8s}   {same[name]}")
     for k, v in extra.items():
