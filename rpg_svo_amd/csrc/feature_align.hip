@@ -16,6 +16,7 @@
 #include "track_kernels.h"
 #include "track_math.h"
 #include "align_lanes.h"
+#include "align_wave.h"
 
 using namespace svo_capi;
 using namespace svo_dev;
@@ -119,6 +120,67 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const Al
   a.px_out[2 * t + 1] = ov;
 }
 
+// ---- small batches: one WAVE per trial (align_wave.h) -------------------------------------------------------------
+// A camera frame's trials (~130 of the reprojector, ~330 seeds of the depth filter) are a handful of waves of the kernel
+// above, each running as long as its slowest lane: ~27 us per launch in the single-stream drop-in.  With a wave per trial
+// and a lane per template pixel an iteration is a fraction of that, and a frame's trials are spread over as many CUs as
+// there are trials.  Same bits (align_wave.h says why); used below ALIGN_WAVE_MAX_M trials, where it is faster: the
+// waves of 8192 trials are all resident at once, beyond ~16 k the lane kernel's 64 trials per wave win.
+constexpr int ALIGNW_WAVES = 4;  // trials (= waves) per workgroup
+template <bool COUNT>
+__global__ void __launch_bounds__(64 * ALIGNW_WAVES) align_wave_kernel(const AlignArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_acc[ALIGNW_WAVES][3 * 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = blockIdx.x * ALIGNW_WAVES + wave;
+  if (t >= (a.M_dev ? min(*a.M_dev, a.M) : a.M)) return;  // (the whole wave: no workgroup barrier below)
+  // the trial's parameters, all requested before the first is looked at (every lane reads the same words)
+  const bool has_act = a.active != nullptr;
+  const uint8_t act_raw = (has_act ? a.active : a.pwb)[t];
+  const int level_raw = a.level[t];
+  const int slot_raw = a.slot[t];
+  const double pin0 = a.px_in[2 * t], pin1 = a.px_in[2 * t + 1];
+  const uint8_t u1d_raw = (a.use_1d ? a.use_1d : a.pwb)[t];
+  const bool has_dir = a.use_1d != nullptr && a.dir != nullptr;
+  const float* const dirp = has_dir ? a.dir : reinterpret_cast<const float*>(a.px_in);
+  const float dir0 = dirp[2 * t], dir1 = dirp[2 * t + 1];
+  const uint8_t* const tpl = a.pwb + (size_t)t * 100;
+  if (has_act && uniform_int(act_raw) == 0) {
+    if (lane == 0) {
+      a.ok[t] = 0;  // px_out is left as it is (findMatchDirect returns before touching px_cur)
+      if (COUNT) a.iters[t] = 0;
+    }
+    return;
+  }
+  const int level = uniform_int(level_raw), slot_t = uniform_int(slot_raw);
+  const bool one_d = a.use_1d != nullptr && uniform_int(u1d_raw) != 0;
+  AlignState st;
+  st.u = (float)pin0;
+  st.v = (float)pin1;
+  st.mean_diff = 0.f; st.chi2 = 0.f; st.up0 = 0.f; st.up1 = 0.f;
+  const uint8_t* img = a.store + (int64_t)slot_t * a.L.slot_bytes + a.L.offset[level];
+  const int cols = a.L.w[level], rows = a.L.h[level], pitch = a.L.pitch[level];
+  bool wrote = true, ok = false;
+  int n_eval = 0;
+  if (one_d) {
+    double h_inv = 0;
+    align1d_wave(img, cols, rows, pitch, tpl, dir0, dir1, a.n_iter, lane, s_acc[wave], st, h_inv, ok, wrote, n_eval);
+    if (a.h_inv && lane == 0) a.h_inv[t] = h_inv;
+  } else {
+    align2d_wave(img, cols, rows, pitch, tpl, a.n_iter, lane, s_acc[wave], st, ok, wrote, n_eval);
+  }
+  if (lane != 0) return;
+  if (COUNT) a.iters[t] = n_eval;
+  a.ok[t] = ok ? 1 : 0;
+  double ou = wrote ? (double)st.u : pin0;
+  double ov = wrote ? (double)st.v : pin1;
+  if (a.scale_out) {
+    ou = ou * (double)(1 << level);
+    ov = ov * (double)(1 << level);
+  }
+  a.px_out[2 * t] = ou;
+  a.px_out[2 * t + 1] = ov;
+}
+
 }  // namespace
 
 namespace svo_track {
@@ -145,6 +207,15 @@ size_t align_phase_workspace_bytes(int M) {
          Carver::round((size_t)M * 6 * sizeof(float));
 }
 
+constexpr int ALIGN_WAVE_MAX_M = 8192;  // batches up to this many trials take the wave-per-trial kernel
+
+static int launch_wave(const AlignArgs& a, hipStream_t s) {
+  const dim3 grid((a.M + ALIGNW_WAVES - 1) / ALIGNW_WAVES), blk(64 * ALIGNW_WAVES);
+  if (a.iters) hipLaunchKernelGGL(align_wave_kernel<true>, grid, blk, 0, s, a);
+  else hipLaunchKernelGGL(align_wave_kernel<false>, grid, blk, 0, s, a);
+  return check_launch();
+}
+
 static int launch_one(const AlignArgs& a, int n_blocks, hipStream_t s) {
   const dim3 grid(n_blocks), blk(ALIGN_BLOCK);
   if (a.iters) hipLaunchKernelGGL(align_kernel<true>, grid, blk, 0, s, a);  // instrumented: also counts evaluations
@@ -156,7 +227,8 @@ int launch_align(const AlignArgs& a0, hipStream_t s, void* d_phase_ws, size_t ph
   if (a0.M <= 0) return SVO_HIP_OK;
   const int all_blocks = (a0.M + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
   const size_t need = align_phase_workspace_bytes(a0.M);
-  if (!d_phase_ws || need == 0 || phase_ws_bytes < need || a0.n_iter <= ALIGN_PHASE_ITERS) return launch_one(a0, all_blocks, s);
+  const bool phased = d_phase_ws && need != 0 && phase_ws_bytes >= need && a0.n_iter > ALIGN_PHASE_ITERS;
+  if (!phased) return a0.M <= ALIGN_WAVE_MAX_M ? launch_wave(a0, s) : launch_one(a0, all_blocks, s);
   Carver c(d_phase_ws, phase_ws_bytes);
   const int cap = phase_queue_cap(a0.M);
   int32_t* queue[2] = {c.take<int32_t>((size_t)ALIGN_NQ * cap), c.take<int32_t>((size_t)ALIGN_NQ * cap)};
