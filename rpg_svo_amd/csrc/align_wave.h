@@ -9,12 +9,16 @@
 //   * per pixel everything is the reference's expression, rounded operation by operation (contraction is off);
 //   * the reference ACCUMULATES Jres (and chi2; align1D also H) over the 64 pixels in raster order in f32, and f32
 //     addition does not associate: the 64 products go to LDS and every lane adds them up in that order (64 dependent
-//     subtractions per accumulator, three accumulators interleaved, read as broadcast float4) -- the sums are the
-//     reference's, and every lane holds them, so the update and the loop's decisions need no broadcast;
+//     subtractions per accumulator -- two accumulators as a packed pair, the third beside it -- read as broadcast
+//     float4): the sums are the reference's, and every lane holds them, so the update and the loop's decisions need
+//     no broadcast;
 //   * align2D's H is a sum of exact terms (see align_lanes.h): a butterfly over the wave gives the same bits.
 //
 // An iteration is then ~40 instructions of pixel work, 4 byte loads that hit L1 after the first iteration, and a chain of
-// 192 additions, instead of ~850 instructions and a 9 x 12-byte window per lane.
+// 128 additions, instead of ~850 instructions and a 9 x 12-byte window per lane.  Measured on 330 trials
+// (scripts/align_small_bench.py, profiles/r05m_align_wave_variants.txt): 15.1 us with three scalar chains, 13.1 us with
+// the packed pair; the window kept in LDS instead of four L1 hits per iteration: 14.2 us alone, 14.0 us with the packed
+// pair -- not kept.  The floor of an iteration is the 64-deep dependent chain itself.
 // The including translation unit sets `#pragma clang fp contract(off)` first.
 #pragma once
 #include "align_lanes.h"
@@ -24,26 +28,30 @@ namespace svo_track {
 
 // three ordered accumulations over the 64 lanes' values: r[j] = (((init - or + v_j[0]) ...) v_j[63]) in lane order.
 // s: the wave's [3][64] floats of LDS.  SUB0/1/2: subtract (Jres -= x) or add (chi2 += x).
+// values 0 and 1 always share their sign (Jres0 / Jres1, H0 / H1): they are summed as a PAIR (v_pk_add_f32: two IEEE
+// additions per instruction, each rounded on its own), the third on its own: 128 dependent instructions instead of 192
 template <bool SUB0, bool SUB1, bool SUB2>
 __device__ __forceinline__ void ordered_sums3(float* s, int lane, float v0, float v1, float v2, float& r0, float& r1, float& r2) {
-  s[lane] = v0;
-  s[64 + lane] = v1;
+  static_assert(SUB0 == SUB1, "the pair shares its sign");
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  *reinterpret_cast<f2*>(s + 2 * lane) = (f2){v0, v1};
   s[128 + lane] = v2;
   SVO_WAVE_LDS_HANDOVER();
-  const float4* q0 = reinterpret_cast<const float4*>(s);
-  const float4* q1 = reinterpret_cast<const float4*>(s + 64);
+  const float4* q01 = reinterpret_cast<const float4*>(s);
   const float4* q2 = reinterpret_cast<const float4*>(s + 128);
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  f2 a01 = {0.f, 0.f};
+  float a2 = 0.f;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const float4 A = q0[k], B = q1[k], C = q2[k];
-    a0 = SUB0 ? a0 - A.x : a0 + A.x; a1 = SUB1 ? a1 - B.x : a1 + B.x; a2 = SUB2 ? a2 - C.x : a2 + C.x;
-    a0 = SUB0 ? a0 - A.y : a0 + A.y; a1 = SUB1 ? a1 - B.y : a1 + B.y; a2 = SUB2 ? a2 - C.y : a2 + C.y;
-    a0 = SUB0 ? a0 - A.z : a0 + A.z; a1 = SUB1 ? a1 - B.z : a1 + B.z; a2 = SUB2 ? a2 - C.z : a2 + C.z;
-    a0 = SUB0 ? a0 - A.w : a0 + A.w; a1 = SUB1 ? a1 - B.w : a1 + B.w; a2 = SUB2 ? a2 - C.w : a2 + C.w;
+    const float4 A = q01[2 * k], B = q01[2 * k + 1], C = q2[k];
+    const f2 p0 = {A.x, A.y}, p1 = {A.z, A.w}, p2 = {B.x, B.y}, p3 = {B.z, B.w};
+    a01 = SUB0 ? a01 - p0 : a01 + p0; a2 = SUB2 ? a2 - C.x : a2 + C.x;
+    a01 = SUB0 ? a01 - p1 : a01 + p1; a2 = SUB2 ? a2 - C.y : a2 + C.y;
+    a01 = SUB0 ? a01 - p2 : a01 + p2; a2 = SUB2 ? a2 - C.z : a2 + C.z;
+    a01 = SUB0 ? a01 - p3 : a01 + p3; a2 = SUB2 ? a2 - C.w : a2 + C.w;
   }
   SVO_WAVE_LDS_HANDOVER();  // (the next iteration's stores stay behind these reads)
-  r0 = a0; r1 = a1; r2 = a2;
+  r0 = a01.x; r1 = a01.y; r2 = a2;
 }
 
 // the lane's four neighbours (x0, y0), (x0+1, y0), (x0, y0+1), (x0+1, y0+1) of a tiled level as floats
@@ -54,6 +62,7 @@ __device__ __forceinline__ void load_quad(const uint8_t* __restrict__ img, int p
   const uint8_t b00 = img[r0 + c0], b01 = img[r0 + c1], b10 = img[r1 + c0], b11 = img[r1 + c1];
   p00 = (float)b00; p01 = (float)b01; p10 = (float)b10; p11 = (float)b11;
 }
+
 
 // the value every lane holds, as a wave-uniform one (lane 0's copy: scalar registers, scalar branches)
 __device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
