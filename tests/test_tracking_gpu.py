@@ -96,6 +96,58 @@ def test_align_batch_bit_exact(gpu_device, orc, scene, pyrs):
     assert n_conv > M // 4
 
 
+def test_wave_per_trial_alignment_is_the_lane_kernel_bit_for_bit(gpu_device, scene, pyrs):
+    """Batches of up to 8192 trials are aligned by one wave per trial (csrc/align_wave.h: a camera frame's trials), larger
+    ones by one lane per trial (align_lanes.h).  The same 3000 trials alone (wave kernel) and as the head of a batch of
+    9000 (lane kernel): verdicts, refined pixels, h_inv and evaluation counts identical in every bit.  Each kernel is
+    pinned to the reference on its own: test_align_batch_bit_exact (3000 trials: the wave kernel), the full-size and
+    phased tests (the lane kernel)."""
+    import ctypes as C
+    store, _ = scene_store(scene)
+    rng = np.random.default_rng(23)
+    M0, M1 = 3000, 9000
+    imgs = scene.images.cpu().numpy()
+    slot = rng.integers(0, imgs.shape[0], size=M1).astype(np.int32)
+    level = rng.integers(0, 3, size=M1).astype(np.int32)
+    pwb = np.zeros((M1, 100), np.uint8)
+    px0 = np.zeros((M1, 2))
+    dirs = rng.normal(size=(M1, 2)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    use_1d = (rng.uniform(size=M1) < 0.3).astype(np.uint8)
+    for t in range(M1):
+        img = pyrs[slot[t]][level[t]]
+        h, w = img.shape
+        u, v = rng.integers(8, w - 8), rng.integers(8, h - 8)
+        src = pyrs[(slot[t] + (t % 2)) % imgs.shape[0]][level[t]]
+        pwb[t] = src[v - 5:v + 5, u - 5:u + 5].ravel()
+        px0[t] = [u + rng.uniform(-4.0, 4.0), v + rng.uniform(-4.0, 4.0)]
+        if t % 37 == 0:
+            px0[t] = [3.0 + rng.uniform(0, 2), v]                       # leaves the image
+        if t % 41 == 0:
+            pwb[t] = 77                                                 # singular H -> NaN
+    lib = capi.load()
+
+    def run(M):
+        px = dev(px0[:M], torch.float64)
+        ok = torch.zeros(M, dtype=torch.int32, device="cuda:0")
+        h_inv = torch.zeros(M, dtype=torch.float64, device="cuda:0")
+        ev = torch.zeros(M, dtype=torch.int32, device="cuda:0")
+        keep = (dev(slot[:M], torch.int32), dev(level[:M], torch.int32), dev(pwb[:M], torch.uint8), dev(dirs[:M], torch.float32),
+                dev(use_1d[:M], torch.uint8))
+        capi.check(lib.svo_hip_align_batch_counted(C.byref(store.layout), store.ptr, M, keep[0].data_ptr(), keep[1].data_ptr(),
+                                                   keep[2].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(), 10, px.data_ptr(),
+                                                   ok.data_ptr(), h_inv.data_ptr(), ev.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        return px.cpu().numpy(), ok.cpu().numpy(), h_inv.cpu().numpy(), ev.cpu().numpy()
+
+    px_w, ok_w, h_w, ev_w = run(M0)   # <= 8192 trials: the wave kernel
+    px_l, ok_l, h_l, ev_l = run(M1)   # beyond: the lane kernel
+    assert np.array_equal(ok_w, ok_l[:M0]) and np.array_equal(ev_w, ev_l[:M0])
+    assert np.array_equal(px_w.view(np.uint64), px_l[:M0].view(np.uint64))
+    assert np.array_equal(h_w.view(np.uint64), h_l[:M0].view(np.uint64))
+    assert ok_w.sum() > M0 // 4 and (ev_w == 10).sum() > 50 and (use_1d[:M0] > 0).sum() > 500
+
+
 def test_phased_alignment_is_the_single_launch_bit_for_bit(gpu_device, scene, pyrs):
     """svo_hip_align_batch_phased (three launches, the unfinished trials compacted in between -- the form
     find_match_direct / update_seeds use for large batches) against the single launch on 73 728 trials: verdicts,
