@@ -42,3 +42,39 @@ def test_design_table_from_a_committed_details_file(tmp_path):
     # DESIGN.md carries exactly this table
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     assert out.strip() in design
+
+
+def test_flag_screen_tabulates_a_kernel_per_variant():
+    """scripts/flag_screen.py (static screening of compiler flags, no GPU): one small translation unit, the default build
+    and one variant -- a row per kernel and build with registers, occupancy and an instruction mix."""
+    import shutil
+    if not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None:
+        import pytest
+        pytest.skip("no hipcc")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "flag_screen.py"), "--units=point_optimizer",
+                          "ilp=-mllvm,-amdgpu-sched-strategy=max-ilp"], capture_output=True, text=True, check=True, timeout=300).stdout
+    lines = out.splitlines()
+    assert any(l.startswith("point_optimizer:") and "point_opt_kernel" in l for l in lines), out
+    rows = [l.split() for l in lines if l.strip().startswith(("default", "ilp"))]
+    assert {r[0] for r in rows} == {"default", "ilp"}
+    for r in rows:
+        d = dict(zip(r[1::2], r[2::2]))
+        assert int(d["vgpr"]) > 0 and int(d["occ"]) >= 1 and int(d["valu"]) > 50 and int(d["code"]) > 500, r
+
+
+def test_env_knobs_runs_its_children_on_the_mock_device(tmp_path):
+    """scripts/env_knobs.py (the single-stream drop-in under runtime settings, one child per setting) end to end on the mock
+    device: the default setting and the deferred-mapper follow-up, same trajectory, a summary file."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "dropin"))
+    import pypipeline as pp
+    if not pp.available("hipmock"):
+        import pytest
+        pytest.skip("tests/dropin/_build/libsvo_pipeline_hipmock.so absent")
+    rel = os.path.relpath(str(tmp_path), ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "env_knobs.py"), "frames=16", "flavour=hipmock", "only=NONE", "reps=1",
+                        "out=" + rel], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.load(open(os.path.join(str(tmp_path), "env_knobs.json")))
+    assert list(d["settings"]) == ["default"] and d["settings"]["default"][0]["tot_time_median_us"] > 0
+    assert d["follow_up"]["default, deferred mapper"][0]["pose_checksum"] == d["settings"]["default"][0]["pose_checksum"]
+    assert all(d["same_trajectory_as_default"].values())
