@@ -12,6 +12,10 @@
 // template gradients are re-formed from them with byte-extract converts (v_cvt_f32_ubyteN)
 // instead of being cached; each 9-byte row of the current image is 3 aligned dwords +
 // v_alignbyte.  No LDS, no cross-lane traffic.
+//
+// Batches of up to 8192 trials -- a camera frame's -- take align_wave_kernel instead: one WAVE per trial, lane = template
+// pixel, the reference's accumulation order kept by an ordered sum through LDS (align_wave.h); same bits, 11 us instead
+// of 27 for the ~130 trials of a frame.
 #pragma clang fp contract(off)
 #include "track_kernels.h"
 #include "track_math.h"
