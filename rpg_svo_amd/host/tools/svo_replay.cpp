@@ -181,6 +181,7 @@ vk::AbstractCamera* makeCamera(const std::string& spec) {
 int main(int argc, char** argv) {
   std::string dataset, out, cam_spec = "pinhole:752,480,315.5,315.5,376,240";
   int n_frames = -1;
+  bool mapper_thread = true;  // the reference's mode: DepthFilter runs in its own thread (depth_filter.cpp:70-76)
   for (int i = 1; i + 1 < argc; i += 2) {
     const std::string k = argv[i], v = argv[i + 1];
     if (k == "--dataset") dataset = v;
@@ -190,10 +191,11 @@ int main(int argc, char** argv) {
     else if (k == "--pyr-levels") Config::nPyrLevels() = std::atoi(v.c_str());
     else if (k == "--max-fts") Config::maxFts() = std::atoi(v.c_str());
     else if (k == "--kfselect-mindist") Config::kfSelectMinDist() = std::atof(v.c_str());
+    else if (k == "--mapper-thread") mapper_thread = std::atoi(v.c_str()) != 0;
     else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
   }
   if (dataset.empty() || out.empty()) {
-    std::fprintf(stderr, "usage: svo_replay --dataset DIR --out DIR [--cam model:params] [--frames N]\n");
+    std::fprintf(stderr, "usage: svo_replay --dataset DIR --out DIR [--cam model:params] [--frames N] [--mapper-thread 0|1]\n");
     return 2;
   }
   try {
@@ -206,6 +208,10 @@ int main(int argc, char** argv) {
     std::srand(1);  // Reprojector::initializeGrid's random_shuffle (reprojector.cpp:54)
     FrameHandlerMono vo(cam);
     vo.start();
+    // --mapper-thread 0: the depth filter updates its seeds inside addImage (DepthFilter::addFrame without a thread,
+    // depth_filter.cpp:97-110): a replay is then deterministic -- which frame first sees a converged seed's point no longer
+    // depends on how far the mapper thread got
+    if (!mapper_thread) vo.depthFilter()->stopThread();
     std::ofstream est((out + "/traj_estimate.txt").c_str());
     est.precision(12);
     size_t n_tracked = 0;

@@ -35,9 +35,10 @@ def replay_dataset(tmp_path_factory):
     return d
 
 
-def _run(flavour, ds, out):
+def _run(flavour, ds, out, mapper_thread=True):
     os.makedirs(out, exist_ok=True)
-    p = subprocess.run([_tool(flavour), "--dataset", ds, "--out", out, "--cam", CAM], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([_tool(flavour), "--dataset", ds, "--out", out, "--cam", CAM, "--mapper-thread", "1" if mapper_thread else "0"],
+                       capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-2000:]
     traj = np.loadtxt(os.path.join(out, "traj_estimate.txt"))
     with open(os.path.join(out, "svo.csv")) as fh:
@@ -64,26 +65,30 @@ def test_dataset_replay_drop_in_host_code_on_the_mock_device(replay_dataset, tmp
     tests/dropin/mock_compute_oracle.cpp, CPU suite): same files, same counters as the all-reference tool."""
     if not os.path.exists(_tool("hipmock")):
         pytest.skip("tests/dropin/_build/svo_replay_hipmock not built")
-    traj_r, header_r, rows_r = _run("ref", replay_dataset, str(tmp_path / "ref"))
-    traj_m, header_m, rows_m = _run("hipmock", replay_dataset, str(tmp_path / "mock"))
+    # --mapper-thread 0: with DepthFilter's thread running, WHEN a seed converges -- hence which frame first sees its point --
+    # depends on how far the thread got, in both flavours (the mock computes with the CPU oracle: on a loaded machine its
+    # mapper lags by whole keyframes and the candidate counts of the two runs drift apart by dozens).  Without the thread
+    # the replay is deterministic and the two flavours make the same decisions frame by frame.
+    traj_r, header_r, rows_r = _run("ref", replay_dataset, str(tmp_path / "ref"), mapper_thread=False)
+    traj_m, header_m, rows_m = _run("hipmock", replay_dataset, str(tmp_path / "mock"), mapper_thread=False)
     assert header_r == header_m and rows_r.shape == rows_m.shape and traj_r.shape == traj_m.shape
     assert np.abs(traj_r[:, 1:] - traj_m[:, 1:]).max() < 1e-4
     col = {n: i for i, n in enumerate(header_r)}
-    # (the tool keeps DepthFilter's thread running: when a seed converges is timing dependent in both flavours)
     for name in ("img_align_n_tracked", "repr_n_mps", "repr_n_new_references", "sfba_n_edges_final", "n_candidates", "dropout"):
         same = np.mean(rows_r[:, col[name]] == rows_m[:, col[name]])
-        assert same >= (0.5 if name == "n_candidates" else 0.95), (name, same)
+        assert same >= 0.95, (name, same)
         if name == "n_candidates":
-            assert np.abs(rows_r[:, col[name]] - rows_m[:, col[name]]).max() <= 10
+            assert np.abs(rows_r[:, col[name]] - rows_m[:, col[name]]).max() <= 3
 
 
 @pytest.mark.gpu
 def test_dataset_replay_hip_matches_reference(replay_dataset, tmp_path, gpu_device):
-    traj_r, header_r, rows_r = _run("ref", replay_dataset, str(tmp_path / "ref"))
-    traj_h, header_h, rows_h = _run("hip", replay_dataset, str(tmp_path / "hip"))
+    traj_r, header_r, rows_r = _run("ref", replay_dataset, str(tmp_path / "ref"), mapper_thread=False)
+    traj_h, header_h, rows_h = _run("hip", replay_dataset, str(tmp_path / "hip"), mapper_thread=False)
     assert header_r == header_h and rows_r.shape == rows_h.shape and traj_r.shape == traj_h.shape
-    # TUM-format poses (timestamp tx ty tz qx qy qz qw).  The tool keeps DepthFilter's thread running in both flavours:
-    # WHEN a seed converges -- hence which frame first sees the new candidate point -- depends on thread timing and on
+    # TUM-format poses (timestamp tx ty tz qx qy qz qw).  Both flavours run with --mapper-thread 0 (with DepthFilter's thread
+    # running, WHEN a seed converges also depends on how far the thread got: a flaky comparison).  What is left: which frame
+    # first sees a new candidate point depends on
     # last-bit differences of the pose a seed is updated with, and a feature set that differs by one point moves a pose
     # by ~1e-4 m on this 0.4 m trajectory (measured maxima of single runs on the MI355X box: 0.6e-4 .. 1.04e-4 m; both
     # flavours stay within 1.4 mm RMSE of the ground truth, bench.py dropin_sequence).  Positions to 2.5e-4 m, orientation
