@@ -91,7 +91,9 @@ def main():
     cam = synth.Camera(752, 480, 315.5, 315.5, 376.0, 240.0)
     T = synth.make_trajectory(n, seed=5, max_step=0.02, max_rot_deg=0.3)
     imgs = synth.render(synth.make_texture(seed=12345), T, cam, device="cuda" if torch.cuda.is_available() else "cpu").cpu().numpy()
-    path = "/tmp/svo_env_knobs_seq.npz"
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="svo_env_knobs_seq_", suffix=".npz")
+    os.close(fd)
     np.savez(path, imgs=imgs, T=np.asarray(T), range0=pp.range_map(cam, T[0]),
              cam=np.array([cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy], dtype=np.float64))
     only = _arg("only", "")
@@ -126,6 +128,7 @@ def main():
     same = {name: all(r.get("pose_checksum") == ref for r in rs) for name, rs in {**results, **extra}.items()}
     summary = {"frames": n, "flavour": flavour, "settings": results, "follow_up": extra, "default_best_us": base,
                "combined_env": winners, "same_trajectory_as_default": same}
+    os.unlink(path)
     with open(os.path.join(out_dir, "env_knobs.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
     print("\nsetting, best of two tot_time medians (us), change against the default, same trajectory")
