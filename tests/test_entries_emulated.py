@@ -106,6 +106,58 @@ def test_emulated_align_batch_and_its_phased_form(emu, oracle, scene):
     assert n_conv > M // 16
 
 
+@pytest.mark.parametrize("n_iter", [0, 1, 3, 10])
+def test_emulated_wave_alignment_iteration_caps_and_borders(emu, oracle, scene, n_iter):
+    """The wave-per-trial kernel (csrc/align_wave.h: batches of up to 8192 trials) against the reference's align2D / align1D
+    at iteration caps 0 / 1 / 3 / 10 (Matcher::Options::align_max_iter), with starts on the rim of the valid region (the
+    first bounds test fails / the position leaves after a step), flat templates (singular H: NaN updates) and templates from
+    a different place (chi2 rises: align1D's early exit): verdict, refined pixel, h_inv and evaluation count per trial."""
+    orc = pytrack.Track("orc")
+    imgs = scene.images.cpu().numpy()
+    pyrs = [orc.create_img_pyramid(im, 5) for im in imgs]
+    layout, store = _store(emu, imgs)
+    rng = np.random.default_rng(100 + n_iter)
+    M = 192
+    slot = rng.integers(0, imgs.shape[0], size=M).astype(np.int32)
+    level = rng.integers(0, 4, size=M).astype(np.int32)
+    pwb, px0 = np.zeros((M, 100), np.uint8), np.zeros((M, 2))
+    dirs = rng.normal(size=(M, 2)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    use_1d = (np.arange(M) % 2).astype(np.uint8)
+    for t in range(M):
+        img = pyrs[slot[t]][level[t]]
+        h, w = img.shape
+        u, v = rng.integers(8, w - 8), rng.integers(8, h - 8)
+        kind = t % 6
+        src = pyrs[(slot[t] + 1) % imgs.shape[0]][level[t]]
+        pwb[t] = src[v - 5:v + 5, u - 5:u + 5].ravel()
+        px0[t] = [u + rng.uniform(-3.0, 3.0), v + rng.uniform(-3.0, 3.0)]
+        if kind == 1:
+            px0[t] = [4.0 + rng.uniform(0, 0.9), v]                     # on the rim: inside now, one step from leaving
+        elif kind == 2:
+            px0[t] = [w - 4.0 + rng.uniform(0, 0.5), v]                 # the first bounds test fails: no evaluation
+        elif kind == 3:
+            pwb[t] = 128                                                # flat template: singular H
+        elif kind == 4:
+            uu, vv = rng.integers(8, w - 8), rng.integers(8, h - 8)     # a template from somewhere else
+            pwb[t] = img[vv - 5:vv + 5, uu - 5:uu + 5].ravel()
+    px, ok, h_inv, ev = px0.copy(), np.zeros(M, np.int32), np.zeros(M), np.full(M, -1, np.int32)
+    rc = emu.svo_hip_align_batch_counted(C.byref(layout), _p(store), M, _p(slot), _p(level), _p(pwb), _p(dirs), _p(use_1d), n_iter, _p(px),
+                                         _p(ok), _p(h_inv), _p(ev), None)
+    assert rc == 0
+    assert ev.min() >= 0 and ev.max() <= n_iter and (n_iter == 0 or (ev == 0).sum() >= M // 8)
+    for t in range(M):
+        img = pyrs[slot[t]][level[t]]
+        patch = pwb[t].reshape(10, 10)[1:9, 1:9].ravel()
+        if use_1d[t]:
+            o, p, hi = orc.align1d(img, dirs[t], pwb[t], patch, n_iter, px0[t])
+            assert hi == h_inv[t] or (np.isnan(hi) and np.isnan(h_inv[t])) or (np.isinf(hi) and np.isinf(h_inv[t])), (t, hi, h_inv[t])
+        else:
+            o, p = orc.align2d(img, pwb[t], patch, n_iter, px0[t])
+        assert bool(ok[t]) == o, (t, n_iter)
+        assert np.array_equal(p, px[t], equal_nan=True), (t, n_iter, p, px[t])
+
+
 def test_emulated_find_epipolar_match_direct(emu, oracle, scene):
     orc = pytrack.Track("orc")
     imgs = scene.images.cpu().numpy()
