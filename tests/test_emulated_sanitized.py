@@ -34,9 +34,10 @@ def _runtime_or_skip(kind):
 
 
 @pytest.fixture(scope="module")
-def sweeps(tmp_path_factory, oracle):
+def sweeps(tmp_path_factory, oracle, schedule_runs):
     """both sanitizer sweeps as child processes, started together (they are independent and take about as long; the
-    checker they both use is built before they start)"""
+    checker they both use is built before they start) -- and, through `schedule_runs`, next to the two reversed-schedule
+    runs of the last test: four children on the suite's idle cores instead of one after the other"""
     procs = {}
     for kind in ("address", "thread"):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -159,13 +160,36 @@ def test_the_race_detector_between_workgroups(tmp_path, mode, between, racy):
     assert (n >= 1 and "two_workgroups" in text) if racy else n == 0, text[:4000]
 
 
-@pytest.mark.parametrize("schedule", ["reverse", "waves"])
-def test_results_do_not_depend_on_the_schedule(schedule):
-    """SVO_EMU_SCHEDULE: the emulator lets the work-items and workgroups (reverse), or the waves (waves), take their turns in the
-    opposite order.  The parity tests -- bit-exact ones among them: the phased alignment with its atomically filled queues,
-    FAST's per-cell maxima, the scan's dynamic group fetch -- must not notice (a child: the mode is read once per process)."""
+@pytest.fixture(scope="module")
+def schedule_runs(tmp_path_factory, oracle):
+    """both reversed-schedule runs as child processes, started together (independent, about equally long)"""
     tests = [t for t in SUBSET if t.startswith("tests/")] + ["tests/test_entries_emulated.py::test_emulated_align_batch_and_its_phased_form[default]",
                                                              "tests/test_fast_emulated.py::test_emulated_fast_detect_bit_exact"]
-    r = subprocess.run([sys.executable, "-m", "pytest", *tests, "-q", "-x", "-p", "no:cacheprovider"], capture_output=True, text=True,
-                       timeout=1500, cwd=ROOT, env=dict(os.environ, SVO_EMU_SCHEDULE=schedule))
-    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout + r.stderr)[-4000:]
+    procs = {}
+    for schedule in ("reverse", "waves"):
+        log = str(tmp_path_factory.mktemp("schedule_" + schedule) / "out")
+        out = open(log, "w")
+        procs[schedule] = (subprocess.Popen([sys.executable, "-m", "pytest", *tests, "-q", "-x", "-p", "no:cacheprovider"], stdout=out,
+                                            stderr=subprocess.STDOUT, cwd=ROOT, env=dict(os.environ, SVO_EMU_SCHEDULE=schedule)), log)
+
+    def result(schedule):
+        p, log = procs[schedule]
+        try:
+            rc = p.wait(timeout=1500)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            raise
+        return rc, open(log).read()
+    yield result
+    for p, _ in procs.values():
+        if p.poll() is None:
+            p.kill()
+
+
+@pytest.mark.parametrize("schedule", ["reverse", "waves"])
+def test_results_do_not_depend_on_the_schedule(schedule, schedule_runs):
+    """SVO_EMU_SCHEDULE: the emulator lets the work-items and workgroups (reverse), or the waves (waves), take their turns in the
+    opposite order.  The parity tests -- bit-exact ones among them: the phased alignment with its atomically filled queues,
+    FAST's per-cell maxima, the scan's dynamic group fetch -- must not notice (children: the mode is read once per process)."""
+    rc, out = schedule_runs(schedule)
+    assert rc == 0 and " passed" in out, out[-4000:]
