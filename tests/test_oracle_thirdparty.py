@@ -114,3 +114,121 @@ def test_fast10_score_nonmax_and_shi_tomasi_against_brute_force(oracle):
     assert set(got) == set(expect)
     for k, v in expect.items():
         assert np.isclose(got[k], v, rtol=1e-4), (k, got[k], v)
+
+
+def _expm_se3(xi):
+    """exp of the twist (upsilon, omega) as a 4x4 matrix exponential (scipy): what Sophus SE3::exp computes in closed form"""
+    from scipy.linalg import expm
+    u, w = xi[:3], xi[3:]
+    M = np.zeros((4, 4))
+    M[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]
+    M[:3, 3] = u
+    return expm(M)
+
+
+def test_se3_exp_is_the_matrix_exponential(oracle):
+    """The oracle's restatement of Sophus SE3::exp (closed form: Rodrigues + V(omega) upsilon) against scipy's Pade matrix
+    exponential of the 4x4 twist, over small and large rotations."""
+    from oracle import pyoracle
+    rng = np.random.default_rng(5)
+    for scale in (1e-9, 1e-5, 1e-2, 0.5, 2.5):
+        for _ in range(20):
+            xi = rng.normal(size=6) * scale
+            T = np.asarray(pyoracle.se3_exp(xi))
+            E = _expm_se3(xi)
+            assert np.allclose(T[:9].reshape(3, 3), E[:3, :3], rtol=0, atol=5e-13), (scale, xi)
+            assert np.allclose(T[9:], E[:3, 3], rtol=1e-12, atol=5e-13), (scale, xi)
+
+
+def _pose_optimize_numpy(fx, T_f_w, f, level, has_point, pos, reproj_thresh, n_iter):
+    """pose_optimizer::optimizeGaussNewton (svo/src/pose_optimizer.cpp:28-161) re-derived in numpy float64 from the published
+    pieces it is built of: vk::project2d, Frame::jacobian_xyz2uv (frame.h:116-138), vk::robust_cost::TukeyWeightFunction
+    (b = 4.6851, a FLOAT function of a float argument), MADScaleEstimator (1.48 x median, on FLOAT errors as the reference
+    stores them), vk::getMedian (the element
+    at n / 2 of the sorted values), a dense solve for A.ldlt().solve(b), and the matrix exponential for SE3::exp."""
+    R, t = np.array(T_f_w[:9]).reshape(3, 3), np.array(T_f_w[9:])
+    idx = [i for i in range(len(f)) if has_point[i]]
+    if not idx:
+        return None
+    proj = lambda v: v[:2] / v[2]
+    inv_cov = lambda i: 1.0 / (1 << int(level[i]))
+    med = lambda v: sorted(v)[len(v) // 2]
+
+    def errors(R, t):
+        return [(proj(f[i]) - proj(R @ pos[i] + t)) * inv_cov(i) for i in idx]
+
+    e32 = [np.float32(np.linalg.norm(e)) for e in errors(R, t)]
+    est_scale = float(np.float32(1.48) * med(e32))
+    scale, chi2 = est_scale, 0.0
+    R_old, t_old = R.copy(), t.copy()
+    chi2_init = None
+    A = np.zeros((6, 6))
+    for it in range(n_iter):
+        if it == 5:
+            scale = 0.85 / fx
+        A, b, new_chi2 = np.zeros((6, 6)), np.zeros(6), 0.0
+        sq = []
+        for i in idx:
+            x, y, z = R @ pos[i] + t
+            zi = 1.0 / z
+            J = np.array([[-zi, 0, x * zi * zi, x * y * zi * zi, -(1 + x * x * zi * zi), y * zi],
+                          [0, -zi, y * zi * zi, 1 + y * y * zi * zi, -x * y * zi * zi, -x * zi]]) * inv_cov(i)
+            e = (proj(f[i]) - np.array([x * zi, y * zi])) * inv_cov(i)
+            sq.append(e @ e)
+            # vikit's weight functions are float: value(const float& x), b = 4.6851f, b * b and the result in float
+            r = np.float32(np.linalg.norm(e) / scale)
+            r2, b2 = r * r, np.float32(4.6851) * np.float32(4.6851)
+            w = float((np.float32(1.0) - r2 / b2) ** 2) if r2 <= b2 else 0.0
+            A += J.T @ J * w
+            b -= J.T @ e * w
+            new_chi2 += (e @ e) * w
+        if it == 0:
+            chi2_init = sq
+        dT = np.linalg.solve(A, b)
+        if (it > 0 and new_chi2 > chi2) or np.isnan(dT[0]):
+            R, t = R_old, t_old
+            break
+        E = _expm_se3(dT)
+        R_old, t_old = R, t
+        R, t = E[:3, :3] @ R, E[:3, :3] @ t + E[:3, 3]
+        chi2 = new_chi2
+        if np.abs(dT).max() <= 1e-10:
+            break
+    final = [e @ e for e in errors(R, t)]
+    thresh = reproj_thresh / fx
+    hp = np.array(has_point, dtype=np.uint8).copy()
+    for k, i in enumerate(idx):
+        if np.sqrt(final[k]) > thresh:
+            hp[i] = 0
+    return dict(T=np.concatenate([R.ravel(), t]), has_point=hp, num_obs=int(hp[idx].sum()),
+                estimated_scale=est_scale * fx, error_init=np.sqrt(med(chi2_init)) * fx, error_final=np.sqrt(med(final)) * fx,
+                Cov=np.linalg.inv(A * fx * fx))
+
+
+def test_pose_optimizer_against_a_numpy_derivation(oracle):
+    """The oracle's optimizeGaussNewton -- with its restated Eigen LDLT, Sophus exp, vikit robust cost and median -- against
+    the derivation above on tracked frames with outliers: pose to 1e-9 (SE(3) log-norm), the same observations pruned, the
+    reported scale / errors / covariance."""
+    from helpers import camera_models
+    from rpg_svo_amd import se3, synth
+    orc = pytrack.Track("orc")
+    scene = synth.make_track_scene(n_kf=3, n_feat=120, cam=camera_models()["pinhole"])
+    rng = np.random.default_rng(8)
+    P = len(scene.pt_pos)
+    for trial in range(6):
+        f = synth._bearing(scene.cam, scene.px_true + rng.normal(size=(P, 2)) * 0.4)
+        level = rng.integers(0, 3, size=P).astype(np.int32)
+        pos = scene.pt_pos.copy()
+        bad = rng.choice(P, size=P // 12, replace=False)
+        pos[bad] += rng.normal(size=(len(bad), 3)) * 0.15                  # outliers the Tukey weight and the pruning meet
+        hp = (rng.uniform(size=P) > 0.15).astype(np.uint8)
+        T0 = se3.mul(se3.exp(rng.normal(size=6) * 4e-3), scene.T_f_w[scene.cur])
+        o = orc.pose_optimize(scene.cam, T0, f, level, hp, pos, 2.0, 10)
+        n = _pose_optimize_numpy(scene.cam.fx, T0, f, level, hp, pos, 2.0, 10)
+        assert o["ran"] and n is not None
+        assert se3.log_norm(o["T_f_w"][None], n["T"][None])[0] < 1e-9, trial
+        assert np.array_equal(o["has_point"], n["has_point"]) and o["num_obs"] == n["num_obs"]
+        assert 0 < n["num_obs"] < int(hp.sum())                           # something was pruned, not everything
+        assert np.isclose(o["estimated_scale"], n["estimated_scale"], rtol=1e-6)      # (a float product in the reference)
+        assert np.isclose(o["error_init"], n["error_init"], rtol=1e-9) and np.isclose(o["error_final"], n["error_final"], rtol=1e-7)
+        assert np.allclose(o["Cov"], n["Cov"], rtol=1e-6, atol=1e-16)
