@@ -1,6 +1,9 @@
 """Independent numpy re-derivations of the third-party arithmetic the oracle restates from published
-sources (rpg_vikit, fast, boost::math are un-vendored and un-pinned): the depth-filter
-closed forms, the FAST-10 detector with its score / non-max rules, and vk::shiTomasiScore.  CPU only."""
+sources (rpg_vikit, fast, boost::math, Sophus, Eigen are un-vendored and un-pinned): the depth-filter
+closed forms, the FAST-10 detector with its score / non-max rules, vk::shiTomasiScore, Sophus SE3::exp against the matrix
+exponential, and the two optimisers built on those pieces end to end -- pose_optimizer::optimizeGaussNewton (robust cost,
+median, LDLT, exp) and SparseImgAlign::run on vk::NLLSSolver's Gauss-Newton loop -- each in float64 from the published
+algorithm, not from the restatement.  CPU only."""
 import math
 
 import numpy as np
@@ -232,3 +235,109 @@ def test_pose_optimizer_against_a_numpy_derivation(oracle):
         assert np.isclose(o["estimated_scale"], n["estimated_scale"], rtol=1e-6)      # (a float product in the reference)
         assert np.isclose(o["error_init"], n["error_init"], rtol=1e-9) and np.isclose(o["error_final"], n["error_final"], rtol=1e-7)
         assert np.allclose(o["Cov"], n["Cov"], rtol=1e-6, atol=1e-16)
+
+
+def _sparse_img_align_numpy(ref_pyr, cur_pyr, cam, T_ref_w, T_cur_w, px, f, pos, max_level, min_level, n_iter=30, eps=1e-6):
+    """SparseImgAlign::run (svo/src/sparse_img_align.cpp:43-258) on top of vk::NLLSSolver::optimizeGaussNewton (rpg_vikit
+    nlls_solver_impl.hpp), re-derived in numpy FLOAT64 from the published algorithm: inverse-compositional photometric
+    alignment of 4x4 patches, reference Jacobians cached per level, Gauss-Newton with roll-back when the mean squared
+    residual rises, T <- T exp(-x).  Not a restatement of the reference's float arithmetic: agreement is to the f32 noise of
+    the reference's pixels, and the iteration counts may differ where a chi2 comparison sits on that noise."""
+    def split(T):
+        return np.array(T[:9]).reshape(3, 3), np.array(T[9:])
+    Rr, tr = split(T_ref_w)
+    Rc, tc = split(T_cur_w)
+    R, t = Rc @ Rr.T, tc - Rc @ Rr.T @ tr                                   # T_cur_from_ref = T_cur_w * T_ref_w^-1
+    ref_pos = -Rr.T @ tr
+    depth = np.linalg.norm(pos - ref_pos, axis=1)
+    xyz_ref = f * depth[:, None]
+    offs = np.arange(4) - 2
+    iters = []
+
+    def sample(img, u, v):                                                  # bilinear, u / v arrays of the same shape
+        ui, vi = np.floor(u).astype(int), np.floor(v).astype(int)
+        su, sv = u - ui, v - vi
+        I = img.astype(np.float64)
+        return ((1 - su) * (1 - sv) * I[vi, ui] + su * (1 - sv) * I[vi, ui + 1] + (1 - su) * sv * I[vi + 1, ui] + su * sv * I[vi + 1, ui + 1])
+
+    visible = np.zeros(len(px), bool)                                       # (never reset between levels, as in the reference)
+    for level in range(max_level, min_level - 1, -1):
+        ref_img, cur_img = ref_pyr[level], cur_pyr[level]
+        h, w = ref_img.shape
+        scale = 1.0 / (1 << level)
+        u_ref, v_ref = px[:, 0] * scale, px[:, 1] * scale
+        ui, vi = np.floor(u_ref).astype(int), np.floor(v_ref).astype(int)
+        visible |= (ui - 3 >= 0) & (vi - 3 >= 0) & (ui + 3 < w) & (vi + 3 < h)
+        idx = np.nonzero(visible)[0]
+        # reference patches and their Jacobians (:107-141): I, dx, dy at the 16 pixels around the sub-pixel position
+        gu = u_ref[idx, None, None] + offs[None, None, :]                   # [n, y, x]
+        gv = v_ref[idx, None, None] + offs[None, :, None]
+        gu, gv = np.broadcast_arrays(gu, gv)
+        I_ref = sample(ref_img, gu, gv)
+        dx = 0.5 * (sample(ref_img, gu + 1, gv) - sample(ref_img, gu - 1, gv))
+        dy = 0.5 * (sample(ref_img, gu, gv + 1) - sample(ref_img, gu, gv - 1))
+        x, y, z = xyz_ref[idx, 0], xyz_ref[idx, 1], xyz_ref[idx, 2]
+        zi = 1.0 / z
+        J0 = np.stack([-zi, 0 * zi, x * zi * zi, x * y * zi * zi, -(1 + x * x * zi * zi), y * zi], -1)       # frame.h:116-138
+        J1 = np.stack([0 * zi, -zi, y * zi * zi, 1 + y * y * zi * zi, -x * y * zi * zi, -x * zi], -1)
+        Jc = (dx[..., None] * J0[:, None, None, :] + dy[..., None] * J1[:, None, None, :]) * (cam.fx / (1 << level))
+        chi2, n_eval = 0.0, 0
+        R_old, t_old = R, t
+        for it in range(n_iter):
+            p = xyz_ref[idx] @ R.T + t
+            uc = (cam.fx * p[:, 0] / p[:, 2] + cam.cx) * scale
+            vc = (cam.fy * p[:, 1] / p[:, 2] + cam.cy) * scale
+            uci, vci = np.floor(uc).astype(int), np.floor(vc).astype(int)
+            ok = (uci - 3 >= 0) & (vci - 3 >= 0) & (uci + 3 < w) & (vci + 3 < h)
+            cu = uc[ok, None, None] + offs[None, None, :]
+            cv = vc[ok, None, None] + offs[None, :, None]
+            cu, cv = np.broadcast_arrays(cu, cv)
+            res = sample(cur_img, cu, cv) - I_ref[ok]
+            n_eval += 1
+            Jv = Jc[ok].reshape(-1, 6)
+            rv = res.reshape(-1)
+            H, Jres = Jv.T @ Jv, -Jv.T @ rv
+            new_chi2 = float(rv @ rv) / max(len(rv), 1)
+            try:
+                xs = np.linalg.solve(H, Jres)
+            except np.linalg.LinAlgError:
+                xs = np.full(6, np.nan)
+            if (it > 0 and new_chi2 > chi2) or np.isnan(xs[0]):
+                R, t = R_old, t_old                                         # roll back and leave the level
+                break
+            E = _expm_se3(-xs)
+            R_old, t_old = R, t
+            R, t = R @ E[:3, :3], R @ E[:3, 3] + t                          # T <- T exp(-x)
+            chi2 = new_chi2
+            if np.abs(xs).max() <= eps:
+                break
+        iters.append(n_eval)
+    Rn, tn = R @ Rr, R @ tr + t                                              # cur.T_f_w = T_cur_from_ref * ref.T_f_w
+    return np.concatenate([Rn.ravel(), tn]), iters
+
+
+def test_sparse_img_align_against_a_numpy_derivation(oracle):
+    """The oracle's SparseImgAlign::run -- restated vikit NLLSSolver loop, Sophus, Eigen LDLT, f32 pixel arithmetic -- against
+    the float64 derivation above on rendered frame pairs, coarse to fine over all four levels: the refined pose to 2e-6
+    (SE(3) log-norm; measured 0.7e-7 .. 1.4e-7: the reference's own f32 pixel noise), both within 1e-3 of the ground truth the
+    prior was 1e-2 away from, and the same number of residual evaluations per level (measured: all 20 identical)."""
+    from helpers import make_batch
+    from rpg_svo_amd import se3, synth
+    seq = synth.make_sequence(6, 120)
+    pairs = [(i, i + 1) for i in range(5)]
+    b = make_batch(seq, pairs, 4)
+    same_iters, total = 0, 0
+    for k, (r, c) in enumerate(pairs):
+        ref_pyr = oracle.create_img_pyramid(b.images[r], 4)
+        cur_pyr = oracle.create_img_pyramid(b.images[c], 4)
+        T_o, res = oracle.sparse_img_align_run(ref_pyr, cur_pyr, b.cam, b.T_ref_w[k], b.T_cur_w[k], b.px[k], b.f[k], b.has_point[k],
+                                               b.pos[k], 3, 0)
+        T_n, iters = _sparse_img_align_numpy(ref_pyr, cur_pyr, b.cam, b.T_ref_w[k], b.T_cur_w[k], b.px[k], b.f[k], b.pos[k], 3, 0)
+        d = se3.log_norm(T_o[None], T_n[None])[0]
+        assert d < 2e-6, (k, d)
+        assert se3.log_norm(T_n[None], b.T_gt_w[k][None])[0] < 1e-3 and se3.log_norm(T_o[None], b.T_gt_w[k][None])[0] < 1e-3
+        assert se3.log_norm(b.T_cur_w[k][None], b.T_gt_w[k][None])[0] > 3e-3     # (the prior was far: something was optimised)
+        o_iters = [int(res["iters"][lv]) for lv in (3, 2, 1, 0)]
+        same_iters += sum(a == bb for a, bb in zip(o_iters, iters))
+        total += 4
+    assert same_iters >= total * 0.9, (same_iters, total)
