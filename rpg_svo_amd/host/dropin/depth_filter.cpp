@@ -109,7 +109,17 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   svo_hip_seeds seeds;
   FeatureColumns ftr;
   SeedStore::Call rc;
+  // sync() commits the store's shadow before anything has reached the device: until the update has completed (or has been
+  // handed to the deferred closure, which guards its own wait) every way out of this function -- slotOf / workspace /
+  // launch / stream failures all throw -- must leave the shadow claiming nothing (SeedStore::invalidate).
+  struct StoreGuard {
+    SeedStore* store;
+    StoreGuard() : store(NULL) {}
+    ~StoreGuard() { if (store) store->invalidate(); }
+    void done() { store = NULL; }
+  } store_guard;
   if (resident) {
+    store_guard.store = &seedStoreOf(this);
     // row N2: state and Feature of every seed stay in HBM; this call sends the slots in list order, the records of the
     // seeds it meets for the first time and the frame table (seed_store.h)
     rc = seedStoreOf(this).sync(seeds_, frame.get(), dev, L, a);
@@ -220,9 +230,16 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   if (thread_ == NULL && svo_hip::Device::deferredMapping()) {
     // the caller is the tracking thread itself (addFrame without the mapping thread): leave the kernels running
     stage_timer.unmarshal();  // this call's share is marshal + enqueue; the join adds its wait and the replay
-    lane.deferred = [this, replay, stream, pdev]() {
+    SeedStore* const pstore = store_guard.store;  // (the filter's destructor joins before it releases the store)
+    store_guard.done();
+    lane.deferred = [this, replay, stream, pdev, pstore]() {
       const double t0 = svo_hip::StageTimer::now();
-      svo_hip::check(svo_hip_stream_sync(stream), "svo_hip_stream_sync");
+      try {
+        svo_hip::check(svo_hip_stream_sync(stream), "svo_hip_stream_sync");
+      } catch (...) {
+        if (pstore) pstore->invalidate();  // the enqueued patch / update did not complete: host and device no longer agree
+        throw;
+      }
       const double t1 = svo_hip::StageTimer::now();
       lock_t relock(seeds_mut_);
       replay();
@@ -231,6 +248,7 @@ void DepthFilter::updateSeeds(FramePtr frame) {
     return;
   }
   dev.finish(lane);
+  store_guard.done();
   stage_timer.unmarshal();
   replay();  // seeds_mut_ is held
 }

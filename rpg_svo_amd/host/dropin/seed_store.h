@@ -33,8 +33,8 @@ namespace hip_dropin {
 class SeedStore {
  public:
   struct Stats {
-    uint64_t calls, rebuilds, records_sent, seeds_released;
-    Stats() : calls(0), rebuilds(0), records_sent(0), seeds_released(0) {}
+    uint64_t calls, rebuilds, records_sent, seeds_released, invalidations;
+    Stats() : calls(0), rebuilds(0), records_sent(0), seeds_released(0), invalidations(0) {}
   };
   Stats stats;
 
@@ -145,6 +145,19 @@ class SeedStore {
 
   size_t size() const { return ids_.size(); }
   const std::vector<int>& ids() const { return ids_; }
+
+  // Forget what the shadow believes the device holds: every seed of the list is met "for the first time" by the next
+  // sync() and its record travels again.  sync() commits the shadow (ids / slots / keys) BEFORE the patch kernel is
+  // even enqueued, so whenever anything between sync() and the completion of the update fails -- slotOf, the workspace,
+  // a launch, the stream's completion in the deferred closure -- the shadow would claim records the device never
+  // received (stale slots, a garbage d_frame indexing the frame table).  The caller invalidates on every such path.
+  // The device columns are kept (their capacity is still right); slots are handed out from 0 again.
+  void invalidate() {
+    ids_.clear(); slot_.clear(); key_.clear(); free_.clear();
+    kf_.clear(); kf_refs_.clear();
+    high_ = 0;
+    ++stats.invalidations;
+  }
 
  private:
   int32_t allocSlot() {

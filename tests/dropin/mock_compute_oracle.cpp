@@ -10,6 +10,7 @@
 // host code against the real kernels.
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -293,6 +294,11 @@ int svo_hip_update_seeds(const svo_hip_pyr_layout* L, const uint8_t* store, cons
                          int S, const int32_t* d_cur_frame, const svo_hip_features* ftr, const svo_hip_seeds* seeds,
                          const svo_hip_depth_filter_options* opt, int32_t* d_status, double* d_xyz_world, double* d_px_cur, void*,
                          size_t, void*) {
+  {  // fault injection (tests/test_dropin_pipeline.py: what the seed store does when an update fails): the k-th call fails
+    static const int fail_at = [] { const char* v = std::getenv("SVO_MOCK_FAIL_UPDATE_SEEDS_AT"); return v ? std::atoi(v) : -1; }();
+    static int n_calls = 0;
+    if (++n_calls == fail_at) return SVO_HIP_EHIP;
+  }
   const orc_pinhole c = camOf(cam);
   const std::vector<orc_frame> fr = framesOf(L, store, frames);
   orc_depth_filter_options dopt;
@@ -342,6 +348,11 @@ int svo_hip_update_seeds(const svo_hip_pyr_layout* L, const uint8_t* store, cons
 // row N2, seeds: the resident store on host memory (the mock's "device" memory is the host's)
 int svo_hip_seed_store_patch(const svo_hip_seed_patch* p, const svo_hip_features* sf, const svo_hip_seeds* ss, void*) {
   if (!p || !sf || !ss || p->n < 0) return SVO_HIP_EINVAL;
+  {  // fault injection: the k-th patch fails (its records never reach the store)
+    static const int fail_at = [] { const char* v = std::getenv("SVO_MOCK_FAIL_SEED_PATCH_AT"); return v ? std::atoi(v) : -1; }();
+    static int n_calls = 0;
+    if (++n_calls == fail_at) return SVO_HIP_EHIP;
+  }
   for (int i = 0; i < p->n; ++i) {
     const int q = p->d_slot[i];
     const_cast<int32_t*>(sf->d_frame)[q] = p->src_ftr.d_frame[i];

@@ -695,6 +695,54 @@ def test_mock_device_resident_seed_store_is_the_flattened_list(mock_lib, tmp_pat
     _seed_store_on_and_off("hipmock", 200, tmp_path)
 
 
+FAULT_CODE = (
+    "import sys, numpy as np\n"
+    "sys.path.insert(0, {here!r}); sys.path.insert(0, {dropin!r})\n"
+    "import pypipeline as pp\n"
+    "import test_dropin_pipeline as t\n"
+    "cam, imgs, T = t._sequence(80)\n"
+    "p = pp.Pipeline('hipmock', cam, max_n_kfs=4)\n"
+    "p.set_first_frame(imgs[0], 0.0, T[0], pp.range_map(cam, T[0]))\n"
+    "out, threw = [], []\n"
+    "for i in range(1, len(imgs)):\n"
+    "    try:\n"
+    "        out.append(p.add_image(imgs[i], float(i))['T_f_w'])\n"
+    "    except RuntimeError as e:\n"
+    "        threw.append(i); out.append(np.zeros(12))\n"
+    "np.save(sys.argv[1], np.stack(out))\n"
+    "print(threw, list(p.seed_store_stats()))\n")
+
+
+def test_mock_device_seed_store_forgets_what_a_failed_call_left_behind(mock_lib, tmp_path):
+    """ADVICE r05 (medium): SeedStore::sync() commits its shadow before the patch kernel is enqueued.  The mock fails the
+    second svo_hip_seed_store_patch (the records of a keyframe's new seeds never reach the store): updateSeeds throws, the
+    store must forget its shadow (SeedStore::invalidate) and re-send the whole list with the next call -- the frames after
+    the failure are then, bit for bit, those of the flattened-list path whose update fails at the same frame.  (Without the
+    invalidation the next update reads slots that were never written and a garbage frame index.)"""
+    import subprocess
+    code = FAULT_CODE.format(here=HERE, dropin=os.path.join(HERE, "dropin"))
+
+    def run(tag, env):
+        path = str(tmp_path / f"fault_{tag}.npy")
+        p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        threw, stats = eval(p.stdout.strip().splitlines()[-1].replace("] [", "], ["))
+        return np.load(path), threw, stats
+
+    on, threw_on, st_on = run("on", {"SVO_MOCK_FAIL_SEED_PATCH_AT": "2"})
+    assert len(threw_on) == 1, threw_on
+    # the store-off path makes one svo_hip_update_seeds call per updateSeeds: find the call of the same frame
+    probe, threw_p, _ = run("probe", {"SVO_HIP_SEED_STORE": "off", "SVO_MOCK_FAIL_UPDATE_SEEDS_AT": "1"})
+    # (a failed first update shifts the later calls by a frame or so: try the neighbours of the estimate)
+    for k in (threw_on[0] - threw_p[0], 1 + threw_on[0] - threw_p[0], 2 + threw_on[0] - threw_p[0]):
+        off, threw_off, st_off = run("off", {"SVO_HIP_SEED_STORE": "off", "SVO_MOCK_FAIL_UPDATE_SEEDS_AT": str(k)})
+        if threw_off == threw_on:
+            break
+    assert threw_off == threw_on, (threw_off, threw_on)
+    assert np.array_equal(on, off)
+    assert st_off[0] == 0 and st_on[0] > 40
+
+
 @pytest.mark.gpu
 def test_dropin_resident_seed_store_is_the_flattened_list_on_the_gpu(pipeline_libs, gpu_device, tmp_path):
     """The same on the real device: svo_hip_seed_store_patch + svo_hip_update_seeds_resident against svo_hip_update_seeds."""
