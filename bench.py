@@ -69,9 +69,20 @@ WORKLOADS = {
     "vga4_n200_sparse_align": (640, 480, 400.0, 4, 3, 0, 200, 28, 32),
     "svo_default_752_l4to2_n120": (752, 480, 315.5, 5, 4, 2, 120, 56, 40),
     "xga5_n1000_sparse_align": (1280, 960, 800.0, 5, 4, 0, 1000, 56, 32),
+    # configs[1]'s shape (4 levels, 3 -> 0, 200 patches) on the image size of the cameras the reference ships (svo_ros/param)
+    "ref752_4_n200_sparse_align": (752, 480, 414.5, 4, 3, 0, 200, 28, 32),
 }
+
+
+def reference_cameras() -> dict:
+    """The two calibrations the reference ships -- svo_ros/param/camera_pinhole.yaml (vk::PinholeCamera with radial-
+    tangential distortion, cam_d0 = -0.283076) and camera_atan.yaml (vk::ATANCamera, cam_d0 = 0.9320) -- and, as the
+    yardstick, camera_pinhole.yaml's intrinsics without its distortion (the model every other number of this file is on)."""
+    return {"pinhole_undistorted": synth.Camera(752, 480, 414.536145, 414.284429, 348.804988, 240.076451),
+            "radtan": synth.Camera.radtan(752, 480, 414.536145, 414.284429, 348.804988, 240.076451, -0.283076, 0.066674, 0.000896, 0.000778),
+            "atan": synth.Camera.atan(752, 480, 0.509326, 0.796651, 0.45905, 0.510056, 0.9320)}
 EXTRA_KEYS = {"f64": "f64_partials", "refine": "align_plus_refine", "full": "full_track", "full_easy": "full_track_easy", "long_scan": "full_track_long_scan", "stream": "stream_replay", "noise": "noise_sigma2", "config3": "config3_xga5_b64",
-              "k0": "k0_pyramid", "dropin": "dropin_sequence"}
+              "k0": "k0_pyramid", "dropin": "dropin_sequence", "cameras": "reference_cameras"}
 
 
 def algorithmic_bytes(n_patches: np.ndarray, n_tracked: np.ndarray, iters: np.ndarray, max_level: int, min_level: int) -> float:
@@ -129,31 +140,37 @@ def compact_line(result: dict, details_path: str | None) -> dict:
     """The one line the driver parses: the contract keys, `roofline` (with counter traffic), `cpu_baseline`,
     `parity`, one headline number per extra leg, and where the full object went.  Kept below COMPACT_LIMIT bytes."""
     c = _pick(result, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                       "vs_baseline", "data"))
+                       "vs_baseline", "data", "value_sparse_align_only"))
     c["dtype"] = result.get("dtype_short", result.get("dtype"))
     c["config"] = _pick(result.get("config", {}), ("workload", "image", "pyr_levels", "schedule", "patches_per_frame",
                                                    "frames_per_step_per_gpu", "n_iter_cap", "image_noise_sigma", "parallelism",
                                                    "k1_kernel", "hip_graph", "mean_gn_iterations_per_frame", "mean_tracked_patches",
-                                                   "k1_launches_before_timed_region", "timed_launches", "median_pose_error_vs_gt"))
+                                                   "k1_launches_before_timed_region", "timed_launches", "median_pose_error_vs_gt",
+                                                   "matches_per_frame", "pose_refine_obs_after_pruning",
+                                                   "median_pose_error_vs_gt_after_refine"))
     c["roofline"] = _pick(result.get("roofline", {}), ("bound", "kernel", "achieved", "peak", "unit", "frac", "ms", "traffic",
                                                        "traffic_over_algorithmic", "algorithmic_bytes_per_launch",
                                                        "algorithmic_bytes_per_frame", "ms_last_10_launches", "kernel_ms_avg"))
     if isinstance(result.get("roofline_valu"), dict):
         c["roofline"]["valu_busy_frac"] = result["roofline_valu"].get("frac")
+    if isinstance(result.get("roofline_pose_optimize"), dict):
+        c["roofline_pose_optimize"] = _pick(result["roofline_pose_optimize"], ("kernel", "achieved", "frac", "ms", "algorithmic_bytes_per_frame"))
     f64 = result.get("f64_partials")
     if isinstance(f64, dict) and isinstance(f64.get("roofline"), dict):
         # the reference-width build of the same kernel (-DSIA_F64_PARTIALS), measured in the same run: its own line
         c["roofline_f64_build"] = dict(_pick(f64["roofline"], ("achieved", "peak", "frac", "ms", "traffic", "traffic_over_algorithmic")),
-                                       value=f64.get("frames_per_s"), unit="frames/s")
+                                       value=f64.get("frames_per_s"), unit="frames/s",
+                                       **({"value_sparse_align_only": f64["frames_per_s_sparse_align_only"]} if f64.get("frames_per_s_sparse_align_only") else {}))
     if "cpu_baseline" in result:
         c["cpu_baseline"] = _pick(result["cpu_baseline"], ("value", "unit", "cores", "kind", "sample_short", "cpu_model", "value_release_flags",
+                                                           "value_sparse_align_only", "pose_optimize_us_per_frame",
                                                            "value_best_threads", "value_release_flags_best_threads", "best_threads",
                                                            "host_logical_cpus", "skipped"))
         if "sample_short" in c["cpu_baseline"]:
             c["cpu_baseline"]["sample"] = c["cpu_baseline"].pop("sample_short")
     if "parity" in result:
         c["parity"] = _pick(result["parity"], ("frames_compared", "se3_lognorm_max", "se3_lognorm_median", "ate_rmse_vs_cpu_m",
-                                               "same_iteration_counts_frac", "against"))
+                                               "same_iteration_counts_frac", "against", "refined_pose_se3_lognorm_max"))
     legs = {}
     ft = result.get("full_track")
     if isinstance(ft, dict):
@@ -193,6 +210,16 @@ def compact_line(result: dict, details_path: str | None) -> dict:
                 legs["dropin_sequence"][k_out] = ds[k_in].get("tot_time")
         if isinstance(ds.get("map_size"), dict):
             legs["dropin_sequence"]["map_size"] = _pick(ds["map_size"], ("n_kfs", "n_candidates", "kf_points_in_frame", "trials", "matches"))
+    rc = result.get("reference_cameras")
+    if isinstance(rc, dict) and isinstance(rc.get("cameras"), dict):
+        # per camera: [K1 M frames/s, K1 frac, K1 counter traffic / algorithmic, full-track ms per step, drop-in ms per frame]
+        g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+        legs["reference_cameras"] = {"frames_per_step": rc.get("frames_per_step"),
+                                     "keys": ["k1_frames_per_s", "k1_frac", "k1_traffic_over_algorithmic", "full_track_ms", "dropin_ms_per_frame"]}
+        for name, r in rc["cameras"].items():
+            legs["reference_cameras"][name] = _num([g(r, "sparse_align", "frames_per_s"), g(r, "sparse_align", "roofline", "frac"),
+                                                    g(r, "sparse_align", "roofline", "traffic_over_algorithmic"),
+                                                    g(r, "full_track", "ms_per_step"), g(r, "dropin", "tot_time")], 4) if "skipped" not in r else "skipped"
     for key in ("gather", "stages_ms"):  # small objects of the multi-GPU / --pipeline full runs: whole
         if isinstance(result.get(key), dict):
             c[key] = result[key]
@@ -204,8 +231,8 @@ def compact_line(result: dict, details_path: str | None) -> dict:
     c["details"] = details_path
     c = _num(c)
     # never exceed the limit: drop the optional blocks, least important first
-    order = ("stream_replay", "k0_pyramid", "config3_xga5_b64", "noise_sigma2", "f64_partials", "align_plus_refine", "full_track_long_scan",
-             "dropin_sequence", "full_track")
+    order = ("stream_replay", "k0_pyramid", "align_plus_refine", "config3_xga5_b64", "noise_sigma2", "f64_partials", "full_track_long_scan",
+             "reference_cameras", "dropin_sequence", "full_track")
     for victim in ("rig_replay", "legs", "stages_ms", "parity"):
         if len(json.dumps(c)) <= COMPACT_LIMIT:
             break
@@ -339,16 +366,18 @@ class Workload:
     """Synthetic replay sequence of B+1 frames on one GPU: problem b = (frame b -> frame b+1)."""
 
     def __init__(self, name: str, B: int, dev, rank: int = 0, noise: float = 0.0, images: torch.Tensor | None = None,
-                 T_gt: np.ndarray | None = None, n_patches: int | None = None):
+                 T_gt: np.ndarray | None = None, n_patches: int | None = None, cam=None):
         (self.width, self.height, self.focal, self.n_levels, self.max_level, self.min_level, self.n_patches,
          margin, cell) = WORKLOADS[name]
+        if cam is not None:  # one of the reference's own cameras (REFERENCE_CAMERAS): its image size and model
+            self.width, self.height, self.focal = cam.width, cam.height, cam.fx
         if n_patches is not None:  # side measurements only (config3_leg's latency floor), never the headline
             self.n_patches = n_patches
         if os.environ.get("SVO_BENCH_PATCHES"):  # kernel experiments only (scripts/): NOT the configuration the metric names
             self.n_patches = int(os.environ["SVO_BENCH_PATCHES"])
         self.name, self.B, self.dev, self.noise = name, B, dev, noise
         w, h, f = self.width, self.height, self.focal
-        self.cam = synth.Camera(w, h, f, f, w / 2.0, h / 2.0)
+        self.cam = synth.Camera(w, h, f, f, w / 2.0, h / 2.0) if cam is None else cam
         self.T_gt = synth.make_trajectory(B + 1, seed=12345 + rank) if T_gt is None else T_gt
         if images is None:
             images = synth.render(synth.make_texture(seed=12345), self.T_gt, self.cam, device=dev, chunk=32 if w <= 800 else 8)
@@ -397,16 +426,22 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=16384, help="frames per step per GPU")
     ap.add_argument("--workload", default="vga4_n200_sparse_align", choices=sorted(WORKLOADS))
     ap.add_argument("--noise", type=float, default=0.0, help="image noise sigma (gray levels) of the headline workload")
+    ap.add_argument("--camera", default="default", choices=["default", "pinhole_undistorted", "radtan", "atan"],
+                    help="default: the workload's own undistorted pinhole; else one of the reference's calibrations "
+                         "(svo_ros/param/camera_pinhole.yaml = radtan, camera_atan.yaml = atan, or camera_pinhole.yaml without its "
+                         "distortion) -- the image size follows the camera (752x480)")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="frames timed on the host for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n-iter", type=int, default=30, help="Gauss-Newton iteration cap per level (30 in the pipeline)")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step (all kernel launches of the pipeline) in a HIP graph and replay it: "
                          "small batches -- e.g. one frame per camera of a rig -- are launch-bound")
-    ap.add_argument("--pipeline", default="align", choices=["align", "full"],
-                    help="what the TIMED step runs.  align: SparseImgAlign only (BASELINE configs[1], the default and the "
-                         "headline); full: configs[2] -- the whole track is the step (the default run reports it as the "
-                         "extra key full_track instead)")
+    ap.add_argument("--pipeline", default="refine", choices=["refine", "align", "full"],
+                    help="what the TIMED step runs.  refine (default, the headline): the metric as worded -- SparseImgAlign "
+                         "followed by the Gauss-Newton pose refinement (K1 + K4) on BASELINE configs[1]'s frames, K4 fed by the "
+                         "matches K2 / K3 produced for them in set-up; align: SparseImgAlign only (configs[1] read literally; the "
+                         "default line carries it as value_sparse_align_only); full: configs[2] -- the whole track is the step "
+                         "(the default run reports it as the extra key full_track instead)")
     ap.add_argument("--extras", default="all",
                     help="comma list of the extra legs to run at N=1 (all, none, or any of: f64, refine, full, full_easy, noise, "
                          "config3, stream, rig, k0, dropin, pmc)")
@@ -451,7 +486,7 @@ def main() -> None:
     lib = capi.load()
     ev = Events(lib, dev)
     if args.extras == "all":
-        extras = {"f64", "refine", "full", "full_easy", "long_scan", "noise", "config3", "stream", "rig", "k0", "dropin", "pmc"}
+        extras = {"f64", "refine", "full", "full_easy", "long_scan", "noise", "config3", "stream", "rig", "k0", "dropin", "pmc", "cameras"}
     elif args.extras == "none":
         extras = set()
     else:
@@ -463,7 +498,7 @@ def main() -> None:
 
     B = args.batch
     t_gen = time.time()
-    W = Workload(args.workload, B, dev, rank, noise=args.noise)
+    W = Workload(args.workload, B, dev, rank, noise=args.noise, cam=None if args.camera == "default" else reference_cameras()[args.camera])
     store = W.store
     sia = SparseImgAlign(W.max_level, W.min_level, args.n_iter)
     sia.kernel = args.k1_kernel
@@ -486,10 +521,19 @@ def main() -> None:
             gather.submit(k)
         gather.drain()
     full = FullTrack(W, dev, rank) if args.pipeline == "full" else None
+    refine = RefineStep(W, sia, dev, rank) if args.pipeline == "refine" else None
+    pos = None
+    if refine is not None:
+        # the step's result is the REFINED pose: with N > 1 that is what the ranks exchange
+        pos = [refine.alloc_result(gather._local[k] if gather is not None else None) for k in range(len(outs))]
+        if gather is not None:
+            for o in outs:  # (K1's relative pose stays local)
+                o.T_cur_from_ref = torch.empty(B, 12, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
 
     marks = []
+    marks4 = []
     graph = None
     counter = [0]
 
@@ -500,8 +544,13 @@ def main() -> None:
             gather.local(counter[0] if len(outs) > 1 else 0)  # waits for the gather that last read this buffer
         e0 = ev.mark() if timed else None
         W.run_align(sia, out=o)
+        e1 = ev.mark() if timed else None
         if timed:
-            marks.append((e0, ev.mark()))
+            marks.append((e0, e1))
+        if refine is not None:
+            refine.run(o.T_cur_from_ref, pos[k])
+            if timed:
+                marks4.append((e1, ev.mark()))
         if full is not None:
             full.step(o.T_cur_from_ref, ev if timed else None)
 
@@ -580,6 +629,13 @@ def main() -> None:
     out = outs[(counter[0] - 1) % len(outs)]  # the result block of the last step
     st = W.align_stats(out)
     iters, n_tracked, alg_bytes = st["iters"], st["n_tracked"], st["alg_bytes"]
+    k4_ms = float(np.mean([ev.ms(a, b) for a, b in marks4])) if marks4 else None
+    po_last = pos[(counter[0] - 1) % len(outs)] if refine is not None else None
+    workload_name = args.workload
+    if full is not None:
+        workload_name = args.workload.replace("sparse_align", "full_track")
+    elif refine is not None:
+        workload_name = args.workload.replace("sparse_align", "sparse_align_plus_pose_refine")
 
     result = {
         "metric": "frames/sec sparse-align+pose-refine (VGA, 4 pyr lvls); ATE vs CPU ref",
@@ -592,19 +648,25 @@ def main() -> None:
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        # what the arithmetic of K1 is carried out in (the reference: f32 pixels / chi2, f64 everything else)
-        "dtype": "f32 pixels, residuals, chi2 and per-pixel Jacobian products (16-term patch sums); f64 projection, per-patch "
+        # what the arithmetic is carried out in (the reference: f32 pixels / chi2, f64 everything else).  `value` is the DEFAULT
+        # build's; the same step on the build that is f64 wherever the reference is: roofline_f64_build.value
+        "dtype": ("K1: " if refine is not None else "") +
+                 "f32 pixels, residuals, chi2 and per-pixel Jacobian products (16-term patch sums); f64 projection, per-patch "
                  "Jacobian rows, per-lane Jres/H partials (tree-reduced per wave; reference: sequential), cross-wave sums, 6x6 "
                  "solve and pose; f32 series for SE3::exp (reference: f64 sin/cos) -- see f64_partials / roofline_f64_build for "
-                 "the build that is f64 throughout",
-        "dtype_short": "f32 pixels/residuals/chi2/per-pixel products, f64 Jacobian rows/partials/reductions/projection/solve/pose",
+                 "the build that is f64 throughout" + ("; K4 (pose refine): f64 throughout, Tukey weight / MAD scale in f32 as vikit has them" if refine is not None else ""),
+        "dtype_short": ("value = default build: K1 f32 pixels/residuals/chi2/per-pixel products, f64 Jacobian rows/partials/reductions/"
+                        "projection/solve/pose; K4 f64 (reference-width build: roofline_f64_build.value)" if refine is not None else
+                        "f32 pixels/residuals/chi2/per-pixel products, f64 Jacobian rows/partials/reductions/projection/solve/pose"),
         "data": "synthetic",
         "config": {
-            "workload": args.workload if full is None else args.workload.replace("sparse_align", "full_track"),
+            "workload": workload_name,
             "image": f"{W.width}x{W.height}", "pyr_levels": W.n_levels,
             "schedule": f"levels {W.max_level}->{W.min_level}", "patches_per_frame": W.n_patches,
             "frames_per_step_per_gpu": B, "n_iter_cap": args.n_iter, "image_noise_sigma": args.noise,
             "timed_region": "svo_hip_sparse_align (SparseImgAlign::run incl. its Gauss-Newton pose solve) over the batch"
+                            + (" + svo_hip_compose_poses + svo_hip_pose_optimize (pose_optimizer::optimizeGaussNewton from K1's pose of the "
+                               "same step, on the matches K2 / K3 produced for these frames in set-up)" if refine is not None else "")
                             + (" + the rest of the track" if full is not None else "")
                             + (" + RCCL all_gather of the poses" if use_dist else ""),
             "parallelism": f"frames sharded 1 rank/GPU x{world}" + (", RCCL all_gather of poses, double-buffered and overlapped with the next step" if use_dist else ""),
@@ -619,12 +681,27 @@ def main() -> None:
         },
         "roofline": roofline(("sia_wave_kernel" if args.k1_kernel == "auto" and W.n_patches <= 192 and B >= 1024 else "sia_kernel") + " (svo_hip_sparse_align)", alg_bytes, kernel_ms, traffic=None, kernel_ms_avg=kernel_ms,
                              algorithmic_bytes_per_frame=alg_bytes / B,
+                             frac_uses="kernel_ms_avg: HIP events on the launch stream around every timed launch of the kernel, averaged "
+                                       "(the launches sit inside the clock ramp of a fresh process; ms_last_10_launches is the settled figure)",
                              ms_last_10_launches=float(np.mean([ev.ms(a, b) for a, b in marks[-10:]])) if marks else None,
                              # iterations/s and per-iteration time of the batch
                              gn_iterations_per_s=float(iters.sum()) / (kernel_ms * 1e-3),
                              us_per_gn_iteration_of_the_batch=kernel_ms * 1e3 / max(float(iters.sum(1).mean()), 1e-9)),
         "setup_s": t_gen,
     }
+    if refine is not None:
+        T_ref_w = po_last.T_f_w.cpu().numpy()
+        result["stages_ms"] = {"sparse_align": kernel_ms, "compose_plus_pose_optimize": k4_ms}
+        # configs[1] read literally ("SparseImgAlign only"): the same launches, K1 on its own
+        result["value_sparse_align_only"] = world * B / (kernel_ms * 1e-3)
+        result["config"].update(
+            matches="K2 / K3 output of the representative full-track workload for the same frames (set-up, untimed)",
+            match_trials_per_frame=refine.trials_per_frame, matches_per_frame=refine.matches_per_frame,
+            pose_refine_obs_after_pruning=float(po_last.stats[:, 3].mean().item()),
+            median_pose_error_vs_gt_after_refine=float(np.median(se3.log_norm(T_ref_w, W.T_gt[1:B + 1]))))
+        result["roofline_pose_optimize"] = roofline("compose_kernel + pose_opt_wave_kernel (svo_hip_pose_optimize)",
+                                                    refine.algorithmic_bytes(), k4_ms,
+                                                    algorithmic_bytes_per_frame=refine.algorithmic_bytes() / B)
     if args.dump_result:
         np.savez(args.dump_result, T_est_w=st["T_est_w"], iters=out.iters.cpu().numpy())
     if args.pmc_child:  # child of the PMC leg: nothing else is needed from this process
@@ -637,14 +714,14 @@ def main() -> None:
     mute.__enter__()
     try:
         _extras_and_print(args, result, extras, full, ev, W, sia, out, st, store, lib, dev, rank, world, use_dist, dist,
-                          gather_stats, rig, kernel_ms, alg_bytes, B)
+                          gather_stats, rig, kernel_ms, alg_bytes, B, refine, po_last)
     except BaseException:
         mute.__exit__()
         raise
 
 
 def _extras_and_print(args, result, extras, full, ev, W, sia, out, st, store, lib, dev, rank, world, use_dist, dist,
-                      gather_stats, rig, kernel_ms, alg_bytes, B) -> None:
+                      gather_stats, rig, kernel_ms, alg_bytes, B, refine=None, po_last=None) -> None:
     if full is not None:
         d = full.describe()
         d.pop("_T_refined")
@@ -673,7 +750,7 @@ def _extras_and_print(args, result, extras, full, ev, W, sia, out, st, store, li
 
     if not args.no_cpu_baseline and world == 1:
         try:
-            result["cpu_baseline"] = cpu_baseline(args, W, st["T_est_w"], result, out.iters.cpu().numpy())
+            result["cpu_baseline"] = cpu_baseline(args, W, st["T_est_w"], result, out.iters.cpu().numpy(), refine, po_last)
         except Exception as e:
             result["cpu_baseline"] = {"skipped": repr(e)}
     leg("f64", lambda: f64_partials_leg(args, st["T_est_w"], out.iters.cpu().numpy(), result))
@@ -687,6 +764,7 @@ def _extras_and_print(args, result, extras, full, ev, W, sia, out, st, store, li
     leg("config3", lambda: config3_leg(ev, dev, rank, args.n_iter, not args.no_cpu_baseline))
     leg("stream", lambda: stream_replay_leg(W, sia, ev, dev))
     leg("dropin", dropin_sequence)   # (before the counter passes, which are what gives way to --time-budget)
+    leg("cameras", lambda: reference_cameras_leg(args, ev, dev, rank, lib))
     if "pmc" in extras:
         t = time.time()
         want_full = "full" in extras and isinstance(result.get("full_track"), dict) and "rooflines" in result["full_track"]
@@ -816,6 +894,52 @@ def refine_inputs(W: Workload, dev, rank: int, px_sigma: float = 0.3):
     level = torch.zeros(B, N, dtype=torch.int32, device=dev)
     has = torch.ones(B, N, dtype=torch.uint8, device=dev)
     return f_cur, level, has
+
+
+class RefineStep:
+    """The metric as it is worded -- "sparse-align + pose-refine" -- as the timed step: K1 (SparseImgAlign::run) followed
+    by pose_optimizer::optimizeGaussNewton (K4) started from K1's pose of the same step (frame_handler_mono.cpp:137-165).
+    K4's observations are the matches the pipeline itself produces for these frames: in set-up (untimed) the
+    representative full-track workload (FullTrack) runs K1 -> Reprojector::reprojectPoint -> Matcher::findMatchDirect
+    (K2 + K3) -> cam2world once; what it matched (~170 of ~200 trials per frame, 35 % of the points with grossly wrong
+    depth, refined pixels off by what alignment leaves) is what every timed step refines on -- not synthetic matches at
+    the true projection."""
+
+    def __init__(self, W: Workload, sia, dev, rank: int):
+        from rpg_svo_amd import tracking as tr
+        self.tr, self.W, self.dev = tr, W, dev
+        B, N = W.B, W.n_patches
+        full = FullTrack(W, dev, rank, with_seeds=False)
+        out = sia.alloc_result(B, dev)
+        W.run_align(sia, out=out)
+        m, _ = full.match_stage(out.T_cur_from_ref)
+        torch.cuda.synchronize()
+        self.f_new = full.f_new.view(B, N, 3)
+        self.level = m.search_level.view(B, N).clone()
+        self.okb = full.okb.clone()
+        self.pt_pos = full.pt_pos.view(B, N, 3)
+        self.n, self.T_ref = full.n, full.T_ref
+        self.T_cur = torch.empty(B, 12, dtype=torch.float64, device=dev)
+        self.trials_per_frame = float(full.in_cur.float().sum().item() / B)
+        self.matches_per_frame = float(self.okb.float().sum().item() / B)
+        self.n_obs = float(self.okb.float().sum().item())
+        del full, out, m
+        torch.cuda.empty_cache()
+
+    def alloc_result(self, T_f_w: torch.Tensor | None = None):
+        B, N, dev = self.W.B, self.W.n_patches, self.dev
+        return self.tr.PoseOptResult(torch.empty(B, 12, dtype=torch.float64, device=dev) if T_f_w is None else T_f_w,
+                                     torch.zeros(B, 36, dtype=torch.float64, device=dev), torch.zeros(B, 4, dtype=torch.float64, device=dev),
+                                     torch.zeros(B, dtype=torch.int32, device=dev), torch.empty(B, N, dtype=torch.uint8, device=dev))
+
+    def run(self, T_cur_from_ref, po):
+        tr = self.tr
+        tr.compose_poses(T_cur_from_ref, self.T_ref, out=self.T_cur)
+        tr.optimize_gauss_newton(self.W.cam, self.n, self.f_new, self.level, self.pt_pos, self.okb, self.T_cur, 2.0, 10, out=po)
+
+    def algorithmic_bytes(self) -> float:
+        """52 B per observation (f, level, pos) + the flag byte of every slot + 416 B of pose / covariance / stats"""
+        return self.n_obs * 52.0 + self.W.B * (self.W.n_patches * 1.0 + 416.0)
 
 
 def align_plus_refine(W: Workload, sia, ev: Events, dev, steps: int) -> dict:
@@ -1117,7 +1241,8 @@ def pmc_leg(args, kernel_ms: float, reserve_s: float = 0.0, only: tuple | None =
         return {"skipped": "rocprofv3 not on PATH"}
     base = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--batch", str(args.batch),
             "--workload", args.workload, "--noise", str(args.noise), "--n-iter", str(args.n_iter), "--no-cpu-baseline",
-            "--extras", "none", "--pmc-child", "1", "--k1-kernel", k1_kernel or args.k1_kernel]
+            "--extras", "none", "--pmc-child", "1", "--k1-kernel", k1_kernel or args.k1_kernel, "--pipeline", "align",
+            "--camera", getattr(args, "camera", "default")]
     passes = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
               "sq": ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
                      "SQ_INSTS_VALU", "SQ_BUSY_CU_CYCLES"],
@@ -1572,11 +1697,96 @@ def dropin_sequence(n_frames: int = 600) -> dict:
             "pyramid_uploads": host.get("uploads"), "pyramid_upload_us_per_frame": host.get("pyramid_upload_us_total", 0.0) / max(1, n_frames - 1)}
 
 
-def dropin_hip_only(n_frames: int, dump: str) -> dict:
+def reference_cameras_leg(args, ev: Events, dev, rank: int, lib, B: int = 4096, dropin_frames: int = 300) -> dict:
+    """the camera models the reference actually ships (svo_ros/param/camera_atan.yaml, camera_pinhole.yaml:
+    both distorted) next to the undistorted pinhole every other number is measured on.  Per camera, on 752x480 images rendered
+    through the model: K1 at configs[1]'s shape (4 levels 3 -> 0, 200 patches; B frames), the representative full-track step
+    (configs[2]) and the single-stream drop-in (hip flavour, `dropin_frames` frames, a child process), with K1's counter
+    traffic from two rocprofv3 --pmc children while the time budget lasts."""
+    out = {"frames_per_step": B, "image": "752x480", "workload": "ref752_4_n200_sparse_align", "cameras": {}}
+    cams = reference_cameras()
+    for name, cam in cams.items():
+        if time_left(args.time_budget) < 25.0:
+            out["cameras"][name] = {"skipped": "time budget"}
+            continue
+        r = {}
+        try:
+            W = Workload("ref752_4_n200_sparse_align", B, dev, rank, cam=cam)
+            sia = SparseImgAlign(W.max_level, W.min_level, args.n_iter)
+            sia.kernel = "workgroup"
+            o = sia.alloc_result(B, dev)
+            ms = ev.time(lambda: W.run_align(sia, out=o), 10, warmup=3)
+            torch.cuda.synchronize()
+            st = W.align_stats(o)
+            r["sparse_align"] = {"frames_per_s": B / ms * 1e3, "ms_per_step": ms,
+                                 "mean_gn_iterations_per_frame": float(st["iters"].sum(1).mean()),
+                                 "mean_tracked_patches": float(st["n_tracked"].mean()),
+                                 "median_pose_error_vs_gt": float(np.median(st["gt_err"])),
+                                 "roofline": _pick(roofline("sia_kernel", st["alg_bytes"], ms), ("achieved", "frac", "ms", "algorithmic_bytes_per_launch"))}
+            full = FullTrack(W, dev, rank)
+            marks = []
+            for i in range(4):
+                e0 = ev.mark()
+                W.run_align(sia, out=o)
+                full.step(o.T_cur_from_ref, ev if i > 0 else None)
+                marks.append((e0, ev.mark()))
+            torch.cuda.synchronize()
+            stages = full.stage_ms(ev)
+            d = full.describe()
+            T_ref = d.pop("_T_refined")
+            r["full_track"] = {"ms_per_step": float(np.mean([ev.ms(a, b) for a, b in marks[1:]])), "stages_ms": stages,
+                               "matches_per_frame": d["matches_per_frame"], "seeds_per_frame": d["seeds_per_frame"],
+                               "seed_status_per_frame": d["seed_status_per_frame"],
+                               "median_pose_error_vs_gt_after_refine": float(np.median(se3.log_norm(T_ref, W.T_gt[1:B + 1])))}
+            r["full_track"]["frames_per_s"] = B / r["full_track"]["ms_per_step"] * 1e3
+            del full, W, o
+            torch.cuda.empty_cache()
+        except Exception as e:
+            r["skipped"] = repr(e)
+        out["cameras"][name] = r
+    # the single-stream drop-in per camera (children: the device context is per process and camera)
+    for name in cams:
+        if time_left(args.time_budget) < 20.0 or "skipped" in out["cameras"].get(name, {}):
+            continue
+        try:
+            code = (f"import sys, json; sys.path.insert(0, {ROOT!r}); import bench; "
+                    f"print(json.dumps(bench.dropin_hip_only({dropin_frames}, '', camera={name!r})))")
+            p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+            out["cameras"][name]["dropin"] = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else {"skipped": p.stderr[-300:]}
+        except Exception as e:
+            out["cameras"][name]["dropin"] = {"skipped": repr(e)}
+    # K1's counter traffic per camera
+    for name in cams:
+        sa = out["cameras"].get(name, {}).get("sparse_align")
+        if not sa or time_left(args.time_budget) < 2 * PMC_PASS_RESERVE_S:
+            continue
+        try:
+            import copy
+            a2 = copy.copy(args)
+            a2.camera, a2.workload, a2.batch, a2.noise = name, "ref752_4_n200_sparse_align", B, 0.0
+            pm = pmc_leg(a2, sa["ms_per_step"], only=("fetch", "write"), k1_kernel="workgroup")
+            if pm.get("traffic_bytes_per_launch"):
+                sa["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
+                sa["roofline"]["traffic_over_algorithmic"] = pm["traffic_bytes_per_launch"] / sa["roofline"]["algorithmic_bytes_per_launch"]
+            else:
+                sa["roofline"]["traffic"] = None
+                sa["roofline"]["pmc_passes"] = pm.get("passes", pm.get("skipped"))
+        except Exception as e:
+            sa["roofline"]["traffic"] = None
+            sa["roofline"]["pmc_passes"] = repr(e)
+    ref = out["cameras"].get("pinhole_undistorted", {}).get("sparse_align", {}).get("ms_per_step")
+    if ref:
+        for name, r in out["cameras"].items():
+            if isinstance(r.get("sparse_align"), dict):
+                r["sparse_align"]["ms_over_undistorted_pinhole"] = r["sparse_align"]["ms_per_step"] / ref
+    return out
+
+
+def dropin_hip_only(n_frames: int, dump: str, camera: str | None = None) -> dict:
     """child of dropin_sequence (one process per SVO_HIP_MAP_MIRROR mode: the mode is read once): the hip flavour alone"""
     sys.path.insert(0, os.path.join(ROOT, "tests", "dropin"))
     import pypipeline as pp
-    cam = synth.Camera(752, 480, 315.5, 315.5, 376.0, 240.0)
+    cam = synth.Camera(752, 480, 315.5, 315.5, 376.0, 240.0) if camera is None else reference_cameras()[camera]
     T = synth.make_trajectory(n_frames, seed=5, max_step=0.02, max_rot_deg=0.3)
     imgs = synth.render(synth.make_texture(seed=12345), T, cam, device="cuda" if torch.cuda.is_available() else "cpu").cpu().numpy()
     devnull = os.open(os.devnull, os.O_WRONLY)
@@ -1584,8 +1794,16 @@ def dropin_hip_only(n_frames: int, dump: str) -> dict:
     pp.run_sequence("hip", cam, imgs[:10], T[:10])
     st = {}
     hip = pp.run_sequence("hip", cam, imgs, T, stats_out=st)
-    np.save(dump, np.stack([r["T_f_w"] for r in hip]))
+    if dump:
+        np.save(dump, np.stack([r["T_f_w"] for r in hip]))
     med = lambda k: float(np.median([r[k] for r in hip[1:]]) * 1e3)
+    if camera is not None:  # reference_cameras_leg: the frame's time by API call, the accuracy, the map the run built
+        pos = lambda TT: se3.inv(TT)[:, 9:]
+        return {"frames": n_frames, "tot_time": med("t_tot_time"), "sparse_img_align": med("t_sparse_img_align"),
+                "reproject": med("t_reproject"), "pose_optimizer": med("t_pose_optimizer"),
+                "ate_rmse_vs_ground_truth_m": horn_ate(pos(np.stack([r["T_f_w"] for r in hip])), pos(T)),
+                "keyframes": int(sum(r["is_keyframe"] for r in hip)), "matches": float(np.median([r["repr_n_new_references"] for r in hip[1:]])),
+                "stage_default_frame_frac": float(np.mean([r["stage"] == pp.STAGE_DEFAULT_FRAME for r in hip[1:]]))}
     return {"tot_time": med("t_tot_time"), "reproject": med("t_reproject"), "map_mirror": st.get("map_mirror")}
 
 
@@ -1619,6 +1837,8 @@ def f64_partials_leg(args, T_default, iters_default, result) -> dict:
     out = {"build": "-DSIA_F64_PARTIALS: f64 Jacobian rows, per-pixel products, per-lane partials, wave reductions and SE3::exp "
                     "(142 VGPRs, 3 waves/SIMD instead of 128 / 4)",
            "frames_per_s": child["value"], "kernel_ms": child["roofline"]["ms"],
+           "frames_per_s_sparse_align_only": child.get("value_sparse_align_only"),
+           "what_frames_per_s_is": "the headline step (K1 + K4 when --pipeline refine) on the reference-width library",
            "frames_per_s_default": result["value"], "kernel_ms_default": result["roofline"]["ms"],
            "slowdown": result["value"] / child["value"],
            "vs_default_kernel": {"se3_lognorm_max": float(se3.log_norm(T64, T_default).max()),
@@ -1646,7 +1866,34 @@ def f64_partials_leg(args, T_default, iters_default, result) -> dict:
     return out
 
 
-def cpu_baseline(args, W: Workload, T_est_w, result, iters_gpu) -> dict:
+def cpu_pose_refine(W: Workload, refine, T_start_w: np.ndarray, which: str, k: int):
+    """pose_optimizer::optimizeGaussNewton of the reference (oracle/_ref; the C port where it is absent) on the first k
+    frames of the headline step, one thread, from the CPU's own K1 poses, on the matches the timed step refines on.
+    Only the calls themselves are timed (arguments converted beforehand)."""
+    from oracle import pytrack
+    trk = pytrack.Track("ref" if which.startswith("ref") and pytrack.ref_available() else "orc")
+    pc = pytrack.make_cam(W.cam)
+    f = refine.f_new[:k].cpu().numpy()
+    lv = refine.level[:k].cpu().numpy().astype(np.int32)
+    ok = refine.okb[:k].cpu().numpy().astype(np.uint8)
+    pos = refine.pt_pos[:k].cpu().numpy()
+    N = f.shape[1]
+    T_out = np.zeros((k, 12))
+    seconds = 0.0
+    for b in range(k):
+        fb, lb, hb, pb = np.ascontiguousarray(f[b]), np.ascontiguousarray(lv[b]), ok[b].copy(), np.ascontiguousarray(pos[b])
+        Tb = np.ascontiguousarray(T_start_w[b], dtype=np.float64)
+        res = pytrack.PoseOptResult()
+        call = (C.c_double(2.0), C.c_int(10), C.byref(pc), Tb.ctypes.data_as(C.c_void_p), C.c_int(N), fb.ctypes.data_as(C.c_void_p),
+                lb.ctypes.data_as(C.c_void_p), hb.ctypes.data_as(C.c_void_p), pb.ctypes.data_as(C.c_void_p), C.byref(res))
+        t0 = time.perf_counter()
+        trk._pose_optimize(*call)
+        seconds += time.perf_counter() - t0
+        T_out[b] = np.array(res.T_f_w[:])
+    return T_out, seconds
+
+
+def cpu_baseline(args, W: Workload, T_est_w, result, iters_gpu, refine=None, po_last=None) -> dict:
     """Times the reference's own SparseImgAlign translation unit (oracle/_ref, kind "reference";
     the C port where that library is absent) on a bounded sample of the same problems, on this
     box's host cores, and fills result["parity"] from the same run."""
@@ -1721,9 +1968,29 @@ def cpu_baseline(args, W: Workload, T_est_w, result, iters_gpu) -> dict:
             release = {"value_release_flags": None, "release_flags_skipped": repr(e)}
     # headline: ONE core, the reference's own execution model (tracking is single-threaded, frame_handler_mono.cpp);
     # the thread sweep over frame pairs is the throughput comparison for batched replay and sits beside it
-    return {**release, "value": s1 / t1, "unit": "frames/s", "cores": 1, "kind": "reference" if which == "ref" else "port",
-            "sample": f"{s1} of the benchmark's own frame pairs on one thread, {impl}",
-            "sample_short": f"{s1} of the same frame pairs, 1 thread, " + ("reference's own sparse_img_align.cpp" if which == "ref" else "C port"),
+    value, k4 = s1 / t1, {}
+    if refine is not None:
+        # the step the headline times is K1 + K4: the reference's pose_optimizer.cpp on the same sample, same thread
+        try:
+            T_ref4, t4 = cpu_pose_refine(W, refine, T_cpu, which, s1)
+            value = s1 / (t1 + t4)
+            k4 = {"value_sparse_align_only": s1 / t1, "pose_optimize_us_per_frame": t4 / s1 * 1e6,
+                  "sparse_align_us_per_frame": t1 / s1 * 1e6}
+            if po_last is not None:
+                d4 = se3.log_norm(po_last.T_f_w[:s1].cpu().numpy(), T_ref4)
+                result["parity"].update(refined_pose_se3_lognorm_max=float(d4.max()), refined_pose_se3_lognorm_median=float(np.median(d4)),
+                                        refined_frames_compared=int(s1))
+            if release.get("value_release_flags"):
+                # (K4 stays the bit-comparable build's: the release library holds SparseImgAlign only)
+                release["value_release_flags_sparse_align_only"] = release["value_release_flags"]
+                release["value_release_flags"] = s1 / (s1 / release["value_release_flags"] + t4)
+        except Exception as e:
+            k4 = {"pose_optimize_skipped": repr(e)}
+    step = "run() + optimizeGaussNewton() calls" if refine is not None and "pose_optimize_us_per_frame" in k4 else "run() calls"
+    return {**release, **k4, "value": value, "unit": "frames/s", "cores": 1, "kind": "reference" if which == "ref" else "port",
+            "sample": f"{s1} of the benchmark's own frame pairs on one thread, {impl}".replace("run() calls", step),
+            "sample_short": f"{s1} of the same frame pairs, 1 thread, " + ("reference's own sparse_img_align.cpp" if which == "ref" else "C port")
+                            + (" + pose_optimizer.cpp" if "pose_optimize_us_per_frame" in k4 else ""),
             "value_best_threads": best_rate, "best_threads": best_threads,
             "sample_threads": f"{S} frame pairs over all / half / a quarter of the logical CPUs",
             "frames_per_s_by_threads": sweep, "host_logical_cpus": cores, "cpu_model": model}
@@ -1765,7 +2032,7 @@ class FullTrack:
     SEED_AGES_UNMATCHED = 30  # unmatched seeds: every search failed so far; kept for three keyframe batches
     SEEDS_UNMATCHED = 14      # ... of them per frame (30 % of the new seeds)
 
-    def __init__(self, W: Workload, dev, rank, mode: str = "representative"):
+    def __init__(self, W: Workload, dev, rank, mode: str = "representative", with_seeds: bool = True):
         from rpg_svo_amd import tracking
         assert mode in ("representative", "easy")
         self.tr = tracking
@@ -1792,9 +2059,9 @@ class FullTrack:
         b_idx = torch.arange(B, device=dev)
         centre = lambda rows: -(T[rows, :9].reshape(-1, 3, 3).transpose(1, 2) @ T[rows, 9:, None])[..., 0]
 
-        def project(rows, pts):  # pts [B,N,3] into frames `rows` [B]: pixels, depth
+        def project(rows, pts):  # pts [B,N,3] into frames `rows` [B]: pixels (through the camera's model), depth
             pc = (T[rows, :9].reshape(-1, 3, 3)[:, None] @ pts[..., None])[..., 0] + T[rows, None, 9:]
-            return torch.stack([cam.fx * pc[..., 0] / pc[..., 2] + cam.cx, cam.fy * pc[..., 1] / pc[..., 2] + cam.cy], -1), pc[..., 2]
+            return torch.stack(synth.cam_distort(cam, pc[..., 0] / pc[..., 2], pc[..., 1] / pc[..., 2]), -1), pc[..., 2]
 
         def inside(px, z, border):
             return (z > 0) & (px[..., 0] >= border) & (px[..., 0] < cam.width - border) & (px[..., 1] >= border) & (px[..., 1] < cam.height - border)
@@ -1842,7 +2109,7 @@ class FullTrack:
         sec = ptr[:-1].long()[has2.reshape(M)] + 1
         o_frame[sec] = older.repeat_interleave(N)[has2.reshape(M)].to(torch.int32)
         o_px[sec] = px2.reshape(M, 2)[has2.reshape(M)]
-        d2 = torch.stack([(o_px[sec][:, 0] - cam.cx) / cam.fx, (o_px[sec][:, 1] - cam.cy) / cam.fy,
+        d2 = torch.stack([*synth.cam_undistort(cam, o_px[sec][:, 0], o_px[sec][:, 1]),
                           torch.ones(len(sec), dtype=torch.float64, device=dev)], -1)
         o_f[sec] = d2 / d2.norm(dim=-1, keepdim=True)
         self.obs_ptr = ptr
@@ -1851,6 +2118,16 @@ class FullTrack:
         self.matcher = tracking.Matcher(align_max_iter=10, n_pyr_levels=W.n_levels)
         self.n = torch.full((B,), N, dtype=torch.int32, device=dev)
         self.df = tracking.DepthFilter(n_pyr_levels=W.n_levels)
+        self.f_new = torch.empty(M, 3, dtype=torch.float64, device=dev)
+        # result blocks reused by every step (no allocation / memset inside the timed stages)
+        self.cell_px = (torch.zeros(M, dtype=torch.int32, device=dev), torch.zeros(M, 2, dtype=torch.float64, device=dev))
+        self.match = self.matcher.alloc_result(M, dev)
+        self.okb = torch.zeros(B, N, dtype=torch.uint8, device=dev)
+        self.events = []
+        self.last = {}
+        self.S = 0
+        if not with_seeds:  # the headline's set-up (RefineStep): only the matcher's stages are run
+            return
         # ---- seeds ---------------------------------------------------------------------------------
         if mode == "easy":
             # one per reference feature, inverse depth known to 10 %, range from 0.6 x depth
@@ -1872,11 +2149,6 @@ class FullTrack:
         self.S = S
         self.seeds = tracking.SeedSet(**{k: v.clone() for k, v in self.seed0.items()},
                                       batch_id=torch.zeros(S, dtype=torch.int32, device=dev))
-        self.f_new = torch.empty(M, 3, dtype=torch.float64, device=dev)
-        # result blocks reused by every step (no allocation / memset inside the timed stages)
-        self.cell_px = (torch.zeros(M, dtype=torch.int32, device=dev), torch.zeros(M, 2, dtype=torch.float64, device=dev))
-        self.match = self.matcher.alloc_result(M, dev)
-        self.okb = torch.zeros(B, N, dtype=torch.uint8, device=dev)
         self.po = tracking.PoseOptResult(torch.empty(B, 12, dtype=torch.float64, device=dev),
                                          torch.zeros(B, 36, dtype=torch.float64, device=dev),
                                          torch.zeros(B, 4, dtype=torch.float64, device=dev),
@@ -1884,8 +2156,6 @@ class FullTrack:
                                          torch.empty(B, N, dtype=torch.uint8, device=dev))
         self.seed_out = (torch.zeros(S, dtype=torch.int32, device=dev), torch.zeros(S, 3, dtype=torch.float64, device=dev),
                          torch.zeros(S, 2, dtype=torch.float64, device=dev))
-        self.events = []
-        self.last = {}
 
     def _make_seed_population(self, T, g):
         """Seeds as the depth filter holds them while frame b+1 arrives: created at frames b, b-1, ... (ages 1, 2, ...)
@@ -1959,11 +2229,11 @@ class FullTrack:
         self.seed_frame_of = cat(part_b)
         self.seed_unmatched = cat(part_kind)
 
-    def step(self, T_cur_from_ref, ev: Events | None):
+    def match_stage(self, T_cur_from_ref, mk=lambda: None):
+        """K1's pose -> compose -> Reprojector::reprojectPoint -> Matcher::findMatchDirect (K2 + K3) -> cam2world: the
+        observations pose_optimizer::optimizeGaussNewton reads (f_new, search_level, okb)"""
         tr = self.tr
         B, N = self.B, self.N
-        mk = (lambda: self.events.append(ev.mark())) if ev is not None else (lambda: None)
-        mk()
         tr.compose_poses(T_cur_from_ref, self.T_ref, out=self.frame_T, out_index=self.cur_rows)
         mk()
         cell, px = tr.reproject_points(self.cam, self.frames, self.cur_frame, self.pt_pos, 30, (self.cam.width + 29) // 30,
@@ -1975,6 +2245,14 @@ class FullTrack:
         tr.cam2world(self.cam, m.px_cur, out=self.f_new)
         mk()
         torch.gt(m.ok.view(B, N), 0, out=self.okb.view(torch.bool))
+        return m, px
+
+    def step(self, T_cur_from_ref, ev: Events | None):
+        tr = self.tr
+        B, N = self.B, self.N
+        mk = (lambda: self.events.append(ev.mark())) if ev is not None else (lambda: None)
+        mk()
+        m, px = self.match_stage(T_cur_from_ref, mk)
         po = tr.optimize_gauss_newton(self.cam, self.n, self.f_new.view(B, N, 3), m.search_level.view(B, N),
                                       self.pt_pos.view(B, N, 3), self.okb, self.frame_T[B + 1:], 2.0, 10, out=self.po)
         self.frame_T[B + 1:].copy_(po.T_f_w)  # the mapper sees the refined pose (frame_handler_mono.cpp:190,221)

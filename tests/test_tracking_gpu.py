@@ -528,6 +528,7 @@ def test_update_seeds(gpu_device, orc, scene, pyrs, align_1d, subpix):
     a, b, mu, s2 = (t.cpu().numpy() for t in (ss.a, ss.b, ss.mu, ss.sigma2))
     hist = {}
     ab_dev = []
+    s2_dev = []  # measured deviation of sigma2: relative, and in units of float eps * mu^2
     for i in range(S):
         st = io[i].status
         hist[st] = hist.get(st, 0) + 1
@@ -551,6 +552,7 @@ def test_update_seeds(gpu_device, orc, scene, pyrs, align_1d, subpix):
             # C1*(s2+m^2) + C2*(sigma2+mu^2) - mu_new^2 in float, i.e. it carries an absolute
             # rounding noise of ~eps*mu^2 whatever its size; a and b come from (e-f)/(f-e/f).
             assert np.isclose(mu[i], so[i].mu, rtol=2e-6, atol=0), (i, mu[i], so[i].mu)
+            s2_dev.append((abs(float(s2[i]) - so[i].sigma2) / abs(so[i].sigma2), abs(float(s2[i]) - so[i].sigma2) / (6e-8 * so[i].mu ** 2)))
             assert abs(float(s2[i]) - so[i].sigma2) <= 1e-4 * abs(so[i].sigma2) + 1e-6 * so[i].mu ** 2, (i, s2[i], so[i].sigma2)
             if ab_known:
                 ab_dev.append(max(abs(float(a[i]) - so[i].a) / abs(so[i].a), abs(float(b[i]) - so[i].b) / abs(so[i].b)))
@@ -561,7 +563,8 @@ def test_update_seeds(gpu_device, orc, scene, pyrs, align_1d, subpix):
         if st == pytrack.SEED_CONVERGED:
             assert np.abs(xyz[i] - np.array(io[i].xyz_world[:])).max() < 1e-5
     print(f"update_seeds[{orc.which}, align_1d={align_1d}, subpix={subpix}]: max relative deviation of a / b over "
-          f"{len(ab_dev)} compared seeds = {max(ab_dev):.3e}")
+          f"{len(ab_dev)} compared seeds = {max(ab_dev):.3e}; sigma2: max relative {max(x[0] for x in s2_dev):.3e}, "
+          f"max in units of eps32 * mu^2 {max(x[1] for x in s2_dev):.2f}")
     assert hist.get(pytrack.SEED_UPDATED, 0) > 50 and hist.get(pytrack.SEED_CONVERGED, 0) > 2
     assert hist.get(pytrack.SEED_ERASED_OLD, 0) > 5 and hist.get(pytrack.SEED_BEHIND if orc.which == "orc" else 0, 0) > 2
 
