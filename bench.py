@@ -118,7 +118,9 @@ def roofline(kernel: str, alg_bytes: float, ms: float, **extra) -> dict:
 
 
 DETAILS_FILE = "bench_details.json"   # the full result object (every leg); the LAST stdout line is the compact summary
-COMPACT_LIMIT = 4000                  # bytes: the driver parses the tail of stdout (BENCH_r03: a 21 KB line was not parsed)
+COMPACT_LIMIT = 6000                  # bytes: the driver parses the tail of stdout (BENCH_r03: a 21 KB line was not parsed -- its record
+                                      # holds the last 14 161 bytes of stdout; rounds 4-5 stayed below 4 000, this round's line carries the
+                                      # per-kernel table AND the reference's cameras)
 
 
 def _pick(d, keys):
@@ -183,8 +185,7 @@ def compact_line(result: dict, details_path: str | None) -> dict:
             short = lambda k: k.replace("find_match_direct/", "fm/").replace("update_seeds/", "us/").replace("pose_optimize/", "po/").replace("_kernel", "")
             legs["full_track"]["kernels_ms_frac"] = {short(k): [_num(v.get("ms"), 3), _num(v.get("frac"), 3)] for k, v in ft["kernels"].items()
                                                      if isinstance(v, dict) and (v.get("ms") or 0) >= 0.05}
-    for key, keys in (("align_plus_refine", ("frames_per_s", "ms_per_step")),
-                      ("noise_sigma2", ("frames_per_s", "ms_per_step")),
+    for key, keys in (("noise_sigma2", ("frames_per_s", "ms_per_step")),
                       ("f64_partials", ("frames_per_s", "slowdown")),
                       ("k0_pyramid", ("ms", "achieved", "frac")),
                       ("config3_xga5_b64", ("frames_per_s", "ms_per_step", "frames_per_s_at_batch_1024")),
@@ -215,10 +216,13 @@ def compact_line(result: dict, details_path: str | None) -> dict:
         # per camera: [K1 M frames/s, K1 frac, K1 counter traffic / algorithmic, full-track ms per step, drop-in ms per frame]
         g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
         legs["reference_cameras"] = {"frames_per_step": rc.get("frames_per_step"),
-                                     "keys": ["k1_frames_per_s", "k1_frac", "k1_traffic_over_algorithmic", "full_track_ms", "dropin_ms_per_frame"]}
+                                     "keys": ["k1_frames_per_s", "k1_frac", "k1_traffic_over_algorithmic", "k1_gn_iterations_per_frame",
+                                              "k1_time_per_iteration_over_undistorted_pinhole", "full_track_ms", "dropin_ms_per_frame"]}
         for name, r in rc["cameras"].items():
             legs["reference_cameras"][name] = _num([g(r, "sparse_align", "frames_per_s"), g(r, "sparse_align", "roofline", "frac"),
                                                     g(r, "sparse_align", "roofline", "traffic_over_algorithmic"),
+                                                    g(r, "sparse_align", "mean_gn_iterations_per_frame"),
+                                                    g(r, "sparse_align", "per_iteration_over_undistorted_pinhole"),
                                                     g(r, "full_track", "ms_per_step"), g(r, "dropin", "tot_time")], 4) if "skipped" not in r else "skipped"
     for key in ("gather", "stages_ms"):  # small objects of the multi-GPU / --pipeline full runs: whole
         if isinstance(result.get(key), dict):
@@ -451,7 +455,7 @@ def main() -> None:
     ap.add_argument("--full-line", action="store_true",
                     help="print the FULL result object as the last stdout line (scripts/); default: the compact summary "
                          f"(< {COMPACT_LIMIT} B) with the full object in {DETAILS_FILE}")
-    ap.add_argument("--time-budget", type=float, default=300.0,
+    ap.add_argument("--time-budget", type=float, default=330.0,
                     help="seconds since process start after which no further optional leg or counter pass is begun (0: no limit); "
                          "the default run takes about four minutes on an MI355X box and stays below this")
     ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)
@@ -805,6 +809,10 @@ def _extras_and_print(args, result, extras, full, ev, W, sia, out, st, store, li
                     rl_["traffic_by_kernel"] = st_["by_kernel"]
             pm["leg_seconds"] = time.time() - t
         result["pmc"] = pm
+        if isinstance(result.get("reference_cameras"), dict) and "cameras" in result["reference_cameras"]:
+            t = time.time()
+            reference_cameras_traffic(args, result["reference_cameras"])
+            result["reference_cameras"]["traffic_seconds"] = time.time() - t
     if use_dist:
         dist.destroy_process_group()  # (the other ranks have left already)
     flush_c_stdio()
@@ -1697,12 +1705,12 @@ def dropin_sequence(n_frames: int = 600) -> dict:
             "pyramid_uploads": host.get("uploads"), "pyramid_upload_us_per_frame": host.get("pyramid_upload_us_total", 0.0) / max(1, n_frames - 1)}
 
 
-def reference_cameras_leg(args, ev: Events, dev, rank: int, lib, B: int = 4096, dropin_frames: int = 300) -> dict:
+def reference_cameras_leg(args, ev: Events, dev, rank: int, lib, B: int = 4096, dropin_frames: int = 200) -> dict:
     """the camera models the reference actually ships (svo_ros/param/camera_atan.yaml, camera_pinhole.yaml:
     both distorted) next to the undistorted pinhole every other number is measured on.  Per camera, on 752x480 images rendered
     through the model: K1 at configs[1]'s shape (4 levels 3 -> 0, 200 patches; B frames), the representative full-track step
-    (configs[2]) and the single-stream drop-in (hip flavour, `dropin_frames` frames, a child process), with K1's counter
-    traffic from two rocprofv3 --pmc children while the time budget lasts."""
+    (configs[2]) and the single-stream drop-in (hip flavour, `dropin_frames` frames, a child process); K1's counter traffic is
+    added by reference_cameras_traffic() after the headline's own counter passes."""
     out = {"frames_per_step": B, "image": "752x480", "workload": "ref752_4_n200_sparse_align", "cameras": {}}
     cams = reference_cameras()
     for name, cam in cams.items():
@@ -1755,9 +1763,28 @@ def reference_cameras_leg(args, ev: Events, dev, rank: int, lib, B: int = 4096, 
             out["cameras"][name]["dropin"] = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else {"skipped": p.stderr[-300:]}
         except Exception as e:
             out["cameras"][name]["dropin"] = {"skipped": repr(e)}
-    # K1's counter traffic per camera
-    for name in cams:
-        sa = out["cameras"].get(name, {}).get("sparse_align")
+    # The distorted models converge in MORE Gauss-Newton iterations on the same frames -- the reference's Jacobian is the
+    # undistorted pinhole's whatever the camera (sparse_img_align.cpp:104-105: frame jacobian_xyz2uv * focal_length), so
+    # its steps are less exact where the distortion is strong: the kernel is compared per ITERATION, the whole run beside it
+    pin = out["cameras"].get("pinhole_undistorted", {}).get("sparse_align", {})
+    for name, r in out["cameras"].items():
+        sa = r.get("sparse_align")
+        if isinstance(sa, dict):
+            sa["us_per_gn_iteration_of_the_batch"] = sa["ms_per_step"] * 1e3 / sa["mean_gn_iterations_per_frame"]
+    if pin:
+        for name, r in out["cameras"].items():
+            sa = r.get("sparse_align")
+            if isinstance(sa, dict):
+                sa["ms_over_undistorted_pinhole"] = sa["ms_per_step"] / pin["ms_per_step"]
+                sa["per_iteration_over_undistorted_pinhole"] = sa["us_per_gn_iteration_of_the_batch"] / pin["us_per_gn_iteration_of_the_batch"]
+    return out
+
+
+def reference_cameras_traffic(args, out: dict, B: int = 4096) -> None:
+    """K1's counter traffic on the two distorted cameras (rocprofv3 --pmc children: FETCH_SIZE, WRITE_SIZE), while the time
+    budget lasts; the undistorted pinhole's is the headline kernel's own ratio."""
+    for name in ("atan", "radtan"):
+        sa = out.get("cameras", {}).get(name, {}).get("sparse_align")
         if not sa or time_left(args.time_budget) < 2 * PMC_PASS_RESERVE_S:
             continue
         try:
@@ -1774,12 +1801,6 @@ def reference_cameras_leg(args, ev: Events, dev, rank: int, lib, B: int = 4096, 
         except Exception as e:
             sa["roofline"]["traffic"] = None
             sa["roofline"]["pmc_passes"] = repr(e)
-    ref = out["cameras"].get("pinhole_undistorted", {}).get("sparse_align", {}).get("ms_per_step")
-    if ref:
-        for name, r in out["cameras"].items():
-            if isinstance(r.get("sparse_align"), dict):
-                r["sparse_align"]["ms_over_undistorted_pinhole"] = r["sparse_align"]["ms_per_step"] / ref
-    return out
 
 
 def dropin_hip_only(n_frames: int, dump: str, camera: str | None = None) -> dict:

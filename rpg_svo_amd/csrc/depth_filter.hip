@@ -4,9 +4,8 @@
 //   age / visibility tests, inverse-depth interval (:216-235)            seed_prepare_kernel
 //   Matcher::findEpipolarMatchDirect (svo/src/matcher.cpp:179-321):        (lane per seed, f64)
 //     epipolar segment, affine warp matrix, edgelet filter, search level
-//     warp::warpAffine 10x10                                              warp_kernel (matcher.hip)
-//     ZMSSD scan along the epipolar line (:248-291)                       epi_scan_kernel
-//                                                                           (8 lanes per seed)
+//     warp::warpAffine 10x10                                            \ epi_scan_kernel (8 lanes per seed; the patch
+//     ZMSSD scan along the epipolar line (:248-291)                     /  stays in LDS between the two: warp_group.h)
 //     sub-pixel refinement align2D / align1D (:295-315)                   K3 (feature_align.hip)
 //     depthFromTriangulation (:109-122)                                  \ seed_finish_kernel
 //   DepthFilter::computeTau (:334-350), updateSeed (:309-332),           | (lane per seed)
@@ -44,7 +43,6 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   // (ref_slot, ref_level, dir, px_scaled, px_cur) are written where the seed becomes active, and seed_finish reads
   // px_cur / align_ok only for seeds that got that far: an early exit costs 19 bytes of workspace, not 71 (round 3:
   // 230 B per seed through these arrays against 36 B of seed state).
-  w.warp_active[s] = 0;
   w.align_active[s] = 0;
   w.use_1d[s] = a.opt.align_1d ? 1 : 0;
   w.mode[s] = MODE_NONE;
@@ -165,7 +163,6 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   w.px_ref_pyr[2 * s + 1] = (float)rpx[1] / (float)(1 << rlevel);
   w.ref_slot[s] = ref_slot_early;
   w.ref_level[s] = rlevel;
-  w.warp_active[s] = 1;
   {  // (px_A-px_B).cast<float>().normalized()
     float d0 = (float)dAB[0], d1 = (float)dAB[1];
     const float n = sqrtf(d0 * d0 + d1 * d1);
@@ -185,7 +182,6 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   const unsigned long long n_steps = (unsigned long long)(epi_length / 0.7);
   if (n_steps > (unsigned long long)a.opt.max_epi_search_steps) {
     w.status[s] = SVO_HIP_SEED_NO_MATCH;  // "skip epipolar search"
-    w.warp_active[s] = 0;
     return;
   }
   w.n_steps[s] = (int)n_steps;
@@ -202,8 +198,9 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
 // idle two thirds of the time.  So the workgroup first sorts its chunk by scan length (counting sort over
 // buckets: up to 8 positions, then powers of two of ceil(positions / 16); in LDS), longest first, and its waves then fetch groups of
 // 8 neighbouring entries of that order from an LDS counter: the seeds a wave holds at a time need about
-// the same number of passes, and no wave waits for another.  Seeds that do not scan (short segment, not visible,
-// rejected) never enter the order.  Results do not depend on the order.
+// the same number of passes, and no wave waits for another.  Seeds that neither warp nor scan (not visible,
+// rejected) never enter the order; a seed with a segment too short to scan comes for its warp only.  Results do not
+// depend on the order.
 // Four waves per SIMD: the scan waits on its box fetch once per pass.  The undistorted instantiation fits (127 VGPRs, no
 // scratch, 35.4 KB of LDS per workgroup); the distorted cameras' one carries the models' f64 code in the loop and spills
 // outside it.  (What registers cost here: nine spilled dwords per seed took 10 % of the kernel, profiles/r05e_*.)
@@ -225,10 +222,12 @@ __global__ void __launch_bounds__(SCAN_BLOCK, SCAN_MINW) epi_scan_kernel(const S
     const int s = base + threadIdx.x + SCAN_BLOCK * k;
     bucket[k] = -1;
     rank[k] = 0;
-    if (s < a.S && w.mode[s] == MODE_SCAN) {
+    const int md = s < a.S ? w.mode[s] : MODE_NONE;
+    if (md != MODE_NONE) {
       // n_steps + 1 positions (matcher.cpp:264): lines of up to SCAN_G positions (one pass of one position per lane) in
-      // bucket 0, then power-of-two buckets of the passes of 2 SCAN_G positions
-      const int n_pos = w.n_steps[s] + 1;
+      // bucket 0, then power-of-two buckets of the passes of 2 SCAN_G positions.  A seed whose segment is too short to be
+      // scanned (MODE_SHORT) is here for its warp alone: bucket 0
+      const int n_pos = md == MODE_SCAN ? w.n_steps[s] + 1 : 1;
       const int passes = (n_pos + SCAN_PP - 1) / SCAN_PP;
       bucket[k] = n_pos <= SCAN_G ? 0 : min(SCAN_BUCKETS - 1, 1 + (passes <= 1 ? 0 : 32 - __clz(passes - 1)));
       rank[k] = atomicAdd(&s_hist[bucket[k]], 1);
@@ -600,7 +599,7 @@ extern "C" int svo_hip_update_seeds_resident(const svo_hip_pyr_layout* layout, c
   return run_seed_chain(layout, d_store, a, S, d_workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
-// seed_prepare -> warp -> epipolar scan -> sub-pixel alignment -> seed_finish on one stream
+// seed_prepare -> (affine warp +) epipolar scan -> sub-pixel alignment -> seed_finish on one stream
 static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_store, SeedArgs& a, int S, void* d_workspace,
                           size_t workspace_bytes, hipStream_t st) {
   Carver c(d_workspace, workspace_bytes);
@@ -613,7 +612,6 @@ static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_sto
   SeedWs& w = a.ws;
   w.n_steps = c.take<int32_t>(n);  // first array of the workspace: svo_hip_update_seeds_scan_steps
   w.pwb = c.take<uint8_t>(n * 100);
-  w.warp_active = c.take<uint8_t>(n);
   w.align_active = c.take<uint8_t>(n);
   w.use_1d = c.take<uint8_t>(n);
   w.status = c.take<int32_t>(n);
@@ -640,19 +638,7 @@ static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_sto
   hipLaunchKernelGGL(seed_prepare_kernel, dim3((S + 63) / 64), dim3(64), 0, st, a);
   int rc = check_launch();
   if (rc) return rc;
-  WarpArgs wa;
-  wa.L = *layout;
-  wa.store = d_store;
-  wa.M = S;
-  wa.active = w.warp_active;
-  wa.ref_slot = w.ref_slot;
-  wa.ref_level = w.ref_level;
-  wa.search_level = w.search_level;
-  wa.A_ref_cur = w.A_ref_cur;
-  wa.px_ref_pyr = w.px_ref_pyr;
-  wa.pwb = w.pwb;
-  rc = launch_warp(wa, st);
-  if (rc) return rc;
+  // (the affine warp of the reference patch is the scan kernel's first step: warp_group.h)
   if (a.cam.model == SVO_HIP_CAM_PINHOLE)
     hipLaunchKernelGGL(epi_scan_kernel<true>, dim3((S + SCAN_CHUNK - 1) / SCAN_CHUNK), dim3(SCAN_BLOCK), 0, st, a);
   else

@@ -10,6 +10,7 @@
 #include "matcher_device.h"
 #include "seed_math.h"
 #include "wave_reduce.h"
+#include "warp_group.h"
 
 using namespace svo_dev;
 using namespace svo_track;
@@ -22,7 +23,6 @@ constexpr int ZMSSD_THRESHOLD = 2000 * 64;  // vk::patch_score::ZMSSD<4>::thresh
 enum : int { MODE_NONE = 0, MODE_SHORT = 1, MODE_SCAN = 2 };
 
 struct SeedWs {
-  uint8_t* warp_active;   // [S]
   uint8_t* align_active;  // [S]
   uint8_t* use_1d;        // [S]
   int32_t* status;        // [S] preliminary status (0 = still running)
@@ -113,10 +113,15 @@ constexpr int SCAN_BUCKETS = 8;
 // among them, and every group of the wave then sits through both rounds.)  A pass whose windows do not fit (a distorted
 // line) is done as two half passes, the box of lanes 0-3 and then the box of lanes 4-7; a group whose half box does not fit
 // either fetches per lane.
-constexpr int SCAN_BOX_ROWS = 20, SCAN_BOX_ROW_DWORDS = 12;
-constexpr int SCAN_TPL_OFF = SCAN_BOX_ROWS * SCAN_BOX_ROW_DWORDS + 4;  // (+ 4 dwords: the cut reads three dwords per row)
-constexpr int SCAN_BOX_DWORDS = SCAN_TPL_OFF + 16;                     // box, then the template's 8 rows of 2 dwords
-static_assert(SCAN_BOX_DWORDS % 4 == 0 && SCAN_TPL_OFF % 4 == 0, "16-byte LDS stores");
+// Round 6: the group also WARPS its seed's reference patch (warp_group.h) -- into the same box, before the scan needs it --
+// and keeps the 10 x 10 patch in LDS: the template is cut from there, and the 100 bytes travel to HBM only for a seed that
+// goes on to the sub-pixel alignment (warp_kernel's launch over the seeds, its 100-byte write and the scan's read of it
+// are gone).
+constexpr int SCAN_BOX_ROWS = WG_BOX_ROWS, SCAN_BOX_ROW_DWORDS = WG_ROW_DWORDS;
+constexpr int SCAN_PATCH_OFF = WG_BOX_DWORDS;                          // box (+ 4 dwords: the cut reads three dwords per row)
+constexpr int SCAN_TPL_OFF = SCAN_PATCH_OFF + WG_PATCH_DWORDS;         // ... the 10 x 10 patch_with_border
+constexpr int SCAN_BOX_DWORDS = SCAN_TPL_OFF + 16;                     // ... the template's 8 rows of 2 dwords
+static_assert(SCAN_BOX_DWORDS % 4 == 0 && SCAN_TPL_OFF % 4 == 0 && SCAN_PATCH_OFF % 4 == 0, "16-byte LDS stores");
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
@@ -168,21 +173,39 @@ __device__ __forceinline__ void scan_world2cam(const Cam& c, const double uv[2],
 template <bool PINHOLE>
 __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, const int lane, uint32_t* box) {
   const SeedWs& w = a.ws;
+  // everything the warp and the scan set-up read, requested together (seed_prepare_kernel wrote it)
   const int sl = w.search_level[s];
-  const uint8_t* img = a.store + (int64_t)w.cur_slot[s] * a.L.slot_bytes + a.L.offset[sl];
+  const int mode = w.mode[s];
+  const int cur_slot = w.cur_slot[s];
+  const int ref_slot = w.ref_slot[s], ref_level = w.ref_level[s] & (SVO_HIP_MAX_LEVELS - 1);
+  const float4 A = *reinterpret_cast<const float4*>(w.A_ref_cur + 4 * (size_t)s);
+  const float2 pyr = *reinterpret_cast<const float2*>(w.px_ref_pyr + 2 * (size_t)s);
+  const double step0 = mode == MODE_SCAN ? w.step[2 * s] : 0.0, step1 = mode == MODE_SCAN ? w.step[2 * s + 1] : 0.0;
+  const double B0 = mode == MODE_SCAN ? w.B[2 * s] : 0.0, B1 = mode == MODE_SCAN ? w.B[2 * s + 1] : 0.0;
+  const int n_total = w.n_steps[s] + 1;
+  // ---- warp::warpAffine of the seed's reference patch (matcher.cpp:221-224), into LDS ------------------------------------
+  uint32_t* const patch = box + SCAN_PATCH_OFF;
+  {
+    const uint8_t* ref_img = a.store + (int64_t)ref_slot * a.L.slot_bytes + a.L.offset[ref_level];
+    warp_patch_group8(ref_img, a.L.w[ref_level], a.L.h[ref_level], a.L.pitch[ref_level], A.x, A.y, A.z, A.w, pyr.x, pyr.y, sl, lane,
+                      box, patch);
+  }
+  if (mode != MODE_SCAN) {
+    // a segment shorter than two pixels (matcher.cpp:226-238): straight to the sub-pixel alignment, which reads the patch
+    warp_patch_store_group8(patch, lane, w.pwb + (size_t)s * 100);
+    return;
+  }
+  const uint8_t* img = a.store + (int64_t)cur_slot * a.L.slot_bytes + a.L.offset[sl];
   const int pitch = a.L.pitch[sl];
   // reference patch: interior of patch_with_border (createPatchFromPatchWithBorder), 8 rows of 8; lane y parks row y
   uint32_t* const tpl = box + SCAN_TPL_OFF;
   int sumA, sumAA;
   {
-    const uint8_t* r = w.pwb + (size_t)s * 100 + (lane + 1) * 10 + 1;
-    // one unaligned 8-byte load per row (gfx950 global memory takes any alignment)
-    uint32_t lo, hi;
-    __builtin_memcpy(&lo, r, 4);
-    __builtin_memcpy(&hi, r + 4, 4);
-    // (the scan of the seed this group held before has read its template for the last time: DS operations of a wave
-    // execute in order)
-    SVO_LANES_LDS_HANDOVER();
+    // bytes 10 (y + 1) + 1 .. + 8 of the patch: three dwords and a byte shift
+    const uint32_t b = 10u * (uint32_t)lane + 11u;
+    const uint32_t* r = patch + (b >> 2);
+    const uint32_t d0 = r[0], d1 = r[1], d2 = r[2];
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, b & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, b & 3u);
     tpl[2 * lane] = lo;
     tpl[2 * lane + 1] = hi;
     SVO_LANES_LDS_HANDOVER();
@@ -192,9 +215,7 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
     sumA = group8_sum((int)sa);
     sumAA = group8_sum((int)saa);
   }
-  const double step0 = w.step[2 * s], step1 = w.step[2 * s + 1];
-  double uv0 = w.B[2 * s] - step0, uv1 = w.B[2 * s + 1] - step1;
-  const int n_total = w.n_steps[s] + 1;
+  double uv0 = B0 - step0, uv1 = B1 - step1;
   int best = ZMSSD_THRESHOLD;
   int best_i = 0x7fffffff;
   double best_uv0 = 0, best_uv1 = 0;
@@ -403,6 +424,8 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
     w.align_active[s] = a.opt.subpix_refinement ? 1 : 0;
     w.accepted_raw[s] = a.opt.subpix_refinement ? 0 : 1;
   }
+  // (every lane holds the group's minimum) a match that goes on to align1D / align2D: its patch_with_border to HBM
+  if (win_score < ZMSSD_THRESHOLD && a.opt.subpix_refinement) warp_patch_store_group8(patch, lane, w.pwb + (size_t)s * 100);
   if (lane == 0 && !(win_score < ZMSSD_THRESHOLD)) w.status[s] = SVO_HIP_SEED_NO_MATCH;
 }
 

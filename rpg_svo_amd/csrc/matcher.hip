@@ -6,8 +6,8 @@
 //   isInFrame test on the ref feature (matcher.cpp:143-145)          |  one lane per candidate,
 //   warp::getWarpMatrixAffine         (matcher.cpp:33-55)            |  f64 geometry
 //   warp::getBestSearchLevel          (matcher.cpp:57-70)            /
-//   warp::warpAffine 10x10            (matcher.cpp:72-105)              warp_kernel, 25 lanes per
-//                                                                       candidate x 4 samples
+//   warp::warpAffine 10x10            (matcher.cpp:72-105)              warp_kernel, 8 lanes per
+//                                                                       candidate (warp_group.h)
 //   feature_alignment::align2D/1D     (feature_alignment.cpp)           K3 (feature_align.hip)
 //
 // The map (Point -> list of observing Features -> Frames) reaches the device as a CSR
@@ -21,6 +21,7 @@
 #include "track_math.h"
 #include "matcher_device.h"
 #include "warp_sample.h"
+#include "warp_group.h"
 
 using namespace svo_capi;
 using namespace svo_dev;
@@ -167,22 +168,17 @@ __global__ void __launch_bounds__(64) match_prepare_kernel(const PrepArgs a) {
   a.active[m] = 1;
 }
 
-// warp::warpAffine (matcher.cpp:72-105), halfpatch_size = 5.  A wave owns SIX trials: lane = (trial,
-// output column), 10 lanes per trial, and walks down the 10 output rows.  One load instruction then
-// touches ONE source row per trial (1-2 cache lines for the usual near-upright warp) instead of the
-// ten rows a 25-lanes-x-4-samples mapping spreads over: the kernel is bound by the number of distinct
-// lines the vector L1 looks up per instruction (80 line look-ups per trial before, ~30 now).  The
-// 100 output bytes of a trial are assembled in LDS and the wave stores its 600 contiguous bytes as
-// coalesced dwords.  Arithmetic per sample is unchanged (bit-identical patches).
-constexpr int WARP_TPW = 6;  // trials per wave
-constexpr int WARP_REG_ROWS = 24;  // rows of the LDS copy of a trial's source region (48 bytes each)
+// warp::warpAffine (matcher.cpp:72-105), halfpatch_size = 5: a wave owns EIGHT trials, 8 lanes each (warp_group.h: the
+// source region through LDS, 13 sample slots per lane, the patch assembled in LDS); a group stores its 100 bytes as 25 dwords.
+// Arithmetic per sample unchanged (bit-identical patches).  The depth filter no longer comes here: its scan kernel warps
+// its own seeds with the same function (epi_scan.h).
+constexpr int WARP_TPW = 8;   // trials per wave
 constexpr int WARP_MINW = 4;  // waves per SIMD the register budget is held to
 constexpr int WARP_WGS_PER_CU = 16;
 __global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) {
   __shared__ long long s_off[SVO_HIP_MAX_LEVELS];
   __shared__ int s_w[SVO_HIP_MAX_LEVELS], s_h[SVO_HIP_MAX_LEVELS], s_p[SVO_HIP_MAX_LEVELS];
-  __shared__ uint32_t s_patch[4][WARP_TPW * 25 + 2];
-  __shared__ __attribute__((aligned(16))) uint32_t s_region[4][WARP_TPW][WARP_REG_ROWS * 12 + 16];  // rows of 48 bytes
+  __shared__ __attribute__((aligned(16))) uint32_t s_lds[4 * WARP_TPW][WG_BOX_DWORDS + WG_PATCH_DWORDS];
   if (threadIdx.x < SVO_HIP_MAX_LEVELS) {
     s_off[threadIdx.x] = a.L.offset[threadIdx.x];
     s_w[threadIdx.x] = a.L.w[threadIdx.x];
@@ -191,25 +187,25 @@ __global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) 
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int t = lane / 10, x = lane - 10 * t;
-  uint8_t* const my_patch = reinterpret_cast<uint8_t*>(s_patch[wave]);
+  const int t = lane >> 3, gl = lane & 7;
+  uint32_t* const region = s_lds[threadIdx.x >> 3];
+  uint32_t* const patch = region + WG_BOX_DWORDS;
   const int M = a.M_dev ? min(*a.M_dev, a.M) : a.M;
   const long long n_wave_groups = ((long long)M + WARP_TPW - 1) / WARP_TPW;
   // An iteration of a wave is a chain of two memory round trips -- the parameters of its trials, then their source
-  // regions -- and the arithmetic; at four waves per SIMD the chain, not an execution unit, sets the pace (see the
-  // sample loop).  The parameters of the NEXT iteration are therefore requested before this iteration's work starts.
+  // regions -- and the arithmetic: the parameters of the NEXT iteration are requested before this iteration's work starts.
   struct TrialParams {
     float4 A;
     float2 pyr;
     int act, level, slot, slev;
   };
-  auto load_params = [&](long long gw) {  // round 1: parameters of the trial (the 10 lanes of a trial read the same words)
+  auto load_params = [&](long long gw) {  // (the 8 lanes of a trial read the same words)
     TrialParams p;
     p.A = make_float4(0.f, 0.f, 0.f, 0.f);
     p.pyr = make_float2(0.f, 0.f);
     p.act = p.level = p.slot = p.slev = 0;
     const long long m = gw * WARP_TPW + t;
-    if (lane < 10 * WARP_TPW && m < M) {
+    if (m < M) {
       p.A = *reinterpret_cast<const float4*>(a.A_ref_cur + 4 * (size_t)m);
       p.pyr = *reinterpret_cast<const float2*>(a.px_ref_pyr + 2 * (size_t)m);
       p.act = a.active[m];
@@ -223,200 +219,18 @@ __global__ void __launch_bounds__(256, WARP_MINW) warp_kernel(const WarpArgs a) 
   long long gw = (long long)blockIdx.x * 4 + wave;
   TrialParams nxt = load_params(gw < n_wave_groups ? gw : 0);
   for (; gw < n_wave_groups; gw += gw_step) {
-    const long long m0 = gw * WARP_TPW;
-    const long long m = m0 + t;
-    const bool lane_on = lane < 10 * WARP_TPW && m < M;
+    const long long m = gw * WARP_TPW + t;
     const TrialParams cur = nxt;
     if (gw + gw_step < n_wave_groups) nxt = load_params(gw + gw_step);
-    uint8_t out[10];
-#pragma unroll
-    for (int y = 0; y < 10; ++y) out[y] = 0;
-    if (lane_on) {
-      const float4 A = cur.A;
-      const float2 pyr = cur.pyr;
-      const int act = cur.act, level = cur.level & (SVO_HIP_MAX_LEVELS - 1), slot = cur.slot, slev = cur.slev;
-      // "Affine warp is NaN": the reference leaves the previous patch in place; here: zeros
-      if (act && !isnan(A.x)) {
-        const uint8_t* img = a.store + (int64_t)slot * a.L.slot_bytes + s_off[level];
-        const int cols = s_w[level], rows = s_h[level], pitch = s_p[level];
-        const float sc = (float)(1 << slev);
-        bool boxed = false;
-        // ---- the source region through LDS ------------------------------------------------------------------
-        // The 100 samples of a trial lie in the parallelogram spanned by its four corner samples (the map is affine and
-        // every rounding in it is monotone, so the extremes ARE the corners).  Its bounding box, at most WARP_REG_ROWS x
-        // 48 bytes of 16-byte tile rows, is fetched once by the trial's 10 lanes (2-7 dwordx4 loads per lane instead of
-        // 20 two-byte gathers plus the tile-straddle fix-ups) and the samples read their four bytes from LDS: no tile
-        // address arithmetic, no 64-bit address per sample.  A trial whose box is larger (strong down-scaling) or not
-        // finite takes the gathers below.
-        {
-          float bx0 = 3.0e38f, bx1 = -3.0e38f, by0 = 3.0e38f, by1 = -3.0e38f;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            float pp0 = (float)((k & 1) ? 4 : -5), pp1 = (float)((k & 2) ? 4 : -5);
-            pp0 *= sc;
-            pp1 *= sc;
-            const float q0 = (A.x * pp0 + A.y * pp1) + pyr.x;
-            const float q1 = (A.z * pp0 + A.w * pp1) + pyr.y;
-            bx0 = fminf(bx0, q0); bx1 = fmaxf(bx1, q0);
-            by0 = fminf(by0, q1); by1 = fmaxf(by1, q1);
-          }
-          // (comparisons are false for NaN: such a trial is not boxed)
-          if (bx0 > -1.0e6f && bx1 < 1.0e6f && by0 > -1.0e6f && by1 < 1.0e6f && bx0 <= bx1 && by0 <= by1) {
-            int xlo = (int)floorf(bx0), xhi = (int)floorf(bx1) + 1, ylo = (int)floorf(by0), yhi = (int)floorf(by1) + 1;
-            xlo = max(xlo, 0); ylo = max(ylo, 0);
-            xhi = min(xhi, cols - 1); yhi = min(yhi, rows - 1);
-            const int cx0 = xlo & ~15;
-            const int nch = xhi >= cx0 ? ((xhi - cx0) >> 4) + 1 : 0, nrow = yhi - ylo + 1;
-            if (xhi < xlo || yhi < ylo) {
-              boxed = true;  // every sample lies outside the image: the patch stays zero
-            } else if (nch <= 3 && nrow <= WARP_REG_ROWS) {
-              boxed = true;
-              uint8_t* const reg = reinterpret_cast<uint8_t*>(s_region[wave][t]);
-              const int n_chunks = nrow * nch;
-              const uint32_t inv = nch == 1 ? 65536u : (nch == 2 ? 32768u : 21846u);  // c / nch for c < 128
-              // the first four chunks of a lane (boxes of up to 40 chunks: the usual 12 rows x 2 are 24) are requested
-              // together and parked afterwards -- as a loop of load-then-store the lane paid one round trip PER chunk
-              {
-                uint4 v[4];
-                int dst[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  const int c = x + 10 * k;
-                  const int row = (int)(((uint32_t)c * inv) >> 16), cc = c - row * nch;
-                  dst[k] = row * 48 + cc * 16;
-                  v[k] = make_uint4(0, 0, 0, 0);
-                  if (c < n_chunks) v[k] = *reinterpret_cast<const uint4*>(img + (svo_pyr::row_off(ylo + row, pitch) + svo_pyr::col_off(cx0 + 16 * cc)));
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                  if (x + 10 * k < n_chunks) *reinterpret_cast<uint4*>(reg + dst[k]) = v[k];
-              }
-              for (int c = x + 40; c < n_chunks; c += 10) {
-                const int row = (int)(((uint32_t)c * inv) >> 16), cc = c - row * nch;
-                const uint4 v = *reinterpret_cast<const uint4*>(img + (svo_pyr::row_off(ylo + row, pitch) + svo_pyr::col_off(cx0 + 16 * cc)));
-                *reinterpret_cast<uint4*>(reg + row * 48 + cc * 16) = v;
-              }
-              // hand-over inside the wave: DS operations of one wave execute in order
-              SVO_LANES_LDS_HANDOVER();
-              // The samples lie between the corner samples (see above), so when the box of the corners is inside the
-              // image every sample is: the usual trial skips the four comparisons and three selects per sample (the
-              // values are the same: `in` would be true everywhere).
-              const bool all_in = bx0 >= 0.f && by0 >= 0.f && bx1 < (float)(cols - 1) && by1 < (float)(rows - 1);
-              // round 4b: floor and fraction of a coordinate with one instruction each (v_cvt_flr_i32_f32, v_fract_f32:
-              // u - floor(u) is exact for u >= 0, so the fraction has the same bits) and the sample's LDS address with one
-              // 24-bit multiply and one three-operand add: four vector instructions fewer per sample, same bits -- and
-              // the same time (profiles/r04q_*).  Neither are the LDS reads what the kernel waits for: the pixel pairs as
-              // 16-bit words from a second, shifted copy of the region (two aligned reads per sample instead of four)
-              // cost 3 % MORE for the extra byte gather of the fill (r04s_*), a bank-friendlier stride between the regions
-              // changed nothing (r04r_*); 16-bit reads at odd addresses, which gfx950 executes, doubled the kernel's time
-              // (r04p_*).  A wave's iteration is a chain of two memory round trips (the trial's parameters, then its
-              // region) and ~1300 cycles of arithmetic at four waves per SIMD: see the parameter prefetch at the loop head.
-              const uint8_t* const reg_o = reg - (__mul24(ylo, 48) + cx0);  // so that pixel (xi, yi) is reg_o[48 yi + xi]
-              auto rows10 = [&](auto check_tag) {
-                constexpr bool CHECK = decltype(check_tag)::value;
-#pragma unroll
-                for (int y = 0; y < 10; ++y) {
-                  float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
-                  pp0 *= sc;
-                  pp1 *= sc;
-                  const float px0 = (A.x * pp0 + A.y * pp1) + pyr.x;
-                  const float px1 = (A.z * pp0 + A.w * pp1) + pyr.y;
-                  const bool in = !CHECK || !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
-                  // vk::interpolateMat_8u (a sample outside the image is 0)
-                  const float u = in ? px0 : (float)xlo, v = in ? px1 : (float)ylo;
-                  const int xi = svo_dev::floor_to_int(u), yi = svo_dev::floor_to_int(v);
-                  const float sx = __builtin_amdgcn_fractf(u), sy = __builtin_amdgcn_fractf(v);
-                  const float w00 = (1.0f - sx) * (1.0f - sy);
-                  const float w01 = (1.0f - sx) * sy;
-                  const float w10 = sx * (1.0f - sy);
-                  const float w11 = 1.0f - w00 - w01 - w10;
-                  const uint8_t* q = reg_o + (__mul24(yi, 48) + xi);
-                  const float p00 = (float)q[0], p10 = (float)q[1], p01 = (float)q[48], p11 = (float)q[49];
-                  const float val = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
-                  out[y] = in ? (uint8_t)val : (uint8_t)0;
-                }
-              };
-              if (all_in) rows10(std::false_type{});
-              else rows10(std::true_type{});
-              SVO_LANES_LDS_HANDOVER();
-            }
-          }
-        }
-        if (!boxed) {
-        // round 2, five output rows at a time: addresses and weights of the five samples of this column, then all
-          // their loads, then the arithmetic.  A sample reads the 2 x 2 pixels (xi, yi) .. (xi+1, yi+1) as two 16-bit
-          // loads (gfx950 global memory takes any alignment).  In the tiled store the pair (xi, xi+1) straddles two
-          // tiles for one column in sixteen: those lanes fetch their right-hand pixels with two byte loads more, issued
-          // together with everything else (a fix-up that waited for its own round trip per row cost +70 %).
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            float w00[5], w01[5], w10[5], w11[5];
-            bool in[5];
-            uint16_t top[5], bot[5];
-            uint32_t fix_t[5], fix_b[5];
-            uint8_t rt8[5], rb8[5];
-            bool cross[5];
-            bool any_cross = false;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-              const int y = 5 * h + k;
-              float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
-              pp0 *= sc;
-              pp1 *= sc;
-              const float px0 = (A.x * pp0 + A.y * pp1) + pyr.x;
-              const float px1 = (A.z * pp0 + A.w * pp1) + pyr.y;
-              in[k] = !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
-              // vk::interpolateMat_8u; samples outside the image read pixel (0,0) and are discarded
-              const float u = in[k] ? px0 : 0.f, v = in[k] ? px1 : 0.f;
-              const int xi = (int)floorf(u), yi = (int)floorf(v);
-              const float sx = u - (float)xi, sy = v - (float)yi;
-              w00[k] = (1.0f - sx) * (1.0f - sy);
-              w01[k] = (1.0f - sx) * sy;
-              w10[k] = sx * (1.0f - sy);
-              w11[k] = 1.0f - w00[k] - w01[k] - w10[k];
-              const uint32_t rt = svo_pyr::row_off(yi, pitch), rb = svo_pyr::row_off(yi + 1, pitch);
-              const uint32_t cl = svo_pyr::col_off(xi);
-              __builtin_memcpy(&top[k], img + (rt + cl), 2);
-              __builtin_memcpy(&bot[k], img + (rb + cl), 2);
-              cross[k] = (xi & 15) == 15;  // pixel xi+1 is the first byte of the next tile
-              any_cross = any_cross || cross[k];
-              fix_t[k] = rt + cl + 113u;   // col_off(xi + 1) - col_off(xi) when xi % 16 == 15
-              fix_b[k] = rb + cl + 113u;
-              rt8[k] = rb8[k] = 0;
-            }
-            if (any_cross) {
-#pragma unroll
-              for (int k = 0; k < 5; ++k)
-                if (cross[k]) {
-                  rt8[k] = img[fix_t[k]];
-                  rb8[k] = img[fix_b[k]];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-              const float p10 = cross[k] ? (float)rt8[k] : (float)(top[k] >> 8);
-              const float p11 = cross[k] ? (float)rb8[k] : (float)(bot[k] >> 8);
-              const float p00 = (float)(top[k] & 0xffu), p01 = (float)(bot[k] & 0xffu);
-              const float val = w00[k] * p00 + w01[k] * p01 + w10[k] * p10 + w11[k] * p11;
-              out[5 * h + k] = in[k] ? (uint8_t)val : (uint8_t)0;
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int y = 0; y < 10; ++y) my_patch[t * 100 + y * 10 + x] = out[y];
+    if (m < M) {
+      const int level = cur.level & (SVO_HIP_MAX_LEVELS - 1);
+      const uint8_t* img = a.store + (int64_t)cur.slot * a.L.slot_bytes + s_off[level];
+      // an inactive trial's patch is zeros (a NaN warp likewise: warp_group.h), as in rounds 1-5
+      const float Ax = cur.act ? cur.A.x : __builtin_nanf("");
+      warp_patch_group8(img, s_w[level], s_h[level], s_p[level], Ax, cur.A.y, cur.A.z, cur.A.w, cur.pyr.x, cur.pyr.y,
+                        cur.slev & 31, gl, region, patch);
+      warp_patch_store_group8(patch, gl, a.pwb + (size_t)m * 100);
     }
-    // same-wave LDS hand-over: DS operations of one wave execute in order
-    SVO_WAVE_LDS_HANDOVER();
-    const long long left = (long long)M - m0;
-    const int n_dw = 25 * (int)(left < WARP_TPW ? left : WARP_TPW);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(a.pwb + (size_t)m0 * 100);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int idx = lane + 64 * k;
-      if (idx < n_dw) dst[idx] = s_patch[wave][idx];
-    }
-    SVO_WAVE_LDS_HANDOVER();
   }
 }
 

@@ -1,6 +1,6 @@
-// warp_sample.h -- the sample arithmetic of warp::warpAffine (matcher.cpp:72-105) as warp_kernel's lanes run it: one
-// output COLUMN x of a trial's 10 x 10 patch, ten samples down the rows, read from a copy of the source region laid out
-// in rows of 48 bytes (reg_o[48 yi + xi] is pixel (xi, yi) of the level).  Device functions of matcher.hip; also
+// warp_sample.h -- the sample arithmetic of warp::warpAffine (matcher.cpp:72-105) as the lanes of warp_group.h run it: a
+// sample of a trial's 10 x 10 patch read from a copy of the source region laid out in rows of 48 bytes (reg_o[48 yi + xi]
+// is pixel (xi, yi) of the level).  Device functions of matcher.hip; also
 // compiled for the CPU by the test suite (SVO_HOST_MATH_TEST, see device_math.h) and compared with the oracle bit for bit.
 // The including translation unit sets `#pragma clang fp contract(off)`: every product and sum rounds on its own.
 #pragma once
@@ -17,31 +17,46 @@ namespace svo_track {
 // has shown that every sample lies inside (the box of the four corner samples does).
 // floor and fraction of a coordinate are one instruction each on the device (v_cvt_flr_i32_f32, v_fract_f32: u - floor(u)
 // is exact for u >= 0, so the fraction has the same bits), the sample's address one 24-bit multiply and one add.
+
+// The four weights of vk::interpolateMat_8u and their blend (every product and sum rounded on its own, in this order).
+__device__ __forceinline__ float warp_blend(const float sx, const float sy, const float p00, const float p10, const float p01,
+                                            const float p11) {
+  const float w00 = (1.0f - sx) * (1.0f - sy);
+  const float w01 = (1.0f - sx) * sy;
+  const float w10 = sx * (1.0f - sy);
+  const float w11 = 1.0f - w00 - w01 - w10;
+  return w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
+}
+
+// Sample (x, y) of the 10 x 10 patch: px_patch = (x - 5, y - 5) * 2^search_level, px = A_ref_cur * px_patch + px_ref_pyr
+// (matcher.cpp:90-93, Eigen's 2 x 2 product: (a * b + c * d) + e), read from a copy of the source region laid out in rows of
+// 48 bytes: reg_o[48 yi + xi] is pixel (xi, yi) of the level.
+template <bool CHECK>
+__device__ __forceinline__ uint8_t warp_sample(const float Ax, const float Ay, const float Az, const float Aw, const float pyrx,
+                                               const float pyry, const float sc, const int x, const int y, const int cols,
+                                               const int rows, const int xlo, const int ylo, const uint8_t* const reg_o) {
+  float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
+  pp0 *= sc;
+  pp1 *= sc;
+  const float px0 = (Ax * pp0 + Ay * pp1) + pyrx;
+  const float px1 = (Az * pp0 + Aw * pp1) + pyry;
+  const bool in = !CHECK || !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
+  // vk::interpolateMat_8u (a sample outside the image is 0)
+  const float u = in ? px0 : (float)xlo, v = in ? px1 : (float)ylo;
+  const int xi = svo_dev::floor_to_int(u), yi = svo_dev::floor_to_int(v);
+  const float sx = __builtin_amdgcn_fractf(u), sy = __builtin_amdgcn_fractf(v);
+  const uint8_t* q = reg_o + (__mul24(yi, 48) + xi);
+  const float val = warp_blend(sx, sy, (float)q[0], (float)q[1], (float)q[48], (float)q[49]);
+  return in ? (uint8_t)val : (uint8_t)0;
+}
+
+// One output COLUMN x of a trial's patch, ten samples down the rows.
 template <bool CHECK>
 __device__ __forceinline__ void warp_column(const float Ax, const float Ay, const float Az, const float Aw, const float pyrx,
                                             const float pyry, const float sc, const int x, const int cols, const int rows,
                                             const int xlo, const int ylo, const uint8_t* const reg_o, uint8_t out[10]) {
 #pragma unroll
-  for (int y = 0; y < 10; ++y) {
-    float pp0 = (float)(x - 5), pp1 = (float)(y - 5);
-    pp0 *= sc;
-    pp1 *= sc;
-    const float px0 = (Ax * pp0 + Ay * pp1) + pyrx;
-    const float px1 = (Az * pp0 + Aw * pp1) + pyry;
-    const bool in = !CHECK || !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
-    // vk::interpolateMat_8u (a sample outside the image is 0)
-    const float u = in ? px0 : (float)xlo, v = in ? px1 : (float)ylo;
-    const int xi = svo_dev::floor_to_int(u), yi = svo_dev::floor_to_int(v);
-    const float sx = __builtin_amdgcn_fractf(u), sy = __builtin_amdgcn_fractf(v);
-    const float w00 = (1.0f - sx) * (1.0f - sy);
-    const float w01 = (1.0f - sx) * sy;
-    const float w10 = sx * (1.0f - sy);
-    const float w11 = 1.0f - w00 - w01 - w10;
-    const uint8_t* q = reg_o + (__mul24(yi, 48) + xi);
-    const float p00 = (float)q[0], p10 = (float)q[1], p01 = (float)q[48], p11 = (float)q[49];
-    const float val = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
-    out[y] = in ? (uint8_t)val : (uint8_t)0;
-  }
+  for (int y = 0; y < 10; ++y) out[y] = warp_sample<CHECK>(Ax, Ay, Az, Aw, pyrx, pyry, sc, x, y, cols, rows, xlo, ylo, reg_o);
 }
 
 // (Two output rows of a lane as the halves of v_pk_*_f32 operations -- the same bits -- measured 4 % slower than this

@@ -8,12 +8,13 @@
 
 extern "C" {
 
-// Scans seeds [0, S) (`form` is unused: there is one form of the scan).  One level-`n_levels` store of one slot;
-// workspace arrays as SeedWs names them (only what the scan reads and writes).
+// Warps and scans seeds [0, S) (`form` is unused: there is one form of the scan).  One level-`n_levels` store of one slot;
+// workspace arrays as SeedWs names them (only what the scan kernel reads and writes).
 int scan_emulated(int form, int S, const uint8_t* store, long long slot_bytes, int n_levels, const long long* level_offset,
                   const int* level_w, const int* level_h, const int* level_pitch, const double cam_k[4], int width, int height,
                   int subpix_refinement, const int32_t* search_level, const int32_t* cur_slot, const int32_t* n_steps, const double* B,
-                  const double* step, const uint8_t* pwb, double* uv_best, double* px_cur, double* px_scaled, uint8_t* align_active,
+                  const double* step, uint8_t* pwb, const float* A_ref_cur, const float* px_ref_pyr, const int32_t* ref_slot,
+                  const int32_t* ref_level, const int32_t* mode, double* uv_best, double* px_cur, double* px_scaled, uint8_t* align_active,
                   uint8_t* accepted_raw, int32_t* status) {
   SeedArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -35,7 +36,12 @@ int scan_emulated(int form, int S, const uint8_t* store, long long slot_bytes, i
   a.ws.n_steps = const_cast<int32_t*>(n_steps);
   a.ws.B = const_cast<double*>(B);
   a.ws.step = const_cast<double*>(step);
-  a.ws.pwb = const_cast<uint8_t*>(pwb);
+  a.ws.pwb = pwb;  // written: the warped patch of a seed that goes on to the alignment
+  a.ws.A_ref_cur = const_cast<float*>(A_ref_cur);
+  a.ws.px_ref_pyr = const_cast<float*>(px_ref_pyr);
+  a.ws.ref_slot = const_cast<int32_t*>(ref_slot);
+  a.ws.ref_level = const_cast<int32_t*>(ref_level);
+  a.ws.mode = const_cast<int32_t*>(mode);
   a.ws.uv_best = uv_best;
   a.ws.px_cur = px_cur;
   a.ws.px_scaled = px_scaled;

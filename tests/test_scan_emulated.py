@@ -26,7 +26,8 @@ def emu():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     csrc = os.path.join(ROOT, "rpg_svo_amd", "csrc")
     deps = [SRC, os.path.join(ROOT, "tests", "host", "hip_emu.h")] + [os.path.join(csrc, h) for h in
-                                                                       ("epi_scan.h", "track_math.h", "device_math.h", "pyr_addr.h", "matcher_device.h")]
+                                                                       ("epi_scan.h", "track_math.h", "device_math.h", "pyr_addr.h", "matcher_device.h",
+                                                                        "warp_group.h", "warp_sample.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         cxx = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang++")
         if not os.path.exists(cxx):
@@ -95,14 +96,37 @@ def _seeds(rng, levels, cam, S):
     return sl, n_steps, B, step, pwb, truth
 
 
-def _run(emu, form, S, store, slot_bytes, offs, ws, hs, ps, cam, size, sl, n_steps, B, step, pwb, subpix):
+ATLAS_PITCH = 16  # the templates' atlas (the last level of the test's store): one 10 x 10 patch per 16 x 16 cell
+
+
+def _atlas(pwb):
+    """The scan kernel warps its template itself (round 6).  The test hands it its templates as an image: an extra level
+    of the store with patch s in cell s; the identity warp A_ref_cur = 2^-search_level * I at the cell's centre then
+    reproduces the patch byte for byte (integer sample positions: the bilinear weights are 1, 0, 0, 0)."""
+    S = len(pwb)
+    n_col = 64
+    img = np.zeros((ATLAS_PITCH * ((S + n_col - 1) // n_col) + 8, ATLAS_PITCH * n_col + 8), np.uint8)
+    centre = np.zeros((S, 2), np.float32)
+    for s in range(S):
+        cx, cy = ATLAS_PITCH * (s % n_col) + 8, ATLAS_PITCH * (s // n_col) + 8
+        img[cy - 5:cy + 5, cx - 5:cx + 5] = pwb[s].reshape(10, 10)
+        centre[s] = (cx, cy)
+    return img, centre
+
+
+def _run(emu, form, S, store, slot_bytes, offs, ws, hs, ps, cam, size, sl, n_steps, B, step, centre, subpix):
     out = dict(uv_best=np.zeros((S, 2)), px_cur=np.zeros((S, 2)), px_scaled=np.zeros((S, 2)), align_active=np.zeros(S, np.uint8),
-               accepted_raw=np.zeros(S, np.uint8), status=np.zeros(S, np.int32))
+               accepted_raw=np.zeros(S, np.uint8), status=np.zeros(S, np.int32), pwb=np.full((S, 100), 7, np.uint8))
     cur_slot = np.zeros(S, np.int32)
-    cam_a, B, step, pwb = np.array(cam, np.float64), np.ascontiguousarray(B), np.ascontiguousarray(step), np.ascontiguousarray(pwb)
+    cam_a, B, step = np.array(cam, np.float64), np.ascontiguousarray(B), np.ascontiguousarray(step)
+    A = np.zeros((S, 4), np.float32)
+    A[:, 0] = A[:, 3] = 1.0 / (1 << sl)
+    ref_slot, ref_level, mode = np.zeros(S, np.int32), np.full(S, len(ws) - 1, np.int32), np.full(S, 2, np.int32)  # MODE_SCAN
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
     emu.scan_emulated(C.c_int(form), C.c_int(S), _p(store), C.c_longlong(slot_bytes), C.c_int(len(ws)), _p(offs), _p(ws), _p(hs), _p(ps),
                       _p(cam_a), C.c_int(size[0]), C.c_int(size[1]), C.c_int(subpix), _p(sl), _p(cur_slot), _p(n_steps),
-                      _p(B), _p(step), _p(pwb), _p(out["uv_best"]),
+                      _p(B), _p(step), _p(out["pwb"]), fp(A), fp(np.ascontiguousarray(centre)), _p(ref_slot), _p(ref_level), _p(mode),
+                      _p(out["uv_best"]),
                       _p(out["px_cur"]), _p(out["px_scaled"]), _p(out["align_active"]), _p(out["accepted_raw"]), _p(out["status"]))
     return out
 
@@ -140,18 +164,21 @@ def test_group_scan_is_the_sequential_scan(emu):
     for _ in range(2):
         p = levels[-1].astype(np.uint16)
         levels.append(((p[0::2, 0::2] + p[0::2, 1::2] + p[1::2, 0::2] + p[1::2, 1::2]) // 4).astype(np.uint8))
-    store, slot_bytes, offs, ws, hs, ps = _store(levels)
     cam, size = (300.0, 300.0, 160.0, 120.0), (320, 240)
     S = 320
     sl, n_steps, B, step, pwb, truth = _seeds(rng, levels, cam, S)
+    atlas, centre = _atlas(pwb)
+    store, slot_bytes, offs, ws, hs, ps = _store(levels + [atlas])
     n_found = 0
     for subpix in (1, 0):
-        a = _run(emu, 0, S, store, slot_bytes, offs, ws, hs, ps, cam, size, sl, n_steps, B, step, pwb, subpix)
+        a = _run(emu, 0, S, store, slot_bytes, offs, ws, hs, ps, cam, size, sl, n_steps, B, step, centre, subpix)
         matched = (a["align_active"] != 0) | (a["accepted_raw"] != 0)
         assert np.array_equal(matched, a["status"] == 0) and matched.sum() > 150 and (~matched).sum() > 20
         for s in range(S):  # the default form against the sequential scan
             best, best_uv = _numpy_scan(levels, cam, int(sl[s]), int(n_steps[s]), B[s], step[s], pwb[s])
             assert matched[s] == (best < ZMSSD_THRESHOLD), (s, best)
+            # the warped patch reaches memory for a seed that goes on to the sub-pixel alignment, and only for it
+            assert np.array_equal(a["pwb"][s], pwb[s] if matched[s] and subpix else np.full(100, 7, np.uint8)), s
             if matched[s]:
                 assert np.array_equal(a["uv_best"][s], best_uv), (s, a["uv_best"][s], best_uv)
                 n_found += int(truth[s][0] >= 0 and np.all(np.floor(a["px_scaled"][s] + 0.5).astype(int) == truth[s]))

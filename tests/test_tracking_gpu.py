@@ -552,7 +552,8 @@ def test_update_seeds(gpu_device, orc, scene, pyrs, align_1d, subpix):
             # C1*(s2+m^2) + C2*(sigma2+mu^2) - mu_new^2 in float, i.e. it carries an absolute
             # rounding noise of ~eps*mu^2 whatever its size; a and b come from (e-f)/(f-e/f).
             assert np.isclose(mu[i], so[i].mu, rtol=2e-6, atol=0), (i, mu[i], so[i].mu)
-            s2_dev.append((abs(float(s2[i]) - so[i].sigma2) / abs(so[i].sigma2), abs(float(s2[i]) - so[i].sigma2) / (6e-8 * so[i].mu ** 2)))
+            if so[i].sigma2 != 0 and so[i].mu != 0:
+                s2_dev.append((abs(float(s2[i]) - so[i].sigma2) / abs(so[i].sigma2), abs(float(s2[i]) - so[i].sigma2) / (6e-8 * so[i].mu ** 2)))
             assert abs(float(s2[i]) - so[i].sigma2) <= 1e-4 * abs(so[i].sigma2) + 1e-6 * so[i].mu ** 2, (i, s2[i], so[i].sigma2)
             if ab_known:
                 ab_dev.append(max(abs(float(a[i]) - so[i].a) / abs(so[i].a), abs(float(b[i]) - so[i].b) / abs(so[i].b)))
