@@ -1324,34 +1324,38 @@ def pmc_leg(args, kernel_ms: float, reserve_s: float = 0.0, only: tuple | None =
 
 
 def full_track_kernel_rooflines(ft: dict, pf: dict, frames_per_step: int, patches: int) -> dict:
-    """Per kernel of the full-track step: rocprofv3's duration (kernel-trace pass of pmc_full_track_leg), counter traffic,
-    and the bytes the kernel has to move AS IT IS CUT -- its inputs once, its outputs once, windows by their footprint --
-    with the fraction of the HBM roofline those bytes reach.  Formulas (bytes per unit):
+    """Per kernel (and use) of the full-track step: rocprofv3's duration (kernel-trace pass of pmc_full_track_leg), counter
+    traffic, and the bytes the kernel has to move AS IT IS CUT -- its inputs once, its outputs once, windows by their
+    footprint -- with the fraction of the HBM roofline those bytes reach.  Formulas (bytes per unit):
       match_prepare   candidate: 52 in (frame, position, observation range, projection); observation record: 52;
                       tried trial: 62 of warp / alignment parameters + 8 of results
-      warp_kernel     trial: 37 parameters + 121 footprint of the 10 x 10 template in the reference level + 100 written
-      align_kernel    trial: 100 template + 50 parameters / results; evaluation: 81 (the 9 x 9 window)
+      warp_kernel     (the matcher's) trial: 37 parameters + 121 footprint of the 10 x 10 template in the reference level + 100 written
+      align_kernel    trial: 100 template + 50 parameters / results; evaluation: 81 (the 9 x 9 window); as the depth filter's
+                      last kernel (round 6: seed_finish is its epilogue) + 96 per seed (state in / out, bearing, flags, status)
       pose_opt        frame: 52 per observation + 416
       seed_prepare    seed: 76 in (seed state, its feature, the frame indices) + 64 of warp / scan parameters
-      epi_scan        scanning seed: 148 (template + segment) + 64 + 7.13 per scanned position: the UNION of the 8 x 8
-                      windows along the segment (0.7 px apart; 8 * 0.7 * (|cos| + |sin|), 4 / pi on average) -- the 64 bytes
-                      per position of SURVEY 8(d) count every window in full although neighbours overlap by 7/8
-      seed_finish     seed: 96 (state in / out, bearing, refined pixel, flags, status)
-    The depth filter's align_kernel has no evaluation count of its own (only the matcher's launches are instrumented):
-    its bytes are left null."""
+      epi_scan        (round 6: with the affine warp) warped seed: 37 parameters + 121 footprint of the template; scanning seed:
+                      32 (segment) + 64 + 7.13 per scanned position: the UNION of the 8 x 8 windows along the segment (0.7 px apart;
+                      8 * 0.7 * (|cos| + |sin|), 4 / pi on average) -- the 64 bytes per position of SURVEY 8(d) count every window
+                      in full although neighbours overlap by 7/8; a seed that goes on to the alignment: 100 written + 36 of results
+      seed_finish     (batches up to 8192 seeds only: a launch of its own) seed: 96"""
     rl = ft.get("rooflines", {})
     fm, us = rl.get("find_match_direct", {}), rl.get("update_seeds", {})
     n_tried, M, n_obs = fm.get("trials", 0.0), fm.get("candidates", 0.0), fm.get("observations", 0.0)
     n_eval = fm.get("alignment_evaluations_per_trial", 0.0) * n_tried
     S, n_pos, S_scan = us.get("seeds", 0.0), us.get("scanned_positions_per_seed", 0.0) * us.get("seeds", 0.0), us.get("seeds_scanning", 0.0)
+    al = us.get("alignment") if isinstance(us.get("alignment"), dict) else {}
+    S_al, us_eval = al.get("aligned_seeds"), al.get("evaluations")
+    st = ft.get("seed_status_per_frame", {})
+    S_warp = frames_per_step * sum(v for k, v in st.items() if k in ("updated", "converged", "no_match", "nan")) if st else S
+    fused_finish = "update_seeds/seed_finish_kernel" not in pf.get("kernels", {})
     need = {"find_match_direct/match_prepare_kernel": M * 52.0 + n_obs * 52.0 + n_tried * 70.0,
             "find_match_direct/warp_kernel": n_tried * 258.0,
             "find_match_direct/align_kernel": n_tried * 150.0 + n_eval * 81.0,
             "pose_optimize/pose_opt_wave_kernel": frames_per_step * (patches * 52.0 + 416.0),
             "update_seeds/seed_prepare_kernel": S * 140.0,
-            "update_seeds/warp_kernel": S * 258.0,
-            "update_seeds/epi_scan_kernel": S_scan * 212.0 + n_pos * 7.13,
-            "update_seeds/align_kernel": None,
+            "update_seeds/epi_scan_kernel": S_warp * 158.0 + S_scan * 96.0 + n_pos * 7.13 + (S_al or 0.0) * 136.0,
+            "update_seeds/align_kernel": (S_al * 150.0 + us_eval * 81.0 + (S * 96.0 if fused_finish else 0.0)) if S_al is not None and us_eval is not None else None,
             "update_seeds/seed_finish_kernel": S * 96.0}
     out = {}
     for kn, kd in pf.get("kernels", {}).items():
@@ -1368,16 +1372,47 @@ def full_track_kernel_rooflines(ft: dict, pf: dict, frames_per_step: int, patche
 
 
 FULL_TRACK_KERNELS = {"find_match_direct": ("match_prepare_kernel", "warp_kernel", "align_kernel"),
-                      "update_seeds": ("seed_prepare_kernel", "warp_kernel", "epi_scan_kernel", "align_kernel", "seed_finish_kernel"),
+                      "update_seeds": ("seed_prepare_kernel", "epi_scan_kernel", "align_kernel", "seed_finish_kernel"),
                       "pose_optimize": ("pose_opt_wave_kernel", "pose_opt_kernel")}
+# the kernel that OPENS a stage of the step (FullTrack.step): whatever is dispatched after it belongs to that stage until the
+# next opener.  align_kernel (and, in round 5, warp_kernel) serves two stages: its launches are told apart by where they
+# stand in the dispatch order, per launch, not by name -- also for the counter passes
+STAGE_OPENERS = {"match_prepare_kernel": "find_match_direct", "pose_opt_wave_kernel": "pose_optimize", "seed_prepare_kernel": "update_seeds"}
+
+
+def attribute_dispatches(rows: list, n_steps: int) -> dict:
+    """rows: (order key, kernel short name, {quantity: value}) of ONE child run of `bench.py --pipeline full`, any order.
+    Returns {"stage/kernel": {quantity: mean over the last n_steps steps of the per-step SUM, "launches_per_step": ...}}.
+    A step starts at its match_prepare_kernel; what precedes the first of the last n_steps steps (the workload's set-up
+    launches the same kernels) is dropped."""
+    rows = sorted(rows, key=lambda r: r[0])
+    starts = [i for i, r in enumerate(rows) if r[1] == "match_prepare_kernel"]
+    if len(starts) < n_steps:
+        return {}
+    first = starts[-n_steps]
+    acc, stage, step = {}, None, -1
+    for _, short, q in rows[first:]:
+        if short == "match_prepare_kernel":
+            step += 1
+        stage = STAGE_OPENERS.get(short, stage)
+        if stage is None or short not in FULL_TRACK_KERNELS[stage]:
+            continue
+        e = acc.setdefault(f"{stage}/{short}", {})
+        for k, v in q.items():
+            e[k] = e.get(k, 0.0) + v
+        e["_launches"] = e.get("_launches", 0) + 1
+    out = {}
+    for kn, e in acc.items():
+        out[kn] = {k: v / n_steps for k, v in e.items() if k != "_launches"}
+        out[kn]["launches_per_step"] = e["_launches"] / n_steps
+    return out
 
 
 def pmc_full_track_leg(args, n_steps: int = 2) -> dict:
-    """HBM traffic of the kernels of the full-track step (configs[2], representative workload), per kernel and per
-    stage: two child runs of `bench.py --pipeline full` under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE; one counter
-    per pass, corrected as for K1).  warp_kernel and align_kernel run twice per step -- first for findMatchDirect,
-    then for the depth filter -- and are told apart by their position in the dispatch order; the set-up of the
-    workload launches the same kernels, so only the dispatches of the last `n_steps` steps are read."""
+    """The kernels of the full-track step (configs[2], representative workload), per STAGE and KERNEL: child runs of
+    `bench.py --pipeline full` under rocprofv3 -- a kernel trace (durations), FETCH_SIZE and WRITE_SIZE (one counter per
+    pass, corrected as for K1), an SQ pass (VALU issue, waiting) and an LDS pass -- each attributed per dispatch by its
+    place in the step (attribute_dispatches), so that the two uses of align_kernel have their own rows in every pass."""
     import csv
     import glob
     import shutil
@@ -1390,61 +1425,51 @@ def pmc_full_track_leg(args, n_steps: int = 2) -> dict:
             "--pmc-child", "1", "--pipeline", "full"]
     env = dict(os.environ, TMPDIR="/tmp")
     env.pop("SVO_BENCH_FORCE_DIST", None)
-    regex = "|".join(sorted({k for ks in FULL_TRACK_KERNELS.values() for k in ks}))
-    per = {}  # counter -> kernel short name -> [values in dispatch order]
+    names = sorted({k for ks in FULL_TRACK_KERNELS.values() for k in ks}, key=len, reverse=True)  # (longest first: pose_opt_wave_kernel / pose_opt_kernel)
+    regex = "|".join(names)
+    short_of = lambda kn: next((k for k in names if k in kn), None)
     status = {}
-    for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        d = tempfile.mkdtemp(prefix=f"svo_pmc_full_{name}_", dir="/tmp")
-        cmd = [exe, "--pmc", ctr, "--kernel-include-regex", regex, "--output-format", "csv", "-d", d, "-o", name, "--", *base]
+
+    def counter_pass(tag, ctrs, timeout_s=2 * PMC_PASS_TIMEOUT_S):
+        """one child under --pmc: {stage/kernel: {counter: per-step sum}}"""
+        d = tempfile.mkdtemp(prefix=f"svo_pmc_full_{tag}_", dir="/tmp")
         try:
-            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=2 * PMC_PASS_TIMEOUT_S)
+            cmd = [exe, "--pmc", *ctrs, "--kernel-include-regex", regex, "--output-format", "csv", "-d", d, "-o", tag, "--", *base]
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                status[tag] = f"rc={p.returncode}: {p.stderr[-200:]}"
+                return None
+            by_dispatch = {}
+            with open(files[0]) as fh:
+                for row in csv.DictReader(fh):
+                    short = short_of(row["Kernel_Name"])
+                    if short and row.get("Counter_Name") in ctrs:
+                        e = by_dispatch.setdefault(int(row["Dispatch_Id"]), (short, {}))
+                        e[1][row["Counter_Name"]] = e[1].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            status[tag] = "ok"
+            return attribute_dispatches([(did, sh, q) for did, (sh, q) in by_dispatch.items()], n_steps)
         except subprocess.TimeoutExpired:
-            status[name] = "timeout"
-            break
-        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-        if p.returncode != 0 or not files:
-            status[name] = f"rc={p.returncode}: {p.stderr[-200:]}"
-            break
-        rows = []
-        with open(files[0]) as fh:
-            for row in csv.DictReader(fh):
-                if row.get("Counter_Name") == ctr:
-                    rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"], float(row["Counter_Value"])))
-        rows.sort()
-        acc = per.setdefault(ctr, {})
-        for _, kn, v in rows:
-            short = next((k for k in regex.split("|") if k in kn), None)
-            if short:
-                acc.setdefault(short, []).append(v)
-        status[name] = "ok"
-        shutil.rmtree(d, ignore_errors=True)
-    if "FETCH_SIZE" not in per or "WRITE_SIZE" not in per:
+            status[tag] = "timeout"
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
+    fetch = counter_pass("fetch", ["FETCH_SIZE"])
+    write = counter_pass("write", ["WRITE_SIZE"]) if fetch is not None else None
+    if fetch is None or write is None:
         return {"passes": status}
-
-    def per_launch(kernel, which, calls_per_step):
-        """bytes per launch (FETCH doubled + WRITE, KiB) of the `which`-th of calls_per_step launches of a step"""
-        out = []
-        for ctr, scale in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
-            v = per[ctr].get(kernel, [])
-            v = v[len(v) - n_steps * calls_per_step:]  # the timed steps come last
-            v = v[which::calls_per_step]
-            out.append(scale * float(np.mean(v)) * 1024.0 if v else float("nan"))
-        return out[0] + out[1]
-
-    twice = ("warp_kernel", "align_kernel")
     stages = {}
-    for stage, kernels in FULL_TRACK_KERNELS.items():
-        kb = {}
-        for k in kernels:
-            if k in twice:
-                kb[k] = per_launch(k, 0 if stage == "find_match_direct" else 1, 2)
-            else:
-                kb[k] = per_launch(k, 0, 1)
-        stages[stage] = {"traffic_bytes_per_step": float(np.nansum(list(kb.values()))), "by_kernel": kb}
+    traffic = {}
+    for kn in sorted(set(fetch) | set(write)):
+        t = (2.0 * fetch.get(kn, {}).get("FETCH_SIZE", 0.0) + write.get(kn, {}).get("WRITE_SIZE", 0.0)) * 1024.0  # KiB; FETCH doubled (gfx950)
+        traffic[kn] = t
+        stage, short = kn.split("/")
+        st = stages.setdefault(stage, {"traffic_bytes_per_step": 0.0, "by_kernel": {}})
+        st["by_kernel"][short] = t
+        st["traffic_bytes_per_step"] += t
 
-    # ---- per kernel: duration (a kernel-trace pass of the same child) and VALU issue (an SQ counter pass) --------------
-    # align_kernel runs in up to three phased launches per use: its launches of a step are summed per use (the first
-    # half of a step's align launches belongs to findMatchDirect -- it is enqueued first -- the rest to the depth filter)
+    # ---- per kernel and use: duration (a kernel-trace pass of the same child) ------------------------------------------
     kernels = {}
     try:
         d = tempfile.mkdtemp(prefix="svo_trace_full_", dir="/tmp")
@@ -1457,108 +1482,42 @@ def pmc_full_track_leg(args, n_steps: int = 2) -> dict:
             rows = []
             with open(files[0]) as fh:
                 for row in csv.DictReader(fh):
-                    short = next((k for k in regex.split("|") if k in row["Kernel_Name"]), None)
+                    short = short_of(row["Kernel_Name"])
                     if short:
-                        rows.append((int(row["Start_Timestamp"]), short, (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6))
-            rows.sort()
-            # the timed steps come last: cut at the last n_steps launches of seed_finish_kernel (one per step, the step's last kernel)
-            ends = [i for i, r in enumerate(rows) if r[1] == "seed_finish_kernel"]
-            first = ends[-n_steps - 1] + 1 if len(ends) > n_steps else 0
-            per_step = {}
-            for _, short, ms in rows[first:]:
-                per_step.setdefault(short, []).append(ms)
-            for short, v in per_step.items():
-                if short in twice:
-                    # dispatch order inside a step: findMatchDirect's launches, then the depth filter's
-                    n_per_step = len(v) // n_steps
-                    steps = [v[i * n_per_step:(i + 1) * n_per_step] for i in range(n_steps)]
-                    if short == "warp_kernel":
-                        kernels["find_match_direct/warp_kernel"] = {"ms": float(np.mean([st[0] for st in steps])), "launches_per_step": 1}
-                        kernels["update_seeds/warp_kernel"] = {"ms": float(np.mean([sum(st[1:]) for st in steps])), "launches_per_step": n_per_step - 1}
-                    else:
-                        h = n_per_step // 2
-                        kernels["find_match_direct/align_kernel"] = {"ms": float(np.mean([sum(st[:h]) for st in steps])), "launches_per_step": h}
-                        kernels["update_seeds/align_kernel"] = {"ms": float(np.mean([sum(st[h:]) for st in steps])), "launches_per_step": n_per_step - h}
-                else:
-                    stage = next(sg for sg, ks in FULL_TRACK_KERNELS.items() if short in ks)
-                    kernels[f"{stage}/{short}"] = {"ms": float(np.sum(v) / n_steps), "launches_per_step": len(v) / n_steps}
+                        rows.append((int(row["Start_Timestamp"]), short, {"ms": (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6}))
+            kernels = attribute_dispatches(rows, n_steps)
             status["trace"] = "ok"
         shutil.rmtree(d, ignore_errors=True)
     except subprocess.TimeoutExpired:
         status["trace"] = "timeout"
-    try:
-        d = tempfile.mkdtemp(prefix="svo_pmc_full_sq_", dir="/tmp")
-        ctrs = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU",
-                "SQ_BUSY_CU_CYCLES"]
-        cmd = [exe, "--pmc", *ctrs, "--kernel-include-regex", regex, "--output-format", "csv", "-d", d, "-o", "sq", "--", *base]
-        p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=2 * PMC_PASS_TIMEOUT_S)
-        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-        if p.returncode != 0 or not files:
-            status["sq"] = f"rc={p.returncode}: {p.stderr[-200:]}"
-        else:
-            rows = []
-            with open(files[0]) as fh:
-                for row in csv.DictReader(fh):
-                    short = next((k for k in regex.split("|") if k in row["Kernel_Name"]), None)
-                    if short:
-                        rows.append((int(row["Dispatch_Id"]), short, row["Counter_Name"], float(row["Counter_Value"])))
-            rows.sort()
-            by = {}
-            for did, short, cn, v in rows:
-                by.setdefault(short, {}).setdefault(cn, []).append(v)
-            for short, cs in by.items():
-                # per-launch averages over every launch of the kernel in the child run (the set-up of the workload launches the
-                # same kernels on the same kind of data); warp / align: both uses together.  The ratio does not depend on the
-                # launch's size: instruction counts over the busy-CU cycles of the same launch
-                raw = {cn: float(np.mean(v)) for cn, v in cs.items()}
-                if raw.get("SQ_BUSY_CU_CYCLES", 0) > 0 and raw.get("SQ_INSTS_VALU", 0) > 0:
-                    vr = valu_roofline(raw, 1.0)
-                    for kn in kernels:
-                        if kn.endswith("/" + short):
-                            kernels[kn]["valu"] = {"busy_frac_at_3_cycles_per_instruction": vr["frac"],
-                                                   "busy_frac_lower_bound_2_cycles": vr["lower_bound_2_cycles_per_instruction"],
-                                                   "wave_cycles_waiting_frac": vr["wave_cycles_waiting_frac"],
-                                                   "wave_cycles_at_waitcnt_frac": vr["wave_cycles_at_waitcnt_frac"]}
-            status["sq"] = "ok"
-        shutil.rmtree(d, ignore_errors=True)
-    except subprocess.TimeoutExpired:
-        status["sq"] = "timeout"
-    # ---- LDS pass: how busy the CU's one LDS port is (the four SIMDs of a CU share it) ----------------------------------
-    try:
-        d = tempfile.mkdtemp(prefix="svo_pmc_full_lds_", dir="/tmp")
-        ctrs = ["SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS", "SQ_WAVE_CYCLES",
-                "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"]
-        cmd = [exe, "--pmc", *ctrs, "--kernel-include-regex", regex, "--output-format", "csv", "-d", d, "-o", "lds", "--", *base]
-        p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=2 * PMC_PASS_TIMEOUT_S)
-        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-        if p.returncode != 0 or not files:
-            status["lds"] = f"rc={p.returncode}: {p.stderr[-200:]}"
-        else:
-            by = {}
-            with open(files[0]) as fh:
-                for row in csv.DictReader(fh):
-                    short = next((k for k in regex.split("|") if k in row["Kernel_Name"]), None)
-                    if short:
-                        by.setdefault(short, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-            for short, cs in by.items():
-                raw = {cn: float(np.mean(v)) for cn, v in cs.items()}
-                lds = lds_port_use(raw)
-                for kn in kernels:
-                    if kn.endswith("/" + short):
-                        kernels[kn]["lds"] = lds
-            status["lds"] = "ok"
-        shutil.rmtree(d, ignore_errors=True)
-    except subprocess.TimeoutExpired:
-        status["lds"] = "timeout"
+    # ---- VALU issue and waiting; the LDS port (the four SIMDs of a CU share it) -----------------------------------------
+    sq = counter_pass("sq", ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+                             "SQ_INSTS_VALU", "SQ_BUSY_CU_CYCLES"]) if kernels else None
+    for kn, raw in (sq or {}).items():
+        if kn in kernels and raw.get("SQ_BUSY_CU_CYCLES", 0) > 0 and raw.get("SQ_INSTS_VALU", 0) > 0:
+            vr = valu_roofline(raw, 1.0)
+            kernels[kn]["valu"] = {"busy_frac_at_3_cycles_per_instruction": vr["frac"],
+                                   "busy_frac_lower_bound_2_cycles": vr["lower_bound_2_cycles_per_instruction"],
+                                   "wave_cycles_waiting_frac": vr["wave_cycles_waiting_frac"],
+                                   "wave_cycles_at_waitcnt_frac": vr["wave_cycles_at_waitcnt_frac"],
+                                   "valu_instructions_per_step": raw["SQ_INSTS_VALU"]}
+    lds = counter_pass("lds", ["SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS",
+                               "SQ_WAVE_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"]) if kernels else None
+    for kn, raw in (lds or {}).items():
+        if kn in kernels:
+            try:
+                kernels[kn]["lds"] = lds_port_use(raw)
+            except Exception as e:
+                kernels[kn]["lds"] = {"skipped": repr(e)}
     for kn, kd in kernels.items():
-        stage, short = kn.split("/")
-        t = stages.get(stage, {}).get("by_kernel", {}).get(short)
+        t = traffic.get(kn)
         if t is not None and t == t:
             kd["traffic_bytes"] = t
-            kd["traffic_GBs"] = t / (kd["ms"] * 1e-3) / 1e9 if kd["ms"] > 0 else None
+            kd["traffic_GBs"] = t / (kd["ms"] * 1e-3) / 1e9 if kd.get("ms", 0) > 0 else None
     return {"passes": status, "stages": stages, "kernels": kernels,
-            "how": f"child runs of `bench.py --pipeline full` ({n_steps} steps) under rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in "
-                   "separate passes, KiB, FETCH_SIZE doubled (gfx950); per kernel launch, averaged over the steps"}
+            "how": f"child runs of `bench.py --pipeline full` ({n_steps} steps) under rocprofv3: kernel trace, then --pmc passes "
+                   "(FETCH_SIZE and WRITE_SIZE separately, KiB, FETCH_SIZE doubled on gfx950; SQ; LDS), every dispatch attributed to "
+                   "its stage by its place in the step, counters summed per step and averaged over the steps"}
 
 
 def pyramid_roofline(ev: Events, store, images, reps: int = 5) -> dict:
@@ -2347,6 +2306,24 @@ class FullTrack:
         capi.check(lib.svo_hip_memcpy_d2d(scan.data_ptr(), steps_ptr, S * 4, stream), "svo_hip_memcpy_d2d")
         torch.cuda.synchronize()
         n_scan = float(scan.sum().item())
+        # residual evaluations of the depth filter's sub-pixel alignment: one more update with the instrumented alignment
+        # kernel (svo_hip_update_seeds_count_evaluations; outside every timed region, the same seeds, the same results)
+        seed_evals = None
+        try:
+            lib.svo_hip_update_seeds_count_evaluations(1)
+            for k, v in self.seed0.items():
+                getattr(self.seeds, k).copy_(v)
+            self.df.update_seeds(self.store, self.cam, self.frames, self.seed_cur, self.seed_ftr, self.seeds, 0, out=self.seed_out)
+            ev_ptr = lib.svo_hip_update_seeds_align_evaluations(self.df.last_workspace.data_ptr(), S)
+            evs = torch.empty(S, dtype=torch.int32, device=dev)
+            capi.check(lib.svo_hip_memcpy_d2d(evs.data_ptr(), ev_ptr, S * 4, stream), "svo_hip_memcpy_d2d")
+            torch.cuda.synchronize()
+            seed_evals = {"aligned_seeds": float((evs > 0).sum().item()), "evaluations": float(evs.sum().item()),
+                          "evaluations_per_wave_of_64_seeds": float(evs[: (S // 64) * 64].view(-1, 64).max(dim=1).values.float().mean().item())}
+        except Exception as e:
+            seed_evals = {"skipped": repr(e)}
+        finally:
+            lib.svo_hip_update_seeds_count_evaluations(0)
         seed_bytes = S * 36.0 + 64.0 * n_scan + S * (121.0 + 100.0)
         edges = [0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1001]
         scan_hist = {f"{lo}..{hi - 1}": float(((scan >= lo) & (scan < hi)).sum().item() / self.B) for lo, hi in zip(edges[:-1], edges[1:])}
@@ -2361,8 +2338,9 @@ class FullTrack:
                                           alignment_evaluations_histogram=eval_hist,
                                           alignment_evaluations_per_wave_of_64_trials=wave_max_mean),
             "pose_optimize": roofline("pose_opt_wave_kernel", B * (N * 52.0 + 416.0), stages["pose_optimize"]),
-            "update_seeds": roofline("seed_prepare + warp_kernel + epi_scan + align_kernel + seed_finish", seed_bytes,
+            "update_seeds": roofline("seed_prepare + epi_scan (with the affine warp) + align_kernel (with seed_finish)", seed_bytes,
                                      stages["update_seeds"], seeds=S, scanned_positions_per_seed=n_scan / S,
+                                     alignment=seed_evals,
                                      seeds_scanning=float((scan > 0).sum().item()),
                                      scanned_positions_per_seed_by_kind=scan_by_kind, scanned_positions_per_seed_by_age=scan_by_age,
                                      seeds_per_frame_by_scanned_positions=scan_hist),

@@ -651,6 +651,16 @@ int svo_hip_find_epipolar_match_direct(const svo_hip_pyr_layout* layout, const u
  * roofline accounting (64 B scanned per step). */
 const int32_t* svo_hip_update_seeds_scan_steps(const void* d_workspace);
 
+/* Roofline accounting of the depth filter's sub-pixel alignment (feature_alignment.cpp:30-277 inside
+ * Matcher::findEpipolarMatchDirect, matcher.cpp:295-315): with counting switched on (process-wide, off by default;
+ * returns the previous setting) svo_hip_update_seeds* and svo_hip_find_epipolar_match_direct run the instrumented
+ * alignment kernel, which also stores the number of residual evaluations (9 x 9 windows read) of every seed;
+ * svo_hip_update_seeds_align_evaluations is the device pointer to that array [S] inside the workspace of the last
+ * such call with S seeds (0 for a seed that did not reach the alignment; undefined while counting was off).
+ * Results do not depend on the switch. */
+int svo_hip_update_seeds_count_evaluations(int on);
+const int32_t* svo_hip_update_seeds_align_evaluations(const void* d_workspace, int S);
+
 /* DepthFilter::updateSeed(x, tau2, seed) for S independent (x, tau2) measurements */
 int svo_hip_update_seed_batch(int S, const float* d_x, const float* d_tau2,
                               const svo_hip_seeds* seeds, void* stream);

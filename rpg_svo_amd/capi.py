@@ -166,6 +166,8 @@ PROTOTYPES = {
     "svo_hip_align_workspace_bytes": (C.c_size_t, [_i]),
     "svo_hip_align_batch_phased": (_i, [_LP, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "svo_hip_update_seeds_scan_steps": (_vp, [_vp]),
+    "svo_hip_update_seeds_count_evaluations": (C.c_int, [C.c_int]),
+    "svo_hip_update_seeds_align_evaluations": (_vp, [_vp, C.c_int]),
     "svo_hip_match_workspace_bytes": (C.c_size_t, [_i]),
     "svo_hip_find_match_direct": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, _vp, _vp,
                                        C.POINTER(Features), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),

@@ -88,7 +88,8 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
   // then subtractions and fused multiply-adds, no integer extraction.
   typedef float f2 __attribute__((ext_vector_type(2)));
   float H[9];
-  f2 G[64];  // {dx, dy} of every template pixel (:176-181), formed once
+  // Round 6: the 64 gradient pairs are NOT kept (128 registers: two waves per SIMD).  The pixel loop re-forms them row by
+  // row from the template rows it converts anyway (see there); here only their sums are needed.
   {
     float sxx = 0.f, sxy = 0.f, syy = 0.f, sx = 0.f, sy = 0.f;
 #pragma unroll
@@ -103,7 +104,6 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
         syy = __builtin_fmaf(gy2, gy2, syy);
         sx += gx2;
         sy += gy2;
-        G[8 * y + x] = (f2){0.5f * gx2, 0.5f * gy2};  // == 0.5f * (float)(int difference): the difference is exact either way
       }
     H[0] = 0.25f * sxx;
     H[1] = H[3] = 0.25f * sxy;
@@ -151,8 +151,20 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
     // as left AND right neighbour pair -- and the two gradient products of a pixel form a pair for the accumulation:
     // {Jres0, Jres1} -= {res, res} * {dx, dy}, pixel after pixel in raster order (the third sum stays scalar).
     const f2 wTL2 = {wTL, wTL}, wTR2 = {wTR, wTR}, wBL2 = {wBL, wBL}, wBR2 = {wBR, wBR}, md2 = {mean_diff, mean_diff};
+    // The gradients of a template row are differences of the rows the loop converts anyway: three rows of the 10 x 10
+    // template as floats, rolling (Tm: above, Tc: the row under the window row, Tp: below), one conversion per byte as
+    // before plus the two border bytes of a row, and 16 subtractions per row.  They are used DOUBLED (2 dx, 2 dy: exact byte
+    // differences): scaling every term of the reference's sequential sum by two scales every partial sum by exactly two
+    // (binary floating point, no overflow or underflow anywhere near), so {2 Jres0, 2 Jres1} come out with the reference's
+    // mantissas and are halved once at the end -- the same bits, without the 128 registers of a gradient cache.
     f2 J01 = {0.f, 0.f};
     f2 Q0[5], Q1[5];
+    float Tm[10], Tc[10], Tp[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      Tm[k] = (float)PWB(k);
+      Tc[k] = (float)PWB(10 + k);
+    }
 #pragma unroll
     for (int k = 0; k < 5; ++k) Q0[k] = (f2){P0[k], P0[k + 4]};
 #pragma unroll
@@ -160,25 +172,32 @@ __device__ __forceinline__ bool align2d_lane(const uint8_t* __restrict__ img, in
       cut_row9(win[y + 1], wsel, P1);
 #pragma unroll
       for (int k = 0; k < 5; ++k) Q1[k] = (f2){P1[k], P1[k + 4]};
+#pragma unroll
+      for (int k = 0; k < 10; ++k) Tp[k] = (float)PWB((y + 2) * 10 + k);
       f2 res2[4];
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
-        const int c = (y + 1) * 10 + x + 1;
         const f2 sp = wTL2 * Q0[x] + wTR2 * Q0[x + 1] + wBL2 * Q1[x] + wBR2 * Q1[x + 1];
-        const f2 ref2 = {(float)PWB(c), (float)PWB(c + 4)};
+        const f2 ref2 = {Tc[x + 1], Tc[x + 5]};
         res2[x] = sp - ref2 + md2;
       }
 #pragma unroll
       for (int x = 0; x < 8; ++x) {  // raster order: x = 0..3 are the low halves, 4..7 the high halves
         const float res = (x < 4) ? res2[x].x : res2[x - 4].y;
-        J01 -= (f2){res, res} * G[8 * y + x];
+        const f2 g2 = {Tc[x + 2] - Tc[x], Tp[x + 1] - Tm[x + 1]};  // {2 dx, 2 dy} of template pixel (x, y)
+        J01 -= (f2){res, res} * g2;
         Jres2 -= res;
       }
 #pragma unroll
       for (int k = 0; k < 5; ++k) Q0[k] = Q1[k];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        Tm[k] = Tc[k];
+        Tc[k] = Tp[k];
+      }
     }
-    Jres0 = J01.x;
-    Jres1 = J01.y;
+    Jres0 = 0.5f * J01.x;
+    Jres1 = 0.5f * J01.y;
     const float up0 = Hinv[0] * Jres0 + Hinv[1] * Jres1 + Hinv[2] * Jres2;
     const float up1 = Hinv[3] * Jres0 + Hinv[4] * Jres1 + Hinv[5] * Jres2;
     const float up2 = Hinv[6] * Jres0 + Hinv[7] * Jres1 + Hinv[8] * Jres2;
@@ -204,7 +223,8 @@ __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, in
   n_eval = 0;
   float u = st.u, v = st.v;
   float H[4] = {0, 0, 0, 0};
-  float Jd[64];  // the directional derivative of every template pixel (:53-56), formed once
+  // (the directional derivative of every template pixel, :53-56, is not kept -- 64 registers -- but re-formed in the pixel
+  // loop from the template rows converted there, as align2D does with its gradients)
 #pragma unroll
   for (int y = 0; y < 8; ++y)
 #pragma unroll
@@ -213,7 +233,6 @@ __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, in
       // J[0] = 0.5*(dir[0]*(it[1]-it[-1]) + dir[1]*(it[ref_step]-it[-ref_step]))  (double 0.5 * float)
       const float s = dir0 * (float)(PWB(c + 1) - PWB(c - 1)) + dir1 * (float)(PWB(c + 10) - PWB(c - 10));
       const float J0 = (float)(0.5 * (double)s);
-      Jd[8 * y + x] = J0;
       H[0] += J0 * J0;
       H[1] += J0 * 1.f;
       H[2] += 1.f * J0;
@@ -255,20 +274,35 @@ __device__ __forceinline__ bool align1d_lane(const uint8_t* __restrict__ img, in
     uint32_t win[9][3];
     svo_pyr::load_window12<9>(img, pitch, wxa, v_r - 4, win);
     cut_row9(win[0], wsel, P0);
+    // three rows of the template as floats, rolling (above / under the window row / below): the byte differences of
+    // :53-56 are differences of these (exact), and 0.5 * (double)s rounded to float is 0.5f * s
+    float Tm[10], Tc[10], Tp[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      Tm[k] = (float)PWB(k);
+      Tc[k] = (float)PWB(10 + k);
+    }
 #pragma unroll
     for (int y = 0; y < 8; ++y) {
       cut_row9(win[y + 1], wsel, P1);
 #pragma unroll
+      for (int k = 0; k < 10; ++k) Tp[k] = (float)PWB((y + 2) * 10 + k);
+#pragma unroll
       for (int x = 0; x < 8; ++x) {
-        const int c = (y + 1) * 10 + x + 1;
         const float search_pixel = wTL * P0[x] + wTR * P0[x + 1] + wBL * P1[x] + wBR * P1[x + 1];
-        const float res = search_pixel - (float)PWB(c) + mean_diff;
-        Jres0 -= res * Jd[8 * y + x];
+        const float res = search_pixel - Tc[x + 1] + mean_diff;
+        const float s = dir0 * (Tc[x + 2] - Tc[x]) + dir1 * (Tp[x + 1] - Tm[x + 1]);
+        Jres0 -= res * (0.5f * s);
         Jres1 -= res;
         new_chi2 += res * res;
       }
 #pragma unroll
       for (int k = 0; k < 9; ++k) P0[k] = P1[k];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        Tm[k] = Tc[k];
+        Tc[k] = Tp[k];
+      }
     }
     if (iter > 0 && new_chi2 > chi2) {
       u -= up0;  // sic (:116-117)

@@ -22,6 +22,8 @@
 // List surgery (erasing seeds, creating svo::Point objects, the converged callback) stays on
 // the host: the kernel reports a status per seed and the new point's position.
 #pragma clang fp contract(off)
+#include <atomic>
+
 #include "track_kernels.h"
 #include "track_math.h"
 #include "matcher_device.h"
@@ -264,106 +266,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK, SCAN_MINW) epi_scan_kernel(const S
 __global__ void SEED_FINISH_BOUNDS seed_finish_kernel(const SeedArgs a) {
   const int s = blockIdx.x * 64 + threadIdx.x;
   if (s >= a.S) return;
-  const SeedWs& w = a.ws;
-  // every record the seed may need is requested before the first early exit, as in seed_prepare_kernel (259 -> 243 us).
-  // Workspace words of a seed that did not get that far hold whatever they held: read, not used.
-  const int cf = a.cur_frame ? a.cur_frame[s] : a.cur_index;
-  const int rec = a.slot_of ? a.slot_of[s] : s;  // the seed's record (resident store: its slot)
-  const int rfi = a.ftr.d_frame[rec];
-  const int aok_early = w.align_ok[s];
-  const double pxc0 = w.px_cur[2 * s], pxc1 = w.px_cur[2 * s + 1];
-  const double f[3] = {a.ftr.d_f[3 * rec], a.ftr.d_f[3 * rec + 1], a.ftr.d_f[3 * rec + 2]};
-  float sa = 0.f, sb = 0.f, smu = 0.f, ssig = 0.f, zr_early = 0.f;
-  if (!a.match_only) {
-    sa = a.seeds.d_a[rec]; sb = a.seeds.d_b[rec]; smu = a.seeds.d_mu[rec]; ssig = a.seeds.d_sigma2[rec];
-    zr_early = a.seeds.d_z_range[rec];
-  }
-  double RtR[12], RtC[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) {
-    RtR[k] = a.frame_T[12 * rfi + k];
-    RtC[k] = a.frame_T[12 * cf + k];
-  }
-  int status = w.status[s];
-  const bool aligned = w.align_active[s] != 0;  // a short segment, or a scan match handed to the sub-pixel alignment
-  if (a.px_cur_out) {
-    // Matcher::px_cur_ exists once the seed reached the alignment (set by seed_prepare for a short segment, by the scan
-    // for a match, refined by the alignment) or was accepted straight from the scan; 0 otherwise
-    const bool has_px = aligned || w.accepted_raw[s] != 0;
-    a.px_cur_out[2 * s] = has_px ? pxc0 : 0.0;
-    a.px_cur_out[2 * s + 1] = has_px ? pxc1 : 0.0;
-  }
-  if (status == SVO_HIP_SEED_ERASED_OLD || status == SVO_HIP_SEED_BEHIND || status == SVO_HIP_SEED_NOT_IN_FRAME) {
-    a.status_out[s] = status;
-    return;
-  }
-  Se3 Tr, Tc;
-  se3_from_Rt(RtR, Tr);
-  se3_from_Rt(RtC, Tc);
-  bool matched = false;
-  double z = 0;
-  if (status == 0) {
-    const int aok = aligned ? aok_early : 0;
-    const Se3 T_cur_ref = se3_compose(Tc, se3_inverse(Tr));
-    if (aligned && aok == 1) {
-      // px_cur_ = px_scaled*(1<<search_level_) was written by the alignment kernel
-      double fc[3];
-      cam2world(a.cam, pxc0, pxc1, fc);
-      matched = depth_from_triangulation(T_cur_ref, f, fc, &z);
-    } else if (w.accepted_raw[s]) {
-      // subpix_refinement == false: vk::unproject2d(uv_best).normalized()
-      double fc[3] = {w.uv_best[2 * s], w.uv_best[2 * s + 1], 1.0};
-      normalize3(fc);
-      matched = depth_from_triangulation(T_cur_ref, f, fc, &z);
-    }
-  }
-  if (a.match_only) {  // findEpipolarMatchDirect's own outputs: the verdict, depth, px_cur_, search_level_
-    a.ok_out[s] = matched ? 1 : 0;
-    a.depth_out[s] = matched ? z : 0.0;
-    if (a.search_level_out) a.search_level_out[s] = w.search_level[s];
-    return;
-  }
-  const float zr = zr_early;
-  if (!matched) {
-    a.seeds.d_b[rec] = sb + 1.0f;  // it->b++ (:240)
-    if (a.state_out) {
-      a.state_out[s] = sa; a.state_out[a.S + s] = sb + 1.0f; a.state_out[2 * a.S + s] = smu; a.state_out[3 * a.S + s] = ssig;
-    }
-    a.status_out[s] = SVO_HIP_SEED_NO_MATCH;
-    return;
-  }
-  // law of chord (depth_filter.cpp:252-255): atan(px_noise / (2 * focal_length)) * 2 depends on the camera alone -- computed
-  // once on the host (run_seed_chain), by the libm the reference itself runs on
-  const Se3 T_ref_cur = se3_compose(Tr, se3_inverse(Tc));
-  const double tau = compute_tau(T_ref_cur, f, z, a.tau_k);
-  const double zmt = (0.0000001 < z - tau) ? z - tau : 0.0000001;
-  const double tau_inverse = 0.5 * (1.0 / zmt - 1.0 / (z + tau));
-  update_seed((float)(1. / z), (float)(tau_inverse * tau_inverse), sa, sb, smu, zr, ssig);
-  a.seeds.d_a[rec] = sa;
-  a.seeds.d_b[rec] = sb;
-  a.seeds.d_mu[rec] = smu;
-  a.seeds.d_sigma2[rec] = ssig;
-  if (a.state_out) {
-    a.state_out[s] = sa; a.state_out[a.S + s] = sb; a.state_out[2 * a.S + s] = smu; a.state_out[3 * a.S + s] = ssig;
-  }
-  if ((double)sqrtf(ssig) < (double)zr / a.opt.seed_convergence_sigma2_thresh) {
-    const Se3 Tr_inv = se3_inverse(Tr);
-    const double kk = 1.0 / (double)smu;
-    const double pw[3] = {f[0] * kk, f[1] * kk, f[2] * kk};
-    double xw[3];
-    se3_apply(Tr_inv, pw, xw);
-    if (a.xyz_world) {
-      a.xyz_world[3 * s] = xw[0];
-      a.xyz_world[3 * s + 1] = xw[1];
-      a.xyz_world[3 * s + 2] = xw[2];
-    }
-    status = SVO_HIP_SEED_CONVERGED;
-  } else if (isnan(w.z_inv_min[s])) {
-    status = SVO_HIP_SEED_NAN;
-  } else {
-    status = SVO_HIP_SEED_UPDATED;
-  }
-  a.status_out[s] = status;
+  seed_finish_seed<false>(a, s, false, 0, 0.0, 0.0);
 }
 
 struct SeedOnlyArgs {
@@ -418,6 +321,7 @@ extern "C" int svo_hip_compute_tau_batch(int S, const double* d_t_ref_cur, const
 
 static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_store, SeedArgs& a, int S, void* d_workspace,
                           size_t workspace_bytes, hipStream_t st);
+static std::atomic<bool> g_count_evaluations{false};  // svo_hip_update_seeds_count_evaluations
 
 extern "C" int svo_hip_find_epipolar_match_direct(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
                                                   const svo_hip_camera* cam, const svo_hip_frames* frames, int S,
@@ -611,6 +515,7 @@ static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_sto
   }
   SeedWs& w = a.ws;
   w.n_steps = c.take<int32_t>(n);  // first array of the workspace: svo_hip_update_seeds_scan_steps
+  int32_t* const align_evals = c.take<int32_t>(n);  // second: svo_hip_update_seeds_align_evaluations
   w.pwb = c.take<uint8_t>(n * 100);
   w.align_active = c.take<uint8_t>(n);
   w.use_1d = c.take<uint8_t>(n);
@@ -661,6 +566,12 @@ static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_sto
   al.scale_out = 1;
   al.ok = w.align_ok;
   al.h_inv = nullptr;
+  if (g_count_evaluations.load(std::memory_order_relaxed)) {
+    SVO_HIP_TRY(hipMemsetAsync(align_evals, 0, n * sizeof(int32_t), st));  // (a seed that never reaches the alignment: 0)
+    al.iters = align_evals;
+  }
+  // large batches: the last step (seed_finish.h) is the epilogue of every seed's last alignment launch
+  if (align_takes_finish(S)) return launch_align(al, st, phase_ws, phase_bytes, &a);
   rc = launch_align(al, st, phase_ws, phase_bytes);
   if (rc) return rc;
   hipLaunchKernelGGL(seed_finish_kernel, dim3((S + 63) / 64), dim3(64), 0, st, a);
@@ -669,6 +580,13 @@ static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_sto
 
 extern "C" const int32_t* svo_hip_update_seeds_scan_steps(const void* d_workspace) {
   return static_cast<const int32_t*>(d_workspace);
+}
+
+extern "C" int svo_hip_update_seeds_count_evaluations(int on) { return g_count_evaluations.exchange(on != 0) ? 1 : 0; }
+
+extern "C" const int32_t* svo_hip_update_seeds_align_evaluations(const void* d_workspace, int S) {
+  if (!d_workspace || S < 0) return nullptr;
+  return reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(d_workspace) + Carver::round((size_t)S * sizeof(int32_t)));
 }
 
 extern "C" int svo_hip_update_seed_batch(int S, const float* d_x, const float* d_tau2, const svo_hip_seeds* seeds,

@@ -11,71 +11,13 @@
 #include "seed_math.h"
 #include "wave_reduce.h"
 #include "warp_group.h"
+#include "seed_finish.h"
 
 using namespace svo_dev;
 using namespace svo_track;
 
 // (an unnamed namespace, as in the translation unit these definitions come from: the kernels' symbols keep their names)
 namespace {
-
-constexpr int ZMSSD_THRESHOLD = 2000 * 64;  // vk::patch_score::ZMSSD<4>::threshold()
-
-enum : int { MODE_NONE = 0, MODE_SHORT = 1, MODE_SCAN = 2 };
-
-struct SeedWs {
-  uint8_t* align_active;  // [S]
-  uint8_t* use_1d;        // [S]
-  int32_t* status;        // [S] preliminary status (0 = still running)
-  int32_t* mode;          // [S]
-  int32_t* ref_slot;
-  int32_t* ref_level;
-  int32_t* cur_slot;
-  int32_t* search_level;
-  int32_t* n_steps;
-  float* A_ref_cur;   // [S][4]
-  float* px_ref_pyr;  // [S][2]
-  float* dir;         // [S][2]
-  float* z_inv_min;   // [S]
-  double* B;          // [S][2] epipolar start (unit plane)
-  double* step;       // [S][2]
-  double* px_scaled;  // [S][2] align start, level coordinates
-  double* px_cur;     // [S][2] Matcher::px_cur_
-  double* uv_best;    // [S][2]
-  uint8_t* pwb;       // [S][100]
-  int32_t* align_ok;  // [S] written by the alignment kernel only
-  uint8_t* accepted_raw;  // [S] 1: scan match accepted without sub-pixel refinement (subpix_refinement == false)
-};
-
-struct SeedArgs {
-  svo_hip_pyr_layout L;
-  const uint8_t* store;
-  Cam cam;
-  int S;
-  const int32_t* frame_slot;
-  const double* frame_T;
-  const int32_t* cur_frame;  // [S], or NULL: every seed is updated with frame `cur_index` of the table
-  int cur_index;
-  const int32_t* slot_of;    // NULL: seed s is record s of ftr / seeds; else the resident store's slot of seed s (row N2)
-  float* state_out;          // [4][S] a, b, mu, sigma2 after the update, dense (resident store only; may be NULL)
-  svo_hip_features ftr;
-  svo_hip_seeds seeds;
-  svo_hip_depth_filter_options opt;
-  int32_t* status_out;
-  double* xyz_world;
-  double* px_cur_out;
-  // Matcher::findEpipolarMatchDirect on its own (svo_hip_find_epipolar_match_direct): the depth interval
-  // is given, nothing of DepthFilter::updateSeeds runs around it
-  int match_only;
-  const double* d_est;
-  const double* d_min;
-  const double* d_max;
-  double* depth_out;
-  int32_t* ok_out;
-  int32_t* search_level_out;
-  double px_error_angle;  // atan(1 / (2 |fx|)) * 2
-  TauConsts tau_k;         // its sines and cosines (seed_math.h)
-  SeedWs ws;
-};
 
 // bytes [bo, bo+7] (bo in 0..7) of a 12-byte run of three aligned dwords, as two dwords
 __device__ __forceinline__ void cut_row8(const uint32_t d[3], uint32_t bo, uint32_t& lo, uint32_t& hi) {
@@ -180,9 +122,6 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
   const int ref_slot = w.ref_slot[s], ref_level = w.ref_level[s] & (SVO_HIP_MAX_LEVELS - 1);
   const float4 A = *reinterpret_cast<const float4*>(w.A_ref_cur + 4 * (size_t)s);
   const float2 pyr = *reinterpret_cast<const float2*>(w.px_ref_pyr + 2 * (size_t)s);
-  const double step0 = mode == MODE_SCAN ? w.step[2 * s] : 0.0, step1 = mode == MODE_SCAN ? w.step[2 * s + 1] : 0.0;
-  const double B0 = mode == MODE_SCAN ? w.B[2 * s] : 0.0, B1 = mode == MODE_SCAN ? w.B[2 * s + 1] : 0.0;
-  const int n_total = w.n_steps[s] + 1;
   // ---- warp::warpAffine of the seed's reference patch (matcher.cpp:221-224), into LDS ------------------------------------
   uint32_t* const patch = box + SCAN_PATCH_OFF;
   {
@@ -195,6 +134,10 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
     warp_patch_store_group8(patch, lane, w.pwb + (size_t)s * 100);
     return;
   }
+  // (the segment: requested here, used after the template's sums)
+  const double step0 = w.step[2 * s], step1 = w.step[2 * s + 1];
+  const double B0 = w.B[2 * s], B1 = w.B[2 * s + 1];
+  const int n_total = w.n_steps[s] + 1;
   const uint8_t* img = a.store + (int64_t)cur_slot * a.L.slot_bytes + a.L.offset[sl];
   const int pitch = a.L.pitch[sl];
   // reference patch: interior of patch_with_border (createPatchFromPatchWithBorder), 8 rows of 8; lane y parks row y

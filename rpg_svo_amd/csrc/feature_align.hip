@@ -17,10 +17,13 @@
 // pixel, the reference's accumulation order kept by an ordered sum through LDS (align_wave.h); same bits, 11 us instead
 // of 27 for the ~130 trials of a frame.
 #pragma clang fp contract(off)
+#include <type_traits>
+
 #include "track_kernels.h"
 #include "track_math.h"
 #include "align_lanes.h"
 #include "align_wave.h"
+#include "seed_finish.h"
 
 using namespace svo_capi;
 using namespace svo_dev;
@@ -32,9 +35,13 @@ constexpr int ALIGN_BLOCK = 64;
 
 // Two waves per SIMD (<= 256 registers): with the bare __launch_bounds__(64) the compiler took 256 VGPRs plus 15-20
 // AGPRs, i.e. ONE wave per SIMD, and nothing hid the round trip of an iteration's window fetch.
-constexpr int ALIGN_MINW = 2;
-template <bool COUNT>
-__global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const AlignArgs a) {
+constexpr int ALIGN_MINW = 3;
+struct NoFinish {};
+// FINISH: the depth filter's call -- trial t is seed t, and a trial that ends in this launch (not active, converged, failed,
+// out of iterations) goes straight on to seed_finish_seed with its verdict and pixel in registers (the gradient registers
+// are dead by then); `fin` is the depth filter's argument block.
+template <bool COUNT, bool FINISH>
+__global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const AlignArgs a, const typename std::conditional<FINISH, SeedArgs, NoFinish>::type fin) {
   // which trial: lane order in the first launch of a run, the queues filled by the previous launch afterwards
   // (workgroup b drains queue b % ALIGN_NQ, 64 entries at a time)
   int t;
@@ -77,8 +84,12 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const Al
   const float dir0 = dirp[2 * t], dir1 = dirp[2 * t + 1];
   const uint8_t u1d = a.use_1d ? u1d_raw : (uint8_t)0;
   if (has_act && act_raw == 0) {
-    a.ok[t] = 0;  // px_out is left as it is (findMatchDirect returns before touching px_cur)
     if (COUNT) a.iters[t] = 0;
+    if constexpr (FINISH) {
+      seed_finish_seed<true>(fin, t, false, 0, 0.0, 0.0);
+    } else {
+      a.ok[t] = 0;  // px_out is left as it is (findMatchDirect returns before touching px_cur)
+    }
     return;
   }
   AlignState st;
@@ -113,15 +124,19 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, ALIGN_MINW) align_kernel(const Al
       return;
     }
   }
-  a.ok[t] = ok ? 1 : 0;
   double ou = wrote ? (double)st.u : a.px_in[2 * t];
   double ov = wrote ? (double)st.v : a.px_in[2 * t + 1];
   if (a.scale_out) {
     ou = ou * (double)(1 << level);
     ov = ov * (double)(1 << level);
   }
-  a.px_out[2 * t] = ou;
-  a.px_out[2 * t + 1] = ov;
+  if constexpr (FINISH) {
+    seed_finish_seed<true>(fin, t, true, ok ? 1 : 0, ou, ov);
+  } else {
+    a.ok[t] = ok ? 1 : 0;
+    a.px_out[2 * t] = ou;
+    a.px_out[2 * t + 1] = ov;
+  }
 }
 
 // ---- small batches: one WAVE per trial (align_wave.h) -------------------------------------------------------------
@@ -201,6 +216,10 @@ namespace svo_track {
 #endif
 constexpr int ALIGN_PHASE_MIN_M = ALIGN_PHASE_MIN_M_VALUE;  // below this the extra launches cost more than the idle lanes
 constexpr int ALIGN_PHASE_ITERS = 3;
+#ifndef ALIGN_WAVE_MAX_M_VALUE  // (the CPU emulation of the test suite has a build with 0: every batch on the lane kernel)
+#define ALIGN_WAVE_MAX_M_VALUE 8192
+#endif
+constexpr int ALIGN_WAVE_MAX_M = ALIGN_WAVE_MAX_M_VALUE;  // batches up to this many trials take the wave-per-trial kernel
 
 static int phase_queue_cap(int M) { return (M + ALIGN_NQ - 1) / ALIGN_NQ + 2 * ALIGN_BLOCK; }
 
@@ -211,8 +230,6 @@ size_t align_phase_workspace_bytes(int M) {
          Carver::round((size_t)M * 6 * sizeof(float));
 }
 
-constexpr int ALIGN_WAVE_MAX_M = 8192;  // batches up to this many trials take the wave-per-trial kernel
-
 static int launch_wave(const AlignArgs& a, hipStream_t s) {
   const dim3 grid((a.M + ALIGNW_WAVES - 1) / ALIGNW_WAVES), blk(64 * ALIGNW_WAVES);
   if (a.iters) hipLaunchKernelGGL(align_wave_kernel<true>, grid, blk, 0, s, a);
@@ -220,25 +237,33 @@ static int launch_wave(const AlignArgs& a, hipStream_t s) {
   return check_launch();
 }
 
-static int launch_one(const AlignArgs& a, int n_blocks, hipStream_t s) {
+static int launch_one(const AlignArgs& a, int n_blocks, hipStream_t s, const SeedArgs* fin) {
   const dim3 grid(n_blocks), blk(ALIGN_BLOCK);
-  if (a.iters) hipLaunchKernelGGL(align_kernel<true>, grid, blk, 0, s, a);  // instrumented: also counts evaluations
-  else hipLaunchKernelGGL(align_kernel<false>, grid, blk, 0, s, a);
+  if (fin) {
+    if (a.iters) hipLaunchKernelGGL((align_kernel<true, true>), grid, blk, 0, s, a, *fin);
+    else hipLaunchKernelGGL((align_kernel<false, true>), grid, blk, 0, s, a, *fin);
+  } else {
+    if (a.iters) hipLaunchKernelGGL((align_kernel<true, false>), grid, blk, 0, s, a, NoFinish{});  // instrumented: also counts evaluations
+    else hipLaunchKernelGGL((align_kernel<false, false>), grid, blk, 0, s, a, NoFinish{});
+  }
   return check_launch();
 }
 
-int launch_align(const AlignArgs& a0, hipStream_t s, void* d_phase_ws, size_t phase_ws_bytes) {
+bool align_takes_finish(int M) { return M > ALIGN_WAVE_MAX_M; }
+
+int launch_align(const AlignArgs& a0, hipStream_t s, void* d_phase_ws, size_t phase_ws_bytes, const SeedArgs* fin) {
   if (a0.M <= 0) return SVO_HIP_OK;
+  if (fin && !align_takes_finish(a0.M)) return SVO_HIP_EINVAL;
   const int all_blocks = (a0.M + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
   const size_t need = align_phase_workspace_bytes(a0.M);
   const bool phased = d_phase_ws && need != 0 && phase_ws_bytes >= need && a0.n_iter > ALIGN_PHASE_ITERS;
-  if (!phased) return a0.M <= ALIGN_WAVE_MAX_M ? launch_wave(a0, s) : launch_one(a0, all_blocks, s);
+  if (!phased) return a0.M <= ALIGN_WAVE_MAX_M ? launch_wave(a0, s) : launch_one(a0, all_blocks, s, fin);
   Carver c(d_phase_ws, phase_ws_bytes);
   const int cap = phase_queue_cap(a0.M);
   int32_t* queue[2] = {c.take<int32_t>((size_t)ALIGN_NQ * cap), c.take<int32_t>((size_t)ALIGN_NQ * cap)};
   int32_t* count = c.take<int32_t>(2 * ALIGN_NQ);
   float* state = c.take<float>((size_t)a0.M * 6);
-  if (!c.ok) return launch_one(a0, all_blocks, s);
+  if (!c.ok) return launch_one(a0, all_blocks, s, fin);
   SVO_HIP_TRY(hipMemsetAsync(count, 0, 2 * ALIGN_NQ * sizeof(int32_t), s));
   // a queue holds the survivors of the workgroups b % ALIGN_NQ == q: at most cap entries; every launch after the first
   // is sized for full queues (workgroups past a queue's end leave at once)
@@ -254,7 +279,7 @@ int launch_align(const AlignArgs& a0, hipStream_t s, void* d_phase_ws, size_t ph
     a.n_in = phase == 0 ? nullptr : count + ((phase - 1) & 1) * ALIGN_NQ;
     a.queue_out = phase == 2 ? nullptr : queue[phase & 1];
     a.n_out = phase == 2 ? nullptr : count + (phase & 1) * ALIGN_NQ;
-    rc = launch_one(a, phase == 0 ? all_blocks : queue_blocks, s);
+    rc = launch_one(a, phase == 0 ? all_blocks : queue_blocks, s, fin);
   }
   return rc;
 }

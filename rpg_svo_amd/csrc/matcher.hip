@@ -408,7 +408,7 @@ extern "C" size_t svo_hip_match_workspace_bytes(int M) {
   // generous: every per-trial scratch array of the matcher and of the depth filter
   size_t b = 0;
   b += Carver::round(m * 100);                 // patches
-  b += 8 * Carver::round(m * sizeof(int32_t)); // slots, levels, flags
+  b += 9 * Carver::round(m * sizeof(int32_t)); // slots, levels, flags, the alignment's evaluation counts
   b += 4 * Carver::round(m);                   // u8 flags
   b += Carver::round(m * 4 * sizeof(float)) + 2 * Carver::round(m * 2 * sizeof(float));
   b += 8 * Carver::round(m * 2 * sizeof(double));  // px arrays, epipolar geometry

@@ -39,7 +39,13 @@ struct AlignArgs {
 // trials still alive, so that a wave no longer runs as long as its slowest trial.  Results do not depend on it.
 constexpr int ALIGN_NQ = 64;           // queues (one atomic counter each: no single hot address)
 size_t align_phase_workspace_bytes(int M);
-int launch_align(const AlignArgs& a, hipStream_t s, void* d_phase_ws = nullptr, size_t phase_ws_bytes = 0);
+struct SeedArgs;  // seed_finish.h
+// finish: the depth filter's last step (seed_finish.h) as the epilogue of every trial's LAST alignment launch -- trial t is
+// seed t.  Only the lane-per-trial kernel takes it: align_takes_finish(M) says whether launch_align will (the caller runs
+// seed_finish_kernel itself otherwise).
+bool align_takes_finish(int M);
+int launch_align(const AlignArgs& a, hipStream_t s, void* d_phase_ws = nullptr, size_t phase_ws_bytes = 0,
+                 const SeedArgs* finish = nullptr);
 
 // K2b (matcher.hip): warp::warpAffine for M trials, 10x10 output, 32 lanes per trial
 struct WarpArgs {

@@ -44,8 +44,11 @@ __device__ __forceinline__ bool wg_slot(const int lane, const int k, int& x, int
 // On return (after the hand-over inside) every lane of the group may read the 100 bytes at `patch`.
 __device__ __forceinline__ void warp_patch_group8(const uint8_t* __restrict__ img, const int cols, const int rows, const int pitch,
                                                   const float Ax, const float Ay, const float Az, const float Aw, const float pyrx,
-                                                  const float pyry, const int slev, const int lane, uint32_t* const region,
+                                                  const float pyry, const int slev, int lane, uint32_t* const region,
                                                   uint32_t* const patch) {
+  // (opaque: what the lane index turns into -- (float)(lane - 5), the extra slots' coordinates and byte offsets, chunk
+  // indices: ~25 registers -- is invariant in the caller's loop over trials, where the compiler would park it all)
+  asm volatile("" : "+v"(lane));
   uint8_t* const pb = reinterpret_cast<uint8_t*>(patch);
   const float sc = (float)(1 << slev);
   // The 100 samples lie in the parallelogram spanned by the four corner samples (the map is affine and every rounding in

@@ -7,6 +7,12 @@
 // Measured: microseconds per exchange with F frames x 4 workgroups in flight, for the two placements of a frame's
 // workgroups -- consecutive ids (they land on four different XCDs: workgroup id % 8 is the XCD) and ids 8 apart (the same
 // XCD, one L2) -- and, as the baseline, the same loop with a workgroup barrier instead of the exchange.
+// Round 6 adds mode 3: the four parts of a frame on ONE XCD exchanging through that XCD's L2 only --
+// no agent-scope release / acquire (which on a multi-XCD part goes past the L2), but sc0 stores and loads (workgroup scope
+// in the ISA's terms: they bypass the CU's vector L1 and are served by the L2 the four CUs share), and no counter: lane l
+// of a part stores {partial l, generation} as ONE 16-byte chunk, the 32 lanes (part, l) of every workgroup poll their
+// chunk until it carries this round's generation (s_sleep back-off) -- data and flag arrive together, one store and one
+// load round trip per exchange.  Placement relies on workgroup id % 8 being the XCD, as the library's XCD-aware launches do.
 //   hipcc --offload-arch=gfx950 -O2 scripts/xwg_exchange_ubench.hip -o build/xwg_exchange_ubench && build/xwg_exchange_ubench
 #include <hip/hip_runtime.h>
 
@@ -19,6 +25,74 @@
     hipError_t e_ = (x);                                                              \
     if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } \
   } while (0)
+
+struct Chunk {  // mode 3: a partial and the generation it belongs to, written and read as one 16-byte access
+  double v;
+  unsigned long long gen;
+};
+struct BlockL2 {  // one frame: [buffer half][part][partial]
+  Chunk c[2][4][8];
+};
+__device__ __forceinline__ void store_sc0_x4(Chunk* p, double v, unsigned long long gen) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  u4 w;
+  w.x = (unsigned)__double_as_longlong(v); w.y = (unsigned)((unsigned long long)__double_as_longlong(v) >> 32);
+  w.z = (unsigned)gen; w.w = (unsigned)(gen >> 32);
+  asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ Chunk load_sc0_x4(const Chunk* p) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  u4 w;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(p) : "memory");
+  Chunk c;
+  c.v = __longlong_as_double((long long)(((unsigned long long)w.y << 32) | w.x));
+  c.gen = ((unsigned long long)w.w << 32) | w.z;
+  return c;
+}
+
+// mode 3: see the header.  ids 8 apart per frame (the same XCD).
+__global__ void __launch_bounds__(256) exchange_l2_kernel(BlockL2* blocks, unsigned* timed_out, int n_frames, int rounds, double* out, long long* cycles) {
+  const int frame = (int)(blockIdx.x / 32) * 8 + (int)(blockIdx.x % 8);
+  const int part = (int)(blockIdx.x / 8) % 4;
+  if (frame >= n_frames) return;
+  BlockL2& b = blocks[frame];
+  __shared__ double s_tot[8];
+  double acc = 0.0;
+  const long long t0 = (long long)__builtin_readcyclecounter();
+  for (int r = 0; r < rounds; ++r) {
+    const int buf = r & 1;
+    const unsigned long long gen = (unsigned long long)(r + 1);
+    __syncthreads();  // (the workgroup's own reduction has happened: wave 0 publishes)
+    if (threadIdx.x < 8) {
+      const double v = (double)(part + 1) * (double)(threadIdx.x + 1) + (double)r;
+      store_sc0_x4(&b.c[buf][part][threadIdx.x], v, gen);
+    }
+    if (threadIdx.x < 32) {  // lane = (p, l): poll the chunk of part p, partial l
+      const int p = (int)threadIdx.x >> 3, l = (int)threadIdx.x & 7;
+      Chunk c = load_sc0_x4(&b.c[buf][p][l]);
+      unsigned spins = 0;
+      while (c.gen != gen) {
+        if (++spins > (1u << 20)) {  // never hang the device: flag and leave
+          atomicOr(timed_out, 1u);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        c = load_sc0_x4(&b.c[buf][p][l]);
+      }
+      // parts in a fixed order (deterministic sums): lanes l, 8 + l, 16 + l, 24 + l of the wave hold them
+      double t = c.v;
+      const double t1 = __shfl(t, l + 8, 64), t2 = __shfl(t, l + 16, 64), t3 = __shfl(t, l + 24, 64);
+      if (p == 0) s_tot[l] = ((t + t1) + t2) + t3;
+    }
+    __syncthreads();
+    acc += s_tot[threadIdx.x & 7];
+  }
+  const long long t1 = (long long)__builtin_readcyclecounter();
+  if (threadIdx.x == 0) {
+    out[blockIdx.x] = acc;
+    cycles[blockIdx.x] = t1 - t0;
+  }
+}
 
 struct Block {  // one frame's exchange block (one 256-byte line per buffer half and part would be kinder; this is the naive layout)
   double part[2][4][8];
@@ -90,11 +164,17 @@ int main(int argc, char** argv) {
   const int frame_counts[3] = {1, 16, 64};
   for (int fi = 0; fi < 3; ++fi) {
     const int F = frame_counts[fi];
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
       Block* d_blocks;
       double* d_out;
       long long* d_cyc;
-      const int n_wg = mode == 1 ? ((F + 7) / 8) * 32 : 4 * F;
+      const int n_wg = (mode == 1 || mode == 3) ? ((F + 7) / 8) * 32 : 4 * F;
+      BlockL2* d_l2 = nullptr;
+      unsigned* d_to = nullptr;
+      if (mode == 3) {
+        CHECK(hipMalloc(&d_l2, sizeof(BlockL2) * (size_t)F));
+        CHECK(hipMalloc(&d_to, sizeof(unsigned)));
+      }
       CHECK(hipMalloc(&d_blocks, sizeof(Block) * (size_t)F));
       CHECK(hipMalloc(&d_out, sizeof(double) * (size_t)n_wg));
       CHECK(hipMalloc(&d_cyc, sizeof(long long) * (size_t)n_wg));
@@ -106,8 +186,13 @@ int main(int argc, char** argv) {
       double check = 0.0;
       for (int rep = 0; rep < 5; ++rep) {
         CHECK(hipMemset(d_blocks, 0, sizeof(Block) * (size_t)F));
+        if (mode == 3) {
+          CHECK(hipMemset(d_l2, 0, sizeof(BlockL2) * (size_t)F));
+          CHECK(hipMemset(d_to, 0, sizeof(unsigned)));
+        }
         CHECK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(exchange_kernel, dim3(n_wg), dim3(256), 0, 0, d_blocks, F, rounds, mode, d_out, d_cyc);
+        if (mode == 3) hipLaunchKernelGGL(exchange_l2_kernel, dim3(n_wg), dim3(256), 0, 0, d_l2, d_to, F, rounds, d_out, d_cyc);
+        else hipLaunchKernelGGL(exchange_kernel, dim3(n_wg), dim3(256), 0, 0, d_blocks, F, rounds, mode, d_out, d_cyc);
         CHECK(hipEventRecord(e1, 0));
         CHECK(hipEventSynchronize(e1));
         float ms;
@@ -116,6 +201,11 @@ int main(int argc, char** argv) {
         std::vector<Block> hb((size_t)F);
         CHECK(hipMemcpy(hb.data(), d_blocks, sizeof(Block) * (size_t)F, hipMemcpyDeviceToHost));
         for (int f = 0; f < F; ++f) timed_out |= hb[(size_t)f].timed_out;
+        if (mode == 3) {
+          unsigned to = 0;
+          CHECK(hipMemcpy(&to, d_to, sizeof(unsigned), hipMemcpyDeviceToHost));
+          timed_out |= to;
+        }
         std::vector<double> ho((size_t)n_wg);
         CHECK(hipMemcpy(ho.data(), d_out, sizeof(double) * (size_t)n_wg, hipMemcpyDeviceToHost));
         check = ho[0];
@@ -127,11 +217,13 @@ int main(int argc, char** argv) {
       // expected value of acc for lane 0 (column 0): sum over rounds of (1+2+3+4)*1 + 4 r = 10 + 4 r
       double expect = 0.0;
       for (int r = 0; r < rounds; ++r) expect += 10.0 + 4.0 * r;
-      const char* names[3] = {"parts_on_four_xcds", "parts_on_one_xcd", "workgroup_barrier_only"};
+      const char* names[4] = {"parts_on_four_xcds", "parts_on_one_xcd", "workgroup_barrier_only", "parts_on_one_xcd_through_its_l2_sc0"};
       std::printf(",\n \"frames_%d_%s\": {\"us_per_exchange\": %.3f, \"kernel_ms\": %.4f, \"shader_cycles_per_exchange\": %.0f, \"timed_out\": %u, \"sum_ok\": %s}",
                   F, names[mode], 1e3 * best_ms / rounds, best_ms, (double)cmax / rounds, timed_out,
                   mode == 2 ? "true" : (check == expect ? "true" : "false"));
       CHECK(hipFree(d_blocks));
+      if (d_l2) CHECK(hipFree(d_l2));
+      if (d_to) CHECK(hipFree(d_to));
       CHECK(hipFree(d_out));
       CHECK(hipFree(d_cyc));
     }

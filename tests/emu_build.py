@@ -16,8 +16,11 @@ UNITS = ("common", "pyramid", "map_mirror", "matcher", "feature_align", "depth_f
 # Compile-time variants of the library the emulated parity tests run on besides the default build (round 4 queued ten of
 # them for timing; round 5 measured them on the GPU, the winners became the only code and the losers were deleted:
 # profiles/r05a_queue_drain.txt).  Tests take their build from this list: a new opt-in flag is one more tuple here.
-BUILDS = [()]
-BUILD_IDS = ["default"]
+# Round 6: ("ALIGN_WAVE_MAX_M_VALUE=0",) -- no batch is small enough for the wave-per-trial alignment, so the depth filter's
+# small test batches take the lane-per-trial kernel WITH the seed_finish epilogue (csrc/seed_finish.h), the path of replay
+# batches beyond 8192 seeds.
+BUILDS = [(), ("ALIGN_WAVE_MAX_M_VALUE=0",)]
+BUILD_IDS = ["default", "lane_kernel_with_finish"]
 
 
 def sanitizer():

@@ -122,3 +122,36 @@ def test_time_budget_arithmetic():
     # headline needs still do (pmc_leg's condition)
     left = bench.time_left(300.0, now=t0 + 200.0)
     assert left < bench.PMC_PASS_RESERVE_S + bench.FULL_TRACK_PMC_RESERVE_S and left > bench.PMC_PASS_RESERVE_S
+
+
+def test_dispatches_are_attributed_to_their_stage_by_their_place_in_the_step():
+    """align_kernel serves findMatchDirect AND the depth filter; bench.attribute_dispatches tells its
+    launches apart by where they stand in the step (the kernel that opens a stage), per dispatch, for the kernel trace and
+    for every counter pass alike; the workload's set-up launches (the same kernels, before the first step) are dropped."""
+    import bench
+    rows, k = [], [0]
+
+    def d(name, **q):
+        k[0] += 1
+        rows.append((k[0], name, q))
+
+    for _ in range(3):  # set-up: update_seeds passes without a matcher
+        d("seed_prepare_kernel", ms=9.0); d("epi_scan_kernel", ms=9.0); d("align_kernel", ms=9.0)
+    for step in range(2):
+        d("match_prepare_kernel", ms=0.2); d("warp_kernel", ms=0.5)
+        for _ in range(3):
+            d("align_kernel", ms=0.3, C=10.0)
+        d("pose_opt_wave_kernel", ms=0.25); d("pose_opt_kernel", ms=0.01)
+        d("seed_prepare_kernel", ms=0.7); d("epi_scan_kernel", ms=2.0 + step)
+        for _ in range(3):
+            d("align_kernel", ms=0.6, C=1.0)
+    import random
+    random.Random(3).shuffle(rows)  # (any order in: sorted by the order key)
+    out = bench.attribute_dispatches(rows, 2)
+    assert set(out) == {"find_match_direct/match_prepare_kernel", "find_match_direct/warp_kernel", "find_match_direct/align_kernel",
+                        "pose_optimize/pose_opt_wave_kernel", "pose_optimize/pose_opt_kernel", "update_seeds/seed_prepare_kernel",
+                        "update_seeds/epi_scan_kernel", "update_seeds/align_kernel"}
+    assert abs(out["find_match_direct/align_kernel"]["ms"] - 0.9) < 1e-12 and out["find_match_direct/align_kernel"]["C"] == 30.0
+    assert abs(out["update_seeds/align_kernel"]["ms"] - 1.8) < 1e-12 and out["update_seeds/align_kernel"]["C"] == 3.0
+    assert out["update_seeds/align_kernel"]["launches_per_step"] == 3 and out["update_seeds/epi_scan_kernel"]["ms"] == 2.5
+    assert bench.attribute_dispatches(rows, 5) == {}  # fewer steps in the run than asked for

@@ -93,7 +93,7 @@ def test_emulated_find_match_direct(emu, oracle, scene):
 # ---- row a12: svo_hip_update_seeds (seed_prepare -> warp -> epipolar scan -> alignment -> seed_finish) -----------------
 
 
-@pytest.fixture(scope="module", params=[0], ids=["default"])
+@pytest.fixture(scope="module", params=[0, 1], ids=["default", "lane_kernel_with_finish"])
 def emu_seeds(request):
     from emu_build import build_emulated
     from emu_build import BUILDS

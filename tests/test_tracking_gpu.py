@@ -548,13 +548,16 @@ def test_update_seeds(gpu_device, orc, scene, pyrs, align_1d, subpix):
         ab_known = not (orc.which == "ref" and st == pytrack.SEED_CONVERGED)
         if st in (pytrack.SEED_UPDATED, pytrack.SEED_CONVERGED, pytrack.SEED_NO_MATCH):
             # Bayesian update: float arithmetic fed by an f64 depth that may differ in the last
-            # bits (acos/atan/sin on the GPU) and by expf.  mu: 2e-6 relative.  sigma2 is formed as
-            # C1*(s2+m^2) + C2*(sigma2+mu^2) - mu_new^2 in float, i.e. it carries an absolute
-            # rounding noise of ~eps*mu^2 whatever its size; a and b come from (e-f)/(f-e/f).
+            # bits (the algebraic computeTau, exp) -- mu: 2e-6 relative.  sigma2 is formed as
+            # C1*(s2+m^2) + C2*(sigma2+mu^2) - mu_new^2 in float: a last-bit difference of its inputs shows as
+            # ~eps32 * mu^2 ABSOLUTE whatever sigma2's size.  MEASURED on the GPU (round 6, three cameras x three option
+            # sets x both checkers, printed below): 0 -- every sigma2 of this test has the checker's bits.  The bound
+            # is therefore what one last-bit input difference could cause (4 eps32 mu^2 + 4 eps32 sigma2), not the 1e-4
+            # sigma2 + 1e-6 mu^2 (0.7 % of a converged seed's sigma2) of rounds 2-5.
             assert np.isclose(mu[i], so[i].mu, rtol=2e-6, atol=0), (i, mu[i], so[i].mu)
             if so[i].sigma2 != 0 and so[i].mu != 0:
                 s2_dev.append((abs(float(s2[i]) - so[i].sigma2) / abs(so[i].sigma2), abs(float(s2[i]) - so[i].sigma2) / (6e-8 * so[i].mu ** 2)))
-            assert abs(float(s2[i]) - so[i].sigma2) <= 1e-4 * abs(so[i].sigma2) + 1e-6 * so[i].mu ** 2, (i, s2[i], so[i].sigma2)
+            assert abs(float(s2[i]) - so[i].sigma2) <= 2.4e-7 * (abs(so[i].sigma2) + so[i].mu ** 2), (i, s2[i], so[i].sigma2)
             if ab_known:
                 ab_dev.append(max(abs(float(a[i]) - so[i].a) / abs(so[i].a), abs(float(b[i]) - so[i].b) / abs(so[i].b)))
                 assert np.allclose([a[i], b[i]], [so[i].a, so[i].b], rtol=AB_RTOL, atol=1e-5), (i, a[i], so[i].a, b[i], so[i].b)
