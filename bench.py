@@ -1634,8 +1634,24 @@ def dropin_sequence(n_frames: int = 600) -> dict:
             with_pyr = {"skipped": p.stderr[-300:]}
     except Exception as e:
         with_pyr = {"skipped": repr(e)}
+    # every step a call of its own (SVO_HIP_CHAIN=0: the round-5 path): what the chain behind the sparse alignment buys
+    try:
+        dump = tempfile.mktemp(suffix=".npy", dir="/tmp")
+        code = f"import sys, json; sys.path.insert(0, {ROOT!r}); import bench; print(json.dumps(bench.dropin_hip_only({n_frames}, {dump!r})))"
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SVO_HIP_CHAIN="0"), capture_output=True, text=True,
+                           timeout=300)
+        if p.returncode == 0:
+            no_chain = json.loads(p.stdout.strip().splitlines()[-1])
+            no_chain["trajectory_identical_to_the_chained_path"] = bool(np.array_equal(np.load(dump), Th))
+            no_chain.pop("map_mirror", None)
+            os.unlink(dump)
+        else:
+            no_chain = {"skipped": p.stderr[-300:]}
+    except Exception as e:
+        no_chain = {"skipped": repr(e)}
     return {"frames": n_frames, "map_size": map_size, "host_pyramid_levels_built_of": host.get("host_pyramid"),
             "median_ms_per_frame_hip_dropin_with_the_host_pyramid_built": with_pyr,
+            "median_ms_per_frame_hip_dropin_without_the_frame_chain": no_chain,
             "map_mirror": host.get("map_mirror"), "seed_store": host.get("seed_store"),
             "median_ms_per_frame_hip_dropin_list_walking_reprojector": list_walk,
             "first_frame_with_a_different_decision": first_diff,
@@ -1657,6 +1673,9 @@ def dropin_sequence(n_frames: int = 600) -> dict:
             # DepthFilter's own thread running (the reference's default mode): tot_time then excludes the mapper
             "median_ms_per_frame_mapper_thread": {"cpu_reference": med(ref_thr, "t_tot_time"), "hip_dropin": med(hip_thr, "t_tot_time")},
             "predicted_pose_refinements": {"taken": host.get("predicted_pose_hits"), "not_taken": host.get("predicted_pose_misses")},
+            # round 6: reprojection + matching + selection + pose refinement enqueued behind the sparse alignment
+            # (rpg_svo_amd/host/dropin/frame_chain.h), verified and taken by reprojectMap
+            "frame_chain": {"taken": host.get("frame_chain_hits"), "not_taken": host.get("frame_chain_misses")},
             # N2 evidence: per drop-in call, the host walking the reference's pointer graph into the pinned
             # arena and back (marshal/unmarshal) against the device round trip (H2D + kernels + D2H + sync)
             "host_vs_device_us_per_call": {k: {q: round(v, 2) if isinstance(v, float) else v for q, v in st.items()}
@@ -1690,6 +1709,27 @@ def reference_cameras_leg(args, ev: Events, dev, rank: int, lib, B: int = 4096, 
                                  "mean_tracked_patches": float(st["n_tracked"].mean()),
                                  "median_pose_error_vs_gt": float(np.median(st["gt_err"])),
                                  "roofline": _pick(roofline("sia_kernel", st["alg_bytes"], ms), ("achieved", "frac", "ms", "algorithmic_bytes_per_launch"))}
+            if not args.no_cpu_baseline:
+                # the reference's own SparseImgAlign through the same camera model on a sample of the same frame pairs: the pose,
+                # and that the iteration counts -- higher on the distorted models -- are the reference's own
+                try:
+                    from oracle import pyoracle
+                    k = 64
+                    which = "ref" if pyoracle.ref_available() else "orc"
+                    pyrs = [pyoracle.create_img_pyramid(im, W.n_levels, pyoracle.HALFSAMPLE_AUTO) for im in W.images[:k + 1].cpu().numpy()]
+                    rs = np.arange(k, dtype=np.int32)
+                    T_cpu, res = pyoracle.sparse_img_align_batch(pyrs, rs, rs + 1, cam, W.T_ref_w[:k], W.T_prior_w[:k], np.full(k, W.n_patches, np.int32),
+                                                                 W.px_all[:k].cpu().numpy(), W.f_all[:k].cpu().numpy(), np.ones((k, W.n_patches), np.uint8),
+                                                                 W.pos_all[:k].cpu().numpy(), W.max_level, W.min_level, args.n_iter,
+                                                                 n_threads=min(16, os.cpu_count() or 1), which=which)
+                    d = se3.log_norm(st["T_est_w"][:k], T_cpu)
+                    it_g = o.iters.cpu().numpy()[:k]
+                    r["sparse_align"]["parity"] = {"frames_compared": k, "against": "reference" if which == "ref" else "port",
+                                                   "se3_lognorm_max": float(d.max()), "se3_lognorm_median": float(np.median(d)),
+                                                   "same_iteration_counts_frac": float(np.mean([np.array_equal(a["iters"], b) for a, b in zip(res, it_g)])),
+                                                   "mean_gn_iterations_per_frame_reference": float(np.mean([np.sum(a["iters"]) for a in res]))}
+                except Exception as e:
+                    r["sparse_align"]["parity"] = {"skipped": repr(e)}
             full = FullTrack(W, dev, rank)
             marks = []
             for i in range(4):

@@ -179,6 +179,10 @@ typedef struct svo_hip_sia_params {
 
 /* status bits written per problem */
 #define SVO_HIP_SIA_STOP 1 /* vk::NLLSSolver::stop_ (solve produced NaN) */
+#define SVO_HIP_SIA_EXCHANGE_TIMEOUT 2 /* a frame split over four workgroups (frames of > 512 patches in batches of <= 128):
+                                        * a part never heard from its siblings -- the GPU was too busy with other work for
+                                        * the frame's workgroups to be resident together; the frame ends like a NaN solve.
+                                        * SVO_HIP_K1_SPLIT=0 keeps every frame on one workgroup */
 
 /*
  * Batched SparseImgAlign::run (svo/src/sparse_img_align.cpp:43-75) for B
@@ -382,7 +386,10 @@ int svo_hip_select_matches(const svo_hip_camera* cam, int M, const int32_t* d_ce
  * findMatchDirect trials in visiting order, and the match kernels follow on the stream without the host in between.
  * All arrays are device memory owned by the caller. */
 typedef struct svo_hip_map {
-  int32_t n_points;      /* entries [0, n_points), <= 8192: the points of the map's keyframes and the depth filter's candidates */
+  int32_t n_points;      /* entries [0, n_points), <= 8192: the points of the map's keyframes and the depth filter's candidates.
+                          * (API CHANGE in round 5: the limit was 16384 up to round 4; a larger map now gets SVO_HIP_ERANGE here --
+                          * the drop-in's Reprojector then takes its list-walking path, other callers split the map or keep the
+                          * keyframe window below ~60 keyframes x 120 features.) */
   int32_t n_obs;         /* observation records [0, n_obs) */
   double* d_pos;         /* [P][3] Point::pos_ */
   int32_t* d_type;       /* [P] Point::type_ (point.h:38-43): 0 deleted = the entry is dead, 1 candidate, 2 unknown, 3 good */
@@ -497,6 +504,23 @@ int svo_hip_compose_poses(int n, const double* d_A, const double* d_B, double* d
                           const int32_t* d_out_index, void* stream);
 int svo_hip_cam2world(const svo_hip_camera* cam, int n, const double* d_px, double* d_f,
                       void* stream);
+/* The new frame's pose as SparseImgAlign::run leaves it (sparse_img_align.cpp:70: cur_frame_->T_f_w_ =
+ * T_cur_from_ref * ref_frame_->T_f_w_), formed ON THE STREAM behind svo_hip_sparse_align so that the kernels of the
+ * frame's next steps (svo_hip_reproject_map, the match kernels, a predicted svo_hip_pose_optimize_deferred) can be
+ * enqueued behind it without the host in between.  The product is Sophus' SE3 product as the host forms it: the left
+ * factor's unit quaternion from d_T_cur_ref's rotation matrix (SE3(R, t)), the right factor's unit quaternion AS THE
+ * HOST HOLDS IT (d_q_ref: w, x, y, z; d_t_ref) -- not re-derived from a rotation matrix --, the result normalised and
+ * converted to (R, t): bit for bit what `poseToRt(poseFromRt(T_cur_ref) * T_ref)` gives on the host, which is how a
+ * caller verifies that the chain it enqueued ran on the pose it later computes itself.
+ *   d_frame_T   [n_frames][12] the frame table the following kernels read; entry cur_frame is overwritten
+ *   d_T_copy    (may be NULL) [12] a second copy, e.g. the in/out pose block of svo_hip_pose_optimize_deferred
+ *   d_T_out     (may be NULL) [12] a third copy for the host to compare (device-mapped host memory in the drop-in)
+ *   d_signal    (may be NULL) signal_value is stored there (system scope, released after the copies) when the kernel
+ *               is through: a host polling it knows that svo_hip_sparse_align's results AND the composed pose are
+ *               in memory */
+int svo_hip_frame_pose_compose(const double* d_T_cur_ref, const double* d_q_ref, const double* d_t_ref, double* d_frame_T,
+                               int cur_frame, double* d_T_copy, double* d_T_out, int32_t* d_signal, int32_t signal_value,
+                               void* stream);
 
 /*
  * K4: batched pose_optimizer::optimizeGaussNewton (svo/src/pose_optimizer.cpp:28-161).
@@ -686,7 +710,15 @@ int svo_hip_fast_detect(const svo_hip_pyr_layout* layout, const uint8_t* d_store
                         float* d_corner_score, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* static DepthFilter::computeTau(T_ref_cur, f, z, px_error_angle) (depth_filter.cpp:334-350) for S
- * independent measurements: d_t_ref_cur [S][3] = T_ref_cur.translation(), d_f [S][3], d_z [S]. */
+ * independent measurements: d_t_ref_cur [S][3] = T_ref_cur.translation(), d_f [S][3], d_z [S].
+ * Arithmetic (since round 5, here and inside svo_hip_update_seeds*): the ALGEBRAIC form -- alpha and beta enter only
+ * through their cosines, which the reference forms as dot products before it calls acos (:339-340); their sines are
+ * sqrt(1 - cos^2) and sin(pi - alpha - beta_plus) follows from the angle-sum formulas with the sine / cosine of
+ * px_error_angle (a per-launch constant, computed on the host by libm).  No acos / sin runs on the device.  The value
+ * differs from the reference's acos / sin expression by rounding only: <= 7e-13 relative on usable geometry
+ * (tests/test_device_math_host.py::test_compute_tau_algebraic_form measures it; test_compute_tau_and_triangulation pins the acos / sin statement against the oracle's acos / sin form), i.e.
+ * tau is NOT bit-identical to DepthFilter::computeTau; the f32 seed update that consumes it (1 / tau^2 rounded to float)
+ * is, in every case the GPU suite compares (tests/test_tracking_gpu.py prints the measured deviation of a, b, sigma2: 0). */
 int svo_hip_compute_tau_batch(int S, const double* d_t_ref_cur, const double* d_f, const double* d_z,
                               double px_error_angle, double* d_tau, void* stream);
 

@@ -35,6 +35,19 @@ class SE3 {
     return m;
   }
   Vector3d translation() const { return Vector3d(s.t[0], s.t[1], s.t[2]); }
+  // so3().unit_quaternion().{w,x,y,z}() as the old Sophus spells them (read-only views)
+  struct QuatView {
+    const double* q;
+    double w() const { return q[0]; }
+    double x() const { return q[1]; }
+    double y() const { return q[2]; }
+    double z() const { return q[3]; }
+  };
+  struct So3View {
+    const double* q;
+    QuatView unit_quaternion() const { QuatView v; v.q = q; return v; }
+  };
+  So3View so3() const { So3View v; v.q = s.q; return v; }
   static SE3 exp(const Vector6d& xi) { return SE3(orc_se3_exp_q(xi.data())); }
   static Vector6d log(const SE3& T) { Vector6d x; orc_se3_log_q(&T.s, x.data()); return x; }
   Vector6d log() const { return log(*this); }

@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
 // outside it.  (What registers cost here: nine spilled dwords per seed took 10 % of the kernel, profiles/r05e_*.)
 constexpr int SCAN_MINW = 4;
 template <bool PINHOLE>
-__global__ void __launch_bounds__(SCAN_BLOCK, SCAN_MINW) epi_scan_kernel(const SeedArgs a) {
+__global__ void __launch_bounds__(SCAN_BLOCK, PINHOLE ? SCAN_MINW : SCAN_MINW - 1) epi_scan_kernel(const SeedArgs a) {
   __shared__ uint16_t s_order[SCAN_CHUNK];
   __shared__ int s_hist[SCAN_BUCKETS], s_off[SCAN_BUCKETS], s_next, s_n;
   __shared__ __attribute__((aligned(16))) uint32_t s_box[SCAN_BLOCK / SCAN_G][SCAN_BOX_DWORDS + 0];

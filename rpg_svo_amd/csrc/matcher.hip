@@ -283,6 +283,33 @@ __global__ void __launch_bounds__(256) compose_kernel(const GlueArgs a) {
   const int o = a.out_index ? a.out_index[i] : i;
   se3_to_Rt(r, a.out + 12 * o);
 }
+// svo_hip_frame_pose_compose: one lane (a dozen dependent f64 operations; what matters is that it sits on the stream)
+struct FramePoseArgs {
+  const double *T_cur_ref, *q_ref, *t_ref;
+  double *frame_T, *T_copy, *T_out;
+  int cur_frame;
+  int32_t* signal;
+  int32_t signal_value;
+};
+__global__ void __launch_bounds__(64) frame_pose_compose_kernel(const FramePoseArgs a) {
+  if (threadIdx.x != 0) return;
+  Se3 x, y;
+  se3_from_Rt(a.T_cur_ref, x);  // SE3(R, t): the quaternion of the rotation matrix (Eigen's Quaternion(Matrix3))
+#pragma unroll
+  for (int k = 0; k < 4; ++k) y.q[k] = a.q_ref[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) y.t[k] = a.t_ref[k];
+  const Se3 r = se3_compose(x, y);
+  double T[12];
+  se3_to_Rt(r, T);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    a.frame_T[12 * a.cur_frame + k] = T[k];
+    if (a.T_copy) a.T_copy[k] = T[k];
+    if (a.T_out) a.T_out[k] = T[k];
+  }
+  if (a.signal) __hip_atomic_store(a.signal, a.signal_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void __launch_bounds__(256) cam2world_kernel(const GlueArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;
@@ -565,6 +592,20 @@ extern "C" int svo_hip_compose_poses(int n, const double* d_A, const double* d_B
   a.out = d_out;
   a.out_index = d_out_index;
   hipLaunchKernelGGL(compose_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch();
+}
+
+extern "C" int svo_hip_frame_pose_compose(const double* d_T_cur_ref, const double* d_q_ref, const double* d_t_ref, double* d_frame_T,
+                                          int cur_frame, double* d_T_copy, double* d_T_out, int32_t* d_signal, int32_t signal_value,
+                                          void* stream) {
+  if (!d_T_cur_ref || !d_q_ref || !d_t_ref || !d_frame_T || cur_frame < 0) return SVO_HIP_EINVAL;
+  FramePoseArgs a{};
+  a.T_cur_ref = d_T_cur_ref; a.q_ref = d_q_ref; a.t_ref = d_t_ref;
+  a.frame_T = d_frame_T; a.T_copy = d_T_copy; a.T_out = d_T_out;
+  a.cur_frame = cur_frame;
+  a.signal = d_signal;
+  a.signal_value = signal_value;
+  hipLaunchKernelGGL(frame_pose_compose_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), a);
   return check_launch();
 }
 

@@ -30,7 +30,68 @@ struct SiaArgs {
   int32_t* iters;
   double* chi2;
   int32_t* status;
+  // A frame split over several workgroups (sparse_align.hip, PARTS > 1): the number of frames (the grid is padded), the
+  // exchange blocks (one SIA_X_CHUNKS-chunk block per frame, zeroed before the launch).  NULL / 0 otherwise.
+  int B = 0;
+  void* xw = nullptr;
 };
+
+// ---- the exchange between the workgroups of a split frame -------------------------------------------------------------
+// One 16-byte chunk = a partial sum and the epoch of the exchange it belongs to, written and read as ONE access: data and
+// flag arrive together, no counter, no atomic, no fence.  PLACEMENT-INDEPENDENT: a part stores its chunks write-through
+// (sc1: the line leaves the XCD's L2 for memory) and every wave polls the other parts' chunks with sc1 loads (which miss
+// the polling CU's vector L1 and are served below it) until they carry this exchange's epoch -- the agent-scope forms,
+// correct wherever the dispatcher puts the four workgroups (it promises nothing; ids 8 apart usually share an XCD, which
+// is a matter of speed only).  Round 6 first built this with sc0 stores kept in a shared L2: it never saw its siblings
+// inside the real kernel although a microbenchmark of the same instructions did (profiles/r06f_*): placement is not a
+// contract.  Each 8-byte half of a chunk carries the epoch, so that a reader can tell a torn 16-byte read (never
+// observed on gfx950) from a whole one.  The blocks are zeroed by the launch function before every launch and epochs count
+// from 1 within the launch: nothing depends on what an earlier launch (or a graph replay of this one) left behind.
+struct XChunk {
+  unsigned lo, tag0, hi, tag1;
+};
+static_assert(sizeof(XChunk) == 16, "one 16-byte access");
+constexpr int SIA_X_SLOTS = 16;   // chunks per part and buffer half of the per-iteration exchange (9 used: 8 sums + "changed")
+constexpr int SIA_XH_SLOTS = 24;  // ... of the H exchange (21 used)
+constexpr int SIA_X_MAX_PARTS = 4;
+constexpr int SIA_X_CHUNKS = 2 * SIA_X_MAX_PARTS * (SIA_X_SLOTS + SIA_XH_SLOTS);  // per frame
+
+#ifndef SVO_HOST_MATH_TEST
+__device__ __forceinline__ void sia_xstore(XChunk* p, double v, unsigned epoch) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  u4 w;
+  w.x = (unsigned)b; w.y = epoch; w.z = (unsigned)(b >> 32); w.w = epoch;
+  // The wait states behind the store are part of it: a VMEM store of more than 8 bytes reads its data registers for a few
+  // cycles after issue, and the compiler's hazard recogniser does not look inside an asm statement -- it placed a VALU
+  // write to the first data register pair right behind this store, and the quad of lanes the store had not read yet
+  // (lanes 12-15 of 21) sent a chunk with a clobbered epoch that no reader ever accepted (profiles/r06h_*).
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" ::"v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ XChunk sia_xload(const XChunk* p) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  u4 w;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(p) : "memory");
+  XChunk c;
+  c.lo = w.x; c.tag0 = w.y; c.hi = w.z; c.tag1 = w.w;
+  return c;
+}
+// the value of chunk p once both its halves carry `epoch`; NaN (and failed = 1) when they never do: a part that is not
+// running (the launcher only splits grids that are resident at once) must not hang the device
+__device__ __forceinline__ double sia_xpoll(const XChunk* p, unsigned epoch, int& failed) {
+  XChunk c = sia_xload(p);
+  unsigned spins = 0;
+  while (c.tag0 != epoch || c.tag1 != epoch) {
+    if (++spins > (1u << 16)) {
+      failed = 1;
+      return __longlong_as_double(0x7ff8000000000000ll);
+    }
+    __builtin_amdgcn_s_sleep(1);
+    c = sia_xload(p);
+  }
+  return __longlong_as_double((long long)(((unsigned long long)c.hi << 32) | c.lo));
+}
+#endif
 
 using svo_pyr::load_window12;
 using svo_pyr::run_start;

@@ -33,6 +33,8 @@
 // -DSIA_F64_PARTIALS builds the REFERENCE-WIDTH variant of this kernel: also the per-pixel products and SE3::exp in f64
 // like H_, Jres_ and jacobian_cache_ of the reference (sparse_img_align.cpp:228-230,253-258).  bench.py times it next to
 // the default (`f64_partials` / `roofline_f64_build` in the JSON line) so the price of that width is a number.
+#include <cstdlib>
+
 #include "sia_common.h"
 
 using namespace svo_capi;
@@ -101,6 +103,8 @@ struct SiaLds {
   double A[36];                  // Gauss-Jordan scratch
   sia_acc part[2][MAX_WAVES][8];  // per-wave partials of Jres[6], chi2, n_meas (double-buffered)
   int chg[2][MAX_WAVES];          // per wave: some patch entered or left the current image (same buffering)
+  double xsum[16];                // a split frame: the frame's sums of the iteration (9 used), published by the exchanging wave
+  int xfail;                      // ... some lane of the workgroup gave up waiting for a sibling part
   sia_acc Hpart[MAX_WAVES][24];   // per-wave partials of H (21 used)
   long long lo[SVO_HIP_MAX_LEVELS];  // pyramid geometry per level (copied from the kernel
   int lw[SVO_HIP_MAX_LEVELS];        // arguments so the level loop can index it dynamically)
@@ -115,11 +119,31 @@ __shared__ SiaLds g_s;
 // once per level (or when the set of patches inside the current image changes).
 // Same-wave LDS traffic: DS instructions of one wave execute in order; the
 // wavefront-scope fences stop the compiler from moving accesses across the exchanges.
-__device__ __forceinline__ void sia_rebuild_hinv(int lane, int nw) {
+// PARTS > 1: the workgroup's sums are one part of the frame's; the parts exchange them (xh: the frame's H chunks of this
+// exchange's buffer half, [PARTS][SIA_XH_SLOTS]) and every part adds them up in the same order.
+template <int PARTS>
+__device__ __forceinline__ void sia_rebuild_hinv(int lane, int nw, [[maybe_unused]] XChunk* xh, [[maybe_unused]] int part,
+                                                 [[maybe_unused]] unsigned gen, [[maybe_unused]] int& xfail) {
   asm volatile("" : "+v"(lane));  // keep this cold block's address math out of the caller's loops
   if (lane < 21) {
     double v = 0.0;
     for (int w = 0; w < nw; ++w) v += (double)g_s.Hpart[w][lane];
+#ifndef SVO_HOST_MATH_TEST
+    if constexpr (PARTS > 1) {
+      sia_xstore(xh + part * SIA_XH_SLOTS + lane, v, gen);
+      double hv[PARTS];
+#pragma unroll
+      for (int p = 0; p < PARTS; ++p) hv[p] = v;
+      // the other parts' sums: requested together, then waited for one by one
+#pragma unroll
+      for (int p = 0; p < PARTS; ++p)
+        if (p != part) hv[p] = sia_xpoll(xh + p * SIA_XH_SLOTS + lane, gen, xfail);
+      if (xfail) g_s.xfail = 1;
+      v = hv[0];
+#pragma unroll
+      for (int p = 1; p < PARTS; ++p) v += hv[p];
+    }
+#endif
     g_s.H[lane] = v;
   }
   SVO_WAVE_LDS_FENCE();
@@ -173,12 +197,29 @@ __device__ __forceinline__ sia_f2 sia_bilerp2(sia_f2 wtl, sia_f2 wtr, sia_f2 wbl
 #else
 #define SIA_PACKED 1
 #endif
-template <int BLOCK, bool WC, bool DIST>
-__global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK)) sia_kernel(const SiaArgs a) {
+// PARTS > 1 (round 6): a frame of more than 512 patches in a batch too small to fill the GPU -- BASELINE configs[3]: 1000
+// patches, 64 frames, i.e. 64 of 256 CUs busy with 16 waves each -- is split over PARTS workgroups of BLOCK lanes, part p
+// owning patches [p BLOCK, (p + 1) BLOCK).  An iteration's eight sums (and the "membership changed" flag, and H when it is
+// rebuilt) are exchanged between the parts as write-through 16-byte chunks (sia_common.h: XChunk); every part then
+// solves and updates for itself -- the same sums in the same order, hence the same pose -- so one exchange per iteration
+// is all the parts ever say to each other.  Part 0 writes the results.
+template <int BLOCK, bool WC, bool DIST, int PARTS = 1>
+__global__ void __launch_bounds__(BLOCK, PARTS > 1 ? 1 : ((DIST && BLOCK < 1024) ? 3 : MINW(BLOCK))) sia_kernel(const SiaArgs a) {
   constexpr int NW = BLOCK / 64;
   // XCD-aware problem order (capi_common.h): in a replay batch consecutive problems share a frame
   // (frame b+1 is the current image of problem b and the reference image of problem b+1)
-  const int b = (int)xcd_contiguous_block();
+  int b, part = 0;
+  if constexpr (PARTS > 1) {
+    // the parts of a frame 8 workgroup ids apart: usually the same XCD (speed only: the exchange does not rely on it)
+    b = (int)(blockIdx.x / (8 * PARTS)) * 8 + (int)(blockIdx.x % 8);
+    part = (int)(blockIdx.x / 8) % PARTS;
+    if (b >= a.B) return;
+  } else {
+    b = (int)xcd_contiguous_block();
+  }
+  [[maybe_unused]] XChunk* const xbase = PARTS > 1 ? static_cast<XChunk*>(a.xw) + (size_t)b * SIA_X_CHUNKS : nullptr;
+  [[maybe_unused]] unsigned xseq = 0;  // epoch of the last exchange (uniform over the frame's parts; the blocks start zeroed)
+  [[maybe_unused]] int xfail = 0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -197,7 +238,7 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
   const svo_hip_sia_params P = a.P;
 
   if (n <= 0) {  // sparse_img_align.cpp:47-51: nothing to track, pose untouched
-    if (tid == 0) {
+    if (tid == 0 && part == 0) {
       for (int k = 0; k < 12; ++k) a.T_out[12 * b + k] = a.T_in[12 * b + k];
       if (a.H_out)
         for (int k = 0; k < 36; ++k) a.H_out[36 * b + k] = 0.0;
@@ -211,8 +252,9 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
   }
 
   // ---- per-lane geometry (Feature::px is re-read per level, f*depth kept) --
-  const size_t fo = (size_t)b * a.n_stride + tid;
-  const bool has = (tid < n) && (a.valid ? a.valid[fo] != 0 : true);
+  const int pid = part * BLOCK + tid;  // this lane's patch
+  const size_t fo = (size_t)b * a.n_stride + pid;
+  const bool has = (pid < n) && (a.valid ? a.valid[fo] != 0 : true);
   double X = 0, Y = 0, Z = 1;
   if (has) {
     X = a.xyz[3 * fo];
@@ -244,7 +286,8 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       g_s.lo[k] = a.L.offset[k];
     }
     for (int k = 0; k < 21; ++k) g_s.H[k] = 0.0;
-    if (a.iters)
+    g_s.xfail = 0;
+    if (a.iters && part == 0)
       for (int k = 0; k < SVO_HIP_MAX_LEVELS; ++k) a.iters[SVO_HIP_MAX_LEVELS * b + k] = 0;
   }
   // model of this wave: every lane computes the same values, lane 0 stores them
@@ -616,6 +659,41 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       int changed = 0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) changed |= g_s.chg[buf][w];
+      [[maybe_unused]] double xtot = 0.0;  // PARTS > 1: lane k < 9 of every wave holds the FRAME's sum k (k = 8: "changed" anywhere)
+#ifndef SVO_HOST_MATH_TEST
+      if constexpr (PARTS > 1) {
+        // every wave takes part (no second barrier): lane = (part xp, sum xk); the workgroup's own sums come from LDS, wave
+        // `sw` publishes them, the other parts' are polled
+        ++xseq;
+        const int xp = lane >> 4, xk = lane & 15;
+#ifdef SIA_X_ONEWAVE
+        if (wave == sw) {
+#endif
+        double own = 0.0;
+        if (xk < 8) {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) own += (double)g_s.part[buf][w][xk];
+        } else if (xk == 8) {
+          own = (double)changed;
+        }
+        XChunk* const slot = xbase + (size_t)(xseq & 1) * (SIA_X_MAX_PARTS * SIA_X_SLOTS);
+        if (wave == sw && xp == part && xk < 9) sia_xstore(slot + part * SIA_X_SLOTS + xk, own, xseq);
+        double val = own;
+        if (xp != part && xp < PARTS && xk < 9) val = sia_xpoll(slot + xp * SIA_X_SLOTS + xk, xseq, xfail);
+        if (xfail) g_s.xfail = 1;
+        // the parts in a fixed order: every part forms the same sums
+        xtot = __shfl(val, xk, 64);
+#pragma unroll
+        for (int p = 1; p < PARTS; ++p) xtot += __shfl(val, 16 * p + xk, 64);
+#ifdef SIA_X_ONEWAVE
+          if (lane < 9) g_s.xsum[lane] = xtot;
+        }
+        __syncthreads();
+        xtot = g_s.xsum[xk < 9 ? xk : 0];
+#endif
+        changed = readlane_f64<8>(xtot) != 0.0;
+      }
+#endif
       [[maybe_unused]] const long long tb1 = SIA_T();
       SIA_ACC(2, tb0, tb1);
       if (changed) {
@@ -644,7 +722,14 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
         }
         inH = (int)m;
         __syncthreads();
-        if (wave == 0) sia_rebuild_hinv(lane, NW);
+        if constexpr (PARTS > 1) {
+          // (its own generation: the H exchange of this iteration follows the iteration's sum exchange)
+          ++xseq;
+          XChunk* const xh = xbase + 2 * SIA_X_MAX_PARTS * SIA_X_SLOTS + (size_t)(xseq & 1) * (SIA_X_MAX_PARTS * SIA_XH_SLOTS);
+          if (wave == 0) sia_rebuild_hinv<PARTS>(lane, NW, xh, part, xseq, xfail);
+        } else {
+          if (wave == 0) sia_rebuild_hinv<1>(lane, NW, nullptr, 0, 0u, xfail);
+        }
         __syncthreads();
       }
       ++evals;
@@ -672,7 +757,9 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       if (rot_wave || trans_wave) {
         __builtin_amdgcn_s_setprio(3);  // the other waves of the workgroup wait for these two: let them win the issue arbitration
         double colsum = 0.0;
-        {
+        if constexpr (PARTS > 1) {
+          colsum = xtot;  // (lanes 0..7: the frame's sums)
+        } else {
           const int k = lane & 7;
 #pragma unroll
           for (int w = 0; w < NW; ++w) colsum += (double)g_s.part[buf][w][k];
@@ -792,10 +879,10 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
       SIA_ACC(4, ts0, SIA_T());
       if (done) break;
     }
-    if (tid == 0 && a.iters) a.iters[SVO_HIP_MAX_LEVELS * b + level] = evals;
+    if (tid == 0 && part == 0 && a.iters) a.iters[SVO_HIP_MAX_LEVELS * b + level] = evals;
   }
 
-  if (tid == 0) {
+  if (tid == 0 && part == 0) {
     for (int k = 0; k < 9; ++k) a.T_out[12 * b + k] = R[k];
     for (int k = 0; k < 3; ++k) a.T_out[12 * b + 9 + k] = tr[k];
     if (a.H_out)
@@ -808,7 +895,8 @@ __global__ void __launch_bounds__(BLOCK, (DIST && BLOCK < 1024) ? 3 : MINW(BLOCK
 #endif
     a.n_tracked[b] = n_meas_last / 16;
     if (a.chi2) a.chi2[b] = chi2_prev;
-    if (a.status) a.status[b] = stop ? SVO_HIP_SIA_STOP : 0;
+    // (g_s.xfail: written by whichever lane gave up, ahead of the barrier that ends its iteration)
+    if (a.status) a.status[b] = (stop ? SVO_HIP_SIA_STOP : 0) | ((PARTS > 1 && g_s.xfail) ? SVO_HIP_SIA_EXCHANGE_TIMEOUT : 0);
   }
 }
 
@@ -869,6 +957,41 @@ int sia_prepare(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int B,
   return 1;  // launch
 }
 
+// ---- a frame split over four workgroups (PARTS = 4) -------------------------------------------------------------------
+// For frames of more than 512 patches in batches that leave most of the GPU idle (4 B workgroups of 256 lanes must be
+// RESIDENT AT ONCE -- the parts spin on each other --: B <= SIA_SPLIT_MAX_B).  The exchange blocks are a stream-ordered
+// allocation of the launch, zeroed by a memset ahead of the kernel; epochs count from 1 inside the launch (no per-launch
+// salt: a captured launch replays with the arguments it was captured with).  SVO_HIP_K1_SPLIT=0 keeps every frame on one
+// workgroup.
+constexpr int SIA_SPLIT_PARTS = 4;
+constexpr int SIA_SPLIT_MAX_B = 128;
+#ifndef SVO_HOST_MATH_TEST
+bool sia_split_applies(const SiaArgs& args, int B) {
+  static const bool on = [] { const char* v = std::getenv("SVO_HIP_K1_SPLIT"); return !(v && v[0] == '0'); }();
+  return on && args.n_stride > 512 && B <= SIA_SPLIT_MAX_B;
+}
+int launch_split(SiaArgs args, int B, hipStream_t s) {
+  void* xw = nullptr;
+  const size_t bytes = (size_t)B * SIA_X_CHUNKS * sizeof(XChunk);
+  SVO_HIP_TRY(hipMallocAsync(&xw, bytes, s));
+  if (hipMemsetAsync(xw, 0, bytes, s) != hipSuccess) {
+    (void)hipFreeAsync(xw, s);
+    return SVO_HIP_EHIP;
+  }
+  args.B = B;
+  args.xw = xw;
+  const dim3 grid((unsigned)((B + 7) / 8) * 8 * SIA_SPLIT_PARTS), blk(256);
+  if (args.P.cam_model == SVO_HIP_CAM_PINHOLE)
+    hipLaunchKernelGGL((sia_kernel<256, true, false, SIA_SPLIT_PARTS>), grid, blk, 0, s, args);
+  else
+    hipLaunchKernelGGL((sia_kernel<256, false, true, SIA_SPLIT_PARTS>), grid, blk, 0, s, args);
+  const int rc = check_launch();
+  SVO_HIP_TRY(hipFreeAsync(xw, s));
+  return rc;
+}
+#endif
+
+
 int launch_workgroup(const SiaArgs& args, int B, hipStream_t s) {
   if (args.n_stride <= 64) return launch<64>(args, B, s);
   if (args.n_stride <= 128) return launch<128>(args, B, s);
@@ -893,6 +1016,9 @@ extern "C" int svo_hip_sparse_align(const svo_hip_pyr_layout* layout, const uint
   hipStream_t s = static_cast<hipStream_t>(stream);
   // large batches of frames with up to 192 patches: one wave per frame (sparse_align_wave.hip); else one workgroup
   if (sia_wave_applies(args, B)) return launch_sia_wave(args, B, s);
+#ifndef SVO_HOST_MATH_TEST
+  if (sia_split_applies(args, B)) return launch_split(args, B, s);
+#endif
   return launch_workgroup(args, B, s);
 }
 

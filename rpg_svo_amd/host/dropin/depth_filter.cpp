@@ -62,7 +62,7 @@ static void releaseSeedStore(const DepthFilter* df) {
   r.all.erase(it);
 }
 static bool seedStoreOn() {
-  static const bool on = [] { const char* v = std::getenv("SVO_HIP_SEED_STORE"); return !(v && std::string(v) == "off"); }();
+  static const bool on = [] { const char* v = std::getenv("SVO_HIP_SEED_STORE"); return !(v && std::string(v) == "off"); }();  // (on | verify)
   return on;
 }
 // calls / records sent / rebuilds, summed over the stores of the process (read-outs of the tests and the benchmark)
@@ -200,7 +200,8 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   const bool is_kf = frame->isKeyframe();
   void* const stream = lane.stream;
   svo_hip::Device* const pdev = &dev;
-  const std::function<void()> replay = [this, frame, is_kf, S, ids, status, sa, sb, smu, ss2, xyz, px_cur]() {
+  SeedStore* const vstore = resident && seedStoreOf(this).verifying() ? &seedStoreOf(this) : NULL;
+  const std::function<void()> replay = [this, frame, is_kf, S, ids, status, sa, sb, smu, ss2, xyz, px_cur, vstore]() {
     size_t s = 0;
     for (std::list<Seed>::iterator it = seeds_.begin(); it != seeds_.end() && s < S;) {
       while (s < S && ids[s] < it->id) ++s;  // erased since the update was enqueued
@@ -211,6 +212,7 @@ void DepthFilter::updateSeeds(FramePtr frame) {
       if (st == SVO_HIP_SEED_BEHIND || st == SVO_HIP_SEED_NOT_IN_FRAME) { ++it; continue; }
       if (st == SVO_HIP_SEED_ERASED_OLD) { it = seeds_.erase(it); continue; }
       it->a = sa[k]; it->b = sb[k]; it->mu = smu[k]; it->sigma2 = ss2[k];
+      if (vstore) vstore->reported(it->id, sa[k], sb[k], smu[k], ss2[k]);
       if (st == SVO_HIP_SEED_NO_MATCH) { ++it; continue; }  // b was incremented on the device
       if (is_kf)  // the detector must not start new seeds next to a matched one
         feature_detector_->setGridOccpuancy(Vector2d(px_cur[2 * k], px_cur[2 * k + 1]));

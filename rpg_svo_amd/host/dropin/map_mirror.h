@@ -128,6 +128,10 @@ class MapMirror {
     return cand_entries_;
   }
 
+  // changes recorded since the last emitPatch() (a caller that enqueued a launch on the last patch asks whether the map
+  // has moved on since)
+  bool pending() const { return !dirty_.empty() || obs_sent_ != obs_ftr_.size(); }
+
   // ---- the device side --------------------------------------------------------------------------------------------
   size_t patchBytes() const { return dirty_.size() * 64 + (obs_ftr_.size() - obs_sent_) * 96 + 4096; }
   // device buffers for the current shadow (grown geometrically; growing re-sends everything) and the visiting ranks

@@ -32,6 +32,7 @@
 #include <svo/map.h>
 #include <svo/point.h>
 
+#include "frame_chain.h"
 #include "map_mirror.h"
 #include "marshal.h"
 
@@ -115,52 +116,366 @@ void releaseMirror(const Map* map) {
   r.all.erase(it);
 }
 
+// ---- one batch of the mirrored path: reproject_map -> match kernels -> selection -> predicted pose refinement ---------
+// The blocks of a batch in the lane's arena, and the launches on them.  Two users: reprojectMapMirrored's own call (fill
+// -> upload -> launch -> wait), and MirrorChain below, which adds the same blocks and launches to the call of
+// SparseImgAlign::run's drop-in, behind K1 (frame_chain.h).
+struct MirrorBatch {
+  static const size_t V_CAP = 4096;
+  // ---- what the batch is about (set by the user before allocInputs)
+  svo_hip::Device* dev;
+  svo_hip::Lane* lane;
+  hip_dropin::MapMirror* mm;
+  svo_hip_camera cam;
+  int cell_size, n_cols, n_rows;
+  size_t n_cells, first_cell, max_cells, T_CAP;
+  int align_max_iter;
+  int i_cur;
+  bool predict;
+  std::vector<int32_t> rank_of;  // per entry of the frame table: rank among the overlapping keyframes, or -1
+  int frame_id;
+  // ---- device addresses and their host views
+  svo_hip_map_patch patch;
+  int32_t* d_rank;
+  svo_hip_frames ft;
+  double* h_frame_T;  // host view of the frame table's poses (the chain re-reads nothing from it; kept for symmetry)
+  double *d_sf, *d_spos; int32_t* d_slvl;
+  svo_hip_reprojection out;
+  int32_t* header;
+  const int32_t *h_point_cell, *h_kf_count, *h_vp, *h_vc, *h_vt, *h_ok, *h_ref, *h_lvl;
+  const double *h_px, *h_A;
+  double* d_A; int32_t *d_ok, *d_ref, *d_lvl;
+  double *d_T, *d_Cov, *d_stats; int32_t *d_nsel, *d_sel, *d_ran, *d_flag; uint8_t* d_has;
+  volatile int32_t* flag;
+  double* h_T;  // the predicted refinement's in/out pose block (host view)
+  size_t inputs_end, match_end, results_begin;
+
+  MirrorBatch() { std::memset(static_cast<void*>(&patch), 0, sizeof(patch)); clear(); }
+  void clear() {
+    dev = NULL; lane = NULL; mm = NULL; predict = false; d_rank = NULL; h_frame_T = NULL; d_sf = d_spos = NULL; d_slvl = NULL;
+    std::memset(&out, 0, sizeof(out)); header = NULL; flag = NULL; d_flag = NULL; d_T = d_Cov = d_stats = NULL; h_T = NULL;
+    d_nsel = d_sel = d_ran = NULL; d_has = NULL; inputs_end = match_end = results_begin = 0; frame_id = -1;
+  }
+  size_t arenaBytes(size_t n_tab) const {
+    return ((size_t)1 << 17) + mm->patchBytes() + mm->entries().size() * 8 + T_CAP * 128 + V_CAP * 16 + n_tab * 128;
+  }
+  // inputs: what changed in the map, the ranks of the overlapping keyframes, the frame table (before Arena::endInputs())
+  void allocInputs(svo_hip::Arena& a, const hip_dropin::FrameTable& frames) {
+    patch = mm->emitPatch(a);
+    int32_t* rank = a.alloc<int32_t>(rank_of.size(), &d_rank);
+    std::copy(rank_of.begin(), rank_of.end(), rank);
+    frames.emit(a, &ft);
+    const size_t cap = (size_t)Config::maxFts() + 1;
+    if (predict) {  // the predicted pose refinement's observations: gathered on the device, never read by the host
+      a.alloc<double>(3 * cap, &d_sf);
+      a.alloc<double>(3 * cap, &d_spos);
+      a.alloc<int32_t>(cap, &d_slvl);
+    }
+  }
+  // outputs the host reads (after Arena::endInputs()); sp: the lane's speculation record, filled when predict
+  void allocOutputs(svo_hip::Arena& a, size_t n_tab, const FramePtr& frame, svo_hip::Speculation& sp, bool pose_from_device) {
+    inputs_end = a.used();
+    const size_t P = mm->entries().size();
+    header = a.alloc<int32_t>(SVO_HIP_REPROJ_HEADER, &out.d_header);
+    header[0] = -1;
+    h_point_cell = a.alloc<int32_t>(P ? P : 1, &out.d_point_cell);
+    h_kf_count = a.alloc<int32_t>(n_tab, &out.d_kf_count);
+    h_vp = a.alloc<int32_t>(V_CAP, &out.d_visit_point);
+    h_vc = a.alloc<int32_t>(V_CAP, &out.d_visit_cell);
+    h_vt = a.alloc<int32_t>(V_CAP, &out.d_visit_trial);
+    h_px = a.alloc<double>(2 * T_CAP, &out.d_trial_px);
+    h_ok = a.alloc<int32_t>(T_CAP, &d_ok);
+    h_ref = a.alloc<int32_t>(T_CAP, &d_ref);
+    h_lvl = a.alloc<int32_t>(T_CAP, &d_lvl);
+    h_A = a.alloc<double>(4 * T_CAP, &d_A);
+    match_end = a.used();
+    out.d_point_px = mm->pointPx();
+    out.d_trial_cur = mm->trialCur(); out.d_trial_pos = mm->trialPos();
+    out.d_trial_obs_begin = mm->trialObsBegin(); out.d_trial_obs_end = mm->trialObsEnd(); out.d_trial_cell = mm->trialCell();
+    results_begin = match_end;
+    if (predict) {
+      const size_t cap = (size_t)Config::maxFts() + 1;
+      sp.frame_id = frame->id_;
+      sp.point.clear(); sp.px.clear(); sp.level.clear(); sp.trial.clear();
+      results_begin = a.used();
+      h_T = a.alloc<double>(12, &d_T);
+      hip_dropin::poseToRt(frame->T_f_w_, h_T);  // (pose_from_device: overwritten on the stream, and T_init set when it is known)
+      if (!pose_from_device) std::copy(h_T, h_T + 12, sp.T_init);
+      sp.T = h_T;
+      sp.n_sel = a.alloc<int32_t>(1, &d_nsel);
+      sp.sel = a.alloc<int32_t>(cap, &d_sel);
+      sp.has_point = a.alloc<uint8_t>(cap, &d_has);
+      sp.Cov = a.alloc<double>(36, &d_Cov);
+      sp.stats = a.alloc<double>(4, &d_stats);
+      sp.ran = a.alloc<int32_t>(1, &d_ran);
+      if (a.mode() != svo_hip::Arena::MIRRORED) {
+        flag = a.alloc<int32_t>(1, &d_flag);
+        *flag = 0;
+      }
+      sp.reproj_thresh = Config::poseOptimThresh();
+      sp.n_iter = (int)Config::poseOptimNumIter();
+    }
+  }
+  // reproject_map -> match kernels -> (predict, flag-capable arena) selection + pose refinement, on the lane's stream
+  void launchMatch(svo_hip::Arena& a) {
+    const svo_hip_map dmap = mm->deviceMap();
+    const svo_hip_features dobs = mm->deviceObs();
+    svo_hip_grid g;
+    g.cell_size = cell_size; g.n_cols = n_cols; g.n_rows = n_rows; g.n_cells = (int32_t)n_cells;
+    g.d_cell_rank = mm->cellRank();
+    void* ws = dev->workspace(*lane, (int)T_CAP);
+    int32_t* const d_M = out.d_header + 3;
+    svo_hip::check(svo_hip_reproject_map(&cam, &ft, i_cur, d_rank, &dmap, &patch, &g, (int)first_cell,
+                                         (int)std::min(max_cells, (size_t)1 << 30), (int)V_CAP, (int)T_CAP, &out, lane->stream),
+                   "svo_hip_reproject_map");
+    svo_hip::check(svo_hip_find_match_direct_indirect(&dev->layout(), dev->store(), &cam, &ft, (int)T_CAP, d_M, out.d_trial_cur,
+                                                      out.d_trial_pos, out.d_trial_obs_begin, out.d_trial_obs_end, &dobs,
+                                                      Config::nPyrLevels(), align_max_iter, out.d_trial_px, d_ok, d_ref, d_lvl, d_A,
+                                                      NULL, ws, lane->workspace_bytes, lane->stream),
+                   "svo_hip_find_match_direct_indirect");
+    a.downloadRange(inputs_end, match_end, lane->stream);
+  }
+  // hybrid / mapped arena: the selection kernel stores `flag` when it starts, i.e. when the match kernels are through;
+  // the host polls that, pose refinement follows on the same stream
+  void launchPredictionSameStream(svo_hip::Speculation& sp) {
+    const size_t cap = (size_t)Config::maxFts() + 1;
+    int32_t* const d_M = out.d_header + 3;
+    svo_hip::check(svo_hip_select_matches_indirect(&cam, (int)T_CAP, d_M, out.d_trial_cell, d_ok, out.d_trial_px, d_lvl,
+                                                   out.d_trial_pos, Config::maxFts(), d_nsel, d_sel, d_sf, d_slvl, d_spos, d_has,
+                                                   d_flag, 1, lane->stream),
+                   "svo_hip_select_matches_indirect");
+    svo_hip::check(svo_hip_pose_optimize_deferred(&cam, 1, d_nsel, (int)cap, d_sf, d_slvl, d_spos, d_has, sp.reproj_thresh,
+                                                  sp.n_iter, d_T, d_Cov, d_stats, d_ran, lane->stream),
+                   "svo_hip_pose_optimize_deferred");
+    sp.stream = lane->stream;
+    sp.in_flight = true;
+  }
+};
+
+// ---- the chain behind SparseImgAlign::run (frame_chain.h) ---------------------------------------------------------------
+// One per Reprojector, registered on the tracking lane of the thread that calls reprojectMap.  GridT: Reprojector::Grid
+// (private: deduced).
+struct ChainRegistry {
+  std::mutex mut;
+  std::map<const void*, hip_dropin::FrameChain*> all;  // Reprojector -> its chain
+};
+ChainRegistry& chains() {
+  static ChainRegistry r;
+  return r;
+}
+
+template <class GridT>
+class MirrorChain : public hip_dropin::FrameChain {
+ public:
+  MirrorChain(Map& map, const GridT& grid, const Reprojector::Options& options, const int* align_max_iter)
+      : map_(map), grid_(grid), options_(options), align_max_iter_(align_max_iter), state_(IDLE), hook_lane_(NULL), d_qt_(NULL),
+        h_Tcomp_(NULL), d_Tcomp_(NULL), flag_k1_(NULL), d_flag_k1_(NULL), n_tab_(0), rebuilds_at_prepare_(0) {}
+
+  svo_hip::Lane* hook_lane_;  // the lane the chain is registered on
+
+  bool prepare(const FramePtr& ref, const FramePtr& cur, svo_hip::Device& dev, svo_hip::Lane& lane, hip_dropin::FrameTable& frames,
+               size_t k1_bytes) {
+    using namespace hip_dropin;
+    state_ = IDLE;
+    if (!options_.find_match_direct || MapMirror::mode() == MapMirror::OFF || !cur->fts_.empty()) return false;
+    if (lane.arena.mode() == svo_hip::Arena::MIRRORED) return false;  // (no host-visible signals)
+    const size_t n_cells = grid_.cells.size();
+    if (n_cells > (size_t)SVO_HIP_REPROJ_MAX_CELLS || options_.max_n_kfs > 16) return false;
+    MapMirror& mm = mirrorOf(&map_);
+    // the overlapping keyframes as the PRIOR pose sees them (frame_handler_mono.cpp:132: cur->T_f_w_ is the last frame's)
+    std::list<KfDist> close_kfs;
+    map_.getCloseKeyframes(cur, close_kfs);
+    close_kfs.sort(closerKf);
+    if (!mm.sync(map_)) return false;  // (the ordinary path will find the same and fall back)
+    const size_t n_mirror = mm.frames().size();
+    if (n_mirror + 2 > 64 || (size_t)dev.slots() < n_mirror + 4) return false;
+    ranked_.clear();
+    std::vector<int32_t> rank_of(n_mirror + 2, -1);  // the mirror's frames, the current one, the reference frame of K1
+    for (std::list<KfDist>::iterator kf = close_kfs.begin(); kf != close_kfs.end() && ranked_.size() < options_.max_n_kfs; ++kf) {
+      const int idx = mm.frameIndex(kf->first.get());
+      if (idx < 0) return false;
+      rank_of[(size_t)idx] = (int32_t)ranked_.size();
+      ranked_.push_back(std::make_pair(kf->first, idx));
+    }
+    b_.clear();
+    b_.dev = &dev; b_.lane = &lane; b_.mm = &mm;
+    b_.T_CAP = mirrorTrialCap();
+    mm.ensureDevice(grid_.cell_order, b_.T_CAP);
+    lane.arena.reserve(b_.arenaBytes(n_mirror + 2) + k1_bytes + 4096);
+    for (size_t i = 0; i < n_mirror; ++i)
+      if (frames.indexOf(mm.frames()[i]) != (int)i) throw std::logic_error("Reprojector: frame table out of order");
+    b_.i_cur = frames.indexOf(cur.get());
+    frames.indexOf(ref.get());  // (a keyframe of the mirror, or one more entry)
+    n_tab_ = (size_t)frames.size();
+    rank_of.resize(n_tab_, -1);
+    b_.rank_of.swap(rank_of);
+    b_.cam = cameraOf(cur->cam_);
+    b_.cell_size = grid_.cell_size; b_.n_cols = grid_.grid_n_cols; b_.n_rows = grid_.grid_n_rows;
+    b_.n_cells = n_cells; b_.first_cell = 0; b_.max_cells = firstBatchCells();
+    b_.align_max_iter = *align_max_iter_;
+    b_.predict = svo_hip::Device::speculationEnabled();
+    b_.frame_id = cur->id_;
+    frames_ = &frames;
+    cur_ = cur;
+    rebuilds_at_prepare_ = mm.stats.rebuilds;
+    state_ = PREPARED;
+    return true;
+  }
+  void allocInputs(svo_hip::Arena& a, const FramePtr& ref) {
+    b_.allocInputs(a, *frames_);
+    double* qt = a.alloc<double>(8, &d_qt_);  // the reference frame's pose as the host's product reads it
+    hip_dropin::poseToQt(ref->T_f_w_, qt, qt + 4);
+    qt[7] = 0.0;
+  }
+  void allocOutputs(svo_hip::Arena& a) {
+    b_.allocOutputs(a, n_tab_, cur_, b_.lane->spec, true);
+    h_Tcomp_ = a.alloc<double>(12, &d_Tcomp_);
+    flag_k1_ = a.alloc<int32_t>(1, &d_flag_k1_);
+    *flag_k1_ = 0;
+  }
+  void enqueue(const double* d_T_cur_ref) {
+    svo_hip::check(svo_hip_frame_pose_compose(d_T_cur_ref, d_qt_, d_qt_ + 4, const_cast<double*>(b_.ft.d_T_f_w), b_.i_cur, b_.predict ? b_.d_T : NULL, d_Tcomp_,
+                                              d_flag_k1_, 1, b_.lane->stream),
+                   "svo_hip_frame_pose_compose");
+    b_.launchMatch(b_.lane->arena);
+    svo_hip::Speculation& sp = b_.lane->spec;
+    if (b_.predict) {
+      b_.launchPredictionSameStream(sp);
+    } else {
+      sp.stream = b_.lane->stream;  // (beginCall() of the lane's next call drains the stream before it refills the arena)
+      sp.in_flight = true;
+    }
+    state_ = IN_FLIGHT;
+  }
+  const volatile int32_t* k1Signal() const { return flag_k1_; }
+  void abandon() { state_ = IDLE; cur_.reset(); }
+
+  // ---- the other end: Reprojector::reprojectMap asks for the batch of `frame` -----------------------------------------
+  // true: the chain's batch is the frame's (verified), its match results have arrived; `ranked` / `rank_of` / n_tab as the
+  // ordinary path would have built them.  false: take the ordinary path (whatever was enqueued is drained by its beginCall()).
+  bool adopt(const FramePtr& frame, svo_hip::Device& dev, svo_hip::Lane& lane, MirrorBatch& out_batch,
+             std::vector<std::pair<FramePtr, int> >& ranked, size_t& n_tab) {
+    using namespace hip_dropin;
+    if (state_ != IN_FLIGHT) return false;
+    state_ = IDLE;
+    FramePtr cur;
+    cur.swap(cur_);
+    std::lock_guard<std::mutex> guard(lane.mut);
+    svo_hip::Speculation& sp = lane.spec;
+    bool ok = b_.lane == &lane && b_.dev == &dev && cur.get() == frame.get() && sp.in_flight && sp.stream == lane.stream &&
+              b_.frame_id == frame->id_ && *flag_k1_ == 1;
+    if (ok) {  // the pose the device formed is the pose the host formed
+      double T[12];
+      poseToRt(frame->T_f_w_, T);
+      ok = std::memcmp(T, h_Tcomp_, sizeof(T)) == 0;
+    }
+    if (ok) {  // the overlapping keyframes of the final pose are, in order, the ones the prior pose found
+      std::list<KfDist> close_kfs;
+      map_.getCloseKeyframes(frame, close_kfs);
+      close_kfs.sort(closerKf);
+      size_t k = 0;
+      for (std::list<KfDist>::iterator kf = close_kfs.begin(); kf != close_kfs.end() && k < options_.max_n_kfs; ++kf, ++k)
+        if (k >= ranked_.size() || ranked_[k].first.get() != kf->first.get()) { ok = false; break; }
+      if (ok && k != ranked_.size()) ok = false;
+    }
+    if (ok) {  // nothing has touched the map since the chain was built
+      MapMirror& mm = *b_.mm;
+      ok = &mm == &mirrorOf(&map_) && mm.sync(map_) && !mm.pending() && mm.stats.rebuilds == rebuilds_at_prepare_;
+    }
+    if (ok) {
+      {
+        svo_hip::StageTimer stage_timer(dev, lane, svo_hip::Device::STAGE_REPROJECT);
+        stage_timer.device(0);
+        if (b_.predict) svo_hip::spinUntil(b_.flag, 1, lane.stream);
+        else dev.finish(lane);
+        stage_timer.unmarshal();
+      }
+      ok = b_.header[0] == 0;
+    }
+    dev.countChain(ok);
+    if (!ok) return false;  // (sp.in_flight stays set: the ordinary path's beginCall() waits for the stream)
+    if (b_.predict) std::copy(h_Tcomp_, h_Tcomp_ + 12, sp.T_init);
+    else sp.in_flight = false;  // (the stream has been waited for)
+    out_batch = b_;
+    ranked = ranked_;
+    n_tab = n_tab_;
+    return true;
+  }
+
+  static size_t mirrorTrialCap() {
+    static const long t_cap_override = [] { const char* v = std::getenv("SVO_HIP_MIRROR_TRIALS"); return v ? std::atol(v) : 0L; }();
+    return t_cap_override > 0 ? (size_t)t_cap_override : 4096;
+  }
+  static size_t firstBatchCells() {
+    static const long first_batch_override = [] { const char* v = std::getenv("SVO_HIP_FIRST_BATCH_CELLS"); return v ? std::atol(v) : 0L; }();
+    return first_batch_override > 0 ? (size_t)first_batch_override : (size_t)Config::maxFts() + 1 + ((size_t)Config::maxFts() + 1) / 3 + 8;
+  }
+
+ private:
+  enum State { IDLE = 0, PREPARED = 1, IN_FLIGHT = 2 };
+  Map& map_;
+  const GridT& grid_;
+  const Reprojector::Options& options_;
+  const int* align_max_iter_;
+  State state_;
+  MirrorBatch b_;
+  hip_dropin::FrameTable* frames_;
+  FramePtr cur_;
+  std::vector<std::pair<FramePtr, int> > ranked_;
+  double* d_qt_;
+  double *h_Tcomp_, *d_Tcomp_;
+  volatile int32_t* flag_k1_;
+  int32_t* d_flag_k1_;
+  size_t n_tab_;
+  uint64_t rebuilds_at_prepare_;
+};
+
 // Steps 1-4 of reprojectMap with the walk of the pointer graph replaced by one kernel over the mirror: the host finds
 // the overlapping keyframes (the reference's own getCloseKeyframes: a dozen keyframes, five key points each), sends what
 // changed in the map since the last frame, and enqueues  reproject_map -> match kernels -> selection -> pose refinement
 // back to back; it then replays the candidate bookkeeping (:108-123) and the cell loop (:131-139, 151-200) from the
 // result tables.  Returns false -- having changed nothing -- when the frame has to take the list-walking path below.
+// `chain`: the Reprojector's MirrorChain, or NULL; when it holds this frame's batch (enqueued behind K1 and verified
+// here) the first batch is taken from there.
 template <class GridT>
 bool reprojectMapMirrored(const FramePtr& frame, std::vector<std::pair<FramePtr, std::size_t> >& overlap_kfs, Map& map_,
                           const GridT& grid_, const Reprojector::Options& options_, int align_max_iter, size_t& n_matches_,
-                          size_t& n_trials_) {
+                          size_t& n_trials_, MirrorChain<GridT>* chain) {
   using namespace hip_dropin;
   const size_t n_cells = grid_.cells.size();
   // trials / visits one batch can hold (status 1 beyond: the frame takes the list-walking path; SVO_HIP_MIRROR_TRIALS
   // overrides the trial capacity: the tests use it to force that hand-over)
-  static const long t_cap_override = [] { const char* v = std::getenv("SVO_HIP_MIRROR_TRIALS"); return v ? std::atol(v) : 0L; }();
-  const size_t T_CAP = t_cap_override > 0 ? (size_t)t_cap_override : 4096, V_CAP = 4096;
+  const size_t T_CAP = MirrorChain<GridT>::mirrorTrialCap();
   if (n_cells > (size_t)SVO_HIP_REPROJ_MAX_CELLS || options_.max_n_kfs > 16) return false;
   MapMirror& mm = mirrorOf(&map_);
   ++mm.stats.calls;
-  std::list<KfDist> close_kfs;
-  map_.getCloseKeyframes(frame, close_kfs);
-  close_kfs.sort(closerKf);
-  if (!mm.sync(map_)) { ++mm.stats.fallbacks; mm.invalidate(); return false; }
   svo_hip::Device& dev = ensureDevice(*frame);
-  const size_t n_tab = mm.frames().size() + 1;  // the mirror's frames, then the current one
-  if ((size_t)dev.slots() < n_tab + 2) { ++mm.stats.fallbacks; mm.invalidate(); return false; }  // every keyframe resident at once
-  std::vector<int32_t> rank_of(n_tab, -1);
-  std::vector<std::pair<FramePtr, int> > ranked;  // (keyframe, its index in the frame table), closest first
-  for (std::list<KfDist>::iterator kf = close_kfs.begin(); kf != close_kfs.end() && ranked.size() < options_.max_n_kfs; ++kf) {
-    const int idx = mm.frameIndex(kf->first.get());
-    if (idx < 0) { ++mm.stats.fallbacks; mm.invalidate(); return false; }  // (a keyframe of the map the mirror does not know: cannot happen after sync)
-    rank_of[(size_t)idx] = (int32_t)ranked.size();
-    ranked.push_back(std::make_pair(kf->first, idx));
-  }
   const int L = svo_hip::Device::LANE_TRACKING;
   svo_hip::Lane& lane = dev.lane(L);
 
-  // the tables of the batch in flight (host addresses of arena blocks)
-  struct View {
-    const int32_t *header, *visit_point, *visit_cell, *visit_trial, *ok, *lvl, *ref;
-    const double *px, *A;
-    size_t V, end_cell;
-  } view;
-  std::memset(&view, 0, sizeof(view));
-  bool predict = false;
-  const int32_t* point_cell = NULL;
-  const int32_t* kf_count = NULL;
+  MirrorBatch batch;  // the batch in flight
+  std::vector<std::pair<FramePtr, int> > ranked;  // (keyframe, its index in the frame table), closest first
+  size_t n_tab = 0;
+  std::vector<int32_t> rank_of;
+  const bool adopted = chain != NULL && chain->adopt(frame, dev, lane, batch, ranked, n_tab);
+  if (adopted) {
+    rank_of = batch.rank_of;
+  } else {
+    std::list<KfDist> close_kfs;
+    map_.getCloseKeyframes(frame, close_kfs);
+    close_kfs.sort(closerKf);
+    if (!mm.sync(map_)) { ++mm.stats.fallbacks; mm.invalidate(); return false; }
+    n_tab = mm.frames().size() + 1;  // the mirror's frames, then the current one
+    if ((size_t)dev.slots() < n_tab + 2) { ++mm.stats.fallbacks; mm.invalidate(); return false; }  // every keyframe resident at once
+    rank_of.assign(n_tab, -1);
+    for (std::list<KfDist>::iterator kf = close_kfs.begin(); kf != close_kfs.end() && ranked.size() < options_.max_n_kfs; ++kf) {
+      const int idx = mm.frameIndex(kf->first.get());
+      if (idx < 0) { ++mm.stats.fallbacks; mm.invalidate(); return false; }  // (a keyframe of the map the mirror does not know: cannot happen after sync)
+      rank_of[(size_t)idx] = (int32_t)ranked.size();
+      ranked.push_back(std::make_pair(kf->first, idx));
+    }
+  }
+  bool predict = adopted && batch.predict;
 
   // one batch: cells [first_cell, ...) until max_cells of them hold a trial.  false: capacity exceeded on the device
   auto runBatch = [&](const size_t first_cell, const size_t max_cells) -> bool {
@@ -169,124 +484,51 @@ bool reprojectMapMirrored(const FramePtr& frame, std::vector<std::pair<FramePtr,
     svo_hip::StageTimer stage_timer(dev, lane, svo_hip::Device::STAGE_REPROJECT);
     svo_hip::Arena& a = lane.arena;
     a.reset();
+    MirrorBatch& b = batch;
+    b.clear();
+    b.dev = &dev; b.lane = &lane; b.mm = &mm;
+    b.T_CAP = T_CAP;
     mm.ensureDevice(grid_.cell_order, T_CAP);
-    const size_t P = mm.entries().size();
-    a.reserve(((size_t)1 << 17) + mm.patchBytes() + P * 8 + T_CAP * 128 + V_CAP * 16 + n_tab * 128);
+    const size_t n_tab_b = mm.frames().size() + 1;
+    a.reserve(b.arenaBytes(n_tab_b));
     FrameTable frames(dev, L);
-    for (size_t i = 0; i + 1 < n_tab; ++i)
+    for (size_t i = 0; i + 1 < n_tab_b; ++i)
       if (frames.indexOf(mm.frames()[i]) != (int)i) throw std::logic_error("Reprojector: frame table out of order");
-    const int i_cur = frames.indexOf(frame.get());
-    predict = first_cell == 0 && svo_hip::Device::speculationEnabled() && frame->fts_.empty();
-    const size_t cap = (size_t)Config::maxFts() + 1;
-
-    // ---- inputs: what changed in the map, the ranks of the overlapping keyframes, the frame table
-    const svo_hip_map_patch patch = mm.emitPatch(a);
-    int32_t* d_rank;
-    int32_t* rank = a.alloc<int32_t>(n_tab, &d_rank);
-    std::copy(rank_of.begin(), rank_of.end(), rank);
-    svo_hip_frames ft;
-    frames.emit(a, &ft);
-    double *d_sf = NULL, *d_spos = NULL;
-    int32_t* d_slvl = NULL;
-    if (predict) {  // the predicted pose refinement's observations: gathered on the device, never read by the host
-      a.alloc<double>(3 * cap, &d_sf);
-      a.alloc<double>(3 * cap, &d_spos);
-      a.alloc<int32_t>(cap, &d_slvl);
-    }
-    a.endInputs();
-    const size_t inputs_end = a.used();
-
-    // ---- outputs the host reads
-    svo_hip_reprojection out;
-    std::memset(&out, 0, sizeof(out));
-    int32_t* header = a.alloc<int32_t>(SVO_HIP_REPROJ_HEADER, &out.d_header);
-    header[0] = -1;
-    const int32_t* h_point_cell = a.alloc<int32_t>(P ? P : 1, &out.d_point_cell);
-    const int32_t* h_kf_count = a.alloc<int32_t>(n_tab, &out.d_kf_count);
-    const int32_t* h_vp = a.alloc<int32_t>(V_CAP, &out.d_visit_point);
-    const int32_t* h_vc = a.alloc<int32_t>(V_CAP, &out.d_visit_cell);
-    const int32_t* h_vt = a.alloc<int32_t>(V_CAP, &out.d_visit_trial);
-    const double* h_px = a.alloc<double>(2 * T_CAP, &out.d_trial_px);
-    double* d_A; int32_t *d_ok, *d_ref, *d_lvl;
-    const int32_t* h_ok = a.alloc<int32_t>(T_CAP, &d_ok);
-    const int32_t* h_ref = a.alloc<int32_t>(T_CAP, &d_ref);
-    const int32_t* h_lvl = a.alloc<int32_t>(T_CAP, &d_lvl);
-    const double* h_A = a.alloc<double>(4 * T_CAP, &d_A);
-    const size_t match_end = a.used();
-    out.d_point_px = mm.pointPx();
-    out.d_trial_cur = mm.trialCur(); out.d_trial_pos = mm.trialPos();
-    out.d_trial_obs_begin = mm.trialObsBegin(); out.d_trial_obs_end = mm.trialObsEnd(); out.d_trial_cell = mm.trialCell();
-    int32_t* const d_M = out.d_header + 3;
-
-    double *d_T = NULL, *d_Cov = NULL, *d_stats = NULL;
-    int32_t *d_nsel = NULL, *d_sel = NULL, *d_ran = NULL, *d_flag = NULL;
-    volatile int32_t* flag = NULL;
-    uint8_t* d_has = NULL;
-    size_t results_begin = match_end;
+    b.i_cur = frames.indexOf(frame.get());
+    b.rank_of.assign(rank_of.begin(), rank_of.begin() + std::min(rank_of.size(), n_tab_b));
+    b.rank_of.resize(n_tab_b, -1);
+    b.cam = cameraOf(frame->cam_);
+    b.cell_size = grid_.cell_size; b.n_cols = grid_.grid_n_cols; b.n_rows = grid_.grid_n_rows;
+    b.n_cells = n_cells; b.first_cell = first_cell; b.max_cells = max_cells;
+    b.align_max_iter = align_max_iter;
+    b.frame_id = frame->id_;
+    predict = b.predict = first_cell == 0 && svo_hip::Device::speculationEnabled() && frame->fts_.empty();
     svo_hip::Speculation& sp = lane.spec;
-    if (predict) {
-      sp.frame_id = frame->id_;
-      sp.point.clear(); sp.px.clear(); sp.level.clear(); sp.trial.clear();
-      results_begin = a.used();
-      double* T = a.alloc<double>(12, &d_T);
-      poseToRt(frame->T_f_w_, T);
-      std::copy(T, T + 12, sp.T_init);
-      sp.T = T;
-      sp.n_sel = a.alloc<int32_t>(1, &d_nsel);
-      sp.sel = a.alloc<int32_t>(cap, &d_sel);
-      sp.has_point = a.alloc<uint8_t>(cap, &d_has);
-      sp.Cov = a.alloc<double>(36, &d_Cov);
-      sp.stats = a.alloc<double>(4, &d_stats);
-      sp.ran = a.alloc<int32_t>(1, &d_ran);
-      if (a.mode() != svo_hip::Arena::MIRRORED) flag = a.alloc<int32_t>(1, &d_flag);
-      sp.reproj_thresh = Config::poseOptimThresh();
-      sp.n_iter = (int)Config::poseOptimNumIter();
-    }
-
-    const svo_hip_camera cam = cameraOf(frame->cam_);
-    const svo_hip_map dmap = mm.deviceMap();
-    const svo_hip_features dobs = mm.deviceObs();
-    svo_hip_grid g;
-    g.cell_size = grid_.cell_size; g.n_cols = grid_.grid_n_cols; g.n_rows = grid_.grid_n_rows; g.n_cells = (int32_t)n_cells;
-    g.d_cell_rank = mm.cellRank();
-    void* ws = dev.workspace(lane, (int)T_CAP);
+    b.allocInputs(a, frames);
+    a.endInputs();
+    b.allocOutputs(a, n_tab_b, frame, sp, false);
     stage_timer.device(a.used());
     a.uploadAll(lane.stream);
-    svo_hip::check(svo_hip_reproject_map(&cam, &ft, i_cur, d_rank, &dmap, &patch, &g, (int)first_cell,
-                                         (int)std::min(max_cells, (size_t)1 << 30), (int)V_CAP, (int)T_CAP, &out, lane.stream),
-                   "svo_hip_reproject_map");
-    svo_hip::check(svo_hip_find_match_direct_indirect(&dev.layout(), dev.store(), &cam, &ft, (int)T_CAP, d_M, out.d_trial_cur,
-                                                      out.d_trial_pos, out.d_trial_obs_begin, out.d_trial_obs_end, &dobs,
-                                                      Config::nPyrLevels(), align_max_iter, out.d_trial_px, d_ok, d_ref, d_lvl, d_A,
-                                                      NULL, ws, lane.workspace_bytes, lane.stream),
-                   "svo_hip_find_match_direct_indirect");
-    a.downloadRange(inputs_end, match_end, lane.stream);
-    if (predict && flag != NULL) {
-      // hybrid / mapped arena: the selection kernel stores `flag` when it starts, i.e. when the match kernels are through;
-      // the host polls that, pose refinement follows on the same stream (see the list-walking path below)
-      *flag = 0;
-      svo_hip::check(svo_hip_select_matches_indirect(&cam, (int)T_CAP, d_M, out.d_trial_cell, d_ok, out.d_trial_px, d_lvl,
-                                                     out.d_trial_pos, Config::maxFts(), d_nsel, d_sel, d_sf, d_slvl, d_spos, d_has,
-                                                     d_flag, 1, lane.stream),
-                     "svo_hip_select_matches_indirect");
-      svo_hip::check(svo_hip_pose_optimize_deferred(&cam, 1, d_nsel, (int)cap, d_sf, d_slvl, d_spos, d_has, sp.reproj_thresh,
-                                                    sp.n_iter, d_T, d_Cov, d_stats, d_ran, lane.stream),
-                     "svo_hip_pose_optimize_deferred");
-      sp.stream = lane.stream;
-      sp.in_flight = true;
-      svo_hip::spinUntil(flag, 1, lane.stream);
+    b.launchMatch(a);
+    if (predict && b.flag != NULL) {
+      b.launchPredictionSameStream(sp);
+      svo_hip::spinUntil(b.flag, 1, lane.stream);
     } else if (predict) {
+      // mirrored arena: behind the match results on the lane's second stream, so that the wait below ends with the copy
+      // of the match results
+      const size_t cap = (size_t)Config::maxFts() + 1;
+      int32_t* const d_M = b.out.d_header + 3;
       void* const next = lane.stream_next;
       svo_hip::check(svo_hip_event_record(lane.ev_results, lane.stream), "svo_hip_event_record");
       svo_hip::check(svo_hip_stream_wait_event(next, lane.ev_results), "svo_hip_stream_wait_event");
-      svo_hip::check(svo_hip_select_matches_indirect(&cam, (int)T_CAP, d_M, out.d_trial_cell, d_ok, out.d_trial_px, d_lvl,
-                                                     out.d_trial_pos, Config::maxFts(), d_nsel, d_sel, d_sf, d_slvl, d_spos, d_has,
-                                                     NULL, 0, next),
+      svo_hip::check(svo_hip_select_matches_indirect(&b.cam, (int)T_CAP, d_M, b.out.d_trial_cell, b.d_ok, b.out.d_trial_px, b.d_lvl,
+                                                     b.out.d_trial_pos, Config::maxFts(), b.d_nsel, b.d_sel, b.d_sf, b.d_slvl, b.d_spos,
+                                                     b.d_has, NULL, 0, next),
                      "svo_hip_select_matches_indirect");
-      svo_hip::check(svo_hip_pose_optimize_deferred(&cam, 1, d_nsel, (int)cap, d_sf, d_slvl, d_spos, d_has, sp.reproj_thresh,
-                                                    sp.n_iter, d_T, d_Cov, d_stats, d_ran, next),
+      svo_hip::check(svo_hip_pose_optimize_deferred(&b.cam, 1, b.d_nsel, (int)cap, b.d_sf, b.d_slvl, b.d_spos, b.d_has, sp.reproj_thresh,
+                                                    sp.n_iter, b.d_T, b.d_Cov, b.d_stats, b.d_ran, next),
                      "svo_hip_pose_optimize_deferred");
-      a.downloadRange(results_begin, a.used(), next);
+      a.downloadRange(b.results_begin, a.used(), next);
       sp.stream = next;
       sp.in_flight = true;
       svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
@@ -294,7 +536,7 @@ bool reprojectMapMirrored(const FramePtr& frame, std::vector<std::pair<FramePtr,
       svo_hip::check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync");
     }
     stage_timer.unmarshal();
-    if (header[0] != 0) {  // a capacity was exceeded (or, -1, the kernel never ran): drop what was enqueued behind it
+    if (b.header[0] != 0) {  // a capacity was exceeded (or, -1, the kernel never ran): drop what was enqueued behind it
       if (predict) {
         sp.in_flight = false;
         svo_hip::check(svo_hip_stream_sync(sp.stream), "svo_hip_stream_sync");
@@ -302,20 +544,15 @@ bool reprojectMapMirrored(const FramePtr& frame, std::vector<std::pair<FramePtr,
       }
       return false;
     }
-    view.header = header; view.visit_point = h_vp; view.visit_cell = h_vc; view.visit_trial = h_vt;
-    view.ok = h_ok; view.lvl = h_lvl; view.ref = h_ref; view.px = h_px; view.A = h_A;
-    view.V = (size_t)header[2];
-    view.end_cell = (size_t)header[4];
-    point_cell = h_point_cell;
-    kf_count = h_kf_count;
     return true;
   };
 
   // The first batch takes the cells a success rate of 3 in 4 would need (see the list-walking path)
-  static const long first_batch_override = [] { const char* v = std::getenv("SVO_HIP_FIRST_BATCH_CELLS"); return v ? std::atol(v) : 0L; }();
-  const size_t first_batch_cells = first_batch_override > 0 ? (size_t)first_batch_override
-                                                            : (size_t)Config::maxFts() + 1 + ((size_t)Config::maxFts() + 1) / 3 + 8;
-  if (!runBatch(0, first_batch_cells)) { ++mm.stats.fallbacks; mm.invalidate(); return false; }
+  if (!adopted && !runBatch(0, MirrorChain<GridT>::firstBatchCells())) { ++mm.stats.fallbacks; mm.invalidate(); return false; }
+  // the tables of the batch in flight (host addresses of arena blocks)
+  size_t view_V = (size_t)batch.header[2], view_end_cell = (size_t)batch.header[4];
+  const int32_t* point_cell = batch.h_point_cell;
+  const int32_t* kf_count = batch.h_kf_count;
 
   // ---- 1. overlap_kfs: (keyframe, points of it that fell inside the frame), closest first (:82-102)
   overlap_kfs.reserve(options_.max_n_kfs);
@@ -348,22 +585,23 @@ bool reprojectMapMirrored(const FramePtr& frame, std::vector<std::pair<FramePtr,
   std::vector<int32_t> pred_level, pred_trial;
   size_t v = 0;
   for (size_t i = 0; i < n_cells; ++i) {
-    if (i == view.end_cell) {
+    if (i == view_end_cell) {
       // the cells of the batch are used up and the loop has not stopped: the rest (the prediction, made on the first
       // batch's trials only, is dropped: beginCall() drains what was enqueued)
       predict = false;
       ++mm.stats.second_batches;
       if (!runBatch(i, n_cells)) throw svo_hip::Error("Reprojector: the second match batch exceeds the mirror's capacity");
+      view_V = (size_t)batch.header[2]; view_end_cell = (size_t)batch.header[4];
       v = 0;
     }
     bool matched = false;
-    for (; v < view.V && (size_t)view.visit_cell[v] == i; ++v) {
+    for (; v < view_V && (size_t)batch.h_vc[v] == i; ++v) {
       if (matched) continue;  // reprojectCell returns at the first success: the rest of the cell is not looked at
       ++n_trials_;
-      const int32_t e = view.visit_point[v];
+      const int32_t e = batch.h_vp[v];
       Point* pt = mm.entries()[(size_t)e].pt;
-      const int m = view.visit_trial[v];
-      if (!(m >= 0 && view.ok[m] != 0)) {
+      const int m = batch.h_vt[v];
+      if (!(m >= 0 && batch.h_ok[m] != 0)) {
         pt->n_failed_reproj_++;
         if (pt->type_ == Point::TYPE_UNKNOWN && pt->n_failed_reproj_ > 15) { map_.safeDeletePoint(pt); mm.markDead(e); }
         if (pt->type_ == Point::TYPE_CANDIDATE && pt->n_failed_reproj_ > 30) { map_.point_candidates_.deleteCandidatePoint(pt); mm.markDead(e); }
@@ -371,23 +609,23 @@ bool reprojectMapMirrored(const FramePtr& frame, std::vector<std::pair<FramePtr,
       }
       pt->n_succeeded_reproj_++;
       if (pt->type_ == Point::TYPE_UNKNOWN && pt->n_succeeded_reproj_ > 10) { pt->type_ = Point::TYPE_GOOD; mm.markType(e, 3); }
-      const Vector2d px(view.px[2 * m], view.px[2 * m + 1]);
-      Feature* new_feature = new Feature(frame.get(), px, view.lvl[m]);
+      const Vector2d px(batch.h_px[2 * m], batch.h_px[2 * m + 1]);
+      Feature* new_feature = new Feature(frame.get(), px, batch.h_lvl[m]);
       frame->addFeature(new_feature);
       new_feature->point = pt;
-      const Feature* ref_ftr = view.ref[m] >= 0 ? mm.obsFeature(view.ref[m]) : NULL;
+      const Feature* ref_ftr = batch.h_ref[m] >= 0 ? mm.obsFeature(batch.h_ref[m]) : NULL;
       if (ref_ftr != NULL && ref_ftr->type == Feature::EDGELET) {
         new_feature->type = Feature::EDGELET;
         Matrix2d A_cur_ref;
-        A_cur_ref(0, 0) = view.A[4 * m]; A_cur_ref(0, 1) = view.A[4 * m + 1];
-        A_cur_ref(1, 0) = view.A[4 * m + 2]; A_cur_ref(1, 1) = view.A[4 * m + 3];
+        A_cur_ref(0, 0) = batch.h_A[4 * m]; A_cur_ref(0, 1) = batch.h_A[4 * m + 1];
+        A_cur_ref(1, 0) = batch.h_A[4 * m + 2]; A_cur_ref(1, 1) = batch.h_A[4 * m + 3];
         new_feature->grad = A_cur_ref * ref_ftr->grad;
         new_feature->grad.normalize();
       }
       if (predict) {
         pred_point.push_back(pt);
         pred_px.push_back(px[0]); pred_px.push_back(px[1]);
-        pred_level.push_back(view.lvl[m]);
+        pred_level.push_back(batch.h_lvl[m]);
         pred_trial.push_back(m);
       }
       selected.push_back(e);
@@ -421,9 +659,30 @@ void mapMirrorStats(uint64_t out[6]) {
 }
 }  // namespace hip_dropin
 
-// The reference's destructor (reprojector.cpp:39-42) plus the release of the map's device-resident shadow.
+// The reference's destructor (reprojector.cpp:39-42) plus the release of the map's device-resident shadow and of the
+// chain this Reprojector registered on its tracking lane (frame_chain.h).
 Reprojector::~Reprojector() {
   std::for_each(grid_.cells.begin(), grid_.cells.end(), [&](Cell* c) { delete c; });
+  {
+    typedef MirrorChain<Grid> Chain;
+    ChainRegistry& r = chains();
+    Chain* ch = NULL;
+    {
+      std::lock_guard<std::mutex> g(r.mut);
+      std::map<const void*, hip_dropin::FrameChain*>::iterator it = r.all.find(this);
+      if (it != r.all.end()) {
+        ch = static_cast<Chain*>(it->second);
+        r.all.erase(it);
+      }
+    }
+    if (ch != NULL) {
+      if (ch->hook_lane_ != NULL) {
+        std::lock_guard<std::mutex> g(ch->hook_lane_->mut);
+        if (ch->hook_lane_->chain_hook == static_cast<hip_dropin::FrameChain*>(ch)) ch->hook_lane_->chain_hook = NULL;
+      }
+      delete ch;
+    }
+  }
   releaseMirror(&map_);
 }
 
@@ -436,8 +695,20 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
   if (options_.find_match_direct && hip_dropin::MapMirror::mode() != hip_dropin::MapMirror::OFF) {
     SVO_START_TIMER("feature_align");
     bool done = false;
+    // this Reprojector's chain (frame_chain.h): created on first use, registered on the calling thread's tracking lane so
+    // that the NEXT frame's SparseImgAlign::run can enqueue this call's device work behind its own
+    typedef MirrorChain<Grid> Chain;
+    Chain* chain = NULL;
+    if (svo_hip::Device::chainEnabled()) {
+      ChainRegistry& r = chains();
+      std::lock_guard<std::mutex> g(r.mut);
+      hip_dropin::FrameChain*& slot = r.all[this];
+      if (slot == NULL) slot = new Chain(map_, grid_, options_, &matcher_.options_.align_max_iter);
+      chain = static_cast<Chain*>(slot);
+    }
     try {
-      done = reprojectMapMirrored(frame, overlap_kfs, map_, grid_, options_, matcher_.options_.align_max_iter, n_matches_, n_trials_);
+      done = reprojectMapMirrored(frame, overlap_kfs, map_, grid_, options_, matcher_.options_.align_max_iter, n_matches_, n_trials_,
+                                  chain);
     } catch (...) {
       // an error between the patch (which marks the shadow's records as sent) and a completed launch leaves the device
       // copy behind the shadow: the next call starts from a fresh walk of the map
@@ -445,6 +716,16 @@ void Reprojector::reprojectMap(FramePtr frame, std::vector<std::pair<FramePtr, s
       throw;
     }
     SVO_STOP_TIMER("feature_align");
+    if (chain != NULL) {  // (the lane of THIS thread: the one the next frame's sparse alignment will run on)
+      svo_hip::Lane& lane = hip_dropin::ensureDevice(*frame).lane(svo_hip::Device::LANE_TRACKING);
+      std::lock_guard<std::mutex> g(lane.mut);
+      if (done) {
+        lane.chain_hook = static_cast<hip_dropin::FrameChain*>(chain);
+        chain->hook_lane_ = &lane;
+      } else if (lane.chain_hook == static_cast<hip_dropin::FrameChain*>(chain)) {
+        lane.chain_hook = NULL;  // the map does not fit the mirror (any more): no chain until it does
+      }
+    }
     if (done) return;
   } else if (hip_dropin::MapMirror::mode() != hip_dropin::MapMirror::OFF) {
     mirrorOf(&map_).invalidate();  // this call changes the map without the mirror looking

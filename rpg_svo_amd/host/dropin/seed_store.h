@@ -18,7 +18,11 @@
 #define SVO_HIP_DROPIN_SEED_STORE_H_
 
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <list>
+#include <map>
+#include <string>
 #include <vector>
 
 #include <svo/depth_filter.h>
@@ -33,12 +37,23 @@ namespace hip_dropin {
 class SeedStore {
  public:
   struct Stats {
-    uint64_t calls, rebuilds, records_sent, seeds_released, invalidations;
-    Stats() : calls(0), rebuilds(0), records_sent(0), seeds_released(0), invalidations(0) {}
+    uint64_t calls, rebuilds, records_sent, seeds_released, invalidations, edits_found;
+    Stats() : calls(0), rebuilds(0), records_sent(0), seeds_released(0), invalidations(0), edits_found(0) {}
   };
   Stats stats;
 
-  SeedStore() : high_(0), cap_(0) { clearDevice(); }
+  SeedStore() : high_(0), cap_(0), verify_(false) {
+    clearDevice();
+    const char* v = std::getenv("SVO_HIP_SEED_STORE");
+    verify_ = v && std::string(v) == "verify";
+  }
+  // verify mode: what the device reported for a seed after an update (the replay of depth_filter.cpp hands it over), to be
+  // compared with the host's copy at the next call
+  bool verifying() const { return verify_; }
+  void reported(int id, float a, float b, float mu, float sigma2) {
+    Reported& r = reported_[id];
+    r.a = a; r.b = b; r.mu = mu; r.sigma2 = sigma2;
+  }
   ~SeedStore() { releaseDevice(); }
 
   // What one call hands to the device (arena input blocks and the store's columns).
@@ -56,13 +71,37 @@ class SeedStore {
   // Uploads nothing itself: the blocks travel with the arena's one H2D copy.
   Call sync(std::list<Seed>& seeds, const Frame* cur, svo_hip::Device& dev, int lane, svo_hip::Arena& a) {
     ++stats.calls;
+    // The merge walk below relies on Seed::id ascending strictly along the list.  A host that resets Seed::seed_counter
+    // (the reference never does; oracle/ref_driver.cpp does, between independent runs) would alias new seeds onto the
+    // slots of old ones by id: checked on every call (one comparison per seed), and answered by forgetting the shadow.
+    {
+      bool ascending = true;
+      int prev = 0;
+      bool first = true;
+      for (std::list<Seed>::const_iterator it = seeds.begin(); it != seeds.end(); ++it) {
+        if (!first && it->id <= prev) { ascending = false; break; }
+        prev = it->id; first = false;
+      }
+      // (ids below the largest id the shadow has seen, appended at the END of the list, are a counter reset too)
+      if (ascending && !seeds.empty() && !ids_.empty() && seeds.back().id < ids_.back() &&
+          (seeds.size() > ids_.size() || seeds.front().id < ids_.front()))
+        ascending = false;
+      if (!ascending) invalidate();
+    }
     // ---- merge walk: the list against the shadow (both ascend in Seed::id) -------------------------------------
     new_ids_.clear(); new_slot_.clear(); new_key_.clear(); fresh_.clear();
     size_t k = 0;
     for (std::list<Seed>::iterator it = seeds.begin(); it != seeds.end(); ++it) {
       while (k < ids_.size() && ids_[k] < it->id) release(k++);
-      if (k < ids_.size() && ids_[k] == it->id) {
+      if (k < ids_.size() && ids_[k] == it->id && !(verify_ && edited(*it))) {
         new_ids_.push_back(ids_[k]); new_slot_.push_back(slot_[k]); new_key_.push_back(key_[k]);
+        ++k;
+      } else if (k < ids_.size() && ids_[k] == it->id) {
+        // SVO_HIP_SEED_STORE=verify: the host's state of a resident seed is not what the device last reported (an external
+        // edit: the static DepthFilter::updateSeed(x, tau2, Seed*), user code): the seed keeps its slot, its record travels again
+        new_ids_.push_back(ids_[k]); new_slot_.push_back(slot_[k]); new_key_.push_back(key_[k]);
+        fresh_.push_back(std::make_pair(&*it, new_ids_.size() - 1));
+        ++stats.edits_found;
         ++k;
       } else {
         const int32_t slot = allocSlot();
@@ -153,6 +192,7 @@ class SeedStore {
   // received (stale slots, a garbage d_frame indexing the frame table).  The caller invalidates on every such path.
   // The device columns are kept (their capacity is still right); slots are handed out from 0 again.
   void invalidate() {
+    reported_.clear();
     ids_.clear(); slot_.clear(); key_.clear(); free_.clear();
     kf_.clear(); kf_refs_.clear();
     high_ = 0;
@@ -160,6 +200,14 @@ class SeedStore {
   }
 
  private:
+  struct Reported { float a, b, mu, sigma2; };
+  bool edited(const Seed& s) const {
+    std::map<int, Reported>::const_iterator r = reported_.find(s.id);
+    if (r == reported_.end()) return false;  // never updated since it was sent: the record that travelled is the host's
+    // (bit patterns: a NaN state compares equal to itself)
+    return std::memcmp(&r->second.a, &s.a, sizeof(float)) != 0 || std::memcmp(&r->second.b, &s.b, sizeof(float)) != 0 ||
+           std::memcmp(&r->second.mu, &s.mu, sizeof(float)) != 0 || std::memcmp(&r->second.sigma2, &s.sigma2, sizeof(float)) != 0;
+  }
   int32_t allocSlot() {
     if (!free_.empty()) {
       const int32_t s = free_.back();
@@ -169,6 +217,7 @@ class SeedStore {
     return high_++;
   }
   void release(size_t k) {
+    if (verify_) reported_.erase(ids_[k]);
     free_.push_back(slot_[k]);
     const int32_t key = key_[k];
     if (--kf_refs_[(size_t)key] == 0) kf_[(size_t)key] = NULL;
@@ -223,6 +272,8 @@ class SeedStore {
   std::vector<int> kf_refs_;                  // seeds per key
   svo_hip_features ftr_;
   svo_hip_seeds seeds_;
+  bool verify_;                               // SVO_HIP_SEED_STORE=verify
+  std::map<int, Reported> reported_;          // ... Seed::id -> the state the device reported last
 };
 
 }  // namespace hip_dropin

@@ -10,6 +10,7 @@
 #include <svo/frame.h>
 #include <svo/point.h>
 
+#include "frame_chain.h"
 #include "marshal.h"
 
 namespace svo {
@@ -41,6 +42,11 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   svo_hip::Device& dev = ensureDevice(*ref_frame);
   const int L = svo_hip::Device::LANE_TRACKING;
   svo_hip::Lane& lane = dev.lane(L);
+  // The frame's next steps behind this call (frame_chain.h): reprojectMap's drop-in reads the map, which the deferred
+  // mapper's pending results feed -- they are written back first, as reprojectMap itself would (before the lane is locked:
+  // the join takes the lanes' mutexes).  (chain_hook is written by this thread's own reprojectMap, or by a dying
+  // Reprojector under the lane's mutex: re-read under it below.)
+  if (lane.chain_hook != NULL && svo_hip::Device::chainEnabled()) svo_hip::Device::joinDeferredAll();
   std::lock_guard<std::mutex> guard(lane.mut);
   dev.beginCall(L);
   svo_hip::StageTimer stage_timer(dev, lane, svo_hip::Device::STAGE_SPARSE_ALIGN);
@@ -50,6 +56,14 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   svo_hip::Arena& a = lane.arena;
   a.reset();
   FrameTable frames(dev, L);
+  FrameChain* chain = svo_hip::Device::chainEnabled() ? static_cast<FrameChain*>(lane.chain_hook) : NULL;
+  // (ref == cur cannot be chained: the table would hold one entry for both)
+  if (chain != NULL && (ref_frame.get() == cur_frame.get() || !chain->prepare(ref_frame, cur_frame, dev, lane, frames, n * 64 + 8192)))
+    chain = NULL;
+  struct Abandon {  // an exception between prepare() and enqueue() leaves the chain idle
+    FrameChain* c;
+    ~Abandon() { if (c) c->abandon(); }
+  } abandon = {chain};
   const int i_ref = frames.indexOf(ref_frame.get());
   const int i_cur = frames.indexOf(cur_frame.get());
 
@@ -76,6 +90,7 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   }
   const SE3 T_cur_from_ref(cur_frame->T_f_w_ * ref_frame->T_f_w_.inverse());  // prior (:59)
   poseToRt(T_cur_from_ref, Tin);
+  if (chain) chain->allocInputs(a, ref_frame);
   a.endInputs();
 
   // ---- outputs ---------------------------------------------------------------------------
@@ -86,6 +101,7 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   int32_t* n_tracked = a.alloc<int32_t>(1, &d_ntracked);
   int32_t* iters = a.alloc<int32_t>(SVO_HIP_MAX_LEVELS, &d_iters);
   int32_t* status = a.alloc<int32_t>(1, &d_status);
+  if (chain) chain->allocOutputs(a);
 
   const svo_hip_camera cam = cameraOf(ref_frame->cam_);
   svo_hip_sia_params P;
@@ -99,8 +115,16 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   svo_hip::check(svo_hip_sparse_align(&dev.layout(), dev.store(), 1, d_slots, d_slots + 1, d_slots + 2, (int)n, d_px, d_xyz,
                                       d_valid, &P, d_Tin, d_Tout, d_H, d_ntracked, d_iters, d_chi2, d_status, lane.stream),
                  "svo_hip_sparse_align");
-  a.download(lane.stream);
-  dev.finish(lane);
+  if (chain) {
+    // reprojection, matching, selection and the predicted pose refinement follow K1 on the stream; this call returns when
+    // K1's results (and the pose the device formed from them) are in host memory
+    chain->enqueue(d_Tout);
+    abandon.c = NULL;
+    svo_hip::spinUntil(chain->k1Signal(), 1, lane.stream);
+  } else {
+    a.download(lane.stream);
+    dev.finish(lane);
+  }
   stage_timer.unmarshal();
 
   cur_frame->T_f_w_ = poseFromRt(Tout) * ref_frame->T_f_w_;  // :70

@@ -302,6 +302,19 @@ void Device::countSpeculation(bool hit) {
   if (hit) ++stats.spec_hits; else ++stats.spec_misses;
 }
 
+void Device::countChain(bool hit) {
+  std::lock_guard<std::mutex> g(stats_mut_);
+  if (hit) ++stats.chain_hits; else ++stats.chain_misses;
+}
+
+bool Device::chainEnabled() {
+  static const bool on = [] {
+    const char* v = std::getenv("SVO_HIP_CHAIN");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
+
 bool Device::speculationEnabled() {
   static const bool on = [] {
     const char* v = std::getenv("SVO_HIP_SPECULATE");

@@ -129,6 +129,10 @@ struct Lane {
   // mode): waits for the stream and writes the results back.  Run by the lane's next beginCall() or by
   // Device::joinDeferred(), whichever comes first; the arena and the pinned frames stay as the call left them until then.
   std::function<void()> deferred;
+  // The frame's NEXT steps enqueued behind its sparse alignment (dropin/frame_chain.h): the drop-in of
+  // Reprojector::reprojectMap registers a hip_dropin::FrameChain here, SparseImgAlign::run's drop-in calls it.  Opaque in
+  // this header (no reference types); owned by the registering Reprojector, which clears it under `mut` when it dies.
+  void* chain_hook;
   Arena arena;
   void* d_workspace;      // matcher / depth-filter scratch (svo_hip_match_workspace_bytes)
   size_t workspace_bytes;
@@ -137,7 +141,7 @@ struct Lane {
   double pyr_upload_us;   // time this lane spent uploading pyramids (StageTimer takes it out of "marshal")
   std::mutex mut;
   std::vector<int> touched;  // frames pinned by the lane's current call
-  Lane() : stream(NULL), stream_next(NULL), ev_results(NULL), d_workspace(NULL), workspace_bytes(0), d_stage(NULL), index(0), pyr_upload_us(0) {}
+  Lane() : stream(NULL), stream_next(NULL), ev_results(NULL), chain_hook(NULL), d_workspace(NULL), workspace_bytes(0), d_stage(NULL), index(0), pyr_upload_us(0) {}
 };
 
 class Device {
@@ -210,10 +214,11 @@ class Device {
   struct Stats {
     uint64_t uploads, evictions, calls;
     uint64_t spec_hits, spec_misses;  // pose refinements taken from / not taken from the reprojector's prediction
+    uint64_t chain_hits, chain_misses;  // reprojections + matches taken from / not taken from the chain enqueued behind K1
     double pyr_upload_us;
     double marshal_us[N_STAGES], device_us[N_STAGES], unmarshal_us[N_STAGES], payload_bytes[N_STAGES];
     uint64_t n[N_STAGES];
-    Stats() : uploads(0), evictions(0), calls(0), spec_hits(0), spec_misses(0), pyr_upload_us(0) {
+    Stats() : uploads(0), evictions(0), calls(0), spec_hits(0), spec_misses(0), chain_hits(0), chain_misses(0), pyr_upload_us(0) {
       for (int i = 0; i < N_STAGES; ++i) { marshal_us[i] = device_us[i] = unmarshal_us[i] = payload_bytes[i] = 0; n[i] = 0; }
     }
   };
@@ -222,6 +227,9 @@ class Device {
   // count = false: the second half of a call already counted (a deferred call's join)
   void addStage(int stage, double marshal_us, double device_us, double unmarshal_us, double payload_bytes, bool count = true);
   void countSpeculation(bool hit);
+  void countChain(bool hit);
+  // SVO_HIP_CHAIN=0 switches the chain behind the sparse alignment off (reprojectMap then starts its own call, as before)
+  static bool chainEnabled();
   // SVO_HIP_SPECULATE=0 switches the reprojector's prediction off (every stage then ends with its own stream sync)
   static bool speculationEnabled();
 

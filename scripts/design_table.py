@@ -22,7 +22,11 @@ def table(d: dict, src: str) -> str:
     L.append("| kernel (per launch / step of 16 384 frames) | ms | algorithmic bytes per unit | GB/s | frac of 8 TB/s | counter traffic / algorithmic | VALU busy | wave cycles waiting |")
     L.append("|---|---|---|---|---|---|---|---|")
     rv = d.get("roofline_valu") or {}
-    L.append(f"| **K1** `sia_kernel<256>` (headline, {d['value'] / 1e6:.2f} M frames/s) | {f(r['ms'], '{:.3f}')} (last 10: {f(r.get('ms_last_10_launches'), '{:.3f}')}) | "
+    k1_only = d.get("value_sparse_align_only")
+    if k1_only:  # round 6: the headline step is K1 + K4
+        L.insert(1, f"Headline step (`value`): K1 + K4 on the matches K2 / K3 produced for the same frames: **{d['value'] / 1e6:.2f} M frames/s** "
+                    f"({d['ms_per_step']:.3f} ms per step of {B} frames); K1 on its own: {k1_only / 1e6:.2f} M frames/s.")
+    L.append(f"| **K1** `sia_kernel<256>` ({(k1_only or d['value']) / 1e6:.2f} M frames/s on its own) | {f(r['ms'], '{:.3f}')} (last 10: {f(r.get('ms_last_10_launches'), '{:.3f}')}) | "
              f"{r['algorithmic_bytes_per_frame'] / 1e3:.1f} KB / frame | {f(r['achieved'], '{:.0f}')} | **{f(r['frac'], '{:.3f}')}** | {f(r.get('traffic_over_algorithmic'))} | "
              f"{f(rv.get('frac'))} | {f(rv.get('wave_cycles_waiting_frac'))} |")
     f64 = d.get("f64_partials") or {}
@@ -30,6 +34,10 @@ def table(d: dict, src: str) -> str:
         q = f64["roofline"]
         L.append(f"| K1, `-DSIA_F64_PARTIALS` build ({f64['frames_per_s'] / 1e6:.2f} M frames/s) | {f(q['ms'], '{:.3f}')} | {q['algorithmic_bytes_per_frame'] / 1e3:.1f} KB / frame | "
                  f"{f(q['achieved'], '{:.0f}')} | {f(q['frac'], '{:.3f}')} | {f(q.get('traffic_over_algorithmic'))} | - | - |")
+    k4 = d.get("roofline_pose_optimize") or {}
+    if "ms" in k4:
+        L.append(f"| K4 `compose_kernel` + `pose_opt_wave_kernel` (in the headline step) | {f(k4['ms'], '{:.3f}')} | {k4.get('algorithmic_bytes_per_frame', 0) / 1e3:.1f} KB / frame | "
+                 f"{f(k4['achieved'], '{:.0f}')} | {f(k4['frac'], '{:.3f}')} | - | - | - |")
     k0 = d.get("k0_pyramid") or {}
     if "ms" in k0:
         L.append(f"| K0 `pyramid_fused_kernel` ({k0['frames']} frames) | {f(k0['ms'], '{:.3f}')} | {k0['algorithmic_bytes_per_frame']} B / frame | {f(k0['achieved'], '{:.0f}')} | "
@@ -38,6 +46,8 @@ def table(d: dict, src: str) -> str:
     unit = {"match_prepare": "48 B geometry / trial", "warp": "<= 121 B footprint + 100 B written / trial", "align": "100 + 81 I B / trial",
             "pose_opt_wave": "52 M + 416 B / frame", "seed_prepare": "89 B in + ~90 B workspace / seed", "epi_scan": "64 + 7.13 B / position (union of the windows)",
             "seed_finish": "36 B state + workspace / seed"}
+    if "update_seeds/epi_scan_kernel" in (ft.get("kernels") or {}) and "update_seeds/warp_kernel" not in (ft.get("kernels") or {}):
+        unit["epi_scan"] = "158 B / warped seed + 96 + 7.13 B / position (union of the windows) + 136 B / aligned seed"  # round 6: with the warp
     for name, v in (ft.get("kernels") or {}).items():
         if not isinstance(v, dict) or (v.get("ms") or 0) < 0.05:
             continue
@@ -46,7 +56,10 @@ def table(d: dict, src: str) -> str:
         extra = ""
         if lds.get("bank_conflict_frac_of_port_cycles") is not None:
             extra = f" (LDS port {f(lds.get('port_busy_frac_vs_busy_cu_cycles', lds.get('port_busy_frac')))} busy, {f(lds['bank_conflict_frac_of_port_cycles'])} of it conflicts)"
-        L.append(f"| `{name}` | {f(v['ms'], '{:.3f}')} | {unit.get(key, '-')} | {f(v.get('achieved_GBs'), '{:.0f}')} | {f(v.get('frac'), '{:.3f}')} | "
+        u = unit.get(key, '-')
+        if name == "update_seeds/align_kernel" and "update_seeds/seed_finish_kernel" not in (ft.get("kernels") or {}):
+            u = "150 + 81 I B / aligned seed + 96 B / seed (seed_finish epilogue)"
+        L.append(f"| `{name}` | {f(v['ms'], '{:.3f}')} | {u} | {f(v.get('achieved_GBs'), '{:.0f}')} | {f(v.get('frac'), '{:.3f}')} | "
                  f"{f(v.get('traffic_over_compulsory'))} | {f(valu.get('busy_frac_at_3_cycles_per_instruction'))} | {f(valu.get('wave_cycles_waiting_frac'))}{extra} |")
     if "ms_per_step" in ft:
         st = ft["stages_ms"]
@@ -63,6 +76,22 @@ def table(d: dict, src: str) -> str:
         L.append(f"Single stream (drop-in, 752x480, 600 frames, map of the reference trace's size): **{ds['median_ms_per_frame_hip_dropin']['tot_time']:.3f} ms** per frame "
                  f"({ds['median_ms_per_frame_hip_dropin_deferred_mapper']['tot_time']:.3f} with the deferred mapper) against {ds['median_ms_per_frame_cpu_reference']['tot_time']:.3f} ms for the "
                  f"all-CPU reference on the same host.")
+    rc = d.get("reference_cameras") or {}
+    if isinstance(rc.get("cameras"), dict):
+        L.append("")
+        L.append(f"The reference's own cameras (`svo_ros/param/camera_pinhole.yaml` = radtan, `camera_atan.yaml`; 752x480, {rc.get('frames_per_step')} frames per step, "
+                 "configs[1]'s shape; `pinhole_undistorted` = camera_pinhole.yaml without its distortion):")
+        L.append("")
+        L.append("| camera | K1 M frames/s | frac | traffic / algorithmic | Gauss-Newton iterations per frame (reference TU on a sample) | K1 time per iteration vs undistorted | full track ms per step (update_seeds) | drop-in ms per frame |")
+        L.append("|---|---|---|---|---|---|---|---|")
+        for name, r in rc["cameras"].items():
+            sa, ftc, dr = r.get("sparse_align") or {}, r.get("full_track") or {}, r.get("dropin") or {}
+            par = sa.get("parity") or {}
+            L.append(f"| {name} | {f((sa.get('frames_per_s') or 0) / 1e6)} | {f((sa.get('roofline') or {}).get('frac'), '{:.3f}')} | {f((sa.get('roofline') or {}).get('traffic_over_algorithmic'))} | "
+                     f"{f(sa.get('mean_gn_iterations_per_frame'), '{:.1f}')} ({f(par.get('mean_gn_iterations_per_frame_reference'), '{:.1f}')}; same counts {f(par.get('same_iteration_counts_frac'), '{:.3f}')}, "
+                     f"log-norm max {f(par.get('se3_lognorm_max'), '{:.1e}')}) | {f(sa.get('per_iteration_over_undistorted_pinhole'), '{:.3f}')} | "
+                     f"{f(ftc.get('ms_per_step'), '{:.2f}')} ({f((ftc.get('stages_ms') or {}).get('update_seeds'), '{:.2f}')}) | {f(dr.get('tot_time'), '{:.3f}')} |")
+        L.append("")
     cb = d.get("cpu_baseline") or {}
     if "value" in cb:
         L.append(f"CPU baseline (the reference's own `sparse_img_align.cpp`, {cb.get('cpu_model', 'host')}): {cb['value']:.0f} frames/s on one core in the bit-comparable build, "

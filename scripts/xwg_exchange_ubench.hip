@@ -33,27 +33,44 @@ struct Chunk {  // mode 3: a partial and the generation it belongs to, written a
 struct BlockL2 {  // one frame: [buffer half][part][partial]
   Chunk c[2][4][8];
 };
+// STORE: 0: sc0 (the line stays in the XCD's L2), 1: sc1 (write-through: the agent-scope form, placement-independent)
+template <int STORE>
 __device__ __forceinline__ void store_sc0_x4(Chunk* p, double v, unsigned long long gen) {
   typedef unsigned int u4 __attribute__((ext_vector_type(4)));
   u4 w;
   w.x = (unsigned)__double_as_longlong(v); w.y = (unsigned)((unsigned long long)__double_as_longlong(v) >> 32);
   w.z = (unsigned)gen; w.w = (unsigned)(gen >> 32);
-  asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(w) : "memory");
+  // (s_nop: the store reads its 16 bytes of data for a few cycles after issue, and the compiler does not see the hazard inside asm)
+  if (STORE == 0) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 3" ::"v"(p), "v"(w) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" ::"v"(p), "v"(w) : "memory");
 }
+// POLICY: the cache-policy bits of the polling load -- 0: sc0 (workgroup scope), 1: sc1 (agent scope), 2: sc0 sc1 (system scope)
+template <int POLICY>
 __device__ __forceinline__ Chunk load_sc0_x4(const Chunk* p) {
   typedef unsigned int u4 __attribute__((ext_vector_type(4)));
   u4 w;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(p) : "memory");
+  if (POLICY == 0) asm volatile("global_load_dwordx4 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(p) : "memory");
+  else if (POLICY == 1) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(p) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(p) : "memory");
   Chunk c;
   c.v = __longlong_as_double((long long)(((unsigned long long)w.y << 32) | w.x));
   c.gen = ((unsigned long long)w.w << 32) | w.z;
   return c;
 }
 
-// mode 3: see the header.  ids 8 apart per frame (the same XCD).
-__global__ void __launch_bounds__(256) exchange_l2_kernel(BlockL2* blocks, unsigned* timed_out, int n_frames, int rounds, double* out, long long* cycles) {
-  const int frame = (int)(blockIdx.x / 32) * 8 + (int)(blockIdx.x % 8);
-  const int part = (int)(blockIdx.x / 8) % 4;
+// modes 3-5: see the header (load policy sc0 / sc1 / sc0 sc1), stores sc0, ids 8 apart per frame (the same XCD);
+// modes 6-7: stores sc1 (write-through) + loads sc1 -- the placement-independent form -- with ids 8 apart / consecutive ids
+// (four XCDs).  xcc[block] = the XCC the block ran on (the census: is "id % 8 = XCD" what the dispatcher did?).
+template <int POLICY, int STORE, bool CONSECUTIVE>
+__global__ void __launch_bounds__(256) exchange_l2_kernel(BlockL2* blocks, unsigned* timed_out, int n_frames, int rounds, double* out, long long* cycles,
+                                                          int* xcc) {
+  const int frame = CONSECUTIVE ? (int)blockIdx.x / 4 : (int)(blockIdx.x / 32) * 8 + (int)(blockIdx.x % 8);
+  const int part = CONSECUTIVE ? (int)blockIdx.x % 4 : (int)(blockIdx.x / 8) % 4;
+  if (threadIdx.x == 0) {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    xcc[blockIdx.x] = frame < n_frames ? (int)(id & 15u) : -1;
+  }
   if (frame >= n_frames) return;
   BlockL2& b = blocks[frame];
   __shared__ double s_tot[8];
@@ -65,19 +82,19 @@ __global__ void __launch_bounds__(256) exchange_l2_kernel(BlockL2* blocks, unsig
     __syncthreads();  // (the workgroup's own reduction has happened: wave 0 publishes)
     if (threadIdx.x < 8) {
       const double v = (double)(part + 1) * (double)(threadIdx.x + 1) + (double)r;
-      store_sc0_x4(&b.c[buf][part][threadIdx.x], v, gen);
+      store_sc0_x4<STORE>(&b.c[buf][part][threadIdx.x], v, gen);
     }
     if (threadIdx.x < 32) {  // lane = (p, l): poll the chunk of part p, partial l
       const int p = (int)threadIdx.x >> 3, l = (int)threadIdx.x & 7;
-      Chunk c = load_sc0_x4(&b.c[buf][p][l]);
+      Chunk c = load_sc0_x4<POLICY>(&b.c[buf][p][l]);
       unsigned spins = 0;
       while (c.gen != gen) {
-        if (++spins > (1u << 20)) {  // never hang the device: flag and leave
+        if (++spins > (1u << 12)) {  // never hang the device: flag and leave (a policy that never sees the store ends here)
           atomicOr(timed_out, 1u);
           break;
         }
         __builtin_amdgcn_s_sleep(1);
-        c = load_sc0_x4(&b.c[buf][p][l]);
+        c = load_sc0_x4<POLICY>(&b.c[buf][p][l]);
       }
       // parts in a fixed order (deterministic sums): lanes l, 8 + l, 16 + l, 24 + l of the wave hold them
       double t = c.v;
@@ -164,14 +181,16 @@ int main(int argc, char** argv) {
   const int frame_counts[3] = {1, 16, 64};
   for (int fi = 0; fi < 3; ++fi) {
     const int F = frame_counts[fi];
-    for (int mode = 0; mode < 4; ++mode) {
+    for (int mode = 0; mode < 8; ++mode) {
       Block* d_blocks;
       double* d_out;
       long long* d_cyc;
-      const int n_wg = (mode == 1 || mode == 3) ? ((F + 7) / 8) * 32 : 4 * F;
+      const int n_wg = (mode == 1 || (mode >= 3 && mode != 7)) ? ((F + 7) / 8) * 32 : 4 * F;
       BlockL2* d_l2 = nullptr;
       unsigned* d_to = nullptr;
-      if (mode == 3) {
+      int* d_xcc = nullptr;
+      CHECK(hipMalloc(&d_xcc, sizeof(int) * (size_t)n_wg));
+      if (mode >= 3) {
         CHECK(hipMalloc(&d_l2, sizeof(BlockL2) * (size_t)F));
         CHECK(hipMalloc(&d_to, sizeof(unsigned)));
       }
@@ -186,12 +205,16 @@ int main(int argc, char** argv) {
       double check = 0.0;
       for (int rep = 0; rep < 5; ++rep) {
         CHECK(hipMemset(d_blocks, 0, sizeof(Block) * (size_t)F));
-        if (mode == 3) {
+        if (mode >= 3) {
           CHECK(hipMemset(d_l2, 0, sizeof(BlockL2) * (size_t)F));
           CHECK(hipMemset(d_to, 0, sizeof(unsigned)));
         }
         CHECK(hipEventRecord(e0, 0));
-        if (mode == 3) hipLaunchKernelGGL(exchange_l2_kernel, dim3(n_wg), dim3(256), 0, 0, d_l2, d_to, F, rounds, d_out, d_cyc);
+        if (mode == 3) hipLaunchKernelGGL((exchange_l2_kernel<0, 0, false>), dim3(n_wg), dim3(256), 0, 0, d_l2, d_to, F, rounds, d_out, d_cyc, d_xcc);
+        else if (mode == 4) hipLaunchKernelGGL((exchange_l2_kernel<1, 0, false>), dim3(n_wg), dim3(256), 0, 0, d_l2, d_to, F, rounds, d_out, d_cyc, d_xcc);
+        else if (mode == 5) hipLaunchKernelGGL((exchange_l2_kernel<2, 0, false>), dim3(n_wg), dim3(256), 0, 0, d_l2, d_to, F, rounds, d_out, d_cyc, d_xcc);
+        else if (mode == 6) hipLaunchKernelGGL((exchange_l2_kernel<1, 1, false>), dim3(n_wg), dim3(256), 0, 0, d_l2, d_to, F, rounds, d_out, d_cyc, d_xcc);
+        else if (mode == 7) hipLaunchKernelGGL((exchange_l2_kernel<1, 1, true>), dim3(n_wg), dim3(256), 0, 0, d_l2, d_to, F, rounds, d_out, d_cyc, d_xcc);
         else hipLaunchKernelGGL(exchange_kernel, dim3(n_wg), dim3(256), 0, 0, d_blocks, F, rounds, mode, d_out, d_cyc);
         CHECK(hipEventRecord(e1, 0));
         CHECK(hipEventSynchronize(e1));
@@ -201,7 +224,7 @@ int main(int argc, char** argv) {
         std::vector<Block> hb((size_t)F);
         CHECK(hipMemcpy(hb.data(), d_blocks, sizeof(Block) * (size_t)F, hipMemcpyDeviceToHost));
         for (int f = 0; f < F; ++f) timed_out |= hb[(size_t)f].timed_out;
-        if (mode == 3) {
+        if (mode >= 3) {
           unsigned to = 0;
           CHECK(hipMemcpy(&to, d_to, sizeof(unsigned), hipMemcpyDeviceToHost));
           timed_out |= to;
@@ -217,13 +240,30 @@ int main(int argc, char** argv) {
       // expected value of acc for lane 0 (column 0): sum over rounds of (1+2+3+4)*1 + 4 r = 10 + 4 r
       double expect = 0.0;
       for (int r = 0; r < rounds; ++r) expect += 10.0 + 4.0 * r;
-      const char* names[4] = {"parts_on_four_xcds", "parts_on_one_xcd", "workgroup_barrier_only", "parts_on_one_xcd_through_its_l2_sc0"};
-      std::printf(",\n \"frames_%d_%s\": {\"us_per_exchange\": %.3f, \"kernel_ms\": %.4f, \"shader_cycles_per_exchange\": %.0f, \"timed_out\": %u, \"sum_ok\": %s}",
+      const char* names[8] = {"parts_on_four_xcds", "parts_on_one_xcd", "workgroup_barrier_only", "parts_on_one_xcd_chunks_load_sc0",
+                              "parts_on_one_xcd_chunks_load_sc1", "parts_on_one_xcd_chunks_load_sc0_sc1",
+                              "ids_8_apart_chunks_store_sc1_load_sc1", "consecutive_ids_chunks_store_sc1_load_sc1"};
+      // census (modes 3-7): the fraction of frames whose four parts reported the same XCC
+      double same = -1.0;
+      if (mode >= 3) {
+        std::vector<int> hx((size_t)n_wg);
+        CHECK(hipMemcpy(hx.data(), d_xcc, sizeof(int) * (size_t)n_wg, hipMemcpyDeviceToHost));
+        int n_same = 0;
+        for (int f = 0; f < F; ++f) {
+          int ids[4];
+          for (int q = 0; q < 4; ++q) ids[q] = hx[(size_t)(mode == 7 ? 4 * f + q : ((f / 8) * 4 + q) * 8 + f % 8)];
+          n_same += ids[0] == ids[1] && ids[1] == ids[2] && ids[2] == ids[3];
+        }
+        same = (double)n_same / F;
+      }
+      std::printf(",\n \"frames_%d_%s\": {\"us_per_exchange\": %.3f, \"kernel_ms\": %.4f, \"shader_cycles_per_exchange\": %.0f, \"timed_out\": %u, \"sum_ok\": %s, \"frames_with_all_parts_on_one_xcc_frac\": %.3f}",
                   F, names[mode], 1e3 * best_ms / rounds, best_ms, (double)cmax / rounds, timed_out,
-                  mode == 2 ? "true" : (check == expect ? "true" : "false"));
+                  mode == 2 ? "true" : (check == expect ? "true" : "false"), same);
+      std::fflush(stdout);
       CHECK(hipFree(d_blocks));
       if (d_l2) CHECK(hipFree(d_l2));
       if (d_to) CHECK(hipFree(d_to));
+      CHECK(hipFree(d_xcc));
       CHECK(hipFree(d_out));
       CHECK(hipFree(d_cyc));
     }

@@ -18,6 +18,7 @@
 
 extern "C" {
 #include "svo_oracle.h"
+#include "orc_math.h"
 }
 
 namespace {
@@ -133,6 +134,23 @@ int svo_hip_sparse_align(const svo_hip_pyr_layout* L, const uint8_t* store, int 
     if (d_chi2) d_chi2[b] = r.chi2;
     if (d_status) d_status[b] = r.stop ? SVO_HIP_SIA_STOP : 0;
   }
+  return SVO_HIP_OK;
+}
+
+int svo_hip_frame_pose_compose(const double* d_T_cur_ref, const double* d_q_ref, const double* d_t_ref, double* d_frame_T, int cur_frame,
+                               double* d_T_copy, double* d_T_out, int32_t* d_signal, int32_t signal_value, void*) {
+  if (!d_T_cur_ref || !d_q_ref || !d_t_ref || !d_frame_T || cur_frame < 0) return SVO_HIP_EINVAL;
+  orc_se3 x, y;
+  orc_se3_from_Rt(d_T_cur_ref, &x);
+  for (int k = 0; k < 4; ++k) y.q[k] = d_q_ref[k];
+  for (int k = 0; k < 3; ++k) y.t[k] = d_t_ref[k];
+  const orc_se3 r = orc_se3_compose(&x, &y);
+  double T[12];
+  orc_se3_to_Rt(&r, T);
+  std::memcpy(d_frame_T + 12 * cur_frame, T, sizeof(T));
+  if (d_T_copy) std::memcpy(d_T_copy, T, sizeof(T));
+  if (d_T_out) std::memcpy(d_T_out, T, sizeof(T));
+  if (d_signal) *d_signal = signal_value;
   return SVO_HIP_OK;
 }
 

@@ -250,6 +250,16 @@ void pipe_device_stats(uint64_t out[5]) {
 #endif
 }
 
+// the chain behind the sparse alignment (rpg_svo_amd/host/dropin/frame_chain.h): reprojectMap calls that took their first
+// batch from the chain / that found one in flight and could not (hip flavour; zeros otherwise)
+void pipe_chain_stats(uint64_t out[2]) {
+  out[0] = out[1] = 0;
+#ifdef SVO_PIPELINE_HIP
+  const svo_hip::Device::Stats st = svo_hip::Device::instance().statsSnapshot();
+  out[0] = st.chain_hits; out[1] = st.chain_misses;
+#endif
+}
+
 // the map mirror of the reprojector's drop-in (row N2): calls, rebuilds, fallbacks to the list-walking path, point records
 // sent, observation records sent, second batches (hip flavour; zeros otherwise)
 void pipe_mirror_stats(uint64_t out[6]) {

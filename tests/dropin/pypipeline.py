@@ -109,6 +109,12 @@ class Pipeline:
         self.lib.pipe_device_stats(out)
         return tuple(int(x) for x in out)
 
+    def chain_stats(self):
+        """(reprojections taken from the chain enqueued behind the sparse alignment, chains found in flight and not taken)."""
+        out = (C.c_uint64 * 2)()
+        self.lib.pipe_chain_stats(out)
+        return tuple(int(x) for x in out)
+
     def mirror_stats(self):
         """(calls, rebuilds, fallbacks, point records sent, observation records sent, second batches) of the
         reprojector's map mirror, process-wide."""
@@ -173,6 +179,7 @@ def run_sequence(flavour, cam, images, T_gt, stats_out=None, range0=None, **cfg)
         s0 = p.device_stats()
         m0 = p.mirror_stats()
         q0 = p.seed_store_stats()
+        c0 = p.chain_stats()
         n0, r0 = p.set_first_frame(images[0], 0.0, T_gt[0], range_map(cam, T_gt[0]) if range0 is None else range0)
         r0["n_first_features"] = n0
         out = [r0]
@@ -189,6 +196,8 @@ def run_sequence(flavour, cam, images, T_gt, stats_out=None, range0=None, **cfg)
             s1 = p.device_stats()
             stats_out.update(uploads=s1[0] - s0[0], evictions=s1[1] - s0[1], calls=s1[2] - s0[2],
                              predicted_pose_hits=s1[3] - s0[3], predicted_pose_misses=s1[4] - s0[4])
+            c1 = p.chain_stats()
+            stats_out.update(frame_chain_hits=c1[0] - c0[0], frame_chain_misses=c1[1] - c0[1])
             m1 = p.mirror_stats()
             stats_out["map_mirror"] = dict(zip(("calls", "rebuilds", "fallbacks", "point_records_sent", "obs_records_sent",
                                                 "second_batches"), (b - a for a, b in zip(m0, m1))))

@@ -342,6 +342,7 @@ MIRROR_CODE = (
     "r = pp.run_sequence({flavour!r}, cam, imgs, T, stats_out=st, **{cfg!r})\n"
     "np.save(sys.argv[1], np.stack([x['T_f_w'] for x in r]))\n"
     "print(json.dumps(dict(st['map_mirror'], hits=st['predicted_pose_hits'], kfs=int(sum(x['is_keyframe'] for x in r)),\n"
+    "                      chain_hits=st['frame_chain_hits'], chain_misses=st['frame_chain_misses'],\n"
     "                      seed_store=st.get('seed_store'), seeds=[x['n_seeds'] for x in r],\n"
     "                      counts=[[x['repr_n_mps'], x['repr_n_new_references'], x['n_kf_points_in_frame'], x['n_candidates']] for x in r])))\n")
 
@@ -688,6 +689,47 @@ def _seed_store_on_and_off(flavour, n, tmp_path):
     assert st["seed_records_sent"] <= 2 * created + 1024 and st["seed_records_sent"] * 8 < sum(s_on["seeds"]), (st, created)
     dfr, s_dfr = _run_mirror(flavour, n, {}, tmp_path, "store_deferred", max_n_kfs=4, defer_mapper=1)
     assert np.array_equal(dfr, on) and s_dfr["seed_store"]["calls"] == st["calls"]
+    # SVO_HIP_SEED_STORE=verify (the host's state of every resident seed compared with what the device last reported, Seed::id
+    # checked for monotonicity): nothing edits the seeds behind the store's back here, so nothing is re-sent
+    ver, s_ver = _run_mirror(flavour, n, {"SVO_HIP_SEED_STORE": "verify"}, tmp_path, "store_verify", max_n_kfs=4)
+    assert np.array_equal(ver, on) and s_ver["seed_store"]["seed_records_sent"] == st["seed_records_sent"]
+
+
+def _frame_chain_on_and_off(flavour, n, tmp_path):
+    """VERDICT r05 "one completion per frame" (rpg_svo_amd/host/dropin/frame_chain.h): reprojection, matching, selection and
+    the predicted pose refinement of a frame enqueued BEHIND its sparse alignment, on the overlapping keyframes the prior
+    pose finds and the pose the device composes from K1's result; reprojectMap verifies both against what the host
+    computes and takes the batch.  Against SVO_HIP_CHAIN=0 (every step a call of its own, as up to round 5): bit-identical
+    trajectories, the same trials / matches / projected points in every frame; the chain is taken on (nearly) every
+    frame after the first reprojection -- a miss is a frame on which the final pose ranks the keyframes differently."""
+    kw = dict(max_n_kfs=4)
+    on, s_on = _run_mirror(flavour, n, {"SVO_HIP_MAP_MIRROR": "verify"}, tmp_path, "chain_on", **kw)
+    off, s_off = _run_mirror(flavour, n, {"SVO_HIP_MAP_MIRROR": "verify", "SVO_HIP_CHAIN": "0"}, tmp_path, "chain_off", **kw)
+    assert np.array_equal(on, off)
+    assert s_on["counts"] == s_off["counts"] and s_on["seeds"] == s_off["seeds"]
+    assert s_off["chain_hits"] == 0 and s_off["chain_misses"] == 0
+    print(f"frame chain [{flavour}]: taken {s_on['chain_hits']}, not taken {s_on['chain_misses']} of {n - 1} frames; "
+          f"pose refinements predicted {s_on['hits']}")
+    assert s_on["chain_hits"] >= 0.9 * (n - 2) and s_on["chain_hits"] + s_on["chain_misses"] <= n - 2
+    assert s_on["hits"] == s_off["hits"] == n - 1 and s_on["fallbacks"] == 0 and s_on["kfs"] >= 5
+    # the deferred mapper (its results are written back before the chain reads the map) and the mapper thread
+    dfr, s_dfr = _run_mirror(flavour, n, {"SVO_HIP_MAP_MIRROR": "verify"}, tmp_path, "chain_deferred", defer_mapper=1, **kw)
+    assert np.array_equal(dfr, on) and s_dfr["chain_hits"] == s_on["chain_hits"]
+    _, s_thr = _run_mirror(flavour, 100, {"SVO_HIP_MAP_MIRROR": "verify"}, tmp_path, "chain_thr", mapper_thread=1)
+    assert s_thr["fallbacks"] == 0 and s_thr["chain_hits"] + s_thr["chain_misses"] <= 98
+    # without the predicted pose refinement the chain ends with the match kernels
+    nop, s_nop = _run_mirror(flavour, 60, {"SVO_HIP_SPECULATE": "0"}, tmp_path, "chain_nopred")
+    ref60, _ = _run_mirror(flavour, 60, {"SVO_HIP_SPECULATE": "0", "SVO_HIP_CHAIN": "0"}, tmp_path, "chain_nopred_off")
+    assert np.array_equal(nop, ref60) and s_nop["chain_hits"] >= 50 and s_nop["hits"] == 0
+
+
+def test_mock_device_frame_chain_behind_the_sparse_alignment(mock_lib, tmp_path):
+    _frame_chain_on_and_off("hipmock", 160, tmp_path)
+
+
+@pytest.mark.gpu
+def test_dropin_frame_chain_behind_the_sparse_alignment_on_the_gpu(pipeline_libs, gpu_device, tmp_path):
+    _frame_chain_on_and_off("hip", 160, tmp_path)
 
 
 def test_mock_device_resident_seed_store_is_the_flattened_list(mock_lib, tmp_path):

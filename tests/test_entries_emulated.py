@@ -296,6 +296,75 @@ def test_emulated_select_matches_compose_poses_cam2world(emu_default, oracle, ki
     assert np.abs(fb - synth._bearing(cam, px)).max() < 1e-14
 
 
+def _host_frame_pose(T_cur_ref, q_ref, t_ref):
+    """poseToRt(SE3(R, t) * T_ref) as the host forms it (oracle/orc_math.h: orc_quat_from_R, orc_se3_compose, orc_quat_to_R),
+    statement for statement in Python floats (IEEE doubles, no contraction): the bits svo_hip_frame_pose_compose must give."""
+    import math
+    R, t = [float(x) for x in T_cur_ref[:9]], [float(x) for x in T_cur_ref[9:]]
+    tr = R[0] + R[4] + R[8]
+    q = [0.0] * 4
+    if tr > 0.0:
+        s = math.sqrt(tr + 1.0)
+        q[0] = 0.5 * s
+        s = 0.5 / s
+        q[1] = (R[7] - R[5]) * s; q[2] = (R[2] - R[6]) * s; q[3] = (R[3] - R[1]) * s
+    else:
+        i = 0
+        if R[4] > R[0]: i = 1
+        if R[8] > R[i * 3 + i]: i = 2
+        j = (i + 1) % 3; k = (j + 1) % 3
+        s = math.sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0)
+        q[1 + i] = 0.5 * s
+        s = 0.5 / s
+        q[0] = (R[k * 3 + j] - R[j * 3 + k]) * s
+        q[1 + j] = (R[j * 3 + i] + R[i * 3 + j]) * s
+        q[1 + k] = (R[k * 3 + i] + R[i * 3 + k]) * s
+    b, v = [float(x) for x in q_ref], [float(x) for x in t_ref]
+    ux = q[2] * v[2] - q[3] * v[1]; uy = q[3] * v[0] - q[1] * v[2]; uz = q[1] * v[1] - q[2] * v[0]
+    ux += ux; uy += uy; uz += uz
+    cx = q[2] * uz - q[3] * uy; cy = q[3] * ux - q[1] * uz; cz = q[1] * uy - q[2] * ux
+    rt = [v[0] + q[0] * ux + cx, v[1] + q[0] * uy + cy, v[2] + q[0] * uz + cz]
+    to = [t[0] + rt[0], t[1] + rt[1], t[2] + rt[2]]
+    w = q[0] * b[0] - q[1] * b[1] - q[2] * b[2] - q[3] * b[3]
+    x = q[0] * b[1] + q[1] * b[0] + q[2] * b[3] - q[3] * b[2]
+    y = q[0] * b[2] + q[2] * b[0] + q[3] * b[1] - q[1] * b[3]
+    z = q[0] * b[3] + q[3] * b[0] + q[1] * b[2] - q[2] * b[1]
+    n = math.sqrt(w * w + x * x + y * y + z * z)
+    w /= n; x /= n; y /= n; z /= n
+    tx, ty, tz = 2.0 * x, 2.0 * y, 2.0 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    return np.array([1.0 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.0 - (txx + tzz), tyz - twx, txz - twy, tyz + twx,
+                     1.0 - (txx + tyy)] + to)
+
+
+def frame_pose_compose_cases(rng, n=200):
+    """(T_cur_ref [12], q_ref [4], t_ref [3]) with rotations in every branch of the matrix -> quaternion conversion"""
+    cases = []
+    for i in range(n):
+        big = i % 4 == 0  # rotations beyond 120 degrees: trace <= 0
+        T = se3.exp(rng.normal(size=6) * (2.5 if big else 0.05))
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        cases.append((np.ascontiguousarray(T), q, rng.normal(size=3) * 3.0))
+    return cases
+
+
+def test_emulated_frame_pose_compose_is_the_hosts_product(emu_default):
+    """svo_hip_frame_pose_compose (round 6: the frame's pose formed on the stream behind K1, rpg_svo_amd/host/dropin/
+    frame_chain.h) gives, bit for bit, the rotation matrix and translation the host gets from SE3(R, t) * T_ref -- the check
+    Reprojector::reprojectMap's drop-in makes before it takes the batch the chain enqueued."""
+    emu = emu_default
+    rng = np.random.default_rng(5)
+    for T, q, t in frame_pose_compose_cases(rng):
+        table = np.zeros((3, 12)); copy = np.zeros(12); out = np.zeros(12); sig = np.zeros(1, np.int32)
+        assert emu.svo_hip_frame_pose_compose(_p(T), _p(q), _p(t), _p(table), 1, _p(copy), _p(out), _p(sig), 7, None) == 0
+        want = _host_frame_pose(T, q, t)
+        assert np.array_equal(table[1], want) and np.array_equal(copy, want) and np.array_equal(out, want) and sig[0] == 7
+        assert not table[0].any() and not table[2].any()
+    assert emu.svo_hip_frame_pose_compose(None, _p(q), _p(t), _p(table), 1, None, None, None, 0, None) == -1  # SVO_HIP_EINVAL
+
+
 def test_emulated_indirect_match_batch_is_the_direct_one(emu, scene):
     """svo_hip_find_match_direct_indirect / svo_hip_select_matches_indirect (batch size read by the kernels, observation ranges
     instead of CSR offsets: what follows svo_hip_reproject_map on the mirror's path) against the plain entry points on the

@@ -35,7 +35,10 @@ def test_no_experiment_switch_is_left_in_the_kernels():
 
 
 def test_design_table_from_a_committed_details_file(tmp_path):
-    src = os.path.join(ROOT, "profiles", "r05y_bench_default_details.json")
+    # (the details file DESIGN.md's table names as its source)
+    import re
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    src = os.path.join(ROOT, re.search(r"<!-- measured:begin -->\s*Source: `([^`]+)`", design).group(1))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "design_table.py"), src], capture_output=True, text=True, check=True).stdout
     d = json.load(open(src))
     assert f"{d['value'] / 1e6:.2f} M frames/s" in out and "epi_scan_kernel" in out and "SIA_F64_PARTIALS" in out

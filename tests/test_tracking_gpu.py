@@ -732,3 +732,30 @@ def test_select_matches_like_the_cell_loop(gpu_device, kind):
         assert np.array_equal(p[:k].cpu().numpy(), pos_o) and bool((has[:k] == 1).all())
         if k:
             assert np.abs(f[:k].cpu().numpy() - f_o).max() <= 1e-14
+
+
+@pytest.mark.gpu
+def test_frame_pose_compose_is_the_hosts_product(gpu_device):
+    """svo_hip_frame_pose_compose on the device: the bits of the host's SE3(R, t) * T_ref (IEEE f64 division and square root,
+    no contraction), which is what lets the drop-in verify a chain enqueued behind K1 (test_entries_emulated.py has the
+    statement-level twin on the CPU)."""
+    from rpg_svo_amd import capi
+    from test_entries_emulated import _host_frame_pose, frame_pose_compose_cases
+    from rpg_svo_amd.pyramid import _stream_ptr
+    lib = capi.load()
+    rng = np.random.default_rng(5)
+    cases = frame_pose_compose_cases(rng, 256)
+    dev = torch.device(gpu_device)
+    for T, q, t in cases:
+        dT, dq, dt = (torch.as_tensor(x, dtype=torch.float64, device=dev) for x in (T, q, t))
+        table = torch.zeros((3, 12), dtype=torch.float64, device=dev)
+        copy = torch.zeros(12, dtype=torch.float64, device=dev)
+        out = torch.zeros(12, dtype=torch.float64, device=dev)
+        sig = torch.zeros(1, dtype=torch.int32, device=dev)
+        capi.check(lib.svo_hip_frame_pose_compose(dT.data_ptr(), dq.data_ptr(), dt.data_ptr(), table.data_ptr(), 1, copy.data_ptr(),
+                                                  out.data_ptr(), sig.data_ptr(), 7, _stream_ptr(dev)), "svo_hip_frame_pose_compose")
+        torch.cuda.synchronize()
+        want = _host_frame_pose(T, q, t)
+        assert np.array_equal(table[1].cpu().numpy(), want) and np.array_equal(copy.cpu().numpy(), want)
+        assert np.array_equal(out.cpu().numpy(), want) and int(sig[0]) == 7
+
