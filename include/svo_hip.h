@@ -517,10 +517,20 @@ int svo_hip_cam2world(const svo_hip_camera* cam, int n, const double* d_px, doub
  *   d_T_out     (may be NULL) [12] a third copy for the host to compare (device-mapped host memory in the drop-in)
  *   d_signal    (may be NULL) signal_value is stored there (system scope, released after the copies) when the kernel
  *               is through: a host polling it knows that svo_hip_sparse_align's results AND the composed pose are
- *               in memory */
+ *               in memory
+ * With d_rank != NULL the kernel also RANKS THE OVERLAPPING KEYFRAMES with the pose it has just formed -- what
+ * Reprojector::reprojectMap does first (reprojector.cpp:78-84) -- so that svo_hip_reproject_map can follow on the
+ * stream: entries [0, n_kf) of the frame table are the map's keyframes in Map::keyframes_ order; keyframe i is "close"
+ * when the first of its key points (d_key_pos [n_kf][5][3] = Frame::key_pts_[k]->point->pos_, d_key_valid [n_kf][5] =
+ * key_pts_[k] != NULL) that Frame::isVisible accepts exists (svo/src/map.cpp:106-131, frame.cpp:115-123), its
+ * distance is the norm of the difference of the two T_f_w translations; the close keyframes are ranked closest first
+ * (equal distances in map order, like the stable list sort) and cut at max_n_kfs.  d_rank [n_frames] (read by
+ * svo_hip_reproject_map as d_kf_rank) and d_rank_out [n_frames] (may be NULL: the host's copy) receive the rank, or
+ * -1; n_frames <= 64.  `cam` is needed for the ranking only. */
 int svo_hip_frame_pose_compose(const double* d_T_cur_ref, const double* d_q_ref, const double* d_t_ref, double* d_frame_T,
-                               int cur_frame, double* d_T_copy, double* d_T_out, int32_t* d_signal, int32_t signal_value,
-                               void* stream);
+                               int cur_frame, double* d_T_copy, double* d_T_out, const svo_hip_camera* cam, int n_frames,
+                               int n_kf, const double* d_key_pos, const uint8_t* d_key_valid, int max_n_kfs, int32_t* d_rank,
+                               int32_t* d_rank_out, int32_t* d_signal, int32_t signal_value, void* stream);
 
 /*
  * K4: batched pose_optimizer::optimizeGaussNewton (svo/src/pose_optimizer.cpp:28-161).

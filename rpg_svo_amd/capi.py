@@ -179,7 +179,7 @@ PROTOTYPES = {
                                              _vp, _vp, _i, _vp]),
     "svo_hip_reproject_points": (_i, [C.POINTER(Camera), C.POINTER(Frames), _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "svo_hip_compose_poses": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
-    "svo_hip_frame_pose_compose": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "svo_hip_frame_pose_compose": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "svo_hip_cam2world": (_i, [C.POINTER(Camera), _i, _vp, _vp, _vp]),
     "svo_hip_select_matches": (_i, [C.POINTER(Camera), _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "svo_hip_pose_optimize": (_i, [C.POINTER(Camera), _i, _vp, _i, _vp, _vp, _vp, _vp, C.c_double, _i, _vp, _vp, _vp,

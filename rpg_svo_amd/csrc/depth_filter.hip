@@ -214,17 +214,19 @@ __global__ void __launch_bounds__(SCAN_BLOCK, PINHOLE ? SCAN_MINW : SCAN_MINW - 
   __shared__ __attribute__((aligned(16))) uint32_t s_box[SCAN_BLOCK / SCAN_G][SCAN_BOX_DWORDS + 0];
   constexpr int PER_LANE = SCAN_CHUNK / SCAN_BLOCK;
   constexpr int GROUPS = 64 / SCAN_G;  // seeds a wave scans at a time
-  const int base = blockIdx.x * SCAN_CHUNK;
+  const int chunk = a.scan_chunk;      // SCAN_CHUNK, or SCAN_CHUNK_SMALL for a small batch
+  const int base = blockIdx.x * chunk;
   const SeedWs& w = a.ws;
   if (threadIdx.x < SCAN_BUCKETS) s_hist[threadIdx.x] = 0;
   __syncthreads();
   int bucket[PER_LANE], rank[PER_LANE];
 #pragma unroll
   for (int k = 0; k < PER_LANE; ++k) {
-    const int s = base + threadIdx.x + SCAN_BLOCK * k;
+    const int in_chunk = threadIdx.x + SCAN_BLOCK * k;
+    const int s = base + in_chunk;
     bucket[k] = -1;
     rank[k] = 0;
-    const int md = s < a.S ? w.mode[s] : MODE_NONE;
+    const int md = (in_chunk < chunk && s < a.S) ? w.mode[s] : MODE_NONE;
     if (md != MODE_NONE) {
       // n_steps + 1 positions (matcher.cpp:264): lines of up to SCAN_G positions (one pass of one position per lane) in
       // bucket 0, then power-of-two buckets of the passes of 2 SCAN_G positions.  A seed whose segment is too short to be
@@ -513,6 +515,7 @@ static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_sto
     a.px_error_angle = atan(px_noise / (2.0 * focal_length)) * 2.0;
     a.tau_k = tau_consts(a.px_error_angle);
   }
+  a.scan_chunk = S <= SCAN_SMALL_S ? SCAN_CHUNK_SMALL : SCAN_CHUNK;
   SeedWs& w = a.ws;
   w.n_steps = c.take<int32_t>(n);  // first array of the workspace: svo_hip_update_seeds_scan_steps
   int32_t* const align_evals = c.take<int32_t>(n);  // second: svo_hip_update_seeds_align_evaluations
@@ -545,9 +548,9 @@ static int run_seed_chain(const svo_hip_pyr_layout* layout, const uint8_t* d_sto
   if (rc) return rc;
   // (the affine warp of the reference patch is the scan kernel's first step: warp_group.h)
   if (a.cam.model == SVO_HIP_CAM_PINHOLE)
-    hipLaunchKernelGGL(epi_scan_kernel<true>, dim3((S + SCAN_CHUNK - 1) / SCAN_CHUNK), dim3(SCAN_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(epi_scan_kernel<true>, dim3((S + a.scan_chunk - 1) / a.scan_chunk), dim3(SCAN_BLOCK), 0, st, a);
   else
-    hipLaunchKernelGGL(epi_scan_kernel<false>, dim3((S + SCAN_CHUNK - 1) / SCAN_CHUNK), dim3(SCAN_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(epi_scan_kernel<false>, dim3((S + a.scan_chunk - 1) / a.scan_chunk), dim3(SCAN_BLOCK), 0, st, a);
   rc = check_launch();
   if (rc) return rc;
   AlignArgs al;

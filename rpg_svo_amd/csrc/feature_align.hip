@@ -215,7 +215,11 @@ namespace svo_track {
 #define ALIGN_PHASE_MIN_M_VALUE (1 << 16)
 #endif
 constexpr int ALIGN_PHASE_MIN_M = ALIGN_PHASE_MIN_M_VALUE;  // below this the extra launches cost more than the idle lanes
-constexpr int ALIGN_PHASE_ITERS = 3;
+// (other boundaries measured slower on the representative workload -- {0, 2, 4}: +2.5 % on update_seeds, {0, 1, 3}: +6 %,
+// four launches {0, 2, 4, 7}: +4 %, {0, 1, 2, 4}: +12 %: a launch re-reads the template and rebuilds H^-1; profiles/r06k_*)
+constexpr int ALIGN_PHASE_START[] = {0, 3, 6};  // first iteration of every launch
+constexpr int ALIGN_N_PHASES = (int)(sizeof(ALIGN_PHASE_START) / sizeof(int));
+constexpr int ALIGN_PHASE_ITERS = ALIGN_PHASE_START[1];
 #ifndef ALIGN_WAVE_MAX_M_VALUE  // (the CPU emulation of the test suite has a build with 0: every batch on the lane kernel)
 #define ALIGN_WAVE_MAX_M_VALUE 8192
 #endif
@@ -226,7 +230,7 @@ static int phase_queue_cap(int M) { return (M + ALIGN_NQ - 1) / ALIGN_NQ + 2 * A
 size_t align_phase_workspace_bytes(int M) {
   if (M < ALIGN_PHASE_MIN_M) return 0;
   const size_t cap = (size_t)phase_queue_cap(M);
-  return 2 * Carver::round(ALIGN_NQ * cap * sizeof(int32_t)) + Carver::round(2 * ALIGN_NQ * sizeof(int32_t)) +
+  return 2 * Carver::round(ALIGN_NQ * cap * sizeof(int32_t)) + Carver::round((ALIGN_N_PHASES - 1) * ALIGN_NQ * sizeof(int32_t)) +
          Carver::round((size_t)M * 6 * sizeof(float));
 }
 
@@ -261,10 +265,10 @@ int launch_align(const AlignArgs& a0, hipStream_t s, void* d_phase_ws, size_t ph
   Carver c(d_phase_ws, phase_ws_bytes);
   const int cap = phase_queue_cap(a0.M);
   int32_t* queue[2] = {c.take<int32_t>((size_t)ALIGN_NQ * cap), c.take<int32_t>((size_t)ALIGN_NQ * cap)};
-  int32_t* count = c.take<int32_t>(2 * ALIGN_NQ);
+  int32_t* count = c.take<int32_t>((ALIGN_N_PHASES - 1) * ALIGN_NQ);
   float* state = c.take<float>((size_t)a0.M * 6);
   if (!c.ok) return launch_one(a0, all_blocks, s, fin);
-  SVO_HIP_TRY(hipMemsetAsync(count, 0, 2 * ALIGN_NQ * sizeof(int32_t), s));
+  SVO_HIP_TRY(hipMemsetAsync(count, 0, (ALIGN_N_PHASES - 1) * ALIGN_NQ * sizeof(int32_t), s));
   // a queue holds the survivors of the workgroups b % ALIGN_NQ == q: at most cap entries; every launch after the first
   // is sized for full queues (workgroups past a queue's end leave at once)
   const int queue_blocks = ALIGN_NQ * ((cap + ALIGN_BLOCK - 1) / ALIGN_BLOCK);
@@ -272,13 +276,14 @@ int launch_align(const AlignArgs& a0, hipStream_t s, void* d_phase_ws, size_t ph
   a.state = state;
   a.queue_cap = cap;
   int rc = SVO_HIP_OK;
-  for (int phase = 0; phase < 3 && rc == SVO_HIP_OK; ++phase) {
-    a.it0 = phase * ALIGN_PHASE_ITERS;
-    a.it1 = phase == 2 ? (1 << 30) : (phase + 1) * ALIGN_PHASE_ITERS;
+  for (int phase = 0; phase < ALIGN_N_PHASES && rc == SVO_HIP_OK; ++phase) {
+    const bool last = phase == ALIGN_N_PHASES - 1;
+    a.it0 = ALIGN_PHASE_START[phase];
+    a.it1 = last ? (1 << 30) : ALIGN_PHASE_START[phase + 1];
     a.queue_in = phase == 0 ? nullptr : queue[(phase - 1) & 1];
-    a.n_in = phase == 0 ? nullptr : count + ((phase - 1) & 1) * ALIGN_NQ;
-    a.queue_out = phase == 2 ? nullptr : queue[phase & 1];
-    a.n_out = phase == 2 ? nullptr : count + (phase & 1) * ALIGN_NQ;
+    a.n_in = phase == 0 ? nullptr : count + (phase - 1) * ALIGN_NQ;
+    a.queue_out = last ? nullptr : queue[phase & 1];
+    a.n_out = last ? nullptr : count + phase * ALIGN_NQ;
     rc = launch_one(a, phase == 0 ? all_blocks : queue_blocks, s, fin);
   }
   return rc;

@@ -283,32 +283,97 @@ __global__ void __launch_bounds__(256) compose_kernel(const GlueArgs a) {
   const int o = a.out_index ? a.out_index[i] : i;
   se3_to_Rt(r, a.out + 12 * o);
 }
-// svo_hip_frame_pose_compose: one lane (a dozen dependent f64 operations; what matters is that it sits on the stream)
+// svo_hip_frame_pose_compose: lane 0 forms the pose (a dozen dependent f64 operations; what matters is that it sits on the
+// stream), then lane i ranks keyframe i among the keyframes whose field of view overlaps the frame's: Map::getCloseKeyframes
+// (svo/src/map.cpp:106-131: the first of a keyframe's key points that Frame::isVisible, frame.cpp:115-123, puts it on the
+// list with the distance of the two T_f_w translations) followed by the reprojector's closest-first sort and its cut at
+// max_n_kfs (reprojector.cpp:78-84; std::list::sort is stable: equal distances keep the map's order).
 struct FramePoseArgs {
   const double *T_cur_ref, *q_ref, *t_ref;
   double *frame_T, *T_copy, *T_out;
   int cur_frame;
   int32_t* signal;
   int32_t signal_value;
+  Cam cam;
+  int n_frames, n_kf, max_n_kfs;
+  const double* key_pos;     // [n_kf][5][3]
+  const uint8_t* key_valid;  // [n_kf][5]
+  int32_t *rank, *rank_out;  // [n_frames]
 };
 __global__ void __launch_bounds__(64) frame_pose_compose_kernel(const FramePoseArgs a) {
-  if (threadIdx.x != 0) return;
-  Se3 x, y;
-  se3_from_Rt(a.T_cur_ref, x);  // SE3(R, t): the quaternion of the rotation matrix (Eigen's Quaternion(Matrix3))
+  __shared__ Se3 s_T;
+  __shared__ double s_dist[64];
+  const int i = (int)threadIdx.x;
+  // what the ranking reads does not depend on the pose: the five key points and the translation of keyframe i are requested
+  // before lane 0 starts on the product (one memory round trip, hidden behind its chain of divisions and square roots)
+  const bool ranks = a.rank != nullptr, mine = ranks && i < a.n_kf;  // (keyframes come first in the table: i != cur_frame)
+  uint8_t valid[5] = {0, 0, 0, 0, 0};
+  double kp[5][3], tk[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-  for (int k = 0; k < 4; ++k) y.q[k] = a.q_ref[k];
+  for (int k = 0; k < 5; ++k) {
+    valid[k] = mine ? a.key_valid[5 * i + k] : (uint8_t)0;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) y.t[k] = a.t_ref[k];
-  const Se3 r = se3_compose(x, y);
-  double T[12];
-  se3_to_Rt(r, T);
-#pragma unroll
-  for (int k = 0; k < 12; ++k) {
-    a.frame_T[12 * a.cur_frame + k] = T[k];
-    if (a.T_copy) a.T_copy[k] = T[k];
-    if (a.T_out) a.T_out[k] = T[k];
+    for (int c = 0; c < 3; ++c) kp[k][c] = mine ? a.key_pos[3 * (5 * i + k) + c] : 0.0;
   }
-  if (a.signal) __hip_atomic_store(a.signal, a.signal_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (mine) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tk[c] = a.frame_T[12 * i + 9 + c];
+  }
+  if (i == 0) {
+    Se3 x, y;
+    se3_from_Rt(a.T_cur_ref, x);  // SE3(R, t): the quaternion of the rotation matrix (Eigen's Quaternion(Matrix3))
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y.q[k] = a.q_ref[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) y.t[k] = a.t_ref[k];
+    const Se3 r = se3_compose(x, y);
+    s_T = r;
+    double T[12];
+    se3_to_Rt(r, T);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      a.frame_T[12 * a.cur_frame + k] = T[k];
+      if (a.T_copy) a.T_copy[k] = T[k];
+      if (a.T_out) a.T_out[k] = T[k];
+    }
+  }
+  if (ranks) {  // (uniform)
+    __syncthreads();
+    const Se3 T = s_T;  // the pose as the host's object holds it: quaternion and translation, not re-derived from R
+    double dist = -1.0;   // < 0: no key point of the keyframe is visible
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      if (found || !valid[k]) continue;
+      double xyz_f[3], px[2];
+      se3_apply(T, kp[k], xyz_f);
+      if (xyz_f[2] < 0.0) continue;  // behind the camera
+      world2cam(a.cam, xyz_f, px);
+      if (px[0] >= 0.0 && px[1] >= 0.0 && px[0] < (double)a.cam.width && px[1] < (double)a.cam.height) {
+        const double d[3] = {T.t[0] - tk[0], T.t[1] - tk[1], T.t[2] - tk[2]};
+        dist = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        found = true;
+      }
+    }
+    s_dist[i] = dist;
+    __syncthreads();
+    if (i < a.n_frames) {
+      int r = -1;
+      if (dist >= 0.0) {
+        r = 0;
+        for (int j = 0; j < a.n_kf; ++j) {
+          const double dj = s_dist[j];
+          if (dj >= 0.0 && (dj < dist || (dj == dist && j < i))) ++r;
+        }
+        if (r >= a.max_n_kfs) r = -1;
+      }
+      a.rank[i] = r;
+      if (a.rank_out) a.rank_out[i] = r;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // (system scope) every lane's rank is out before lane 0 signals
+    __syncthreads();
+  }
+  if (i == 0 && a.signal) __hip_atomic_store(a.signal, a.signal_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ void __launch_bounds__(256) cam2world_kernel(const GlueArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -596,7 +661,9 @@ extern "C" int svo_hip_compose_poses(int n, const double* d_A, const double* d_B
 }
 
 extern "C" int svo_hip_frame_pose_compose(const double* d_T_cur_ref, const double* d_q_ref, const double* d_t_ref, double* d_frame_T,
-                                          int cur_frame, double* d_T_copy, double* d_T_out, int32_t* d_signal, int32_t signal_value,
+                                          int cur_frame, double* d_T_copy, double* d_T_out, const svo_hip_camera* cam, int n_frames,
+                                          int n_kf, const double* d_key_pos, const uint8_t* d_key_valid, int max_n_kfs,
+                                          int32_t* d_rank, int32_t* d_rank_out, int32_t* d_signal, int32_t signal_value,
                                           void* stream) {
   if (!d_T_cur_ref || !d_q_ref || !d_t_ref || !d_frame_T || cur_frame < 0) return SVO_HIP_EINVAL;
   FramePoseArgs a{};
@@ -605,6 +672,15 @@ extern "C" int svo_hip_frame_pose_compose(const double* d_T_cur_ref, const doubl
   a.cur_frame = cur_frame;
   a.signal = d_signal;
   a.signal_value = signal_value;
+  if (d_rank != nullptr) {
+    if (!cam || !cam_model_ok(cam) || n_frames < 1 || n_frames > 64 || n_kf < 0 || n_kf > n_frames || cur_frame >= n_frames ||
+        (n_kf > 0 && (!d_key_pos || !d_key_valid)) || max_n_kfs < 0)
+      return SVO_HIP_EINVAL;
+    a.cam = make_cam(cam);
+    a.n_frames = n_frames; a.n_kf = n_kf; a.max_n_kfs = max_n_kfs;
+    a.key_pos = d_key_pos; a.key_valid = d_key_valid;
+    a.rank = d_rank; a.rank_out = d_rank_out;
+  }
   hipLaunchKernelGGL(frame_pose_compose_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), a);
   return check_launch();
 }

@@ -69,6 +69,9 @@ struct SeedArgs {
   double px_error_angle;  // atan(1 / (2 |fx|)) * 2
   TauConsts tau_k;         // its sines and cosines (seed_math.h)
   SeedWs ws;
+  // seeds per workgroup of the scan kernel (epi_scan.h: SCAN_CHUNK for batches, SCAN_CHUNK_SMALL for a camera frame's few
+  // hundred seeds, which one workgroup of 32 groups would otherwise work through round by round)
+  int scan_chunk;
 };
 
 

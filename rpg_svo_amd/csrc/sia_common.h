@@ -31,7 +31,7 @@ struct SiaArgs {
   double* chi2;
   int32_t* status;
   // A frame split over several workgroups (sparse_align.hip, PARTS > 1): the number of frames (the grid is padded), the
-  // exchange blocks (one SIA_X_CHUNKS-chunk block per frame, zeroed before the launch).  NULL / 0 otherwise.
+  // exchange blocks (one SIA_X_BLOCK-chunk block per frame).  NULL / 0 otherwise.
   int B = 0;
   void* xw = nullptr;
 };
@@ -45,8 +45,10 @@ struct SiaArgs {
 // is a matter of speed only).  Round 6 first built this with sc0 stores kept in a shared L2: it never saw its siblings
 // inside the real kernel although a microbenchmark of the same instructions did (profiles/r06f_*): placement is not a
 // contract.  Each 8-byte half of a chunk carries the epoch, so that a reader can tell a torn 16-byte read (never
-// observed on gfx950) from a whole one.  The blocks are zeroed by the launch function before every launch and epochs count
-// from 1 within the launch: nothing depends on what an earlier launch (or a graph replay of this one) left behind.
+// observed on gfx950) from a whole one.  Epochs never repeat in a block: a frame's block ends with a word holding the last
+// epoch used in it (zero when the block is new), every part reads it when it starts and part 0 writes it back when the
+// frame is done, so a launch continues counting where the block's last user stopped and no chunk an earlier launch (or an
+// earlier replay of a captured one) left behind can carry an epoch this launch waits for -- nothing is cleared per launch.
 struct XChunk {
   unsigned lo, tag0, hi, tag1;
 };
@@ -54,7 +56,8 @@ static_assert(sizeof(XChunk) == 16, "one 16-byte access");
 constexpr int SIA_X_SLOTS = 16;   // chunks per part and buffer half of the per-iteration exchange (9 used: 8 sums + "changed")
 constexpr int SIA_XH_SLOTS = 24;  // ... of the H exchange (21 used)
 constexpr int SIA_X_MAX_PARTS = 4;
-constexpr int SIA_X_CHUNKS = 2 * SIA_X_MAX_PARTS * (SIA_X_SLOTS + SIA_XH_SLOTS);  // per frame
+constexpr int SIA_X_CHUNKS = 2 * SIA_X_MAX_PARTS * (SIA_X_SLOTS + SIA_XH_SLOTS);  // exchange chunks per frame ...
+constexpr int SIA_X_BLOCK = SIA_X_CHUNKS + 1;                                     // ... + the chunk that holds the block's last epoch
 
 #ifndef SVO_HOST_MATH_TEST
 __device__ __forceinline__ void sia_xstore(XChunk* p, double v, unsigned epoch) {
@@ -75,6 +78,13 @@ __device__ __forceinline__ XChunk sia_xload(const XChunk* p) {
   XChunk c;
   c.lo = w.x; c.tag0 = w.y; c.hi = w.z; c.tag1 = w.w;
   return c;
+}
+// the word at the end of a frame's block: the last epoch used in it
+__device__ __forceinline__ void sia_xstore_epoch(XChunk* p, unsigned epoch) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  u4 w;
+  w.x = epoch; w.y = 0u; w.z = 0u; w.w = 0u;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" ::"v"(p), "v"(w) : "memory");
 }
 // the value of chunk p once both its halves carry `epoch`; NaN (and failed = 1) when they never do: a part that is not
 // running (the launcher only splits grids that are resident at once) must not hang the device

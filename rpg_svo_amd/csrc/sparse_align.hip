@@ -34,6 +34,9 @@
 // like H_, Jres_ and jacobian_cache_ of the reference (sparse_img_align.cpp:228-230,253-258).  bench.py times it next to
 // the default (`f64_partials` / `roofline_f64_build` in the JSON line) so the price of that width is a number.
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "sia_common.h"
 
@@ -103,7 +106,6 @@ struct SiaLds {
   double A[36];                  // Gauss-Jordan scratch
   sia_acc part[2][MAX_WAVES][8];  // per-wave partials of Jres[6], chi2, n_meas (double-buffered)
   int chg[2][MAX_WAVES];          // per wave: some patch entered or left the current image (same buffering)
-  double xsum[16];                // a split frame: the frame's sums of the iteration (9 used), published by the exchanging wave
   int xfail;                      // ... some lane of the workgroup gave up waiting for a sibling part
   sia_acc Hpart[MAX_WAVES][24];   // per-wave partials of H (21 used)
   long long lo[SVO_HIP_MAX_LEVELS];  // pyramid geometry per level (copied from the kernel
@@ -125,25 +127,33 @@ template <int PARTS>
 __device__ __forceinline__ void sia_rebuild_hinv(int lane, int nw, [[maybe_unused]] XChunk* xh, [[maybe_unused]] int part,
                                                  [[maybe_unused]] unsigned gen, [[maybe_unused]] int& xfail) {
   asm volatile("" : "+v"(lane));  // keep this cold block's address math out of the caller's loops
+#ifndef SVO_HOST_MATH_TEST
+  if constexpr (PARTS > 1) {
+    // lane = (j-th of the OTHER parts, element k): the 3 x 21 chunks are polled side by side -- one memory round trip, where
+    // a lane per element polling its three chunks one after the other paid three (lane 63 idles)
+    static_assert((PARTS - 1) * 21 <= 64, "one lane per chunk of the other parts");
+    const int j = lane / 21, k = lane - 21 * j;
+    double v = 0.0;
+    for (int w = 0; w < nw; ++w) v += (double)g_s.Hpart[w][k];
+    if (j == 0) sia_xstore(xh + part * SIA_XH_SLOTS + k, v, gen);
+    const int other = j < part ? j : j + 1;
+    double got = 0.0;
+    if (j < PARTS - 1) got = sia_xpoll(xh + other * SIA_XH_SLOTS + k, gen, xfail);
+    if (xfail) g_s.xfail = 1;
+    // the parts in a fixed order: every part forms the same sums
+    double tot = 0.0;
+#pragma unroll
+    for (int p = 0; p < PARTS; ++p) {
+      const double theirs = __shfl(got, (p < part ? p : p - 1) * 21 + k, 64);  // (p == part: not used)
+      const double term = p == part ? v : theirs;
+      tot = p == 0 ? term : tot + term;
+    }
+    if (lane < 21) g_s.H[lane] = tot;
+  } else
+#endif
   if (lane < 21) {
     double v = 0.0;
     for (int w = 0; w < nw; ++w) v += (double)g_s.Hpart[w][lane];
-#ifndef SVO_HOST_MATH_TEST
-    if constexpr (PARTS > 1) {
-      sia_xstore(xh + part * SIA_XH_SLOTS + lane, v, gen);
-      double hv[PARTS];
-#pragma unroll
-      for (int p = 0; p < PARTS; ++p) hv[p] = v;
-      // the other parts' sums: requested together, then waited for one by one
-#pragma unroll
-      for (int p = 0; p < PARTS; ++p)
-        if (p != part) hv[p] = sia_xpoll(xh + p * SIA_XH_SLOTS + lane, gen, xfail);
-      if (xfail) g_s.xfail = 1;
-      v = hv[0];
-#pragma unroll
-      for (int p = 1; p < PARTS; ++p) v += hv[p];
-    }
-#endif
     g_s.H[lane] = v;
   }
   SVO_WAVE_LDS_FENCE();
@@ -217,8 +227,13 @@ __global__ void __launch_bounds__(BLOCK, PARTS > 1 ? 1 : ((DIST && BLOCK < 1024)
   } else {
     b = (int)xcd_contiguous_block();
   }
-  [[maybe_unused]] XChunk* const xbase = PARTS > 1 ? static_cast<XChunk*>(a.xw) + (size_t)b * SIA_X_CHUNKS : nullptr;
-  [[maybe_unused]] unsigned xseq = 0;  // epoch of the last exchange (uniform over the frame's parts; the blocks start zeroed)
+  [[maybe_unused]] XChunk* const xbase = PARTS > 1 ? static_cast<XChunk*>(a.xw) + (size_t)b * SIA_X_BLOCK : nullptr;
+  // epoch of the last exchange (uniform over the frame's parts): continues from the block's last user (sia_common.h).  No
+  // part can overwrite the word before all have read it: part 0 writes it at the end, behind exchanges every part joined.
+  [[maybe_unused]] unsigned xseq = 0;
+#ifndef SVO_HOST_MATH_TEST
+  if constexpr (PARTS > 1) xseq = (unsigned)__builtin_amdgcn_readfirstlane((int)sia_xload(xbase + SIA_X_CHUNKS).lo);
+#endif
   [[maybe_unused]] int xfail = 0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -663,12 +678,10 @@ __global__ void __launch_bounds__(BLOCK, PARTS > 1 ? 1 : ((DIST && BLOCK < 1024)
 #ifndef SVO_HOST_MATH_TEST
       if constexpr (PARTS > 1) {
         // every wave takes part (no second barrier): lane = (part xp, sum xk); the workgroup's own sums come from LDS, wave
-        // `sw` publishes them, the other parts' are polled
+        // `sw` publishes them, the other parts' are polled.  (One polling wave per workgroup that hands the sums to the others
+        // through LDS behind a second barrier measured the same: 0.0938 against 0.0949 ms, profiles/r06j_*.)
         ++xseq;
         const int xp = lane >> 4, xk = lane & 15;
-#ifdef SIA_X_ONEWAVE
-        if (wave == sw) {
-#endif
         double own = 0.0;
         if (xk < 8) {
 #pragma unroll
@@ -685,12 +698,6 @@ __global__ void __launch_bounds__(BLOCK, PARTS > 1 ? 1 : ((DIST && BLOCK < 1024)
         xtot = __shfl(val, xk, 64);
 #pragma unroll
         for (int p = 1; p < PARTS; ++p) xtot += __shfl(val, 16 * p + xk, 64);
-#ifdef SIA_X_ONEWAVE
-          if (lane < 9) g_s.xsum[lane] = xtot;
-        }
-        __syncthreads();
-        xtot = g_s.xsum[xk < 9 ? xk : 0];
-#endif
         changed = readlane_f64<8>(xtot) != 0.0;
       }
 #endif
@@ -895,6 +902,13 @@ __global__ void __launch_bounds__(BLOCK, PARTS > 1 ? 1 : ((DIST && BLOCK < 1024)
 #endif
     a.n_tracked[b] = n_meas_last / 16;
     if (a.chi2) a.chi2[b] = chi2_prev;
+    if constexpr (PARTS > 1) {
+      // the block's next user starts behind this frame's last epoch (far behind it after a time-out, whose parts may not
+      // have counted alike)
+#ifndef SVO_HOST_MATH_TEST
+      sia_xstore_epoch(xbase + SIA_X_CHUNKS, xseq + (g_s.xfail ? (1u << 16) : 0u));
+#endif
+    }
     // (g_s.xfail: written by whichever lane gave up, ahead of the barrier that ends its iteration)
     if (a.status) a.status[b] = (stop ? SVO_HIP_SIA_STOP : 0) | ((PARTS > 1 && g_s.xfail) ? SVO_HIP_SIA_EXCHANGE_TIMEOUT : 0);
   }
@@ -959,10 +973,12 @@ int sia_prepare(const svo_hip_pyr_layout* layout, const uint8_t* d_store, int B,
 
 // ---- a frame split over four workgroups (PARTS = 4) -------------------------------------------------------------------
 // For frames of more than 512 patches in batches that leave most of the GPU idle (4 B workgroups of 256 lanes must be
-// RESIDENT AT ONCE -- the parts spin on each other --: B <= SIA_SPLIT_MAX_B).  The exchange blocks are a stream-ordered
-// allocation of the launch, zeroed by a memset ahead of the kernel; epochs count from 1 inside the launch (no per-launch
-// salt: a captured launch replays with the arguments it was captured with).  SVO_HIP_K1_SPLIT=0 keeps every frame on one
-// workgroup.
+// RESIDENT AT ONCE -- the parts spin on each other --: B <= SIA_SPLIT_MAX_B).  The exchange blocks belong to the (device,
+// stream) pair: allocated and zeroed once, on the pair's first split launch, and never cleared again -- a block remembers
+// the last epoch used in it (sia_common.h), launches on one stream follow each other, launches on different streams use
+// different blocks.  No per-launch allocation, memset or salt argument: a captured launch replays correctly.  A stream
+// that is being captured when its blocks would have to be created keeps the frame on one workgroup (an allocation is not
+// a capturable operation).  SVO_HIP_K1_SPLIT=0 keeps every frame on one workgroup.
 constexpr int SIA_SPLIT_PARTS = 4;
 constexpr int SIA_SPLIT_MAX_B = 128;
 #ifndef SVO_HOST_MATH_TEST
@@ -970,14 +986,28 @@ bool sia_split_applies(const SiaArgs& args, int B) {
   static const bool on = [] { const char* v = std::getenv("SVO_HIP_K1_SPLIT"); return !(v && v[0] == '0'); }();
   return on && args.n_stride > 512 && B <= SIA_SPLIT_MAX_B;
 }
-int launch_split(SiaArgs args, int B, hipStream_t s) {
-  void* xw = nullptr;
-  const size_t bytes = (size_t)B * SIA_X_CHUNKS * sizeof(XChunk);
-  SVO_HIP_TRY(hipMallocAsync(&xw, bytes, s));
-  if (hipMemsetAsync(xw, 0, bytes, s) != hipSuccess) {
-    (void)hipFreeAsync(xw, s);
-    return SVO_HIP_EHIP;
+// the exchange blocks of (current device, stream); NULL: none can be had right now
+void* sia_split_blocks(hipStream_t s) {
+  static std::mutex mut;
+  static std::map<std::pair<int, hipStream_t>, void*> blocks;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> g(mut);
+  void*& p = blocks[std::make_pair(dev, s)];
+  if (p) return p;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+  const size_t bytes = (size_t)SIA_SPLIT_MAX_B * SIA_X_BLOCK * sizeof(XChunk);
+  void* q = nullptr;
+  if (hipMalloc(&q, bytes) != hipSuccess) return nullptr;
+  if (hipMemset(q, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipFree(q);
+    return nullptr;
   }
+  p = q;
+  return p;
+}
+int launch_split(SiaArgs args, int B, void* xw, hipStream_t s) {
   args.B = B;
   args.xw = xw;
   const dim3 grid((unsigned)((B + 7) / 8) * 8 * SIA_SPLIT_PARTS), blk(256);
@@ -985,12 +1015,9 @@ int launch_split(SiaArgs args, int B, hipStream_t s) {
     hipLaunchKernelGGL((sia_kernel<256, true, false, SIA_SPLIT_PARTS>), grid, blk, 0, s, args);
   else
     hipLaunchKernelGGL((sia_kernel<256, false, true, SIA_SPLIT_PARTS>), grid, blk, 0, s, args);
-  const int rc = check_launch();
-  SVO_HIP_TRY(hipFreeAsync(xw, s));
-  return rc;
+  return check_launch();
 }
 #endif
-
 
 int launch_workgroup(const SiaArgs& args, int B, hipStream_t s) {
   if (args.n_stride <= 64) return launch<64>(args, B, s);
@@ -1017,7 +1044,8 @@ extern "C" int svo_hip_sparse_align(const svo_hip_pyr_layout* layout, const uint
   // large batches of frames with up to 192 patches: one wave per frame (sparse_align_wave.hip); else one workgroup
   if (sia_wave_applies(args, B)) return launch_sia_wave(args, B, s);
 #ifndef SVO_HOST_MATH_TEST
-  if (sia_split_applies(args, B)) return launch_split(args, B, s);
+  if (sia_split_applies(args, B))
+    if (void* xw = sia_split_blocks(s)) return launch_split(args, B, xw, s);
 #endif
   return launch_workgroup(args, B, s);
 }

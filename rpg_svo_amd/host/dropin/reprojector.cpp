@@ -268,54 +268,72 @@ template <class GridT>
 class MirrorChain : public hip_dropin::FrameChain {
  public:
   MirrorChain(Map& map, const GridT& grid, const Reprojector::Options& options, const int* align_max_iter)
-      : map_(map), grid_(grid), options_(options), align_max_iter_(align_max_iter), state_(IDLE), hook_lane_(NULL), d_qt_(NULL),
+      : map_(map), grid_(grid), options_(options), align_max_iter_(align_max_iter), state_(IDLE), hook_lane_(NULL), frames_(NULL), n_kf_(0), d_key_pos_(NULL), d_key_valid_(NULL), h_rank_(NULL),
+        d_rank_host_(NULL), d_qt_(NULL),
         h_Tcomp_(NULL), d_Tcomp_(NULL), flag_k1_(NULL), d_flag_k1_(NULL), n_tab_(0), rebuilds_at_prepare_(0) {}
 
   svo_hip::Lane* hook_lane_;  // the lane the chain is registered on
 
-  bool prepare(const FramePtr& ref, const FramePtr& cur, svo_hip::Device& dev, svo_hip::Lane& lane, hip_dropin::FrameTable& frames,
-               size_t k1_bytes) {
+  size_t outputBytesBound() const {
+    // (MirrorBatch::allocOutputs at its largest: 8192 map entries, 64 frames, the trial capacity; + the chain's own words)
+    const size_t T = mirrorTrialCap();
+    return 8192 * 4 + 64 * 4 + 3 * MirrorBatch::V_CAP * 4 + T * (16 + 12 + 32) + ((size_t)Config::maxFts() + 1) * 8 + 64 * 256;
+  }
+  bool prepare(const FramePtr& ref, const FramePtr& cur, svo_hip::Device& dev, svo_hip::Lane& lane) {
     using namespace hip_dropin;
     state_ = IDLE;
+    delete frames_;
+    frames_ = NULL;
     if (!options_.find_match_direct || MapMirror::mode() == MapMirror::OFF || !cur->fts_.empty()) return false;
     if (lane.arena.mode() == svo_hip::Arena::MIRRORED) return false;  // (no host-visible signals)
     const size_t n_cells = grid_.cells.size();
     if (n_cells > (size_t)SVO_HIP_REPROJ_MAX_CELLS || options_.max_n_kfs > 16) return false;
     MapMirror& mm = mirrorOf(&map_);
-    // the overlapping keyframes as the PRIOR pose sees them (frame_handler_mono.cpp:132: cur->T_f_w_ is the last frame's)
-    std::list<KfDist> close_kfs;
-    map_.getCloseKeyframes(cur, close_kfs);
-    close_kfs.sort(closerKf);
     if (!mm.sync(map_)) return false;  // (the ordinary path will find the same and fall back)
     const size_t n_mirror = mm.frames().size();
     if (n_mirror + 2 > 64 || (size_t)dev.slots() < n_mirror + 4) return false;
-    ranked_.clear();
-    std::vector<int32_t> rank_of(n_mirror + 2, -1);  // the mirror's frames, the current one, the reference frame of K1
-    for (std::list<KfDist>::iterator kf = close_kfs.begin(); kf != close_kfs.end() && ranked_.size() < options_.max_n_kfs; ++kf) {
-      const int idx = mm.frameIndex(kf->first.get());
-      if (idx < 0) return false;
-      rank_of[(size_t)idx] = (int32_t)ranked_.size();
-      ranked_.push_back(std::make_pair(kf->first, idx));
+    // The overlapping keyframes are ranked ON THE DEVICE, with the pose it forms from K1's result (svo_hip_frame_pose_compose):
+    // what the host sends are the key points Map::getCloseKeyframes looks at, keyframes in map order = the first entries
+    // of the mirror's frame table.  (Ranking them here with the prior pose -- the first version of the chain -- was right
+    // on 78 % of the frames of a 600-frame sequence with ten keyframes in view: the order of two keyframes at nearly the
+    // same distance flips with the 2 cm the pose moves.)
+    n_kf_ = map_.keyframes_.size();
+    if (n_kf_ > n_mirror) return false;
+    key_pos_.assign(15 * n_kf_, 0.0);
+    key_valid_.assign(5 * n_kf_, 0);
+    {
+      size_t i = 0;
+      for (std::list<FramePtr>::const_iterator kf = map_.keyframes_.begin(); kf != map_.keyframes_.end(); ++kf, ++i) {
+        if (mm.frames()[i] != kf->get() || (*kf)->key_pts_.size() != 5) return false;
+        for (size_t k = 0; k < 5; ++k) {
+          const Feature* ftr = (*kf)->key_pts_[k];
+          if (ftr == NULL) continue;
+          if (ftr->point == NULL) return false;  // (the reference would dereference it)
+          key_valid_[5 * i + k] = 1;
+          for (int c = 0; c < 3; ++c) key_pos_[3 * (5 * i + k) + c] = ftr->point->pos_[c];
+        }
+      }
     }
     b_.clear();
     b_.dev = &dev; b_.lane = &lane; b_.mm = &mm;
     b_.T_CAP = mirrorTrialCap();
     mm.ensureDevice(grid_.cell_order, b_.T_CAP);
-    lane.arena.reserve(b_.arenaBytes(n_mirror + 2) + k1_bytes + 4096);
+    lane.arena_chain.reset();
+    lane.arena_chain.reserve(b_.arenaBytes(n_mirror + 2) + 4096);
+    frames_ = new FrameTable(dev, svo_hip::Device::LANE_TRACKING);
+    FrameTable& frames = *frames_;
     for (size_t i = 0; i < n_mirror; ++i)
       if (frames.indexOf(mm.frames()[i]) != (int)i) throw std::logic_error("Reprojector: frame table out of order");
     b_.i_cur = frames.indexOf(cur.get());
     frames.indexOf(ref.get());  // (a keyframe of the mirror, or one more entry)
     n_tab_ = (size_t)frames.size();
-    rank_of.resize(n_tab_, -1);
-    b_.rank_of.swap(rank_of);
+    b_.rank_of.assign(n_tab_, -1);  // (written on the device)
     b_.cam = cameraOf(cur->cam_);
     b_.cell_size = grid_.cell_size; b_.n_cols = grid_.grid_n_cols; b_.n_rows = grid_.grid_n_rows;
     b_.n_cells = n_cells; b_.first_cell = 0; b_.max_cells = firstBatchCells();
     b_.align_max_iter = *align_max_iter_;
     b_.predict = svo_hip::Device::speculationEnabled();
     b_.frame_id = cur->id_;
-    frames_ = &frames;
     cur_ = cur;
     rebuilds_at_prepare_ = mm.stats.rebuilds;
     state_ = PREPARED;
@@ -326,16 +344,23 @@ class MirrorChain : public hip_dropin::FrameChain {
     double* qt = a.alloc<double>(8, &d_qt_);  // the reference frame's pose as the host's product reads it
     hip_dropin::poseToQt(ref->T_f_w_, qt, qt + 4);
     qt[7] = 0.0;
+    double* kp = a.alloc<double>(key_pos_.size() ? key_pos_.size() : 1, &d_key_pos_);
+    uint8_t* kv = a.alloc<uint8_t>(key_valid_.size() ? key_valid_.size() : 1, &d_key_valid_);
+    std::copy(key_pos_.begin(), key_pos_.end(), kp);
+    std::copy(key_valid_.begin(), key_valid_.end(), kv);
   }
   void allocOutputs(svo_hip::Arena& a) {
     b_.allocOutputs(a, n_tab_, cur_, b_.lane->spec, true);
     h_Tcomp_ = a.alloc<double>(12, &d_Tcomp_);
+    h_rank_ = a.alloc<int32_t>(n_tab_, &d_rank_host_);
     flag_k1_ = a.alloc<int32_t>(1, &d_flag_k1_);
     *flag_k1_ = 0;
   }
   void enqueue(const double* d_T_cur_ref) {
-    svo_hip::check(svo_hip_frame_pose_compose(d_T_cur_ref, d_qt_, d_qt_ + 4, const_cast<double*>(b_.ft.d_T_f_w), b_.i_cur, b_.predict ? b_.d_T : NULL, d_Tcomp_,
-                                              d_flag_k1_, 1, b_.lane->stream),
+    svo_hip::check(svo_hip_frame_pose_compose(d_T_cur_ref, d_qt_, d_qt_ + 4, const_cast<double*>(b_.ft.d_T_f_w), b_.i_cur,
+                                              b_.predict ? b_.d_T : NULL, d_Tcomp_, &b_.cam, (int)n_tab_, (int)n_kf_, d_key_pos_,
+                                              d_key_valid_, (int)options_.max_n_kfs, b_.d_rank, d_rank_host_, d_flag_k1_, 1,
+                                              b_.lane->stream),
                    "svo_hip_frame_pose_compose");
     b_.launchMatch(b_.lane->arena);
     svo_hip::Speculation& sp = b_.lane->spec;
@@ -349,6 +374,7 @@ class MirrorChain : public hip_dropin::FrameChain {
   }
   const volatile int32_t* k1Signal() const { return flag_k1_; }
   void abandon() { state_ = IDLE; cur_.reset(); }
+  ~MirrorChain() { delete frames_; }
 
   // ---- the other end: Reprojector::reprojectMap asks for the batch of `frame` -----------------------------------------
   // true: the chain's batch is the frame's (verified), its match results have arrived; `ranked` / `rank_of` / n_tab as the
@@ -362,27 +388,37 @@ class MirrorChain : public hip_dropin::FrameChain {
     cur.swap(cur_);
     std::lock_guard<std::mutex> guard(lane.mut);
     svo_hip::Speculation& sp = lane.spec;
+    int why = 0;
     bool ok = b_.lane == &lane && b_.dev == &dev && cur.get() == frame.get() && sp.in_flight && sp.stream == lane.stream &&
               b_.frame_id == frame->id_ && *flag_k1_ == 1;
     if (ok) {  // the pose the device formed is the pose the host formed
+      why = 1;
       double T[12];
       poseToRt(frame->T_f_w_, T);
       ok = std::memcmp(T, h_Tcomp_, sizeof(T)) == 0;
     }
-    if (ok) {  // the overlapping keyframes of the final pose are, in order, the ones the prior pose found
+    std::vector<std::pair<FramePtr, int> > ranked_now;
+    std::vector<int32_t> rank_now(n_tab_, -1);
+    if (ok) {  // the device ranked the overlapping keyframes as the host ranks them
+      why = 2;
       std::list<KfDist> close_kfs;
       map_.getCloseKeyframes(frame, close_kfs);
       close_kfs.sort(closerKf);
-      size_t k = 0;
-      for (std::list<KfDist>::iterator kf = close_kfs.begin(); kf != close_kfs.end() && k < options_.max_n_kfs; ++kf, ++k)
-        if (k >= ranked_.size() || ranked_[k].first.get() != kf->first.get()) { ok = false; break; }
-      if (ok && k != ranked_.size()) ok = false;
+      for (std::list<KfDist>::iterator kf = close_kfs.begin(); kf != close_kfs.end() && ranked_now.size() < options_.max_n_kfs; ++kf) {
+        const int idx = b_.mm->frameIndex(kf->first.get());
+        if (idx < 0 || (size_t)idx >= n_tab_) { ok = false; break; }
+        rank_now[(size_t)idx] = (int32_t)ranked_now.size();
+        ranked_now.push_back(std::make_pair(kf->first, idx));
+      }
+      for (size_t i = 0; ok && i < n_tab_; ++i) ok = h_rank_[i] == rank_now[i];
     }
     if (ok) {  // nothing has touched the map since the chain was built
+      why = 3;
       MapMirror& mm = *b_.mm;
       ok = &mm == &mirrorOf(&map_) && mm.sync(map_) && !mm.pending() && mm.stats.rebuilds == rebuilds_at_prepare_;
     }
     if (ok) {
+      why = 4;
       {
         svo_hip::StageTimer stage_timer(dev, lane, svo_hip::Device::STAGE_REPROJECT);
         stage_timer.device(0);
@@ -392,12 +428,13 @@ class MirrorChain : public hip_dropin::FrameChain {
       }
       ok = b_.header[0] == 0;
     }
-    dev.countChain(ok);
+    dev.countChain(ok, why);
     if (!ok) return false;  // (sp.in_flight stays set: the ordinary path's beginCall() waits for the stream)
     if (b_.predict) std::copy(h_Tcomp_, h_Tcomp_ + 12, sp.T_init);
     else sp.in_flight = false;  // (the stream has been waited for)
     out_batch = b_;
-    ranked = ranked_;
+    out_batch.rank_of = rank_now;
+    ranked = ranked_now;
     n_tab = n_tab_;
     return true;
   }
@@ -421,7 +458,13 @@ class MirrorChain : public hip_dropin::FrameChain {
   MirrorBatch b_;
   hip_dropin::FrameTable* frames_;
   FramePtr cur_;
-  std::vector<std::pair<FramePtr, int> > ranked_;
+  size_t n_kf_;
+  std::vector<double> key_pos_;
+  std::vector<uint8_t> key_valid_;
+  double* d_key_pos_;
+  uint8_t* d_key_valid_;
+  const int32_t* h_rank_;
+  int32_t* d_rank_host_;
   double* d_qt_;
   double *h_Tcomp_, *d_Tcomp_;
   volatile int32_t* flag_k1_;

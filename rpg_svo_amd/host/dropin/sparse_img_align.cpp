@@ -57,13 +57,9 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   a.reset();
   FrameTable frames(dev, L);
   FrameChain* chain = svo_hip::Device::chainEnabled() ? static_cast<FrameChain*>(lane.chain_hook) : NULL;
-  // (ref == cur cannot be chained: the table would hold one entry for both)
-  if (chain != NULL && (ref_frame.get() == cur_frame.get() || !chain->prepare(ref_frame, cur_frame, dev, lane, frames, n * 64 + 8192)))
-    chain = NULL;
-  struct Abandon {  // an exception between prepare() and enqueue() leaves the chain idle
-    FrameChain* c;
-    ~Abandon() { if (c) c->abandon(); }
-  } abandon = {chain};
+  // (no host-visible signals in a mirrored arena; ref == cur: one table entry would have to hold two poses)
+  if (chain != NULL && (a.mode() == svo_hip::Arena::MIRRORED || ref_frame.get() == cur_frame.get())) chain = NULL;
+  if (chain != NULL) a.reserve(n * 64 + 8192 + chain->outputBytesBound());
   const int i_ref = frames.indexOf(ref_frame.get());
   const int i_cur = frames.indexOf(cur_frame.get());
 
@@ -90,7 +86,6 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   }
   const SE3 T_cur_from_ref(cur_frame->T_f_w_ * ref_frame->T_f_w_.inverse());  // prior (:59)
   poseToRt(T_cur_from_ref, Tin);
-  if (chain) chain->allocInputs(a, ref_frame);
   a.endInputs();
 
   // ---- outputs ---------------------------------------------------------------------------
@@ -101,7 +96,6 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   int32_t* n_tracked = a.alloc<int32_t>(1, &d_ntracked);
   int32_t* iters = a.alloc<int32_t>(SVO_HIP_MAX_LEVELS, &d_iters);
   int32_t* status = a.alloc<int32_t>(1, &d_status);
-  if (chain) chain->allocOutputs(a);
 
   const svo_hip_camera cam = cameraOf(ref_frame->cam_);
   svo_hip_sia_params P;
@@ -115,11 +109,26 @@ size_t SparseImgAlign::run(FramePtr ref_frame, FramePtr cur_frame) {
   svo_hip::check(svo_hip_sparse_align(&dev.layout(), dev.store(), 1, d_slots, d_slots + 1, d_slots + 2, (int)n, d_px, d_xyz,
                                       d_valid, &P, d_Tin, d_Tout, d_H, d_ntracked, d_iters, d_chi2, d_status, lane.stream),
                  "svo_hip_sparse_align");
-  if (chain) {
+  // K1 is running: the chain's host work, its inputs (second arena, own copy command) and its launches follow
+  bool chained = false;
+  if (chain != NULL) {
+    struct Abandon {  // an exception between prepare() and enqueue() leaves the chain idle
+      FrameChain* c;
+      ~Abandon() { if (c) c->abandon(); }
+    } abandon = {chain};
+    if (chain->prepare(ref_frame, cur_frame, dev, lane)) {
+      chain->allocInputs(lane.arena_chain, ref_frame);
+      lane.arena_chain.uploadAll(lane.stream);
+      chain->allocOutputs(a);
+      chain->enqueue(d_Tout);
+      chained = true;
+    }
+    abandon.c = NULL;
+    if (!chained) chain->abandon();
+  }
+  if (chained) {
     // reprojection, matching, selection and the predicted pose refinement follow K1 on the stream; this call returns when
     // K1's results (and the pose the device formed from them) are in host memory
-    chain->enqueue(d_Tout);
-    abandon.c = NULL;
     svo_hip::spinUntil(chain->k1Signal(), 1, lane.stream);
   } else {
     a.download(lane.stream);

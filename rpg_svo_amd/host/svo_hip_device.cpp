@@ -140,6 +140,7 @@ void destroyLane(Lane* l) {  // everything makeLane() / workspace() may have giv
   if (l->ev_results) { svo_hip_event_destroy(l->ev_results); l->ev_results = NULL; }
   l->deferred = nullptr;  // its owner is about to lose the device; nothing is written back
   l->arena.release();
+  l->arena_chain.release();
   if (l->d_workspace) { svo_hip_free(l->d_workspace); l->d_workspace = NULL; l->workspace_bytes = 0; }
   if (l->d_stage) { svo_hip_free(l->d_stage); l->d_stage = NULL; }
   delete l;
@@ -164,6 +165,8 @@ Lane* Device::makeLane() {
     check(svo_hip_malloc(&l->d_stage, (size_t)layout_.w[0] * layout_.h[0]), "svo_hip_malloc(stage)");
     l->arena.reserve((size_t)4 << 20);
     l->arena.setMode(arena_mode);
+    l->arena_chain.reserve((size_t)1 << 20);
+    l->arena_chain.setMode(arena_mode);  // (never endInputs(): every block is an input -- device mirror, or host memory when mapped)
   } catch (...) {
     destroyLane(l);  // not in lanes_ yet: shutdown() would never see it
     throw;
@@ -302,9 +305,13 @@ void Device::countSpeculation(bool hit) {
   if (hit) ++stats.spec_hits; else ++stats.spec_misses;
 }
 
-void Device::countChain(bool hit) {
+void Device::countChain(bool hit, int why) {
   std::lock_guard<std::mutex> g(stats_mut_);
-  if (hit) ++stats.chain_hits; else ++stats.chain_misses;
+  if (hit) ++stats.chain_hits;
+  else {
+    ++stats.chain_misses;
+    ++stats.chain_miss_why[why >= 0 && why < 6 ? why : 5];
+  }
 }
 
 bool Device::chainEnabled() {

@@ -134,6 +134,7 @@ struct Lane {
   // this header (no reference types); owned by the registering Reprojector, which clears it under `mut` when it dies.
   void* chain_hook;
   Arena arena;
+  Arena arena_chain;      // the chain's INPUT blocks: filled and uploaded while K1 (whose inputs left with `arena`) is running
   void* d_workspace;      // matcher / depth-filter scratch (svo_hip_match_workspace_bytes)
   size_t workspace_bytes;
   void* d_stage;          // packed level-0 image on its way into the tiled store (svo_hip_pyramid_upload_*)
@@ -215,10 +216,13 @@ class Device {
     uint64_t uploads, evictions, calls;
     uint64_t spec_hits, spec_misses;  // pose refinements taken from / not taken from the reprojector's prediction
     uint64_t chain_hits, chain_misses;  // reprojections + matches taken from / not taken from the chain enqueued behind K1
+    uint64_t chain_miss_why[6];         // ... not taken because: 0 not this frame / drained, 1 pose bits, 2 keyframe ranking,
+                                        //     3 the map moved on, 4 a capacity was exceeded on the device, 5 (spare)
     double pyr_upload_us;
     double marshal_us[N_STAGES], device_us[N_STAGES], unmarshal_us[N_STAGES], payload_bytes[N_STAGES];
     uint64_t n[N_STAGES];
     Stats() : uploads(0), evictions(0), calls(0), spec_hits(0), spec_misses(0), chain_hits(0), chain_misses(0), pyr_upload_us(0) {
+      for (int i = 0; i < 6; ++i) chain_miss_why[i] = 0;
       for (int i = 0; i < N_STAGES; ++i) { marshal_us[i] = device_us[i] = unmarshal_us[i] = payload_bytes[i] = 0; n[i] = 0; }
     }
   };
@@ -227,7 +231,7 @@ class Device {
   // count = false: the second half of a call already counted (a deferred call's join)
   void addStage(int stage, double marshal_us, double device_us, double unmarshal_us, double payload_bytes, bool count = true);
   void countSpeculation(bool hit);
-  void countChain(bool hit);
+  void countChain(bool hit, int why = 0);
   // SVO_HIP_CHAIN=0 switches the chain behind the sparse alignment off (reprojectMap then starts its own call, as before)
   static bool chainEnabled();
   // SVO_HIP_SPECULATE=0 switches the reprojector's prediction off (every stage then ends with its own stream sync)

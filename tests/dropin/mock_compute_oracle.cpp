@@ -138,7 +138,9 @@ int svo_hip_sparse_align(const svo_hip_pyr_layout* L, const uint8_t* store, int 
 }
 
 int svo_hip_frame_pose_compose(const double* d_T_cur_ref, const double* d_q_ref, const double* d_t_ref, double* d_frame_T, int cur_frame,
-                               double* d_T_copy, double* d_T_out, int32_t* d_signal, int32_t signal_value, void*) {
+                               double* d_T_copy, double* d_T_out, const svo_hip_camera* cam, int n_frames, int n_kf,
+                               const double* d_key_pos, const uint8_t* d_key_valid, int max_n_kfs, int32_t* d_rank, int32_t* d_rank_out,
+                               int32_t* d_signal, int32_t signal_value, void*) {
   if (!d_T_cur_ref || !d_q_ref || !d_t_ref || !d_frame_T || cur_frame < 0) return SVO_HIP_EINVAL;
   orc_se3 x, y;
   orc_se3_from_Rt(d_T_cur_ref, &x);
@@ -150,6 +152,37 @@ int svo_hip_frame_pose_compose(const double* d_T_cur_ref, const double* d_q_ref,
   std::memcpy(d_frame_T + 12 * cur_frame, T, sizeof(T));
   if (d_T_copy) std::memcpy(d_T_copy, T, sizeof(T));
   if (d_T_out) std::memcpy(d_T_out, T, sizeof(T));
+  if (d_rank) {  // Map::getCloseKeyframes + the reprojector's closest-first sort, cut at max_n_kfs
+    if (!cam || n_frames < 1 || n_frames > 64 || n_kf < 0 || n_kf > n_frames) return SVO_HIP_EINVAL;
+    const orc_pinhole c = camOf(cam);
+    std::vector<double> dist((size_t)n_frames, -1.0);
+    for (int i = 0; i < n_kf; ++i)
+      for (int k = 0; k < 5; ++k) {
+        if (!d_key_valid[5 * i + k]) continue;
+        double xyz_f[3], uv[2], px[2];
+        orc_se3_apply(&r, d_key_pos + 3 * (5 * i + k), xyz_f);
+        if (xyz_f[2] < 0.0) continue;
+        uv[0] = xyz_f[0] / xyz_f[2]; uv[1] = xyz_f[1] / xyz_f[2];
+        orc_cam_world2cam_uv(&c, uv, px);
+        if (px[0] >= 0.0 && px[1] >= 0.0 && px[0] < (double)c.width && px[1] < (double)c.height) {
+          const double* tk = d_frame_T + 12 * i + 9;
+          const double d[3] = {r.t[0] - tk[0], r.t[1] - tk[1], r.t[2] - tk[2]};
+          dist[(size_t)i] = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+          break;
+        }
+      }
+    for (int i = 0; i < n_frames; ++i) {
+      int rk = -1;
+      if (dist[(size_t)i] >= 0.0) {
+        rk = 0;
+        for (int j = 0; j < n_kf; ++j)
+          if (dist[(size_t)j] >= 0.0 && (dist[(size_t)j] < dist[(size_t)i] || (dist[(size_t)j] == dist[(size_t)i] && j < i))) ++rk;
+        if (rk >= max_n_kfs) rk = -1;
+      }
+      d_rank[i] = rk;
+      if (d_rank_out) d_rank_out[i] = rk;
+    }
+  }
   if (d_signal) *d_signal = signal_value;
   return SVO_HIP_OK;
 }

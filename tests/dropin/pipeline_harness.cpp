@@ -252,11 +252,12 @@ void pipe_device_stats(uint64_t out[5]) {
 
 // the chain behind the sparse alignment (rpg_svo_amd/host/dropin/frame_chain.h): reprojectMap calls that took their first
 // batch from the chain / that found one in flight and could not (hip flavour; zeros otherwise)
-void pipe_chain_stats(uint64_t out[2]) {
-  out[0] = out[1] = 0;
+void pipe_chain_stats(uint64_t out[8]) {
+  for (int i = 0; i < 8; ++i) out[i] = 0;
 #ifdef SVO_PIPELINE_HIP
   const svo_hip::Device::Stats st = svo_hip::Device::instance().statsSnapshot();
   out[0] = st.chain_hits; out[1] = st.chain_misses;
+  for (int i = 0; i < 6; ++i) out[2 + i] = st.chain_miss_why[i];  // not this frame, pose bits, keyframe ranking, map moved on, capacity
 #endif
 }
 

@@ -111,7 +111,7 @@ class Pipeline:
 
     def chain_stats(self):
         """(reprojections taken from the chain enqueued behind the sparse alignment, chains found in flight and not taken)."""
-        out = (C.c_uint64 * 2)()
+        out = (C.c_uint64 * 8)()
         self.lib.pipe_chain_stats(out)
         return tuple(int(x) for x in out)
 
@@ -197,7 +197,9 @@ def run_sequence(flavour, cam, images, T_gt, stats_out=None, range0=None, **cfg)
             stats_out.update(uploads=s1[0] - s0[0], evictions=s1[1] - s0[1], calls=s1[2] - s0[2],
                              predicted_pose_hits=s1[3] - s0[3], predicted_pose_misses=s1[4] - s0[4])
             c1 = p.chain_stats()
-            stats_out.update(frame_chain_hits=c1[0] - c0[0], frame_chain_misses=c1[1] - c0[1])
+            stats_out.update(frame_chain_hits=c1[0] - c0[0], frame_chain_misses=c1[1] - c0[1],
+                             frame_chain_miss_reasons=dict(zip(("not_this_frame", "pose_bits", "keyframe_ranking", "map_moved_on", "capacity"),
+                                                               (b - a for a, b in zip(c0[2:7], c1[2:7])))))
             m1 = p.mirror_stats()
             stats_out["map_mirror"] = dict(zip(("calls", "rebuilds", "fallbacks", "point_records_sent", "obs_records_sent",
                                                 "second_batches"), (b - a for a, b in zip(m0, m1))))

@@ -350,19 +350,115 @@ def frame_pose_compose_cases(rng, n=200):
     return cases
 
 
+def host_keyframe_ranks(cam, T12, q_cur, key_pos, key_valid, table, n_kf, max_n_kfs):
+    """Map::getCloseKeyframes + the reprojector's stable closest-first sort and cut, in Python floats: per frame-table entry the
+    rank or -1.  T12: the composed (R | t); q_cur: its unit quaternion (w, x, y, z) as the SE3 object holds it."""
+    import math
+    w, x, y, z = [float(v) for v in q_cur]
+    t = [float(v) for v in T12[9:]]
+    dist = [-1.0] * len(table)
+    for i in range(n_kf):
+        for k in range(5):
+            if not key_valid[i, k]:
+                continue
+            v = [float(c) for c in key_pos[i, k]]
+            ux = y * v[2] - z * v[1]; uy = z * v[0] - x * v[2]; uz = x * v[1] - y * v[0]
+            ux += ux; uy += uy; uz += uz
+            cx = y * uz - z * uy; cy = z * ux - x * uz; cz = x * uy - y * ux
+            f = [(v[0] + w * ux + cx) + t[0], (v[1] + w * uy + cy) + t[1], (v[2] + w * uz + cz) + t[2]]
+            if f[2] < 0.0:
+                continue
+            px = (cam.fx * (f[0] / f[2]) + cam.cx, cam.fy * (f[1] / f[2]) + cam.cy)  # (the undistorted pinhole)
+            if px[0] >= 0.0 and px[1] >= 0.0 and px[0] < cam.width and px[1] < cam.height:
+                d = [t[c] - float(table[i][9 + c]) for c in range(3)]
+                dist[i] = math.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+                break
+    ranks = []
+    for i in range(len(table)):
+        r = -1
+        if dist[i] >= 0.0:
+            r = sum(1 for j in range(n_kf) if dist[j] >= 0.0 and (dist[j] < dist[i] or (dist[j] == dist[i] and j < i)))
+            if r >= max_n_kfs:
+                r = -1
+        ranks.append(r)
+    return np.array(ranks, np.int32)
+
+
+def keyframe_rank_case(rng, n_kf=12, n_tab=14):
+    """a frame table of n_tab poses around the origin looking at points near z = 2, key points per keyframe (some missing, some
+    behind / outside), two keyframes at EXACTLY the same distance (the stable order decides)"""
+    table = np.stack([se3.exp(np.concatenate([rng.normal(size=3) * 0.3, rng.normal(size=3) * 0.05])) for _ in range(n_tab)])
+    table[5, 9:] = table[3, 9:]  # equal translations -> equal distances
+    key_pos = np.concatenate([rng.uniform(-2.5, 2.5, size=(n_kf, 5, 2)), rng.uniform(-1.0, 4.0, size=(n_kf, 5, 1))], axis=2)
+    key_valid = (rng.uniform(size=(n_kf, 5)) < 0.8).astype(np.uint8)
+    key_valid[7] = 0  # a keyframe without key points is never close
+    return np.ascontiguousarray(table), np.ascontiguousarray(key_pos), key_valid
+
+
+def _quat_of(T12):
+    """unit quaternion the host's SE3(R, t) constructor derives (orc_quat_from_R): via _host_frame_pose's first lines"""
+    import math
+    R = [float(x) for x in T12[:9]]
+    tr = R[0] + R[4] + R[8]
+    q = [0.0] * 4
+    if tr > 0.0:
+        s = math.sqrt(tr + 1.0); q[0] = 0.5 * s; s = 0.5 / s
+        q[1] = (R[7] - R[5]) * s; q[2] = (R[2] - R[6]) * s; q[3] = (R[3] - R[1]) * s
+    else:
+        i = 0
+        if R[4] > R[0]: i = 1
+        if R[8] > R[i * 3 + i]: i = 2
+        j = (i + 1) % 3; k = (j + 1) % 3
+        s = math.sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0)
+        q[1 + i] = 0.5 * s; s = 0.5 / s
+        q[0] = (R[k * 3 + j] - R[j * 3 + k]) * s; q[1 + j] = (R[j * 3 + i] + R[i * 3 + j]) * s; q[1 + k] = (R[k * 3 + i] + R[i * 3 + k]) * s
+    return q
+
+
+def _composed_quat(T_cur_ref, q_ref):
+    """the unit quaternion of SE3(R, t) * T_ref before it is turned into a matrix (what Frame::isVisible rotates with)"""
+    import math
+    q = _quat_of(T_cur_ref); b = [float(x) for x in q_ref]
+    w = q[0] * b[0] - q[1] * b[1] - q[2] * b[2] - q[3] * b[3]
+    x = q[0] * b[1] + q[1] * b[0] + q[2] * b[3] - q[3] * b[2]
+    y = q[0] * b[2] + q[2] * b[0] + q[3] * b[1] - q[1] * b[3]
+    z = q[0] * b[3] + q[3] * b[0] + q[1] * b[2] - q[2] * b[1]
+    n = math.sqrt(w * w + x * x + y * y + z * z)
+    return [w / n, x / n, y / n, z / n]
+
+
 def test_emulated_frame_pose_compose_is_the_hosts_product(emu_default):
     """svo_hip_frame_pose_compose (round 6: the frame's pose formed on the stream behind K1, rpg_svo_amd/host/dropin/
     frame_chain.h) gives, bit for bit, the rotation matrix and translation the host gets from SE3(R, t) * T_ref -- the check
-    Reprojector::reprojectMap's drop-in makes before it takes the batch the chain enqueued."""
+    Reprojector::reprojectMap's drop-in makes before it takes the batch the chain enqueued -- and ranks the overlapping
+    keyframes like Map::getCloseKeyframes + the reprojector's sort."""
     emu = emu_default
     rng = np.random.default_rng(5)
     for T, q, t in frame_pose_compose_cases(rng):
         table = np.zeros((3, 12)); copy = np.zeros(12); out = np.zeros(12); sig = np.zeros(1, np.int32)
-        assert emu.svo_hip_frame_pose_compose(_p(T), _p(q), _p(t), _p(table), 1, _p(copy), _p(out), _p(sig), 7, None) == 0
+        assert emu.svo_hip_frame_pose_compose(_p(T), _p(q), _p(t), _p(table), 1, _p(copy), _p(out), None, 0, 0, None, None, 0, None, None,
+                                              _p(sig), 7, None) == 0
         want = _host_frame_pose(T, q, t)
         assert np.array_equal(table[1], want) and np.array_equal(copy, want) and np.array_equal(out, want) and sig[0] == 7
         assert not table[0].any() and not table[2].any()
-    assert emu.svo_hip_frame_pose_compose(None, _p(q), _p(t), _p(table), 1, None, None, None, 0, None) == -1  # SVO_HIP_EINVAL
+    assert emu.svo_hip_frame_pose_compose(None, _p(q), _p(t), _p(table), 1, None, None, None, 0, 0, None, None, 0, None, None, None, 0,
+                                          None) == -1  # SVO_HIP_EINVAL
+    # the ranking, on the undistorted pinhole (the distorted models' projection has its own bit-exact tests)
+    cam = camera_models()["pinhole"]
+    cs = capi.camera(cam)
+    for trial in range(40):
+        table, key_pos, key_valid = keyframe_rank_case(rng)
+        n_tab, n_kf = len(table), len(key_pos)
+        T = np.ascontiguousarray(se3.exp(rng.normal(size=6) * 0.05)); q = rng.normal(size=4); q /= np.linalg.norm(q); t = rng.normal(size=3) * 0.2
+        for max_n in (3, 10):
+            tab = table.copy(); rank = np.full(n_tab, 99, np.int32); rank2 = np.full(n_tab, 99, np.int32)
+            assert emu.svo_hip_frame_pose_compose(_p(T), _p(q), _p(t), _p(tab), n_tab - 2, None, None, C.byref(cs), n_tab, n_kf, _p(key_pos),
+                                                  _p(key_valid), max_n, _p(rank), _p(rank2), None, 0, None) == 0
+            want = host_keyframe_ranks(cam, _host_frame_pose(T, q, t), _composed_quat(T, q), key_pos, key_valid, tab, n_kf, max_n)
+            assert np.array_equal(rank, want) and np.array_equal(rank2, want), (trial, rank, want)
+            assert (rank[n_kf:] == -1).all() and rank.max() < max_n and rank[7] == -1
+            if want[3] >= 0 and want[5] >= 0:
+                assert want[5] == want[3] + 1  # equal distances: map order
 
 
 def test_emulated_indirect_match_batch_is_the_direct_one(emu, scene):

@@ -737,25 +737,42 @@ def test_select_matches_like_the_cell_loop(gpu_device, kind):
 @pytest.mark.gpu
 def test_frame_pose_compose_is_the_hosts_product(gpu_device):
     """svo_hip_frame_pose_compose on the device: the bits of the host's SE3(R, t) * T_ref (IEEE f64 division and square root,
-    no contraction), which is what lets the drop-in verify a chain enqueued behind K1 (test_entries_emulated.py has the
-    statement-level twin on the CPU)."""
+    no contraction) and the host's ranking of the overlapping keyframes, which is what lets the drop-in verify a chain
+    enqueued behind K1 (test_entries_emulated.py has the statement-level twin on the CPU)."""
     from rpg_svo_amd import capi
-    from test_entries_emulated import _host_frame_pose, frame_pose_compose_cases
     from rpg_svo_amd.pyramid import _stream_ptr
+    import ctypes as C
+    from test_entries_emulated import (_composed_quat, _host_frame_pose, frame_pose_compose_cases, host_keyframe_ranks,
+                                       keyframe_rank_case)
     lib = capi.load()
     rng = np.random.default_rng(5)
-    cases = frame_pose_compose_cases(rng, 256)
     dev = torch.device(gpu_device)
-    for T, q, t in cases:
-        dT, dq, dt = (torch.as_tensor(x, dtype=torch.float64, device=dev) for x in (T, q, t))
+    td = lambda x, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(x), dtype=dt, device=dev)
+    for T, q, t in frame_pose_compose_cases(rng, 256):
+        dT, dq, dt = td(T), td(q), td(t)
         table = torch.zeros((3, 12), dtype=torch.float64, device=dev)
         copy = torch.zeros(12, dtype=torch.float64, device=dev)
         out = torch.zeros(12, dtype=torch.float64, device=dev)
         sig = torch.zeros(1, dtype=torch.int32, device=dev)
         capi.check(lib.svo_hip_frame_pose_compose(dT.data_ptr(), dq.data_ptr(), dt.data_ptr(), table.data_ptr(), 1, copy.data_ptr(),
-                                                  out.data_ptr(), sig.data_ptr(), 7, _stream_ptr(dev)), "svo_hip_frame_pose_compose")
+                                                  out.data_ptr(), None, 0, 0, None, None, 0, None, None, sig.data_ptr(), 7,
+                                                  _stream_ptr(dev)), "svo_hip_frame_pose_compose")
         torch.cuda.synchronize()
         want = _host_frame_pose(T, q, t)
         assert np.array_equal(table[1].cpu().numpy(), want) and np.array_equal(copy.cpu().numpy(), want)
         assert np.array_equal(out.cpu().numpy(), want) and int(sig[0]) == 7
-
+    cam = camera_models()["pinhole"]
+    cs = capi.camera(cam)
+    for trial in range(60):
+        table, key_pos, key_valid = keyframe_rank_case(rng)
+        n_tab, n_kf = len(table), len(key_pos)
+        T = np.ascontiguousarray(se3.exp(rng.normal(size=6) * 0.05)); q = rng.normal(size=4); q /= np.linalg.norm(q); t = rng.normal(size=3) * 0.2
+        for max_n in (3, 10):
+            tab = td(table); rank = torch.full((n_tab,), 99, dtype=torch.int32, device=dev); rank2 = rank.clone()
+            dT, dq, dt, kp, kv = td(T), td(q), td(t), td(key_pos), td(key_valid, torch.uint8)
+            capi.check(lib.svo_hip_frame_pose_compose(dT.data_ptr(), dq.data_ptr(), dt.data_ptr(), tab.data_ptr(), n_tab - 2, None, None,
+                                                      C.byref(cs), n_tab, n_kf, kp.data_ptr(), kv.data_ptr(), max_n, rank.data_ptr(),
+                                                      rank2.data_ptr(), None, 0, _stream_ptr(dev)), "svo_hip_frame_pose_compose")
+            torch.cuda.synchronize()
+            want = host_keyframe_ranks(cam, _host_frame_pose(T, q, t), _composed_quat(T, q), key_pos, key_valid, tab.cpu().numpy(), n_kf, max_n)
+            assert np.array_equal(rank.cpu().numpy(), want) and np.array_equal(rank2.cpu().numpy(), want), (trial, rank, want)
