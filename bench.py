@@ -1676,6 +1676,9 @@ def dropin_sequence(n_frames: int = 600) -> dict:
             # round 6: reprojection + matching + selection + pose refinement enqueued behind the sparse alignment
             # (rpg_svo_amd/host/dropin/frame_chain.h), verified and taken by reprojectMap
             "frame_chain": {"taken": host.get("frame_chain_hits"), "not_taken": host.get("frame_chain_misses")},
+            # ... and the depth filter's update enqueued by the pose optimizer's drop-in, before the host's bookkeeping of the
+            # frame (dropin/depth_filter.cpp, EarlyUpdate): taken by the reference's updateSeeds call / dropped (keyframes)
+            "early_mapper": {"taken": host.get("early_mapper_taken"), "dropped": host.get("early_mapper_dropped")},
             # N2 evidence: per drop-in call, the host walking the reference's pointer graph into the pinned
             # arena and back (marshal/unmarshal) against the device round trip (H2D + kernels + D2H + sync)
             "host_vs_device_us_per_call": {k: {q: round(v, 2) if isinstance(v, float) else v for q, v in st.items()}
@@ -2359,7 +2362,8 @@ class FullTrack:
             capi.check(lib.svo_hip_memcpy_d2d(evs.data_ptr(), ev_ptr, S * 4, stream), "svo_hip_memcpy_d2d")
             torch.cuda.synchronize()
             seed_evals = {"aligned_seeds": float((evs > 0).sum().item()), "evaluations": float(evs.sum().item()),
-                          "evaluations_per_wave_of_64_seeds": float(evs[: (S // 64) * 64].view(-1, 64).max(dim=1).values.float().mean().item())}
+                          "evaluations_per_wave_of_64_seeds": float(evs[: (S // 64) * 64].view(-1, 64).max(dim=1).values.float().mean().item()),
+                          "evaluations_histogram": torch.bincount(evs[evs > 0].long(), minlength=12)[:12].tolist()}
         except Exception as e:
             seed_evals = {"skipped": repr(e)}
         finally:

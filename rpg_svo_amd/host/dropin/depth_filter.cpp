@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -65,6 +66,42 @@ static bool seedStoreOn() {
   static const bool on = [] { const char* v = std::getenv("SVO_HIP_SEED_STORE"); return !(v && std::string(v) == "off"); }();  // (on | verify)
   return on;
 }
+// ---- an update enqueued early (round 6) -------------------------------------------------------------------------------
+// FrameHandlerMono::processFrame calls depth_filter_->addFrame -- hence, without the mapping thread, updateSeeds -- at its very
+// end (frame_handler_mono.cpp:198), a few dozen microseconds of host work (optimizeStructure, tracking quality, scene depth,
+// the keyframe decision) after pose_optimizer::optimizeGaussNewton has fixed the pose the update depends on.  The
+// optimizer's drop-in therefore calls the mapping lane's `early_hook` as its last act: the update's kernels are enqueued
+// then and run while the host finishes the frame; updateSeeds, when the reference calls it, finds them (nearly) done.  It
+// TAKES the early update only for the same frame with the same pose and the same seed list, and only for a frame that has
+// not become a keyframe; anything else -- a frame that fails, a keyframe (addKeyframe does not update), another call on
+// the mapping lane -- DROPS it: the stream is drained, nothing is replayed into the list and the resident seed store is
+// told to forget its shadow (the kernels have advanced the seeds' state in HBM: the next call re-sends the list).
+struct EarlyUpdate {
+  bool valid;
+  int frame_id;
+  double T[12];
+  std::vector<int> ids;
+  std::function<void()> replay;  // (needs seeds_mut_)
+  SeedStore* store;
+  void* stream;
+  svo_hip::Lane* lane;           // where the hook is registered
+  EarlyUpdate() : valid(false), frame_id(-1), store(NULL), stream(NULL), lane(NULL) {}
+};
+struct EarlyRegistry {
+  std::mutex mut;
+  std::map<const DepthFilter*, EarlyUpdate> all;
+};
+static EarlyRegistry& earlyUpdates() {
+  static EarlyRegistry r;
+  return r;
+}
+static EarlyUpdate& earlyOf(const DepthFilter* df) {
+  EarlyRegistry& r = earlyUpdates();
+  std::lock_guard<std::mutex> g(r.mut);
+  return r.all[df];  // (node addresses are stable)
+}
+static thread_local bool tl_early_call = false;  // updateSeeds is being called through the hook
+
 // calls / records sent / rebuilds, summed over the stores of the process (read-outs of the tests and the benchmark)
 void seedStoreStats(uint64_t out[3]) {
   SeedStoreRegistry& r = seedStores();
@@ -78,20 +115,70 @@ void seedStoreStats(uint64_t out[3]) {
 
 // ---- the update, on the device ---------------------------------------------------------------
 void DepthFilter::updateSeeds(FramePtr frame) {
-  svo_hip::Device::joinDeferredAll();  // the previous frame's update writes into seeds_ first (takes seeds_mut_ itself)
-  {  // (nothing to do: do not touch the device)
-    lock_t peek(seeds_mut_);
-    if (seeds_updating_halt_ || seeds_.empty()) return;
-  }
   using namespace hip_dropin;
+  const bool early = tl_early_call;  // enqueue only: called by the pose optimizer's drop-in through the lane's hook
+  if (early && (thread_ != NULL || svo_hip::Device::deferredMapping() || frame->isKeyframe())) return;
+  svo_hip::Device::joinDeferredAll();  // the previous frame's update writes into seeds_ first (takes seeds_mut_ itself)
   svo_hip::Device& dev = ensureDevice(*frame);
   const int L = svo_hip::Device::LANE_MAPPING;
   svo_hip::Lane& lane = dev.lane(L);
+  EarlyUpdate& eu = earlyOf(this);
+  {  // (nothing to do: do not touch the device)
+    lock_t peek(seeds_mut_);
+    if ((seeds_updating_halt_ || seeds_.empty()) && !eu.valid) return;
+  }
   // Lock order: the lane, then the seed list -- the order the deferred closure below takes them in when a later call joins it
   // (it runs under the lane's mutex and locks seeds_mut_ itself).  The other way round here would be a lock-order inversion
   // (ThreadSanitizer names it), harmless only as long as every path joins before it locks.
   std::lock_guard<std::mutex> guard(lane.mut);
   lock_t lock(seeds_mut_);
+  if (thread_ == NULL && !svo_hip::Device::deferredMapping() && svo_hip::Device::earlyMappingEnabled()) {
+    if (!lane.early_hook || eu.lane != &lane) {  // (once per filter and lane)
+      eu.lane = &lane;
+      lane.early_hook = [this](const void* fp) {
+        struct Flag { Flag() { tl_early_call = true; } ~Flag() { tl_early_call = false; } } flag;
+        updateSeeds(*static_cast<const FramePtr*>(fp));
+      };
+    }
+  }
+  if (!early && eu.valid) {
+    // an update of this filter is running on the stream: this call's, or one to be dropped
+    const size_t S_now = seeds_.size();
+    bool same = eu.frame_id == frame->id_ && eu.ids.size() == S_now && !frame->isKeyframe() && !seeds_updating_halt_;
+    if (same) {
+      double T[12];
+      poseToRt(frame->T_f_w_, T);
+      same = std::memcmp(T, eu.T, sizeof(T)) == 0;
+    }
+    if (same) {
+      size_t s = 0;
+      for (std::list<Seed>::const_iterator it = seeds_.begin(); it != seeds_.end(); ++it, ++s)
+        if (eu.ids[s] != it->id) { same = false; break; }
+    }
+    if (same) {
+      eu.valid = false;
+      lane.early_drop = nullptr;
+      const double t0 = svo_hip::StageTimer::now();
+      try {
+        svo_hip::check(svo_hip_stream_sync(eu.stream), "svo_hip_stream_sync");
+      } catch (...) {
+        if (eu.store) eu.store->invalidate();
+        throw;
+      }
+      const double t1 = svo_hip::StageTimer::now();
+      std::function<void()> replay;
+      replay.swap(eu.replay);
+      replay();  // seeds_mut_ is held
+      dev.addStage(svo_hip::Device::STAGE_DEPTH_FILTER, 0.0, t1 - t0, svo_hip::StageTimer::now() - t1, 0.0, false);
+      dev.countEarlyMapping(true);
+      return;
+    }
+    if (lane.early_drop) {
+      std::function<void()> drop;
+      drop.swap(lane.early_drop);
+      drop();
+    }
+  }
   if (seeds_updating_halt_) return;  // the halt flag is honoured between launches
   const size_t S = seeds_.size();
   if (S == 0) return;
@@ -229,6 +316,29 @@ void DepthFilter::updateSeeds(FramePtr frame) {
       }
     }
   };
+  if (early) {
+    // enqueued ahead of the reference's call: the kernels run while the host finishes the frame (see EarlyUpdate)
+    stage_timer.unmarshal();  // this call's share is marshal + enqueue; taking it adds the wait and the replay
+    eu.valid = true;
+    eu.frame_id = frame->id_;
+    poseToRt(frame->T_f_w_, eu.T);
+    eu.ids = ids;
+    eu.replay = replay;
+    eu.store = store_guard.store;
+    eu.stream = stream;
+    store_guard.done();
+    EarlyUpdate* const peu = &eu;
+    lane.early_drop = [peu, pdev]() {
+      peu->valid = false;
+      peu->replay = nullptr;
+      pdev->countEarlyMapping(false);
+      SeedStore* const st = peu->store;
+      peu->store = NULL;
+      if (st) st->invalidate();  // (first: whatever the wait below does, the shadow claims nothing)
+      svo_hip::check(svo_hip_stream_sync(peu->stream), "svo_hip_stream_sync(early update dropped)");
+    };
+    return;
+  }
   if (thread_ == NULL && svo_hip::Device::deferredMapping()) {
     // the caller is the tracking thread itself (addFrame without the mapping thread): leave the kernels running
     stage_timer.unmarshal();  // this call's share is marshal + enqueue; the join adds its wait and the replay
@@ -260,6 +370,26 @@ void DepthFilter::updateSeeds(FramePtr frame) {
 // or the next reprojectMap -- after they are gone.  (No-op unless SVO_HIP_MAPPER=deferred left an update pending.)
 DepthFilter::~DepthFilter() {
   svo_hip::Device::joinDeferredAll();
+  {  // an early update still pending writes nothing back; the hook must not outlive the filter
+    hip_dropin::EarlyRegistry& r = hip_dropin::earlyUpdates();
+    svo_hip::Lane* lane = NULL;
+    {
+      std::lock_guard<std::mutex> g(r.mut);
+      std::map<const DepthFilter*, hip_dropin::EarlyUpdate>::iterator it = r.all.find(this);
+      if (it != r.all.end()) lane = it->second.lane;
+    }
+    if (lane != NULL) {
+      std::lock_guard<std::mutex> g(lane->mut);
+      if (lane->early_drop) {
+        std::function<void()> drop;
+        drop.swap(lane->early_drop);
+        try { drop(); } catch (...) {}
+      }
+      lane->early_hook = nullptr;
+    }
+    std::lock_guard<std::mutex> g(r.mut);
+    r.all.erase(this);
+  }
   stopThread();
   hip_dropin::releaseSeedStore(this);
   SVO_INFO_STREAM("DepthFilter destructed.");

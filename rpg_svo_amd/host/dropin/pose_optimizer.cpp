@@ -7,6 +7,7 @@
 #include <svo/pose_optimizer.h>
 
 #include <cstring>
+#include <functional>
 
 #include <svo/feature.h>
 #include <svo/frame.h>
@@ -59,8 +60,36 @@ bool predicted(const svo_hip::Speculation& sp, const FramePtr& frame, double rep
 }
 }  // namespace
 
+namespace {
+void optimizeOnDevice(const double reproj_thresh, const size_t n_iter, const bool verbose, FramePtr& frame, double& estimated_scale,
+                      double& error_init, double& error_final, size_t& num_obs);
+}
+
 void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const bool verbose, FramePtr& frame,
                          double& estimated_scale, double& error_init, double& error_final, size_t& num_obs) {
+  if (frame->fts_.empty()) return;
+  optimizeOnDevice(reproj_thresh, n_iter, verbose, frame, estimated_scale, error_init, error_final, num_obs);
+  // The frame's pose is final: a host that runs the depth filter WITHOUT its thread will hand the frame to updateSeeds after
+  // a few dozen microseconds of bookkeeping (frame_handler_mono.cpp:176-198) -- the filter's drop-in, when it has registered
+  // its hook on this thread's mapping lane, enqueues that update now (dropin/depth_filter.cpp: EarlyUpdate).  A frame the
+  // reference is about to give up (fewer than 20 observations left, :176) is not worth the launch.  (The tracking lane's
+  // mutex has been released: the hook takes the mapping lane's and the seed list's.)
+  if (svo_hip::Device::earlyMappingEnabled() && num_obs >= 20) {
+    svo_hip::Lane* ml = hip_dropin::ensureDevice(*frame).findLane(svo_hip::Device::LANE_MAPPING);
+    if (ml != NULL) {
+      std::function<void(const void*)> hook;
+      {
+        std::lock_guard<std::mutex> g(ml->mut);
+        hook = ml->early_hook;
+      }
+      if (hook) hook(&frame);
+    }
+  }
+}
+
+namespace {
+void optimizeOnDevice(const double reproj_thresh, const size_t n_iter, const bool verbose, FramePtr& frame, double& estimated_scale,
+                      double& error_init, double& error_final, size_t& num_obs) {
   using namespace hip_dropin;
   const size_t n = frame->fts_.size();
   if (n == 0) return;
@@ -143,6 +172,7 @@ void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const 
   if (!*ran) return;  // no observation carried a point: the reference returns untouched (:57-58)
   applyResult(frame, Tout, Cov, stats, has_out, verbose, estimated_scale, error_init, error_final, num_obs);
 }
+}  // namespace
 
 }  // namespace pose_optimizer
 }  // namespace svo

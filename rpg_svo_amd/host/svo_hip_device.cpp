@@ -139,6 +139,8 @@ void destroyLane(Lane* l) {  // everything makeLane() / workspace() may have giv
   if (l->stream_next) { svo_hip_stream_sync(l->stream_next); svo_hip_stream_destroy(l->stream_next); l->stream_next = NULL; }
   if (l->ev_results) { svo_hip_event_destroy(l->ev_results); l->ev_results = NULL; }
   l->deferred = nullptr;  // its owner is about to lose the device; nothing is written back
+  l->early_drop = nullptr;
+  l->early_hook = nullptr;
   l->arena.release();
   l->arena_chain.release();
   if (l->d_workspace) { svo_hip_free(l->d_workspace); l->d_workspace = NULL; l->workspace_bytes = 0; }
@@ -250,13 +252,14 @@ void Device::setDeferredMapping(bool on) { g_deferred_mapping.store(on ? 1 : 0);
 
 void Device::finish(Lane& lane) { check(svo_hip_stream_sync(lane.stream), "svo_hip_stream_sync"); }
 
+Lane* Device::findLane(int which) {
+  std::lock_guard<std::mutex> g(lanes_mut_);
+  std::map<std::pair<std::thread::id, int>, Lane*>::iterator it = lanes_.find(std::make_pair(std::this_thread::get_id(), which));
+  return it != lanes_.end() ? it->second : NULL;
+}
+
 void Device::joinDeferred(int which_lane) {
-  Lane* l = NULL;
-  {
-    std::lock_guard<std::mutex> g(lanes_mut_);
-    std::map<std::pair<std::thread::id, int>, Lane*>::iterator it = lanes_.find(std::make_pair(std::this_thread::get_id(), which_lane));
-    if (it != lanes_.end()) l = it->second;
-  }
+  Lane* l = findLane(which_lane);
   if (!l) return;
   std::lock_guard<std::mutex> g(l->mut);
   runDeferred(*l);
@@ -274,6 +277,11 @@ void Device::joinDeferredAll() {
 
 void Device::beginCall(Lane& lane) {
   runDeferred(lane);  // the caller holds lane.mut
+  if (lane.early_drop) {  // an early update of the depth filter nobody has claimed: its blocks are about to be overwritten
+    std::function<void()> drop;
+    drop.swap(lane.early_drop);
+    drop();
+  }
   // work a previous call left running reads and writes the arena this call is about to refill
   if (lane.spec.in_flight) {
     lane.spec.in_flight = false;
@@ -312,6 +320,19 @@ void Device::countChain(bool hit, int why) {
     ++stats.chain_misses;
     ++stats.chain_miss_why[why >= 0 && why < 6 ? why : 5];
   }
+}
+
+void Device::countEarlyMapping(bool hit) {
+  std::lock_guard<std::mutex> g(stats_mut_);
+  if (hit) ++stats.early_map_hits; else ++stats.early_map_misses;
+}
+
+bool Device::earlyMappingEnabled() {
+  static const bool on = [] {
+    const char* v = std::getenv("SVO_HIP_EARLY_MAPPER");
+    return !(v && v[0] == '0');
+  }();
+  return on;
 }
 
 bool Device::chainEnabled() {

@@ -115,6 +115,12 @@ class Pipeline:
         self.lib.pipe_chain_stats(out)
         return tuple(int(x) for x in out)
 
+    def early_mapper_stats(self):
+        """(depth-filter updates enqueued by the pose optimizer's drop-in that updateSeeds took, ... that were dropped)."""
+        out = (C.c_uint64 * 2)()
+        self.lib.pipe_early_mapper_stats(out)
+        return tuple(int(x) for x in out)
+
     def mirror_stats(self):
         """(calls, rebuilds, fallbacks, point records sent, observation records sent, second batches) of the
         reprojector's map mirror, process-wide."""
@@ -180,6 +186,7 @@ def run_sequence(flavour, cam, images, T_gt, stats_out=None, range0=None, **cfg)
         m0 = p.mirror_stats()
         q0 = p.seed_store_stats()
         c0 = p.chain_stats()
+        e0 = p.early_mapper_stats()
         n0, r0 = p.set_first_frame(images[0], 0.0, T_gt[0], range_map(cam, T_gt[0]) if range0 is None else range0)
         r0["n_first_features"] = n0
         out = [r0]
@@ -200,6 +207,8 @@ def run_sequence(flavour, cam, images, T_gt, stats_out=None, range0=None, **cfg)
             stats_out.update(frame_chain_hits=c1[0] - c0[0], frame_chain_misses=c1[1] - c0[1],
                              frame_chain_miss_reasons=dict(zip(("not_this_frame", "pose_bits", "keyframe_ranking", "map_moved_on", "capacity"),
                                                                (b - a for a, b in zip(c0[2:7], c1[2:7])))))
+            e1 = p.early_mapper_stats()
+            stats_out.update(early_mapper_taken=e1[0] - e0[0], early_mapper_dropped=e1[1] - e0[1])
             m1 = p.mirror_stats()
             stats_out["map_mirror"] = dict(zip(("calls", "rebuilds", "fallbacks", "point_records_sent", "obs_records_sent",
                                                 "second_batches"), (b - a for a, b in zip(m0, m1))))

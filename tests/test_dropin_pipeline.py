@@ -343,6 +343,7 @@ MIRROR_CODE = (
     "np.save(sys.argv[1], np.stack([x['T_f_w'] for x in r]))\n"
     "print(json.dumps(dict(st['map_mirror'], hits=st['predicted_pose_hits'], kfs=int(sum(x['is_keyframe'] for x in r)),\n"
     "                      chain_hits=st['frame_chain_hits'], chain_misses=st['frame_chain_misses'],\n"
+    "                      early_taken=st['early_mapper_taken'], early_dropped=st['early_mapper_dropped'],\n"
     "                      seed_store=st.get('seed_store'), seeds=[x['n_seeds'] for x in r],\n"
     "                      counts=[[x['repr_n_mps'], x['repr_n_new_references'], x['n_kf_points_in_frame'], x['n_candidates']] for x in r])))\n")
 
@@ -688,7 +689,16 @@ def _seed_store_on_and_off(flavour, n, tmp_path):
     created = sum(max(0, b - a) for a, b in zip(s_on["seeds"], s_on["seeds"][1:])) + s_on["seeds"][0]
     assert st["seed_records_sent"] <= 2 * created + 1024 and st["seed_records_sent"] * 8 < sum(s_on["seeds"]), (st, created)
     dfr, s_dfr = _run_mirror(flavour, n, {}, tmp_path, "store_deferred", max_n_kfs=4, defer_mapper=1)
-    assert np.array_equal(dfr, on) and s_dfr["seed_store"]["calls"] == st["calls"]
+    # (the synchronous mapper's update is enqueued by the pose optimizer's drop-in -- EarlyUpdate in dropin/depth_filter.cpp --
+    # and dropped when the frame becomes a keyframe: those launches are calls the deferred mapper, which enqueues when the
+    # reference calls, does not make)
+    assert np.array_equal(dfr, on) and s_dfr["seed_store"]["calls"] == st["calls"] - s_on["early_dropped"]
+    assert s_dfr["early_taken"] == 0 and s_dfr["early_dropped"] == 0 and s_on["early_taken"] > n // 2
+    # ... and SVO_HIP_EARLY_MAPPER=0 (the update enqueued when the reference calls it, as up to round 5): the same frames
+    late, s_late = _run_mirror(flavour, n, {"SVO_HIP_EARLY_MAPPER": "0"}, tmp_path, "store_late", max_n_kfs=4)
+    assert np.array_equal(late, on) and s_late["seeds"] == s_on["seeds"] and s_late["early_taken"] == 0
+    assert s_late["seed_store"]["calls"] == s_dfr["seed_store"]["calls"]
+    print(f"early mapper [{flavour}]: taken {s_on['early_taken']}, dropped {s_on['early_dropped']} of {n - 1} frames")
     # SVO_HIP_SEED_STORE=verify (the host's state of every resident seed compared with what the device last reported, Seed::id
     # checked for monotonicity): nothing edits the seeds behind the store's back here, so nothing is re-sent
     ver, s_ver = _run_mirror(flavour, n, {"SVO_HIP_SEED_STORE": "verify"}, tmp_path, "store_verify", max_n_kfs=4)
