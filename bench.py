@@ -209,6 +209,12 @@ def compact_line(result: dict, details_path: str | None) -> dict:
                             ("ms_hip_deferred_mapper", "median_ms_per_frame_hip_dropin_deferred_mapper")):
             if isinstance(ds.get(k_in), dict):
                 legs["dropin_sequence"][k_out] = ds[k_in].get("tot_time")
+        op = ds.get("median_ms_per_frame_in_a_process_of_its_own")
+        if isinstance(op, dict) and "hip_dropin" in op:
+            legs["dropin_sequence"]["ms_hip_own_process"] = op["hip_dropin"]
+            legs["dropin_sequence"]["ms_hip_deferred_mapper_own_process"] = op["hip_dropin_deferred_mapper"]
+        if isinstance(ds.get("early_mapper"), dict):
+            legs["dropin_sequence"]["early_mapper"] = ds["early_mapper"]
         if isinstance(ds.get("map_size"), dict):
             legs["dropin_sequence"]["map_size"] = _pick(ds["map_size"], ("n_kfs", "n_candidates", "kf_points_in_frame", "trials", "matches"))
     rc = result.get("reference_cameras")
@@ -1649,7 +1655,30 @@ def dropin_sequence(n_frames: int = 600) -> dict:
             no_chain = {"skipped": p.stderr[-300:]}
     except Exception as e:
         no_chain = {"skipped": repr(e)}
+    # The drop-in in a process of its own, as a host runs it (this process has been through every other leg by now -- a
+    # dozen streams, the reference's own run, counters -- and measures the same frames 5-12 % slower): synchronous and deferred
+    # mapper alternating, two processes each; same frames, same trajectory.
+    own = {"hip_dropin": [], "hip_dropin_deferred_mapper": []}
+    own_same = True
+    try:
+        for rep in range(2):
+            for key, dm in (("hip_dropin", 0), ("hip_dropin_deferred_mapper", 1)):
+                dump = tempfile.mktemp(suffix=".npy", dir="/tmp")
+                code = (f"import sys, json; sys.path.insert(0, {ROOT!r}); import bench; "
+                        f"print(json.dumps(bench.dropin_hip_only({n_frames}, {dump!r}, defer_mapper={dm})))")
+                p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=300)
+                if p.returncode != 0:
+                    raise RuntimeError(p.stderr[-300:])
+                r = json.loads(p.stdout.strip().splitlines()[-1])
+                own[key].append(r["tot_time"])
+                own_same = own_same and bool(np.array_equal(np.load(dump), Th))
+                os.unlink(dump)
+        own_process = {"hip_dropin": float(np.median(own["hip_dropin"])), "hip_dropin_deferred_mapper": float(np.median(own["hip_dropin_deferred_mapper"])),
+                       "runs": own, "trajectory_identical_to_this_process": own_same}
+    except Exception as e:
+        own_process = {"skipped": repr(e)}
     return {"frames": n_frames, "map_size": map_size, "host_pyramid_levels_built_of": host.get("host_pyramid"),
+            "median_ms_per_frame_in_a_process_of_its_own": own_process,
             "median_ms_per_frame_hip_dropin_with_the_host_pyramid_built": with_pyr,
             "median_ms_per_frame_hip_dropin_without_the_frame_chain": no_chain,
             "map_mirror": host.get("map_mirror"), "seed_store": host.get("seed_store"),
@@ -1805,7 +1834,7 @@ def reference_cameras_traffic(args, out: dict, B: int = 4096) -> None:
             sa["roofline"]["pmc_passes"] = repr(e)
 
 
-def dropin_hip_only(n_frames: int, dump: str, camera: str | None = None) -> dict:
+def dropin_hip_only(n_frames: int, dump: str, camera: str | None = None, defer_mapper: int = 0) -> dict:
     """child of dropin_sequence (one process per SVO_HIP_MAP_MIRROR mode: the mode is read once): the hip flavour alone"""
     sys.path.insert(0, os.path.join(ROOT, "tests", "dropin"))
     import pypipeline as pp
@@ -1816,7 +1845,7 @@ def dropin_hip_only(n_frames: int, dump: str, camera: str | None = None) -> dict
     os.dup2(devnull, 2)
     pp.run_sequence("hip", cam, imgs[:10], T[:10])
     st = {}
-    hip = pp.run_sequence("hip", cam, imgs, T, stats_out=st)
+    hip = pp.run_sequence("hip", cam, imgs, T, stats_out=st, defer_mapper=defer_mapper)
     if dump:
         np.save(dump, np.stack([r["T_f_w"] for r in hip]))
     med = lambda k: float(np.median([r[k] for r in hip[1:]]) * 1e3)
@@ -1827,7 +1856,8 @@ def dropin_hip_only(n_frames: int, dump: str, camera: str | None = None) -> dict
                 "ate_rmse_vs_ground_truth_m": horn_ate(pos(np.stack([r["T_f_w"] for r in hip])), pos(T)),
                 "keyframes": int(sum(r["is_keyframe"] for r in hip)), "matches": float(np.median([r["repr_n_new_references"] for r in hip[1:]])),
                 "stage_default_frame_frac": float(np.mean([r["stage"] == pp.STAGE_DEFAULT_FRAME for r in hip[1:]]))}
-    return {"tot_time": med("t_tot_time"), "reproject": med("t_reproject"), "map_mirror": st.get("map_mirror")}
+    return {"tot_time": med("t_tot_time"), "reproject": med("t_reproject"), "map_mirror": st.get("map_mirror"),
+            "wall_ms_per_frame": st.get("wall_ms_per_frame")}
 
 
 _CPU_REF: dict = {}  # poses and iteration counts of the CPU reference run (cpu_baseline), for the f64_partials leg
@@ -2472,11 +2502,25 @@ def full_track_leg(W: Workload, sia, ev: Events, dev, rank, lib, with_parity: bo
 
     step(False)
     torch.cuda.synchronize()
+    # (a library built with -DSCAN_PROFILE -- scripts/scan_phase_profile.sh -- keeps per-region clock totals of the scan kernel)
+    scan_prof = getattr(lib, "svo_hip_scan_profile_read", None) if hasattr(lib, "svo_hip_scan_profile_read") else None
+    if scan_prof is not None:
+        import ctypes
+        buf = (ctypes.c_ulonglong * 8)()
+        scan_prof(buf)  # clear what the warm-up step left
     t0 = time.perf_counter()
     for _ in range(steps):
         step(True)
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / steps * 1e3
+    scan_profile = None
+    if scan_prof is not None:
+        scan_prof(buf)
+        names = ("parameters_and_affine_warp", "template_and_setup", "positions_of_a_pass", "box_fetch", "scoring_from_the_box",
+                 "fallback_scores_advance", "reduction_and_results")
+        tot = float(sum(buf[k] for k in range(7))) or 1.0
+        scan_profile = {"wave_clock_share": {n: buf[k] / tot for k, n in enumerate(names)}, "wave_iterations_per_step": buf[7] / steps,
+                        "clocks_per_wave_iteration": tot / max(1, buf[7])}
     stages = full.stage_ms(ev)
     stages["sparse_align"] = float(np.mean([ev.ms(a, b) for a, b, _ in marks]))
     step_ms = float(np.mean([ev.ms(a, c) for a, _, c in marks]))
@@ -2487,6 +2531,8 @@ def full_track_leg(W: Workload, sia, ev: Events, dev, rank, lib, with_parity: bo
            "ms_per_step_host_wall": wall, "stages_ms": stages,
            "median_pose_error_vs_gt_after_refine": float(np.median(se3.log_norm(T_ref_est, W.T_gt[1:W.B + 1])))}
     res.update(d)
+    if scan_profile is not None:
+        res["scan_profile"] = scan_profile
     st = W.align_stats(out)
     rl = full.stage_rooflines(lib, stages)
     rl["sparse_align"] = roofline("sia_kernel", st["alg_bytes"], stages["sparse_align"])

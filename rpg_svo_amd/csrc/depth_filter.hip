@@ -207,6 +207,9 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
 // scratch, 35.4 KB of LDS per workgroup); the distorted cameras' one carries the models' f64 code in the loop and spills
 // outside it.  (What registers cost here: nine spilled dwords per seed took 10 % of the kernel, profiles/r05e_*.)
 constexpr int SCAN_MINW = 4;
+#ifdef SCAN_PROFILE
+__device__ unsigned long long g_scan_prof[8];
+#endif
 template <bool PINHOLE>
 __global__ void __launch_bounds__(SCAN_BLOCK, PINHOLE ? SCAN_MINW : SCAN_MINW - 1) epi_scan_kernel(const SeedArgs a) {
   __shared__ uint16_t s_order[SCAN_CHUNK];
@@ -255,14 +258,38 @@ __global__ void __launch_bounds__(SCAN_BLOCK, PINHOLE ? SCAN_MINW : SCAN_MINW - 
   const int n_scan = s_n;
   const int wl = threadIdx.x & 63;
   const int grp = wl / SCAN_G, lane = wl % SCAN_G;
+#ifdef SCAN_PROFILE
+  __shared__ uint32_t s_prof[SCAN_BLOCK / 64][8];
+  uint32_t* const prof = s_prof[threadIdx.x >> 6];
+  if (wl < 8) prof[wl] = 0;
+#endif
   for (;;) {
     int p = 0;
     if (wl == 0) p = atomicAdd(&s_next, GROUPS);
     p = __builtin_amdgcn_readfirstlane(p);
     if (p >= n_scan) break;
+#ifdef SCAN_PROFILE
+    if (wl == 0) prof[7] += 1;
+    if (p + grp < n_scan) epi_scan_seed<PINHOLE>(a, base + (int)s_order[p + grp], lane, s_box[threadIdx.x / SCAN_G], prof);
+#else
     if (p + grp < n_scan) epi_scan_seed<PINHOLE>(a, base + (int)s_order[p + grp], lane, s_box[threadIdx.x / SCAN_G]);
+#endif
   }
+#ifdef SCAN_PROFILE
+  if (wl < 8) atomicAdd(&g_scan_prof[wl], (unsigned long long)prof[wl]);
+#endif
 }
+
+#ifdef SCAN_PROFILE
+// (instrumentation build only: reads and clears the region totals)
+extern "C" int svo_hip_scan_profile_read(unsigned long long out[8]) {
+  if (hipDeviceSynchronize() != hipSuccess) return SVO_HIP_EHIP;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return SVO_HIP_EHIP;
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_scan_prof), zero, sizeof(zero)) != hipSuccess) return SVO_HIP_EHIP;
+  return SVO_HIP_OK;
+}
+#endif
 
 #define SEED_FINISH_BOUNDS __launch_bounds__(64, 5)  // the early loads cost six registers: held to five waves per SIMD as before
 __global__ void SEED_FINISH_BOUNDS seed_finish_kernel(const SeedArgs a) {

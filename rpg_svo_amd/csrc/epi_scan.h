@@ -114,11 +114,31 @@ __device__ __forceinline__ void scan_world2cam(const Cam& c, const double uv[2],
   }
 }
 
+// SCAN_PROFILE (instrumentation build only, scripts/scan_phase_profile.py): shader-clock totals of every wave per region of
+// epi_scan_seed -- 0 parameters + affine warp, 1 template + set-up, 2 a pass's positions (camera model, pixels, boxes),
+// 3 box fetch, 4 scoring from the box, 5 per-lane fallback + scores + advancing the chain, 6 reduction + results,
+// 7 wave iterations -- summed into g_scan_prof by the kernel.
+#ifdef SCAN_PROFILE
+#define SCAN_T() ((long long)__builtin_readcyclecounter())
+// (one of the lanes that are active at the point adds the wave's delta to the wave's totals in LDS)
+#define SCAN_ACC(k, t0, t1)                                                                                   \
+  do {                                                                                                        \
+    const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true);                                          \
+    if ((int)(threadIdx.x & 63) == __builtin_ctzll(m_)) atomicAdd(prof + (k), (uint32_t)((t1) - (t0)));       \
+  } while (0)
+#define SCAN_PROF_PARAM , uint32_t* prof
+#else
+#define SCAN_T() 0ll
+#define SCAN_ACC(k, t0, t1)
+#define SCAN_PROF_PARAM
+#endif
+
 // ZMSSD scan of one seed, matcher.cpp:248-291, by the SCAN_G lanes of a group (lane = position in the group).
 // box: the group's SCAN_BOX_DWORDS dwords of LDS (16-byte aligned).
 template <bool PINHOLE>
-__device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, const int lane, uint32_t* box) {
+__device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, const int lane, uint32_t* box SCAN_PROF_PARAM) {
   const SeedWs& w = a.ws;
+  [[maybe_unused]] long long tp0 = SCAN_T(), tp1;
   // everything the warp and the scan set-up read, requested together (seed_prepare_kernel wrote it)
   const int sl = w.search_level[s];
   const int mode = w.mode[s];
@@ -133,6 +153,7 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
     warp_patch_group8(ref_img, a.L.w[ref_level], a.L.h[ref_level], a.L.pitch[ref_level], A.x, A.y, A.z, A.w, pyr.x, pyr.y, sl, lane,
                       box, patch);
   }
+  tp1 = SCAN_T(); SCAN_ACC(0, tp0, tp1); tp0 = tp1;
   if (mode != MODE_SCAN) {
     // a segment shorter than two pixels (matcher.cpp:226-238): straight to the sub-pixel alignment, which reads the patch
     warp_patch_store_group8(patch, lane, w.pwb + (size_t)s * 100);
@@ -188,6 +209,7 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
     uv0 += step0; uv1 += step1;
   }
   int carry0 = 0, carry1 = 0;  // pixel of the last step of the pass before (last_x, last_y before the first step: 0, 0)
+  tp1 = SCAN_T(); SCAN_ACC(1, tp0, tp1); tp0 = tp1;
   for (int base = 0; base < n_total; base += PP * SCAN_G) {
     const int ia = base + PP * lane, ib = ia + 1;
     const double ub0 = uv0 + step0, ub1 = uv1 + step1;  // the lane's second step
@@ -230,6 +252,7 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
     // one box for the whole group if it fits (uniform over the group); else a box per half group, one after the other
     const bool whole = gy_hi - gy_lo < SCAN_BOX_ROWS && gx_hi - (gx_lo & ~15) < 48 &&
                        (gy_hi - gy_lo + 1) * (((gx_hi - (gx_lo & ~15)) >> 4) + 1) <= 48;
+    tp1 = SCAN_T(); SCAN_ACC(2, tp0, tp1); tp0 = tp1;
     if (gx_hi < 0) {
       // nobody wants anything in this pass (uniform over the group)
     } else {
@@ -271,6 +294,7 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
           if (lane + 8 * k < n_chunks) *reinterpret_cast<uint4*>(box + dst[k]) = v[k];
         // hand-over inside the wave
         SVO_LANES_LDS_HANDOVER();
+        tp1 = SCAN_T(); SCAN_ACC(3, tp0, tp1); tp0 = tp1;
         // (each position in a branch of its own: a wave in which no lane has a second position jumps over that block)
         const uint2* t2 = reinterpret_cast<const uint2*>(tpl);
         if (mine && (want_a || want_b)) scored = true;
@@ -294,6 +318,7 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
             scan_row(rb + SCAN_BOX_ROW_DWORDS * y, selb, t.x, t.y, sb);
           }
         }
+        tp1 = SCAN_T(); SCAN_ACC(4, tp0, tp1); tp0 = tp1;
       }
       if (!scored && (want_a || want_b)) {
         // 8 rows x 8 bytes [px-4, px+3]: 12-byte runs, inside one tile row of the store where the 8 bytes are
@@ -342,6 +367,7 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
         uv0 += step0; uv1 += step1;
       }
     }
+    tp1 = SCAN_T(); SCAN_ACC(5, tp0, tp1); tp0 = tp1;
   }
   // first strictly smaller score along the line == lexicographic minimum of (score, step)
   unsigned long long key = ((unsigned long long)(unsigned)best << 32) | (unsigned)best_i;
@@ -374,6 +400,7 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
   // (every lane holds the group's minimum) a match that goes on to align1D / align2D: its patch_with_border to HBM
   if (win_score < ZMSSD_THRESHOLD && a.opt.subpix_refinement) warp_patch_store_group8(patch, lane, w.pwb + (size_t)s * 100);
   if (lane == 0 && !(win_score < ZMSSD_THRESHOLD)) w.status[s] = SVO_HIP_SEED_NO_MATCH;
+  tp1 = SCAN_T(); SCAN_ACC(6, tp0, tp1);
 }
 
 }  // namespace

@@ -17,7 +17,7 @@ def table(d: dict, src: str) -> str:
     L = []
     r = d["roofline"]
     B = d["config"]["frames_per_step_per_gpu"]
-    L.append(f"Source: `{src}` (default `bench.py` run: 50 timed launches of {B} frames after 5 warm-ups).")
+    L.append(f"Source: `{src}` (`bench.py --steps {d.get('steps')} --warmup {d.get('warmup')}`: {d.get('steps')} timed steps of {B} frames).")
     L.append("")
     L.append("| kernel (per launch / step of 16 384 frames) | ms | algorithmic bytes per unit | GB/s | frac of 8 TB/s | counter traffic / algorithmic | VALU busy | wave cycles waiting |")
     L.append("|---|---|---|---|---|---|---|---|")
@@ -75,7 +75,12 @@ def table(d: dict, src: str) -> str:
     if "median_ms_per_frame_hip_dropin" in ds:
         L.append(f"Single stream (drop-in, 752x480, 600 frames, map of the reference trace's size): **{ds['median_ms_per_frame_hip_dropin']['tot_time']:.3f} ms** per frame "
                  f"({ds['median_ms_per_frame_hip_dropin_deferred_mapper']['tot_time']:.3f} with the deferred mapper) against {ds['median_ms_per_frame_cpu_reference']['tot_time']:.3f} ms for the "
-                 f"all-CPU reference on the same host.")
+                 f"all-CPU reference on the same host"
+                 + (f"; in a process of its own: {ds['median_ms_per_frame_in_a_process_of_its_own']['hip_dropin']:.3f} / "
+                    f"{ds['median_ms_per_frame_in_a_process_of_its_own']['hip_dropin_deferred_mapper']:.3f} ms"
+                    if isinstance(ds.get("median_ms_per_frame_in_a_process_of_its_own"), dict) and "hip_dropin" in ds["median_ms_per_frame_in_a_process_of_its_own"] else "")
+                 + (f"; with `DepthFilter`'s own thread (the reference's default): {ds['median_ms_per_frame_mapper_thread']['hip_dropin']:.3f} against "
+                    f"{ds['median_ms_per_frame_mapper_thread']['cpu_reference']:.3f} ms" if isinstance(ds.get("median_ms_per_frame_mapper_thread"), dict) else "") + ".")
     rc = d.get("reference_cameras") or {}
     if isinstance(rc.get("cameras"), dict):
         L.append("")
