@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   world2cam_uv(a.cam, A, px_A);
   world2cam_uv(a.cam, B, px_B);
   const double dAB[2] = {px_A[0] - px_B[0], px_A[1] - px_B[1]};
-  const double epi_length = norm2(dAB) / (double)(1 << sl);
+  const double epi_length = norm2(dAB) * pow2_inv_f64(sl);  // (/ 2^sl, same bits)
   // warp set-up (matcher.cpp:221-224)
   double Ainv[4];
   inv2<double>(Am, Ainv);
@@ -161,8 +161,8 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
   w.A_ref_cur[4 * s + 1] = (float)Ainv[1];
   w.A_ref_cur[4 * s + 2] = (float)Ainv[2];
   w.A_ref_cur[4 * s + 3] = (float)Ainv[3];
-  w.px_ref_pyr[2 * s] = (float)rpx[0] / (float)(1 << rlevel);
-  w.px_ref_pyr[2 * s + 1] = (float)rpx[1] / (float)(1 << rlevel);
+  w.px_ref_pyr[2 * s] = (float)rpx[0] * pow2_inv_f32(rlevel);  // (/ 2^level, same bits)
+  w.px_ref_pyr[2 * s + 1] = (float)rpx[1] * pow2_inv_f32(rlevel);
   w.ref_slot[s] = ref_slot_early;
   w.ref_level[s] = rlevel;
   {  // (px_A-px_B).cast<float>().normalized()
@@ -175,8 +175,8 @@ __global__ void __launch_bounds__(64) seed_prepare_kernel(const SeedArgs a) {
     const double pc[2] = {(px_A[0] + px_B[0]) / 2.0, (px_A[1] + px_B[1]) / 2.0};
     w.px_cur[2 * s] = pc[0];
     w.px_cur[2 * s + 1] = pc[1];
-    w.px_scaled[2 * s] = pc[0] / (double)(1 << sl);
-    w.px_scaled[2 * s + 1] = pc[1] / (double)(1 << sl);
+    w.px_scaled[2 * s] = pc[0] * pow2_inv_f64(sl);
+    w.px_scaled[2 * s + 1] = pc[1] * pow2_inv_f64(sl);
     w.mode[s] = MODE_SHORT;
     w.align_active[s] = 1;
     return;

@@ -22,6 +22,11 @@ using std::sqrt;
 #include <hip/hip_runtime.h>
 #endif
 
+// 2^-k (0 <= k < 64) from its exponent bits.  x * pow2_inv(k) == x / 2^k bit for bit (scaling by a power of two is exact
+// away from the subnormals), without the division sequence -- 11 f64 instructions -- a run-time k otherwise costs.
+__device__ __forceinline__ double pow2_inv_f64(const int k) { return __builtin_bit_cast(double, (unsigned long long)(1023 - k) << 52); }
+__device__ __forceinline__ float pow2_inv_f32(const int k) { return __builtin_bit_cast(float, (unsigned)(127 - k) << 23); }
+
 // Hand-over of LDS data between lanes of ONE wave: the DS operations of a wave execute in order, so all it takes is to
 // keep the compiler from moving the reads above the writes.  Two names for the same two builtins, by who takes part:
 // SVO_WAVE_LDS_HANDOVER: every live lane of the wave reaches this line; SVO_LANES_LDS_HANDOVER: the lanes that took this

@@ -189,7 +189,7 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
   double best_uv0 = 0, best_uv1 = 0;
   const double lvl = (double)(1 << sl);
   // Dividing by 2^level is exact, so multiplying by 2^-level gives the same bits without f64 division sequences.
-  const double inv_lvl = 1.0 / lvl;
+  const double inv_lvl = pow2_inv_f64(sl);
   // The reference walks the line sequentially (matcher.cpp:268: uv += step, in f64) and skips a step whose
   // integer pixel equals the previous step's.  Lane l of the seed's group takes the steps 2l, 2l+1, 2l+16, 2l+17, ...: it
   // replays only the CHAIN of additions up to its steps (two v_add_f64 per step, so the positions carry the reference's
@@ -371,10 +371,20 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
   }
   // first strictly smaller score along the line == lexicographic minimum of (score, step)
   unsigned long long key = ((unsigned long long)(unsigned)best << 32) | (unsigned)best_i;
+  {  // minimum over the seed's eight lanes: two butterflies inside the quads, then the mirror lane (DPP moves, no LDS)
+    auto other = [&](const int which) {
+      const int lo = (int)(unsigned)key, hi = (int)(unsigned)(key >> 32);
+      int olo, ohi;
+      if (which == 0) { olo = dpp_i32<svo_dev::DPP_QUAD_XOR1>(lo); ohi = dpp_i32<svo_dev::DPP_QUAD_XOR1>(hi); }
+      else if (which == 1) { olo = dpp_i32<svo_dev::DPP_QUAD_XOR2>(lo); ohi = dpp_i32<svo_dev::DPP_QUAD_XOR2>(hi); }
+      else { olo = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(lo); ohi = dpp_i32<svo_dev::DPP_ROW_HALF_MIRROR>(hi); }
+      return ((unsigned long long)(unsigned)ohi << 32) | (unsigned)olo;
+    };
 #pragma unroll
-  for (int off = SCAN_G / 2; off > 0; off >>= 1) {  // within the seed's lane group
-    const unsigned long long o = __shfl_xor(key, off, 64);
-    key = o < key ? o : key;
+    for (int k = 0; k < 3; ++k) {
+      const unsigned long long o = other(k);
+      key = o < key ? o : key;
+    }
   }
   const int win_score = (int)(key >> 32);
   const int win_i = (int)(key & 0xffffffffu);
@@ -390,8 +400,8 @@ __device__ __forceinline__ void epi_scan_seed(const SeedArgs& a, const int s, co
     const double pc0 = pcs[0], pc1 = pcs[1];
     w.px_cur[2 * s] = pc0;
     w.px_cur[2 * s + 1] = pc1;
-    w.px_scaled[2 * s] = pc0 / lvl;
-    w.px_scaled[2 * s + 1] = pc1 / lvl;
+    w.px_scaled[2 * s] = pc0 * inv_lvl;  // == pc0 / lvl, bit for bit (a power of two)
+    w.px_scaled[2 * s + 1] = pc1 * inv_lvl;
     // matcher.cpp:293-318: refine with align1D/2D, or triangulate straight from uv_best.  The
     // second case is flagged in its own array: the alignment kernel clears ok[] of inactive trials.
     w.align_active[s] = a.opt.subpix_refinement ? 1 : 0;

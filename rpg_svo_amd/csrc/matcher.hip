@@ -148,12 +148,12 @@ __global__ void __launch_bounds__(64) match_prepare_kernel(const PrepArgs a) {
   a.A_ref_cur[4 * m + 1] = (float)Ainv[1];
   a.A_ref_cur[4 * m + 2] = (float)Ainv[2];
   a.A_ref_cur[4 * m + 3] = (float)Ainv[3];
-  a.px_ref_pyr[2 * m] = (float)rpx[0] / (float)(1 << rlevel);
-  a.px_ref_pyr[2 * m + 1] = (float)rpx[1] / (float)(1 << rlevel);
+  a.px_ref_pyr[2 * m] = (float)rpx[0] * pow2_inv_f32(rlevel);  // (/ 2^level, same bits)
+  a.px_ref_pyr[2 * m + 1] = (float)rpx[1] * pow2_inv_f32(rlevel);
   a.ref_slot[m] = a.frame_slot[rfi];
   a.ref_level[m] = rlevel;
-  a.px_scaled[2 * m] = a.px_cur[2 * m] / (double)(1 << sl);
-  a.px_scaled[2 * m + 1] = a.px_cur[2 * m + 1] / (double)(1 << sl);
+  a.px_scaled[2 * m] = a.px_cur[2 * m] * pow2_inv_f64(sl);
+  a.px_scaled[2 * m + 1] = a.px_cur[2 * m + 1] * pow2_inv_f64(sl);
   const bool edgelet = a.obs.d_type && a.obs.d_type[best] == SVO_HIP_FTR_EDGELET;
   if (edgelet) {
     const double gx = a.obs.d_grad[2 * best], gy = a.obs.d_grad[2 * best + 1];
