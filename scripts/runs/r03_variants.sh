@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: scripts/r03_variants.sh <outdir under gpurun_out> <extras> <lib or "main"> ...   -- headline + extras per library variant
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/$1; mkdir -p "$O"; EX=$2; shift 2
 cd $R
 for v in "$@"; do

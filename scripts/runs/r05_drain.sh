@@ -6,7 +6,7 @@
 #   bash scripts/round5_queue.sh build     (CPU side)
 #   gpurun --timeout 1200 -- 'bash scripts/r05_drain.sh'
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"
 V=$PWD/build/variants
 O=gpurun_out/r05a

@@ -2,7 +2,7 @@
 # Round 5, the round's evidence in one call: the whole GPU suite, the default bench run (line + details), rocprofv3
 # --kernel-trace --stats of the headline and of the full-track step, the single-stream drop-in untraced.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=$R/gpurun_out/r05z; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 stats() {
   python - "$1" "$2" <<'PY'

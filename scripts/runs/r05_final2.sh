@@ -2,7 +2,7 @@
 # Round 5, the bench lines of the final tree: the driver's own command, then the default run (its f64_partials leg needs
 # the -DSIA_F64_PARTIALS library __graft_entry__.build() makes: the first final call ran with a stale one).
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=$R/gpurun_out/r05y; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 {
 echo "== the driver's command"

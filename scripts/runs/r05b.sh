@@ -5,7 +5,7 @@
 #   3. the default bench run (line + details; its f64_partials leg carries the reference-width build's own roofline)
 #   4. rocprofv3 --kernel-trace --stats of the headline: default build and -DSIA_F64_PARTIALS build
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=$R/gpurun_out/r05b; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 stats() {
   python - "$1" "$2" <<'PY'

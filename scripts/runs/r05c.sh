@@ -3,7 +3,7 @@
 # libsvo_hip_oldscan.so = the same tree at 88286ce), on one box: parity suites, per-kernel rocprofv3 tables of the
 # full-track step alternating, the untraced step, and the scan's LDS / wait / traffic counters for both.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r05c; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 V=$PWD/build/variants
 {

@@ -3,7 +3,7 @@
 # drop-in against the CPU reference over six trajectories (scripts/dropin_many.py), K1's per-phase cycle profile alone
 # on a CU / one / four frames per CU / the benchmark batch (scripts/k1_phase_profile.py on the -DSIA_PROFILE build).
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r05d; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 V=$PWD/build/variants
 {

@@ -2,7 +2,7 @@
 # Round 5, fifth GPU call: the scan with one position per lane for lines of up to 8 positions (two per lane otherwise)
 # against the scan of rounds 3-4; the resident seed store's parity test.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r05e; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 V=$PWD/build/variants
 {

@@ -2,7 +2,7 @@
 # Round 5, sixth GPU call: scan (one / two positions per lane, 4 / 6 chunks per lane) per-kernel + counters; the resident
 # seed store: parity test and the single-stream frame with the store on / off.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r05f; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 {
 echo "== parity: tracking suite (incl. the resident seed store), drop-in pipeline, replay"

@@ -2,7 +2,7 @@
 # Round 5, seventh GPU call: the scan (runtime one / two positions per lane, no spills); K4 at two waves per SIMD against
 # three (build/variants/libsvo_hip_pw2.so); the cross-workgroup exchange microbenchmark (configs[3] split).
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r05g; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 V=$PWD/build/variants
 {

@@ -2,7 +2,7 @@
 # Round 6, first GPU call: the new headline (K1 + K4 on pipeline matches), the reference-cameras leg, the sigma2 deviation
 # the tracking test measures, the seed-store tests.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=$R/gpurun_out/r06a; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 {
 echo "== tracking + dropin store tests"

@@ -2,7 +2,7 @@
 # Round 6, second GPU call: the fused warp + scan kernel and the 8-lane warp_kernel against the round-5 library
 # (build/variants/libsvo_hip_r05.so): parity first, then per-kernel times of the full-track step, then the step itself.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r06b; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 V=$PWD/build/variants
 {

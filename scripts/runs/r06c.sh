@@ -4,7 +4,7 @@
 #   r05      the round-5 library          oldalign  the tree with round 5's alignment (gradient cache, two waves)
 #   nofin    the tree with seed_finish_kernel as a launch of its own      box296  the tree with the scan's LDS stride 296 dwords
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r06c; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 V=$PWD/build/variants
 {

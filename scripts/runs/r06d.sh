@@ -2,7 +2,7 @@
 # Round 6, fourth GPU call: the alignment's window cache (wc2: two waves per SIMD, no spill; wc3 = the tree: three waves,
 # 20 spilled dwords) against the committed tree (nowc); the XCD-local exchange microbenchmark.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r06d; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 V=$PWD/build/variants
 {

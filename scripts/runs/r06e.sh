@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, fifth GPU call: the exchange microbenchmark (three load policies), then the default bench of the tree.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=$R/gpurun_out/r06e; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 {
 echo "== cross-workgroup exchange microbenchmark"

@@ -2,7 +2,7 @@
 # Round 6, sixth GPU call: K1 split over four workgroups (configs[3] at B = 64): parity, then the configs[3] leg with the split
 # on and off; the distorted scan at three waves per SIMD (the tree) against four (build/variants/libsvo_hip_scan4.so).
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r06f; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 {
 echo "== parity: K1 suites"

@@ -2,7 +2,7 @@
 # Round 6, seventh GPU call: the split K1 with the placement-independent exchange (sc1 write-through chunks, epoch in both
 # halves, blocks zeroed per launch): microbenchmark with the XCC census, parity, configs[3] leg on/off; then the whole GPU suite.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r06g; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 {
 echo "== cross-workgroup exchange microbenchmark"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, ninth GPU call: the split K1 with the store hazard closed: debug read-out, microbenchmark, parity, configs[3] leg on/off.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r06i; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 {
 echo "== debug variant"

@@ -2,7 +2,7 @@
 # Round 6, tenth GPU call: the split K1's exchange polled by every wave (the tree) against one wave + a barrier (variant); the
 # frame chain behind the sparse alignment on the GPU (tests, then the drop-in leg of the bench: chained vs SVO_HIP_CHAIN=0).
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r06j; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 {
 for v in main onewave main onewave; do

@@ -2,7 +2,7 @@
 # Round 6, eleventh GPU call: the drop-in leg of the bench (chained vs SVO_HIP_CHAIN=0), then the full-track step with the
 # alignment's phase boundaries moved and with the packed warp sample arithmetic.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r06k; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 {
 echo "== drop-in leg of the bench"

@@ -2,7 +2,7 @@
 # Round 6, twelfth GPU call: the split K1 with persistent epochs (no per-launch memset) and side-by-side H polls; the frame
 # chain with the keyframes ranked on the device: tests, the drop-in leg (chained vs SVO_HIP_CHAIN=0), the frame's timeline.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r06l; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 {
 echo "== parity: K1 suites + the new entry point"

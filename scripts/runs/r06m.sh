@@ -3,7 +3,7 @@
 # the pose product, a camera frame's seeds over eleven workgroups of the scan kernel instead of one: tests, configs[3] again,
 # the drop-in leg (chained vs SVO_HIP_CHAIN=0), the frame's timeline.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r06m; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 {
 echo "== parity: K1 suites + the new entry point"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, fourteenth GPU call: the frame chain on / off, each in a process of its own (bench.dropin_hip_only), alternating.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r06n; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 {
 for rep in 1 2 3; do

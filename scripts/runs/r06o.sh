@@ -2,7 +2,7 @@
 # Round 6, fifteenth GPU call: the chain's inputs on the second stream (beside K1): chain on / off in processes of their own,
 # then the chain's GPU test.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r06o; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 {
 for rep in 1 2 3; do

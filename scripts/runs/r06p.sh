@@ -3,7 +3,7 @@
 # off, each in a process of its own, alternating; the drop-in GPU tests that cover it; the frame's timeline; then the
 # driver's command on the tree as it stands.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r06p; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 {
 for rep in 1 2 3; do

@@ -3,7 +3,7 @@
 # full-track workload (-DSCAN_PROFILE build of depth_filter.hip), the seeds' alignment histogram, and the drop-in leg with the
 # runs in processes of their own.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"; O=gpurun_out/r06q; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 {
 for v in scanprof main scanprof; do
