@@ -39,7 +39,10 @@ constexpr int SCAN_G = 8;
 constexpr int SCAN_PP = 2 * SCAN_G;
 
 // Seeds per workgroup of the scan.  The seeds of a chunk are ordered by scan length inside the workgroup (below).
-constexpr int SCAN_CHUNK = 1024;
+#ifndef SCAN_CHUNK_VALUE
+#define SCAN_CHUNK_VALUE 1024
+#endif
+constexpr int SCAN_CHUNK = SCAN_CHUNK_VALUE;
 // ... of a batch of up to SCAN_SMALL_S seeds (a single camera frame: ~330): one round of the workgroup's 32 groups.  With
 // the warp inside the scan kernel (round 6) a frame's seeds on ONE workgroup took 39.6 us, eleven rounds one after the
 // other, where the separate warp and scan kernels of round 5 had taken 5 + 6.5 (profiles/r06l_dropin_frame_timeline_600.txt).

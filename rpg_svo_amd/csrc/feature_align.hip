@@ -31,7 +31,15 @@ using namespace svo_track;
 
 namespace {
 
-constexpr int ALIGN_BLOCK = 64;
+#ifndef ALIGN_BLOCK_VALUE
+#define ALIGN_BLOCK_VALUE 128
+#endif
+// Trials per workgroup (a multiple of 64: every wave is on its own).  The launches after the first are sized for FULL queues
+// -- how many trials survive is known on the device only -- and a workgroup past its queue's end leaves at once: with 64
+// trials per workgroup the depth filter's 13 M seeds meant 205 k such workgroups per launch, ~90 + ~45 us of dispatcher time
+// for the 2.7 % and 0.3 % of the seeds that get that far (profiles/r06r_*); 128: update_seeds -1.4 % / -1.1 % on two boxes,
+// 256 no better (profiles/r06s_*, r06t_*).
+constexpr int ALIGN_BLOCK = ALIGN_BLOCK_VALUE;
 
 // Two waves per SIMD (<= 256 registers): with the bare __launch_bounds__(64) the compiler took 256 VGPRs plus 15-20
 // AGPRs, i.e. ONE wave per SIMD, and nothing hid the round trip of an iteration's window fetch.

@@ -25,7 +25,7 @@ def test_no_experiment_switch_is_left_in_the_kernels():
     """csrc/ keeps three switches: the reference-width build the bench times, the phase counters, the CPU test seams."""
     import glob
     import re
-    allowed = {"SIA_F64_PARTIALS", "SIA_PROFILE", "SCAN_PROFILE", "SIA_PACKED", "SVO_HOST_MATH_TEST", "SIA_VCC_SELECT", "ALIGN_PHASE_MIN_M_VALUE", "ALIGN_WAVE_MAX_M_VALUE",
+    allowed = {"SIA_F64_PARTIALS", "SIA_PROFILE", "SCAN_PROFILE", "SIA_PACKED", "SVO_HOST_MATH_TEST", "SIA_VCC_SELECT", "ALIGN_PHASE_MIN_M_VALUE", "ALIGN_WAVE_MAX_M_VALUE", "ALIGN_BLOCK_VALUE", "SCAN_CHUNK_VALUE",
                "__HIP_DEVICE_COMPILE__", "SVO_HIP_EMU"}  # (SVO_HIP_EMU: set by tests/host/hip_emu.h next to SVO_HOST_MATH_TEST)
     found = set()
     for f in glob.glob(os.path.join(ROOT, "rpg_svo_amd", "csrc", "*")):
