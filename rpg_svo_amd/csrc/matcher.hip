@@ -508,6 +508,7 @@ extern "C" size_t svo_hip_match_workspace_bytes(int M) {
   b += Carver::round(m * 12 * sizeof(double));     // T_cur_ref (quaternion + t padded)
   b += align_phase_workspace_bytes(M) + 256;       // queues + parked loop state of the phased alignment
   b += Carver::round(m * sizeof(uint16_t));        // (spare)
+  b += Carver::round(m * sizeof(int32_t)) + Carver::round(m * 14 * sizeof(double));  // the depth filter's pair poses (round 6)
   return b + 4096;
 }
 

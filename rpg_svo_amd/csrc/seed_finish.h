@@ -38,6 +38,10 @@ struct SeedWs {
   uint8_t* pwb;       // [S][100]
   int32_t* align_ok;  // [S] written by the alignment kernel only
   uint8_t* accepted_raw;  // [S] 1: scan match accepted without sub-pixel refinement (subpix_refinement == false)
+  // T_cur_ref and T_ref_cur (q0..3, t0..2 each) of the seed's (reference keyframe, current frame) pair live at
+  // pair_T[14 * pair_index[s]]: formed once per run of seeds by seed_prepare_kernel.
+  int32_t* pair_index;    // [S]
+  double* pair_T;         // [S][14], written at the first seed of a run only
 };
 
 struct SeedArgs {
@@ -84,7 +88,6 @@ __device__ __forceinline__ void seed_finish_seed(const SeedArgs& a, const int s,
   const SeedWs& w = a.ws;
   // every record the seed may need is requested before the first early exit, as in seed_prepare_kernel (259 -> 243 us).
   // Workspace words of a seed that did not get that far hold whatever they held: read, not used.
-  const int cf = a.cur_frame ? a.cur_frame[s] : a.cur_index;
   const int rec = a.slot_of ? a.slot_of[s] : s;  // the seed's record (resident store: its slot)
   const int rfi = a.ftr.d_frame[rec];
   // (a seed that went through the alignment in this very launch: its results are in registers)
@@ -96,11 +99,13 @@ __device__ __forceinline__ void seed_finish_seed(const SeedArgs& a, const int s,
     sa = a.seeds.d_a[rec]; sb = a.seeds.d_b[rec]; smu = a.seeds.d_mu[rec]; ssig = a.seeds.d_sigma2[rec];
     zr_early = a.seeds.d_z_range[rec];
   }
-  double RtR[12], RtC[12];
+  // T_cur_ref and T_ref_cur of the seed's (reference, current) pair: formed once per run of seeds by seed_prepare_kernel
+  // (rounds 1-5 rebuilt them per seed from the frame table: two quaternions from matrices, two products, three inverses)
+  double PT[14];
+  {
+    const double* const pt = w.pair_T + 14 * (size_t)w.pair_index[s];
 #pragma unroll
-  for (int k = 0; k < 12; ++k) {
-    RtR[k] = a.frame_T[12 * rfi + k];
-    RtC[k] = a.frame_T[12 * cf + k];
+    for (int k = 0; k < 14; ++k) PT[k] = pt[k];
   }
   int status = w.status[s];
   const bool aligned = w.align_active[s] != 0;  // a short segment, or a scan match handed to the sub-pixel alignment
@@ -115,14 +120,15 @@ __device__ __forceinline__ void seed_finish_seed(const SeedArgs& a, const int s,
     a.status_out[s] = status;
     return;
   }
-  Se3 Tr, Tc;
-  se3_from_Rt(RtR, Tr);
-  se3_from_Rt(RtC, Tc);
+  Se3 T_cur_ref, T_ref_cur;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { T_cur_ref.q[k] = PT[k]; T_ref_cur.q[k] = PT[7 + k]; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { T_cur_ref.t[k] = PT[4 + k]; T_ref_cur.t[k] = PT[11 + k]; }
   bool matched = false;
   double z = 0;
   if (status == 0) {
     const int aok = aligned ? aok_early : 0;
-    const Se3 T_cur_ref = se3_compose(Tc, se3_inverse(Tr));
     if (aligned && aok == 1) {
       // px_cur_ = px_scaled*(1<<search_level_) was written by the alignment kernel
       double fc[3];
@@ -152,7 +158,6 @@ __device__ __forceinline__ void seed_finish_seed(const SeedArgs& a, const int s,
   }
   // law of chord (depth_filter.cpp:252-255): atan(px_noise / (2 * focal_length)) * 2 depends on the camera alone -- computed
   // once on the host (run_seed_chain), by the libm the reference itself runs on
-  const Se3 T_ref_cur = se3_compose(Tr, se3_inverse(Tc));
   const double tau = compute_tau(T_ref_cur, f, z, a.tau_k);
   const double zmt = (0.0000001 < z - tau) ? z - tau : 0.0000001;
   const double tau_inverse = 0.5 * (1.0 / zmt - 1.0 / (z + tau));
@@ -165,6 +170,13 @@ __device__ __forceinline__ void seed_finish_seed(const SeedArgs& a, const int s,
     a.state_out[s] = sa; a.state_out[a.S + s] = sb; a.state_out[2 * a.S + s] = smu; a.state_out[3 * a.S + s] = ssig;
   }
   if ((double)sqrtf(ssig) < (double)zr / a.opt.seed_convergence_sigma2_thresh) {
+    Se3 Tr;  // (rare: a seed converges once in its life)
+    {
+      double Rt[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) Rt[k] = a.frame_T[12 * rfi + k];
+      se3_from_Rt(Rt, Tr);
+    }
     const Se3 Tr_inv = se3_inverse(Tr);
     const double kk = 1.0 / (double)smu;
     const double pw[3] = {f[0] * kk, f[1] * kk, f[2] * kk};

@@ -154,9 +154,30 @@ def test_emulated_update_seeds(emu_seeds, oracle, scene, align_1d, subpix):
     emu.svo_hip_match_workspace_bytes.restype = C.c_size_t
     ws = np.full(emu.svo_hip_match_workspace_bytes(S) + 256, 0xFF, np.uint8)   # (poisoned: NaN / -1 to whoever reads scratch it did not write)
     cam = capi.camera(scene.cam)
+    state0 = [x.copy() for x in (a, b, mu, zr, s2, bid)]
     rc = emu.svo_hip_update_seeds(C.byref(layout), _p(store), C.byref(cam), C.byref(frames), S, _p(cur), C.byref(ftr), C.byref(sd),
                                   C.byref(dopt), _p(status), _p(xyz), _p(px), _p(ws), C.c_size_t(ws.size), None)
     assert rc == 0, rc
+    # The same seeds keyframe by keyframe, as a seed list holds them: a workgroup of seed_prepare_kernel then finds a handful
+    # of RUNS of equal (reference, current) pairs and forms the pairs' poses once per run (the list order above changes
+    # keyframe from seed to seed: more runs than the workgroup takes, i.e. the per-seed path).  Same bits either way.
+    order = np.argsort(f_frame, kind="stable")
+    assert len(np.unique(f_frame)) >= 2 and np.count_nonzero(np.diff(f_frame) != 0) > 64 > np.count_nonzero(np.diff(f_frame[order]) != 0)
+    for ws_bytes in (ws.size,):
+        pf = [c(x[order], x.dtype) for x in (f_frame, f_level, f_type, f_px, f_f, f_grad)]
+        ps = [c(x[order], x.dtype) for x in state0]
+        pftr = capi.Features(pf[0].ctypes.data, pf[1].ctypes.data, pf[2].ctypes.data, pf[3].ctypes.data, pf[4].ctypes.data, pf[5].ctypes.data)
+        psd = capi.Seeds(*[x.ctypes.data for x in ps])
+        st2, xyz2, px2 = np.zeros(S, np.int32), np.zeros((S, 3)), np.zeros((S, 2))
+        ws2 = np.full(ws.size, 0xFF, np.uint8)
+        rc = emu.svo_hip_update_seeds(C.byref(layout), _p(store), C.byref(cam), C.byref(frames), S, _p(cur), C.byref(pftr), C.byref(psd),
+                                      C.byref(dopt), _p(st2), _p(xyz2), _p(px2), _p(ws2), C.c_size_t(ws_bytes), None)
+        assert rc == 0, rc
+        assert np.array_equal(st2, status[order]) and np.array_equal(px2, px[order])
+        conv = status[order] == pytrack.SEED_CONVERGED
+        assert np.array_equal(xyz2[conv], xyz[order][conv])
+        for got, want in zip(ps, (a, b, mu, zr, s2, bid)):
+            assert np.array_equal(got, want[order])
     hist = {}
     for i in range(S):
         st = io[i].status

@@ -571,6 +571,31 @@ def test_update_seeds(gpu_device, orc, scene, pyrs, align_1d, subpix):
           f"max in units of eps32 * mu^2 {max(x[1] for x in s2_dev):.2f}")
     assert hist.get(pytrack.SEED_UPDATED, 0) > 50 and hist.get(pytrack.SEED_CONVERGED, 0) > 2
     assert hist.get(pytrack.SEED_ERASED_OLD, 0) > 5 and hist.get(pytrack.SEED_BEHIND if orc.which == "orc" else 0, 0) > 2
+    # The same seeds keyframe by keyframe, as a seed list holds them: a workgroup of seed_prepare_kernel then finds a handful
+    # of runs of equal (reference, current) pairs and forms the pairs' poses once per run; in the order above the keyframe
+    # changes from seed to seed -- more runs than a workgroup takes: the per-seed path.  The same bits either way.
+    fr = np.array([o[0] for o in feats])
+    order = np.argsort(fr, kind="stable")
+    assert np.count_nonzero(np.diff(fr) != 0) > 64 > np.count_nonzero(np.diff(fr[order]) != 0)
+    sel = lambda xs, dt: dev([xs[i] for i in order], dt)
+    fs2 = tracking.FeatureSet(frame=sel([o[0] for o in feats], torch.int32), level=sel([o[3] for o in feats], torch.int32),
+                              px=sel([o[1] for o in feats], torch.float64), f=sel([o[2] for o in feats], torch.float64),
+                              type=sel([o[4] for o in feats], torch.uint8), grad=sel([o[5] for o in feats], torch.float64))
+    seeds2, _ = _make_seeds(scene, orc, np.random.default_rng(8))  # (the checker has updated `seeds` in place)
+    ss2 = tracking.SeedSet(a=sel([s.a for s in seeds2], torch.float32), b=sel([s.b for s in seeds2], torch.float32),
+                           mu=sel([s.mu for s in seeds2], torch.float32), z_range=sel([s.z_range for s in seeds2], torch.float32),
+                           sigma2=sel([s.sigma2 for s in seeds2], torch.float32), batch_id=sel([s.batch_id for s in seeds2], torch.int32))
+    status2, xyz2, px2 = df.update_seeds(store, scene.cam, frames, torch.full((S,), scene.cur, dtype=torch.int32, device="cuda:0"),
+                                         fs2, ss2, batch_counter=5)
+    torch.cuda.synchronize()
+    st2 = status2.cpu().numpy()
+    if orc.which == "ref":
+        st2 = np.where(np.isin(st2, (pytrack.SEED_BEHIND, pytrack.SEED_NOT_IN_FRAME)), 0, st2)
+    assert np.array_equal(st2, status[order]) and np.array_equal(px2.cpu().numpy(), px[order])
+    conv = status[order] == pytrack.SEED_CONVERGED
+    assert np.array_equal(xyz2.cpu().numpy()[conv], xyz[order][conv])
+    for got, want in zip((ss2.a, ss2.b, ss2.mu, ss2.sigma2), (a, b, mu, s2)):
+        assert np.array_equal(got.cpu().numpy(), want[order])
 
 
 def test_update_seeds_on_the_resident_store(gpu_device, scene, pyrs, orc):
