@@ -1657,11 +1657,11 @@ def dropin_sequence(n_frames: int = 600) -> dict:
         no_chain = {"skipped": repr(e)}
     # The drop-in in a process of its own, as a host runs it (this process has been through every other leg by now -- a
     # dozen streams, the reference's own run, counters -- and measures the same frames 5-12 % slower): synchronous and deferred
-    # mapper alternating, two processes each; same frames, same trajectory.
+    # mapper alternating, three processes each (medians reported); same frames, same trajectory.
     own = {"hip_dropin": [], "hip_dropin_deferred_mapper": []}
     own_same = True
     try:
-        for rep in range(2):
+        for rep in range(3):
             for key, dm in (("hip_dropin", 0), ("hip_dropin_deferred_mapper", 1)):
                 dump = tempfile.mktemp(suffix=".npy", dir="/tmp")
                 code = (f"import sys, json; sys.path.insert(0, {ROOT!r}); import bench; "
