@@ -37,24 +37,15 @@ using namespace svo_track;
 
 namespace {
 
-// The relative poses a seed needs -- T_ref_cur, its inverse, T_cur_ref -- depend on its (reference keyframe, current frame)
-// PAIR alone, and a seed list holds its seeds keyframe by keyframe: rounds 1-5 rebuilt the two quaternions from the frame
-// table's matrices, inverted and composed them per SEED, here and again in seed_finish -- a third of the instructions of
-// both (two sqrt and sixteen f64 divisions among them).  Round 6: a workgroup of PREP_BLOCK consecutive seeds finds its RUNS
-// of equal pairs, ONE lane per run forms the three poses (the same functions on the same matrices: the same bits), the
-// seeds of the run take them from LDS, and seed_finish from `pair_T` at the index of the run's first seed.  A workgroup
-// with more than PREP_MAX_RUNS runs (seeds of many keyframes interleaved) computes per seed as before and files every
-// seed as a run of its own.
-constexpr int PREP_BLOCK = 256, PREP_MAX_RUNS = 64;
-__device__ __forceinline__ void pair_poses(const double* __restrict__ RtR, const double* __restrict__ RtC, Se3& T_ref_cur, Se3& T_cur_ref0,
-                                           Se3& T_cur_ref) {
-  Se3 Tr, Tc;
-  se3_from_Rt(RtR, Tr);
-  se3_from_Rt(RtC, Tc);
-  T_ref_cur = se3_compose(Tr, se3_inverse(Tc));
-  T_cur_ref0 = se3_inverse(T_ref_cur);
-  T_cur_ref = se3_compose(Tc, se3_inverse(Tr));
-}
+// The relative poses of a seed -- T_ref_cur, T_cur_ref -- depend on its (reference keyframe, current frame) PAIR alone, and
+// a seed list holds its seeds keyframe by keyframe.  Rounds 1-5 rebuilt the two quaternions from the frame table's matrices,
+// inverted and composed them per seed here and AGAIN in seed_finish (a third of its instructions: two sqrt and sixteen f64
+// divisions among them).  Round 6: this kernel forms them once per seed, before its early exits, the first seed of every
+// RUN of equal pairs inside a wave files them in `pair_T`, every seed notes where (`pair_index`), and seed_finish reads
+// 14 doubles.  (Forming them once per run HERE as well -- workgroups of 256, one lane per run, the poses handed out
+// through LDS -- measured slower for this kernel: the one wave that forms a workgroup's poses is a bubble the other
+// three wait behind, 0.75 -> 0.86 ms per 13 M seeds, profiles/r06u_*, r06z_*.)
+constexpr int PREP_BLOCK = 64;
 __device__ __forceinline__ void pair_store(double* __restrict__ dst, const Se3& T_cur_ref, const Se3& T_ref_cur) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) { dst[k] = T_cur_ref.q[k]; dst[7 + k] = T_ref_cur.q[k]; }
@@ -62,65 +53,10 @@ __device__ __forceinline__ void pair_store(double* __restrict__ dst, const Se3& 
   for (int k = 0; k < 3; ++k) { dst[4 + k] = T_cur_ref.t[k]; dst[11 + k] = T_ref_cur.t[k]; }
 }
 
-__global__ void __launch_bounds__(PREP_BLOCK, 4) seed_prepare_kernel(const SeedArgs a) {
-  __shared__ unsigned long long s_key[PREP_BLOCK];
-  __shared__ int s_wave_runs[PREP_BLOCK / 64];
-  __shared__ int s_run_rfi[PREP_MAX_RUNS], s_run_cf[PREP_MAX_RUNS], s_run_start[PREP_MAX_RUNS];
-  __shared__ double s_T[21][PREP_MAX_RUNS];  // [component][run]: T_ref_cur, T_cur_ref0, T_cur_ref as q0..3, t0..2
+__global__ void __launch_bounds__(PREP_BLOCK) seed_prepare_kernel(const SeedArgs a) {
   const int s = blockIdx.x * PREP_BLOCK + threadIdx.x;
-  const SeedWs& w = a.ws;
-  bool have_pair = false;
-  int my_run = 0;
-  {  // (every lane of the workgroup stays for the barriers)
-    const bool valid = s < a.S;
-    const int sc = valid ? s : a.S - 1;
-    const int cf_ = a.cur_frame ? a.cur_frame[sc] : a.cur_index;
-    const int rfi_ = a.ftr.d_frame[a.slot_of ? a.slot_of[sc] : sc];
-    const unsigned long long key = valid ? ((unsigned long long)(unsigned)rfi_ << 32 | (unsigned)cf_) : ~0ull;
-    s_key[threadIdx.x] = key;
-    __syncthreads();
-    const bool flag = valid && (threadIdx.x == 0 || s_key[threadIdx.x - 1] != key);  // first seed of a run
-    const uint64_t flags = __builtin_amdgcn_ballot_w64(flag);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) s_wave_runs[wave] = (int)__popcll(flags);
-    __syncthreads();
-    int base = 0, n_runs = 0;
-#pragma unroll
-    for (int k = 0; k < PREP_BLOCK / 64; ++k) {
-      const int c = s_wave_runs[k];
-      base += k < wave ? c : 0;
-      n_runs += c;
-    }
-    // runs begun up to and including this lane, minus one: the run the seed belongs to (lane 0 of the workgroup begins one)
-    const int run = base + (int)__popcll(flags & (~0ull >> (63 - lane))) - 1;
-    if (n_runs <= PREP_MAX_RUNS) {
-      if (flag) { s_run_rfi[run] = rfi_; s_run_cf[run] = cf_; s_run_start[run] = s; }
-      __syncthreads();
-      if ((int)threadIdx.x < n_runs) {
-        const int r = s_run_rfi[threadIdx.x], c = s_run_cf[threadIdx.x];
-        double RtR[12], RtC[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) {
-          RtR[k] = a.frame_T[12 * r + k];
-          RtC[k] = a.frame_T[12 * c + k];
-        }
-        Se3 A, B, C;
-        pair_poses(RtR, RtC, A, B, C);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { s_T[k][threadIdx.x] = A.q[k]; s_T[7 + k][threadIdx.x] = B.q[k]; s_T[14 + k][threadIdx.x] = C.q[k]; }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { s_T[4 + k][threadIdx.x] = A.t[k]; s_T[11 + k][threadIdx.x] = B.t[k]; s_T[18 + k][threadIdx.x] = C.t[k]; }
-        pair_store(w.pair_T + 14 * (size_t)s_run_start[threadIdx.x], C, A);
-      }
-      __syncthreads();
-      if (valid) {  // (the poses are read from s_T where the seed needs them: 42 registers less across the early exits)
-        w.pair_index[s] = s_run_start[run];
-        have_pair = true;
-        my_run = run;
-      }
-    }
-  }
   if (s >= a.S) return;
+  const SeedWs& w = a.ws;
   // What every seed needs whatever happens to it.  Arrays only the warp / scan / alignment of an ACTIVE seed read
   // (ref_slot, ref_level, dir, px_scaled, px_cur) are written where the seed becomes active, and seed_finish reads
   // px_cur / align_ok only for seeds that got that far: an early exit costs 19 bytes of workspace, not 71 (round 3:
@@ -153,37 +89,38 @@ __global__ void __launch_bounds__(PREP_BLOCK, 4) seed_prepare_kernel(const SeedA
   const double* const gradp = (a.ftr.d_type && a.ftr.d_grad) ? a.ftr.d_grad : a.ftr.d_px;
   const double gx_early = gradp[2 * rec], gy_early = gradp[2 * rec + 1];
   double RtR[12], RtC[12];
-  if (!have_pair) {  // (uniform over the workgroup)
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      RtR[k] = a.frame_T[12 * rfi + k];
-      RtC[k] = a.frame_T[12 * cf + k];
-    }
+  for (int k = 0; k < 12; ++k) {
+    RtR[k] = a.frame_T[12 * rfi + k];
+    RtC[k] = a.frame_T[12 * cf + k];
   }
   const int ref_slot_early = a.frame_slot[rfi];
   w.cur_slot[s] = a.frame_slot[cf];
-  if (!have_pair) w.pair_index[s] = s;  // a run of its own (its poses: further down, if it gets there)
+  // the pair's poses, for this kernel and (through pair_T) for seed_finish: before the early exits, so that the first seed
+  // of a run files them whatever happens to it
+  Se3 Tr, Tc;
+  se3_from_Rt(RtR, Tr);
+  se3_from_Rt(RtC, Tc);
+  const Se3 T_ref_cur = se3_compose(Tr, se3_inverse(Tc));
+  const Se3 T_cur_ref = se3_compose(Tc, se3_inverse(Tr));
+  {
+    // a run starts at lane 0 of the wave and wherever the (reference, current) pair differs from the lane before
+    const int lane = threadIdx.x & 63;
+    const int rfi_left = __shfl_up(rfi, 1, 64), cf_left = __shfl_up(cf, 1, 64);
+    const bool starts = lane == 0 || rfi_left != rfi || cf_left != cf;
+    const uint64_t flags = __builtin_amdgcn_ballot_w64(starts);
+    const int start_lane = 63 - __builtin_clzll(flags & (~0ull >> (63 - lane)));  // the last start at or before this lane
+    w.pair_index[s] = s - lane + start_lane;
+    if (starts) pair_store(w.pair_T + 14 * (size_t)s, T_cur_ref, T_ref_cur);
+  }
   // check if seed is not already too old (:216-219)
   if (!a.match_only && (a.opt.batch_counter - batch_id) > a.opt.max_n_kfs) {
     w.status[s] = SVO_HIP_SEED_ERASED_OLD;
     return;
   }
-  Se3 Tr, Tc;
-  if (!have_pair) {
-    se3_from_Rt(RtR, Tr);
-    se3_from_Rt(RtC, Tc);
-  }
   // visibility (:221-232)
   if (!a.match_only) {
-    Se3 T_cur_ref0;  // (T_ref_cur = Tr * Tc^-1, inverted: depth_filter.cpp:221-222)
-    if (have_pair) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) T_cur_ref0.q[k] = s_T[7 + k][my_run];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) T_cur_ref0.t[k] = s_T[11 + k][my_run];
-    } else {
-      T_cur_ref0 = se3_inverse(se3_compose(Tr, se3_inverse(Tc)));
-    }
+    const Se3 T_cur_ref0 = se3_inverse(T_ref_cur);
     const double k = 1.0 / (double)mu;
     const double pr[3] = {k * f[0], k * f[1], k * f[2]};
     double xyz_f[3];
@@ -210,16 +147,6 @@ __global__ void __launch_bounds__(PREP_BLOCK, 4) seed_prepare_kernel(const SeedA
   const double d_max = a.match_only ? a.d_max[s] : 1.0 / (double)z_inv_max;
 
   // ---- Matcher::findEpipolarMatchDirect, matcher.cpp:188-246 -------------------------
-  Se3 T_cur_ref;  // Tc * Tr^-1
-  if (have_pair) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) T_cur_ref.q[k] = s_T[14 + k][my_run];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) T_cur_ref.t[k] = s_T[18 + k][my_run];
-  } else {
-    T_cur_ref = se3_compose(Tc, se3_inverse(Tr));
-    pair_store(w.pair_T + 14 * (size_t)s, T_cur_ref, se3_compose(Tr, se3_inverse(Tc)));
-  }
   double p[3], q[3], A[2], B[2];
   p[0] = f[0] * d_min; p[1] = f[1] * d_min; p[2] = f[2] * d_min;
   se3_apply(T_cur_ref, p, q);

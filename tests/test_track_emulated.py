@@ -158,9 +158,9 @@ def test_emulated_update_seeds(emu_seeds, oracle, scene, align_1d, subpix):
     rc = emu.svo_hip_update_seeds(C.byref(layout), _p(store), C.byref(cam), C.byref(frames), S, _p(cur), C.byref(ftr), C.byref(sd),
                                   C.byref(dopt), _p(status), _p(xyz), _p(px), _p(ws), C.c_size_t(ws.size), None)
     assert rc == 0, rc
-    # The same seeds keyframe by keyframe, as a seed list holds them: a workgroup of seed_prepare_kernel then finds a handful
-    # of RUNS of equal (reference, current) pairs and forms the pairs' poses once per run (the list order above changes
-    # keyframe from seed to seed: more runs than the workgroup takes, i.e. the per-seed path).  Same bits either way.
+    # The same seeds keyframe by keyframe, as a seed list holds them: a wave of seed_prepare_kernel then finds a handful of
+    # RUNS of equal (reference, current) pairs whose first seed files the pair's poses for seed_finish (in the list order
+    # above the keyframe changes from seed to seed: nearly every seed a run of its own).  Same bits either way.
     order = np.argsort(f_frame, kind="stable")
     assert len(np.unique(f_frame)) >= 2 and np.count_nonzero(np.diff(f_frame) != 0) > 64 > np.count_nonzero(np.diff(f_frame[order]) != 0)
     for ws_bytes in (ws.size,):

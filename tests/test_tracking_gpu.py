@@ -571,9 +571,9 @@ def test_update_seeds(gpu_device, orc, scene, pyrs, align_1d, subpix):
           f"max in units of eps32 * mu^2 {max(x[1] for x in s2_dev):.2f}")
     assert hist.get(pytrack.SEED_UPDATED, 0) > 50 and hist.get(pytrack.SEED_CONVERGED, 0) > 2
     assert hist.get(pytrack.SEED_ERASED_OLD, 0) > 5 and hist.get(pytrack.SEED_BEHIND if orc.which == "orc" else 0, 0) > 2
-    # The same seeds keyframe by keyframe, as a seed list holds them: a workgroup of seed_prepare_kernel then finds a handful
-    # of runs of equal (reference, current) pairs and forms the pairs' poses once per run; in the order above the keyframe
-    # changes from seed to seed -- more runs than a workgroup takes: the per-seed path.  The same bits either way.
+    # The same seeds keyframe by keyframe, as a seed list holds them: a wave of seed_prepare_kernel then finds a handful of
+    # runs of equal (reference, current) pairs whose first seed files the pair's poses for seed_finish; in the order above
+    # the keyframe changes from seed to seed -- nearly every seed a run of its own.  The same bits either way.
     fr = np.array([o[0] for o in feats])
     order = np.argsort(fr, kind="stable")
     assert np.count_nonzero(np.diff(fr) != 0) > 64 > np.count_nonzero(np.diff(fr[order]) != 0)
