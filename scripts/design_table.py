@@ -54,7 +54,7 @@ def table(d: dict, src: str) -> str:
         key = name.split("/")[-1].replace("_kernel", "")
         valu, lds = v.get("valu") or {}, v.get("lds") or {}
         extra = ""
-        if lds.get("bank_conflict_frac_of_port_cycles") is not None:
+        if lds.get("bank_conflict_frac_of_port_cycles") is not None and (lds.get("port_busy_frac") or 0) >= 0.005:
             extra = f" (LDS port {f(lds.get('port_busy_frac_vs_busy_cu_cycles', lds.get('port_busy_frac')))} busy, {f(lds['bank_conflict_frac_of_port_cycles'])} of it conflicts)"
         u = unit.get(key, '-')
         if name == "update_seeds/align_kernel" and "update_seeds/seed_finish_kernel" not in (ft.get("kernels") or {}):
