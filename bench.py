@@ -1707,7 +1707,8 @@ def dropin_sequence(n_frames: int = 600) -> dict:
             "frame_chain": {"taken": host.get("frame_chain_hits"), "not_taken": host.get("frame_chain_misses")},
             # ... and the depth filter's update enqueued by the pose optimizer's drop-in, before the host's bookkeeping of the
             # frame (dropin/depth_filter.cpp, EarlyUpdate): taken by the reference's updateSeeds call / dropped (keyframes)
-            "early_mapper": {"taken": host.get("early_mapper_taken"), "dropped": host.get("early_mapper_dropped")},
+            "early_mapper": {"taken": host.get("early_mapper_taken"), "dropped": host.get("early_mapper_dropped"),
+                             "launched_in_two_phases": host.get("early_mapper_two_phase")},
             # N2 evidence: per drop-in call, the host walking the reference's pointer graph into the pinned
             # arena and back (marshal/unmarshal) against the device round trip (H2D + kernels + D2H + sync)
             "host_vs_device_us_per_call": {k: {q: round(v, 2) if isinstance(v, float) else v for q, v in st.items()}

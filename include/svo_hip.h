@@ -660,6 +660,18 @@ int svo_hip_update_seeds_resident(const svo_hip_pyr_layout* layout, const uint8_
                                   const svo_hip_seeds* store_seeds, const svo_hip_depth_filter_options* opt,
                                   int32_t* d_status, double* d_xyz_world, double* d_px_cur, float* d_state_out,
                                   void* d_workspace, size_t workspace_bytes, void* stream);
+/* The same with the pose of frame `cur_frame` handed over BY VALUE: T_cur_f_w is a HOST pointer to the 12 doubles of its
+ * frame-table row (R row-major, then t), read before the call returns; row `cur_frame` of frames->d_T_f_w is not read.  For
+ * a host that uploads the call's tables BEFORE the frame's pose is known -- the depth filter's drop-in marshals and uploads
+ * while pose_optimizer::optimizeGaussNewton is still running on the device and launches when its result has arrived
+ * (frame_handler_mono.cpp:166-198; dropin/depth_filter.cpp, EarlyUpdate).  Same arithmetic, same results. */
+int svo_hip_update_seeds_resident_pose(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
+                                       const svo_hip_camera* cam, const svo_hip_frames* frames, int cur_frame,
+                                       const double* T_cur_f_w, int S, const int32_t* d_slot_of,
+                                       const svo_hip_features* store_ftr, const svo_hip_seeds* store_seeds,
+                                       const svo_hip_depth_filter_options* opt, int32_t* d_status, double* d_xyz_world,
+                                       double* d_px_cur, float* d_state_out, void* d_workspace, size_t workspace_bytes,
+                                       void* stream);
 
 /*
  * Batched Matcher::findEpipolarMatchDirect (svo/src/matcher.cpp:179-321; matcher.h:113-123) on its own:

@@ -194,6 +194,8 @@ PROTOTYPES = {
     "svo_hip_seed_store_patch": (_i, [C.POINTER(SeedPatch), C.POINTER(Features), C.POINTER(Seeds), _vp]),
     "svo_hip_update_seeds_resident": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _i, _vp, C.POINTER(Features),
                                            C.POINTER(Seeds), C.POINTER(DepthFilterOptions), _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "svo_hip_update_seeds_resident_pose": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, _i, _vp, C.POINTER(Features),
+                                                C.POINTER(Seeds), C.POINTER(DepthFilterOptions), _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "svo_hip_find_epipolar_match_direct": (_i, [_LP, _vp, C.POINTER(Camera), C.POINTER(Frames), _i, _vp, C.POINTER(Features),
                                                 _vp, _vp, _vp, C.POINTER(DepthFilterOptions), _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "svo_hip_update_seed_batch": (_i, [_i, _vp, _vp, C.POINTER(Seeds), _vp]),

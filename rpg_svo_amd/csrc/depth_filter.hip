@@ -94,6 +94,10 @@ __global__ void __launch_bounds__(PREP_BLOCK) seed_prepare_kernel(const SeedArgs
     RtR[k] = a.frame_T[12 * rfi + k];
     RtC[k] = a.frame_T[12 * cf + k];
   }
+  if (a.cur_T_set && cf == a.cur_index) {  // (the current frame's pose arrived with the launch: uniform in practice)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) RtC[k] = a.cur_T[k];
+  }
   const int ref_slot_early = a.frame_slot[rfi];
   w.cur_slot[s] = a.frame_slot[cf];
   // the pair's poses, for this kernel and (through pair_T) for seed_finish: before the early exits, so that the first seed
@@ -405,6 +409,7 @@ extern "C" int svo_hip_find_epipolar_match_direct(const svo_hip_pyr_layout* layo
   a.frame_T = frames->d_T_f_w;
   a.cur_frame = d_cur_frame;
   a.cur_index = 0;
+  a.cur_T_set = 0;
   a.slot_of = nullptr;
   a.state_out = nullptr;
   a.ftr = *ftr;
@@ -450,6 +455,7 @@ extern "C" int svo_hip_update_seeds(const svo_hip_pyr_layout* layout, const uint
   a.frame_T = frames->d_T_f_w;
   a.cur_frame = d_cur_frame;
   a.cur_index = 0;
+  a.cur_T_set = 0;
   a.slot_of = nullptr;
   a.state_out = nullptr;
   a.ftr = *ftr;
@@ -518,12 +524,12 @@ extern "C" int svo_hip_seed_store_patch(const svo_hip_seed_patch* patch, const s
   return check_launch();
 }
 
-extern "C" int svo_hip_update_seeds_resident(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
-                                             const svo_hip_camera* cam, const svo_hip_frames* frames, int cur_frame, int S,
-                                             const int32_t* d_slot_of, const svo_hip_features* ftr,
-                                             const svo_hip_seeds* seeds, const svo_hip_depth_filter_options* opt,
-                                             int32_t* d_status, double* d_xyz_world, double* d_px_cur, float* d_state_out,
-                                             void* d_workspace, size_t workspace_bytes, void* stream) {
+static int update_seeds_resident_impl(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
+                                      const svo_hip_camera* cam, const svo_hip_frames* frames, int cur_frame, const double* T_cur_host, int S,
+                                      const int32_t* d_slot_of, const svo_hip_features* ftr,
+                                      const svo_hip_seeds* seeds, const svo_hip_depth_filter_options* opt,
+                                      int32_t* d_status, double* d_xyz_world, double* d_px_cur, float* d_state_out,
+                                      void* d_workspace, size_t workspace_bytes, void* stream) {
   if (!layout_ok(layout) || !d_store || !cam || !cam_model_ok(cam) || !frames || !ftr || !seeds || !opt || S < 0) return SVO_HIP_EINVAL;
   if (S == 0) return SVO_HIP_OK;
   if (!d_slot_of || !d_status || !frames->d_slot || !frames->d_T_f_w || cur_frame < 0 || cur_frame >= frames->n_frames ||
@@ -544,6 +550,8 @@ extern "C" int svo_hip_update_seeds_resident(const svo_hip_pyr_layout* layout, c
   a.frame_T = frames->d_T_f_w;
   a.cur_frame = nullptr;
   a.cur_index = cur_frame;
+  a.cur_T_set = T_cur_host != nullptr;
+  for (int k = 0; k < 12; ++k) a.cur_T[k] = T_cur_host ? T_cur_host[k] : 0.0;
   a.slot_of = d_slot_of;
   a.state_out = d_state_out;
   a.ftr = *ftr;
@@ -558,6 +566,27 @@ extern "C" int svo_hip_update_seeds_resident(const svo_hip_pyr_layout* layout, c
   a.ok_out = nullptr;
   a.search_level_out = nullptr;
   return run_seed_chain(layout, d_store, a, S, d_workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int svo_hip_update_seeds_resident(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
+                                             const svo_hip_camera* cam, const svo_hip_frames* frames, int cur_frame, int S,
+                                             const int32_t* d_slot_of, const svo_hip_features* ftr,
+                                             const svo_hip_seeds* seeds, const svo_hip_depth_filter_options* opt,
+                                             int32_t* d_status, double* d_xyz_world, double* d_px_cur, float* d_state_out,
+                                             void* d_workspace, size_t workspace_bytes, void* stream) {
+  return update_seeds_resident_impl(layout, d_store, cam, frames, cur_frame, nullptr, S, d_slot_of, ftr, seeds, opt, d_status, d_xyz_world,
+                                    d_px_cur, d_state_out, d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int svo_hip_update_seeds_resident_pose(const svo_hip_pyr_layout* layout, const uint8_t* d_store,
+                                                  const svo_hip_camera* cam, const svo_hip_frames* frames, int cur_frame,
+                                                  const double* T_cur_f_w, int S, const int32_t* d_slot_of, const svo_hip_features* ftr,
+                                                  const svo_hip_seeds* seeds, const svo_hip_depth_filter_options* opt,
+                                                  int32_t* d_status, double* d_xyz_world, double* d_px_cur, float* d_state_out,
+                                                  void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (!T_cur_f_w) return SVO_HIP_EINVAL;
+  return update_seeds_resident_impl(layout, d_store, cam, frames, cur_frame, T_cur_f_w, S, d_slot_of, ftr, seeds, opt, d_status, d_xyz_world,
+                                    d_px_cur, d_state_out, d_workspace, workspace_bytes, stream);
 }
 
 // seed_prepare -> (affine warp +) epipolar scan -> sub-pixel alignment -> seed_finish on one stream

@@ -53,6 +53,10 @@ struct SeedArgs {
   const double* frame_T;
   const int32_t* cur_frame;  // [S], or NULL: every seed is updated with frame `cur_index` of the table
   int cur_index;
+  // the pose of frame `cur_index` handed over BY VALUE (svo_hip_update_seeds_resident_pose: a host that uploaded the call's
+  // tables before the frame's pose was known); 0: row cur_index of frame_T
+  int cur_T_set;
+  double cur_T[12];
   const int32_t* slot_of;    // NULL: seed s is record s of ftr / seeds; else the resident store's slot of seed s (row N2)
   float* state_out;          // [4][S] a, b, mu, sigma2 after the update, dense (resident store only; may be NULL)
   svo_hip_features ftr;

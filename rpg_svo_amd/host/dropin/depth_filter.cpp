@@ -76,8 +76,14 @@ static bool seedStoreOn() {
 // not become a keyframe; anything else -- a frame that fails, a keyframe (addKeyframe does not update), another call on
 // the mapping lane -- DROPS it: the stream is drained, nothing is replayed into the list and the resident seed store is
 // told to forget its shadow (the kernels have advanced the seeds' state in HBM: the next call re-sends the list).
+// Two phases: the optimizer's drop-in calls the hook BEFORE it waits for the refinement the reprojector predicted (the host
+// would only wait: the seed list's merge walk, the call's tables and their upload happen then -- phase 1, nothing of it
+// depends on the pose) and AFTER it (phase 2: svo_hip_update_seeds_resident_pose, the pose by value); a phase 2 that finds
+// nothing held does both at once.
 struct EarlyUpdate {
-  bool valid;
+  bool valid;      // the update's kernels are running (or done) on `stream`
+  bool prepared;   // phase 1 only: tables marshalled and uploaded, `launch` holds the rest (the frame's pose is not final yet)
+  std::function<void(const double*)> launch;  // (phase 2: the kernels, with the pose's frame-table row by value)
   int frame_id;
   double T[12];
   std::vector<int> ids;
@@ -85,7 +91,7 @@ struct EarlyUpdate {
   SeedStore* store;
   void* stream;
   svo_hip::Lane* lane;           // where the hook is registered
-  EarlyUpdate() : valid(false), frame_id(-1), store(NULL), stream(NULL), lane(NULL) {}
+  EarlyUpdate() : valid(false), prepared(false), frame_id(-1), store(NULL), stream(NULL), lane(NULL) {}
 };
 struct EarlyRegistry {
   std::mutex mut;
@@ -100,7 +106,7 @@ static EarlyUpdate& earlyOf(const DepthFilter* df) {
   std::lock_guard<std::mutex> g(r.mut);
   return r.all[df];  // (node addresses are stable)
 }
-static thread_local bool tl_early_call = false;  // updateSeeds is being called through the hook
+static thread_local int tl_early_phase = 0;  // updateSeeds is being called through the hook: phase 1 (marshal, upload, hold) or 2 (launch)
 
 // calls / records sent / rebuilds, summed over the stores of the process (read-outs of the tests and the benchmark)
 void seedStoreStats(uint64_t out[3]) {
@@ -116,8 +122,13 @@ void seedStoreStats(uint64_t out[3]) {
 // ---- the update, on the device ---------------------------------------------------------------
 void DepthFilter::updateSeeds(FramePtr frame) {
   using namespace hip_dropin;
-  const bool early = tl_early_call;  // enqueue only: called by the pose optimizer's drop-in through the lane's hook
+  const int phase = tl_early_phase;
+  const bool early = phase != 0;  // enqueue only: called by the pose optimizer's drop-in through the lane's hook
   if (early && (thread_ != NULL || svo_hip::Device::deferredMapping() || frame->isKeyframe())) return;
+  if (phase == 1) {  // (the flattened list carries the pose in its tables; SVO_HIP_EARLY_MAPPER=1phase: phase 2 does it all)
+    static const bool one_phase = [] { const char* v = std::getenv("SVO_HIP_EARLY_MAPPER"); return v && std::string(v) == "1phase"; }();
+    if (one_phase || !seedStoreOn()) return;
+  }
   svo_hip::Device::joinDeferredAll();  // the previous frame's update writes into seeds_ first (takes seeds_mut_ itself)
   svo_hip::Device& dev = ensureDevice(*frame);
   const int L = svo_hip::Device::LANE_MAPPING;
@@ -125,7 +136,7 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   EarlyUpdate& eu = earlyOf(this);
   {  // (nothing to do: do not touch the device)
     lock_t peek(seeds_mut_);
-    if ((seeds_updating_halt_ || seeds_.empty()) && !eu.valid) return;
+    if ((seeds_updating_halt_ || seeds_.empty()) && !eu.valid && !eu.prepared) return;
   }
   // Lock order: the lane, then the seed list -- the order the deferred closure below takes them in when a later call joins it
   // (it runs under the lane's mutex and locks seeds_mut_ itself).  The other way round here would be a lock-order inversion
@@ -135,16 +146,47 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   if (thread_ == NULL && !svo_hip::Device::deferredMapping() && svo_hip::Device::earlyMappingEnabled()) {
     if (!lane.early_hook || eu.lane != &lane) {  // (once per filter and lane)
       eu.lane = &lane;
-      lane.early_hook = [this](const void* fp) {
-        struct Flag { Flag() { tl_early_call = true; } ~Flag() { tl_early_call = false; } } flag;
+      lane.early_hook = [this](const void* fp, const int ph) {
+        struct Flag { explicit Flag(int p) { tl_early_phase = p; } ~Flag() { tl_early_phase = 0; } } flag(ph);
         updateSeeds(*static_cast<const FramePtr*>(fp));
       };
     }
   }
-  if (!early && eu.valid) {
-    // an update of this filter is running on the stream: this call's, or one to be dropped
+  if (phase == 2 && eu.prepared) {
+    // phase 1 holds this frame's update: launch it with the pose the optimizer has just fixed -- or drop what is held
+    if (eu.frame_id == frame->id_ && eu.ids.size() == seeds_.size() && !seeds_updating_halt_) {
+      double T[12];
+      poseToRt(frame->T_f_w_, T);
+      std::function<void(const double*)> launch;
+      launch.swap(eu.launch);
+      eu.prepared = false;
+      try {
+        launch(T);
+      } catch (...) {
+        if (lane.early_drop) {
+          std::function<void()> drop;
+          drop.swap(lane.early_drop);
+          try { drop(); } catch (...) {}
+        }
+        throw;
+      }
+      std::memcpy(eu.T, T, sizeof(T));
+      eu.valid = true;
+      dev.countEarlyTwoPhase();
+      return;
+    }
+    if (lane.early_drop) {
+      std::function<void()> drop;
+      drop.swap(lane.early_drop);
+      drop();
+    }
+    // (and the update in one go, below)
+  }
+  if (early && (eu.valid || eu.prepared)) return;  // (the hook called twice for a frame: nothing to add)
+  if (!early && (eu.valid || eu.prepared)) {
+    // an update of this filter is running on the stream (or held before its launch): this call's, or one to be dropped
     const size_t S_now = seeds_.size();
-    bool same = eu.frame_id == frame->id_ && eu.ids.size() == S_now && !frame->isKeyframe() && !seeds_updating_halt_;
+    bool same = eu.valid && eu.frame_id == frame->id_ && eu.ids.size() == S_now && !frame->isKeyframe() && !seeds_updating_halt_;
     if (same) {
       double T[12];
       poseToRt(frame->T_f_w_, T);
@@ -266,20 +308,35 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   void* ws = dev.workspace(lane, (int)S);
 
   stage_timer.device(a.used());
+  std::function<void(const double*)> held;  // phase 1: the launches that wait for the frame's pose
   if (resident) {
     a.upload(lane.stream);
     if (rc.patch.n > 0)
       svo_hip::check(svo_hip_seed_store_patch(&rc.patch, &rc.ftr, &rc.seeds, lane.stream), "svo_hip_seed_store_patch");
-    svo_hip::check(svo_hip_update_seeds_resident(&dev.layout(), dev.store(), &cam, &ft, rc.cur_key, (int)S, rc.d_slot_of, &rc.ftr,
-                                                 &rc.seeds, &opt, d_status, d_xyz, d_px, d_state, ws, lane.workspace_bytes, lane.stream),
-                   "svo_hip_update_seeds_resident");
+    if (phase == 1) {
+      svo_hip::Device* const pd = &dev;
+      svo_hip::Arena* const pa = &a;
+      void* const st_ = lane.stream;
+      const size_t ws_bytes = lane.workspace_bytes;
+      const SeedStore::Call rcv = rc;
+      held = [pd, pa, st_, ws_bytes, rcv, cam, ft, opt, S, d_status, d_xyz, d_px, d_state, ws](const double* T_cur) {
+        svo_hip::check(svo_hip_update_seeds_resident_pose(&pd->layout(), pd->store(), &cam, &ft, rcv.cur_key, T_cur, (int)S, rcv.d_slot_of,
+                                                          &rcv.ftr, &rcv.seeds, &opt, d_status, d_xyz, d_px, d_state, ws, ws_bytes, st_),
+                       "svo_hip_update_seeds_resident_pose");
+        pa->download(st_);
+      };
+    } else {
+      svo_hip::check(svo_hip_update_seeds_resident(&dev.layout(), dev.store(), &cam, &ft, rc.cur_key, (int)S, rc.d_slot_of, &rc.ftr,
+                                                   &rc.seeds, &opt, d_status, d_xyz, d_px, d_state, ws, lane.workspace_bytes, lane.stream),
+                     "svo_hip_update_seeds_resident");
+    }
   } else {
     a.uploadAll(lane.stream);
     svo_hip::check(svo_hip_update_seeds(&dev.layout(), dev.store(), &cam, &ft, (int)S, d_cur, &ftr.dev, &seeds, &opt, d_status, d_xyz,
                                         d_px, ws, lane.workspace_bytes, lane.stream),
                    "svo_hip_update_seeds");
   }
-  a.download(lane.stream);
+  if (phase != 1) a.download(lane.stream);
 
   // ---- replay of the list surgery, in list order (:216-219, :238-245, :255-290) ---------------
   // Seeds are found again by Seed::id (ascending along the list): in deferred mode the list may have lost seeds
@@ -319,9 +376,11 @@ void DepthFilter::updateSeeds(FramePtr frame) {
   if (early) {
     // enqueued ahead of the reference's call: the kernels run while the host finishes the frame (see EarlyUpdate)
     stage_timer.unmarshal();  // this call's share is marshal + enqueue; taking it adds the wait and the replay
-    eu.valid = true;
+    eu.valid = phase != 1;
+    eu.prepared = phase == 1;
+    eu.launch.swap(held);
     eu.frame_id = frame->id_;
-    poseToRt(frame->T_f_w_, eu.T);
+    poseToRt(frame->T_f_w_, eu.T);  // (phase 1: not the final pose yet -- phase 2 writes the one it launches with)
     eu.ids = ids;
     eu.replay = replay;
     eu.store = store_guard.store;
@@ -330,6 +389,8 @@ void DepthFilter::updateSeeds(FramePtr frame) {
     EarlyUpdate* const peu = &eu;
     lane.early_drop = [peu, pdev]() {
       peu->valid = false;
+      peu->prepared = false;
+      peu->launch = nullptr;
       peu->replay = nullptr;
       pdev->countEarlyMapping(false);
       SeedStore* const st = peu->store;

@@ -68,23 +68,29 @@ void optimizeOnDevice(const double reproj_thresh, const size_t n_iter, const boo
 void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const bool verbose, FramePtr& frame,
                          double& estimated_scale, double& error_init, double& error_final, size_t& num_obs) {
   if (frame->fts_.empty()) return;
-  optimizeOnDevice(reproj_thresh, n_iter, verbose, frame, estimated_scale, error_init, error_final, num_obs);
-  // The frame's pose is final: a host that runs the depth filter WITHOUT its thread will hand the frame to updateSeeds after
-  // a few dozen microseconds of bookkeeping (frame_handler_mono.cpp:176-198) -- the filter's drop-in, when it has registered
-  // its hook on this thread's mapping lane, enqueues that update now (dropin/depth_filter.cpp: EarlyUpdate).  A frame the
-  // reference is about to give up (fewer than 20 observations left, :176) is not worth the launch.  (The tracking lane's
-  // mutex has been released: the hook takes the mapping lane's and the seed list's.)
-  if (svo_hip::Device::earlyMappingEnabled() && num_obs >= 20) {
+  // A host that runs the depth filter WITHOUT its thread will hand the frame to updateSeeds a few dozen microseconds of
+  // bookkeeping after this call returns (frame_handler_mono.cpp:176-198), with the pose this call fixes.  The filter's
+  // drop-in, when it has registered its hook on this thread's mapping lane, enqueues that update from here
+  // (dropin/depth_filter.cpp: EarlyUpdate), in two phases: 1 -- its tables are marshalled and uploaded NOW, while the
+  // refinement the reprojector predicted is still running on the device and this call would only wait for it; 2 -- the
+  // kernels are launched with the final pose (by value: svo_hip_update_seeds_resident_pose).  A frame the reference is
+  // about to give up (fewer than 20 observations left, :176) is not worth the launch: what phase 1 holds is then dropped
+  // by the next call on the mapping lane.  (The tracking lane's mutex is not held here: the hook takes the mapping
+  // lane's and the seed list's.)
+  auto early = [&frame](const int phase) {
+    if (!svo_hip::Device::earlyMappingEnabled()) return;
     svo_hip::Lane* ml = hip_dropin::ensureDevice(*frame).findLane(svo_hip::Device::LANE_MAPPING);
-    if (ml != NULL) {
-      std::function<void(const void*)> hook;
-      {
-        std::lock_guard<std::mutex> g(ml->mut);
-        hook = ml->early_hook;
-      }
-      if (hook) hook(&frame);
+    if (ml == NULL) return;
+    std::function<void(const void*, int)> hook;
+    {
+      std::lock_guard<std::mutex> g(ml->mut);
+      hook = ml->early_hook;
     }
-  }
+    if (hook) hook(&frame, phase);
+  };
+  early(1);
+  optimizeOnDevice(reproj_thresh, n_iter, verbose, frame, estimated_scale, error_init, error_final, num_obs);
+  if (num_obs >= 20) early(2);
 }
 
 namespace {

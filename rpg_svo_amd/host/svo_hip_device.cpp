@@ -327,6 +327,11 @@ void Device::countEarlyMapping(bool hit) {
   if (hit) ++stats.early_map_hits; else ++stats.early_map_misses;
 }
 
+void Device::countEarlyTwoPhase() {
+  std::lock_guard<std::mutex> g(stats_mut_);
+  ++stats.early_map_two_phase;
+}
+
 bool Device::earlyMappingEnabled() {
   static const bool on = [] {
     const char* v = std::getenv("SVO_HIP_EARLY_MAPPER");

@@ -139,7 +139,7 @@ struct Lane {
   // and the update's kernels run while the host finishes the frame.  `early_drop` is set while such an update is pending:
   // the real updateSeeds takes it (same frame, same pose, same seed list) or drops it; beginCall() of any other call on
   // the lane drops it (the arena is about to be refilled).
-  std::function<void(const void*)> early_hook;
+  std::function<void(const void*, int)> early_hook;  // (frame, phase: 1 = marshal + upload and hold, 2 = launch what is held -- or all of it)
   std::function<void()> early_drop;
   Arena arena;
   Arena arena_chain;      // the chain's INPUT blocks: filled and uploaded while K1 (whose inputs left with `arena`) is running
@@ -225,12 +225,13 @@ class Device {
     uint64_t spec_hits, spec_misses;  // pose refinements taken from / not taken from the reprojector's prediction
     uint64_t chain_hits, chain_misses;  // reprojections + matches taken from / not taken from the chain enqueued behind K1
     uint64_t early_map_hits, early_map_misses;  // depth-filter updates enqueued by the pose optimizer's drop-in: taken / dropped
+    uint64_t early_map_two_phase;               // ... of them launched in two phases (tables uploaded before the pose was known)
     uint64_t chain_miss_why[6];         // ... not taken because: 0 not this frame / drained, 1 pose bits, 2 keyframe ranking,
                                         //     3 the map moved on, 4 a capacity was exceeded on the device, 5 (spare)
     double pyr_upload_us;
     double marshal_us[N_STAGES], device_us[N_STAGES], unmarshal_us[N_STAGES], payload_bytes[N_STAGES];
     uint64_t n[N_STAGES];
-    Stats() : uploads(0), evictions(0), calls(0), spec_hits(0), spec_misses(0), chain_hits(0), chain_misses(0), early_map_hits(0), early_map_misses(0),
+    Stats() : uploads(0), evictions(0), calls(0), spec_hits(0), spec_misses(0), chain_hits(0), chain_misses(0), early_map_hits(0), early_map_misses(0), early_map_two_phase(0),
               pyr_upload_us(0) {
       for (int i = 0; i < 6; ++i) chain_miss_why[i] = 0;
       for (int i = 0; i < N_STAGES; ++i) { marshal_us[i] = device_us[i] = unmarshal_us[i] = payload_bytes[i] = 0; n[i] = 0; }
@@ -243,6 +244,7 @@ class Device {
   void countSpeculation(bool hit);
   void countChain(bool hit, int why = 0);
   void countEarlyMapping(bool hit);
+  void countEarlyTwoPhase();
   // SVO_HIP_EARLY_MAPPER=0: the depth filter's update is enqueued when the reference calls it, as up to round 5
   static bool earlyMappingEnabled();
   // the calling thread's lane of that role if it exists (no lane is created)

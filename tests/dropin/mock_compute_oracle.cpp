@@ -449,6 +449,20 @@ int svo_hip_update_seeds_resident(const svo_hip_pyr_layout* L, const uint8_t* st
   return SVO_HIP_OK;
 }
 
+int svo_hip_update_seeds_resident_pose(const svo_hip_pyr_layout* L, const uint8_t* store, const svo_hip_camera* cam, const svo_hip_frames* frames,
+                                       int cur_frame, const double* T_cur_f_w, int S, const int32_t* d_slot_of, const svo_hip_features* ftr,
+                                       const svo_hip_seeds* seeds, const svo_hip_depth_filter_options* opt, int32_t* d_status,
+                                       double* d_xyz_world, double* d_px_cur, float* d_state_out, void* ws, size_t ws_bytes, void* stream) {
+  // the frame table with row cur_frame replaced by the pose handed over by value
+  if (!T_cur_f_w || !frames || cur_frame < 0 || cur_frame >= frames->n_frames) return SVO_HIP_EINVAL;
+  std::vector<double> T(frames->d_T_f_w, frames->d_T_f_w + 12 * (size_t)frames->n_frames);
+  for (int k = 0; k < 12; ++k) T[12 * (size_t)cur_frame + k] = T_cur_f_w[k];
+  svo_hip_frames fr = *frames;
+  fr.d_T_f_w = T.data();
+  return svo_hip_update_seeds_resident(L, store, cam, &fr, cur_frame, S, d_slot_of, ftr, seeds, opt, d_status, d_xyz_world, d_px_cur,
+                                       d_state_out, ws, ws_bytes, stream);
+}
+
 int svo_hip_update_seed_batch(int S, const float* d_x, const float* d_tau2, const svo_hip_seeds* seeds, void*) {
   for (int s = 0; s < S; ++s) {
     orc_seed sd;

@@ -263,11 +263,11 @@ void pipe_chain_stats(uint64_t out[8]) {
 
 // the depth filter's update enqueued by the pose optimizer's drop-in (dropin/depth_filter.cpp, EarlyUpdate): updates the
 // reference's own updateSeeds call then found running and took / early updates that were dropped (hip flavour; zeros otherwise)
-void pipe_early_mapper_stats(uint64_t out[2]) {
-  out[0] = out[1] = 0;
+void pipe_early_mapper_stats(uint64_t out[3]) {
+  out[0] = out[1] = out[2] = 0;
 #ifdef SVO_PIPELINE_HIP
   const svo_hip::Device::Stats st = svo_hip::Device::instance().statsSnapshot();
-  out[0] = st.early_map_hits; out[1] = st.early_map_misses;
+  out[0] = st.early_map_hits; out[1] = st.early_map_misses; out[2] = st.early_map_two_phase;
 #endif
 }
 

@@ -117,7 +117,7 @@ class Pipeline:
 
     def early_mapper_stats(self):
         """(depth-filter updates enqueued by the pose optimizer's drop-in that updateSeeds took, ... that were dropped)."""
-        out = (C.c_uint64 * 2)()
+        out = (C.c_uint64 * 3)()
         self.lib.pipe_early_mapper_stats(out)
         return tuple(int(x) for x in out)
 
@@ -208,7 +208,7 @@ def run_sequence(flavour, cam, images, T_gt, stats_out=None, range0=None, **cfg)
                              frame_chain_miss_reasons=dict(zip(("not_this_frame", "pose_bits", "keyframe_ranking", "map_moved_on", "capacity"),
                                                                (b - a for a, b in zip(c0[2:7], c1[2:7])))))
             e1 = p.early_mapper_stats()
-            stats_out.update(early_mapper_taken=e1[0] - e0[0], early_mapper_dropped=e1[1] - e0[1])
+            stats_out.update(early_mapper_taken=e1[0] - e0[0], early_mapper_dropped=e1[1] - e0[1], early_mapper_two_phase=e1[2] - e0[2])
             m1 = p.mirror_stats()
             stats_out["map_mirror"] = dict(zip(("calls", "rebuilds", "fallbacks", "point_records_sent", "obs_records_sent",
                                                 "second_batches"), (b - a for a, b in zip(m0, m1))))
