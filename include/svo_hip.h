@@ -56,6 +56,17 @@ const char* svo_hip_version(void);
 /* number of visible HIP devices (<0 on error) */
 int svo_hip_device_count(void);
 
+/* Binds the CALLING THREAD to the CPUs next to the current device (the PCI function's local_cpulist in sysfs, intersected
+ * with the thread's present affinity mask).  Returns the number of CPUs of the new mask, 0 when nothing was changed (no
+ * NUMA information, nothing in common, already there), < 0 when the device could not be asked.  A single camera's frame
+ * is a dozen host <-> device hand-overs through pinned memory: on a two-socket host the same 600-frame sequence takes
+ * 0.263 ms per frame with the PROCESS bound to the GPU's own node (taskset), 0.268 on the other node and 0.280 wherever
+ * the scheduler puts and moves it (profiles/r06aa_*).  Binding only the calling thread -- what this function can do from
+ * inside -- did not reproduce that (profiles/r06ab_*: the runtime's own threads stay where they are), so nothing in the
+ * library calls it by default (the drop-in's host layer does with SVO_HIP_PIN_HOST=1): a host that wants the gain
+ * starts its process under `numactl --cpunodebind` / `taskset`, or calls this first thing in main(). */
+int svo_hip_pin_calling_thread(void);
+
 /* ---- raw device helpers for non-HIP host code (C++ host classes) -------- */
 int svo_hip_set_device(int device);
 int svo_hip_malloc(void** d_ptr, size_t bytes);

@@ -119,6 +119,7 @@ PROTOTYPES = {
     "svo_hip_last_hip_error": (_i, []),
     "svo_hip_version": (C.c_char_p, []),
     "svo_hip_device_count": (_i, []),
+    "svo_hip_pin_calling_thread": (_i, []),
     "svo_hip_set_device": (_i, [_i]),
     "svo_hip_malloc": (_i, [C.POINTER(_vp), C.c_size_t]),
     "svo_hip_free": (_i, [_vp]),

@@ -1,5 +1,12 @@
 // capi_util.hip -- error strings, raw device helpers and the pyramid-store
 // layout of the C ABI (include/svo_hip.h).  No kernels here.
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#include <sched.h>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
 #include <dlfcn.h>
 
 #include <cstring>
@@ -40,6 +47,46 @@ int svo_hip_device_count(void) {
     return SVO_HIP_ENODEV;
   }
   return n;
+}
+
+// The CPUs next to the current device (its PCI function's local_cpulist in sysfs), intersected with what the calling
+// thread may run on; the calling thread is bound to them.  See the header.
+int svo_hip_pin_calling_thread(void) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  char bdf[32] = {0};
+  if (e == hipSuccess) e = hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), dev);
+  if (e != hipSuccess) {
+    g_last_hip_error = static_cast<int>(e);
+    return SVO_HIP_EHIP;
+  }
+  for (char* c = bdf; *c; ++c) *c = (char)tolower(*c);
+  char path[128];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+  FILE* f = fopen(path, "r");
+  if (!f) return 0;  // (no sysfs, no NUMA information: nothing to do)
+  char list[4096] = {0};
+  const size_t n_read = fread(list, 1, sizeof(list) - 1, f);
+  fclose(f);
+  if (n_read == 0) return 0;
+  cpu_set_t allowed, want;
+  CPU_ZERO(&want);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return 0;
+  // "0-63,128-191"
+  int n_want = 0;
+  for (const char* c = list; *c;) {
+    while (*c && !isdigit((unsigned char)*c)) ++c;
+    if (!*c) break;
+    char* end;
+    long lo = strtol(c, &end, 10), hi = lo;
+    if (*end == '-') hi = strtol(end + 1, &end, 10);
+    c = end;
+    for (long k = lo; k <= hi && k < CPU_SETSIZE; ++k)
+      if (k >= 0 && CPU_ISSET((int)k, &allowed)) { CPU_SET((int)k, &want); ++n_want; }
+  }
+  if (n_want == 0 || n_want == CPU_COUNT(&allowed)) return 0;  // nothing in common, or nothing to narrow
+  if (sched_setaffinity(0, sizeof(want), &want) != 0) return 0;
+  return n_want;
 }
 
 int svo_hip_set_device(int device) {

@@ -159,6 +159,14 @@ Lane* Device::makeLane() {
     else if (m == "mirrored") arena_mode = Arena::MIRRORED;
     else if (m != "hybrid") throw Error("SVO_HIP_ARENA must be 'hybrid', 'mirrored' or 'mapped'");
   }
+  // SVO_HIP_PIN_HOST=1: the thread that gets a lane is bound to the CPUs next to the GPU (include/svo_hip.h).  Off by default:
+  // binding ONE thread of a process measured no gain (0.274 against 0.265 ms per frame, profiles/r06ab_*) where binding the whole
+  // process from outside -- `taskset` / `numactl --cpunodebind`, the runtime's own threads included -- is worth 6 % over an
+  // unpinned one (profiles/r06aa_*): a deployment choice, like GPU_MAX_HW_QUEUES.
+  {
+    const char* pin = std::getenv("SVO_HIP_PIN_HOST");
+    if (pin && pin[0] == '1') svo_hip_pin_calling_thread();
+  }
   Lane* l = new Lane();
   try {
     check(svo_hip_stream_create(&l->stream), "svo_hip_stream_create");

@@ -19,6 +19,7 @@ const char* svo_hip_strerror(int code) { return code == SVO_HIP_EINVAL ? "invali
 int svo_hip_last_hip_error(void) { return 0; }
 int svo_hip_device_count(void) { return 1; }
 int svo_hip_set_device(int) { return SVO_HIP_OK; }
+int svo_hip_pin_calling_thread(void) { return 0; }  // (no device: nothing to be next to)
 
 int svo_hip_malloc(void** p, size_t bytes) {  // page aligned, like the real allocations
   if (!p) return SVO_HIP_EINVAL;

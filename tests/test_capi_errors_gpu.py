@@ -55,3 +55,40 @@ def test_bad_arguments_are_rejected(hip_lib, gpu_device):
     assert b"invalid" in lib.svo_hip_strerror(EINVAL) and b"limit" in lib.svo_hip_strerror(ERANGE)
     torch.cuda.synchronize()  # nothing above may have poisoned the context
     assert int(buf.sum().item()) == 0
+
+
+def test_pin_calling_thread_stays_next_to_the_device(gpu_device):
+    """svo_hip_pin_calling_thread: in a process of its own (the mask is inherited by everything the process starts), the calling
+    thread ends up inside the device's local_cpulist -- or, on a host without NUMA information, where it was."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, glob, json\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import torch\n"
+        "from rpg_svo_amd import capi\n"
+        "lib = capi.load()\n"
+        "torch.zeros(1, device='cuda:0')\n"
+        "before = sorted(os.sched_getaffinity(0))\n"
+        "n = lib.svo_hip_pin_calling_thread()\n"
+        "after = sorted(os.sched_getaffinity(0))\n"
+        "p = torch.cuda.get_device_properties(0)\n"
+        "bdf = '%04x:%02x:%02x.0' % (getattr(p, 'pci_domain_id', 0), p.pci_bus_id, p.pci_device_id)\n"
+        "f = '/sys/bus/pci/devices/' + bdf + '/local_cpulist'\n"
+        "local = open(f).read().strip() if os.path.exists(f) else ''\n"
+        "print(json.dumps(dict(n=n, before=before, after=after, local=local)))\n")
+    q = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0, q.stderr[-2000:]
+    import json
+    r = json.loads(q.stdout.strip().splitlines()[-1])
+    assert r["n"] >= 0
+    if r["n"] == 0:
+        assert r["after"] == r["before"]
+        return
+    cpus = set()
+    for part in r["local"].split(","):
+        lo, _, hi = part.partition("-")
+        cpus |= set(range(int(lo), int(hi or lo) + 1))
+    assert len(r["after"]) == r["n"] and set(r["after"]) <= cpus and set(r["after"]) <= set(r["before"])
