@@ -32,6 +32,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import shutil
 import subprocess
 import sys
 import time
@@ -213,6 +214,9 @@ def compact_line(result: dict, details_path: str | None) -> dict:
         if isinstance(op, dict) and "hip_dropin" in op:
             legs["dropin_sequence"]["ms_hip_own_process"] = op["hip_dropin"]
             legs["dropin_sequence"]["ms_hip_deferred_mapper_own_process"] = op["hip_dropin_deferred_mapper"]
+            if "hip_dropin_bound_to_the_gpus_numa_node" in op:
+                legs["dropin_sequence"]["ms_hip_own_process_bound_to_gpu_numa_node"] = op["hip_dropin_bound_to_the_gpus_numa_node"]
+                legs["dropin_sequence"]["ms_hip_deferred_mapper_own_process_bound_to_gpu_numa_node"] = op.get("hip_dropin_deferred_mapper_bound_to_the_gpus_numa_node")
         if isinstance(ds.get("early_mapper"), dict):
             legs["dropin_sequence"]["early_mapper"] = ds["early_mapper"]
         if isinstance(ds.get("map_size"), dict):
@@ -1657,24 +1661,41 @@ def dropin_sequence(n_frames: int = 600) -> dict:
         no_chain = {"skipped": repr(e)}
     # The drop-in in a process of its own, as a host runs it (this process has been through every other leg by now -- a
     # dozen streams, the reference's own run, counters -- and measures the same frames 5-12 % slower): synchronous and deferred
-    # mapper alternating, three processes each (medians reported); same frames, same trajectory.
-    own = {"hip_dropin": [], "hip_dropin_deferred_mapper": []}
+    # mapper alternating, two processes each (medians reported); same frames, same trajectory.
+    own = {"hip_dropin": [], "hip_dropin_deferred_mapper": [], "hip_dropin_bound_to_the_gpus_numa_node": [],
+           "hip_dropin_deferred_mapper_bound_to_the_gpus_numa_node": []}
     own_same = True
+    # ... and bound (taskset) to the CPUs next to the GPU, as INTEGRATION.md recommends for a single camera: a frame is a dozen
+    # host <-> device hand-overs through pinned memory (scripts/numa_placement.py, profiles/r06aa_*)
+    local_cpus = None
     try:
-        for rep in range(3):
-            for key, dm in (("hip_dropin", 0), ("hip_dropin_deferred_mapper", 1)):
+        pr = torch.cuda.get_device_properties(0)
+        f = "/sys/bus/pci/devices/%04x:%02x:%02x.0/local_cpulist" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        local_cpus = open(f).read().strip() or None
+        if local_cpus is not None and not shutil.which("taskset"):
+            local_cpus = None
+    except Exception:
+        local_cpus = None
+    try:
+        for rep in range(2):
+            for key, dm, bound in (("hip_dropin", 0, False), ("hip_dropin_deferred_mapper", 1, False),
+                                   ("hip_dropin_bound_to_the_gpus_numa_node", 0, True),
+                                   ("hip_dropin_deferred_mapper_bound_to_the_gpus_numa_node", 1, True)):
+                if bound and local_cpus is None:
+                    continue
                 dump = tempfile.mktemp(suffix=".npy", dir="/tmp")
                 code = (f"import sys, json; sys.path.insert(0, {ROOT!r}); import bench; "
                         f"print(json.dumps(bench.dropin_hip_only({n_frames}, {dump!r}, defer_mapper={dm})))")
-                p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=300)
+                cmd = (["taskset", "-c", local_cpus] if bound else []) + [sys.executable, "-c", code]
+                p = subprocess.run(cmd, env=dict(os.environ), capture_output=True, text=True, timeout=300)
                 if p.returncode != 0:
                     raise RuntimeError(p.stderr[-300:])
                 r = json.loads(p.stdout.strip().splitlines()[-1])
                 own[key].append(r["tot_time"])
                 own_same = own_same and bool(np.array_equal(np.load(dump), Th))
                 os.unlink(dump)
-        own_process = {"hip_dropin": float(np.median(own["hip_dropin"])), "hip_dropin_deferred_mapper": float(np.median(own["hip_dropin_deferred_mapper"])),
-                       "runs": own, "trajectory_identical_to_this_process": own_same}
+        own_process = {k: float(np.median(v)) for k, v in own.items() if v}
+        own_process.update(runs=own, trajectory_identical_to_this_process=own_same, gpus_local_cpulist=local_cpus)
     except Exception as e:
         own_process = {"skipped": repr(e)}
     return {"frames": n_frames, "map_size": map_size, "host_pyramid_levels_built_of": host.get("host_pyramid"),

@@ -1,8 +1,5 @@
 // capi_util.hip -- error strings, raw device helpers and the pyramid-store
 // layout of the C ABI (include/svo_hip.h).  No kernels here.
-#ifndef _GNU_SOURCE
-#define _GNU_SOURCE
-#endif
 #include <sched.h>
 #include <cctype>
 #include <cstdio>

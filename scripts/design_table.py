@@ -79,6 +79,10 @@ def table(d: dict, src: str) -> str:
                  + (f"; in a process of its own: {ds['median_ms_per_frame_in_a_process_of_its_own']['hip_dropin']:.3f} / "
                     f"{ds['median_ms_per_frame_in_a_process_of_its_own']['hip_dropin_deferred_mapper']:.3f} ms"
                     if isinstance(ds.get("median_ms_per_frame_in_a_process_of_its_own"), dict) and "hip_dropin" in ds["median_ms_per_frame_in_a_process_of_its_own"] else "")
+                 + (f", bound to the GPU's NUMA node: {ds['median_ms_per_frame_in_a_process_of_its_own']['hip_dropin_bound_to_the_gpus_numa_node']:.3f} / "
+                    f"{ds['median_ms_per_frame_in_a_process_of_its_own']['hip_dropin_deferred_mapper_bound_to_the_gpus_numa_node']:.3f} ms"
+                    if isinstance(ds.get("median_ms_per_frame_in_a_process_of_its_own"), dict)
+                    and "hip_dropin_deferred_mapper_bound_to_the_gpus_numa_node" in ds["median_ms_per_frame_in_a_process_of_its_own"] else "")
                  + (f"; with `DepthFilter`'s own thread (the reference's default): {ds['median_ms_per_frame_mapper_thread']['hip_dropin']:.3f} against "
                     f"{ds['median_ms_per_frame_mapper_thread']['cpu_reference']:.3f} ms" if isinstance(ds.get("median_ms_per_frame_mapper_thread"), dict) else "") + ".")
     rc = d.get("reference_cameras") or {}
