@@ -154,6 +154,8 @@ def compact_line(result: dict, details_path: str | None) -> dict:
     c["roofline"] = _pick(result.get("roofline", {}), ("bound", "kernel", "achieved", "peak", "unit", "frac", "ms", "traffic",
                                                        "traffic_over_algorithmic", "algorithmic_bytes_per_launch",
                                                        "algorithmic_bytes_per_frame", "ms_last_10_launches", "kernel_ms_avg"))
+    if "frac_uses" in result.get("roofline", {}):
+        c["roofline"]["frac_uses"] = "kernel_ms_avg"  # (= ms: HIP events over the timed launches; ms_last_10_launches is the settled figure)
     if isinstance(result.get("roofline_valu"), dict):
         c["roofline"]["valu_busy_frac"] = result["roofline_valu"].get("frac")
     if isinstance(result.get("roofline_pose_optimize"), dict):
