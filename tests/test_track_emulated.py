@@ -266,3 +266,29 @@ def test_emulated_update_seeds_on_the_resident_store(emu_seeds, scene):
     free = np.ones(cap, bool)
     free[slot_of] = False
     assert (sS[2][free] == 77).all() and (fS[1][free] == 77).all() and (sS[5][free] == 77).all() and touched.sum() > 100
+    # svo_hip_update_seeds_resident_pose: the current frame's pose by value, its row of the table poisoned (a host that uploaded
+    # the tables before the pose was known) -- on a second store patched with the same records: the same bits
+    fS2 = [np.full(cap, 77, np.int32), np.full(cap, 77, np.int32), np.full(cap, 77, np.uint8), np.full((cap, 2), 77.0), np.full((cap, 3), 77.0), np.full((cap, 2), 77.0)]
+    sS2 = [np.full(cap, 77, np.float32) for _ in range(5)] + [np.full(cap, 77, np.int32)]
+    ftrS2, sdS2 = structs(fS2, sS2)
+    fp, sp = columns(list(range(S)))
+    ftp, sdp = structs(fp, sp)
+    sl = np.ascontiguousarray(slot_of)
+    patch = capi.SeedPatch(S, 0, sl.ctypes.data, ftp, sdp)
+    assert emu.svo_hip_seed_store_patch(C.byref(patch), C.byref(ftrS2), C.byref(sdS2), None) == 0
+    T_poisoned = T.copy()
+    T_cur = np.ascontiguousarray(T[scene.cur].copy())
+    T_poisoned[scene.cur] = np.nan
+    frames_p = capi.Frames(n_frames, 0, slots_f.ctypes.data, T_poisoned.ctypes.data)
+    ws[:] = 0xFF
+    st2, xyz2, px2, state2 = np.zeros(S, np.int32), np.zeros((S, 3)), np.zeros((S, 2)), np.zeros((4, S), np.float32)
+    assert emu.svo_hip_update_seeds_resident_pose(C.byref(layout), _p(store), C.byref(cam), C.byref(frames_p), int(scene.cur), _p(T_cur), S,
+                                                  _p(slot_of), C.byref(ftrS2), C.byref(sdS2), C.byref(dopt), _p(st2), _p(xyz2), _p(px2),
+                                                  _p(state2), _p(ws), C.c_size_t(ws.size), None) == 0
+    assert np.array_equal(st2, st1) and np.array_equal(px2, px1) and np.array_equal(xyz2[conv], xyz1[conv])
+    assert np.array_equal(state2[:, touched].view(np.int32), state[:, touched].view(np.int32))
+    for k in (0, 1, 2, 4):
+        assert np.array_equal(sS2[k].view(np.int32), sS[k].view(np.int32))
+    assert emu.svo_hip_update_seeds_resident_pose(C.byref(layout), _p(store), C.byref(cam), C.byref(frames_p), int(scene.cur), None, S,
+                                                  _p(slot_of), C.byref(ftrS2), C.byref(sdS2), C.byref(dopt), _p(st2), _p(xyz2), _p(px2),
+                                                  _p(state2), _p(ws), C.c_size_t(ws.size), None) == -1  # (EINVAL: no pose)
