@@ -286,7 +286,6 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_MINW) pose_opt_wave_kernel(c
   // ---- error scale (:45-60) and the median of chi2_vec_init (same residuals as iteration 0) ----
   double estimated_scale, med_init;
   {
-    uint32_t kf[NPL];
     unsigned long long kd[NPL];
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
@@ -296,12 +295,14 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_MINW) pose_opt_wave_kernel(c
       const double k = (double)kk[j];
       const double e0 = (ux[j] - x / z) * k, e1 = (uy[j] - y / z) * k;
       const double e2 = e0 * e0 + e1 * e1;
-      kf[j] = live[j] ? __float_as_uint((float)sqrt(e2)) : 0x7f800000u;
       kd[j] = live[j] ? (unsigned long long)__double_as_longlong(e2) : 0x7ff0000000000000ull;
     }
-    const float median_f = __uint_as_float(radix_select<NPL, uint32_t>(kf, n_err / 2, 30));
-    estimated_scale = (double)(1.48f * median_f);  // MADScaleEstimator::compute
     med_init = __longlong_as_double((long long)radix_select<NPL, unsigned long long>(kd, n_err / 2, 62));
+    // The scale estimator's median is over errors = (float)sqrt(e2) of the same observations (:52-56), rank n / 2 as well:
+    // sqrt and the conversion are monotone, so the rank-k error IS the image of the rank-k e2 -- one selection, not two
+    // (equal images of different e2 are the same value).
+    const float median_f = (float)sqrt(med_init);
+    estimated_scale = (double)(1.48f * median_f);  // MADScaleEstimator::compute
   }
 
   // ---- Gauss-Newton (:66-121) ----------------------------------------------------------

@@ -63,6 +63,10 @@ __device__ __forceinline__ uint8_t warp_sample(const float Ax, const float Ay, c
   const int xi = svo_dev::floor_to_int(u), yi = svo_dev::floor_to_int(v);
   const float sx = __builtin_amdgcn_fractf(u), sy = __builtin_amdgcn_fractf(v);
   const uint8_t* q = reg_o + (__mul24(yi, 48) + xi);
+  // (Four 1-byte reads.  The two pixels of a row as ONE 2-byte read at any byte address -- the DS unit takes it, the
+  // compiler emits ds_read_u16 -- halves the LDS instructions of a sample and measured update_seeds 6.95 -> 9.17 ms,
+  // find_match_direct 1.60 -> 2.31: an unaligned DS access stalls the unit for far longer than the read it saves,
+  // profiles/r06ac_*.)
   const float val = warp_blend_pk(sx, sy, (float)q[0], (float)q[1], (float)q[48], (float)q[49]);
   return in ? (uint8_t)val : (uint8_t)0;
 }
