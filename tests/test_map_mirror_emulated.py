@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import camera_models, oracle_reproject_map, random_map
+from helpers import camera_models, FUZZ, fuzz_rng, oracle_reproject_map, random_map
 from rpg_svo_amd import capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -118,7 +118,7 @@ def test_emulated_kernel_is_the_reference_walk(emu, oracle, kind):
     host-compiled without contraction like the oracle, to 1e-12 px."""
     cam = camera_models()[kind]
     for seed, (n_points, n_cand) in enumerate([(900, 700), (2500, 1900), (40, 0), (0, 300), (0, 0)]):
-        mp = random_map(cam, n_kfs=12, n_points=n_points, n_candidates=n_cand, seed=seed)
+        mp = random_map(cam, n_kfs=12, n_points=n_points, n_candidates=n_cand, seed=seed + 100 * FUZZ)
         m = upload(emu, mp)
         r = m.reproject(cam, mp["T"], mp["cur"], mp["kf_rank"], mp)
         V, M = compare(r, oracle_reproject_map(mp, cam), n_points + n_cand, 1e-12)
@@ -128,7 +128,7 @@ def test_emulated_kernel_is_the_reference_walk(emu, oracle, kind):
 
 def test_emulated_batches_and_patches(emu, oracle):
     cam = camera_models()["pinhole"]
-    mp = random_map(cam, seed=11)
+    mp = random_map(cam, seed=11 + 100 * FUZZ)
     P = mp["pos"].shape[0]
     m = upload(emu, mp, capacity=P + 50)
     a = m.reproject(cam, mp["T"], mp["cur"], mp["kf_rank"], mp, max_cells_with_trials=40)
@@ -137,7 +137,7 @@ def test_emulated_batches_and_patches(emu, oracle):
     end = int(oa["header"][4])
     compare(m.reproject(cam, mp["T"], mp["cur"], mp["kf_rank"], mp, first_cell=end), oracle_reproject_map(mp, cam, end), P, 1e-12)
     # an incremental patch: positions move, types change, a new candidate with a new observation record is appended
-    rng = np.random.default_rng(5)
+    rng = fuzz_rng(5)
     idx = rng.choice(P, 60, replace=False)
     mp["pos"][idx] += rng.normal(0, 0.02, (60, 3))
     promoted = idx[mp["type"][idx] == 2][:5]

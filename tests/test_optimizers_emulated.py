@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from helpers import camera_models
+from helpers import FUZZ, camera_models, fuzz_rng
 from oracle import pytrack
 from rpg_svo_amd import capi, se3, synth
 
@@ -28,7 +28,7 @@ def emu_default():
 
 @pytest.fixture(scope="module", params=["pinhole", "atan"])
 def scene(request):
-    return synth.make_track_scene(n_kf=4, n_feat=100, cam=camera_models()[request.param])
+    return synth.make_track_scene(n_kf=4, n_feat=100, cam=camera_models()[request.param], seed=777 + FUZZ)
 
 
 def _p(a):
@@ -51,7 +51,7 @@ def pose_optimize(emu, cam, n, f, level, pos, hp, T0, thresh, n_iter, entry="svo
 @pytest.mark.parametrize("ordered", [True, False], ids=["ordered", "wave"])
 def test_emulated_pose_optimize(emu, oracle, scene, ordered):
     orc = pytrack.Track("orc")
-    rng = np.random.default_rng(2)
+    rng = fuzz_rng(2)
     P = len(scene.pt_pos)
     B, ns = 12, P
     f = synth._bearing(scene.cam, scene.px_true + rng.normal(size=(P, 2)) * 0.3)
@@ -71,18 +71,21 @@ def test_emulated_pose_optimize(emu, oracle, scene, ordered):
         if not o["ran"]:
             assert np.array_equal(Tg[b], T0[b]) and np.array_equal(hpg[b], hp[b])
             continue
+        if FUZZ and int(hp[b, :n[b]].sum()) < 6:  # (rank-deficient or nearly: see tests/test_tracking_gpu.py::test_pose_optimize)
+            assert np.isfinite(Tg[b]).all() == np.isfinite(o["T_f_w"]).all(), b
+            continue
         assert se3.log_norm(Tg[b][None], o["T_f_w"][None])[0] < (1e-10 if ordered else 1e-9), b
         assert np.array_equal(hpg[b, :n[b]], o["has_point"]), b
         assert stats[b, 3] == o["num_obs"]
         assert np.allclose(stats[b, :3], [o["estimated_scale"], o["error_init"], o["error_final"]], rtol=1e-9, atol=1e-12)
         if n[b] >= 40:
             assert np.allclose(Cov[b].reshape(6, 6), o["Cov"], rtol=1e-6, atol=1e-14), b
-    assert se3.log_norm(Tg[0][None], scene.T_f_w[scene.cur][None])[0] < 2e-3
+    assert se3.log_norm(Tg[0][None], scene.T_f_w[scene.cur][None])[0] < (5e-3 if FUZZ else 2e-3)
 
 
 def test_emulated_pose_optimize_deferred(emu, scene):
     """(tests/test_tracking_gpu.py::test_pose_optimize_deferred)"""
-    rng = np.random.default_rng(4)
+    rng = fuzz_rng(4)
     P = min(len(scene.pt_pos), 200)
     B = 6
     pt_pos = scene.pt_pos[:P]
@@ -114,7 +117,7 @@ def test_emulated_pose_optimize_deferred(emu, scene):
 def test_emulated_point_optimize(emu_default, oracle, scene):
     emu = emu_default
     orc = pytrack.Track("orc")
-    rng = np.random.default_rng(4)
+    rng = fuzz_rng(4)
     T = np.ascontiguousarray(scene.T_f_w)
     slots = np.arange(T.shape[0], dtype=np.int32)
     frames = capi.Frames(T.shape[0], 0, slots.ctypes.data, T.ctypes.data)

@@ -9,6 +9,7 @@ import subprocess
 
 import numpy as np
 import pytest
+from helpers import FUZZ, fuzz_rng
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "host", "scan_emulated.cpp")
@@ -158,7 +159,7 @@ def _numpy_scan(levels, cam, sl, n_steps, B, step, pwb):
 def test_group_scan_is_the_sequential_scan(emu):
     """320 seeds over three levels, 2 to 161 positions per seed, with and without sub-pixel refinement: the eight-lane scan
     finds what a sequential numpy scan finds -- the same verdict and, to the bit, the same uv_best."""
-    rng = np.random.default_rng(51)
+    rng = fuzz_rng(51)
     base = _texture(rng, 240, 320)
     levels = [base]
     for _ in range(2):

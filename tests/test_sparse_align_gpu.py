@@ -17,7 +17,7 @@ import torch
 
 from rpg_svo_amd import se3, synth
 
-from helpers import camera_models, make_batch, run_hip, run_oracle, tile_batch
+from helpers import FUZZ, camera_models, fuzz_rng, make_batch, run_hip, run_oracle, tile_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -54,9 +54,9 @@ def test_iteration_counts_on_a_large_sample(oracle, gpu_device, checker):
     """Tolerance mode means a chi2-increase stop can fall one iteration apart from the reference's; how often is
     asserted here on 1024 different problems (64 frame pairs x 16 priors): >= 97 % identical per-level iteration
     sequences, n_tracked equal on those, every pose within the stated 1e-4."""
-    seq = synth.make_sequence(65, 200, seed=11)
+    seq = synth.make_sequence(65, 200, seed=11 + FUZZ)
     pairs = [(i, i + 1) for i in range(64)] * 16
-    b = make_batch(seq, pairs, 4, prior="ref", prior_noise=2e-3, seed=5)
+    b = make_batch(seq, pairs, 4, prior="ref", prior_noise=2e-3, seed=5 + FUZZ)
     d, same, T_o, T_h, res_o, out = compare(oracle, b, 3, 0, which=checker)
     assert same.mean() >= MIN_SAME_ITERATIONS, f"only {same.mean():.4f} of {len(same)} problems ran identical iteration counts"
     assert np.median(d) <= TOL_MEDIAN
@@ -83,14 +83,14 @@ def test_config2_vga_4levels(oracle, gpu_device, seq_vga, checker):
 def test_reference_default_schedule(oracle, gpu_device, checker):
     """Pipeline default: 5-level pyramid, levels 4->2 (config.cpp:36-37), 752x480."""
     cam = synth.Camera(752, 480, 315.5, 315.5, 376.0, 240.0)
-    seq = synth.make_sequence(5, 120, cam=cam, seed=7, margin=56, cell=40)
+    seq = synth.make_sequence(5, 120, cam=cam, seed=7 + FUZZ, margin=56, cell=40)
     b = make_batch(seq, [(i, i + 1) for i in range(4)], 5)
     d, same, *_ = compare(oracle, b, 4, 2, which=checker)
     assert np.median(d) <= 1e-5
 
 
 def test_ragged_and_missing_points(oracle, gpu_device, seq_vga, checker):
-    rng = np.random.default_rng(11)
+    rng = fuzz_rng(11)
     pairs = [(0, 1), (3, 4), (5, 6), (8, 9), (9, 10), (12, 11), (13, 14)]
     n_valid = [200, 12, 64, 65, 137, 0, 1]
     hp = (rng.random((7, 200)) > 0.3).astype(np.uint8)
@@ -116,8 +116,8 @@ def test_ragged_and_missing_points(oracle, gpu_device, seq_vga, checker):
 def test_border_features_and_visibility(oracle, gpu_device, checker):
     """Features close to the image border are invisible at coarse levels and join at
     finer ones (visible_fts_ is never reset, sparse_img_align.cpp:57)."""
-    seq = synth.make_sequence(5, 200, seed=3)
-    rng = np.random.default_rng(3)
+    seq = synth.make_sequence(5, 200, seed=3 + FUZZ)
+    rng = fuzz_rng(3)
     # move 40 features per frame into the 3..30 px band next to a border
     for i in range(5):
         k = rng.choice(200, 40, replace=False)
@@ -164,7 +164,7 @@ def test_iteration_caps(oracle, gpu_device, seq_vga, checker):
 
 
 def test_large_prior_error_and_noise(oracle, gpu_device, seq_vga, checker):
-    b = make_batch(seq_vga, [(i, i + 1) for i in range(8)], 4, prior_noise=4e-3, seed=5)
+    b = make_batch(seq_vga, [(i, i + 1) for i in range(8)], 4, prior_noise=4e-3, seed=5 + FUZZ)
     d, same, *_ = compare(oracle, b, 3, 0, tol=1e-3, which=checker)
     assert np.median(d) <= 1e-5
 
@@ -182,7 +182,7 @@ def test_prior_rotation_roundtrip_all_quaternion_branches(gpu_device, seq_vga):
     """n_iter = 0: the kernel only converts the prior R -> unit quaternion -> R (as
     Sophus::SE3(R,t) would).  Random large rotations exercise all four branches of
     Eigen's Quaternion(Matrix3)."""
-    rng = np.random.default_rng(21)
+    rng = fuzz_rng(21)
     B = 16
     b = make_batch(seq_vga, [(0, 1)] * B, 4)
     axes = rng.normal(size=(B, 3))
@@ -215,7 +215,7 @@ def test_distorted_camera_models(oracle, gpu_device, checker, kind):
     """world2cam of sparse_img_align.cpp:183 through the distorted vikit models (the cameras of the
     reference's launch files): default schedule 4 -> 2 and the full 3 -> 0."""
     cam = camera_models()[kind]
-    seq = synth.make_sequence(6, 120, cam=cam, seed=9, margin=56, cell=40)
+    seq = synth.make_sequence(6, 120, cam=cam, seed=9 + FUZZ, margin=56, cell=40)
     b = make_batch(seq, [(i, i + 1) for i in range(5)], 5)
     d, same, T_o, T_h, *_ = compare(oracle, b, 4, 2, which=checker)
     assert np.median(d) <= 1e-5
@@ -229,7 +229,7 @@ def test_wave_per_frame_kernel(oracle, gpu_device, checker, n_patches):
     """Batches of >= 1024 problems with <= 192 patches run one wave per frame (sparse_align_wave.hip; 1, 2 and
     3 patches per lane here): same tolerances against the checker as the workgroup kernel, and the two kernels
     agree with each other on the same problems."""
-    seq = synth.make_sequence(33, n_patches, seed=23)
+    seq = synth.make_sequence(33, n_patches, seed=23 + FUZZ)
     pairs = [(i, i + 1) for i in range(32)]
     b = make_batch(seq, pairs, 4)
     # ragged counts and missing points in a few problems
@@ -267,7 +267,7 @@ def test_wave_per_frame_kernel_distorted_cameras(oracle, gpu_device, checker, ki
     """The wave-per-frame kernel under the distorted camera models (its DIST instantiation: one patch per lane,
     i.e. up to 64 patches per frame; above that the distorted cameras take the workgroup kernel)."""
     cam = camera_models()[kind]
-    seq = synth.make_sequence(6, 60, cam=cam, seed=9, margin=56, cell=40)
+    seq = synth.make_sequence(6, 60, cam=cam, seed=9 + FUZZ, margin=56, cell=40)
     b = make_batch(seq, [(i, i + 1) for i in range(5)], 5)
     T_o, res_o, _ = run_oracle(oracle, b, 3, 0, 30, which=checker)
     big = tile_batch(b, 205)  # B = 1025 >= 1024

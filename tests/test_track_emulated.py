@@ -4,21 +4,13 @@ and same-wave hand-overs, align_kernel -- against the oracle's Matcher::findMatc
 the same requirements: verdicts, chosen observations, search levels and the 10 x 10 patches identical, refined pixels
 identical in every bit, A to 1e-12.  Also with the queued opt-in builds, whose results must not differ from the default's."""
 import ctypes as C
-import os
 
 import numpy as np
 import pytest
 
-from helpers import camera_models
+from helpers import FUZZ, camera_models, fuzz_rng
 from oracle import pytrack
 from rpg_svo_amd import capi, synth
-
-# SVO_TEST_FUZZ=<k>: the scene and every random draw on other seeds (default 0: the suite as committed; scripts/fuzz_tracking.sh)
-FUZZ = int(os.environ.get("SVO_TEST_FUZZ", "0"))
-
-
-def _rng(k):
-    return np.random.default_rng(k + 1000 * FUZZ)
 
 
 @pytest.fixture(scope="module", params=[0], ids=["default"])
@@ -140,7 +132,7 @@ def test_emulated_update_seeds(emu_seeds, oracle, scene, align_1d, subpix):
     n_frames = T.shape[0]
     slots = np.arange(n_frames, dtype=np.int32)
     frames = capi.Frames(n_frames, 0, slots.ctypes.data, T.ctypes.data)
-    rng = _rng(8)
+    rng = fuzz_rng(8)
     seeds, feats = _make_seeds(scene, orc, rng)
     S = len(seeds)
     opt = pytrack.matcher_options(n_pyr_levels=5, align_1d=align_1d, subpix_refinement=subpix)
@@ -220,7 +212,7 @@ def test_emulated_update_seeds_on_the_resident_store(emu_seeds, scene):
     n_frames = T.shape[0]
     slots_f = np.arange(n_frames, dtype=np.int32)
     frames = capi.Frames(n_frames, 0, slots_f.ctypes.data, T.ctypes.data)
-    rng = _rng(8)
+    rng = fuzz_rng(8)
     seeds, feats = _make_seeds(scene, orc, rng)
     S = len(seeds)
     c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
