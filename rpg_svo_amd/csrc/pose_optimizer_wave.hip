@@ -2,8 +2,8 @@
 // WAVE per frame, several frames per workgroup, no workgroup barrier and no LDS.
 //
 // Replaces svo::pose_optimizer::optimizeGaussNewton (svo/src/pose_optimizer.cpp:28-161) to a
-// stated tolerance (pose within 1e-9 of the reference, SE(3) log-map norm; pruning decisions are
-// taken with IEEE sqrt on the same residuals).  The bit-ordered variant that reproduces the
+// stated tolerance (pose within 1e-9 of the reference, SE(3) log-map norm; pruning decisions on
+// the residuals of that pose: e2 > thresh^2).  The bit-ordered variant that reproduces the
 // reference's summation order (pose_optimizer.hip, svo_hip_pose_optimize_ordered) stays as the
 // checker; this kernel is what the pipeline runs:
 //
@@ -94,10 +94,12 @@ __device__ __forceinline__ double fast_sqrt(double x) {
   const double h = 0.5 * r;
   g = fma(fma(-g, g, x), h, g);
   g = fma(fma(-g, g, x), h, g);
-  return x > 0.0 ? g : 0.0;
+  return fmax(g, 0.0);  // x == 0: rsq is +inf and g a NaN, which the maximum drops (one v_max_f64 for a compare and two selects)
 }
 
-// ldlt6_factor (device_math.h) with the six pivot reciprocals by v_rcp_f64 + Newton
+// ldlt6_factor (device_math.h) with the six pivot reciprocals by v_rcp_f64 + Newton.  A vanished pivot leaves LD[15 + j] = 0
+// and a column that means nothing (v * 0: ldlt6_factor keeps v): the only caller hands such a frame to the ordered kernel
+// (pivots_ok) before anything reads the factor -- fifteen selects per Gauss-Newton iteration less.
 __device__ __forceinline__ void ldlt6_factor_fast(const double H[21], double LD[21]) {
   double d[6];
 #pragma unroll
@@ -114,7 +116,7 @@ __device__ __forceinline__ void ldlt6_factor_fast(const double H[21], double LD[
       double v = H[sym6(j, i)];
 #pragma unroll
       for (int k = 0; k < j; ++k) v -= LD[low6(i, k)] * LD[low6(j, k)] * d[k];
-      LD[low6(i, j)] = ok ? v * inv : v;
+      LD[low6(i, j)] = v * inv;
     }
   }
 }
@@ -242,6 +244,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_MINW) pose_opt_wave_kernel(c
   if (b >= a.B) return;
   int n = a.n[b];
   n = n < 0 ? 0 : (n > a.n_stride ? a.n_stride : n);  // contract: n <= n_stride (svo_hip.h); never read past the row
+  n = __builtin_amdgcn_readfirstlane(n);              // (the wave's frame: the same in every lane -- scalar branches on it below)
   const size_t base = (size_t)b * a.n_stride;
   const double focal = fabs(a.cam.fx);
 
@@ -288,12 +291,16 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_MINW) pose_opt_wave_kernel(c
   {
     unsigned long long kd[NPL];
 #pragma unroll
+    for (int j = 0; j < NPL; ++j) kd[j] = 0x7ff0000000000000ull;
+#pragma unroll
     for (int j = 0; j < NPL; ++j) {
+      if (j == NPL - 1 && j * 64 >= n) continue;  // (uniform: kd[j] stays +inf)
       const double x = R[0] * px[j] + R[1] * py[j] + R[2] * pz[j] + T.t[0];
       const double y = R[3] * px[j] + R[4] * py[j] + R[5] * pz[j] + T.t[1];
       const double z = R[6] * px[j] + R[7] * py[j] + R[8] * pz[j] + T.t[2];
       const double k = (double)kk[j];
-      const double e0 = (ux[j] - x / z) * k, e1 = (uy[j] - y / z) * k;
+      const double zi = fast_rcp(z);  // (as in the iterations below: the same residuals as iteration 0)
+      const double e0 = (ux[j] - x * zi) * k, e1 = (uy[j] - y * zi) * k;
       const double e2 = e0 * e0 + e1 * e1;
       kd[j] = live[j] ? (unsigned long long)__double_as_longlong(e2) : 0x7ff0000000000000ull;
     }
@@ -321,6 +328,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_MINW) pose_opt_wave_kernel(c
     for (int k = 0; k < 32; ++k) acc[k] = 0.0;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
+      if (j == NPL - 1 && j * 64 >= n) continue;  // (uniform) a slot no observation of the frame reaches: its terms would be w = 0 times finite numbers
       const double x = R[0] * px[j] + R[1] * py[j] + R[2] * pz[j] + T.t[0];
       const double y = R[3] * px[j] + R[4] * py[j] + R[5] * pz[j] + T.t[1];
       const double z = R[6] * px[j] + R[7] * py[j] + R[8] * pz[j] + T.t[2];
@@ -435,20 +443,27 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_MINW) pose_opt_wave_kernel(c
 
   // ---- prune outliers (:128-145) and the median of chi2_vec_final ---------------------------
   const double reproj_thresh_scaled = a.reproj_thresh / focal;
+  const double reproj_thresh2 = reproj_thresh_scaled * reproj_thresh_scaled;
   int n_deleted = 0;
   double med_final;
   {
     unsigned long long kd[NPL];
 #pragma unroll
+    for (int j = 0; j < NPL; ++j) kd[j] = 0x7ff0000000000000ull;
+#pragma unroll
     for (int j = 0; j < NPL; ++j) {
+      if (j == NPL - 1 && j * 64 >= n) continue;  // (uniform: kd[j] stays +inf)
       const double x = R[0] * px[j] + R[1] * py[j] + R[2] * pz[j] + T.t[0];
       const double y = R[3] * px[j] + R[4] * py[j] + R[5] * pz[j] + T.t[1];
       const double z = R[6] * px[j] + R[7] * py[j] + R[8] * pz[j] + T.t[2];
       const double k = (double)kk[j];
-      const double e0 = (ux[j] - x / z) * k, e1 = (uy[j] - y / z) * k;
+      const double zi = fast_rcp(z);
+      const double e0 = (ux[j] - x * zi) * k, e1 = (uy[j] - y * zi) * k;
       const double e2 = e0 * e0 + e1 * e1;
       kd[j] = live[j] ? (unsigned long long)__double_as_longlong(e2) : 0x7ff0000000000000ull;
-      const bool prune = live[j] && sqrt(e2) > reproj_thresh_scaled;
+      // e.norm() > reproj_thresh_scaled (:136) as e2 > thresh^2: the pose this kernel arrives at differs from the reference's
+      // by up to 1e-9, which moves e2 by far more than the rounding of a division or a square root -- no decision hangs on them
+      const bool prune = live[j] && e2 > reproj_thresh2;
       if (prune) a.has_point[base + j * 64 + lane] = 0;  // (*it)->point = NULL
       n_deleted += __popcll(__ballot(prune));
     }
