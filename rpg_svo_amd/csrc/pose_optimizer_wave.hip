@@ -100,6 +100,8 @@ __device__ __forceinline__ double fast_sqrt(double x) {
 // ldlt6_factor (device_math.h) with the six pivot reciprocals by v_rcp_f64 + Newton.  A vanished pivot leaves LD[15 + j] = 0
 // and a column that means nothing (v * 0: ldlt6_factor keeps v): the only caller hands such a frame to the ordered kernel
 // (pivots_ok) before anything reads the factor -- fifteen selects per Gauss-Newton iteration less.
+// (Skipping the fourth observation slot of a frame of <= 192 observations behind a scalar branch: five more 8-byte spills,
+// 0.232 -> 0.235 ms, profiles/r06ag_*.)
 __device__ __forceinline__ void ldlt6_factor_fast(const double H[21], double LD[21]) {
   double d[6];
 #pragma unroll
@@ -244,7 +246,6 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_MINW) pose_opt_wave_kernel(c
   if (b >= a.B) return;
   int n = a.n[b];
   n = n < 0 ? 0 : (n > a.n_stride ? a.n_stride : n);  // contract: n <= n_stride (svo_hip.h); never read past the row
-  n = __builtin_amdgcn_readfirstlane(n);              // (the wave's frame: the same in every lane -- scalar branches on it below)
   const size_t base = (size_t)b * a.n_stride;
   const double focal = fabs(a.cam.fx);
 
@@ -291,10 +292,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_MINW) pose_opt_wave_kernel(c
   {
     unsigned long long kd[NPL];
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) kd[j] = 0x7ff0000000000000ull;
-#pragma unroll
     for (int j = 0; j < NPL; ++j) {
-      if (j == NPL - 1 && j * 64 >= n) continue;  // (uniform: kd[j] stays +inf)
       const double x = R[0] * px[j] + R[1] * py[j] + R[2] * pz[j] + T.t[0];
       const double y = R[3] * px[j] + R[4] * py[j] + R[5] * pz[j] + T.t[1];
       const double z = R[6] * px[j] + R[7] * py[j] + R[8] * pz[j] + T.t[2];
@@ -328,7 +326,6 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_MINW) pose_opt_wave_kernel(c
     for (int k = 0; k < 32; ++k) acc[k] = 0.0;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
-      if (j == NPL - 1 && j * 64 >= n) continue;  // (uniform) a slot no observation of the frame reaches: its terms would be w = 0 times finite numbers
       const double x = R[0] * px[j] + R[1] * py[j] + R[2] * pz[j] + T.t[0];
       const double y = R[3] * px[j] + R[4] * py[j] + R[5] * pz[j] + T.t[1];
       const double z = R[6] * px[j] + R[7] * py[j] + R[8] * pz[j] + T.t[2];
@@ -449,10 +446,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_MINW) pose_opt_wave_kernel(c
   {
     unsigned long long kd[NPL];
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) kd[j] = 0x7ff0000000000000ull;
-#pragma unroll
     for (int j = 0; j < NPL; ++j) {
-      if (j == NPL - 1 && j * 64 >= n) continue;  // (uniform: kd[j] stays +inf)
       const double x = R[0] * px[j] + R[1] * py[j] + R[2] * pz[j] + T.t[0];
       const double y = R[3] * px[j] + R[4] * py[j] + R[5] * pz[j] + T.t[1];
       const double z = R[6] * px[j] + R[7] * py[j] + R[8] * pz[j] + T.t[2];
