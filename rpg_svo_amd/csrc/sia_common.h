@@ -139,6 +139,15 @@ __device__ __forceinline__ void cut_row5_plain(const uint32_t d[3], uint32_t bo,
   out[4] = (float)(hi & 0xffu);
 }
 
+// 1 / z as v_rcp_f64 + two Newton steps (the IEEE division sequence is three times as long; K1 is a tolerance-mode kernel
+// and its agreement with the reference's translation unit is the same to six digits either way: profiles/r06ah_*)
+__device__ __forceinline__ double sia_rcp(double z) {
+  double r = __builtin_amdgcn_rcp(z);
+  r = fma(fma(-z, r, 1.0), r, r);
+  r = fma(fma(-z, r, 1.0), r, r);
+  return r;
+}
+
 // ---- window cache (template parameter WC) --------------------------------------------------------------
 // The 5x5 window of the current image moves by a fraction of a pixel per Gauss-Newton iteration,
 // yet re-fetching it every iteration misses L2 (128 resident problems per XCD x ~64 KB of touched

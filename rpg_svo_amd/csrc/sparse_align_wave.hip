@@ -107,9 +107,10 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
       p.Y = a.xyz[3 * fo + 1];
       p.Z = a.xyz[3 * fo + 2];
     }
-    p.zi = (float)(1.0 / p.Z);
-    p.xn = (float)(p.X / p.Z);
-    p.yn = (float)(p.Y / p.Z);
+    const double rz = sia_rcp(p.Z);  // (as sparse_align.hip: the two kernels keep the same per-patch arithmetic)
+    p.zi = (float)rz;
+    p.xn = (float)(p.X * rz);
+    p.yn = (float)(p.Y * rz);
     p.Sxx = p.Sxy = p.Syy = 0.f;
     p.gmask = 0.f;
     p.vis = false;
@@ -464,7 +465,7 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
             const double bkj = g.Hinv[kk * 6 + gj];
             const double aij = g.A[lane];
             const double bij = g.Hinv[lane];
-            const double ip = (fabs(pv) > 2.2250738585072014e-308) ? 1.0 / pv : 0.0;
+            const double ip = (fabs(pv) > 2.2250738585072014e-308) ? sia_rcp(pv) : 0.0;
             const double na = (gi == kk) ? akj * ip : aij - aik * (akj * ip);
             const double nb = (gi == kk) ? bkj * ip : bij - aik * (bkj * ip);
             SVO_LANES_LDS_FENCE();
