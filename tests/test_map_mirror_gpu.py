@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import CAMERA_KINDS, camera_models, oracle_reproject_map, random_map
+from helpers import CAMERA_KINDS, camera_models, FUZZ, fuzz_rng, oracle_reproject_map, random_map
 from rpg_svo_amd import capi
 from rpg_svo_amd.map_mirror import Grid, MapMirror
 
@@ -56,7 +56,7 @@ def test_reproject_map_is_the_reference_walk(gpu_device, oracle, kind):
     cam = camera_models()[kind]
     tol = 1e-9   # (tests/test_tracking_gpu.py::test_reproject_points: same arithmetic, same bound)
     for seed, (n_points, n_cand) in enumerate([(900, 700), (2500, 1900), (40, 0), (0, 300), (0, 0)]):
-        mp = random_map(cam, n_kfs=12, n_points=n_points, n_candidates=n_cand, seed=seed)
+        mp = random_map(cam, n_kfs=12, n_points=n_points, n_candidates=n_cand, seed=seed + 100 * FUZZ)
         m = upload(mp, gpu_device)
         r = run(m, mp, cam, gpu_device)
         V, M = compare(r, oracle_reproject_map(mp, cam), n_points + n_cand, tol)
@@ -66,7 +66,7 @@ def test_reproject_map_is_the_reference_walk(gpu_device, oracle, kind):
 
 def test_batches_patches_and_capacities(gpu_device, oracle):
     cam = camera_models()["pinhole"]
-    mp = random_map(cam, seed=11)
+    mp = random_map(cam, seed=11 + 100 * FUZZ)
     P = mp["pos"].shape[0]
     m = upload(mp, gpu_device, capacity=P + 50)
     # the first batch (cells until 40 of them hold a trial), then the rest from end_cell
@@ -77,7 +77,7 @@ def test_batches_patches_and_capacities(gpu_device, oracle):
     compare(run(m, mp, cam, gpu_device, first_cell=end), oracle_reproject_map(mp, cam, end), P, 1e-9)
     # an incremental patch: positions move, types change (a point promoted, one deleted, a candidate gone), a new candidate
     # with a new observation record appended
-    rng = np.random.default_rng(5)
+    rng = fuzz_rng(5)
     idx = rng.choice(P, size=60, replace=False)
     mp["pos"][idx] += rng.normal(0, 0.05, (60, 3))
     mp["type"][idx[:10]] = 3
