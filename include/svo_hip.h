@@ -548,9 +548,13 @@ int svo_hip_frame_pose_compose(const double* d_T_cur_ref, const double* d_q_ref,
  * Observations of frame b are rows [b*n_stride, b*n_stride+d_n[b]); d_n[b] <= n_stride is the
  * caller's contract (the kernels clamp it, they never read past a frame's row).
  *   svo_hip_pose_optimize          one wave per frame, f64 sums reduced by a wave butterfly:
- *                                  pose within 1e-9 (SE(3) log norm) of the reference, pruning
- *                                  decisions and medians exact.  n_stride > 256 runs the
- *                                  ordered kernel.
+ *                                  pose within 1e-9 (SE(3) log norm) of the reference on a frame of
+ *                                  20 or more observations (measured: 1e-15; a frame of five to
+ *                                  seven can amplify the summation order to 6e-9), medians exact
+ *                                  order statistics of that pose's residuals, pruning as
+ *                                  e2 > thresh^2 on them (the reference: e.norm() > thresh) -- the
+ *                                  reference's decisions on every frame of the tests.  n_stride > 256
+ *                                  runs the ordered kernel.
  *   svo_hip_pose_optimize_ordered  one workgroup per frame, sums in the reference's observation
  *                                  order (same normal equations as the reference, pose <= 1e-12;
  *                                  Cov_ to 1e-6 relative: pivoted LDLT here, Matrix6d::inverse()
