@@ -549,8 +549,10 @@ int svo_hip_frame_pose_compose(const double* d_T_cur_ref, const double* d_q_ref,
  * caller's contract (the kernels clamp it, they never read past a frame's row).
  *   svo_hip_pose_optimize          one wave per frame, f64 sums reduced by a wave butterfly:
  *                                  pose within 1e-9 (SE(3) log norm) of the reference on a frame of
- *                                  20 or more observations (measured: 1e-15; a frame of five to
- *                                  seven can amplify the summation order to 6e-9), medians exact
+ *                                  20 or more observations (measured: 1e-15; 2e-9 where the stop
+ *                                  decision at convergence falls the other way and leaves the last
+ *                                  step; a frame of five to seven observations can amplify the
+ *                                  summation order to 6e-9), medians exact
  *                                  order statistics of that pose's residuals, pruning as
  *                                  e2 > thresh^2 on them (the reference: e.norm() > thresh) -- the
  *                                  reference's decisions on every frame of the tests.  n_stride > 256
