@@ -184,7 +184,7 @@ __device__ __forceinline__ K radix_select(const K key[NPL], int k, int top_bit) 
     const K cand = prefix | ((K)1 << bit);
     int cnt = 0;
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) cnt += __popcll(__ballot(key[j] < cand));
+    for (int j = 0; j < NPL; ++j) cnt += __popcll(__ballot(key[j] < cand));  // (64-bit keys compared as doubles instead: no difference, profiles/r06al_*)
     if (cnt <= k) {
       prefix = cand;
       cnt_lo = cnt;
