@@ -182,6 +182,8 @@ def compact_line(result: dict, details_path: str | None) -> dict:
         legs["full_track"] = _pick(ft, ("ms_per_step", "frames_per_s", "skipped"))
         if isinstance(ft.get("stages_ms"), dict):
             legs["full_track"]["stages_ms"] = _num({k: v for k, v in ft["stages_ms"].items() if v >= 0.05}, 4)
+        if isinstance(ft.get("mapper_on_its_own_stream"), dict) and "ms_per_step" in ft["mapper_on_its_own_stream"]:
+            legs["full_track"]["ms_per_step_mapper_on_its_own_stream"] = _num(ft["mapper_on_its_own_stream"]["ms_per_step"], 4)
         if isinstance(ft.get("rooflines"), dict):
             legs["full_track"]["frac"] = _num({k: v.get("frac") for k, v in ft["rooflines"].items() if isinstance(v, dict)}, 3)
         if isinstance(ft.get("kernels"), dict):  # per kernel: [rocprof ms per step, fraction of the HBM roofline by compulsory bytes]
@@ -2341,6 +2343,34 @@ class FullTrack:
         mk()
         self.last = dict(match=m, pose=po, seed_status=status, px_proj=px)
 
+    def step_mapper_overlapped(self, T_cur_from_ref, s_map, pose_ready, mapper_done):
+        """The same step with DepthFilter::updateSeeds on a stream of its own -- the reference runs its depth filter in a
+        thread of its own (depth_filter.cpp:75-93, startThread) while the tracker is on the next frame: the mapper's update
+        of step i runs beside sparse alignment, matching and pose refinement of step i + 1.  The mapper reads a frame table
+        of its own (frame_T_mapper), which the tracker fills with the refined poses once the mapper's previous update has
+        finished with it; nothing else is shared between the two (seed state and the update's workspace are the mapper's,
+        matches and poses the tracker's)."""
+        tr = self.tr
+        B, N = self.B, self.N
+        if not hasattr(self, "frames_mapper"):
+            self.frame_T_mapper = self.frame_T.clone()
+            self.frames_mapper = tr.FrameTable(self.frames.slot, self.frame_T_mapper)
+        m, px = self.match_stage(T_cur_from_ref)
+        po = tr.optimize_gauss_newton(self.cam, self.n, self.f_new.view(B, N, 3), m.search_level.view(B, N),
+                                      self.pt_pos.view(B, N, 3), self.okb, self.frame_T[B + 1:], 2.0, 10, out=self.po)
+        trk = torch.cuda.current_stream(self.dev)
+        trk.wait_event(mapper_done)              # (the mapper's previous update has read its table)
+        self.frame_T_mapper[B + 1:].copy_(po.T_f_w)
+        pose_ready.record(trk)
+        with torch.cuda.stream(s_map):
+            s_map.wait_event(pose_ready)
+            for k, v in self.seed0.items():
+                getattr(self.seeds, k).copy_(v)
+            status, _, _ = self.df.update_seeds(self.store, self.cam, self.frames_mapper, self.seed_cur, self.seed_ftr, self.seeds, 0,
+                                                out=self.seed_out)
+            mapper_done.record(s_map)
+        return status
+
     def stage_ms(self, ev: Events):
         k = len(self.STAGES) + 1
         acc = {s: [] for s in self.STAGES}
@@ -2549,12 +2579,42 @@ def full_track_leg(W: Workload, sia, ev: Events, dev, rank, lib, with_parity: bo
     stages["sparse_align"] = float(np.mean([ev.ms(a, b) for a, b, _ in marks]))
     step_ms = float(np.mean([ev.ms(a, c) for a, _, c in marks]))
     d = full.describe()
+    # The same steps with the depth filter on a second stream, as the reference's mapper thread runs beside its tracker
+    # (FullTrack.step_mapper_overlapped): the period of a step in steady state, host wall clock around 2 x `steps` steps.
+    overlapped = None
+    if mode == "representative":
+        try:
+            status_serial = full.last["seed_status"].clone()
+            s_map = torch.cuda.Stream(dev)
+            pose_ready, mapper_done = torch.cuda.Event(), torch.cuda.Event()
+            mapper_done.record(torch.cuda.current_stream(dev))
+
+            def ostep():
+                W.run_align(sia, out=out)
+                return full.step_mapper_overlapped(out.T_cur_from_ref, s_map, pose_ready, mapper_done)
+
+            ostep()
+            torch.cuda.synchronize()
+            n_o = 2 * steps
+            t0 = time.perf_counter()
+            for _ in range(n_o):
+                st_o = ostep()
+            torch.cuda.synchronize()
+            o_ms = (time.perf_counter() - t0) / n_o * 1e3
+            overlapped = {"ms_per_step": o_ms, "frames_per_s": W.B / o_ms * 1e3, "steps": n_o,
+                          "same_seed_statuses_as_the_serial_step": bool(torch.equal(st_o, status_serial)),
+                          "what": "depth filter of step i on a second stream beside sparse alignment, matching and pose refinement of "
+                                  "step i + 1 (the reference's mapper thread); host wall clock over the steps / their number"}
+        except Exception as e:
+            overlapped = {"skipped": repr(e)}
     T_ref_est = d.pop("_T_refined")
     res = {"workload": "vga4_n200_full_track" + ("_easy" if mode == "easy" else ""), "frames_per_step": W.B,
            "frames_per_s": W.B / step_ms * 1e3, "ms_per_step": step_ms,
            "ms_per_step_host_wall": wall, "stages_ms": stages,
            "median_pose_error_vs_gt_after_refine": float(np.median(se3.log_norm(T_ref_est, W.T_gt[1:W.B + 1])))}
     res.update(d)
+    if overlapped is not None:
+        res["mapper_on_its_own_stream"] = overlapped
     if scan_profile is not None:
         res["scan_profile"] = scan_profile
     st = W.align_stats(out)
