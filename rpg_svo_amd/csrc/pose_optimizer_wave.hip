@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, PW_MINW) pose_opt_wave_kernel(c
       px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
       ux[j] = f[0] / f[2];  // vk::project2d(f), once
       uy[j] = f[1] / f[2];
-      kk[j] = 1.0f / (float)(1 << a.level[base + i]);
+      kk[j] = pow2_inv_f32(a.level[base + i]);  // == 1.0f / (float)(1 << level), from exponent bits
     }
     n_err += __popcll(__ballot(live[j]));
   }

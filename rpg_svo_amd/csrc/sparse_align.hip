@@ -345,9 +345,9 @@ __global__ void __launch_bounds__(BLOCK, PARTS > 1 ? 1 : ((DIST && BLOCK < 1024)
     const int cols = g_s.lw[level], rows = g_s.lh[level], pitch = g_s.lp[level];
     const uint8_t* ref_img = ref_base + g_s.lo[level];
     const uint8_t* cur_img = cur_base + g_s.lo[level];
-    const float scale = 1.0f / (float)(1 << level);
+    const float scale = pow2_inv_f32(level);  // == 1.0f / (float)(1 << level), from exponent bits (no division sequence)
     // focal_length / 2^level (:139-140), folded into the per-patch sums
-    const sia_acc fl = (sia_acc)(fabs(P.fx) / (double)(1 << level));
+    const sia_acc fl = (sia_acc)(fabs(P.fx) * pow2_inv_f64(level));  // == / 2^level, bit for bit
 
     uint32_t wc[WC ? 7 : 1][3];
     int wc_u0 = 0, wc_v0 = -100000;  // cached columns [wc_u0, wc_u0+11], rows [wc_v0, wc_v0+6]

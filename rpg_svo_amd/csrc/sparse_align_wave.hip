@@ -160,9 +160,9 @@ __global__ void __launch_bounds__(64, SIAW_MINW) sia_wave_kernel(const SiaArgs a
     const int cols = g.lw[level], rows = g.lh[level], pitch = g.lp[level];
     const uint8_t* ref_img = ref_base + g.lo[level];
     const uint8_t* cur_img = cur_base + g.lo[level];
-    const float scale = 1.0f / (float)(1 << level);
+    const float scale = pow2_inv_f32(level);  // == 1.0f / (float)(1 << level), from exponent bits (no division sequence)
     // focal_length / 2^level (:139-140), folded into the per-patch sums
-    const float fl = (float)(fabs(P.fx) / (double)(1 << level));
+    const float fl = (float)(fabs(P.fx) * pow2_inv_f64(level));  // == / 2^level, bit for bit
 
     // ---- precomputeReferencePatches (:84-145) --------------------------------------------------------
     // Stage A, all of the lane's patches: positions, then EVERY global load of the level in one go -- the
